@@ -1,0 +1,16 @@
+"""dril.jl_amd — MI355X-native rollout + PPO-update hot path for DRiL.jl.
+
+The directory name contains a dot, so it is loaded by path (see `load_package` in
+__graft_entry__.py / tests/conftest.py) under the module name `dril_jl_amd`.
+
+    csrc/     hand-written HIP kernels + the C ABI (libdril_hip.so, include/dril_hip.h)
+    _capi.py  ctypes binding of the C ABI (no fallback: raises if the .so is missing)
+    host.py   mirror of the reference's Agent / ActorCriticLayer / PPO / train! / AbstractParallelEnv interface
+    julia/    the `ccall` shim a DRiL.jl user loads (cannot be executed in the build image: no Julia)
+"""
+from . import _capi  # noqa: F401
+from .host import (  # noqa: F401
+    Agent, ActorCriticLayer, Box, CartPoleEnv, ContinuousActorCriticLayer, DeviceParallelEnv, Discrete,
+    DiscreteActorCriticLayer, DrilError, Handle, PendulumEnv, PPO, RolloutBuffer, collect_rollout_,
+    flatten_params, get_action_and_values, make_config, predict_values, train_, unflatten_params,
+)

@@ -1,0 +1,678 @@
+// dril_api.hip — the C ABI of libdril_hip.so (include/dril_hip.h): handle, device memory, launch sequencing.
+// One HIP stream per handle; kernels of one PPO iteration are enqueued back-to-back with no host sync
+// (KL early-stop and NaN detection are device flags the later kernels test), RCCL all-reduces ride the
+// same stream.  RCCL is dlopen'ed lazily so single-GPU users never load it.
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dril_hip.h"
+#include "dril_internal.h"
+
+using namespace dril;
+
+#define DRIL_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// ---- minimal RCCL surface, resolved at run time ------------------------------------------------
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, const void*, int) = nullptr;   // ncclUniqueId passed by value = 128-byte struct
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+struct NcclId { char bytes[128]; };
+typedef int (*nccl_init_rank_fn)(void**, int, NcclId, int);
+RcclApi g_rccl;
+bool load_rccl(std::string& err) {
+    if (g_rccl.lib) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.lib) break; }
+    if (!g_rccl.lib) { err = std::string("dlopen(librccl) failed: ") + dlerror(); return false; }
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, const void*, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) { err = "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclAllReduce"; return false; }
+    return true;
+}
+constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0;
+
+struct ProfEvent { int kid; hipEvent_t a, b; };
+
+}  // namespace
+
+struct dril_handle {
+    dril_config cfg;
+    int D = 0, A = 0, S = 0, P = 0, Pa = 0, Pc = 0, log_std_off = 0;
+    bool discrete = true;
+    NetOff actor{}, critic{};
+    int64_t N = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *bt = nullptr, *flat = nullptr, *norm_out = nullptr;
+    double* norm_partials = nullptr; int n_norm_partials = 0;
+    float *slabs_a = nullptr, *slabs_c = nullptr; int slab_a = 0, slab_c = 0, Gmax = 0;
+    float* state = nullptr; int32_t* step_count = nullptr; uint32_t *episode = nullptr, *gstep = nullptr; float* disc_returns = nullptr;
+    float *obs = nullptr, *rew = nullptr, *adv = nullptr, *ret = nullptr, *logp = nullptr, *val = nullptr, *boot = nullptr, *last_values = nullptr;
+    void* act = nullptr; uint8_t* flags = nullptr;
+    void* noise_dev = nullptr; bool noise_set = false;
+    int64_t* perm_dev = nullptr; size_t perm_count = 0;
+    double *adv_partials = nullptr, *adv_stats = nullptr, *ev_partials = nullptr; int adv_blocks = 0, ev_blocks = 0;
+    float* step_stats = nullptr; int step_stats_cap = 0;
+    int *stop_flag = nullptr, *nan_flag = nullptr;
+    float *e_obs = nullptr, *e_rew = nullptr, *e_tobs = nullptr; uint8_t *e_term = nullptr, *e_trunc = nullptr; void* e_act = nullptr;
+    uint64_t env_seed0 = 0, adam_steps = 0, update_counter = 0; uint32_t policy_calls = 0;
+    float lr = 0;
+    bool env_ready = false;
+    void* comm = nullptr;
+    std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+    double prof_ms[DRIL_K_COUNT] = {0}; int64_t prof_n[DRIL_K_COUNT] = {0};
+    std::string err;
+};
+
+namespace {
+
+int fail(dril_handle* h, int code, const std::string& msg) { if (h) h->err = msg; else g_create_error = msg; return code; }
+#define HIPCHK(h, expr)                                                                                      \
+    do { hipError_t _e = (expr); if (_e != hipSuccess)                                                       \
+        return fail(h, DRIL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+#define NEED(h) do { if (!(h)) return fail(nullptr, DRIL_ERR_NOT_INITIALISED, "null handle"); } while (0)
+
+template <typename T> hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, (n ? n : 1) * sizeof(T)); }
+
+void prof_begin(dril_handle* h, int kid) {
+    if (!h->cfg.profile_events) return;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!h->prof_pool.empty()) { ev = h->prof_pool.back(); h->prof_pool.pop_back(); }
+    else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
+    hipEventRecord(ev.first, h->stream);
+    h->prof_pending.push_back({kid, ev.first, ev.second});
+}
+void prof_end(dril_handle* h) {
+    if (!h->cfg.profile_events) return;
+    hipEventRecord(h->prof_pending.back().b, h->stream);
+}
+void prof_resolve(dril_handle* h) {   // stream must be drained
+    for (auto& p : h->prof_pending) {
+        float ms = 0; if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { h->prof_ms[p.kid] += ms; h->prof_n[p.kid] += 1; }
+        h->prof_pool.push_back({p.a, p.b});
+    }
+    h->prof_pending.clear();
+}
+int sync(dril_handle* h) { HIPCHK(h, hipStreamSynchronize(h->stream)); prof_resolve(h); return DRIL_OK; }
+
+int rccl_allreduce(dril_handle* h, void* buf, size_t count, int dtype) {
+    if (!h->comm) return DRIL_OK;
+    prof_begin(h, DRIL_K_ALLREDUCE);
+    const int rc = g_rccl.AllReduce(buf, buf, count, dtype, kNcclSum, h->comm, h->stream);
+    prof_end(h);
+    if (rc != 0) return fail(h, DRIL_ERR_RCCL, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+    return DRIL_OK;
+}
+
+bool normalizing(const dril_handle* h) { return h->cfg.norm_obs || h->cfg.norm_reward; }
+size_t act_bytes_per(const dril_handle* h) { return h->discrete ? 4 : 4 * (size_t)h->A; }
+
+PolicyArgs policy_args(dril_handle* h, const float* obs, int64_t B, const void* noise, void* actions, float* values, float* logp,
+                       float* entropy, int mode) {
+    PolicyArgs a{};
+    a.params = h->params; a.obs = obs; a.B = B; a.noise = noise; a.actions = actions; a.values = values; a.logp = logp; a.entropy = entropy;
+    a.mode = mode; a.action_start = h->cfg.action_start; a.log_std_off = h->log_std_off; a.seed = h->cfg.seed; a.call_counter = h->policy_calls;
+    a.actor = h->actor; a.critic = h->critic;
+    return a;
+}
+
+// one optimiser step on [pos0, pos0+count) of the current epoch order; all launches asynchronous
+int ppo_step(dril_handle* h, const float* obs, const void* actions, const float* adv, const float* ret, const float* logp_old,
+             const float* val_old, const int64_t* perm, int64_t pos0, int64_t count, int64_t N, uint64_t key, int bits,
+             float* step_stats, bool apply) {
+    const int world = h->comm ? h->cfg.world_size : 1;
+    const int64_t tiles = (count + kTile - 1) / kTile;
+    int G = (int)((tiles + 3) / 4); if (G > h->Gmax) G = h->Gmax; if (G < 1) G = 1;
+    if (h->cfg.normalize_advantage) {
+        MomentsArgs m{}; m.adv = adv; m.perm = perm; m.pos0 = pos0; m.count = count; m.N = N; m.idx_lo = 0; m.n_local = N;
+        m.perm_key = key; m.perm_bits = bits; m.partials = h->adv_partials; m.stop_flag = h->stop_flag;
+        int nb = (int)((count + 255) / 256); if (nb > h->adv_blocks) nb = h->adv_blocks; if (nb < 1) nb = 1;
+        prof_begin(h, DRIL_K_ADV_MOMENTS);
+        HIPCHK(h, launch_adv_moments(m, nb, h->stream));
+        HIPCHK(h, launch_moments_finalize(h->adv_partials, nb, h->adv_stats, (double)count, h->stop_flag, h->stream));
+        prof_end(h);
+        if (world > 1) { int rc = rccl_allreduce(h, h->adv_stats, 3, kNcclFloat64); if (rc) return rc; }
+    }
+    GradArgs g{};
+    g.params = h->params; g.obs = obs; g.actions = actions; g.adv = adv; g.ret = ret; g.logp_old = logp_old; g.val_old = val_old;
+    g.perm = perm; g.pos0 = pos0; g.count = count; g.N = N; g.idx_lo = 0; g.n_local = N; g.perm_key = key; g.perm_bits = bits;
+    g.adv_stats = h->adv_stats; g.invB = 1.0f / (float)(count * world);
+    g.clip_range = h->cfg.clip_range; g.ent_coef = h->cfg.ent_coef; g.vf_coef = h->cfg.vf_coef; g.clip_range_vf = h->cfg.clip_range_vf;
+    g.has_clip_vf = h->cfg.has_clip_range_vf; g.normalize_adv = h->cfg.normalize_advantage; g.action_start = h->cfg.action_start;
+    g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
+    g.G = G; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
+    prof_begin(h, DRIL_K_PPO_GRAD);
+    HIPCHK(h, launch_ppo_grad(h->cfg.env_kind, h->cfg.hidden1, g, h->stream));
+    prof_end(h);
+    ReduceArgs r{};
+    r.slabs_actor = h->slabs_a; r.slabs_critic = h->slabs_c; r.slab_a = h->slab_a; r.slab_c = h->slab_c; r.G = G;
+    r.P = h->P; r.Pa = h->Pa; r.Pc = h->Pc; r.flat = h->flat; r.norm_partials = h->norm_partials; r.n_samples_local = (double)count;
+    r.stop_flag = h->stop_flag;
+    prof_begin(h, DRIL_K_GRAD_REDUCE);
+    HIPCHK(h, launch_grad_reduce(r, h->stream));
+    prof_end(h);
+    if (world > 1) {
+        int rc = rccl_allreduce(h, h->flat, (size_t)h->P + 8, kNcclFloat32); if (rc) return rc;
+        HIPCHK(h, launch_grad_norm(h->flat, h->P, h->norm_partials, h->stop_flag, h->stream));
+    }
+    if (!apply) return DRIL_OK;
+    AdamArgs ad{};
+    ad.params = h->params; ad.m = h->adam_m; ad.v = h->adam_v; ad.flat = h->flat; ad.P = h->P;
+    ad.norm_partials = h->norm_partials; ad.n_partials = h->n_norm_partials; ad.bt = h->bt; ad.step_parity = (int)(h->adam_steps & 1);
+    ad.beta1 = h->cfg.adam_beta1; ad.beta2 = h->cfg.adam_beta2; ad.eps = h->cfg.adam_eps; ad.lr = h->lr;
+    ad.max_grad_norm = h->cfg.max_grad_norm; ad.target_kl = h->cfg.target_kl; ad.ent_coef = h->cfg.ent_coef; ad.vf_coef = h->cfg.vf_coef;
+    ad.has_max_grad_norm = h->cfg.has_max_grad_norm; ad.has_target_kl = h->cfg.has_target_kl; ad.use_stats = 1;
+    ad.step_stats = step_stats; ad.norm_out = h->norm_out; ad.nan_flag = h->nan_flag; ad.stop_flag = h->stop_flag; ad.stop_flag_w = h->stop_flag;
+    prof_begin(h, DRIL_K_ADAM);
+    HIPCHK(h, launch_adam(ad, h->stream));
+    prof_end(h);
+    h->adam_steps += 1;
+    return DRIL_OK;
+}
+
+uint64_t perm_key(uint64_t seed, uint64_t counter, int epoch) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)counter, (uint32_t)(counter >> 32), 2, (uint32_t)epoch, r);
+    return ((uint64_t)r[0] << 32) | r[1];
+}
+
+int reset_optimizer(dril_handle* h) {
+    HIPCHK(h, hipMemsetAsync(h->adam_m, 0, sizeof(float) * h->P, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->adam_v, 0, sizeof(float) * h->P, h->stream));
+    const float bt[4] = {h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_beta1, h->cfg.adam_beta2};
+    HIPCHK(h, hipMemcpyAsync(h->bt, bt, sizeof(bt), hipMemcpyHostToDevice, h->stream));
+    h->adam_steps = 0;
+    return sync(h);
+}
+
+void* buf_ptr(dril_handle* h, int which, size_t* bytes) {
+    const size_t N = (size_t)h->N;
+    switch (which) {
+    case DRIL_BUF_OBSERVATIONS: *bytes = N * h->D * 4; return h->obs;
+    case DRIL_BUF_ACTIONS: *bytes = N * act_bytes_per(h); return h->act;
+    case DRIL_BUF_REWARDS: *bytes = N * 4; return h->rew;
+    case DRIL_BUF_ADVANTAGES: *bytes = N * 4; return h->adv;
+    case DRIL_BUF_RETURNS: *bytes = N * 4; return h->ret;
+    case DRIL_BUF_LOGPROBS: *bytes = N * 4; return h->logp;
+    case DRIL_BUF_VALUES: *bytes = N * 4; return h->val;
+    case DRIL_BUF_FLAGS: *bytes = N; return h->flags;
+    case DRIL_BUF_BOOTSTRAP: *bytes = N * 4; return h->boot;
+    case DRIL_BUF_LAST_VALUES: *bytes = (size_t)h->cfg.n_envs * 4; return h->last_values;
+    }
+    *bytes = 0; return nullptr;
+}
+
+}  // namespace
+
+// ================================================================================================
+DRIL_EXPORT int32_t dril_config_default(dril_config* c, int32_t env_kind) {
+    if (!c || (env_kind != DRIL_ENV_CARTPOLE && env_kind != DRIL_ENV_PENDULUM)) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad cfg/env_kind");
+    std::memset(c, 0, sizeof(*c));
+    c->abi_version = DRIL_ABI_VERSION; c->env_kind = env_kind; c->n_envs = 4; c->n_steps = 2048; c->hidden1 = c->hidden2 = 64;
+    c->episode_len = env_kind == DRIL_ENV_CARTPOLE ? 500 : 200; c->action_start = 1;
+    c->gamma = 0.99f; c->gae_lambda = 0.95f; c->clip_range = 0.2f; c->ent_coef = 0.0f; c->vf_coef = 0.5f;
+    c->max_grad_norm = 0.5f; c->has_max_grad_norm = 1; c->normalize_advantage = 1; c->batch_size = 64; c->epochs = 10;
+    c->learning_rate = 3.0e-4f; c->adam_beta1 = 0.9f; c->adam_beta2 = 0.999f; c->adam_eps = 1.0e-5f;
+    c->clip_obs = c->clip_reward = 10.0f; c->norm_gamma = 0.99f; c->norm_epsilon = 1.0e-8f; c->seed = 42; c->world_size = 1;
+    return DRIL_OK;
+}
+
+DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
+    if (!cfg || !out) return fail(nullptr, DRIL_ERR_INVALID_ARG, "null cfg/out");
+    if (cfg->abi_version != DRIL_ABI_VERSION) return fail(nullptr, DRIL_ERR_INVALID_ARG, "abi_version mismatch");
+    if (cfg->env_kind != DRIL_ENV_CARTPOLE && cfg->env_kind != DRIL_ENV_PENDULUM) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
+    if (cfg->n_envs < 1 || cfg->n_steps < 1 || cfg->epochs < 0 || cfg->batch_size < 1) return fail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs/n_steps/batch_size must be positive");
+    if (cfg->hidden1 != cfg->hidden2 || cfg->hidden1 != 64) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden_dims: only [64,64] is built in this round");
+    if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad rank/world_size");
+    if (cfg->batch_size % cfg->world_size != 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "batch_size must be divisible by world_size");
+    if (cfg->norm_obs || cfg->norm_reward) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "NormalizeWrapperEnv on device is not built yet");
+    dril_handle* h = nullptr;
+    try { h = new dril_handle(); } catch (...) { return fail(nullptr, DRIL_ERR_INVALID_ARG, "out of host memory"); }
+    h->cfg = *cfg;
+    h->discrete = cfg->env_kind == DRIL_ENV_CARTPOLE;
+    h->D = h->discrete ? 4 : 3; h->A = h->discrete ? 2 : 1; h->S = h->discrete ? 4 : 2;
+    h->actor = net_off(0, h->D, cfg->hidden1, cfg->hidden2, h->A);
+    h->critic = net_off(h->actor.end, h->D, cfg->hidden1, cfg->hidden2, 1);
+    h->Pa = h->actor.end; h->Pc = h->critic.end - h->actor.end; h->log_std_off = h->critic.end;
+    h->P = h->critic.end + (h->discrete ? 0 : h->A);
+    h->N = (int64_t)cfg->n_envs * cfg->n_steps; h->lr = cfg->learning_rate;
+#define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
+    CCHK(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop; CCHK(hipGetDeviceProperties(&prop, cfg->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { std::string m = std::string("libdril_hip targets gfx950 (MI355X) only; device is ") + prop.gcnArchName; dril_destroy(h); return fail(nullptr, DRIL_ERR_UNSUPPORTED, m); }
+    h->num_cus = prop.multiProcessorCount;
+    CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t E = cfg->n_envs, N = (size_t)h->N, P = h->P;
+    CCHK(dmalloc(&h->params, P)); CCHK(dmalloc(&h->adam_m, P)); CCHK(dmalloc(&h->adam_v, P)); CCHK(dmalloc(&h->bt, 4));
+    CCHK(dmalloc(&h->flat, P + 8)); CCHK(dmalloc(&h->norm_out, 1));
+    h->n_norm_partials = (int)((P + 255) / 256); CCHK(dmalloc(&h->norm_partials, h->n_norm_partials));
+    h->slab_a = slab_size_actor(cfg->env_kind, cfg->hidden1); h->slab_c = slab_size_critic(cfg->env_kind, cfg->hidden1);
+    h->Gmax = h->num_cus / 2 > 0 ? h->num_cus / 2 : 1;
+    CCHK(dmalloc(&h->slabs_a, (size_t)h->Gmax * h->slab_a)); CCHK(dmalloc(&h->slabs_c, (size_t)h->Gmax * h->slab_c));
+    CCHK(dmalloc(&h->state, E * h->S)); CCHK(dmalloc(&h->step_count, E)); CCHK(dmalloc(&h->episode, E)); CCHK(dmalloc(&h->gstep, E));
+    CCHK(dmalloc(&h->disc_returns, E));
+    CCHK(dmalloc(&h->obs, N * h->D)); CCHK(hipMalloc(&h->act, N * act_bytes_per(h))); CCHK(dmalloc(&h->rew, N)); CCHK(dmalloc(&h->adv, N));
+    CCHK(dmalloc(&h->ret, N)); CCHK(dmalloc(&h->logp, N)); CCHK(dmalloc(&h->val, N)); CCHK(dmalloc(&h->boot, N)); CCHK(dmalloc(&h->flags, N));
+    CCHK(dmalloc(&h->last_values, E));
+    h->adv_blocks = 1024; CCHK(dmalloc(&h->adv_partials, 2 * (size_t)h->adv_blocks)); CCHK(dmalloc(&h->adv_stats, 4));
+    h->ev_blocks = 1024; CCHK(dmalloc(&h->ev_partials, 4 * (size_t)h->ev_blocks));
+    CCHK(dmalloc(&h->stop_flag, 1)); CCHK(dmalloc(&h->nan_flag, 1));
+    CCHK(dmalloc(&h->e_obs, E * h->D)); CCHK(dmalloc(&h->e_rew, E)); CCHK(dmalloc(&h->e_tobs, E * h->D)); CCHK(dmalloc(&h->e_term, E));
+    CCHK(dmalloc(&h->e_trunc, E)); CCHK(hipMalloc(&h->e_act, E * act_bytes_per(h)));
+    CCHK(hipMemsetAsync(h->params, 0, P * 4, h->stream)); CCHK(hipMemsetAsync(h->boot, 0, N * 4, h->stream));
+    CCHK(hipMemsetAsync(h->flags, 0, N, h->stream)); CCHK(hipMemsetAsync(h->last_values, 0, E * 4, h->stream));
+    CCHK(hipMemsetAsync(h->stop_flag, 0, 4, h->stream)); CCHK(hipMemsetAsync(h->nan_flag, 0, 4, h->stream));
+    CCHK(hipMemsetAsync(h->e_tobs, 0, E * h->D * 4, h->stream));
+    if (!h->discrete) { std::vector<float> ls(h->A, cfg->log_std_init); CCHK(hipMemcpyAsync(h->params + h->log_std_off, ls.data(), 4 * h->A, hipMemcpyHostToDevice, h->stream)); CCHK(hipStreamSynchronize(h->stream)); }
+#undef CCHK
+    int rc = reset_optimizer(h);
+    if (rc) { std::string m = h->err; dril_destroy(h); return fail(nullptr, rc, m); }
+    *out = h;
+    return DRIL_OK;
+}
+
+DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
+    if (!h) return DRIL_OK;
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
+                    h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
+                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
+                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act};
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (auto& p : h->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto& p : h->prof_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return DRIL_OK;
+}
+DRIL_EXPORT const char* dril_last_error(const dril_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+DRIL_EXPORT int32_t dril_synchronize(dril_handle* h) { NEED(h); return sync(h); }
+DRIL_EXPORT int32_t dril_obs_dim(const dril_handle* h) { return h ? h->D : -1; }
+DRIL_EXPORT int32_t dril_action_dim(const dril_handle* h) { return h ? h->A : -1; }
+DRIL_EXPORT int32_t dril_is_discrete(const dril_handle* h) { return h ? (h->discrete ? 1 : 0) : -1; }
+DRIL_EXPORT int64_t dril_param_count(const dril_handle* h) { return h ? h->P : -1; }
+
+DRIL_EXPORT int32_t dril_set_params(dril_handle* h, const float* flat, size_t n) {
+    NEED(h); if (!flat || n != (size_t)h->P) return fail(h, DRIL_ERR_INVALID_ARG, "dril_set_params: n != dril_param_count");
+    HIPCHK(h, hipMemcpyAsync(h->params, flat, n * 4, hipMemcpyHostToDevice, h->stream)); return sync(h);
+}
+DRIL_EXPORT int32_t dril_get_params(dril_handle* h, float* flat, size_t n) {
+    NEED(h); if (!flat || n != (size_t)h->P) return fail(h, DRIL_ERR_INVALID_ARG, "dril_get_params: n != dril_param_count");
+    HIPCHK(h, hipMemcpyAsync(flat, h->params, n * 4, hipMemcpyDeviceToHost, h->stream)); return sync(h);
+}
+DRIL_EXPORT int32_t dril_reset_optimizer(dril_handle* h) { NEED(h); return reset_optimizer(h); }
+DRIL_EXPORT int32_t dril_set_learning_rate(dril_handle* h, float lr) { NEED(h); h->lr = lr; return DRIL_OK; }
+
+// ---- env verbs -----------------------------------------------------------------------------------
+DRIL_EXPORT int32_t dril_env_reset(dril_handle* h, uint64_t seed) {
+    NEED(h);
+    h->env_seed0 = seed + (uint64_t)h->cfg.rank * (uint64_t)h->cfg.n_envs;
+    HIPCHK(h, launch_env_reset(h->cfg.env_kind, h->cfg.n_envs, h->env_seed0, h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->stream));
+    h->env_ready = true;
+    return sync(h);
+}
+DRIL_EXPORT int32_t dril_env_observe(dril_handle* h, float* host_obs, int32_t update_stats) {
+    NEED(h); (void)update_stats;
+    if (!h->env_ready) return fail(h, DRIL_ERR_NOT_INITIALISED, "dril_env_observe before dril_env_reset");
+    if (!host_obs) return fail(h, DRIL_ERR_INVALID_ARG, "null host_obs");
+    HIPCHK(h, launch_env_observe(h->cfg.env_kind, h->cfg.n_envs, h->state, h->e_obs, h->stream));
+    HIPCHK(h, hipMemcpyAsync(host_obs, h->e_obs, (size_t)h->cfg.n_envs * h->D * 4, hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+DRIL_EXPORT int32_t dril_env_step(dril_handle* h, const void* actions, float* rewards, uint8_t* terminated, uint8_t* truncated, float* terminal_obs) {
+    NEED(h);
+    if (!h->env_ready) return fail(h, DRIL_ERR_NOT_INITIALISED, "dril_env_step before dril_env_reset");
+    if (!actions) return fail(h, DRIL_ERR_INVALID_ARG, "null actions");
+    const size_t E = h->cfg.n_envs;
+    HIPCHK(h, hipMemcpyAsync(h->e_act, actions, E * act_bytes_per(h), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_env_step(h->cfg.env_kind, (int)E, h->env_seed0, h->cfg.episode_len, h->cfg.fixed_length_episodes, h->cfg.action_start,
+                              h->e_act, h->state, h->step_count, h->episode, h->gstep, h->e_rew, h->e_term, h->e_trunc, h->e_tobs, h->stream));
+    if (rewards) HIPCHK(h, hipMemcpyAsync(rewards, h->e_rew, E * 4, hipMemcpyDeviceToHost, h->stream));
+    if (terminated) HIPCHK(h, hipMemcpyAsync(terminated, h->e_term, E, hipMemcpyDeviceToHost, h->stream));
+    if (truncated) HIPCHK(h, hipMemcpyAsync(truncated, h->e_trunc, E, hipMemcpyDeviceToHost, h->stream));
+    if (terminal_obs) HIPCHK(h, hipMemcpyAsync(terminal_obs, h->e_tobs, E * h->D * 4, hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+DRIL_EXPORT int32_t dril_env_get_state(dril_handle* h, float* state, int32_t* step_count) {
+    NEED(h); if (!state) return fail(h, DRIL_ERR_INVALID_ARG, "null state");
+    HIPCHK(h, hipMemcpyAsync(state, h->state, (size_t)h->cfg.n_envs * h->S * 4, hipMemcpyDeviceToHost, h->stream));
+    if (step_count) HIPCHK(h, hipMemcpyAsync(step_count, h->step_count, (size_t)h->cfg.n_envs * 4, hipMemcpyDeviceToHost, h->stream));
+    return sync(h);
+}
+DRIL_EXPORT int32_t dril_env_set_state(dril_handle* h, const float* state, const int32_t* step_count) {
+    NEED(h); if (!state) return fail(h, DRIL_ERR_INVALID_ARG, "null state");
+    HIPCHK(h, hipMemcpyAsync(h->state, state, (size_t)h->cfg.n_envs * h->S * 4, hipMemcpyHostToDevice, h->stream));
+    if (step_count) HIPCHK(h, hipMemcpyAsync(h->step_count, step_count, (size_t)h->cfg.n_envs * 4, hipMemcpyHostToDevice, h->stream));
+    return sync(h);
+}
+DRIL_EXPORT int32_t dril_norm_get_stats(dril_handle* h, float*, float*, int64_t*, float*, float*, int64_t*) {
+    NEED(h); return fail(h, DRIL_ERR_UNSUPPORTED, "NormalizeWrapperEnv on device is not built yet");
+}
+DRIL_EXPORT int32_t dril_norm_set_stats(dril_handle* h, const float*, const float*, int64_t, float, float, int64_t) {
+    NEED(h); return fail(h, DRIL_ERR_UNSUPPORTED, "NormalizeWrapperEnv on device is not built yet");
+}
+
+// ---- policy on host batches ----------------------------------------------------------------------
+namespace {
+int policy_host(dril_handle* h, const float* obs, int64_t B, const void* noise, void* actions, bool actions_in, float* values, float* logp,
+                float* entropy, int mode) {
+    if (!obs || B < 1) return fail(h, DRIL_ERR_INVALID_ARG, "policy: null obs or batch < 1");
+    float *d_obs = nullptr, *d_val = nullptr, *d_lp = nullptr, *d_ent = nullptr; void *d_noise = nullptr, *d_act = nullptr;
+    const size_t ab = (size_t)B * act_bytes_per(h), nb = (size_t)B * (h->discrete ? 8 : 4 * (size_t)h->A);
+    int rc = DRIL_OK;
+    auto cleanup = [&]() { hipFree(d_obs); hipFree(d_val); hipFree(d_lp); hipFree(d_ent); hipFree(d_noise); hipFree(d_act); };
+#define PCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(h, DRIL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+    PCHK(dmalloc(&d_obs, (size_t)B * h->D)); PCHK(dmalloc(&d_val, (size_t)B)); PCHK(dmalloc(&d_lp, (size_t)B)); PCHK(dmalloc(&d_ent, (size_t)B));
+    PCHK(hipMalloc(&d_act, ab));
+    PCHK(hipMemcpyAsync(d_obs, obs, (size_t)B * h->D * 4, hipMemcpyHostToDevice, h->stream));
+    if (noise) { PCHK(hipMalloc(&d_noise, nb)); PCHK(hipMemcpyAsync(d_noise, noise, nb, hipMemcpyHostToDevice, h->stream)); }
+    if (actions_in) PCHK(hipMemcpyAsync(d_act, actions, ab, hipMemcpyHostToDevice, h->stream));
+    PolicyArgs a = policy_args(h, d_obs, B, d_noise, d_act, d_val, d_lp, d_ent, mode);
+    PCHK(launch_policy(h->cfg.env_kind, h->cfg.hidden1, a, 8 * h->num_cus, h->stream));
+    h->policy_calls += 1;
+    if (values) PCHK(hipMemcpyAsync(values, d_val, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (logp && mode != 2) PCHK(hipMemcpyAsync(logp, d_lp, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (entropy && mode == 1) PCHK(hipMemcpyAsync(entropy, d_ent, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (actions && mode == 0) PCHK(hipMemcpyAsync(actions, d_act, ab, hipMemcpyDeviceToHost, h->stream));
+    rc = sync(h);
+#undef PCHK
+    cleanup();
+    return rc;
+}
+}  // namespace
+DRIL_EXPORT int32_t dril_policy_forward(dril_handle* h, const float* obs, int64_t batch, const void* noise, void* actions, float* values, float* logprobs) {
+    NEED(h); return policy_host(h, obs, batch, noise, actions, false, values, logprobs, nullptr, 0);
+}
+DRIL_EXPORT int32_t dril_evaluate_actions(dril_handle* h, const float* obs, const void* actions, int64_t batch, float* values, float* logprobs, float* entropy) {
+    NEED(h); if (!actions) return fail(h, DRIL_ERR_INVALID_ARG, "null actions");
+    return policy_host(h, obs, batch, nullptr, const_cast<void*>(actions), true, values, logprobs, entropy, 1);
+}
+DRIL_EXPORT int32_t dril_predict_values(dril_handle* h, const float* obs, int64_t batch, float* values) {
+    NEED(h); return policy_host(h, obs, batch, nullptr, nullptr, false, values, nullptr, nullptr, 2);
+}
+
+// ---- rollout ---------------------------------------------------------------------------------------
+namespace {
+int compute_gae(dril_handle* h) {
+    prof_begin(h, DRIL_K_GAE);
+    HIPCHK(h, launch_gae(h->cfg.n_envs, h->cfg.n_steps, h->cfg.gamma, h->cfg.gae_lambda, h->rew, h->val, h->flags, h->boot, h->last_values,
+                         h->adv, h->ret, h->stream));
+    prof_end(h);
+    return DRIL_OK;
+}
+int collect_rollout(dril_handle* h, double* fps, bool do_sync) {
+    if (!h->env_ready) return fail(h, DRIL_ERR_NOT_INITIALISED, "dril_collect_rollout before dril_env_reset");
+    RolloutArgs a{};
+    a.params = h->params; a.state = h->state; a.step_count = h->step_count; a.episode = h->episode; a.gstep = h->gstep;
+    a.obs = h->obs; a.act = h->act; a.rew = h->rew; a.logp = h->logp; a.val = h->val; a.boot = h->boot; a.flags = h->flags; a.last_values = h->last_values;
+    a.noise = h->noise_set ? h->noise_dev : nullptr;
+    a.E = h->cfg.n_envs; a.T = h->cfg.n_steps; a.episode_len = h->cfg.episode_len; a.fixed_len = h->cfg.fixed_length_episodes;
+    a.action_start = h->cfg.action_start; a.log_std_off = h->log_std_off; a.env_seed0 = h->env_seed0; a.actor = h->actor; a.critic = h->critic;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (fps) HIPCHK(h, hipStreamSynchronize(h->stream));
+    prof_begin(h, DRIL_K_ROLLOUT);
+    HIPCHK(h, launch_rollout(h->cfg.env_kind, h->cfg.hidden1, a, h->stream));
+    prof_end(h);
+    if (fps) {   // fps = steps / wall time of collect_trajectories, rollout_buffer.jl:60-64
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        *fps = (double)h->N / (dt > 0 ? dt : 1e-12);
+    }
+    h->noise_set = false;
+    int rc = compute_gae(h); if (rc) return rc;
+    return do_sync ? sync(h) : DRIL_OK;
+}
+}  // namespace
+DRIL_EXPORT int32_t dril_collect_rollout(dril_handle* h, double* fps) { NEED(h); return collect_rollout(h, fps, true); }
+DRIL_EXPORT int32_t dril_debug_set_noise(dril_handle* h, const void* noise, size_t count) {
+    NEED(h);
+    if (!noise) { h->noise_set = false; return DRIL_OK; }
+    const size_t need = (size_t)h->N * (h->discrete ? 1 : (size_t)h->A);
+    if (count != need) return fail(h, DRIL_ERR_INVALID_ARG, "dril_debug_set_noise: count must be n_envs*n_steps (*action_dim)");
+    const size_t bytes = need * (h->discrete ? 8 : 4);
+    if (!h->noise_dev) HIPCHK(h, hipMalloc(&h->noise_dev, bytes));
+    HIPCHK(h, hipMemcpyAsync(h->noise_dev, noise, bytes, hipMemcpyHostToDevice, h->stream));
+    h->noise_set = true;
+    return sync(h);
+}
+DRIL_EXPORT int32_t dril_buffer_copy_out(dril_handle* h, int32_t which, void* host, size_t bytes) {
+    NEED(h); size_t b; void* p = buf_ptr(h, which, &b);
+    if (!p || !host || b != bytes) return fail(h, DRIL_ERR_INVALID_ARG, "dril_buffer_copy_out: bad id or byte count");
+    HIPCHK(h, hipMemcpyAsync(host, p, b, hipMemcpyDeviceToHost, h->stream)); return sync(h);
+}
+DRIL_EXPORT int32_t dril_buffer_copy_in(dril_handle* h, int32_t which, const void* host, size_t bytes) {
+    NEED(h); size_t b; void* p = buf_ptr(h, which, &b);
+    if (!p || !host || b != bytes) return fail(h, DRIL_ERR_INVALID_ARG, "dril_buffer_copy_in: bad id or byte count");
+    HIPCHK(h, hipMemcpyAsync(p, host, b, hipMemcpyHostToDevice, h->stream)); return sync(h);
+}
+DRIL_EXPORT int32_t dril_compute_gae(dril_handle* h) { NEED(h); int rc = compute_gae(h); return rc ? rc : sync(h); }
+
+DRIL_EXPORT int32_t dril_gae(int32_t E, int32_t T, float gamma, float lam, const float* rewards, const float* values, const uint8_t* flags,
+                             const float* bootstrap, const float* last_values, float* advantages, float* returns) {
+    if (E < 1 || T < 1 || !rewards || !values || !flags || !bootstrap || !last_values || !advantages || !returns)
+        return fail(nullptr, DRIL_ERR_INVALID_ARG, "dril_gae: bad argument");
+    const size_t N = (size_t)E * T;
+    float *d_r = nullptr, *d_v = nullptr, *d_b = nullptr, *d_l = nullptr, *d_a = nullptr, *d_ret = nullptr; uint8_t* d_f = nullptr;
+    auto cleanup = [&]() { hipFree(d_r); hipFree(d_v); hipFree(d_b); hipFree(d_l); hipFree(d_a); hipFree(d_ret); hipFree(d_f); };
+#define GCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(nullptr, DRIL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+    GCHK(dmalloc(&d_r, N)); GCHK(dmalloc(&d_v, N)); GCHK(dmalloc(&d_b, N)); GCHK(dmalloc(&d_l, (size_t)E)); GCHK(dmalloc(&d_a, N)); GCHK(dmalloc(&d_ret, N)); GCHK(dmalloc(&d_f, N));
+    GCHK(hipMemcpy(d_r, rewards, N * 4, hipMemcpyHostToDevice)); GCHK(hipMemcpy(d_v, values, N * 4, hipMemcpyHostToDevice));
+    GCHK(hipMemcpy(d_b, bootstrap, N * 4, hipMemcpyHostToDevice)); GCHK(hipMemcpy(d_l, last_values, (size_t)E * 4, hipMemcpyHostToDevice));
+    GCHK(hipMemcpy(d_f, flags, N, hipMemcpyHostToDevice));
+    GCHK(launch_gae(E, T, gamma, lam, d_r, d_v, d_f, d_b, d_l, d_a, d_ret, nullptr));
+    GCHK(hipDeviceSynchronize());
+    GCHK(hipMemcpy(advantages, d_a, N * 4, hipMemcpyDeviceToHost)); GCHK(hipMemcpy(returns, d_ret, N * 4, hipMemcpyDeviceToHost));
+#undef GCHK
+    cleanup();
+    return DRIL_OK;
+}
+
+// ---- PPO update ------------------------------------------------------------------------------------
+DRIL_EXPORT int32_t dril_debug_set_permutation(dril_handle* h, const int64_t* perm, size_t count) {
+    NEED(h);
+    if (!perm) { h->perm_count = 0; return DRIL_OK; }
+    const size_t need = (size_t)h->cfg.epochs * (size_t)h->N;
+    if (count != need) return fail(h, DRIL_ERR_INVALID_ARG, "dril_debug_set_permutation: count must be epochs * n_envs * n_steps");
+    for (size_t i = 0; i < count; ++i) if (perm[i] < 0 || perm[i] >= h->N) return fail(h, DRIL_ERR_INVALID_ARG, "dril_debug_set_permutation: index out of range");
+    if (!h->perm_dev) HIPCHK(h, dmalloc(&h->perm_dev, need));
+    HIPCHK(h, hipMemcpyAsync(h->perm_dev, perm, need * 8, hipMemcpyHostToDevice, h->stream));
+    h->perm_count = need;
+    return sync(h);
+}
+
+namespace {
+int ppo_update(dril_handle* h, dril_ppo_stats* out) {
+    const int world = h->comm ? h->cfg.world_size : 1;
+    if (h->cfg.world_size > 1 && !h->comm) return fail(h, DRIL_ERR_NOT_INITIALISED, "world_size > 1 but dril_comm_init was not called");
+    const int64_t N = h->N, B = h->cfg.batch_size / h->cfg.world_size;
+    const int64_t nb = (N + B - 1) / B;                       // partial last batch kept (MLUtils partial=true)
+    const int64_t total_steps = nb * h->cfg.epochs;
+    if (total_steps > h->step_stats_cap) {
+        if (h->step_stats) hipFree(h->step_stats);
+        h->step_stats = nullptr; HIPCHK(h, dmalloc(&h->step_stats, (size_t)total_steps * 16)); h->step_stats_cap = (int)total_steps;
+    }
+    if (total_steps > 0) HIPCHK(h, hipMemsetAsync(h->step_stats, 0, (size_t)total_steps * 16 * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->stop_flag, 0, 4, h->stream)); HIPCHK(h, hipMemsetAsync(h->nan_flag, 0, 4, h->stream));
+    const int bits = perm_bits(N);
+    int64_t step = 0;
+    for (int ep = 0; ep < h->cfg.epochs; ++ep) {
+        const uint64_t key = perm_key(h->cfg.seed + (uint64_t)h->cfg.rank, h->update_counter, ep);
+        const int64_t* perm = h->perm_count ? h->perm_dev + (size_t)ep * N : nullptr;
+        for (int64_t k = 0; k < nb; ++k, ++step) {
+            const int64_t pos0 = k * B, count = (pos0 + B <= N) ? B : N - pos0;
+            int rc = ppo_step(h, h->obs, h->act, h->adv, h->ret, h->logp, h->val, perm, pos0, count, N, key, bits, h->step_stats + step * 16, true);
+            if (rc) return rc;
+        }
+    }
+    h->update_counter += 1;
+    HIPCHK(h, launch_explained_var(h->val, h->ret, N, h->ev_partials, h->ev_blocks, h->stream));
+    std::vector<float> st((size_t)total_steps * 16); std::vector<double> ev(4 * (size_t)h->ev_blocks); int nan = 0;
+    if (total_steps > 0) HIPCHK(h, hipMemcpyAsync(st.data(), h->step_stats, st.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ev.data(), h->ev_partials, ev.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&nan, h->nan_flag, 4, hipMemcpyDeviceToHost, h->stream));
+    int rc = sync(h); if (rc) return rc;
+    // per-iteration means over the applied steps (ppo.jl:242-264); grad_norm also counts the KL-stopped step (:223)
+    double acc[8] = {0}; int n_upd = 0, n_gn = 0, stopped = 0; float ratio_first = 0;
+    for (int64_t s = 0; s < total_steps; ++s) {
+        const float* o = &st[(size_t)s * 16];
+        if (s == 0) ratio_first = o[6];
+        if (o[9] == 1.0f) { acc[0] += o[2]; acc[1] += o[0]; acc[2] += o[1]; acc[3] += o[4]; acc[4] += o[3]; acc[5] += o[7]; acc[6] += o[8]; acc[7] += o[5]; ++n_upd; ++n_gn; }
+        else if (o[11] == 1.0f) { acc[6] += o[8]; ++n_gn; stopped = 1; break; }
+        else if (o[10] == 1.0f) break;
+    }
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int i = 0; i < h->ev_blocks; ++i) { s0 += ev[4 * i]; s1 += ev[4 * i + 1]; s2 += ev[4 * i + 2]; s3 += ev[4 * i + 3]; }
+    double nn = (double)N;
+    if (world > 1) {   // explained variance over all shards: tiny host-free all-reduce of the four sums
+        double v[5] = {s0, s1, s2, s3, nn}; double* d = h->adv_stats;   // reuse the 4-double scratch + norm scratch is too small: use ev_partials
+        HIPCHK(h, hipMemcpyAsync(h->ev_partials, v, sizeof(v), hipMemcpyHostToDevice, h->stream)); (void)d;
+        rc = rccl_allreduce(h, h->ev_partials, 5, kNcclFloat64); if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(v, h->ev_partials, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+        rc = sync(h); if (rc) return rc;
+        s0 = v[0]; s1 = v[1]; s2 = v[2]; s3 = v[3]; nn = v[4];
+    }
+    const double var_d = (s1 - s0 * s0 / nn) / (nn - 1.0), var_r = (s3 - s2 * s2 / nn) / (nn - 1.0);
+    if (out) {
+        std::memset(out, 0, sizeof(*out));
+        const double den = n_upd > 0 ? n_upd : 1, gden = n_gn > 0 ? n_gn : 1;
+        out->entropy_loss = (float)(acc[0] / den); out->policy_loss = (float)(acc[1] / den); out->value_loss = (float)(acc[2] / den);
+        out->approx_kl_div = (float)(acc[3] / den); out->clip_fraction = (float)(acc[4] / den); out->loss = (float)(acc[5] / den);
+        out->grad_norm = (float)(acc[6] / gden); out->entropy = (float)(acc[7] / den);
+        out->explained_variance = (float)(1.0 - var_d / var_r); out->ratio_first = ratio_first;
+        out->n_updates = n_upd; out->early_stopped = stopped; out->nan_or_inf = nan;
+    }
+    if (nan) return fail(h, DRIL_ERR_NAN_IN_GRADS, "gradient contains nan or is not finite (ppo.jl:213-214)");
+    return DRIL_OK;
+}
+}  // namespace
+DRIL_EXPORT int32_t dril_ppo_update(dril_handle* h, dril_ppo_stats* out) { NEED(h); return ppo_update(h, out); }
+
+DRIL_EXPORT int32_t dril_ppo_loss_grad(dril_handle* h, const float* obs, const void* actions, const float* advantages, const float* returns,
+                                       const float* old_logprobs, const float* old_values, int64_t batch, float* loss, float* stats7, float* grads) {
+    NEED(h);
+    if (!obs || !actions || !advantages || !returns || !old_logprobs || !old_values || batch < 1) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ppo_loss_grad: bad argument");
+    if (h->cfg.world_size > 1) return fail(h, DRIL_ERR_UNSUPPORTED, "dril_ppo_loss_grad is a single-rank parity entry point");
+    const size_t B = (size_t)batch;
+    float *d_obs = nullptr, *d_adv = nullptr, *d_ret = nullptr, *d_lp = nullptr, *d_val = nullptr; void* d_act = nullptr;
+    auto cleanup = [&]() { hipFree(d_obs); hipFree(d_adv); hipFree(d_ret); hipFree(d_lp); hipFree(d_val); hipFree(d_act); };
+#define LCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(h, DRIL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+    LCHK(dmalloc(&d_obs, B * h->D)); LCHK(dmalloc(&d_adv, B)); LCHK(dmalloc(&d_ret, B)); LCHK(dmalloc(&d_lp, B)); LCHK(dmalloc(&d_val, B)); LCHK(hipMalloc(&d_act, B * act_bytes_per(h)));
+    LCHK(hipMemcpyAsync(d_obs, obs, B * h->D * 4, hipMemcpyHostToDevice, h->stream)); LCHK(hipMemcpyAsync(d_adv, advantages, B * 4, hipMemcpyHostToDevice, h->stream));
+    LCHK(hipMemcpyAsync(d_ret, returns, B * 4, hipMemcpyHostToDevice, h->stream)); LCHK(hipMemcpyAsync(d_lp, old_logprobs, B * 4, hipMemcpyHostToDevice, h->stream));
+    LCHK(hipMemcpyAsync(d_val, old_values, B * 4, hipMemcpyHostToDevice, h->stream)); LCHK(hipMemcpyAsync(d_act, actions, B * act_bytes_per(h), hipMemcpyHostToDevice, h->stream));
+    LCHK(hipMemsetAsync(h->stop_flag, 0, 4, h->stream));
+#undef LCHK
+    int rc = ppo_step(h, d_obs, d_act, d_adv, d_ret, d_lp, d_val, nullptr, 0, batch, batch, 0, /*bits=0: identity order*/ 0, nullptr, false);
+    std::vector<float> flat((size_t)h->P + 8);
+    if (!rc) { hipError_t e = hipMemcpyAsync(flat.data(), h->flat, flat.size() * 4, hipMemcpyDeviceToHost, h->stream); if (e != hipSuccess) rc = fail(h, DRIL_ERR_HIP, hipGetErrorString(e)); }
+    if (!rc) rc = sync(h);
+    cleanup();
+    if (rc) return rc;
+    const float* s = flat.data() + h->P; const float n = s[6];
+    const float pl = s[0] / n, ent = s[1] / n, vl = s[5] / n;
+    if (grads) std::memcpy(grads, flat.data(), (size_t)h->P * 4);
+    if (loss) *loss = pl + h->cfg.ent_coef * (-ent) + h->cfg.vf_coef * vl;
+    if (stats7) { stats7[0] = pl; stats7[1] = vl; stats7[2] = -ent; stats7[3] = s[2] / n; stats7[4] = s[3] / n; stats7[5] = ent; stats7[6] = s[4] / n; }
+    return DRIL_OK;
+}
+
+DRIL_EXPORT int32_t dril_apply_gradients(dril_handle* h, const float* grads, size_t n, float* grad_norm) {
+    NEED(h);
+    if (!grads || n != (size_t)h->P) return fail(h, DRIL_ERR_INVALID_ARG, "dril_apply_gradients: n != dril_param_count");
+    HIPCHK(h, hipMemcpyAsync(h->flat, grads, n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->stop_flag, 0, 4, h->stream)); HIPCHK(h, hipMemsetAsync(h->nan_flag, 0, 4, h->stream));
+    HIPCHK(h, launch_grad_norm(h->flat, h->P, h->norm_partials, h->stop_flag, h->stream));
+    AdamArgs ad{};
+    ad.params = h->params; ad.m = h->adam_m; ad.v = h->adam_v; ad.flat = h->flat; ad.P = h->P; ad.norm_partials = h->norm_partials;
+    ad.n_partials = h->n_norm_partials; ad.bt = h->bt; ad.step_parity = (int)(h->adam_steps & 1);
+    ad.beta1 = h->cfg.adam_beta1; ad.beta2 = h->cfg.adam_beta2; ad.eps = h->cfg.adam_eps; ad.lr = h->lr; ad.max_grad_norm = h->cfg.max_grad_norm;
+    ad.has_max_grad_norm = h->cfg.has_max_grad_norm; ad.has_target_kl = 0; ad.use_stats = 0; ad.step_stats = nullptr; ad.norm_out = h->norm_out;
+    ad.nan_flag = h->nan_flag; ad.stop_flag = h->stop_flag; ad.stop_flag_w = h->stop_flag;
+    HIPCHK(h, launch_adam(ad, h->stream));
+    h->adam_steps += 1;
+    float norm = 0; int nan = 0;
+    HIPCHK(h, hipMemcpyAsync(&norm, h->norm_out, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&nan, h->nan_flag, 4, hipMemcpyDeviceToHost, h->stream));
+    int rc = sync(h); if (rc) return rc;
+    if (grad_norm) *grad_norm = norm;
+    if (nan) return fail(h, DRIL_ERR_NAN_IN_GRADS, "gradient contains nan or is not finite (ppo.jl:213-214)");
+    return DRIL_OK;
+}
+
+// ---- train! ------------------------------------------------------------------------------------------
+DRIL_EXPORT int32_t dril_train(dril_handle* h, int64_t max_steps, dril_ppo_stats* stats, double* fps, int32_t* iterations_done) {
+    NEED(h);
+    const int64_t per_iter = (int64_t)h->cfg.n_steps * h->cfg.n_envs * h->cfg.world_size;
+    const int64_t iterations = max_steps / per_iter;                                   // ppo.jl:117
+    int32_t done = 0;
+    for (int64_t i = 0; i < iterations; ++i) {
+        h->lr = h->cfg.learning_rate;                                                  // ppo.jl:155-156
+        double f = 0; int rc = collect_rollout(h, &f, false);                          // ppo.jl:167
+        if (rc) { if (iterations_done) *iterations_done = done; return rc; }
+        if (fps) fps[i] = f;
+        rc = ppo_update(h, stats ? &stats[i] : nullptr);                               // ppo.jl:188-264
+        if (rc) { if (iterations_done) *iterations_done = done; return rc; }
+        ++done;
+    }
+    if (iterations_done) *iterations_done = done;
+    return DRIL_OK;
+}
+
+// ---- multi-GPU ------------------------------------------------------------------------------------------
+DRIL_EXPORT int32_t dril_comm_unique_id(uint8_t id[128]) {
+    std::string err;
+    if (!id) return fail(nullptr, DRIL_ERR_INVALID_ARG, "null id");
+    if (!load_rccl(err)) return fail(nullptr, DRIL_ERR_RCCL, err);
+    NcclId nid; std::memset(&nid, 0, sizeof(nid));
+    const int rc = g_rccl.GetUniqueId(&nid);
+    if (rc != 0) return fail(nullptr, DRIL_ERR_RCCL, "ncclGetUniqueId failed");
+    std::memcpy(id, nid.bytes, 128);
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_comm_init(dril_handle* h, const uint8_t id[128]) {
+    NEED(h); std::string err;
+    if (!id) return fail(h, DRIL_ERR_INVALID_ARG, "null id");
+    if (!load_rccl(err)) return fail(h, DRIL_ERR_RCCL, err);
+    NcclId nid; std::memcpy(nid.bytes, id, 128);
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int rc = ((nccl_init_rank_fn)(void*)g_rccl.CommInitRank)(&h->comm, h->cfg.world_size, nid, h->cfg.rank);
+    if (rc != 0) { h->comm = nullptr; return fail(h, DRIL_ERR_RCCL, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error")); }
+    return DRIL_OK;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------------
+DRIL_EXPORT int32_t dril_profile_get(dril_handle* h, int32_t kid, double* total_ms, int64_t* launches) {
+    NEED(h); if (kid < 0 || kid >= DRIL_K_COUNT) return fail(h, DRIL_ERR_INVALID_ARG, "bad kernel id");
+    int rc = sync(h); if (rc) return rc;
+    if (total_ms) *total_ms = h->prof_ms[kid]; if (launches) *launches = h->prof_n[kid];
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_profile_reset(dril_handle* h) {
+    NEED(h); int rc = sync(h); if (rc) return rc;
+    for (int i = 0; i < DRIL_K_COUNT; ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+    return DRIL_OK;
+}
+DRIL_EXPORT const char* dril_kernel_name(int32_t kid) {
+    static const char* names[] = {"rollout_kernel", "gae_kernel", "adv_moments_kernel", "ppo_grad_kernel", "grad_reduce_kernel", "adam_kernel", "ncclAllReduce"};
+    return (kid >= 0 && kid < DRIL_K_COUNT) ? names[kid] : "?";
+}
+DRIL_EXPORT const char* dril_version(void) { return "dril_hip 0.1 (gfx950, abi 1)"; }

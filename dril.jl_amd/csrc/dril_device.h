@@ -1,0 +1,333 @@
+// dril_device.h — device-side building blocks shared by every kernel of libdril_hip.so (gfx950 only).
+//
+//   * Philox4x32-10 counter RNG + the keyed index bijection that stands in for MLUtils' shuffle
+//   * env physics (Gymnasium CartPole-v1 / Pendulum-v1 — SURVEY.md §8c item 3)
+//   * the wave-level MLP tile: exact-f32 MFMA (v_mfma_f32_32x32x2_f32) with weights staged in LDS
+//
+// MLP tile geometry.  One wave owns a tile of 32 samples.  Activations live in
+// MFMA C/D layout: f32x16 X[H/32]; element (mt, r, lane) is X[row = 32*mt + rowfn(r, lane>>5)][col = lane&31]
+// with rows = hidden units and cols = samples.  A layer Y = W * X takes X straight from the accumulator
+// registers as the B operand (k-step (mi, r): lanes 0-31 contribute hidden row rowfn(r,0), lanes 32-63
+// rowfn(r,1)); W comes from LDS as the A operand, 4 consecutive k per ds_read_b128 from a [out][in+4]
+// image (the +4 pad makes the 16-lane b128 groups conflict-free).  No LDS round trip between layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dril {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kTile = 32;   // samples per wave tile (MFMA N)
+constexpr int kWPad = 4;    // pad of weight image rows (floats)
+constexpr int kTS = 36;     // row stride of the transposed activation images (32 samples + 4)
+
+// ---------------------------------------------------------------------------------------------
+// RNG (spec shared with oracle/dril_oracle.c; both are restatements of the same published Philox)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
+                                              uint32_t c3, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__host__ __device__ inline float u01_f32(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+__host__ __device__ inline double u01_f64(uint32_t hi, uint32_t lo) {
+    return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ inline float randn_f32(uint32_t a, uint32_t b) {
+    const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+// keyed bijection on [0, n): position in the epoch -> buffer index (DataLoader(shuffle=true), ppo.jl:188-195)
+__host__ __device__ inline uint64_t mix_bij(uint64_t x, uint64_t key, int bits) {
+    const uint64_t mask = bits >= 64 ? ~0ull : (((uint64_t)1 << bits) - 1);
+    const int s = bits / 2 > 0 ? bits / 2 : 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        x ^= (key >> (r * 13)) & mask;
+        x = (x * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull) & mask;
+        x ^= x >> s;
+        x = (x * 0xBF58476D1CE4E5B9ull) & mask;
+        x ^= x >> (s + 1 < bits ? s + 1 : s);
+    }
+    return x;
+}
+__host__ __device__ inline int64_t perm_index(int64_t p, int64_t n, uint64_t key, int bits) {
+    uint64_t x = (uint64_t)p;
+    do { x = mix_bij(x, key, bits); } while ((int64_t)x >= n);
+    return (int64_t)x;
+}
+__host__ inline int perm_bits(int64_t n) { int b = 1; while (((int64_t)1 << b) < n) ++b; return b; }
+
+// ---------------------------------------------------------------------------------------------
+// math
+// ---------------------------------------------------------------------------------------------
+// tanh with <= ~2e-7 absolute error: odd polynomial near 0, 1 - 2/(e^{2x}+1) elsewhere
+// (v_exp_f32 + v_rcp_f32 are 1-ulp units).  The reference applies Julia's tanh inside Lux.Dense
+// (layer_helpers.jl:33-56).
+__device__ __forceinline__ float tanh_f32(float x) {
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    // Taylor/minimax-ish odd series good to 1e-7 for |x| < 0.3
+    float p = fmaf(x2, 0.021869488536155203f, -0.05396825396825397f);   // 62/2835, -17/315
+    p = fmaf(x2, p, 0.13333333333333333f);                               // 2/15
+    p = fmaf(x2, p, -0.3333333333333333f);                               // -1/3
+    const float small = fmaf(x * x2, p, x);
+    const float e = __expf(2.0f * ax);                                    // exp2-based, 1 ulp
+    const float big = copysignf(1.0f - 2.0f * __frcp_rn(e + 1.0f), x);
+    return ax < 0.3f ? small : big;
+}
+
+// ---------------------------------------------------------------------------------------------
+// environments
+// ---------------------------------------------------------------------------------------------
+template <int KIND> struct EnvSpec;
+template <> struct EnvSpec<0> { static constexpr int D = 4, S = 4, A = 2; static constexpr bool discrete = true; };
+template <> struct EnvSpec<1> { static constexpr int D = 3, S = 2, A = 1; static constexpr bool discrete = false; };
+
+template <int KIND> __device__ inline void env_reset(uint64_t env_seed, uint32_t episode, float* st) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)env_seed, (uint32_t)(env_seed >> 32), episode, 0, 0, 0, r);
+    if (KIND == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st[i] = u01_f32(r[i]) * 0.1f - 0.05f;
+    } else {
+        st[0] = u01_f32(r[0]) * 6.28318530717958647692f - 3.14159265358979323846f;
+        st[1] = u01_f32(r[1]) * 2.0f - 1.0f;
+    }
+}
+template <int KIND> __device__ inline void env_obs(const float* st, float* obs) {
+    if (KIND == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) obs[i] = st[i];
+    } else { obs[0] = cosf(st[0]); obs[1] = sinf(st[0]); obs[2] = st[1]; }
+}
+// one step; act_i is the env-space discrete action (0/1), act_f the env-space continuous action
+template <int KIND> __device__ inline float env_step(float* st, float act_f, int act_i, bool fixed_len, bool* terminated) {
+    if (KIND == 0) {
+        const float gravity = 9.8f, masspole = 0.1f, total_mass = 1.1f, length = 0.5f;
+        const float polemass_length = 0.05f, force_mag = 10.0f, tau = 0.02f;
+        float x = st[0], x_dot = st[1], th = st[2], th_dot = st[3];
+        const float force = act_i == 1 ? force_mag : -force_mag;
+        const float c = cosf(th), s = sinf(th);
+        const float temp = (force + polemass_length * th_dot * th_dot * s) / total_mass;
+        const float thacc = (gravity * s - c * temp) / (length * (4.0f / 3.0f - masspole * c * c / total_mass));
+        const float xacc = temp - polemass_length * thacc * c / total_mass;
+        x = x + tau * x_dot; x_dot = x_dot + tau * xacc;
+        th = th + tau * th_dot; th_dot = th_dot + tau * thacc;
+        st[0] = x; st[1] = x_dot; st[2] = th; st[3] = th_dot;
+        const bool term = (x < -2.4f) || (x > 2.4f) || (th < -0.20943951023931953f) || (th > 0.20943951023931953f);
+        *terminated = fixed_len ? false : term;
+        return 1.0f;
+    } else {
+        const float max_speed = 8.0f, max_torque = 2.0f, dt = 0.05f, g = 10.0f, m = 1.0f, l = 1.0f;
+        const float pi = 3.14159265358979323846f;
+        const float th = st[0], thdot = st[1];
+        const float u = fminf(fmaxf(act_f, -max_torque), max_torque);
+        float an = fmodf(th + pi, 2.0f * pi); if (an < 0) an += 2.0f * pi; an -= pi;
+        const float cost = an * an + 0.1f * thdot * thdot + 0.001f * u * u;
+        float nthdot = thdot + (3.0f * g / (2.0f * l) * sinf(th) + 3.0f / (m * l * l) * u) * dt;
+        nthdot = fminf(fmaxf(nthdot, -max_speed), max_speed);
+        st[0] = th + nthdot * dt; st[1] = nthdot;
+        *terminated = false;
+        return -cost;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// parameter layout (flat, include/dril_hip.h): net = {W1 b1 W2 b2 W3 b3}, W column-major (out x in)
+// ---------------------------------------------------------------------------------------------
+struct NetOff { int w1, b1, w2, b2, w3, b3, end; };
+__host__ __device__ inline NetOff net_off(int base, int D, int H1, int H2, int O) {
+    NetOff n; n.w1 = base; n.b1 = n.w1 + H1 * D; n.w2 = n.b1 + H1; n.b2 = n.w2 + H2 * H1;
+    n.w3 = n.b2 + H2; n.b3 = n.w3 + O * H2; n.end = n.b3 + O; return n;
+}
+
+// LDS image of one net (offsets in floats; every block starts on a 16-byte boundary)
+template <int D, int H1, int H2, int O> struct NetLds {
+    static constexpr int DP = 4;                        // obs dim padded to the MFMA k-pairing (D <= 4)
+    static constexpr int WS1 = H1 + kWPad;              // row stride of W2S ([out=H2][in=H1])
+    static constexpr int WS2 = H2 + kWPad;              // row stride of W2T ([in=H1][out=H2])
+    static constexpr int OP = (O + 3) / 4 * 4;
+    static constexpr int W1T = 0;                       // [DP][H1]   W1T[k][o] = W1[o][k]
+    static constexpr int B1 = W1T + DP * H1;
+    static constexpr int W2S = B1 + H1;                 // [H2][WS1]  W2S[o][k] = W2[o][k]
+    static constexpr int B2 = W2S + H2 * WS1;
+    static constexpr int W3S = B2 + H2;                 // [O][H2]
+    static constexpr int B3 = W3S + O * H2;
+    static constexpr int FWD_END = B3 + OP;
+    static constexpr int W2T = FWD_END;                 // [H1][WS2]  W2T[k][o] = W2[o][k]   (backward only)
+    static constexpr int BWD_END = W2T + H1 * WS2;
+    static_assert(D <= DP, "obs dim > 4 needs a wider first-layer pairing");
+    static_assert(H1 % 32 == 0 && H2 % 32 == 0, "hidden widths must be multiples of 32");
+};
+
+// cooperative global -> LDS staging of one net's weights (all threads of the workgroup)
+template <int D, int H1, int H2, int O, bool BWD>
+__device__ inline void stage_net(float* lds, const float* __restrict__ P, NetOff n, int tid, int nthreads) {
+    using L = NetLds<D, H1, H2, O>;
+    for (int i = tid; i < L::DP * H1; i += nthreads) {
+        const int o = i % H1, k = i / H1;
+        lds[L::W1T + k * H1 + o] = k < D ? P[n.w1 + o + k * H1] : 0.0f;
+    }
+    for (int i = tid; i < H1; i += nthreads) lds[L::B1 + i] = P[n.b1 + i];
+    for (int i = tid; i < H2 * H1; i += nthreads) {
+        const int o = i % H2, k = i / H2;
+        const float w = P[n.w2 + i];
+        lds[L::W2S + o * L::WS1 + k] = w;
+        if (BWD) lds[L::W2T + k * L::WS2 + o] = w;
+    }
+    for (int i = tid; i < H2; i += nthreads) lds[L::B2 + i] = P[n.b2 + i];
+    for (int i = tid; i < O * H2; i += nthreads) {
+        const int o = i % O, k = i / O;
+        lds[L::W3S + o * H2 + k] = P[n.w3 + i];
+    }
+    for (int i = tid; i < L::OP; i += nthreads) lds[L::B3 + i] = i < O ? P[n.b3 + i] : 0.0f;
+}
+
+__device__ __forceinline__ int rowfn(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Y[MO] (+bias) = W * X[KI]; W image [32*MO rows][WS], A operand by ds_read_b128
+template <int KI, int MO, bool BIAS>
+__device__ __forceinline__ void dense_mfma(const float* __restrict__ Wimg, int WS, const float* __restrict__ bias,
+                                           const f32x16 (&X)[KI], f32x16 (&Y)[MO], int lane) {
+    const int o = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (BIAS) b = *reinterpret_cast<const f32x4*>(bias + 32 * mo + 8 * q + 4 * h);
+            acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+        }
+        const float* wrow = Wimg + (32 * mo + o) * WS + 4 * h;
+#pragma unroll
+        for (int mi = 0; mi < KI; ++mi) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(wrow + 32 * mi + 8 * q);
+                acc = mfma32(a[0], X[mi][4 * q + 0], acc);
+                acc = mfma32(a[1], X[mi][4 * q + 1], acc);
+                acc = mfma32(a[2], X[mi][4 * q + 2], acc);
+                acc = mfma32(a[3], X[mi][4 * q + 3], acc);
+            }
+        }
+        Y[mo] = acc;
+    }
+}
+
+// first layer: K = DP = 4 -> two k-steps; xk[s] = obs[2s + (lane>>5)] of sample (lane&31)
+template <int H1, int MO>
+__device__ __forceinline__ void dense_first(const float* __restrict__ W1T, const float* __restrict__ bias,
+                                            const float (&xk)[2], f32x16 (&Y)[MO], int lane) {
+    const int o = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mo = 0; mo < MO; ++mo) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 32 * mo + 8 * q + 4 * h);
+            acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc = mfma32(W1T[(2 * s + h) * H1 + 32 * mo + o], xk[s], acc);
+        Y[mo] = acc;
+    }
+}
+
+template <int M> __device__ __forceinline__ void tanh_tiles(f32x16 (&X)[M]) {
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[m][r] = tanh_f32(X[m][r]);
+}
+
+// output layer on the VALU: out[o] = b3[o] + sum_j W3[o][j] * h2[j][sample]; each half-wave owns half the rows
+template <int M, int O, int H2>
+__device__ __forceinline__ void dense_out(const float* __restrict__ W3S, const float* __restrict__ b3,
+                                          const f32x16 (&X)[M], float (&out)[O], int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        float p = 0.f;
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(W3S + o * H2 + 32 * m + 8 * q + 4 * h);
+                p = fmaf(w[0], X[m][4 * q + 0], p); p = fmaf(w[1], X[m][4 * q + 1], p);
+                p = fmaf(w[2], X[m][4 * q + 2], p); p = fmaf(w[3], X[m][4 * q + 3], p);
+            }
+        out[o] = p + __shfl_xor(p, 32) + b3[o];
+    }
+}
+
+// full forward of one net for a 32-sample tile
+template <int D, int H1, int H2, int O>
+__device__ __forceinline__ void net_forward(const float* __restrict__ lds, const float (&xk)[2], f32x16 (&h1)[H1 / 32],
+                                            f32x16 (&h2)[H2 / 32], float (&out)[O], int lane) {
+    using L = NetLds<D, H1, H2, O>;
+    dense_first<H1, H1 / 32>(lds + L::W1T, lds + L::B1, xk, h1, lane);
+    tanh_tiles(h1);
+    dense_mfma<H1 / 32, H2 / 32, true>(lds + L::W2S, L::WS1, lds + L::B2, h1, h2, lane);
+    tanh_tiles(h2);
+    dense_out<H2 / 32, O, H2>(lds + L::W3S, lds + L::B3, h2, out, lane);
+}
+
+// ---- transposes through a per-wave LDS image [H][kTS] ---------------------------------------------------
+// store X (C/D layout) as img[hidden row][sample col]
+template <int M> __device__ __forceinline__ void store_image(float* img, const f32x16 (&X)[M], int lane) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) img[(32 * m + rowfn(r, h)) * kTS + c] = X[m][r];
+}
+// read m-tile m of an image as an MFMA A/B operand set for a contraction over samples:
+// lane (i = lane&31, h) gets regs kk = 0..15 = img[32m + i][16h + kk]   (k-step kk pairs samples kk and 16+kk)
+__device__ __forceinline__ f32x16 load_operand(const float* img, int m, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+    const float* p = img + (32 * m + i) * kTS + 16 * h;
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+        v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+    }
+    return v;
+}
+__device__ __forceinline__ f32x16 mfma_outer(const f32x16& a, const f32x16& b, f32x16 acc) {
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc = mfma32(a[kk], b[kk], acc);
+    return acc;
+}
+__device__ __forceinline__ float sum16(const f32x16& v) {
+    float s0 = (v[0] + v[1]) + (v[2] + v[3]), s1 = (v[4] + v[5]) + (v[6] + v[7]);
+    float s2 = (v[8] + v[9]) + (v[10] + v[11]), s3 = (v[12] + v[13]) + (v[14] + v[15]);
+    return (s0 + s1) + (s2 + s3);
+}
+// sum over the 32 lanes of each half-wave (result valid in every lane of the half)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+}  // namespace dril

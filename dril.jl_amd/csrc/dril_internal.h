@@ -1,0 +1,77 @@
+// dril_internal.h — kernel argument blocks and launcher prototypes shared by dril_kernels.hip and dril_api.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dril_device.h"
+
+namespace dril {
+
+struct PolicyArgs {
+    const float* params; const float* obs; int64_t B; const void* noise;
+    void* actions; float* values; float* logp; float* entropy;
+    int mode; int action_start; int log_std_off; uint64_t seed; uint32_t call_counter;
+    NetOff actor, critic;
+};
+
+struct RolloutArgs {
+    const float* params;
+    float* state; int32_t* step_count; uint32_t* episode; uint32_t* gstep;
+    float* obs; void* act; float* rew; float* logp; float* val; float* boot; uint8_t* flags; float* last_values;
+    const void* noise;
+    int E, T, episode_len, fixed_len, action_start, log_std_off;
+    uint64_t env_seed0;
+    NetOff actor, critic;
+};
+
+struct MomentsArgs {
+    const float* adv; const int64_t* perm; int64_t pos0, count, N, idx_lo, n_local; uint64_t perm_key; int perm_bits;
+    double* partials; const int* stop_flag;
+};
+
+struct GradArgs {
+    const float* params; const float* obs; const void* actions; const float* adv; const float* ret;
+    const float* logp_old; const float* val_old;
+    const int64_t* perm; int64_t pos0, count, N, idx_lo, n_local; uint64_t perm_key; int perm_bits;
+    const double* adv_stats;
+    float invB, clip_range, ent_coef, vf_coef, clip_range_vf;
+    int has_clip_vf, normalize_adv, action_start, log_std_off;
+    float* slabs_actor; float* slabs_critic; int slab_a, slab_c, G;
+    const int* stop_flag;
+    NetOff actor, critic;
+};
+
+struct ReduceArgs {
+    const float* slabs_actor; const float* slabs_critic; int slab_a, slab_c, G;
+    int P, Pa, Pc; float* flat; double* norm_partials; double n_samples_local; const int* stop_flag;
+};
+
+struct AdamArgs {
+    float* params; float* m; float* v; const float* flat; int P;
+    const double* norm_partials; int n_partials;
+    float* bt; int step_parity;
+    float beta1, beta2, eps, lr, max_grad_norm, target_kl, ent_coef, vf_coef;
+    int has_max_grad_norm, has_target_kl, use_stats;
+    float* step_stats; float* norm_out; int* nan_flag; const int* stop_flag; int* stop_flag_w;
+};
+
+hipError_t launch_env_reset(int kind, int E, uint64_t seed0, float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* dr, hipStream_t s);
+hipError_t launch_env_observe(int kind, int E, const float* state, float* obs, hipStream_t s);
+hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int fixed_len, int action_start, const void* actions,
+                           float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* rew, uint8_t* term, uint8_t* trunc,
+                           float* tobs, hipStream_t s);
+hipError_t launch_policy(int kind, int hidden, const PolicyArgs& a, int max_blocks, hipStream_t s);
+hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_t s);
+hipError_t launch_gae(int E, int T, float gamma, float lam, const float* rew, const float* val, const uint8_t* flags,
+                      const float* boot, const float* last_values, float* adv, float* ret, hipStream_t s);
+hipError_t launch_adv_moments(const MomentsArgs& a, int nblocks, hipStream_t s);
+hipError_t launch_moments_finalize(const double* partials, int nblocks, double* out3, double n_local, const int* stop_flag, hipStream_t s);
+hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t s);
+hipError_t launch_grad_reduce(const ReduceArgs& a, hipStream_t s);
+hipError_t launch_grad_norm(const float* flat, int P, double* norm_partials, const int* stop_flag, hipStream_t s);
+hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
+hipError_t launch_explained_var(const float* val, const float* ret, int64_t N, double* partials, int nblocks, hipStream_t s);
+int slab_size_actor(int kind, int hidden);
+int slab_size_critic(int kind, int hidden);
+
+}  // namespace dril

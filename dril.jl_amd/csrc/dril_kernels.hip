@@ -1,0 +1,848 @@
+// dril_kernels.hip — every HIP kernel of libdril_hip.so (gfx950 / CDNA4 only) and their launchers.
+//
+// Kernel map (reference function each one replaces — paths relative to the reference root):
+//   env_reset_kernel / env_observe_kernel / env_step_kernel   MultiThreadedParallelEnv reset!/observe/act!
+//                                                            src/environment_wrappers/multithreadedParallelEnv.jl:12-74
+//   policy_kernel        layer(obs,ps,st) / evaluate_actions / predict_values
+//                        src/layers/layer_forward.jl:3-39, src/layers/layer_methods.jl:28-61
+//   rollout_kernel       collect_trajectories, src/buffers/trajectory.jl:22-78 (persistent: one wave owns 32 envs for all T steps)
+//   gae_kernel           compute_advantages! trajectory.jl:80-102 + returns rollout_buffer.jl:87
+//   adv_moments_kernel   normalize! statistics, src/algorithms/ppo.jl:350-356
+//   ppo_grad_kernel      (alg::PPO)(layer,ps,st,batch) ppo.jl:365-407 + its reverse pass (Zygote in the reference, ppo.jl:207)
+//   grad_reduce_kernel / grad_norm_kernel / adam_kernel   nested_norm, nested_scale!, target_kl check, Adam — ppo.jl:213-239
+//   explained_var_kernel ppo.jl:256
+#include "dril_internal.h"
+
+namespace dril {
+
+// =============================================================================================
+// env verbs (step-granular path)
+// =============================================================================================
+template <int KIND>
+__global__ void env_reset_kernel(int E, uint64_t seed0, float* state, int32_t* step_count, uint32_t* episode,
+                                 uint32_t* gstep, float* disc_returns) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float st[EnvSpec<KIND>::S];
+    env_reset<KIND>(seed0 + (uint64_t)e, 0u, st);
+#pragma unroll
+    for (int i = 0; i < EnvSpec<KIND>::S; ++i) state[(size_t)e * EnvSpec<KIND>::S + i] = st[i];
+    step_count[e] = 0; episode[e] = 0; gstep[e] = 0; disc_returns[e] = 0.f;
+}
+
+template <int KIND>
+__global__ void env_observe_kernel(int E, const float* state, float* obs) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float st[EnvSpec<KIND>::S], o[EnvSpec<KIND>::D];
+#pragma unroll
+    for (int i = 0; i < EnvSpec<KIND>::S; ++i) st[i] = state[(size_t)e * EnvSpec<KIND>::S + i];
+    env_obs<KIND>(st, o);
+#pragma unroll
+    for (int i = 0; i < EnvSpec<KIND>::D; ++i) obs[(size_t)e * EnvSpec<KIND>::D + i] = o[i];
+}
+
+template <int KIND>
+__global__ void env_step_kernel(int E, uint64_t seed0, int episode_len, int fixed_len, int action_start,
+                                const void* actions, float* state, int32_t* step_count, uint32_t* episode,
+                                uint32_t* gstep, float* rewards, uint8_t* term, uint8_t* trunc, float* terminal_obs) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    constexpr int S = EnvSpec<KIND>::S, D = EnvSpec<KIND>::D;
+    float st[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) st[i] = state[(size_t)e * S + i];
+    int ai = 0; float af = 0.f;
+    if (EnvSpec<KIND>::discrete) ai = ((const int32_t*)actions)[e] - action_start; else af = ((const float*)actions)[e];
+    bool t;
+    const float r = env_step<KIND>(st, af, ai, fixed_len != 0, &t);
+    const int sc = step_count[e] + 1;
+    const bool tr = sc >= episode_len;
+    rewards[e] = r; term[e] = t; trunc[e] = tr; gstep[e] += 1;
+    if (tr) { float o[D]; env_obs<KIND>(st, o);
+#pragma unroll
+        for (int i = 0; i < D; ++i) terminal_obs[(size_t)e * D + i] = o[i]; }
+    if (t || tr) { const uint32_t ep = episode[e] + 1; episode[e] = ep; step_count[e] = 0; env_reset<KIND>(seed0 + (uint64_t)e, ep, st); }
+    else step_count[e] = sc;
+#pragma unroll
+    for (int i = 0; i < S; ++i) state[(size_t)e * S + i] = st[i];
+}
+
+// =============================================================================================
+// distribution heads shared by policy_kernel / rollout_kernel / ppo_grad_kernel
+// =============================================================================================
+// Lux.softmax + Categorical: layer_forward.jl:141-149, categorical.jl:20-52
+template <int A> __device__ __forceinline__ void softmax_n(const float (&z)[A], float (&p)[A]) {
+    float m = z[0];
+#pragma unroll
+    for (int i = 1; i < A; ++i) m = fmaxf(m, z[i]);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < A; ++i) { p[i] = expf(z[i] - m); s += p[i]; }
+#pragma unroll
+    for (int i = 0; i < A; ++i) p[i] = p[i] / s;
+}
+template <int A> __device__ __forceinline__ int categorical_sample(const float (&p)[A], double u) {
+    float cs = 0.f; int a = A - 1; bool found = false;
+#pragma unroll
+    for (int i = 0; i < A; ++i) { cs += p[i]; if (!found && (double)cs >= u) { a = i; found = true; } }
+    return a;
+}
+template <int A> __device__ __forceinline__ float pick(const float (&p)[A], int a) {
+    float v = p[0];
+#pragma unroll
+    for (int i = 1; i < A; ++i) v = (a == i) ? p[i] : v;
+    return v;
+}
+template <int A> __device__ __forceinline__ float categorical_entropy(const float (&p)[A]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < A; ++i) s += p[i] * logf(p[i]);
+    return -s;
+}
+constexpr float kLog2Pi = 1.8378770664093453f;
+// DiagGaussian logpdf / entropy: diagGaussian.jl:25-43
+template <int A> __device__ __forceinline__ float gauss_logpdf(const float (&x)[A], const float (&mu)[A], const float* ls) {
+    float lss = 0.f, dss = 0.f;
+#pragma unroll
+    for (int i = 0; i < A; ++i) { lss += ls[i]; const float d = x[i] - mu[i]; dss += d * d * expf(-2.0f * ls[i]); }
+    return -0.5f * (2.0f * lss + dss + (float)A * kLog2Pi);
+}
+template <int A> __device__ __forceinline__ float gauss_entropy(const float* ls) {
+    float lss = 0.f;
+#pragma unroll
+    for (int i = 0; i < A; ++i) lss += ls[i];
+    return 0.5f * (float)A * (1.0f + kLog2Pi) + lss;
+}
+
+// first-layer B operand from an observation held in registers: xk[s] = obs[2s + h] (static register indices only)
+template <int D> __device__ __forceinline__ void pair_obs(const float (&obs)[D], int h, float (&xk)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float v0 = (2 * s < D) ? obs[(2 * s < D) ? 2 * s : 0] : 0.f;
+        const float v1 = (2 * s + 1 < D) ? obs[(2 * s + 1 < D) ? 2 * s + 1 : 0] : 0.f;
+        xk[s] = h ? v1 : v0;
+    }
+}
+
+// =============================================================================================
+// policy_kernel: host-batch / step-granular forward.  One wave = 32 samples.
+// mode 0: sample + logprob + value; 1: evaluate given actions (+entropy); 2: critic only
+// =============================================================================================
+template <int KIND, int H>
+__global__ __launch_bounds__(256, 2) void policy_kernel(PolicyArgs a) {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A, MT = H / 32;
+    constexpr bool DISC = EnvSpec<KIND>::discrete;
+    using LA = NetLds<D, H, H, A>; using LC = NetLds<D, H, H, 1>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* la = smem; float* lc = smem + LA::FWD_END;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.mode != 2) stage_net<D, H, H, A, false>(la, a.params, a.actor, tid, blockDim.x);
+    stage_net<D, H, H, 1, false>(lc, a.params, a.critic, tid, blockDim.x);
+    __syncthreads();
+    const int64_t ntiles = (a.B + kTile - 1) / kTile;
+    const int c = lane & 31, h = lane >> 5;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t b = tile * kTile + c;
+        const bool valid = b < a.B;
+        const int64_t bb = valid ? b : a.B - 1;
+        float xk[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; xk[s] = d < D ? a.obs[bb * D + d] : 0.f; }
+        f32x16 h1[MT], h2[MT];
+        float v[1];
+        net_forward<D, H, H, 1>(lc, xk, h1, h2, v, lane);
+        if (valid && h == 0 && a.values) a.values[b] = v[0];
+        if (a.mode == 2) continue;
+        float out[A];
+        net_forward<D, H, H, A>(la, xk, h1, h2, out, lane);
+        if (DISC) {
+            float p[A]; softmax_n<A>(out, p);
+            int act;
+            if (a.mode == 0) {
+                double u;
+                if (a.noise) u = ((const double*)a.noise)[bb];
+                else { uint32_t r[4]; philox4x32_10((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)bb, (uint32_t)(bb >> 32), 3, a.call_counter, r); u = u01_f64(r[0], r[1]); }
+                act = categorical_sample<A>(p, u);
+                if (valid && h == 0) ((int32_t*)a.actions)[b] = act + a.action_start;
+            } else act = ((const int32_t*)a.actions)[bb] - a.action_start;
+            if (valid && h == 0) {
+                a.logp[b] = logf(pick<A>(p, act));
+                if (a.mode == 1 && a.entropy) a.entropy[b] = categorical_entropy<A>(p);
+            }
+        } else {
+            const float* ls = a.params + a.log_std_off;
+            float x[A];
+            if (a.mode == 0) {
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    float z;
+                    if (a.noise) z = ((const float*)a.noise)[bb * A + i];
+                    else { uint32_t r[4]; philox4x32_10((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)bb, (uint32_t)(bb >> 32), 3 + 16 * (uint32_t)i, a.call_counter, r); z = randn_f32(r[0], r[1]); }
+                    x[i] = out[i] + expf(ls[i]) * z;
+                    if (valid && h == 0) ((float*)a.actions)[b * A + i] = x[i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < A; ++i) x[i] = ((const float*)a.actions)[bb * A + i];
+            }
+            if (valid && h == 0) {
+                a.logp[b] = gauss_logpdf<A>(x, out, ls);
+                if (a.mode == 1 && a.entropy) a.entropy[b] = gauss_entropy<A>(ls);
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// rollout_kernel: persistent collect_trajectories (trajectory.jl:22-78).  A wave owns 32 envs for all
+// T steps: env state lives in registers, both nets' weights in LDS, only buffer writes touch HBM.
+// Buffer layout: time-major, index k = t*E + e; every store of a wave is one full 128-byte line
+// (or 512 B for the float4 observation rows).
+// =============================================================================================
+template <int KIND, int H>
+__global__ __launch_bounds__(256, 2) void rollout_kernel(RolloutArgs a) {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A, S = EnvSpec<KIND>::S, MT = H / 32;
+    constexpr bool DISC = EnvSpec<KIND>::discrete;
+    using LA = NetLds<D, H, H, A>; using LC = NetLds<D, H, H, 1>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* la = smem; float* lc = smem + LA::FWD_END;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    stage_net<D, H, H, A, false>(la, a.params, a.actor, tid, blockDim.x);
+    stage_net<D, H, H, 1, false>(lc, a.params, a.critic, tid, blockDim.x);
+    __syncthreads();
+    const int c = lane & 31, h = lane >> 5;
+    const int e_raw = (blockIdx.x * 4 + wave) * kTile + c;
+    if ((blockIdx.x * 4 + wave) * kTile >= a.E) return;  // whole wave out of range (wave-uniform)
+    const bool valid = e_raw < a.E;
+    const int e = valid ? e_raw : a.E - 1;
+    const bool writer = valid && h == 0;
+    const uint64_t env_seed = a.env_seed0 + (uint64_t)e;
+
+    float st[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) st[i] = a.state[(size_t)e * S + i];
+    int sc = a.step_count[e];
+    uint32_t ep = a.episode[e], gs = a.gstep[e];
+    float obs[D];
+    env_obs<KIND>(st, obs);
+    const float* ls = a.params + a.log_std_off;
+
+    for (int t = 0; t < a.T; ++t) {
+        const size_t k = (size_t)t * a.E + e;
+        // keep the weights in LDS: an opaque zero offset stops hipcc from hoisting ~150 loop-invariant
+        // ds_reads into VGPRs (which spilled at the 256-register budget of 2 waves/SIMD)
+        int zoff = 0; asm volatile("" : "+v"(zoff));
+        const float* la_t = la + zoff; const float* lc_t = lc + zoff;
+        float xk[2];
+        pair_obs<D>(obs, h, xk);
+        f32x16 h1[MT], h2[MT];
+        float v[1], out[A];
+        net_forward<D, H, H, 1>(lc_t, xk, h1, h2, v, lane);
+        __builtin_amdgcn_sched_barrier(0);   // do not interleave the two nets: that doubles the live weight fragments
+        net_forward<D, H, H, A>(la_t, xk, h1, h2, out, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- sample (layer_forward.jl:10-11 / :36-37) ----
+        int act_env = 0; float actf_env = 0.f; float logp;
+        if (DISC) {
+            float p[A]; softmax_n<A>(out, p);
+            double u;
+            if (a.noise) u = ((const double*)a.noise)[k];
+            else { uint32_t r[4]; philox4x32_10((uint32_t)env_seed, (uint32_t)(env_seed >> 32), gs, 0, 1, 0, r); u = u01_f64(r[0], r[1]); }
+            const int act = categorical_sample<A>(p, u);
+            logp = logf(pick<A>(p, act));
+            act_env = act;                                                   // DiscreteAdapter: identity (default_adapters.jl:34-38)
+            if (writer) ((int32_t*)a.act)[k] = act + a.action_start;         // raw action stored (trajectory.jl:48)
+        } else {
+            float x[A];
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                float z;
+                if (a.noise) z = ((const float*)a.noise)[k * A + i];
+                else { uint32_t r[4]; philox4x32_10((uint32_t)env_seed, (uint32_t)(env_seed >> 32), gs, 0, 1, (uint32_t)(i / 2), r); z = (i & 1) ? randn_f32(r[2], r[3]) : randn_f32(r[0], r[1]); }
+                x[i] = out[i] + expf(ls[i]) * z;
+                if (writer) ((float*)a.act)[k * A + i] = x[i];
+            }
+            logp = gauss_logpdf<A>(x, out, ls);
+            actf_env = fminf(fmaxf(x[0], -2.0f), 2.0f);                      // ClampAdapter on Box(-2,2) (default_adapters.jl:4-11)
+        }
+        if (writer) {
+            if (D == 4) *reinterpret_cast<float4*>(a.obs + k * 4) = make_float4(obs[0], obs[1], obs[2], obs[3]);
+            else {
+#pragma unroll
+                for (int i = 0; i < D; ++i) a.obs[k * D + i] = obs[i];
+            }
+            a.val[k] = v[0]; a.logp[k] = logp;
+        }
+        // ---- act! with auto-reset (multithreadedParallelEnv.jl:56-71) ----
+        bool term;
+        const float rew = env_step<KIND>(st, actf_env, act_env, a.fixed_len != 0, &term);
+        sc += 1; gs += 1;
+        const bool trunc = sc >= a.episode_len;
+        if (__any(trunc && valid)) {                                         // V(terminal_observation), trajectory.jl:57-61
+            float tobs[D]; env_obs<KIND>(st, tobs);
+            float tk[2];
+            pair_obs<D>(tobs, h, tk);
+            float bv[1];
+            net_forward<D, H, H, 1>(lc_t, tk, h1, h2, bv, lane);
+            if (writer && trunc) a.boot[k] = bv[0];
+        }
+        if (term || trunc) { ep += 1; sc = 0; env_reset<KIND>(env_seed, ep, st); }
+        if (writer) { a.rew[k] = rew; a.flags[k] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0)); }
+        env_obs<KIND>(st, obs);                                              // observe(env), trajectory.jl:45
+    }
+    {   // V(new_obs) for rollout-limited trajectories, trajectory.jl:65-70 (computed for every env; GAE uses it when needed)
+        float xk[2];
+        pair_obs<D>(obs, h, xk);
+        f32x16 h1[MT], h2[MT]; float v[1];
+        net_forward<D, H, H, 1>(lc, xk, h1, h2, v, lane);
+        if (writer) a.last_values[e] = v[0];
+    }
+    if (writer) {
+#pragma unroll
+        for (int i = 0; i < S; ++i) a.state[(size_t)e * S + i] = st[i];
+        a.step_count[e] = sc; a.episode[e] = ep; a.gstep[e] = gs;
+    }
+}
+
+// =============================================================================================
+// gae_kernel: one thread per env, backward scan over the time-major buffer (coalesced 256 B rows)
+// =============================================================================================
+__global__ void gae_kernel(int E, int T, float gamma, float lam, const float* __restrict__ rew,
+                           const float* __restrict__ val, const uint8_t* __restrict__ flags,
+                           const float* __restrict__ boot, const float* __restrict__ last_values,
+                           float* __restrict__ adv, float* __restrict__ ret) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float next_adv = 0.f, next_val = 0.f;
+    const float lv = last_values[e];
+#pragma unroll 8
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t k = (size_t)t * E + e;
+        const float r = rew[k], v = val[k];
+        const uint8_t f = flags[k];
+        const bool term = f & 1, trunc = f & 2;
+        float a;
+        if (term || trunc || t == T - 1) {                    // last step of a trajectory, trajectory.jl:85-95
+            float delta;
+            if (term) delta = r - v;
+            else if (trunc) delta = r + gamma * boot[k] - v;
+            else delta = r + gamma * lv - v;
+            a = delta;
+        } else {                                              // trajectory.jl:96-99
+            const float delta = r + gamma * next_val - v;
+            a = delta + gamma * lam * next_adv;
+        }
+        adv[k] = a; ret[k] = a + v;                           // rollout_buffer.jl:87
+        next_adv = a; next_val = v;
+    }
+}
+
+// =============================================================================================
+// advantage moments of one minibatch (normalize!, ppo.jl:350-356): per-block f64 partials, fixed-order finalize
+// =============================================================================================
+__device__ __forceinline__ double block_sum_f64(double v, double* sh) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double s = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+    return s;
+}
+__global__ void adv_moments_kernel(MomentsArgs a) {
+    __shared__ double sh[16];
+    if (*a.stop_flag) return;
+    double s = 0, q = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.count; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = a.pos0 + i;
+        const int64_t idx = a.perm ? a.perm[p] : (a.perm_bits ? perm_index(p, a.N, a.perm_key, a.perm_bits) : p);
+        const int64_t li = idx - a.idx_lo;                    // this rank's shard of the buffer
+        if (li >= 0 && li < a.n_local) { const double x = a.adv[li]; s += x; q += x * x; }
+    }
+    s = block_sum_f64(s, sh); q = block_sum_f64(q, sh);
+    if (threadIdx.x == 0) { a.partials[2 * blockIdx.x] = s; a.partials[2 * blockIdx.x + 1] = q; }
+}
+__global__ void moments_finalize_kernel(const double* partials, int nblocks, double* out3, double n_local, const int* stop_flag) {
+    if (*stop_flag) return;
+    if (threadIdx.x == 0) {
+        double s = 0, q = 0;
+        for (int i = 0; i < nblocks; ++i) { s += partials[2 * i]; q += partials[2 * i + 1]; }
+        out3[0] = s; out3[1] = q; out3[2] = n_local;
+    }
+}
+
+// =============================================================================================
+// ppo_grad_kernel — the dominant kernel.  Fused forward + loss + backward of ONE net per workgroup
+// (even blocks: actor, odd blocks: critic — the two MLPs share no parameters, layer_helpers.jl:13-25,
+// so their gradients decouple given the batch).  Per 32-sample tile and net: 228 v_mfma_f32_32x32x2_f32
+//   fwd  L1 4 + L2 64                      (L3 and its transpose products run on the VALU, O <= 2)
+//   bwd  dh1 = W2' dz2 64, dW2 += dz2 h1' 64, dW1|db1 += dz1 [x;1]' 32
+// Weight gradients accumulate in registers over the workgroup's whole share of the minibatch and
+// leave as ONE slab per workgroup (plain coalesced stores) — grad_reduce_kernel sums the slabs in a
+// fixed order, so the result is bitwise reproducible and no float atomics are used.
+// =============================================================================================
+enum { HEAD_CATEGORICAL = 0, HEAD_GAUSSIAN = 1, HEAD_VALUE = 2 };
+
+template <int KIND, int H, int O, int HEAD>
+__device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
+    constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
+    using L = NetLds<D, H, H, O>;
+    constexpr int SCR = 2 * H * kTS + 8 * kTS;                // per-wave scratch: two [H][kTS] images + [8][kTS] x image
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
+    float* wl = smem;
+    float* T0 = smem + L::BWD_END + wave * SCR;               // h1 image
+    float* T1 = T0 + H * kTS;                                 // dz2 image, then dz1 image
+    float* XI = T1 + H * kTS;                                 // [8][kTS]: rows 0..D-1 = x, row D = 1, rest 0
+    stage_net<D, H, H, O, true>(wl, a.params, off, tid, blockDim.x);
+    for (int i = lane; i < 8 * kTS; i += 64) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
+    __syncthreads();
+
+    // advantage normalisation constants (ppo.jl:350-356): mean, corrected std, eps added to the std
+    float adv_mean = 0.f, adv_den = 1.f;
+    if (HEAD != HEAD_VALUE && a.normalize_adv) {
+        const double s = a.adv_stats[0], q = a.adv_stats[1], n = a.adv_stats[2];
+        const double mean = s / n;
+        double var = (q - s * mean) / (n - 1.0);
+        if (var < 0) var = 0;
+        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
+    }
+    const float* ls = a.params + a.log_std_off;
+
+    f32x16 dW2[MT][MT], dW1[MT], dW3p[O][MT];
+    float db2p[MT], db3p[O], dlsp[O], st[5];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        db2p[i] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW1[i][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dW2[i][j][r] = 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        db3p[o] = 0.f; dlsp[o] = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dW3p[o][m][r] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) st[i] = 0.f;
+
+    const int g = blockIdx.x >> 1;
+    const int64_t ntiles = (a.count + kTile - 1) / kTile;
+    for (int64_t tile = (int64_t)g * 4 + wave; tile < ntiles; tile += (int64_t)a.G * 4) {
+        // ---- gather one tile of the minibatch (DataLoader, ppo.jl:188-195) ----
+        const int64_t i = tile * kTile + c;
+        const bool inb = i < a.count;
+        const int64_t p = a.pos0 + (inb ? i : 0);
+        const int64_t gidx = a.perm ? a.perm[p] : (a.perm_bits ? perm_index(p, a.N, a.perm_key, a.perm_bits) : p);   // bits 0 = identity order
+        const int64_t li = gidx - a.idx_lo;
+        const bool valid = inb && li >= 0 && li < a.n_local;
+        const int64_t idx = valid ? li : 0;
+        float xk[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; xk[s] = d < D ? a.obs[idx * D + d] : 0.f; }
+        // ---- forward ----
+        f32x16 h1[MT], h2[MT];
+        float out[O], dz[O];
+        net_forward<D, H, H, O>(wl, xk, h1, h2, out, lane);
+        // ---- loss head (ppo.jl:377-404) and dLoss/dout ----
+        if (HEAD == HEAD_VALUE) {
+            const float R = a.ret[idx];
+            float value = out[0]; bool vpass = true;
+            if (a.has_clip_vf) {                                              // clip_range, ppo.jl:344-346,378
+                const float ov = a.val_old[idx], d = value - ov;
+                vpass = d >= -a.clip_range_vf && d <= a.clip_range_vf;
+                value = ov + fminf(fmaxf(d, -a.clip_range_vf), a.clip_range_vf);
+            }
+            const float ve = value - R;
+            dz[0] = (valid && vpass) ? a.invB * a.vf_coef * 2.0f * ve : 0.f;
+            if (valid && h == 0) st[0] += ve * ve;                            // value_loss numerator, ppo.jl:385
+        } else {
+            const float advn = (a.adv[idx] - adv_mean) / adv_den;
+            const float olp = a.logp_old[idx];
+            float logp, ent;
+            float p[O];
+            int act = 0;
+            float xa[O];
+            if (HEAD == HEAD_CATEGORICAL) {
+                softmax_n<O>(out, p);
+                act = ((const int32_t*)a.actions)[idx] - a.action_start;
+                logp = logf(pick<O>(p, act));
+                ent = categorical_entropy<O>(p);
+            } else {
+#pragma unroll
+                for (int o = 0; o < O; ++o) xa[o] = ((const float*)a.actions)[idx * O + o];
+                logp = gauss_logpdf<O>(xa, out, ls);
+                ent = gauss_entropy<O>(ls);
+            }
+            const float lr = logp - olp;
+            const float r = expf(lr);                                          // ppo.jl:380
+            const float lo = 1.0f - a.clip_range, hi = 1.0f + a.clip_range;
+            const float rc = fminf(fmaxf(r, lo), hi);                          // :381
+            const float t1 = r * advn, t2 = rc * advn;
+            const float mn = t2 < t1 ? t2 : t1;                                // :382
+            const float dm_dr = (t2 < t1) ? ((r >= lo && r <= hi) ? advn : 0.f) : advn;
+            const float dlogp = valid ? -a.invB * dm_dr * r : 0.f;
+            const float dent = valid ? -a.invB * a.ent_coef : 0.f;             // ent_loss = -mean(entropy), :383,:386
+            if (HEAD == HEAD_CATEGORICAL) {
+#pragma unroll
+                for (int o = 0; o < O; ++o)
+                    dz[o] = dlogp * ((o == act ? 1.0f : 0.0f) - p[o]) + dent * (-p[o] * (logf(p[o]) + ent));
+            } else {
+#pragma unroll
+                for (int o = 0; o < O; ++o) {
+                    const float iv = expf(-2.0f * ls[o]), d = xa[o] - out[o];
+                    dz[o] = dlogp * d * iv;
+                    if (h == 0) dlsp[o] += dlogp * (d * d * iv - 1.0f) + dent;
+                }
+            }
+            if (valid && h == 0) {
+                st[0] += -mn; st[1] += ent; st[2] += (r != rc) ? 1.0f : 0.0f;   // :382,:383,:390
+                st[3] += (r - 1.0f) - lr; st[4] += r;                           // :393,:402
+            }
+        }
+        // ---- backward: output layer on the VALU ----
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            if (h == 0) db3p[o] += dz[o];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) dW3p[o][m] += dz[o] * h2[m];
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float dh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < O; ++o) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * m + 8 * q + 4 * h);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(w[cc], dz[o], dh[cc]);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) { const float hv = h2[m][4 * q + cc]; h2[m][4 * q + cc] = dh[cc] * (1.0f - hv * hv); }  // dz2
+            }
+        // ---- transposed images for the sample contractions ----
+        store_image<MT>(T0, h1, lane);
+        store_image<MT>(T1, h2, lane);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) XI[d * kTS + c] = xk[s]; }
+        // ---- dh1 = W2' dz2 ; dz1 = dh1 .* (1 - h1^2) ----
+        f32x16 g1[MT];
+        dense_mfma<MT, MT, false>(wl + L::W2T, L::WS2, nullptr, h2, g1, lane);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g1[m][r] = g1[m][r] * (1.0f - h1[m][r] * h1[m][r]);
+        // ---- dW2 += dz2 * h1' ; db2 += rowsum(dz2) ----
+        {
+            f32x16 Bh[MT];
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj) Bh[mj] = load_operand(T0, mj, lane);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                const f32x16 Az = load_operand(T1, mi, lane);
+                db2p[mi] += sum16(Az);
+#pragma unroll
+                for (int mj = 0; mj < MT; ++mj) dW2[mi][mj] = mfma_outer(Az, Bh[mj], dW2[mi][mj]);
+            }
+        }
+        // ---- dW1 | db1 += dz1 * [x; 1]' ----
+        store_image<MT>(T1, g1, lane);
+        {
+            const int xr = c <= D ? c : 7;
+            f32x16 Bx;
+            const float* px = XI + xr * kTS + 16 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(px + 4 * q);
+                Bx[4 * q + 0] = t[0]; Bx[4 * q + 1] = t[1]; Bx[4 * q + 2] = t[2]; Bx[4 * q + 3] = t[3];
+            }
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                const f32x16 Az = load_operand(T1, mi, lane);
+                dW1[mi] = mfma_outer(Az, Bx, dW1[mi]);
+            }
+        }
+    }
+
+    // ---- epilogue: 4 waves -> one slab (fixed wave order => deterministic) ----
+    __syncthreads();
+    float* red = smem + L::BWD_END;
+    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
+    const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
+    const int o_ls = o_b3 + O, o_st = SL - 8;
+    for (int i = tid; i < SL; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * mi + rowfn(r, h);
+#pragma unroll
+                    for (int mj = 0; mj < MT; ++mj) red[o_w2 + row + (32 * mj + c) * H] += dW2[mi][mj][r];
+                    if (c < D) red[o_w1 + row + c * H] += dW1[mi][r];
+                    else if (c == D) red[o_b1 + row] += dW1[mi][r];
+                }
+                const float b2 = db2p[mi] + __shfl_xor(db2p[mi], 32);
+                if (h == 0) red[o_b2 + 32 * mi + c] += b2;
+            }
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = half_sum(dW3p[o][m][r]);
+                        if (c == 0) red[o_w3 + o + (32 * m + rowfn(r, h)) * O] += v;
+                    }
+                const float b3 = half_sum(db3p[o]);
+                if (lane == 0) red[o_b3 + o] += b3;
+                if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (lane == 0) red[o_ls + o] += l; }
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (lane == 0) red[o_st + k] += v; }
+        }
+        __syncthreads();
+    }
+    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
+    for (int i = tid; i < SL; i += blockDim.x) slab[i] = red[i];
+}
+
+template <int KIND, int H>
+__global__ __launch_bounds__(256, 1) void ppo_grad_kernel(GradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (*a.stop_flag) return;
+    constexpr int A = EnvSpec<KIND>::A;
+    if ((blockIdx.x & 1) == 0) grad_body<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN>(a, smem);
+    else grad_body<KIND, H, 1, HEAD_VALUE>(a, smem);
+}
+
+// =============================================================================================
+// slab reduction -> flat [grads | stats] buffer; norm; clip + KL check + Adam
+// flat layout: params order (actor net, critic net, log_std) then 8 stats:
+//   0 sum(-min term)  1 sum(entropy)  2 sum(clipped)  3 sum(kl)  4 sum(ratio)  5 sum((V-R)^2)  6 n_samples  7 unused
+// =============================================================================================
+__global__ void grad_reduce_kernel(ReduceArgs a) {
+    __shared__ double sh[16];
+    if (*a.stop_flag) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    float gsum = 0.f;
+    if (p < a.P) {
+        const float* base; int stride, offp;
+        if (p < a.Pa) { base = a.slabs_actor; stride = a.slab_a; offp = p; }
+        else if (p < a.Pa + a.Pc) { base = a.slabs_critic; stride = a.slab_c; offp = p - a.Pa; }
+        else { base = a.slabs_actor; stride = a.slab_a; offp = a.Pa + (p - a.Pa - a.Pc); }   // log_std grads sit after the actor net
+        for (int g = 0; g < a.G; ++g) gsum += base[(size_t)g * stride + offp];
+        a.flat[p] = gsum;
+    }
+    const double q = block_sum_f64((double)gsum * (double)gsum, sh);
+    if (threadIdx.x == 0) a.norm_partials[blockIdx.x] = q;
+    if (blockIdx.x == 0 && threadIdx.x < 8) {
+        const int k = threadIdx.x; double s = 0;
+        if (k < 5) for (int g = 0; g < a.G; ++g) s += a.slabs_actor[(size_t)g * a.slab_a + a.slab_a - 8 + k];
+        else if (k == 5) for (int g = 0; g < a.G; ++g) s += a.slabs_critic[(size_t)g * a.slab_c + a.slab_c - 8];
+        else if (k == 6) s = a.n_samples_local;
+        a.flat[a.P + k] = (float)s;
+    }
+}
+__global__ void grad_norm_kernel(const float* flat, int P, double* norm_partials, const int* stop_flag) {
+    __shared__ double sh[16];
+    if (*stop_flag) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const float g = p < P ? flat[p] : 0.f;
+    const double q = block_sum_f64((double)g * (double)g, sh);
+    if (threadIdx.x == 0) norm_partials[blockIdx.x] = q;
+}
+__global__ void adam_kernel(AdamArgs a) {
+    if (*a.stop_flag) return;
+    __shared__ float s_norm;
+    if (threadIdx.x == 0) { double s = 0; for (int i = 0; i < a.n_partials; ++i) s += a.norm_partials[i]; s_norm = sqrtf((float)s); }
+    __syncthreads();
+    const float norm = s_norm;
+    const float* stf = a.flat + a.P;
+    const float n = a.use_stats ? stf[6] : 1.f;
+    const float kl = a.use_stats ? stf[3] / n : 0.f;
+    const bool bad = !(norm == norm) || isinf(norm);                              // NaN/Inf anywhere poisons the norm (ppo.jl:213-214)
+    const bool kl_stop = a.use_stats && a.has_target_kl && kl > 1.5f * a.target_kl;   // ppo.jl:235-238: skip this apply, stop
+    const float* bt_in = a.bt + 2 * (a.step_parity & 1);
+    float* bt_out = a.bt + 2 * ((a.step_parity + 1) & 1);
+    const float bt1 = bt_in[0], bt2 = bt_in[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (a.step_stats) {
+            float* o = a.step_stats;
+            const float pl = stf[0] / n, ent = stf[1] / n, vl = stf[5] / n;
+            o[0] = pl; o[1] = vl; o[2] = -ent; o[3] = stf[2] / n; o[4] = kl; o[5] = ent; o[6] = stf[4] / n;
+            o[7] = pl + a.ent_coef * (-ent) + a.vf_coef * vl;                       // loss, ppo.jl:386
+            o[8] = norm; o[9] = (bad || kl_stop) ? 0.f : 1.f; o[10] = bad ? 1.f : 0.f; o[11] = kl_stop ? 1.f : 0.f;
+        }
+        if (a.norm_out) *a.norm_out = norm;
+        if (bad) { *a.nan_flag = 1; *a.stop_flag_w = 1; }
+        if (kl_stop) *a.stop_flag_w = 1;
+        if (bad || kl_stop) { bt_out[0] = bt1; bt_out[1] = bt2; } else { bt_out[0] = bt1 * a.beta1; bt_out[1] = bt2 * a.beta2; }
+    }
+    if (bad || kl_stop) return;
+    const float scale = (a.has_max_grad_norm && norm > a.max_grad_norm) ? a.max_grad_norm / norm : 1.0f;   // optimization_utils.jl:98-107
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < a.P) {
+        float g = a.flat[p];
+        if (scale != 1.0f) g = g * scale;
+        const float m = a.beta1 * a.m[p] + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * a.v[p] + (1.0f - a.beta2) * g * g;
+        a.m[p] = m; a.v[p] = v;
+        a.params[p] -= m / (1.0f - bt1) / (sqrtf(v / (1.0f - bt2)) + a.eps) * a.lr;  // Optimisers.Adam, eps=1e-5 (ppo.jl:64-66)
+    }
+}
+
+// explained_variance sums over the whole buffer (ppo.jl:256): partials of (v-r), (v-r)^2, r, r^2
+__global__ void explained_var_kernel(const float* val, const float* ret, int64_t N, double* partials) {
+    __shared__ double sh[16];
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const double d = (double)val[i] - (double)ret[i], r = ret[i];
+        s0 += d; s1 += d * d; s2 += r; s3 += r * r;
+    }
+    s0 = block_sum_f64(s0, sh); s1 = block_sum_f64(s1, sh); s2 = block_sum_f64(s2, sh); s3 = block_sum_f64(s3, sh);
+    if (threadIdx.x == 0) { double* o = partials + 4 * blockIdx.x; o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; }
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+template <int KIND, int H> static size_t fwd_lds_bytes() {
+    return sizeof(float) * (NetLds<EnvSpec<KIND>::D, H, H, EnvSpec<KIND>::A>::FWD_END + NetLds<EnvSpec<KIND>::D, H, H, 1>::FWD_END);
+}
+template <int KIND, int H> static size_t grad_lds_bytes() {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
+    constexpr int SCR = 2 * H * kTS + 8 * kTS;
+    constexpr int wa = NetLds<D, H, H, A>::BWD_END, wc = NetLds<D, H, H, 1>::BWD_END;
+    return sizeof(float) * ((wa > wc ? wa : wc) + 4 * SCR);
+}
+
+#define DRIL_DISPATCH(kind, hidden, CALL)                                            \
+    do {                                                                             \
+        if ((kind) == 0 && (hidden) == 64) { CALL(0, 64); }                          \
+        else if ((kind) == 1 && (hidden) == 64) { CALL(1, 64); }                     \
+        else return hipErrorInvalidValue;                                            \
+    } while (0)
+
+hipError_t launch_env_reset(int kind, int E, uint64_t seed0, float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* dr, hipStream_t s) {
+    const int blocks = (E + 255) / 256;
+    if (kind == 0) env_reset_kernel<0><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
+    else env_reset_kernel<1><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
+    return hipGetLastError();
+}
+hipError_t launch_env_observe(int kind, int E, const float* state, float* obs, hipStream_t s) {
+    const int blocks = (E + 255) / 256;
+    if (kind == 0) env_observe_kernel<0><<<blocks, 256, 0, s>>>(E, state, obs);
+    else env_observe_kernel<1><<<blocks, 256, 0, s>>>(E, state, obs);
+    return hipGetLastError();
+}
+hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int fixed_len, int action_start, const void* actions,
+                           float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* rew, uint8_t* term, uint8_t* trunc,
+                           float* tobs, hipStream_t s) {
+    const int blocks = (E + 255) / 256;
+    if (kind == 0) env_step_kernel<0><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs);
+    else env_step_kernel<1><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs);
+    return hipGetLastError();
+}
+
+hipError_t launch_policy(int kind, int hidden, const PolicyArgs& a, int max_blocks, hipStream_t s) {
+    const int64_t ntiles = (a.B + kTile - 1) / kTile;
+    int blocks = (int)((ntiles + 3) / 4);
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks < 1) blocks = 1;
+#define CALL(K, HH)                                                                                           \
+    {                                                                                                         \
+        const size_t lds = fwd_lds_bytes<K, HH>();                                                            \
+        hipError_t e = hipFuncSetAttribute((const void*)policy_kernel<K, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                        \
+        policy_kernel<K, HH><<<blocks, 256, lds, s>>>(a);                                                     \
+    }
+    DRIL_DISPATCH(kind, hidden, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_t s) {
+    const int blocks = (a.E + 4 * kTile - 1) / (4 * kTile);
+#define CALL(K, HH)                                                                                           \
+    {                                                                                                         \
+        const size_t lds = fwd_lds_bytes<K, HH>();                                                            \
+        hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel<K, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                        \
+        rollout_kernel<K, HH><<<blocks, 256, lds, s>>>(a);                                                    \
+    }
+    DRIL_DISPATCH(kind, hidden, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_gae(int E, int T, float gamma, float lam, const float* rew, const float* val, const uint8_t* flags,
+                      const float* boot, const float* last_values, float* adv, float* ret, hipStream_t s) {
+    gae_kernel<<<(E + 63) / 64, 64, 0, s>>>(E, T, gamma, lam, rew, val, flags, boot, last_values, adv, ret);
+    return hipGetLastError();
+}
+
+hipError_t launch_adv_moments(const MomentsArgs& a, int nblocks, hipStream_t s) {
+    adv_moments_kernel<<<nblocks, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+hipError_t launch_moments_finalize(const double* partials, int nblocks, double* out3, double n_local, const int* stop_flag, hipStream_t s) {
+    moments_finalize_kernel<<<1, 64, 0, s>>>(partials, nblocks, out3, n_local, stop_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t s) {
+#define CALL(K, HH)                                                                                           \
+    {                                                                                                         \
+        const size_t lds = grad_lds_bytes<K, HH>();                                                           \
+        hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<K, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                        \
+        ppo_grad_kernel<K, HH><<<2 * a.G, 256, lds, s>>>(a);                                                  \
+    }
+    DRIL_DISPATCH(kind, hidden, CALL);
+#undef CALL
+    return hipGetLastError();
+}
+
+hipError_t launch_grad_reduce(const ReduceArgs& a, hipStream_t s) {
+    grad_reduce_kernel<<<(a.P + 255) / 256, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+hipError_t launch_grad_norm(const float* flat, int P, double* norm_partials, const int* stop_flag, hipStream_t s) {
+    grad_norm_kernel<<<(P + 255) / 256, 256, 0, s>>>(flat, P, norm_partials, stop_flag);
+    return hipGetLastError();
+}
+hipError_t launch_adam(const AdamArgs& a, hipStream_t s) {
+    adam_kernel<<<(a.P + 255) / 256, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+hipError_t launch_explained_var(const float* val, const float* ret, int64_t N, double* partials, int nblocks, hipStream_t s) {
+    explained_var_kernel<<<nblocks, 256, 0, s>>>(val, ret, N, partials);
+    return hipGetLastError();
+}
+
+int slab_size_actor(int kind, int hidden) {
+    const int D = kind == 0 ? 4 : 3, A = kind == 0 ? 2 : 1;
+    const NetOff n = net_off(0, D, hidden, hidden, A);
+    return (n.end + (kind == 0 ? 0 : A) + 8 + 3) / 4 * 4 + 0;
+}
+int slab_size_critic(int kind, int hidden) {
+    const int D = kind == 0 ? 4 : 3;
+    const NetOff n = net_off(0, D, hidden, hidden, 1);
+    return (n.end + 8 + 3) / 4 * 4;
+}
+
+}  // namespace dril

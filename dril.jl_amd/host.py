@@ -1,0 +1,651 @@
+"""Host-side mirror of DRiL.jl's interface for the rollout + PPO-update hot path.
+
+The reference is Julia (no Julia toolchain exists in the build image), so this module mirrors the
+reference's types and verbs in Python on top of the C ABI (include/dril_hip.h); the Julia `ccall`
+shim a maintainer would use lives in dril.jl_amd/julia/DRiLHIP.jl and binds the same symbols.
+
+Names follow the reference (Julia's `f!` is spelled `f_`):
+    Box, Discrete                      src/spaces.jl
+    ActorCriticLayer(...)              src/layers/layer_constructors.jl:3-96
+    PPO(...)                           src/algorithms/ppo.jl:25-40
+    Agent(layer, alg)                  src/algorithms/ppo.jl:42-62
+    DeviceParallelEnv <: AbstractParallelEnv   stands in for MultiThreadedParallelEnv
+                                       (src/environment_wrappers/multithreadedParallelEnv.jl)
+    RolloutBuffer, collect_rollout_    src/buffers/rollout_buffer.jl:6-18,46-90
+    train_(agent, env, alg, max_steps) src/algorithms/ppo.jl:100-325
+
+All arithmetic happens in libdril_hip.so; nothing here computes the hot path and there is no CPU
+fallback (loading fails loudly when the library is missing).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import time
+from dataclasses import dataclass, field, asdict
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import DrilConfig, DrilPPOStats
+
+
+class DrilError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[dril status {code}] {msg}")
+        self.code = code
+
+
+# --------------------------------------------------------------------------------------------
+# spaces (src/spaces.jl)
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Box:
+    low: tuple
+    high: tuple
+
+    @property
+    def shape(self):
+        return (len(self.low),)
+
+
+@dataclass(frozen=True)
+class Discrete:
+    n: int
+    start: int = 1  # src/spaces.jl:160
+
+
+# env descriptors: CartPoleEnv / PendulumEnv come from ClassicControlEnvironments.jl in the reference
+# (test/Project.toml:22-23); here they only carry the constructor kwargs the device simulator needs.
+@dataclass
+class CartPoleEnv:
+    max_steps: int = 500
+    action_start: int = 1
+    kind: int = capi.ENV_CARTPOLE
+
+    def observation_space(self):
+        return Box((-4.8, -math.inf, -0.41887903, -math.inf), (4.8, math.inf, 0.41887903, math.inf))
+
+    def action_space(self):
+        return Discrete(2, self.action_start)
+
+
+@dataclass
+class PendulumEnv:
+    max_steps: int = 200
+    kind: int = capi.ENV_PENDULUM
+
+    def observation_space(self):
+        return Box((-1.0, -1.0, -8.0), (1.0, 1.0, 8.0))
+
+    def action_space(self):
+        return Box((-2.0,), (2.0,))
+
+
+# --------------------------------------------------------------------------------------------
+# PPO (src/algorithms/ppo.jl:25-40)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class PPO:
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    clip_range: float = 0.2
+    clip_range_vf: Optional[float] = None
+    ent_coef: float = 0.0
+    vf_coef: float = 0.5
+    max_grad_norm: Optional[float] = 0.5
+    target_kl: Optional[float] = None
+    normalize_advantage: bool = True
+    n_steps: int = 2048
+    batch_size: int = 64
+    epochs: int = 10
+    learning_rate: float = 3e-4
+
+
+# --------------------------------------------------------------------------------------------
+# layers (src/layers/): parameter tree + orthogonal init
+# --------------------------------------------------------------------------------------------
+def _orthogonal(rng: np.random.Generator, out_dims: int, in_dims: int, gain: float) -> np.ndarray:
+    """WeightInitializers.orthogonal equivalent (QR of a normal matrix, sign-fixed); the exact Julia
+    RNG stream is not reproducible outside Julia."""
+    rows, cols = (out_dims, in_dims) if out_dims >= in_dims else (in_dims, out_dims)
+    a = rng.standard_normal((rows, cols))
+    q, r = np.linalg.qr(a)
+    q = q * np.sign(np.diag(r))
+    w = q if out_dims >= in_dims else q.T
+    return (gain * w).astype(np.float32)
+
+
+@dataclass
+class ActorCriticLayer:
+    """ActorCriticLayer(observation_space, action_space; hidden_dims=[64,64], activation=tanh, log_std_init=0)
+    (src/layers/layer_constructors.jl:3-96).  Actor and critic are always separate MLPs
+    (layer_helpers.jl:13-25)."""
+    observation_space: Box
+    action_space: object
+    hidden_dims: Sequence[int] = (64, 64)
+    log_std_init: float = 0.0
+
+    @property
+    def discrete(self) -> bool:
+        return isinstance(self.action_space, Discrete)
+
+    @property
+    def obs_dim(self) -> int:
+        return len(self.observation_space.low)
+
+    @property
+    def actor_out(self) -> int:
+        return self.action_space.n if self.discrete else len(self.action_space.low)
+
+    def parameterlength(self) -> int:
+        """Lux.parameterlength (test/test_policies.jl:55-57)."""
+        d, (h1, h2), a = self.obs_dim, self.hidden_dims, self.actor_out
+        net = lambda o: d * h1 + h1 + h1 * h2 + h2 + h2 * o + o
+        return net(a) + net(1) + (0 if self.discrete else a)
+
+    def initialparameters(self, rng: np.random.Generator) -> dict:
+        """Lux.initialparameters: orthogonal gains sqrt(2) / 0.01 / 1.0, zero bias (layer_constructors.jl:16-20,61-65)."""
+        d, (h1, h2) = self.obs_dim, self.hidden_dims
+
+        def mlp(out, out_gain):
+            return {
+                "layer_1": {"weight": _orthogonal(rng, h1, d, math.sqrt(2.0)), "bias": np.zeros(h1, np.float32)},
+                "layer_2": {"weight": _orthogonal(rng, h2, h1, math.sqrt(2.0)), "bias": np.zeros(h2, np.float32)},
+                "layer_3": {"weight": _orthogonal(rng, out, h2, out_gain), "bias": np.zeros(out, np.float32)},
+            }
+
+        ps = {"feature_extractor": {}, "actor_head": mlp(self.actor_out, 0.01), "critic_head": mlp(1, 1.0)}
+        if not self.discrete:
+            ps["log_std"] = np.full(self.actor_out, self.log_std_init, np.float32)
+        return ps
+
+
+DiscreteActorCriticLayer = ActorCriticLayer
+ContinuousActorCriticLayer = ActorCriticLayer
+
+
+def flatten_params(ps: dict) -> np.ndarray:
+    """Lux NamedTuple -> the flat layout of dril_set_params (weights column-major out x in)."""
+    parts = []
+    for head in ("actor_head", "critic_head"):
+        for l in ("layer_1", "layer_2", "layer_3"):
+            parts.append(np.asarray(ps[head][l]["weight"], np.float32).ravel(order="F"))
+            parts.append(np.asarray(ps[head][l]["bias"], np.float32).ravel())
+    if "log_std" in ps:
+        parts.append(np.asarray(ps["log_std"], np.float32).ravel())
+    return np.concatenate(parts)
+
+
+def unflatten_params(flat: np.ndarray, like: dict) -> dict:
+    out = {"feature_extractor": {}, "actor_head": {}, "critic_head": {}}
+    off = 0
+    for head in ("actor_head", "critic_head"):
+        for l in ("layer_1", "layer_2", "layer_3"):
+            w = like[head][l]["weight"]
+            n = w.size
+            out[head][l] = {"weight": flat[off:off + n].reshape(w.shape, order="F").copy()}
+            off += n
+            b = like[head][l]["bias"]
+            out[head][l]["bias"] = flat[off:off + b.size].copy()
+            off += b.size
+    if "log_std" in like:
+        out["log_std"] = flat[off:off + like["log_std"].size].copy()
+    return out
+
+
+@dataclass
+class TrainState:
+    parameters: dict
+    step: int = 0
+
+
+@dataclass
+class Agent:
+    """Agent(layer, alg; rng) — src/algorithms/ppo.jl:42-62 (optimiser Adam(eta=lr, eps=1e-5), :64-66)."""
+    layer: ActorCriticLayer
+    alg: PPO
+    seed: int = 0
+    verbose: int = 0
+    train_state: TrainState = field(init=False)
+    rng: np.random.Generator = field(init=False)
+    steps_taken: int = 0
+    gradient_updates: int = 0
+
+    def __post_init__(self):
+        self.rng = np.random.default_rng(self.seed)
+        self.train_state = TrainState(self.layer.initialparameters(self.rng))
+
+
+# --------------------------------------------------------------------------------------------
+# the device handle
+# --------------------------------------------------------------------------------------------
+def make_config(env, n_envs: int, alg: PPO, layer: Optional[ActorCriticLayer] = None, *, seed: int = 42,
+                fixed_length_episodes: bool = False, device: int = 0, rank: int = 0, world_size: int = 1,
+                profile_events: bool = False) -> DrilConfig:
+    c = capi.default_config(env.kind)
+    c.n_envs, c.n_steps = n_envs, alg.n_steps
+    if layer is not None:
+        c.hidden1, c.hidden2 = layer.hidden_dims
+        c.log_std_init = layer.log_std_init
+    c.episode_len = env.max_steps
+    c.fixed_length_episodes = int(fixed_length_episodes)
+    c.action_start = getattr(env, "action_start", 1)
+    c.gamma, c.gae_lambda, c.clip_range = alg.gamma, alg.gae_lambda, alg.clip_range
+    c.has_clip_range_vf = int(alg.clip_range_vf is not None)
+    c.clip_range_vf = alg.clip_range_vf or 0.0
+    c.ent_coef, c.vf_coef = alg.ent_coef, alg.vf_coef
+    c.has_max_grad_norm = int(alg.max_grad_norm is not None)
+    c.max_grad_norm = alg.max_grad_norm or 0.0
+    c.has_target_kl = int(alg.target_kl is not None)
+    c.target_kl = alg.target_kl or 0.0
+    c.normalize_advantage = int(alg.normalize_advantage)
+    c.batch_size, c.epochs, c.learning_rate = alg.batch_size, alg.epochs, alg.learning_rate
+    c.seed, c.device, c.rank, c.world_size = seed, device, rank, world_size
+    c.profile_events = int(profile_events)
+    return c
+
+
+class Handle:
+    """Owns one dril_handle*; every method is a thin typed wrapper of one C entry point."""
+
+    def __init__(self, cfg: DrilConfig, lib: Optional[C.CDLL] = None):
+        self.lib = lib or capi.load_library()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        rc = self.lib.dril_create(C.byref(cfg), C.byref(self._h))
+        if rc != capi.OK:
+            raise DrilError(rc, (self.lib.dril_last_error(None) or b"").decode())
+        self.D = self.lib.dril_obs_dim(self._h)
+        self.A = self.lib.dril_action_dim(self._h)
+        self.discrete = bool(self.lib.dril_is_discrete(self._h))
+        self.P = int(self.lib.dril_param_count(self._h))
+        self.E, self.T = cfg.n_envs, cfg.n_steps
+        self.N = self.E * self.T
+
+    def close(self):
+        if self._h:
+            self.lib.dril_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int):
+        if rc != capi.OK:
+            raise DrilError(rc, (self.lib.dril_last_error(self._h) or b"").decode())
+
+    @staticmethod
+    def _p(a: Optional[np.ndarray]):
+        return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+    # parameters
+    def set_params(self, flat: np.ndarray):
+        flat = np.ascontiguousarray(flat, np.float32)
+        self._chk(self.lib.dril_set_params(self._h, self._p(flat), flat.size))
+
+    def get_params(self) -> np.ndarray:
+        out = np.empty(self.P, np.float32)
+        self._chk(self.lib.dril_get_params(self._h, self._p(out), out.size))
+        return out
+
+    def reset_optimizer(self):
+        self._chk(self.lib.dril_reset_optimizer(self._h))
+
+    def set_learning_rate(self, lr: float):
+        self._chk(self.lib.dril_set_learning_rate(self._h, lr))
+
+    # env verbs
+    def env_reset(self, seed: int):
+        self._chk(self.lib.dril_env_reset(self._h, seed))
+
+    def env_observe(self, update_stats: bool = True) -> np.ndarray:
+        obs = np.empty((self.E, self.D), np.float32)  # row e = observation of env e ((D x E) column-major)
+        self._chk(self.lib.dril_env_observe(self._h, self._p(obs), int(update_stats)))
+        return obs
+
+    def env_step(self, actions: np.ndarray):
+        actions = np.ascontiguousarray(actions, np.int32 if self.discrete else np.float32)
+        rew = np.empty(self.E, np.float32)
+        term = np.empty(self.E, np.uint8)
+        trunc = np.empty(self.E, np.uint8)
+        tobs = np.zeros((self.E, self.D), np.float32)
+        self._chk(self.lib.dril_env_step(self._h, self._p(actions), self._p(rew), self._p(term), self._p(trunc), self._p(tobs)))
+        return rew, term.astype(bool), trunc.astype(bool), tobs
+
+    def env_get_state(self):
+        S = 4 if self.discrete else 2
+        st = np.empty((self.E, S), np.float32)
+        sc = np.empty(self.E, np.int32)
+        self._chk(self.lib.dril_env_get_state(self._h, self._p(st), self._p(sc)))
+        return st, sc
+
+    def env_set_state(self, st: np.ndarray, sc: Optional[np.ndarray] = None):
+        st = np.ascontiguousarray(st, np.float32)
+        sc = None if sc is None else np.ascontiguousarray(sc, np.int32)
+        self._chk(self.lib.dril_env_set_state(self._h, self._p(st), self._p(sc)))
+
+    # policy on host batches
+    def policy_forward(self, obs: np.ndarray, noise: Optional[np.ndarray] = None):
+        obs = np.ascontiguousarray(obs, np.float32)
+        B = obs.shape[0]
+        act = np.empty(B, np.int32) if self.discrete else np.empty((B, self.A), np.float32)
+        val = np.empty(B, np.float32)
+        lp = np.empty(B, np.float32)
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, np.float64 if self.discrete else np.float32)
+        self._chk(self.lib.dril_policy_forward(self._h, self._p(obs), B, self._p(noise), self._p(act), self._p(val), self._p(lp)))
+        return act, val, lp
+
+    def evaluate_actions(self, obs: np.ndarray, actions: np.ndarray):
+        obs = np.ascontiguousarray(obs, np.float32)
+        actions = np.ascontiguousarray(actions, np.int32 if self.discrete else np.float32)
+        B = obs.shape[0]
+        val, lp, ent = (np.empty(B, np.float32) for _ in range(3))
+        self._chk(self.lib.dril_evaluate_actions(self._h, self._p(obs), self._p(actions), B, self._p(val), self._p(lp), self._p(ent)))
+        return val, lp, ent
+
+    def predict_values(self, obs: np.ndarray) -> np.ndarray:
+        obs = np.ascontiguousarray(obs, np.float32)
+        val = np.empty(obs.shape[0], np.float32)
+        self._chk(self.lib.dril_predict_values(self._h, self._p(obs), obs.shape[0], self._p(val)))
+        return val
+
+    # rollout
+    def collect_rollout(self) -> float:
+        fps = C.c_double()
+        self._chk(self.lib.dril_collect_rollout(self._h, C.byref(fps)))
+        return fps.value
+
+    def set_noise(self, noise: Optional[np.ndarray]):
+        if noise is None:
+            self._chk(self.lib.dril_debug_set_noise(self._h, None, 0))
+            return
+        noise = np.ascontiguousarray(noise, np.float64 if self.discrete else np.float32)
+        self._chk(self.lib.dril_debug_set_noise(self._h, self._p(noise), noise.size))
+
+    _BUF = {
+        capi.BUF_OBSERVATIONS: ("f4", "ND"), capi.BUF_ACTIONS: (None, "NA"), capi.BUF_REWARDS: ("f4", "N"),
+        capi.BUF_ADVANTAGES: ("f4", "N"), capi.BUF_RETURNS: ("f4", "N"), capi.BUF_LOGPROBS: ("f4", "N"),
+        capi.BUF_VALUES: ("f4", "N"), capi.BUF_FLAGS: ("u1", "N"), capi.BUF_BOOTSTRAP: ("f4", "N"),
+        capi.BUF_LAST_VALUES: ("f4", "E"),
+    }
+
+    def _buf_like(self, which: int) -> np.ndarray:
+        dt, shp = self._BUF[which]
+        if which == capi.BUF_ACTIONS:
+            return np.empty(self.N, np.int32) if self.discrete else np.empty((self.N, self.A), np.float32)
+        shape = {"ND": (self.N, self.D), "N": (self.N,), "E": (self.E,)}[shp]
+        return np.empty(shape, np.dtype(dt))
+
+    def buffer(self, which: int) -> np.ndarray:
+        """time-major copy of one RolloutBuffer field (index n = t*E + e)."""
+        out = self._buf_like(which)
+        self._chk(self.lib.dril_buffer_copy_out(self._h, which, self._p(out), out.nbytes))
+        return out
+
+    def set_buffer(self, which: int, arr: np.ndarray):
+        like = self._buf_like(which)
+        arr = np.ascontiguousarray(arr, like.dtype).reshape(like.shape)
+        self._chk(self.lib.dril_buffer_copy_in(self._h, which, self._p(arr), arr.nbytes))
+
+    def compute_gae(self):
+        self._chk(self.lib.dril_compute_gae(self._h))
+
+    # update
+    def ppo_update(self) -> DrilPPOStats:
+        st = DrilPPOStats()
+        self._chk(self.lib.dril_ppo_update(self._h, C.byref(st)))
+        return st
+
+    def set_permutation(self, perm: Optional[np.ndarray]):
+        if perm is None:
+            self._chk(self.lib.dril_debug_set_permutation(self._h, None, 0))
+            return
+        perm = np.ascontiguousarray(perm, np.int64)
+        self._chk(self.lib.dril_debug_set_permutation(self._h, self._p(perm), perm.size))
+
+    def ppo_loss_grad(self, obs, actions, adv, ret, old_logp, old_val):
+        obs = np.ascontiguousarray(obs, np.float32)
+        actions = np.ascontiguousarray(actions, np.int32 if self.discrete else np.float32)
+        adv, ret, old_logp, old_val = (np.ascontiguousarray(x, np.float32) for x in (adv, ret, old_logp, old_val))
+        loss = C.c_float()
+        stats = np.empty(7, np.float32)
+        grads = np.empty(self.P, np.float32)
+        self._chk(self.lib.dril_ppo_loss_grad(self._h, self._p(obs), self._p(actions), self._p(adv), self._p(ret), self._p(old_logp),
+                                              self._p(old_val), obs.shape[0], C.byref(loss), self._p(stats), self._p(grads)))
+        return loss.value, stats, grads
+
+    def apply_gradients(self, grads: np.ndarray) -> float:
+        grads = np.ascontiguousarray(grads, np.float32)
+        norm = C.c_float()
+        self._chk(self.lib.dril_apply_gradients(self._h, self._p(grads), grads.size, C.byref(norm)))
+        return norm.value
+
+    def train(self, max_steps: int):
+        per_iter = self.N * self.cfg.world_size
+        iters = max_steps // per_iter
+        stats = (DrilPPOStats * max(iters, 1))()
+        fps = (C.c_double * max(iters, 1))()
+        done = C.c_int32()
+        self._chk(self.lib.dril_train(self._h, max_steps, stats, fps, C.byref(done)))
+        return [stats[i] for i in range(done.value)], [fps[i] for i in range(done.value)]
+
+    # multi-GPU
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        rc = self.lib.dril_comm_unique_id(buf)
+        if rc != capi.OK:
+            raise DrilError(rc, (self.lib.dril_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def comm_init(self, uid: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._chk(self.lib.dril_comm_init(self._h, buf))
+
+    # measurement
+    def synchronize(self):
+        self._chk(self.lib.dril_synchronize(self._h))
+
+    def profile(self) -> dict:
+        out = {}
+        for k in range(capi.K_COUNT):
+            ms, n = C.c_double(), C.c_int64()
+            self._chk(self.lib.dril_profile_get(self._h, k, C.byref(ms), C.byref(n)))
+            out[self.lib.dril_kernel_name(k).decode()] = {"total_ms": ms.value, "launches": n.value}
+        return out
+
+    def profile_reset(self):
+        self._chk(self.lib.dril_profile_reset(self._h))
+
+
+# --------------------------------------------------------------------------------------------
+# DeviceParallelEnv <: AbstractParallelEnv (interfaces/environments.jl:21-39)
+# --------------------------------------------------------------------------------------------
+class DeviceParallelEnv:
+    """Device-resident batched simulator standing in for
+    `MultiThreadedParallelEnv([CartPoleEnv() for _ in 1:n_envs])`.  The env verbs keep the reference's
+    contract (auto-reset, `terminal_observation` only on truncation,
+    multithreadedParallelEnv.jl:47-74) with host copy-out, so generic callers keep working; `train_`
+    dispatches to the fused device path."""
+
+    def __init__(self, env, n_envs: int, *, seed: int = 42, fixed_length_episodes: bool = False, device: int = 0,
+                 rank: int = 0, world_size: int = 1, profile_events: bool = False):
+        self.env, self.n_envs, self.seed = env, n_envs, seed
+        self._kw = dict(fixed_length_episodes=fixed_length_episodes, device=device, rank=rank, world_size=world_size,
+                        profile_events=profile_events)
+        self.handle: Optional[Handle] = None
+        self._bound_key = None
+        self._last_term = np.zeros(n_envs, bool)
+        self._last_trunc = np.zeros(n_envs, bool)
+
+    # binding: one handle carries env + agent + alg state; (re)created when the alg/layer shape changes
+    def bind(self, alg: PPO, layer: Optional[ActorCriticLayer] = None) -> Handle:
+        key = (tuple(sorted(asdict(alg).items())), None if layer is None else (tuple(layer.hidden_dims), layer.log_std_init))
+        if self.handle is None or key != self._bound_key:
+            if self.handle is not None:
+                self.handle.close()
+            cfg = make_config(self.env, self.n_envs, alg, layer, seed=self.seed, **self._kw)
+            self.handle = Handle(cfg)
+            self.handle.env_reset(self.seed)  # Random.seed!(env, seed) + reset!(env)
+            self._bound_key = key
+        return self.handle
+
+    def _h(self) -> Handle:
+        return self.handle or self.bind(PPO(n_steps=1, batch_size=self.n_envs * max(1, self._kw["world_size"])))
+
+    def number_of_envs(self) -> int:
+        return self.n_envs
+
+    def observation_space(self):
+        return self.env.observation_space()
+
+    def action_space(self):
+        return self.env.action_space()
+
+    def reset_(self):
+        self._h().env_reset(self.seed)
+
+    def observe(self):
+        """-> list of n_envs observation vectors (multithreadedParallelEnv.jl:19-25)."""
+        return list(self._h().env_observe())
+
+    def act_(self, actions):
+        """-> (rewards, terminateds, truncateds, infos) (multithreadedParallelEnv.jl:47-74)."""
+        rew, term, trunc, tobs = self._h().env_step(np.asarray(actions))
+        infos = [dict() for _ in range(self.n_envs)]
+        for i in np.nonzero(trunc)[0]:
+            infos[i]["terminal_observation"] = tobs[i].copy()
+        self._last_term, self._last_trunc = term, trunc
+        return rew, term, trunc, infos
+
+    def terminated(self):
+        return self._last_term
+
+    def truncated(self):
+        return self._last_trunc
+
+
+# --------------------------------------------------------------------------------------------
+# RolloutBuffer + collect_rollout! (src/buffers/rollout_buffer.jl)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class RolloutBuffer:
+    """Host mirror of RolloutBuffer (buffer_types.jl:3-15).  Arrays are TIME-MAJOR copies of the device
+    buffer (n = t*n_envs + env); `to_reference_order` gives the permutation into the reference's
+    trajectory-major completion order (rollout_buffer.jl:70-80)."""
+    n_steps: int
+    n_envs: int
+    gae_lambda: float
+    gamma: float
+    observations: np.ndarray = None
+    actions: np.ndarray = None
+    rewards: np.ndarray = None
+    advantages: np.ndarray = None
+    returns: np.ndarray = None
+    logprobs: np.ndarray = None
+    values: np.ndarray = None
+    flags: np.ndarray = None
+
+    def __len__(self):
+        return self.n_steps * self.n_envs
+
+    def to_reference_order(self) -> np.ndarray:
+        """order[p] = time-major index of element p of the reference's flat buffer: trajectories are
+        appended when they end, scanning steps then envs (trajectory.jl:46-75)."""
+        E, T = self.n_envs, self.n_steps
+        done = (self.flags.reshape(T, E) != 0)
+        done[T - 1, :] = True
+        order = []
+        start = np.zeros(E, np.int64)
+        for t in range(T):
+            for e in np.nonzero(done[t])[0]:
+                order.extend(range(start[e] * E + e, t * E + e + 1, E))
+                start[e] = t + 1
+        return np.asarray(order, np.int64)
+
+
+def collect_rollout_(buffer: RolloutBuffer, agent: Agent, alg: PPO, env: DeviceParallelEnv):
+    """collect_rollout!(rollout_buffer, agent, alg, env) -> (fps, success), rollout_buffer.jl:46-90."""
+    h = env.bind(alg, agent.layer)
+    h.set_params(flatten_params(agent.train_state.parameters))
+    fps = h.collect_rollout()
+    buffer.observations = h.buffer(capi.BUF_OBSERVATIONS)
+    acts = h.buffer(capi.BUF_ACTIONS)
+    buffer.actions = acts.astype(np.int64) if h.discrete else acts  # eltype(Discrete{Int}) = Int64, spaces.jl:169
+    buffer.rewards = h.buffer(capi.BUF_REWARDS)
+    buffer.advantages = h.buffer(capi.BUF_ADVANTAGES)
+    buffer.returns = h.buffer(capi.BUF_RETURNS)
+    buffer.logprobs = h.buffer(capi.BUF_LOGPROBS)
+    buffer.values = h.buffer(capi.BUF_VALUES)
+    buffer.flags = h.buffer(capi.BUF_FLAGS)
+    return fps, True
+
+
+# --------------------------------------------------------------------------------------------
+# train! (src/algorithms/ppo.jl:100-325)
+# --------------------------------------------------------------------------------------------
+_STAT_KEYS = ("entropy_losses", "policy_losses", "value_losses", "approx_kl_divs", "clip_fractions", "losses",
+              "explained_variances", "fps", "grad_norms", "learning_rates")
+
+
+def train_(agent: Agent, env: DeviceParallelEnv, alg: PPO, max_steps: int, callbacks=None):
+    """train!(agent, env, alg, max_steps) -> (learn_stats, timer).  learn_stats has the reference's keys
+    (ppo.jl:301-312); `timer` holds the TimerOutputs section names (ppo.jl:109,154,167,205-207,239) with
+    wall seconds.  Callbacks with per-step hooks are not routed to the fused path."""
+    if callbacks:
+        raise NotImplementedError("callbacks need the step-granular path (dril_env_step); not wired in this round")
+    timer = {}
+    t0 = time.perf_counter()
+    h = env.bind(alg, agent.layer)
+    h.set_params(flatten_params(agent.train_state.parameters))
+    per_iter = alg.n_steps * env.n_envs * h.cfg.world_size
+    iterations = max_steps // per_iter  # ppo.jl:117
+    timer["setup"] = time.perf_counter() - t0
+    learn_stats = {k: [] for k in _STAT_KEYS}
+    t1 = time.perf_counter()
+    t_roll = t_upd = 0.0
+    for _ in range(iterations):
+        h.set_learning_rate(alg.learning_rate)  # Optimisers.adjust!, ppo.jl:155-156
+        learn_stats["learning_rates"].append(alg.learning_rate)
+        a = time.perf_counter()
+        fps = h.collect_rollout()  # ppo.jl:167
+        b = time.perf_counter()
+        st = h.ppo_update()  # ppo.jl:188-264
+        c = time.perf_counter()
+        t_roll += b - a
+        t_upd += c - b
+        agent.steps_taken += per_iter
+        agent.gradient_updates += st.n_updates
+        learn_stats["fps"].append(fps)
+        learn_stats["entropy_losses"].append(st.entropy_loss)
+        learn_stats["policy_losses"].append(st.policy_loss)
+        learn_stats["value_losses"].append(st.value_loss)
+        learn_stats["approx_kl_divs"].append(st.approx_kl_div)
+        learn_stats["clip_fractions"].append(st.clip_fraction)
+        learn_stats["losses"].append(st.loss)
+        learn_stats["explained_variances"].append(st.explained_variance)
+        learn_stats["grad_norms"].append(st.grad_norm)
+    timer["training_loop"] = time.perf_counter() - t1
+    timer["collect_rollout"] = t_roll
+    timer["epoch loop"] = t_upd
+    agent.train_state.parameters = unflatten_params(h.get_params(), agent.train_state.parameters)
+    return learn_stats, timer
+
+
+def get_action_and_values(agent: Agent, env: DeviceParallelEnv, observations):
+    """get_action_and_values(agent, observations) -> (actions, values, logprobs), agent_methods.jl:19-35."""
+    h = env.bind(agent.alg, agent.layer)
+    h.set_params(flatten_params(agent.train_state.parameters))
+    return h.policy_forward(np.stack(observations))
+
+
+def predict_values(agent: Agent, env: DeviceParallelEnv, observations):
+    """predict_values(agent, observations), agent_methods.jl:49-64."""
+    h = env.bind(agent.alg, agent.layer)
+    h.set_params(flatten_params(agent.train_state.parameters))
+    return h.predict_values(np.stack(observations))

@@ -1,0 +1,250 @@
+/*
+ * dril_hip.h — C ABI of libdril_hip.so: the MI355X (gfx950) implementation of
+ * DRiL.jl's vectorised rollout-collection + PPO-update hot path.
+ *
+ * The reference (KristianHolme/DRiL.jl) is pure Julia and has no FFI; the seam
+ * this library plugs into is Julia dispatch.  Every entry point
+ * below names the reference function it stands in for (paths relative to the
+ * reference checkout).  A Julia `ccall` shim (dril.jl_amd/julia/DRiLHIP.jl) and
+ * a Python ctypes mirror (dril.jl_amd/host.py) both bind exactly these symbols.
+ *
+ * Conventions
+ *   - every function returns int32_t status, 0 == DRIL_OK; no C++ exception
+ *     crosses the ABI; dril_last_error() returns the message of the last failure
+ *   - the library owns all device memory and the handle; the CALLER owns every
+ *     host pointer and must keep it alive for the duration of the call only
+ *   - a handle is not thread-safe; different handles may be used concurrently
+ *   - all calls are synchronous at return (the handle's HIP stream is drained)
+ *     unless documented otherwise
+ *   - arrays use the reference's memory layout: observations (D x n) column-major
+ *     (each observation's D floats contiguous, src/spaces.jl:259), weights
+ *     (out x in) column-major exactly as Lux.Dense stores them
+ *   - the device rollout buffer is TIME-MAJOR: flat index n = t * n_envs + env
+ *     (the reference buffer is trajectory-major in completion order,
+ *     src/buffers/rollout_buffer.jl:70-80; DESIGN.md §3 gives the index map)
+ */
+#ifndef DRIL_HIP_H
+#define DRIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRIL_ABI_VERSION 1u
+
+typedef struct dril_handle dril_handle;
+
+enum dril_status {
+    DRIL_OK = 0,
+    DRIL_ERR_INVALID_ARG = 1,
+    DRIL_ERR_HIP = 2,
+    DRIL_ERR_RCCL = 3,
+    DRIL_ERR_NAN_IN_GRADS = 4, /* mirrors `@assert !nested_has_nan(grads)` src/algorithms/ppo.jl:213-214 */
+    DRIL_ERR_NOT_INITIALISED = 5,
+    DRIL_ERR_UNSUPPORTED = 6
+};
+
+enum dril_env_kind {
+    DRIL_ENV_CARTPOLE = 0, /* CartPole-v1: D=4, Discrete(2)            */
+    DRIL_ENV_PENDULUM = 1  /* Pendulum-v1: D=3, Box(-2,2) 1-dim action */
+};
+
+/* ids for dril_buffer_copy_out / dril_buffer_copy_in (fields of RolloutBuffer,
+ * src/buffers/buffer_types.jl:3-15, plus the per-step flags the reference keeps
+ * in Trajectory, buffer_types.jl:17-26) */
+enum dril_buffer_id {
+    DRIL_BUF_OBSERVATIONS = 0, /* f32  (D, N)                                  */
+    DRIL_BUF_ACTIONS = 1,      /* i32 (1, N) discrete | f32 (A, N) continuous   */
+    DRIL_BUF_REWARDS = 2,      /* f32 (N)                                       */
+    DRIL_BUF_ADVANTAGES = 3,   /* f32 (N)                                       */
+    DRIL_BUF_RETURNS = 4,      /* f32 (N)                                       */
+    DRIL_BUF_LOGPROBS = 5,     /* f32 (N)                                       */
+    DRIL_BUF_VALUES = 6,       /* f32 (N)                                       */
+    DRIL_BUF_FLAGS = 7,        /* u8 (N): bit0 terminated, bit1 truncated       */
+    DRIL_BUF_BOOTSTRAP = 8,    /* f32 (N): V(terminal_observation), valid where truncated */
+    DRIL_BUF_LAST_VALUES = 9   /* f32 (n_envs): V(obs after the last step)      */
+};
+
+/* kernels whose HIP-event timings dril_profile_get reports */
+enum dril_kernel_id {
+    DRIL_K_ROLLOUT = 0,
+    DRIL_K_GAE = 1,
+    DRIL_K_ADV_MOMENTS = 2,
+    DRIL_K_PPO_GRAD = 3,
+    DRIL_K_GRAD_REDUCE = 4,
+    DRIL_K_ADAM = 5,
+    DRIL_K_ALLREDUCE = 6,
+    DRIL_K_COUNT = 7
+};
+
+/* Plain-C mirror of `PPO` (src/algorithms/ppo.jl:25-40), the layer kwargs
+ * (src/layers/layer_constructors.jl:3-11,55-56), `NormalizeWrapperEnv` kwargs
+ * (src/environment_wrappers/normalizeWrapperEnv.jl:71-80) and the env ctor
+ * kwargs used by the reference's benchmarks (benchmark/bench_utils.jl:14,20). */
+typedef struct dril_config {
+    uint32_t abi_version;      /* must be DRIL_ABI_VERSION */
+    int32_t env_kind;          /* enum dril_env_kind */
+    int32_t n_envs;            /* E on THIS rank */
+    int32_t n_steps;           /* T (PPO.n_steps) */
+    int32_t hidden1, hidden2;  /* hidden_dims = [hidden1, hidden2]; multiples of 32 */
+    int32_t episode_len;       /* max_steps kwarg: 500 CartPole-v1, 200 Pendulum-v1 */
+    int32_t fixed_length_episodes; /* 1: termination disabled (synthetic bench episodes) */
+    int32_t action_start;      /* Discrete(n, start): src/spaces.jl:157-164 */
+
+    float gamma, gae_lambda, clip_range;
+    float clip_range_vf;  int32_t has_clip_range_vf;   /* Union{T,Nothing} */
+    float ent_coef, vf_coef;
+    float max_grad_norm;  int32_t has_max_grad_norm;
+    float target_kl;      int32_t has_target_kl;
+    int32_t normalize_advantage;
+    int64_t batch_size;        /* GLOBAL minibatch size B (over all ranks) */
+    int32_t epochs;
+    float learning_rate;
+    float adam_beta1, adam_beta2, adam_eps; /* Optimisers.Adam defaults + eps=1e-5, ppo.jl:64-66 */
+    float log_std_init;
+
+    int32_t norm_obs, norm_reward, norm_training; /* NormalizeWrapperEnv; all 0 = no wrapper */
+    float clip_obs, clip_reward, norm_gamma, norm_epsilon;
+
+    uint64_t seed;             /* env i (0-based, global index) is seeded seed + i, wrapper_utils.jl:39-44 */
+    int32_t device;            /* HIP device ordinal */
+    int32_t rank, world_size;  /* data-parallel position; global env index = rank*n_envs + local */
+    int32_t profile_events;    /* 1: bracket hot kernels with HIP events (dril_profile_get) */
+    int32_t reserved[7];
+} dril_config;
+
+/* per-iteration means returned by dril_ppo_update; field names follow the
+ * `learn_stats` NamedTuple, src/algorithms/ppo.jl:301-312 */
+typedef struct dril_ppo_stats {
+    float entropy_loss, policy_loss, value_loss, approx_kl_div, clip_fraction;
+    float loss, grad_norm, explained_variance, entropy, ratio_first; /* ratio of epoch1/batch1, ppo.jl:209-212 */
+    int32_t n_updates;         /* optimiser steps actually applied */
+    int32_t early_stopped;     /* 1 if target_kl stopped the loops, ppo.jl:235-238 */
+    int32_t nan_or_inf;        /* 1 if a gradient contained NaN/Inf (status is DRIL_ERR_NAN_IN_GRADS too) */
+    int32_t reserved;
+} dril_ppo_stats;
+
+/* fill cfg with the reference defaults: PPO() ppo.jl:26-39, hidden_dims [64,64]
+ * layer_constructors.jl:55, NormalizeWrapperEnv kwargs normalizeWrapperEnv.jl:71-80 (disabled) */
+int32_t dril_config_default(dril_config* cfg, int32_t env_kind);
+
+/* ---- lifetime ------------------------------------------------------------ */
+/* RolloutBuffer(...) ppo.jl:112-115 + Agent(layer, alg) ppo.jl:42-62 (device state only) */
+int32_t dril_create(const dril_config* cfg, dril_handle** out);
+int32_t dril_destroy(dril_handle* h);
+/* message of the last failing call on h (or of the last failing create when h == NULL) */
+const char* dril_last_error(const dril_handle* h);
+/* drains the handle's stream */
+int32_t dril_synchronize(dril_handle* h);
+
+/* ---- shapes ---------------------------------------------------------------*/
+int32_t dril_obs_dim(const dril_handle* h);     /* D  */
+int32_t dril_action_dim(const dril_handle* h);  /* A: n for Discrete, dims for Box */
+int32_t dril_is_discrete(const dril_handle* h);
+int64_t dril_param_count(const dril_handle* h); /* Lux.parameterlength, layer_lux.jl */
+
+/* ---- parameters: agent.train_state.parameters <-> flat f32 -----------------
+ * layout: actor_head {W1(H1xD) b1 W2(H2xH1) b2 W3(AoutxH2) b3}, critic_head {W1 b1 W2 b2 W3(1xH2) b3},
+ * then log_std(A) for Box actions (layer_lux.jl:4-39); every W column-major (out x in) */
+int32_t dril_set_params(dril_handle* h, const float* flat, size_t n);
+int32_t dril_get_params(dril_handle* h, float* flat, size_t n);
+/* fresh optimiser state (load_policy_params_and_state! rebuilds Adam, ppo.jl:77-94) */
+int32_t dril_reset_optimizer(dril_handle* h);
+/* Optimisers.adjust!(train_state, lr) ppo.jl:155-156 */
+int32_t dril_set_learning_rate(dril_handle* h, float lr);
+
+/* ---- env verbs (MultiThreadedParallelEnv, src/environment_wrappers/multithreadedParallelEnv.jl) */
+/* Random.seed!(env, seed) wrapper_utils.jl:39-44 followed by reset!(env) :12-17 */
+int32_t dril_env_reset(dril_handle* h, uint64_t seed);
+/* observe(env) :19-25 (NormalizeWrapperEnv.observe normalizeWrapperEnv.jl:123-137 when enabled:
+ * updates obs statistics when update_stats != 0); host_obs is (D x E) column-major */
+int32_t dril_env_observe(dril_handle* h, float* host_obs, int32_t update_stats);
+/* act!(env, actions) :47-74 with auto-reset; actions i32(E) | f32(A x E) are ENV-space
+ * (already passed through to_env, src/adapters/default_adapters.jl:4-11,34-38);
+ * terminal_obs (D x E) is written only for truncated envs; any out pointer may be NULL */
+int32_t dril_env_step(dril_handle* h, const void* host_actions, float* rewards, uint8_t* terminated,
+                      uint8_t* truncated, float* terminal_obs);
+/* raw simulator state: CartPole (x, x_dot, theta, theta_dot), Pendulum (theta, theta_dot), + step counter */
+int32_t dril_env_get_state(dril_handle* h, float* state /* S x E */, int32_t* step_count /* E */);
+int32_t dril_env_set_state(dril_handle* h, const float* state, const int32_t* step_count);
+/* RunningMeanStd fields, normalizeWrapperEnv.jl:8-19 (save/load :261-297) */
+int32_t dril_norm_get_stats(dril_handle* h, float* obs_mean, float* obs_var, int64_t* obs_count,
+                            float* ret_mean, float* ret_var, int64_t* ret_count);
+int32_t dril_norm_set_stats(dril_handle* h, const float* obs_mean, const float* obs_var, int64_t obs_count,
+                            float ret_mean, float ret_var, int64_t ret_count);
+
+/* ---- policy (src/layers/layer_forward.jl, layer_methods.jl) on host batches -- */
+/* layer(obs, ps, st) -> (actions, values, logprobs): layer_forward.jl:3-13 / :30-39.
+ * noise: f64(B) uniforms for Categorical.rand (categorical.jl:47-52) or f32(A x B) normals for
+ * DiagGaussian.rand (diagGaussian.jl:13-17); NULL = draw from the handle's Philox stream.
+ * actions are the RAW policy actions (pre-adapter, trajectory.jl:48) */
+int32_t dril_policy_forward(dril_handle* h, const float* obs, int64_t batch, const void* noise,
+                            void* actions, float* values, float* logprobs);
+/* evaluate_actions(layer, obs, actions, ps, st): layer_methods.jl:28-55 */
+int32_t dril_evaluate_actions(dril_handle* h, const float* obs, const void* actions, int64_t batch,
+                              float* values, float* logprobs, float* entropy);
+/* predict_values(layer, obs, ps, st): layer_methods.jl:57-61 */
+int32_t dril_predict_values(dril_handle* h, const float* obs, int64_t batch, float* values);
+
+/* ---- rollout --------------------------------------------------------------- */
+/* collect_rollout!(buffer, agent, alg, env): rollout_buffer.jl:46-90 =
+ * collect_trajectories trajectory.jl:22-78 + compute_advantages! :80-102 + returns :87.
+ * fps = steps / wall time of the collection part, rollout_buffer.jl:60-64 */
+int32_t dril_collect_rollout(dril_handle* h, double* fps);
+/* injected sampling noise for the NEXT dril_collect_rollout call only: f64 (E x T) uniforms
+ * [t*E+e] (discrete) or f32 (A x E x T) normals; NULL clears */
+int32_t dril_debug_set_noise(dril_handle* h, const void* noise, size_t count);
+int32_t dril_buffer_copy_out(dril_handle* h, int32_t which, void* host, size_t bytes);
+int32_t dril_buffer_copy_in(dril_handle* h, int32_t which, const void* host, size_t bytes);
+/* compute_advantages! over the device buffer as it stands (rewards/values/flags/bootstrap/last_values) */
+int32_t dril_compute_gae(dril_handle* h);
+/* stand-alone GAE on caller arrays, time-major [t*E+e]; no handle state is used or changed */
+int32_t dril_gae(int32_t n_envs, int32_t n_steps, float gamma, float gae_lambda, const float* rewards,
+                 const float* values, const uint8_t* flags, const float* bootstrap, const float* last_values,
+                 float* advantages, float* returns);
+
+/* ---- PPO update -------------------------------------------------------------- */
+/* the epoch x minibatch loop of train!, ppo.jl:188-264 (DataLoader shuffle, loss :365-407 + gradient,
+ * NaN asserts :213-214, nested_norm/nested_scale! :216-232, target_kl :235-238, Adam :239,
+ * explained_variance :256, per-iteration means :257-264) */
+int32_t dril_ppo_update(dril_handle* h, dril_ppo_stats* out);
+/* injected DataLoader order: perm[e*N + p] = 0-based buffer index at position p of epoch e
+ * (ppo.jl:188-195); NULL = device-generated pseudo-random bijection per epoch */
+int32_t dril_debug_set_permutation(dril_handle* h, const int64_t* perm, size_t count);
+/* (alg::PPO)(layer, ps, st, batch) ppo.jl:365-407 and its gradient (Lux.Training.compute_gradients,
+ * ppo.jl:207) on a caller minibatch; stats7 = policy_loss, value_loss, entropy_loss, clip_fraction,
+ * approx_kl_div, entropy, ratio; grads has dril_param_count entries, same layout as the params.
+ * normalises advantages per ppo.jl:350-363 when cfg.normalize_advantage */
+int32_t dril_ppo_loss_grad(dril_handle* h, const float* obs, const void* actions, const float* advantages,
+                           const float* returns, const float* old_logprobs, const float* old_values,
+                           int64_t batch, float* loss, float* stats7, float* grads);
+/* one optimiser step from caller gradients: nested_norm, nested_scale!, Adam (ppo.jl:216-239);
+ * returns the pre-clip norm */
+int32_t dril_apply_gradients(dril_handle* h, const float* grads, size_t n, float* grad_norm);
+
+/* ---- train! ------------------------------------------------------------------ */
+/* iterations = max_steps / (T*E*world) of {set lr, collect_rollout!, ppo update}: ppo.jl:154-298.
+ * stats / fps arrays need `iterations` entries (may be NULL) */
+int32_t dril_train(dril_handle* h, int64_t max_steps, dril_ppo_stats* stats, double* fps, int32_t* iterations_done);
+
+/* ---- multi-GPU (new; the reference is single-process) ------------------------- */
+/* 128-byte ncclUniqueId from rank 0, distributed to the other ranks by the host */
+int32_t dril_comm_unique_id(uint8_t id[128]);
+/* RCCL communicator over cfg.world_size ranks; gradients and loss statistics are summed with one
+ * ncclAllReduce per optimiser step on the handle's stream */
+int32_t dril_comm_init(dril_handle* h, const uint8_t id[128]);
+
+/* ---- measurement ---------------------------------------------------------------- */
+/* accumulated HIP-event time and launch count of one kernel class since the last reset */
+int32_t dril_profile_get(dril_handle* h, int32_t kernel_id, double* total_ms, int64_t* launches);
+int32_t dril_profile_reset(dril_handle* h);
+const char* dril_kernel_name(int32_t kernel_id);
+const char* dril_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRIL_HIP_H */

@@ -1,0 +1,208 @@
+"""CPU: parts of the path the reference's tests leave UNPINNED — PPO loss/gradient, grad clip,
+Adam, env physics — cross-checked against independent engines: torch-CPU autograd / torch.optim.Adam and a
+float64 numpy restatement of the published Gymnasium equations."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+
+def _nets(flat, D, H, A, discrete):
+    """split the flat parameter vector (include/dril_hip.h layout) into torch tensors (out x in, column-major)"""
+    t = torch.tensor(flat, dtype=torch.float64, requires_grad=True)
+    off = 0
+    out = []
+    for O in (A, 1):
+        net = []
+        for (o, i) in ((H, D), (H, H), (O, H)):
+            W = t[off:off + o * i].reshape(i, o).T; off += o * i
+            b = t[off:off + o]; off += o
+            net.append((W, b))
+        out.append(net)
+    ls = None if discrete else t[off:off + A]
+    return t, out[0], out[1], ls
+
+
+def _mlp(net, x):
+    h = torch.tanh(x @ net[0][0].T + net[0][1])
+    h = torch.tanh(h @ net[1][0].T + net[1][1])
+    return h @ net[2][0].T + net[2][1]
+
+
+def torch_ppo_loss(flat, cfg, obs, actions, adv, ret, old_logp, old_val, discrete, A):
+    """(alg::PPO)(policy, ps, st, batch): src/algorithms/ppo.jl:365-407 written with torch ops (float64)."""
+    D = obs.shape[1]
+    t, actor, critic, ls = _nets(flat, D, cfg.hidden1, A, discrete)
+    x = torch.tensor(obs, dtype=torch.float64)
+    advt = torch.tensor(adv, dtype=torch.float64)
+    if cfg.normalize_advantage:
+        advt = (advt - advt.mean()) / (advt.std(unbiased=True) + 1e-8)      # ppo.jl:350-356
+    out = _mlp(actor, x)
+    values = _mlp(critic, x)[:, 0]
+    if discrete:
+        p = torch.softmax(out, dim=1)
+        a = torch.tensor(actions - cfg.action_start, dtype=torch.long)
+        logp = torch.log(p.gather(1, a[:, None])[:, 0])
+        ent = -(p * torch.log(p)).sum(1)
+    else:
+        xa = torch.tensor(actions, dtype=torch.float64)
+        k = A
+        logp = -0.5 * (2 * ls.sum() + ((xa - out) ** 2 * torch.exp(-2 * ls)).sum(1) + k * math.log(2 * math.pi))
+        ent = (0.5 * k * (1 + math.log(2 * math.pi)) + ls.sum()).expand(x.shape[0])
+    if cfg.has_clip_range_vf:
+        ov = torch.tensor(old_val, dtype=torch.float64)
+        values = ov + torch.clamp(values - ov, -cfg.clip_range_vf, cfg.clip_range_vf)
+    r = torch.exp(logp - torch.tensor(old_logp, dtype=torch.float64))
+    rc = torch.clamp(r, 1 - cfg.clip_range, 1 + cfg.clip_range)
+    p_loss = -torch.minimum(r * advt, rc * advt).mean()
+    ent_loss = -ent.mean()
+    v_loss = ((values - torch.tensor(ret, dtype=torch.float64)) ** 2).mean()
+    loss = p_loss + cfg.ent_coef * ent_loss + cfg.vf_coef * v_loss
+    loss.backward()
+    lr = logp - torch.tensor(old_logp, dtype=torch.float64)
+    stats = [p_loss.item(), v_loss.item(), ent_loss.item(), (r != rc).double().mean().item(),
+             (torch.exp(lr) - 1 - lr).mean().item(), ent.mean().item(), r.mean().item()]
+    return loss.item(), np.array(stats), t.grad.numpy()
+
+
+def make_batch(oracle, cfg, B, seed, discrete, A):
+    """SURVEY.md §8d parity inputs: obs~U(-1,1), uniform actions, adv/ret/old_values~N(0,1), old_logp = eval + N(0, 0.1)"""
+    rng = np.random.default_rng(seed)
+    D = oracle.D
+    obs = rng.uniform(-1, 1, (B, D)).astype(np.float32)
+    actions = (rng.integers(0, A, B) + cfg.action_start).astype(np.int32) if discrete else rng.normal(0, 1, (B, A)).astype(np.float32)
+    adv, ret, old_val = (rng.standard_normal(B).astype(np.float32) for _ in range(3))
+    _, lp, _ = oracle.evaluate_actions(obs, actions)
+    old_logp = (lp + rng.normal(0, 0.1, B)).astype(np.float32)
+    return obs, actions, adv, ret, old_logp, old_val
+
+
+@pytest.mark.parametrize("kind,B,variant", [(0, 64, "default"), (0, 1000, "ent_vfclip"), (1, 64, "default"), (1, 777, "ent_vfclip"), (0, 37, "no_norm")])
+def test_ppo_loss_and_gradient_vs_torch_autograd(oracle_mod, pkg, kind, B, variant):
+    cfg = pkg._capi.default_config(kind); cfg.n_envs, cfg.n_steps = 2, 2
+    if variant == "ent_vfclip":
+        cfg.ent_coef = 0.01; cfg.has_clip_range_vf = 1; cfg.clip_range_vf = 0.3; cfg.clip_range = 0.1
+    if variant == "no_norm":
+        cfg.normalize_advantage = 0
+    o = oracle_mod.Oracle(cfg)
+    rng = np.random.default_rng(100 + B)
+    flat = (rng.standard_normal(o.P) * 0.25).astype(np.float32)
+    o.set_params(flat)
+    batch = make_batch(o, cfg, B, 7 + B, o.discrete, o.A)
+    loss, stats, grads = o.ppo_loss_grad(*batch)
+    tl, ts, tg = torch_ppo_loss(flat, cfg, *batch, o.discrete, o.A)
+    assert loss == pytest.approx(tl, rel=1e-4)                     # BASELINE.json: PPO loss rel-err <= 1e-4
+    np.testing.assert_allclose(stats, ts, rtol=2e-4, atol=2e-6)
+    assert 0.0 < stats[3] < 0.95                                  # a real fraction of ratios is clipped
+    np.testing.assert_allclose(grads, tg, rtol=2e-3, atol=2e-6)
+    assert np.linalg.norm(grads - tg) <= 1e-4 * np.linalg.norm(tg)
+
+
+def test_grad_clip_and_adam_vs_torch(oracle_mod, pkg):
+    """nested_norm / nested_scale! (optimization_utils.jl:74-107) + Adam(eps=1e-5) (ppo.jl:64-66) vs torch.optim.Adam."""
+    cfg = pkg._capi.default_config(0); cfg.n_envs, cfg.n_steps = 2, 2
+    o = oracle_mod.Oracle(cfg)
+    rng = np.random.default_rng(3)
+    flat = (rng.standard_normal(o.P) * 0.2).astype(np.float32)
+    o.set_params(flat)
+    p = torch.tensor(flat.astype(np.float64), requires_grad=True)
+    opt = torch.optim.Adam([p], lr=cfg.learning_rate, betas=(0.9, 0.999), eps=1e-5)
+    for step in range(6):
+        g = (rng.standard_normal(o.P) * (0.02 if step % 2 else 0.001)).astype(np.float32)   # alternately above / below max_grad_norm
+        norm = o.apply_gradients(g)
+        assert norm == pytest.approx(float(np.linalg.norm(g.astype(np.float64))), rel=1e-5)
+        gt = torch.tensor(g.astype(np.float64))
+        if norm > cfg.max_grad_norm:
+            gt = gt * (cfg.max_grad_norm / norm)
+        p.grad = gt
+        opt.step()
+        np.testing.assert_allclose(o.get_params(), p.detach().numpy(), rtol=1e-5, atol=2e-7)
+    g = np.zeros(o.P, np.float32); g[5] = np.nan
+    o.apply_gradients(g)
+    assert o.last_rc == pkg._capi.ERR_NAN_IN_GRADS                  # @assert !nested_has_nan(grads), ppo.jl:213
+
+
+def _cartpole_f64(s, a):
+    """Gymnasium CartPole-v1 step (Euler), float64"""
+    x, xd, th, thd = s
+    force = 10.0 if a == 1 else -10.0
+    c, sn = math.cos(th), math.sin(th)
+    temp = (force + 0.05 * thd * thd * sn) / 1.1
+    thacc = (9.8 * sn - c * temp) / (0.5 * (4.0 / 3.0 - 0.1 * c * c / 1.1))
+    xacc = temp - 0.05 * thacc * c / 1.1
+    return np.array([x + 0.02 * xd, xd + 0.02 * xacc, th + 0.02 * thd, thd + 0.02 * thacc])
+
+
+def _pendulum_f64(s, u):
+    th, thd = s
+    u = min(max(u, -2.0), 2.0)
+    an = ((th + math.pi) % (2 * math.pi)) - math.pi
+    cost = an * an + 0.1 * thd * thd + 0.001 * u * u
+    nthd = min(max(thd + (3 * 10.0 / 2 * math.sin(th) + 3.0 * u) * 0.05, -8.0), 8.0)
+    return np.array([th + nthd * 0.05, nthd]), -cost
+
+
+def test_env_physics_vs_gymnasium_equations(oracle_mod, pkg):
+    """physics parity is unpinned by the reference: check the published equations."""
+    capi = pkg._capi
+    cfg = capi.default_config(0); cfg.n_envs, cfg.n_steps, cfg.episode_len = 16, 4, 500
+    o = oracle_mod.Oracle(cfg); o.env_reset(5)
+    st, _ = o.env_get_state()
+    assert np.all(np.abs(st) <= 0.05)                               # reset ~ U(-0.05, 0.05)^4
+    rng = np.random.default_rng(0)
+    for _ in range(30):
+        a = rng.integers(0, 2, cfg.n_envs).astype(np.int32)
+        prev, _ = o.env_get_state()
+        rew, term, trunc, _ = o.env_step(a + cfg.action_start)
+        cur, sc = o.env_get_state()
+        for e in range(cfg.n_envs):
+            exp = _cartpole_f64(prev[e].astype(np.float64), a[e])
+            t_exp = abs(exp[0]) > 2.4 or abs(exp[2]) > 12 * 2 * math.pi / 360
+            assert bool(term[e]) == t_exp and rew[e] == 1.0
+            if not term[e]:
+                np.testing.assert_allclose(cur[e], exp, rtol=1e-5, atol=1e-6)
+            else:
+                assert np.all(np.abs(cur[e]) <= 0.05) and sc[e] == 0    # auto-reset, multithreadedParallelEnv.jl:68-70
+    cfg = capi.default_config(1); cfg.n_envs, cfg.n_steps, cfg.episode_len = 8, 4, 5
+    o = oracle_mod.Oracle(cfg); o.env_reset(9)
+    st, _ = o.env_get_state()
+    assert np.all(np.abs(st[:, 0]) <= math.pi + 1e-6) and np.all(np.abs(st[:, 1]) <= 1.0)
+    for step in range(1, 8):
+        u = rng.uniform(-3, 3, (cfg.n_envs, 1)).astype(np.float32)
+        prev, _ = o.env_get_state()
+        rew, term, trunc, tobs = o.env_step(u)
+        cur, _ = o.env_get_state()
+        assert not term.any() and trunc.all() == (step % 5 == 0)
+        for e in range(cfg.n_envs):
+            exp, r = _pendulum_f64(prev[e].astype(np.float64), float(u[e, 0]))
+            assert rew[e] == pytest.approx(r, rel=1e-5, abs=1e-5)
+            if trunc[e]:    # terminal_observation only on truncation (multithreadedParallelEnv.jl:64-66)
+                np.testing.assert_allclose(tobs[e], [math.cos(exp[0]), math.sin(exp[0]), exp[1]], rtol=1e-5, atol=1e-5)
+            else:
+                np.testing.assert_allclose(cur[e], exp, rtol=1e-5, atol=1e-5)
+
+
+def test_update_loop_control_flow(oracle_mod, pkg):
+    """ppo.jl:205-254: partial last batch kept, target_kl early stop skips the apply and both loops."""
+    capi = pkg._capi
+    cfg = capi.default_config(0); cfg.n_envs, cfg.n_steps, cfg.batch_size, cfg.epochs, cfg.episode_len = 5, 14, 16, 3, 6
+    o = oracle_mod.Oracle(cfg)
+    o.set_params((np.random.default_rng(0).standard_normal(o.P) * 0.3).astype(np.float32))
+    o.env_reset(1); o.collect_rollout()
+    st = o.ppo_update()
+    assert st.n_updates == 3 * math.ceil(70 / 16) and not st.early_stopped     # ceil(N/B) minibatches per epoch
+    assert np.isfinite([st.loss, st.grad_norm, st.explained_variance, st.approx_kl_div]).all()
+    # a 1-sample trailing minibatch makes std(adv) NaN (ppo.jl:350-356, Julia std of one element) -> the NaN assert fires (:213)
+    cfg1 = capi.default_config(0); cfg1.n_envs, cfg1.n_steps, cfg1.batch_size, cfg1.epochs, cfg1.episode_len = 5, 13, 16, 1, 6
+    o1 = oracle_mod.Oracle(cfg1)
+    o1.set_params((np.random.default_rng(0).standard_normal(o1.P) * 0.3).astype(np.float32))
+    o1.env_reset(1); o1.collect_rollout()
+    st1 = o1.ppo_update()
+    assert o1.last_rc == capi.ERR_NAN_IN_GRADS and st1.nan_or_inf and st1.n_updates == 4
+    cfg.has_target_kl = 1; cfg.target_kl = 1e-9
+    o2 = oracle_mod.Oracle(cfg)
+    p0 = (np.random.default_rng(0).standard_normal(o2.P) * 0.3).astype(np.float32)
+    o2.set_params(p0); o2.env_reset(1); o2.collect_rollout()
+    st2 = o2.ppo_update()
+    assert st2.early_stopped and st2.n_updates <= 1                            # first batch has ratio == 1 -> kl == 0 -> one apply, then stop
