@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of one full PPO iteration (rollout + GAE + epochs x minibatches update) on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with
+torch.distributed.run (one rank per GPU).  A "step" = one PPO iteration of BASELINE.json configs[1]:
+CartPole-v1, n_envs = 65 536 per GPU, hidden [64,64], PPO defaults, n_steps = 2048, synthetic fixed-length
+episodes (termination disabled, truncation every 500 steps), batch_size = N/32 (BASELINE.json leaves it open;
+SURVEY.md §8d) — all state resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+N > 1: envs are sharded (weak scaling, 65 536 per GPU), the only data-path collective is the RCCL all-reduce of
+[gradients | loss sums] per optimiser step (+ the 3-double advantage-moment reduce), issued inside the library
+on its own stream.  torch.distributed (gloo) is used only for rendezvous, the barrier and the max-over-ranks.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as g  # noqa: E402
+
+FLOP_FWD = 17_792            # 2*(4*64+64*64+64*2 + 4*64+64*64+64*1)
+FLOP_FWD_BWD = 3 * FLOP_FWD  # a16: backward ~ 2x forward
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(pkg, seed: int) -> dict:
+    """The CPU oracle (a C restatement of the reference algorithm, OpenMP over envs/samples like the reference's
+    @threads) timed on this box's host cores on a bounded sample of the same workload.  kind = "port": the real
+    reference is Julia and cannot run here."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+    capi = pkg._capi
+    E, T = 65536, 4
+    cfg = capi.default_config(capi.ENV_CARTPOLE)
+    cfg.n_envs, cfg.n_steps, cfg.episode_len, cfg.fixed_length_episodes = E, T, 500, 1
+    cfg.batch_size, cfg.epochs, cfg.seed = E * T // 2, 1, seed
+    o = oracle_lib.Oracle(cfg)
+    layer = pkg.ActorCriticLayer(pkg.CartPoleEnv().observation_space(), pkg.CartPoleEnv().action_space())
+    o.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(seed))))
+    o.env_reset(seed)
+    t0 = time.perf_counter(); o.collect_rollout(); t1 = time.perf_counter()
+    o.ppo_update(); t2 = time.perf_counter()
+    per_step_roll = (t1 - t0) / (E * T)
+    per_sample_epoch = (t2 - t1) / (E * T)
+    epochs = 10
+    value = 1.0 / (per_step_roll + epochs * per_sample_epoch)
+    return {"value": value, "unit": "env-steps/s", "cores": int(oracle_lib.lib().orc_num_threads()), "kind": "port",
+            "sample": f"C/OpenMP oracle: rollout of {T} steps x {E} envs ({t1 - t0:.2f}s) + 1 PPO epoch over those {E * T} samples in 2 minibatches "
+                      f"({t2 - t1:.2f}s); extrapolated to 1 rollout step + {epochs} epochs per env-step",
+            "rollout_only": 1.0 / per_step_roll}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-envs", type=int, default=65536)
+    ap.add_argument("--n-steps", type=int, default=2048)
+    ap.add_argument("--minibatches", type=int, default=32, help="optimiser steps per epoch; batch_size = N / this")
+    ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    pkg = g.load_package()           # loads libdril_hip.so first (binds /opt/rocm's HIP runtime); no CPU fallback exists
+    capi = pkg._capi
+    capi.load_library()
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # rendezvous / barrier only; never touches torch.cuda
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    E, T = args.n_envs, args.n_steps
+    N_local = E * T
+    B_global = (N_local // args.minibatches) * world
+    env = pkg.CartPoleEnv(max_steps=500)
+    alg = pkg.PPO(n_steps=T, batch_size=B_global, epochs=args.epochs)
+    layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space())
+    cfg = pkg.make_config(env, E, alg, layer, seed=42, fixed_length_episodes=True, device=local_rank, rank=rank, world_size=world,
+                          profile_events=not args.no_events)
+    h = pkg.Handle(cfg)
+    h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(42))))   # random-init weights of the named architecture
+    if world > 1:
+        uid = [h.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        h.comm_init(uid[0])
+    h.env_reset(42)
+
+    def iteration():
+        h.set_learning_rate(alg.learning_rate)
+        h.lib.dril_collect_rollout(h._h, None)      # no fps query: keeps the iteration free of host syncs until the update's end
+        return h.ppo_update()
+
+    for _ in range(args.warmup):
+        iteration()
+    h.synchronize(); h.profile_reset()
+    if dist: dist.barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = iteration()
+    h.synchronize()
+    if dist: dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    prof = h.profile()
+
+    if rank == 0:
+        total_env_steps = N_local * world * args.steps
+        value = total_env_steps / dt
+        out = {
+            "metric": "env-steps/s (rollout+PPO update) at n_envs=65536", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CartPole-v1 configs[1]: device-resident envs, ActorCritic hidden_dims=[64,64], PPO rollout + update",
+                       "n_envs_per_gpu": E, "n_steps": T, "epochs": args.epochs, "batch_size": B_global,
+                       "optimizer_steps_per_iteration": args.epochs * (-(-N_local * world // B_global)),
+                       "episodes": "fixed length 500 (termination disabled)", "parallelism": f"dp{world} (env shards)"},
+            "loss_last": last.loss, "n_updates_last": last.n_updates,
+        }
+        gk = prof.get("ppo_grad_kernel", {"total_ms": 0, "launches": 0})
+        if gk["launches"]:
+            # dominant kernel: ppo_grad_kernel. ALGORITHMIC flops per launch = B_local samples x 53 376 (fwd + bwd of both MLPs,
+            # SURVEY.md §8 a16); duration = HIP events on the library's stream around each launch in the timed region.
+            avg_ms = gk["total_ms"] / gk["launches"]
+            flops = (B_global // world) * FLOP_FWD_BWD
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            traffic = None
+            pmc = ROOT / "profiles" / "r01_ppo_grad_pmc.json"
+            if pmc.exists():
+                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                               "traffic": traffic, "kernel": "ppo_grad_kernel", "avg_launch_ms": avg_ms, "launches": gk["launches"],
+                               "flops_per_launch": flops}
+            out["kernel_ms_per_step"] = {k: v["total_ms"] / args.steps for k, v in prof.items() if v["launches"]}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pkg, 42)
+        print(json.dumps(out), flush=True)
+    h.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,22 @@ _lib = None
 _P = C.c_void_p
 
 
+def host_threads() -> int:
+    """threads the oracle may use: the CPU share of the box (cgroup quota / affinity), capped at 16 — a GPU box
+    reports 256 logical CPUs but grants one GPU's job about 16 of them; ORACLE_THREADS overrides."""
+    import os
+    if os.environ.get("ORACLE_THREADS"):
+        return max(1, int(os.environ["ORACLE_THREADS"]))
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def ensure_built():
     src = ROOT / "oracle" / "dril_oracle.c"
     if not SO.exists() or SO.stat().st_mtime < src.stat().st_mtime:
@@ -77,6 +93,8 @@ def lib() -> C.CDLL:
         L.orc_norm_get_stats.argtypes = [_P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         L.orc_destroy.argtypes = [_P]
         L.orc_reset_optimizer.argtypes = [_P]
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads(host_threads())
         _lib = L
     return _lib
 

@@ -1,0 +1,324 @@
+"""GPU (-m gpu): the HIP path through the C ABI vs the CPU oracle on the same seeded inputs, the committed golden
+vectors, and size-independent properties at larger sizes.  Tolerances are fp32 (reference arithmetic is Float32):
+  GAE returns            atol 1e-4   (the reference's own test tolerance, test/test_gae.jl:66,70)
+  forward values/logp    atol/rtol 1e-5 scale (test/test_buffers.jl:166-214 uses 1e-5)
+  PPO loss               rel 1e-4    (BASELINE.json north_star)
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).parent / "golden"
+
+
+def _cfg(pkg, kind, **kw):
+    c = pkg._capi.default_config(kind)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _params(P, seed, scale=0.3):
+    return (np.random.default_rng(seed).standard_normal(P) * scale).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def lib(hip):
+    return hip
+
+
+@pytest.mark.parametrize("case", json.loads((G / "gae.json").read_text()), ids=lambda c: c["name"])
+def test_gae_golden_on_device(pkg, lib, case):
+    """the reference's analytic GAE tests (test/test_gae.jl, test/test_buffers.jl:60-115) through dril_gae"""
+    import ctypes as C
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    E, T = case["n_envs"], case["n_steps"]
+    f32 = lambda k: np.asarray(case[k], np.float32)
+    r, v, b, lv = f32("rewards"), f32("values"), f32("bootstrap"), f32("last_values")
+    fl = np.asarray(case["flags"], np.uint8)
+    adv = np.zeros(E * T, np.float32); ret = np.zeros(E * T, np.float32)
+    assert lib.dril_gae(E, T, case["gamma"], case["gae_lambda"], p(r), p(v), p(fl), p(b), p(lv), p(adv), p(ret)) == 0
+    np.testing.assert_allclose(adv, case["expected_advantages"], atol=case["atol"], rtol=0)
+    np.testing.assert_allclose(ret, case["expected_returns"], atol=case["atol"], rtol=0)
+
+
+def test_gae_random_vs_oracle(pkg, lib, oracle_mod):
+    import ctypes as C
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(0)
+    for E, T in ((1, 1), (3, 7), (257, 33), (1000, 129)):   # ragged: not multiples of the wave / unroll factor
+        r = rng.standard_normal(E * T).astype(np.float32); v = rng.standard_normal(E * T).astype(np.float32)
+        fl = rng.choice([0, 0, 0, 0, 1, 2, 3], E * T).astype(np.uint8)
+        b = rng.standard_normal(E * T).astype(np.float32); lv = rng.standard_normal(E).astype(np.float32)
+        out = [np.zeros(E * T, np.float32) for _ in range(4)]
+        assert lib.dril_gae(E, T, 0.99, 0.95, p(r), p(v), p(fl), p(b), p(lv), p(out[0]), p(out[1])) == 0
+        assert oracle_mod.lib().orc_gae(E, T, 0.99, 0.95, p(r), p(v), p(fl), p(b), p(lv), p(out[2]), p(out[3])) == 0
+        np.testing.assert_allclose(out[0], out[2], atol=1e-4, rtol=1e-5)
+        np.testing.assert_allclose(out[1], out[3], atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_env_verbs_match_oracle(pkg, oracle_mod, kind):
+    """reset!/observe/act! with auto-reset and terminal_observation (multithreadedParallelEnv.jl:12-74)"""
+    cfg = _cfg(pkg, kind, n_envs=300, n_steps=4, episode_len=7, batch_size=4)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    h.env_reset(123); o.env_reset(123)
+    np.testing.assert_array_equal(h.env_get_state()[0], o.env_get_state()[0])       # Philox reset noise is bit-exact
+    rng = np.random.default_rng(1)
+    for step in range(20):
+        np.testing.assert_allclose(h.env_observe(), o.env_observe(), atol=2e-6, rtol=2e-6)
+        a = (rng.integers(0, 2, cfg.n_envs) + cfg.action_start).astype(np.int32) if kind == 0 else rng.uniform(-3, 3, (cfg.n_envs, 1)).astype(np.float32)
+        rh, th, uh, oh = h.env_step(a); ro, to, uo, oo = o.env_step(a)
+        np.testing.assert_array_equal(th, to); np.testing.assert_array_equal(uh, uo)
+        np.testing.assert_allclose(rh, ro, atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(oh[uh], oo[uo], atol=1e-5, rtol=1e-5)              # terminal_observation only where truncated
+        sh, ch = h.env_get_state(); so, co = o.env_get_state()
+        np.testing.assert_array_equal(ch, co)
+        np.testing.assert_allclose(sh, so, atol=1e-5, rtol=1e-5)
+        o.env_set_state(sh, ch)                                                       # teacher forcing: no drift accumulation
+    assert uh.any() or step < 6
+
+
+@pytest.mark.parametrize("kind,B", [(0, 1), (0, 31), (0, 32), (0, 1000), (1, 65), (1, 4096)])
+def test_policy_forward_evaluate_predict(pkg, oracle_mod, kind, B):
+    """layer(obs,ps,st), evaluate_actions, predict_values (layer_forward.jl:3-39, layer_methods.jl:28-61)"""
+    cfg = _cfg(pkg, kind, n_envs=2, n_steps=2, batch_size=2)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 5 + B, 0.5); h.set_params(flat); o.set_params(flat)
+    np.testing.assert_array_equal(h.get_params(), flat)
+    rng = np.random.default_rng(B)
+    obs = rng.uniform(-2, 2, (B, h.D)).astype(np.float32)
+    noise = rng.random(B) if kind == 0 else rng.standard_normal((B, h.A)).astype(np.float32)
+    ah, vh, lh = h.policy_forward(obs, noise); ao, vo, lo = o.policy_forward(obs, noise)
+    np.testing.assert_allclose(vh, vo, atol=2e-5, rtol=2e-5)
+    if kind == 0:
+        same = ah == ao
+        assert same.mean() >= 0.999                       # an action may flip only when u sits within fp32 rounding of the CDF
+        np.testing.assert_allclose(lh[same], lo[same], atol=2e-5, rtol=2e-5)
+        assert set(np.unique(ah)) <= {cfg.action_start, cfg.action_start + 1}
+    else:
+        np.testing.assert_allclose(ah, ao, atol=2e-5, rtol=2e-5)
+        np.testing.assert_allclose(lh, lo, atol=1e-4, rtol=1e-4)
+    ve, le, ee = h.evaluate_actions(obs, ao); vo2, lo2, eo2 = o.evaluate_actions(obs, ao)
+    np.testing.assert_allclose(ve, vo2, atol=2e-5, rtol=2e-5)
+    np.testing.assert_allclose(le, lo2, atol=1e-4 if kind else 2e-5, rtol=1e-4)
+    np.testing.assert_allclose(ee, eo2, atol=2e-5, rtol=2e-5)
+    np.testing.assert_allclose(h.predict_values(obs), vo, atol=2e-5, rtol=2e-5)
+    # forward vs evaluate self-consistency, test/test_policies.jl:127-145
+    np.testing.assert_allclose(h.evaluate_actions(obs, ah)[1], lh, atol=1e-5, rtol=1e-5)
+
+
+def _rollout_pair(pkg, oracle_mod, kind, E, T, L, seed, fixed=False):
+    cfg = _cfg(pkg, kind, n_envs=E, n_steps=T, episode_len=L, batch_size=max(2, (E * T) // 4), epochs=2, fixed_length_episodes=int(fixed))
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, seed, 0.4); h.set_params(flat); o.set_params(flat)
+    h.env_reset(seed); o.env_reset(seed)
+    return cfg, h, o
+
+
+@pytest.mark.parametrize("kind,E,T,L,fixed", [(0, 64, 48, 500, False), (0, 100, 40, 9, True), (1, 33, 50, 12, False), (0, 1, 5, 3, False)])
+def test_collect_rollout_matches_oracle(pkg, oracle_mod, kind, E, T, L, fixed):
+    """collect_rollout! (rollout_buffer.jl:46-90): every buffer field vs the trajectory-based oracle, with injected
+    sampling noise and with the shared Philox stream; includes terminations, mid-rollout truncations with
+    V(terminal_observation) bootstraps and rollout-limited tails (trajectory.jl:52-74)."""
+    capi = pkg._capi
+    for inject in (True, False):
+        cfg, h, o = _rollout_pair(pkg, oracle_mod, kind, E, T, L, seed=17 + E, fixed=fixed)
+        if inject:
+            rng = np.random.default_rng(E)
+            noise = rng.random(E * T) if kind == 0 else rng.standard_normal((E * T, h.A)).astype(np.float32)
+            h.set_noise(noise); o.set_noise(noise)
+        for rollout in range(2):                       # the env is NOT reset between rollouts (trajectory.jl:26)
+            fps = h.collect_rollout(); o.collect_rollout()
+            assert fps > 0
+            ah, ao = h.buffer(capi.BUF_ACTIONS).reshape(T, E, -1), o.buffer(capi.BUF_ACTIONS).reshape(T, E, -1)
+            if kind == 0:
+                ok = np.cumprod((ah == ao).all(axis=2), axis=0).astype(bool)     # env matches up to its first action flip
+                assert ok.all(axis=0).mean() >= 0.98
+            else:
+                ok = np.ones((T, E), bool)
+            for which, tol in ((capi.BUF_OBSERVATIONS, 2e-5), (capi.BUF_VALUES, 5e-5), (capi.BUF_LOGPROBS, 1e-4), (capi.BUF_REWARDS, 1e-4),
+                               (capi.BUF_ADVANTAGES, 1e-3), (capi.BUF_RETURNS, 1e-3)):
+                a, b = h.buffer(which), o.buffer(which)
+                a, b = a.reshape(T, E, -1), b.reshape(T, E, -1)
+                full = ok.all(axis=0)                   # GAE looks ahead, so compare whole envs that never diverged
+                np.testing.assert_allclose(a[:, full], b[:, full], atol=tol, rtol=tol)
+            fh, fo = h.buffer(capi.BUF_FLAGS).reshape(T, E), o.buffer(capi.BUF_FLAGS).reshape(T, E)
+            full = ok.all(axis=0)
+            np.testing.assert_array_equal(fh[:, full], fo[:, full])
+            tr = (fo & 2).astype(bool) & full[None, :]
+            np.testing.assert_allclose(h.buffer(capi.BUF_BOOTSTRAP).reshape(T, E)[tr], o.buffer(capi.BUF_BOOTSTRAP).reshape(T, E)[tr], atol=5e-5, rtol=5e-5)
+            np.testing.assert_allclose(h.buffer(capi.BUF_LAST_VALUES)[full], o.buffer(capi.BUF_LAST_VALUES)[full], atol=5e-5, rtol=5e-5)
+            np.testing.assert_allclose(h.buffer(capi.BUF_RETURNS), h.buffer(capi.BUF_ADVANTAGES) + h.buffer(capi.BUF_VALUES), atol=1e-5)
+            if not inject:
+                break
+            # keep the two simulators in lock-step for the second rollout
+            st, sc = h.env_get_state(); o.env_set_state(st, sc)
+        if L < T:
+            assert (fh & 2).any()
+    # stored logprobs/values == evaluate_actions recomputed on device (test/test_buffers.jl:166-214)
+    val, lp, ent = h.evaluate_actions(h.buffer(capi.BUF_OBSERVATIONS), h.buffer(capi.BUF_ACTIONS))
+    np.testing.assert_allclose(val, h.buffer(capi.BUF_VALUES), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(lp, h.buffer(capi.BUF_LOGPROBS), atol=1e-5, rtol=1e-5)
+
+
+def _batch(oracle, cfg, B, seed):
+    rng = np.random.default_rng(seed)
+    obs = rng.uniform(-1, 1, (B, oracle.D)).astype(np.float32)
+    act = (rng.integers(0, oracle.A, B) + cfg.action_start).astype(np.int32) if oracle.discrete else rng.normal(0, 1, (B, oracle.A)).astype(np.float32)
+    adv, ret, ov = (rng.standard_normal(B).astype(np.float32) for _ in range(3))
+    _, lp, _ = oracle.evaluate_actions(obs, act)
+    return obs, act, adv, ret, (lp + rng.normal(0, 0.1, B)).astype(np.float32), ov
+
+
+@pytest.mark.parametrize("kind,B,variant", [(0, 64, "default"), (0, 33, "default"), (0, 4096, "ent_vfclip"), (0, 65536, "default"),
+                                             (1, 64, "default"), (1, 1000, "ent_vfclip"), (0, 200, "no_norm")])
+def test_ppo_loss_and_gradient(pkg, oracle_mod, kind, B, variant):
+    """(alg::PPO)(...) ppo.jl:365-407 + gradient: loss within 1e-4 rel (north_star), gradient within fp32 noise"""
+    kw = dict(n_envs=2, n_steps=2, batch_size=2)
+    if variant == "ent_vfclip":
+        kw.update(ent_coef=0.01, has_clip_range_vf=1, clip_range_vf=0.3, clip_range=0.1)
+    if variant == "no_norm":
+        kw.update(normalize_advantage=0)
+    cfg = _cfg(pkg, kind, **kw)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    for seed in range(2):
+        flat = _params(h.P, 40 + seed, 0.25); h.set_params(flat); o.set_params(flat)
+        batch = _batch(o, cfg, B, seed)
+        lh, sh, gh = h.ppo_loss_grad(*batch); lo, so, go = o.ppo_loss_grad(*batch)
+        assert lh == pytest.approx(lo, rel=1e-4)
+        np.testing.assert_allclose(sh, so, rtol=2e-4, atol=2e-6)
+        assert np.linalg.norm(gh - go) <= 2e-4 * np.linalg.norm(go)
+        np.testing.assert_allclose(gh, go, rtol=5e-3, atol=1e-5 * np.abs(go).max())
+        lh2, _, gh2 = h.ppo_loss_grad(*batch)
+        assert lh2 == lh and np.array_equal(gh, gh2)                     # slab reduction is bitwise reproducible
+
+
+def test_apply_gradients_clip_adam_nan(pkg, oracle_mod):
+    """nested_norm / nested_scale! / Adam (ppo.jl:216-239) incl. the NaN assert (:213-214)"""
+    cfg = _cfg(pkg, 0, n_envs=2, n_steps=2, batch_size=2)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 9, 0.2); h.set_params(flat); o.set_params(flat)
+    rng = np.random.default_rng(3)
+    for step in range(7):
+        g = (rng.standard_normal(h.P) * (0.02 if step % 2 else 0.001)).astype(np.float32)
+        nh, no = h.apply_gradients(g), o.apply_gradients(g)
+        assert nh == pytest.approx(no, rel=1e-5)
+        np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=1e-5, atol=2e-7)
+    before = h.get_params()
+    g = np.zeros(h.P, np.float32); g[17] = np.inf
+    with pytest.raises(pkg.DrilError) as e:
+        h.apply_gradients(g)
+    assert e.value.code == pkg._capi.ERR_NAN_IN_GRADS
+    np.testing.assert_array_equal(h.get_params(), before)               # a poisoned step is never applied
+    h.reset_optimizer(); o.reset_optimizer()
+    g = (rng.standard_normal(h.P) * 0.01).astype(np.float32)
+    o.set_params(before); h.apply_gradients(g); o.apply_gradients(g)
+    np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=1e-5, atol=2e-7)
+
+
+@pytest.mark.parametrize("kind,E,T,B,kw", [
+    (0, 16, 24, 64, {}),
+    (0, 10, 13, 16, {}),                                   # N = 130: ragged last minibatch of 2 kept (MLUtils partial=true)
+    (1, 12, 20, 60, {"ent_coef": 0.01}),
+    (0, 16, 24, 96, {"has_target_kl": 1, "target_kl": 0.002}),
+    (0, 16, 24, 384, {"has_clip_range_vf": 1, "clip_range_vf": 0.2}),
+])
+def test_ppo_update_matches_oracle(pkg, oracle_mod, kind, E, T, B, kw):
+    """the epoch x minibatch loop (ppo.jl:188-264) on identical buffers and an injected DataLoader order:
+    parameters after the update, per-iteration stats, KL early stop"""
+    capi = pkg._capi
+    cfg = _cfg(pkg, kind, n_envs=E, n_steps=T, batch_size=B, epochs=3, episode_len=11, **kw)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 77, 0.3); h.set_params(flat); o.set_params(flat)
+    o.env_reset(5); o.collect_rollout()
+    for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+        h.set_buffer(which, o.buffer(which))
+    N = E * T
+    perm = np.stack([np.random.default_rng(e).permutation(N) for e in range(cfg.epochs)]).astype(np.int64)
+    h.set_permutation(perm); o.set_permutation(perm)
+    sh, so = h.ppo_update(), o.ppo_update()
+    assert (sh.n_updates, sh.early_stopped) == (so.n_updates, so.early_stopped)
+    if "has_target_kl" in kw:
+        assert sh.early_stopped and sh.n_updates < cfg.epochs * -(-N // B)
+    for f in ("policy_loss", "value_loss", "entropy_loss", "approx_kl_div", "clip_fraction", "loss", "grad_norm", "explained_variance", "ratio_first"):
+        assert getattr(sh, f) == pytest.approx(getattr(so, f), rel=5e-4, abs=2e-6), f
+    assert sh.loss == pytest.approx(so.loss, rel=1e-4)
+    np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=2e-4, atol=3e-6)
+    if B == 16:                                              # appendix item 5: a 1-sample minibatch -> NaN assert, like the reference
+        cfg1 = _cfg(pkg, 0, n_envs=5, n_steps=13, batch_size=16, epochs=1, episode_len=11)
+        h1, o1 = pkg.Handle(cfg1), oracle_mod.Oracle(cfg1)
+        h1.set_params(flat); o1.set_params(flat); o1.env_reset(5); o1.collect_rollout()
+        for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+            h1.set_buffer(which, o1.buffer(which))
+        p1 = np.arange(65, dtype=np.int64)[None, :]
+        h1.set_permutation(p1)
+        with pytest.raises(pkg.DrilError) as e:
+            h1.ppo_update()
+        assert e.value.code == capi.ERR_NAN_IN_GRADS
+
+
+def test_device_permutation_matches_oracle_and_train_end_to_end(pkg, oracle_mod):
+    """train! (ppo.jl:100-325) for 3 iterations with the device-generated DataLoader order and Philox sampling:
+    the oracle draws the same streams, so parameters and learn_stats agree to fp32 noise on a small problem"""
+    cfg = _cfg(pkg, 0, n_envs=32, n_steps=16, batch_size=128, epochs=2, episode_len=500, seed=4)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 1, 0.05); h.set_params(flat); o.set_params(flat)   # small logits: p ~ 0.5, flips are measure-zero
+    h.env_reset(cfg.seed); o.env_reset(cfg.seed)
+    sh, fh = h.train(3 * 32 * 16 + 5); so, _ = o.train(3 * 32 * 16 + 5)  # remainder steps are dropped (ppo.jl:117)
+    assert len(sh) == len(so) == 3 and all(f > 0 for f in fh)
+    for a, b in zip(sh, so):
+        assert a.n_updates == b.n_updates == 2 * 4
+        assert a.loss == pytest.approx(b.loss, rel=2e-3, abs=1e-5)
+        assert a.explained_variance == pytest.approx(b.explained_variance, rel=2e-3, abs=1e-4)
+    np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=2e-3, atol=2e-5)
+
+
+def test_large_size_properties(pkg):
+    """BASELINE-size invariants that need no oracle: reproducibility, returns = adv + values, flags pattern of
+    fixed-length episodes, finite stats, parameters move."""
+    capi = pkg._capi
+    cfg = _cfg(pkg, 0, n_envs=65536, n_steps=64, episode_len=25, fixed_length_episodes=1, batch_size=65536 * 64 // 8, epochs=1)
+    flat = _params(9155, 3, 0.3)
+    outs = []
+    for rep in range(2):
+        h = pkg.Handle(cfg); h.set_params(flat); h.env_reset(42)
+        h.collect_rollout()
+        outs.append((h.buffer(capi.BUF_ADVANTAGES), h.buffer(capi.BUF_ACTIONS)))
+        if rep == 0:
+            fl = h.buffer(capi.BUF_FLAGS).reshape(64, 65536)
+            expect = np.zeros(64, np.uint8); expect[24::25] = 2
+            assert (fl == expect[:, None]).all()                          # every env truncates at steps 25, 50 (synthetic fixed-length episodes)
+            np.testing.assert_allclose(h.buffer(capi.BUF_RETURNS), h.buffer(capi.BUF_ADVANTAGES) + h.buffer(capi.BUF_VALUES), atol=1e-5)
+            assert (h.buffer(capi.BUF_REWARDS) == 1.0).all()
+            st = h.ppo_update()
+            assert st.n_updates == 8 and np.isfinite([st.loss, st.grad_norm, st.explained_variance]).all()
+            assert st.ratio_first == pytest.approx(1.0, abs=1e-5)        # first minibatch of the first epoch: ratio == 1 (ppo.jl:209-212)
+            assert not np.array_equal(h.get_params(), flat)
+        h.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_host_mirror_train(pkg):
+    """the reference-shaped API end to end: Agent / ActorCriticLayer / PPO / DeviceParallelEnv / train_ / collect_rollout_"""
+    env = pkg.DeviceParallelEnv(pkg.CartPoleEnv(), 64, seed=1)
+    alg = pkg.PPO(n_steps=32, batch_size=256, epochs=2)
+    layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space())
+    agent = pkg.Agent(layer, alg, seed=3)
+    p0 = pkg.flatten_params(agent.train_state.parameters)
+    obs = env.observe()
+    assert len(obs) == 64 and obs[0].shape == (4,)
+    rew, term, trunc, infos = env.act_(np.full(64, 1, np.int32))
+    assert rew.shape == (64,) and not trunc.any() and all(i == {} for i in infos)
+    stats, timer = pkg.train_(agent, env, alg, 3 * 64 * 32)
+    assert set(stats) == {"entropy_losses", "policy_losses", "value_losses", "approx_kl_divs", "clip_fractions", "losses",
+                          "explained_variances", "fps", "grad_norms", "learning_rates"}          # ppo.jl:301-312
+    assert all(len(v) == 3 for v in stats.values()) and {"setup", "training_loop", "collect_rollout"} <= set(timer)
+    assert not np.array_equal(pkg.flatten_params(agent.train_state.parameters), p0)
+    buf = pkg.RolloutBuffer(alg.n_steps, 64, alg.gae_lambda, alg.gamma)
+    fps, ok = pkg.collect_rollout_(buf, agent, alg, env)
+    assert ok and buf.observations.shape == (64 * 32, 4) and buf.actions.dtype == np.int64
+    assert np.array_equal(np.sort(buf.to_reference_order()), np.arange(64 * 32))
