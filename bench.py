@@ -38,10 +38,10 @@ def cpu_baseline(pkg, seed: int) -> dict:
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib
     capi = pkg._capi
-    E, T = 65536, 4
+    E, T, EP = 65536, 96, 2
     cfg = capi.default_config(capi.ENV_CARTPOLE)
     cfg.n_envs, cfg.n_steps, cfg.episode_len, cfg.fixed_length_episodes = E, T, 500, 1
-    cfg.batch_size, cfg.epochs, cfg.seed = E * T // 2, 1, seed
+    cfg.batch_size, cfg.epochs, cfg.seed = E * T // 2, EP, seed
     o = oracle_lib.Oracle(cfg)
     layer = pkg.ActorCriticLayer(pkg.CartPoleEnv().observation_space(), pkg.CartPoleEnv().action_space())
     o.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(seed))))
@@ -49,11 +49,11 @@ def cpu_baseline(pkg, seed: int) -> dict:
     t0 = time.perf_counter(); o.collect_rollout(); t1 = time.perf_counter()
     o.ppo_update(); t2 = time.perf_counter()
     per_step_roll = (t1 - t0) / (E * T)
-    per_sample_epoch = (t2 - t1) / (E * T)
+    per_sample_epoch = (t2 - t1) / (E * T * EP)
     epochs = 10
     value = 1.0 / (per_step_roll + epochs * per_sample_epoch)
     return {"value": value, "unit": "env-steps/s", "cores": int(oracle_lib.lib().orc_num_threads()), "kind": "port",
-            "sample": f"C/OpenMP oracle: rollout of {T} steps x {E} envs ({t1 - t0:.2f}s) + 1 PPO epoch over those {E * T} samples in 2 minibatches "
+            "sample": f"C/OpenMP oracle: rollout of {T} steps x {E} envs ({t1 - t0:.2f}s) + {EP} PPO epochs over those {E * T} samples in 2 minibatches each "
                       f"({t2 - t1:.2f}s); extrapolated to 1 rollout step + {epochs} epochs per env-step",
             "rollout_only": 1.0 / per_step_roll}
 

@@ -263,7 +263,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     const size_t E = cfg->n_envs, N = (size_t)h->N, P = h->P;
     CCHK(dmalloc(&h->params, P)); CCHK(dmalloc(&h->adam_m, P)); CCHK(dmalloc(&h->adam_v, P)); CCHK(dmalloc(&h->bt, 4));
     CCHK(dmalloc(&h->flat, P + 8)); CCHK(dmalloc(&h->norm_out, 1));
-    h->n_norm_partials = (int)((P + 255) / 256); CCHK(dmalloc(&h->norm_partials, h->n_norm_partials));
+    h->n_norm_partials = (int)((P + 31) / 32); CCHK(dmalloc(&h->norm_partials, h->n_norm_partials));
     h->slab_a = slab_size_actor(cfg->env_kind, cfg->hidden1); h->slab_c = slab_size_critic(cfg->env_kind, cfg->hidden1);
     h->Gmax = h->num_cus / 2 > 0 ? h->num_cus / 2 : 1;
     CCHK(dmalloc(&h->slabs_a, (size_t)h->Gmax * h->slab_a)); CCHK(dmalloc(&h->slabs_c, (size_t)h->Gmax * h->slab_c));

@@ -74,20 +74,15 @@ __host__ inline int perm_bits(int64_t n) { int b = 1; while (((int64_t)1 << b) <
 // ---------------------------------------------------------------------------------------------
 // math
 // ---------------------------------------------------------------------------------------------
-// tanh with <= ~2e-7 absolute error: odd polynomial near 0, 1 - 2/(e^{2x}+1) elsewhere
-// (v_exp_f32 + v_rcp_f32 are 1-ulp units).  The reference applies Julia's tanh inside Lux.Dense
-// (layer_helpers.jl:33-56).
+// tanh(x) = 1 - 2 / (e^{2x} + 1) on the 1-ulp hardware units (v_exp_f32, v_rcp_f32): 5 VALU instructions,
+// absolute error <= ~2e-7 over the whole line (exp2 overflow -> rcp(inf) = 0 -> 1; underflow -> 1 - 2 = -1).
+// The first version (odd polynomial near 0 + correctly rounded division) cost ~20 instructions and was 55 %
+// of the VALU work of ppo_grad_kernel (profiles/r01_v1_*).  The reference applies Julia's tanh inside
+// Lux.Dense (layer_helpers.jl:33-56); activations only enter the outputs through O(1) weights, so absolute
+// error is what matters for the 1e-4 loss tolerance.
 __device__ __forceinline__ float tanh_f32(float x) {
-    const float ax = fabsf(x);
-    const float x2 = x * x;
-    // Taylor/minimax-ish odd series good to 1e-7 for |x| < 0.3
-    float p = fmaf(x2, 0.021869488536155203f, -0.05396825396825397f);   // 62/2835, -17/315
-    p = fmaf(x2, p, 0.13333333333333333f);                               // 2/15
-    p = fmaf(x2, p, -0.3333333333333333f);                               // -1/3
-    const float small = fmaf(x * x2, p, x);
-    const float e = __expf(2.0f * ax);                                    // exp2-based, 1 ulp
-    const float big = copysignf(1.0f - 2.0f * __frcp_rn(e + 1.0f), x);
-    return ax < 0.3f ? small : big;
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // e^{2x} = 2^{2x log2(e)}
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
 // ---------------------------------------------------------------------------------------------

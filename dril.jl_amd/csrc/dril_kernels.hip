@@ -366,12 +366,12 @@ __global__ void adv_moments_kernel(MomentsArgs a) {
     if (threadIdx.x == 0) { a.partials[2 * blockIdx.x] = s; a.partials[2 * blockIdx.x + 1] = q; }
 }
 __global__ void moments_finalize_kernel(const double* partials, int nblocks, double* out3, double n_local, const int* stop_flag) {
+    __shared__ double sh[16];
     if (*stop_flag) return;
-    if (threadIdx.x == 0) {
-        double s = 0, q = 0;
-        for (int i = 0; i < nblocks; ++i) { s += partials[2 * i]; q += partials[2 * i + 1]; }
-        out3[0] = s; out3[1] = q; out3[2] = n_local;
-    }
+    double s = 0, q = 0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { s += partials[2 * i]; q += partials[2 * i + 1]; }   // fixed order per thread
+    s = block_sum_f64(s, sh); q = block_sum_f64(q, sh);
+    if (threadIdx.x == 0) { out3[0] = s; out3[1] = q; out3[2] = n_local; }
 }
 
 // =============================================================================================
@@ -385,6 +385,36 @@ __global__ void moments_finalize_kernel(const double* partials, int nblocks, dou
 // fixed order, so the result is bitwise reproducible and no float atomics are used.
 // =============================================================================================
 enum { HEAD_CATEGORICAL = 0, HEAD_GAUSSIAN = 1, HEAD_VALUE = 2 };
+
+// one lane's share of a minibatch tile (DataLoader gather, ppo.jl:188-195).  Loaded one tile AHEAD of its use so the
+// random-gather latency (~2 us under load, fully exposed in v1: 23 % of wave time in s_waitcnt) hides under the
+// previous tile's MFMAs; the loop body issues no other vector-memory op, so the loads stay in flight until first use.
+template <int O> struct TileIn { float xk[2]; float s0, s1; int act; float xa[O]; bool valid; };
+
+template <int KIND, int O, int HEAD>
+__device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64_t ntiles, int c, int h, TileIn<O>& t) {
+    constexpr int D = EnvSpec<KIND>::D;
+    const bool live = tile < ntiles;
+    const int64_t i = (live ? tile : ntiles - 1) * kTile + c;
+    const bool inb = live && i < a.count;
+    const int64_t p = a.pos0 + (inb ? i : 0);
+    const int64_t gidx = a.perm ? a.perm[p] : (a.perm_bits ? perm_index(p, a.N, a.perm_key, a.perm_bits) : p);   // bits 0 = identity order
+    const int64_t li = gidx - a.idx_lo;
+    t.valid = inb && li >= 0 && li < a.n_local;
+    const int64_t idx = t.valid ? li : 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; t.xk[s] = d < D ? a.obs[idx * D + d] : 0.f; }
+    t.act = 0; t.s0 = 0.f; t.s1 = 0.f;
+    if (HEAD == HEAD_VALUE) { t.s0 = a.ret[idx]; t.s1 = a.has_clip_vf ? a.val_old[idx] : 0.f; }
+    else {
+        t.s0 = a.adv[idx]; t.s1 = a.logp_old[idx];
+        if (HEAD == HEAD_CATEGORICAL) t.act = ((const int32_t*)a.actions)[idx] - a.action_start;
+        else {
+#pragma unroll
+            for (int o = 0; o < O; ++o) t.xa[o] = ((const float*)a.actions)[idx * O + o];
+        }
+    }
+}
 
 template <int KIND, int H, int O, int HEAD>
 __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
@@ -438,28 +468,24 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
 
     const int g = blockIdx.x >> 1;
     const int64_t ntiles = (a.count + kTile - 1) / kTile;
-    for (int64_t tile = (int64_t)g * 4 + wave; tile < ntiles; tile += (int64_t)a.G * 4) {
-        // ---- gather one tile of the minibatch (DataLoader, ppo.jl:188-195) ----
-        const int64_t i = tile * kTile + c;
-        const bool inb = i < a.count;
-        const int64_t p = a.pos0 + (inb ? i : 0);
-        const int64_t gidx = a.perm ? a.perm[p] : (a.perm_bits ? perm_index(p, a.N, a.perm_key, a.perm_bits) : p);   // bits 0 = identity order
-        const int64_t li = gidx - a.idx_lo;
-        const bool valid = inb && li >= 0 && li < a.n_local;
-        const int64_t idx = valid ? li : 0;
-        float xk[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; xk[s] = d < D ? a.obs[idx * D + d] : 0.f; }
+    const int64_t tstride = (int64_t)a.G * 4;
+    TileIn<O> cur, nxt;
+    int64_t tile = (int64_t)g * 4 + wave;
+    if (tile < ntiles) load_tile<KIND, O, HEAD>(a, tile, ntiles, c, h, cur);
+    for (; tile < ntiles; tile += tstride) {
+        load_tile<KIND, O, HEAD>(a, tile + tstride, ntiles, c, h, nxt);      // prefetch the next tile's gathers
+        const bool valid = cur.valid;
+        float xk[2] = {cur.xk[0], cur.xk[1]};
         // ---- forward ----
         f32x16 h1[MT], h2[MT];
         float out[O], dz[O];
         net_forward<D, H, H, O>(wl, xk, h1, h2, out, lane);
         // ---- loss head (ppo.jl:377-404) and dLoss/dout ----
         if (HEAD == HEAD_VALUE) {
-            const float R = a.ret[idx];
+            const float R = cur.s0;
             float value = out[0]; bool vpass = true;
             if (a.has_clip_vf) {                                              // clip_range, ppo.jl:344-346,378
-                const float ov = a.val_old[idx], d = value - ov;
+                const float ov = cur.s1, d = value - ov;
                 vpass = d >= -a.clip_range_vf && d <= a.clip_range_vf;
                 value = ov + fminf(fmaxf(d, -a.clip_range_vf), a.clip_range_vf);
             }
@@ -467,20 +493,20 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
             dz[0] = (valid && vpass) ? a.invB * a.vf_coef * 2.0f * ve : 0.f;
             if (valid && h == 0) st[0] += ve * ve;                            // value_loss numerator, ppo.jl:385
         } else {
-            const float advn = (a.adv[idx] - adv_mean) / adv_den;
-            const float olp = a.logp_old[idx];
+            const float advn = (cur.s0 - adv_mean) / adv_den;
+            const float olp = cur.s1;
             float logp, ent;
             float p[O];
             int act = 0;
             float xa[O];
             if (HEAD == HEAD_CATEGORICAL) {
                 softmax_n<O>(out, p);
-                act = ((const int32_t*)a.actions)[idx] - a.action_start;
+                act = cur.act;
                 logp = logf(pick<O>(p, act));
                 ent = categorical_entropy<O>(p);
             } else {
 #pragma unroll
-                for (int o = 0; o < O; ++o) xa[o] = ((const float*)a.actions)[idx * O + o];
+                for (int o = 0; o < O; ++o) xa[o] = cur.xa[o];
                 logp = gauss_logpdf<O>(xa, out, ls);
                 ent = gauss_entropy<O>(ls);
             }
@@ -573,6 +599,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
                 dW1[mi] = mfma_outer(Az, Bx, dW1[mi]);
             }
         }
+        cur = nxt;
     }
 
     // ---- epilogue: 4 waves -> one slab (fixed wave order => deterministic) ----
@@ -635,19 +662,30 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_kernel(GradArgs a) {
 //   0 sum(-min term)  1 sum(entropy)  2 sum(clipped)  3 sum(kl)  4 sum(ratio)  5 sum((V-R)^2)  6 n_samples  7 unused
 // =============================================================================================
 __global__ void grad_reduce_kernel(ReduceArgs a) {
+    // block = 32 parameters x 8 slab groups: coalesced 128-byte rows per group, fixed summation order => deterministic
     __shared__ double sh[16];
+    __shared__ float part[8][33];
     if (*a.stop_flag) return;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    float gsum = 0.f;
+    const int pl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int p = blockIdx.x * 32 + pl;
+    float acc = 0.f;
     if (p < a.P) {
         const float* base; int stride, offp;
         if (p < a.Pa) { base = a.slabs_actor; stride = a.slab_a; offp = p; }
         else if (p < a.Pa + a.Pc) { base = a.slabs_critic; stride = a.slab_c; offp = p - a.Pa; }
         else { base = a.slabs_actor; stride = a.slab_a; offp = a.Pa + (p - a.Pa - a.Pc); }   // log_std grads sit after the actor net
-        for (int g = 0; g < a.G; ++g) gsum += base[(size_t)g * stride + offp];
-        a.flat[p] = gsum;
+#pragma unroll 4
+        for (int g = grp; g < a.G; g += 8) acc += base[(size_t)g * stride + offp];
     }
-    const double q = block_sum_f64((double)gsum * (double)gsum, sh);
+    part[grp][pl] = acc;
+    __syncthreads();
+    float gsum = 0.f;
+    if (grp == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gsum += part[k][pl];
+        if (p < a.P) a.flat[p] = gsum;
+    }
+    const double q = block_sum_f64(grp == 0 ? (double)gsum * (double)gsum : 0.0, sh);
     if (threadIdx.x == 0) a.norm_partials[blockIdx.x] = q;
     if (blockIdx.x == 0 && threadIdx.x < 8) {
         const int k = threadIdx.x; double s = 0;
@@ -660,8 +698,8 @@ __global__ void grad_reduce_kernel(ReduceArgs a) {
 __global__ void grad_norm_kernel(const float* flat, int P, double* norm_partials, const int* stop_flag) {
     __shared__ double sh[16];
     if (*stop_flag) return;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const float g = p < P ? flat[p] : 0.f;
+    const int p = blockIdx.x * 32 + (threadIdx.x & 31);          // same 32-parameter blocking as grad_reduce_kernel
+    const float g = (p < P && threadIdx.x < 32) ? flat[p] : 0.f;
     const double q = block_sum_f64((double)g * (double)g, sh);
     if (threadIdx.x == 0) norm_partials[blockIdx.x] = q;
 }
@@ -800,7 +838,7 @@ hipError_t launch_adv_moments(const MomentsArgs& a, int nblocks, hipStream_t s) 
     return hipGetLastError();
 }
 hipError_t launch_moments_finalize(const double* partials, int nblocks, double* out3, double n_local, const int* stop_flag, hipStream_t s) {
-    moments_finalize_kernel<<<1, 64, 0, s>>>(partials, nblocks, out3, n_local, stop_flag);
+    moments_finalize_kernel<<<1, 256, 0, s>>>(partials, nblocks, out3, n_local, stop_flag);
     return hipGetLastError();
 }
 
@@ -818,11 +856,11 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
 }
 
 hipError_t launch_grad_reduce(const ReduceArgs& a, hipStream_t s) {
-    grad_reduce_kernel<<<(a.P + 255) / 256, 256, 0, s>>>(a);
+    grad_reduce_kernel<<<(a.P + 31) / 32, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 hipError_t launch_grad_norm(const float* flat, int P, double* norm_partials, const int* stop_flag, hipStream_t s) {
-    grad_norm_kernel<<<(P + 255) / 256, 256, 0, s>>>(flat, P, norm_partials, stop_flag);
+    grad_norm_kernel<<<(P + 31) / 32, 256, 0, s>>>(flat, P, norm_partials, stop_flag);
     return hipGetLastError();
 }
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s) {

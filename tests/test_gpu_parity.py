@@ -68,6 +68,7 @@ def test_env_verbs_match_oracle(pkg, oracle_mod, kind):
     h.env_reset(123); o.env_reset(123)
     np.testing.assert_array_equal(h.env_get_state()[0], o.env_get_state()[0])       # Philox reset noise is bit-exact
     rng = np.random.default_rng(1)
+    saw_trunc = False
     for step in range(20):
         np.testing.assert_allclose(h.env_observe(), o.env_observe(), atol=2e-6, rtol=2e-6)
         a = (rng.integers(0, 2, cfg.n_envs) + cfg.action_start).astype(np.int32) if kind == 0 else rng.uniform(-3, 3, (cfg.n_envs, 1)).astype(np.float32)
@@ -79,7 +80,8 @@ def test_env_verbs_match_oracle(pkg, oracle_mod, kind):
         np.testing.assert_array_equal(ch, co)
         np.testing.assert_allclose(sh, so, atol=1e-5, rtol=1e-5)
         o.env_set_state(sh, ch)                                                       # teacher forcing: no drift accumulation
-    assert uh.any() or step < 6
+        saw_trunc |= bool(uh.any())
+    assert saw_trunc
 
 
 @pytest.mark.parametrize("kind,B", [(0, 1), (0, 31), (0, 32), (0, 1000), (1, 65), (1, 4096)])
@@ -151,7 +153,8 @@ def test_collect_rollout_matches_oracle(pkg, oracle_mod, kind, E, T, L, fixed):
             np.testing.assert_array_equal(fh[:, full], fo[:, full])
             tr = (fo & 2).astype(bool) & full[None, :]
             np.testing.assert_allclose(h.buffer(capi.BUF_BOOTSTRAP).reshape(T, E)[tr], o.buffer(capi.BUF_BOOTSTRAP).reshape(T, E)[tr], atol=5e-5, rtol=5e-5)
-            np.testing.assert_allclose(h.buffer(capi.BUF_LAST_VALUES)[full], o.buffer(capi.BUF_LAST_VALUES)[full], atol=5e-5, rtol=5e-5)
+            live = full & (fo[T - 1] == 0)                # V(new_obs) is only consumed for rollout-limited tails (trajectory.jl:65-70)
+            np.testing.assert_allclose(h.buffer(capi.BUF_LAST_VALUES)[live], o.buffer(capi.BUF_LAST_VALUES)[live], atol=5e-5, rtol=5e-5)
             np.testing.assert_allclose(h.buffer(capi.BUF_RETURNS), h.buffer(capi.BUF_ADVANTAGES) + h.buffer(capi.BUF_VALUES), atol=1e-5)
             if not inject:
                 break
