@@ -265,7 +265,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(dmalloc(&h->flat, P + 8)); CCHK(dmalloc(&h->norm_out, 1));
     h->n_norm_partials = (int)((P + 31) / 32); CCHK(dmalloc(&h->norm_partials, h->n_norm_partials));
     h->slab_a = slab_size_actor(cfg->env_kind, cfg->hidden1); h->slab_c = slab_size_critic(cfg->env_kind, cfg->hidden1);
-    h->Gmax = h->num_cus / 2 > 0 ? h->num_cus / 2 : 1;
+    h->Gmax = h->num_cus;   // 2 workgroups per CU (one actor + one critic), 4 waves each => 2 waves per SIMD
     CCHK(dmalloc(&h->slabs_a, (size_t)h->Gmax * h->slab_a)); CCHK(dmalloc(&h->slabs_c, (size_t)h->Gmax * h->slab_c));
     CCHK(dmalloc(&h->state, E * h->S)); CCHK(dmalloc(&h->step_count, E)); CCHK(dmalloc(&h->episode, E)); CCHK(dmalloc(&h->gstep, E));
     CCHK(dmalloc(&h->disc_returns, E));

@@ -228,6 +228,45 @@ __device__ __forceinline__ void dense_mfma(const float* __restrict__ Wimg, int W
     }
 }
 
+// one output m-tile of Y = W * X (+bias): lets callers consume/retire tiles one at a time (shorter live ranges)
+template <int KI, bool BIAS>
+__device__ __forceinline__ f32x16 dense_mfma_tile(const float* __restrict__ Wimg, int WS, const float* __restrict__ bias,
+                                                  const f32x16 (&X)[KI], int mo, int lane) {
+    const int o = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (BIAS) b = *reinterpret_cast<const f32x4*>(bias + 32 * mo + 8 * q + 4 * h);
+        acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+    }
+    const float* wrow = Wimg + (32 * mo + o) * WS + 4 * h;
+#pragma unroll
+    for (int mi = 0; mi < KI; ++mi) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(wrow + 32 * mi + 8 * q);
+            acc = mfma32(a[0], X[mi][4 * q + 0], acc);
+            acc = mfma32(a[1], X[mi][4 * q + 1], acc);
+            acc = mfma32(a[2], X[mi][4 * q + 2], acc);
+            acc = mfma32(a[3], X[mi][4 * q + 3], acc);
+        }
+    }
+    return acc;
+}
+
+// v_mfma_f32_16x16x4_f32: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15], C/D col = lane&15, row = 4*(lane>>4) + reg
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// 8 values of row `row` of a [rows][kTS] image for the 16x16x4 contraction over the 32 samples of a tile:
+// lane group g = lane>>4 owns samples 8g..8g+7, k-step s pairs samples {s, 8+s, 16+s, 24+s}
+__device__ __forceinline__ void load_row8(const float* img, int row, int lane, float (&v)[8]) {
+    const float* p = img + row * kTS + 8 * (lane >> 4);
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(p), t1 = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = t0[0]; v[1] = t0[1]; v[2] = t0[2]; v[3] = t0[3]; v[4] = t1[0]; v[5] = t1[1]; v[6] = t1[2]; v[7] = t1[3];
+}
+
 // first layer: K = DP = 4 -> two k-steps; xk[s] = obs[2s + (lane>>5)] of sample (lane&31)
 template <int H1, int MO>
 __device__ __forceinline__ void dense_first(const float* __restrict__ W1T, const float* __restrict__ bias,

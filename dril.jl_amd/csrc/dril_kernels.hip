@@ -416,20 +416,31 @@ __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64
     }
 }
 
+// per-wave LDS scratch of grad_body (floats): one [H][kTS] transpose image reused in turn for h2, h1, dz2, dz1,
+// the [D+2][kTS] first-layer input image (rows 0..D-1 = x, row D = 1 for the bias column, row D+1 = 0) and the [O][kTS]
+// dLoss/dout image.  2 workgroups (4 waves each) per CU => 2 waves per SIMD, so one wave's VALU/LDS phases overlap the
+// other's MFMAs; that needs <= 256 registers and <= 80 KB LDS per workgroup.
+template <int D, int H, int O> struct GradScratch {
+    static constexpr int T = 0;
+    static constexpr int XI = T + H * kTS;
+    static constexpr int ZI = XI + (D + 2) * kTS;
+    static constexpr int SIZE = ZI + O * kTS;
+};
+
 template <int KIND, int H, int O, int HEAD>
 __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
     constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
     using L = NetLds<D, H, H, O>;
-    constexpr int SCR = 2 * H * kTS + 8 * kTS;                // per-wave scratch: two [H][kTS] images + [8][kTS] x image
+    using SC = GradScratch<D, H, O>;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
     float* wl = smem;
-    float* T0 = smem + L::BWD_END + wave * SCR;               // h1 image
-    float* T1 = T0 + H * kTS;                                 // dz2 image, then dz1 image
-    float* XI = T1 + H * kTS;                                 // [8][kTS]: rows 0..D-1 = x, row D = 1, rest 0
+    float* T = smem + L::BWD_END + wave * SC::SIZE + SC::T;
+    float* XI = smem + L::BWD_END + wave * SC::SIZE + SC::XI;
+    float* ZI = smem + L::BWD_END + wave * SC::SIZE + SC::ZI;
     stage_net<D, H, H, O, true>(wl, a.params, off, tid, blockDim.x);
-    for (int i = lane; i < 8 * kTS; i += 64) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
+    for (int i = lane; i < (D + 2) * kTS; i += 64) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
     __syncthreads();
 
     // advantage normalisation constants (ppo.jl:350-356): mean, corrected std, eps added to the std
@@ -443,13 +454,14 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
     }
     const float* ls = a.params + a.log_std_off;
 
-    f32x16 dW2[MT][MT], dW1[MT], dW3p[O][MT];
-    float db2p[MT], db3p[O], dlsp[O], st[5];
+    f32x16 dW2[MT][MT];
+    f32x4 dW1[H / 16];                                             // 16x16x4 tiles: rows = hidden, cols = [x | 1 | 0...]
+    float dW3a[O][MT], db2p[MT], db3p[O], dlsp[O], st[5];
+#pragma unroll
+    for (int i = 0; i < H / 16; ++i) dW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         db2p[i] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dW1[i][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < MT; ++j)
 #pragma unroll
@@ -459,9 +471,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
     for (int o = 0; o < O; ++o) {
         db3p[o] = 0.f; dlsp[o] = 0.f;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dW3p[o][m][r] = 0.f;
+        for (int m = 0; m < MT; ++m) dW3a[o][m] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) st[i] = 0.f;
@@ -479,7 +489,16 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
         // ---- forward ----
         f32x16 h1[MT], h2[MT];
         float out[O], dz[O];
-        net_forward<D, H, H, O>(wl, xk, h1, h2, out, lane);
+        dense_first<H, MT>(wl + L::W1T, wl + L::B1, xk, h1, lane);
+        tanh_tiles(h1);
+#pragma unroll
+        for (int mo = 0; mo < MT; ++mo) {
+            h2[mo] = dense_mfma_tile<MT, true>(wl + L::W2S, L::WS1, wl + L::B2, h1, mo, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h2[mo][r] = tanh_f32(h2[mo][r]);
+        }
+        dense_out<MT, O, H>(wl + L::W3S, wl + L::B3, h2, out, lane);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- loss head (ppo.jl:377-404) and dLoss/dout ----
         if (HEAD == HEAD_VALUE) {
             const float R = cur.s0;
@@ -536,13 +555,35 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
                 st[3] += (r - 1.0f) - lr; st[4] += r;                           // :393,:402
             }
         }
-        // ---- backward: output layer on the VALU ----
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- output layer backward: dW3 += dz * h2' over samples (h2 read back transposed: hidden on the lane) ----
 #pragma unroll
-        for (int o = 0; o < O; ++o) {
-            if (h == 0) db3p[o] += dz[o];
+        for (int o = 0; o < O; ++o) { if (h == 0) { db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
+        store_image<MT>(T, h2, lane);
+        {
+            f32x16 Bh2[MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) dW3p[o][m] += dz[o] * h2[m];
+            for (int mj = 0; mj < MT; ++mj) Bh2[mj] = load_operand(T, mj, lane);
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                float acc[MT];
+#pragma unroll
+                for (int mj = 0; mj < MT; ++mj) acc[mj] = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 z = *reinterpret_cast<const f32x4*>(ZI + o * kTS + 16 * h + 4 * q);   // broadcast within the half-wave
+#pragma unroll
+                    for (int mj = 0; mj < MT; ++mj) {
+                        acc[mj] = fmaf(Bh2[mj][4 * q + 0], z[0], acc[mj]); acc[mj] = fmaf(Bh2[mj][4 * q + 1], z[1], acc[mj]);
+                        acc[mj] = fmaf(Bh2[mj][4 * q + 2], z[2], acc[mj]); acc[mj] = fmaf(Bh2[mj][4 * q + 3], z[3], acc[mj]);
+                    }
+                }
+#pragma unroll
+                for (int mj = 0; mj < MT; ++mj) dW3a[o][mj] += acc[mj];
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dz2 = (W3' dz) .* (1 - h2^2), in h2's registers ----
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -555,50 +596,52 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
                     for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(w[cc], dz[o], dh[cc]);
                 }
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { const float hv = h2[m][4 * q + cc]; h2[m][4 * q + cc] = dh[cc] * (1.0f - hv * hv); }  // dz2
+                for (int cc = 0; cc < 4; ++cc) { const float hv = h2[m][4 * q + cc]; h2[m][4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
             }
-        // ---- transposed images for the sample contractions ----
-        store_image<MT>(T0, h1, lane);
-        store_image<MT>(T1, h2, lane);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) XI[d * kTS + c] = xk[s]; }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- h1 image (the LDS unit executes a wave's accesses in order, so the Bh2 reads above precede these writes) ----
+        store_image<MT>(T, h1, lane);
         // ---- dh1 = W2' dz2 ; dz1 = dh1 .* (1 - h1^2) ----
         f32x16 g1[MT];
-        dense_mfma<MT, MT, false>(wl + L::W2T, L::WS2, nullptr, h2, g1, lane);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+            g1[m] = dense_mfma_tile<MT, false>(wl + L::W2T, L::WS2, nullptr, h2, m, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) g1[m][r] = g1[m][r] * (1.0f - h1[m][r] * h1[m][r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- dW2 += dz2 * h1' ; db2 += rowsum(dz2) ----
         {
             f32x16 Bh[MT];
 #pragma unroll
-            for (int mj = 0; mj < MT; ++mj) Bh[mj] = load_operand(T0, mj, lane);
+            for (int mj = 0; mj < MT; ++mj) Bh[mj] = load_operand(T, mj, lane);
+            store_image<MT>(T, h2, lane);                                      // dz2 image
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
-                const f32x16 Az = load_operand(T1, mi, lane);
+                const f32x16 Az = load_operand(T, mi, lane);
                 db2p[mi] += sum16(Az);
 #pragma unroll
                 for (int mj = 0; mj < MT; ++mj) dW2[mi][mj] = mfma_outer(Az, Bh[mj], dW2[mi][mj]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- dW1 | db1 += dz1 * [x; 1]' ----
-        store_image<MT>(T1, g1, lane);
-        {
-            const int xr = c <= D ? c : 7;
-            f32x16 Bx;
-            const float* px = XI + xr * kTS + 16 * h;
+        store_image<MT>(T, g1, lane);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(px + 4 * q);
-                Bx[4 * q + 0] = t[0]; Bx[4 * q + 1] = t[1]; Bx[4 * q + 2] = t[2]; Bx[4 * q + 3] = t[3];
-            }
+        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) XI[d * kTS + c] = xk[s]; }
+        {   // v_mfma_f32_16x16x4_f32: M = 16 hidden rows, N = 16 columns [x_0..x_{D-1}, 1, 0...], K = 4 samples per step
+            const int j = lane & 15;
+            float bx[8];
+            load_row8(XI, j <= D ? j : D + 1, lane, bx);
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const f32x16 Az = load_operand(T1, mi, lane);
-                dW1[mi] = mfma_outer(Az, Bx, dW1[mi]);
+            for (int mt = 0; mt < H / 16; ++mt) {
+                float az[8];
+                load_row8(T, 16 * mt + j, lane, az);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dW1[mt] = mfma16(az[k], bx[k], dW1[mt]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
     }
 
@@ -619,21 +662,25 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
                     const int row = 32 * mi + rowfn(r, h);
 #pragma unroll
                     for (int mj = 0; mj < MT; ++mj) red[o_w2 + row + (32 * mj + c) * H] += dW2[mi][mj][r];
-                    if (c < D) red[o_w1 + row + c * H] += dW1[mi][r];
-                    else if (c == D) red[o_b1 + row] += dW1[mi][r];
                 }
                 const float b2 = db2p[mi] + __shfl_xor(db2p[mi], 32);
                 if (h == 0) red[o_b2 + 32 * mi + c] += b2;
             }
 #pragma unroll
+            for (int mt = 0; mt < H / 16; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * mt + 4 * (lane >> 4) + r, col = lane & 15;
+                    if (col < D) red[o_w1 + row + col * H] += dW1[mt][r];
+                    else if (col == D) red[o_b1 + row] += dW1[mt][r];
+                }
+#pragma unroll
             for (int o = 0; o < O; ++o) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = half_sum(dW3p[o][m][r]);
-                        if (c == 0) red[o_w3 + o + (32 * m + rowfn(r, h)) * O] += v;
-                    }
+                for (int m = 0; m < MT; ++m) {
+                    const float v = dW3a[o][m] + __shfl_xor(dW3a[o][m], 32);      // the two halves hold different samples
+                    if (h == 0) red[o_w3 + o + (32 * m + c) * O] += v;
+                }
                 const float b3 = half_sum(db3p[o]);
                 if (lane == 0) red[o_b3 + o] += b3;
                 if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (lane == 0) red[o_ls + o] += l; }
@@ -648,7 +695,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
 }
 
 template <int KIND, int H>
-__global__ __launch_bounds__(256, 1) void ppo_grad_kernel(GradArgs a) {
+__global__ __launch_bounds__(256, 2) void ppo_grad_kernel(GradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (*a.stop_flag) return;
     constexpr int A = EnvSpec<KIND>::A;
@@ -763,9 +810,9 @@ template <int KIND, int H> static size_t fwd_lds_bytes() {
 }
 template <int KIND, int H> static size_t grad_lds_bytes() {
     constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
-    constexpr int SCR = 2 * H * kTS + 8 * kTS;
-    constexpr int wa = NetLds<D, H, H, A>::BWD_END, wc = NetLds<D, H, H, 1>::BWD_END;
-    return sizeof(float) * ((wa > wc ? wa : wc) + 4 * SCR);
+    constexpr int wa = NetLds<D, H, H, A>::BWD_END + 4 * GradScratch<D, H, A>::SIZE;
+    constexpr int wc = NetLds<D, H, H, 1>::BWD_END + 4 * GradScratch<D, H, 1>::SIZE;
+    return sizeof(float) * (wa > wc ? wa : wc);
 }
 
 #define DRIL_DISPATCH(kind, hidden, CALL)                                            \
