@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -76,6 +77,8 @@ struct dril_handle {
     uint64_t env_seed0 = 0, adam_steps = 0, update_counter = 0; uint32_t policy_calls = 0;
     float lr = 0;
     bool env_ready = false;
+    unsigned long long* dbg = nullptr;
+    int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
     void* comm = nullptr;
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
     double prof_ms[DRIL_K_COUNT] = {0}; int64_t prof_n[DRIL_K_COUNT] = {0};
@@ -158,7 +161,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     g.clip_range = h->cfg.clip_range; g.ent_coef = h->cfg.ent_coef; g.vf_coef = h->cfg.vf_coef; g.clip_range_vf = h->cfg.clip_range_vf;
     g.has_clip_vf = h->cfg.has_clip_range_vf; g.normalize_adv = h->cfg.normalize_advantage; g.action_start = h->cfg.action_start;
     g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
-    g.G = G; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
+    g.G = G; g.dbg = h->dbg; g.layout = h->grad_layout; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
     prof_begin(h, DRIL_K_PPO_GRAD);
     HIPCHK(h, launch_ppo_grad(h->cfg.env_kind, h->cfg.hidden1, g, h->stream));
     prof_end(h);
@@ -254,6 +257,9 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     h->Pa = h->actor.end; h->Pc = h->critic.end - h->actor.end; h->log_std_off = h->critic.end;
     h->P = h->critic.end + (h->discrete ? 0 : h->A);
     h->N = (int64_t)cfg->n_envs * cfg->n_steps; h->lr = cfg->learning_rate;
+    if (const char* e = std::getenv("DRIL_GRAD_LAYOUT")) h->grad_layout = std::atoi(e);
+    if (const char* e = std::getenv("DRIL_GRAD_PRIO")) h->grad_prio = std::atoi(e);
+    if (const char* e = std::getenv("DRIL_GRAD_SPLIT")) h->grad_split = std::atoi(e);
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
     CCHK(hipSetDevice(cfg->device));
     hipDeviceProp_t prop; CCHK(hipGetDeviceProperties(&prop, cfg->device));
@@ -275,6 +281,9 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     h->adv_blocks = 1024; CCHK(dmalloc(&h->adv_partials, 2 * (size_t)h->adv_blocks)); CCHK(dmalloc(&h->adv_stats, 4));
     h->ev_blocks = 1024; CCHK(dmalloc(&h->ev_partials, 4 * (size_t)h->ev_blocks));
     CCHK(dmalloc(&h->stop_flag, 1)); CCHK(dmalloc(&h->nan_flag, 1));
+#ifdef DRIL_STAMPS
+    CCHK(dmalloc(&h->dbg, (size_t)2 * h->Gmax * 4 * 12)); CCHK(hipMemset(h->dbg, 0, (size_t)2 * h->Gmax * 4 * 12 * 8));
+#endif
     CCHK(dmalloc(&h->e_obs, E * h->D)); CCHK(dmalloc(&h->e_rew, E)); CCHK(dmalloc(&h->e_tobs, E * h->D)); CCHK(dmalloc(&h->e_term, E));
     CCHK(dmalloc(&h->e_trunc, E)); CCHK(hipMalloc(&h->e_act, E * act_bytes_per(h)));
     CCHK(hipMemsetAsync(h->params, 0, P * 4, h->stream)); CCHK(hipMemsetAsync(h->boot, 0, N * 4, h->stream));
@@ -530,6 +539,21 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
     HIPCHK(h, hipMemcpyAsync(ev.data(), h->ev_partials, ev.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&nan, h->nan_flag, 4, hipMemcpyDeviceToHost, h->stream));
     int rc = sync(h); if (rc) return rc;
+#ifdef DRIL_STAMPS
+    {   // shares of the LAST grad launch, averaged over waves, per head
+        std::vector<unsigned long long> d((size_t)2 * h->Gmax * 4 * 12);
+        hipMemcpy(d.data(), h->dbg, d.size() * 8, hipMemcpyDeviceToHost);
+        const char* names[] = {"gather/loop", "L1+tanh", "L2+tanh", "out+head", "dW3 block", "dz2", "h1img+dh1+dz1", "dW2 block", "dW1 block"};
+        for (int head = 0; head < 3; ++head) {
+            double acc[10] = {0}; double tiles = 0; int nw = 0;
+            for (size_t w = 0; w < d.size() / 12; ++w) if (d[w * 12 + 10] > 0 && (int)d[w * 12 + 11] == head) { for (int k = 0; k < 10; ++k) acc[k] += (double)d[w * 12 + k]; tiles += (double)d[w * 12 + 10]; ++nw; }
+            if (!nw) continue;
+            double tot = 0; for (int k = 0; k < 9; ++k) tot += acc[k];
+            fprintf(stderr, "[stamps] head %d: %d waves, %.0f tiles/wave, %.0f ticks/tile (s_memtime ticks)\n", head, nw, tiles / nw, tot / tiles);
+            for (int k = 0; k < 9; ++k) fprintf(stderr, "   %-16s %8.0f ticks/tile  %5.1f %%\n", names[k], acc[k] / tiles, 100.0 * acc[k] / tot);
+        }
+    }
+#endif
     // per-iteration means over the applied steps (ppo.jl:242-264); grad_norm also counts the KL-stopped step (:223)
     double acc[8] = {0}; int n_upd = 0, n_gn = 0, stopped = 0; float ratio_first = 0;
     for (int64_t s = 0; s < total_steps; ++s) {

@@ -286,12 +286,27 @@ __device__ __forceinline__ void dense_first(const float* __restrict__ W1T, const
     }
 }
 
+// stage-wise over the 16 registers of a tile so the five dependent ops of one element interleave with the other
+// fifteen (the element-by-element form left s_nop bubbles after every v_exp/v_rcp: stamps, profiles/r01_v3)
+__device__ __forceinline__ void tanh16(f32x16& x) {
+    f32x16 t = x * 2.8853900817779268f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = __builtin_amdgcn_exp2f(t[i]);
+    t = t + 1.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = __builtin_amdgcn_rcpf(t[i]);
+    x = 1.0f - 2.0f * t;
+}
 template <int M> __device__ __forceinline__ void tanh_tiles(f32x16 (&X)[M]) {
 #pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) X[m][r] = tanh_f32(X[m][r]);
+    for (int m = 0; m < M; ++m) tanh16(X[m]);
 }
+
+// fast transcendental forms for the distribution heads: v_exp_f32 / v_log_f32 / v_rcp_f32 are 1-ulp units; the libm
+// versions (and IEEE division) cost 10-30 dependent instructions each and made the actor head 312 VALU instructions
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // output layer on the VALU: out[o] = b3[o] + sum_j W3[o][j] * h2[j][sample]; each half-wave owns half the rows
 template <int M, int O, int H2>

@@ -37,6 +37,9 @@ struct GradArgs {
     float invB, clip_range, ent_coef, vf_coef, clip_range_vf;
     int has_clip_vf, normalize_adv, action_start, log_std_off;
     float* slabs_actor; float* slabs_critic; int slab_a, slab_c, G;
+    unsigned long long* dbg;   // -DDRIL_STAMPS diagnostic buffer (12 x u64 per wave), else unused
+    int prio, split_pct;   // tuning knobs: static wave priority + share of tiles for the high-priority half
+    int layout;   // 0: actor/critic workgroups interleaved by blockIdx parity, 1: first G blocks actor, next G critic
     const int* stop_flag;
     NetOff actor, critic;
 };

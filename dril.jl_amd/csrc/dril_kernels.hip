@@ -78,9 +78,10 @@ template <int A> __device__ __forceinline__ void softmax_n(const float (&z)[A], 
     for (int i = 1; i < A; ++i) m = fmaxf(m, z[i]);
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < A; ++i) { p[i] = expf(z[i] - m); s += p[i]; }
+    for (int i = 0; i < A; ++i) { p[i] = fexp(z[i] - m); s += p[i]; }
+    const float inv = frcp(s);
 #pragma unroll
-    for (int i = 0; i < A; ++i) p[i] = p[i] / s;
+    for (int i = 0; i < A; ++i) p[i] = p[i] * inv;
 }
 template <int A> __device__ __forceinline__ int categorical_sample(const float (&p)[A], double u) {
     float cs = 0.f; int a = A - 1; bool found = false;
@@ -97,7 +98,7 @@ template <int A> __device__ __forceinline__ float pick(const float (&p)[A], int 
 template <int A> __device__ __forceinline__ float categorical_entropy(const float (&p)[A]) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < A; ++i) s += p[i] * logf(p[i]);
+    for (int i = 0; i < A; ++i) s += p[i] * flog(p[i]);
     return -s;
 }
 constexpr float kLog2Pi = 1.8378770664093453f;
@@ -105,7 +106,7 @@ constexpr float kLog2Pi = 1.8378770664093453f;
 template <int A> __device__ __forceinline__ float gauss_logpdf(const float (&x)[A], const float (&mu)[A], const float* ls) {
     float lss = 0.f, dss = 0.f;
 #pragma unroll
-    for (int i = 0; i < A; ++i) { lss += ls[i]; const float d = x[i] - mu[i]; dss += d * d * expf(-2.0f * ls[i]); }
+    for (int i = 0; i < A; ++i) { lss += ls[i]; const float d = x[i] - mu[i]; dss += d * d * fexp(-2.0f * ls[i]); }
     return -0.5f * (2.0f * lss + dss + (float)A * kLog2Pi);
 }
 template <int A> __device__ __forceinline__ float gauss_entropy(const float* ls) {
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void policy_kernel(PolicyArgs a) {
                 if (valid && h == 0) ((int32_t*)a.actions)[b] = act + a.action_start;
             } else act = ((const int32_t*)a.actions)[bb] - a.action_start;
             if (valid && h == 0) {
-                a.logp[b] = logf(pick<A>(p, act));
+                a.logp[b] = flog(pick<A>(p, act));
                 if (a.mode == 1 && a.entropy) a.entropy[b] = categorical_entropy<A>(p);
             }
         } else {
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void policy_kernel(PolicyArgs a) {
                     float z;
                     if (a.noise) z = ((const float*)a.noise)[bb * A + i];
                     else { uint32_t r[4]; philox4x32_10((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)bb, (uint32_t)(bb >> 32), 3 + 16 * (uint32_t)i, a.call_counter, r); z = randn_f32(r[0], r[1]); }
-                    x[i] = out[i] + expf(ls[i]) * z;
+                    x[i] = out[i] + fexp(ls[i]) * z;
                     if (valid && h == 0) ((float*)a.actions)[b * A + i] = x[i];
                 }
             } else {
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(RolloutArgs a) {
             if (a.noise) u = ((const double*)a.noise)[k];
             else { uint32_t r[4]; philox4x32_10((uint32_t)env_seed, (uint32_t)(env_seed >> 32), gs, 0, 1, 0, r); u = u01_f64(r[0], r[1]); }
             const int act = categorical_sample<A>(p, u);
-            logp = logf(pick<A>(p, act));
+            logp = flog(pick<A>(p, act));
             act_env = act;                                                   // DiscreteAdapter: identity (default_adapters.jl:34-38)
             if (writer) ((int32_t*)a.act)[k] = act + a.action_start;         // raw action stored (trajectory.jl:48)
         } else {
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(RolloutArgs a) {
                 float z;
                 if (a.noise) z = ((const float*)a.noise)[k * A + i];
                 else { uint32_t r[4]; philox4x32_10((uint32_t)env_seed, (uint32_t)(env_seed >> 32), gs, 0, 1, (uint32_t)(i / 2), r); z = (i & 1) ? randn_f32(r[2], r[3]) : randn_f32(r[0], r[1]); }
-                x[i] = out[i] + expf(ls[i]) * z;
+                x[i] = out[i] + fexp(ls[i]) * z;
                 if (writer) ((float*)a.act)[k * A + i] = x[i];
             }
             logp = gauss_logpdf<A>(x, out, ls);
@@ -386,6 +387,14 @@ __global__ void moments_finalize_kernel(const double* partials, int nblocks, dou
 // =============================================================================================
 enum { HEAD_CATEGORICAL = 0, HEAD_GAUSSIAN = 1, HEAD_VALUE = 2 };
 
+// diagnostic build only (-DDRIL_STAMPS): per-phase s_memtime shares of one tile; never used for timing claims
+#ifdef DRIL_STAMPS
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \
+                      __builtin_amdgcn_sched_barrier(0); stamp_acc[k] += _t - stamp_prev; stamp_prev = _t; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 // one lane's share of a minibatch tile (DataLoader gather, ppo.jl:188-195).  Loaded one tile AHEAD of its use so the
 // random-gather latency (~2 us under load, fully exposed in v1: 23 % of wave time in s_waitcnt) hides under the
 // previous tile's MFMAs; the loop body issues no other vector-memory op, so the loads stay in flight until first use.
@@ -432,7 +441,11 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
     constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
     using L = NetLds<D, H, H, O>;
     using SC = GradScratch<D, H, O>;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // threadIdx.x / 64 IS wave-uniform but hipcc cannot prove it: readfirstlane moves the wave id - and every tile index,
+    // LDS base and loop bound derived from it - into SGPRs (v3 spilled those to scratch, and each scratch reload's
+    // s_waitcnt vmcnt(0) drained the prefetched gathers: profiles/r01 stamps, "out+head" 7.0k cycles)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, h = lane >> 5;
     const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
     float* wl = smem;
@@ -452,6 +465,8 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
         if (var < 0) var = 0;
         adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
     }
+    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
+    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
     const float* ls = a.params + a.log_std_off;
 
     f32x16 dW2[MT][MT];
@@ -476,27 +491,43 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) st[i] = 0.f;
 
-    const int g = blockIdx.x >> 1;
-    const int64_t ntiles = (a.count + kTile - 1) / kTile;
-    const int64_t tstride = (int64_t)a.G * 4;
+    const int g = a.layout ? (int)(blockIdx.x % a.G) : (int)(blockIdx.x >> 1);
+    const int64_t ntiles_all = (a.count + kTile - 1) / kTile;
+    // static priority experiment: co-resident workgroups (g of the actor, g of the critic) get opposite priorities;
+    // the high-priority half of each net takes split_pct % of the tiles (deterministic partition)
+    int64_t tile0 = 0, ntiles = ntiles_all, tstride = (int64_t)a.G * 4, first = (int64_t)g * 4 + wave;
+    if (a.prio && a.G >= 2 && (a.G & 1) == 0) {
+        const bool hi = ((g & 1) == 0) == (HEAD != HEAD_VALUE);
+        const int64_t nh = ntiles_all * a.split_pct / 100;
+        tile0 = hi ? 0 : nh; ntiles = hi ? nh : ntiles_all;
+        tstride = (int64_t)(a.G / 2) * 4; first = tile0 + (int64_t)(g >> 1) * 4 + wave;
+        if (hi) __builtin_amdgcn_s_setprio(1);
+    }
     TileIn<O> cur, nxt;
-    int64_t tile = (int64_t)g * 4 + wave;
+    int64_t tile = first;
     if (tile < ntiles) load_tile<KIND, O, HEAD>(a, tile, ntiles, c, h, cur);
+#ifdef DRIL_STAMPS
+    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
+#endif
     for (; tile < ntiles; tile += tstride) {
         load_tile<KIND, O, HEAD>(a, tile + tstride, ntiles, c, h, nxt);      // prefetch the next tile's gathers
         const bool valid = cur.valid;
         float xk[2] = {cur.xk[0], cur.xk[1]};
+        STAMP(0);
         // ---- forward ----
         f32x16 h1[MT], h2[MT];
         float out[O], dz[O];
         dense_first<H, MT>(wl + L::W1T, wl + L::B1, xk, h1, lane);
         tanh_tiles(h1);
+        STAMP(1);
 #pragma unroll
         for (int mo = 0; mo < MT; ++mo) {
             h2[mo] = dense_mfma_tile<MT, true>(wl + L::W2S, L::WS1, wl + L::B2, h1, mo, lane);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h2[mo][r] = tanh_f32(h2[mo][r]);
+            tanh16(h2[mo]);
         }
+        store_image<MT>(T, h2, lane);          // early: the LDS write -> read round trip hides under the head below
+        STAMP(2);
         dense_out<MT, O, H>(wl + L::W3S, wl + L::B3, h2, out, lane);
         __builtin_amdgcn_sched_barrier(0);
         // ---- loss head (ppo.jl:377-404) and dLoss/dout ----
@@ -512,7 +543,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
             dz[0] = (valid && vpass) ? a.invB * a.vf_coef * 2.0f * ve : 0.f;
             if (valid && h == 0) st[0] += ve * ve;                            // value_loss numerator, ppo.jl:385
         } else {
-            const float advn = (cur.s0 - adv_mean) / adv_den;
+            const float advn = (cur.s0 - adv_mean) * adv_inv;
             const float olp = cur.s1;
             float logp, ent;
             float p[O];
@@ -521,7 +552,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
             if (HEAD == HEAD_CATEGORICAL) {
                 softmax_n<O>(out, p);
                 act = cur.act;
-                logp = logf(pick<O>(p, act));
+                logp = flog(pick<O>(p, act));
                 ent = categorical_entropy<O>(p);
             } else {
 #pragma unroll
@@ -530,7 +561,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
                 ent = gauss_entropy<O>(ls);
             }
             const float lr = logp - olp;
-            const float r = expf(lr);                                          // ppo.jl:380
+            const float r = fexp(lr);                                          // ppo.jl:380
             const float lo = 1.0f - a.clip_range, hi = 1.0f + a.clip_range;
             const float rc = fminf(fmaxf(r, lo), hi);                          // :381
             const float t1 = r * advn, t2 = rc * advn;
@@ -541,11 +572,11 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
             if (HEAD == HEAD_CATEGORICAL) {
 #pragma unroll
                 for (int o = 0; o < O; ++o)
-                    dz[o] = dlogp * ((o == act ? 1.0f : 0.0f) - p[o]) + dent * (-p[o] * (logf(p[o]) + ent));
+                    dz[o] = dlogp * ((o == act ? 1.0f : 0.0f) - p[o]) + dent * (-p[o] * (flog(p[o]) + ent));
             } else {
 #pragma unroll
                 for (int o = 0; o < O; ++o) {
-                    const float iv = expf(-2.0f * ls[o]), d = xa[o] - out[o];
+                    const float iv = fexp(-2.0f * ls[o]), d = xa[o] - out[o];
                     dz[o] = dlogp * d * iv;
                     if (h == 0) dlsp[o] += dlogp * (d * d * iv - 1.0f) + dent;
                 }
@@ -555,11 +586,11 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
                 st[3] += (r - 1.0f) - lr; st[4] += r;                           // :393,:402
             }
         }
+        STAMP(3);
         __builtin_amdgcn_sched_barrier(0);
         // ---- output layer backward: dW3 += dz * h2' over samples (h2 read back transposed: hidden on the lane) ----
 #pragma unroll
         for (int o = 0; o < O; ++o) { if (h == 0) { db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
-        store_image<MT>(T, h2, lane);
         {
             f32x16 Bh2[MT];
 #pragma unroll
@@ -582,6 +613,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
                 for (int mj = 0; mj < MT; ++mj) dW3a[o][mj] += acc[mj];
             }
         }
+        STAMP(4);
         __builtin_amdgcn_sched_barrier(0);
         // ---- dz2 = (W3' dz) .* (1 - h2^2), in h2's registers ----
 #pragma unroll
@@ -598,6 +630,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) { const float hv = h2[m][4 * q + cc]; h2[m][4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
             }
+        STAMP(5);
         __builtin_amdgcn_sched_barrier(0);
         // ---- h1 image (the LDS unit executes a wave's accesses in order, so the Bh2 reads above precede these writes) ----
         store_image<MT>(T, h1, lane);
@@ -609,6 +642,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) g1[m][r] = g1[m][r] * (1.0f - h1[m][r] * h1[m][r]);
         }
+        STAMP(6);
         __builtin_amdgcn_sched_barrier(0);
         // ---- dW2 += dz2 * h1' ; db2 += rowsum(dz2) ----
         {
@@ -624,6 +658,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
                 for (int mj = 0; mj < MT; ++mj) dW2[mi][mj] = mfma_outer(Az, Bh[mj], dW2[mi][mj]);
             }
         }
+        STAMP(7);
         __builtin_amdgcn_sched_barrier(0);
         // ---- dW1 | db1 += dz1 * [x; 1]' ----
         store_image<MT>(T, g1, lane);
@@ -641,9 +676,17 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
                 for (int k = 0; k < 8; ++k) dW1[mt] = mfma16(az[k], bx[k], dW1[mt]);
             }
         }
+        STAMP(8);
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
     }
+#ifdef DRIL_STAMPS
+    if (lane == 0 && a.dbg) {
+        unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
+        for (int k = 0; k < 10; ++k) o[k] = stamp_acc[k];
+        o[10] = (unsigned long long)((ntiles - first + tstride - 1) / tstride); o[11] = HEAD;
+    }
+#endif
 
     // ---- epilogue: 4 waves -> one slab (fixed wave order => deterministic) ----
     __syncthreads();
@@ -699,7 +742,8 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_kernel(GradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (*a.stop_flag) return;
     constexpr int A = EnvSpec<KIND>::A;
-    if ((blockIdx.x & 1) == 0) grad_body<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN>(a, smem);
+    const bool actor = a.layout ? (blockIdx.x < (unsigned)a.G) : ((blockIdx.x & 1) == 0);
+    if (actor) grad_body<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN>(a, smem);
     else grad_body<KIND, H, 1, HEAD_VALUE>(a, smem);
 }
 
@@ -708,10 +752,11 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_kernel(GradArgs a) {
 // flat layout: params order (actor net, critic net, log_std) then 8 stats:
 //   0 sum(-min term)  1 sum(entropy)  2 sum(clipped)  3 sum(kl)  4 sum(ratio)  5 sum((V-R)^2)  6 n_samples  7 unused
 // =============================================================================================
-__global__ void grad_reduce_kernel(ReduceArgs a) {
-    // block = 32 parameters x 8 slab groups: coalesced 128-byte rows per group, fixed summation order => deterministic
+__global__ __launch_bounds__(1024) void grad_reduce_kernel(ReduceArgs a) {
+    // block = 32 parameters x 32 slab groups: every thread has all its (<= 8) slab loads in flight at once; the slabs were
+    // written by other XCDs, so each load is a full memory round trip and serial loops cost ~0.5 us per iteration (v2: 65 us)
     __shared__ double sh[16];
-    __shared__ float part[8][33];
+    __shared__ float part[32][33];
     if (*a.stop_flag) return;
     const int pl = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int p = blockIdx.x * 32 + pl;
@@ -721,25 +766,35 @@ __global__ void grad_reduce_kernel(ReduceArgs a) {
         if (p < a.Pa) { base = a.slabs_actor; stride = a.slab_a; offp = p; }
         else if (p < a.Pa + a.Pc) { base = a.slabs_critic; stride = a.slab_c; offp = p - a.Pa; }
         else { base = a.slabs_actor; stride = a.slab_a; offp = a.Pa + (p - a.Pa - a.Pc); }   // log_std grads sit after the actor net
-#pragma unroll 4
-        for (int g = grp; g < a.G; g += 8) acc += base[(size_t)g * stride + offp];
+#pragma unroll 8
+        for (int g = grp; g < a.G; g += 32) acc += base[(size_t)g * stride + offp];
     }
     part[grp][pl] = acc;
     __syncthreads();
     float gsum = 0.f;
     if (grp == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) gsum += part[k][pl];
+        for (int k = 0; k < 32; ++k) gsum += part[k][pl];                      // fixed order => deterministic
         if (p < a.P) a.flat[p] = gsum;
     }
     const double q = block_sum_f64(grp == 0 ? (double)gsum * (double)gsum : 0.0, sh);
     if (threadIdx.x == 0) a.norm_partials[blockIdx.x] = q;
-    if (blockIdx.x == 0 && threadIdx.x < 8) {
-        const int k = threadIdx.x; double s = 0;
-        if (k < 5) for (int g = 0; g < a.G; ++g) s += a.slabs_actor[(size_t)g * a.slab_a + a.slab_a - 8 + k];
-        else if (k == 5) for (int g = 0; g < a.G; ++g) s += a.slabs_critic[(size_t)g * a.slab_c + a.slab_c - 8];
-        else if (k == 6) s = a.n_samples_local;
-        a.flat[a.P + k] = (float)s;
+    if (blockIdx.x == 0) {                                                     // loss/statistics sums: 8 stats x 32 slab groups
+        __syncthreads();
+        const int k = threadIdx.x & 7, sg = (threadIdx.x >> 3) & 31;
+        float sacc = 0.f;
+        if (threadIdx.x < 256) {
+            if (k < 5) { for (int g = sg; g < a.G; g += 32) sacc += a.slabs_actor[(size_t)g * a.slab_a + a.slab_a - 8 + k]; }
+            else if (k == 5) { for (int g = sg; g < a.G; g += 32) sacc += a.slabs_critic[(size_t)g * a.slab_c + a.slab_c - 8]; }
+            part[sg][k] = sacc;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            double t = 0;
+            for (int j = 0; j < 32; ++j) t += (double)part[j][threadIdx.x];
+            if (threadIdx.x == 6) t = a.n_samples_local;
+            a.flat[a.P + threadIdx.x] = (float)t;
+        }
     }
 }
 __global__ void grad_norm_kernel(const float* flat, int P, double* norm_partials, const int* stop_flag) {
@@ -752,10 +807,10 @@ __global__ void grad_norm_kernel(const float* flat, int P, double* norm_partials
 }
 __global__ void adam_kernel(AdamArgs a) {
     if (*a.stop_flag) return;
-    __shared__ float s_norm;
-    if (threadIdx.x == 0) { double s = 0; for (int i = 0; i < a.n_partials; ++i) s += a.norm_partials[i]; s_norm = sqrtf((float)s); }
-    __syncthreads();
-    const float norm = s_norm;
+    __shared__ double shn[16];
+    double ps = 0;
+    for (int i = threadIdx.x; i < a.n_partials; i += blockDim.x) ps += a.norm_partials[i];    // same order in every block
+    const float norm = sqrtf((float)block_sum_f64(ps, shn));
     const float* stf = a.flat + a.P;
     const float n = a.use_stats ? stf[6] : 1.f;
     const float kl = a.use_stats ? stf[3] / n : 0.f;
@@ -903,7 +958,7 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
 }
 
 hipError_t launch_grad_reduce(const ReduceArgs& a, hipStream_t s) {
-    grad_reduce_kernel<<<(a.P + 31) / 32, 256, 0, s>>>(a);
+    grad_reduce_kernel<<<(a.P + 31) / 32, 1024, 0, s>>>(a);
     return hipGetLastError();
 }
 hipError_t launch_grad_norm(const float* flat, int P, double* norm_partials, const int* stop_flag, hipStream_t s) {

@@ -1,0 +1,18 @@
+"""Diagnostic: run one PPO update with the -DDRIL_STAMPS build of the library (per-phase s_memtime shares on stderr)."""
+import sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as g
+pkg = g.load_package()
+capi = pkg._capi
+lib = capi.load_library(ROOT / "dril.jl_amd" / "csrc" / "libdril_hip_stamps.so")
+env = pkg.CartPoleEnv(max_steps=500)
+E, T = 65536, 2048
+alg = pkg.PPO(n_steps=T, batch_size=E * T // 32, epochs=1)
+layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space())
+cfg = pkg.make_config(env, E, alg, layer, seed=42, fixed_length_episodes=True)
+h = pkg.Handle(cfg, lib)
+h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(42))))
+h.env_reset(42); h.collect_rollout(); st = h.ppo_update(); print("loss", st.loss)
