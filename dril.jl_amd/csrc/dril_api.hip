@@ -78,6 +78,7 @@ struct dril_handle {
     float lr = 0;
     bool env_ready = false;
     unsigned long long* dbg = nullptr;
+    bool force_allreduce = false;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
     void* comm = nullptr;
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
@@ -142,6 +143,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
              const float* val_old, const int64_t* perm, int64_t pos0, int64_t count, int64_t N, uint64_t key, int bits,
              float* step_stats, bool apply) {
     const int world = h->comm ? h->cfg.world_size : 1;
+    const bool reduce = world > 1 || (h->comm && h->force_allreduce);   // force: exercise the RCCL path on one rank (tests)
     const int64_t tiles = (count + kTile - 1) / kTile;
     int G = (int)((tiles + 3) / 4); if (G > h->Gmax) G = h->Gmax; if (G < 1) G = 1;
     if (h->cfg.normalize_advantage) {
@@ -152,7 +154,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
         HIPCHK(h, launch_adv_moments(m, nb, h->stream));
         HIPCHK(h, launch_moments_finalize(h->adv_partials, nb, h->adv_stats, (double)count, h->stop_flag, h->stream));
         prof_end(h);
-        if (world > 1) { int rc = rccl_allreduce(h, h->adv_stats, 3, kNcclFloat64); if (rc) return rc; }
+        if (reduce) { int rc = rccl_allreduce(h, h->adv_stats, 3, kNcclFloat64); if (rc) return rc; }
     }
     GradArgs g{};
     g.params = h->params; g.obs = obs; g.actions = actions; g.adv = adv; g.ret = ret; g.logp_old = logp_old; g.val_old = val_old;
@@ -172,7 +174,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     prof_begin(h, DRIL_K_GRAD_REDUCE);
     HIPCHK(h, launch_grad_reduce(r, h->stream));
     prof_end(h);
-    if (world > 1) {
+    if (reduce) {
         int rc = rccl_allreduce(h, h->flat, (size_t)h->P + 8, kNcclFloat32); if (rc) return rc;
         HIPCHK(h, launch_grad_norm(h->flat, h->P, h->norm_partials, h->stop_flag, h->stream));
     }
@@ -258,6 +260,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     h->P = h->critic.end + (h->discrete ? 0 : h->A);
     h->N = (int64_t)cfg->n_envs * cfg->n_steps; h->lr = cfg->learning_rate;
     if (const char* e = std::getenv("DRIL_GRAD_LAYOUT")) h->grad_layout = std::atoi(e);
+    if (const char* e = std::getenv("DRIL_FORCE_ALLREDUCE")) h->force_allreduce = std::atoi(e) != 0;
     if (const char* e = std::getenv("DRIL_GRAD_PRIO")) h->grad_prio = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_SPLIT")) h->grad_split = std::atoi(e);
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)

@@ -1,0 +1,263 @@
+# DRiLHIP.jl — the `ccall` shim that routes DRiL.jl's rollout + PPO-update hot path to libdril_hip.so (MI355X).
+#
+# Nothing here computes: every call is one entry point of include/dril_hip.h.  The shim adds ONE env type and
+# more specific methods of DRiL's own generic functions, so `Agent`, `ActorCriticLayer`, `PPO` and `train!` are used
+# exactly as in the reference README (README.md:50-73):
+#
+#     env   = DeviceParallelEnv(:CartPole, 65_536; max_steps = 500)          # instead of MultiThreadedParallelEnv([...])
+#     layer = ActorCriticLayer(observation_space(env), action_space(env))
+#     alg   = PPO(; n_steps = 2048, batch_size = 4_194_304)
+#     agent = Agent(layer, alg; verbose = 0)
+#     learn_stats, to = train!(agent, env, alg, 10 * 2048 * 65_536)
+#
+# NOTE: the build image has no Julia runtime, so this file is syntax-reviewed only; every behaviour it relies on is
+# exercised through the same C symbols by the Python ctypes mirror (dril.jl_amd/host.py, tests/test_gpu_parity.py).
+module DRiLHIP
+
+using DRiL
+using DRiL: AbstractParallelEnv, AbstractCallback, Agent, PPO, RolloutBuffer, Box, Discrete
+import DRiL: train!, collect_rollout!, observe, act!, reset!, terminated, truncated, number_of_envs,
+             observation_space, action_space, get_info
+using Random
+using TimerOutputs
+
+const LIB = Ref{String}(joinpath(@__DIR__, "..", "csrc", "libdril_hip.so"))
+const ABI_VERSION = UInt32(1)
+
+# struct dril_config (include/dril_hip.h) — isbits, C layout
+struct DrilConfig
+    abi_version::UInt32; env_kind::Int32; n_envs::Int32; n_steps::Int32
+    hidden1::Int32; hidden2::Int32; episode_len::Int32; fixed_length_episodes::Int32; action_start::Int32
+    gamma::Float32; gae_lambda::Float32; clip_range::Float32
+    clip_range_vf::Float32; has_clip_range_vf::Int32
+    ent_coef::Float32; vf_coef::Float32
+    max_grad_norm::Float32; has_max_grad_norm::Int32
+    target_kl::Float32; has_target_kl::Int32
+    normalize_advantage::Int32
+    batch_size::Int64; epochs::Int32
+    learning_rate::Float32; adam_beta1::Float32; adam_beta2::Float32; adam_eps::Float32; log_std_init::Float32
+    norm_obs::Int32; norm_reward::Int32; norm_training::Int32
+    clip_obs::Float32; clip_reward::Float32; norm_gamma::Float32; norm_epsilon::Float32
+    seed::UInt64
+    device::Int32; rank::Int32; world_size::Int32; profile_events::Int32
+    reserved::NTuple{7, Int32}
+end
+
+# struct dril_ppo_stats
+struct DrilPPOStats
+    entropy_loss::Float32; policy_loss::Float32; value_loss::Float32; approx_kl_div::Float32; clip_fraction::Float32
+    loss::Float32; grad_norm::Float32; explained_variance::Float32; entropy::Float32; ratio_first::Float32
+    n_updates::Int32; early_stopped::Int32; nan_or_inf::Int32; reserved::Int32
+end
+
+const ENV_KINDS = Dict(:CartPole => Int32(0), :Pendulum => Int32(1))
+
+"""
+    DeviceParallelEnv(kind, n_envs; max_steps, seed, fixed_length_episodes, device) <: AbstractParallelEnv
+
+Device-resident batched simulator replacing `MultiThreadedParallelEnv([CartPoleEnv() for _ in 1:n_envs])`
+(src/environment_wrappers/multithreadedParallelEnv.jl).  The handle is created lazily by `bind!` because one
+`dril_handle` carries env + agent + algorithm state.
+"""
+mutable struct DeviceParallelEnv <: AbstractParallelEnv
+    kind::Symbol
+    n_envs::Int
+    max_steps::Int
+    seed::UInt64
+    fixed_length_episodes::Bool
+    device::Int
+    handle::Ptr{Cvoid}
+    bound::Any                     # (alg, hidden_dims, log_std_init) the handle was created for
+    last_terminated::Vector{Bool}
+    last_truncated::Vector{Bool}
+end
+
+function DeviceParallelEnv(kind::Symbol, n_envs::Integer; max_steps::Integer = kind === :CartPole ? 500 : 200,
+        seed::Integer = 42, fixed_length_episodes::Bool = false, device::Integer = 0)
+    haskey(ENV_KINDS, kind) || error("unknown device env $kind")
+    env = DeviceParallelEnv(kind, n_envs, max_steps, UInt64(seed), fixed_length_episodes, device, C_NULL, nothing,
+        fill(false, n_envs), fill(false, n_envs))
+    finalizer(e -> (e.handle != C_NULL && ccall((:dril_destroy, LIB[]), Int32, (Ptr{Cvoid},), e.handle); nothing), env)
+    return env
+end
+
+number_of_envs(env::DeviceParallelEnv) = env.n_envs
+observation_space(env::DeviceParallelEnv) = env.kind === :CartPole ?
+    Box(Float32[-4.8, -Inf, -0.41887903, -Inf], Float32[4.8, Inf, 0.41887903, Inf]) :
+    Box(Float32[-1, -1, -8], Float32[1, 1, 8])
+action_space(env::DeviceParallelEnv) = env.kind === :CartPole ? Discrete(2) : Box(Float32[-2], Float32[2])
+obs_dim(env::DeviceParallelEnv) = env.kind === :CartPole ? 4 : 3
+
+last_error(h) = unsafe_string(ccall((:dril_last_error, LIB[]), Cstring, (Ptr{Cvoid},), h))
+function check(rc::Int32, h = C_NULL)
+    rc == 0 && return nothing
+    # status 4 mirrors `@assert !nested_has_nan(grads)` (src/algorithms/ppo.jl:213-214)
+    error("libdril_hip status $rc: $(last_error(h))")
+end
+
+function make_config(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int}, log_std_init::Float32)
+    opt(x) = isnothing(x) ? (0.0f0, Int32(0)) : (Float32(x), Int32(1))
+    cvf, hcvf = opt(alg.clip_range_vf); mgn, hmgn = opt(alg.max_grad_norm); tkl, htkl = opt(alg.target_kl)
+    start = env.kind === :CartPole ? Int32(action_space(env).start) : Int32(1)
+    return DrilConfig(ABI_VERSION, ENV_KINDS[env.kind], env.n_envs, alg.n_steps, hidden[1], hidden[2], env.max_steps,
+        Int32(env.fixed_length_episodes), start, alg.gamma, alg.gae_lambda, alg.clip_range, cvf, hcvf, alg.ent_coef,
+        alg.vf_coef, mgn, hmgn, tkl, htkl, Int32(alg.normalize_advantage), alg.batch_size, alg.epochs, alg.learning_rate,
+        0.9f0, 0.999f0, 1.0f-5, log_std_init,                    # Optimisers.Adam(eta, (0.9, 0.999), 1e-5): ppo.jl:64-66
+        0, 0, 0, 10.0f0, 10.0f0, 0.99f0, 1.0f-8, env.seed, env.device, 0, 1, 0, ntuple(_ -> Int32(0), 7))
+end
+
+"(re)create the handle when the algorithm / layer shape changes; Random.seed!(env, seed) + reset!(env) follow"
+function bind!(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int} = [64, 64], log_std_init::Float32 = 0.0f0)
+    key = (alg, hidden, log_std_init)
+    if env.handle == C_NULL || env.bound != key
+        env.handle != C_NULL && ccall((:dril_destroy, LIB[]), Int32, (Ptr{Cvoid},), env.handle)
+        cfg = Ref(make_config(env, alg, hidden, log_std_init))
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:dril_create, LIB[]), Int32, (Ref{DrilConfig}, Ref{Ptr{Cvoid}}), cfg, h))
+        env.handle = h[]; env.bound = key
+        check(ccall((:dril_env_reset, LIB[]), Int32, (Ptr{Cvoid}, UInt64), env.handle, env.seed), env.handle)
+    end
+    return env.handle
+end
+handle(env::DeviceParallelEnv) = env.handle == C_NULL ? bind!(env, PPO(; n_steps = 1, batch_size = env.n_envs)) : env.handle
+
+# ---- env verbs with host copy-out: generic DRiL callers (evaluate_agent, check_env, wrappers) keep working ----
+function reset!(env::DeviceParallelEnv)
+    check(ccall((:dril_env_reset, LIB[]), Int32, (Ptr{Cvoid}, UInt64), handle(env), env.seed), env.handle)
+    return nothing
+end
+Random.seed!(env::DeviceParallelEnv, seed::Integer) = (env.seed = UInt64(seed); env)     # applied by the next reset!
+
+function observe(env::DeviceParallelEnv)
+    obs = Matrix{Float32}(undef, obs_dim(env), env.n_envs)              # (D x E) column-major, spaces.jl:259
+    GC.@preserve obs check(ccall((:dril_env_observe, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Int32), handle(env), obs, 1), env.handle)
+    return [obs[:, i] for i in 1:env.n_envs]
+end
+
+function act!(env::DeviceParallelEnv, actions::AbstractVector)
+    E, D = env.n_envs, obs_dim(env)
+    a = env.kind === :CartPole ? Int32[Int32(x) for x in actions] : Float32[Float32(x[1]) for x in actions]
+    rewards = Vector{Float32}(undef, E); term = Vector{UInt8}(undef, E); trunc = Vector{UInt8}(undef, E)
+    tobs = zeros(Float32, D, E)
+    GC.@preserve a rewards term trunc tobs check(ccall((:dril_env_step, LIB[]), Int32,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float32}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float32}),
+        handle(env), a, rewards, term, trunc, tobs), env.handle)
+    env.last_terminated = term .!= 0; env.last_truncated = trunc .!= 0
+    infos = [Dict{String, Any}() for _ in 1:E]
+    for i in findall(env.last_truncated)                                # only on truncation, multithreadedParallelEnv.jl:64-66
+        infos[i]["terminal_observation"] = tobs[:, i]
+    end
+    return rewards, env.last_terminated, env.last_truncated, infos
+end
+terminated(env::DeviceParallelEnv) = env.last_terminated
+truncated(env::DeviceParallelEnv) = env.last_truncated
+get_info(env::DeviceParallelEnv) = [Dict{String, Any}() for _ in 1:env.n_envs]
+
+# ---- parameters: Lux NamedTuple <-> flat f32 (layout: include/dril_hip.h, dril_set_params) ----
+mlp_of(head) = haskey(head, :layer_3) ? head : head.layer_1             # Box actions: Chain(chain, ReshapeLayer), layer_helpers.jl:77
+function flatten_params(ps)
+    parts = Vector{Float32}[]
+    for head in (mlp_of(ps.actor_head), mlp_of(ps.critic_head)), l in (:layer_1, :layer_2, :layer_3)
+        push!(parts, vec(getproperty(head, l).weight)); push!(parts, vec(getproperty(head, l).bias))   # W is (out x in) column-major
+    end
+    haskey(ps, :log_std) && push!(parts, vec(ps.log_std))
+    return reduce(vcat, parts)
+end
+function scatter_params!(ps, flat::Vector{Float32})
+    off = 0
+    for head in (mlp_of(ps.actor_head), mlp_of(ps.critic_head)), l in (:layer_1, :layer_2, :layer_3)
+        for arr in (getproperty(head, l).weight, getproperty(head, l).bias)
+            n = length(arr); copyto!(arr, 1, flat, off + 1, n); off += n
+        end
+    end
+    if haskey(ps, :log_std)
+        copyto!(ps.log_std, 1, flat, off + 1, length(ps.log_std))
+    end
+    return ps
+end
+function hidden_dims_of(ps)
+    h = mlp_of(ps.actor_head)
+    return [size(h.layer_1.weight, 1), size(h.layer_2.weight, 1)]
+end
+function push_params!(env, agent)
+    flat = flatten_params(agent.train_state.parameters)
+    GC.@preserve flat check(ccall((:dril_set_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), env.handle, flat, length(flat)), env.handle)
+end
+function pull_params!(env, agent)
+    flat = Vector{Float32}(undef, ccall((:dril_param_count, LIB[]), Int64, (Ptr{Cvoid},), env.handle))
+    GC.@preserve flat check(ccall((:dril_get_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), env.handle, flat, length(flat)), env.handle)
+    scatter_params!(agent.train_state.parameters, flat)
+end
+function bind_agent!(env::DeviceParallelEnv, agent, alg::PPO)
+    ps = agent.train_state.parameters
+    ls = haskey(ps, :log_std) ? Float32(ps.log_std[1]) : 0.0f0
+    bind!(env, alg, hidden_dims_of(ps), ls)
+end
+
+# ---- collect_rollout!(::RolloutBuffer, agent, alg, env::DeviceParallelEnv)  (src/buffers/rollout_buffer.jl:46-90) ----
+has_step_hooks(::Nothing) = false
+has_step_hooks(cbs) = any(cb -> which(DRiL.on_step, (typeof(cb), Dict)).sig != which(DRiL.on_step, (AbstractCallback, Dict)).sig, cbs)
+
+function collect_rollout!(buf::RolloutBuffer, agent::Agent, alg::PPO, env::DeviceParallelEnv; callbacks = nothing)
+    has_step_hooks(callbacks) && return invoke(collect_rollout!, Tuple{RolloutBuffer, Agent, DRiL.OnPolicyAlgorithm, DRiL.AbstractEnv},
+        buf, agent, alg, env; callbacks = callbacks)    # on_step hooks: reference loop over the env verbs above (SURVEY.md §8b)
+    bind_agent!(env, agent, alg); push_params!(env, agent)
+    fps = Ref{Float64}(0)
+    check(ccall((:dril_collect_rollout, LIB[]), Int32, (Ptr{Cvoid}, Ref{Float64}), env.handle, fps), env.handle)
+    copy_out!(env, 0, buf.observations)
+    if env.kind === :CartPole                                          # device actions are Int32; the reference buffer is Int64 (spaces.jl:169)
+        tmp = Vector{Int32}(undef, length(buf.rewards)); copy_out!(env, 1, tmp); buf.actions .= reshape(tmp, 1, :)
+    else
+        copy_out!(env, 1, buf.actions)
+    end
+    copy_out!(env, 2, buf.rewards); copy_out!(env, 3, buf.advantages); copy_out!(env, 4, buf.returns)
+    copy_out!(env, 5, buf.logprobs); copy_out!(env, 6, buf.values)     # TIME-MAJOR order: n = (t-1)*n_envs + env (DESIGN.md §3)
+    return fps[], true
+end
+function copy_out!(env, which::Integer, dst::Array)
+    GC.@preserve dst check(ccall((:dril_buffer_copy_out, LIB[]), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Csize_t),
+        env.handle, which, dst, sizeof(dst)), env.handle)
+end
+
+# ---- train!(agent, env::DeviceParallelEnv, alg::PPO, max_steps)  (src/algorithms/ppo.jl:100-325) ----
+function train!(agent::Agent, env::DeviceParallelEnv, alg::PPO{T}, max_steps::Int; ad_type = nothing, callbacks = nothing) where {T}
+    has_step_hooks(callbacks) && error("on_step callbacks need the step-granular path: call DRiL's generic train! on the env verbs")
+    to = TimerOutput()
+    @timeit to "setup" begin
+        bind_agent!(env, agent, alg); push_params!(env, agent)
+        iterations = max_steps ÷ (alg.n_steps * env.n_envs)            # ppo.jl:117
+        iterations == 0 && @warn "max_steps is less than n_steps * n_envs; there will be no training."
+    end
+    stats = NamedTuple{(:entropy_losses, :policy_losses, :value_losses, :approx_kl_divs, :clip_fractions, :losses,
+        :explained_variances, :fps, :grad_norms, :learning_rates)}(ntuple(_ -> Float32[], 10))
+    locals() = Dict{Symbol, Any}(:agent => agent, :env => env, :alg => alg, :max_steps => max_steps, :iterations => iterations)
+    !isnothing(callbacks) && !all(c -> DRiL.on_training_start(c, locals()), callbacks) && return nothing       # ppo.jl:145-152
+    @timeit to "training_loop" for i in 1:iterations
+        check(ccall((:dril_set_learning_rate, LIB[]), Int32, (Ptr{Cvoid}, Float32), env.handle, alg.learning_rate), env.handle)  # ppo.jl:155-156
+        push!(stats.learning_rates, alg.learning_rate)
+        !isnothing(callbacks) && !all(c -> DRiL.on_rollout_start(c, locals()), callbacks) && return nothing
+        fps = Ref{Float64}(0)
+        @timeit to "collect_rollout" check(ccall((:dril_collect_rollout, LIB[]), Int32, (Ptr{Cvoid}, Ref{Float64}), env.handle, fps), env.handle)
+        push!(stats.fps, fps[]); DRiL.add_step!(agent, alg.n_steps * env.n_envs)
+        DRiL.increment_step!(agent.logger, alg.n_steps * env.n_envs); DRiL.log_scalar!(agent.logger, "env/fps", fps[])
+        !isnothing(callbacks) && !all(c -> DRiL.on_rollout_end(c, locals()), callbacks) && return nothing
+        st = Ref{DrilPPOStats}()
+        @timeit to "epoch loop" check(ccall((:dril_ppo_update, LIB[]), Int32, (Ptr{Cvoid}, Ref{DrilPPOStats}), env.handle, st), env.handle)
+        s = st[]
+        push!(stats.entropy_losses, s.entropy_loss); push!(stats.policy_losses, s.policy_loss); push!(stats.value_losses, s.value_loss)
+        push!(stats.approx_kl_divs, s.approx_kl_div); push!(stats.clip_fractions, s.clip_fraction); push!(stats.losses, s.loss)
+        push!(stats.explained_variances, s.explained_variance); push!(stats.grad_norms, s.grad_norm)
+        for (k, v) in ("entropy_loss" => s.entropy_loss, "explained_variance" => s.explained_variance, "policy_loss" => s.policy_loss,
+            "value_loss" => s.value_loss, "approx_kl_div" => s.approx_kl_div, "clip_fraction" => s.clip_fraction, "loss" => s.loss,
+            "grad_norm" => s.grad_norm, "learning_rate" => alg.learning_rate)
+            DRiL.log_scalar!(agent.logger, "train/" * k, v)                                                    # ppo.jl:286-294
+        end
+    end
+    pull_params!(env, agent)                                           # agent.train_state.parameters now hold the trained weights
+    !isnothing(callbacks) && !all(c -> DRiL.on_training_end(c, locals()), callbacks) && return nothing
+    return stats, to
+end
+
+export DeviceParallelEnv
+
+end # module

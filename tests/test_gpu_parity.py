@@ -325,3 +325,27 @@ def test_host_mirror_train(pkg):
     fps, ok = pkg.collect_rollout_(buf, agent, alg, env)
     assert ok and buf.observations.shape == (64 * 32, 4) and buf.actions.dtype == np.int64
     assert np.array_equal(np.sort(buf.to_reference_order()), np.arange(64 * 32))
+
+
+def test_rccl_plumbing_single_rank(pkg, oracle_mod, monkeypatch):
+    """dril_comm_unique_id / dril_comm_init / the in-stream ncclAllReduce of [grads | sums] and of the advantage moments,
+    exercised with a 1-rank communicator (DRIL_FORCE_ALLREDUCE=1): results must equal the oracle's single-process update.
+    The N>1 arithmetic is covered on CPU by tests/test_distributed_gloo.py; the driver runs the real 2/4/8-GPU bench."""
+    monkeypatch.setenv("DRIL_FORCE_ALLREDUCE", "1")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    capi = pkg._capi
+    cfg = _cfg(pkg, 0, n_envs=16, n_steps=24, batch_size=96, epochs=2, episode_len=11)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    uid = h.comm_unique_id()
+    assert len(uid) == 128
+    h.comm_init(uid)
+    flat = _params(h.P, 77, 0.3); h.set_params(flat); o.set_params(flat)
+    o.env_reset(5); o.collect_rollout()
+    for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+        h.set_buffer(which, o.buffer(which))
+    perm = np.stack([np.random.default_rng(e).permutation(h.N) for e in range(cfg.epochs)]).astype(np.int64)
+    h.set_permutation(perm); o.set_permutation(perm)
+    sh, so = h.ppo_update(), o.ppo_update()
+    assert sh.n_updates == so.n_updates and sh.loss == pytest.approx(so.loss, rel=1e-4)
+    np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=2e-4, atol=3e-6)
+    assert h.profile is not None
