@@ -78,7 +78,9 @@ struct dril_handle {
     float lr = 0;
     bool env_ready = false;
     unsigned long long* dbg = nullptr;
-    bool force_allreduce = false;
+    bool force_allreduce = false, force_stepwise = false;
+    RmsState *obs_rms = nullptr, *ret_rms = nullptr; int obs_par = 0, ret_par = 0;   // ping-pong RunningMeanStd pairs
+    double* rms_partials = nullptr; int rms_blocks = 256; float* e_obs_raw = nullptr;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
     void* comm = nullptr;
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
@@ -136,6 +138,37 @@ PolicyArgs policy_args(dril_handle* h, const float* obs, int64_t B, const void* 
     a.mode = mode; a.action_start = h->cfg.action_start; a.log_std_off = h->log_std_off; a.seed = h->cfg.seed; a.call_counter = h->policy_calls;
     a.actor = h->actor; a.critic = h->critic;
     return a;
+}
+
+// ---- step-granular env verbs on device (NormalizeWrapperEnv.observe / act!, normalizeWrapperEnv.jl:123-165) ----
+int observe_dev(dril_handle* h, bool update_stats) {
+    const int E = h->cfg.n_envs;
+    int nb = (E + 255) / 256; if (nb > h->rms_blocks) nb = h->rms_blocks;
+    HIPCHK(h, launch_obs_partials(h->cfg.env_kind, E, h->state, h->e_obs_raw, h->rms_partials, nb, h->stream));
+    NormObsArgs a{};
+    a.E = E; a.D = h->D; a.update = (update_stats && h->cfg.norm_training && h->cfg.norm_obs) ? 1 : 0; a.nblocks = nb;
+    a.raw = h->e_obs_raw; a.partials = h->rms_partials; a.in = h->obs_rms + h->obs_par; a.out = h->obs_rms + (h->obs_par ^ 1);
+    a.obs_n = h->e_obs; a.clip = h->cfg.clip_obs; a.eps = h->cfg.norm_epsilon; a.norm_obs = h->cfg.norm_obs;
+    HIPCHK(h, launch_norm_obs_apply(a, h->stream));
+    h->obs_par ^= 1;
+    return DRIL_OK;
+}
+// actions: device pointer (stored/raw policy actions; the kernels apply the adapters); rew_out/flags_out: device destinations
+int step_dev(dril_handle* h, const void* actions, float* rew_out, uint8_t* flags_out) {
+    const int E = h->cfg.n_envs;
+    HIPCHK(h, launch_env_step(h->cfg.env_kind, E, h->env_seed0, h->cfg.episode_len, h->cfg.fixed_length_episodes, h->cfg.action_start, actions,
+                              h->state, h->step_count, h->episode, h->gstep, h->e_rew, h->e_term, h->e_trunc, h->e_tobs, h->stream));
+    int nb = (E + 255) / 256; if (nb > h->rms_blocks) nb = h->rms_blocks;
+    const int upd = (h->cfg.norm_reward && h->cfg.norm_training) ? 1 : 0;
+    HIPCHK(h, launch_rew_partials(E, h->e_rew, h->disc_returns, h->cfg.norm_gamma, upd, h->rms_partials, nb, h->stream));
+    NormRewArgs a{};
+    a.E = E; a.D = h->D; a.update = upd; a.nblocks = nb; a.norm_obs = h->cfg.norm_obs; a.norm_reward = h->cfg.norm_reward;
+    a.rew_raw = h->e_rew; a.partials = h->rms_partials; a.in = h->ret_rms + h->ret_par; a.out = h->ret_rms + (h->ret_par ^ 1);
+    a.obs_stats = h->obs_rms + h->obs_par; a.rew_out = rew_out; a.disc_returns = h->disc_returns; a.term = h->e_term; a.trunc = h->e_trunc;
+    a.tobs = h->e_tobs; a.clip_obs = h->cfg.clip_obs; a.clip_reward = h->cfg.clip_reward; a.eps = h->cfg.norm_epsilon; a.flags_out = flags_out;
+    HIPCHK(h, launch_norm_rew_apply(a, h->stream));
+    h->ret_par ^= 1;
+    return DRIL_OK;
 }
 
 // one optimiser step on [pos0, pos0+count) of the current epoch order; all launches asynchronous
@@ -248,7 +281,6 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (cfg->hidden1 != cfg->hidden2 || cfg->hidden1 != 64) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden_dims: only [64,64] is built in this round");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad rank/world_size");
     if (cfg->batch_size % cfg->world_size != 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "batch_size must be divisible by world_size");
-    if (cfg->norm_obs || cfg->norm_reward) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "NormalizeWrapperEnv on device is not built yet");
     dril_handle* h = nullptr;
     try { h = new dril_handle(); } catch (...) { return fail(nullptr, DRIL_ERR_INVALID_ARG, "out of host memory"); }
     h->cfg = *cfg;
@@ -261,6 +293,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     h->N = (int64_t)cfg->n_envs * cfg->n_steps; h->lr = cfg->learning_rate;
     if (const char* e = std::getenv("DRIL_GRAD_LAYOUT")) h->grad_layout = std::atoi(e);
     if (const char* e = std::getenv("DRIL_FORCE_ALLREDUCE")) h->force_allreduce = std::atoi(e) != 0;
+    if (const char* e = std::getenv("DRIL_FORCE_STEPWISE")) h->force_stepwise = std::atoi(e) != 0;
     if (const char* e = std::getenv("DRIL_GRAD_PRIO")) h->grad_prio = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_SPLIT")) h->grad_split = std::atoi(e);
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
@@ -289,6 +322,9 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
 #endif
     CCHK(dmalloc(&h->e_obs, E * h->D)); CCHK(dmalloc(&h->e_rew, E)); CCHK(dmalloc(&h->e_tobs, E * h->D)); CCHK(dmalloc(&h->e_term, E));
     CCHK(dmalloc(&h->e_trunc, E)); CCHK(hipMalloc(&h->e_act, E * act_bytes_per(h)));
+    CCHK(dmalloc(&h->e_obs_raw, E * h->D)); CCHK(dmalloc(&h->obs_rms, 2)); CCHK(dmalloc(&h->ret_rms, 2)); CCHK(dmalloc(&h->rms_partials, (size_t)h->rms_blocks * 16));
+    { RmsState init[2]; for (auto& r : init) { for (int d = 0; d < 8; ++d) { r.mean[d] = 0.f; r.var[d] = 1.f; } r.count = 0; }   // RunningMeanStd{T}(shape): zeros, ones, 0 (normalizeWrapperEnv.jl:14-16)
+      CCHK(hipMemcpy(h->obs_rms, init, sizeof(init), hipMemcpyHostToDevice)); CCHK(hipMemcpy(h->ret_rms, init, sizeof(init), hipMemcpyHostToDevice)); }
     CCHK(hipMemsetAsync(h->params, 0, P * 4, h->stream)); CCHK(hipMemsetAsync(h->boot, 0, N * 4, h->stream));
     CCHK(hipMemsetAsync(h->flags, 0, N, h->stream)); CCHK(hipMemsetAsync(h->last_values, 0, E * 4, h->stream));
     CCHK(hipMemsetAsync(h->stop_flag, 0, 4, h->stream)); CCHK(hipMemsetAsync(h->nan_flag, 0, 4, h->stream));
@@ -308,7 +344,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
                     h->flags, h->last_values, h->noise_dev, h->perm_dev, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
-                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act};
+                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->obs_rms, h->ret_rms, h->rms_partials, h->dbg};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& p : h->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& p : h->prof_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -343,10 +379,11 @@ DRIL_EXPORT int32_t dril_env_reset(dril_handle* h, uint64_t seed) {
     return sync(h);
 }
 DRIL_EXPORT int32_t dril_env_observe(dril_handle* h, float* host_obs, int32_t update_stats) {
-    NEED(h); (void)update_stats;
+    NEED(h);
     if (!h->env_ready) return fail(h, DRIL_ERR_NOT_INITIALISED, "dril_env_observe before dril_env_reset");
     if (!host_obs) return fail(h, DRIL_ERR_INVALID_ARG, "null host_obs");
-    HIPCHK(h, launch_env_observe(h->cfg.env_kind, h->cfg.n_envs, h->state, h->e_obs, h->stream));
+    if (normalizing(h)) { int rc = observe_dev(h, update_stats != 0); if (rc) return rc; }
+    else HIPCHK(h, launch_env_observe(h->cfg.env_kind, h->cfg.n_envs, h->state, h->e_obs, h->stream));
     HIPCHK(h, hipMemcpyAsync(host_obs, h->e_obs, (size_t)h->cfg.n_envs * h->D * 4, hipMemcpyDeviceToHost, h->stream));
     return sync(h);
 }
@@ -356,9 +393,11 @@ DRIL_EXPORT int32_t dril_env_step(dril_handle* h, const void* actions, float* re
     if (!actions) return fail(h, DRIL_ERR_INVALID_ARG, "null actions");
     const size_t E = h->cfg.n_envs;
     HIPCHK(h, hipMemcpyAsync(h->e_act, actions, E * act_bytes_per(h), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, launch_env_step(h->cfg.env_kind, (int)E, h->env_seed0, h->cfg.episode_len, h->cfg.fixed_length_episodes, h->cfg.action_start,
-                              h->e_act, h->state, h->step_count, h->episode, h->gstep, h->e_rew, h->e_term, h->e_trunc, h->e_tobs, h->stream));
-    if (rewards) HIPCHK(h, hipMemcpyAsync(rewards, h->e_rew, E * 4, hipMemcpyDeviceToHost, h->stream));
+    float* rew_dev = h->e_rew;
+    if (normalizing(h)) { rew_dev = h->e_obs_raw; int rc = step_dev(h, h->e_act, rew_dev, nullptr); if (rc) return rc; }   // e_obs_raw doubles as scratch for the normalised rewards
+    else HIPCHK(h, launch_env_step(h->cfg.env_kind, (int)E, h->env_seed0, h->cfg.episode_len, h->cfg.fixed_length_episodes, h->cfg.action_start,
+                                   h->e_act, h->state, h->step_count, h->episode, h->gstep, h->e_rew, h->e_term, h->e_trunc, h->e_tobs, h->stream));
+    if (rewards) HIPCHK(h, hipMemcpyAsync(rewards, rew_dev, E * 4, hipMemcpyDeviceToHost, h->stream));
     if (terminated) HIPCHK(h, hipMemcpyAsync(terminated, h->e_term, E, hipMemcpyDeviceToHost, h->stream));
     if (truncated) HIPCHK(h, hipMemcpyAsync(truncated, h->e_trunc, E, hipMemcpyDeviceToHost, h->stream));
     if (terminal_obs) HIPCHK(h, hipMemcpyAsync(terminal_obs, h->e_tobs, E * h->D * 4, hipMemcpyDeviceToHost, h->stream));
@@ -376,11 +415,25 @@ DRIL_EXPORT int32_t dril_env_set_state(dril_handle* h, const float* state, const
     if (step_count) HIPCHK(h, hipMemcpyAsync(h->step_count, step_count, (size_t)h->cfg.n_envs * 4, hipMemcpyHostToDevice, h->stream));
     return sync(h);
 }
-DRIL_EXPORT int32_t dril_norm_get_stats(dril_handle* h, float*, float*, int64_t*, float*, float*, int64_t*) {
-    NEED(h); return fail(h, DRIL_ERR_UNSUPPORTED, "NormalizeWrapperEnv on device is not built yet");
+DRIL_EXPORT int32_t dril_norm_get_stats(dril_handle* h, float* obs_mean, float* obs_var, int64_t* obs_count, float* ret_mean, float* ret_var, int64_t* ret_count) {
+    NEED(h);
+    RmsState o, r;
+    HIPCHK(h, hipMemcpyAsync(&o, h->obs_rms + h->obs_par, sizeof(o), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&r, h->ret_rms + h->ret_par, sizeof(r), hipMemcpyDeviceToHost, h->stream));
+    int rc = sync(h); if (rc) return rc;
+    if (obs_mean) std::memcpy(obs_mean, o.mean, 4 * h->D); if (obs_var) std::memcpy(obs_var, o.var, 4 * h->D); if (obs_count) *obs_count = o.count;
+    if (ret_mean) *ret_mean = r.mean[0]; if (ret_var) *ret_var = r.var[0]; if (ret_count) *ret_count = r.count;
+    return DRIL_OK;
 }
-DRIL_EXPORT int32_t dril_norm_set_stats(dril_handle* h, const float*, const float*, int64_t, float, float, int64_t) {
-    NEED(h); return fail(h, DRIL_ERR_UNSUPPORTED, "NormalizeWrapperEnv on device is not built yet");
+DRIL_EXPORT int32_t dril_norm_set_stats(dril_handle* h, const float* obs_mean, const float* obs_var, int64_t obs_count, float ret_mean, float ret_var, int64_t ret_count) {
+    NEED(h);
+    if (!obs_mean || !obs_var) return fail(h, DRIL_ERR_INVALID_ARG, "null statistics");
+    RmsState o{}, r{};
+    for (int d = 0; d < 8; ++d) { o.mean[d] = d < h->D ? obs_mean[d] : 0.f; o.var[d] = d < h->D ? obs_var[d] : 1.f; r.mean[d] = 0.f; r.var[d] = 1.f; }
+    o.count = obs_count; r.mean[0] = ret_mean; r.var[0] = ret_var; r.count = ret_count;
+    HIPCHK(h, hipMemcpyAsync(h->obs_rms + h->obs_par, &o, sizeof(o), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->ret_rms + h->ret_par, &r, sizeof(r), hipMemcpyHostToDevice, h->stream));
+    return sync(h);
 }
 
 // ---- policy on host batches ----------------------------------------------------------------------
@@ -431,8 +484,42 @@ int compute_gae(dril_handle* h) {
     prof_end(h);
     return DRIL_OK;
 }
+// step-granular collect_trajectories (trajectory.jl:22-78) for wrapped envs: per-step launches on the handle's stream
+int collect_rollout_stepwise(dril_handle* h) {
+    const int E = h->cfg.n_envs, T = h->cfg.n_steps, D = h->D, A = h->A;
+    const size_t ab = act_bytes_per(h);
+    int rc = observe_dev(h, true); if (rc) return rc;                                      // new_obs = observe(env), trajectory.jl:32
+    for (int t = 0; t < T; ++t) {
+        const size_t k = (size_t)t * E;
+        const void* nz = h->noise_set ? (const void*)((const char*)h->noise_dev + k * (h->discrete ? 8 : 4 * (size_t)A)) : nullptr;
+        PolicyArgs p = policy_args(h, h->e_obs, E, nz, (char*)h->act + k * ab, h->val + k, h->logp + k, nullptr, 0);
+        p.gstep = h->gstep; p.env_seed0 = h->env_seed0; p.obs_out = h->obs + k * D;
+        HIPCHK(h, launch_policy(h->cfg.env_kind, h->cfg.hidden1, p, 8 * h->num_cus, h->stream));   // get_action_and_values, :41
+        rc = step_dev(h, (const char*)h->act + k * ab, h->rew + k, h->flags + k); if (rc) return rc;   // to_env + act!, :43-44
+        PolicyArgs b = policy_args(h, h->e_tobs, E, nullptr, nullptr, h->boot + k, nullptr, nullptr, 2);
+        b.only_where = h->e_trunc;
+        HIPCHK(h, launch_policy(h->cfg.env_kind, h->cfg.hidden1, b, 8 * h->num_cus, h->stream));   // V(terminal_observation), :57-61
+        rc = observe_dev(h, true); if (rc) return rc;                                       // new_obs = observe(env), :45
+    }
+    PolicyArgs l = policy_args(h, h->e_obs, E, nullptr, nullptr, h->last_values, nullptr, nullptr, 2);
+    HIPCHK(h, launch_policy(h->cfg.env_kind, h->cfg.hidden1, l, 8 * h->num_cus, h->stream));       // V(new_obs) for rollout-limited tails, :65-70
+    return DRIL_OK;
+}
+
 int collect_rollout(dril_handle* h, double* fps, bool do_sync) {
     if (!h->env_ready) return fail(h, DRIL_ERR_NOT_INITIALISED, "dril_collect_rollout before dril_env_reset");
+    if (normalizing(h) || h->force_stepwise) {
+        const auto t0s = std::chrono::steady_clock::now();
+        if (fps) HIPCHK(h, hipStreamSynchronize(h->stream));
+        prof_begin(h, DRIL_K_ROLLOUT);
+        int rcs = collect_rollout_stepwise(h);
+        prof_end(h);
+        if (rcs) return rcs;
+        if (fps) { HIPCHK(h, hipStreamSynchronize(h->stream)); const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0s).count(); *fps = (double)h->N / (dt > 0 ? dt : 1e-12); }
+        h->noise_set = false;
+        rcs = compute_gae(h); if (rcs) return rcs;
+        return do_sync ? sync(h) : DRIL_OK;
+    }
     RolloutArgs a{};
     a.params = h->params; a.state = h->state; a.step_count = h->step_count; a.episode = h->episode; a.gstep = h->gstep;
     a.obs = h->obs; a.act = h->act; a.rew = h->rew; a.logp = h->logp; a.val = h->val; a.boot = h->boot; a.flags = h->flags; a.last_values = h->last_values;

@@ -11,7 +11,24 @@ struct PolicyArgs {
     const float* params; const float* obs; int64_t B; const void* noise;
     void* actions; float* values; float* logp; float* entropy;
     int mode; int action_start; int log_std_off; uint64_t seed; uint32_t call_counter;
+    const uint32_t* gstep; uint64_t env_seed0;   // step-granular rollout: draw from the env-keyed Philox stream (same as rollout_kernel)
+    float* obs_out;                              // optional copy of the consumed observations (rollout buffer slice)
+    const uint8_t* only_where;                   // optional: waves with no flagged sample skip (bootstrap critic on truncated envs)
     NetOff actor, critic;
+};
+
+// RunningMeanStd of NormalizeWrapperEnv (normalizeWrapperEnv.jl:8-19); kept ping-pong so that every block of the
+// kernel that merges new batch moments reads the old statistics while block 0 writes the new ones
+struct RmsState { float mean[8]; float var[8]; long long count; };
+
+struct NormObsArgs {
+    int E, D, update, nblocks; const float* raw; const double* partials; const RmsState* in; RmsState* out;
+    float* obs_n; float clip, eps; int norm_obs;
+};
+struct NormRewArgs {
+    int E, D, update, nblocks, norm_obs, norm_reward; const float* rew_raw; const double* partials; const RmsState* in; RmsState* out;
+    const RmsState* obs_stats; float* rew_out; float* disc_returns; const uint8_t* term; const uint8_t* trunc;
+    float* tobs; float clip_obs, clip_reward, eps; uint8_t* flags_out;
 };
 
 struct RolloutArgs {
@@ -64,6 +81,10 @@ hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int
                            float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* rew, uint8_t* term, uint8_t* trunc,
                            float* tobs, hipStream_t s);
 hipError_t launch_policy(int kind, int hidden, const PolicyArgs& a, int max_blocks, hipStream_t s);
+hipError_t launch_obs_partials(int kind, int E, const float* state, float* raw, double* partials, int nblocks, hipStream_t s);
+hipError_t launch_norm_obs_apply(const NormObsArgs& a, hipStream_t s);
+hipError_t launch_rew_partials(int E, const float* rew_raw, float* disc_returns, float gamma, int update, double* partials, int nblocks, hipStream_t s);
+hipError_t launch_norm_rew_apply(const NormRewArgs& a, hipStream_t s);
 hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_t s);
 hipError_t launch_gae(int E, int T, float gamma, float lam, const float* rew, const float* val, const uint8_t* flags,
                       const float* boot, const float* last_values, float* adv, float* ret, hipStream_t s);

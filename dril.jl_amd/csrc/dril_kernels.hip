@@ -69,6 +69,114 @@ __global__ void env_step_kernel(int E, uint64_t seed0, int episode_len, int fixe
 }
 
 // =============================================================================================
+// NormalizeWrapperEnv on device (src/environment_wrappers/normalizeWrapperEnv.jl): batch moments over the env axis,
+// parallel-Welford merge (update_from_moments! :28-50), normalise + clip (:174-197).  Two launches per statistic:
+// *_partials (per-block f64 sums) and *_apply (every block folds the partials in the same order and merges; block 0
+// persists the new RunningMeanStd into the other half of the ping-pong state).
+// =============================================================================================
+__device__ __forceinline__ double block_sum_f64(double v, double* sh);
+
+template <int KIND>
+__global__ void obs_partials_kernel(int E, const float* __restrict__ state, float* __restrict__ raw, double* __restrict__ partials) {
+    constexpr int S = EnvSpec<KIND>::S, D = EnvSpec<KIND>::D;
+    __shared__ double sh[16];
+    double s[D], q[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { s[d] = 0; q[d] = 0; }
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        float st[S], o[D];
+#pragma unroll
+        for (int i = 0; i < S; ++i) st[i] = state[(size_t)e * S + i];
+        env_obs<KIND>(st, o);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { raw[(size_t)e * D + d] = o[d]; s[d] += o[d]; q[d] += (double)o[d] * o[d]; }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const double ss = block_sum_f64(s[d], sh), qq = block_sum_f64(q[d], sh);
+        if (threadIdx.x == 0) { partials[(size_t)blockIdx.x * 16 + 2 * d] = ss; partials[(size_t)blockIdx.x * 16 + 2 * d + 1] = qq; }
+    }
+}
+
+// update_from_moments! (normalizeWrapperEnv.jl:28-50) in the reference's f32 arithmetic
+__device__ __forceinline__ void rms_merge(float& mean, float& var, long long count, float bmean, float bvar, long long bcount) {
+    if (count == 0) { mean = bmean; var = bvar; }
+    else {
+        const long long tot = count + bcount;
+        const float delta = bmean - mean;
+        const float new_mean = mean + delta * (float)bcount / (float)tot;
+        const float m_a = var * (float)count, m_b = bvar * (float)bcount;
+        const float M2 = m_a + m_b + delta * delta * (float)count * (float)bcount / (float)tot;
+        mean = new_mean; var = M2 / (float)tot;
+    }
+}
+
+__global__ void norm_obs_apply_kernel(NormObsArgs a) {
+    __shared__ float s_mean[8], s_var[8];
+    if (threadIdx.x < a.D) {
+        const int d = threadIdx.x;
+        float mean = a.in->mean[d], var = a.in->var[d];
+        if (a.update) {
+            double s = 0, q = 0;
+            for (int b = 0; b < a.nblocks; ++b) { s += a.partials[(size_t)b * 16 + 2 * d]; q += a.partials[(size_t)b * 16 + 2 * d + 1]; }
+            const double bm = s / a.E; double bv = q / a.E - bm * bm; if (bv < 0) bv = 0;      // mean / var(corrected=false), :21-26
+            rms_merge(mean, var, a.in->count, (float)bm, (float)bv, a.E);
+        }
+        s_mean[d] = mean; s_var[d] = var;
+        if (blockIdx.x == 0) { a.out->mean[d] = mean; a.out->var[d] = var; if (d == 0) a.out->count = a.in->count + (a.update ? a.E : 0); }
+    }
+    __syncthreads();
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.E * a.D; i += gridDim.x * blockDim.x) {
+        const int d = i % a.D;
+        float v = a.raw[i];
+        if (a.norm_obs) { v = (v - s_mean[d]) / sqrtf(s_var[d] + a.eps); v = fminf(fmaxf(v, -a.clip), a.clip); }   // normalize_obs! :174-179
+        a.obs_n[i] = v;
+    }
+}
+
+__global__ void rew_partials_kernel(int E, const float* __restrict__ rew_raw, float* __restrict__ disc, float gamma, int update,
+                                    double* __restrict__ partials) {
+    __shared__ double sh[16];
+    double s = 0, q = 0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+        float r = disc[e];
+        if (update) { r = r * gamma + rew_raw[e]; disc[e] = r; }                        // update_reward_stats! :167-171
+        s += r; q += (double)r * r;
+    }
+    s = block_sum_f64(s, sh); q = block_sum_f64(q, sh);
+    if (threadIdx.x == 0) { partials[(size_t)blockIdx.x * 16] = s; partials[(size_t)blockIdx.x * 16 + 1] = q; }
+}
+
+__global__ void norm_rew_apply_kernel(NormRewArgs a) {
+    __shared__ float s_var;
+    if (threadIdx.x == 0) {
+        float mean = a.in->mean[0], var = a.in->var[0];
+        if (a.update) {
+            double s = 0, q = 0;
+            for (int b = 0; b < a.nblocks; ++b) { s += a.partials[(size_t)b * 16]; q += a.partials[(size_t)b * 16 + 1]; }
+            const double bm = s / a.E; double bv = q / a.E - bm * bm; if (bv < 0) bv = 0;
+            rms_merge(mean, var, a.in->count, (float)bm, (float)bv, a.E);
+        }
+        s_var = var;
+        if (blockIdx.x == 0) { a.out->mean[0] = mean; a.out->var[0] = var; a.out->count = a.in->count + (a.update ? a.E : 0); }
+    }
+    __syncthreads();
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.E; e += gridDim.x * blockDim.x) {
+        float r = a.rew_raw[e];
+        if (a.norm_reward) { r = r / sqrtf(s_var + a.eps); r = fminf(fmaxf(r, -a.clip_reward), a.clip_reward); }   // normalize_rewards! :188-197 (no mean subtraction)
+        a.rew_out[e] = r;
+        if (a.flags_out) a.flags_out[e] = (uint8_t)((a.term[e] ? 1 : 0) | (a.trunc[e] ? 2 : 0));
+        if (a.term[e] || a.trunc[e]) a.disc_returns[e] = 0.f;                                                    // :152-155
+        if (a.norm_obs && a.trunc[e]) {                                                                          // terminal_observation, :157-163
+            for (int d = 0; d < a.D; ++d) {
+                float v = (a.tobs[(size_t)e * a.D + d] - a.obs_stats->mean[d]) / sqrtf(a.obs_stats->var[d] + a.eps);
+                a.tobs[(size_t)e * a.D + d] = fminf(fmaxf(v, -a.clip_obs), a.clip_obs);
+            }
+        }
+    }
+}
+
+// =============================================================================================
 // distribution heads shared by policy_kernel / rollout_kernel / ppo_grad_kernel
 // =============================================================================================
 // Lux.softmax + Categorical: layer_forward.jl:141-149, categorical.jl:20-52
@@ -147,9 +255,14 @@ __global__ __launch_bounds__(256, 2) void policy_kernel(PolicyArgs a) {
         const int64_t b = tile * kTile + c;
         const bool valid = b < a.B;
         const int64_t bb = valid ? b : a.B - 1;
+        if (a.only_where && !__any(valid && a.only_where[bb] != 0)) continue;     // wave-uniform skip
         float xk[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; xk[s] = d < D ? a.obs[bb * D + d] : 0.f; }
+        if (a.obs_out && valid) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) a.obs_out[b * D + d] = xk[s]; }
+        }
         f32x16 h1[MT], h2[MT];
         float v[1];
         net_forward<D, H, H, 1>(lc, xk, h1, h2, v, lane);
@@ -163,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void policy_kernel(PolicyArgs a) {
             if (a.mode == 0) {
                 double u;
                 if (a.noise) u = ((const double*)a.noise)[bb];
+                else if (a.gstep) { const uint64_t k = a.env_seed0 + (uint64_t)bb; uint32_t r[4]; philox4x32_10((uint32_t)k, (uint32_t)(k >> 32), a.gstep[bb], 0, 1, 0, r); u = u01_f64(r[0], r[1]); }
                 else { uint32_t r[4]; philox4x32_10((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)bb, (uint32_t)(bb >> 32), 3, a.call_counter, r); u = u01_f64(r[0], r[1]); }
                 act = categorical_sample<A>(p, u);
                 if (valid && h == 0) ((int32_t*)a.actions)[b] = act + a.action_start;
@@ -179,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void policy_kernel(PolicyArgs a) {
                 for (int i = 0; i < A; ++i) {
                     float z;
                     if (a.noise) z = ((const float*)a.noise)[bb * A + i];
+                    else if (a.gstep) { const uint64_t k = a.env_seed0 + (uint64_t)bb; uint32_t r[4]; philox4x32_10((uint32_t)k, (uint32_t)(k >> 32), a.gstep[bb], 0, 1, (uint32_t)(i / 2), r); z = (i & 1) ? randn_f32(r[2], r[3]) : randn_f32(r[0], r[1]); }
                     else { uint32_t r[4]; philox4x32_10((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)bb, (uint32_t)(bb >> 32), 3 + 16 * (uint32_t)i, a.call_counter, r); z = randn_f32(r[0], r[1]); }
                     x[i] = out[i] + fexp(ls[i]) * z;
                     if (valid && h == 0) ((float*)a.actions)[b * A + i] = x[i];
@@ -895,6 +1010,26 @@ hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int
     const int blocks = (E + 255) / 256;
     if (kind == 0) env_step_kernel<0><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs);
     else env_step_kernel<1><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs);
+    return hipGetLastError();
+}
+
+hipError_t launch_obs_partials(int kind, int E, const float* state, float* raw, double* partials, int nblocks, hipStream_t s) {
+    if (kind == 0) obs_partials_kernel<0><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
+    else obs_partials_kernel<1><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
+    return hipGetLastError();
+}
+hipError_t launch_norm_obs_apply(const NormObsArgs& a, hipStream_t s) {
+    int blocks = (a.E * a.D + 255) / 256; if (blocks > 1024) blocks = 1024;
+    norm_obs_apply_kernel<<<blocks, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+hipError_t launch_rew_partials(int E, const float* rew_raw, float* disc_returns, float gamma, int update, double* partials, int nblocks, hipStream_t s) {
+    rew_partials_kernel<<<nblocks, 256, 0, s>>>(E, rew_raw, disc_returns, gamma, update, partials);
+    return hipGetLastError();
+}
+hipError_t launch_norm_rew_apply(const NormRewArgs& a, hipStream_t s) {
+    int blocks = (a.E + 255) / 256; if (blocks > 1024) blocks = 1024;
+    norm_rew_apply_kernel<<<blocks, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 

@@ -223,7 +223,7 @@ class Agent:
 # --------------------------------------------------------------------------------------------
 def make_config(env, n_envs: int, alg: PPO, layer: Optional[ActorCriticLayer] = None, *, seed: int = 42,
                 fixed_length_episodes: bool = False, device: int = 0, rank: int = 0, world_size: int = 1,
-                profile_events: bool = False) -> DrilConfig:
+                profile_events: bool = False, normalize: Optional[dict] = None) -> DrilConfig:
     c = capi.default_config(env.kind)
     c.n_envs, c.n_steps = n_envs, alg.n_steps
     if layer is not None:
@@ -244,6 +244,14 @@ def make_config(env, n_envs: int, alg: PPO, layer: Optional[ActorCriticLayer] = 
     c.batch_size, c.epochs, c.learning_rate = alg.batch_size, alg.epochs, alg.learning_rate
     c.seed, c.device, c.rank, c.world_size = seed, device, rank, world_size
     c.profile_events = int(profile_events)
+    if normalize is not None:   # NormalizeWrapperEnv kwargs, normalizeWrapperEnv.jl:71-80
+        c.norm_training = int(normalize.get("training", True))
+        c.norm_obs = int(normalize.get("norm_obs", True))
+        c.norm_reward = int(normalize.get("norm_reward", True))
+        c.clip_obs = normalize.get("clip_obs", 10.0)
+        c.clip_reward = normalize.get("clip_reward", 10.0)
+        c.norm_gamma = normalize.get("gamma", 0.99)
+        c.norm_epsilon = normalize.get("epsilon", 1e-8)
     return c
 
 
@@ -328,6 +336,17 @@ class Handle:
         st = np.ascontiguousarray(st, np.float32)
         sc = None if sc is None else np.ascontiguousarray(sc, np.int32)
         self._chk(self.lib.dril_env_set_state(self._h, self._p(st), self._p(sc)))
+
+    def norm_get_stats(self) -> dict:
+        """RunningMeanStd fields of the wrapper (normalizeWrapperEnv.jl:8-19)."""
+        om = np.empty(self.D, np.float32); ov = np.empty(self.D, np.float32)
+        oc, rc = C.c_int64(), C.c_int64(); rm, rv = C.c_float(), C.c_float()
+        self._chk(self.lib.dril_norm_get_stats(self._h, self._p(om), self._p(ov), C.byref(oc), C.byref(rm), C.byref(rv), C.byref(rc)))
+        return dict(obs_mean=om, obs_var=ov, obs_count=oc.value, ret_mean=rm.value, ret_var=rv.value, ret_count=rc.value)
+
+    def norm_set_stats(self, obs_mean, obs_var, obs_count, ret_mean, ret_var, ret_count):
+        om = np.ascontiguousarray(obs_mean, np.float32); ov = np.ascontiguousarray(obs_var, np.float32)
+        self._chk(self.lib.dril_norm_set_stats(self._h, self._p(om), self._p(ov), int(obs_count), float(ret_mean), float(ret_var), int(ret_count)))
 
     # policy on host batches
     def policy_forward(self, obs: np.ndarray, noise: Optional[np.ndarray] = None):
@@ -477,7 +496,7 @@ class DeviceParallelEnv:
                  rank: int = 0, world_size: int = 1, profile_events: bool = False):
         self.env, self.n_envs, self.seed = env, n_envs, seed
         self._kw = dict(fixed_length_episodes=fixed_length_episodes, device=device, rank=rank, world_size=world_size,
-                        profile_events=profile_events)
+                        profile_events=profile_events, normalize=None)
         self.handle: Optional[Handle] = None
         self._bound_key = None
         self._last_term = np.zeros(n_envs, bool)
@@ -485,7 +504,8 @@ class DeviceParallelEnv:
 
     # binding: one handle carries env + agent + alg state; (re)created when the alg/layer shape changes
     def bind(self, alg: PPO, layer: Optional[ActorCriticLayer] = None) -> Handle:
-        key = (tuple(sorted(asdict(alg).items())), None if layer is None else (tuple(layer.hidden_dims), layer.log_std_init))
+        key = (tuple(sorted(asdict(alg).items())), None if layer is None else (tuple(layer.hidden_dims), layer.log_std_init),
+               None if self._kw["normalize"] is None else tuple(sorted(self._kw["normalize"].items())))
         if self.handle is None or key != self._bound_key:
             if self.handle is not None:
                 self.handle.close()
@@ -528,6 +548,17 @@ class DeviceParallelEnv:
 
     def truncated(self):
         return self._last_trunc
+
+
+def NormalizeWrapperEnv(env: DeviceParallelEnv, *, training: bool = True, norm_obs: bool = True, norm_reward: bool = True,
+                        clip_obs: float = 10.0, clip_reward: float = 10.0, gamma: float = 0.99, epsilon: float = 1e-8) -> DeviceParallelEnv:
+    """NormalizeWrapperEnv(env; kwargs...) (normalizeWrapperEnv.jl:71-107).  On device the wrapper is a mode of the same
+    handle (running mean/std kernels fused around the env step), so this returns the env with the wrapper switched on."""
+    env._kw["normalize"] = dict(training=training, norm_obs=norm_obs, norm_reward=norm_reward, clip_obs=clip_obs,
+                                clip_reward=clip_reward, gamma=gamma, epsilon=epsilon)
+    if env.handle is not None:
+        env.handle.close(); env.handle = None
+    return env
 
 
 # --------------------------------------------------------------------------------------------

@@ -349,3 +349,92 @@ def test_rccl_plumbing_single_rank(pkg, oracle_mod, monkeypatch):
     assert sh.n_updates == so.n_updates and sh.loss == pytest.approx(so.loss, rel=1e-4)
     np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=2e-4, atol=3e-6)
     assert h.profile is not None
+
+
+@pytest.mark.parametrize("kind,flags", [(1, (1, 1)), (0, (1, 1)), (1, (1, 0)), (1, (0, 1))])
+def test_normalize_wrapper_rollout_matches_oracle(pkg, oracle_mod, kind, flags):
+    """NormalizeWrapperEnv on device (normalizeWrapperEnv.jl:21-50,123-197): running obs/return statistics (updated on EVERY
+    observe, including the double update at a rollout boundary), normalised + clipped obs and rewards, normalised
+    terminal_observation for the truncation bootstrap — vs the oracle's line-by-line restatement."""
+    capi = pkg._capi
+    E, T, L = 48, 30, 9
+    cfg = _cfg(pkg, kind, n_envs=E, n_steps=T, episode_len=L, batch_size=E * T // 2, epochs=1, norm_training=1, norm_obs=flags[0],
+               norm_reward=flags[1], clip_obs=5.0, clip_reward=2.0)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 31, 0.4); h.set_params(flat); o.set_params(flat)
+    h.env_reset(9); o.env_reset(9)
+    rng = np.random.default_rng(2)
+    for rollout in range(2):
+        noise = rng.random(E * T) if kind == 0 else rng.standard_normal((E * T, h.A)).astype(np.float32)
+        h.set_noise(noise); o.set_noise(noise)
+        h.collect_rollout(); o.collect_rollout()
+        sh = h.norm_get_stats(); om, ov, oc, rm, rv, rc = o.norm_stats()
+        assert (sh["obs_count"], sh["ret_count"]) == (oc, rc)
+        assert oc == (E * (T + 1) * (rollout + 1) if flags[0] else 0)            # stats update on every observe call (T+1 per rollout)
+        np.testing.assert_allclose(sh["obs_mean"], om, rtol=2e-5, atol=2e-6); np.testing.assert_allclose(sh["obs_var"], ov, rtol=1e-4, atol=1e-6)
+        assert sh["ret_mean"] == pytest.approx(rm, rel=1e-4, abs=1e-5) and sh["ret_var"] == pytest.approx(rv, rel=1e-4, abs=1e-5)
+        ah, ao = h.buffer(capi.BUF_ACTIONS).reshape(T, E, -1), o.buffer(capi.BUF_ACTIONS).reshape(T, E, -1)
+        ok = np.cumprod((ah == ao).all(axis=2), axis=0).astype(bool).all(axis=0) if kind == 0 else np.ones(E, bool)
+        assert ok.mean() >= 0.95
+        for which, tol in ((capi.BUF_OBSERVATIONS, 1e-4), (capi.BUF_VALUES, 2e-4), (capi.BUF_LOGPROBS, 2e-4), (capi.BUF_REWARDS, 2e-4),
+                           (capi.BUF_ADVANTAGES, 2e-3), (capi.BUF_RETURNS, 2e-3)):
+            a, b = h.buffer(which).reshape(T, E, -1), o.buffer(which).reshape(T, E, -1)
+            np.testing.assert_allclose(a[:, ok], b[:, ok], atol=tol, rtol=tol)
+        fh, fo = h.buffer(capi.BUF_FLAGS).reshape(T, E), o.buffer(capi.BUF_FLAGS).reshape(T, E)
+        np.testing.assert_array_equal(fh[:, ok], fo[:, ok])
+        tr = (fo & 2).astype(bool) & ok[None, :]
+        assert tr.any()
+        np.testing.assert_allclose(h.buffer(capi.BUF_BOOTSTRAP).reshape(T, E)[tr], o.buffer(capi.BUF_BOOTSTRAP).reshape(T, E)[tr], atol=2e-4, rtol=2e-4)
+        if flags[0]:
+            assert np.abs(h.buffer(capi.BUF_OBSERVATIONS)).max() <= 5.0 + 1e-6      # clip_obs
+        if flags[1]:
+            assert np.abs(h.buffer(capi.BUF_REWARDS)).max() <= 2.0 + 1e-6           # clip_reward
+        st, sc = h.env_get_state(); o.env_set_state(st, sc)
+
+
+def test_normalize_wrapper_env_verbs_and_training_flag(pkg, oracle_mod):
+    """observe/act! through the wrapper (normalizeWrapperEnv.jl:123-165); training=false freezes the statistics (:281-324 of the
+    reference's test file); dril_norm_set_stats round-trips (save/load, :261-297)."""
+    cfg = _cfg(pkg, 1, n_envs=100, n_steps=4, episode_len=6, batch_size=4, norm_training=1, norm_obs=1, norm_reward=1)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    h.env_reset(3); o.env_reset(3)
+    rng = np.random.default_rng(0)
+    for step in range(14):
+        np.testing.assert_allclose(h.env_observe(True), o.env_observe(True), atol=2e-5, rtol=2e-5)
+        a = rng.uniform(-2.5, 2.5, (100, 1)).astype(np.float32)
+        rh, th, uh, oh = h.env_step(a); ro, to, uo, oo = o.env_step(a)
+        np.testing.assert_allclose(rh, ro, atol=2e-5, rtol=2e-4); np.testing.assert_array_equal(uh, uo)
+        np.testing.assert_allclose(oh[uh], oo[uo], atol=2e-5, rtol=2e-5)            # normalised terminal_observation
+        st, sc = h.env_get_state(); o.env_set_state(st, sc)
+    s = h.norm_get_stats()
+    assert s["obs_count"] == 14 * 100 and s["ret_count"] == 14 * 100
+    # frozen statistics
+    cfg2 = _cfg(pkg, 1, n_envs=100, n_steps=4, episode_len=6, batch_size=4, norm_training=0, norm_obs=1, norm_reward=1)
+    h2 = pkg.Handle(cfg2); h2.env_reset(3)
+    h2.norm_set_stats(s["obs_mean"], s["obs_var"], s["obs_count"], s["ret_mean"], s["ret_var"], s["ret_count"])
+    before = h2.norm_get_stats()
+    h2.env_observe(True); h2.env_step(a); h2.env_observe(True)
+    after = h2.norm_get_stats()
+    assert before["obs_count"] == after["obs_count"] == 1400 and np.array_equal(before["obs_mean"], after["obs_mean"])
+    assert after["ret_var"] == before["ret_var"]
+
+
+def test_stepwise_path_equals_persistent_kernel(pkg, monkeypatch):
+    """the step-granular launch sequence and the fused persistent rollout_kernel are the same algorithm"""
+    capi = pkg._capi
+    cfg = _cfg(pkg, 0, n_envs=200, n_steps=40, episode_len=13, batch_size=400, epochs=1)
+    flat = _params(9155, 8, 0.4)
+    outs = []
+    for force in ("0", "1"):
+        monkeypatch.setenv("DRIL_FORCE_STEPWISE", force)
+        h = pkg.Handle(cfg); h.set_params(flat); h.env_reset(21); h.collect_rollout()
+        outs.append({w: h.buffer(w) for w in range(10)})
+        h.close()
+    for w in range(10):
+        if w in (capi.BUF_BOOTSTRAP,):
+            m = (outs[0][capi.BUF_FLAGS] & 2).astype(bool)
+            np.testing.assert_allclose(outs[0][w][m], outs[1][w][m], atol=1e-6)
+        elif w == capi.BUF_LAST_VALUES:
+            np.testing.assert_allclose(outs[0][w], outs[1][w], atol=1e-6)
+        else:
+            np.testing.assert_allclose(outs[0][w].astype(np.float64), outs[1][w].astype(np.float64), atol=1e-6)
