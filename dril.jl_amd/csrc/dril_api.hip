@@ -79,6 +79,8 @@ struct dril_handle {
     bool env_ready = false;
     unsigned long long* dbg = nullptr;
     bool force_allreduce = false, force_stepwise = false;
+    double *epoch_tables = nullptr, *epoch_stats = nullptr; int epoch_blocks = 512, epoch_nb_cap = 0;   // per-epoch advantage moments
+    float4* rec = nullptr;   // packed minibatch records (see pack_records_kernel)
     RmsState *obs_rms = nullptr, *ret_rms = nullptr; int obs_par = 0, ret_par = 0;   // ping-pong RunningMeanStd pairs
     double* rms_partials = nullptr; int rms_blocks = 256; float* e_obs_raw = nullptr;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
@@ -174,12 +176,14 @@ int step_dev(dril_handle* h, const void* actions, float* rew_out, uint8_t* flags
 // one optimiser step on [pos0, pos0+count) of the current epoch order; all launches asynchronous
 int ppo_step(dril_handle* h, const float* obs, const void* actions, const float* adv, const float* ret, const float* logp_old,
              const float* val_old, const int64_t* perm, int64_t pos0, int64_t count, int64_t N, uint64_t key, int bits,
-             float* step_stats, bool apply) {
+             float* step_stats, bool apply, const float4* rec = nullptr, const double* pre_stats = nullptr) {
     const int world = h->comm ? h->cfg.world_size : 1;
     const bool reduce = world > 1 || (h->comm && h->force_allreduce);   // force: exercise the RCCL path on one rank (tests)
     const int64_t tiles = (count + kTile - 1) / kTile;
     int G = (int)((tiles + 3) / 4); if (G > h->Gmax) G = h->Gmax; if (G < 1) G = 1;
-    if (h->cfg.normalize_advantage) {
+    const double* adv_stats = h->adv_stats;
+    if (h->cfg.normalize_advantage && pre_stats && !reduce) adv_stats = pre_stats;
+    else if (h->cfg.normalize_advantage) {
         MomentsArgs m{}; m.adv = adv; m.perm = perm; m.pos0 = pos0; m.count = count; m.N = N; m.idx_lo = 0; m.n_local = N;
         m.perm_key = key; m.perm_bits = bits; m.partials = h->adv_partials; m.stop_flag = h->stop_flag;
         int nb = (int)((count + 255) / 256); if (nb > h->adv_blocks) nb = h->adv_blocks; if (nb < 1) nb = 1;
@@ -192,7 +196,8 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     GradArgs g{};
     g.params = h->params; g.obs = obs; g.actions = actions; g.adv = adv; g.ret = ret; g.logp_old = logp_old; g.val_old = val_old;
     g.perm = perm; g.pos0 = pos0; g.count = count; g.N = N; g.idx_lo = 0; g.n_local = N; g.perm_key = key; g.perm_bits = bits;
-    g.adv_stats = h->adv_stats; g.invB = 1.0f / (float)(count * world);
+    g.rec = rec;
+    g.adv_stats = adv_stats; g.invB = 1.0f / (float)(count * world);
     g.clip_range = h->cfg.clip_range; g.ent_coef = h->cfg.ent_coef; g.vf_coef = h->cfg.vf_coef; g.clip_range_vf = h->cfg.clip_range_vf;
     g.has_clip_vf = h->cfg.has_clip_range_vf; g.normalize_adv = h->cfg.normalize_advantage; g.action_start = h->cfg.action_start;
     g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
@@ -314,6 +319,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(dmalloc(&h->obs, N * h->D)); CCHK(hipMalloc(&h->act, N * act_bytes_per(h))); CCHK(dmalloc(&h->rew, N)); CCHK(dmalloc(&h->adv, N));
     CCHK(dmalloc(&h->ret, N)); CCHK(dmalloc(&h->logp, N)); CCHK(dmalloc(&h->val, N)); CCHK(dmalloc(&h->boot, N)); CCHK(dmalloc(&h->flags, N));
     CCHK(dmalloc(&h->last_values, E));
+    if (!std::getenv("DRIL_NO_RECORDS")) CCHK(dmalloc(&h->rec, 2 * N));
     h->adv_blocks = 1024; CCHK(dmalloc(&h->adv_partials, 2 * (size_t)h->adv_blocks)); CCHK(dmalloc(&h->adv_stats, 4));
     h->ev_blocks = 1024; CCHK(dmalloc(&h->ev_partials, 4 * (size_t)h->ev_blocks));
     CCHK(dmalloc(&h->stop_flag, 1)); CCHK(dmalloc(&h->nan_flag, 1));
@@ -344,7 +350,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
                     h->flags, h->last_values, h->noise_dev, h->perm_dev, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
-                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->obs_rms, h->ret_rms, h->rms_partials, h->dbg};
+                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->obs_rms, h->ret_rms, h->rms_partials, h->dbg, h->rec, h->epoch_tables, h->epoch_stats};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& p : h->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& p : h->prof_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -612,13 +618,27 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
     if (total_steps > 0) HIPCHK(h, hipMemsetAsync(h->step_stats, 0, (size_t)total_steps * 16 * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(h->stop_flag, 0, 4, h->stream)); HIPCHK(h, hipMemsetAsync(h->nan_flag, 0, 4, h->stream));
     const int bits = perm_bits(N);
+    if (h->rec) HIPCHK(h, launch_pack_records(h->cfg.env_kind, N, h->obs, h->act, h->adv, h->logp, h->ret, h->rec, h->stream));
     int64_t step = 0;
     for (int ep = 0; ep < h->cfg.epochs; ++ep) {
         const uint64_t key = perm_key(h->cfg.seed + (uint64_t)h->cfg.rank, h->update_counter, ep);
         const int64_t* perm = h->perm_count ? h->perm_dev + (size_t)ep * N : nullptr;
+        const bool epoch_moments = h->cfg.normalize_advantage && !perm && nb >= 2 && nb <= 2048 && !std::getenv("DRIL_NO_EPOCH_MOMENTS");
+        if (epoch_moments) {
+            if (nb > h->epoch_nb_cap) {
+                if (h->epoch_tables) hipFree(h->epoch_tables); if (h->epoch_stats) hipFree(h->epoch_stats);
+                h->epoch_tables = nullptr; h->epoch_stats = nullptr;
+                HIPCHK(h, dmalloc(&h->epoch_tables, (size_t)h->epoch_blocks * 2 * nb)); HIPCHK(h, dmalloc(&h->epoch_stats, (size_t)3 * nb));
+                h->epoch_nb_cap = (int)nb;
+            }
+            prof_begin(h, DRIL_K_ADV_MOMENTS);
+            HIPCHK(h, launch_epoch_moments(h->adv, N, B, (int)nb, key, bits, h->epoch_tables, h->epoch_blocks, h->epoch_stats, h->stop_flag, h->stream));
+            prof_end(h);
+        }
         for (int64_t k = 0; k < nb; ++k, ++step) {
             const int64_t pos0 = k * B, count = (pos0 + B <= N) ? B : N - pos0;
-            int rc = ppo_step(h, h->obs, h->act, h->adv, h->ret, h->logp, h->val, perm, pos0, count, N, key, bits, h->step_stats + step * 16, true);
+            int rc = ppo_step(h, h->obs, h->act, h->adv, h->ret, h->logp, h->val, perm, pos0, count, N, key, bits, h->step_stats + step * 16, true, h->rec,
+                              epoch_moments ? h->epoch_stats + 3 * k : nullptr);
             if (rc) return rc;
         }
     }

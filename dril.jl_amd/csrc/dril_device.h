@@ -71,6 +71,40 @@ __host__ __device__ inline int64_t perm_index(int64_t p, int64_t n, uint64_t key
 }
 __host__ inline int perm_bits(int64_t n) { int b = 1; while (((int64_t)1 << b) < n) ++b; return b; }
 
+// inverse of mix_bij: every step is invertible on `bits`-bit words (xorshift-right: x = y ^ y>>s ^ y>>2s ...; odd multiply:
+// modular inverse; xor key).  Used to bin buffer indices by minibatch in ONE sequential pass per epoch.
+__host__ __device__ inline uint64_t unxorshift(uint64_t y, int s, int bits) {
+    uint64_t x = y;
+    for (int sh = s; sh < bits; sh += s) x ^= y >> sh;
+    return x;
+}
+__host__ __device__ constexpr uint64_t mul_inverse(uint64_t a) {   // Newton iteration mod 2^64, a odd
+    uint64_t x = a;
+    for (int i = 0; i < 6; ++i) x *= 2 - a * x;
+    return x;
+}
+__host__ __device__ inline uint64_t mix_bij_inv(uint64_t x, uint64_t key, int bits) {
+    const uint64_t mask = bits >= 64 ? ~0ull : (((uint64_t)1 << bits) - 1);
+    const int s = bits / 2 > 0 ? bits / 2 : 1;
+    const int s2 = s + 1 < bits ? s + 1 : s;
+    constexpr uint64_t I1 = mul_inverse(0x9E3779B97F4A7C15ull), I2 = mul_inverse(0xBF58476D1CE4E5B9ull);
+#pragma unroll
+    for (int r = 3; r >= 0; --r) {
+        x = unxorshift(x, s2, bits);
+        x = (x * I2) & mask;
+        x = unxorshift(x, s, bits);
+        x = ((x - 0xD1B54A32D192ED03ull) * I1) & mask;
+        x ^= (key >> (r * 13)) & mask;
+    }
+    return x;
+}
+// position in the epoch order of buffer index idx (inverse of perm_index; cycle walking inverts by walking backwards)
+__host__ __device__ inline int64_t perm_position(int64_t idx, int64_t n, uint64_t key, int bits) {
+    uint64_t x = (uint64_t)idx;
+    do { x = mix_bij_inv(x, key, bits); } while ((int64_t)x >= n);
+    return (int64_t)x;
+}
+
 // ---------------------------------------------------------------------------------------------
 // math
 // ---------------------------------------------------------------------------------------------

@@ -50,6 +50,7 @@ struct GradArgs {
     const float* params; const float* obs; const void* actions; const float* adv; const float* ret;
     const float* logp_old; const float* val_old;
     const int64_t* perm; int64_t pos0, count, N, idx_lo, n_local; uint64_t perm_key; int perm_bits;
+    const float4* rec;   // packed minibatch records [N][2] x float4: {obs0..3} {action bits, adv, logp_old, ret}; null = gather from the SoA buffers
     const double* adv_stats;
     float invB, clip_range, ent_coef, vf_coef, clip_range_vf;
     int has_clip_vf, normalize_adv, action_start, log_std_off;
@@ -89,8 +90,11 @@ hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_
 hipError_t launch_gae(int E, int T, float gamma, float lam, const float* rew, const float* val, const uint8_t* flags,
                       const float* boot, const float* last_values, float* adv, float* ret, hipStream_t s);
 hipError_t launch_adv_moments(const MomentsArgs& a, int nblocks, hipStream_t s);
+hipError_t launch_epoch_moments(const float* adv, int64_t N, int64_t B, int nb, uint64_t key, int bits, double* block_tables, int nblocks,
+                                double* table3, const int* stop_flag, hipStream_t s);
 hipError_t launch_moments_finalize(const double* partials, int nblocks, double* out3, double n_local, const int* stop_flag, hipStream_t s);
 hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t s);
+hipError_t launch_pack_records(int kind, int64_t N, const float* obs, const void* act, const float* adv, const float* logp, const float* ret, float4* rec, hipStream_t s);
 hipError_t launch_grad_reduce(const ReduceArgs& a, hipStream_t s);
 hipError_t launch_grad_norm(const float* flat, int P, double* norm_partials, const int* stop_flag, hipStream_t s);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);

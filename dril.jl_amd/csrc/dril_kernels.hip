@@ -481,6 +481,38 @@ __global__ void adv_moments_kernel(MomentsArgs a) {
     s = block_sum_f64(s, sh); q = block_sum_f64(q, sh);
     if (threadIdx.x == 0) { a.partials[2 * blockIdx.x] = s; a.partials[2 * blockIdx.x + 1] = q; }
 }
+// epoch_moments_kernel: advantage sums of ALL minibatches of one epoch in a single sequential pass over the buffer
+// (v1-v4 gathered adv[perm(p)] per optimiser step: 32 x 85 us of random 4-byte reads per epoch).  Each index is mapped back
+// to its position in the epoch order by the inverse bijection, binned by minibatch in LDS (ds_add_f64), one partial
+// table per block; epoch_moments_finalize_kernel folds the blocks in a fixed order.
+__global__ void epoch_moments_kernel(const float* __restrict__ adv, int64_t N, int64_t B, int nb, uint64_t key, int bits,
+                                     double* __restrict__ block_tables, const int* stop_flag) {
+    extern __shared__ double bins[];     // [nb][2]
+    if (*stop_flag) return;
+    for (int i = threadIdx.x; i < 2 * nb; i += blockDim.x) bins[i] = 0.0;
+    __syncthreads();
+    const int64_t per = (N + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < N ? lo + per : N;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const double x = adv[i];
+        const int64_t p = perm_position(i, N, key, bits);
+        const int k = (int)((uint64_t)p / (uint64_t)B);
+        atomicAdd(&bins[2 * k], x); atomicAdd(&bins[2 * k + 1], x * x);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * nb; i += blockDim.x) block_tables[(size_t)blockIdx.x * 2 * nb + i] = bins[i];
+}
+__global__ void epoch_moments_finalize_kernel(const double* __restrict__ block_tables, int nblocks, int nb, int64_t N, int64_t B,
+                                              double* __restrict__ table3, const int* stop_flag) {
+    if (*stop_flag) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    double s = 0, q = 0;
+    for (int b = 0; b < nblocks; ++b) { s += block_tables[(size_t)b * 2 * nb + 2 * i]; q += block_tables[(size_t)b * 2 * nb + 2 * i + 1]; }
+    const int64_t pos0 = (int64_t)i * B;
+    table3[3 * i] = s; table3[3 * i + 1] = q; table3[3 * i + 2] = (double)(pos0 + B <= N ? B : N - pos0);
+}
+
 __global__ void moments_finalize_kernel(const double* partials, int nblocks, double* out3, double n_local, const int* stop_flag) {
     __shared__ double sh[16];
     if (*stop_flag) return;
@@ -510,12 +542,29 @@ enum { HEAD_CATEGORICAL = 0, HEAD_GAUSSIAN = 1, HEAD_VALUE = 2 };
 #define STAMP(k) do { } while (0)
 #endif
 
+// pack_records_kernel: the six per-sample fields the loss reads (ppo.jl:366-371) as one 32-byte record, so that a
+// minibatch gather is ONE 16-byte load per lane (the two half-waves of a sample fetch the two halves of its record = one
+// 32-B sector) instead of five scattered 4-byte loads (v1-v4: FETCH 1.6-3.1 GB per launch vs 0.22 GB algorithmic).
+template <int KIND>
+__global__ void pack_records_kernel(int64_t N, const float* __restrict__ obs, const void* __restrict__ act, const float* __restrict__ adv,
+                                    const float* __restrict__ logp, const float* __restrict__ ret, float4* __restrict__ rec) {
+    constexpr int D = EnvSpec<KIND>::D;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < D; ++d) o[d] = obs[n * D + d];
+        const float a = EnvSpec<KIND>::discrete ? __int_as_float(((const int32_t*)act)[n]) : ((const float*)act)[n];
+        rec[2 * n] = make_float4(o[0], o[1], o[2], o[3]);
+        rec[2 * n + 1] = make_float4(a, adv[n], logp[n], ret[n]);
+    }
+}
+
 // one lane's share of a minibatch tile (DataLoader gather, ppo.jl:188-195).  Loaded one tile AHEAD of its use so the
 // random-gather latency (~2 us under load, fully exposed in v1: 23 % of wave time in s_waitcnt) hides under the
 // previous tile's MFMAs; the loop body issues no other vector-memory op, so the loads stay in flight until first use.
-template <int O> struct TileIn { float xk[2]; float s0, s1; int act; float xa[O]; bool valid; };
+template <int O> struct TileIn { float xk[2]; float s0, s1; int act; float xa[O]; bool valid; float4 raw; };
 
-template <int KIND, int O, int HEAD>
+template <int KIND, int O, int HEAD, bool REC>
 __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64_t ntiles, int c, int h, TileIn<O>& t) {
     constexpr int D = EnvSpec<KIND>::D;
     const bool live = tile < ntiles;
@@ -526,9 +575,15 @@ __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64
     const int64_t li = gidx - a.idx_lo;
     t.valid = inb && li >= 0 && li < a.n_local;
     const int64_t idx = t.valid ? li : 0;
+    t.act = 0; t.s0 = 0.f; t.s1 = 0.f;
+    if (REC) {
+        // lane (sample, h) loads half h of the record; t.raw is exchanged between the half-waves at first use (unpack_tile)
+        t.raw = a.rec[2 * idx + h];
+        if (HEAD == HEAD_VALUE && a.has_clip_vf) t.s1 = a.val_old[idx];
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; t.xk[s] = d < D ? a.obs[idx * D + d] : 0.f; }
-    t.act = 0; t.s0 = 0.f; t.s1 = 0.f;
     if (HEAD == HEAD_VALUE) { t.s0 = a.ret[idx]; t.s1 = a.has_clip_vf ? a.val_old[idx] : 0.f; }
     else {
         t.s0 = a.adv[idx]; t.s1 = a.logp_old[idx];
@@ -537,6 +592,27 @@ __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64
 #pragma unroll
             for (int o = 0; o < O; ++o) t.xa[o] = ((const float*)a.actions)[idx * O + o];
         }
+    }
+}
+
+// exchange the two record halves between the half-waves: v_permlane32_swap(a, b) swaps a[32..63] with b[0..31], so with
+// a = b = v the results are {lo-half value in every lane, hi-half value in every lane}
+template <int KIND, int O, int HEAD, bool REC>
+__device__ __forceinline__ void unpack_tile(const GradArgs& a, int h, TileIn<O>& t) {
+    if (!REC) return;
+    float lo[4], hi[4];
+    const float v[4] = {t.raw.x, t.raw.y, t.raw.z, t.raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned u = __float_as_uint(v[i]);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        lo[i] = __uint_as_float(r[0]); hi[i] = __uint_as_float(r[1]);
+    }
+    t.xk[0] = h ? lo[1] : lo[0]; t.xk[1] = h ? lo[3] : lo[2];      // xk[s] = obs[2s + h]
+    if (HEAD == HEAD_VALUE) t.s0 = hi[3];
+    else {
+        t.s0 = hi[1]; t.s1 = hi[2];
+        if (HEAD == HEAD_CATEGORICAL) t.act = __float_as_int(hi[0]) - a.action_start; else t.xa[0] = hi[0];
     }
 }
 
@@ -551,7 +627,7 @@ template <int D, int H, int O> struct GradScratch {
     static constexpr int SIZE = ZI + O * kTS;
 };
 
-template <int KIND, int H, int O, int HEAD>
+template <int KIND, int H, int O, int HEAD, bool REC>
 __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
     constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
     using L = NetLds<D, H, H, O>;
@@ -611,7 +687,9 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
     // static priority experiment: co-resident workgroups (g of the actor, g of the critic) get opposite priorities;
     // the high-priority half of each net takes split_pct % of the tiles (deterministic partition)
     int64_t tile0 = 0, ntiles = ntiles_all, tstride = (int64_t)a.G * 4, first = (int64_t)g * 4 + wave;
-    if (a.prio && a.G >= 2 && (a.G & 1) == 0) {
+    if (a.prio == 2) { if (HEAD == HEAD_VALUE) __builtin_amdgcn_s_setprio(1); }          // younger (second-dispatched) workgroups only
+    else if (a.prio == 3) { if (HEAD != HEAD_VALUE) __builtin_amdgcn_s_setprio(1); }
+    else if (a.prio && a.G >= 2 && (a.G & 1) == 0) {
         const bool hi = ((g & 1) == 0) == (HEAD != HEAD_VALUE);
         const int64_t nh = ntiles_all * a.split_pct / 100;
         tile0 = hi ? 0 : nh; ntiles = hi ? nh : ntiles_all;
@@ -620,13 +698,14 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
     }
     TileIn<O> cur, nxt;
     int64_t tile = first;
-    if (tile < ntiles) load_tile<KIND, O, HEAD>(a, tile, ntiles, c, h, cur);
+    if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
 #ifdef DRIL_STAMPS
     unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
 #endif
     for (; tile < ntiles; tile += tstride) {
-        load_tile<KIND, O, HEAD>(a, tile + tstride, ntiles, c, h, nxt);      // prefetch the next tile's gathers
+        load_tile<KIND, O, HEAD, REC>(a, tile + tstride, ntiles, c, h, nxt);      // prefetch the next tile's gathers
+        unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
         const bool valid = cur.valid;
         float xk[2] = {cur.xk[0], cur.xk[1]};
         STAMP(0);
@@ -852,14 +931,14 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
     for (int i = tid; i < SL; i += blockDim.x) slab[i] = red[i];
 }
 
-template <int KIND, int H>
+template <int KIND, int H, bool REC>
 __global__ __launch_bounds__(256, 2) void ppo_grad_kernel(GradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (*a.stop_flag) return;
     constexpr int A = EnvSpec<KIND>::A;
     const bool actor = a.layout ? (blockIdx.x < (unsigned)a.G) : ((blockIdx.x & 1) == 0);
-    if (actor) grad_body<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN>(a, smem);
-    else grad_body<KIND, H, 1, HEAD_VALUE>(a, smem);
+    if (actor) grad_body<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN, REC>(a, smem);
+    else grad_body<KIND, H, 1, HEAD_VALUE, REC>(a, smem);
 }
 
 // =============================================================================================
@@ -1074,24 +1153,38 @@ hipError_t launch_adv_moments(const MomentsArgs& a, int nblocks, hipStream_t s) 
     adv_moments_kernel<<<nblocks, 256, 0, s>>>(a);
     return hipGetLastError();
 }
+hipError_t launch_epoch_moments(const float* adv, int64_t N, int64_t B, int nb, uint64_t key, int bits, double* block_tables, int nblocks,
+                                double* table3, const int* stop_flag, hipStream_t s) {
+    epoch_moments_kernel<<<nblocks, 256, (size_t)2 * nb * sizeof(double), s>>>(adv, N, B, nb, key, bits, block_tables, stop_flag);
+    epoch_moments_finalize_kernel<<<(nb + 63) / 64, 64, 0, s>>>(block_tables, nblocks, nb, N, B, table3, stop_flag);
+    return hipGetLastError();
+}
 hipError_t launch_moments_finalize(const double* partials, int nblocks, double* out3, double n_local, const int* stop_flag, hipStream_t s) {
     moments_finalize_kernel<<<1, 256, 0, s>>>(partials, nblocks, out3, n_local, stop_flag);
     return hipGetLastError();
 }
 
 hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t s) {
-#define CALL(K, HH)                                                                                           \
+#define CALLR(K, HH, R)                                                                                       \
     {                                                                                                         \
         const size_t lds = grad_lds_bytes<K, HH>();                                                           \
-        hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<K, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<K, HH, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                        \
-        ppo_grad_kernel<K, HH><<<2 * a.G, 256, lds, s>>>(a);                                                  \
+        ppo_grad_kernel<K, HH, R><<<2 * a.G, 256, lds, s>>>(a);                                               \
     }
+#define CALL(K, HH) { if (a.rec) CALLR(K, HH, true) else CALLR(K, HH, false) }
     DRIL_DISPATCH(kind, hidden, CALL);
 #undef CALL
+#undef CALLR
     return hipGetLastError();
 }
 
+hipError_t launch_pack_records(int kind, int64_t N, const float* obs, const void* act, const float* adv, const float* logp, const float* ret, float4* rec, hipStream_t s) {
+    int blocks = (int)((N + 255) / 256); if (blocks > 8192) blocks = 8192;
+    if (kind == 0) pack_records_kernel<0><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
+    else pack_records_kernel<1><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
+    return hipGetLastError();
+}
 hipError_t launch_grad_reduce(const ReduceArgs& a, hipStream_t s) {
     grad_reduce_kernel<<<(a.P + 31) / 32, 1024, 0, s>>>(a);
     return hipGetLastError();
