@@ -92,7 +92,8 @@ def main() -> None:
     env = pkg.CartPoleEnv(max_steps=500)
     alg = pkg.PPO(n_steps=T, batch_size=B_global, epochs=args.epochs)
     layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space())
-    cfg = pkg.make_config(env, E, alg, layer, seed=42, fixed_length_episodes=True, device=local_rank, rank=rank, world_size=world,
+    device = int(os.environ.get("DRIL_DEVICE_OVERRIDE", local_rank))   # debugging aid only (several ranks on one card)
+    cfg = pkg.make_config(env, E, alg, layer, seed=42, fixed_length_episodes=True, device=device, rank=rank, world_size=world,
                           profile_events=not args.no_events)
     h = pkg.Handle(cfg)
     h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(42))))   # random-init weights of the named architecture
