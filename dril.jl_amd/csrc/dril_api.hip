@@ -80,6 +80,7 @@ struct dril_handle {
     unsigned long long* dbg = nullptr;
     bool force_allreduce = false, force_stepwise = false;
     double *epoch_tables = nullptr, *epoch_stats = nullptr; int epoch_blocks = 512, epoch_nb_cap = 0;   // per-epoch advantage moments
+    float *w2a_actor = nullptr, *w2ta_actor = nullptr, *w2a_critic = nullptr, *w2ta_critic = nullptr; bool wide = false, wimg_dirty = true;   // wide nets (H > 64)
     float4* rec = nullptr;   // packed minibatch records (see pack_records_kernel)
     RmsState *obs_rms = nullptr, *ret_rms = nullptr; int obs_par = 0, ret_par = 0;   // ping-pong RunningMeanStd pairs
     double* rms_partials = nullptr; int rms_blocks = 256; float* e_obs_raw = nullptr;
@@ -133,12 +134,21 @@ int rccl_allreduce(dril_handle* h, void* buf, size_t count, int dtype) {
 bool normalizing(const dril_handle* h) { return h->cfg.norm_obs || h->cfg.norm_reward; }
 size_t act_bytes_per(const dril_handle* h) { return h->discrete ? 4 : 4 * (size_t)h->A; }
 
+// wide nets: (re)build the pre-tiled W2 / W2' images after every parameter change (enqueued on the handle's stream)
+int ensure_wimg(dril_handle* h) {
+    if (!h->wide || !h->wimg_dirty) return DRIL_OK;
+    HIPCHK(h, launch_build_wimg(h->params, h->actor, h->cfg.hidden1, h->w2a_actor, h->w2ta_actor, h->stream));
+    HIPCHK(h, launch_build_wimg(h->params, h->critic, h->cfg.hidden1, h->w2a_critic, h->w2ta_critic, h->stream));
+    h->wimg_dirty = false;
+    return DRIL_OK;
+}
+
 PolicyArgs policy_args(dril_handle* h, const float* obs, int64_t B, const void* noise, void* actions, float* values, float* logp,
                        float* entropy, int mode) {
     PolicyArgs a{};
     a.params = h->params; a.obs = obs; a.B = B; a.noise = noise; a.actions = actions; a.values = values; a.logp = logp; a.entropy = entropy;
     a.mode = mode; a.action_start = h->cfg.action_start; a.log_std_off = h->log_std_off; a.seed = h->cfg.seed; a.call_counter = h->policy_calls;
-    a.actor = h->actor; a.critic = h->critic;
+    a.actor = h->actor; a.critic = h->critic; a.w2a_actor = h->w2a_actor; a.w2a_critic = h->w2a_critic;
     return a;
 }
 
@@ -180,7 +190,8 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     const int world = h->comm ? h->cfg.world_size : 1;
     const bool reduce = world > 1 || (h->comm && h->force_allreduce);   // force: exercise the RCCL path on one rank (tests)
     const int64_t tiles = (count + kTile - 1) / kTile;
-    int G = (int)((tiles + 3) / 4); if (G > h->Gmax) G = h->Gmax; if (G < 1) G = 1;
+    int G = h->wide ? (int)(tiles < h->Gmax ? tiles : h->Gmax) : (int)((tiles + 3) / 4); if (G > h->Gmax) G = h->Gmax; if (G < 1) G = 1;
+    { int rcw = ensure_wimg(h); if (rcw) return rcw; }
     const double* adv_stats = h->adv_stats;
     if (h->cfg.normalize_advantage && pre_stats && !reduce) adv_stats = pre_stats;
     else if (h->cfg.normalize_advantage) {
@@ -196,7 +207,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     GradArgs g{};
     g.params = h->params; g.obs = obs; g.actions = actions; g.adv = adv; g.ret = ret; g.logp_old = logp_old; g.val_old = val_old;
     g.perm = perm; g.pos0 = pos0; g.count = count; g.N = N; g.idx_lo = 0; g.n_local = N; g.perm_key = key; g.perm_bits = bits;
-    g.rec = rec;
+    g.rec = rec; g.w2a_actor = h->w2a_actor; g.w2ta_actor = h->w2ta_actor; g.w2a_critic = h->w2a_critic; g.w2ta_critic = h->w2ta_critic;
     g.adv_stats = adv_stats; g.invB = 1.0f / (float)(count * world);
     g.clip_range = h->cfg.clip_range; g.ent_coef = h->cfg.ent_coef; g.vf_coef = h->cfg.vf_coef; g.clip_range_vf = h->cfg.clip_range_vf;
     g.has_clip_vf = h->cfg.has_clip_range_vf; g.normalize_adv = h->cfg.normalize_advantage; g.action_start = h->cfg.action_start;
@@ -227,7 +238,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     prof_begin(h, DRIL_K_ADAM);
     HIPCHK(h, launch_adam(ad, h->stream));
     prof_end(h);
-    h->adam_steps += 1;
+    h->adam_steps += 1; h->wimg_dirty = true;
     return DRIL_OK;
 }
 
@@ -283,7 +294,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (cfg->abi_version != DRIL_ABI_VERSION) return fail(nullptr, DRIL_ERR_INVALID_ARG, "abi_version mismatch");
     if (cfg->env_kind != DRIL_ENV_CARTPOLE && cfg->env_kind != DRIL_ENV_PENDULUM) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
     if (cfg->n_envs < 1 || cfg->n_steps < 1 || cfg->epochs < 0 || cfg->batch_size < 1) return fail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs/n_steps/batch_size must be positive");
-    if (cfg->hidden1 != cfg->hidden2 || cfg->hidden1 != 64) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden_dims: only [64,64] is built in this round");
+    if (cfg->hidden1 != cfg->hidden2 || (cfg->hidden1 != 64 && cfg->hidden1 != 256)) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden_dims: [64,64] and [256,256] are built");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad rank/world_size");
     if (cfg->batch_size % cfg->world_size != 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "batch_size must be divisible by world_size");
     dril_handle* h = nullptr;
@@ -312,7 +323,9 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(dmalloc(&h->flat, P + 8)); CCHK(dmalloc(&h->norm_out, 1));
     h->n_norm_partials = (int)((P + 31) / 32); CCHK(dmalloc(&h->norm_partials, h->n_norm_partials));
     h->slab_a = slab_size_actor(cfg->env_kind, cfg->hidden1); h->slab_c = slab_size_critic(cfg->env_kind, cfg->hidden1);
-    h->Gmax = h->num_cus;   // 2 workgroups per CU (one actor + one critic), 4 waves each => 2 waves per SIMD
+    h->wide = cfg->hidden1 > 64;
+    h->Gmax = h->wide ? (h->num_cus / 2 > 0 ? h->num_cus / 2 : 1) : h->num_cus;   // [64,64]: 2 workgroups per CU (actor + critic), 4 waves each; wide: 1 workgroup of H/32 waves per CU
+    if (h->wide) { const size_t hh = (size_t)cfg->hidden1 * cfg->hidden1; CCHK(dmalloc(&h->w2a_actor, hh)); CCHK(dmalloc(&h->w2ta_actor, hh)); CCHK(dmalloc(&h->w2a_critic, hh)); CCHK(dmalloc(&h->w2ta_critic, hh)); }
     CCHK(dmalloc(&h->slabs_a, (size_t)h->Gmax * h->slab_a)); CCHK(dmalloc(&h->slabs_c, (size_t)h->Gmax * h->slab_c));
     CCHK(dmalloc(&h->state, E * h->S)); CCHK(dmalloc(&h->step_count, E)); CCHK(dmalloc(&h->episode, E)); CCHK(dmalloc(&h->gstep, E));
     CCHK(dmalloc(&h->disc_returns, E));
@@ -350,7 +363,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
                     h->flags, h->last_values, h->noise_dev, h->perm_dev, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
-                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->obs_rms, h->ret_rms, h->rms_partials, h->dbg, h->rec, h->epoch_tables, h->epoch_stats};
+                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->obs_rms, h->ret_rms, h->rms_partials, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& p : h->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& p : h->prof_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -367,7 +380,7 @@ DRIL_EXPORT int64_t dril_param_count(const dril_handle* h) { return h ? h->P : -
 
 DRIL_EXPORT int32_t dril_set_params(dril_handle* h, const float* flat, size_t n) {
     NEED(h); if (!flat || n != (size_t)h->P) return fail(h, DRIL_ERR_INVALID_ARG, "dril_set_params: n != dril_param_count");
-    HIPCHK(h, hipMemcpyAsync(h->params, flat, n * 4, hipMemcpyHostToDevice, h->stream)); return sync(h);
+    HIPCHK(h, hipMemcpyAsync(h->params, flat, n * 4, hipMemcpyHostToDevice, h->stream)); h->wimg_dirty = true; return sync(h);
 }
 DRIL_EXPORT int32_t dril_get_params(dril_handle* h, float* flat, size_t n) {
     NEED(h); if (!flat || n != (size_t)h->P) return fail(h, DRIL_ERR_INVALID_ARG, "dril_get_params: n != dril_param_count");
@@ -457,6 +470,7 @@ int policy_host(dril_handle* h, const float* obs, int64_t B, const void* noise, 
     PCHK(hipMemcpyAsync(d_obs, obs, (size_t)B * h->D * 4, hipMemcpyHostToDevice, h->stream));
     if (noise) { PCHK(hipMalloc(&d_noise, nb)); PCHK(hipMemcpyAsync(d_noise, noise, nb, hipMemcpyHostToDevice, h->stream)); }
     if (actions_in) PCHK(hipMemcpyAsync(d_act, actions, ab, hipMemcpyHostToDevice, h->stream));
+    { int rcw = ensure_wimg(h); if (rcw) { cleanup(); return rcw; } }
     PolicyArgs a = policy_args(h, d_obs, B, d_noise, d_act, d_val, d_lp, d_ent, mode);
     PCHK(launch_policy(h->cfg.env_kind, h->cfg.hidden1, a, 8 * h->num_cus, h->stream));
     h->policy_calls += 1;
@@ -514,6 +528,7 @@ int collect_rollout_stepwise(dril_handle* h) {
 
 int collect_rollout(dril_handle* h, double* fps, bool do_sync) {
     if (!h->env_ready) return fail(h, DRIL_ERR_NOT_INITIALISED, "dril_collect_rollout before dril_env_reset");
+    { int rcw = ensure_wimg(h); if (rcw) return rcw; }
     if (normalizing(h) || h->force_stepwise) {
         const auto t0s = std::chrono::steady_clock::now();
         if (fps) HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -532,6 +547,7 @@ int collect_rollout(dril_handle* h, double* fps, bool do_sync) {
     a.noise = h->noise_set ? h->noise_dev : nullptr;
     a.E = h->cfg.n_envs; a.T = h->cfg.n_steps; a.episode_len = h->cfg.episode_len; a.fixed_len = h->cfg.fixed_length_episodes;
     a.action_start = h->cfg.action_start; a.log_std_off = h->log_std_off; a.env_seed0 = h->env_seed0; a.actor = h->actor; a.critic = h->critic;
+    a.w2a_actor = h->w2a_actor; a.w2a_critic = h->w2a_critic;
     const auto t0 = std::chrono::steady_clock::now();
     if (fps) HIPCHK(h, hipStreamSynchronize(h->stream));
     prof_begin(h, DRIL_K_ROLLOUT);
@@ -742,7 +758,7 @@ DRIL_EXPORT int32_t dril_apply_gradients(dril_handle* h, const float* grads, siz
     ad.has_max_grad_norm = h->cfg.has_max_grad_norm; ad.has_target_kl = 0; ad.use_stats = 0; ad.step_stats = nullptr; ad.norm_out = h->norm_out;
     ad.nan_flag = h->nan_flag; ad.stop_flag = h->stop_flag; ad.stop_flag_w = h->stop_flag;
     HIPCHK(h, launch_adam(ad, h->stream));
-    h->adam_steps += 1;
+    h->adam_steps += 1; h->wimg_dirty = true;
     float norm = 0; int nan = 0;
     HIPCHK(h, hipMemcpyAsync(&norm, h->norm_out, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&nan, h->nan_flag, 4, hipMemcpyDeviceToHost, h->stream));

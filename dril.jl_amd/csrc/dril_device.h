@@ -374,6 +374,76 @@ __device__ __forceinline__ void net_forward(const float* __restrict__ lds, const
     dense_out<H2 / 32, O, H2>(lds + L::W3S, lds + L::B3, h2, out, lane);
 }
 
+// ---- wide nets (H > 64): W2 (H*H*4 bytes = 256 KB at H = 256) does not fit LDS next to anything else, so the two
+// H x H operand streams live in global memory PRE-TILED in MFMA A-operand order, [(mo*MT + mi)*4 + q][lane][4]: one
+// wave-instruction reads 1 KiB contiguous and the image (0.5 MB per net) stays L2-resident.  Small parts stay in LDS.
+template <int D, int H, int O> struct NetLdsSmall {
+    static constexpr int DP = 4, OP = (O + 3) / 4 * 4;
+    static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, END = B3 + OP;
+};
+template <int D, int H, int O>
+__device__ inline void stage_net_small(float* lds, const float* __restrict__ P, NetOff n, int tid, int nthreads) {
+    using L = NetLdsSmall<D, H, O>;
+    for (int i = tid; i < L::DP * H; i += nthreads) { const int o = i % H, k = i / H; lds[L::W1T + k * H + o] = k < D ? P[n.w1 + o + k * H] : 0.0f; }
+    for (int i = tid; i < H; i += nthreads) { lds[L::B1 + i] = P[n.b1 + i]; lds[L::B2 + i] = P[n.b2 + i]; }
+    for (int i = tid; i < O * H; i += nthreads) { const int o = i % O, k = i / O; lds[L::W3S + o * H + k] = P[n.w3 + i]; }
+    for (int i = tid; i < L::OP; i += nthreads) lds[L::B3 + i] = i < O ? P[n.b3 + i] : 0.0f;
+}
+// one output m-tile of Y = W * X with W streamed from the pre-tiled global image
+template <int MT, bool BIAS>
+__device__ __forceinline__ f32x16 dense_tile_global(const float* __restrict__ wimg, const float* __restrict__ bias, const f32x16 (&X)[MT], int mo, int lane) {
+    const int h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (BIAS) b = *reinterpret_cast<const f32x4*>(bias + 32 * mo + 8 * q + 4 * h);
+        acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+    }
+    const float* base = wimg + ((size_t)mo * MT * 4 * 64 + lane) * 4;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(base + (size_t)(mi * 4 + q) * 256);
+            acc = mfma32(a[0], X[mi][4 * q + 0], acc);
+            acc = mfma32(a[1], X[mi][4 * q + 1], acc);
+            acc = mfma32(a[2], X[mi][4 * q + 2], acc);
+            acc = mfma32(a[3], X[mi][4 * q + 3], acc);
+        }
+    }
+    return acc;
+}
+// forward of a wide net for one 32-sample tile: h1 stays in registers (H/2 VGPRs), h2 is consumed m-tile by m-tile
+template <int D, int H, int O>
+__device__ __forceinline__ void net_forward_wide(const float* __restrict__ lds, const float* __restrict__ w2a, const float (&xk)[2],
+                                                 float (&out)[O], int lane) {
+    using L = NetLdsSmall<D, H, O>;
+    constexpr int MT = H / 32;
+    const int h = lane >> 5;
+    f32x16 h1[MT];
+    dense_first<H, MT>(lds + L::W1T, lds + L::B1, xk, h1, lane);
+    tanh_tiles(h1);
+    float part[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) part[o] = 0.f;
+#pragma unroll 1
+    for (int mo = 0; mo < MT; ++mo) {
+        f32x16 acc = dense_tile_global<MT, true>(w2a, lds + L::B2, h1, mo, lane);
+        tanh16(acc);
+#pragma unroll
+        for (int o = 0; o < O; ++o)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(lds + L::W3S + o * H + 32 * mo + 8 * q + 4 * h);
+                part[o] = fmaf(w[0], acc[4 * q + 0], part[o]); part[o] = fmaf(w[1], acc[4 * q + 1], part[o]);
+                part[o] = fmaf(w[2], acc[4 * q + 2], part[o]); part[o] = fmaf(w[3], acc[4 * q + 3], part[o]);
+            }
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) out[o] = part[o] + __shfl_xor(part[o], 32) + lds[L::B3 + o];
+}
+
 // ---- transposes through a per-wave LDS image [H][kTS] ---------------------------------------------------
 // store X (C/D layout) as img[hidden row][sample col]
 template <int M> __device__ __forceinline__ void store_image(float* img, const f32x16 (&X)[M], int lane) {

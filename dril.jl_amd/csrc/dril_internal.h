@@ -14,6 +14,7 @@ struct PolicyArgs {
     const uint32_t* gstep; uint64_t env_seed0;   // step-granular rollout: draw from the env-keyed Philox stream (same as rollout_kernel)
     float* obs_out;                              // optional copy of the consumed observations (rollout buffer slice)
     const uint8_t* only_where;                   // optional: waves with no flagged sample skip (bootstrap critic on truncated envs)
+    const float* w2a_actor; const float* w2a_critic;   // wide nets: pre-tiled W2 images in global memory
     NetOff actor, critic;
 };
 
@@ -38,6 +39,7 @@ struct RolloutArgs {
     const void* noise;
     int E, T, episode_len, fixed_len, action_start, log_std_off;
     uint64_t env_seed0;
+    const float* w2a_actor; const float* w2a_critic;
     NetOff actor, critic;
 };
 
@@ -50,6 +52,7 @@ struct GradArgs {
     const float* params; const float* obs; const void* actions; const float* adv; const float* ret;
     const float* logp_old; const float* val_old;
     const int64_t* perm; int64_t pos0, count, N, idx_lo, n_local; uint64_t perm_key; int perm_bits;
+    const float* w2a_actor; const float* w2ta_actor; const float* w2a_critic; const float* w2ta_critic;   // wide nets: pre-tiled W2 / W2' images
     const float4* rec;   // packed minibatch records [N][2] x float4: {obs0..3} {action bits, adv, logp_old, ret}; null = gather from the SoA buffers
     const double* adv_stats;
     float invB, clip_range, ent_coef, vf_coef, clip_range_vf;
@@ -99,6 +102,7 @@ hipError_t launch_grad_reduce(const ReduceArgs& a, hipStream_t s);
 hipError_t launch_grad_norm(const float* flat, int P, double* norm_partials, const int* stop_flag, hipStream_t s);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_explained_var(const float* val, const float* ret, int64_t N, double* partials, int nblocks, hipStream_t s);
+hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a, float* w2ta, hipStream_t s);
 int slab_size_actor(int kind, int hidden);
 int slab_size_critic(int kind, int hidden);
 

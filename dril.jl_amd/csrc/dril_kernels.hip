@@ -234,20 +234,41 @@ template <int D> __device__ __forceinline__ void pair_obs(const float (&obs)[D],
     }
 }
 
+// forward of one net for a 32-sample tile: LDS-resident weights (H = 64) or the wide path (W2 streamed from L2)
+template <int D, int H, int O, bool WIDE>
+__device__ __forceinline__ void eval_net(const float* __restrict__ lds, const float* __restrict__ w2a, const float (&xk)[2], float (&out)[O], int lane) {
+    if constexpr (WIDE) net_forward_wide<D, H, O>(lds, w2a, xk, out, lane);
+    else { f32x16 h1[H / 32], h2[H / 32]; net_forward<D, H, H, O>(lds, xk, h1, h2, out, lane); }
+}
+template <int D, int H, int O, bool WIDE> struct FwdLds { static constexpr int SIZE = WIDE ? NetLdsSmall<D, H, O>::END : NetLds<D, H, H, O>::FWD_END; };
+template <int D, int H, int O, bool WIDE>
+__device__ __forceinline__ void stage_fwd(float* lds, const float* __restrict__ P, NetOff n, int tid, int nthreads) {
+    if constexpr (WIDE) stage_net_small<D, H, O>(lds, P, n, tid, nthreads); else stage_net<D, H, H, O, false>(lds, P, n, tid, nthreads);
+}
+// pre-tile W2 and W2' of one net for the wide path (see dril_device.h "wide nets")
+__global__ void build_wimg_kernel(const float* __restrict__ P, NetOff off, int H, float* __restrict__ w2a, float* __restrict__ w2ta) {
+    const int MT = H / 32;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < H * H; idx += gridDim.x * blockDim.x) {
+        const int c = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) & 3, mi = (idx >> 10) % MT, mo = (idx >> 10) / MT;
+        const int o = 32 * mo + (lane & 31), k = 32 * mi + 8 * q + 4 * (lane >> 5) + c;
+        w2a[idx] = P[off.w2 + o + k * H];      // W2[o][k]  (column-major out x in)
+        w2ta[idx] = P[off.w2 + k + o * H];     // W2'[o][k] = W2[k][o]
+    }
+}
+
 // =============================================================================================
 // policy_kernel: host-batch / step-granular forward.  One wave = 32 samples.
 // mode 0: sample + logprob + value; 1: evaluate given actions (+entropy); 2: critic only
 // =============================================================================================
-template <int KIND, int H>
-__global__ __launch_bounds__(256, 2) void policy_kernel(PolicyArgs a) {
-    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A, MT = H / 32;
+template <int KIND, int H, bool WIDE>
+__global__ __launch_bounds__(256, WIDE ? 1 : 2) void policy_kernel(PolicyArgs a) {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
     constexpr bool DISC = EnvSpec<KIND>::discrete;
-    using LA = NetLds<D, H, H, A>; using LC = NetLds<D, H, H, 1>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* la = smem; float* lc = smem + LA::FWD_END;
+    float* la = smem; float* lc = smem + FwdLds<D, H, A, WIDE>::SIZE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (a.mode != 2) stage_net<D, H, H, A, false>(la, a.params, a.actor, tid, blockDim.x);
-    stage_net<D, H, H, 1, false>(lc, a.params, a.critic, tid, blockDim.x);
+    if (a.mode != 2) stage_fwd<D, H, A, WIDE>(la, a.params, a.actor, tid, blockDim.x);
+    stage_fwd<D, H, 1, WIDE>(lc, a.params, a.critic, tid, blockDim.x);
     __syncthreads();
     const int64_t ntiles = (a.B + kTile - 1) / kTile;
     const int c = lane & 31, h = lane >> 5;
@@ -263,13 +284,12 @@ __global__ __launch_bounds__(256, 2) void policy_kernel(PolicyArgs a) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) a.obs_out[b * D + d] = xk[s]; }
         }
-        f32x16 h1[MT], h2[MT];
         float v[1];
-        net_forward<D, H, H, 1>(lc, xk, h1, h2, v, lane);
+        eval_net<D, H, 1, WIDE>(lc, a.w2a_critic, xk, v, lane);
         if (valid && h == 0 && a.values) a.values[b] = v[0];
         if (a.mode == 2) continue;
         float out[A];
-        net_forward<D, H, H, A>(la, xk, h1, h2, out, lane);
+        eval_net<D, H, A, WIDE>(la, a.w2a_actor, xk, out, lane);
         if (DISC) {
             float p[A]; softmax_n<A>(out, p);
             int act;
@@ -316,16 +336,15 @@ __global__ __launch_bounds__(256, 2) void policy_kernel(PolicyArgs a) {
 // Buffer layout: time-major, index k = t*E + e; every store of a wave is one full 128-byte line
 // (or 512 B for the float4 observation rows).
 // =============================================================================================
-template <int KIND, int H>
-__global__ __launch_bounds__(256, 2) void rollout_kernel(RolloutArgs a) {
-    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A, S = EnvSpec<KIND>::S, MT = H / 32;
+template <int KIND, int H, bool WIDE>
+__global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs a) {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A, S = EnvSpec<KIND>::S;
     constexpr bool DISC = EnvSpec<KIND>::discrete;
-    using LA = NetLds<D, H, H, A>; using LC = NetLds<D, H, H, 1>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* la = smem; float* lc = smem + LA::FWD_END;
+    float* la = smem; float* lc = smem + FwdLds<D, H, A, WIDE>::SIZE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    stage_net<D, H, H, A, false>(la, a.params, a.actor, tid, blockDim.x);
-    stage_net<D, H, H, 1, false>(lc, a.params, a.critic, tid, blockDim.x);
+    stage_fwd<D, H, A, WIDE>(la, a.params, a.actor, tid, blockDim.x);
+    stage_fwd<D, H, 1, WIDE>(lc, a.params, a.critic, tid, blockDim.x);
     __syncthreads();
     const int c = lane & 31, h = lane >> 5;
     const int e_raw = (blockIdx.x * 4 + wave) * kTile + c;
@@ -352,11 +371,10 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(RolloutArgs a) {
         const float* la_t = la + zoff; const float* lc_t = lc + zoff;
         float xk[2];
         pair_obs<D>(obs, h, xk);
-        f32x16 h1[MT], h2[MT];
         float v[1], out[A];
-        net_forward<D, H, H, 1>(lc_t, xk, h1, h2, v, lane);
+        eval_net<D, H, 1, WIDE>(lc_t, a.w2a_critic, xk, v, lane);
         __builtin_amdgcn_sched_barrier(0);   // do not interleave the two nets: that doubles the live weight fragments
-        net_forward<D, H, H, A>(la_t, xk, h1, h2, out, lane);
+        eval_net<D, H, A, WIDE>(la_t, a.w2a_actor, xk, out, lane);
         __builtin_amdgcn_sched_barrier(0);
         // ---- sample (layer_forward.jl:10-11 / :36-37) ----
         int act_env = 0; float actf_env = 0.f; float logp;
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(RolloutArgs a) {
             float tk[2];
             pair_obs<D>(tobs, h, tk);
             float bv[1];
-            net_forward<D, H, H, 1>(lc_t, tk, h1, h2, bv, lane);
+            eval_net<D, H, 1, WIDE>(lc_t, a.w2a_critic, tk, bv, lane);
             if (writer && trunc) a.boot[k] = bv[0];
         }
         if (term || trunc) { ep += 1; sc = 0; env_reset<KIND>(env_seed, ep, st); }
@@ -410,8 +428,8 @@ __global__ __launch_bounds__(256, 2) void rollout_kernel(RolloutArgs a) {
     {   // V(new_obs) for rollout-limited trajectories, trajectory.jl:65-70 (computed for every env; GAE uses it when needed)
         float xk[2];
         pair_obs<D>(obs, h, xk);
-        f32x16 h1[MT], h2[MT]; float v[1];
-        net_forward<D, H, H, 1>(lc, xk, h1, h2, v, lane);
+        float v[1];
+        eval_net<D, H, 1, WIDE>(lc, a.w2a_critic, xk, v, lane);
         if (writer) a.last_values[e] = v[0];
     }
     if (writer) {
@@ -616,6 +634,68 @@ __device__ __forceinline__ void unpack_tile(const GradArgs& a, int h, TileIn<O>&
     }
 }
 
+// (alg::PPO)(...) loss terms and dLoss/d(net output) for one sample per lane (ppo.jl:377-404); `tally` selects the lanes that
+// add to the statistics / log_std sums (each sample is replicated in the two half-waves, and in every wave of a wide workgroup)
+template <int O, int HEAD>
+__device__ __forceinline__ void loss_head(const GradArgs& a, const TileIn<O>& cur, const float (&out)[O], bool valid, bool tally, const float* ls,
+                                          float adv_mean, float adv_inv, float (&dz)[O], float (&st)[5], float (&dlsp)[O]) {
+    if (HEAD == HEAD_VALUE) {
+        const float R = cur.s0;
+        float value = out[0]; bool vpass = true;
+        if (a.has_clip_vf) {                                              // clip_range, ppo.jl:344-346,378
+            const float ov = cur.s1, d = value - ov;
+            vpass = d >= -a.clip_range_vf && d <= a.clip_range_vf;
+            value = ov + fminf(fmaxf(d, -a.clip_range_vf), a.clip_range_vf);
+        }
+        const float ve = value - R;
+        dz[0] = (valid && vpass) ? a.invB * a.vf_coef * 2.0f * ve : 0.f;
+        if (valid && tally) st[0] += ve * ve;                            // value_loss numerator, ppo.jl:385
+    } else {
+        const float advn = (cur.s0 - adv_mean) * adv_inv;
+        const float olp = cur.s1;
+        float logp, ent;
+        float p[O];
+        int act = 0;
+        float xa[O];
+        if (HEAD == HEAD_CATEGORICAL) {
+            softmax_n<O>(out, p);
+            act = cur.act;
+            logp = flog(pick<O>(p, act));
+            ent = categorical_entropy<O>(p);
+        } else {
+#pragma unroll
+            for (int o = 0; o < O; ++o) xa[o] = cur.xa[o];
+            logp = gauss_logpdf<O>(xa, out, ls);
+            ent = gauss_entropy<O>(ls);
+        }
+        const float lr = logp - olp;
+        const float r = fexp(lr);                                          // ppo.jl:380
+        const float lo = 1.0f - a.clip_range, hi = 1.0f + a.clip_range;
+        const float rc = fminf(fmaxf(r, lo), hi);                          // :381
+        const float t1 = r * advn, t2 = rc * advn;
+        const float mn = t2 < t1 ? t2 : t1;                                // :382
+        const float dm_dr = (t2 < t1) ? ((r >= lo && r <= hi) ? advn : 0.f) : advn;
+        const float dlogp = valid ? -a.invB * dm_dr * r : 0.f;
+        const float dent = valid ? -a.invB * a.ent_coef : 0.f;             // ent_loss = -mean(entropy), :383,:386
+        if (HEAD == HEAD_CATEGORICAL) {
+#pragma unroll
+            for (int o = 0; o < O; ++o)
+                dz[o] = dlogp * ((o == act ? 1.0f : 0.0f) - p[o]) + dent * (-p[o] * (flog(p[o]) + ent));
+        } else {
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const float iv = fexp(-2.0f * ls[o]), d = xa[o] - out[o];
+                dz[o] = dlogp * d * iv;
+                if (tally) dlsp[o] += dlogp * (d * d * iv - 1.0f) + dent;
+            }
+        }
+        if (valid && tally) {
+            st[0] += -mn; st[1] += ent; st[2] += (r != rc) ? 1.0f : 0.0f;   // :382,:383,:390
+            st[3] += (r - 1.0f) - lr; st[4] += r;                           // :393,:402
+        }
+    }
+}
+
 // per-wave LDS scratch of grad_body (floats): one [H][kTS] transpose image reused in turn for h2, h1, dz2, dz1,
 // the [D+2][kTS] first-layer input image (rows 0..D-1 = x, row D = 1 for the bias column, row D+1 = 0) and the [O][kTS]
 // dLoss/dout image.  2 workgroups (4 waves each) per CU => 2 waves per SIMD, so one wave's VALU/LDS phases overlap the
@@ -725,61 +805,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
         dense_out<MT, O, H>(wl + L::W3S, wl + L::B3, h2, out, lane);
         __builtin_amdgcn_sched_barrier(0);
         // ---- loss head (ppo.jl:377-404) and dLoss/dout ----
-        if (HEAD == HEAD_VALUE) {
-            const float R = cur.s0;
-            float value = out[0]; bool vpass = true;
-            if (a.has_clip_vf) {                                              // clip_range, ppo.jl:344-346,378
-                const float ov = cur.s1, d = value - ov;
-                vpass = d >= -a.clip_range_vf && d <= a.clip_range_vf;
-                value = ov + fminf(fmaxf(d, -a.clip_range_vf), a.clip_range_vf);
-            }
-            const float ve = value - R;
-            dz[0] = (valid && vpass) ? a.invB * a.vf_coef * 2.0f * ve : 0.f;
-            if (valid && h == 0) st[0] += ve * ve;                            // value_loss numerator, ppo.jl:385
-        } else {
-            const float advn = (cur.s0 - adv_mean) * adv_inv;
-            const float olp = cur.s1;
-            float logp, ent;
-            float p[O];
-            int act = 0;
-            float xa[O];
-            if (HEAD == HEAD_CATEGORICAL) {
-                softmax_n<O>(out, p);
-                act = cur.act;
-                logp = flog(pick<O>(p, act));
-                ent = categorical_entropy<O>(p);
-            } else {
-#pragma unroll
-                for (int o = 0; o < O; ++o) xa[o] = cur.xa[o];
-                logp = gauss_logpdf<O>(xa, out, ls);
-                ent = gauss_entropy<O>(ls);
-            }
-            const float lr = logp - olp;
-            const float r = fexp(lr);                                          // ppo.jl:380
-            const float lo = 1.0f - a.clip_range, hi = 1.0f + a.clip_range;
-            const float rc = fminf(fmaxf(r, lo), hi);                          // :381
-            const float t1 = r * advn, t2 = rc * advn;
-            const float mn = t2 < t1 ? t2 : t1;                                // :382
-            const float dm_dr = (t2 < t1) ? ((r >= lo && r <= hi) ? advn : 0.f) : advn;
-            const float dlogp = valid ? -a.invB * dm_dr * r : 0.f;
-            const float dent = valid ? -a.invB * a.ent_coef : 0.f;             // ent_loss = -mean(entropy), :383,:386
-            if (HEAD == HEAD_CATEGORICAL) {
-#pragma unroll
-                for (int o = 0; o < O; ++o)
-                    dz[o] = dlogp * ((o == act ? 1.0f : 0.0f) - p[o]) + dent * (-p[o] * (flog(p[o]) + ent));
-            } else {
-#pragma unroll
-                for (int o = 0; o < O; ++o) {
-                    const float iv = fexp(-2.0f * ls[o]), d = xa[o] - out[o];
-                    dz[o] = dlogp * d * iv;
-                    if (h == 0) dlsp[o] += dlogp * (d * d * iv - 1.0f) + dent;
-                }
-            }
-            if (valid && h == 0) {
-                st[0] += -mn; st[1] += ent; st[2] += (r != rc) ? 1.0f : 0.0f;   // :382,:383,:390
-                st[3] += (r - 1.0f) - lr; st[4] += r;                           // :393,:402
-            }
-        }
+        loss_head<O, HEAD>(a, cur, out, valid, h == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
         STAMP(3);
         __builtin_amdgcn_sched_barrier(0);
         // ---- output layer backward: dW3 += dz * h2' over samples (h2 read back transposed: hidden on the lane) ----
@@ -942,6 +968,277 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_kernel(GradArgs a) {
 }
 
 // =============================================================================================
+// ppo_grad_wide_kernel — the same fused forward + loss + backward for hidden widths that do not fit one wave
+// (H = 256: W2 is 256 KB, dW2 is 64 K accumulators).  A workgroup of H/32 waves processes a 32-sample tile TOGETHER:
+// wave w owns m-tile w (hidden rows 32w..32w+31) of every layer and the 32 x H slice of dW2 in registers (H/2 VGPRs);
+// activations are exchanged through LDS (B-operand images [m][lane][16]), the two H x H operand streams W2 / W2' come
+// pre-tiled from L2 (dril_device.h "wide nets").  Four workgroup barriers per tile.  Per tile and wave:
+//   2 (L1) + 4*MT (L2) + 4*MT (dh1) + 4*MT... in 32x32x2 units: L2 16*MT, dh1 16*MT, dW2 16*MT, dW1 1.
+// Every wave owns distinct rows of every gradient, so the slab is written straight from registers (no cross-wave sum).
+// =============================================================================================
+template <int D, int H, int O> struct WideScratch {
+    static constexpr int MT = H / 32;
+    static constexpr int SMALL = NetLdsSmall<D, H, O>::END;
+    static constexpr int XA = (SMALL + 3) / 4 * 4;          // h1 as B-operand image [MT][64][16]
+    static constexpr int XB = XA + MT * 1024;               // dz2 as B-operand image
+    static constexpr int TA = XB + MT * 1024;               // h1 transposed [H][kTS]
+    static constexpr int TB = TA + H * kTS;                 // per-wave rows: h2', then dz2', then dz1'
+    static constexpr int XI = TB + H * kTS;                 // [D+2][kTS]
+    static constexpr int ZI = XI + (D + 2) * kTS;           // [MT waves][O][kTS]
+    static constexpr int PO = ZI + MT * O * kTS;            // [MT waves][O][32] output-layer partial sums
+    static constexpr int SIZE = PO + MT * O * 32;
+};
+
+__device__ __forceinline__ void store_breg(float* img, int m, const f32x16& x, int lane) {
+    float* p = img + ((size_t)m * 64 + lane) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p + 4 * q) = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+}
+__device__ __forceinline__ f32x16 load_breg(const float* img, int m, int lane) {
+    const float* p = img + ((size_t)m * 64 + lane) * 16;
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q); v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3]; }
+    return v;
+}
+__device__ __forceinline__ void store_image_tile(float* img, int m, const f32x16& x, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) img[(32 * m + rowfn(r, h)) * kTS + c] = x[r];
+}
+// Y tile mo = W * X with W from the pre-tiled global image and X read tile by tile from an LDS B-operand image
+template <int MT, bool BIAS>
+__device__ __forceinline__ f32x16 dense_tile_global_ldsB(const float* __restrict__ wimg, const float* __restrict__ bias, const float* __restrict__ ximg, int mo, int lane) {
+    const int h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (BIAS) b = *reinterpret_cast<const f32x4*>(bias + 32 * mo + 8 * q + 4 * h);
+        acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+    }
+    const float* base = wimg + ((size_t)mo * MT * 4 * 64 + lane) * 4;
+#pragma unroll 2
+    for (int mi = 0; mi < MT; ++mi) {
+        const f32x16 X = load_breg(ximg, mi, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(base + (size_t)(mi * 4 + q) * 256);
+            acc = mfma32(a[0], X[4 * q + 0], acc);
+            acc = mfma32(a[1], X[4 * q + 1], acc);
+            acc = mfma32(a[2], X[4 * q + 2], acc);
+            acc = mfma32(a[3], X[4 * q + 3], acc);
+        }
+    }
+    return acc;
+}
+
+template <int KIND, int H, int O, int HEAD, bool REC>
+__device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
+    constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
+    using L = NetLdsSmall<D, H, O>;
+    using SC = WideScratch<D, H, O>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // this wave's m-tile
+    const int c = lane & 31, h = lane >> 5;
+    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
+    const float* w2a = HEAD == HEAD_VALUE ? a.w2a_critic : a.w2a_actor;
+    const float* w2ta = HEAD == HEAD_VALUE ? a.w2ta_critic : a.w2ta_actor;
+    float* wl = smem;
+    float* XA = smem + SC::XA; float* XB = smem + SC::XB; float* TA = smem + SC::TA; float* TB = smem + SC::TB;
+    float* XI = smem + SC::XI; float* ZI = smem + SC::ZI + w * O * kTS; float* PO = smem + SC::PO;
+    stage_net_small<D, H, O>(wl, a.params, off, tid, blockDim.x);
+    for (int i = tid; i < (D + 2) * kTS; i += blockDim.x) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
+    __syncthreads();
+
+    float adv_mean = 0.f, adv_den = 1.f;
+    if (HEAD != HEAD_VALUE && a.normalize_adv) {
+        const double s = a.adv_stats[0], q = a.adv_stats[1], n = a.adv_stats[2];
+        const double mean = s / n;
+        double var = (q - s * mean) / (n - 1.0);
+        if (var < 0) var = 0;
+        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
+    }
+    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
+    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
+    const float* ls = a.params + a.log_std_off;
+
+    f32x16 dW2[MT];                                                  // rows 32w.., all H columns
+    f32x4 dW1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float dW3a[O], db2p = 0.f, db3p[O], dlsp[O], st[5];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW2[j][r] = 0.f;
+#pragma unroll
+    for (int o = 0; o < O; ++o) { dW3a[o] = 0.f; db3p[o] = 0.f; dlsp[o] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) st[i] = 0.f;
+
+    const int g = a.layout ? (int)(blockIdx.x % a.G) : (int)(blockIdx.x >> 1);
+    const int64_t ntiles = (a.count + kTile - 1) / kTile;
+    TileIn<O> cur, nxt;
+    int64_t tile = g;
+    if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
+    for (; tile < ntiles; tile += a.G) {
+        load_tile<KIND, O, HEAD, REC>(a, tile + a.G, ntiles, c, h, nxt);
+        unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
+        const bool valid = cur.valid;
+        const float xk[2] = {cur.xk[0], cur.xk[1]};
+        // ---- S2: h1 tile w ----
+        f32x16 h1w;
+        {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B1 + 32 * w + 8 * q + 4 * h);
+                h1w[4 * q + 0] = b[0]; h1w[4 * q + 1] = b[1]; h1w[4 * q + 2] = b[2]; h1w[4 * q + 3] = b[3];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
+            tanh16(h1w);
+        }
+        store_breg(XA, w, h1w, lane);
+        store_image_tile(TA, w, h1w, lane);
+        if (w == 0) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) XI[d * kTS + c] = xk[s]; }
+        }
+        __syncthreads();                                                              // B1: XA, TA, XI complete
+        // ---- S3: h2 tile w ----
+        f32x16 h2w = dense_tile_global_ldsB<MT, true>(w2a, wl + L::B2, XA, w, lane);
+        tanh16(h2w);
+        // ---- S4: output layer: partial over this wave's rows, summed across waves through LDS ----
+        float out[O], dz[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float p = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
+                p = fmaf(wv[0], h2w[4 * q + 0], p); p = fmaf(wv[1], h2w[4 * q + 1], p);
+                p = fmaf(wv[2], h2w[4 * q + 2], p); p = fmaf(wv[3], h2w[4 * q + 3], p);
+            }
+            p += __shfl_xor(p, 32);
+            if (h == 0) PO[(w * O + o) * 32 + c] = p;
+        }
+        store_image_tile(TB, w, h2w, lane);                                            // h2' (own rows; only this wave reads them)
+        __syncthreads();                                                              // B2: PO complete
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float v = wl[L::B3 + o];
+#pragma unroll
+            for (int ww = 0; ww < MT; ++ww) v += PO[(ww * O + o) * 32 + c];            // fixed order: every wave gets the same bits
+            out[o] = v;
+        }
+        loss_head<O, HEAD>(a, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
+        // ---- dW3 (own rows) ----
+#pragma unroll
+        for (int o = 0; o < O; ++o) { if (h == 0) { if (w == 0) db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
+        {
+            const f32x16 Bh2 = load_operand(TB, w, lane);
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 z = *reinterpret_cast<const f32x4*>(ZI + o * kTS + 16 * h + 4 * q);
+                    acc = fmaf(Bh2[4 * q + 0], z[0], acc); acc = fmaf(Bh2[4 * q + 1], z[1], acc);
+                    acc = fmaf(Bh2[4 * q + 2], z[2], acc); acc = fmaf(Bh2[4 * q + 3], z[3], acc);
+                }
+                dW3a[o] += acc;
+            }
+        }
+        // ---- dz2 tile w (in h2w's registers) ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float dh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(wv[cc], dz[o], dh[cc]);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
+        }
+        store_breg(XB, w, h2w, lane);
+        store_image_tile(TB, w, h2w, lane);                                            // dz2' (after the Bh2 read: same wave, LDS in order)
+        __syncthreads();                                                              // B3: XB complete
+        // ---- S6: dh1 tile w = W2' dz2 ; dz1 ----
+        f32x16 g1 = dense_tile_global_ldsB<MT, false>(w2ta, nullptr, XB, w, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g1[r] = g1[r] * (1.0f - h1w[r] * h1w[r]);
+        // ---- S7: dW2[rows of w][:] += dz2 h1' ----
+        {
+            const f32x16 Az = load_operand(TB, w, lane);
+            db2p += sum16(Az);
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj) {
+                const f32x16 Bh = load_operand(TA, mj, lane);
+                dW2[mj] = mfma_outer(Az, Bh, dW2[mj]);
+            }
+        }
+        // ---- S8: dW1 | db1 (own rows) ----
+        store_image_tile(TB, w, g1, lane);
+        {
+            const int j = lane & 15;
+            float bx[8];
+            load_row8(XI, j <= D ? j : D + 1, lane, bx);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float az[8];
+                load_row8(TB, 32 * w + 16 * t + j, lane, az);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dW1[t] = mfma16(az[k], bx[k], dW1[t]);
+            }
+        }
+        __syncthreads();                                                              // B4: XA/TA/XB/PO/XI free for the next tile
+        cur = nxt;
+    }
+
+    // ---- epilogue: every wave owns distinct gradient rows -> straight to the workgroup's slab ----
+    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
+    const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
+    const int o_ls = o_b3 + O, o_st = SL - 8;
+    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
+#pragma unroll
+    for (int mj = 0; mj < MT; ++mj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H] = dW2[mj][r];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 32 * w + 16 * t + 4 * (lane >> 4) + r, col = lane & 15;
+            if (col < D) slab[o_w1 + row + col * H] = dW1[t][r];
+            else if (col == D) slab[o_b1 + row] = dW1[t][r];
+        }
+    { const float b2 = db2p + __shfl_xor(db2p, 32); if (h == 0) slab[o_b2 + 32 * w + c] = b2; }
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        const float v = dW3a[o] + __shfl_xor(dW3a[o], 32);
+        if (h == 0) slab[o_w3 + o + (32 * w + c) * O] = v;
+        const float b3 = half_sum(db3p[o]);
+        if (w == 0 && lane == 0) slab[o_b3 + o] = b3;
+        if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (w == 0 && lane == 0) slab[o_ls + o] = l; }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (w == 0 && lane == 0) slab[o_st + k] = v; }
+    if (w == 0 && lane < 3) slab[o_st + 5 + lane] = 0.f;
+    for (int i = (HEAD == HEAD_GAUSSIAN ? o_ls + O : o_ls) + tid; i < o_st; i += blockDim.x) slab[i] = 0.f;   // padding
+}
+
+template <int KIND, int H, bool REC>
+__global__ __launch_bounds__(H * 2, 2) void ppo_grad_wide_kernel(GradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (*a.stop_flag) return;
+    constexpr int A = EnvSpec<KIND>::A;
+    const bool actor = a.layout ? (blockIdx.x < (unsigned)a.G) : ((blockIdx.x & 1) == 0);
+    if (actor) grad_body_wide<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN, REC>(a, smem);
+    else grad_body_wide<KIND, H, 1, HEAD_VALUE, REC>(a, smem);
+}
+
+// =============================================================================================
 // slab reduction -> flat [grads | stats] buffer; norm; clip + KL check + Adam
 // flat layout: params order (actor net, critic net, log_std) then 8 stats:
 //   0 sum(-min term)  1 sum(entropy)  2 sum(clipped)  3 sum(kl)  4 sum(ratio)  5 sum((V-R)^2)  6 n_samples  7 unused
@@ -1054,8 +1351,8 @@ __global__ void explained_var_kernel(const float* val, const float* ret, int64_t
 // =============================================================================================
 // launchers
 // =============================================================================================
-template <int KIND, int H> static size_t fwd_lds_bytes() {
-    return sizeof(float) * (NetLds<EnvSpec<KIND>::D, H, H, EnvSpec<KIND>::A>::FWD_END + NetLds<EnvSpec<KIND>::D, H, H, 1>::FWD_END);
+template <int KIND, int H, bool WIDE> static size_t fwd_lds_bytes() {
+    return sizeof(float) * (FwdLds<EnvSpec<KIND>::D, H, EnvSpec<KIND>::A, WIDE>::SIZE + FwdLds<EnvSpec<KIND>::D, H, 1, WIDE>::SIZE);
 }
 template <int KIND, int H> static size_t grad_lds_bytes() {
     constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
@@ -1070,6 +1367,20 @@ template <int KIND, int H> static size_t grad_lds_bytes() {
         else if ((kind) == 1 && (hidden) == 64) { CALL(1, 64); }                     \
         else return hipErrorInvalidValue;                                            \
     } while (0)
+
+#define DRIL_DISPATCH_FWD(kind, hidden, CALL)                                        \
+    do {                                                                             \
+        if ((kind) == 0 && (hidden) == 64) { CALL(0, 64); }                          \
+        else if ((kind) == 1 && (hidden) == 64) { CALL(1, 64); }                     \
+        else if ((kind) == 0 && (hidden) == 256) { CALL(0, 256); }                   \
+        else if ((kind) == 1 && (hidden) == 256) { CALL(1, 256); }                   \
+        else return hipErrorInvalidValue;                                            \
+    } while (0)
+
+hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a, float* w2ta, hipStream_t s) {
+    build_wimg_kernel<<<(H * H + 255) / 256, 256, 0, s>>>(params, off, H, w2a, w2ta);
+    return hipGetLastError();
+}
 
 hipError_t launch_env_reset(int kind, int E, uint64_t seed0, float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* dr, hipStream_t s) {
     const int blocks = (E + 255) / 256;
@@ -1119,12 +1430,12 @@ hipError_t launch_policy(int kind, int hidden, const PolicyArgs& a, int max_bloc
     if (blocks < 1) blocks = 1;
 #define CALL(K, HH)                                                                                           \
     {                                                                                                         \
-        const size_t lds = fwd_lds_bytes<K, HH>();                                                            \
-        hipError_t e = hipFuncSetAttribute((const void*)policy_kernel<K, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        const size_t lds = fwd_lds_bytes<K, HH, (HH > 64)>();                                                 \
+        hipError_t e = hipFuncSetAttribute((const void*)policy_kernel<K, HH, (HH > 64)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                        \
-        policy_kernel<K, HH><<<blocks, 256, lds, s>>>(a);                                                     \
+        policy_kernel<K, HH, (HH > 64)><<<blocks, 256, lds, s>>>(a);                                          \
     }
-    DRIL_DISPATCH(kind, hidden, CALL);
+    DRIL_DISPATCH_FWD(kind, hidden, CALL);
 #undef CALL
     return hipGetLastError();
 }
@@ -1133,12 +1444,12 @@ hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_
     const int blocks = (a.E + 4 * kTile - 1) / (4 * kTile);
 #define CALL(K, HH)                                                                                           \
     {                                                                                                         \
-        const size_t lds = fwd_lds_bytes<K, HH>();                                                            \
-        hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel<K, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        const size_t lds = fwd_lds_bytes<K, HH, (HH > 64)>();                                                 \
+        hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel<K, HH, (HH > 64)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                        \
-        rollout_kernel<K, HH><<<blocks, 256, lds, s>>>(a);                                                    \
+        rollout_kernel<K, HH, (HH > 64)><<<blocks, 256, lds, s>>>(a);                                         \
     }
-    DRIL_DISPATCH(kind, hidden, CALL);
+    DRIL_DISPATCH_FWD(kind, hidden, CALL);
 #undef CALL
     return hipGetLastError();
 }
@@ -1164,6 +1475,11 @@ hipError_t launch_moments_finalize(const double* partials, int nblocks, double* 
     return hipGetLastError();
 }
 
+template <int KIND, int H> static size_t grad_wide_lds_bytes() {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
+    constexpr int wa = WideScratch<D, H, A>::SIZE, wc = WideScratch<D, H, 1>::SIZE;
+    return sizeof(float) * (wa > wc ? wa : wc);
+}
 hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t s) {
 #define CALLR(K, HH, R)                                                                                       \
     {                                                                                                         \
@@ -1172,10 +1488,23 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
         if (e != hipSuccess) return e;                                                                        \
         ppo_grad_kernel<K, HH, R><<<2 * a.G, 256, lds, s>>>(a);                                               \
     }
+#define CALLW(K, HH, R)                                                                                       \
+    {                                                                                                         \
+        const size_t lds = grad_wide_lds_bytes<K, HH>();                                                      \
+        hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wide_kernel<K, HH, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                        \
+        ppo_grad_wide_kernel<K, HH, R><<<2 * a.G, HH * 2, lds, s>>>(a);                                       \
+    }
+    if (hidden == 256) {
+        if (kind == 0) { if (a.rec) CALLW(0, 256, true) else CALLW(0, 256, false) }
+        else { if (a.rec) CALLW(1, 256, true) else CALLW(1, 256, false) }
+        return hipGetLastError();
+    }
 #define CALL(K, HH) { if (a.rec) CALLR(K, HH, true) else CALLR(K, HH, false) }
     DRIL_DISPATCH(kind, hidden, CALL);
 #undef CALL
 #undef CALLR
+#undef CALLW
     return hipGetLastError();
 }
 

@@ -59,7 +59,7 @@ def test_null_and_bad_arguments_fail_loudly(pkg):
     cfg = pkg._capi.default_config(0); cfg.abi_version = 77
     assert lib.dril_create(C.byref(cfg), C.byref(h)) == pkg._capi.ERR_INVALID_ARG
     assert b"abi_version" in lib.dril_last_error(None)
-    cfg = pkg._capi.default_config(0); cfg.hidden1 = cfg.hidden2 = 48
+    cfg = pkg._capi.default_config(0); cfg.hidden1 = cfg.hidden2 = 96
     assert lib.dril_create(C.byref(cfg), C.byref(h)) == pkg._capi.ERR_UNSUPPORTED
     assert lib.dril_synchronize(None) == pkg._capi.ERR_NOT_INITIALISED
     assert lib.dril_param_count(None) == -1

@@ -438,3 +438,65 @@ def test_stepwise_path_equals_persistent_kernel(pkg, monkeypatch):
             np.testing.assert_allclose(outs[0][w], outs[1][w], atol=1e-6)
         else:
             np.testing.assert_allclose(outs[0][w].astype(np.float64), outs[1][w].astype(np.float64), atol=1e-6)
+
+
+# ---- hidden_dims = [256, 256] (BASELINE configs[2]): wide forward (W2 streamed from L2) and the workgroup-cooperative grad kernel ----
+@pytest.mark.parametrize("kind,B", [(1, 100), (0, 33)])
+def test_wide_forward_evaluate(pkg, oracle_mod, kind, B):
+    cfg = _cfg(pkg, kind, n_envs=2, n_steps=2, batch_size=2, hidden1=256, hidden2=256)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    assert h.P == (134147 if kind == 1 else 2 * (256 * 4 + 256 + 256 * 256 + 256) + 256 * 2 + 2 + 256 + 1)
+    flat = _params(h.P, 3, 0.12); h.set_params(flat); o.set_params(flat)
+    rng = np.random.default_rng(B)
+    obs = rng.uniform(-2, 2, (B, h.D)).astype(np.float32)
+    noise = rng.random(B) if kind == 0 else rng.standard_normal((B, h.A)).astype(np.float32)
+    ah, vh, lh = h.policy_forward(obs, noise); ao, vo, lo = o.policy_forward(obs, noise)
+    np.testing.assert_allclose(vh, vo, atol=5e-5, rtol=5e-5)
+    if kind == 0:
+        assert (ah == ao).mean() >= 0.99
+    else:
+        np.testing.assert_allclose(ah, ao, atol=5e-5, rtol=5e-5)
+    ve, le, ee = h.evaluate_actions(obs, ao); vo2, lo2, eo2 = o.evaluate_actions(obs, ao)
+    np.testing.assert_allclose(ve, vo2, atol=5e-5, rtol=5e-5); np.testing.assert_allclose(le, lo2, atol=2e-4, rtol=2e-4)
+    np.testing.assert_allclose(h.predict_values(obs), vo, atol=5e-5, rtol=5e-5)
+
+
+@pytest.mark.parametrize("kind,B,variant", [(1, 64, "default"), (1, 1000, "ent_vfclip"), (0, 333, "default")])
+def test_wide_ppo_loss_and_gradient(pkg, oracle_mod, kind, B, variant):
+    kw = dict(n_envs=2, n_steps=2, batch_size=2, hidden1=256, hidden2=256)
+    if variant == "ent_vfclip":
+        kw.update(ent_coef=0.01, has_clip_range_vf=1, clip_range_vf=0.3, clip_range=0.1)
+    cfg = _cfg(pkg, kind, **kw)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 40, 0.1); h.set_params(flat); o.set_params(flat)
+    batch = _batch(o, cfg, B, 1)
+    lh, sh, gh = h.ppo_loss_grad(*batch); lo, so, go = o.ppo_loss_grad(*batch)
+    assert lh == pytest.approx(lo, rel=1e-4)
+    np.testing.assert_allclose(sh, so, rtol=3e-4, atol=3e-6)
+    assert np.linalg.norm(gh - go) <= 3e-4 * np.linalg.norm(go)
+    lh2, _, gh2 = h.ppo_loss_grad(*batch)
+    assert lh2 == lh and np.array_equal(gh, gh2)
+
+
+def test_wide_rollout_and_update_config3_shape(pkg, oracle_mod):
+    """configs[2] at test size: Pendulum, DiagGaussian, hidden [256,256], NormalizeWrapperEnv — rollout then PPO update"""
+    capi = pkg._capi
+    E, T = 40, 24
+    cfg = _cfg(pkg, 1, n_envs=E, n_steps=T, episode_len=10, batch_size=E * T // 3, epochs=2, hidden1=256, hidden2=256,
+               norm_training=1, norm_obs=1, norm_reward=1)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 12, 0.08); h.set_params(flat); o.set_params(flat)
+    h.env_reset(4); o.env_reset(4)
+    noise = np.random.default_rng(0).standard_normal((E * T, 1)).astype(np.float32)
+    h.set_noise(noise); o.set_noise(noise)
+    h.collect_rollout(); o.collect_rollout()
+    for which, tol in ((capi.BUF_OBSERVATIONS, 2e-4), (capi.BUF_VALUES, 3e-4), (capi.BUF_LOGPROBS, 3e-4), (capi.BUF_REWARDS, 3e-4),
+                       (capi.BUF_ADVANTAGES, 3e-3), (capi.BUF_RETURNS, 3e-3)):
+        np.testing.assert_allclose(h.buffer(which), o.buffer(which), atol=tol, rtol=tol)
+    for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+        h.set_buffer(which, o.buffer(which))
+    perm = np.stack([np.random.default_rng(e).permutation(E * T) for e in range(cfg.epochs)]).astype(np.int64)
+    h.set_permutation(perm); o.set_permutation(perm)
+    sh, so = h.ppo_update(), o.ppo_update()
+    assert sh.n_updates == so.n_updates == 6 and sh.loss == pytest.approx(so.loss, rel=1e-4)
+    np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=3e-4, atol=3e-6)
