@@ -28,6 +28,10 @@ import __graft_entry__ as g  # noqa: E402
 
 FLOP_FWD = 17_792            # 2*(4*64+64*64+64*2 + 4*64+64*64+64*1)
 FLOP_FWD_BWD = 3 * FLOP_FWD  # a16: backward ~ 2x forward
+
+
+def flop_fwd(D: int, H: int, A: int) -> int:
+    return 2 * ((D * H + H * H + H * A) + (D * H + H * H + H))
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
@@ -67,6 +71,9 @@ def main() -> None:
     ap.add_argument("--n-steps", type=int, default=2048)
     ap.add_argument("--minibatches", type=int, default=32, help="optimiser steps per epoch; batch_size = N / this")
     ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--env", choices=["cartpole", "pendulum"], default="cartpole", help="pendulum + --hidden 256 + --normalize = BASELINE configs[2]")
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--normalize", action="store_true", help="NormalizeWrapperEnv on device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
@@ -89,12 +96,12 @@ def main() -> None:
     E, T = args.n_envs, args.n_steps
     N_local = E * T
     B_global = (N_local // args.minibatches) * world
-    env = pkg.CartPoleEnv(max_steps=500)
+    env = pkg.CartPoleEnv(max_steps=500) if args.env == "cartpole" else pkg.PendulumEnv(max_steps=200)
     alg = pkg.PPO(n_steps=T, batch_size=B_global, epochs=args.epochs)
-    layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space())
+    layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(args.hidden, args.hidden))
     device = int(os.environ.get("DRIL_DEVICE_OVERRIDE", local_rank))   # debugging aid only (several ranks on one card)
     cfg = pkg.make_config(env, E, alg, layer, seed=42, fixed_length_episodes=True, device=device, rank=rank, world_size=world,
-                          profile_events=not args.no_events)
+                          profile_events=not args.no_events, normalize={} if args.normalize else None)
     h = pkg.Handle(cfg)
     h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(42))))   # random-init weights of the named architecture
     if world > 1:
@@ -131,10 +138,11 @@ def main() -> None:
             "metric": "env-steps/s (rollout+PPO update) at n_envs=65536", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "CartPole-v1 configs[1]: device-resident envs, ActorCritic hidden_dims=[64,64], PPO rollout + update",
+            "config": {"workload": ("CartPole-v1 configs[1]" if args.env == "cartpole" else "Pendulum-v1 configs[2]" + (" + NormalizeWrapperEnv" if args.normalize else ""))
+                                   + f": device-resident envs, ActorCritic hidden_dims=[{args.hidden},{args.hidden}], PPO rollout + update",
                        "n_envs_per_gpu": E, "n_steps": T, "epochs": args.epochs, "batch_size": B_global,
                        "optimizer_steps_per_iteration": args.epochs * (-(-N_local * world // B_global)),
-                       "episodes": "fixed length 500 (termination disabled)", "parallelism": f"dp{world} (env shards)"},
+                       "episodes": f"fixed length {env.max_steps} (termination disabled)", "parallelism": f"dp{world} (env shards)"},
             "loss_last": last.loss, "n_updates_last": last.n_updates,
         }
         gk = prof.get("ppo_grad_kernel", {"total_ms": 0, "launches": 0})
@@ -142,12 +150,12 @@ def main() -> None:
             # dominant kernel: ppo_grad_kernel. ALGORITHMIC flops per launch = B_local samples x 53 376 (fwd + bwd of both MLPs,
             # SURVEY.md §8 a16); duration = HIP events on the library's stream around each launch in the timed region.
             avg_ms = gk["total_ms"] / gk["launches"]
-            flops = (B_global // world) * FLOP_FWD_BWD
+            flops = (B_global // world) * 3 * flop_fwd(h.D, args.hidden, h.A)
             ach = flops / (avg_ms * 1e-3) / 1e12
             traffic = None
             pmc = ROOT / "profiles" / "r01_ppo_grad_pmc.json"
-            if pmc.exists():
-                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            if pmc.exists() and args.env == "cartpole" and args.hidden == 64 and args.minibatches == 32 and E == 65536 and T == 2048:
+                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")   # PMC passes were taken on exactly this workload
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                                "traffic": traffic, "kernel": "ppo_grad_kernel", "avg_launch_ms": avg_ms, "launches": gk["launches"],
                                "flops_per_launch": flops}
