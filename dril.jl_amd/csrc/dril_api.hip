@@ -84,6 +84,7 @@ struct dril_handle {
     float4* rec = nullptr;   // packed minibatch records (see pack_records_kernel)
     RmsState *obs_rms = nullptr, *ret_rms = nullptr; int obs_par = 0, ret_par = 0;   // ping-pong RunningMeanStd pairs
     double* rms_partials = nullptr; int rms_blocks = 256; float* e_obs_raw = nullptr;
+    int grad_stagger = 0;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
     void* comm = nullptr;
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
@@ -193,7 +194,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     int G = h->wide ? (int)(tiles < h->Gmax ? tiles : h->Gmax) : (int)((tiles + 3) / 4); if (G > h->Gmax) G = h->Gmax; if (G < 1) G = 1;
     { int rcw = ensure_wimg(h); if (rcw) return rcw; }
     const double* adv_stats = h->adv_stats;
-    if (h->cfg.normalize_advantage && pre_stats && !reduce) adv_stats = pre_stats;
+    if (h->cfg.normalize_advantage && pre_stats) adv_stats = pre_stats;   // per-epoch table (already all-reduced in data-parallel runs)
     else if (h->cfg.normalize_advantage) {
         MomentsArgs m{}; m.adv = adv; m.perm = perm; m.pos0 = pos0; m.count = count; m.N = N; m.idx_lo = 0; m.n_local = N;
         m.perm_key = key; m.perm_bits = bits; m.partials = h->adv_partials; m.stop_flag = h->stop_flag;
@@ -212,7 +213,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     g.clip_range = h->cfg.clip_range; g.ent_coef = h->cfg.ent_coef; g.vf_coef = h->cfg.vf_coef; g.clip_range_vf = h->cfg.clip_range_vf;
     g.has_clip_vf = h->cfg.has_clip_range_vf; g.normalize_adv = h->cfg.normalize_advantage; g.action_start = h->cfg.action_start;
     g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
-    g.G = G; g.dbg = h->dbg; g.layout = h->grad_layout; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
+    g.G = G; g.dbg = h->dbg; g.layout = h->grad_layout; g.stagger = h->grad_stagger; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
     prof_begin(h, DRIL_K_PPO_GRAD);
     HIPCHK(h, launch_ppo_grad(h->cfg.env_kind, h->cfg.hidden1, g, h->stream));
     prof_end(h);
@@ -311,6 +312,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (const char* e = std::getenv("DRIL_FORCE_ALLREDUCE")) h->force_allreduce = std::atoi(e) != 0;
     if (const char* e = std::getenv("DRIL_FORCE_STEPWISE")) h->force_stepwise = std::atoi(e) != 0;
     if (const char* e = std::getenv("DRIL_GRAD_PRIO")) h->grad_prio = std::atoi(e);
+    if (const char* e = std::getenv("DRIL_GRAD_STAGGER")) h->grad_stagger = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_SPLIT")) h->grad_split = std::atoi(e);
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
     CCHK(hipSetDevice(cfg->device));
@@ -650,6 +652,9 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
             prof_begin(h, DRIL_K_ADV_MOMENTS);
             HIPCHK(h, launch_epoch_moments(h->adv, N, B, (int)nb, key, bits, h->epoch_tables, h->epoch_blocks, h->epoch_stats, h->stop_flag, h->stream));
             prof_end(h);
+            if (world > 1 || (h->comm && h->force_allreduce)) {     // ONE all-reduce per epoch for the advantage moments of all its minibatches
+                int rca = rccl_allreduce(h, h->epoch_stats, (size_t)3 * nb, kNcclFloat64); if (rca) return rca;
+            }
         }
         for (int64_t k = 0; k < nb; ++k, ++step) {
             const int64_t pos0 = k * B, count = (pos0 + B <= N) ? B : N - pos0;

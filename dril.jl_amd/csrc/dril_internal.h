@@ -59,6 +59,7 @@ struct GradArgs {
     int has_clip_vf, normalize_adv, action_start, log_std_off;
     float* slabs_actor; float* slabs_critic; int slab_a, slab_c, G;
     unsigned long long* dbg;   // -DDRIL_STAMPS diagnostic buffer (12 x u64 per wave), else unused
+    int stagger;   // tuning knob: start-up delay of the critic workgroups, in units of 8128 clocks
     int prio, split_pct;   // tuning knobs: static wave priority + share of tiles for the high-priority half
     int layout;   // 0: actor/critic workgroups interleaved by blockIdx parity, 1: first G blocks actor, next G critic
     const int* stop_flag;

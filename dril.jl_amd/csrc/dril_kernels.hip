@@ -779,6 +779,9 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
     TileIn<O> cur, nxt;
     int64_t tile = first;
     if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
+    if (HEAD == HEAD_VALUE && a.stagger > 0) {                      // start the critic workgroups out of phase with their co-resident actor workgroups
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);      // 127 * 64 clocks each
+    }
 #ifdef DRIL_STAMPS
     unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");

@@ -348,7 +348,11 @@ def test_rccl_plumbing_single_rank(pkg, oracle_mod, monkeypatch):
     sh, so = h.ppo_update(), o.ppo_update()
     assert sh.n_updates == so.n_updates and sh.loss == pytest.approx(so.loss, rel=1e-4)
     np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=2e-4, atol=3e-6)
-    assert h.profile is not None
+    # device-generated order: the per-epoch advantage-moment table goes through one all-reduce per epoch
+    h.set_permutation(None); o.set_permutation(None)
+    sh, so = h.ppo_update(), o.ppo_update()
+    assert sh.n_updates == so.n_updates and sh.loss == pytest.approx(so.loss, rel=2e-4)
+    np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=5e-4, atol=5e-6)
 
 
 @pytest.mark.parametrize("kind,flags", [(1, (1, 1)), (0, (1, 1)), (1, (1, 0)), (1, (0, 1))])
