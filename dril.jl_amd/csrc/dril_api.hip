@@ -506,24 +506,38 @@ int compute_gae(dril_handle* h) {
     prof_end(h);
     return DRIL_OK;
 }
-// step-granular collect_trajectories (trajectory.jl:22-78) for wrapped envs: per-step launches on the handle's stream
+// step-granular collect_trajectories (trajectory.jl:22-78) for wrapped envs: three launches per env step on the handle's stream
+//   policy_kernel (+ V(terminal_observation) of the previous step) -> norm_step_kernel -> norm_apply_kernel
 int collect_rollout_stepwise(dril_handle* h) {
     const int E = h->cfg.n_envs, T = h->cfg.n_steps, D = h->D, A = h->A;
     const size_t ab = act_bytes_per(h);
+    int nb = (E + 255) / 256; if (nb > h->rms_blocks) nb = h->rms_blocks;
     int rc = observe_dev(h, true); if (rc) return rc;                                      // new_obs = observe(env), trajectory.jl:32
     for (int t = 0; t < T; ++t) {
         const size_t k = (size_t)t * E;
         const void* nz = h->noise_set ? (const void*)((const char*)h->noise_dev + k * (h->discrete ? 8 : 4 * (size_t)A)) : nullptr;
         PolicyArgs p = policy_args(h, h->e_obs, E, nz, (char*)h->act + k * ab, h->val + k, h->logp + k, nullptr, 0);
         p.gstep = h->gstep; p.env_seed0 = h->env_seed0; p.obs_out = h->obs + k * D;
+        if (t > 0) { p.boot_obs = h->e_tobs; p.boot_where = h->e_trunc; p.boot_out = h->boot + (k - E); }   // :57-61 for step t-1
         HIPCHK(h, launch_policy(h->cfg.env_kind, h->cfg.hidden1, p, 8 * h->num_cus, h->stream));   // get_action_and_values, :41
-        rc = step_dev(h, (const char*)h->act + k * ab, h->rew + k, h->flags + k); if (rc) return rc;   // to_env + act!, :43-44
-        PolicyArgs b = policy_args(h, h->e_tobs, E, nullptr, nullptr, h->boot + k, nullptr, nullptr, 2);
-        b.only_where = h->e_trunc;
-        HIPCHK(h, launch_policy(h->cfg.env_kind, h->cfg.hidden1, b, 8 * h->num_cus, h->stream));   // V(terminal_observation), :57-61
-        rc = observe_dev(h, true); if (rc) return rc;                                       // new_obs = observe(env), :45
+        NormStepArgs s{};
+        s.E = E; s.episode_len = h->cfg.episode_len; s.fixed_len = h->cfg.fixed_length_episodes; s.action_start = h->cfg.action_start;
+        s.seed0 = h->env_seed0; s.gamma = h->cfg.norm_gamma; s.update_ret = (h->cfg.norm_reward && h->cfg.norm_training) ? 1 : 0;
+        s.actions = (const char*)h->act + k * ab; s.state = h->state; s.step_count = h->step_count; s.episode = h->episode; s.gstep = h->gstep;
+        s.disc_returns = h->disc_returns; s.rew_raw = h->e_rew; s.term = h->e_term; s.trunc = h->e_trunc; s.flags_out = h->flags + k;
+        s.tobs_raw = h->e_tobs; s.obs_raw = h->e_obs_raw; s.partials = h->rms_partials;
+        HIPCHK(h, launch_norm_step(h->cfg.env_kind, s, nb, h->stream));                              // to_env + act!, :43-44
+        NormApplyArgs ap{};
+        ap.E = E; ap.D = D; ap.nblocks = nb; ap.update_obs = (h->cfg.norm_obs && h->cfg.norm_training) ? 1 : 0; ap.update_ret = s.update_ret;
+        ap.norm_obs = h->cfg.norm_obs; ap.norm_reward = h->cfg.norm_reward; ap.partials = h->rms_partials;
+        ap.obs_in = h->obs_rms + h->obs_par; ap.obs_out = h->obs_rms + (h->obs_par ^ 1); ap.ret_in = h->ret_rms + h->ret_par; ap.ret_out = h->ret_rms + (h->ret_par ^ 1);
+        ap.rew_raw = h->e_rew; ap.rew_out = h->rew + k; ap.disc_returns = h->disc_returns; ap.term = h->e_term; ap.trunc = h->e_trunc; ap.tobs = h->e_tobs;
+        ap.obs_raw = h->e_obs_raw; ap.obs_n = h->e_obs; ap.clip_obs = h->cfg.clip_obs; ap.clip_reward = h->cfg.clip_reward; ap.eps = h->cfg.norm_epsilon;
+        HIPCHK(h, launch_norm_apply(ap, h->stream));                                                 // new_obs = observe(env), :45
+        h->obs_par ^= 1; h->ret_par ^= 1;
     }
     PolicyArgs l = policy_args(h, h->e_obs, E, nullptr, nullptr, h->last_values, nullptr, nullptr, 2);
+    l.boot_obs = h->e_tobs; l.boot_where = h->e_trunc; l.boot_out = h->boot + (size_t)(T - 1) * E;
     HIPCHK(h, launch_policy(h->cfg.env_kind, h->cfg.hidden1, l, 8 * h->num_cus, h->stream));       // V(new_obs) for rollout-limited tails, :65-70
     return DRIL_OK;
 }

@@ -15,6 +15,7 @@ struct PolicyArgs {
     float* obs_out;                              // optional copy of the consumed observations (rollout buffer slice)
     const uint8_t* only_where;                   // optional: waves with no flagged sample skip (bootstrap critic on truncated envs)
     const float* w2a_actor; const float* w2a_critic;   // wide nets: pre-tiled W2 images in global memory
+    const float* boot_obs; const uint8_t* boot_where; float* boot_out;   // fused V(terminal_observation) of the PREVIOUS env step (trajectory.jl:57-61)
     NetOff actor, critic;
 };
 
@@ -86,6 +87,19 @@ hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int
                            float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* rew, uint8_t* term, uint8_t* trunc,
                            float* tobs, hipStream_t s);
 hipError_t launch_policy(int kind, int hidden, const PolicyArgs& a, int max_blocks, hipStream_t s);
+struct NormStepArgs {   // fused act! of NormalizeWrapperEnv over MultiThreadedParallelEnv: physics + auto-reset + all partial moments
+    int E, episode_len, fixed_len, action_start; uint64_t seed0; float gamma; int update_ret;
+    const void* actions; float* state; int32_t* step_count; uint32_t* episode; uint32_t* gstep; float* disc_returns;
+    float* rew_raw; uint8_t* term; uint8_t* trunc; uint8_t* flags_out; float* tobs_raw; float* obs_raw; double* partials;
+};
+struct NormApplyArgs {
+    int E, D, nblocks, update_obs, update_ret, norm_obs, norm_reward;
+    const double* partials; const RmsState* obs_in; RmsState* obs_out; const RmsState* ret_in; RmsState* ret_out;
+    const float* rew_raw; float* rew_out; float* disc_returns; const uint8_t* term; const uint8_t* trunc; float* tobs; const float* obs_raw; float* obs_n;
+    float clip_obs, clip_reward, eps;
+};
+hipError_t launch_norm_step(int kind, const NormStepArgs& a, int nblocks, hipStream_t s);
+hipError_t launch_norm_apply(const NormApplyArgs& a, hipStream_t s);
 hipError_t launch_obs_partials(int kind, int E, const float* state, float* raw, double* partials, int nblocks, hipStream_t s);
 hipError_t launch_norm_obs_apply(const NormObsArgs& a, hipStream_t s);
 hipError_t launch_rew_partials(int E, const float* rew_raw, float* disc_returns, float gamma, int update, double* partials, int nblocks, hipStream_t s);

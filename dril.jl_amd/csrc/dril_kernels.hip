@@ -176,6 +176,91 @@ __global__ void norm_rew_apply_kernel(NormRewArgs a) {
     }
 }
 
+// fused step of the normalised rollout: one launch does act! for every env (physics, flags, terminal_observation, auto-reset,
+// discounted-return update) AND the per-block partial moments of the new observations and of the discounted returns;
+// norm_apply_kernel then merges both RunningMeanStd states and normalises rewards, terminal observations (OLD obs statistics,
+// normalizeWrapperEnv.jl:157-163) and the next observations (NEW statistics, :123-137).  7 launches per env step -> 3.
+template <int KIND>
+__global__ void norm_step_kernel(NormStepArgs a) {
+    constexpr int S = EnvSpec<KIND>::S, D = EnvSpec<KIND>::D;
+    __shared__ double sh[16];
+    double acc[2 + 2 * D];
+#pragma unroll
+    for (int i = 0; i < 2 + 2 * D; ++i) acc[i] = 0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.E; e += gridDim.x * blockDim.x) {
+        float st[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) st[i] = a.state[(size_t)e * S + i];
+        int ai = 0; float af = 0.f;
+        if (EnvSpec<KIND>::discrete) ai = ((const int32_t*)a.actions)[e] - a.action_start; else af = ((const float*)a.actions)[e];
+        bool t;
+        const float r = env_step<KIND>(st, af, ai, a.fixed_len != 0, &t);
+        const int sc = a.step_count[e] + 1;
+        const bool tr = sc >= a.episode_len;
+        a.rew_raw[e] = r; a.term[e] = t; a.trunc[e] = tr; a.gstep[e] += 1;
+        if (a.flags_out) a.flags_out[e] = (uint8_t)((t ? 1 : 0) | (tr ? 2 : 0));
+        float disc = a.disc_returns[e];
+        if (a.update_ret) { disc = disc * a.gamma + r; a.disc_returns[e] = disc; }       // update_reward_stats! :167-171 (reset of done envs happens in norm_apply_kernel)
+        acc[0] += disc; acc[1] += (double)disc * disc;
+        if (tr) { float o[D]; env_obs<KIND>(st, o);
+#pragma unroll
+            for (int i = 0; i < D; ++i) a.tobs_raw[(size_t)e * D + i] = o[i]; }
+        if (t || tr) { const uint32_t ep = a.episode[e] + 1; a.episode[e] = ep; a.step_count[e] = 0; env_reset<KIND>(a.seed0 + (uint64_t)e, ep, st); }
+        else a.step_count[e] = sc;
+#pragma unroll
+        for (int i = 0; i < S; ++i) a.state[(size_t)e * S + i] = st[i];
+        float o[D]; env_obs<KIND>(st, o);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { a.obs_raw[(size_t)e * D + d] = o[d]; acc[2 + 2 * d] += o[d]; acc[3 + 2 * d] += (double)o[d] * o[d]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 2 + 2 * D; ++i) {
+        const double v = block_sum_f64(acc[i], sh);
+        if (threadIdx.x == 0) a.partials[(size_t)blockIdx.x * 16 + i] = v;
+    }
+}
+
+__global__ void norm_apply_kernel(NormApplyArgs a) {
+    __shared__ float s_mean_new[8], s_var_new[8], s_mean_old[8], s_var_old[8], s_rvar;
+    if (threadIdx.x <= a.D) {
+        const int i = threadIdx.x;                       // 0: discounted returns, 1..D: observation dims
+        const RmsState* in = i == 0 ? a.ret_in : a.obs_in;
+        const int d = i == 0 ? 0 : i - 1;
+        float mean = in->mean[d], var = in->var[d];
+        const float mean_old = mean, var_old = var;
+        const int upd = i == 0 ? a.update_ret : a.update_obs;
+        if (upd) {
+            double s = 0, q = 0;
+            const int col = i == 0 ? 0 : 2 * i;
+            for (int b = 0; b < a.nblocks; ++b) { s += a.partials[(size_t)b * 16 + col]; q += a.partials[(size_t)b * 16 + col + 1]; }
+            const double bm = s / a.E; double bv = q / a.E - bm * bm; if (bv < 0) bv = 0;
+            rms_merge(mean, var, in->count, (float)bm, (float)bv, a.E);
+        }
+        if (i == 0) { s_rvar = var; if (blockIdx.x == 0) { a.ret_out->mean[0] = mean; a.ret_out->var[0] = var; a.ret_out->count = in->count + (upd ? a.E : 0); } }
+        else {
+            s_mean_new[d] = mean; s_var_new[d] = var; s_mean_old[d] = mean_old; s_var_old[d] = var_old;
+            if (blockIdx.x == 0) { a.obs_out->mean[d] = mean; a.obs_out->var[d] = var; if (d == 0) a.obs_out->count = in->count + (upd ? a.E : 0); }
+        }
+    }
+    __syncthreads();
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.E; e += gridDim.x * blockDim.x) {
+        float r = a.rew_raw[e];
+        if (a.norm_reward) { r = r / sqrtf(s_rvar + a.eps); r = fminf(fmaxf(r, -a.clip_reward), a.clip_reward); }
+        a.rew_out[e] = r;
+        const bool tr = a.trunc[e] != 0;
+        if (a.term[e] || tr) a.disc_returns[e] = 0.f;
+        for (int d = 0; d < a.D; ++d) {
+            float v = a.obs_raw[(size_t)e * a.D + d];
+            if (a.norm_obs) { v = (v - s_mean_new[d]) / sqrtf(s_var_new[d] + a.eps); v = fminf(fmaxf(v, -a.clip_obs), a.clip_obs); }
+            a.obs_n[(size_t)e * a.D + d] = v;
+            if (a.norm_obs && tr) {
+                float tv = (a.tobs[(size_t)e * a.D + d] - s_mean_old[d]) / sqrtf(s_var_old[d] + a.eps);
+                a.tobs[(size_t)e * a.D + d] = fminf(fmaxf(tv, -a.clip_obs), a.clip_obs);
+            }
+        }
+    }
+}
+
 // =============================================================================================
 // distribution heads shared by policy_kernel / rollout_kernel / ppo_grad_kernel
 // =============================================================================================
@@ -277,6 +362,17 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void policy_kernel(PolicyArgs a)
         const bool valid = b < a.B;
         const int64_t bb = valid ? b : a.B - 1;
         if (a.only_where && !__any(valid && a.only_where[bb] != 0)) continue;     // wave-uniform skip
+        if (a.boot_where) {                                                        // V(terminal_observation) of the previous env step
+            const bool tr = valid && a.boot_where[bb] != 0;
+            if (__any(tr)) {
+                float tk[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; tk[s] = d < D ? a.boot_obs[bb * D + d] : 0.f; }
+                float bv[1];
+                eval_net<D, H, 1, WIDE>(lc, a.w2a_critic, tk, bv, lane);
+                if (tr && h == 0) a.boot_out[b] = bv[0];
+            }
+        }
         float xk[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; xk[s] = d < D ? a.obs[bb * D + d] : 0.f; }
@@ -1406,6 +1502,15 @@ hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int
     return hipGetLastError();
 }
 
+hipError_t launch_norm_step(int kind, const NormStepArgs& a, int nblocks, hipStream_t s) {
+    if (kind == 0) norm_step_kernel<0><<<nblocks, 256, 0, s>>>(a); else norm_step_kernel<1><<<nblocks, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+hipError_t launch_norm_apply(const NormApplyArgs& a, hipStream_t s) {
+    int blocks = (a.E + 255) / 256; if (blocks > 1024) blocks = 1024;
+    norm_apply_kernel<<<blocks, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
 hipError_t launch_obs_partials(int kind, int E, const float* state, float* raw, double* partials, int nblocks, hipStream_t s) {
     if (kind == 0) obs_partials_kernel<0><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
     else obs_partials_kernel<1><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
@@ -1434,8 +1539,9 @@ hipError_t launch_policy(int kind, int hidden, const PolicyArgs& a, int max_bloc
 #define CALL(K, HH)                                                                                           \
     {                                                                                                         \
         const size_t lds = fwd_lds_bytes<K, HH, (HH > 64)>();                                                 \
-        hipError_t e = hipFuncSetAttribute((const void*)policy_kernel<K, HH, (HH > 64)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) return e;                                                                        \
+        static bool attr_set = false;                                                                         \
+        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)policy_kernel<K, HH, (HH > 64)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e; attr_set = true; }                                                 \
         policy_kernel<K, HH, (HH > 64)><<<blocks, 256, lds, s>>>(a);                                          \
     }
     DRIL_DISPATCH_FWD(kind, hidden, CALL);
@@ -1448,8 +1554,9 @@ hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_
 #define CALL(K, HH)                                                                                           \
     {                                                                                                         \
         const size_t lds = fwd_lds_bytes<K, HH, (HH > 64)>();                                                 \
-        hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel<K, HH, (HH > 64)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) return e;                                                                        \
+        static bool attr_set = false;                                                                         \
+        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel<K, HH, (HH > 64)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e; attr_set = true; }                                                 \
         rollout_kernel<K, HH, (HH > 64)><<<blocks, 256, lds, s>>>(a);                                         \
     }
     DRIL_DISPATCH_FWD(kind, hidden, CALL);
@@ -1487,15 +1594,17 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
 #define CALLR(K, HH, R)                                                                                       \
     {                                                                                                         \
         const size_t lds = grad_lds_bytes<K, HH>();                                                           \
-        hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<K, HH, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) return e;                                                                        \
+        static bool attr_set = false;                                                                         \
+        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<K, HH, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e; attr_set = true; }                                                 \
         ppo_grad_kernel<K, HH, R><<<2 * a.G, 256, lds, s>>>(a);                                               \
     }
 #define CALLW(K, HH, R)                                                                                       \
     {                                                                                                         \
         const size_t lds = grad_wide_lds_bytes<K, HH>();                                                      \
-        hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wide_kernel<K, HH, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) return e;                                                                        \
+        static bool attr_set = false;                                                                         \
+        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wide_kernel<K, HH, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e; attr_set = true; }                                                 \
         ppo_grad_wide_kernel<K, HH, R><<<2 * a.G, HH * 2, lds, s>>>(a);                                       \
     }
     if (hidden == 256) {
