@@ -118,6 +118,9 @@ __device__ __forceinline__ float tanh_f32(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // e^{2x} = 2^{2x log2(e)}
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
+// The forward weight images (W1, b1, W2, b2) are staged PRE-SCALED by 2*log2(e), so the MFMA accumulator already holds
+// 2*log2(e)*x and tanh needs no multiply: tanh(x) = 1 - 2/(2^acc + 1).  The backward reads the unscaled W2' image.
+constexpr float kTanhScale = 2.8853900817779268f;
 
 // ---------------------------------------------------------------------------------------------
 // environments
@@ -209,16 +212,16 @@ __device__ inline void stage_net(float* lds, const float* __restrict__ P, NetOff
     using L = NetLds<D, H1, H2, O>;
     for (int i = tid; i < L::DP * H1; i += nthreads) {
         const int o = i % H1, k = i / H1;
-        lds[L::W1T + k * H1 + o] = k < D ? P[n.w1 + o + k * H1] : 0.0f;
+        lds[L::W1T + k * H1 + o] = k < D ? kTanhScale * P[n.w1 + o + k * H1] : 0.0f;
     }
-    for (int i = tid; i < H1; i += nthreads) lds[L::B1 + i] = P[n.b1 + i];
+    for (int i = tid; i < H1; i += nthreads) lds[L::B1 + i] = kTanhScale * P[n.b1 + i];
     for (int i = tid; i < H2 * H1; i += nthreads) {
         const int o = i % H2, k = i / H2;
         const float w = P[n.w2 + i];
-        lds[L::W2S + o * L::WS1 + k] = w;
+        lds[L::W2S + o * L::WS1 + k] = kTanhScale * w;
         if (BWD) lds[L::W2T + k * L::WS2 + o] = w;
     }
-    for (int i = tid; i < H2; i += nthreads) lds[L::B2 + i] = P[n.b2 + i];
+    for (int i = tid; i < H2; i += nthreads) lds[L::B2 + i] = kTanhScale * P[n.b2 + i];
     for (int i = tid; i < O * H2; i += nthreads) {
         const int o = i % O, k = i / O;
         lds[L::W3S + o * H2 + k] = P[n.w3 + i];
@@ -323,9 +326,9 @@ __device__ __forceinline__ void dense_first(const float* __restrict__ W1T, const
 // stage-wise over the 16 registers of a tile so the five dependent ops of one element interleave with the other
 // fifteen (the element-by-element form left s_nop bubbles after every v_exp/v_rcp: stamps, profiles/r01_v3)
 __device__ __forceinline__ void tanh16(f32x16& x) {
-    f32x16 t = x * 2.8853900817779268f;
+    f32x16 t;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t[i] = __builtin_amdgcn_exp2f(t[i]);
+    for (int i = 0; i < 16; ++i) t[i] = __builtin_amdgcn_exp2f(x[i]);        // x is pre-scaled by kTanhScale
     t = t + 1.0f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t[i] = __builtin_amdgcn_rcpf(t[i]);
@@ -384,8 +387,8 @@ template <int D, int H, int O> struct NetLdsSmall {
 template <int D, int H, int O>
 __device__ inline void stage_net_small(float* lds, const float* __restrict__ P, NetOff n, int tid, int nthreads) {
     using L = NetLdsSmall<D, H, O>;
-    for (int i = tid; i < L::DP * H; i += nthreads) { const int o = i % H, k = i / H; lds[L::W1T + k * H + o] = k < D ? P[n.w1 + o + k * H] : 0.0f; }
-    for (int i = tid; i < H; i += nthreads) { lds[L::B1 + i] = P[n.b1 + i]; lds[L::B2 + i] = P[n.b2 + i]; }
+    for (int i = tid; i < L::DP * H; i += nthreads) { const int o = i % H, k = i / H; lds[L::W1T + k * H + o] = k < D ? kTanhScale * P[n.w1 + o + k * H] : 0.0f; }
+    for (int i = tid; i < H; i += nthreads) { lds[L::B1 + i] = kTanhScale * P[n.b1 + i]; lds[L::B2 + i] = kTanhScale * P[n.b2 + i]; }
     for (int i = tid; i < O * H; i += nthreads) { const int o = i % O, k = i / O; lds[L::W3S + o * H + k] = P[n.w3 + i]; }
     for (int i = tid; i < L::OP; i += nthreads) lds[L::B3 + i] = i < O ? P[n.b3 + i] : 0.0f;
 }

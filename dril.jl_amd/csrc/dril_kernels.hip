@@ -336,7 +336,7 @@ __global__ void build_wimg_kernel(const float* __restrict__ P, NetOff off, int H
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < H * H; idx += gridDim.x * blockDim.x) {
         const int c = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) & 3, mi = (idx >> 10) % MT, mo = (idx >> 10) / MT;
         const int o = 32 * mo + (lane & 31), k = 32 * mi + 8 * q + 4 * (lane >> 5) + c;
-        w2a[idx] = P[off.w2 + o + k * H];      // W2[o][k]  (column-major out x in)
+        w2a[idx] = kTanhScale * P[off.w2 + o + k * H];      // W2[o][k]  (column-major out x in), pre-scaled for tanh16
         w2ta[idx] = P[off.w2 + k + o * H];     // W2'[o][k] = W2[k][o]
     }
 }
