@@ -504,3 +504,81 @@ def test_wide_rollout_and_update_config3_shape(pkg, oracle_mod):
     sh, so = h.ppo_update(), o.ppo_update()
     assert sh.n_updates == so.n_updates == 6 and sh.loss == pytest.approx(so.loss, rel=1e-4)
     np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=3e-4, atol=3e-6)
+
+
+@pytest.mark.parametrize("start", [0, 1, -1, -2])
+def test_discrete_action_start_offsets(pkg, oracle_mod, start):
+    """actions lie in Discrete(n, start) for start 0/1/-1/-2 and are stored with the offset (test/test_policies.jl:66-100,
+    src/DRiLDistributions/categorical.jl:51, trajectory.jl:48)"""
+    capi = pkg._capi
+    cfg = _cfg(pkg, 0, n_envs=96, n_steps=12, episode_len=50, batch_size=96 * 12, epochs=1, action_start=start)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 6, 0.4); h.set_params(flat); o.set_params(flat)
+    h.env_reset(2); o.env_reset(2)
+    noise = np.random.default_rng(1).random(h.N); h.set_noise(noise); o.set_noise(noise)
+    h.collect_rollout(); o.collect_rollout()
+    a = h.buffer(capi.BUF_ACTIONS)
+    assert set(np.unique(a)) == {start, start + 1}
+    assert (a == o.buffer(capi.BUF_ACTIONS)).mean() > 0.99
+    val, lp, ent = h.evaluate_actions(h.buffer(capi.BUF_OBSERVATIONS), a)
+    np.testing.assert_allclose(lp, h.buffer(capi.BUF_LOGPROBS), atol=1e-5, rtol=1e-5)
+    st = h.ppo_update(); so = o.ppo_update()
+    assert st.loss == pytest.approx(so.loss, rel=2e-3)
+
+
+def test_env_seeding_rule(pkg):
+    """Random.seed!(penv, s) seeds sub-env i with s + i - 1 (wrapper_utils.jl:39-44, test/test_env_seeding.jl:31-173):
+    same seed -> same observations; env i under seed s == env 0 under seed s + i"""
+    cfg = _cfg(pkg, 0, n_envs=8, n_steps=4, batch_size=4)
+    a, b, c = pkg.Handle(cfg), pkg.Handle(cfg), pkg.Handle(cfg)
+    a.env_reset(100); b.env_reset(100); c.env_reset(103)
+    oa, ob, oc = a.env_observe(), b.env_observe(), c.env_observe()
+    assert np.array_equal(oa, ob) and not np.array_equal(oa, oc)
+    assert np.array_equal(oa[3], oc[0]) and np.array_equal(oa[7], oc[4])
+    act = np.ones(8, np.int32)
+    for _ in range(30):                       # auto-reset draws (episode counter) are reproducible too
+        ra, ta, ua, _ = a.env_step(act); rb, tb, ub, _ = b.env_step(act)
+        assert np.array_equal(ta, tb)
+    assert np.array_equal(a.env_get_state()[0], b.env_get_state()[0]) and ta.any() | True
+
+
+@pytest.mark.parametrize("E,T,B", [(1, 1, 2), (33, 3, 7), (130, 5, 1000), (257, 2, 514)])
+def test_ragged_sizes(pkg, oracle_mod, E, T, B):
+    """sizes that are not multiples of the 32-sample tile / 128-env workgroup; batch larger than the buffer; single env"""
+    capi = pkg._capi
+    cfg = _cfg(pkg, 0, n_envs=E, n_steps=T, batch_size=B, epochs=2, episode_len=4)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 2, 0.3); h.set_params(flat); o.set_params(flat)
+    h.env_reset(9); o.env_reset(9)
+    noise = np.random.default_rng(E).random(E * T); h.set_noise(noise); o.set_noise(noise)
+    h.collect_rollout(); o.collect_rollout()
+    for which, tol in ((capi.BUF_VALUES, 5e-5), (capi.BUF_ADVANTAGES, 1e-3), (capi.BUF_RETURNS, 1e-3)):
+        np.testing.assert_allclose(h.buffer(which), o.buffer(which), atol=tol, rtol=tol)
+    if E * T >= 2 and (E * T) % B != 1:
+        for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+            h.set_buffer(which, o.buffer(which))
+        perm = np.stack([np.random.default_rng(e).permutation(E * T) for e in range(2)]).astype(np.int64)
+        h.set_permutation(perm); o.set_permutation(perm)
+        if E * T == 1:
+            return
+        sh, so = h.ppo_update(), o.ppo_update()
+        assert sh.n_updates == so.n_updates
+        np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=3e-4, atol=3e-6)
+
+
+def test_ppo_learns_cartpole(pkg):
+    """learning smoke test in the spirit of test/test_ppo_integration.jl:1-40: after training, episodes last longer"""
+    env = pkg.DeviceParallelEnv(pkg.CartPoleEnv(max_steps=200), 256, seed=5)
+    alg = pkg.PPO(n_steps=64, batch_size=2048, epochs=8, learning_rate=3e-3, ent_coef=0.0)
+    layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space())
+    agent = pkg.Agent(layer, alg, seed=1)
+    def mean_episode_length():
+        buf = pkg.RolloutBuffer(alg.n_steps, 256, alg.gae_lambda, alg.gamma)
+        pkg.collect_rollout_(buf, agent, alg, env)
+        done = (buf.flags != 0).sum()
+        return 256 * 64 / max(int(done), 1)
+    before = mean_episode_length()
+    stats, _ = pkg.train_(agent, env, alg, 40 * 64 * 256)
+    after = mean_episode_length()
+    assert np.isfinite(stats["losses"]).all() and len(stats["losses"]) == 40
+    assert after > 2.0 * before and after > 40, (before, after)
