@@ -38,7 +38,7 @@ class DrilConfig(C.Structure):
         ("norm_obs", C.c_int32), ("norm_reward", C.c_int32), ("norm_training", C.c_int32),
         ("clip_obs", C.c_float), ("clip_reward", C.c_float), ("norm_gamma", C.c_float), ("norm_epsilon", C.c_float),
         ("seed", C.c_uint64), ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
-        ("profile_events", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("profile_events", C.c_int32), ("monitor_window", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -78,6 +78,7 @@ def default_config(env_kind: int) -> DrilConfig:
     c.seed = 42
     c.device, c.rank, c.world_size = 0, 0, 1
     c.profile_events = 0
+    c.monitor_window = 0
     return c
 
 
@@ -104,6 +105,7 @@ _SIG = {
     "dril_env_set_state": (C.c_int32, [_P, _P, _P]),
     "dril_norm_get_stats": (C.c_int32, [_P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "dril_norm_set_stats": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_int64]),
+    "dril_monitor_get_stats": (C.c_int32, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "dril_policy_forward": (C.c_int32, [_P, _P, C.c_int64, _P, _P, _P, _P]),
     "dril_evaluate_actions": (C.c_int32, [_P, _P, _P, C.c_int64, _P, _P, _P]),
     "dril_predict_values": (C.c_int32, [_P, _P, C.c_int64, _P]),

@@ -81,6 +81,9 @@ struct dril_handle {
     bool force_allreduce = false, force_stepwise = false;
     double *epoch_tables = nullptr, *epoch_stats = nullptr; int epoch_blocks = 512, epoch_nb_cap = 0;   // per-epoch advantage moments
     float *w2a_actor = nullptr, *w2ta_actor = nullptr, *w2a_critic = nullptr, *w2ta_critic = nullptr; bool wide = false, wimg_dirty = true;   // wide nets (H > 64)
+    // MonitorWrapperEnv (cfg.monitor_window > 0)
+    float *mon_cur_ret = nullptr, *ep_ret = nullptr, *mon_ring_ret = nullptr, *e_ep_ret = nullptr; int32_t *mon_cur_len = nullptr, *ep_len = nullptr, *mon_ring_len = nullptr, *e_ep_len = nullptr;
+    int *mon_cnt = nullptr, *mon_meta = nullptr; uint8_t* e_flags = nullptr;
     float4* rec = nullptr;   // packed minibatch records (see pack_records_kernel)
     RmsState *obs_rms = nullptr, *ret_rms = nullptr; int obs_par = 0, ret_par = 0;   // ping-pong RunningMeanStd pairs
     double* rms_partials = nullptr; int rms_blocks = 256; float* e_obs_raw = nullptr;
@@ -153,6 +156,22 @@ PolicyArgs policy_args(dril_handle* h, const float* obs, int64_t B, const void* 
     return a;
 }
 
+// ---- MonitorWrapperEnv helpers ----
+MonitorArgs monitor_step_args(dril_handle* h) {   // one env step: finished episodes land in the E-sized step arrays
+    MonitorArgs m{}; if (h->mon_cur_ret) { m.cur_ret = h->mon_cur_ret; m.cur_len = h->mon_cur_len; m.ep_ret = h->e_ep_ret; m.ep_len = h->e_ep_len; m.flags_out = h->e_flags; }
+    return m;
+}
+int monitor_collect_step(dril_handle* h) {
+    if (!h->mon_cur_ret) return DRIL_OK;
+    HIPCHK(h, launch_monitor_collect(h->e_flags, h->e_ep_ret, h->e_ep_len, h->cfg.n_envs, 1, h->cfg.monitor_window, h->mon_cnt, h->mon_ring_ret, h->mon_ring_len, h->mon_meta, h->stream));
+    return DRIL_OK;
+}
+int monitor_collect_rollout(dril_handle* h) {
+    if (!h->mon_cur_ret) return DRIL_OK;
+    HIPCHK(h, launch_monitor_collect(h->flags, h->ep_ret, h->ep_len, h->cfg.n_envs, h->cfg.n_steps, h->cfg.monitor_window, h->mon_cnt, h->mon_ring_ret, h->mon_ring_len, h->mon_meta, h->stream));
+    return DRIL_OK;
+}
+
 // ---- step-granular env verbs on device (NormalizeWrapperEnv.observe / act!, normalizeWrapperEnv.jl:123-165) ----
 int observe_dev(dril_handle* h, bool update_stats) {
     const int E = h->cfg.n_envs;
@@ -170,7 +189,8 @@ int observe_dev(dril_handle* h, bool update_stats) {
 int step_dev(dril_handle* h, const void* actions, float* rew_out, uint8_t* flags_out) {
     const int E = h->cfg.n_envs;
     HIPCHK(h, launch_env_step(h->cfg.env_kind, E, h->env_seed0, h->cfg.episode_len, h->cfg.fixed_length_episodes, h->cfg.action_start, actions,
-                              h->state, h->step_count, h->episode, h->gstep, h->e_rew, h->e_term, h->e_trunc, h->e_tobs, h->stream));
+                              h->state, h->step_count, h->episode, h->gstep, h->e_rew, h->e_term, h->e_trunc, h->e_tobs, monitor_step_args(h), h->stream));
+    { int rcm = monitor_collect_step(h); if (rcm) return rcm; }
     int nb = (E + 255) / 256; if (nb > h->rms_blocks) nb = h->rms_blocks;
     const int upd = (h->cfg.norm_reward && h->cfg.norm_training) ? 1 : 0;
     HIPCHK(h, launch_rew_partials(E, h->e_rew, h->disc_returns, h->cfg.norm_gamma, upd, h->rms_partials, nb, h->stream));
@@ -296,6 +316,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (cfg->env_kind != DRIL_ENV_CARTPOLE && cfg->env_kind != DRIL_ENV_PENDULUM) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
     if (cfg->n_envs < 1 || cfg->n_steps < 1 || cfg->epochs < 0 || cfg->batch_size < 1) return fail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs/n_steps/batch_size must be positive");
     if (cfg->hidden1 != cfg->hidden2 || (cfg->hidden1 != 64 && cfg->hidden1 != 256)) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden_dims: [64,64] and [256,256] are built");
+    if (cfg->monitor_window < 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "monitor_window must be >= 0");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad rank/world_size");
     if (cfg->batch_size % cfg->world_size != 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "batch_size must be divisible by world_size");
     dril_handle* h = nullptr;
@@ -335,6 +356,13 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(dmalloc(&h->ret, N)); CCHK(dmalloc(&h->logp, N)); CCHK(dmalloc(&h->val, N)); CCHK(dmalloc(&h->boot, N)); CCHK(dmalloc(&h->flags, N));
     CCHK(dmalloc(&h->last_values, E));
     if (!std::getenv("DRIL_NO_RECORDS")) CCHK(dmalloc(&h->rec, 2 * N));
+    if (cfg->monitor_window > 0) {
+        const size_t W = cfg->monitor_window;
+        CCHK(dmalloc(&h->mon_cur_ret, E)); CCHK(dmalloc(&h->mon_cur_len, E)); CCHK(dmalloc(&h->ep_ret, N)); CCHK(dmalloc(&h->ep_len, N));
+        CCHK(dmalloc(&h->mon_ring_ret, W)); CCHK(dmalloc(&h->mon_ring_len, W)); CCHK(dmalloc(&h->e_ep_ret, E)); CCHK(dmalloc(&h->e_ep_len, E));
+        CCHK(dmalloc(&h->mon_cnt, (size_t)cfg->n_steps)); CCHK(dmalloc(&h->mon_meta, 2)); CCHK(dmalloc(&h->e_flags, E));
+        CCHK(hipMemset(h->mon_cur_ret, 0, E * 4)); CCHK(hipMemset(h->mon_cur_len, 0, E * 4)); CCHK(hipMemset(h->mon_meta, 0, 8));
+    }
     h->adv_blocks = 1024; CCHK(dmalloc(&h->adv_partials, 2 * (size_t)h->adv_blocks)); CCHK(dmalloc(&h->adv_stats, 4));
     h->ev_blocks = 1024; CCHK(dmalloc(&h->ev_partials, 4 * (size_t)h->ev_blocks));
     CCHK(dmalloc(&h->stop_flag, 1)); CCHK(dmalloc(&h->nan_flag, 1));
@@ -365,7 +393,8 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
                     h->flags, h->last_values, h->noise_dev, h->perm_dev, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
-                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->obs_rms, h->ret_rms, h->rms_partials, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic};
+                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->obs_rms, h->ret_rms, h->rms_partials, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
+                    h->mon_ring_len, h->e_ep_len, h->mon_cnt, h->mon_meta, h->e_flags};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& p : h->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& p : h->prof_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
@@ -396,6 +425,7 @@ DRIL_EXPORT int32_t dril_env_reset(dril_handle* h, uint64_t seed) {
     NEED(h);
     h->env_seed0 = seed + (uint64_t)h->cfg.rank * (uint64_t)h->cfg.n_envs;
     HIPCHK(h, launch_env_reset(h->cfg.env_kind, h->cfg.n_envs, h->env_seed0, h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->stream));
+    if (h->mon_cur_ret) { HIPCHK(h, hipMemsetAsync(h->mon_cur_ret, 0, (size_t)h->cfg.n_envs * 4, h->stream)); HIPCHK(h, hipMemsetAsync(h->mon_cur_len, 0, (size_t)h->cfg.n_envs * 4, h->stream)); }   // MonitorWrapperEnv.reset! :38-44
     h->env_ready = true;
     return sync(h);
 }
@@ -416,8 +446,11 @@ DRIL_EXPORT int32_t dril_env_step(dril_handle* h, const void* actions, float* re
     HIPCHK(h, hipMemcpyAsync(h->e_act, actions, E * act_bytes_per(h), hipMemcpyHostToDevice, h->stream));
     float* rew_dev = h->e_rew;
     if (normalizing(h)) { rew_dev = h->e_obs_raw; int rc = step_dev(h, h->e_act, rew_dev, nullptr); if (rc) return rc; }   // e_obs_raw doubles as scratch for the normalised rewards
-    else HIPCHK(h, launch_env_step(h->cfg.env_kind, (int)E, h->env_seed0, h->cfg.episode_len, h->cfg.fixed_length_episodes, h->cfg.action_start,
-                                   h->e_act, h->state, h->step_count, h->episode, h->gstep, h->e_rew, h->e_term, h->e_trunc, h->e_tobs, h->stream));
+    else {
+        HIPCHK(h, launch_env_step(h->cfg.env_kind, (int)E, h->env_seed0, h->cfg.episode_len, h->cfg.fixed_length_episodes, h->cfg.action_start,
+                                  h->e_act, h->state, h->step_count, h->episode, h->gstep, h->e_rew, h->e_term, h->e_trunc, h->e_tobs, monitor_step_args(h), h->stream));
+        int rcm = monitor_collect_step(h); if (rcm) return rcm;
+    }
     if (rewards) HIPCHK(h, hipMemcpyAsync(rewards, rew_dev, E * 4, hipMemcpyDeviceToHost, h->stream));
     if (terminated) HIPCHK(h, hipMemcpyAsync(terminated, h->e_term, E, hipMemcpyDeviceToHost, h->stream));
     if (truncated) HIPCHK(h, hipMemcpyAsync(truncated, h->e_trunc, E, hipMemcpyDeviceToHost, h->stream));
@@ -455,6 +488,23 @@ DRIL_EXPORT int32_t dril_norm_set_stats(dril_handle* h, const float* obs_mean, c
     HIPCHK(h, hipMemcpyAsync(h->obs_rms + h->obs_par, &o, sizeof(o), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->ret_rms + h->ret_par, &r, sizeof(r), hipMemcpyHostToDevice, h->stream));
     return sync(h);
+}
+
+DRIL_EXPORT int32_t dril_monitor_get_stats(dril_handle* h, float* ep_rew_mean, float* ep_len_mean, int32_t* n_episodes) {
+    NEED(h);
+    if (!h->mon_cur_ret) return fail(h, DRIL_ERR_NOT_INITIALISED, "MonitorWrapperEnv is off (cfg.monitor_window == 0)");
+    const int W = h->cfg.monitor_window;
+    std::vector<float> r(W); std::vector<int32_t> l(W); int meta[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(r.data(), h->mon_ring_ret, (size_t)W * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(l.data(), h->mon_ring_len, (size_t)W * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(meta, h->mon_meta, 8, hipMemcpyDeviceToHost, h->stream));
+    int rc = sync(h); if (rc) return rc;
+    double sr = 0, sl = 0;
+    for (int i = 0; i < meta[0]; ++i) { sr += r[i]; sl += l[i]; }
+    if (n_episodes) *n_episodes = meta[0];
+    if (ep_rew_mean) *ep_rew_mean = meta[0] ? (float)(sr / meta[0]) : 0.f;      // log_stats: mean over the CircularBuffer, monitorWrapperEnv.jl:64-70
+    if (ep_len_mean) *ep_len_mean = meta[0] ? (float)(sl / meta[0]) : 0.f;
+    return DRIL_OK;
 }
 
 // ---- policy on host batches ----------------------------------------------------------------------
@@ -526,6 +576,7 @@ int collect_rollout_stepwise(dril_handle* h) {
         s.actions = (const char*)h->act + k * ab; s.state = h->state; s.step_count = h->step_count; s.episode = h->episode; s.gstep = h->gstep;
         s.disc_returns = h->disc_returns; s.rew_raw = h->e_rew; s.term = h->e_term; s.trunc = h->e_trunc; s.flags_out = h->flags + k;
         s.tobs_raw = h->e_tobs; s.obs_raw = h->e_obs_raw; s.partials = h->rms_partials;
+        if (h->mon_cur_ret) { s.mon_cur_ret = h->mon_cur_ret; s.mon_cur_len = h->mon_cur_len; s.ep_ret = h->ep_ret + k; s.ep_len = h->ep_len + k; }
         HIPCHK(h, launch_norm_step(h->cfg.env_kind, s, nb, h->stream));                              // to_env + act!, :43-44
         NormApplyArgs ap{};
         ap.E = E; ap.D = D; ap.nblocks = nb; ap.update_obs = (h->cfg.norm_obs && h->cfg.norm_training) ? 1 : 0; ap.update_ret = s.update_ret;
@@ -539,7 +590,7 @@ int collect_rollout_stepwise(dril_handle* h) {
     PolicyArgs l = policy_args(h, h->e_obs, E, nullptr, nullptr, h->last_values, nullptr, nullptr, 2);
     l.boot_obs = h->e_tobs; l.boot_where = h->e_trunc; l.boot_out = h->boot + (size_t)(T - 1) * E;
     HIPCHK(h, launch_policy(h->cfg.env_kind, h->cfg.hidden1, l, 8 * h->num_cus, h->stream));       // V(new_obs) for rollout-limited tails, :65-70
-    return DRIL_OK;
+    return monitor_collect_rollout(h);
 }
 
 int collect_rollout(dril_handle* h, double* fps, bool do_sync) {
@@ -564,6 +615,7 @@ int collect_rollout(dril_handle* h, double* fps, bool do_sync) {
     a.E = h->cfg.n_envs; a.T = h->cfg.n_steps; a.episode_len = h->cfg.episode_len; a.fixed_len = h->cfg.fixed_length_episodes;
     a.action_start = h->cfg.action_start; a.log_std_off = h->log_std_off; a.env_seed0 = h->env_seed0; a.actor = h->actor; a.critic = h->critic;
     a.w2a_actor = h->w2a_actor; a.w2a_critic = h->w2a_critic;
+    a.mon_cur_ret = h->mon_cur_ret; a.mon_cur_len = h->mon_cur_len; a.ep_ret = h->ep_ret; a.ep_len = h->ep_len;
     const auto t0 = std::chrono::steady_clock::now();
     if (fps) HIPCHK(h, hipStreamSynchronize(h->stream));
     prof_begin(h, DRIL_K_ROLLOUT);
@@ -575,6 +627,7 @@ int collect_rollout(dril_handle* h, double* fps, bool do_sync) {
         *fps = (double)h->N / (dt > 0 ? dt : 1e-12);
     }
     h->noise_set = false;
+    { int rcm = monitor_collect_rollout(h); if (rcm) return rcm; }
     int rc = compute_gae(h); if (rc) return rc;
     return do_sync ? sync(h) : DRIL_OK;
 }

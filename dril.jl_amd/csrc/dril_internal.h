@@ -41,6 +41,7 @@ struct RolloutArgs {
     int E, T, episode_len, fixed_len, action_start, log_std_off;
     uint64_t env_seed0;
     const float* w2a_actor; const float* w2a_critic;
+    float* mon_cur_ret; int32_t* mon_cur_len; float* ep_ret; int32_t* ep_len;   // MonitorWrapperEnv (null = off)
     NetOff actor, critic;
 };
 
@@ -83,14 +84,18 @@ struct AdamArgs {
 
 hipError_t launch_env_reset(int kind, int E, uint64_t seed0, float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* dr, hipStream_t s);
 hipError_t launch_env_observe(int kind, int E, const float* state, float* obs, hipStream_t s);
+struct MonitorArgs { float* cur_ret; int32_t* cur_len; float* ep_ret; int32_t* ep_len; uint8_t* flags_out; };
 hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int fixed_len, int action_start, const void* actions,
                            float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* rew, uint8_t* term, uint8_t* trunc,
-                           float* tobs, hipStream_t s);
+                           float* tobs, MonitorArgs mon, hipStream_t s);
+hipError_t launch_monitor_collect(const uint8_t* flags, const float* ep_ret, const int32_t* ep_len, int E, int T, int W, int* cnt,
+                                  float* ring_ret, int32_t* ring_len, int* meta, hipStream_t s);
 hipError_t launch_policy(int kind, int hidden, const PolicyArgs& a, int max_blocks, hipStream_t s);
 struct NormStepArgs {   // fused act! of NormalizeWrapperEnv over MultiThreadedParallelEnv: physics + auto-reset + all partial moments
     int E, episode_len, fixed_len, action_start; uint64_t seed0; float gamma; int update_ret;
     const void* actions; float* state; int32_t* step_count; uint32_t* episode; uint32_t* gstep; float* disc_returns;
     float* rew_raw; uint8_t* term; uint8_t* trunc; uint8_t* flags_out; float* tobs_raw; float* obs_raw; double* partials;
+    float* mon_cur_ret; int32_t* mon_cur_len; float* ep_ret; int32_t* ep_len;   // MonitorWrapperEnv (null = off)
 };
 struct NormApplyArgs {
     int E, D, nblocks, update_obs, update_ret, norm_obs, norm_reward;

@@ -45,7 +45,7 @@ __global__ void env_observe_kernel(int E, const float* state, float* obs) {
 template <int KIND>
 __global__ void env_step_kernel(int E, uint64_t seed0, int episode_len, int fixed_len, int action_start,
                                 const void* actions, float* state, int32_t* step_count, uint32_t* episode,
-                                uint32_t* gstep, float* rewards, uint8_t* term, uint8_t* trunc, float* terminal_obs) {
+                                uint32_t* gstep, float* rewards, uint8_t* term, uint8_t* trunc, float* terminal_obs, MonitorArgs mon) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     constexpr int S = EnvSpec<KIND>::S, D = EnvSpec<KIND>::D;
@@ -59,6 +59,11 @@ __global__ void env_step_kernel(int E, uint64_t seed0, int episode_len, int fixe
     const int sc = step_count[e] + 1;
     const bool tr = sc >= episode_len;
     rewards[e] = r; term[e] = t; trunc[e] = tr; gstep[e] += 1;
+    if (mon.cur_ret) {                                             // MonitorWrapperEnv.act! (monitorWrapperEnv.jl:46-60), raw reward
+        const float cr = mon.cur_ret[e] + r; const int cl = mon.cur_len[e] + 1;
+        if (t || tr) { mon.ep_ret[e] = cr; mon.ep_len[e] = cl; mon.cur_ret[e] = 0.f; mon.cur_len[e] = 0; } else { mon.cur_ret[e] = cr; mon.cur_len[e] = cl; }
+        mon.flags_out[e] = (uint8_t)((t ? 1 : 0) | (tr ? 2 : 0));
+    }
     if (tr) { float o[D]; env_obs<KIND>(st, o);
 #pragma unroll
         for (int i = 0; i < D; ++i) terminal_obs[(size_t)e * D + i] = o[i]; }
@@ -199,6 +204,10 @@ __global__ void norm_step_kernel(NormStepArgs a) {
         const bool tr = sc >= a.episode_len;
         a.rew_raw[e] = r; a.term[e] = t; a.trunc[e] = tr; a.gstep[e] += 1;
         if (a.flags_out) a.flags_out[e] = (uint8_t)((t ? 1 : 0) | (tr ? 2 : 0));
+        if (a.mon_cur_ret) {                                       // MonitorWrapperEnv sits inside the normaliser: raw reward
+            const float cr = a.mon_cur_ret[e] + r; const int cl = a.mon_cur_len[e] + 1;
+            if (t || tr) { a.ep_ret[e] = cr; a.ep_len[e] = cl; a.mon_cur_ret[e] = 0.f; a.mon_cur_len[e] = 0; } else { a.mon_cur_ret[e] = cr; a.mon_cur_len[e] = cl; }
+        }
         float disc = a.disc_returns[e];
         if (a.update_ret) { disc = disc * a.gamma + r; a.disc_returns[e] = disc; }       // update_reward_stats! :167-171 (reset of done envs happens in norm_apply_kernel)
         acc[0] += disc; acc[1] += (double)disc * disc;
@@ -258,6 +267,59 @@ __global__ void norm_apply_kernel(NormApplyArgs a) {
                 a.tobs[(size_t)e * a.D + d] = fminf(fmaxf(tv, -a.clip_obs), a.clip_obs);
             }
         }
+    }
+}
+
+// MonitorWrapperEnv's CircularBuffer of the last W finished episodes (monitorWrapperEnv.jl:1-7,53-58), kept on device.
+// Episodes finish in (step, env) order; after a rollout the collector pushes this rollout's events in that order, which
+// only requires the LAST min(n_events, W) of them: count per step, suffix-sum to the first contributing step, then a
+// block-wide prefix scan over the few rows that matter.
+__global__ void monitor_count_kernel(const uint8_t* __restrict__ flags, int E, int T, int* __restrict__ cnt) {
+    for (int t = blockIdx.x; t < T; t += gridDim.x) {
+        int c = 0;
+        for (int e = threadIdx.x; e < E; e += blockDim.x) c += flags[(size_t)t * E + e] != 0;
+        __shared__ int sh[16];
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) { int s = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w]; cnt[t] = s; }
+        __syncthreads();
+    }
+}
+__global__ void monitor_collect_kernel(const uint8_t* __restrict__ flags, const float* __restrict__ ep_ret, const int32_t* __restrict__ ep_len,
+                                       int E, int T, int W, const int* __restrict__ cnt, float* ring_ret, int32_t* ring_len, int* meta) {
+    __shared__ int s_t0, s_skip, s_total, s_base, wsum[16];
+    if (threadIdx.x == 0) {
+        int total = 0, t0 = T;
+        for (int t = T - 1; t >= 0; --t) { if (total >= W) break; total += cnt[t]; t0 = t; }
+        int all = 0; for (int t = 0; t < T; ++t) all += cnt[t];
+        s_t0 = t0; s_total = all; s_skip = total > W ? total - W : 0; s_base = 0;
+    }
+    __syncthreads();
+    if (s_total == 0) return;
+    const int head0 = meta[1];
+    for (int t = s_t0; t < T; ++t) {
+        for (int e0 = 0; e0 < E; e0 += blockDim.x) {
+            const int e = e0 + threadIdx.x;
+            const int f = (e < E && flags[(size_t)t * E + e] != 0) ? 1 : 0;
+            int incl = f;                                                            // inclusive scan within the wave
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+            if (lane == 63) wsum[wv] = incl;
+            __syncthreads();
+            int off = 0; for (int w = 0; w < wv; ++w) off += wsum[w];
+            int chunk = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) chunk += wsum[w];
+            const int gi = s_base + off + incl - f;                                  // index of this event among the rows t0..T-1
+            if (f && gi >= s_skip) { const int pos = (head0 + gi - s_skip) % W; ring_ret[pos] = ep_ret[(size_t)t * E + e]; ring_len[pos] = ep_len[(size_t)t * E + e]; }
+            __syncthreads();
+            if (threadIdx.x == 0) s_base += chunk;
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        const int pushed = s_base - s_skip;
+        meta[1] = (head0 + pushed) % W;
+        const int c = meta[0] + pushed; meta[0] = c > W ? W : c;
     }
 }
 
@@ -458,6 +520,8 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
     float obs[D];
     env_obs<KIND>(st, obs);
     const float* ls = a.params + a.log_std_off;
+    float mon_ret = a.mon_cur_ret ? a.mon_cur_ret[e] : 0.f;           // MonitorWrapperEnv running episode return / length
+    int mon_len = a.mon_cur_len ? a.mon_cur_len[e] : 0;
 
     for (int t = 0; t < a.T; ++t) {
         const size_t k = (size_t)t * a.E + e;
@@ -517,7 +581,12 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
             eval_net<D, H, 1, WIDE>(lc_t, a.w2a_critic, tk, bv, lane);
             if (writer && trunc) a.boot[k] = bv[0];
         }
-        if (term || trunc) { ep += 1; sc = 0; env_reset<KIND>(env_seed, ep, st); }
+        mon_ret += rew; mon_len += 1;
+        if (term || trunc) {
+            ep += 1; sc = 0; env_reset<KIND>(env_seed, ep, st);
+            if (writer && a.ep_ret) { a.ep_ret[k] = mon_ret; a.ep_len[k] = mon_len; }     // finished episode (monitorWrapperEnv.jl:53-58)
+            mon_ret = 0.f; mon_len = 0;
+        }
         if (writer) { a.rew[k] = rew; a.flags[k] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0)); }
         env_obs<KIND>(st, obs);                                              // observe(env), trajectory.jl:45
     }
@@ -532,6 +601,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
 #pragma unroll
         for (int i = 0; i < S; ++i) a.state[(size_t)e * S + i] = st[i];
         a.step_count[e] = sc; a.episode[e] = ep; a.gstep[e] = gs;
+        if (a.mon_cur_ret) { a.mon_cur_ret[e] = mon_ret; a.mon_cur_len[e] = mon_len; }
     }
 }
 
@@ -1495,10 +1565,16 @@ hipError_t launch_env_observe(int kind, int E, const float* state, float* obs, h
 }
 hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int fixed_len, int action_start, const void* actions,
                            float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* rew, uint8_t* term, uint8_t* trunc,
-                           float* tobs, hipStream_t s) {
+                           float* tobs, MonitorArgs mon, hipStream_t s) {
     const int blocks = (E + 255) / 256;
-    if (kind == 0) env_step_kernel<0><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs);
-    else env_step_kernel<1><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs);
+    if (kind == 0) env_step_kernel<0><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
+    else env_step_kernel<1><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
+    return hipGetLastError();
+}
+hipError_t launch_monitor_collect(const uint8_t* flags, const float* ep_ret, const int32_t* ep_len, int E, int T, int W, int* cnt,
+                                  float* ring_ret, int32_t* ring_len, int* meta, hipStream_t s) {
+    monitor_count_kernel<<<T < 1024 ? T : 1024, 256, 0, s>>>(flags, E, T, cnt);
+    monitor_collect_kernel<<<1, 1024, 0, s>>>(flags, ep_ret, ep_len, E, T, W, cnt, ring_ret, ring_len, meta);
     return hipGetLastError();
 }
 

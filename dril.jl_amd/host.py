@@ -223,7 +223,7 @@ class Agent:
 # --------------------------------------------------------------------------------------------
 def make_config(env, n_envs: int, alg: PPO, layer: Optional[ActorCriticLayer] = None, *, seed: int = 42,
                 fixed_length_episodes: bool = False, device: int = 0, rank: int = 0, world_size: int = 1,
-                profile_events: bool = False, normalize: Optional[dict] = None) -> DrilConfig:
+                profile_events: bool = False, normalize: Optional[dict] = None, monitor_window: int = 0) -> DrilConfig:
     c = capi.default_config(env.kind)
     c.n_envs, c.n_steps = n_envs, alg.n_steps
     if layer is not None:
@@ -244,6 +244,7 @@ def make_config(env, n_envs: int, alg: PPO, layer: Optional[ActorCriticLayer] = 
     c.batch_size, c.epochs, c.learning_rate = alg.batch_size, alg.epochs, alg.learning_rate
     c.seed, c.device, c.rank, c.world_size = seed, device, rank, world_size
     c.profile_events = int(profile_events)
+    c.monitor_window = int(monitor_window)
     if normalize is not None:   # NormalizeWrapperEnv kwargs, normalizeWrapperEnv.jl:71-80
         c.norm_training = int(normalize.get("training", True))
         c.norm_obs = int(normalize.get("norm_obs", True))
@@ -336,6 +337,12 @@ class Handle:
         st = np.ascontiguousarray(st, np.float32)
         sc = None if sc is None else np.ascontiguousarray(sc, np.int32)
         self._chk(self.lib.dril_env_set_state(self._h, self._p(st), self._p(sc)))
+
+    def monitor_stats(self):
+        """(ep_rew_mean, ep_len_mean, n_episodes) of MonitorWrapperEnv's window (log_stats, monitorWrapperEnv.jl:64-70)."""
+        r, l, n = C.c_float(), C.c_float(), C.c_int32()
+        self._chk(self.lib.dril_monitor_get_stats(self._h, C.byref(r), C.byref(l), C.byref(n)))
+        return r.value, l.value, n.value
 
     def norm_get_stats(self) -> dict:
         """RunningMeanStd fields of the wrapper (normalizeWrapperEnv.jl:8-19)."""
@@ -496,7 +503,7 @@ class DeviceParallelEnv:
                  rank: int = 0, world_size: int = 1, profile_events: bool = False):
         self.env, self.n_envs, self.seed = env, n_envs, seed
         self._kw = dict(fixed_length_episodes=fixed_length_episodes, device=device, rank=rank, world_size=world_size,
-                        profile_events=profile_events, normalize=None)
+                        profile_events=profile_events, normalize=None, monitor_window=0)
         self.handle: Optional[Handle] = None
         self._bound_key = None
         self._last_term = np.zeros(n_envs, bool)
@@ -505,7 +512,7 @@ class DeviceParallelEnv:
     # binding: one handle carries env + agent + alg state; (re)created when the alg/layer shape changes
     def bind(self, alg: PPO, layer: Optional[ActorCriticLayer] = None) -> Handle:
         key = (tuple(sorted(asdict(alg).items())), None if layer is None else (tuple(layer.hidden_dims), layer.log_std_init),
-               None if self._kw["normalize"] is None else tuple(sorted(self._kw["normalize"].items())))
+               None if self._kw["normalize"] is None else tuple(sorted(self._kw["normalize"].items())), self._kw["monitor_window"])
         if self.handle is None or key != self._bound_key:
             if self.handle is not None:
                 self.handle.close()
@@ -548,6 +555,15 @@ class DeviceParallelEnv:
 
     def truncated(self):
         return self._last_trunc
+
+
+def MonitorWrapperEnv(env: DeviceParallelEnv, stats_window: int = 100) -> DeviceParallelEnv:
+    """MonitorWrapperEnv(env, stats_window) (monitorWrapperEnv.jl:15-24): episode return/length statistics from the device
+    done flags; `env.handle.monitor_stats()` gives what `log_stats` logs (env/ep_rew_mean, env/ep_len_mean)."""
+    env._kw["monitor_window"] = int(stats_window)
+    if env.handle is not None:
+        env.handle.close(); env.handle = None
+    return env
 
 
 def NormalizeWrapperEnv(env: DeviceParallelEnv, *, training: bool = True, norm_obs: bool = True, norm_reward: bool = True,

@@ -39,8 +39,8 @@ struct DrilConfig
     norm_obs::Int32; norm_reward::Int32; norm_training::Int32
     clip_obs::Float32; clip_reward::Float32; norm_gamma::Float32; norm_epsilon::Float32
     seed::UInt64
-    device::Int32; rank::Int32; world_size::Int32; profile_events::Int32
-    reserved::NTuple{7, Int32}
+    device::Int32; rank::Int32; world_size::Int32; profile_events::Int32; monitor_window::Int32
+    reserved::NTuple{6, Int32}
 end
 
 # struct dril_ppo_stats
@@ -103,7 +103,7 @@ function make_config(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int}, log_
         Int32(env.fixed_length_episodes), start, alg.gamma, alg.gae_lambda, alg.clip_range, cvf, hcvf, alg.ent_coef,
         alg.vf_coef, mgn, hmgn, tkl, htkl, Int32(alg.normalize_advantage), alg.batch_size, alg.epochs, alg.learning_rate,
         0.9f0, 0.999f0, 1.0f-5, log_std_init,                    # Optimisers.Adam(eta, (0.9, 0.999), 1e-5): ppo.jl:64-66
-        0, 0, 0, 10.0f0, 10.0f0, 0.99f0, 1.0f-8, env.seed, env.device, 0, 1, 0, ntuple(_ -> Int32(0), 7))
+        0, 0, 0, 10.0f0, 10.0f0, 0.99f0, 1.0f-8, env.seed, env.device, 0, 1, 0, 0, ntuple(_ -> Int32(0), 6))
 end
 
 "(re)create the handle when the algorithm / layer shape changes; Random.seed!(env, seed) + reset!(env) follow"

@@ -113,7 +113,8 @@ typedef struct dril_config {
     int32_t device;            /* HIP device ordinal */
     int32_t rank, world_size;  /* data-parallel position; global env index = rank*n_envs + local */
     int32_t profile_events;    /* 1: bracket hot kernels with HIP events (dril_profile_get) */
-    int32_t reserved[7];
+    int32_t monitor_window;    /* MonitorWrapperEnv(env, stats_window): > 0 tracks episode returns/lengths (monitorWrapperEnv.jl:15-24); 0 = no wrapper */
+    int32_t reserved[6];
 } dril_config;
 
 /* per-iteration means returned by dril_ppo_update; field names follow the
@@ -175,6 +176,10 @@ int32_t dril_norm_get_stats(dril_handle* h, float* obs_mean, float* obs_var, int
                             float* ret_mean, float* ret_var, int64_t* ret_count);
 int32_t dril_norm_set_stats(dril_handle* h, const float* obs_mean, const float* obs_var, int64_t obs_count,
                             float ret_mean, float ret_var, int64_t ret_count);
+
+/* MonitorWrapperEnv: mean return / length over the last `monitor_window` finished episodes (log_stats, monitorWrapperEnv.jl:64-70)
+ * and the number of episodes currently in the window; rewards are the RAW env rewards (the monitor sits inside the normaliser) */
+int32_t dril_monitor_get_stats(dril_handle* h, float* ep_rew_mean, float* ep_len_mean, int32_t* n_episodes);
 
 /* ---- policy (src/layers/layer_forward.jl, layer_methods.jl) on host batches -- */
 /* layer(obs, ps, st) -> (actions, values, logprobs): layer_forward.jl:3-13 / :30-39.

@@ -91,6 +91,7 @@ def lib() -> C.CDLL:
         L.orc_apply_gradients.argtypes = [_P, _P, C.c_size_t, C.POINTER(C.c_float)]
         L.orc_train.argtypes = [_P, C.c_int64, _P, _P, C.POINTER(C.c_int32)]
         L.orc_norm_get_stats.argtypes = [_P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        L.orc_monitor_get_stats.argtypes = [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.orc_destroy.argtypes = [_P]
         L.orc_reset_optimizer.argtypes = [_P]
         L.orc_set_num_threads.argtypes = [C.c_int]
@@ -260,6 +261,11 @@ class Oracle:
         stats = (DrilPPOStats * max(iters, 1))(); fps = (C.c_double * max(iters, 1))(); done = C.c_int32()
         self.L.orc_train(self._h, max_steps, stats, fps, C.byref(done))
         return [stats[i] for i in range(done.value)], [fps[i] for i in range(done.value)]
+
+    def monitor_stats(self):
+        r, l, n = C.c_float(), C.c_float(), C.c_int32()
+        self.L.orc_monitor_get_stats(self._h, C.byref(r), C.byref(l), C.byref(n))
+        return r.value, l.value, n.value
 
     def norm_stats(self):
         om = np.empty(self.D, np.float32); ov = np.empty(self.D, np.float32)

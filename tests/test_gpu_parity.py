@@ -582,3 +582,44 @@ def test_ppo_learns_cartpole(pkg):
     after = mean_episode_length()
     assert np.isfinite(stats["losses"]).all() and len(stats["losses"]) == 40
     assert after > 2.0 * before and after > 40, (before, after)
+
+
+@pytest.mark.parametrize("kind,norm,L,W", [(0, 0, 500, 100), (0, 0, 7, 100), (1, 1, 9, 25), (0, 1, 500, 10)])
+def test_monitor_wrapper_episode_stats(pkg, oracle_mod, kind, norm, L, W):
+    """MonitorWrapperEnv (monitorWrapperEnv.jl:46-70): mean return / length over the last `stats_window` finished episodes in
+    (step, env) completion order, from RAW rewards, across rollouts and across the fused / step-granular / host-stepped paths."""
+    E, T = 70, 40
+    cfg = _cfg(pkg, kind, n_envs=E, n_steps=T, episode_len=L, batch_size=E * T, epochs=1, monitor_window=W,
+               norm_training=norm, norm_obs=norm, norm_reward=norm)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 5, 0.5)
+    if kind == 0:
+        flat[4608:4610] = (1.5, -1.5)                     # biased policy: CartPole episodes terminate quickly
+    h.set_params(flat); o.set_params(flat)
+    h.env_reset(8); o.env_reset(8)
+    assert h.monitor_stats() == (0.0, 0.0, 0)
+    rng = np.random.default_rng(3)
+    for rollout in range(3):
+        noise = rng.random(E * T) if kind == 0 else rng.standard_normal((E * T, h.A)).astype(np.float32)
+        h.set_noise(noise); o.set_noise(noise)
+        h.collect_rollout(); o.collect_rollout()
+        rh, lh, nh = h.monitor_stats(); ro, lo, no = o.monitor_stats()
+        assert nh == no and nh > 0
+        assert lh == pytest.approx(lo, rel=1e-6) and rh == pytest.approx(ro, rel=1e-5, abs=1e-5)
+        st, sc = h.env_get_state(); o.env_set_state(st, sc)
+    # host-stepped path keeps feeding the same window
+    for step in range(12):
+        a = (rng.integers(0, 2, E) + cfg.action_start).astype(np.int32) if kind == 0 else rng.uniform(-2, 2, (E, 1)).astype(np.float32)
+        h.env_step(a); o.env_step(a)
+        st, sc = h.env_get_state(); o.env_set_state(st, sc)
+    rh, lh, nh = h.monitor_stats(); ro, lo, no = o.monitor_stats()
+    assert nh == no == min(W, nh) and lh == pytest.approx(lo, rel=1e-6) and rh == pytest.approx(ro, rel=1e-5, abs=1e-5)
+    if kind == 0:
+        assert rh == pytest.approx(lh, rel=1e-6)          # CartPole: reward 1 per step => return == length
+
+
+def test_monitor_off_is_an_error(pkg):
+    h = pkg.Handle(_cfg(pkg, 0, n_envs=4, n_steps=2, batch_size=4))
+    with pytest.raises(pkg.DrilError) as e:
+        h.monitor_stats()
+    assert e.value.code == pkg._capi.ERR_NOT_INITIALISED

@@ -206,3 +206,25 @@ def test_update_loop_control_flow(oracle_mod, pkg):
     o2.set_params(p0); o2.env_reset(1); o2.collect_rollout()
     st2 = o2.ppo_update()
     assert st2.early_stopped and st2.n_updates <= 1                            # first batch has ratio == 1 -> kl == 0 -> one apply, then stop
+
+
+def test_monitor_wrapper_oracle_vs_python(oracle_mod, pkg):
+    """MonitorWrapperEnv restatement (monitorWrapperEnv.jl:46-70) against a direct Python transcription"""
+    from collections import deque
+    capi = pkg._capi
+    cfg = capi.default_config(1); cfg.n_envs, cfg.n_steps, cfg.episode_len, cfg.monitor_window = 6, 4, 5, 7
+    o = oracle_mod.Oracle(cfg); o.env_reset(1)
+    rets, lens = deque(maxlen=7), deque(maxlen=7)
+    cur_r, cur_l = np.zeros(6), np.zeros(6, int)
+    rng = np.random.default_rng(0)
+    for step in range(23):
+        a = rng.uniform(-2, 2, (6, 1)).astype(np.float32)
+        rew, term, trunc, _ = o.env_step(a)
+        cur_r += rew; cur_l += 1
+        for i in np.nonzero(term | trunc)[0]:
+            rets.append(cur_r[i]); lens.append(cur_l[i]); cur_r[i] = 0; cur_l[i] = 0
+        r, l, n = o.monitor_stats()
+        assert n == len(rets)
+        if n:
+            assert r == pytest.approx(np.mean(rets), rel=1e-5) and l == pytest.approx(np.mean(lens), rel=1e-6)
+    assert n == 7
