@@ -66,6 +66,8 @@ mutable struct DeviceParallelEnv <: AbstractParallelEnv
     seed::UInt64
     fixed_length_episodes::Bool
     device::Int
+    monitor_window::Int            # MonitorWrapperEnv(env, stats_window): 0 = off
+    normalize::Union{Nothing, NamedTuple}   # NormalizeWrapperEnv kwargs (normalizeWrapperEnv.jl:71-80) or nothing
     handle::Ptr{Cvoid}
     bound::Any                     # (alg, hidden_dims, log_std_init) the handle was created for
     last_terminated::Vector{Bool}
@@ -73,10 +75,11 @@ mutable struct DeviceParallelEnv <: AbstractParallelEnv
 end
 
 function DeviceParallelEnv(kind::Symbol, n_envs::Integer; max_steps::Integer = kind === :CartPole ? 500 : 200,
-        seed::Integer = 42, fixed_length_episodes::Bool = false, device::Integer = 0)
+        seed::Integer = 42, fixed_length_episodes::Bool = false, device::Integer = 0, monitor_window::Integer = 0,
+        normalize::Union{Nothing, NamedTuple} = nothing)
     haskey(ENV_KINDS, kind) || error("unknown device env $kind")
-    env = DeviceParallelEnv(kind, n_envs, max_steps, UInt64(seed), fixed_length_episodes, device, C_NULL, nothing,
-        fill(false, n_envs), fill(false, n_envs))
+    env = DeviceParallelEnv(kind, n_envs, max_steps, UInt64(seed), fixed_length_episodes, device, monitor_window, normalize,
+        C_NULL, nothing, fill(false, n_envs), fill(false, n_envs))
     finalizer(e -> (e.handle != C_NULL && ccall((:dril_destroy, LIB[]), Int32, (Ptr{Cvoid},), e.handle); nothing), env)
     return env
 end
@@ -99,11 +102,16 @@ function make_config(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int}, log_
     opt(x) = isnothing(x) ? (0.0f0, Int32(0)) : (Float32(x), Int32(1))
     cvf, hcvf = opt(alg.clip_range_vf); mgn, hmgn = opt(alg.max_grad_norm); tkl, htkl = opt(alg.target_kl)
     start = env.kind === :CartPole ? Int32(action_space(env).start) : Int32(1)
+    nz = env.normalize
+    nget(k, d) = isnothing(nz) ? d : get(nz, k, d)
+    on = isnothing(nz) ? Int32(0) : Int32(1)
     return DrilConfig(ABI_VERSION, ENV_KINDS[env.kind], env.n_envs, alg.n_steps, hidden[1], hidden[2], env.max_steps,
         Int32(env.fixed_length_episodes), start, alg.gamma, alg.gae_lambda, alg.clip_range, cvf, hcvf, alg.ent_coef,
         alg.vf_coef, mgn, hmgn, tkl, htkl, Int32(alg.normalize_advantage), alg.batch_size, alg.epochs, alg.learning_rate,
         0.9f0, 0.999f0, 1.0f-5, log_std_init,                    # Optimisers.Adam(eta, (0.9, 0.999), 1e-5): ppo.jl:64-66
-        0, 0, 0, 10.0f0, 10.0f0, 0.99f0, 1.0f-8, env.seed, env.device, 0, 1, 0, 0, ntuple(_ -> Int32(0), 6))
+        on * Int32(nget(:norm_obs, true)), on * Int32(nget(:norm_reward, true)), on * Int32(nget(:training, true)),
+        Float32(nget(:clip_obs, 10)), Float32(nget(:clip_reward, 10)), Float32(nget(:gamma, 0.99)), Float32(nget(:epsilon, 1.0e-8)),
+        env.seed, env.device, 0, 1, 0, env.monitor_window, ntuple(_ -> Int32(0), 6))
 end
 
 "(re)create the handle when the algorithm / layer shape changes; Random.seed!(env, seed) + reset!(env) follow"
@@ -148,6 +156,16 @@ function act!(env::DeviceParallelEnv, actions::AbstractVector)
         infos[i]["terminal_observation"] = tobs[:, i]
     end
     return rewards, env.last_terminated, env.last_truncated, infos
+end
+# log_stats(env::MonitorWrapperEnv, logger) (monitorWrapperEnv.jl:64-70) from the device ring of finished episodes
+function DRiL.log_stats(env::DeviceParallelEnv, logger::DRiL.AbstractTrainingLogger)
+    (env.monitor_window > 0 && env.handle != C_NULL) || return nothing
+    r = Ref{Float32}(0); l = Ref{Float32}(0); n = Ref{Int32}(0)
+    check(ccall((:dril_monitor_get_stats, LIB[]), Int32, (Ptr{Cvoid}, Ref{Float32}, Ref{Float32}, Ref{Int32}), env.handle, r, l, n), env.handle)
+    if n[] > 0
+        DRiL.log_scalar!(logger, "env/ep_rew_mean", r[]); DRiL.log_scalar!(logger, "env/ep_len_mean", l[])
+    end
+    return nothing
 end
 terminated(env::DeviceParallelEnv) = env.last_terminated
 truncated(env::DeviceParallelEnv) = env.last_truncated
@@ -240,6 +258,7 @@ function train!(agent::Agent, env::DeviceParallelEnv, alg::PPO{T}, max_steps::In
         @timeit to "collect_rollout" check(ccall((:dril_collect_rollout, LIB[]), Int32, (Ptr{Cvoid}, Ref{Float64}), env.handle, fps), env.handle)
         push!(stats.fps, fps[]); DRiL.add_step!(agent, alg.n_steps * env.n_envs)
         DRiL.increment_step!(agent.logger, alg.n_steps * env.n_envs); DRiL.log_scalar!(agent.logger, "env/fps", fps[])
+        DRiL.log_stats(env, agent.logger)                                                                   # ppo.jl:177
         !isnothing(callbacks) && !all(c -> DRiL.on_rollout_end(c, locals()), callbacks) && return nothing
         st = Ref{DrilPPOStats}()
         @timeit to "epoch loop" check(ccall((:dril_ppo_update, LIB[]), Int32, (Ptr{Cvoid}, Ref{DrilPPOStats}), env.handle, st), env.handle)
