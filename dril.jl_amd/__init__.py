@@ -12,5 +12,5 @@ from . import _capi  # noqa: F401
 from .host import (  # noqa: F401
     Agent, ActorCriticLayer, Box, CartPoleEnv, ContinuousActorCriticLayer, DeviceParallelEnv, Discrete,
     DiscreteActorCriticLayer, DrilError, Handle, MonitorWrapperEnv, NormalizeWrapperEnv, PendulumEnv, PPO, RolloutBuffer, collect_rollout_,
-    flatten_params, get_action_and_values, make_config, predict_values, train_, unflatten_params,
+    evaluate_agent, flatten_params, get_action_and_values, make_config, predict_values, train_, unflatten_params,
 )

@@ -52,6 +52,12 @@ class DrilPPOStats(C.Structure):
     ]
 
 
+class DrilEvalStats(C.Structure):
+    """struct dril_eval_stats, include/dril_hip.h"""
+    _fields_ = [("mean_reward", C.c_double), ("std_reward", C.c_double), ("mean_length", C.c_double), ("std_length", C.c_double),
+                ("n_episodes", C.c_int32), ("n_steps", C.c_int32)]
+
+
 def default_config(env_kind: int) -> DrilConfig:
     """Python twin of dril_config_default (PPO() defaults, src/algorithms/ppo.jl:26-39)."""
     c = DrilConfig()
@@ -119,6 +125,7 @@ _SIG = {
     "dril_debug_set_permutation": (C.c_int32, [_P, _P, C.c_size_t]),
     "dril_ppo_loss_grad": (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_float), _P, _P]),
     "dril_apply_gradients": (C.c_int32, [_P, _P, C.c_size_t, C.POINTER(C.c_float)]),
+    "dril_evaluate_agent": (C.c_int32, [_P, C.c_int32, C.c_int32, C.POINTER(DrilEvalStats), _P, _P]),
     "dril_train": (C.c_int32, [_P, C.c_int64, _P, _P, C.POINTER(C.c_int32)]),
     "dril_comm_unique_id": (C.c_int32, [_P]),
     "dril_comm_init": (C.c_int32, [_P, _P]),

@@ -840,6 +840,49 @@ DRIL_EXPORT int32_t dril_apply_gradients(dril_handle* h, const float* grads, siz
     return DRIL_OK;
 }
 
+// ---- evaluate_agent (src/evaluation.jl:54-143) ------------------------------------------------------------
+DRIL_EXPORT int32_t dril_evaluate_agent(dril_handle* h, int32_t n_eval, int32_t deterministic, dril_eval_stats* out, float* ep_rewards, int32_t* ep_lengths) {
+    NEED(h);
+    if (n_eval < 1 || !out) return fail(h, DRIL_ERR_INVALID_ARG, "dril_evaluate_agent: n_eval_episodes >= 1 and out != NULL");
+    const int E = h->cfg.n_envs;
+    int rc = ensure_wimg(h); if (rc) return rc;
+    HIPCHK(h, launch_env_reset(h->cfg.env_kind, E, h->env_seed0, h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->stream));   // reset!(env), :87
+    if (h->mon_cur_ret) { HIPCHK(h, hipMemsetAsync(h->mon_cur_ret, 0, (size_t)E * 4, h->stream)); HIPCHK(h, hipMemsetAsync(h->mon_cur_len, 0, (size_t)E * 4, h->stream)); }
+    h->env_ready = true;
+    const bool raw = h->mon_cur_ret != nullptr;                                  // monitored: infos[i]["episode"]["r"] is the raw return
+    std::vector<float> rew(E), cur_r(E, 0.f), er; std::vector<uint8_t> term(E), trunc(E); std::vector<int32_t> cur_l(E, 0), el;
+    float* rew_n = h->e_obs_raw;                                                 // scratch for wrapper-delivered rewards (see dril_env_step)
+    rc = observe_dev(h, true); if (rc) return rc;                                // observations = observe(env), :88
+    int steps = 0;
+    while ((int)er.size() < n_eval) {
+        PolicyArgs p = policy_args(h, h->e_obs, E, nullptr, h->e_act, nullptr, h->logp /*scratch*/, nullptr, 0);
+        p.gstep = h->gstep; p.env_seed0 = h->env_seed0; p.deterministic = deterministic ? 1 : 0;
+        p.logp = h->e_rew;                                                       // logprobs are not needed: park them in a scratch array
+        HIPCHK(h, launch_policy(h->cfg.env_kind, h->cfg.hidden1, p, 8 * h->num_cus, h->stream));   // predict_actions(agent, observations; deterministic), :92
+        rc = step_dev(h, h->e_act, rew_n, nullptr); if (rc) return rc;           // act!(env, actions), :94
+        HIPCHK(h, hipMemcpyAsync(rew.data(), raw ? h->e_rew : rew_n, (size_t)E * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(term.data(), h->e_term, E, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(trunc.data(), h->e_trunc, E, hipMemcpyDeviceToHost, h->stream));
+        rc = observe_dev(h, true); if (rc) return rc;                            // observations = observe(env), :97
+        rc = sync(h); if (rc) return rc;
+        ++steps;
+        for (int i = 0; i < E; ++i) {
+            cur_r[i] += rew[i]; cur_l[i] += 1;                                   // :95-96
+            if ((term[i] || trunc[i]) && (int)er.size() < n_eval) { er.push_back(cur_r[i]); el.push_back(cur_l[i]); cur_r[i] = 0.f; cur_l[i] = 0; }   // :100-121
+        }
+        if (steps > 100000000 / (E > 0 ? E : 1) + 100000) return fail(h, DRIL_ERR_UNSUPPORTED, "dril_evaluate_agent: no episode finishes");
+    }
+    double mr = 0, ml = 0; for (int i = 0; i < n_eval; ++i) { mr += er[i]; ml += el[i]; }
+    mr /= n_eval; ml /= n_eval;
+    double vr = 0, vl = 0; for (int i = 0; i < n_eval; ++i) { vr += (er[i] - mr) * (er[i] - mr); vl += (el[i] - ml) * (el[i] - ml); }
+    out->mean_reward = mr; out->mean_length = ml;
+    out->std_reward = std::sqrt(vr / (n_eval - 1)); out->std_length = std::sqrt(vl / (n_eval - 1));     // Julia std: corrected; NaN for one episode
+    out->n_episodes = n_eval; out->n_steps = steps;
+    if (ep_rewards) std::memcpy(ep_rewards, er.data(), (size_t)n_eval * 4);
+    if (ep_lengths) std::memcpy(ep_lengths, el.data(), (size_t)n_eval * 4);
+    return DRIL_OK;
+}
+
 // ---- train! ------------------------------------------------------------------------------------------
 DRIL_EXPORT int32_t dril_train(dril_handle* h, int64_t max_steps, dril_ppo_stats* stats, double* fps, int32_t* iterations_done) {
     NEED(h);

@@ -15,6 +15,7 @@ struct PolicyArgs {
     float* obs_out;                              // optional copy of the consumed observations (rollout buffer slice)
     const uint8_t* only_where;                   // optional: waves with no flagged sample skip (bootstrap critic on truncated envs)
     const float* w2a_actor; const float* w2a_critic;   // wide nets: pre-tiled W2 images in global memory
+    int deterministic;                           // predict_actions(...; deterministic = true): mode(d) instead of rand(d)
     const float* boot_obs; const uint8_t* boot_where; float* boot_out;   // fused V(terminal_observation) of the PREVIOUS env step (trajectory.jl:57-61)
     NetOff actor, critic;
 };

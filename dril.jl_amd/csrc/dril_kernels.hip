@@ -457,6 +457,11 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void policy_kernel(PolicyArgs a)
                 else if (a.gstep) { const uint64_t k = a.env_seed0 + (uint64_t)bb; uint32_t r[4]; philox4x32_10((uint32_t)k, (uint32_t)(k >> 32), a.gstep[bb], 0, 1, 0, r); u = u01_f64(r[0], r[1]); }
                 else { uint32_t r[4]; philox4x32_10((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)bb, (uint32_t)(bb >> 32), 3, a.call_counter, r); u = u01_f64(r[0], r[1]); }
                 act = categorical_sample<A>(p, u);
+                if (a.deterministic) {                                   // mode(d) = argmax(p) (first maximum), categorical.jl:42-44
+                    act = 0; float best = p[0];
+#pragma unroll
+                    for (int i = 1; i < A; ++i) if (p[i] > best) { best = p[i]; act = i; }
+                }
                 if (valid && h == 0) ((int32_t*)a.actions)[b] = act + a.action_start;
             } else act = ((const int32_t*)a.actions)[bb] - a.action_start;
             if (valid && h == 0) {
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void policy_kernel(PolicyArgs a)
                     if (a.noise) z = ((const float*)a.noise)[bb * A + i];
                     else if (a.gstep) { const uint64_t k = a.env_seed0 + (uint64_t)bb; uint32_t r[4]; philox4x32_10((uint32_t)k, (uint32_t)(k >> 32), a.gstep[bb], 0, 1, (uint32_t)(i / 2), r); z = (i & 1) ? randn_f32(r[2], r[3]) : randn_f32(r[0], r[1]); }
                     else { uint32_t r[4]; philox4x32_10((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)bb, (uint32_t)(bb >> 32), 3 + 16 * (uint32_t)i, a.call_counter, r); z = randn_f32(r[0], r[1]); }
-                    x[i] = out[i] + fexp(ls[i]) * z;
+                    x[i] = a.deterministic ? out[i] : out[i] + fexp(ls[i]) * z;            // mode(d) = mean, diagGaussian.jl:45-47
                     if (valid && h == 0) ((float*)a.actions)[b * A + i] = x[i];
                 }
             } else {

@@ -452,6 +452,14 @@ class Handle:
         self._chk(self.lib.dril_apply_gradients(self._h, self._p(grads), grads.size, C.byref(norm)))
         return norm.value
 
+    def evaluate_agent(self, n_eval_episodes: int = 10, deterministic: bool = True):
+        """evaluate_agent(agent, env; n_eval_episodes, deterministic) -> (stats dict, episode_rewards, episode_lengths), evaluation.jl:54-143"""
+        st = capi.DrilEvalStats()
+        er = np.empty(n_eval_episodes, np.float32); el = np.empty(n_eval_episodes, np.int32)
+        self._chk(self.lib.dril_evaluate_agent(self._h, n_eval_episodes, int(deterministic), C.byref(st), self._p(er), self._p(el)))
+        return dict(mean_reward=st.mean_reward, std_reward=st.std_reward, mean_length=st.mean_length, std_length=st.std_length,
+                    n_steps=st.n_steps), er, el
+
     def train(self, max_steps: int):
         per_iter = self.N * self.cfg.world_size
         iters = max_steps // per_iter
@@ -682,6 +690,17 @@ def train_(agent: Agent, env: DeviceParallelEnv, alg: PPO, max_steps: int, callb
     timer["epoch loop"] = t_upd
     agent.train_state.parameters = unflatten_params(h.get_params(), agent.train_state.parameters)
     return learn_stats, timer
+
+
+def evaluate_agent(agent: Agent, env: DeviceParallelEnv, n_eval_episodes: int = 10, deterministic: bool = True,
+                   reward_threshold: Optional[float] = None, return_stats: bool = True):
+    """evaluate_agent(agent, env; ...) (src/evaluation.jl:54-143)."""
+    h = env.bind(agent.alg, agent.layer)
+    h.set_params(flatten_params(agent.train_state.parameters))
+    stats, er, el = h.evaluate_agent(n_eval_episodes, deterministic)
+    if reward_threshold is not None and stats["mean_reward"] < reward_threshold:
+        raise RuntimeError(f"Mean reward below threshold: {stats['mean_reward']:.2f} < {reward_threshold}")   # evaluation.jl:131-135
+    return {k: stats[k] for k in ("mean_reward", "std_reward", "mean_length", "std_length")} if return_stats else (er, el)
 
 
 def get_action_and_values(agent: Agent, env: DeviceParallelEnv, observations):

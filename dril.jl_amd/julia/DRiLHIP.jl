@@ -277,6 +277,25 @@ function train!(agent::Agent, env::DeviceParallelEnv, alg::PPO{T}, max_steps::In
     return stats, to
 end
 
+# ---- evaluate_agent(agent, env::DeviceParallelEnv; ...)  (src/evaluation.jl:54-143) ----
+struct DrilEvalStats
+    mean_reward::Float64; std_reward::Float64; mean_length::Float64; std_length::Float64
+    n_episodes::Int32; n_steps::Int32
+end
+function DRiL.evaluate_agent(agent, env::DeviceParallelEnv; n_eval_episodes::Int = 10, deterministic::Bool = true,
+        reward_threshold::Union{Nothing, Real} = nothing, return_stats::Bool = true, warn::Bool = true, kwargs...)
+    bind_agent!(env, agent, agent.algorithm); push_params!(env, agent)
+    st = Ref{DrilEvalStats}(); er = Vector{Float32}(undef, n_eval_episodes); el = Vector{Int32}(undef, n_eval_episodes)
+    GC.@preserve er el check(ccall((:dril_evaluate_agent, LIB[]), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{DrilEvalStats}, Ptr{Float32}, Ptr{Int32}),
+        env.handle, n_eval_episodes, deterministic, st, er, el), env.handle)
+    s = st[]
+    if reward_threshold !== nothing && s.mean_reward < reward_threshold
+        error("Mean reward below threshold: $(round(s.mean_reward, digits = 2)) < $(reward_threshold)")            # evaluation.jl:131-135
+    end
+    return return_stats ? (; mean_reward = s.mean_reward, std_reward = s.std_reward, mean_length = s.mean_length, std_length = s.std_length) :
+        (er, Int.(el))
+end
+
 export DeviceParallelEnv
 
 end # module

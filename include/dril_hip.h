@@ -230,6 +230,19 @@ int32_t dril_ppo_loss_grad(dril_handle* h, const float* obs, const void* actions
  * returns the pre-clip norm */
 int32_t dril_apply_gradients(dril_handle* h, const float* grads, size_t n, float* grad_norm);
 
+/* ---- evaluate_agent (src/evaluation.jl:54-143) --------------------------------------------- */
+typedef struct dril_eval_stats {
+    double mean_reward, std_reward, mean_length, std_length;   /* Julia mean / std (corrected) over the collected episodes */
+    int32_t n_episodes, n_steps;                               /* episodes collected, env steps taken */
+} dril_eval_stats;
+/* reset!(env); then predict_actions(agent, obs; deterministic) -> act! -> observe until the first n_eval_episodes episodes have
+ * finished, taken in (step, env) order (evaluation.jl:90-124).  deterministic: mode(d) — argmax for Categorical (categorical.jl:42-44),
+ * the mean for DiagGaussian (diagGaussian.jl:45-47).  With MonitorWrapperEnv on (cfg.monitor_window > 0) episode returns use the RAW
+ * rewards, like infos[i]["episode"]["r"]; otherwise the rewards as the wrappers deliver them.  episode_rewards / episode_lengths
+ * (n_eval_episodes entries each) may be NULL. */
+int32_t dril_evaluate_agent(dril_handle* h, int32_t n_eval_episodes, int32_t deterministic, dril_eval_stats* out,
+                            float* episode_rewards, int32_t* episode_lengths);
+
 /* ---- train! ------------------------------------------------------------------ */
 /* iterations = max_steps / (T*E*world) of {set lr, collect_rollout!, ppo update}: ppo.jl:154-298.
  * stats / fps arrays need `iterations` entries (may be NULL) */

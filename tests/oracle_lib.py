@@ -92,6 +92,7 @@ def lib() -> C.CDLL:
         L.orc_train.argtypes = [_P, C.c_int64, _P, _P, C.POINTER(C.c_int32)]
         L.orc_norm_get_stats.argtypes = [_P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         L.orc_monitor_get_stats.argtypes = [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.orc_evaluate_agent.argtypes = [_P, C.c_int32, C.c_int32, C.POINTER(capi.DrilEvalStats), _P, _P]
         L.orc_destroy.argtypes = [_P]
         L.orc_reset_optimizer.argtypes = [_P]
         L.orc_set_num_threads.argtypes = [C.c_int]
@@ -261,6 +262,12 @@ class Oracle:
         stats = (DrilPPOStats * max(iters, 1))(); fps = (C.c_double * max(iters, 1))(); done = C.c_int32()
         self.L.orc_train(self._h, max_steps, stats, fps, C.byref(done))
         return [stats[i] for i in range(done.value)], [fps[i] for i in range(done.value)]
+
+    def evaluate_agent(self, n_eval_episodes=10, deterministic=True):
+        st = capi.DrilEvalStats()
+        er = np.empty(n_eval_episodes, np.float32); el = np.empty(n_eval_episodes, np.int32)
+        assert self.L.orc_evaluate_agent(self._h, n_eval_episodes, int(deterministic), C.byref(st), _p(er), _p(el)) == 0
+        return dict(mean_reward=st.mean_reward, std_reward=st.std_reward, mean_length=st.mean_length, std_length=st.std_length, n_steps=st.n_steps), er, el
 
     def monitor_stats(self):
         r, l, n = C.c_float(), C.c_float(), C.c_int32()

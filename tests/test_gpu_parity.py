@@ -623,3 +623,42 @@ def test_monitor_off_is_an_error(pkg):
     with pytest.raises(pkg.DrilError) as e:
         h.monitor_stats()
     assert e.value.code == pkg._capi.ERR_NOT_INITIALISED
+
+
+@pytest.mark.parametrize("kind,det,kw", [(0, True, {}), (0, False, {}), (1, True, dict(norm_training=1, norm_obs=1, norm_reward=1, monitor_window=50)),
+                                         (1, False, dict(norm_training=1, norm_obs=1, norm_reward=1))])
+def test_evaluate_agent(pkg, oracle_mod, kind, det, kw):
+    """evaluate_agent (src/evaluation.jl:54-143): reset, predict(deterministic) / act! / observe until the first n episodes finish,
+    mean / corrected std of returns and lengths; monitored envs report RAW returns"""
+    cfg = _cfg(pkg, kind, n_envs=24, n_steps=4, episode_len=15 if kind else 60, batch_size=24, **kw)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 21, 0.5)
+    if kind == 0:
+        flat[4608:4610] = (0.8, -0.8)
+    h.set_params(flat); o.set_params(flat)
+    h.env_reset(13); o.env_reset(13)
+    n = 40
+    sh, rh, lh = h.evaluate_agent(n, det); so, ro, lo = o.evaluate_agent(n, det)
+    assert np.array_equal(lh, lo)
+    np.testing.assert_allclose(rh, ro, rtol=2e-4, atol=2e-4)
+    for k in ("mean_reward", "std_reward", "mean_length", "std_length"):
+        assert sh[k] == pytest.approx(so[k], rel=2e-4, abs=2e-4), k
+    assert sh["n_steps"] == so["n_steps"] and sh["mean_length"] == pytest.approx(float(np.mean(lh)))
+    assert sh["std_reward"] == pytest.approx(float(np.std(rh.astype(np.float64), ddof=1)), rel=1e-5, abs=1e-6)
+    if kind == 0:
+        assert np.allclose(rh, lh)                       # CartPole: one reward per step
+    if det:                                              # deterministic evaluation is repeatable (reset! + mode)
+        sh2, rh2, lh2 = h.evaluate_agent(n, det)
+        assert np.array_equal(lh, lh2) and (kw or np.array_equal(rh, rh2))
+
+
+def test_host_mirror_evaluate_and_wrappers(pkg):
+    env = pkg.MonitorWrapperEnv(pkg.DeviceParallelEnv(pkg.CartPoleEnv(max_steps=100), 32, seed=3), 20)
+    alg = pkg.PPO(n_steps=16, batch_size=128, epochs=1)
+    agent = pkg.Agent(pkg.ActorCriticLayer(env.observation_space(), env.action_space()), alg, seed=0)
+    stats = pkg.evaluate_agent(agent, env, n_eval_episodes=12)
+    assert set(stats) == {"mean_reward", "std_reward", "mean_length", "std_length"} and stats["mean_reward"] == stats["mean_length"] > 0
+    with pytest.raises(RuntimeError):
+        pkg.evaluate_agent(agent, env, n_eval_episodes=5, reward_threshold=1e9)
+    r, l, n = env.handle.monitor_stats()
+    assert n == 20 and r == l
