@@ -6,6 +6,7 @@ __graft_entry__.py / tests/conftest.py) under the module name `dril_jl_amd`.
     csrc/     hand-written HIP kernels + the C ABI (libdril_hip.so, include/dril_hip.h)
     _capi.py  ctypes binding of the C ABI (no fallback: raises if the .so is missing)
     host.py   mirror of the reference's Agent / ActorCriticLayer / PPO / train! / AbstractParallelEnv interface
+    sac.py    mirror of the reference's SAC / SACLayer / ReplayBuffer / train!(…, ::SAC, …) interface (include/dril_sac.h)
     julia/    the `ccall` shim a DRiL.jl user loads (cannot be executed in the build image: no Julia)
 """
 from . import _capi  # noqa: F401
@@ -13,4 +14,8 @@ from .host import (  # noqa: F401
     Agent, ActorCriticLayer, Box, CartPoleEnv, ContinuousActorCriticLayer, DeviceParallelEnv, Discrete,
     DiscreteActorCriticLayer, DrilError, Handle, MonitorWrapperEnv, NormalizeWrapperEnv, PendulumEnv, PPO, RolloutBuffer, collect_rollout_,
     evaluate_agent, flatten_params, get_action_and_values, make_config, predict_values, train_, unflatten_params,
+)
+from .sac import (  # noqa: F401
+    SAC, AutoEntropyCoefficient, FixedEntropyCoefficient, ReplayBuffer, SACAgent, SACLayer, SacHandle, get_gradient_steps, make_sac_config,
+    sac_flatten_params, sac_train_, sac_unflatten_params,
 )

@@ -58,6 +58,30 @@ class DrilEvalStats(C.Structure):
                 ("n_episodes", C.c_int32), ("n_steps", C.c_int32)]
 
 
+class DrilSacConfig(C.Structure):
+    """struct dril_sac_config, include/dril_sac.h"""
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("env_kind", C.c_int32), ("n_envs", C.c_int32), ("episode_len", C.c_int32),
+        ("hidden1", C.c_int32), ("hidden2", C.c_int32), ("activation", C.c_int32),
+        ("buffer_capacity", C.c_int64), ("start_steps", C.c_int32), ("batch_size", C.c_int32),
+        ("tau", C.c_float), ("gamma", C.c_float),
+        ("train_freq", C.c_int32), ("gradient_steps", C.c_int32), ("target_update_interval", C.c_int32),
+        ("auto_ent_coef", C.c_int32), ("ent_coef_init", C.c_float), ("auto_target_entropy", C.c_int32), ("target_entropy", C.c_float),
+        ("learning_rate", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
+        ("seed", C.c_uint64), ("device", C.c_int32), ("profile_events", C.c_int32), ("reserved", C.c_int32 * 8),
+    ]
+
+
+class DrilSacStats(C.Structure):
+    """struct dril_sac_stats, include/dril_sac.h"""
+    _fields_ = [("actor_loss", C.c_float), ("critic_loss", C.c_float), ("entropy_loss", C.c_float), ("mean_q_values", C.c_float),
+                ("entropy_coefficient", C.c_float), ("grad_norm", C.c_float), ("has_entropy_loss", C.c_int32), ("reserved", C.c_int32)]
+
+
+SAC_ABI_VERSION = 1
+(RB_OBSERVATIONS, RB_ACTIONS, RB_REWARDS, RB_TERMINATED, RB_TRUNCATED, RB_NEXT_OBSERVATIONS) = range(6)
+
+
 def default_config(env_kind: int) -> DrilConfig:
     """Python twin of dril_config_default (PPO() defaults, src/algorithms/ppo.jl:26-39)."""
     c = DrilConfig()
@@ -134,6 +158,44 @@ _SIG = {
     "dril_kernel_name": (C.c_char_p, [C.c_int32]),
     "dril_version": (C.c_char_p, []),
 }
+# every symbol include/dril_sac.h declares, keyed by the name WITHOUT its "dril_sac_" prefix (the CPU oracle exports the same
+# signatures under "orc_sac_", which is how the parity tests drive both through one wrapper)
+_PD, _PF, _PI64 = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int64)
+_SAC_SIG = {
+    "config_default": (C.c_int32, [C.POINTER(DrilSacConfig), C.c_int32]),
+    "create": (C.c_int32, [C.POINTER(DrilSacConfig), C.POINTER(_P)]),
+    "destroy": (C.c_int32, [_P]),
+    "last_error": (C.c_char_p, [_P]),
+    "obs_dim": (C.c_int32, [_P]),
+    "action_dim": (C.c_int32, [_P]),
+    "param_count": (C.c_int64, [_P]),
+    "q_param_count": (C.c_int64, [_P]),
+    "set_params": (C.c_int32, [_P, _P, C.c_size_t]),
+    "get_params": (C.c_int32, [_P, _P, C.c_size_t]),
+    "get_target_params": (C.c_int32, [_P, _P, C.c_size_t]),
+    "set_target_params": (C.c_int32, [_P, _P, C.c_size_t]),
+    "get_log_ent_coef": (C.c_int32, [_P, _PF]),
+    "set_log_ent_coef": (C.c_int32, [_P, C.c_float]),
+    "reset_optimizer": (C.c_int32, [_P]),
+    "env_reset": (C.c_int32, [_P, C.c_uint64]),
+    "env_observe": (C.c_int32, [_P, _P]),
+    "action_log_prob": (C.c_int32, [_P, _P, C.c_int64, _P, _P, _P]),
+    "predict_actions": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
+    "predict_q": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
+    "collect_rollout": (C.c_int32, [_P, C.c_int32, C.c_int32, _PD]),
+    "debug_set_collect_noise": (C.c_int32, [_P, _P, C.c_size_t]),
+    "replay_size": (C.c_int64, [_P]),
+    "replay_capacity": (C.c_int64, [_P]),
+    "replay_copy_out": (C.c_int32, [_P, C.c_int32, _P, C.c_size_t]),
+    "replay_fill": (C.c_int32, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    "update": (C.c_int32, [_P, C.c_int32, _P]),
+    "debug_set_batches": (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P]),
+    "get_last_grads": (C.c_int32, [_P, _P, _P, C.c_size_t]),
+    "train": (C.c_int32, [_P, C.c_int64, _P, C.c_int64, _PI64, _PD, C.c_int64, C.POINTER(C.c_int32), _PI64]),
+    "profile_get": (C.c_int32, [_P, _PD, _PI64, _PD, _PI64]),
+    "profile_reset": (C.c_int32, [_P]),
+}
+_SIG.update({"dril_sac_" + k: v for k, v in _SAC_SIG.items()})
 EXPORTED_SYMBOLS = tuple(_SIG)
 
 _lib = None

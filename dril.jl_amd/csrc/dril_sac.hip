@@ -1,0 +1,994 @@
+// dril_sac.hip — the off-policy (SAC) path of libdril_hip.so: kernels + the C ABI of include/dril_sac.h.
+//
+// Reference: src/algorithms/sac.jl (losses :93-150, update! :299-404, train! :406-549), src/buffers/replay_buffer.jl,
+// src/buffers/off_policy_collection.jl, src/DRiLDistributions/squashedDiagGaussian.jl.  BASELINE.json configs[4]:
+// Pendulum-v1, 4096 device envs, SACLayer [512,512] relu, batch 256.
+//
+// Shape of the work: one gradient step is ~25 small dense contractions (256 samples x 512 x 512) separated by
+// per-sample head math, all on one stream with no host round trip; one env step of the collection is the actor forward over
+// 4096 envs + the env kernels of the on-policy path + a ring write.  The contractions are fp32 MFMA (v_mfma_f32_32x32x2_f32:
+// exact fp32 products, fp32 accumulate) in ONE generic strided kernel: a workgroup owns one 32x32 output tile and its four
+// waves split the contraction axis (in-workgroup split-K, summed through LDS in fixed wave order => deterministic), because
+// with only 128..272 output tiles per contraction the chip is filled by K-parallelism, not by tiles.  Bias rides in the forward
+// epilogue; [dW | db] come out of one contraction by appending a ones column to the activation operand (the flat parameter
+// layout stores b right behind the column-major W, i.e. [W | b] is one (out x (in+1)) column-major matrix).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/dril_sac.h"
+#include "dril_internal.h"
+
+using namespace dril;
+
+#define DRIL_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_sac_create_error;
+
+// =================================================================================================================
+// generic strided contraction  C[z](M x N) = epi(alpha * A[z](M x K) . B[z](K x N) + bias[z](M))
+// =================================================================================================================
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias; const float* aux;
+    int M, N, K;
+    int sAm, sAk, sBk, sBn, sCm, sCn;             // element strides
+    long long zA, zB, zC, zBias, zAux;            // batch (blockIdx.z) strides
+    int vecA, vecB;                               // operand has unit stride along k, 16-byte aligned rows and K % 4 == 0: float4 loads
+    int ones_n;                                   // B(:, N-1) == 1 (appends the bias column to a weight-gradient contraction)
+    int epi; float alpha;
+};
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_TANH = 2, EPI_MASK_RELU = 3, EPI_MASK_TANH = 4 };
+
+__device__ __forceinline__ void load_operand4(const float* __restrict__ P, int idx, int lim, int s_idx, int s_k, int k0, int K, int vec, float (&v)[4]) {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (idx >= lim || k0 >= K) return;
+    if (vec) {
+        const float4 t = *reinterpret_cast<const float4*>(P + (size_t)idx * s_idx + k0);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (k0 + t < K) v[t] = P[(size_t)idx * s_idx + (size_t)(k0 + t) * s_k];
+    }
+}
+
+// MFMA operand slots: A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]; step t of chunk q contracts k = 8q + 4h + t
+// for the half-wave h, so a k-major operand is one float4 per lane per chunk.  D: col = lane & 31, row = rowfn(r, lane >> 5).
+__global__ __launch_bounds__(256) void sac_gemm_kernel(GemmArgs g) {
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5, z = blockIdx.z;
+    const float* __restrict__ A = g.A + (size_t)z * g.zA;
+    const float* __restrict__ B = g.B + (size_t)z * g.zB;
+    const int m = blockIdx.x * 32 + c, n = blockIdx.y * 32 + c;
+    const int Q = (g.K + 7) >> 3, Qw = (Q + 3) >> 2, q0 = wave * Qw, q1 = min(Q, q0 + Qw);
+    const bool ones = g.ones_n && n == g.N - 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float a[4], b[4], an[4], bn[4];
+    auto loadB = [&](int k0, float (&v)[4]) {
+        if (ones) { for (int t = 0; t < 4; ++t) v[t] = k0 + t < g.K ? 1.f : 0.f; }
+        else load_operand4(B, n, g.N, g.sBn, g.sBk, k0, g.K, g.vecB, v);
+    };
+    if (q0 < q1) { load_operand4(A, m, g.M, g.sAm, g.sAk, 8 * q0 + 4 * h, g.K, g.vecA, a); loadB(8 * q0 + 4 * h, b); }
+    for (int q = q0; q < q1; ++q) {
+        if (q + 1 < q1) { load_operand4(A, m, g.M, g.sAm, g.sAk, 8 * (q + 1) + 4 * h, g.K, g.vecA, an); loadB(8 * (q + 1) + 4 * h, bn); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = mfma32(a[t], b[t], acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { a[t] = an[t]; b[t] = bn[t]; }
+    }
+    if (wave) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave) return;
+    float* __restrict__ C = g.C + (size_t)z * g.zC;
+    const float* __restrict__ bias = g.bias ? g.bias + (size_t)z * g.zBias : nullptr;
+    const float* __restrict__ aux = g.aux ? g.aux + (size_t)z * g.zAux : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mm = blockIdx.x * 32 + rowfn(r, h);
+        if (mm >= g.M || n >= g.N) continue;
+        float v = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];      // fixed order
+        v *= g.alpha;
+        if (bias) v += bias[mm];
+        const size_t ci = (size_t)mm * g.sCm + (size_t)n * g.sCn;
+        if (g.epi == EPI_RELU) v = v > 0.f ? v : 0.f;
+        else if (g.epi == EPI_TANH) v = tanhf(v);
+        else if (g.epi == EPI_MASK_RELU) v = aux[ci] > 0.f ? v : 0.f;
+        else if (g.epi == EPI_MASK_TANH) { const float y = aux[ci]; v *= 1.0f - y * y; }
+        C[ci] = v;
+    }
+}
+
+// =================================================================================================================
+// SquashedDiagGaussian (squashedDiagGaussian.jl:24-46) — per-sample scalar math, accurate libm
+// =================================================================================================================
+constexpr int kMaxA = 8;
+constexpr float kLog2Pi = 1.8378770664093453f;
+__device__ inline float softplus_f(float x) { return log1pf(expf(-fabsf(x))) + (x > 0.f ? x : 0.f); }   // Lux.softplus
+// a = tanh(mu + exp(ls) * noise); returns logpdf(d, a) (:36-46), g = atanh(clamp(a))
+__device__ inline float squashed_sample_logp(const float* mu, const float* ls, const float* noise, int A, float* a, float* g) {
+    const float eps = 1.0e-6f, lo = -1.0f + eps, hi = 1.0f - eps;
+    float lss = 0.f, dss = 0.f, corr = 0.f;
+    for (int i = 0; i < A; ++i) {
+        a[i] = tanhf(mu[i] + expf(ls[i]) * noise[i]);
+        const float xc = a[i] < lo ? lo : (a[i] > hi ? hi : a[i]);
+        g[i] = atanhf(xc);
+        corr += 2.0f * (logf(2.0f) - g[i] - softplus_f(-2.0f * g[i]));
+        lss += ls[i]; const float d = g[i] - mu[i]; dss += d * d * expf(-2.0f * ls[i]);
+    }
+    return -0.5f * (2.0f * lss + dss + (float)A * kLog2Pi) - corr;       // diagGaussian.jl:25-36 minus the correction
+}
+
+// deterministic block reduction (blockDim.x == 256): pairwise tree in shared memory
+__device__ inline double block_sum(double v, double* sh) {
+    const int t = threadIdx.x;
+    sh[t] = v; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) sh[t] += sh[t + s]; __syncthreads(); }
+    const double r = sh[0]; __syncthreads();
+    return r;
+}
+
+struct SacRng { uint64_t key; uint64_t u; };
+__device__ inline float sac_noise(SacRng r, int stream, int i, int a) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)r.key, (uint32_t)(r.key >> 32), (uint32_t)r.u, (uint32_t)(r.u >> 32), (uint32_t)stream, (uint32_t)(i * 4 + a / 2), o);
+    return (a & 1) ? randn_f32(o[2], o[3]) : randn_f32(o[0], o[1]);
+}
+
+// ---- get_data_loader (replay_buffer.jl:116-157): gather one batch + its three noise draws -------------------------------
+struct GatherArgs {
+    int B, D, A; long long cap, head, size;
+    const float *rb_obs, *rb_next, *rb_act, *rb_rew; const uint8_t* rb_term;
+    const long long* inj_idx; const float *inj_ne, *inj_nn, *inj_np;     // injected batch (tests), per sample; null = Philox
+    SacRng rng;
+    float* xa;        // [2B][D]: rows [0,B) observations, [B,2B) next observations (actor input)
+    float* xq;        // [B][D+A]: (obs, stored action)
+    float *rew, *ne, *nn, *np; uint8_t* term;
+};
+__global__ void sac_gather_kernel(GatherArgs g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.B) return;
+    long long j;
+    if (g.inj_idx) j = g.inj_idx[i];
+    else {
+        uint32_t o[4];
+        philox4x32_10((uint32_t)g.rng.key, (uint32_t)(g.rng.key >> 32), (uint32_t)g.rng.u, (uint32_t)(g.rng.u >> 32), 4u, (uint32_t)i, o);
+        j = (long long)(u01_f64(o[0], o[1]) * (double)g.size); if (j >= g.size) j = g.size - 1;
+    }
+    const long long slot = (g.head + j) % g.cap;
+    for (int d = 0; d < g.D; ++d) {
+        const float o = g.rb_obs[slot * g.D + d];
+        g.xa[(size_t)i * g.D + d] = o; g.xq[(size_t)i * (g.D + g.A) + d] = o;
+        g.xa[(size_t)(g.B + i) * g.D + d] = g.rb_next[slot * g.D + d];
+    }
+    for (int a = 0; a < g.A; ++a) {
+        g.xq[(size_t)i * (g.D + g.A) + g.D + a] = g.rb_act[slot * g.A + a];
+        g.ne[i * g.A + a] = g.inj_ne ? g.inj_ne[i * g.A + a] : sac_noise(g.rng, 5, i, a);
+        g.nn[i * g.A + a] = g.inj_nn ? g.inj_nn[i * g.A + a] : sac_noise(g.rng, 6, i, a);
+        g.np[i * g.A + a] = g.inj_np ? g.inj_np[i * g.A + a] : sac_noise(g.rng, 7, i, a);
+    }
+    g.rew[i] = g.rb_rew[slot]; g.term[i] = g.rb_term[slot];
+}
+
+// device scalars shared by the kernels of one gradient step
+struct SacScalars { float log_ent, ent_m, ent_v, alpha; };
+
+// ---- entropy-coefficient step (sac.jl:313-343) + next actions for the critic target (:131) ----------------------------------
+struct EntNextArgs {
+    int B, D, A; const float* mu;    // [2B][A] actor means of (obs | next obs)
+    const float* log_std; const float *ne, *nn; const float* xa;
+    float* xq_next;   // [B][D+A] (next obs, next action)
+    float* nlp;       // [B] next log-probs
+    SacScalars* sc; float target_entropy, lr, b1, b2, eps, bt1, bt2; int auto_ent;
+    float* stats;     // [8]: 0 actor_loss 1 critic_loss 2 entropy_loss 3 mean_q 4 ent_coef 5 |gc|^2 6 |ga|^2
+};
+__global__ __launch_bounds__(256) void sac_ent_next_kernel(EntNextArgs g) {
+    __shared__ double sh[256];
+    float ls[kMaxA]; for (int a = 0; a < g.A; ++a) ls[a] = g.log_std[a];
+    double s = 0;
+    for (int i = threadIdx.x; i < g.B; i += 256) {
+        float a_[kMaxA], gg[kMaxA];
+        if (g.auto_ent) s += (double)(squashed_sample_logp(g.mu + (size_t)i * g.A, ls, g.ne + (size_t)i * g.A, g.A, a_, gg) + g.target_entropy);
+        g.nlp[i] = squashed_sample_logp(g.mu + (size_t)(g.B + i) * g.A, ls, g.nn + (size_t)i * g.A, g.A, a_, gg);
+        for (int d = 0; d < g.D; ++d) g.xq_next[(size_t)i * (g.D + g.A) + d] = g.xa[(size_t)(g.B + i) * g.D + d];
+        for (int a = 0; a < g.A; ++a) g.xq_next[(size_t)i * (g.D + g.A) + g.D + a] = a_[a];
+    }
+    const double tot = block_sum(s, sh);
+    if (threadIdx.x == 0) {
+        float le = g.sc->log_ent;
+        if (g.auto_ent) {
+            const float cc = (float)(tot / g.B);
+            g.stats[2] = -(le * cc);                                                          // loss = -(log_ent_coef * c), :330
+            const float gr = -cc;
+            const float m = g.b1 * g.sc->ent_m + (1.0f - g.b1) * gr, v = g.b2 * g.sc->ent_v + (1.0f - g.b2) * gr * gr;
+            g.sc->ent_m = m; g.sc->ent_v = v;
+            le -= m / (1.0f - g.bt1) / (sqrtf(v / (1.0f - g.bt2)) + g.eps) * g.lr;           // Optimisers.Adam
+            g.sc->log_ent = le;
+        }
+        g.sc->alpha = expf(le);
+        g.stats[4] = g.sc->alpha;                                                             // :391
+    }
+}
+
+// ---- Bellman target + critic loss head (sac_critic_loss :136-150) ---------------------------------------------------------
+struct CriticHeadArgs {
+    int B; const float* q_next;  // [2][B] target-network values of (next obs, next action)
+    const float* q;              // [2][B] current values of (obs, action)
+    const float *rew, *nlp; const uint8_t* term; const SacScalars* sc; float gamma;
+    float* dq;                   // [2][B] dL/dq
+    float* stats;
+};
+__global__ __launch_bounds__(256) void sac_critic_head_kernel(CriticHeadArgs g) {
+    __shared__ double sh[256];
+    const float alpha = g.sc->alpha;
+    double cl = 0, qs = 0;
+    for (int i = threadIdx.x; i < g.B; i += 256) {
+        const float n0 = g.q_next[i], n1 = g.q_next[g.B + i], mn = n0 < n1 ? n0 : n1;
+        const float y = g.term[i] ? g.rew[i] : g.rew[i] + g.gamma * (mn - alpha * g.nlp[i]);
+        for (int k = 0; k < 2; ++k) {
+            const float qv = g.q[k * g.B + i], d = qv - y;
+            cl += 0.5 * (double)d * d / g.B; qs += qv;
+            g.dq[k * g.B + i] = d / (float)g.B;
+        }
+    }
+    cl = block_sum(cl, sh); qs = block_sum(qs, sh);
+    if (threadIdx.x == 0) { g.stats[1] = (float)cl; g.stats[3] = (float)(qs / (2.0 * g.B)); }
+}
+
+// ---- actor sample for the actor loss (sac_actor_loss :101): a_pi, logp, atanh(clamp(a)) -----------------------------------
+struct PiHeadArgs {
+    int B, D, A; const float* mu; const float* log_std; const float* np; const float* xa;
+    float* xq_pi; float *a_pi, *g_pi, *lp_pi;
+};
+__global__ void sac_pi_head_kernel(PiHeadArgs g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.B) return;
+    float ls[kMaxA], a_[kMaxA], gg[kMaxA]; for (int a = 0; a < g.A; ++a) ls[a] = g.log_std[a];
+    g.lp_pi[i] = squashed_sample_logp(g.mu + (size_t)i * g.A, ls, g.np + (size_t)i * g.A, g.A, a_, gg);
+    for (int d = 0; d < g.D; ++d) g.xq_pi[(size_t)i * (g.D + g.A) + d] = g.xa[(size_t)i * g.D + d];
+    for (int a = 0; a < g.A; ++a) { g.xq_pi[(size_t)i * (g.D + g.A) + g.D + a] = a_[a]; g.a_pi[i * g.A + a] = a_[a]; g.g_pi[i * g.A + a] = gg[a]; }
+}
+// actor loss head (:102-104): min over the critics, dL/dq
+struct ActorHeadArgs { int B; const float* q_pi; const float* lp_pi; const SacScalars* sc; float* dq; float* stats; };
+__global__ __launch_bounds__(256) void sac_actor_head_kernel(ActorHeadArgs g) {
+    __shared__ double sh[256];
+    const float alpha = g.sc->alpha;
+    double al = 0;
+    for (int i = threadIdx.x; i < g.B; i += 256) {
+        const float q0 = g.q_pi[i], q1 = g.q_pi[g.B + i];
+        const int km = q1 < q0 ? 1 : 0;
+        al += ((double)alpha * g.lp_pi[i] - (km ? q1 : q0)) / g.B;
+        g.dq[km * g.B + i] = -1.0f / (float)g.B; g.dq[(1 - km) * g.B + i] = 0.f;
+    }
+    al = block_sum(al, sh);
+    if (threadIdx.x == 0) g.stats[0] = (float)al;
+}
+// reverse of the squashed sample (Zygote through tanh -> clamp -> atanh -> logpdf): dL/dmu per sample, dL/dlog_std summed
+struct SquashBwdArgs {
+    int B, D, A; const float* mu; const float* log_std; const float* np; const float *a_pi, *g_pi;
+    const float* dxq;   // [2][B][D+A] input gradients of the two critics
+    const SacScalars* sc; float* dmu; float* g_log_std;
+};
+__global__ __launch_bounds__(256) void sac_squash_bwd_kernel(SquashBwdArgs g) {
+    __shared__ double sh[256];
+    const float alpha = g.sc->alpha, eps = 1.0e-6f, lo = -1.0f + eps, hi = 1.0f - eps;
+    double dls[kMaxA]; for (int a = 0; a < g.A; ++a) dls[a] = 0;
+    const int W = g.D + g.A;
+    for (int i = threadIdx.x; i < g.B; i += 256) {
+        const float dlogp = alpha / (float)g.B;
+        for (int a = 0; a < g.A; ++a) {
+            const float da = g.dxq[(size_t)i * W + g.D + a] + g.dxq[((size_t)g.B + i) * W + g.D + a];
+            const float ls = g.log_std[a], sig = expf(ls), e2 = expf(-2.0f * ls);
+            const float x = g.a_pi[i * g.A + a], gg = g.g_pi[i * g.A + a], mu = g.mu[(size_t)i * g.A + a], d = gg - mu;
+            const float inside = (x >= lo && x <= hi) ? 1.0f : 0.0f;
+            const float dlp_dg = -d * e2 + 2.0f * tanhf(gg);
+            const float du = dlogp * dlp_dg * inside + da * (1.0f - x * x);
+            g.dmu[(size_t)i * g.A + a] = dlogp * (d * e2) + du;
+            dls[a] += (double)(dlogp * (-1.0f + d * d * e2) + du * sig * g.np[i * g.A + a]);
+        }
+    }
+    for (int a = 0; a < g.A; ++a) { const double t = block_sum(dls[a], sh); if (threadIdx.x == 0) g.g_log_std[a] = (float)t; }
+}
+
+// ---- Optimisers.Adam on a parameter range; grads == nullptr applies ZERO gradients (zero_critic_grads! then apply_gradients,
+// sac.jl:381-382: the moments decay and the parameters keep moving along the remaining momentum) ---------------------------
+struct AdamRangeArgs { float* p; float* m; float* v; const float* g; int n; float lr, b1, b2, eps, bt1, bt2; double* sumsq_partials; };
+__global__ __launch_bounds__(256) void sac_adam_kernel(AdamRangeArgs a) {
+    __shared__ double sh[256];
+    double ss = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
+        const float gi = a.g ? a.g[i] : 0.f;
+        const float m = a.b1 * a.m[i] + (1.0f - a.b1) * gi, v = a.b2 * a.v[i] + (1.0f - a.b2) * gi * gi;
+        a.m[i] = m; a.v[i] = v;
+        a.p[i] -= m / (1.0f - a.bt1) / (sqrtf(v / (1.0f - a.bt2)) + a.eps) * a.lr;
+        ss += (double)gi * gi;
+    }
+    if (a.sumsq_partials) { ss = block_sum(ss, sh); if (threadIdx.x == 0) a.sumsq_partials[blockIdx.x] = ss; }
+}
+// polyak_update! (optimization_utils.jl:3-6) + the step's statistics
+struct FinishArgs { float* target; const float* src; int n; float tau; int do_polyak; const double *ssq_c, *ssq_a, *ssq_ls; int nblk_c, nblk_a; float* stats; float* out; };
+__global__ __launch_bounds__(256) void sac_finish_kernel(FinishArgs f) {
+    if (f.do_polyak)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < f.n; i += gridDim.x * 256) f.target[i] = f.tau * f.src[i] + (1.0f - f.tau) * f.target[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double c = 0, a = 0;
+        for (int i = 0; i < f.nblk_c; ++i) c += f.ssq_c[i];
+        for (int i = 0; i < f.nblk_a; ++i) a += f.ssq_a[i];
+        a += f.ssq_ls[0];
+        f.out[0] = f.stats[0]; f.out[1] = f.stats[1]; f.out[2] = f.stats[2]; f.out[3] = f.stats[3]; f.out[4] = f.stats[4];
+        f.out[5] = (float)sqrt(c + a);                                                        // sac.jl:393
+    }
+}
+
+// ---- collection (off_policy_collection.jl:28-96) ---------------------------------------------------------------------------
+struct CollectHeadArgs {
+    int E, A, use_random; const float* mu; const float* log_std; const float* inj_noise; const uint32_t* gstep; uint64_t seed0;
+    float low, high; float* raw; float* envact;
+};
+__global__ void sac_collect_head_kernel(CollectHeadArgs g) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= g.E) return;
+    for (int a0 = 0; a0 < g.A; a0 += 2) {
+        float z[2];
+        if (g.inj_noise) { z[0] = g.inj_noise[e * g.A + a0]; z[1] = a0 + 1 < g.A ? g.inj_noise[e * g.A + a0 + 1] : 0.f; }
+        else {
+            uint32_t o[4]; const uint64_t k = g.seed0 + (uint64_t)e;
+            philox4x32_10((uint32_t)k, (uint32_t)(k >> 32), g.gstep[e], 0u, 1u, (uint32_t)(a0 / 2), o);
+            if (g.use_random) { z[0] = u01_f32(o[0]); z[1] = u01_f32(o[2]); } else { z[0] = randn_f32(o[0], o[1]); z[1] = randn_f32(o[2], o[3]); }
+        }
+        for (int t = 0; t < 2 && a0 + t < g.A; ++t) {
+            const int a = a0 + t; float r, ev;
+            if (g.use_random) { r = g.low + z[t] * (g.high - g.low); ev = r; }               // rand(rng, act_space): already env space, :50-53
+            else {
+                r = tanhf(g.mu[(size_t)e * g.A + a] + expf(g.log_std[a]) * z[t]);            // rand(SquashedDiagGaussian) squashedDiagGaussian.jl:24-27
+                ev = tanhf(r) * (g.high - g.low) / 2.0f + (g.low + g.high) / 2.0f;           // to_env(TanhScaleAdapter) default_adapters.jl:13-21
+            }
+            g.raw[e * g.A + a] = r; g.envact[e * g.A + a] = ev;
+        }
+    }
+}
+struct PushArgs {
+    int E, D, A; long long cap, tail; const float *obs, *raw, *rew, *tobs, *nobs; const uint8_t *term, *trunc;
+    float *rb_obs, *rb_next, *rb_act, *rb_rew; uint8_t *rb_term, *rb_trunc;
+};
+__global__ void sac_push_kernel(PushArgs g) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= g.E) return;
+    const long long slot = (g.tail + e) % g.cap;
+    const bool tr = g.trunc[e] != 0;
+    for (int d = 0; d < g.D; ++d) {
+        g.rb_obs[slot * g.D + d] = g.obs[(size_t)e * g.D + d];
+        g.rb_next[slot * g.D + d] = tr ? g.tobs[(size_t)e * g.D + d] : g.nobs[(size_t)e * g.D + d];   // truncated_observation | next observation
+    }
+    for (int a = 0; a < g.A; ++a) g.rb_act[slot * g.A + a] = g.raw[e * g.A + a];               // unprocessed action, :72
+    g.rb_rew[slot] = g.rew[e]; g.rb_term[slot] = g.term[e]; g.rb_trunc[slot] = g.trunc[e];
+}
+// host-batch helpers
+__global__ void sac_squash_eval_kernel(int B, int A, const float* mu, const float* log_std, const float* noise, int deterministic, float low, float high,
+                                       float* actions, float* logp, float* envact) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    float ls[kMaxA], a_[kMaxA], gg[kMaxA], nz[kMaxA];
+    for (int a = 0; a < A; ++a) { ls[a] = log_std[a]; nz[a] = deterministic ? 0.f : noise[i * A + a]; }
+    const float lp = squashed_sample_logp(mu + (size_t)i * A, ls, nz, A, a_, gg);              // deterministic: mode(d) = tanh(mean) :48-50
+    for (int a = 0; a < A; ++a) {
+        if (actions) actions[i * A + a] = a_[a];
+        if (envact) envact[i * A + a] = tanhf(a_[a]) * (high - low) / 2.0f + (low + high) / 2.0f;
+    }
+    if (logp) logp[i] = lp;
+}
+__global__ void sac_concat_kernel(int B, int D, int A, const float* obs, const float* act, float* xq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    for (int d = 0; d < D; ++d) xq[(size_t)i * (D + A) + d] = obs[(size_t)i * D + d];
+    for (int a = 0; a < A; ++a) xq[(size_t)i * (D + A) + D + a] = act[(size_t)i * A + a];
+}
+__global__ void sac_noise_fill_kernel(int n, int A, SacRng rng, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int a = 0; a < A; ++a) out[i * A + a] = sac_noise(rng, 8, i, a);
+}
+
+}  // namespace
+
+// =================================================================================================================
+// handle
+// =================================================================================================================
+struct dril_sac_handle {
+    dril_sac_config cfg;
+    int D = 0, A = 0, S = 0, H1 = 0, H2 = 0, nmax = 0;
+    int P = 0, Pa = 0, Pq = 0;                       // host (ABI) layout: actor | q1 | q2 | log_std
+    int Pd = 0, Pqd = 0, log_std_off = 0;            // DEVICE layout: every net starts on a 16-byte boundary (float4 operand loads); pads stay zero
+    NetOff actor{}, q0{};                            // device offsets
+    hipStream_t stream = nullptr;
+    float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *target = nullptr, *g_critic = nullptr, *g_actor = nullptr;
+    SacScalars* sc = nullptr; float* stats = nullptr; float* stats_out = nullptr; int stats_cap = 0;
+    double *ssq_c = nullptr, *ssq_a = nullptr, *ssq_ls = nullptr; int adam_blocks_c = 0, adam_blocks_a = 0;
+    float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
+    float target_entropy = 0;
+    // env
+    float* state = nullptr; int32_t* step_count = nullptr; uint32_t *episode = nullptr, *gstep = nullptr; float* disc_returns = nullptr;
+    float *obs_cur = nullptr, *obs_nxt = nullptr, *e_rew = nullptr, *e_tobs = nullptr, *e_raw = nullptr, *e_envact = nullptr; uint8_t *e_term = nullptr, *e_trunc = nullptr;
+    uint64_t env_seed0 = 0; bool env_ready = false, obs_valid = false;
+    // replay ring
+    long long cap = 0, size = 0, head = 0;
+    float *rb_obs = nullptr, *rb_next = nullptr, *rb_act = nullptr, *rb_rew = nullptr; uint8_t *rb_term = nullptr, *rb_trunc = nullptr;
+    // batch + activations
+    float *xa = nullptr, *ah1 = nullptr, *ah2 = nullptr, *mu = nullptr;               // actor: [nmax][D], [nmax][H], [nmax][A]
+    float *xq = nullptr, *xq_next = nullptr, *xq_pi = nullptr;                       // [B][D+A]
+    float *qh1 = nullptr, *qh2 = nullptr, *th1 = nullptr, *th2 = nullptr;            // [2][nq][H]
+    float *q_cur = nullptr, *q_next = nullptr, *q_pi = nullptr, *dq = nullptr;       // [2][nq]
+    float *dz2 = nullptr, *dz1 = nullptr, *dxq = nullptr, *dmu = nullptr;            // [2][nq][H], [2][nq][D+A], [B][A]
+    float *b_rew = nullptr, *b_ne = nullptr, *b_nn = nullptr, *b_np = nullptr, *b_nlp = nullptr, *a_pi = nullptr, *g_pi = nullptr, *lp_pi = nullptr; uint8_t* b_term = nullptr;
+    int nq = 0;
+    // injected inputs (tests)
+    float* collect_noise = nullptr; size_t collect_noise_count = 0;
+    int inj_updates = 0; long long* inj_idx = nullptr; float *inj_ne = nullptr, *inj_nn = nullptr, *inj_np = nullptr;
+    // host-batch scratch
+    float *s_in = nullptr, *s_act = nullptr, *s_noise = nullptr, *s_out = nullptr, *s_out2 = nullptr;
+    // timing
+    hipEvent_t ev_a = nullptr, ev_b = nullptr; double collect_ms = 0, update_ms = 0; int64_t collect_steps = 0, updates = 0;
+    std::string err;
+};
+
+namespace {
+
+int sfail(dril_sac_handle* h, int code, const std::string& msg) { if (h) h->err = msg; else g_sac_create_error = msg; return code; }
+#define SHIP(h, expr)                                                                                        \
+    do { hipError_t _e = (expr); if (_e != hipSuccess)                                                       \
+        return sfail(h, DRIL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+#define SNEED(h) do { if (!(h)) return sfail(nullptr, DRIL_ERR_NOT_INITIALISED, "null handle"); } while (0)
+#define SDO(expr) do { int _rc = (expr); if (_rc != DRIL_OK) return _rc; } while (0)
+
+template <typename T> hipError_t smalloc(T** p, size_t n) {
+    hipError_t e = hipMalloc((void**)p, (n ? n : 1) * sizeof(T));
+    if (e == hipSuccess) e = hipMemset(*p, 0, (n ? n : 1) * sizeof(T));
+    return e;
+}
+bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+
+int gemm(dril_sac_handle* h, GemmArgs g, int Z) {
+    g.vecA = g.sAk == 1 && g.sAm % 4 == 0 && g.K % 4 == 0 && aligned16(g.A) && g.zA % 4 == 0;
+    g.vecB = !g.ones_n && g.sBk == 1 && g.sBn % 4 == 0 && g.K % 4 == 0 && aligned16(g.B) && g.zB % 4 == 0;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return sfail(h, DRIL_ERR_INVALID_ARG, "gemm: empty contraction");
+    dim3 grid((g.M + 31) / 32, (g.N + 31) / 32, Z);
+    hipLaunchKernelGGL(sac_gemm_kernel, grid, dim3(256), 0, h->stream, g);
+    SHIP(h, hipGetLastError());
+    return DRIL_OK;
+}
+GemmArgs gemm_args() { GemmArgs g; memset(&g, 0, sizeof(g)); g.alpha = 1.0f; return g; }
+
+// One net = {W1 b1 W2 b2 W3 b3} at `P + off` (+ z * zP for the second critic); activations are (features x n) column-major
+struct NetBufs { float* h1; float* h2; float* out; long long zh, zo; };   // [Z][n][H], [Z][n][O]
+int net_forward(dril_sac_handle* h, const float* P, NetOff off, long long zP, int in, int O, const float* X, int ldx, long long zX, int n,
+                NetBufs b, int Z) {
+    const int H1 = h->H1, H2 = h->H2, act = h->cfg.activation ? EPI_RELU : EPI_TANH;
+    GemmArgs g = gemm_args();                                                       // h1 = act(W1 x + b1)
+    g.A = P + off.w1; g.sAm = 1; g.sAk = H1; g.zA = zP; g.B = X; g.sBk = 1; g.sBn = ldx; g.zB = zX;
+    g.C = b.h1; g.sCm = 1; g.sCn = H1; g.zC = b.zh; g.bias = P + off.b1; g.zBias = zP; g.M = H1; g.N = n; g.K = in; g.epi = act;
+    SDO(gemm(h, g, Z));
+    g = gemm_args();                                                                // h2 = act(W2 h1 + b2)
+    g.A = P + off.w2; g.sAm = 1; g.sAk = H2; g.zA = zP; g.B = b.h1; g.sBk = 1; g.sBn = H1; g.zB = b.zh;
+    g.C = b.h2; g.sCm = 1; g.sCn = H2; g.zC = b.zh; g.bias = P + off.b2; g.zBias = zP; g.M = H2; g.N = n; g.K = H1; g.epi = act;
+    SDO(gemm(h, g, Z));
+    g = gemm_args();                                                                // out = W3 h2 + b3
+    g.A = P + off.w3; g.sAm = 1; g.sAk = O; g.zA = zP; g.B = b.h2; g.sBk = 1; g.sBn = H2; g.zB = b.zh;
+    g.C = b.out; g.sCm = 1; g.sCn = O; g.zC = b.zo; g.bias = P + off.b3; g.zBias = zP; g.M = O; g.N = n; g.K = H2; g.epi = EPI_NONE;
+    return gemm(h, g, Z);
+}
+// reverse pass given dOut [Z][n][O]: parameter gradients into G (same layout as P; null = skip) and/or dX [Z][n][in] (null = skip)
+int net_backward(dril_sac_handle* h, const float* P, NetOff off, long long zP, int in, int O, const float* X, int ldx, long long zX, int n,
+                 NetBufs b, const float* dOut, float* G, float* dX, int Z) {
+    const int H1 = h->H1, H2 = h->H2, mask = h->cfg.activation ? EPI_MASK_RELU : EPI_MASK_TANH;
+    const long long zd = (long long)h->nq * H1;   // dz buffers are [2][nq][H] (H1 == H2 layouts are separate buffers)
+    GemmArgs g;
+    if (G) {                                                                        // [dW3 | db3] = dOut . [h2' | 1]
+        g = gemm_args(); g.A = dOut; g.sAm = 1; g.sAk = O; g.zA = b.zo; g.B = b.h2; g.sBk = H2; g.sBn = 1; g.zB = b.zh; g.ones_n = 1;
+        g.C = G + off.w3; g.sCm = 1; g.sCn = O; g.zC = zP; g.M = O; g.N = H2 + 1; g.K = n; SDO(gemm(h, g, Z));
+    }
+    g = gemm_args();                                                                // dz2 = (W3' dOut) .* act'(h2)
+    g.A = P + off.w3; g.sAm = O; g.sAk = 1; g.zA = zP; g.B = dOut; g.sBk = 1; g.sBn = O; g.zB = b.zo;
+    g.C = h->dz2; g.sCm = 1; g.sCn = H2; g.zC = (long long)h->nq * H2; g.aux = b.h2; g.zAux = b.zh; g.M = H2; g.N = n; g.K = O; g.epi = mask;
+    SDO(gemm(h, g, Z));
+    if (G) {                                                                        // [dW2 | db2] = dz2 . [h1' | 1]
+        g = gemm_args(); g.A = h->dz2; g.sAm = 1; g.sAk = H2; g.zA = (long long)h->nq * H2; g.B = b.h1; g.sBk = H1; g.sBn = 1; g.zB = b.zh; g.ones_n = 1;
+        g.C = G + off.w2; g.sCm = 1; g.sCn = H2; g.zC = zP; g.M = H2; g.N = H1 + 1; g.K = n; SDO(gemm(h, g, Z));
+    }
+    g = gemm_args();                                                                // dz1 = (W2' dz2) .* act'(h1)
+    g.A = P + off.w2; g.sAm = H2; g.sAk = 1; g.zA = zP; g.B = h->dz2; g.sBk = 1; g.sBn = H2; g.zB = (long long)h->nq * H2;
+    g.C = h->dz1; g.sCm = 1; g.sCn = H1; g.zC = zd; g.aux = b.h1; g.zAux = b.zh; g.M = H1; g.N = n; g.K = H2; g.epi = mask;
+    SDO(gemm(h, g, Z));
+    if (G) {                                                                        // [dW1 | db1] = dz1 . [x' | 1]
+        g = gemm_args(); g.A = h->dz1; g.sAm = 1; g.sAk = H1; g.zA = zd; g.B = X; g.sBk = ldx; g.sBn = 1; g.zB = zX; g.ones_n = 1;
+        g.C = G + off.w1; g.sCm = 1; g.sCn = H1; g.zC = zP; g.M = H1; g.N = in + 1; g.K = n; SDO(gemm(h, g, Z));
+    }
+    if (dX) {                                                                       // dx = W1' dz1
+        g = gemm_args(); g.A = P + off.w1; g.sAm = H1; g.sAk = 1; g.zA = zP; g.B = h->dz1; g.sBk = 1; g.sBn = H1; g.zB = zd;
+        g.C = dX; g.sCm = 1; g.sCn = in; g.zC = (long long)h->nq * in; g.M = in; g.N = n; g.K = H1; SDO(gemm(h, g, Z));
+    }
+    return DRIL_OK;
+}
+NetBufs actor_bufs(dril_sac_handle* h) { return NetBufs{h->ah1, h->ah2, h->mu, 0, 0}; }
+NetBufs q_bufs(dril_sac_handle* h, float* h1, float* h2, float* out) { return NetBufs{h1, h2, out, (long long)h->nq * h->H1, (long long)h->nq}; }
+
+int ssync(dril_sac_handle* h) { SHIP(h, hipStreamSynchronize(h->stream)); return DRIL_OK; }
+
+int adam_range(dril_sac_handle* h, int lo, int n, const float* grads, const float* bt, double* ssq, int blocks) {
+    AdamRangeArgs a{h->params + lo, h->adam_m + lo, h->adam_v + lo, grads ? grads + lo : nullptr, n, h->cfg.learning_rate, h->cfg.adam_beta1,
+                    h->cfg.adam_beta2, h->cfg.adam_eps, bt[0], bt[1], ssq};
+    hipLaunchKernelGGL(sac_adam_kernel, dim3(blocks), dim3(256), 0, h->stream, a);
+    SHIP(h, hipGetLastError());
+    return DRIL_OK;
+}
+
+// one update!(agent, alg, batch): sac.jl:299-404.  `slot` = index into the injected batches (-1 = Philox), `out` = device stats row
+int sac_one_update(dril_sac_handle* h, int slot, float* out) {
+    const int B = h->cfg.batch_size, D = h->D, A = h->A, W = D + A;
+    const SacRng rng{h->cfg.seed ^ 0x5ac5ac5ac5ac5ac5ull, h->update_counter};
+    GatherArgs ga{B, D, A, h->cap, h->head, h->size, h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term,
+                  slot >= 0 && h->inj_idx ? h->inj_idx + (size_t)slot * B : nullptr, slot >= 0 && h->inj_ne ? h->inj_ne + (size_t)slot * B * A : nullptr,
+                  slot >= 0 && h->inj_nn ? h->inj_nn + (size_t)slot * B * A : nullptr, slot >= 0 && h->inj_np ? h->inj_np + (size_t)slot * B * A : nullptr,
+                  rng, h->xa, h->xq, h->b_rew, h->b_ne, h->b_nn, h->b_np, h->b_term};
+    hipLaunchKernelGGL(sac_gather_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, ga);
+    // actor means of (obs | next obs) in one pass: the entropy constant (:318-325) and the actor loss (:101) share the obs half,
+    // the critic target (:131) uses the next-obs half; the actor parameters do not change until the actor step
+    SDO(net_forward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, 2 * B, actor_bufs(h), 1));
+    EntNextArgs en{B, D, A, h->mu, h->params + h->log_std_off, h->b_ne, h->b_nn, h->xa, h->xq_next, h->b_nlp, h->sc, h->target_entropy,
+                   h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->bt_ent[0], h->bt_ent[1], h->cfg.auto_ent_coef, h->stats};
+    hipLaunchKernelGGL(sac_ent_next_kernel, dim3(1), dim3(256), 0, h->stream, en);
+    if (h->cfg.auto_ent_coef) { h->bt_ent[0] *= h->cfg.adam_beta1; h->bt_ent[1] *= h->cfg.adam_beta2; }
+    // critic: target values with the target networks (:133-135), current values (:117), loss head, reverse pass, Adam (:362)
+    SDO(net_forward(h, h->target, net_off(0, W, h->H1, h->H2, 1), h->Pqd, W, 1, h->xq_next, W, 0, B, q_bufs(h, h->th1, h->th2, h->q_next), 2));
+    SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), 2));
+    CriticHeadArgs ch{B, h->q_next, h->q_cur, h->b_rew, h->b_nlp, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats};
+    hipLaunchKernelGGL(sac_critic_head_kernel, dim3(1), dim3(256), 0, h->stream, ch);
+    SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), h->dq, h->g_critic, nullptr, 2));
+    SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, h->ssq_c, h->adam_blocks_c));
+    h->bt_critic[0] *= h->cfg.adam_beta1; h->bt_critic[1] *= h->cfg.adam_beta2;
+    // actor (:93-105) with the UPDATED critics: sample, values, loss head, input gradients of the critics, squash reverse, actor reverse
+    PiHeadArgs ph{B, D, A, h->mu, h->params + h->log_std_off, h->b_np, h->xa, h->xq_pi, h->a_pi, h->g_pi, h->lp_pi};
+    hipLaunchKernelGGL(sac_pi_head_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, ph);
+    SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), 2));
+    ActorHeadArgs ah{B, h->q_pi, h->lp_pi, h->sc, h->dq, h->stats};
+    hipLaunchKernelGGL(sac_actor_head_kernel, dim3(1), dim3(256), 0, h->stream, ah);
+    SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), h->dq, nullptr, h->dxq, 2));
+    SquashBwdArgs sb{B, D, A, h->mu, h->params + h->log_std_off, h->b_np, h->a_pi, h->g_pi, h->dxq, h->sc, h->dmu, h->g_actor + h->log_std_off};
+    hipLaunchKernelGGL(sac_squash_bwd_kernel, dim3(1), dim3(256), 0, h->stream, sb);
+    SDO(net_backward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, B, actor_bufs(h), h->dmu, h->g_actor, nullptr, 1));
+    // apply_gradients(train_state, actor_loss_grad) :382 — actor + log_std with their gradients, the critics with ZERO gradients
+    SDO(adam_range(h, 0, h->actor.end, h->g_actor, h->bt_actor, h->ssq_a, h->adam_blocks_a));
+    SDO(adam_range(h, h->log_std_off, A, h->g_actor, h->bt_actor, h->ssq_ls, 1));
+    SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, nullptr, h->bt_critic, nullptr, h->adam_blocks_c));
+    h->bt_actor[0] *= h->cfg.adam_beta1; h->bt_actor[1] *= h->cfg.adam_beta2;
+    h->bt_critic[0] *= h->cfg.adam_beta1; h->bt_critic[1] *= h->cfg.adam_beta2;
+    const int do_polyak = h->grad_updates % h->cfg.target_update_interval == 0;                  // :385-389
+    FinishArgs fa{h->target, h->params + h->q0.w1, 2 * h->Pqd, h->cfg.tau, do_polyak, h->ssq_c, h->ssq_a, h->ssq_ls, h->adam_blocks_c, h->adam_blocks_a, h->stats, out};
+    hipLaunchKernelGGL(sac_finish_kernel, dim3(h->adam_blocks_c), dim3(256), 0, h->stream, fa);
+    SHIP(h, hipGetLastError());
+    h->grad_updates += 1; h->update_counter += 1;
+    return DRIL_OK;
+}
+
+int ensure_obs(dril_sac_handle* h) {
+    if (!h->env_ready) return sfail(h, DRIL_ERR_NOT_INITIALISED, "dril_sac_env_reset has not been called");
+    if (!h->obs_valid) { SHIP(h, launch_env_observe(h->cfg.env_kind, h->cfg.n_envs, h->state, h->obs_cur, h->stream)); h->obs_valid = true; }
+    return DRIL_OK;
+}
+// one step of collect_trajectories (off_policy_collection.jl:42-93) for all envs
+int collect_step(dril_sac_handle* h, int use_random, const float* inj_noise) {
+    const int E = h->cfg.n_envs, D = h->D, A = h->A;
+    if (!use_random) SDO(net_forward(h, h->params, h->actor, 0, D, A, h->obs_cur, D, 0, E, actor_bufs(h), 1));          // predict_actions_raw :55
+    CollectHeadArgs ca{E, A, use_random, h->mu, h->params + h->log_std_off, inj_noise, h->gstep, h->env_seed0, -2.0f, 2.0f, h->e_raw, h->e_envact};
+    hipLaunchKernelGGL(sac_collect_head_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, ca);
+    MonitorArgs mon{nullptr, nullptr, nullptr, nullptr, nullptr};
+    SHIP(h, launch_env_step(h->cfg.env_kind, E, h->env_seed0, h->cfg.episode_len, 0, 0, h->e_envact, h->state, h->step_count, h->episode, h->gstep,
+                            h->e_rew, h->e_term, h->e_trunc, h->e_tobs, mon, h->stream));                                     // act! :60
+    SHIP(h, launch_env_observe(h->cfg.env_kind, E, h->state, h->obs_nxt, h->stream));                                         // observe :61
+    const long long tail = (h->head + h->size) % h->cap;
+    PushArgs pa{E, D, A, h->cap, tail, h->obs_cur, h->e_raw, h->e_rew, h->e_tobs, h->obs_nxt, h->e_term, h->e_trunc,
+                h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc};
+    hipLaunchKernelGGL(sac_push_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, pa);
+    SHIP(h, hipGetLastError());
+    const long long over = h->size + E - h->cap;                                                  // CircularBuffer: overwrite the oldest
+    if (over > 0) { h->head = (h->head + over) % h->cap; h->size = h->cap; } else h->size += E;
+    std::swap(h->obs_cur, h->obs_nxt);
+    return DRIL_OK;
+}
+int collect(dril_sac_handle* h, int n_steps, int use_random, double* fps) {
+    if (n_steps <= 0) return sfail(h, DRIL_ERR_INVALID_ARG, "n_steps must be positive");
+    if (h->collect_noise && h->collect_noise_count != (size_t)n_steps * h->cfg.n_envs * h->A)
+        return sfail(h, DRIL_ERR_INVALID_ARG, "injected collect noise must hold n_steps * n_envs * action_dim values");
+    SDO(ensure_obs(h));
+    const auto t0 = std::chrono::steady_clock::now();
+    if (h->cfg.profile_events) hipEventRecord(h->ev_a, h->stream);
+    for (int t = 0; t < n_steps; ++t)
+        SDO(collect_step(h, use_random, h->collect_noise ? h->collect_noise + (size_t)t * h->cfg.n_envs * h->A : nullptr));
+    if (h->cfg.profile_events) hipEventRecord(h->ev_b, h->stream);
+    SDO(ssync(h));
+    if (h->cfg.profile_events) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev_a, h->ev_b) == hipSuccess) { h->collect_ms += ms; h->collect_steps += n_steps; } }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (fps) *fps = (double)n_steps * h->cfg.n_envs / (dt > 0 ? dt : 1e-9);                      // :126-128
+    if (h->collect_noise) { hipFree(h->collect_noise); h->collect_noise = nullptr; h->collect_noise_count = 0; }
+    return DRIL_OK;
+}
+int ensure_stats(dril_sac_handle* h, int n) {
+    if (n <= h->stats_cap) return DRIL_OK;
+    if (h->stats_out) hipFree(h->stats_out);
+    SHIP(h, smalloc(&h->stats_out, (size_t)n * 8)); h->stats_cap = n;
+    return DRIL_OK;
+}
+void fill_stats(const dril_sac_handle* h, const float* rows, int n, dril_sac_stats* out) {
+    for (int k = 0; k < n; ++k) {
+        const float* r = rows + (size_t)k * 8; dril_sac_stats& s = out[k]; memset(&s, 0, sizeof(s));
+        s.actor_loss = r[0]; s.critic_loss = r[1]; s.entropy_loss = h->cfg.auto_ent_coef ? r[2] : 0.f; s.mean_q_values = r[3];
+        s.entropy_coefficient = r[4]; s.grad_norm = r[5]; s.has_entropy_loss = h->cfg.auto_ent_coef ? 1 : 0;
+    }
+}
+int run_updates(dril_sac_handle* h, int n_updates, bool injected, dril_sac_stats* out) {
+    if (h->size <= 0) return sfail(h, DRIL_ERR_NOT_INITIALISED, "the replay buffer is empty");
+    SDO(ensure_stats(h, n_updates));
+    if (h->cfg.profile_events) hipEventRecord(h->ev_a, h->stream);
+    for (int k = 0; k < n_updates; ++k) SDO(sac_one_update(h, injected ? k : -1, h->stats_out + (size_t)k * 8));
+    if (h->cfg.profile_events) hipEventRecord(h->ev_b, h->stream);
+    SDO(ssync(h));
+    if (h->cfg.profile_events) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev_a, h->ev_b) == hipSuccess) { h->update_ms += ms; h->updates += n_updates; } }
+    if (out) {
+        std::vector<float> rows((size_t)n_updates * 8);
+        SHIP(h, hipMemcpy(rows.data(), h->stats_out, rows.size() * 4, hipMemcpyDeviceToHost));
+        fill_stats(h, rows.data(), n_updates, out);
+    }
+    return DRIL_OK;
+}
+void clear_injected(dril_sac_handle* h) {
+    if (h->inj_idx) hipFree(h->inj_idx); if (h->inj_ne) hipFree(h->inj_ne); if (h->inj_nn) hipFree(h->inj_nn); if (h->inj_np) hipFree(h->inj_np);
+    h->inj_idx = nullptr; h->inj_ne = h->inj_nn = h->inj_np = nullptr; h->inj_updates = 0;
+}
+void reset_optimizer(dril_sac_handle* h) {
+    h->bt_actor[0] = h->bt_critic[0] = h->bt_ent[0] = h->cfg.adam_beta1; h->bt_actor[1] = h->bt_critic[1] = h->bt_ent[1] = h->cfg.adam_beta2;
+    h->grad_updates = 0;
+}
+// ---- host (ABI) layout <-> padded device layout ------------------------------------------------------------------------
+struct Seg { int host, dev, len; };
+void param_segs(const dril_sac_handle* h, Seg (&s)[4]) {
+    s[0] = {0, 0, h->Pa}; s[1] = {h->Pa, h->q0.w1, h->Pq}; s[2] = {h->Pa + h->Pq, h->q0.w1 + h->Pqd, h->Pq}; s[3] = {h->Pa + 2 * h->Pq, h->log_std_off, h->A};
+}
+int params_to_device(dril_sac_handle* h, float* dev, const float* host) {
+    Seg s[4]; param_segs(h, s);
+    for (const Seg& g : s) SHIP(h, hipMemcpyAsync(dev + g.dev, host + g.host, (size_t)g.len * 4, hipMemcpyHostToDevice, h->stream));
+    return ssync(h);
+}
+int params_from_device(dril_sac_handle* h, float* host, const float* dev) {
+    SDO(ssync(h));
+    Seg s[4]; param_segs(h, s);
+    for (const Seg& g : s) SHIP(h, hipMemcpy(host + g.host, dev + g.dev, (size_t)g.len * 4, hipMemcpyDeviceToHost));
+    return DRIL_OK;
+}
+int round4(int x) { return (x + 3) & ~3; }
+
+}  // namespace
+
+// =================================================================================================================
+// exported entry points (include/dril_sac.h)
+// =================================================================================================================
+DRIL_EXPORT int32_t dril_sac_config_default(dril_sac_config* c, int32_t env_kind) {
+    if (!c || env_kind != DRIL_ENV_PENDULUM) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "SAC needs a Box action space (sac.jl:74): env_kind must be DRIL_ENV_PENDULUM");
+    memset(c, 0, sizeof(*c));
+    c->abi_version = DRIL_SAC_ABI_VERSION; c->env_kind = env_kind; c->n_envs = 1; c->episode_len = 200;
+    c->hidden1 = 512; c->hidden2 = 512; c->activation = 1;
+    c->buffer_capacity = 1000000; c->start_steps = 100; c->batch_size = 256; c->tau = 0.005f; c->gamma = 0.99f;
+    c->train_freq = 1; c->gradient_steps = 1; c->target_update_interval = 1;
+    c->auto_ent_coef = 1; c->ent_coef_init = 1.0f; c->auto_target_entropy = 1; c->target_entropy = 0.0f;
+    c->learning_rate = 3.0e-4f; c->adam_beta1 = 0.9f; c->adam_beta2 = 0.999f; c->adam_eps = 1.0e-8f;
+    c->seed = 42;
+    return DRIL_OK;
+}
+
+DRIL_EXPORT int32_t dril_sac_destroy(dril_sac_handle* h) {
+    if (!h) return DRIL_OK;
+    if (h->stream) hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->target, h->g_critic, h->g_actor, h->sc, h->stats, h->stats_out, h->ssq_c, h->ssq_a, h->ssq_ls,
+                    h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->obs_cur, h->obs_nxt, h->e_rew, h->e_tobs, h->e_raw, h->e_envact, h->e_term, h->e_trunc,
+                    h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc, h->xa, h->ah1, h->ah2, h->mu, h->xq, h->xq_next, h->xq_pi,
+                    h->qh1, h->qh2, h->th1, h->th2, h->q_cur, h->q_next, h->q_pi, h->dq, h->dz2, h->dz1, h->dxq, h->dmu, h->b_rew, h->b_ne, h->b_nn, h->b_np,
+                    h->b_nlp, h->a_pi, h->g_pi, h->lp_pi, h->b_term, h->collect_noise, h->inj_idx, h->inj_ne, h->inj_nn, h->inj_np, h->s_in, h->s_act, h->s_noise, h->s_out, h->s_out2};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (h->ev_a) hipEventDestroy(h->ev_a); if (h->ev_b) hipEventDestroy(h->ev_b);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return DRIL_OK;
+}
+
+DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle** out) {
+    if (!cfg || !out) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "null config / out pointer");
+    if (cfg->abi_version != DRIL_SAC_ABI_VERSION) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "dril_sac_config.abi_version mismatch");
+    if (cfg->env_kind != DRIL_ENV_PENDULUM) return sfail(nullptr, DRIL_ERR_UNSUPPORTED, "SAC needs a Box action space (sac.jl:74): only DRIL_ENV_PENDULUM");
+    if (cfg->n_envs <= 0 || cfg->episode_len <= 0 || cfg->batch_size <= 0 || cfg->buffer_capacity < cfg->n_envs || cfg->train_freq <= 0 || cfg->target_update_interval <= 0)
+        return sfail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs, episode_len, batch_size, train_freq, target_update_interval must be positive and buffer_capacity >= n_envs");
+    if (cfg->hidden1 <= 0 || cfg->hidden2 <= 0 || cfg->hidden1 % 4 || cfg->hidden2 % 4) return sfail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden dims must be positive multiples of 4");
+    if (cfg->activation != 0 && cfg->activation != 1) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "activation: 0 tanh, 1 relu");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sfail(nullptr, DRIL_ERR_HIP, "no HIP device: libdril_hip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "device ordinal out of range");
+    dril_sac_handle* h = new dril_sac_handle(); h->cfg = *cfg;
+#define CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_sac_destroy(h); return sfail(nullptr, DRIL_ERR_HIP, m); } } while (0)
+    CHK(hipSetDevice(cfg->device));
+    CHK(hipStreamCreate(&h->stream));
+    const int D = h->D = 3, A = h->A = 1, S = h->S = 2, H1 = h->H1 = cfg->hidden1, H2 = h->H2 = cfg->hidden2, E = cfg->n_envs, B = cfg->batch_size, W = D + A;
+    h->Pa = D * H1 + H1 + H1 * H2 + H2 + H2 * A + A; h->Pq = W * H1 + H1 + H1 * H2 + H2 + H2 + 1; h->P = h->Pa + 2 * h->Pq + A;
+    h->actor = net_off(0, D, H1, H2, A); h->Pqd = round4(h->Pq); h->q0 = net_off(round4(h->actor.end), W, H1, H2, 1);
+    h->log_std_off = h->q0.w1 + 2 * h->Pqd; h->Pd = round4(h->log_std_off + A);
+    h->nq = B; h->nmax = std::max(E, 2 * B);
+    h->target_entropy = cfg->auto_target_entropy ? -(float)A : cfg->target_entropy;
+    CHK(smalloc(&h->params, h->Pd)); CHK(smalloc(&h->adam_m, h->Pd)); CHK(smalloc(&h->adam_v, h->Pd)); CHK(smalloc(&h->target, 2 * (size_t)h->Pqd));
+    CHK(smalloc(&h->g_critic, h->Pd)); CHK(smalloc(&h->g_actor, h->Pd)); CHK(smalloc(&h->sc, 1)); CHK(smalloc(&h->stats, 8));
+    h->adam_blocks_c = std::min(1024, (2 * h->Pqd + 255) / 256); h->adam_blocks_a = std::min(1024, (h->actor.end + 255) / 256);
+    CHK(smalloc(&h->ssq_c, h->adam_blocks_c)); CHK(smalloc(&h->ssq_a, h->adam_blocks_a)); CHK(smalloc(&h->ssq_ls, 1));
+    CHK(smalloc(&h->state, (size_t)E * S)); CHK(smalloc(&h->step_count, E)); CHK(smalloc(&h->episode, E)); CHK(smalloc(&h->gstep, E)); CHK(smalloc(&h->disc_returns, E));
+    CHK(smalloc(&h->obs_cur, (size_t)E * D)); CHK(smalloc(&h->obs_nxt, (size_t)E * D)); CHK(smalloc(&h->e_rew, E)); CHK(smalloc(&h->e_tobs, (size_t)E * D));
+    CHK(smalloc(&h->e_raw, (size_t)E * A)); CHK(smalloc(&h->e_envact, (size_t)E * A)); CHK(smalloc(&h->e_term, E)); CHK(smalloc(&h->e_trunc, E));
+    h->cap = cfg->buffer_capacity;
+    CHK(smalloc(&h->rb_obs, (size_t)h->cap * D)); CHK(smalloc(&h->rb_next, (size_t)h->cap * D)); CHK(smalloc(&h->rb_act, (size_t)h->cap * A));
+    CHK(smalloc(&h->rb_rew, (size_t)h->cap)); CHK(smalloc(&h->rb_term, (size_t)h->cap)); CHK(smalloc(&h->rb_trunc, (size_t)h->cap));
+    const size_t nm = h->nmax, nq = h->nq;
+    CHK(smalloc(&h->xa, nm * D)); CHK(smalloc(&h->ah1, nm * H1)); CHK(smalloc(&h->ah2, nm * H2)); CHK(smalloc(&h->mu, nm * A));
+    CHK(smalloc(&h->xq, nq * W)); CHK(smalloc(&h->xq_next, nq * W)); CHK(smalloc(&h->xq_pi, nq * W));
+    CHK(smalloc(&h->qh1, 2 * nq * H1)); CHK(smalloc(&h->qh2, 2 * nq * H2)); CHK(smalloc(&h->th1, 2 * nq * H1)); CHK(smalloc(&h->th2, 2 * nq * H2));
+    CHK(smalloc(&h->q_cur, 2 * nq)); CHK(smalloc(&h->q_next, 2 * nq)); CHK(smalloc(&h->q_pi, 2 * nq)); CHK(smalloc(&h->dq, 2 * nq));
+    CHK(smalloc(&h->dz2, 2 * nq * H2)); CHK(smalloc(&h->dz1, 2 * nq * H1)); CHK(smalloc(&h->dxq, 2 * nq * W)); CHK(smalloc(&h->dmu, nq * A));
+    CHK(smalloc(&h->b_rew, nq)); CHK(smalloc(&h->b_ne, nq * A)); CHK(smalloc(&h->b_nn, nq * A)); CHK(smalloc(&h->b_np, nq * A)); CHK(smalloc(&h->b_nlp, nq));
+    CHK(smalloc(&h->a_pi, nq * A)); CHK(smalloc(&h->g_pi, nq * A)); CHK(smalloc(&h->lp_pi, nq)); CHK(smalloc(&h->b_term, nq));
+    CHK(smalloc(&h->s_in, nm * D)); CHK(smalloc(&h->s_act, nm * A)); CHK(smalloc(&h->s_noise, nm * A)); CHK(smalloc(&h->s_out, nm * A)); CHK(smalloc(&h->s_out2, nm * A));
+    CHK(hipEventCreate(&h->ev_a)); CHK(hipEventCreate(&h->ev_b));
+#undef CHK
+    const SacScalars sc0{logf(cfg->ent_coef_init), 0.f, 0.f, cfg->ent_coef_init};                   // init_entropy_coefficient sac.jl:207-213
+    if (hipMemcpy(h->sc, &sc0, sizeof(sc0), hipMemcpyHostToDevice) != hipSuccess) { dril_sac_destroy(h); return sfail(nullptr, DRIL_ERR_HIP, "hipMemcpy(log_ent_coef)"); }
+    reset_optimizer(h);
+    *out = h;
+    return DRIL_OK;
+}
+DRIL_EXPORT const char* dril_sac_last_error(const dril_sac_handle* h) { return h ? h->err.c_str() : g_sac_create_error.c_str(); }
+DRIL_EXPORT int32_t dril_sac_obs_dim(const dril_sac_handle* h) { return h ? h->D : 0; }
+DRIL_EXPORT int32_t dril_sac_action_dim(const dril_sac_handle* h) { return h ? h->A : 0; }
+DRIL_EXPORT int64_t dril_sac_param_count(const dril_sac_handle* h) { return h ? h->P : 0; }
+DRIL_EXPORT int64_t dril_sac_q_param_count(const dril_sac_handle* h) { return h ? h->Pq : 0; }
+
+DRIL_EXPORT int32_t dril_sac_set_params(dril_sac_handle* h, const float* flat, size_t n) {
+    SNEED(h); if (!flat || n != (size_t)h->P) return sfail(h, DRIL_ERR_INVALID_ARG, "dril_sac_set_params: n must equal dril_sac_param_count");
+    SDO(params_to_device(h, h->params, flat));
+    SHIP(h, hipMemcpy(h->target, h->params + h->q0.w1, 2 * (size_t)h->Pqd * 4, hipMemcpyDeviceToDevice));   // copy_critic_parameters sac.jl:172,191-197
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_sac_get_params(dril_sac_handle* h, float* flat, size_t n) {
+    SNEED(h); if (!flat || n != (size_t)h->P) return sfail(h, DRIL_ERR_INVALID_ARG, "dril_sac_get_params: n must equal dril_sac_param_count");
+    return params_from_device(h, flat, h->params);
+}
+DRIL_EXPORT int32_t dril_sac_get_target_params(dril_sac_handle* h, float* flat, size_t n) {
+    SNEED(h); if (!flat || n != 2 * (size_t)h->Pq) return sfail(h, DRIL_ERR_INVALID_ARG, "target parameters: n must equal 2 * dril_sac_q_param_count");
+    SDO(ssync(h));
+    for (int k = 0; k < 2; ++k) SHIP(h, hipMemcpy(flat + (size_t)k * h->Pq, h->target + (size_t)k * h->Pqd, (size_t)h->Pq * 4, hipMemcpyDeviceToHost));
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_sac_set_target_params(dril_sac_handle* h, const float* flat, size_t n) {
+    SNEED(h); if (!flat || n != 2 * (size_t)h->Pq) return sfail(h, DRIL_ERR_INVALID_ARG, "target parameters: n must equal 2 * dril_sac_q_param_count");
+    SDO(ssync(h));
+    for (int k = 0; k < 2; ++k) SHIP(h, hipMemcpy(h->target + (size_t)k * h->Pqd, flat + (size_t)k * h->Pq, (size_t)h->Pq * 4, hipMemcpyHostToDevice));
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_sac_get_log_ent_coef(dril_sac_handle* h, float* v) {
+    SNEED(h); if (!v) return sfail(h, DRIL_ERR_INVALID_ARG, "null out pointer");
+    SDO(ssync(h)); SacScalars sc; SHIP(h, hipMemcpy(&sc, h->sc, sizeof(sc), hipMemcpyDeviceToHost)); *v = sc.log_ent; return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_sac_set_log_ent_coef(dril_sac_handle* h, float v) {
+    SNEED(h); SDO(ssync(h)); SacScalars sc; SHIP(h, hipMemcpy(&sc, h->sc, sizeof(sc), hipMemcpyDeviceToHost));
+    sc.log_ent = v; sc.alpha = expf(v); SHIP(h, hipMemcpy(h->sc, &sc, sizeof(sc), hipMemcpyHostToDevice)); return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_sac_reset_optimizer(dril_sac_handle* h) {
+    SNEED(h); SDO(ssync(h));
+    SHIP(h, hipMemset(h->adam_m, 0, (size_t)h->Pd * 4)); SHIP(h, hipMemset(h->adam_v, 0, (size_t)h->Pd * 4));
+    SacScalars sc; SHIP(h, hipMemcpy(&sc, h->sc, sizeof(sc), hipMemcpyDeviceToHost)); sc.ent_m = sc.ent_v = 0.f;
+    SHIP(h, hipMemcpy(h->sc, &sc, sizeof(sc), hipMemcpyHostToDevice));
+    reset_optimizer(h); return DRIL_OK;
+}
+
+DRIL_EXPORT int32_t dril_sac_env_reset(dril_sac_handle* h, uint64_t seed) {
+    SNEED(h);
+    h->env_seed0 = seed;
+    SHIP(h, launch_env_reset(h->cfg.env_kind, h->cfg.n_envs, seed, h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->stream));
+    h->env_ready = true; h->obs_valid = false;
+    return ssync(h);
+}
+DRIL_EXPORT int32_t dril_sac_env_observe(dril_sac_handle* h, float* host_obs) {
+    SNEED(h); if (!host_obs) return sfail(h, DRIL_ERR_INVALID_ARG, "null observation buffer");
+    SDO(ensure_obs(h)); SDO(ssync(h));
+    SHIP(h, hipMemcpy(host_obs, h->obs_cur, (size_t)h->cfg.n_envs * h->D * 4, hipMemcpyDeviceToHost));
+    return DRIL_OK;
+}
+
+namespace {
+// actor means of a host batch chunk already staged in h->xa, then the squashed sample / mode
+int actor_chunk(dril_sac_handle* h, const float* obs, const float* noise, int n, int deterministic, int64_t chunk_id) {
+    SHIP(h, hipMemcpyAsync(h->xa, obs, (size_t)n * h->D * 4, hipMemcpyHostToDevice, h->stream));
+    if (!deterministic) {
+        if (noise) SHIP(h, hipMemcpyAsync(h->s_noise, noise, (size_t)n * h->A * 4, hipMemcpyHostToDevice, h->stream));
+        else {
+            const SacRng rng{h->cfg.seed ^ 0x0b5e55edull, h->aux_counter++};
+            hipLaunchKernelGGL(sac_noise_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, h->A, rng, h->s_noise);
+        }
+    }
+    (void)chunk_id;
+    return net_forward(h, h->params, h->actor, 0, h->D, h->A, h->xa, h->D, 0, n, actor_bufs(h), 1);
+}
+}  // namespace
+
+DRIL_EXPORT int32_t dril_sac_action_log_prob(dril_sac_handle* h, const float* obs, int64_t batch, const float* noise, float* actions, float* logp) {
+    SNEED(h); if (!obs || batch <= 0) return sfail(h, DRIL_ERR_INVALID_ARG, "dril_sac_action_log_prob: obs / batch");
+    for (int64_t o = 0; o < batch; o += h->nmax) {
+        const int n = (int)std::min<int64_t>(h->nmax, batch - o);
+        SDO(actor_chunk(h, obs + o * h->D, noise ? noise + o * h->A : nullptr, n, 0, o));
+        hipLaunchKernelGGL(sac_squash_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, h->A, h->mu, h->params + h->log_std_off, h->s_noise, 0,
+                           -2.0f, 2.0f, h->s_out, h->s_out2, (float*)nullptr);
+        SDO(ssync(h));
+        if (actions) SHIP(h, hipMemcpy(actions + o * h->A, h->s_out, (size_t)n * h->A * 4, hipMemcpyDeviceToHost));
+        if (logp) SHIP(h, hipMemcpy(logp + o, h->s_out2, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_sac_predict_actions(dril_sac_handle* h, const float* obs, int64_t batch, int32_t deterministic, const float* noise, float* raw, float* env) {
+    SNEED(h); if (!obs || batch <= 0) return sfail(h, DRIL_ERR_INVALID_ARG, "dril_sac_predict_actions: obs / batch");
+    for (int64_t o = 0; o < batch; o += h->nmax) {
+        const int n = (int)std::min<int64_t>(h->nmax, batch - o);
+        SDO(actor_chunk(h, obs + o * h->D, noise ? noise + o * h->A : nullptr, n, deterministic, o));
+        hipLaunchKernelGGL(sac_squash_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, h->A, h->mu, h->params + h->log_std_off, h->s_noise, deterministic,
+                           -2.0f, 2.0f, h->s_out, (float*)nullptr, h->s_out2);
+        SDO(ssync(h));
+        if (raw) SHIP(h, hipMemcpy(raw + o * h->A, h->s_out, (size_t)n * h->A * 4, hipMemcpyDeviceToHost));
+        if (env) SHIP(h, hipMemcpy(env + o * h->A, h->s_out2, (size_t)n * h->A * 4, hipMemcpyDeviceToHost));
+    }
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_sac_predict_q(dril_sac_handle* h, const float* obs, const float* actions, int64_t batch, int32_t use_target, float* q) {
+    SNEED(h); if (!obs || !actions || !q || batch <= 0) return sfail(h, DRIL_ERR_INVALID_ARG, "dril_sac_predict_q: null pointer / empty batch");
+    const int W = h->D + h->A;
+    std::vector<float> tmp(2 * (size_t)h->nq);
+    for (int64_t o = 0; o < batch; o += h->nq) {
+        const int n = (int)std::min<int64_t>(h->nq, batch - o);
+        SHIP(h, hipMemcpyAsync(h->s_in, obs + o * h->D, (size_t)n * h->D * 4, hipMemcpyHostToDevice, h->stream));
+        SHIP(h, hipMemcpyAsync(h->s_act, actions + o * h->A, (size_t)n * h->A * 4, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(sac_concat_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, h->D, h->A, h->s_in, h->s_act, h->xq_next);
+        if (use_target) SDO(net_forward(h, h->target, net_off(0, W, h->H1, h->H2, 1), h->Pqd, W, 1, h->xq_next, W, 0, n, q_bufs(h, h->th1, h->th2, h->q_next), 2));
+        else SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_next, W, 0, n, q_bufs(h, h->th1, h->th2, h->q_next), 2));
+        SDO(ssync(h));
+        SHIP(h, hipMemcpy(tmp.data(), h->q_next, tmp.size() * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) { q[(o + i) * 2] = tmp[i]; q[(o + i) * 2 + 1] = tmp[(size_t)h->nq + i]; }       // vcat of the critics: (2 x B)
+    }
+    return DRIL_OK;
+}
+
+DRIL_EXPORT int32_t dril_sac_debug_set_collect_noise(dril_sac_handle* h, const float* noise, size_t count) {
+    SNEED(h); SDO(ssync(h));
+    if (h->collect_noise) { hipFree(h->collect_noise); h->collect_noise = nullptr; h->collect_noise_count = 0; }
+    if (!noise || !count) return DRIL_OK;
+    SHIP(h, smalloc(&h->collect_noise, count)); SHIP(h, hipMemcpy(h->collect_noise, noise, count * 4, hipMemcpyHostToDevice)); h->collect_noise_count = count;
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_sac_collect_rollout(dril_sac_handle* h, int32_t n_steps, int32_t use_random_actions, double* fps) {
+    SNEED(h); return collect(h, n_steps, use_random_actions != 0, fps);
+}
+
+DRIL_EXPORT int64_t dril_sac_replay_size(const dril_sac_handle* h) { return h ? h->size : 0; }
+DRIL_EXPORT int64_t dril_sac_replay_capacity(const dril_sac_handle* h) { return h ? h->cap : 0; }
+DRIL_EXPORT int32_t dril_sac_replay_copy_out(dril_sac_handle* h, int32_t which, void* host, size_t bytes) {
+    SNEED(h);
+    size_t w; const char* src;
+    switch (which) {
+        case DRIL_RB_OBSERVATIONS: w = (size_t)h->D * 4; src = (const char*)h->rb_obs; break;
+        case DRIL_RB_NEXT_OBSERVATIONS: w = (size_t)h->D * 4; src = (const char*)h->rb_next; break;
+        case DRIL_RB_ACTIONS: w = (size_t)h->A * 4; src = (const char*)h->rb_act; break;
+        case DRIL_RB_REWARDS: w = 4; src = (const char*)h->rb_rew; break;
+        case DRIL_RB_TERMINATED: w = 1; src = (const char*)h->rb_term; break;
+        case DRIL_RB_TRUNCATED: w = 1; src = (const char*)h->rb_trunc; break;
+        default: return sfail(h, DRIL_ERR_INVALID_ARG, "unknown replay field");
+    }
+    if (!host || bytes != w * (size_t)h->size) return sfail(h, DRIL_ERR_INVALID_ARG, "dril_sac_replay_copy_out: bytes must equal replay_size * element size");
+    SDO(ssync(h));
+    const long long first = std::min(h->size, h->cap - h->head);                                  // logical 0.. = [head, cap) then [0, ...)
+    if (first > 0) SHIP(h, hipMemcpy(host, src + (size_t)h->head * w, (size_t)first * w, hipMemcpyDeviceToHost));
+    if (h->size > first) SHIP(h, hipMemcpy((char*)host + (size_t)first * w, src, (size_t)(h->size - first) * w, hipMemcpyDeviceToHost));
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_sac_replay_fill(dril_sac_handle* h, int64_t count, const float* obs, const float* actions, const float* rewards,
+                                         const uint8_t* terminated, const uint8_t* truncated, const float* next_obs) {
+    SNEED(h); if (count <= 0 || !obs || !actions || !rewards || !terminated || !next_obs) return sfail(h, DRIL_ERR_INVALID_ARG, "dril_sac_replay_fill: null pointer / empty");
+    SDO(ssync(h));
+    const int64_t skip = count > h->cap ? count - h->cap : 0, n = count - skip;                   // pushes beyond the capacity overwrite the oldest
+    SHIP(h, hipMemcpy(h->rb_obs, obs + skip * h->D, (size_t)n * h->D * 4, hipMemcpyHostToDevice));
+    SHIP(h, hipMemcpy(h->rb_next, next_obs + skip * h->D, (size_t)n * h->D * 4, hipMemcpyHostToDevice));
+    SHIP(h, hipMemcpy(h->rb_act, actions + skip * h->A, (size_t)n * h->A * 4, hipMemcpyHostToDevice));
+    SHIP(h, hipMemcpy(h->rb_rew, rewards + skip, (size_t)n * 4, hipMemcpyHostToDevice));
+    SHIP(h, hipMemcpy(h->rb_term, terminated + skip, (size_t)n, hipMemcpyHostToDevice));
+    if (truncated) SHIP(h, hipMemcpy(h->rb_trunc, truncated + skip, (size_t)n, hipMemcpyHostToDevice)); else SHIP(h, hipMemset(h->rb_trunc, 0, (size_t)n));
+    h->head = 0; h->size = n;
+    return DRIL_OK;
+}
+
+DRIL_EXPORT int32_t dril_sac_debug_set_batches(dril_sac_handle* h, int32_t n_updates, const int64_t* idx, const float* ne, const float* nn, const float* np) {
+    SNEED(h); SDO(ssync(h));
+    clear_injected(h);
+    if (n_updates <= 0) return DRIL_OK;
+    const size_t nb = (size_t)n_updates * h->cfg.batch_size, na = nb * h->A;
+    if (idx) {
+        for (size_t i = 0; i < nb; ++i) if (idx[i] < 0 || idx[i] >= h->size) return sfail(h, DRIL_ERR_INVALID_ARG, "injected replay index out of range");
+        SHIP(h, smalloc(&h->inj_idx, nb)); SHIP(h, hipMemcpy(h->inj_idx, idx, nb * 8, hipMemcpyHostToDevice));
+    }
+    if (ne) { SHIP(h, smalloc(&h->inj_ne, na)); SHIP(h, hipMemcpy(h->inj_ne, ne, na * 4, hipMemcpyHostToDevice)); }
+    if (nn) { SHIP(h, smalloc(&h->inj_nn, na)); SHIP(h, hipMemcpy(h->inj_nn, nn, na * 4, hipMemcpyHostToDevice)); }
+    if (np) { SHIP(h, smalloc(&h->inj_np, na)); SHIP(h, hipMemcpy(h->inj_np, np, na * 4, hipMemcpyHostToDevice)); }
+    h->inj_updates = n_updates;
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_sac_update(dril_sac_handle* h, int32_t n_updates, dril_sac_stats* out) {
+    SNEED(h); if (n_updates <= 0) return sfail(h, DRIL_ERR_INVALID_ARG, "n_updates must be positive");
+    if (h->inj_updates && h->inj_updates != n_updates) return sfail(h, DRIL_ERR_INVALID_ARG, "injected batches were set for a different n_updates");
+    const int rc = run_updates(h, n_updates, h->inj_updates != 0, out);
+    clear_injected(h);
+    return rc;
+}
+DRIL_EXPORT int32_t dril_sac_get_last_grads(dril_sac_handle* h, float* gc, float* ga, size_t n) {
+    SNEED(h); if (n != (size_t)h->P) return sfail(h, DRIL_ERR_INVALID_ARG, "dril_sac_get_last_grads: n must equal dril_sac_param_count");
+    if (gc) { memset(gc, 0, n * 4); SDO(ssync(h));
+        for (int k = 0; k < 2; ++k) SHIP(h, hipMemcpy(gc + h->Pa + (size_t)k * h->Pq, h->g_critic + h->q0.w1 + (size_t)k * h->Pqd, (size_t)h->Pq * 4, hipMemcpyDeviceToHost)); }
+    if (ga) { memset(ga, 0, n * 4); SDO(ssync(h));
+        SHIP(h, hipMemcpy(ga, h->g_actor, (size_t)h->Pa * 4, hipMemcpyDeviceToHost));
+        SHIP(h, hipMemcpy(ga + h->Pa + 2 * (size_t)h->Pq, h->g_actor + h->log_std_off, (size_t)h->A * 4, hipMemcpyDeviceToHost)); }
+    return DRIL_OK;
+}
+
+DRIL_EXPORT int32_t dril_sac_train(dril_sac_handle* h, int64_t max_steps, dril_sac_stats* stats, int64_t stats_capacity, int64_t* n_updates_done,
+                                   double* fps, int64_t fps_capacity, int32_t* iterations_done, int64_t* total_steps) {
+    SNEED(h);
+    const int64_t E = h->cfg.n_envs, tf = h->cfg.train_freq;
+    const int64_t total_start = h->cfg.start_steps > 0 ? h->cfg.start_steps : tf * E;            // sac.jl:436
+    const int64_t adjusted = std::max<int64_t>(1, total_start / E) * E;                           // :437
+    int64_t n_steps = adjusted / E;                                                               // :438
+    const int64_t iterations = (max_steps - adjusted) / (tf * E) + 1;                             // :443 (div truncates toward zero, as in Julia)
+    const int64_t total = n_steps * E + tf * E * (iterations - 1);                                // :445
+    const int64_t n_upd = h->cfg.gradient_steps == -1 ? tf * E : h->cfg.gradient_steps;           // get_gradient_steps :59-65
+    int64_t done = 0; int64_t it = 0;
+    for (; it < iterations; ++it) {
+        double f = 0;
+        SDO(collect(h, (int)n_steps, it == 0 && h->cfg.start_steps > 0, &f));                     // :485-489
+        if (fps && it < fps_capacity) fps[it] = f;
+        n_steps = tf;                                                                             // :511
+        if (n_upd > 0) {
+            const int64_t room = stats ? std::max<int64_t>(0, std::min<int64_t>(n_upd, stats_capacity - done)) : 0;
+            std::vector<dril_sac_stats> tmp((size_t)n_upd);
+            SDO(run_updates(h, (int)n_upd, false, tmp.data()));                                   // :514-531
+            for (int64_t k = 0; k < room; ++k) stats[done + k] = tmp[(size_t)k];
+            done += n_upd;
+        }
+    }
+    if (n_updates_done) *n_updates_done = done;
+    if (iterations_done) *iterations_done = (int32_t)std::max<int64_t>(0, it);
+    if (total_steps) *total_steps = it > 0 ? total : 0;
+    return DRIL_OK;
+}
+
+DRIL_EXPORT int32_t dril_sac_profile_get(dril_sac_handle* h, double* collect_ms, int64_t* collect_steps, double* update_ms, int64_t* updates) {
+    SNEED(h);
+    if (collect_ms) *collect_ms = h->collect_ms; if (collect_steps) *collect_steps = h->collect_steps;
+    if (update_ms) *update_ms = h->update_ms; if (updates) *updates = h->updates;
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_sac_profile_reset(dril_sac_handle* h) { SNEED(h); h->collect_ms = h->update_ms = 0; h->collect_steps = h->updates = 0; return DRIL_OK; }

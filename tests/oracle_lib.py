@@ -38,8 +38,8 @@ def host_threads() -> int:
 
 
 def ensure_built():
-    src = ROOT / "oracle" / "dril_oracle.c"
-    if not SO.exists() or SO.stat().st_mtime < src.stat().st_mtime:
+    srcs = [ROOT / "oracle" / "dril_oracle.c", ROOT / "oracle" / "dril_sac_oracle.c", ROOT / "include" / "dril_hip.h", ROOT / "include" / "dril_sac.h"]
+    if not SO.exists() or SO.stat().st_mtime < max(p.stat().st_mtime for p in srcs):
         subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True)
 
 
@@ -279,3 +279,15 @@ class Oracle:
         oc, rc = C.c_int64(), C.c_int64(); rm, rv = C.c_float(), C.c_float()
         self.L.orc_norm_get_stats(self._h, _p(om), _p(ov), C.byref(oc), C.byref(rm), C.byref(rv), C.byref(rc))
         return om, ov, oc.value, rm.value, rv.value, rc.value
+
+
+def sac_oracle(cfg):
+    """the SAC oracle behind the product's own typed wrapper (dril.jl_amd/sac.py): same signatures, prefix orc_sac_"""
+    L = lib()
+    L.orc_squashed_logpdf.restype = C.c_float
+    L.orc_squashed_logpdf.argtypes = [_P, _P, _P, C.c_int]
+    L.orc_polyak_update.restype = None
+    L.orc_polyak_update.argtypes = [_P, _P, C.c_size_t, C.c_float]
+    L.orc_sac_schedule.restype = None
+    L.orc_sac_schedule.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.POINTER(C.c_int64)] * 4
+    return _pkg.SacHandle(cfg, lib=L, prefix="orc_sac_")

@@ -13,7 +13,7 @@ ROOT = Path(__file__).resolve().parents[1]
 def test_library_exports_every_declared_symbol(pkg):
     so = ROOT / "dril.jl_amd" / "csrc" / "libdril_hip.so"
     assert so.exists(), "build with __graft_entry__.build()"
-    header = (ROOT / "include" / "dril_hip.h").read_text()
+    header = "".join(p.read_text() for p in sorted((ROOT / "include").glob("*.h")))      # dril_hip.h + dril_sac.h
     declared = set(re.findall(r"\b(dril_[a-z0-9_]+)\s*\(", header))
     assert declared == set(pkg._capi.EXPORTED_SYMBOLS)          # the ctypes table covers the whole header
     lib = pkg._capi.load_library()                               # types every entry point; AttributeError if one is missing

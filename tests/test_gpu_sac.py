@@ -1,0 +1,229 @@
+"""GPU (-m gpu): the SAC path (include/dril_sac.h) through the C ABI vs the CPU oracle on the same inputs.
+Both are driven through the same typed wrapper (dril.jl_amd/sac.py) — the product with prefix dril_sac_, the oracle with orc_sac_.
+Tolerances (fp32 arithmetic on both sides; the device contracts with fp32 MFMA in a different summation order):
+  layer calls (actions, log-probs, Q)     rtol 2e-5 / atol 2e-5
+  losses                                  rel 1e-4   (BASELINE.json north_star's loss tolerance)
+  gradients / parameters after k steps    rtol 2e-4 / atol 2e-6
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(pkg, E=8, hidden=(32, 32), B=16, cap=4096, act="relu", seed=7, max_steps=200, **alg_kw):
+    env = pkg.PendulumEnv(max_steps=max_steps)
+    alg = pkg.SAC(batch_size=B, buffer_capacity=cap, **alg_kw)
+    layer = pkg.SACLayer(env.observation_space(), env.action_space(), hidden_dims=hidden, activation=act)
+    cfg = pkg.make_sac_config(env, E, alg, layer, seed=seed)
+    return pkg.SacHandle(cfg), O.sac_oracle(cfg), layer, alg
+
+
+def init_params(pkg, layer, seed=0, scale_out=30.0):
+    ps = layer.initialparameters(np.random.default_rng(seed))
+    ps["actor_head"]["layer_3"]["weight"] *= scale_out
+    rng = np.random.default_rng(seed + 1)
+    for head in (ps["actor_head"], ps["critic_head"]["layer_1"], ps["critic_head"]["layer_2"]):
+        for l in head.values():
+            l["bias"] = rng.normal(0, 0.1, l["bias"].shape).astype(np.float32)
+    ps["log_std"] = np.full_like(ps["log_std"], -1.0)
+    return pkg.sac_flatten_params(ps)
+
+
+def random_replay(rng, n, D=3, A=1, p_term=0.2):
+    obs, nobs = rng.uniform(-1, 1, (n, D)).astype(np.float32), rng.uniform(-1, 1, (n, D)).astype(np.float32)
+    act = np.tanh(rng.normal(0, 1, (n, A))).astype(np.float32)
+    rew = rng.normal(-1, 1, n).astype(np.float32)
+    term = (rng.uniform(size=n) < p_term).astype(np.uint8)
+    return obs, act, rew, term, np.zeros(n, np.uint8), nobs
+
+
+def close(a, b, rtol=2e-5, atol=2e-5):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("hidden,act", [((32, 32), "relu"), ((64, 32), "tanh"), ((512, 512), "relu")])
+def test_layer_calls_match_oracle(pkg, hidden, act):
+    """action_log_prob / predict_actions / predict_values(obs, actions) incl. target networks; batch sizes ragged w.r.t. the 32-wide tiles"""
+    h, o, layer, _ = make_pair(pkg, hidden=hidden, act=act, B=48)
+    flat = init_params(pkg, layer)
+    rng = np.random.default_rng(1)
+    for x in (h, o):
+        x.set_params(flat)
+        x.set_target_params((flat[layer.parameterlength() - 1 - 2 * layer.q_parameterlength():-1] * 0.9).astype(np.float32))
+    for n in (1, 37, 96, 257):
+        obs = rng.uniform(-1, 1, (n, 3)).astype(np.float32); nz = rng.normal(0, 1, (n, 1)).astype(np.float32)
+        act_in = np.tanh(rng.normal(0, 1, (n, 1))).astype(np.float32)
+        a1, l1 = h.action_log_prob(obs, nz); a2, l2 = o.action_log_prob(obs, nz)
+        close(a1, a2); close(l1, l2, rtol=1e-4, atol=1e-4)
+        for det in (False, True):
+            r1, e1 = h.predict_actions(obs, det, nz); r2, e2 = o.predict_actions(obs, det, nz)
+            close(r1, r2); close(e1, e2)
+        for tgt in (False, True):
+            close(h.predict_q(obs, act_in, tgt), o.predict_q(obs, act_in, tgt), rtol=5e-5, atol=5e-5)
+    assert h.predict_q(obs, act_in, True)[0, 0] != h.predict_q(obs, act_in, False)[0, 0]
+    # Philox noise when none is given: deterministic per handle state, finite, inside the squash range
+    a, lp = h.action_log_prob(obs)
+    assert np.isfinite(lp).all() and np.abs(a).max() <= 1.0
+
+
+@pytest.mark.parametrize("act,auto_ent,interval,hidden,B", [("relu", True, 1, (32, 32), 16), ("tanh", True, 2, (64, 32), 40),
+                                                            ("relu", False, 1, (32, 32), 16), ("relu", True, 1, (512, 512), 256)])
+def test_update_matches_oracle(pkg, act, auto_ent, interval, hidden, B):
+    """three consecutive update! steps with injected batches: losses, both gradients, parameters, targets, log_ent_coef"""
+    ent = pkg.AutoEntropyCoefficient(initial_value=0.7) if auto_ent else pkg.FixedEntropyCoefficient(0.3)
+    h, o, layer, alg = make_pair(pkg, hidden=hidden, B=B, act=act, ent_coef=ent, target_update_interval=interval, learning_rate=3e-3, tau=0.05)
+    flat = init_params(pkg, layer)
+    rng = np.random.default_rng(3)
+    rb = random_replay(rng, 300)
+    n_upd = 3
+    idx = rng.integers(0, 300, (n_upd, B))
+    nz = [rng.normal(0, 1, (n_upd, B, 1)).astype(np.float32) for _ in range(3)]
+    for x in (h, o):
+        x.set_params(flat); x.replay_fill(*rb)
+    for k in range(n_upd):
+        st = []
+        for x in (h, o):
+            x.set_batches(1, idx[k:k + 1], *[z[k:k + 1] for z in nz])
+            st.append(x.update(1)[0])
+        a, b = st
+        for f in ("critic_loss", "actor_loss", "mean_q_values", "grad_norm", "entropy_coefficient"):
+            assert getattr(a, f) == pytest.approx(getattr(b, f), rel=1e-4, abs=1e-5), (k, f)
+        assert a.has_entropy_loss == b.has_entropy_loss == int(auto_ent)
+        if auto_ent:
+            assert a.entropy_loss == pytest.approx(b.entropy_loss, rel=1e-4, abs=1e-5)
+        (gc1, ga1), (gc2, ga2) = h.last_grads(), o.last_grads()
+        scale_c, scale_a = np.abs(gc2).max(), np.abs(ga2).max()
+        close(gc1, gc2, rtol=2e-4, atol=2e-6 * max(1.0, scale_c)); close(ga1, ga2, rtol=2e-4, atol=2e-6 * max(1.0, scale_a))
+        n_actor = layer.parameterlength() - 1 - 2 * layer.q_parameterlength()
+        assert not gc1[:n_actor].any() and not gc1[-1:].any() and not ga1[n_actor:-1].any()       # test/test_sac.jl:282-284,337-341
+        close(h.get_params(), o.get_params(), rtol=2e-4, atol=5e-6)
+        close(h.get_target_params(), o.get_target_params(), rtol=2e-5, atol=2e-6)
+        assert h.get_log_ent_coef() == pytest.approx(o.get_log_ent_coef(), rel=1e-5, abs=1e-6)
+
+
+def test_many_updates_in_one_call_and_reset_optimizer(pkg):
+    h, o, layer, _ = make_pair(pkg, B=32, learning_rate=1e-3)
+    flat = init_params(pkg, layer)
+    rng = np.random.default_rng(9)
+    rb = random_replay(rng, 128)
+    idx = rng.integers(0, 128, (6, 32)); nz = [rng.normal(0, 1, (6, 32, 1)).astype(np.float32) for _ in range(3)]
+    for x in (h, o):
+        x.set_params(flat); x.replay_fill(*rb); x.set_batches(6, idx, *nz)
+    s1, s2 = h.update(6), o.update(6)
+    for a, b in zip(s1, s2):
+        assert a.critic_loss == pytest.approx(b.critic_loss, rel=2e-4) and a.actor_loss == pytest.approx(b.actor_loss, rel=2e-4, abs=1e-5)
+    close(h.get_params(), o.get_params(), rtol=5e-4, atol=1e-5)
+    for x in (h, o):
+        x.reset_optimizer(); x.set_params(flat); x.set_log_ent_coef(0.0); x.set_batches(1, idx[:1], *[z[:1] for z in nz])
+    a, b = h.update(1)[0], o.update(1)[0]
+    assert a.critic_loss == pytest.approx(s2[0].critic_loss, rel=1e-4) and b.critic_loss == pytest.approx(s2[0].critic_loss, rel=1e-6)
+    close(h.get_params(), o.get_params(), rtol=2e-4, atol=5e-6)
+
+
+def test_collect_matches_oracle(pkg):
+    """off_policy_collection.jl:28-96 with injected noise: the replay contents agree field by field, through a truncation and a ring wrap"""
+    E, L = 50, 5
+    h, o, layer, _ = make_pair(pkg, E=E, max_steps=L, cap=400)
+    flat = init_params(pkg, layer)
+    rng = np.random.default_rng(2)
+    for x in (h, o):
+        x.set_params(flat); x.env_reset(11)
+    close(h.env_observe(), o.env_observe(), rtol=1e-6, atol=1e-6)
+    u = rng.uniform(0, 1, (3, E, 1)).astype(np.float32); nz = rng.normal(0, 1, (7, E, 1)).astype(np.float32)
+    for x in (h, o):
+        x.set_collect_noise(u); x.collect_rollout(3, True)
+        x.set_collect_noise(nz); x.collect_rollout(7, False)                # 10 steps: two truncations, 500 pushes into 400 slots
+    assert h.replay_size() == o.replay_size() == 400
+    C = pkg._capi
+    for which in (C.RB_OBSERVATIONS, C.RB_NEXT_OBSERVATIONS, C.RB_ACTIONS, C.RB_REWARDS):
+        close(h.replay(which), o.replay(which), rtol=1e-4, atol=2e-5)
+    for which in (C.RB_TERMINATED, C.RB_TRUNCATED):
+        np.testing.assert_array_equal(h.replay(which), o.replay(which))
+    assert h.replay(C.RB_TRUNCATED).sum() == 2 * E
+    close(h.env_observe(), o.env_observe(), rtol=1e-4, atol=2e-5)
+    # un-injected noise: the env-keyed Philox stream; same uniforms / normals up to libm ulps
+    for x in (h, o):
+        x.collect_rollout(2, True); x.collect_rollout(2, False)
+    close(h.replay(C.RB_ACTIONS), o.replay(C.RB_ACTIONS), rtol=1e-3, atol=1e-4)
+    close(h.replay(C.RB_REWARDS), o.replay(C.RB_REWARDS), rtol=1e-3, atol=1e-3)
+
+
+def test_replay_fill_copy_out_and_errors(pkg):
+    h, _, layer, _ = make_pair(pkg, cap=64)
+    rng = np.random.default_rng(0)
+    rb = random_replay(rng, 100)                                            # 100 pushes into 64 slots: the last 64 survive
+    h.replay_fill(*rb)
+    assert h.replay_size() == 64
+    np.testing.assert_array_equal(h.replay(pkg._capi.RB_REWARDS), rb[2][36:])
+    np.testing.assert_array_equal(h.replay(pkg._capi.RB_NEXT_OBSERVATIONS), rb[5][36:])
+    with pytest.raises(pkg.DrilError):
+        h.set_batches(1, np.full((1, 16), 64))                              # index out of range
+    with pytest.raises(pkg.DrilError):
+        h.collect_rollout(1)                                                # env not reset
+    h2, _, _, _ = make_pair(pkg)
+    h2.set_params(init_params(pkg, layer))
+    with pytest.raises(pkg.DrilError):
+        h2.update(1)                                                        # empty replay buffer
+
+
+def test_train_loop_matches_oracle_statistically(pkg):
+    """train! sac.jl:414-549 with device Philox streams on both sides: identical schedule; losses track the oracle (noise differs by libm ulps,
+    so the comparison is on the first updates tightly and on the tail loosely)"""
+    E = 16
+    kw = dict(E=E, B=64, cap=4096, start_steps=128, train_freq=2, gradient_steps=2, learning_rate=1e-3)
+    h, o, layer, alg = make_pair(pkg, **kw)
+    flat = init_params(pkg, layer, scale_out=1.0)
+    res = []
+    for x in (h, o):
+        x.set_params(flat); x.env_reset(5)
+        res.append(x.train(128 + 10 * 2 * E))
+    (s1, f1, n1, i1, t1), (s2, f2, n2, i2, t2) = res
+    assert (n1, i1, t1) == (n2, i2, t2) == (22, 11, 128 + 20 * E)
+    assert h.replay_size() == o.replay_size() == t1
+    assert len(f1) == 11 and (f1 > 0).all()
+    assert s1[0].critic_loss == pytest.approx(s2[0].critic_loss, rel=1e-3)
+    assert s1[0].actor_loss == pytest.approx(s2[0].actor_loss, rel=1e-3, abs=1e-4)
+    a = np.array([[s.critic_loss, s.actor_loss, s.entropy_coefficient, s.mean_q_values] for s in s1])
+    b = np.array([[s.critic_loss, s.actor_loss, s.entropy_coefficient, s.mean_q_values] for s in s2])
+    assert np.isfinite(a).all()
+    np.testing.assert_allclose(a, b, rtol=0.05, atol=0.02)
+    close(h.get_params(), o.get_params(), rtol=5e-2, atol=2e-3)
+
+
+def test_host_mirror_and_config5_shape(pkg):
+    """SAC / SACLayer / SACAgent / ReplayBuffer / sac_train_ (the reference's user-facing surface) at BASELINE.json configs[4] shape:
+    Pendulum, 4096 envs, SACLayer [512, 512] relu, batch 256"""
+    env = pkg.DeviceParallelEnv(pkg.PendulumEnv(max_steps=200), 4096, seed=42)
+    alg = pkg.SAC(start_steps=4096 * 2, buffer_capacity=100_000)
+    layer = pkg.SACLayer(env.observation_space(), env.action_space())
+    agent = pkg.SACAgent(layer, alg, seed=1)
+    assert layer.parameterlength() == (3 * 512 + 512 + 512 * 512 + 512 + 512 + 1) + 2 * (4 * 512 + 512 + 512 * 512 + 512 + 512 + 1) + 1
+    before = pkg.sac_flatten_params(agent.parameters).copy()
+    agent, rb, stats, timer = pkg.sac_train_(agent, env, alg, 4096 * 2 + 30 * 4096)
+    assert len(rb) == 100_000 and rb.isfull()                               # 32 steps x 4096 envs pushed into 100 000 slots
+    assert len(stats["critic_losses"]) == 31 and agent.gradient_updates == 31 and agent.steps_taken == 32 * 4096
+    assert np.isfinite(stats["critic_losses"]).all() and np.isfinite(stats["actor_losses"]).all()
+    after = pkg.sac_flatten_params(agent.parameters)
+    assert np.isfinite(after).all() and not np.array_equal(before, after)
+    # log_std_init = -3: log-probs far above -target_entropy, so c > 0 and the coefficient climbs (sac.jl:326-330)
+    assert 1.0 < stats["entropy_coefficients"][-1] < 1.1
+    obs = rb.observations
+    np.testing.assert_allclose(np.hypot(obs[:, 0], obs[:, 1]), 1.0, rtol=1e-5)   # (cos, sin, theta_dot)
+    assert np.abs(rb.actions).max() <= 2.0
+
+
+def test_critic_learns_fixed_targets(pkg):
+    """learning signal: on a fixed replay with terminated transitions only (target = reward), the critic loss falls by > 10x"""
+    h, _, layer, _ = make_pair(pkg, hidden=(64, 64), B=128, learning_rate=3e-3, ent_coef=pkg.FixedEntropyCoefficient(0.01))
+    h.set_params(init_params(pkg, layer, scale_out=1.0))
+    rng = np.random.default_rng(4)
+    obs, act, _, _, trunc, nobs = random_replay(rng, 512)
+    rew = (obs[:, 0] * 2 - act[:, 0]).astype(np.float32)
+    h.replay_fill(obs, act, rew, np.ones(512, np.uint8), trunc, nobs)
+    losses = [s.critic_loss for s in h.update(300)]
+    assert losses[-1] < 0.1 * losses[0]
