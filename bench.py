@@ -62,8 +62,81 @@ def cpu_baseline(pkg, seed: int) -> dict:
             "rollout_only": 1.0 / per_step_roll}
 
 
+def sac_flops(D: int, A: int, H: int, B: int, E: int) -> tuple:
+    """ALGORITHMIC flops (2 x MACs of the dense layers; head math excluded) of one gradient step and one collection step.
+    update! (sac.jl:299-404): actor forward on obs and next obs (2B), target-Q forward (2 nets), Q forward + backward (3x forward, 2 nets),
+    Q forward + input-gradient backward on the actor's actions (2x forward, 2 nets), actor backward (2x forward)."""
+    fa = 2 * (D * H + H * H + H * A)            # actor forward / sample
+    fq = 2 * ((D + A) * H + H * H + H)          # one Q net forward / sample
+    upd = B * (2 * fa + 2 * fq + 2 * 3 * fq + 2 * 2 * fq + 2 * fa)
+    return upd, E * fa
+
+
+def main_sac(args) -> None:
+    """BASELINE.json configs[4]: SAC on Pendulum-v1, n_envs = 4096, SACLayer [512,512] relu, SAC() defaults (batch 256, train_freq 1,
+    gradient_steps 1).  One bench "step" = --sac-iters iterations of train!'s loop body (sac.jl:464-535): collect one env step over all
+    envs into the device replay ring, then one update!.  Single GPU (the path has one learner; N > 1 would be replicas)."""
+    pkg = g.load_package()
+    pkg._capi.load_library()
+    E, H, B = args.n_envs if args.n_envs != 65536 else 4096, args.hidden if args.hidden != 64 else 512, 256
+    env = pkg.PendulumEnv(max_steps=200)
+    alg = pkg.SAC(batch_size=B, buffer_capacity=1_000_000)
+    layer = pkg.SACLayer(env.observation_space(), env.action_space(), hidden_dims=(H, H))
+    cfg = pkg.make_sac_config(env, E, alg, layer, seed=42, profile_events=not args.no_events)
+    h = pkg.SacHandle(cfg)
+    flat = pkg.sac_flatten_params(layer.initialparameters(np.random.default_rng(42)))
+    h.set_params(flat); h.env_reset(42)
+    h.collect_rollout(max(1, alg.start_steps // E), True)          # train!'s first, random-action collection (sac.jl:436-440)
+    iters = args.sac_iters
+
+    # the loop body of train! without its per-iteration host bookkeeping: collect 1 step, 1 update (both enqueue-only until their sync)
+    def iteration():
+        h.collect_rollout(alg.train_freq, False)
+        h.update(pkg.get_gradient_steps(alg, alg.train_freq, E))
+
+    for _ in range(args.warmup * iters):
+        iteration()
+    h.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps * iters):
+        iteration()
+    dt = time.perf_counter() - t0
+    prof = h.profile()
+    n_it = args.steps * iters
+    f_upd, f_col = sac_flops(3, 1, H, B, E)
+    out = {"metric": "env-steps/s (SAC collect + update!) at n_envs=4096", "value": E * n_it / dt, "unit": "env-steps/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"Pendulum-v1 configs[4]: SAC, device-resident envs + replay ring, SACLayer hidden_dims=[{H},{H}] relu, batch {B}, "
+                                  f"train_freq 1, gradient_steps 1; one step = {iters} iterations of (1 env step x {E} envs, 1 update!)",
+                      "n_envs": E, "batch_size": B, "iterations_per_step": iters, "buffer_capacity": alg.buffer_capacity}}
+    if prof["updates"]:
+        u_ms, c_ms = prof["update_ms"] / prof["updates"], prof["collect_ms"] / max(1, prof["collect_steps"])
+        ach = (f_upd + f_col) / ((u_ms + c_ms) * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "kernel": "sac_gemm_kernel (all launches of one iteration; HIP events around update! and around the collection step)",
+                           "update_ms": u_ms, "collect_step_ms": c_ms, "flops_per_update": f_upd, "flops_per_collect_step": f_col}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_lib
+        ccfg = pkg.make_sac_config(env, E, pkg.SAC(batch_size=B, buffer_capacity=200_000), layer, seed=42)
+        o = oracle_lib.sac_oracle(ccfg)
+        o.set_params(flat); o.env_reset(42); o.collect_rollout(1, True)
+        n = 12
+        t0 = time.perf_counter()
+        for _ in range(n):
+            o.collect_rollout(1, False); o.update(1)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": E * n / dtc, "unit": "env-steps/s", "cores": int(oracle_lib.lib().orc_num_threads()), "kind": "port",
+                               "sample": f"C/OpenMP oracle: {n} iterations of (1 env step x {E} envs, 1 update! at batch {B}) in {dtc:.2f}s"}
+    print(json.dumps(out), flush=True)
+    h.close()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
+    ap.add_argument("--algo", choices=["ppo", "sac"], default="ppo", help="sac = BASELINE configs[4] (single GPU)")
+    ap.add_argument("--sac-iters", type=int, default=500, help="train! iterations per bench step in --algo sac")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
@@ -77,6 +150,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
+    if args.algo == "sac":
+        if args.gpus != 1:
+            raise SystemExit("--algo sac is a single-learner path: --gpus 1 only")
+        return main_sac(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -62,52 +62,85 @@ __device__ __forceinline__ void load_operand4(const float* __restrict__ P, int i
 
 // MFMA operand slots: A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]; step t of chunk q contracts k = 8q + 4h + t
 // for the half-wave h, so a k-major operand is one float4 per lane per chunk.  D: col = lane & 31, row = rowfn(r, lane >> 5).
-__global__ __launch_bounds__(256) void sac_gemm_kernel(GemmArgs g) {
-    __shared__ float red[3][16][64];
+// Two shapes of the same kernel:
+//   SPLIT  (few output tiles: the 256-sample contractions of update!) — the 8 waves of a workgroup split the chunks of ONE 32x32 tile
+//          and the partial tiles are summed through LDS in fixed wave order (deterministic);
+//   !SPLIT (many tiles: the 4096-env actor forward of the collection) — the 8 waves take 8 neighbouring column tiles of the same
+//          row tile (the weight operand is shared through L1) and each contracts the whole K.
+// Every wave first issues ALL operand loads of up to kGemmDepth chunks and only then runs their MFMAs (one exposed L2 round trip per
+// kGemmDepth chunks instead of one per chunk).  The epilogue goes through LDS so that global stores run along C's unit-stride axis
+// (m): a wave writes 2 x 128 contiguous bytes per instruction instead of 64 scattered words.
+constexpr int kGemmWaves = 8, kGemmDepth = 8, kRedStride = 65;
+__device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int mm, size_t ci, const float* __restrict__ bias, const float* __restrict__ aux) {
+    v *= g.alpha;
+    if (bias) v += bias[mm];
+    if (g.epi == EPI_RELU) v = v > 0.f ? v : 0.f;
+    else if (g.epi == EPI_TANH) v = tanhf(v);
+    else if (g.epi == EPI_MASK_RELU) v = aux[ci] > 0.f ? v : 0.f;
+    else if (g.epi == EPI_MASK_TANH) { const float y = aux[ci]; v *= 1.0f - y * y; }
+    return v;
+}
+template <bool SPLIT>
+__global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_kernel(GemmArgs g) {
+    __shared__ float red[kGemmWaves][16][kRedStride];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5, z = blockIdx.z;
     const float* __restrict__ A = g.A + (size_t)z * g.zA;
     const float* __restrict__ B = g.B + (size_t)z * g.zB;
-    const int m = blockIdx.x * 32 + c, n = blockIdx.y * 32 + c;
-    const int Q = (g.K + 7) >> 3, Qw = (Q + 3) >> 2, q0 = wave * Qw, q1 = min(Q, q0 + Qw);
+    const int tile_n = SPLIT ? (int)blockIdx.y : (int)blockIdx.y * kGemmWaves + wave;
+    const int m = blockIdx.x * 32 + c, n = tile_n * 32 + c;
+    const int Q = (g.K + 7) >> 3, Qw = SPLIT ? (Q + kGemmWaves - 1) / kGemmWaves : Q, q0 = SPLIT ? wave * Qw : 0, q1 = min(Q, q0 + Qw);
     const bool ones = g.ones_n && n == g.N - 1;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float a[4], b[4], an[4], bn[4];
-    auto loadB = [&](int k0, float (&v)[4]) {
-        if (ones) { for (int t = 0; t < 4; ++t) v[t] = k0 + t < g.K ? 1.f : 0.f; }
-        else load_operand4(B, n, g.N, g.sBn, g.sBk, k0, g.K, g.vecB, v);
-    };
-    if (q0 < q1) { load_operand4(A, m, g.M, g.sAm, g.sAk, 8 * q0 + 4 * h, g.K, g.vecA, a); loadB(8 * q0 + 4 * h, b); }
-    for (int q = q0; q < q1; ++q) {
-        if (q + 1 < q1) { load_operand4(A, m, g.M, g.sAm, g.sAk, 8 * (q + 1) + 4 * h, g.K, g.vecA, an); loadB(8 * (q + 1) + 4 * h, bn); }
+    for (int q = q0; q < q1; q += kGemmDepth) {
+        float a[kGemmDepth][4], b[kGemmDepth][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc = mfma32(a[t], b[t], acc);
+        for (int u = 0; u < kGemmDepth; ++u) {
+            const int k0 = 8 * (q + u) + 4 * h;
+            if (q + u < q1) {
+                load_operand4(A, m, g.M, g.sAm, g.sAk, k0, g.K, g.vecA, a[u]);
+                if (ones) { for (int t = 0; t < 4; ++t) b[u][t] = k0 + t < g.K ? 1.f : 0.f; }
+                else load_operand4(B, n, g.N, g.sBn, g.sBk, k0, g.K, g.vecB, b[u]);
+            }
+        }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { a[t] = an[t]; b[t] = bn[t]; }
+        for (int u = 0; u < kGemmDepth; ++u)
+            if (q + u < q1) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = mfma32(a[u][t], b[u][t], acc);
+            }
     }
-    if (wave) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
-    }
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
-    if (wave) return;
     float* __restrict__ C = g.C + (size_t)z * g.zC;
     const float* __restrict__ bias = g.bias ? g.bias + (size_t)z * g.zBias : nullptr;
     const float* __restrict__ aux = g.aux ? g.aux + (size_t)z * g.zAux : nullptr;
+    // element e of a 32x32 tile: m_local = e & 31 (fastest, C's unit stride), n_local = e >> 5; it sits in register rr of lane ll
+    if (SPLIT) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int mm = blockIdx.x * 32 + rowfn(r, h);
-        if (mm >= g.M || n >= g.N) continue;
-        float v = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];      // fixed order
-        v *= g.alpha;
-        if (bias) v += bias[mm];
-        const size_t ci = (size_t)mm * g.sCm + (size_t)n * g.sCn;
-        if (g.epi == EPI_RELU) v = v > 0.f ? v : 0.f;
-        else if (g.epi == EPI_TANH) v = tanhf(v);
-        else if (g.epi == EPI_MASK_RELU) v = aux[ci] > 0.f ? v : 0.f;
-        else if (g.epi == EPI_MASK_TANH) { const float y = aux[ci]; v *= 1.0f - y * y; }
-        C[ci] = v;
+        for (int i = 0; i < 2; ++i) {
+            const int e = threadIdx.x + 512 * i, ml = e & 31, nl = e >> 5;
+            const int rr = (ml & 3) + 4 * (ml >> 3), ll = nl + 32 * ((ml >> 2) & 1);
+            const int mm = blockIdx.x * 32 + ml, nn = tile_n * 32 + nl;
+            if (mm >= g.M || nn >= g.N) continue;
+            float v = red[0][rr][ll];
+#pragma unroll
+            for (int w = 1; w < kGemmWaves; ++w) v += red[w][rr][ll];                          // fixed order
+            const size_t ci = (size_t)mm * g.sCm + (size_t)nn * g.sCn;
+            C[ci] = gemm_epilogue(g, v, mm, ci, bias, aux);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = lane + 64 * i, ml = e & 31, nl = e >> 5;
+            const int rr = (ml & 3) + 4 * (ml >> 3), ll = nl + 32 * ((ml >> 2) & 1);
+            const int mm = blockIdx.x * 32 + ml, nn = tile_n * 32 + nl;
+            if (mm >= g.M || nn >= g.N) continue;
+            const size_t ci = (size_t)mm * g.sCm + (size_t)nn * g.sCn;
+            C[ci] = gemm_epilogue(g, red[wave][rr][ll], mm, ci, bias, aux);
+        }
     }
 }
 
@@ -191,6 +224,7 @@ struct EntNextArgs {
     const float* log_std; const float *ne, *nn; const float* xa;
     float* xq_next;   // [B][D+A] (next obs, next action)
     float* nlp;       // [B] next log-probs
+    const float* np; float *xq_pi, *a_pi, *g_pi, *lp_pi;   // the actor-loss sample (sac_actor_loss :101): it only depends on the actor, which does not change before the actor step
     SacScalars* sc; float target_entropy, lr, b1, b2, eps, bt1, bt2; int auto_ent;
     float* stats;     // [8]: 0 actor_loss 1 critic_loss 2 entropy_loss 3 mean_q 4 ent_coef 5 |gc|^2 6 |ga|^2
 };
@@ -204,6 +238,9 @@ __global__ __launch_bounds__(256) void sac_ent_next_kernel(EntNextArgs g) {
         g.nlp[i] = squashed_sample_logp(g.mu + (size_t)(g.B + i) * g.A, ls, g.nn + (size_t)i * g.A, g.A, a_, gg);
         for (int d = 0; d < g.D; ++d) g.xq_next[(size_t)i * (g.D + g.A) + d] = g.xa[(size_t)(g.B + i) * g.D + d];
         for (int a = 0; a < g.A; ++a) g.xq_next[(size_t)i * (g.D + g.A) + g.D + a] = a_[a];
+        g.lp_pi[i] = squashed_sample_logp(g.mu + (size_t)i * g.A, ls, g.np + (size_t)i * g.A, g.A, a_, gg);
+        for (int d = 0; d < g.D; ++d) g.xq_pi[(size_t)i * (g.D + g.A) + d] = g.xa[(size_t)i * g.D + d];
+        for (int a = 0; a < g.A; ++a) { g.xq_pi[(size_t)i * (g.D + g.A) + g.D + a] = a_[a]; g.a_pi[i * g.A + a] = a_[a]; g.g_pi[i * g.A + a] = gg[a]; }
     }
     const double tot = block_sum(s, sh);
     if (threadIdx.x == 0) {
@@ -247,19 +284,6 @@ __global__ __launch_bounds__(256) void sac_critic_head_kernel(CriticHeadArgs g) 
     if (threadIdx.x == 0) { g.stats[1] = (float)cl; g.stats[3] = (float)(qs / (2.0 * g.B)); }
 }
 
-// ---- actor sample for the actor loss (sac_actor_loss :101): a_pi, logp, atanh(clamp(a)) -----------------------------------
-struct PiHeadArgs {
-    int B, D, A; const float* mu; const float* log_std; const float* np; const float* xa;
-    float* xq_pi; float *a_pi, *g_pi, *lp_pi;
-};
-__global__ void sac_pi_head_kernel(PiHeadArgs g) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.B) return;
-    float ls[kMaxA], a_[kMaxA], gg[kMaxA]; for (int a = 0; a < g.A; ++a) ls[a] = g.log_std[a];
-    g.lp_pi[i] = squashed_sample_logp(g.mu + (size_t)i * g.A, ls, g.np + (size_t)i * g.A, g.A, a_, gg);
-    for (int d = 0; d < g.D; ++d) g.xq_pi[(size_t)i * (g.D + g.A) + d] = g.xa[(size_t)i * g.D + d];
-    for (int a = 0; a < g.A; ++a) { g.xq_pi[(size_t)i * (g.D + g.A) + g.D + a] = a_[a]; g.a_pi[i * g.A + a] = a_[a]; g.g_pi[i * g.A + a] = gg[a]; }
-}
 // actor loss head (:102-104): min over the critics, dL/dq
 struct ActorHeadArgs { int B; const float* q_pi; const float* lp_pi; const SacScalars* sc; float* dq; float* stats; };
 __global__ __launch_bounds__(256) void sac_actor_head_kernel(ActorHeadArgs g) {
@@ -317,18 +341,55 @@ __global__ __launch_bounds__(256) void sac_adam_kernel(AdamRangeArgs a) {
     }
     if (a.sumsq_partials) { ss = block_sum(ss, sh); if (threadIdx.x == 0) a.sumsq_partials[blockIdx.x] = ss; }
 }
-// polyak_update! (optimization_utils.jl:3-6) + the step's statistics
-struct FinishArgs { float* target; const float* src; int n; float tau; int do_polyak; const double *ssq_c, *ssq_a, *ssq_ls; int nblk_c, nblk_a; float* stats; float* out; };
-__global__ __launch_bounds__(256) void sac_finish_kernel(FinishArgs f) {
-    if (f.do_polyak)
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < f.n; i += gridDim.x * 256) f.target[i] = f.tau * f.src[i] + (1.0f - f.tau) * f.target[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double c = 0, a = 0;
-        for (int i = 0; i < f.nblk_c; ++i) c += f.ssq_c[i];
-        for (int i = 0; i < f.nblk_a; ++i) a += f.ssq_a[i];
-        a += f.ssq_ls[0];
-        f.out[0] = f.stats[0]; f.out[1] = f.stats[1]; f.out[2] = f.stats[2]; f.out[3] = f.stats[3]; f.out[4] = f.stats[4];
-        f.out[5] = (float)sqrt(c + a);                                                        // sac.jl:393
+// End of one update!: apply_gradients(train_state, actor_loss_grad) (sac.jl:382 — actor_head and log_std with their gradients, the
+// critic leaves with the ZERO arrays zero_critic_grads! left, :381), polyak_update! of the targets (:385-389, optimization_utils.jl:3-6)
+// and the step's statistics, in ONE launch.  The block that finishes last sums the per-block partials in index order (deterministic).
+struct StepEndArgs {
+    float *p, *m, *v; const float* g_actor; int n_actor, ls_off, n_ls, q_off, n_q;
+    float lr, b1, b2, eps, bt1_a, bt2_a, bt1_c, bt2_c;
+    float* target; float tau; int do_polyak;
+    const double* ssq_c; int nblk_c; double* ssq_a; unsigned int* counter; const float* stats; float* out;
+};
+__device__ __forceinline__ float adam_one(float* p, float* m, float* v, int i, float gi, float lr, float b1, float b2, float eps, float bt1, float bt2) {
+    const float mm = b1 * m[i] + (1.0f - b1) * gi, vv = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mm; v[i] = vv;
+    const float np_ = p[i] - mm / (1.0f - bt1) / (sqrtf(vv / (1.0f - bt2)) + eps) * lr;
+    p[i] = np_; return np_;
+}
+__global__ __launch_bounds__(256) void sac_step_end_kernel(StepEndArgs a) {
+    __shared__ double sh[256];
+    __shared__ bool last;
+    const int total = a.n_actor + a.n_ls + a.n_q;
+    double ss = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        if (i < a.n_actor + a.n_ls) {
+            const int j = i < a.n_actor ? i : a.ls_off + (i - a.n_actor);
+            const float gi = a.g_actor[j];
+            adam_one(a.p, a.m, a.v, j, gi, a.lr, a.b1, a.b2, a.eps, a.bt1_a, a.bt2_a);
+            ss += (double)gi * gi;
+        } else {
+            const int k = i - a.n_actor - a.n_ls, j = a.q_off + k;
+            const float np_ = adam_one(a.p, a.m, a.v, j, 0.f, a.lr, a.b1, a.b2, a.eps, a.bt1_c, a.bt2_c);
+            if (a.do_polyak) a.target[k] = a.tau * np_ + (1.0f - a.tau) * a.target[k];
+        }
+    }
+    ss = block_sum(ss, sh);
+    if (threadIdx.x == 0) {
+        a.ssq_a[blockIdx.x] = ss;
+        __threadfence();
+        last = atomicAdd(a.counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double c = 0, g = 0;
+    for (int i = threadIdx.x; i < a.nblk_c; i += 256) c += ((volatile const double*)a.ssq_c)[i];
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) g += ((volatile double*)a.ssq_a)[i];
+    c = block_sum(c, sh); g = block_sum(g, sh);
+    if (threadIdx.x == 0) {
+        a.out[0] = a.stats[0]; a.out[1] = a.stats[1]; a.out[2] = a.stats[2]; a.out[3] = a.stats[3]; a.out[4] = a.stats[4];
+        a.out[5] = (float)sqrt(c + g);                                                        // sac.jl:393
+        *a.counter = 0u;
     }
 }
 
@@ -415,7 +476,7 @@ struct dril_sac_handle {
     hipStream_t stream = nullptr;
     float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *target = nullptr, *g_critic = nullptr, *g_actor = nullptr;
     SacScalars* sc = nullptr; float* stats = nullptr; float* stats_out = nullptr; int stats_cap = 0;
-    double *ssq_c = nullptr, *ssq_a = nullptr, *ssq_ls = nullptr; int adam_blocks_c = 0, adam_blocks_a = 0;
+    double *ssq_c = nullptr, *ssq_a = nullptr; unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
     float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
     float target_entropy = 0;
     // env
@@ -463,8 +524,9 @@ int gemm(dril_sac_handle* h, GemmArgs g, int Z) {
     g.vecA = g.sAk == 1 && g.sAm % 4 == 0 && g.K % 4 == 0 && aligned16(g.A) && g.zA % 4 == 0;
     g.vecB = !g.ones_n && g.sBk == 1 && g.sBn % 4 == 0 && g.K % 4 == 0 && aligned16(g.B) && g.zB % 4 == 0;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return sfail(h, DRIL_ERR_INVALID_ARG, "gemm: empty contraction");
-    dim3 grid((g.M + 31) / 32, (g.N + 31) / 32, Z);
-    hipLaunchKernelGGL(sac_gemm_kernel, grid, dim3(256), 0, h->stream, g);
+    const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
+    if ((long long)tm * tn * Z >= 2048) hipLaunchKernelGGL(sac_gemm_kernel<false>, dim3(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), dim3(64 * kGemmWaves), 0, h->stream, g);
+    else hipLaunchKernelGGL(sac_gemm_kernel<true>, dim3(tm, tn, Z), dim3(64 * kGemmWaves), 0, h->stream, g);
     SHIP(h, hipGetLastError());
     return DRIL_OK;
 }
@@ -545,7 +607,7 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
     // actor means of (obs | next obs) in one pass: the entropy constant (:318-325) and the actor loss (:101) share the obs half,
     // the critic target (:131) uses the next-obs half; the actor parameters do not change until the actor step
     SDO(net_forward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, 2 * B, actor_bufs(h), 1));
-    EntNextArgs en{B, D, A, h->mu, h->params + h->log_std_off, h->b_ne, h->b_nn, h->xa, h->xq_next, h->b_nlp, h->sc, h->target_entropy,
+    EntNextArgs en{B, D, A, h->mu, h->params + h->log_std_off, h->b_ne, h->b_nn, h->xa, h->xq_next, h->b_nlp, h->b_np, h->xq_pi, h->a_pi, h->g_pi, h->lp_pi, h->sc, h->target_entropy,
                    h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->bt_ent[0], h->bt_ent[1], h->cfg.auto_ent_coef, h->stats};
     hipLaunchKernelGGL(sac_ent_next_kernel, dim3(1), dim3(256), 0, h->stream, en);
     if (h->cfg.auto_ent_coef) { h->bt_ent[0] *= h->cfg.adam_beta1; h->bt_ent[1] *= h->cfg.adam_beta2; }
@@ -558,8 +620,6 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
     SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, h->ssq_c, h->adam_blocks_c));
     h->bt_critic[0] *= h->cfg.adam_beta1; h->bt_critic[1] *= h->cfg.adam_beta2;
     // actor (:93-105) with the UPDATED critics: sample, values, loss head, input gradients of the critics, squash reverse, actor reverse
-    PiHeadArgs ph{B, D, A, h->mu, h->params + h->log_std_off, h->b_np, h->xa, h->xq_pi, h->a_pi, h->g_pi, h->lp_pi};
-    hipLaunchKernelGGL(sac_pi_head_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, ph);
     SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), 2));
     ActorHeadArgs ah{B, h->q_pi, h->lp_pi, h->sc, h->dq, h->stats};
     hipLaunchKernelGGL(sac_actor_head_kernel, dim3(1), dim3(256), 0, h->stream, ah);
@@ -567,16 +627,15 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
     SquashBwdArgs sb{B, D, A, h->mu, h->params + h->log_std_off, h->b_np, h->a_pi, h->g_pi, h->dxq, h->sc, h->dmu, h->g_actor + h->log_std_off};
     hipLaunchKernelGGL(sac_squash_bwd_kernel, dim3(1), dim3(256), 0, h->stream, sb);
     SDO(net_backward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, B, actor_bufs(h), h->dmu, h->g_actor, nullptr, 1));
-    // apply_gradients(train_state, actor_loss_grad) :382 — actor + log_std with their gradients, the critics with ZERO gradients
-    SDO(adam_range(h, 0, h->actor.end, h->g_actor, h->bt_actor, h->ssq_a, h->adam_blocks_a));
-    SDO(adam_range(h, h->log_std_off, A, h->g_actor, h->bt_actor, h->ssq_ls, 1));
-    SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, nullptr, h->bt_critic, nullptr, h->adam_blocks_c));
+    // apply_gradients(train_state, actor_loss_grad) :382 + target networks :385-389 + statistics: one launch
+    const int do_polyak = h->grad_updates % h->cfg.target_update_interval == 0;
+    StepEndArgs se{h->params, h->adam_m, h->adam_v, h->g_actor, h->actor.end, h->log_std_off, A, h->q0.w1, 2 * h->Pqd,
+                   h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->bt_actor[0], h->bt_actor[1], h->bt_critic[0], h->bt_critic[1],
+                   h->target, h->cfg.tau, do_polyak, h->ssq_c, h->adam_blocks_c, h->ssq_a, h->counter, h->stats, out};
+    hipLaunchKernelGGL(sac_step_end_kernel, dim3(h->end_blocks), dim3(256), 0, h->stream, se);
+    SHIP(h, hipGetLastError());
     h->bt_actor[0] *= h->cfg.adam_beta1; h->bt_actor[1] *= h->cfg.adam_beta2;
     h->bt_critic[0] *= h->cfg.adam_beta1; h->bt_critic[1] *= h->cfg.adam_beta2;
-    const int do_polyak = h->grad_updates % h->cfg.target_update_interval == 0;                  // :385-389
-    FinishArgs fa{h->target, h->params + h->q0.w1, 2 * h->Pqd, h->cfg.tau, do_polyak, h->ssq_c, h->ssq_a, h->ssq_ls, h->adam_blocks_c, h->adam_blocks_a, h->stats, out};
-    hipLaunchKernelGGL(sac_finish_kernel, dim3(h->adam_blocks_c), dim3(256), 0, h->stream, fa);
-    SHIP(h, hipGetLastError());
     h->grad_updates += 1; h->update_counter += 1;
     return DRIL_OK;
 }
@@ -698,7 +757,7 @@ DRIL_EXPORT int32_t dril_sac_config_default(dril_sac_config* c, int32_t env_kind
 DRIL_EXPORT int32_t dril_sac_destroy(dril_sac_handle* h) {
     if (!h) return DRIL_OK;
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->target, h->g_critic, h->g_actor, h->sc, h->stats, h->stats_out, h->ssq_c, h->ssq_a, h->ssq_ls,
+    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->target, h->g_critic, h->g_actor, h->sc, h->stats, h->stats_out, h->ssq_c, h->ssq_a, h->counter,
                     h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->obs_cur, h->obs_nxt, h->e_rew, h->e_tobs, h->e_raw, h->e_envact, h->e_term, h->e_trunc,
                     h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc, h->xa, h->ah1, h->ah2, h->mu, h->xq, h->xq_next, h->xq_pi,
                     h->qh1, h->qh2, h->th1, h->th2, h->q_cur, h->q_next, h->q_pi, h->dq, h->dz2, h->dz1, h->dxq, h->dmu, h->b_rew, h->b_ne, h->b_nn, h->b_np,
@@ -733,8 +792,8 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     h->target_entropy = cfg->auto_target_entropy ? -(float)A : cfg->target_entropy;
     CHK(smalloc(&h->params, h->Pd)); CHK(smalloc(&h->adam_m, h->Pd)); CHK(smalloc(&h->adam_v, h->Pd)); CHK(smalloc(&h->target, 2 * (size_t)h->Pqd));
     CHK(smalloc(&h->g_critic, h->Pd)); CHK(smalloc(&h->g_actor, h->Pd)); CHK(smalloc(&h->sc, 1)); CHK(smalloc(&h->stats, 8));
-    h->adam_blocks_c = std::min(1024, (2 * h->Pqd + 255) / 256); h->adam_blocks_a = std::min(1024, (h->actor.end + 255) / 256);
-    CHK(smalloc(&h->ssq_c, h->adam_blocks_c)); CHK(smalloc(&h->ssq_a, h->adam_blocks_a)); CHK(smalloc(&h->ssq_ls, 1));
+    h->adam_blocks_c = std::min(1024, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(1024, (h->actor.end + A + 2 * h->Pqd + 255) / 256);
+    CHK(smalloc(&h->ssq_c, h->adam_blocks_c)); CHK(smalloc(&h->ssq_a, h->end_blocks)); CHK(smalloc(&h->counter, 1));
     CHK(smalloc(&h->state, (size_t)E * S)); CHK(smalloc(&h->step_count, E)); CHK(smalloc(&h->episode, E)); CHK(smalloc(&h->gstep, E)); CHK(smalloc(&h->disc_returns, E));
     CHK(smalloc(&h->obs_cur, (size_t)E * D)); CHK(smalloc(&h->obs_nxt, (size_t)E * D)); CHK(smalloc(&h->e_rew, E)); CHK(smalloc(&h->e_tobs, (size_t)E * D));
     CHK(smalloc(&h->e_raw, (size_t)E * A)); CHK(smalloc(&h->e_envact, (size_t)E * A)); CHK(smalloc(&h->e_term, E)); CHK(smalloc(&h->e_trunc, E));

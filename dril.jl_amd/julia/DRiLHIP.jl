@@ -319,6 +319,134 @@ function DRiL.evaluate_agent(agent, env::DeviceParallelEnv; n_eval_episodes::Int
         (er, Int.(el))
 end
 
+
+# =====================================================================================================================
+# SAC: train!(agent, env::DeviceParallelEnv, alg::SAC, max_steps)  (src/algorithms/sac.jl:406-549) over include/dril_sac.h
+# =====================================================================================================================
+# struct dril_sac_config / dril_sac_stats (include/dril_sac.h) — isbits, C layout
+struct DrilSacConfig
+    abi_version::UInt32; env_kind::Int32; n_envs::Int32; episode_len::Int32
+    hidden1::Int32; hidden2::Int32; activation::Int32
+    buffer_capacity::Int64; start_steps::Int32; batch_size::Int32
+    tau::Float32; gamma::Float32
+    train_freq::Int32; gradient_steps::Int32; target_update_interval::Int32
+    auto_ent_coef::Int32; ent_coef_init::Float32; auto_target_entropy::Int32; target_entropy::Float32
+    learning_rate::Float32; adam_beta1::Float32; adam_beta2::Float32; adam_eps::Float32
+    seed::UInt64; device::Int32; profile_events::Int32
+    reserved::NTuple{8, Int32}
+end
+struct DrilSacStats
+    actor_loss::Float32; critic_loss::Float32; entropy_loss::Float32; mean_q_values::Float32; entropy_coefficient::Float32; grad_norm::Float32
+    has_entropy_loss::Int32; reserved::Int32
+end
+sac_check(rc::Int32, h = C_NULL) = rc == 0 ? nothing :
+    error("libdril_hip (SAC) status $rc: " * unsafe_string(ccall((:dril_sac_last_error, LIB[]), Cstring, (Ptr{Cvoid},), h)))
+
+# ContinuousActorCriticLayer{QCritic}: actor_head = Chain(mlp, ReshapeLayer), critic_head = Parallel(vcat, mlp, mlp) (layer_helpers.jl:77,100-112)
+function sac_flatten_params(ps)
+    parts = Vector{Float32}[]
+    for head in (mlp_of(ps.actor_head), ps.critic_head.layer_1, ps.critic_head.layer_2), l in (:layer_1, :layer_2, :layer_3)
+        push!(parts, vec(getproperty(head, l).weight)); push!(parts, vec(getproperty(head, l).bias))
+    end
+    push!(parts, vec(ps.log_std))
+    return reduce(vcat, parts)
+end
+function sac_scatter_params!(ps, flat::Vector{Float32})
+    off = 0
+    for head in (mlp_of(ps.actor_head), ps.critic_head.layer_1, ps.critic_head.layer_2), l in (:layer_1, :layer_2, :layer_3)
+        for arr in (getproperty(head, l).weight, getproperty(head, l).bias)
+            n = length(arr); copyto!(arr, 1, flat, off + 1, n); off += n
+        end
+    end
+    copyto!(ps.log_std, 1, flat, off + 1, length(ps.log_std))
+    return ps
+end
+function sac_flatten_targets(tp)
+    parts = Vector{Float32}[]
+    for head in (tp.critic_head.layer_1, tp.critic_head.layer_2), l in (:layer_1, :layer_2, :layer_3)
+        push!(parts, vec(getproperty(head, l).weight)); push!(parts, vec(getproperty(head, l).bias))
+    end
+    return reduce(vcat, parts)
+end
+function sac_scatter_targets!(tp, flat::Vector{Float32})
+    off = 0
+    for head in (tp.critic_head.layer_1, tp.critic_head.layer_2), l in (:layer_1, :layer_2, :layer_3)
+        for arr in (getproperty(head, l).weight, getproperty(head, l).bias)
+            n = length(arr); copyto!(arr, 1, flat, off + 1, n); off += n
+        end
+    end
+    return tp
+end
+
+function sac_config(env::DeviceParallelEnv, alg::DRiL.SAC, agent)
+    env.kind === :Pendulum || error("SAC needs a Box action space (sac.jl:74): DeviceParallelEnv(:Pendulum, ...)")
+    hd = hidden_dims_of(agent.train_state.parameters)
+    act = agent.layer.actor_head.layers[1].layers[1].activation === DRiL.Lux.relu ? Int32(1) : Int32(0)   # SACLayer default relu (sac.jl:77)
+    ec = alg.ent_coef
+    auto = ec isa DRiL.AutoEntropyCoefficient
+    auto_t = auto && ec.target isa DRiL.AutoEntropyTarget
+    return DrilSacConfig(UInt32(1), ENV_KINDS[env.kind], env.n_envs, env.max_steps, hd[1], hd[2], act,
+        alg.buffer_capacity, alg.start_steps, alg.batch_size, alg.tau, alg.gamma, alg.train_freq, alg.gradient_steps, alg.target_update_interval,
+        Int32(auto), auto ? Float32(ec.initial_value) : Float32(ec.coef), Int32(auto ? auto_t : true),
+        auto && !auto_t ? Float32(ec.target.target) : 0.0f0,
+        alg.learning_rate, 0.9f0, 0.999f0, 1.0f-8,                                                # Optimisers.Adam(lr) defaults, agent_methods.jl:116-118
+        env.seed, env.device, Int32(0), ntuple(_ -> Int32(0), 8))
+end
+
+"""
+    train!(agent, env::DeviceParallelEnv, alg::SAC, max_steps) -> (agent, nothing, training_stats, to)
+
+Same contract as `train!(agent, replay_buffer, env, alg::SAC, max_steps)` (sac.jl:414-549) with the ReplayBuffer resident on the device
+(second return value `nothing`; read it through `dril_sac_replay_copy_out`).  Callbacks with `on_step` hooks are not supported on this path.
+"""
+function train!(agent::Agent, env::DeviceParallelEnv, alg::DRiL.SAC{T}, max_steps::Int; ad_type = nothing, callbacks = nothing) where {T}
+    has_step_hooks(callbacks) && error("on_step callbacks need the step-granular path: use DRiL's generic train! on the env verbs")
+    to = TimerOutput()
+    cfg = Ref(sac_config(env, alg, agent)); hp = Ref{Ptr{Cvoid}}(C_NULL)
+    sac_check(ccall((:dril_sac_create, LIB[]), Int32, (Ref{DrilSacConfig}, Ref{Ptr{Cvoid}}), cfg, hp)); h = hp[]
+    try
+        flat = sac_flatten_params(agent.train_state.parameters); tgt = sac_flatten_targets(agent.aux.Q_target_parameters)
+        GC.@preserve flat tgt begin
+            sac_check(ccall((:dril_sac_set_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h, flat, length(flat)), h)
+            sac_check(ccall((:dril_sac_set_target_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h, tgt, length(tgt)), h)
+        end
+        sac_check(ccall((:dril_sac_set_log_ent_coef, LIB[]), Int32, (Ptr{Cvoid}, Float32), h, first(agent.aux.ent_train_state.parameters.log_ent_coef)), h)
+        sac_check(ccall((:dril_sac_env_reset, LIB[]), Int32, (Ptr{Cvoid}, UInt64), h, env.seed), h)
+        n_envs = env.n_envs                                                                       # schedule: sac.jl:436-447
+        total_start = alg.start_steps > 0 ? alg.start_steps : alg.train_freq * n_envs
+        adjusted = max(1, div(total_start, n_envs)) * n_envs
+        iterations = div(max_steps - adjusted, alg.train_freq * n_envs) + 1
+        n_upd = DRiL.get_gradient_steps(alg, alg.train_freq, n_envs)
+        cap = max(1, iterations * n_upd)
+        st = Vector{DrilSacStats}(undef, cap); fps = Vector{Float64}(undef, max(1, iterations))
+        nu = Ref{Int64}(0); it = Ref{Int32}(0); tot = Ref{Int64}(0)
+        !isnothing(callbacks) && !all(c -> DRiL.on_training_start(c, Dict{Symbol, Any}(:agent => agent, :env => env, :alg => alg)), callbacks) && return agent, nothing, DRiL.SACTrainingStats{T}()
+        @timeit to "training_loop" GC.@preserve st fps sac_check(ccall((:dril_sac_train, LIB[]), Int32,
+            (Ptr{Cvoid}, Int64, Ptr{DrilSacStats}, Int64, Ref{Int64}, Ptr{Float64}, Int64, Ref{Int32}, Ref{Int64}),
+            h, max_steps, st, cap, nu, fps, length(fps), it, tot), h)
+        ts = DRiL.SACTrainingStats{T}()                                                            # sac.jl:243-257
+        for k in 1:min(nu[], cap)
+            s = st[k]
+            push!(ts.actor_losses, s.actor_loss); push!(ts.critic_losses, s.critic_loss); s.has_entropy_loss != 0 && push!(ts.entropy_losses, s.entropy_loss)
+            push!(ts.entropy_coefficients, s.entropy_coefficient); push!(ts.q_values, s.mean_q_values); push!(ts.learning_rates, alg.learning_rate)
+            push!(ts.grad_norms, s.grad_norm)
+        end
+        append!(ts.fps, T.(fps[1:it[]]))
+        DRiL.add_step!(agent, tot[])
+        GC.@preserve flat tgt begin
+            sac_check(ccall((:dril_sac_get_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h, flat, length(flat)), h)
+            sac_check(ccall((:dril_sac_get_target_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h, tgt, length(tgt)), h)
+        end
+        sac_scatter_params!(agent.train_state.parameters, flat); sac_scatter_targets!(agent.aux.Q_target_parameters, tgt)
+        le = Ref{Float32}(0); sac_check(ccall((:dril_sac_get_log_ent_coef, LIB[]), Int32, (Ptr{Cvoid}, Ref{Float32}), h, le), h)
+        agent.aux.ent_train_state.parameters.log_ent_coef[1] = le[]
+        !isnothing(callbacks) && all(c -> DRiL.on_training_end(c, Dict{Symbol, Any}(:agent => agent, :env => env, :alg => alg)), callbacks)
+        return agent, nothing, ts, to
+    finally
+        ccall((:dril_sac_destroy, LIB[]), Int32, (Ptr{Cvoid},), h)
+    end
+end
+
 export DeviceParallelEnv
 
 end # module
