@@ -699,9 +699,16 @@ int run_updates(dril_sac_handle* h, int n_updates, bool injected, dril_sac_stats
     if (h->size <= 0) return sfail(h, DRIL_ERR_NOT_INITIALISED, "the replay buffer is empty");
     SDO(ensure_stats(h, n_updates));
     if (h->cfg.profile_events) hipEventRecord(h->ev_a, h->stream);
+    const auto t_enq0 = std::chrono::steady_clock::now();
     for (int k = 0; k < n_updates; ++k) SDO(sac_one_update(h, injected ? k : -1, h->stats_out + (size_t)k * 8));
     if (h->cfg.profile_events) hipEventRecord(h->ev_b, h->stream);
+    const auto t_enq1 = std::chrono::steady_clock::now();
     SDO(ssync(h));
+    if (getenv("DRIL_SAC_TRACE_ENQUEUE")) {
+        const auto t_done = std::chrono::steady_clock::now();
+        fprintf(stderr, "[dril_sac] %d update(s): enqueue %.1f us, until drained %.1f us\n", n_updates,
+                std::chrono::duration<double, std::micro>(t_enq1 - t_enq0).count(), std::chrono::duration<double, std::micro>(t_done - t_enq0).count());
+    }
     if (h->cfg.profile_events) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev_a, h->ev_b) == hipSuccess) { h->update_ms += ms; h->updates += n_updates; } }
     if (out) {
         std::vector<float> rows((size_t)n_updates * 8);

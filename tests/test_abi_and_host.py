@@ -117,3 +117,52 @@ def test_perm_bijection(oracle_mod):
     a = np.array([L.orc_perm_index(p, 4097, L.orc_perm_key(42, 0, 0)) for p in range(4097)])
     b = np.array([L.orc_perm_index(p, 4097, L.orc_perm_key(42, 0, 1)) for p in range(4097)])
     assert (a != b).mean() > 0.99 and abs(np.corrcoef(a, np.arange(4097))[0, 1]) < 0.1
+
+
+def test_checkpoint_roundtrip_schema(pkg, tmp_path):
+    """test/test_ppo_integration.jl:42-83 (parameters identical after save -> load into a freshly initialised agent) + the SAC aux"""
+    env = pkg.CartPoleEnv()
+    alg = pkg.PPO(n_steps=16, batch_size=16, epochs=2)
+    layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(32, 32))
+    a, b = pkg.Agent(layer, alg, seed=77), pkg.Agent(layer, alg, seed=88)
+    fa, fb = pkg.flatten_params(a.train_state.parameters), pkg.flatten_params(b.train_state.parameters)
+    assert not np.array_equal(fa, fb)
+    path = pkg.save_policy_params_and_state(a, tmp_path / "ppo_agent")
+    keys = set(np.load(path).files)
+    assert {"layer", "states", "parameters/actor_head/layer_1/weight", "parameters/critic_head/layer_3/bias"} <= keys       # agent_methods.jl:129-136
+    pkg.load_policy_params_and_state_(b, alg, path)
+    np.testing.assert_array_equal(pkg.flatten_params(b.train_state.parameters), fa)
+    penv = pkg.PendulumEnv()
+    sl = pkg.SACLayer(penv.observation_space(), penv.action_space(), hidden_dims=(32, 32))
+    s1, s2 = pkg.SACAgent(sl, pkg.SAC(), seed=1), pkg.SACAgent(sl, pkg.SAC(), seed=2)
+    s1.log_ent_coef = -0.25
+    pkg.load_policy_params_and_state_(s2, s1.alg, pkg.save_policy_params_and_state(s1, tmp_path / "sac_agent"))
+    np.testing.assert_array_equal(pkg.sac_flatten_params(s2.parameters), pkg.sac_flatten_params(s1.parameters))
+    np.testing.assert_array_equal(s2.q_target_parameters, s1.q_target_parameters)
+    assert s2.log_ent_coef == pytest.approx(-0.25)
+
+
+def test_sac_struct_layout_and_defaults(pkg, tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dril_sac.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(dril_sac_config),'
+                   ' offsetof(dril_sac_config, buffer_capacity), offsetof(dril_sac_config, seed), offsetof(dril_sac_config, profile_events), sizeof(dril_sac_stats));return 0;}')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    sz, off_b, off_s, off_p, sz_st = map(int, subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    K = pkg._capi.DrilSacConfig
+    assert (C.sizeof(K), K.buffer_capacity.offset, K.seed.offset, K.profile_events.offset) == (sz, off_b, off_s, off_p)
+    assert C.sizeof(pkg._capi.DrilSacStats) == sz_st
+    lib = pkg._capi.load_library()
+    c = K()
+    assert lib.dril_sac_config_default(C.byref(c), pkg._capi.ENV_PENDULUM) == 0                 # SAC() sac.jl:25-36, SACLayer :72-85
+    assert (c.buffer_capacity, c.start_steps, c.batch_size, c.train_freq, c.gradient_steps, c.target_update_interval) == (1_000_000, 100, 256, 1, 1, 1)
+    assert (c.hidden1, c.hidden2, c.activation, c.auto_ent_coef, c.auto_target_entropy) == (512, 512, 1, 1, 1)
+    assert (c.tau, c.gamma, c.learning_rate, c.adam_eps, c.ent_coef_init) == pytest.approx((0.005, 0.99, 3e-4, 1e-8, 1.0))
+    py = pkg.make_sac_config(pkg.PendulumEnv(), 1, pkg.SAC(), pkg.SACLayer(pkg.PendulumEnv().observation_space(), pkg.PendulumEnv().action_space()))
+    for name, _ in K._fields_:
+        if name not in ("reserved",):
+            assert getattr(c, name) == pytest.approx(getattr(py, name)), name
+    assert lib.dril_sac_config_default(C.byref(c), pkg._capi.ENV_CARTPOLE) == pkg._capi.ERR_INVALID_ARG   # Box action space required (sac.jl:74)
+    h = C.c_void_p()
+    assert lib.dril_sac_create(None, C.byref(h)) == pkg._capi.ERR_INVALID_ARG
+    assert b"null" in lib.dril_sac_last_error(None)
