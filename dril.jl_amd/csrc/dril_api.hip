@@ -299,7 +299,7 @@ void* buf_ptr(dril_handle* h, int which, size_t* bytes) {
 
 // ================================================================================================
 DRIL_EXPORT int32_t dril_config_default(dril_config* c, int32_t env_kind) {
-    if (!c || (env_kind != DRIL_ENV_CARTPOLE && env_kind != DRIL_ENV_PENDULUM)) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad cfg/env_kind");
+    if (!c || env_kind < DRIL_ENV_CARTPOLE || env_kind > DRIL_ENV_PENDULUM_SCALED) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad cfg/env_kind");
     std::memset(c, 0, sizeof(*c));
     c->abi_version = DRIL_ABI_VERSION; c->env_kind = env_kind; c->n_envs = 4; c->n_steps = 2048; c->hidden1 = c->hidden2 = 64;
     c->episode_len = env_kind == DRIL_ENV_CARTPOLE ? 500 : 200; c->action_start = 1;
@@ -313,7 +313,7 @@ DRIL_EXPORT int32_t dril_config_default(dril_config* c, int32_t env_kind) {
 DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (!cfg || !out) return fail(nullptr, DRIL_ERR_INVALID_ARG, "null cfg/out");
     if (cfg->abi_version != DRIL_ABI_VERSION) return fail(nullptr, DRIL_ERR_INVALID_ARG, "abi_version mismatch");
-    if (cfg->env_kind != DRIL_ENV_CARTPOLE && cfg->env_kind != DRIL_ENV_PENDULUM) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
+    if (cfg->env_kind < DRIL_ENV_CARTPOLE || cfg->env_kind > DRIL_ENV_PENDULUM_SCALED) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
     if (cfg->n_envs < 1 || cfg->n_steps < 1 || cfg->epochs < 0 || cfg->batch_size < 1) return fail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs/n_steps/batch_size must be positive");
     if (cfg->hidden1 != cfg->hidden2 || (cfg->hidden1 != 64 && cfg->hidden1 != 256)) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden_dims: [64,64] and [256,256] are built");
     if (cfg->monitor_window < 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "monitor_window must be >= 0");

@@ -128,6 +128,12 @@ constexpr float kTanhScale = 2.8853900817779268f;
 template <int KIND> struct EnvSpec;
 template <> struct EnvSpec<0> { static constexpr int D = 4, S = 4, A = 2; static constexpr bool discrete = true; };
 template <> struct EnvSpec<1> { static constexpr int D = 3, S = 2, A = 1; static constexpr bool discrete = false; };
+template <> struct EnvSpec<2> : EnvSpec<1> {};   // ScalingWrapperEnv(PendulumEnv()): same simulator, affine maps at the boundary
+// ScalingWrapperEnv (scalingWrapperEnv.jl): scale! :71-74 `(x - low) * sf - 1`, unscale! :76-79 `(x + 1) / sf + low`, sf = 2 / (high - low) :36-44
+__host__ __device__ inline float scale_to_unit(float x, float low, float high) { const float sf = 2.0f / (high - low); return (x - low) * sf - 1.0f; }
+__host__ __device__ inline float unscale_from_unit(float x, float low, float high) { const float sf = 2.0f / (high - low); return (x + 1.0f) / sf + low; }
+// bound of the agent-facing action space (ClampAdapter / TanhScaleAdapter act on action_space(env)): Box(-2,2), Box(-1,1) under the wrapper
+template <int KIND> __host__ __device__ constexpr float act_bound() { return KIND == 2 ? 1.0f : 2.0f; }
 
 template <int KIND> __device__ inline void env_reset(uint64_t env_seed, uint32_t episode, float* st) {
     uint32_t r[4];
@@ -144,7 +150,12 @@ template <int KIND> __device__ inline void env_obs(const float* st, float* obs) 
     if (KIND == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) obs[i] = st[i];
-    } else { obs[0] = cosf(st[0]); obs[1] = sinf(st[0]); obs[2] = st[1]; }
+    } else {
+        obs[0] = cosf(st[0]); obs[1] = sinf(st[0]); obs[2] = st[1];
+        if (KIND == 2) {                                           // observe(::ScalingWrapperEnv) :93-98 on Box((-1,-1,-8), (1,1,8))
+            obs[0] = scale_to_unit(obs[0], -1.0f, 1.0f); obs[1] = scale_to_unit(obs[1], -1.0f, 1.0f); obs[2] = scale_to_unit(obs[2], -8.0f, 8.0f);
+        }
+    }
 }
 // one step; act_i is the env-space discrete action (0/1), act_f the env-space continuous action
 template <int KIND> __device__ inline float env_step(float* st, float act_f, int act_i, bool fixed_len, bool* terminated) {
@@ -167,6 +178,7 @@ template <int KIND> __device__ inline float env_step(float* st, float act_f, int
         const float max_speed = 8.0f, max_torque = 2.0f, dt = 0.05f, g = 10.0f, m = 1.0f, l = 1.0f;
         const float pi = 3.14159265358979323846f;
         const float th = st[0], thdot = st[1];
+        if (KIND == 2) act_f = unscale_from_unit(act_f, -2.0f, 2.0f);   // act!(::ScalingWrapperEnv, action) :110-113
         const float u = fminf(fmaxf(act_f, -max_torque), max_torque);
         float an = fmodf(th + pi, 2.0f * pi); if (an < 0) an += 2.0f * pi; an -= pi;
         const float cost = an * an + 0.1f * thdot * thdot + 0.001f * u * u;

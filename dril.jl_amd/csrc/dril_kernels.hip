@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
                 if (writer) ((float*)a.act)[k * A + i] = x[i];
             }
             logp = gauss_logpdf<A>(x, out, ls);
-            actf_env = fminf(fmaxf(x[0], -2.0f), 2.0f);                      // ClampAdapter on Box(-2,2) (default_adapters.jl:4-11)
+            actf_env = fminf(fmaxf(x[0], -act_bound<KIND>()), act_bound<KIND>());   // ClampAdapter on action_space(env) (default_adapters.jl:4-11)
         }
         if (writer) {
             if (D == 4) *reinterpret_cast<float4*>(a.obs + k * 4) = make_float4(obs[0], obs[1], obs[2], obs[3]);
@@ -1535,19 +1535,32 @@ template <int KIND, int H> static size_t grad_lds_bytes() {
     return sizeof(float) * (wa > wc ? wa : wc);
 }
 
+// kind 2 (ScalingWrapperEnv(Pendulum)) shares every kernel that never touches the simulator with kind 1
 #define DRIL_DISPATCH(kind, hidden, CALL)                                            \
     do {                                                                             \
         if ((kind) == 0 && (hidden) == 64) { CALL(0, 64); }                          \
-        else if ((kind) == 1 && (hidden) == 64) { CALL(1, 64); }                     \
+        else if (((kind) == 1 || (kind) == 2) && (hidden) == 64) { CALL(1, 64); }    \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
 #define DRIL_DISPATCH_FWD(kind, hidden, CALL)                                        \
     do {                                                                             \
         if ((kind) == 0 && (hidden) == 64) { CALL(0, 64); }                          \
+        else if (((kind) == 1 || (kind) == 2) && (hidden) == 64) { CALL(1, 64); }    \
+        else if ((kind) == 0 && (hidden) == 256) { CALL(0, 256); }                   \
+        else if (((kind) == 1 || (kind) == 2) && (hidden) == 256) { CALL(1, 256); }  \
+        else return hipErrorInvalidValue;                                            \
+    } while (0)
+
+// kernels that step / observe the simulator: one instantiation per env kind
+#define DRIL_DISPATCH_ENV(kind, hidden, CALL)                                        \
+    do {                                                                             \
+        if ((kind) == 0 && (hidden) == 64) { CALL(0, 64); }                          \
         else if ((kind) == 1 && (hidden) == 64) { CALL(1, 64); }                     \
+        else if ((kind) == 2 && (hidden) == 64) { CALL(2, 64); }                     \
         else if ((kind) == 0 && (hidden) == 256) { CALL(0, 256); }                   \
         else if ((kind) == 1 && (hidden) == 256) { CALL(1, 256); }                   \
+        else if ((kind) == 2 && (hidden) == 256) { CALL(2, 256); }                   \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
@@ -1565,7 +1578,8 @@ hipError_t launch_env_reset(int kind, int E, uint64_t seed0, float* state, int32
 hipError_t launch_env_observe(int kind, int E, const float* state, float* obs, hipStream_t s) {
     const int blocks = (E + 255) / 256;
     if (kind == 0) env_observe_kernel<0><<<blocks, 256, 0, s>>>(E, state, obs);
-    else env_observe_kernel<1><<<blocks, 256, 0, s>>>(E, state, obs);
+    else if (kind == 1) env_observe_kernel<1><<<blocks, 256, 0, s>>>(E, state, obs);
+    else env_observe_kernel<2><<<blocks, 256, 0, s>>>(E, state, obs);
     return hipGetLastError();
 }
 hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int fixed_len, int action_start, const void* actions,
@@ -1573,7 +1587,8 @@ hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int
                            float* tobs, MonitorArgs mon, hipStream_t s) {
     const int blocks = (E + 255) / 256;
     if (kind == 0) env_step_kernel<0><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
-    else env_step_kernel<1><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
+    else if (kind == 1) env_step_kernel<1><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
+    else env_step_kernel<2><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
     return hipGetLastError();
 }
 hipError_t launch_monitor_collect(const uint8_t* flags, const float* ep_ret, const int32_t* ep_len, int E, int T, int W, int* cnt,
@@ -1584,7 +1599,7 @@ hipError_t launch_monitor_collect(const uint8_t* flags, const float* ep_ret, con
 }
 
 hipError_t launch_norm_step(int kind, const NormStepArgs& a, int nblocks, hipStream_t s) {
-    if (kind == 0) norm_step_kernel<0><<<nblocks, 256, 0, s>>>(a); else norm_step_kernel<1><<<nblocks, 256, 0, s>>>(a);
+    if (kind == 0) norm_step_kernel<0><<<nblocks, 256, 0, s>>>(a); else if (kind == 1) norm_step_kernel<1><<<nblocks, 256, 0, s>>>(a); else norm_step_kernel<2><<<nblocks, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 hipError_t launch_norm_apply(const NormApplyArgs& a, hipStream_t s) {
@@ -1594,7 +1609,8 @@ hipError_t launch_norm_apply(const NormApplyArgs& a, hipStream_t s) {
 }
 hipError_t launch_obs_partials(int kind, int E, const float* state, float* raw, double* partials, int nblocks, hipStream_t s) {
     if (kind == 0) obs_partials_kernel<0><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
-    else obs_partials_kernel<1><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
+    else if (kind == 1) obs_partials_kernel<1><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
+    else obs_partials_kernel<2><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
     return hipGetLastError();
 }
 hipError_t launch_norm_obs_apply(const NormObsArgs& a, hipStream_t s) {
@@ -1640,7 +1656,7 @@ hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_
             if (e != hipSuccess) return e; attr_set = true; }                                                 \
         rollout_kernel<K, HH, (HH > 64)><<<blocks, 256, lds, s>>>(a);                                         \
     }
-    DRIL_DISPATCH_FWD(kind, hidden, CALL);
+    DRIL_DISPATCH_ENV(kind, hidden, CALL);
 #undef CALL
     return hipGetLastError();
 }

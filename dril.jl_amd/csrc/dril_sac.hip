@@ -478,7 +478,7 @@ struct dril_sac_handle {
     SacScalars* sc = nullptr; float* stats = nullptr; float* stats_out = nullptr; int stats_cap = 0;
     double *ssq_c = nullptr, *ssq_a = nullptr; unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
     float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
-    float target_entropy = 0;
+    float target_entropy = 0, act_hi = 2.0f;   // bound of the agent-facing action space: Box(-2,2), Box(-1,1) under ScalingWrapperEnv
     // env
     float* state = nullptr; int32_t* step_count = nullptr; uint32_t *episode = nullptr, *gstep = nullptr; float* disc_returns = nullptr;
     float *obs_cur = nullptr, *obs_nxt = nullptr, *e_rew = nullptr, *e_tobs = nullptr, *e_raw = nullptr, *e_envact = nullptr; uint8_t *e_term = nullptr, *e_trunc = nullptr;
@@ -649,7 +649,7 @@ int ensure_obs(dril_sac_handle* h) {
 int collect_step(dril_sac_handle* h, int use_random, const float* inj_noise) {
     const int E = h->cfg.n_envs, D = h->D, A = h->A;
     if (!use_random) SDO(net_forward(h, h->params, h->actor, 0, D, A, h->obs_cur, D, 0, E, actor_bufs(h), 1));          // predict_actions_raw :55
-    CollectHeadArgs ca{E, A, use_random, h->mu, h->params + h->log_std_off, inj_noise, h->gstep, h->env_seed0, -2.0f, 2.0f, h->e_raw, h->e_envact};
+    CollectHeadArgs ca{E, A, use_random, h->mu, h->params + h->log_std_off, inj_noise, h->gstep, h->env_seed0, -h->act_hi, h->act_hi, h->e_raw, h->e_envact};
     hipLaunchKernelGGL(sac_collect_head_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, ca);
     MonitorArgs mon{nullptr, nullptr, nullptr, nullptr, nullptr};
     SHIP(h, launch_env_step(h->cfg.env_kind, E, h->env_seed0, h->cfg.episode_len, 0, 0, h->e_envact, h->state, h->step_count, h->episode, h->gstep,
@@ -749,7 +749,7 @@ int round4(int x) { return (x + 3) & ~3; }
 // exported entry points (include/dril_sac.h)
 // =================================================================================================================
 DRIL_EXPORT int32_t dril_sac_config_default(dril_sac_config* c, int32_t env_kind) {
-    if (!c || env_kind != DRIL_ENV_PENDULUM) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "SAC needs a Box action space (sac.jl:74): env_kind must be DRIL_ENV_PENDULUM");
+    if (!c || (env_kind != DRIL_ENV_PENDULUM && env_kind != DRIL_ENV_PENDULUM_SCALED)) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "SAC needs a Box action space (sac.jl:74): env_kind must be DRIL_ENV_PENDULUM[_SCALED]");
     memset(c, 0, sizeof(*c));
     c->abi_version = DRIL_SAC_ABI_VERSION; c->env_kind = env_kind; c->n_envs = 1; c->episode_len = 200;
     c->hidden1 = 512; c->hidden2 = 512; c->activation = 1;
@@ -779,7 +779,7 @@ DRIL_EXPORT int32_t dril_sac_destroy(dril_sac_handle* h) {
 DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle** out) {
     if (!cfg || !out) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "null config / out pointer");
     if (cfg->abi_version != DRIL_SAC_ABI_VERSION) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "dril_sac_config.abi_version mismatch");
-    if (cfg->env_kind != DRIL_ENV_PENDULUM) return sfail(nullptr, DRIL_ERR_UNSUPPORTED, "SAC needs a Box action space (sac.jl:74): only DRIL_ENV_PENDULUM");
+    if (cfg->env_kind != DRIL_ENV_PENDULUM && cfg->env_kind != DRIL_ENV_PENDULUM_SCALED) return sfail(nullptr, DRIL_ERR_UNSUPPORTED, "SAC needs a Box action space (sac.jl:74): only DRIL_ENV_PENDULUM[_SCALED]");
     if (cfg->n_envs <= 0 || cfg->episode_len <= 0 || cfg->batch_size <= 0 || cfg->buffer_capacity < cfg->n_envs || cfg->train_freq <= 0 || cfg->target_update_interval <= 0)
         return sfail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs, episode_len, batch_size, train_freq, target_update_interval must be positive and buffer_capacity >= n_envs");
     if (cfg->hidden1 <= 0 || cfg->hidden2 <= 0 || cfg->hidden1 % 4 || cfg->hidden2 % 4) return sfail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden dims must be positive multiples of 4");
@@ -797,6 +797,7 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     h->log_std_off = h->q0.w1 + 2 * h->Pqd; h->Pd = round4(h->log_std_off + A);
     h->nq = B; h->nmax = std::max(E, 2 * B);
     h->target_entropy = cfg->auto_target_entropy ? -(float)A : cfg->target_entropy;
+    h->act_hi = cfg->env_kind == DRIL_ENV_PENDULUM_SCALED ? 1.0f : 2.0f;
     CHK(smalloc(&h->params, h->Pd)); CHK(smalloc(&h->adam_m, h->Pd)); CHK(smalloc(&h->adam_v, h->Pd)); CHK(smalloc(&h->target, 2 * (size_t)h->Pqd));
     CHK(smalloc(&h->g_critic, h->Pd)); CHK(smalloc(&h->g_actor, h->Pd)); CHK(smalloc(&h->sc, 1)); CHK(smalloc(&h->stats, 8));
     h->adam_blocks_c = std::min(1024, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(1024, (h->actor.end + A + 2 * h->Pqd + 255) / 256);
@@ -904,7 +905,7 @@ DRIL_EXPORT int32_t dril_sac_action_log_prob(dril_sac_handle* h, const float* ob
         const int n = (int)std::min<int64_t>(h->nmax, batch - o);
         SDO(actor_chunk(h, obs + o * h->D, noise ? noise + o * h->A : nullptr, n, 0, o));
         hipLaunchKernelGGL(sac_squash_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, h->A, h->mu, h->params + h->log_std_off, h->s_noise, 0,
-                           -2.0f, 2.0f, h->s_out, h->s_out2, (float*)nullptr);
+                           -h->act_hi, h->act_hi, h->s_out, h->s_out2, (float*)nullptr);
         SDO(ssync(h));
         if (actions) SHIP(h, hipMemcpy(actions + o * h->A, h->s_out, (size_t)n * h->A * 4, hipMemcpyDeviceToHost));
         if (logp) SHIP(h, hipMemcpy(logp + o, h->s_out2, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -917,7 +918,7 @@ DRIL_EXPORT int32_t dril_sac_predict_actions(dril_sac_handle* h, const float* ob
         const int n = (int)std::min<int64_t>(h->nmax, batch - o);
         SDO(actor_chunk(h, obs + o * h->D, noise ? noise + o * h->A : nullptr, n, deterministic, o));
         hipLaunchKernelGGL(sac_squash_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, h->A, h->mu, h->params + h->log_std_off, h->s_noise, deterministic,
-                           -2.0f, 2.0f, h->s_out, (float*)nullptr, h->s_out2);
+                           -h->act_hi, h->act_hi, h->s_out, (float*)nullptr, h->s_out2);
         SDO(ssync(h));
         if (raw) SHIP(h, hipMemcpy(raw + o * h->A, h->s_out, (size_t)n * h->A * 4, hipMemcpyDeviceToHost));
         if (env) SHIP(h, hipMemcpy(env + o * h->A, h->s_out2, (size_t)n * h->A * 4, hipMemcpyDeviceToHost));

@@ -83,6 +83,49 @@ class PendulumEnv:
         return Box((-2.0,), (2.0,))
 
 
+@dataclass
+class ScalingWrapperEnv:
+    """ScalingWrapperEnv(env) (src/environment_wrappers/scalingWrapperEnv.jl:15-49) around a Box/Box env: the agent-facing spaces become
+    [-1, 1]; on device the two affine maps are fused into the env kernels (env kind DRIL_ENV_PENDULUM_SCALED)."""
+    env: PendulumEnv
+
+    def __post_init__(self):
+        if not isinstance(self.env, PendulumEnv):
+            raise NotImplementedError("ScalingWrapperEnv needs Box observation and action spaces (scalingWrapperEnv.jl:22); the device env with both is Pendulum-v1")
+
+    @property
+    def max_steps(self) -> int:
+        return self.env.max_steps
+
+    @property
+    def kind(self) -> int:
+        return capi.ENV_PENDULUM_SCALED
+
+    def unwrap(self):
+        return self.env
+
+    def observation_space(self):
+        n = len(self.env.observation_space().low)
+        return Box((-1.0,) * n, (1.0,) * n)
+
+    def action_space(self):
+        n = len(self.env.action_space().low)
+        return Box((-1.0,) * n, (1.0,) * n)
+
+    # scale! / unscale! (:71-79) on host arrays, for callers that want the original units back
+    def scale_observation(self, obs):
+        lo, hi = (np.asarray(v, np.float32) for v in (self.env.observation_space().low, self.env.observation_space().high))
+        return (np.asarray(obs, np.float32) - lo) * (np.float32(2) / (hi - lo)) - np.float32(1)
+
+    def unscale_observation(self, obs):
+        lo, hi = (np.asarray(v, np.float32) for v in (self.env.observation_space().low, self.env.observation_space().high))
+        return (np.asarray(obs, np.float32) + np.float32(1)) / (np.float32(2) / (hi - lo)) + lo
+
+    def unscale_action(self, act):
+        lo, hi = (np.asarray(v, np.float32) for v in (self.env.action_space().low, self.env.action_space().high))
+        return (np.asarray(act, np.float32) + np.float32(1)) / (np.float32(2) / (hi - lo)) + lo
+
+
 # --------------------------------------------------------------------------------------------
 # PPO (src/algorithms/ppo.jl:25-40)
 # --------------------------------------------------------------------------------------------

@@ -50,7 +50,7 @@ struct DrilPPOStats
     n_updates::Int32; early_stopped::Int32; nan_or_inf::Int32; reserved::Int32
 end
 
-const ENV_KINDS = Dict(:CartPole => Int32(0), :Pendulum => Int32(1))
+const ENV_KINDS = Dict(:CartPole => Int32(0), :Pendulum => Int32(1), :ScaledPendulum => Int32(2))   # :ScaledPendulum = ScalingWrapperEnv(PendulumEnv()) on every sub-env (scalingWrapperEnv.jl)
 
 """
     DeviceParallelEnv(kind, n_envs; max_steps, seed, fixed_length_episodes, device) <: AbstractParallelEnv
@@ -87,8 +87,8 @@ end
 number_of_envs(env::DeviceParallelEnv) = env.n_envs
 observation_space(env::DeviceParallelEnv) = env.kind === :CartPole ?
     Box(Float32[-4.8, -Inf, -0.41887903, -Inf], Float32[4.8, Inf, 0.41887903, Inf]) :
-    Box(Float32[-1, -1, -8], Float32[1, 1, 8])
-action_space(env::DeviceParallelEnv) = env.kind === :CartPole ? Discrete(2) : Box(Float32[-2], Float32[2])
+    env.kind === :ScaledPendulum ? Box(Float32[-1, -1, -1], Float32[1, 1, 1]) : Box(Float32[-1, -1, -8], Float32[1, 1, 8])
+action_space(env::DeviceParallelEnv) = env.kind === :CartPole ? Discrete(2) : env.kind === :ScaledPendulum ? Box(Float32[-1], Float32[1]) : Box(Float32[-2], Float32[2])
 obs_dim(env::DeviceParallelEnv) = env.kind === :CartPole ? 4 : 3
 
 last_error(h) = unsafe_string(ccall((:dril_last_error, LIB[]), Cstring, (Ptr{Cvoid},), h))
@@ -379,7 +379,7 @@ function sac_scatter_targets!(tp, flat::Vector{Float32})
 end
 
 function sac_config(env::DeviceParallelEnv, alg::DRiL.SAC, agent)
-    env.kind === :Pendulum || error("SAC needs a Box action space (sac.jl:74): DeviceParallelEnv(:Pendulum, ...)")
+    env.kind === :CartPole && error("SAC needs a Box action space (sac.jl:74): DeviceParallelEnv(:Pendulum | :ScaledPendulum, ...)")
     hd = hidden_dims_of(agent.train_state.parameters)
     act = agent.layer.actor_head.layers[1].layers[1].activation === DRiL.Lux.relu ? Int32(1) : Int32(0)   # SACLayer default relu (sac.jl:77)
     ec = alg.ent_coef

@@ -21,7 +21,7 @@ import numpy as np
 
 from . import _capi as capi
 from ._capi import DrilSacConfig, DrilSacStats
-from .host import Box, DrilError, PendulumEnv, _orthogonal
+from .host import Box, DrilError, PendulumEnv, ScalingWrapperEnv, _orthogonal
 
 
 # --------------------------------------------------------------------------------------------
@@ -135,11 +135,11 @@ def sac_unflatten_params(flat: np.ndarray, like: dict) -> dict:
 
 def make_sac_config(env, n_envs: int, alg: SAC, layer: SACLayer, *, seed: int = 42, device: int = 0,
                     profile_events: bool = False) -> DrilSacConfig:
-    if not isinstance(env, PendulumEnv):
-        raise NotImplementedError("SAC needs a Box action space (sac.jl:74); the device env with one is Pendulum-v1")
+    if not isinstance(env, (PendulumEnv, ScalingWrapperEnv)):
+        raise NotImplementedError("SAC needs a Box action space (sac.jl:74); the device env with one is Pendulum-v1 (optionally under ScalingWrapperEnv)")
     c = DrilSacConfig()
     c.abi_version = capi.SAC_ABI_VERSION
-    c.env_kind, c.n_envs, c.episode_len = capi.ENV_PENDULUM, n_envs, env.max_steps
+    c.env_kind, c.n_envs, c.episode_len = env.kind, n_envs, env.max_steps
     c.hidden1, c.hidden2 = layer.hidden_dims
     c.activation = {"tanh": 0, "relu": 1}[layer.activation]
     c.buffer_capacity, c.start_steps, c.batch_size = alg.buffer_capacity, alg.start_steps, alg.batch_size

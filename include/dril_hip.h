@@ -49,7 +49,11 @@ enum dril_status {
 
 enum dril_env_kind {
     DRIL_ENV_CARTPOLE = 0, /* CartPole-v1: D=4, Discrete(2)            */
-    DRIL_ENV_PENDULUM = 1  /* Pendulum-v1: D=3, Box(-2,2) 1-dim action */
+    DRIL_ENV_PENDULUM = 1, /* Pendulum-v1: D=3, Box(-2,2) 1-dim action */
+    /* ScalingWrapperEnv(PendulumEnv()) (src/environment_wrappers/scalingWrapperEnv.jl:15-49): every sub-env is wrapped, so the agent sees
+     * observation_space = action_space = Box(-1, 1): observe returns (obs - low) * 2/(high - low) - 1 (:71-74,93-98) and act! maps the
+     * action back with (a + 1) / (2/(high - low)) + low (:76-79,110-113) before the physics; the affine maps are fused into the env kernels */
+    DRIL_ENV_PENDULUM_SCALED = 2
 };
 
 /* ids for dril_buffer_copy_out / dril_buffer_copy_in (fields of RolloutBuffer,

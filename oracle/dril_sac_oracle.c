@@ -120,7 +120,7 @@ ORC_API int32_t orc_sac_reset_optimizer(orc_sac* c) {
     c->ent_m = c->ent_v = 0; c->grad_updates = 0; return DRIL_OK;
 }
 ORC_API int32_t orc_sac_create(const dril_sac_config* cfg, orc_sac** out) {
-    if (!cfg || cfg->abi_version != DRIL_SAC_ABI_VERSION || cfg->env_kind != DRIL_ENV_PENDULUM) return DRIL_ERR_INVALID_ARG;
+    if (!cfg || cfg->abi_version != DRIL_SAC_ABI_VERSION || (cfg->env_kind != DRIL_ENV_PENDULUM && cfg->env_kind != DRIL_ENV_PENDULUM_SCALED)) return DRIL_ERR_INVALID_ARG;
     orc_sac* c = (orc_sac*)calloc(1, sizeof(orc_sac)); c->cfg = *cfg; c->es = spec_of(cfg->env_kind);
     const int D = c->D = c->es.D, A = c->A = c->es.A, H1 = c->H1 = cfg->hidden1, H2 = c->H2 = cfg->hidden2, E = cfg->n_envs;
     c->actor = net_at(0, D, H1, H2, A); c->q[0] = net_at(c->actor.end, D + A, H1, H2, 1); c->q[1] = net_at(c->q[0].end, D + A, H1, H2, 1);
@@ -188,7 +188,7 @@ ORC_API int32_t orc_sac_action_log_prob(orc_sac* c, const float* obs, int64_t B,
  * scale_to_space spaces.jl:134-139 with Box(-2, 2) */
 ORC_API int32_t orc_sac_predict_actions(orc_sac* c, const float* obs, int64_t B, int32_t deterministic, const float* noise, float* raw, float* env) {
     const int D = c->D, A = c->A, act = c->cfg.activation;
-    const float low = -2.0f, high = 2.0f;
+    const float high = act_bound(c->es.kind), low = -high;
 #pragma omp parallel if (B >= 256)
     {
         float* h1 = (float*)malloc(4 * c->H1); float* h2 = (float*)malloc(4 * c->H2); float mu[ORC_MAX_OUT], a[ORC_MAX_OUT];
@@ -261,7 +261,7 @@ ORC_API int32_t orc_sac_collect_rollout(orc_sac* c, int32_t n_steps, int32_t use
     if (c->collect_noise && c->collect_noise_count != (size_t)n_steps * E * A) return DRIL_ERR_INVALID_ARG;
     float* obs = (float*)malloc((size_t)E * D * 4); float* nobs = (float*)malloc((size_t)E * D * 4); float* nz = (float*)malloc((size_t)E * A * 4);
     float* raw = (float*)malloc((size_t)E * A * 4); float* envact = (float*)malloc((size_t)E * A * 4);
-    const float low = -2.0f, high = 2.0f;
+    const float high = act_bound(c->es.kind), low = -high;
     orc_sac_env_observe(c, obs);                                                              /* :41 */
     for (int t = 0; t < n_steps; ++t) {
         if (c->collect_noise) memcpy(nz, c->collect_noise + (size_t)t * E * A, (size_t)E * A * 4);

@@ -60,7 +60,7 @@ def test_gae_random_vs_oracle(pkg, lib, oracle_mod):
         np.testing.assert_allclose(out[1], out[3], atol=1e-4, rtol=1e-5)
 
 
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind", [0, 1, 2])                       # 2 = ScalingWrapperEnv(Pendulum): affine maps fused into the env kernels
 def test_env_verbs_match_oracle(pkg, oracle_mod, kind):
     """reset!/observe/act! with auto-reset and terminal_observation (multithreadedParallelEnv.jl:12-74)"""
     cfg = _cfg(pkg, kind, n_envs=300, n_steps=4, episode_len=7, batch_size=4)
@@ -121,7 +121,7 @@ def _rollout_pair(pkg, oracle_mod, kind, E, T, L, seed, fixed=False):
     return cfg, h, o
 
 
-@pytest.mark.parametrize("kind,E,T,L,fixed", [(0, 64, 48, 500, False), (0, 100, 40, 9, True), (1, 33, 50, 12, False), (0, 1, 5, 3, False)])
+@pytest.mark.parametrize("kind,E,T,L,fixed", [(0, 64, 48, 500, False), (0, 100, 40, 9, True), (1, 33, 50, 12, False), (0, 1, 5, 3, False), (2, 40, 30, 12, False)])
 def test_collect_rollout_matches_oracle(pkg, oracle_mod, kind, E, T, L, fixed):
     """collect_rollout! (rollout_buffer.jl:46-90): every buffer field vs the trajectory-based oracle, with injected
     sampling noise and with the shared Philox stream; includes terminations, mid-rollout truncations with
@@ -227,6 +227,7 @@ def test_apply_gradients_clip_adam_nan(pkg, oracle_mod):
     (0, 16, 24, 64, {}),
     (0, 10, 13, 16, {}),                                   # N = 130: ragged last minibatch of 2 kept (MLUtils partial=true)
     (1, 12, 20, 60, {"ent_coef": 0.01}),
+    (2, 12, 20, 60, {}),                                   # ScalingWrapperEnv(Pendulum): the update shares the Pendulum kernels
     (0, 16, 24, 96, {"has_target_kl": 1, "target_kl": 0.002}),
     (0, 16, 24, 384, {"has_clip_range_vf": 1, "clip_range_vf": 0.2}),
 ])
@@ -355,7 +356,7 @@ def test_rccl_plumbing_single_rank(pkg, oracle_mod, monkeypatch):
     np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=5e-4, atol=5e-6)
 
 
-@pytest.mark.parametrize("kind,flags", [(1, (1, 1)), (0, (1, 1)), (1, (1, 0)), (1, (0, 1))])
+@pytest.mark.parametrize("kind,flags", [(1, (1, 1)), (0, (1, 1)), (1, (1, 0)), (1, (0, 1)), (2, (1, 1))])   # last: Normalize(Parallel([Scaling(Pendulum)]))
 def test_normalize_wrapper_rollout_matches_oracle(pkg, oracle_mod, kind, flags):
     """NormalizeWrapperEnv on device (normalizeWrapperEnv.jl:21-50,123-197): running obs/return statistics (updated on EVERY
     observe, including the double update at a rollout boundary), normalised + clipped obs and rewards, normalised
@@ -626,7 +627,7 @@ def test_monitor_off_is_an_error(pkg):
 
 
 @pytest.mark.parametrize("kind,det,kw", [(0, True, {}), (0, False, {}), (1, True, dict(norm_training=1, norm_obs=1, norm_reward=1, monitor_window=50)),
-                                         (1, False, dict(norm_training=1, norm_obs=1, norm_reward=1))])
+                                         (1, False, dict(norm_training=1, norm_obs=1, norm_reward=1)), (2, True, dict(monitor_window=20))])
 def test_evaluate_agent(pkg, oracle_mod, kind, det, kw):
     """evaluate_agent (src/evaluation.jl:54-143): reset, predict(deterministic) / act! / observe until the first n episodes finish,
     mean / corrected std of returns and lengths; monitored envs report RAW returns"""
@@ -662,3 +663,29 @@ def test_host_mirror_evaluate_and_wrappers(pkg):
         pkg.evaluate_agent(agent, env, n_eval_episodes=5, reward_threshold=1e9)
     r, l, n = env.handle.monitor_stats()
     assert n == 20 and r == l
+
+
+def test_scaling_wrapper_is_pendulum_in_other_units(pkg):
+    """ScalingWrapperEnv(Pendulum) vs plain Pendulum on device: same simulator state trajectory when the wrapper-space action a is the torque
+    2a; observations differ by exactly the affine map (scalingWrapperEnv.jl:71-79); wide [256,256] rollout runs on the wrapped env too"""
+    capi = pkg._capi
+    w = pkg.ScalingWrapperEnv(pkg.PendulumEnv())
+    ca, cb = _cfg(pkg, 1, n_envs=200, n_steps=4, episode_len=6, batch_size=8), _cfg(pkg, 2, n_envs=200, n_steps=4, episode_len=6, batch_size=8)
+    a, b = pkg.Handle(ca), pkg.Handle(cb)
+    a.env_reset(3); b.env_reset(3)
+    rng = np.random.default_rng(0)
+    for _ in range(8):
+        np.testing.assert_allclose(b.env_observe(), w.scale_observation(a.env_observe()), atol=1e-6)
+        act = rng.uniform(-1.2, 1.2, (200, 1)).astype(np.float32)
+        ra, ta, ua, xa = a.env_step(np.clip(w.unscale_action(act), -2, 2)); rb, tb, ub, xb = b.env_step(act)
+        np.testing.assert_allclose(rb, ra, rtol=1e-5, atol=1e-5); np.testing.assert_array_equal(ub, ua)
+        np.testing.assert_allclose(xb[ub], w.scale_observation(xa[ua]), atol=1e-6)
+        sa, _ = a.env_get_state(); sb, _ = b.env_get_state()
+        np.testing.assert_allclose(sb, sa, rtol=1e-5, atol=1e-5)
+    env = pkg.DeviceParallelEnv(w, 256, seed=1)
+    alg = pkg.PPO(n_steps=16, batch_size=1024, epochs=2)
+    agent = pkg.Agent(pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(256, 256)), alg)
+    stats, _ = pkg.train_(agent, env, alg, 2 * 16 * 256)
+    assert len(stats["losses"]) == 2 and np.isfinite(stats["losses"]).all()
+    obs = env.handle.buffer(capi.BUF_OBSERVATIONS)
+    assert np.abs(obs).max() <= 1.0 + 1e-6                                                  # every observation inside the wrapper's Box(-1, 1)

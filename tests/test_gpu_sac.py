@@ -15,8 +15,10 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-def make_pair(pkg, E=8, hidden=(32, 32), B=16, cap=4096, act="relu", seed=7, max_steps=200, **alg_kw):
+def make_pair(pkg, E=8, hidden=(32, 32), B=16, cap=4096, act="relu", seed=7, max_steps=200, scaled=False, **alg_kw):
     env = pkg.PendulumEnv(max_steps=max_steps)
+    if scaled:
+        env = pkg.ScalingWrapperEnv(env)
     alg = pkg.SAC(batch_size=B, buffer_capacity=cap, **alg_kw)
     layer = pkg.SACLayer(env.observation_space(), env.action_space(), hidden_dims=hidden, activation=act)
     cfg = pkg.make_sac_config(env, E, alg, layer, seed=seed)
@@ -125,10 +127,12 @@ def test_many_updates_in_one_call_and_reset_optimizer(pkg):
     close(h.get_params(), o.get_params(), rtol=2e-4, atol=5e-6)
 
 
-def test_collect_matches_oracle(pkg):
-    """off_policy_collection.jl:28-96 with injected noise: the replay contents agree field by field, through a truncation and a ring wrap"""
+@pytest.mark.parametrize("scaled", [False, True])
+def test_collect_matches_oracle(pkg, scaled):
+    """off_policy_collection.jl:28-96 with injected noise: the replay contents agree field by field, through a truncation and a ring wrap;
+    scaled = under ScalingWrapperEnv (TanhScaleAdapter then maps onto the wrapper's Box(-1, 1))"""
     E, L = 50, 5
-    h, o, layer, _ = make_pair(pkg, E=E, max_steps=L, cap=400)
+    h, o, layer, _ = make_pair(pkg, E=E, max_steps=L, cap=400, scaled=scaled)
     flat = init_params(pkg, layer)
     rng = np.random.default_rng(2)
     for x in (h, o):

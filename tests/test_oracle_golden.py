@@ -106,3 +106,49 @@ def test_rollout_logprob_value_consistency(oracle_mod, pkg):
         assert np.array_equal(np.sort(o.ref_order()), np.arange(o.N))
         flags = o.buffer(capi.BUF_FLAGS)
         assert (flags & 2).sum() >= 2 * cfg.n_envs   # episode_len 17 over 40 steps: two truncations per env
+
+
+def test_scaling_wrapper_known_answers(pkg, oracle_mod):
+    """the reference's own ScalingWrapperEnv cases (test/test_scaling_wrapper.jl:42-130,208-244) through the oracle's scale!/unscale!
+    restatement (scalingWrapperEnv.jl:71-79) and through the host mirror's helpers"""
+    import ctypes as C
+    import json
+    from pathlib import Path
+    G = json.loads((Path(__file__).parent / "golden" / "scaling_kats.json").read_text())
+    L = oracle_mod.lib()
+    for fn in (L.orc_scale, L.orc_unscale):
+        fn.restype = None; fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    for kind, fn in (("observation", L.orc_scale), ("action", L.orc_unscale)):
+        for c in G[kind]:
+            x, lo, hi = (np.array(c[k], np.float32) for k in ("x", "low", "high"))
+            fn(x.ctypes.data, lo.ctypes.data, hi.ctypes.data, x.size)
+            np.testing.assert_allclose(x, c["expected"], atol=c["atol"], rtol=0)
+    w = pkg.ScalingWrapperEnv(pkg.PendulumEnv())
+    assert w.observation_space() == pkg.Box((-1.0,) * 3, (1.0,) * 3) and w.action_space() == pkg.Box((-1.0,), (1.0,))      # :26-33
+    np.testing.assert_allclose(w.scale_observation([1.0, -1.0, 0.0]), [1.0, -1.0, 0.0], atol=1e-7)
+    np.testing.assert_allclose(w.unscale_observation(w.scale_observation([0.3, -0.7, 5.0])), [0.3, -0.7, 5.0], atol=1e-6)
+    np.testing.assert_allclose(w.unscale_action([-1.0, 0.0, 0.25, 1.0]), [-2.0, 0.0, 0.5, 2.0], atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        pkg.ScalingWrapperEnv(pkg.CartPoleEnv())                      # Box / Box only (scalingWrapperEnv.jl:22)
+
+
+def test_scaled_pendulum_oracle_semantics(pkg, oracle_mod):
+    """ScalingWrapperEnv(Pendulum) in the oracle: observations are the scaled Pendulum observations, a wrapper-space action a is the torque
+    2a, and the rollout stores raw actions while the env sees the ClampAdapter'ed action of the wrapper's Box(-1,1)"""
+    capi = pkg._capi
+    def mk(kind):
+        c = capi.default_config(kind); c.n_envs, c.n_steps, c.episode_len, c.batch_size = 6, 4, 3, 24
+        o = oracle_mod.Oracle(c); o.env_reset(5); return o
+    a, b = mk(capi.ENV_PENDULUM), mk(capi.ENV_PENDULUM_SCALED)
+    oa, ob = a.env_observe(), b.env_observe()
+    w = pkg.ScalingWrapperEnv(pkg.PendulumEnv())
+    np.testing.assert_allclose(ob, w.scale_observation(oa), atol=1e-7)
+    act = np.linspace(-1.3, 1.3, 6, dtype=np.float32).reshape(6, 1)
+    ra, ta, ua, xa = a.env_step(np.clip(2 * act, -2, 2))
+    rb, tb, ub, xb = b.env_step(act)
+    np.testing.assert_allclose(rb, ra, rtol=1e-6, atol=1e-6); np.testing.assert_array_equal(ub, ua)
+    np.testing.assert_allclose(b.env_observe(), w.scale_observation(a.env_observe()), atol=1e-6)
+    for _ in range(2):
+        ra, ta, ua, xa = a.env_step(np.zeros((6, 1), np.float32)); rb, tb, ub, xb = b.env_step(np.zeros((6, 1), np.float32))
+    assert ub.all()
+    np.testing.assert_allclose(xb, w.scale_observation(xa), atol=1e-6)                          # terminal observation passes through the wrapper too
