@@ -751,7 +751,7 @@ __global__ void pack_records_kernel(int64_t N, const float* __restrict__ obs, co
 // one lane's share of a minibatch tile (DataLoader gather, ppo.jl:188-195).  Loaded one tile AHEAD of its use so the
 // random-gather latency (~2 us under load, fully exposed in v1: 23 % of wave time in s_waitcnt) hides under the
 // previous tile's MFMAs; the loop body issues no other vector-memory op, so the loads stay in flight until first use.
-template <int O> struct TileIn { float xk[2]; float s0, s1; int act; float xa[O]; bool valid; float4 raw; };
+template <int O> struct TileIn { float xk[2]; float s0, s1; int act; float xa[O]; bool valid; float4 raw; float s1c; };   // s1c: old value (dual kernel, clip_range_vf)
 
 template <int KIND, int O, int HEAD, bool REC>
 __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64_t ntiles, int c, int h, TileIn<O>& t) {
@@ -769,6 +769,7 @@ __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64
         // lane (sample, h) loads half h of the record; t.raw is exchanged between the half-waves at first use (unpack_tile)
         t.raw = a.rec[2 * idx + h];
         if (HEAD == HEAD_VALUE && a.has_clip_vf) t.s1 = a.val_old[idx];
+        t.s1c = (a.layout == 2 && a.has_clip_vf) ? a.val_old[idx] : 0.f;
         return;
     }
 #pragma unroll
@@ -1139,6 +1140,315 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_kernel(GradArgs a) {
     const bool actor = a.layout ? (blockIdx.x < (unsigned)a.G) : ((blockIdx.x & 1) == 0);
     if (actor) grad_body<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN, REC>(a, smem);
     else grad_body<KIND, H, 1, HEAD_VALUE, REC>(a, smem);
+}
+
+// =============================================================================================
+// ppo_grad_dual_kernel (GradArgs.layout == 2) — ONE wave runs BOTH nets on the same 32-sample tile, software-pipelined so that
+// the matrix-core stages of one net sit in the same scheduling region as the VALU / LDS stages of the other:
+//     region 1:  critic.back(k-1) [dh1, dW2, dW1: 144 MFMA]   +   actor.front(k) [L1, tanh, L2: 64 MFMA, head, dW3, dz2]
+//     region 2:  actor.back(k)    [144 MFMA]                  +   critic.front(k)
+// One workgroup (4 waves = 1 wave per SIMD, up to 512 registers) per CU holds both weight images and both per-wave scratch sets in
+// LDS (157 KB).  Versus two co-resident single-net workgroups (ppo_grad_kernel) the overlap no longer depends on how the hardware
+// happens to arbitrate two independent waves, and the minibatch record is gathered once for both nets instead of twice.
+// =============================================================================================
+template <int H, int O> struct GradAcc {
+    static constexpr int MT = H / 32;
+    f32x16 dW2[MT][MT]; f32x4 dW1[H / 16]; float dW3a[O][MT], db2p[MT], db3p[O], dlsp[O], st[5];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < H / 16; ++i) dW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            db2p[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dW2[i][j][r] = 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            db3p[o] = 0.f; dlsp[o] = 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) dW3a[o][m] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) st[i] = 0.f;
+    }
+};
+template <int H> struct GradTile {
+    static constexpr int MT = H / 32;
+    f32x16 h1[MT], h2[MT]; float xk[2];      // after front(): h1 = layer-1 activations, h2 = dz2
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { h1[m][r] = 0.f; h2[m][r] = 0.f; }
+        xk[0] = xk[1] = 0.f;
+    }
+};
+
+// grad_front_a: layers 1-2 of one net on one tile (h1, h2 in registers, h2 image in LDS); grad_front_b: output layer, loss head,
+// output-layer backward — leaves h1 and dz2 (in t.h2) for grad_back
+template <int D, int H, int O>
+__device__ __forceinline__ void grad_front_a(const float* __restrict__ wl, float* __restrict__ T, const float (&xin)[2], GradTile<H>& t, int lane) {
+    constexpr int MT = H / 32;
+    using L = NetLds<D, H, H, O>;
+    t.xk[0] = xin[0]; t.xk[1] = xin[1];
+    struct { float xk[2]; } cur{{xin[0], xin[1]}};
+    float xk[2] = {cur.xk[0], cur.xk[1]};
+    dense_first<H, MT>(wl + L::W1T, wl + L::B1, xk, t.h1, lane);
+    tanh_tiles(t.h1);
+#pragma unroll
+    for (int mo = 0; mo < MT; ++mo) {
+        t.h2[mo] = dense_mfma_tile<MT, true>(wl + L::W2S, L::WS1, wl + L::B2, t.h1, mo, lane);
+        tanh16(t.h2[mo]);
+    }
+    store_image<MT>(T, t.h2, lane);
+}
+template <int D, int H, int O, int HEAD>
+__device__ __forceinline__ void grad_front_b(const GradArgs& a, const float* __restrict__ wl, float* __restrict__ T, float* __restrict__ ZI,
+                                             const TileIn<O>& cur, const float* ls, float adv_mean, float adv_inv, GradAcc<H, O>& acc, GradTile<H>& t, int lane) {
+    constexpr int MT = H / 32;
+    using L = NetLds<D, H, H, O>;
+    const int c = lane & 31, h = lane >> 5;
+    float out[O], dz[O];
+    dense_out<MT, O, H>(wl + L::W3S, wl + L::B3, t.h2, out, lane);
+    loss_head<O, HEAD>(a, cur, out, cur.valid, h == 0, ls, adv_mean, adv_inv, dz, acc.st, acc.dlsp);
+#pragma unroll
+    for (int o = 0; o < O; ++o) { if (h == 0) { acc.db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
+    {   // dW3 += dz * h2' over samples (h2 read back transposed: hidden on the lane)
+        f32x16 Bh2[MT];
+#pragma unroll
+        for (int mj = 0; mj < MT; ++mj) Bh2[mj] = load_operand(T, mj, lane);
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float s[MT];
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj) s[mj] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 z = *reinterpret_cast<const f32x4*>(ZI + o * kTS + 16 * h + 4 * q);
+#pragma unroll
+                for (int mj = 0; mj < MT; ++mj) {
+                    s[mj] = fmaf(Bh2[mj][4 * q + 0], z[0], s[mj]); s[mj] = fmaf(Bh2[mj][4 * q + 1], z[1], s[mj]);
+                    s[mj] = fmaf(Bh2[mj][4 * q + 2], z[2], s[mj]); s[mj] = fmaf(Bh2[mj][4 * q + 3], z[3], s[mj]);
+                }
+            }
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj) acc.dW3a[o][mj] += s[mj];
+        }
+    }
+    // dz2 = (W3' dz) .* (1 - h2^2), in h2's registers
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float dh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * m + 8 * q + 4 * h);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(w[cc], dz[o], dh[cc]);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) { const float hv = t.h2[m][4 * q + cc]; t.h2[m][4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
+        }
+}
+// hidden-layer backward of one net on one tile: dh1 = W2' dz2, dz1, dW2 += dz2 h1', db2, dW1 | db1 += dz1 [x; 1]'
+template <int D, int H, int O>
+__device__ __forceinline__ void grad_back(const float* __restrict__ wl, float* __restrict__ T, float* __restrict__ XI, GradAcc<H, O>& acc, GradTile<H>& t, int lane) {
+    constexpr int MT = H / 32;
+    using L = NetLds<D, H, H, O>;
+    const int c = lane & 31, h = lane >> 5;
+    store_image<MT>(T, t.h1, lane);
+    f32x16 g1[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        g1[m] = dense_mfma_tile<MT, false>(wl + L::W2T, L::WS2, nullptr, t.h2, m, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g1[m][r] = g1[m][r] * (1.0f - t.h1[m][r] * t.h1[m][r]);
+    }
+    {
+        f32x16 Bh[MT];
+#pragma unroll
+        for (int mj = 0; mj < MT; ++mj) Bh[mj] = load_operand(T, mj, lane);
+        store_image<MT>(T, t.h2, lane);                                    // dz2 image
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const f32x16 Az = load_operand(T, mi, lane);
+            acc.db2p[mi] += sum16(Az);
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj) acc.dW2[mi][mj] = mfma_outer(Az, Bh[mj], acc.dW2[mi][mj]);
+        }
+    }
+    store_image<MT>(T, g1, lane);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) XI[d * kTS + c] = t.xk[s]; }
+    {
+        const int j = lane & 15;
+        float bx[8];
+        load_row8(XI, j <= D ? j : D + 1, lane, bx);
+#pragma unroll
+        for (int mt = 0; mt < H / 16; ++mt) {
+            float az[8];
+            load_row8(T, 16 * mt + j, lane, az);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc.dW1[mt] = mfma16(az[k], bx[k], acc.dW1[mt]);
+        }
+    }
+}
+// 4 waves -> one slab (fixed wave order => deterministic); same slab layout as grad_body's epilogue
+template <int D, int H, int O, int HEAD>
+__device__ __forceinline__ void grad_slab(float* __restrict__ red, float* __restrict__ slab, int SL, const GradAcc<H, O>& acc, int tid, int wave, int lane) {
+    constexpr int MT = H / 32;
+    const int c = lane & 31, h = lane >> 5;
+    const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
+    const int o_ls = o_b3 + O, o_st = SL - 8;
+    for (int i = tid; i < SL; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * mi + rowfn(r, h);
+#pragma unroll
+                    for (int mj = 0; mj < MT; ++mj) red[o_w2 + row + (32 * mj + c) * H] += acc.dW2[mi][mj][r];
+                }
+                const float b2 = acc.db2p[mi] + __shfl_xor(acc.db2p[mi], 32);
+                if (h == 0) red[o_b2 + 32 * mi + c] += b2;
+            }
+#pragma unroll
+            for (int mt = 0; mt < H / 16; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * mt + 4 * (lane >> 4) + r, col = lane & 15;
+                    if (col < D) red[o_w1 + row + col * H] += acc.dW1[mt][r];
+                    else if (col == D) red[o_b1 + row] += acc.dW1[mt][r];
+                }
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float v = acc.dW3a[o][m] + __shfl_xor(acc.dW3a[o][m], 32);
+                    if (h == 0) red[o_w3 + o + (32 * m + c) * O] += v;
+                }
+                const float b3 = half_sum(acc.db3p[o]);
+                if (lane == 0) red[o_b3 + o] += b3;
+                if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(acc.dlsp[o]); if (lane == 0) red[o_ls + o] += l; }
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { const float v = half_sum(acc.st[k]); if (lane == 0) red[o_st + k] += v; }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < SL; i += blockDim.x) slab[i] = red[i];
+    __syncthreads();
+}
+
+// scheduling hint for a region that holds one net's matrix-core stage and the other net's VALU stage: ask for N x {1 MFMA, V VALU}
+// (sched_group_barrier masks: 0x008 MFMA, 0x002 VALU incl. transcendental); LDS ops are left to float.
+// Measured (profiles/r01_dual_kernel.md): without hints the scheduler keeps the two nets' stages almost sequential (96 TFLOP/s, no
+// spills); with 144 x {1, 4} it interleaves for ~40 MFMAs, then falls back, and the longer live ranges spill 72 VGPRs (83 TFLOP/s).
+// Hints are therefore OFF (N = 0); the two-workgroup layout (111 TFLOP/s) stays the default.
+constexpr int kDualMfma = 0, kDualValuPerMfma = 4;
+template <int N, int V> __device__ __forceinline__ void mfma_valu_pipeline() {
+#pragma unroll
+    for (int i = 0; i < N; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, V, 0); }
+}
+
+template <int KIND, int H> struct DualLds {
+    static constexpr int D = EnvSpec<KIND>::D, OA = EnvSpec<KIND>::A;
+    using LA = NetLds<D, H, H, OA>; using LC = NetLds<D, H, H, 1>;
+    using SA = GradScratch<D, H, OA>; using SC = GradScratch<D, H, 1>;
+    static constexpr int WA = 0, WC = (LA::BWD_END + 3) / 4 * 4, SCR = WC + (LC::BWD_END + 3) / 4 * 4;
+    static constexpr int PER_WAVE = SA::SIZE + SC::SIZE;
+    static constexpr int SIZE = SCR + 4 * PER_WAVE;
+    static_assert(sizeof(float) * SIZE <= 160 * 1024, "dual-net workgroup must fit the 160 KB LDS of one CU");
+    static_assert(4 * PER_WAVE >= 2 * (2 * H * H + 8 * H), "the epilogue's slab image overlays the per-wave scratch");
+};
+
+template <int KIND, int H>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ppo_grad_dual_kernel(GradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (*a.stop_flag) return;
+    constexpr int D = EnvSpec<KIND>::D, OA = EnvSpec<KIND>::A;
+    constexpr int HEADA = EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN;
+    using DL = DualLds<KIND, H>;
+    using SA = typename DL::SA; using SC = typename DL::SC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    float* wlA = smem + DL::WA; float* wlC = smem + DL::WC;
+    float* scr = smem + DL::SCR + wave * DL::PER_WAVE;
+    float *TA = scr + SA::T, *XIA = scr + SA::XI, *ZIA = scr + SA::ZI;
+    float *TC = scr + SA::SIZE + SC::T, *XIC = scr + SA::SIZE + SC::XI, *ZIC = scr + SA::SIZE + SC::ZI;
+    stage_net<D, H, H, OA, true>(wlA, a.params, a.actor, tid, blockDim.x);
+    stage_net<D, H, H, 1, true>(wlC, a.params, a.critic, tid, blockDim.x);
+    for (int i = lane; i < DL::PER_WAVE; i += 64) scr[i] = 0.f;                       // images start at zero: the pipeline's first critic.back() adds nothing
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int i = lane; i < (D + 2) * kTS; i += 64) { const float v = (i / kTS == D) ? 1.0f : 0.0f; XIA[i] = v; XIC[i] = v; }
+    __syncthreads();
+
+    float adv_mean = 0.f, adv_den = 1.f;                                              // ppo.jl:350-356
+    if (a.normalize_adv) {
+        const double s = a.adv_stats[0], q = a.adv_stats[1], n = a.adv_stats[2];
+        const double mean = s / n;
+        double var = (q - s * mean) / (n - 1.0);
+        if (var < 0) var = 0;
+        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
+    }
+    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
+    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
+    const float* ls = a.params + a.log_std_off;
+
+    GradAcc<H, OA> accA; GradAcc<H, 1> accC; accA.zero(); accC.zero();
+    GradTile<H> tA, tC; tA.zero(); tC.zero();
+    const int g = blockIdx.x;
+    const int64_t ntiles = (a.count + kTile - 1) / kTile, tstride = (int64_t)a.G * 4;
+    int64_t tile = (int64_t)g * 4 + wave;
+    TileIn<OA> cur, nxt;
+    if (tile < ntiles) load_tile<KIND, OA, HEADA, true>(a, tile, ntiles, c, h, cur);
+    for (; tile < ntiles; tile += tstride) {
+        load_tile<KIND, OA, HEADA, true>(a, tile + tstride, ntiles, c, h, nxt);      // prefetch the next tile's record (one gather serves both nets)
+        // unpack: the two half-waves exchange the record halves (see unpack_tile)
+        float lo[4], hi[4];
+        {
+            const float v[4] = {cur.raw.x, cur.raw.y, cur.raw.z, cur.raw.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned u = __float_as_uint(v[i]);
+                const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                lo[i] = __uint_as_float(r[0]); hi[i] = __uint_as_float(r[1]);
+            }
+        }
+        cur.xk[0] = h ? lo[1] : lo[0]; cur.xk[1] = h ? lo[3] : lo[2];
+        cur.s0 = hi[1]; cur.s1 = hi[2];
+        if (HEADA == HEAD_CATEGORICAL) cur.act = __float_as_int(hi[0]) - a.action_start; else cur.xa[0] = hi[0];
+        TileIn<1> curC; curC.xk[0] = cur.xk[0]; curC.xk[1] = cur.xk[1]; curC.s0 = hi[3]; curC.s1 = cur.s1c; curC.valid = cur.valid; curC.act = 0;
+        __builtin_amdgcn_sched_barrier(0);
+        // region 1a: actor layers 1-2;  1b: actor head + output-layer backward (VALU / LDS) under critic.back(k-1) (144 MFMA)
+        grad_front_a<D, H, OA>(wlA, TA, cur.xk, tA, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        grad_front_b<D, H, OA, HEADA>(a, wlA, TA, ZIA, cur, ls, adv_mean, adv_inv, accA, tA, lane);
+        grad_back<D, H, 1>(wlC, TC, XIC, accC, tC, lane);
+        mfma_valu_pipeline<kDualMfma, kDualValuPerMfma>();
+        __builtin_amdgcn_sched_barrier(0);
+        // region 2a: critic layers 1-2;  2b: critic head + output-layer backward under actor.back(k)
+        grad_front_a<D, H, 1>(wlC, TC, curC.xk, tC, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        grad_front_b<D, H, 1, HEAD_VALUE>(a, wlC, TC, ZIC, curC, ls, adv_mean, adv_inv, accC, tC, lane);
+        grad_back<D, H, OA>(wlA, TA, XIA, accA, tA, lane);
+        mfma_valu_pipeline<kDualMfma, kDualValuPerMfma>();
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    grad_back<D, H, 1>(wlC, TC, XIC, accC, tC, lane);                                   // drain: critic.back(last)
+    __syncthreads();
+    float* red = smem + DL::SCR;
+    grad_slab<D, H, OA, HEADA>(red, a.slabs_actor + (size_t)g * a.slab_a, a.slab_a, accA, tid, wave, lane);
+    grad_slab<D, H, 1, HEAD_VALUE>(red, a.slabs_critic + (size_t)g * a.slab_c, a.slab_c, accC, tid, wave, lane);
 }
 
 // =============================================================================================
@@ -1707,6 +2017,19 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
     if (hidden == 256) {
         if (kind == 0) { if (a.rec) CALLW(0, 256, true) else CALLW(0, 256, false) }
         else { if (a.rec) CALLW(1, 256, true) else CALLW(1, 256, false) }
+        return hipGetLastError();
+    }
+    if (a.layout == 2 && a.rec && hidden == 64) {
+#define CALLD(K)                                                                                              \
+    {                                                                                                         \
+        const size_t lds = sizeof(float) * DualLds<K, 64>::SIZE;                                              \
+        static bool attr_set = false;                                                                         \
+        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_dual_kernel<K, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e; attr_set = true; }                                                 \
+        ppo_grad_dual_kernel<K, 64><<<a.G, 256, lds, s>>>(a);                                                 \
+    }
+        if (kind == 0) CALLD(0) else CALLD(1)
+#undef CALLD
         return hipGetLastError();
     }
 #define CALL(K, HH) { if (a.rec) CALLR(K, HH, true) else CALLR(K, HH, false) }

@@ -42,6 +42,7 @@ struct GemmArgs {
     int M, N, K;
     int sAm, sAk, sBk, sBn, sCm, sCn;             // element strides
     long long zA, zB, zC, zBias, zAux;            // batch (blockIdx.z) strides
+    int zdivB;                                    // B uses batch index z / zdivB (several nets reading one input)
     int vecA, vecB;                               // operand has unit stride along k, 16-byte aligned rows and K % 4 == 0: float4 loads
     int ones_n;                                   // B(:, N-1) == 1 (appends the bias column to a weight-gradient contraction)
     int epi; float alpha;
@@ -81,12 +82,12 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int m
     return v;
 }
 template <bool SPLIT>
-__global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_kernel(GemmArgs g) {
-    __shared__ float red[kGemmWaves][16][kRedStride];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5, z = blockIdx.z;
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)[kGemmWaves][16][kRedStride]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
     const float* __restrict__ A = g.A + (size_t)z * g.zA;
-    const float* __restrict__ B = g.B + (size_t)z * g.zB;
+    const float* __restrict__ B = g.B + (size_t)(z / g.zdivB) * g.zB;
     const int tile_n = SPLIT ? (int)blockIdx.y : (int)blockIdx.y * kGemmWaves + wave;
+    if (SPLIT && ((int)blockIdx.x * 32 >= g.M || tile_n * 32 >= g.N)) return;                  // pair launches: the grid covers the larger problem
     const int m = blockIdx.x * 32 + c, n = tile_n * 32 + c;
     const int Q = (g.K + 7) >> 3, Qw = SPLIT ? (Q + kGemmWaves - 1) / kGemmWaves : Q, q0 = SPLIT ? wave * Qw : 0, q1 = min(Q, q0 + Qw);
     const bool ones = g.ones_n && n == g.N - 1;
@@ -142,6 +143,17 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_kernel(GemmArgs g) {
             C[ci] = gemm_epilogue(g, red[wave][rr][ll], mm, ci, bias, aux);
         }
     }
+}
+template <bool SPLIT>
+__global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_kernel(GemmArgs g) {
+    __shared__ float red[kGemmWaves][16][kRedStride];
+    gemm_body<SPLIT>(g, blockIdx.z, red);
+}
+// two independent contractions in one launch (the weight-gradient and the data-gradient of one layer): blockIdx.z < za runs `a`
+struct GemmPair { GemmArgs a, b; int za; };
+__global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_pair_kernel(GemmPair p) {
+    __shared__ float red[kGemmWaves][16][kRedStride];
+    if ((int)blockIdx.z < p.za) gemm_body<true>(p.a, blockIdx.z, red); else gemm_body<true>(p.b, (int)blockIdx.z - p.za, red);
 }
 
 // =================================================================================================================
@@ -356,22 +368,43 @@ __device__ __forceinline__ float adam_one(float* p, float* m, float* v, int i, f
     const float np_ = p[i] - mm / (1.0f - bt1) / (sqrtf(vv / (1.0f - bt2)) + eps) * lr;
     p[i] = np_; return np_;
 }
+__device__ __forceinline__ float4 adam_vec(float* p, float* m, float* v, int i, float4 g, float lr, float b1, float b2, float eps, float bt1, float bt2) {
+    float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+    float* P = reinterpret_cast<float*>(&pp); float* M = reinterpret_cast<float*>(&mm); float* V = reinterpret_cast<float*>(&vv); const float* G = reinterpret_cast<const float*>(&g);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        M[t] = b1 * M[t] + (1.0f - b1) * G[t]; V[t] = b2 * V[t] + (1.0f - b2) * G[t] * G[t];
+        P[t] -= M[t] / (1.0f - bt1) / (sqrtf(V[t] / (1.0f - bt2)) + eps) * lr;
+    }
+    *reinterpret_cast<float4*>(p + i) = pp; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
+    return pp;
+}
+// n_actor and n_q are multiples of 4 (the device layout pads every net to 16 bytes; pads hold zero parameters and zero gradients)
 __global__ __launch_bounds__(256) void sac_step_end_kernel(StepEndArgs a) {
     __shared__ double sh[256];
     __shared__ bool last;
-    const int total = a.n_actor + a.n_ls + a.n_q;
+    const int va = a.n_actor / 4, vq = a.n_q / 4;
     double ss = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        if (i < a.n_actor + a.n_ls) {
-            const int j = i < a.n_actor ? i : a.ls_off + (i - a.n_actor);
-            const float gi = a.g_actor[j];
-            adam_one(a.p, a.m, a.v, j, gi, a.lr, a.b1, a.b2, a.eps, a.bt1_a, a.bt2_a);
-            ss += (double)gi * gi;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < va + vq; i += gridDim.x * 256) {
+        if (i < va) {
+            const float4 g = *reinterpret_cast<const float4*>(a.g_actor + 4 * i);
+            adam_vec(a.p, a.m, a.v, 4 * i, g, a.lr, a.b1, a.b2, a.eps, a.bt1_a, a.bt2_a);
+            ss += (double)g.x * g.x + (double)g.y * g.y + (double)g.z * g.z + (double)g.w * g.w;
         } else {
-            const int k = i - a.n_actor - a.n_ls, j = a.q_off + k;
-            const float np_ = adam_one(a.p, a.m, a.v, j, 0.f, a.lr, a.b1, a.b2, a.eps, a.bt1_c, a.bt2_c);
-            if (a.do_polyak) a.target[k] = a.tau * np_ + (1.0f - a.tau) * a.target[k];
+            const int k = 4 * (i - va);
+            const float4 np_ = adam_vec(a.p, a.m, a.v, a.q_off + k, make_float4(0.f, 0.f, 0.f, 0.f), a.lr, a.b1, a.b2, a.eps, a.bt1_c, a.bt2_c);
+            if (a.do_polyak) {
+                float4 t = *reinterpret_cast<float4*>(a.target + k);
+                t.x = a.tau * np_.x + (1.0f - a.tau) * t.x; t.y = a.tau * np_.y + (1.0f - a.tau) * t.y;
+                t.z = a.tau * np_.z + (1.0f - a.tau) * t.z; t.w = a.tau * np_.w + (1.0f - a.tau) * t.w;
+                *reinterpret_cast<float4*>(a.target + k) = t;
+            }
         }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < a.n_ls) {                                              // log_std: a handful of scalars
+        const int j = a.ls_off + threadIdx.x; const float gi = a.g_actor[j];
+        adam_one(a.p, a.m, a.v, j, gi, a.lr, a.b1, a.b2, a.eps, a.bt1_a, a.bt2_a);
+        ss += (double)gi * gi;
     }
     ss = block_sum(ss, sh);
     if (threadIdx.x == 0) {
@@ -519,11 +552,24 @@ template <typename T> hipError_t smalloc(T** p, size_t n) {
     return e;
 }
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
+int round4(int x) { return (x + 3) & ~3; }
 
-int gemm(dril_sac_handle* h, GemmArgs g, int Z) {
+bool gemm_prepare(GemmArgs& g) {
     g.vecA = g.sAk == 1 && g.sAm % 4 == 0 && g.K % 4 == 0 && aligned16(g.A) && g.zA % 4 == 0;
     g.vecB = !g.ones_n && g.sBk == 1 && g.sBn % 4 == 0 && g.K % 4 == 0 && aligned16(g.B) && g.zB % 4 == 0;
-    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return sfail(h, DRIL_ERR_INVALID_ARG, "gemm: empty contraction");
+    if (g.zdivB <= 0) g.zdivB = 1;
+    return g.M > 0 && g.N > 0 && g.K > 0;
+}
+int gemm_pair(dril_sac_handle* h, GemmArgs a, int Za, GemmArgs b, int Zb) {
+    if (!gemm_prepare(a) || !gemm_prepare(b)) return sfail(h, DRIL_ERR_INVALID_ARG, "gemm: empty contraction");
+    GemmPair p{a, b, Za};
+    const int tm = std::max((a.M + 31) / 32, (b.M + 31) / 32), tn = std::max((a.N + 31) / 32, (b.N + 31) / 32);
+    hipLaunchKernelGGL(sac_gemm_pair_kernel, dim3(tm, tn, Za + Zb), dim3(64 * kGemmWaves), 0, h->stream, p);
+    SHIP(h, hipGetLastError());
+    return DRIL_OK;
+}
+int gemm(dril_sac_handle* h, GemmArgs g, int Z) {
+    if (!gemm_prepare(g)) return sfail(h, DRIL_ERR_INVALID_ARG, "gemm: empty contraction");
     const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
     if ((long long)tm * tn * Z >= 2048) hipLaunchKernelGGL(sac_gemm_kernel<false>, dim3(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), dim3(64 * kGemmWaves), 0, h->stream, g);
     else hipLaunchKernelGGL(sac_gemm_kernel<true>, dim3(tm, tn, Z), dim3(64 * kGemmWaves), 0, h->stream, g);
@@ -535,10 +581,10 @@ GemmArgs gemm_args() { GemmArgs g; memset(&g, 0, sizeof(g)); g.alpha = 1.0f; ret
 // One net = {W1 b1 W2 b2 W3 b3} at `P + off` (+ z * zP for the second critic); activations are (features x n) column-major
 struct NetBufs { float* h1; float* h2; float* out; long long zh, zo; };   // [Z][n][H], [Z][n][O]
 int net_forward(dril_sac_handle* h, const float* P, NetOff off, long long zP, int in, int O, const float* X, int ldx, long long zX, int n,
-                NetBufs b, int Z) {
+                NetBufs b, int Z, int zdivX = 1) {
     const int H1 = h->H1, H2 = h->H2, act = h->cfg.activation ? EPI_RELU : EPI_TANH;
     GemmArgs g = gemm_args();                                                       // h1 = act(W1 x + b1)
-    g.A = P + off.w1; g.sAm = 1; g.sAk = H1; g.zA = zP; g.B = X; g.sBk = 1; g.sBn = ldx; g.zB = zX;
+    g.A = P + off.w1; g.sAm = 1; g.sAk = H1; g.zA = zP; g.B = X; g.sBk = 1; g.sBn = ldx; g.zB = zX; g.zdivB = zdivX;
     g.C = b.h1; g.sCm = 1; g.sCn = H1; g.zC = b.zh; g.bias = P + off.b1; g.zBias = zP; g.M = H1; g.N = n; g.K = in; g.epi = act;
     SDO(gemm(h, g, Z));
     g = gemm_args();                                                                // h2 = act(W2 h1 + b2)
@@ -555,31 +601,25 @@ int net_backward(dril_sac_handle* h, const float* P, NetOff off, long long zP, i
                  NetBufs b, const float* dOut, float* G, float* dX, int Z) {
     const int H1 = h->H1, H2 = h->H2, mask = h->cfg.activation ? EPI_MASK_RELU : EPI_MASK_TANH;
     const long long zd = (long long)h->nq * H1;   // dz buffers are [2][nq][H] (H1 == H2 layouts are separate buffers)
-    GemmArgs g;
-    if (G) {                                                                        // [dW3 | db3] = dOut . [h2' | 1]
-        g = gemm_args(); g.A = dOut; g.sAm = 1; g.sAk = O; g.zA = b.zo; g.B = b.h2; g.sBk = H2; g.sBn = 1; g.zB = b.zh; g.ones_n = 1;
-        g.C = G + off.w3; g.sCm = 1; g.sCn = O; g.zC = zP; g.M = O; g.N = H2 + 1; g.K = n; SDO(gemm(h, g, Z));
-    }
+    const bool big = (long long)((H2 + 31) / 32) * ((n + 31) / 32) * Z >= 2048;          // large batches: one launch per contraction (the pair kernel is the split-K shape)
+    GemmArgs w, g;
+    w = gemm_args(); w.A = dOut; w.sAm = 1; w.sAk = O; w.zA = b.zo; w.B = b.h2; w.sBk = H2; w.sBn = 1; w.zB = b.zh; w.ones_n = 1;      // [dW3 | db3] = dOut . [h2' | 1]
+    w.C = G ? G + off.w3 : nullptr; w.sCm = 1; w.sCn = O; w.zC = zP; w.M = O; w.N = H2 + 1; w.K = n;
     g = gemm_args();                                                                // dz2 = (W3' dOut) .* act'(h2)
     g.A = P + off.w3; g.sAm = O; g.sAk = 1; g.zA = zP; g.B = dOut; g.sBk = 1; g.sBn = O; g.zB = b.zo;
     g.C = h->dz2; g.sCm = 1; g.sCn = H2; g.zC = (long long)h->nq * H2; g.aux = b.h2; g.zAux = b.zh; g.M = H2; g.N = n; g.K = O; g.epi = mask;
-    SDO(gemm(h, g, Z));
-    if (G) {                                                                        // [dW2 | db2] = dz2 . [h1' | 1]
-        g = gemm_args(); g.A = h->dz2; g.sAm = 1; g.sAk = H2; g.zA = (long long)h->nq * H2; g.B = b.h1; g.sBk = H1; g.sBn = 1; g.zB = b.zh; g.ones_n = 1;
-        g.C = G + off.w2; g.sCm = 1; g.sCn = H2; g.zC = zP; g.M = H2; g.N = H1 + 1; g.K = n; SDO(gemm(h, g, Z));
-    }
+    if (G && !big) SDO(gemm_pair(h, w, Z, g, Z)); else { if (G) SDO(gemm(h, w, Z)); SDO(gemm(h, g, Z)); }
+    w = gemm_args(); w.A = h->dz2; w.sAm = 1; w.sAk = H2; w.zA = (long long)h->nq * H2; w.B = b.h1; w.sBk = H1; w.sBn = 1; w.zB = b.zh; w.ones_n = 1;   // [dW2 | db2] = dz2 . [h1' | 1]
+    w.C = G ? G + off.w2 : nullptr; w.sCm = 1; w.sCn = H2; w.zC = zP; w.M = H2; w.N = H1 + 1; w.K = n;
     g = gemm_args();                                                                // dz1 = (W2' dz2) .* act'(h1)
     g.A = P + off.w2; g.sAm = H2; g.sAk = 1; g.zA = zP; g.B = h->dz2; g.sBk = 1; g.sBn = H2; g.zB = (long long)h->nq * H2;
     g.C = h->dz1; g.sCm = 1; g.sCn = H1; g.zC = zd; g.aux = b.h1; g.zAux = b.zh; g.M = H1; g.N = n; g.K = H2; g.epi = mask;
-    SDO(gemm(h, g, Z));
-    if (G) {                                                                        // [dW1 | db1] = dz1 . [x' | 1]
-        g = gemm_args(); g.A = h->dz1; g.sAm = 1; g.sAk = H1; g.zA = zd; g.B = X; g.sBk = ldx; g.sBn = 1; g.zB = zX; g.ones_n = 1;
-        g.C = G + off.w1; g.sCm = 1; g.sCn = H1; g.zC = zP; g.M = H1; g.N = in + 1; g.K = n; SDO(gemm(h, g, Z));
-    }
-    if (dX) {                                                                       // dx = W1' dz1
-        g = gemm_args(); g.A = P + off.w1; g.sAm = H1; g.sAk = 1; g.zA = zP; g.B = h->dz1; g.sBk = 1; g.sBn = H1; g.zB = zd;
-        g.C = dX; g.sCm = 1; g.sCn = in; g.zC = (long long)h->nq * in; g.M = in; g.N = n; g.K = H1; SDO(gemm(h, g, Z));
-    }
+    if (G && !big) SDO(gemm_pair(h, w, Z, g, Z)); else { if (G) SDO(gemm(h, w, Z)); SDO(gemm(h, g, Z)); }
+    w = gemm_args(); w.A = h->dz1; w.sAm = 1; w.sAk = H1; w.zA = zd; w.B = X; w.sBk = ldx; w.sBn = 1; w.zB = zX; w.ones_n = 1;          // [dW1 | db1] = dz1 . [x' | 1]
+    w.C = G ? G + off.w1 : nullptr; w.sCm = 1; w.sCn = H1; w.zC = zP; w.M = H1; w.N = in + 1; w.K = n;
+    g = gemm_args(); g.A = P + off.w1; g.sAm = H1; g.sAk = 1; g.zA = zP; g.B = h->dz1; g.sBk = 1; g.sBn = H1; g.zB = zd;               // dx = W1' dz1
+    g.C = dX; g.sCm = 1; g.sCn = in; g.zC = (long long)h->nq * in; g.M = in; g.N = n; g.K = H1;
+    if (G && dX && !big) SDO(gemm_pair(h, w, Z, g, Z)); else { if (G) SDO(gemm(h, w, Z)); if (dX) SDO(gemm(h, g, Z)); }
     return DRIL_OK;
 }
 NetBufs actor_bufs(dril_sac_handle* h) { return NetBufs{h->ah1, h->ah2, h->mu, 0, 0}; }
@@ -612,8 +652,8 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
     hipLaunchKernelGGL(sac_ent_next_kernel, dim3(1), dim3(256), 0, h->stream, en);
     if (h->cfg.auto_ent_coef) { h->bt_ent[0] *= h->cfg.adam_beta1; h->bt_ent[1] *= h->cfg.adam_beta2; }
     // critic: target values with the target networks (:133-135), current values (:117), loss head, reverse pass, Adam (:362)
-    SDO(net_forward(h, h->target, net_off(0, W, h->H1, h->H2, 1), h->Pqd, W, 1, h->xq_next, W, 0, B, q_bufs(h, h->th1, h->th2, h->q_next), 2));
-    SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), 2));
+    // all four Q nets in one pass: z = 0,1 the critics on (obs, action), z = 2,3 the targets on (next obs, next action)
+    SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, (long long)h->nq * W, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), 4, 2));
     CriticHeadArgs ch{B, h->q_next, h->q_cur, h->b_rew, h->b_nlp, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats};
     hipLaunchKernelGGL(sac_critic_head_kernel, dim3(1), dim3(256), 0, h->stream, ch);
     SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), h->dq, h->g_critic, nullptr, 2));
@@ -629,7 +669,7 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
     SDO(net_backward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, B, actor_bufs(h), h->dmu, h->g_actor, nullptr, 1));
     // apply_gradients(train_state, actor_loss_grad) :382 + target networks :385-389 + statistics: one launch
     const int do_polyak = h->grad_updates % h->cfg.target_update_interval == 0;
-    StepEndArgs se{h->params, h->adam_m, h->adam_v, h->g_actor, h->actor.end, h->log_std_off, A, h->q0.w1, 2 * h->Pqd,
+    StepEndArgs se{h->params, h->adam_m, h->adam_v, h->g_actor, round4(h->actor.end), h->log_std_off, A, h->q0.w1, 2 * h->Pqd,
                    h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->bt_actor[0], h->bt_actor[1], h->bt_critic[0], h->bt_critic[1],
                    h->target, h->cfg.tau, do_polyak, h->ssq_c, h->adam_blocks_c, h->ssq_a, h->counter, h->stats, out};
     hipLaunchKernelGGL(sac_step_end_kernel, dim3(h->end_blocks), dim3(256), 0, h->stream, se);
@@ -741,7 +781,6 @@ int params_from_device(dril_sac_handle* h, float* host, const float* dev) {
     for (const Seg& g : s) SHIP(h, hipMemcpy(host + g.host, dev + g.dev, (size_t)g.len * 4, hipMemcpyDeviceToHost));
     return DRIL_OK;
 }
-int round4(int x) { return (x + 3) & ~3; }
 
 }  // namespace
 
@@ -764,10 +803,10 @@ DRIL_EXPORT int32_t dril_sac_config_default(dril_sac_config* c, int32_t env_kind
 DRIL_EXPORT int32_t dril_sac_destroy(dril_sac_handle* h) {
     if (!h) return DRIL_OK;
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->target, h->g_critic, h->g_actor, h->sc, h->stats, h->stats_out, h->ssq_c, h->ssq_a, h->counter,
+    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->g_critic, h->g_actor, h->sc, h->stats, h->stats_out, h->ssq_c, h->ssq_a, h->counter,
                     h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->obs_cur, h->obs_nxt, h->e_rew, h->e_tobs, h->e_raw, h->e_envact, h->e_term, h->e_trunc,
-                    h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc, h->xa, h->ah1, h->ah2, h->mu, h->xq, h->xq_next, h->xq_pi,
-                    h->qh1, h->qh2, h->th1, h->th2, h->q_cur, h->q_next, h->q_pi, h->dq, h->dz2, h->dz1, h->dxq, h->dmu, h->b_rew, h->b_ne, h->b_nn, h->b_np,
+                    h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc, h->xa, h->ah1, h->ah2, h->mu, h->xq, h->xq_pi,
+                    h->qh1, h->qh2, h->q_cur, h->q_pi, h->dq, h->dz2, h->dz1, h->dxq, h->dmu, h->b_rew, h->b_ne, h->b_nn, h->b_np,
                     h->b_nlp, h->a_pi, h->g_pi, h->lp_pi, h->b_term, h->collect_noise, h->inj_idx, h->inj_ne, h->inj_nn, h->inj_np, h->s_in, h->s_act, h->s_noise, h->s_out, h->s_out2};
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->ev_a) hipEventDestroy(h->ev_a); if (h->ev_b) hipEventDestroy(h->ev_b);
@@ -794,13 +833,14 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     const int D = h->D = 3, A = h->A = 1, S = h->S = 2, H1 = h->H1 = cfg->hidden1, H2 = h->H2 = cfg->hidden2, E = cfg->n_envs, B = cfg->batch_size, W = D + A;
     h->Pa = D * H1 + H1 + H1 * H2 + H2 + H2 * A + A; h->Pq = W * H1 + H1 + H1 * H2 + H2 + H2 + 1; h->P = h->Pa + 2 * h->Pq + A;
     h->actor = net_off(0, D, H1, H2, A); h->Pqd = round4(h->Pq); h->q0 = net_off(round4(h->actor.end), W, H1, H2, 1);
-    h->log_std_off = h->q0.w1 + 2 * h->Pqd; h->Pd = round4(h->log_std_off + A);
+    h->log_std_off = h->q0.w1 + 4 * h->Pqd; h->Pd = round4(h->log_std_off + A);      // device layout: actor | q1 | q2 | target q1 | target q2 | log_std
     h->nq = B; h->nmax = std::max(E, 2 * B);
     h->target_entropy = cfg->auto_target_entropy ? -(float)A : cfg->target_entropy;
     h->act_hi = cfg->env_kind == DRIL_ENV_PENDULUM_SCALED ? 1.0f : 2.0f;
-    CHK(smalloc(&h->params, h->Pd)); CHK(smalloc(&h->adam_m, h->Pd)); CHK(smalloc(&h->adam_v, h->Pd)); CHK(smalloc(&h->target, 2 * (size_t)h->Pqd));
+    CHK(smalloc(&h->params, h->Pd)); CHK(smalloc(&h->adam_m, h->Pd)); CHK(smalloc(&h->adam_v, h->Pd));
+    h->target = h->params + h->q0.w1 + 2 * h->Pqd;   // the targets sit right behind the critics so that one launch runs all four Q nets (blockIdx.z stride Pqd)
     CHK(smalloc(&h->g_critic, h->Pd)); CHK(smalloc(&h->g_actor, h->Pd)); CHK(smalloc(&h->sc, 1)); CHK(smalloc(&h->stats, 8));
-    h->adam_blocks_c = std::min(1024, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(1024, (h->actor.end + A + 2 * h->Pqd + 255) / 256);
+    h->adam_blocks_c = std::min(1024, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(1024, ((h->actor.end + 3) / 4 + 2 * h->Pqd / 4 + 255) / 256);
     CHK(smalloc(&h->ssq_c, h->adam_blocks_c)); CHK(smalloc(&h->ssq_a, h->end_blocks)); CHK(smalloc(&h->counter, 1));
     CHK(smalloc(&h->state, (size_t)E * S)); CHK(smalloc(&h->step_count, E)); CHK(smalloc(&h->episode, E)); CHK(smalloc(&h->gstep, E)); CHK(smalloc(&h->disc_returns, E));
     CHK(smalloc(&h->obs_cur, (size_t)E * D)); CHK(smalloc(&h->obs_nxt, (size_t)E * D)); CHK(smalloc(&h->e_rew, E)); CHK(smalloc(&h->e_tobs, (size_t)E * D));
@@ -810,9 +850,9 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     CHK(smalloc(&h->rb_rew, (size_t)h->cap)); CHK(smalloc(&h->rb_term, (size_t)h->cap)); CHK(smalloc(&h->rb_trunc, (size_t)h->cap));
     const size_t nm = h->nmax, nq = h->nq;
     CHK(smalloc(&h->xa, nm * D)); CHK(smalloc(&h->ah1, nm * H1)); CHK(smalloc(&h->ah2, nm * H2)); CHK(smalloc(&h->mu, nm * A));
-    CHK(smalloc(&h->xq, nq * W)); CHK(smalloc(&h->xq_next, nq * W)); CHK(smalloc(&h->xq_pi, nq * W));
-    CHK(smalloc(&h->qh1, 2 * nq * H1)); CHK(smalloc(&h->qh2, 2 * nq * H2)); CHK(smalloc(&h->th1, 2 * nq * H1)); CHK(smalloc(&h->th2, 2 * nq * H2));
-    CHK(smalloc(&h->q_cur, 2 * nq)); CHK(smalloc(&h->q_next, 2 * nq)); CHK(smalloc(&h->q_pi, 2 * nq)); CHK(smalloc(&h->dq, 2 * nq));
+    CHK(smalloc(&h->xq, 2 * nq * W)); h->xq_next = h->xq + nq * W; CHK(smalloc(&h->xq_pi, nq * W));       // [xq | xq_next]: one input buffer, batch index z / 2
+    CHK(smalloc(&h->qh1, 4 * nq * H1)); CHK(smalloc(&h->qh2, 4 * nq * H2)); h->th1 = h->qh1 + 2 * nq * H1; h->th2 = h->qh2 + 2 * nq * H2;   // z = 0,1 critics (kept for the reverse pass), 2,3 targets
+    CHK(smalloc(&h->q_cur, 4 * nq)); h->q_next = h->q_cur + 2 * nq; CHK(smalloc(&h->q_pi, 2 * nq)); CHK(smalloc(&h->dq, 2 * nq));
     CHK(smalloc(&h->dz2, 2 * nq * H2)); CHK(smalloc(&h->dz1, 2 * nq * H1)); CHK(smalloc(&h->dxq, 2 * nq * W)); CHK(smalloc(&h->dmu, nq * A));
     CHK(smalloc(&h->b_rew, nq)); CHK(smalloc(&h->b_ne, nq * A)); CHK(smalloc(&h->b_nn, nq * A)); CHK(smalloc(&h->b_np, nq * A)); CHK(smalloc(&h->b_nlp, nq));
     CHK(smalloc(&h->a_pi, nq * A)); CHK(smalloc(&h->g_pi, nq * A)); CHK(smalloc(&h->lp_pi, nq)); CHK(smalloc(&h->b_term, nq));
