@@ -299,10 +299,10 @@ void* buf_ptr(dril_handle* h, int which, size_t* bytes) {
 
 // ================================================================================================
 DRIL_EXPORT int32_t dril_config_default(dril_config* c, int32_t env_kind) {
-    if (!c || env_kind < DRIL_ENV_CARTPOLE || env_kind > DRIL_ENV_PENDULUM_SCALED) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad cfg/env_kind");
+    if (!c || env_kind < DRIL_ENV_CARTPOLE || env_kind > DRIL_ENV_MOUNTAINCAR_CONTINUOUS) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad cfg/env_kind");
     std::memset(c, 0, sizeof(*c));
     c->abi_version = DRIL_ABI_VERSION; c->env_kind = env_kind; c->n_envs = 4; c->n_steps = 2048; c->hidden1 = c->hidden2 = 64;
-    c->episode_len = env_kind == DRIL_ENV_CARTPOLE ? 500 : 200; c->action_start = 1;
+    c->episode_len = env_kind == DRIL_ENV_CARTPOLE ? 500 : env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS ? 999 : 200; c->action_start = 1;   // the Gymnasium time limits
     c->gamma = 0.99f; c->gae_lambda = 0.95f; c->clip_range = 0.2f; c->ent_coef = 0.0f; c->vf_coef = 0.5f;
     c->max_grad_norm = 0.5f; c->has_max_grad_norm = 1; c->normalize_advantage = 1; c->batch_size = 64; c->epochs = 10;
     c->learning_rate = 3.0e-4f; c->adam_beta1 = 0.9f; c->adam_beta2 = 0.999f; c->adam_eps = 1.0e-5f;
@@ -313,7 +313,8 @@ DRIL_EXPORT int32_t dril_config_default(dril_config* c, int32_t env_kind) {
 DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (!cfg || !out) return fail(nullptr, DRIL_ERR_INVALID_ARG, "null cfg/out");
     if (cfg->abi_version != DRIL_ABI_VERSION) return fail(nullptr, DRIL_ERR_INVALID_ARG, "abi_version mismatch");
-    if (cfg->env_kind < DRIL_ENV_CARTPOLE || cfg->env_kind > DRIL_ENV_PENDULUM_SCALED) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
+    if (cfg->env_kind < DRIL_ENV_CARTPOLE || cfg->env_kind > DRIL_ENV_MOUNTAINCAR_CONTINUOUS) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
+    if (cfg->env_kind >= DRIL_ENV_MOUNTAINCAR && cfg->hidden1 != 64) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "MountainCar envs: hidden_dims [64,64] is built");
     if (cfg->n_envs < 1 || cfg->n_steps < 1 || cfg->epochs < 0 || cfg->batch_size < 1) return fail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs/n_steps/batch_size must be positive");
     if (cfg->hidden1 != cfg->hidden2 || (cfg->hidden1 != 64 && cfg->hidden1 != 256)) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden_dims: [64,64] and [256,256] are built");
     if (cfg->monitor_window < 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "monitor_window must be >= 0");
@@ -322,8 +323,12 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     dril_handle* h = nullptr;
     try { h = new dril_handle(); } catch (...) { return fail(nullptr, DRIL_ERR_INVALID_ARG, "out of host memory"); }
     h->cfg = *cfg;
-    h->discrete = cfg->env_kind == DRIL_ENV_CARTPOLE;
-    h->D = h->discrete ? 4 : 3; h->A = h->discrete ? 2 : 1; h->S = h->discrete ? 4 : 2;
+    switch (cfg->env_kind) {
+        case DRIL_ENV_CARTPOLE: h->discrete = true; h->D = 4; h->A = 2; h->S = 4; break;
+        case DRIL_ENV_MOUNTAINCAR: h->discrete = true; h->D = 2; h->A = 3; h->S = 2; break;
+        case DRIL_ENV_MOUNTAINCAR_CONTINUOUS: h->discrete = false; h->D = 2; h->A = 1; h->S = 2; break;
+        default: h->discrete = false; h->D = 3; h->A = 1; h->S = 2; break;                    // Pendulum, ScalingWrapperEnv(Pendulum)
+    }
     h->actor = net_off(0, h->D, cfg->hidden1, cfg->hidden2, h->A);
     h->critic = net_off(h->actor.end, h->D, cfg->hidden1, cfg->hidden2, 1);
     h->Pa = h->actor.end; h->Pc = h->critic.end - h->actor.end; h->log_std_off = h->critic.end;

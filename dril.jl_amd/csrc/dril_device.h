@@ -129,11 +129,13 @@ template <int KIND> struct EnvSpec;
 template <> struct EnvSpec<0> { static constexpr int D = 4, S = 4, A = 2; static constexpr bool discrete = true; };
 template <> struct EnvSpec<1> { static constexpr int D = 3, S = 2, A = 1; static constexpr bool discrete = false; };
 template <> struct EnvSpec<2> : EnvSpec<1> {};   // ScalingWrapperEnv(PendulumEnv()): same simulator, affine maps at the boundary
+template <> struct EnvSpec<3> { static constexpr int D = 2, S = 2, A = 3; static constexpr bool discrete = true; };    // MountainCar-v0: (position, velocity), Discrete(3)
+template <> struct EnvSpec<4> { static constexpr int D = 2, S = 2, A = 1; static constexpr bool discrete = false; };   // MountainCarContinuous-v0: Box(-1, 1)
 // ScalingWrapperEnv (scalingWrapperEnv.jl): scale! :71-74 `(x - low) * sf - 1`, unscale! :76-79 `(x + 1) / sf + low`, sf = 2 / (high - low) :36-44
 __host__ __device__ inline float scale_to_unit(float x, float low, float high) { const float sf = 2.0f / (high - low); return (x - low) * sf - 1.0f; }
 __host__ __device__ inline float unscale_from_unit(float x, float low, float high) { const float sf = 2.0f / (high - low); return (x + 1.0f) / sf + low; }
 // bound of the agent-facing action space (ClampAdapter / TanhScaleAdapter act on action_space(env)): Box(-2,2), Box(-1,1) under the wrapper
-template <int KIND> __host__ __device__ constexpr float act_bound() { return KIND == 2 ? 1.0f : 2.0f; }
+template <int KIND> __host__ __device__ constexpr float act_bound() { return (KIND == 2 || KIND == 4) ? 1.0f : 2.0f; }
 
 template <int KIND> __device__ inline void env_reset(uint64_t env_seed, uint32_t episode, float* st) {
     uint32_t r[4];
@@ -141,6 +143,8 @@ template <int KIND> __device__ inline void env_reset(uint64_t env_seed, uint32_t
     if (KIND == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) st[i] = u01_f32(r[i]) * 0.1f - 0.05f;
+    } else if (KIND == 3 || KIND == 4) {                           // MountainCar: position ~ U(-0.6, -0.4), velocity 0
+        st[0] = u01_f32(r[0]) * 0.2f - 0.6f; st[1] = 0.f;
     } else {
         st[0] = u01_f32(r[0]) * 6.28318530717958647692f - 3.14159265358979323846f;
         st[1] = u01_f32(r[1]) * 2.0f - 1.0f;
@@ -150,7 +154,8 @@ template <int KIND> __device__ inline void env_obs(const float* st, float* obs) 
     if (KIND == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) obs[i] = st[i];
-    } else {
+    } else if (KIND == 3 || KIND == 4) { obs[0] = st[0]; obs[1] = st[1]; }
+    else {
         obs[0] = cosf(st[0]); obs[1] = sinf(st[0]); obs[2] = st[1];
         if (KIND == 2) {                                           // observe(::ScalingWrapperEnv) :93-98 on Box((-1,-1,-8), (1,1,8))
             obs[0] = scale_to_unit(obs[0], -1.0f, 1.0f); obs[1] = scale_to_unit(obs[1], -1.0f, 1.0f); obs[2] = scale_to_unit(obs[2], -8.0f, 8.0f);
@@ -174,6 +179,22 @@ template <int KIND> __device__ inline float env_step(float* st, float act_f, int
         const bool term = (x < -2.4f) || (x > 2.4f) || (th < -0.20943951023931953f) || (th > 0.20943951023931953f);
         *terminated = fixed_len ? false : term;
         return 1.0f;
+    } else if (KIND == 3 || KIND == 4) {
+        // MountainCar-v0 (act_i in {0,1,2}) / MountainCarContinuous-v0 (act_f clipped to [-1,1]); Gymnasium equations
+        const float min_position = -1.2f, max_position = 0.6f, max_speed = 0.07f;
+        float position = st[0], velocity = st[1], reward;
+        float force = 0.f;
+        if (KIND == 3) velocity += (float)(act_i - 1) * 0.001f + cosf(3.0f * position) * (-0.0025f);
+        else { force = fminf(fmaxf(act_f, -1.0f), 1.0f); velocity += force * 0.0015f - 0.0025f * cosf(3.0f * position); }
+        velocity = fminf(fmaxf(velocity, -max_speed), max_speed);
+        position += velocity;
+        position = fminf(fmaxf(position, min_position), max_position);
+        if (position == min_position && velocity < 0.f) velocity = 0.f;
+        const bool goal = position >= (KIND == 3 ? 0.5f : 0.45f) && velocity >= 0.f;
+        if (KIND == 3) reward = -1.0f; else reward = (goal ? 100.0f : 0.0f) - force * force * 0.1f;
+        st[0] = position; st[1] = velocity;
+        *terminated = fixed_len ? false : goal;
+        return reward;
     } else {
         const float max_speed = 8.0f, max_torque = 2.0f, dt = 0.05f, g = 10.0f, m = 1.0f, l = 1.0f;
         const float pi = 3.14159265358979323846f;

@@ -1850,6 +1850,8 @@ template <int KIND, int H> static size_t grad_lds_bytes() {
     do {                                                                             \
         if ((kind) == 0 && (hidden) == 64) { CALL(0, 64); }                          \
         else if (((kind) == 1 || (kind) == 2) && (hidden) == 64) { CALL(1, 64); }    \
+        else if ((kind) == 3 && (hidden) == 64) { CALL(3, 64); }                     \
+        else if ((kind) == 4 && (hidden) == 64) { CALL(4, 64); }                     \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
@@ -1859,6 +1861,8 @@ template <int KIND, int H> static size_t grad_lds_bytes() {
         else if (((kind) == 1 || (kind) == 2) && (hidden) == 64) { CALL(1, 64); }    \
         else if ((kind) == 0 && (hidden) == 256) { CALL(0, 256); }                   \
         else if (((kind) == 1 || (kind) == 2) && (hidden) == 256) { CALL(1, 256); }  \
+        else if ((kind) == 3 && (hidden) == 64) { CALL(3, 64); }                     \
+        else if ((kind) == 4 && (hidden) == 64) { CALL(4, 64); }                     \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
@@ -1871,6 +1875,8 @@ template <int KIND, int H> static size_t grad_lds_bytes() {
         else if ((kind) == 0 && (hidden) == 256) { CALL(0, 256); }                   \
         else if ((kind) == 1 && (hidden) == 256) { CALL(1, 256); }                   \
         else if ((kind) == 2 && (hidden) == 256) { CALL(2, 256); }                   \
+        else if ((kind) == 3 && (hidden) == 64) { CALL(3, 64); }                     \
+        else if ((kind) == 4 && (hidden) == 64) { CALL(4, 64); }                     \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
@@ -1882,6 +1888,7 @@ hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a,
 hipError_t launch_env_reset(int kind, int E, uint64_t seed0, float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* dr, hipStream_t s) {
     const int blocks = (E + 255) / 256;
     if (kind == 0) env_reset_kernel<0><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
+    else if (kind == 3 || kind == 4) env_reset_kernel<3><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
     else env_reset_kernel<1><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
     return hipGetLastError();
 }
@@ -1889,7 +1896,8 @@ hipError_t launch_env_observe(int kind, int E, const float* state, float* obs, h
     const int blocks = (E + 255) / 256;
     if (kind == 0) env_observe_kernel<0><<<blocks, 256, 0, s>>>(E, state, obs);
     else if (kind == 1) env_observe_kernel<1><<<blocks, 256, 0, s>>>(E, state, obs);
-    else env_observe_kernel<2><<<blocks, 256, 0, s>>>(E, state, obs);
+    else if (kind == 2) env_observe_kernel<2><<<blocks, 256, 0, s>>>(E, state, obs);
+    else env_observe_kernel<3><<<blocks, 256, 0, s>>>(E, state, obs);
     return hipGetLastError();
 }
 hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int fixed_len, int action_start, const void* actions,
@@ -1898,7 +1906,9 @@ hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int
     const int blocks = (E + 255) / 256;
     if (kind == 0) env_step_kernel<0><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
     else if (kind == 1) env_step_kernel<1><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
-    else env_step_kernel<2><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
+    else if (kind == 2) env_step_kernel<2><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
+    else if (kind == 3) env_step_kernel<3><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
+    else env_step_kernel<4><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
     return hipGetLastError();
 }
 hipError_t launch_monitor_collect(const uint8_t* flags, const float* ep_ret, const int32_t* ep_len, int E, int T, int W, int* cnt,
@@ -1909,7 +1919,8 @@ hipError_t launch_monitor_collect(const uint8_t* flags, const float* ep_ret, con
 }
 
 hipError_t launch_norm_step(int kind, const NormStepArgs& a, int nblocks, hipStream_t s) {
-    if (kind == 0) norm_step_kernel<0><<<nblocks, 256, 0, s>>>(a); else if (kind == 1) norm_step_kernel<1><<<nblocks, 256, 0, s>>>(a); else norm_step_kernel<2><<<nblocks, 256, 0, s>>>(a);
+    if (kind == 0) norm_step_kernel<0><<<nblocks, 256, 0, s>>>(a); else if (kind == 1) norm_step_kernel<1><<<nblocks, 256, 0, s>>>(a); else if (kind == 2) norm_step_kernel<2><<<nblocks, 256, 0, s>>>(a);
+    else if (kind == 3) norm_step_kernel<3><<<nblocks, 256, 0, s>>>(a); else norm_step_kernel<4><<<nblocks, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 hipError_t launch_norm_apply(const NormApplyArgs& a, hipStream_t s) {
@@ -1920,7 +1931,8 @@ hipError_t launch_norm_apply(const NormApplyArgs& a, hipStream_t s) {
 hipError_t launch_obs_partials(int kind, int E, const float* state, float* raw, double* partials, int nblocks, hipStream_t s) {
     if (kind == 0) obs_partials_kernel<0><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
     else if (kind == 1) obs_partials_kernel<1><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
-    else obs_partials_kernel<2><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
+    else if (kind == 2) obs_partials_kernel<2><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
+    else obs_partials_kernel<3><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
     return hipGetLastError();
 }
 hipError_t launch_norm_obs_apply(const NormObsArgs& a, hipStream_t s) {
@@ -2019,7 +2031,7 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
         else { if (a.rec) CALLW(1, 256, true) else CALLW(1, 256, false) }
         return hipGetLastError();
     }
-    if (a.layout == 2 && a.rec && hidden == 64) {
+    if (a.layout == 2 && a.rec && hidden == 64 && kind <= 2) {
 #define CALLD(K)                                                                                              \
     {                                                                                                         \
         const size_t lds = sizeof(float) * DualLds<K, 64>::SIZE;                                              \
@@ -2043,6 +2055,8 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
 hipError_t launch_pack_records(int kind, int64_t N, const float* obs, const void* act, const float* adv, const float* logp, const float* ret, float4* rec, hipStream_t s) {
     int blocks = (int)((N + 255) / 256); if (blocks > 8192) blocks = 8192;
     if (kind == 0) pack_records_kernel<0><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
+    else if (kind == 3) pack_records_kernel<3><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
+    else if (kind == 4) pack_records_kernel<4><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
     else pack_records_kernel<1><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
     return hipGetLastError();
 }
@@ -2063,13 +2077,21 @@ hipError_t launch_explained_var(const float* val, const float* ret, int64_t N, d
     return hipGetLastError();
 }
 
+static void kind_dims(int kind, int& D, int& A, bool& disc) {
+    switch (kind) {
+        case 0: D = 4; A = 2; disc = true; break;
+        case 3: D = 2; A = 3; disc = true; break;
+        case 4: D = 2; A = 1; disc = false; break;
+        default: D = 3; A = 1; disc = false; break;
+    }
+}
 int slab_size_actor(int kind, int hidden) {
-    const int D = kind == 0 ? 4 : 3, A = kind == 0 ? 2 : 1;
+    int D, A; bool disc; kind_dims(kind, D, A, disc);
     const NetOff n = net_off(0, D, hidden, hidden, A);
-    return (n.end + (kind == 0 ? 0 : A) + 8 + 3) / 4 * 4 + 0;
+    return (n.end + (disc ? 0 : A) + 8 + 3) / 4 * 4 + 0;
 }
 int slab_size_critic(int kind, int hidden) {
-    const int D = kind == 0 ? 4 : 3;
+    int D, A_; bool disc_; kind_dims(kind, D, A_, disc_);
     const NetOff n = net_off(0, D, hidden, hidden, 1);
     return (n.end + 8 + 3) / 4 * 4;
 }

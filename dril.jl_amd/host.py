@@ -84,6 +84,33 @@ class PendulumEnv:
 
 
 @dataclass
+class MountainCarEnv:
+    """MountainCar-v0 (Gymnasium equations; the reference takes its classic-control envs from ClassicControlEnvironments.jl)"""
+    max_steps: int = 200
+    action_start: int = 1
+    kind: int = capi.ENV_MOUNTAINCAR
+
+    def observation_space(self):
+        return Box((-1.2, -0.07), (0.6, 0.07))
+
+    def action_space(self):
+        return Discrete(3, self.action_start)
+
+
+@dataclass
+class MountainCarContinuousEnv:
+    """MountainCarContinuous-v0"""
+    max_steps: int = 999
+    kind: int = capi.ENV_MOUNTAINCAR_CONTINUOUS
+
+    def observation_space(self):
+        return Box((-1.2, -0.07), (0.6, 0.07))
+
+    def action_space(self):
+        return Box((-1.0,), (1.0,))
+
+
+@dataclass
 class ScalingWrapperEnv:
     """ScalingWrapperEnv(env) (src/environment_wrappers/scalingWrapperEnv.jl:15-49) around a Box/Box env: the agent-facing spaces become
     [-1, 1]; on device the two affine maps are fused into the env kernels (env kind DRIL_ENV_PENDULUM_SCALED)."""
@@ -370,7 +397,7 @@ class Handle:
         return rew, term.astype(bool), trunc.astype(bool), tobs
 
     def env_get_state(self):
-        S = 4 if self.discrete else 2
+        S = 4 if self.cfg.env_kind == capi.ENV_CARTPOLE else 2      # CartPole (x, x_dot, theta, theta_dot); Pendulum (theta, theta_dot); MountainCar (position, velocity)
         st = np.empty((self.E, S), np.float32)
         sc = np.empty(self.E, np.int32)
         self._chk(self.lib.dril_env_get_state(self._h, self._p(st), self._p(sc)))

@@ -50,7 +50,7 @@ struct DrilPPOStats
     n_updates::Int32; early_stopped::Int32; nan_or_inf::Int32; reserved::Int32
 end
 
-const ENV_KINDS = Dict(:CartPole => Int32(0), :Pendulum => Int32(1), :ScaledPendulum => Int32(2))   # :ScaledPendulum = ScalingWrapperEnv(PendulumEnv()) on every sub-env (scalingWrapperEnv.jl)
+const ENV_KINDS = Dict(:CartPole => Int32(0), :Pendulum => Int32(1), :ScaledPendulum => Int32(2), :MountainCar => Int32(3), :MountainCarContinuous => Int32(4))   # :ScaledPendulum = ScalingWrapperEnv(PendulumEnv()) on every sub-env (scalingWrapperEnv.jl)
 
 """
     DeviceParallelEnv(kind, n_envs; max_steps, seed, fixed_length_episodes, device) <: AbstractParallelEnv
@@ -74,7 +74,7 @@ mutable struct DeviceParallelEnv <: AbstractParallelEnv
     last_truncated::Vector{Bool}
 end
 
-function DeviceParallelEnv(kind::Symbol, n_envs::Integer; max_steps::Integer = kind === :CartPole ? 500 : 200,
+function DeviceParallelEnv(kind::Symbol, n_envs::Integer; max_steps::Integer = kind === :CartPole ? 500 : kind === :MountainCarContinuous ? 999 : 200,
         seed::Integer = 42, fixed_length_episodes::Bool = false, device::Integer = 0, monitor_window::Integer = 0,
         normalize::Union{Nothing, NamedTuple} = nothing)
     haskey(ENV_KINDS, kind) || error("unknown device env $kind")
@@ -85,11 +85,14 @@ function DeviceParallelEnv(kind::Symbol, n_envs::Integer; max_steps::Integer = k
 end
 
 number_of_envs(env::DeviceParallelEnv) = env.n_envs
-observation_space(env::DeviceParallelEnv) = env.kind === :CartPole ?
+is_discrete(env) = env.kind === :CartPole || env.kind === :MountainCar
+observation_space(env::DeviceParallelEnv) = (env.kind === :MountainCar || env.kind === :MountainCarContinuous) ? Box(Float32[-1.2, -0.07], Float32[0.6, 0.07]) :
+    env.kind === :CartPole ?
     Box(Float32[-4.8, -Inf, -0.41887903, -Inf], Float32[4.8, Inf, 0.41887903, Inf]) :
     env.kind === :ScaledPendulum ? Box(Float32[-1, -1, -1], Float32[1, 1, 1]) : Box(Float32[-1, -1, -8], Float32[1, 1, 8])
-action_space(env::DeviceParallelEnv) = env.kind === :CartPole ? Discrete(2) : env.kind === :ScaledPendulum ? Box(Float32[-1], Float32[1]) : Box(Float32[-2], Float32[2])
-obs_dim(env::DeviceParallelEnv) = env.kind === :CartPole ? 4 : 3
+action_space(env::DeviceParallelEnv) = env.kind === :CartPole ? Discrete(2) : env.kind === :MountainCar ? Discrete(3) :
+    (env.kind === :ScaledPendulum || env.kind === :MountainCarContinuous) ? Box(Float32[-1], Float32[1]) : Box(Float32[-2], Float32[2])
+obs_dim(env::DeviceParallelEnv) = env.kind === :CartPole ? 4 : (env.kind === :MountainCar || env.kind === :MountainCarContinuous) ? 2 : 3
 
 last_error(h) = unsafe_string(ccall((:dril_last_error, LIB[]), Cstring, (Ptr{Cvoid},), h))
 function check(rc::Int32, h = C_NULL)
@@ -101,7 +104,7 @@ end
 function make_config(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int}, log_std_init::Float32)
     opt(x) = isnothing(x) ? (0.0f0, Int32(0)) : (Float32(x), Int32(1))
     cvf, hcvf = opt(alg.clip_range_vf); mgn, hmgn = opt(alg.max_grad_norm); tkl, htkl = opt(alg.target_kl)
-    start = env.kind === :CartPole ? Int32(action_space(env).start) : Int32(1)
+    start = is_discrete(env) ? Int32(action_space(env).start) : Int32(1)
     nz = env.normalize
     nget(k, d) = isnothing(nz) ? d : get(nz, k, d)
     on = isnothing(nz) ? Int32(0) : Int32(1)
@@ -144,7 +147,7 @@ end
 
 function act!(env::DeviceParallelEnv, actions::AbstractVector)
     E, D = env.n_envs, obs_dim(env)
-    a = env.kind === :CartPole ? Int32[Int32(x) for x in actions] : Float32[Float32(x[1]) for x in actions]
+    a = is_discrete(env) ? Int32[Int32(x) for x in actions] : Float32[Float32(x[1]) for x in actions]
     rewards = Vector{Float32}(undef, E); term = Vector{UInt8}(undef, E); trunc = Vector{UInt8}(undef, E)
     tobs = zeros(Float32, D, E)
     GC.@preserve a rewards term trunc tobs check(ccall((:dril_env_step, LIB[]), Int32,
@@ -223,7 +226,7 @@ function collect_rollout!(buf::RolloutBuffer, agent::Agent, alg::PPO, env::Devic
     fps = Ref{Float64}(0)
     check(ccall((:dril_collect_rollout, LIB[]), Int32, (Ptr{Cvoid}, Ref{Float64}), env.handle, fps), env.handle)
     copy_out!(env, 0, buf.observations)
-    if env.kind === :CartPole                                          # device actions are Int32; the reference buffer is Int64 (spaces.jl:169)
+    if is_discrete(env)                                                # device actions are Int32; the reference buffer is Int64 (spaces.jl:169)
         tmp = Vector{Int32}(undef, length(buf.rewards)); copy_out!(env, 1, tmp); buf.actions .= reshape(tmp, 1, :)
     else
         copy_out!(env, 1, buf.actions)
@@ -379,7 +382,7 @@ function sac_scatter_targets!(tp, flat::Vector{Float32})
 end
 
 function sac_config(env::DeviceParallelEnv, alg::DRiL.SAC, agent)
-    env.kind === :CartPole && error("SAC needs a Box action space (sac.jl:74): DeviceParallelEnv(:Pendulum | :ScaledPendulum, ...)")
+    is_discrete(env) && error("SAC needs a Box action space (sac.jl:74): DeviceParallelEnv(:Pendulum | :ScaledPendulum, ...)")
     hd = hidden_dims_of(agent.train_state.parameters)
     act = agent.layer.actor_head.layers[1].layers[1].activation === DRiL.Lux.relu ? Int32(1) : Int32(0)   # SACLayer default relu (sac.jl:77)
     ec = alg.ent_coef

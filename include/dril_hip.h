@@ -53,7 +53,9 @@ enum dril_env_kind {
     /* ScalingWrapperEnv(PendulumEnv()) (src/environment_wrappers/scalingWrapperEnv.jl:15-49): every sub-env is wrapped, so the agent sees
      * observation_space = action_space = Box(-1, 1): observe returns (obs - low) * 2/(high - low) - 1 (:71-74,93-98) and act! maps the
      * action back with (a + 1) / (2/(high - low)) + low (:76-79,110-113) before the physics; the affine maps are fused into the env kernels */
-    DRIL_ENV_PENDULUM_SCALED = 2
+    DRIL_ENV_PENDULUM_SCALED = 2,
+    DRIL_ENV_MOUNTAINCAR = 3,            /* MountainCar-v0: D=2 (position, velocity), Discrete(3), reward -1/step, goal at 0.5, limit 200 */
+    DRIL_ENV_MOUNTAINCAR_CONTINUOUS = 4  /* MountainCarContinuous-v0: D=2, Box(-1,1), reward 100 at the goal (0.45) - 0.1 a^2, limit 999 */
 };
 
 /* ids for dril_buffer_copy_out / dril_buffer_copy_in (fields of RolloutBuffer,

@@ -114,8 +114,8 @@ class Oracle:
         self._h = _P()
         rc = self.L.orc_create(C.byref(cfg), C.byref(self._h))
         assert rc == 0, rc
-        self.discrete = cfg.env_kind == capi.ENV_CARTPOLE
-        self.D, self.A, self.S = (4, 2, 4) if self.discrete else (3, 1, 2)
+        self.discrete = cfg.env_kind in (capi.ENV_CARTPOLE, capi.ENV_MOUNTAINCAR)
+        self.D, self.A, self.S = {capi.ENV_CARTPOLE: (4, 2, 4), capi.ENV_MOUNTAINCAR: (2, 3, 2), capi.ENV_MOUNTAINCAR_CONTINUOUS: (2, 1, 2)}.get(cfg.env_kind, (3, 1, 2))
         self.P = int(self.L.orc_param_count(self._h))
         self.E, self.T = cfg.n_envs, cfg.n_steps
         self.N = self.E * self.T

@@ -60,7 +60,7 @@ def test_gae_random_vs_oracle(pkg, lib, oracle_mod):
         np.testing.assert_allclose(out[1], out[3], atol=1e-4, rtol=1e-5)
 
 
-@pytest.mark.parametrize("kind", [0, 1, 2])                       # 2 = ScalingWrapperEnv(Pendulum): affine maps fused into the env kernels
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])                 # 2 = ScalingWrapperEnv(Pendulum); 3 / 4 = MountainCar-v0 / MountainCarContinuous-v0
 def test_env_verbs_match_oracle(pkg, oracle_mod, kind):
     """reset!/observe/act! with auto-reset and terminal_observation (multithreadedParallelEnv.jl:12-74)"""
     cfg = _cfg(pkg, kind, n_envs=300, n_steps=4, episode_len=7, batch_size=4)
@@ -71,7 +71,7 @@ def test_env_verbs_match_oracle(pkg, oracle_mod, kind):
     saw_trunc = False
     for step in range(20):
         np.testing.assert_allclose(h.env_observe(), o.env_observe(), atol=2e-6, rtol=2e-6)
-        a = (rng.integers(0, 2, cfg.n_envs) + cfg.action_start).astype(np.int32) if kind == 0 else rng.uniform(-3, 3, (cfg.n_envs, 1)).astype(np.float32)
+        a = (rng.integers(0, h.A, cfg.n_envs) + cfg.action_start).astype(np.int32) if h.discrete else rng.uniform(-3, 3, (cfg.n_envs, 1)).astype(np.float32)
         rh, th, uh, oh = h.env_step(a); ro, to, uo, oo = o.env_step(a)
         np.testing.assert_array_equal(th, to); np.testing.assert_array_equal(uh, uo)
         np.testing.assert_allclose(rh, ro, atol=1e-5, rtol=1e-5)
@@ -84,7 +84,7 @@ def test_env_verbs_match_oracle(pkg, oracle_mod, kind):
     assert saw_trunc
 
 
-@pytest.mark.parametrize("kind,B", [(0, 1), (0, 31), (0, 32), (0, 1000), (1, 65), (1, 4096)])
+@pytest.mark.parametrize("kind,B", [(0, 1), (0, 31), (0, 32), (0, 1000), (1, 65), (1, 4096), (3, 333), (4, 97)])
 def test_policy_forward_evaluate_predict(pkg, oracle_mod, kind, B):
     """layer(obs,ps,st), evaluate_actions, predict_values (layer_forward.jl:3-39, layer_methods.jl:28-61)"""
     cfg = _cfg(pkg, kind, n_envs=2, n_steps=2, batch_size=2)
@@ -93,14 +93,14 @@ def test_policy_forward_evaluate_predict(pkg, oracle_mod, kind, B):
     np.testing.assert_array_equal(h.get_params(), flat)
     rng = np.random.default_rng(B)
     obs = rng.uniform(-2, 2, (B, h.D)).astype(np.float32)
-    noise = rng.random(B) if kind == 0 else rng.standard_normal((B, h.A)).astype(np.float32)
+    noise = rng.random(B) if h.discrete else rng.standard_normal((B, h.A)).astype(np.float32)
     ah, vh, lh = h.policy_forward(obs, noise); ao, vo, lo = o.policy_forward(obs, noise)
     np.testing.assert_allclose(vh, vo, atol=2e-5, rtol=2e-5)
-    if kind == 0:
+    if h.discrete:
         same = ah == ao
-        assert same.mean() >= 0.999                       # an action may flip only when u sits within fp32 rounding of the CDF
+        assert same.mean() >= 0.995                       # an action may flip only when u sits within fp32 rounding of the CDF
         np.testing.assert_allclose(lh[same], lo[same], atol=2e-5, rtol=2e-5)
-        assert set(np.unique(ah)) <= {cfg.action_start, cfg.action_start + 1}
+        assert set(np.unique(ah)) <= {cfg.action_start + i for i in range(h.A)}
     else:
         np.testing.assert_allclose(ah, ao, atol=2e-5, rtol=2e-5)
         np.testing.assert_allclose(lh, lo, atol=1e-4, rtol=1e-4)
@@ -121,7 +121,7 @@ def _rollout_pair(pkg, oracle_mod, kind, E, T, L, seed, fixed=False):
     return cfg, h, o
 
 
-@pytest.mark.parametrize("kind,E,T,L,fixed", [(0, 64, 48, 500, False), (0, 100, 40, 9, True), (1, 33, 50, 12, False), (0, 1, 5, 3, False), (2, 40, 30, 12, False)])
+@pytest.mark.parametrize("kind,E,T,L,fixed", [(0, 64, 48, 500, False), (0, 100, 40, 9, True), (1, 33, 50, 12, False), (0, 1, 5, 3, False), (2, 40, 30, 12, False), (3, 70, 40, 15, False), (4, 33, 24, 10, False)])
 def test_collect_rollout_matches_oracle(pkg, oracle_mod, kind, E, T, L, fixed):
     """collect_rollout! (rollout_buffer.jl:46-90): every buffer field vs the trajectory-based oracle, with injected
     sampling noise and with the shared Philox stream; includes terminations, mid-rollout truncations with
@@ -131,13 +131,13 @@ def test_collect_rollout_matches_oracle(pkg, oracle_mod, kind, E, T, L, fixed):
         cfg, h, o = _rollout_pair(pkg, oracle_mod, kind, E, T, L, seed=17 + E, fixed=fixed)
         if inject:
             rng = np.random.default_rng(E)
-            noise = rng.random(E * T) if kind == 0 else rng.standard_normal((E * T, h.A)).astype(np.float32)
+            noise = rng.random(E * T) if h.discrete else rng.standard_normal((E * T, h.A)).astype(np.float32)
             h.set_noise(noise); o.set_noise(noise)
         for rollout in range(2):                       # the env is NOT reset between rollouts (trajectory.jl:26)
             fps = h.collect_rollout(); o.collect_rollout()
             assert fps > 0
             ah, ao = h.buffer(capi.BUF_ACTIONS).reshape(T, E, -1), o.buffer(capi.BUF_ACTIONS).reshape(T, E, -1)
-            if kind == 0:
+            if h.discrete:
                 ok = np.cumprod((ah == ao).all(axis=2), axis=0).astype(bool)     # env matches up to its first action flip
                 assert ok.all(axis=0).mean() >= 0.98
             else:
@@ -178,7 +178,7 @@ def _batch(oracle, cfg, B, seed):
 
 
 @pytest.mark.parametrize("kind,B,variant", [(0, 64, "default"), (0, 33, "default"), (0, 4096, "ent_vfclip"), (0, 65536, "default"),
-                                             (1, 64, "default"), (1, 1000, "ent_vfclip"), (0, 200, "no_norm")])
+                                             (1, 64, "default"), (1, 1000, "ent_vfclip"), (0, 200, "no_norm"), (3, 500, "ent_vfclip"), (4, 129, "default")])
 def test_ppo_loss_and_gradient(pkg, oracle_mod, kind, B, variant):
     """(alg::PPO)(...) ppo.jl:365-407 + gradient: loss within 1e-4 rel (north_star), gradient within fp32 noise"""
     kw = dict(n_envs=2, n_steps=2, batch_size=2)
@@ -228,6 +228,8 @@ def test_apply_gradients_clip_adam_nan(pkg, oracle_mod):
     (0, 10, 13, 16, {}),                                   # N = 130: ragged last minibatch of 2 kept (MLUtils partial=true)
     (1, 12, 20, 60, {"ent_coef": 0.01}),
     (2, 12, 20, 60, {}),                                   # ScalingWrapperEnv(Pendulum): the update shares the Pendulum kernels
+    (3, 12, 20, 60, {"ent_coef": 0.01}),                   # MountainCar-v0: Categorical over 3 actions, D = 2
+    (4, 12, 20, 48, {}),                                   # MountainCarContinuous-v0
     (0, 16, 24, 96, {"has_target_kl": 1, "target_kl": 0.002}),
     (0, 16, 24, 384, {"has_clip_range_vf": 1, "clip_range_vf": 0.2}),
 ])
@@ -356,7 +358,7 @@ def test_rccl_plumbing_single_rank(pkg, oracle_mod, monkeypatch):
     np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=5e-4, atol=5e-6)
 
 
-@pytest.mark.parametrize("kind,flags", [(1, (1, 1)), (0, (1, 1)), (1, (1, 0)), (1, (0, 1)), (2, (1, 1))])   # last: Normalize(Parallel([Scaling(Pendulum)]))
+@pytest.mark.parametrize("kind,flags", [(1, (1, 1)), (0, (1, 1)), (1, (1, 0)), (1, (0, 1)), (2, (1, 1)), (3, (1, 1)), (4, (1, 1))])   # 2: Normalize(Parallel([Scaling(Pendulum)])); 3, 4: MountainCar
 def test_normalize_wrapper_rollout_matches_oracle(pkg, oracle_mod, kind, flags):
     """NormalizeWrapperEnv on device (normalizeWrapperEnv.jl:21-50,123-197): running obs/return statistics (updated on EVERY
     observe, including the double update at a rollout boundary), normalised + clipped obs and rewards, normalised
@@ -370,7 +372,7 @@ def test_normalize_wrapper_rollout_matches_oracle(pkg, oracle_mod, kind, flags):
     h.env_reset(9); o.env_reset(9)
     rng = np.random.default_rng(2)
     for rollout in range(2):
-        noise = rng.random(E * T) if kind == 0 else rng.standard_normal((E * T, h.A)).astype(np.float32)
+        noise = rng.random(E * T) if h.discrete else rng.standard_normal((E * T, h.A)).astype(np.float32)
         h.set_noise(noise); o.set_noise(noise)
         h.collect_rollout(); o.collect_rollout()
         sh = h.norm_get_stats(); om, ov, oc, rm, rv, rc = o.norm_stats()
@@ -379,7 +381,7 @@ def test_normalize_wrapper_rollout_matches_oracle(pkg, oracle_mod, kind, flags):
         np.testing.assert_allclose(sh["obs_mean"], om, rtol=2e-5, atol=2e-6); np.testing.assert_allclose(sh["obs_var"], ov, rtol=1e-4, atol=1e-6)
         assert sh["ret_mean"] == pytest.approx(rm, rel=1e-4, abs=1e-5) and sh["ret_var"] == pytest.approx(rv, rel=1e-4, abs=1e-5)
         ah, ao = h.buffer(capi.BUF_ACTIONS).reshape(T, E, -1), o.buffer(capi.BUF_ACTIONS).reshape(T, E, -1)
-        ok = np.cumprod((ah == ao).all(axis=2), axis=0).astype(bool).all(axis=0) if kind == 0 else np.ones(E, bool)
+        ok = np.cumprod((ah == ao).all(axis=2), axis=0).astype(bool).all(axis=0) if h.discrete else np.ones(E, bool)
         assert ok.mean() >= 0.95
         for which, tol in ((capi.BUF_OBSERVATIONS, 1e-4), (capi.BUF_VALUES, 2e-4), (capi.BUF_LOGPROBS, 2e-4), (capi.BUF_REWARDS, 2e-4),
                            (capi.BUF_ADVANTAGES, 2e-3), (capi.BUF_RETURNS, 2e-3)):
@@ -627,11 +629,11 @@ def test_monitor_off_is_an_error(pkg):
 
 
 @pytest.mark.parametrize("kind,det,kw", [(0, True, {}), (0, False, {}), (1, True, dict(norm_training=1, norm_obs=1, norm_reward=1, monitor_window=50)),
-                                         (1, False, dict(norm_training=1, norm_obs=1, norm_reward=1)), (2, True, dict(monitor_window=20))])
+                                         (1, False, dict(norm_training=1, norm_obs=1, norm_reward=1)), (2, True, dict(monitor_window=20)), (3, True, {}), (4, False, dict(monitor_window=10))])
 def test_evaluate_agent(pkg, oracle_mod, kind, det, kw):
     """evaluate_agent (src/evaluation.jl:54-143): reset, predict(deterministic) / act! / observe until the first n episodes finish,
     mean / corrected std of returns and lengths; monitored envs report RAW returns"""
-    cfg = _cfg(pkg, kind, n_envs=24, n_steps=4, episode_len=15 if kind else 60, batch_size=24, **kw)
+    cfg = _cfg(pkg, kind, n_envs=24, n_steps=4, episode_len=15 if kind else 60, batch_size=24, **kw)      # MountainCar: every episode ends at the time limit
     h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
     flat = _params(h.P, 21, 0.5)
     if kind == 0:

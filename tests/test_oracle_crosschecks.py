@@ -183,6 +183,66 @@ def test_env_physics_vs_gymnasium_equations(oracle_mod, pkg):
                 np.testing.assert_allclose(cur[e], exp, rtol=1e-5, atol=1e-5)
 
 
+def _mountaincar_f64(st, action, continuous):
+    """Gymnasium MountainCar-v0 / MountainCarContinuous-v0 step in float64 -> (state, reward, terminated)"""
+    pos, vel = float(st[0]), float(st[1])
+    if continuous:
+        force = min(max(float(action), -1.0), 1.0)
+        vel += force * 0.0015 - 0.0025 * math.cos(3 * pos)
+    else:
+        force = 0.0
+        vel += (int(action) - 1) * 0.001 + math.cos(3 * pos) * (-0.0025)
+    vel = min(max(vel, -0.07), 0.07)
+    pos += vel
+    pos = min(max(pos, -1.2), 0.6)
+    if pos == -1.2 and vel < 0:
+        vel = 0.0
+    goal = pos >= (0.45 if continuous else 0.5) and vel >= 0
+    rew = ((100.0 if goal else 0.0) - 0.1 * force * force) if continuous else -1.0
+    return np.array([pos, vel]), rew, goal
+
+
+@pytest.mark.parametrize("kind", [3, 4])
+def test_mountaincar_physics_vs_gymnasium_equations(oracle_mod, pkg, kind):
+    """MountainCar-v0 / MountainCarContinuous-v0: reset distribution, step, wall rule, goal termination, time limit"""
+    capi = pkg._capi
+    cont = kind == capi.ENV_MOUNTAINCAR_CONTINUOUS
+    cfg = capi.default_config(kind); cfg.n_envs, cfg.n_steps, cfg.episode_len = 32, 4, 40
+    assert capi.default_config(kind).episode_len == (999 if cont else 200)
+    o = oracle_mod.Oracle(cfg); o.env_reset(5)
+    st, _ = o.env_get_state()
+    assert np.all((st[:, 0] >= -0.6) & (st[:, 0] <= -0.4)) and not st[:, 1].any()
+    np.testing.assert_array_equal(o.env_observe(), st)
+    rng = np.random.default_rng(0)
+    # put some cars next to the wall / the goal so that both special cases are hit
+    st[:4] = [[-1.199, -0.05], [-1.2, -0.01], [0.49, 0.06], [0.44, 0.069]]
+    o.env_set_state(st, np.zeros(32, np.int32))
+    saw_goal = saw_wall = False
+    for step in range(1, 45):
+        a = rng.uniform(-1.5, 1.5, (32, 1)).astype(np.float32) if cont else (rng.integers(0, 3, 32) + cfg.action_start).astype(np.int32)
+        if step <= 2:
+            a[:2] = -1.0 if cont else cfg.action_start
+            a[2:4] = 1.0 if cont else cfg.action_start + 2
+        prev, psc = o.env_get_state()
+        rew, term, trunc, tobs = o.env_step(a)
+        cur, sc = o.env_get_state()
+        for e in range(32):
+            exp, r, goal = _mountaincar_f64(prev[e].astype(np.float64), a[e, 0] if cont else a[e] - cfg.action_start, cont)
+            near = abs(exp[0] - (0.45 if cont else 0.5)) < 1e-6 or abs(exp[0] + 1.2) < 1e-7 and abs(prev[e][0] + 1.2) > 1e-7
+            if not near:
+                assert bool(term[e]) == goal
+                assert rew[e] == pytest.approx(r, rel=1e-5, abs=1e-6)
+            saw_goal |= bool(term[e]); saw_wall |= (exp[0] == -1.2 and exp[1] == 0.0)
+            assert bool(trunc[e]) == (psc[e] + 1 >= 40)
+            if term[e] or trunc[e]:
+                assert -0.6 <= cur[e][0] <= -0.4 and cur[e][1] == 0 and sc[e] == 0         # auto-reset
+                if trunc[e] and not near:
+                    np.testing.assert_allclose(tobs[e], exp, rtol=1e-5, atol=1e-6)
+            elif not near:
+                np.testing.assert_allclose(cur[e], exp, rtol=1e-5, atol=1e-6)
+    assert saw_goal and saw_wall
+
+
 def test_update_loop_control_flow(oracle_mod, pkg):
     """ppo.jl:205-254: partial last batch kept, target_kl early stop skips the apply and both loops."""
     capi = pkg._capi
