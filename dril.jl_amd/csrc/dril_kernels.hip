@@ -11,6 +11,8 @@
 //   ppo_grad_kernel      (alg::PPO)(layer,ps,st,batch) ppo.jl:365-407 + its reverse pass (Zygote in the reference, ppo.jl:207)
 //   grad_reduce_kernel / grad_norm_kernel / adam_kernel   nested_norm, nested_scale!, target_kl check, Adam — ppo.jl:213-239
 //   explained_var_kernel ppo.jl:256
+#include <utility>
+
 #include "dril_internal.h"
 
 namespace dril {
@@ -1200,7 +1202,24 @@ __device__ __forceinline__ void grad_front_a(const float* __restrict__ wl, float
     tanh_tiles(t.h1);
 #pragma unroll
     for (int mo = 0; mo < MT; ++mo) {
-        t.h2[mo] = dense_mfma_tile<MT, true>(wl + L::W2S, L::WS1, wl + L::B2, t.h1, mo, lane);
+        const int o_ = lane & 31, h_ = lane >> 5;
+        f32x16 accm;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B2 + 32 * mo + 8 * q + 4 * h_);
+            accm[4 * q + 0] = b[0]; accm[4 * q + 1] = b[1]; accm[4 * q + 2] = b[2]; accm[4 * q + 3] = b[3];
+        }
+        const float* wrow = wl + L::W2S + (32 * mo + o_) * L::WS1 + 4 * h_;
+        f32x4 avs[MT * 4];                                            // all A operands of the chain up front
+#pragma unroll
+        for (int gg = 0; gg < MT * 4; ++gg) avs[gg] = *reinterpret_cast<const f32x4*>(wrow + 32 * (gg / 4) + 8 * (gg % 4));
+#pragma unroll
+        for (int gg = 0; gg < MT * 4; ++gg) {
+            const int mi = gg / 4, q = gg % 4;
+            accm = mfma32(avs[gg][0], t.h1[mi][4 * q + 0], accm); accm = mfma32(avs[gg][1], t.h1[mi][4 * q + 1], accm);
+            accm = mfma32(avs[gg][2], t.h1[mi][4 * q + 2], accm); accm = mfma32(avs[gg][3], t.h1[mi][4 * q + 3], accm);
+        }
+        t.h2[mo] = accm;
         tanh16(t.h2[mo]);
     }
     store_image<MT>(T, t.h2, lane);
@@ -1449,6 +1468,236 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* red = smem + DL::SCR;
     grad_slab<D, H, OA, HEADA>(red, a.slabs_actor + (size_t)g * a.slab_a, a.slab_a, accA, tid, wave, lane);
     grad_slab<D, H, 1, HEAD_VALUE>(red, a.slabs_critic + (size_t)g * a.slab_c, a.slab_c, accC, tid, wave, lane);
+}
+
+// =============================================================================================
+// ppo_grad_pipe_kernel (GradArgs.layout == 3) — one net per workgroup like ppo_grad_kernel, but ONE wave per SIMD (up to 512
+// registers) and the tile loop software-pipelined: the hidden-layer backward of tile k-1 (144 MFMA: dh1, dW2, dW1) runs in the same
+// instruction stream as the output layer / loss head / output-layer backward of tile k (VALU + LDS), with the VALU work cut into
+// chunks that are issued from INSIDE the MFMA group loops (one chunk after every 4 MFMAs) — the overlap is fixed by program order
+// instead of depending on how the hardware arbitrates two independent waves.
+// =============================================================================================
+template <int I> struct IC { static constexpr int value = I; };
+template <class Fn, int... Is> __device__ __forceinline__ void static_for_impl(Fn&& fn, std::integer_sequence<int, Is...>) { (fn(IC<Is>{}), ...); }
+template <int N, class Fn> __device__ __forceinline__ void static_for(Fn&& fn) { static_for_impl(fn, std::make_integer_sequence<int, N>{}); }
+
+// the VALU / LDS stage of one tile as a list of chunks; run<I>() executes chunk I (no-op past the end)
+template <int D, int H, int O, int HEAD> struct FrontB {
+    static constexpr int MT = H / 32;
+    using L = NetLds<D, H, H, O>;
+    static constexpr int C_OUT = 0, C_RED = MT, C_HEAD = MT + 1, C_ZI = MT + 2, C_W3 = MT + 3, C_Z2 = C_W3 + 4 * O, N = C_Z2 + 4 * MT;
+    const GradArgs& a; const float* wl; float* T; float* ZI; const TileIn<O>& cur; const float* ls; float adv_mean, adv_inv;
+    GradAcc<H, O>& acc; GradTile<H>& t; int lane, c, h;
+    float part[O], out[O], dz[O]; f32x16 Bh2[MT];
+    f32x4 w3[O][MT][4], zv[O][4];                                 // W3 rows of the lane's 16 hidden units (used twice: output layer and dz2), dz broadcast vectors
+    __device__ __forceinline__ void preload() {                   // issue the weight reads before the MFMA stage they hide under
+#pragma unroll
+        for (int o = 0; o < O; ++o)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w3[o][m][q] = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * m + 8 * q + 4 * h);
+    }
+    __device__ __forceinline__ FrontB(const GradArgs& a_, const float* wl_, float* T_, float* ZI_, const TileIn<O>& cur_, const float* ls_, float am, float ai,
+                                      GradAcc<H, O>& acc_, GradTile<H>& t_, int lane_)
+        : a(a_), wl(wl_), T(T_), ZI(ZI_), cur(cur_), ls(ls_), adv_mean(am), adv_inv(ai), acc(acc_), t(t_), lane(lane_), c(lane_ & 31), h(lane_ >> 5) {}
+    template <int I> __device__ __forceinline__ void run() {
+        if constexpr (I >= C_OUT && I < C_RED) {                     // output layer, m-tile I: partial sums over the lane's 16 hidden rows
+            constexpr int mo = I - C_OUT;
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                float s = mo == 0 ? 0.f : part[o];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = w3[o][mo][q];
+                    s = fmaf(w[0], t.h2[mo][4 * q + 0], s); s = fmaf(w[1], t.h2[mo][4 * q + 1], s);
+                    s = fmaf(w[2], t.h2[mo][4 * q + 2], s); s = fmaf(w[3], t.h2[mo][4 * q + 3], s);
+                }
+                part[o] = s;
+            }
+        } else if constexpr (I == C_RED) {
+#pragma unroll
+            for (int o = 0; o < O; ++o) out[o] = part[o] + __shfl_xor(part[o], 32) + wl[L::B3 + o];
+        } else if constexpr (I == C_HEAD) {
+            loss_head<O, HEAD>(a, cur, out, cur.valid, h == 0, ls, adv_mean, adv_inv, dz, acc.st, acc.dlsp);
+        } else if constexpr (I == C_ZI) {
+#pragma unroll
+            for (int o = 0; o < O; ++o) { if (h == 0) { acc.db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj) Bh2[mj] = load_operand(T, mj, lane);
+        } else if constexpr (I >= C_W3 && I < C_Z2) {                // dW3[o] += dz[o] * h2' over the samples 16h + 4q .. +3
+            constexpr int o = (I - C_W3) / 4, q = (I - C_W3) % 4;
+            if constexpr (I == C_W3) {
+#pragma unroll
+                for (int oo = 0; oo < O; ++oo)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) zv[oo][qq] = *reinterpret_cast<const f32x4*>(ZI + oo * kTS + 16 * h + 4 * qq);
+            }
+            const f32x4 z = zv[o][q];
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj) {
+                float s = acc.dW3a[o][mj];
+                s = fmaf(Bh2[mj][4 * q + 0], z[0], s); s = fmaf(Bh2[mj][4 * q + 1], z[1], s);
+                s = fmaf(Bh2[mj][4 * q + 2], z[2], s); s = fmaf(Bh2[mj][4 * q + 3], z[3], s);
+                acc.dW3a[o][mj] = s;
+            }
+        } else if constexpr (I >= C_Z2 && I < N) {                   // dz2 = (W3' dz) .* (1 - h2^2), in h2's registers
+            constexpr int m = (I - C_Z2) / 4, q = (I - C_Z2) % 4;
+            float dh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const f32x4 w = w3[o][m][q];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(w[cc], dz[o], dh[cc]);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) { const float hv = t.h2[m][4 * q + cc]; t.h2[m][4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
+        }
+    }
+    template <int FROM> __device__ __forceinline__ void run_rest() { static_for<(N > FROM ? N - FROM : 0)>([&](auto ic) __attribute__((always_inline)) { run<FROM + decltype(ic)::value>(); }); }
+};
+struct NoSteps { template <int I> __device__ __forceinline__ void run() {} __device__ __forceinline__ void preload() {} };
+
+// grad_back with one step of `S` issued after every group of 4 MFMAs (36 groups: dh1 16, dW2 16, dW1 4)
+template <int D, int H, int O, class S>
+__device__ __forceinline__ void grad_back_steps(const float* __restrict__ wl, float* __restrict__ T, float* __restrict__ XI, GradAcc<H, O>& acc, GradTile<H>& t, int lane, S& steps) {
+    constexpr int MT = H / 32;
+    static_assert(MT == 2, "group numbering below assumes H = 64");
+    using L = NetLds<D, H, H, O>;
+    const int c = lane & 31, h = lane >> 5;
+    store_image<MT>(T, t.h1, lane);
+    f32x16 g1[MT];
+    static_for<MT>([&](auto im) __attribute__((always_inline)) {
+        constexpr int m = decltype(im)::value;
+        f32x16 accm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accm[r] = 0.f;
+        const float* wrow = wl + L::W2T + (32 * m + (lane & 31)) * L::WS2 + 4 * h;
+        f32x4 avs[MT * 4];                                            // all A operands of the chain up front: one exposed LDS round trip per 32 MFMAs instead of one per 4
+#pragma unroll
+        for (int gg = 0; gg < MT * 4; ++gg) avs[gg] = *reinterpret_cast<const f32x4*>(wrow + 32 * (gg / 4) + 8 * (gg % 4));
+        if (m == 0) steps.preload();
+        static_for<MT * 4>([&](auto ig) __attribute__((always_inline)) {
+            constexpr int g = decltype(ig)::value, mi = g / 4, q = g % 4;
+            const f32x4 av = avs[g];
+            accm = mfma32(av[0], t.h2[mi][4 * q + 0], accm); accm = mfma32(av[1], t.h2[mi][4 * q + 1], accm);
+            accm = mfma32(av[2], t.h2[mi][4 * q + 2], accm); accm = mfma32(av[3], t.h2[mi][4 * q + 3], accm);
+            steps.template run<m * 8 + g>();
+        });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g1[m][r] = accm[r] * (1.0f - t.h1[m][r] * t.h1[m][r]);
+    });
+    f32x16 Bh[MT];
+#pragma unroll
+    for (int mj = 0; mj < MT; ++mj) Bh[mj] = load_operand(T, mj, lane);
+    store_image<MT>(T, t.h2, lane);                                    // dz2 image
+    static_for<MT>([&](auto imi) __attribute__((always_inline)) {
+        constexpr int mi = decltype(imi)::value;
+        const f32x16 Az = load_operand(T, mi, lane);
+        acc.db2p[mi] += sum16(Az);
+        static_for<MT * 4>([&](auto ig) __attribute__((always_inline)) {
+            constexpr int g = decltype(ig)::value, mj = g / 4, qq = g % 4;
+#pragma unroll
+            for (int kk = 4 * qq; kk < 4 * qq + 4; ++kk) acc.dW2[mi][mj] = mfma32(Az[kk], Bh[mj][kk], acc.dW2[mi][mj]);
+            steps.template run<16 + mi * 8 + g>();
+        });
+    });
+    store_image<MT>(T, g1, lane);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) XI[d * kTS + c] = t.xk[s]; }
+    {
+        const int j = lane & 15;
+        float bx[8];
+        load_row8(XI, j <= D ? j : D + 1, lane, bx);
+        float azs[H / 16][8];
+#pragma unroll
+        for (int mt = 0; mt < H / 16; ++mt) load_row8(T, 16 * mt + j, lane, azs[mt]);
+        static_for<H / 16>([&](auto imt) __attribute__((always_inline)) {
+            constexpr int mt = decltype(imt)::value;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc.dW1[mt] = mfma16(azs[mt][k], bx[k], acc.dW1[mt]);
+            steps.template run<32 + mt>();
+        });
+    }
+}
+
+template <int D, int H, int O> struct PipeLds {
+    using L = NetLds<D, H, H, O>; using SC = GradScratch<D, H, O>;
+    static constexpr int SCR = (L::BWD_END + 3) / 4 * 4;
+    static constexpr int PER_WAVE = SC::SIZE + H * kTS;              // back-stage image + XI + ZI, plus the front-stage image
+    static constexpr int SIZE = SCR + 4 * PER_WAVE;
+};
+
+template <int KIND, int H, int O, int HEAD>
+__device__ __forceinline__ void grad_body_pipe(const GradArgs& a, float* smem) {
+    constexpr int D = EnvSpec<KIND>::D;
+    using PL = PipeLds<D, H, O>; using SC = typename PL::SC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
+    float* wl = smem;
+    float* scr = smem + PL::SCR + wave * PL::PER_WAVE;
+    float *TB = scr + SC::T, *XI = scr + SC::XI, *ZI = scr + SC::ZI, *TF = scr + SC::SIZE;
+    stage_net<D, H, H, O, true>(wl, a.params, off, tid, blockDim.x);
+    for (int i = lane; i < PL::PER_WAVE; i += 64) scr[i] = 0.f;        // the first back() of the pipeline runs on zero images
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int i = lane; i < (D + 2) * kTS; i += 64) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
+    __syncthreads();
+    float adv_mean = 0.f, adv_den = 1.f;
+    if (HEAD != HEAD_VALUE && a.normalize_adv) {
+        const double s = a.adv_stats[0], q = a.adv_stats[1], n = a.adv_stats[2];
+        const double mean = s / n;
+        double var = (q - s * mean) / (n - 1.0);
+        if (var < 0) var = 0;
+        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
+    }
+    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
+    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
+    const float* ls = a.params + a.log_std_off;
+
+    GradAcc<H, O> acc; acc.zero();
+    GradTile<H> tp, tn; tp.zero();
+    const int g = (int)(blockIdx.x % a.G);
+    const int64_t ntiles = (a.count + kTile - 1) / kTile, tstride = (int64_t)a.G * 4;
+    int64_t tile = (int64_t)g * 4 + wave;
+    TileIn<O> cur, nxt;
+    if (tile < ntiles) load_tile<KIND, O, HEAD, true>(a, tile, ntiles, c, h, cur);
+    for (; tile < ntiles; tile += tstride) {
+        load_tile<KIND, O, HEAD, true>(a, tile + tstride, ntiles, c, h, nxt);
+        unpack_tile<KIND, O, HEAD, true>(a, h, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        grad_front_a<D, H, O>(wl, TF, cur.xk, tn, lane);                 // layers 1-2 of tile k (64 MFMA) + h2 image
+        __builtin_amdgcn_sched_barrier(0);
+        {   // hidden-layer backward of tile k-1 (144 MFMA) with the head / output-layer backward of tile k issued between the MFMA groups
+            FrontB<D, H, O, HEAD> fb(a, wl, TF, ZI, cur, ls, adv_mean, adv_inv, acc, tn, lane);
+            grad_back_steps<D, H, O>(wl, TB, XI, acc, tp, lane, fb);
+            fb.template run_rest<36>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < H / 32; ++m) { tp.h1[m] = tn.h1[m]; tp.h2[m] = tn.h2[m]; }
+        tp.xk[0] = tn.xk[0]; tp.xk[1] = tn.xk[1];
+        cur = nxt;
+    }
+    { NoSteps ns; grad_back_steps<D, H, O>(wl, TB, XI, acc, tp, lane, ns); }   // drain: back(last tile)
+    __syncthreads();
+    float* red = smem + PL::SCR;
+    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
+    grad_slab<D, H, O, HEAD>(red, (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL, SL, acc, tid, wave, lane);
+}
+template <int KIND, int H>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ppo_grad_pipe_kernel(GradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (*a.stop_flag) return;
+    constexpr int A = EnvSpec<KIND>::A;
+    if (blockIdx.x < (unsigned)a.G) grad_body_pipe<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN>(a, smem);
+    else grad_body_pipe<KIND, H, 1, HEAD_VALUE>(a, smem);
+}
+template <int KIND, int H> static size_t grad_pipe_lds_bytes() {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
+    constexpr int wa = PipeLds<D, H, A>::SIZE, wc = PipeLds<D, H, 1>::SIZE;
+    return sizeof(float) * (wa > wc ? wa : wc);
 }
 
 // =============================================================================================
@@ -2029,6 +2278,19 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
     if (hidden == 256) {
         if (kind == 0) { if (a.rec) CALLW(0, 256, true) else CALLW(0, 256, false) }
         else { if (a.rec) CALLW(1, 256, true) else CALLW(1, 256, false) }
+        return hipGetLastError();
+    }
+    if (a.layout == 3 && a.rec && hidden == 64 && kind <= 2) {
+#define CALLP(K)                                                                                              \
+    {                                                                                                         \
+        const size_t lds = grad_pipe_lds_bytes<K, 64>();                                                      \
+        static bool attr_set = false;                                                                         \
+        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_pipe_kernel<K, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e; attr_set = true; }                                                 \
+        ppo_grad_pipe_kernel<K, 64><<<2 * a.G, 256, lds, s>>>(a);                                             \
+    }
+        if (kind == 0) CALLP(0) else CALLP(1)
+#undef CALLP
         return hipGetLastError();
     }
     if (a.layout == 2 && a.rec && hidden == 64 && kind <= 2) {

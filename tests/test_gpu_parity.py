@@ -691,3 +691,26 @@ def test_scaling_wrapper_is_pendulum_in_other_units(pkg):
     assert len(stats["losses"]) == 2 and np.isfinite(stats["losses"]).all()
     obs = env.handle.buffer(capi.BUF_OBSERVATIONS)
     assert np.abs(obs).max() <= 1.0 + 1e-6                                                  # every observation inside the wrapper's Box(-1, 1)
+
+
+@pytest.mark.parametrize("layout", [2, 3])
+def test_experimental_grad_layouts_are_exact(pkg, oracle_mod, monkeypatch, layout):
+    """DRIL_GRAD_LAYOUT=2 (both nets in one wave) and =3 (software-pipelined tile loop): same update as the default layout and as the oracle
+    (they are kept as measured A/B experiments, profiles/r01_mfma_valu_microbench.md)"""
+    capi = pkg._capi
+    for kind in (0, 1):
+        cfg = _cfg(pkg, kind, n_envs=32, n_steps=40, episode_len=11, batch_size=320, epochs=2)
+        flat = None; res = []
+        for lay in (1, layout):
+            monkeypatch.setenv("DRIL_GRAD_LAYOUT", str(lay))
+            h = pkg.Handle(cfg)
+            flat = _params(h.P, 3, 0.4) if flat is None else flat
+            h.set_params(flat); h.env_reset(4)
+            noise = np.random.default_rng(1).random(32 * 40) if kind == 0 else np.random.default_rng(1).standard_normal((32 * 40, 1)).astype(np.float32)
+            h.set_noise(noise); h.collect_rollout()
+            perm = np.stack([np.random.default_rng(7 + e).permutation(h.N) for e in range(2)]).astype(np.int64)
+            h.set_permutation(perm)
+            st = h.ppo_update()
+            res.append((st.loss, st.grad_norm, h.get_params()))
+        assert res[0][0] == pytest.approx(res[1][0], rel=1e-5) and res[0][1] == pytest.approx(res[1][1], rel=1e-5)
+        np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-4, atol=2e-6)
