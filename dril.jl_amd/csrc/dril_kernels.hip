@@ -526,7 +526,12 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
     uint32_t ep = a.episode[e], gs = a.gstep[e];
     float obs[D];
     env_obs<KIND>(st, obs);
-    const float* ls = a.params + a.log_std_off;
+    float lsr[4] = {0.f, 0.f, 0.f, 0.f};                               // log_std in registers for the whole rollout (the parameters are read-only during it)
+    if (!DISC) {
+#pragma unroll
+        for (int i = 0; i < (A < 4 ? A : 4); ++i) lsr[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + i])));
+    }
+    const float* ls = lsr;
     float mon_ret = a.mon_cur_ret ? a.mon_cur_ret[e] : 0.f;           // MonitorWrapperEnv running episode return / length
     int mon_len = a.mon_cur_len ? a.mon_cur_len[e] : 0;
 
@@ -724,6 +729,7 @@ __global__ void moments_finalize_kernel(const double* partials, int nblocks, dou
 // fixed order, so the result is bitwise reproducible and no float atomics are used.
 // =============================================================================================
 enum { HEAD_CATEGORICAL = 0, HEAD_GAUSSIAN = 1, HEAD_VALUE = 2 };
+constexpr int kLsMax = 4;   // action dims whose log_std the kernels keep in registers
 
 // diagnostic build only (-DDRIL_STAMPS): per-phase s_memtime shares of one tile; never used for timing claims
 #ifdef DRIL_STAMPS
@@ -912,7 +918,17 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
     }
     adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
     const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
-    const float* ls = a.params + a.log_std_off;
+    constexpr bool LS_GAUSS = HEAD == HEAD_GAUSSIAN; constexpr int LS_N = O;
+    // log_std hoisted into scalar registers: a per-tile global load would sit in the in-order vmcnt queue between the prefetched
+    // gathers and their first use and drain them every tile (Pendulum [64,64]: 91 -> TFLOP/s below)
+    float lsr[kLsMax];
+#pragma unroll
+    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
+    if (LS_GAUSS) {
+#pragma unroll
+        for (int o = 0; o < LS_N; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
+    }
+    const float* ls = lsr;
 
     f32x16 dW2[MT][MT];
     f32x4 dW1[H / 16];                                             // 16x16x4 tiles: rows = hidden, cols = [x | 1 | 0...]
@@ -1060,7 +1076,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
         // ---- dW1 | db1 += dz1 * [x; 1]' ----
         store_image<MT>(T, g1, lane);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) XI[d * kTS + c] = xk[s]; }
+        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
         {   // v_mfma_f32_16x16x4_f32: M = 16 hidden rows, N = 16 columns [x_0..x_{D-1}, 1, 0...], K = 4 samples per step
             const int j = lane & 15;
             float bx[8];
@@ -1302,7 +1318,7 @@ __device__ __forceinline__ void grad_back(const float* __restrict__ wl, float* _
     }
     store_image<MT>(T, g1, lane);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) XI[d * kTS + c] = t.xk[s]; }
+    for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? t.xk[s] : 0.f; }
     {
         const int j = lane & 15;
         float bx[8];
@@ -1420,7 +1436,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
     const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
-    const float* ls = a.params + a.log_std_off;
+    constexpr bool LS_GAUSS = HEADA == HEAD_GAUSSIAN; constexpr int LS_N = OA;
+    // log_std hoisted into scalar registers: a per-tile global load would sit in the in-order vmcnt queue between the prefetched
+    // gathers and their first use and drain them every tile (Pendulum [64,64]: 91 -> TFLOP/s below)
+    float lsr[kLsMax];
+#pragma unroll
+    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
+    if (LS_GAUSS) {
+#pragma unroll
+        for (int o = 0; o < LS_N; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
+    }
+    const float* ls = lsr;
 
     GradAcc<H, OA> accA; GradAcc<H, 1> accC; accA.zero(); accC.zero();
     GradTile<H> tA, tC; tA.zero(); tC.zero();
@@ -1604,7 +1630,7 @@ __device__ __forceinline__ void grad_back_steps(const float* __restrict__ wl, fl
     });
     store_image<MT>(T, g1, lane);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) XI[d * kTS + c] = t.xk[s]; }
+    for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? t.xk[s] : 0.f; }
     {
         const int j = lane & 15;
         float bx[8];
@@ -1654,7 +1680,17 @@ __device__ __forceinline__ void grad_body_pipe(const GradArgs& a, float* smem) {
     }
     adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
     const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
-    const float* ls = a.params + a.log_std_off;
+    constexpr bool LS_GAUSS = HEAD == HEAD_GAUSSIAN; constexpr int LS_N = O;
+    // log_std hoisted into scalar registers: a per-tile global load would sit in the in-order vmcnt queue between the prefetched
+    // gathers and their first use and drain them every tile (Pendulum [64,64]: 91 -> TFLOP/s below)
+    float lsr[kLsMax];
+#pragma unroll
+    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
+    if (LS_GAUSS) {
+#pragma unroll
+        for (int o = 0; o < LS_N; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
+    }
+    const float* ls = lsr;
 
     GradAcc<H, O> acc; acc.zero();
     GradTile<H> tp, tn; tp.zero();
@@ -1794,7 +1830,17 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
     }
     adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
     const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
-    const float* ls = a.params + a.log_std_off;
+    constexpr bool LS_GAUSS = HEAD == HEAD_GAUSSIAN; constexpr int LS_N = O;
+    // log_std hoisted into scalar registers: a per-tile global load would sit in the in-order vmcnt queue between the prefetched
+    // gathers and their first use and drain them every tile (Pendulum [64,64]: 91 -> TFLOP/s below)
+    float lsr[kLsMax];
+#pragma unroll
+    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
+    if (LS_GAUSS) {
+#pragma unroll
+        for (int o = 0; o < LS_N; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
+    }
+    const float* ls = lsr;
 
     f32x16 dW2[MT];                                                  // rows 32w.., all H columns
     f32x4 dW1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -1834,7 +1880,7 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
         store_image_tile(TA, w, h1w, lane);
         if (w == 0) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) XI[d * kTS + c] = xk[s]; }
+            for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
         }
         __syncthreads();                                                              // B1: XA, TA, XI complete
         // ---- S3: h2 tile w ----
