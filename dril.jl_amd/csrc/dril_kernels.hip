@@ -1787,16 +1787,35 @@ __device__ __forceinline__ f32x16 dense_tile_global_ldsB(const float* __restrict
         acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
     }
     const float* base = wimg + ((size_t)mo * MT * 4 * 64 + lane) * 4;
-#pragma unroll 2
-    for (int mi = 0; mi < MT; ++mi) {
-        const f32x16 X = load_breg(ximg, mi, lane);
+    // The A fragments stream from L2 (pre-tiled image, 1 KiB contiguous per wave-instruction).  Ping-pong buffers keep the NEXT m-tile's four
+    // fragments in flight under the current m-tile's 16 MFMAs (the loop stays rolled: fully unrolled, hipcc hoists all 32 loads and spills 330 VGPRs)
+    static_assert(MT % 2 == 0, "ping-pong over pairs of m-tiles");
+    f32x4 a0[4], a1[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(base + (size_t)(mi * 4 + q) * 256);
-            acc = mfma32(a[0], X[4 * q + 0], acc);
-            acc = mfma32(a[1], X[4 * q + 1], acc);
-            acc = mfma32(a[2], X[4 * q + 2], acc);
-            acc = mfma32(a[3], X[4 * q + 3], acc);
+    for (int q = 0; q < 4; ++q) a0[q] = *reinterpret_cast<const f32x4*>(base + (size_t)q * 256);
+#pragma unroll 1
+    for (int mi = 0; mi < MT; mi += 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a1[q] = *reinterpret_cast<const f32x4*>(base + (size_t)((mi + 1) * 4 + q) * 256);
+        {
+            const f32x16 X = load_breg(ximg, mi, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc = mfma32(a0[q][0], X[4 * q + 0], acc); acc = mfma32(a0[q][1], X[4 * q + 1], acc);
+                acc = mfma32(a0[q][2], X[4 * q + 2], acc); acc = mfma32(a0[q][3], X[4 * q + 3], acc);
+            }
+        }
+        if (mi + 2 < MT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a0[q] = *reinterpret_cast<const f32x4*>(base + (size_t)((mi + 2) * 4 + q) * 256);
+        }
+        {
+            const f32x16 X = load_breg(ximg, mi + 1, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc = mfma32(a1[q][0], X[4 * q + 0], acc); acc = mfma32(a1[q][1], X[4 * q + 1], acc);
+                acc = mfma32(a1[q][2], X[4 * q + 2], acc); acc = mfma32(a1[q][3], X[4 * q + 3], acc);
+            }
         }
     }
     return acc;
@@ -1859,8 +1878,11 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
     TileIn<O> cur, nxt;
     int64_t tile = g;
     if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
+#ifdef DRIL_STAMPS
+    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
+#endif
     for (; tile < ntiles; tile += a.G) {
-        load_tile<KIND, O, HEAD, REC>(a, tile + a.G, ntiles, c, h, nxt);
         unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
         const bool valid = cur.valid;
         const float xk[2] = {cur.xk[0], cur.xk[1]};
@@ -1882,10 +1904,16 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
         }
+        STAMP(0);
         __syncthreads();                                                              // B1: XA, TA, XI complete
+        STAMP(1);
+        // prefetch the next tile's record only now: issued before unpack_tile(cur) it sat behind cur's loads in the in-order vmcnt queue and the
+        // spill reloads' s_waitcnt vmcnt(0) made every tile wait for a full gather latency (stamps: 10 k cycles in this phase)
+        load_tile<KIND, O, HEAD, REC>(a, tile + a.G, ntiles, c, h, nxt);
         // ---- S3: h2 tile w ----
         f32x16 h2w = dense_tile_global_ldsB<MT, true>(w2a, wl + L::B2, XA, w, lane);
         tanh16(h2w);
+        STAMP(2);
         // ---- S4: output layer: partial over this wave's rows, summed across waves through LDS ----
         float out[O], dz[O];
 #pragma unroll
@@ -1902,6 +1930,7 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
         }
         store_image_tile(TB, w, h2w, lane);                                            // h2' (own rows; only this wave reads them)
         __syncthreads();                                                              // B2: PO complete
+        STAMP(3);
 #pragma unroll
         for (int o = 0; o < O; ++o) {
             float v = wl[L::B3 + o];
@@ -1942,11 +1971,14 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
         }
         store_breg(XB, w, h2w, lane);
         store_image_tile(TB, w, h2w, lane);                                            // dz2' (after the Bh2 read: same wave, LDS in order)
+        STAMP(4);
         __syncthreads();                                                              // B3: XB complete
+        STAMP(5);
         // ---- S6: dh1 tile w = W2' dz2 ; dz1 ----
         f32x16 g1 = dense_tile_global_ldsB<MT, false>(w2ta, nullptr, XB, w, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) g1[r] = g1[r] * (1.0f - h1w[r] * h1w[r]);
+        STAMP(6);
         // ---- S7: dW2[rows of w][:] += dz2 h1' ----
         {
             const f32x16 Az = load_operand(TB, w, lane);
@@ -1957,6 +1989,7 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
                 dW2[mj] = mfma_outer(Az, Bh, dW2[mj]);
             }
         }
+        STAMP(7);
         // ---- S8: dW1 | db1 (own rows) ----
         store_image_tile(TB, w, g1, lane);
         {
@@ -1972,8 +2005,15 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
             }
         }
         __syncthreads();                                                              // B4: XA/TA/XB/PO/XI free for the next tile
+        STAMP(8);
         cur = nxt;
     }
+#ifdef DRIL_STAMPS
+    if (lane == 0 && a.dbg) {
+        unsigned long long* o_ = a.dbg + ((size_t)(blockIdx.x % (2 * a.G)) * 4 + (w & 3)) * 12;
+        if (w < 4) { for (int k = 0; k < 10; ++k) o_[k] = stamp_acc[k]; o_[10] = (unsigned long long)((ntiles - g + a.G - 1) / a.G); o_[11] = HEAD; }
+    }
+#endif
 
     // ---- epilogue: every wave owns distinct gradient rows -> straight to the workgroup's slab ----
     const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
