@@ -15,6 +15,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def pkg():
     import __graft_entry__ as g
+    so = ROOT / "dril.jl_amd" / "csrc" / "libdril_hip.so"
+    if not so.exists():            # fresh checkout (the .so is git-ignored): compile it — hipcc cross-compiles gfx950 without a GPU
+        g.build()
     return g.load_package()
 
 
