@@ -231,3 +231,23 @@ def test_critic_learns_fixed_targets(pkg):
     h.replay_fill(obs, act, rew, np.ones(512, np.uint8), trunc, nobs)
     losses = [s.critic_loss for s in h.update(300)]
     assert losses[-1] < 0.1 * losses[0]
+
+
+def test_training_is_bitwise_reproducible(pkg):
+    """two fresh handles with the same seeds: identical parameters, targets, replay contents and statistics bit for bit (every reduction in the
+    path sums in a fixed order; the only atomic elects the block that finalises the statistics)"""
+    runs = []
+    for _ in range(2):
+        env = pkg.PendulumEnv(max_steps=200)
+        alg = pkg.SAC(batch_size=256, buffer_capacity=50_000, start_steps=1024)
+        layer = pkg.SACLayer(env.observation_space(), env.action_space(), hidden_dims=(128, 128))
+        h = pkg.SacHandle(pkg.make_sac_config(env, 512, alg, layer, seed=3))
+        h.set_params(pkg.sac_flatten_params(layer.initialparameters(np.random.default_rng(5)))); h.env_reset(3)
+        stats, fps, n_upd, iters, total = h.train(1024 + 40 * 512)
+        runs.append((h.get_params(), h.get_target_params(), h.replay(pkg._capi.RB_REWARDS), h.replay(pkg._capi.RB_ACTIONS),
+                     np.array([[s.critic_loss, s.actor_loss, s.grad_norm] for s in stats]), n_upd))
+    a, b = runs
+    assert a[5] == b[5] == 41
+    for x, y in zip(a[:5], b[:5]):
+        np.testing.assert_array_equal(x, y)
+    assert np.isfinite(a[4]).all()
