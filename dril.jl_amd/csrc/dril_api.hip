@@ -101,7 +101,8 @@ int fail(dril_handle* h, int code, const std::string& msg) { if (h) h->err = msg
 #define HIPCHK(h, expr)                                                                                      \
     do { hipError_t _e = (expr); if (_e != hipSuccess)                                                       \
         return fail(h, DRIL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
-#define NEED(h) do { if (!(h)) return fail(nullptr, DRIL_ERR_NOT_INITIALISED, "null handle"); } while (0)
+// every entry point makes the handle's device current first: a process may hold handles on several devices
+#define NEED(h) do { if (!(h)) return fail(nullptr, DRIL_ERR_NOT_INITIALISED, "null handle"); (void)hipSetDevice((h)->cfg.device); } while (0)
 
 template <typename T> hipError_t dmalloc(T** p, size_t n) { return hipMalloc((void**)p, (n ? n : 1) * sizeof(T)); }
 
@@ -393,6 +394,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
 }
 
 DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
+    if (h) (void)hipSetDevice(h->cfg.device);
     if (!h) return DRIL_OK;
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);

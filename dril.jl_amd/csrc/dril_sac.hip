@@ -543,7 +543,7 @@ int sfail(dril_sac_handle* h, int code, const std::string& msg) { if (h) h->err 
 #define SHIP(h, expr)                                                                                        \
     do { hipError_t _e = (expr); if (_e != hipSuccess)                                                       \
         return sfail(h, DRIL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
-#define SNEED(h) do { if (!(h)) return sfail(nullptr, DRIL_ERR_NOT_INITIALISED, "null handle"); } while (0)
+#define SNEED(h) do { if (!(h)) return sfail(nullptr, DRIL_ERR_NOT_INITIALISED, "null handle"); (void)hipSetDevice((h)->cfg.device); } while (0)
 #define SDO(expr) do { int _rc = (expr); if (_rc != DRIL_OK) return _rc; } while (0)
 
 template <typename T> hipError_t smalloc(T** p, size_t n) {
@@ -802,6 +802,7 @@ DRIL_EXPORT int32_t dril_sac_config_default(dril_sac_config* c, int32_t env_kind
 
 DRIL_EXPORT int32_t dril_sac_destroy(dril_sac_handle* h) {
     if (!h) return DRIL_OK;
+    (void)hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->g_critic, h->g_actor, h->sc, h->stats, h->stats_out, h->ssq_c, h->ssq_a, h->counter,
                     h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->obs_cur, h->obs_nxt, h->e_rew, h->e_tobs, h->e_raw, h->e_envact, h->e_term, h->e_trunc,
