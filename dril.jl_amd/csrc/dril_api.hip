@@ -215,7 +215,11 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     int G = h->wide ? (int)(tiles < h->Gmax ? tiles : h->Gmax) : (int)((tiles + 3) / 4); if (G > h->Gmax) G = h->Gmax; if (G < 1) G = 1;
     { int rcw = ensure_wimg(h); if (rcw) return rcw; }
     const double* adv_stats = h->adv_stats;
+    // launch-bound regime (the reference's default batch_size = 64): the advantage moments are computed inside the grad kernel and
+    // reduce + norm + Adam run as one workgroup: 2 dependent launches per optimiser step instead of 6
+    const bool small = !reduce && !h->wide && h->grad_layout == 1 && count <= 4096 && !std::getenv("DRIL_NO_SMALL_PATH");
     if (h->cfg.normalize_advantage && pre_stats) adv_stats = pre_stats;   // per-epoch table (already all-reduced in data-parallel runs)
+    else if (h->cfg.normalize_advantage && small) adv_stats = nullptr;
     else if (h->cfg.normalize_advantage) {
         MomentsArgs m{}; m.adv = adv; m.perm = perm; m.pos0 = pos0; m.count = count; m.N = N; m.idx_lo = 0; m.n_local = N;
         m.perm_key = key; m.perm_bits = bits; m.partials = h->adv_partials; m.stop_flag = h->stop_flag;
@@ -230,7 +234,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     g.params = h->params; g.obs = obs; g.actions = actions; g.adv = adv; g.ret = ret; g.logp_old = logp_old; g.val_old = val_old;
     g.perm = perm; g.pos0 = pos0; g.count = count; g.N = N; g.idx_lo = 0; g.n_local = N; g.perm_key = key; g.perm_bits = bits;
     g.rec = rec; g.w2a_actor = h->w2a_actor; g.w2ta_actor = h->w2ta_actor; g.w2a_critic = h->w2a_critic; g.w2ta_critic = h->w2ta_critic;
-    g.adv_stats = adv_stats; g.invB = 1.0f / (float)(count * world);
+    g.adv_stats = adv_stats; g.inline_moments = (h->cfg.normalize_advantage && adv_stats == nullptr) ? 1 : 0; g.invB = 1.0f / (float)(count * world);
     g.clip_range = h->cfg.clip_range; g.ent_coef = h->cfg.ent_coef; g.vf_coef = h->cfg.vf_coef; g.clip_range_vf = h->cfg.clip_range_vf;
     g.has_clip_vf = h->cfg.has_clip_range_vf; g.normalize_adv = h->cfg.normalize_advantage; g.action_start = h->cfg.action_start;
     g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
@@ -242,6 +246,20 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     r.slabs_actor = h->slabs_a; r.slabs_critic = h->slabs_c; r.slab_a = h->slab_a; r.slab_c = h->slab_c; r.G = G;
     r.P = h->P; r.Pa = h->Pa; r.Pc = h->Pc; r.flat = h->flat; r.norm_partials = h->norm_partials; r.n_samples_local = (double)count;
     r.stop_flag = h->stop_flag;
+    if (small && apply && h->P <= 16384 && G <= 32) {
+        AdamArgs ad{};
+        ad.params = h->params; ad.m = h->adam_m; ad.v = h->adam_v; ad.flat = h->flat; ad.P = h->P;
+        ad.norm_partials = h->norm_partials; ad.n_partials = h->n_norm_partials; ad.bt = h->bt; ad.step_parity = (int)(h->adam_steps & 1);
+        ad.beta1 = h->cfg.adam_beta1; ad.beta2 = h->cfg.adam_beta2; ad.eps = h->cfg.adam_eps; ad.lr = h->lr;
+        ad.max_grad_norm = h->cfg.max_grad_norm; ad.target_kl = h->cfg.target_kl; ad.ent_coef = h->cfg.ent_coef; ad.vf_coef = h->cfg.vf_coef;
+        ad.has_max_grad_norm = h->cfg.has_max_grad_norm; ad.has_target_kl = h->cfg.has_target_kl; ad.use_stats = 1;
+        ad.step_stats = step_stats; ad.norm_out = h->norm_out; ad.nan_flag = h->nan_flag; ad.stop_flag = h->stop_flag; ad.stop_flag_w = h->stop_flag;
+        prof_begin(h, DRIL_K_ADAM);
+        HIPCHK(h, launch_finish_small(r, ad, h->stream));
+        prof_end(h);
+        h->adam_steps += 1; h->wimg_dirty = true;
+        return DRIL_OK;
+    }
     prof_begin(h, DRIL_K_GRAD_REDUCE);
     HIPCHK(h, launch_grad_reduce(r, h->stream));
     prof_end(h);

@@ -64,6 +64,7 @@ struct GradArgs {
     unsigned long long* dbg;   // -DDRIL_STAMPS diagnostic buffer (12 x u64 per wave), else unused
     int stagger;   // tuning knob: start-up delay of the critic workgroups, in units of 8128 clocks
     int prio, split_pct;   // tuning knobs: static wave priority + share of tiles for the high-priority half
+    int inline_moments;   // small minibatches: every actor workgroup computes the advantage moments itself (adv_stats == nullptr), saving two launches per optimiser step
     int layout;   // 0: actor/critic workgroups interleaved by blockIdx parity, 1: first G blocks actor, next G critic
     const int* stop_flag;
     NetOff actor, critic;
@@ -122,6 +123,7 @@ hipError_t launch_pack_records(int kind, int64_t N, const float* obs, const void
 hipError_t launch_grad_reduce(const ReduceArgs& a, hipStream_t s);
 hipError_t launch_grad_norm(const float* flat, int P, double* norm_partials, const int* stop_flag, hipStream_t s);
 hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
+hipError_t launch_finish_small(const ReduceArgs& r, const AdamArgs& a, hipStream_t s);   // grad_reduce + norm + Adam in one workgroup (few slabs)
 hipError_t launch_explained_var(const float* val, const float* ret, int64_t N, double* partials, int nblocks, hipStream_t s);
 hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a, float* w2ta, hipStream_t s);
 int slab_size_actor(int kind, int hidden);

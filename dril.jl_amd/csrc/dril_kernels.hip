@@ -910,7 +910,23 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
     // advantage normalisation constants (ppo.jl:350-356): mean, corrected std, eps added to the std
     float adv_mean = 0.f, adv_den = 1.f;
     if (HEAD != HEAD_VALUE && a.normalize_adv) {
-        const double s = a.adv_stats[0], q = a.adv_stats[1], n = a.adv_stats[2];
+        double s, q, n;
+        if (a.inline_moments) {
+            // small minibatch: sum A and A^2 of the whole minibatch here (same index map as load_tile), fixed-order tree => every workgroup gets the same bits
+            double* shd = reinterpret_cast<double*>(smem + ((L::BWD_END + 1) & ~1));      // per-wave scratch, not yet in use
+            double ls_ = 0, lq_ = 0;
+            for (int64_t i2 = tid; i2 < a.count; i2 += blockDim.x) {
+                const int64_t p2 = a.pos0 + i2;
+                const int64_t gi = a.perm ? a.perm[p2] : (a.perm_bits ? perm_index(p2, a.N, a.perm_key, a.perm_bits) : p2);
+                const int64_t li2 = gi - a.idx_lo;
+                if (li2 >= 0 && li2 < a.n_local) { const float v = REC ? a.rec[2 * li2 + 1].y : a.adv[li2]; ls_ += v; lq_ += (double)v * v; }
+            }
+            shd[tid] = ls_; shd[256 + tid] = lq_;
+            __syncthreads();
+            for (int st_ = 128; st_ > 0; st_ >>= 1) { if (tid < st_) { shd[tid] += shd[tid + st_]; shd[256 + tid] += shd[256 + tid + st_]; } __syncthreads(); }
+            s = shd[0]; q = shd[256]; n = (double)a.count;
+            __syncthreads();
+        } else { s = a.adv_stats[0]; q = a.adv_stats[1]; n = a.adv_stats[2]; }
         const double mean = s / n;
         double var = (q - s * mean) / (n - 1.0);
         if (var < 0) var = 0;
@@ -2155,6 +2171,76 @@ __global__ void adam_kernel(AdamArgs a) {
     }
 }
 
+// Small minibatches (few slabs): grad_reduce_kernel + norm + adam_kernel in ONE workgroup — at B = 64 the optimiser step is bound by its
+// dependent launches (~6 x 5-8 us), not by work.  Same arithmetic as the two kernels; the squared norm is summed in a different (fixed) order.
+__global__ __launch_bounds__(1024) void ppo_finish_small_kernel(ReduceArgs r, AdamArgs a) {
+    __shared__ double sh[16];
+    __shared__ float stf[8];
+    if (*a.stop_flag) return;
+    constexpr int KMAX = 16;                                                            // P <= 16 384 (checked by the host)
+    const int tid = threadIdx.x;
+    float gacc[KMAX], mo[KMAX], vo[KMAX], po[KMAX];
+    double ss = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int p = tid + 1024 * k;
+        gacc[k] = 0.f; mo[k] = 0.f; vo[k] = 0.f; po[k] = 0.f;
+        if (p < r.P) {
+            const float* base; int stride, offp;
+            if (p < r.Pa) { base = r.slabs_actor; stride = r.slab_a; offp = p; }
+            else if (p < r.Pa + r.Pc) { base = r.slabs_critic; stride = r.slab_c; offp = p - r.Pa; }
+            else { base = r.slabs_actor; stride = r.slab_a; offp = r.Pa + (p - r.Pa - r.Pc); }
+            float acc = 0.f;
+            for (int g = 0; g < r.G; ++g) acc += base[(size_t)g * stride + offp];      // fixed order
+            gacc[k] = acc; r.flat[p] = acc; ss += (double)acc * (double)acc;
+            mo[k] = a.m[p]; vo[k] = a.v[p]; po[k] = a.params[p];                        // optimiser state in flight under the norm reduction
+        }
+    }
+    if (tid < 8) {
+        double t = 0;
+        if (tid < 5) { for (int g = 0; g < r.G; ++g) t += (double)r.slabs_actor[(size_t)g * r.slab_a + r.slab_a - 8 + tid]; }
+        else if (tid == 5) { for (int g = 0; g < r.G; ++g) t += (double)r.slabs_critic[(size_t)g * r.slab_c + r.slab_c - 8]; }
+        else if (tid == 6) t = r.n_samples_local;
+        stf[tid] = (float)t; r.flat[r.P + tid] = (float)t;
+    }
+    const float norm = sqrtf((float)block_sum_f64(ss, sh));
+    __syncthreads();
+    const float n = a.use_stats ? stf[6] : 1.f;
+    const float kl = a.use_stats ? stf[3] / n : 0.f;
+    const bool bad = !(norm == norm) || isinf(norm);
+    const bool kl_stop = a.use_stats && a.has_target_kl && kl > 1.5f * a.target_kl;
+    const float* bt_in = a.bt + 2 * (a.step_parity & 1);
+    float* bt_out = a.bt + 2 * ((a.step_parity + 1) & 1);
+    const float bt1 = bt_in[0], bt2 = bt_in[1];
+    if (tid == 0) {
+        if (a.step_stats) {
+            float* o = a.step_stats;
+            const float pl = stf[0] / n, ent = stf[1] / n, vl = stf[5] / n;
+            o[0] = pl; o[1] = vl; o[2] = -ent; o[3] = stf[2] / n; o[4] = kl; o[5] = ent; o[6] = stf[4] / n;
+            o[7] = pl + a.ent_coef * (-ent) + a.vf_coef * vl;
+            o[8] = norm; o[9] = (bad || kl_stop) ? 0.f : 1.f; o[10] = bad ? 1.f : 0.f; o[11] = kl_stop ? 1.f : 0.f;
+        }
+        if (a.norm_out) *a.norm_out = norm;
+        if (bad) { *a.nan_flag = 1; *a.stop_flag_w = 1; }
+        if (kl_stop) *a.stop_flag_w = 1;
+        if (bad || kl_stop) { bt_out[0] = bt1; bt_out[1] = bt2; } else { bt_out[0] = bt1 * a.beta1; bt_out[1] = bt2 * a.beta2; }
+    }
+    if (bad || kl_stop) return;
+    const float scale = (a.has_max_grad_norm && norm > a.max_grad_norm) ? a.max_grad_norm / norm : 1.0f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int p = tid + 1024 * k;
+        if (p < r.P) {
+            float g = gacc[k];
+            if (scale != 1.0f) g = g * scale;
+            const float m = a.beta1 * mo[k] + (1.0f - a.beta1) * g;
+            const float v = a.beta2 * vo[k] + (1.0f - a.beta2) * g * g;
+            a.m[p] = m; a.v[p] = v;
+            a.params[p] = po[k] - m / (1.0f - bt1) / (sqrtf(v / (1.0f - bt2)) + a.eps) * a.lr;
+        }
+    }
+}
+
 // explained_variance sums over the whole buffer (ppo.jl:256): partials of (v-r), (v-r)^2, r, r^2
 __global__ void explained_var_kernel(const float* val, const float* ret, int64_t N, double* partials) {
     __shared__ double sh[16];
@@ -2410,6 +2496,10 @@ hipError_t launch_pack_records(int kind, int64_t N, const float* obs, const void
 }
 hipError_t launch_grad_reduce(const ReduceArgs& a, hipStream_t s) {
     grad_reduce_kernel<<<(a.P + 31) / 32, 1024, 0, s>>>(a);
+    return hipGetLastError();
+}
+hipError_t launch_finish_small(const ReduceArgs& r, const AdamArgs& a, hipStream_t s) {
+    ppo_finish_small_kernel<<<1, 1024, 0, s>>>(r, a);
     return hipGetLastError();
 }
 hipError_t launch_grad_norm(const float* flat, int P, double* norm_partials, const int* stop_flag, hipStream_t s) {
