@@ -1803,35 +1803,21 @@ __device__ __forceinline__ f32x16 dense_tile_global_ldsB(const float* __restrict
         acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
     }
     const float* base = wimg + ((size_t)mo * MT * 4 * 64 + lane) * 4;
-    // The A fragments stream from L2 (pre-tiled image, 1 KiB contiguous per wave-instruction).  Ping-pong buffers keep the NEXT m-tile's four
-    // fragments in flight under the current m-tile's 16 MFMAs (the loop stays rolled: fully unrolled, hipcc hoists all 32 loads and spills 330 VGPRs)
-    static_assert(MT % 2 == 0, "ping-pong over pairs of m-tiles");
-    f32x4 a0[4], a1[4];
+    // The A fragments stream from L2 (pre-tiled image, 1 KiB contiguous per wave-instruction).  Each of the four fragment registers is refilled
+    // with the NEXT m-tile's fragment right after the four MFMAs that consumed it were issued, so every load has 12-16 MFMAs (~1 k cycles) of
+    // cover with only 16 registers of buffering (the loop stays rolled: fully unrolled, hipcc hoists all 32 loads and spills 330 VGPRs)
+    f32x4 af[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a0[q] = *reinterpret_cast<const f32x4*>(base + (size_t)q * 256);
+    for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(base + (size_t)q * 256);
 #pragma unroll 1
-    for (int mi = 0; mi < MT; mi += 2) {
+    for (int mi = 0; mi < MT; ++mi) {
+        const f32x16 X = load_breg(ximg, mi, lane);
+        const float* nextp = base + (size_t)((mi + 1 < MT ? mi + 1 : mi) * 4) * 256;   // last iteration re-reads its own fragments (in bounds, unused)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a1[q] = *reinterpret_cast<const f32x4*>(base + (size_t)((mi + 1) * 4 + q) * 256);
-        {
-            const f32x16 X = load_breg(ximg, mi, lane);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc = mfma32(a0[q][0], X[4 * q + 0], acc); acc = mfma32(a0[q][1], X[4 * q + 1], acc);
-                acc = mfma32(a0[q][2], X[4 * q + 2], acc); acc = mfma32(a0[q][3], X[4 * q + 3], acc);
-            }
-        }
-        if (mi + 2 < MT) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a0[q] = *reinterpret_cast<const f32x4*>(base + (size_t)((mi + 2) * 4 + q) * 256);
-        }
-        {
-            const f32x16 X = load_breg(ximg, mi + 1, lane);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc = mfma32(a1[q][0], X[4 * q + 0], acc); acc = mfma32(a1[q][1], X[4 * q + 1], acc);
-                acc = mfma32(a1[q][2], X[4 * q + 2], acc); acc = mfma32(a1[q][3], X[4 * q + 3], acc);
-            }
+        for (int q = 0; q < 4; ++q) {
+            acc = mfma32(af[q][0], X[4 * q + 0], acc); acc = mfma32(af[q][1], X[4 * q + 1], acc);
+            acc = mfma32(af[q][2], X[4 * q + 2], acc); acc = mfma32(af[q][3], X[4 * q + 3], acc);
+            af[q] = *reinterpret_cast<const f32x4*>(nextp + (size_t)q * 256);
         }
     }
     return acc;
@@ -1992,8 +1978,11 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
         STAMP(5);
         // ---- S6: dh1 tile w = W2' dz2 ; dz1 ----
         f32x16 g1 = dense_tile_global_ldsB<MT, false>(w2ta, nullptr, XB, w, lane);
+        {
+            const f32x16 h1r = load_breg(XA, w, lane);                                 // h1 tile w re-read from its LDS image: 16 registers less across the two MFMA chains
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g1[r] = g1[r] * (1.0f - h1w[r] * h1w[r]);
+            for (int r = 0; r < 16; ++r) g1[r] = g1[r] * (1.0f - h1r[r] * h1r[r]);
+        }
         STAMP(6);
         // ---- S7: dW2[rows of w][:] += dz2 h1' ----
         {
