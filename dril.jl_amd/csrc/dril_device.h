@@ -463,9 +463,31 @@ __device__ __forceinline__ void net_forward_wide(const float* __restrict__ lds, 
     float part[O];
 #pragma unroll
     for (int o = 0; o < O; ++o) part[o] = 0.f;
+    // W2 streams from L2 as ONE linear sequence of MT*MT*4 fragments (pre-tiled image): each of the four fragment registers is refilled with the
+    // fragment four places ahead right after the MFMAs that consumed it, across m-tile boundaries too, so no output tile starts on a cold load
+    const float* fbase = w2a + (size_t)lane * 4;
+    constexpr int F = MT * MT * 4;
+    f32x4 af[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(fbase + (size_t)q * 256);
 #pragma unroll 1
     for (int mo = 0; mo < MT; ++mo) {
-        f32x16 acc = dense_tile_global<MT, true>(w2a, lds + L::B2, h1, mo, lane);
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + L::B2 + 32 * mo + 8 * q + 4 * h);
+            acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc = mfma32(af[q][0], h1[mi][4 * q + 0], acc); acc = mfma32(af[q][1], h1[mi][4 * q + 1], acc);
+                acc = mfma32(af[q][2], h1[mi][4 * q + 2], acc); acc = mfma32(af[q][3], h1[mi][4 * q + 3], acc);
+                int f = (mo * MT + mi) * 4 + q + 4; f = f < F ? f : F - 4 + q;       // the tail re-reads the last fragments (in bounds, unused)
+                af[q] = *reinterpret_cast<const f32x4*>(fbase + (size_t)f * 256);
+            }
+        }
         tanh16(acc);
 #pragma unroll
         for (int o = 0; o < O; ++o)
