@@ -1814,8 +1814,13 @@ __device__ __forceinline__ void store_image_tile(float* img, int m, const f32x16
     for (int r = 0; r < 16; ++r) img[(32 * m + rowfn(r, h)) * kTS + c] = x[r];
 }
 // Y tile mo = W * X with W from the pre-tiled global image and X read tile by tile from an LDS B-operand image
+__device__ __forceinline__ void wide_preload(const float* __restrict__ wimg, int MTv, int mo, int lane, f32x4 (&af)[4]) {
+    const float* base = wimg + ((size_t)mo * MTv * 4 * 64 + lane) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(base + (size_t)q * 256);
+}
 template <int MT, bool BIAS>
-__device__ __forceinline__ f32x16 dense_tile_global_ldsB(const float* __restrict__ wimg, const float* __restrict__ bias, const float* __restrict__ ximg, int mo, int lane) {
+__device__ __forceinline__ f32x16 dense_tile_global_ldsB(const float* __restrict__ wimg, const float* __restrict__ bias, const float* __restrict__ ximg, int mo, int lane, f32x4 (&af)[4]) {
     const int h = lane >> 5;
     f32x16 acc;
 #pragma unroll
@@ -1828,9 +1833,7 @@ __device__ __forceinline__ f32x16 dense_tile_global_ldsB(const float* __restrict
     // The A fragments stream from L2 (pre-tiled image, 1 KiB contiguous per wave-instruction).  Each of the four fragment registers is refilled
     // with the NEXT m-tile's fragment right after the four MFMAs that consumed it were issued, so every load has 12-16 MFMAs (~1 k cycles) of
     // cover with only 16 registers of buffering (the loop stays rolled: fully unrolled, hipcc hoists all 32 loads and spills 330 VGPRs)
-    f32x4 af[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(base + (size_t)q * 256);
+    // af[] arrives preloaded with the first m-tile's fragments (wide_preload, issued before the workgroup barrier that precedes this chain)
 #pragma unroll 1
     for (int mi = 0; mi < MT; ++mi) {
         const f32x16 X = load_breg(ximg, mi, lane);
@@ -1929,13 +1932,15 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
             for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
         }
         STAMP(0);
+        f32x4 afw[4];
+        wide_preload(w2a, MT, w, lane, afw);                                          // first W2 fragments in flight across the barrier
         __syncthreads();                                                              // B1: XA, TA, XI complete
         STAMP(1);
         // prefetch the next tile's record only now: issued before unpack_tile(cur) it sat behind cur's loads in the in-order vmcnt queue and the
         // spill reloads' s_waitcnt vmcnt(0) made every tile wait for a full gather latency (stamps: 10 k cycles in this phase)
         load_tile<KIND, O, HEAD, REC>(a, tile + a.G, ntiles, c, h, nxt);
         // ---- S3: h2 tile w ----
-        f32x16 h2w = dense_tile_global_ldsB<MT, true>(w2a, wl + L::B2, XA, w, lane);
+        f32x16 h2w = dense_tile_global_ldsB<MT, true>(w2a, wl + L::B2, XA, w, lane, afw);
         tanh16(h2w);
         STAMP(2);
         // ---- S4: output layer: partial over this wave's rows, summed across waves through LDS ----
@@ -1995,11 +2000,12 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
         }
         store_breg(XB, w, h2w, lane);
         store_image_tile(TB, w, h2w, lane);                                            // dz2' (after the Bh2 read: same wave, LDS in order)
+        wide_preload(w2ta, MT, w, lane, afw);                                         // first W2' fragments in flight across the barrier
         STAMP(4);
         __syncthreads();                                                              // B3: XB complete
         STAMP(5);
         // ---- S6: dh1 tile w = W2' dz2 ; dz1 ----
-        f32x16 g1 = dense_tile_global_ldsB<MT, false>(w2ta, nullptr, XB, w, lane);
+        f32x16 g1 = dense_tile_global_ldsB<MT, false>(w2ta, nullptr, XB, w, lane, afw);
         {
             const f32x16 h1r = load_breg(XA, w, lane);                                 // h1 tile w re-read from its LDS image: 16 registers less across the two MFMA chains
 #pragma unroll
