@@ -149,6 +149,71 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_kernel(GemmArgs g) {
     __shared__ float red[kGemmWaves][16][kRedStride];
     gemm_body<SPLIT>(g, blockIdx.z, red);
 }
+// Throughput shape (the 4096-env actor forward of the collection): classic LDS-tiled contraction.  A workgroup owns a 32 (m) x 256 (n) output block,
+// one 32 x 32 tile per wave; per 32-deep k-chunk it stages the weight chunk (m-major in memory, read coalesced along m) and the activation chunk (each
+// sample row contiguous: 8 threads read one row's 128 B) into LDS with b128 stores and the waves read their MFMA operands back as one ds_read_b128 per
+// lane per 8 k.  The plain !SPLIT shape read every activation row straight from L2, 16 B per lane = 32 cache lines per wave instruction (56 us for
+// 512 x 512 x 4096); the next chunk's global loads are issued before the current chunk's MFMAs (register double buffer, one barrier pair per chunk).
+constexpr int kBigKc = 32, kBigStride = kBigKc + 4;
+__global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_big_kernel(GemmArgs g) {
+    __shared__ float red[kGemmWaves][16][kRedStride];
+    __shared__ __attribute__((aligned(16))) float As[32][kBigStride];
+    __shared__ __attribute__((aligned(16))) float Xs[32 * kGemmWaves][kBigStride];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5, z = blockIdx.z;
+    const float* __restrict__ A = g.A + (size_t)z * g.zA;
+    const float* __restrict__ B = g.B + (size_t)(z / g.zdivB) * g.zB;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32 * kGemmWaves;
+    // loader roles: X chunk = 256 rows x 8 float4 -> 4 float4 per thread; A chunk = 32 k x 32 m floats -> 2 floats per thread
+    int xr[4], xk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int i = tid + 512 * j; xr[j] = i >> 3; xk[j] = (i & 7) * 4; }
+    const int am = tid & 31, ak = tid >> 5;                                      // k = ak and ak + 16
+    float4 xv[4]; float av[2];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + xr[j];
+            xv[j] = n < g.N ? *reinterpret_cast<const float4*>(B + (size_t)n * g.sBn + kc + xk[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int mg = m0 + am; av[j] = mg < g.M ? A[(size_t)mg + (size_t)(kc + ak + 16 * j) * g.sAk] : 0.f; }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    gload(0);
+    for (int kc = 0; kc < g.K; kc += kBigKc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&Xs[xr[j]][xk[j]]) = xv[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) As[am][ak + 16 * j] = av[j];
+        __syncthreads();
+        if (kc + kBigKc < g.K) gload(kc + kBigKc);                               // next chunk in flight under this chunk's MFMAs
+#pragma unroll
+        for (int q = 0; q < kBigKc / 8; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&As[c][8 * q + 4 * h]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&Xs[32 * wave + c][8 * q + 4 * h]);
+            acc = mfma32(a[0], b[0], acc); acc = mfma32(a[1], b[1], acc); acc = mfma32(a[2], b[2], acc); acc = mfma32(a[3], b[3], acc);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    float* __restrict__ C = g.C + (size_t)z * g.zC;
+    const float* __restrict__ bias = g.bias ? g.bias + (size_t)z * g.zBias : nullptr;
+    const float* __restrict__ aux = g.aux ? g.aux + (size_t)z * g.zAux : nullptr;
+    const int tile_n = (int)blockIdx.y * kGemmWaves + wave;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int e = lane + 64 * i, ml = e & 31, nl = e >> 5;
+        const int rr = (ml & 3) + 4 * (ml >> 3), ll = nl + 32 * ((ml >> 2) & 1);
+        const int mm = m0 + ml, nn = tile_n * 32 + nl;
+        if (mm >= g.M || nn >= g.N) continue;
+        const size_t ci = (size_t)mm * g.sCm + (size_t)nn * g.sCn;
+        C[ci] = gemm_epilogue(g, red[wave][rr][ll], mm, ci, bias, aux);
+    }
+}
 // two independent contractions in one launch (the weight-gradient and the data-gradient of one layer): blockIdx.z < za runs `a`
 struct GemmPair { GemmArgs a, b; int za; };
 __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_pair_kernel(GemmPair p) {
@@ -571,7 +636,8 @@ int gemm_pair(dril_sac_handle* h, GemmArgs a, int Za, GemmArgs b, int Zb) {
 int gemm(dril_sac_handle* h, GemmArgs g, int Z) {
     if (!gemm_prepare(g)) return sfail(h, DRIL_ERR_INVALID_ARG, "gemm: empty contraction");
     const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
-    if ((long long)tm * tn * Z >= 2048) hipLaunchKernelGGL(sac_gemm_kernel<false>, dim3(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), dim3(64 * kGemmWaves), 0, h->stream, g);
+    if ((long long)tm * tn * Z >= 2048 && g.sAm == 1 && g.sBk == 1 && g.vecB && g.K % kBigKc == 0 && !g.ones_n) hipLaunchKernelGGL(sac_gemm_big_kernel, dim3(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), dim3(64 * kGemmWaves), 0, h->stream, g);
+    else if ((long long)tm * tn * Z >= 2048) hipLaunchKernelGGL(sac_gemm_kernel<false>, dim3(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), dim3(64 * kGemmWaves), 0, h->stream, g);
     else hipLaunchKernelGGL(sac_gemm_kernel<true>, dim3(tm, tn, Z), dim3(64 * kGemmWaves), 0, h->stream, g);
     SHIP(h, hipGetLastError());
     return DRIL_OK;
