@@ -841,17 +841,19 @@ __device__ __forceinline__ void unpack_tile(const GradArgs& a, int h, TileIn<O>&
 template <int O, int HEAD>
 __device__ __forceinline__ void loss_head(const GradArgs& a, const TileIn<O>& cur, const float (&out)[O], bool valid, bool tally, const float* ls,
                                           float adv_mean, float adv_inv, float (&dz)[O], float (&st)[5], float (&dlsp)[O]) {
+    // branch-free on purpose: a lane-dependent `if` here becomes an s_cbranch_execz in the middle of the tile loop and splits it into basic blocks
+    // that the scheduler cannot move MFMAs / LDS reads across
+    const bool count_it = valid && tally;
     if (HEAD == HEAD_VALUE) {
         const float R = cur.s0;
-        float value = out[0]; bool vpass = true;
-        if (a.has_clip_vf) {                                              // clip_range, ppo.jl:344-346,378
-            const float ov = cur.s1, d = value - ov;
-            vpass = d >= -a.clip_range_vf && d <= a.clip_range_vf;
-            value = ov + fminf(fmaxf(d, -a.clip_range_vf), a.clip_range_vf);
-        }
+        const float ov = cur.s1, dcl = out[0] - ov;                        // clip_range, ppo.jl:344-346,378
+        const bool inside = (dcl >= -a.clip_range_vf) & (dcl <= a.clip_range_vf);      // bitwise: && / ?: compile to branches
+        const bool vpass = inside | (a.has_clip_vf == 0);
+        const float vclip = ov + fminf(fmaxf(dcl, -a.clip_range_vf), a.clip_range_vf);
+        const float value = a.has_clip_vf ? vclip : out[0];
         const float ve = value - R;
-        dz[0] = (valid && vpass) ? a.invB * a.vf_coef * 2.0f * ve : 0.f;
-        if (valid && tally) st[0] += ve * ve;                            // value_loss numerator, ppo.jl:385
+        dz[0] = (valid & vpass) ? a.invB * a.vf_coef * 2.0f * ve : 0.f;
+        st[0] += count_it ? ve * ve : 0.f;                                 // value_loss numerator, ppo.jl:385
     } else {
         const float advn = (cur.s0 - adv_mean) * adv_inv;
         const float olp = cur.s1;
@@ -888,13 +890,11 @@ __device__ __forceinline__ void loss_head(const GradArgs& a, const TileIn<O>& cu
             for (int o = 0; o < O; ++o) {
                 const float iv = fexp(-2.0f * ls[o]), d = xa[o] - out[o];
                 dz[o] = dlogp * d * iv;
-                if (tally) dlsp[o] += dlogp * (d * d * iv - 1.0f) + dent;
+                dlsp[o] += tally ? dlogp * (d * d * iv - 1.0f) + dent : 0.f;
             }
         }
-        if (valid && tally) {
-            st[0] += -mn; st[1] += ent; st[2] += (r != rc) ? 1.0f : 0.0f;   // :382,:383,:390
-            st[3] += (r - 1.0f) - lr; st[4] += r;                           // :393,:402
-        }
+        st[0] += count_it ? -mn : 0.f; st[1] += count_it ? ent : 0.f; st[2] += (count_it && r != rc) ? 1.0f : 0.0f;   // :382,:383,:390
+        st[3] += count_it ? (r - 1.0f) - lr : 0.f; st[4] += count_it ? r : 0.f;                                       // :393,:402
     }
 }
 
