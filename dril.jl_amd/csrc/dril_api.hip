@@ -333,9 +333,8 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (!cfg || !out) return fail(nullptr, DRIL_ERR_INVALID_ARG, "null cfg/out");
     if (cfg->abi_version != DRIL_ABI_VERSION) return fail(nullptr, DRIL_ERR_INVALID_ARG, "abi_version mismatch");
     if (cfg->env_kind < DRIL_ENV_CARTPOLE || cfg->env_kind > DRIL_ENV_MOUNTAINCAR_CONTINUOUS) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
-    if (cfg->env_kind >= DRIL_ENV_MOUNTAINCAR && cfg->hidden1 != 64) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "MountainCar envs: hidden_dims [64,64] is built");
     if (cfg->n_envs < 1 || cfg->n_steps < 1 || cfg->epochs < 0 || cfg->batch_size < 1) return fail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs/n_steps/batch_size must be positive");
-    if (cfg->hidden1 != cfg->hidden2 || (cfg->hidden1 != 64 && cfg->hidden1 != 256)) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden_dims: [64,64] and [256,256] are built");
+    if (cfg->hidden1 != cfg->hidden2 || (cfg->hidden1 != 64 && cfg->hidden1 != 128 && cfg->hidden1 != 256)) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden_dims: [64,64], [128,128] and [256,256] are built");
     if (cfg->monitor_window < 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "monitor_window must be >= 0");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad rank/world_size");
     if (cfg->batch_size % cfg->world_size != 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "batch_size must be divisible by world_size");

@@ -2293,28 +2293,26 @@ template <int KIND, int H> static size_t grad_lds_bytes() {
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
+// every kernel below is built for hidden widths 64 (one wave per net), 128 and 256 (wide path)
+#define DRIL_DISPATCH_H(K, hidden, CALL)                                             \
+    { if ((hidden) == 64) { CALL(K, 64); } else if ((hidden) == 128) { CALL(K, 128); } else if ((hidden) == 256) { CALL(K, 256); } else return hipErrorInvalidValue; }
 #define DRIL_DISPATCH_FWD(kind, hidden, CALL)                                        \
     do {                                                                             \
-        if ((kind) == 0 && (hidden) == 64) { CALL(0, 64); }                          \
-        else if (((kind) == 1 || (kind) == 2) && (hidden) == 64) { CALL(1, 64); }    \
-        else if ((kind) == 0 && (hidden) == 256) { CALL(0, 256); }                   \
-        else if (((kind) == 1 || (kind) == 2) && (hidden) == 256) { CALL(1, 256); }  \
-        else if ((kind) == 3 && (hidden) == 64) { CALL(3, 64); }                     \
-        else if ((kind) == 4 && (hidden) == 64) { CALL(4, 64); }                     \
+        if ((kind) == 0) DRIL_DISPATCH_H(0, hidden, CALL)                            \
+        else if ((kind) == 1 || (kind) == 2) DRIL_DISPATCH_H(1, hidden, CALL)        \
+        else if ((kind) == 3) DRIL_DISPATCH_H(3, hidden, CALL)                       \
+        else if ((kind) == 4) DRIL_DISPATCH_H(4, hidden, CALL)                       \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
 // kernels that step / observe the simulator: one instantiation per env kind
 #define DRIL_DISPATCH_ENV(kind, hidden, CALL)                                        \
     do {                                                                             \
-        if ((kind) == 0 && (hidden) == 64) { CALL(0, 64); }                          \
-        else if ((kind) == 1 && (hidden) == 64) { CALL(1, 64); }                     \
-        else if ((kind) == 2 && (hidden) == 64) { CALL(2, 64); }                     \
-        else if ((kind) == 0 && (hidden) == 256) { CALL(0, 256); }                   \
-        else if ((kind) == 1 && (hidden) == 256) { CALL(1, 256); }                   \
-        else if ((kind) == 2 && (hidden) == 256) { CALL(2, 256); }                   \
-        else if ((kind) == 3 && (hidden) == 64) { CALL(3, 64); }                     \
-        else if ((kind) == 4 && (hidden) == 64) { CALL(4, 64); }                     \
+        if ((kind) == 0) DRIL_DISPATCH_H(0, hidden, CALL)                            \
+        else if ((kind) == 1) DRIL_DISPATCH_H(1, hidden, CALL)                       \
+        else if ((kind) == 2) DRIL_DISPATCH_H(2, hidden, CALL)                       \
+        else if ((kind) == 3) DRIL_DISPATCH_H(3, hidden, CALL)                       \
+        else if ((kind) == 4) DRIL_DISPATCH_H(4, hidden, CALL)                       \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
@@ -2464,9 +2462,12 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
             if (e != hipSuccess) return e; attr_set = true; }                                                 \
         ppo_grad_wide_kernel<K, HH, R><<<2 * a.G, HH * 2, lds, s>>>(a);                                       \
     }
-    if (hidden == 256) {
-        if (kind == 0) { if (a.rec) CALLW(0, 256, true) else CALLW(0, 256, false) }
-        else { if (a.rec) CALLW(1, 256, true) else CALLW(1, 256, false) }
+    if (hidden > 64) {
+#define CALLWK(K, HH) { if (a.rec) CALLW(K, HH, true) else CALLW(K, HH, false) }
+#define CALLWH(K) { if (hidden == 256) CALLWK(K, 256) else if (hidden == 128) CALLWK(K, 128) else return hipErrorInvalidValue; }
+        if (kind == 0) CALLWH(0) else if (kind == 3) CALLWH(3) else if (kind == 4) CALLWH(4) else CALLWH(1)
+#undef CALLWH
+#undef CALLWK
         return hipGetLastError();
     }
     if (a.layout == 3 && a.rec && hidden == 64 && kind <= 2) {

@@ -447,12 +447,15 @@ def test_stepwise_path_equals_persistent_kernel(pkg, monkeypatch):
             np.testing.assert_allclose(outs[0][w].astype(np.float64), outs[1][w].astype(np.float64), atol=1e-6)
 
 
-# ---- hidden_dims = [256, 256] (BASELINE configs[2]): wide forward (W2 streamed from L2) and the workgroup-cooperative grad kernel ----
-@pytest.mark.parametrize("kind,B", [(1, 100), (0, 33)])
-def test_wide_forward_evaluate(pkg, oracle_mod, kind, B):
-    cfg = _cfg(pkg, kind, n_envs=2, n_steps=2, batch_size=2, hidden1=256, hidden2=256)
+# ---- hidden_dims = [256, 256] (BASELINE configs[2]) and [128, 128]: wide forward (W2 streamed from L2) and the workgroup-cooperative grad
+# kernel (H / 32 waves per workgroup) ----
+@pytest.mark.parametrize("H", [256, 128])
+@pytest.mark.parametrize("kind,B", [(1, 100), (0, 33), (3, 70), (4, 45)])
+def test_wide_forward_evaluate(pkg, oracle_mod, kind, B, H):
+    cfg = _cfg(pkg, kind, n_envs=2, n_steps=2, batch_size=2, hidden1=H, hidden2=H)
     h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
-    assert h.P == (134147 if kind == 1 else 2 * (256 * 4 + 256 + 256 * 256 + 256) + 256 * 2 + 2 + 256 + 1)
+    if H == 256 and kind < 2:
+        assert h.P == (134147 if kind == 1 else 2 * (256 * 4 + 256 + 256 * 256 + 256) + 256 * 2 + 2 + 256 + 1)
     flat = _params(h.P, 3, 0.12); h.set_params(flat); o.set_params(flat)
     rng = np.random.default_rng(B)
     obs = rng.uniform(-2, 2, (B, h.D)).astype(np.float32)
@@ -468,9 +471,10 @@ def test_wide_forward_evaluate(pkg, oracle_mod, kind, B):
     np.testing.assert_allclose(h.predict_values(obs), vo, atol=5e-5, rtol=5e-5)
 
 
-@pytest.mark.parametrize("kind,B,variant", [(1, 64, "default"), (1, 1000, "ent_vfclip"), (0, 333, "default")])
-def test_wide_ppo_loss_and_gradient(pkg, oracle_mod, kind, B, variant):
-    kw = dict(n_envs=2, n_steps=2, batch_size=2, hidden1=256, hidden2=256)
+@pytest.mark.parametrize("H", [256, 128])
+@pytest.mark.parametrize("kind,B,variant", [(1, 64, "default"), (1, 1000, "ent_vfclip"), (0, 333, "default"), (3, 200, "default"), (4, 129, "ent_vfclip")])
+def test_wide_ppo_loss_and_gradient(pkg, oracle_mod, kind, B, variant, H):
+    kw = dict(n_envs=2, n_steps=2, batch_size=2, hidden1=H, hidden2=H)
     if variant == "ent_vfclip":
         kw.update(ent_coef=0.01, has_clip_range_vf=1, clip_range_vf=0.3, clip_range=0.1)
     cfg = _cfg(pkg, kind, **kw)
@@ -485,11 +489,12 @@ def test_wide_ppo_loss_and_gradient(pkg, oracle_mod, kind, B, variant):
     assert lh2 == lh and np.array_equal(gh, gh2)
 
 
-def test_wide_rollout_and_update_config3_shape(pkg, oracle_mod):
+@pytest.mark.parametrize("kind,H", [(1, 256), (1, 128), (4, 128), (2, 128)])
+def test_wide_rollout_and_update_config3_shape(pkg, oracle_mod, kind, H):
     """configs[2] at test size: Pendulum, DiagGaussian, hidden [256,256], NormalizeWrapperEnv — rollout then PPO update"""
     capi = pkg._capi
     E, T = 40, 24
-    cfg = _cfg(pkg, 1, n_envs=E, n_steps=T, episode_len=10, batch_size=E * T // 3, epochs=2, hidden1=256, hidden2=256,
+    cfg = _cfg(pkg, kind, n_envs=E, n_steps=T, episode_len=10, batch_size=E * T // 3, epochs=2, hidden1=H, hidden2=H,
                norm_training=1, norm_obs=1, norm_reward=1)
     h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
     flat = _params(h.P, 12, 0.08); h.set_params(flat); o.set_params(flat)
