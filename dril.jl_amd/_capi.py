@@ -14,7 +14,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "csrc" / "libdril_hip.so"
 
 ABI_VERSION = 1
-ENV_CARTPOLE, ENV_PENDULUM, ENV_PENDULUM_SCALED, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONTINUOUS = 0, 1, 2, 3, 4
+ENV_CARTPOLE, ENV_PENDULUM, ENV_PENDULUM_SCALED, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONTINUOUS, ENV_EXTERNAL = 0, 1, 2, 3, 4, 5
 (BUF_OBSERVATIONS, BUF_ACTIONS, BUF_REWARDS, BUF_ADVANTAGES, BUF_RETURNS, BUF_LOGPROBS, BUF_VALUES,
  BUF_FLAGS, BUF_BOOTSTRAP, BUF_LAST_VALUES) = range(10)
 (K_ROLLOUT, K_GAE, K_ADV_MOMENTS, K_PPO_GRAD, K_GRAD_REDUCE, K_ADAM, K_ALLREDUCE, K_COUNT) = range(8)
@@ -38,7 +38,9 @@ class DrilConfig(C.Structure):
         ("norm_obs", C.c_int32), ("norm_reward", C.c_int32), ("norm_training", C.c_int32),
         ("clip_obs", C.c_float), ("clip_reward", C.c_float), ("norm_gamma", C.c_float), ("norm_epsilon", C.c_float),
         ("seed", C.c_uint64), ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
-        ("profile_events", C.c_int32), ("monitor_window", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("profile_events", C.c_int32), ("monitor_window", C.c_int32),
+        ("ext_obs_dim", C.c_int32), ("ext_action_dim", C.c_int32), ("ext_discrete", C.c_int32),
+        ("ext_action_low", C.c_float), ("ext_action_high", C.c_float), ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -139,6 +141,10 @@ _SIG = {
     "dril_policy_forward": (C.c_int32, [_P, _P, C.c_int64, _P, _P, _P, _P]),
     "dril_evaluate_actions": (C.c_int32, [_P, _P, _P, C.c_int64, _P, _P, _P]),
     "dril_predict_values": (C.c_int32, [_P, _P, C.c_int64, _P]),
+    "dril_ext_act": (C.c_int32, [_P, _P, _P, _P]),
+    "dril_ext_record": (C.c_int32, [_P, _P, _P, _P, _P]),
+    "dril_ext_finish": (C.c_int32, [_P, _P]),
+    "dril_ext_steps": (C.c_int32, [_P]),
     "dril_collect_rollout": (C.c_int32, [_P, C.POINTER(C.c_double)]),
     "dril_debug_set_noise": (C.c_int32, [_P, _P, C.c_size_t]),
     "dril_buffer_copy_out": (C.c_int32, [_P, C.c_int32, _P, C.c_size_t]),

@@ -89,6 +89,7 @@ struct dril_handle {
     double* rms_partials = nullptr; int rms_blocks = 256; float* e_obs_raw = nullptr;
     int grad_stagger = 0;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
+    bool external = false; GenericDims gd{}; GenericWs gws; int ext_t = 0; bool ext_acted = false;   // DRIL_ENV_EXTERNAL: host envs, generic kernels
     void* comm = nullptr;
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
     double prof_ms[DRIL_K_COUNT] = {0}; int64_t prof_n[DRIL_K_COUNT] = {0};
@@ -147,6 +148,13 @@ int ensure_wimg(dril_handle* h) {
     h->wimg_dirty = false;
     return DRIL_OK;
 }
+
+// fused per-kind kernels for the device envs, the layer-by-layer generic path for DRIL_ENV_EXTERNAL
+hipError_t run_policy(dril_handle* h, const PolicyArgs& a) {
+    if (h->external) return generic_policy(h->gd, a, h->gws, h->stream);
+    return launch_policy(h->cfg.env_kind, h->cfg.hidden1, a, 8 * h->num_cus, h->stream);
+}
+#define NOT_EXTERNAL(h, what) do { if ((h)->external) return fail(h, DRIL_ERR_UNSUPPORTED, what ": the envs of DRIL_ENV_EXTERNAL live on the host (use dril_ext_act / dril_ext_record / dril_ext_finish)"); } while (0)
 
 PolicyArgs policy_args(dril_handle* h, const float* obs, int64_t B, const void* noise, void* actions, float* values, float* logp,
                        float* entropy, int mode) {
@@ -213,11 +221,12 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     const bool reduce = world > 1 || (h->comm && h->force_allreduce);   // force: exercise the RCCL path on one rank (tests)
     const int64_t tiles = (count + kTile - 1) / kTile;
     int G = h->wide ? (int)(tiles < h->Gmax ? tiles : h->Gmax) : (int)((tiles + 3) / 4); if (G > h->Gmax) G = h->Gmax; if (G < 1) G = 1;
+    if (h->external) { G = generic_pick_slabs(h->gd, count, h->Gmax); if (G < 1) return fail(h, DRIL_ERR_UNSUPPORTED, "minibatch too large for the generic path's workspace"); }
     { int rcw = ensure_wimg(h); if (rcw) return rcw; }
     const double* adv_stats = h->adv_stats;
     // launch-bound regime (the reference's default batch_size = 64): the advantage moments are computed inside the grad kernel and
     // reduce + norm + Adam run as one workgroup: 2 dependent launches per optimiser step instead of 6
-    const bool small = !reduce && !h->wide && h->grad_layout == 1 && count <= 4096 && !std::getenv("DRIL_NO_SMALL_PATH");
+    const bool small = !reduce && !h->wide && !h->external && h->grad_layout == 1 && count <= 4096 && !std::getenv("DRIL_NO_SMALL_PATH");
     if (h->cfg.normalize_advantage && pre_stats) adv_stats = pre_stats;   // per-epoch table (already all-reduced in data-parallel runs)
     else if (h->cfg.normalize_advantage && small) adv_stats = nullptr;
     else if (h->cfg.normalize_advantage) {
@@ -240,7 +249,8 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
     g.G = G; g.dbg = h->dbg; g.layout = h->grad_layout; g.stagger = h->grad_stagger; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
     prof_begin(h, DRIL_K_PPO_GRAD);
-    HIPCHK(h, launch_ppo_grad(h->cfg.env_kind, h->cfg.hidden1, g, h->stream));
+    if (h->external) HIPCHK(h, generic_ppo_grad(h->gd, g, h->gws, h->stream));
+    else HIPCHK(h, launch_ppo_grad(h->cfg.env_kind, h->cfg.hidden1, g, h->stream));
     prof_end(h);
     ReduceArgs r{};
     r.slabs_actor = h->slabs_a; r.slabs_critic = h->slabs_c; r.slab_a = h->slab_a; r.slab_c = h->slab_c; r.G = G;
@@ -332,9 +342,13 @@ DRIL_EXPORT int32_t dril_config_default(dril_config* c, int32_t env_kind) {
 DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (!cfg || !out) return fail(nullptr, DRIL_ERR_INVALID_ARG, "null cfg/out");
     if (cfg->abi_version != DRIL_ABI_VERSION) return fail(nullptr, DRIL_ERR_INVALID_ARG, "abi_version mismatch");
-    if (cfg->env_kind < DRIL_ENV_CARTPOLE || cfg->env_kind > DRIL_ENV_MOUNTAINCAR_CONTINUOUS) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
+    if (cfg->env_kind < DRIL_ENV_CARTPOLE || cfg->env_kind > DRIL_ENV_EXTERNAL) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
+    const bool ext = cfg->env_kind == DRIL_ENV_EXTERNAL;
+    if (ext && (cfg->ext_obs_dim < 1 || cfg->ext_obs_dim > 1024 || cfg->ext_action_dim < 1 || cfg->ext_action_dim > 64)) return fail(nullptr, DRIL_ERR_INVALID_ARG, "DRIL_ENV_EXTERNAL: ext_obs_dim must be 1..1024 and ext_action_dim 1..64");
+    if (ext && (cfg->hidden1 < 1 || cfg->hidden1 > 1024 || cfg->hidden2 < 1 || cfg->hidden2 > 1024)) return fail(nullptr, DRIL_ERR_INVALID_ARG, "DRIL_ENV_EXTERNAL: hidden widths must be 1..1024");
+    if (ext && (cfg->norm_obs || cfg->norm_reward || cfg->monitor_window)) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "DRIL_ENV_EXTERNAL: NormalizeWrapperEnv / MonitorWrapperEnv wrap the host env on the host");
     if (cfg->n_envs < 1 || cfg->n_steps < 1 || cfg->epochs < 0 || cfg->batch_size < 1) return fail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs/n_steps/batch_size must be positive");
-    if (cfg->hidden1 != cfg->hidden2 || (cfg->hidden1 != 64 && cfg->hidden1 != 128 && cfg->hidden1 != 256)) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden_dims: [64,64], [128,128] and [256,256] are built");
+    if (!ext && (cfg->hidden1 != cfg->hidden2 || (cfg->hidden1 != 64 && cfg->hidden1 != 128 && cfg->hidden1 != 256))) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden_dims: [64,64], [128,128] and [256,256] are built for the device envs");
     if (cfg->monitor_window < 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "monitor_window must be >= 0");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad rank/world_size");
     if (cfg->batch_size % cfg->world_size != 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "batch_size must be divisible by world_size");
@@ -345,6 +359,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
         case DRIL_ENV_CARTPOLE: h->discrete = true; h->D = 4; h->A = 2; h->S = 4; break;
         case DRIL_ENV_MOUNTAINCAR: h->discrete = true; h->D = 2; h->A = 3; h->S = 2; break;
         case DRIL_ENV_MOUNTAINCAR_CONTINUOUS: h->discrete = false; h->D = 2; h->A = 1; h->S = 2; break;
+        case DRIL_ENV_EXTERNAL: h->discrete = cfg->ext_discrete != 0; h->D = cfg->ext_obs_dim; h->A = cfg->ext_action_dim; h->S = 0; h->external = true; break;
         default: h->discrete = false; h->D = 3; h->A = 1; h->S = 2; break;                    // Pendulum, ScalingWrapperEnv(Pendulum)
     }
     h->actor = net_off(0, h->D, cfg->hidden1, cfg->hidden2, h->A);
@@ -352,6 +367,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     h->Pa = h->actor.end; h->Pc = h->critic.end - h->actor.end; h->log_std_off = h->critic.end;
     h->P = h->critic.end + (h->discrete ? 0 : h->A);
     h->N = (int64_t)cfg->n_envs * cfg->n_steps; h->lr = cfg->learning_rate;
+    h->gd = GenericDims{h->D, h->A, cfg->hidden1, cfg->hidden2, h->discrete ? 1 : 0};
     if (const char* e = std::getenv("DRIL_GRAD_LAYOUT")) h->grad_layout = std::atoi(e);
     if (const char* e = std::getenv("DRIL_FORCE_ALLREDUCE")) h->force_allreduce = std::atoi(e) != 0;
     if (const char* e = std::getenv("DRIL_FORCE_STEPWISE")) h->force_stepwise = std::atoi(e) != 0;
@@ -368,9 +384,11 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(dmalloc(&h->params, P)); CCHK(dmalloc(&h->adam_m, P)); CCHK(dmalloc(&h->adam_v, P)); CCHK(dmalloc(&h->bt, 4));
     CCHK(dmalloc(&h->flat, P + 8)); CCHK(dmalloc(&h->norm_out, 1));
     h->n_norm_partials = (int)((P + 31) / 32); CCHK(dmalloc(&h->norm_partials, h->n_norm_partials));
-    h->slab_a = slab_size_actor(cfg->env_kind, cfg->hidden1); h->slab_c = slab_size_critic(cfg->env_kind, cfg->hidden1);
-    h->wide = cfg->hidden1 > 64;
+    if (ext) { h->slab_a = generic_slab_size(h->gd, true); h->slab_c = generic_slab_size(h->gd, false); }
+    else { h->slab_a = slab_size_actor(cfg->env_kind, cfg->hidden1); h->slab_c = slab_size_critic(cfg->env_kind, cfg->hidden1); }
+    h->wide = !ext && cfg->hidden1 > 64;
     h->Gmax = h->wide ? (h->num_cus / 2 > 0 ? h->num_cus / 2 : 1) : h->num_cus;   // [64,64]: 2 workgroups per CU (actor + critic), 4 waves each; wide: 1 workgroup of H/32 waves per CU
+    if (ext) h->Gmax = 64;                                                         // generic path: one slab per row chunk of the minibatch
     if (const char* e = std::getenv("DRIL_GRAD_GMAX")) { const int g = std::atoi(e); if (g > 0 && g < h->Gmax) h->Gmax = g; }   // diagnostic: fewer workgroups per net
     if (h->wide) { const size_t hh = (size_t)cfg->hidden1 * cfg->hidden1; CCHK(dmalloc(&h->w2a_actor, hh)); CCHK(dmalloc(&h->w2ta_actor, hh)); CCHK(dmalloc(&h->w2a_critic, hh)); CCHK(dmalloc(&h->w2ta_critic, hh)); }
     CCHK(dmalloc(&h->slabs_a, (size_t)h->Gmax * h->slab_a)); CCHK(dmalloc(&h->slabs_c, (size_t)h->Gmax * h->slab_c));
@@ -379,7 +397,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(dmalloc(&h->obs, N * h->D)); CCHK(hipMalloc(&h->act, N * act_bytes_per(h))); CCHK(dmalloc(&h->rew, N)); CCHK(dmalloc(&h->adv, N));
     CCHK(dmalloc(&h->ret, N)); CCHK(dmalloc(&h->logp, N)); CCHK(dmalloc(&h->val, N)); CCHK(dmalloc(&h->boot, N)); CCHK(dmalloc(&h->flags, N));
     CCHK(dmalloc(&h->last_values, E));
-    if (!std::getenv("DRIL_NO_RECORDS")) CCHK(dmalloc(&h->rec, 2 * N));
+    if (!ext && !std::getenv("DRIL_NO_RECORDS")) CCHK(dmalloc(&h->rec, 2 * N));
     if (cfg->monitor_window > 0) {
         const size_t W = cfg->monitor_window;
         CCHK(dmalloc(&h->mon_cur_ret, E)); CCHK(dmalloc(&h->mon_cur_len, E)); CCHK(dmalloc(&h->ep_ret, N)); CCHK(dmalloc(&h->ep_len, N));
@@ -415,6 +433,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     if (!h) return DRIL_OK;
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    generic_ws_free(h->gws);
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
                     h->flags, h->last_values, h->noise_dev, h->perm_dev, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
@@ -447,7 +466,7 @@ DRIL_EXPORT int32_t dril_set_learning_rate(dril_handle* h, float lr) { NEED(h); 
 
 // ---- env verbs -----------------------------------------------------------------------------------
 DRIL_EXPORT int32_t dril_env_reset(dril_handle* h, uint64_t seed) {
-    NEED(h);
+    NEED(h); NOT_EXTERNAL(h, "dril_env_reset");
     h->env_seed0 = seed + (uint64_t)h->cfg.rank * (uint64_t)h->cfg.n_envs;
     HIPCHK(h, launch_env_reset(h->cfg.env_kind, h->cfg.n_envs, h->env_seed0, h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->stream));
     if (h->mon_cur_ret) { HIPCHK(h, hipMemsetAsync(h->mon_cur_ret, 0, (size_t)h->cfg.n_envs * 4, h->stream)); HIPCHK(h, hipMemsetAsync(h->mon_cur_len, 0, (size_t)h->cfg.n_envs * 4, h->stream)); }   // MonitorWrapperEnv.reset! :38-44
@@ -455,7 +474,7 @@ DRIL_EXPORT int32_t dril_env_reset(dril_handle* h, uint64_t seed) {
     return sync(h);
 }
 DRIL_EXPORT int32_t dril_env_observe(dril_handle* h, float* host_obs, int32_t update_stats) {
-    NEED(h);
+    NEED(h); NOT_EXTERNAL(h, "dril_env_observe");
     if (!h->env_ready) return fail(h, DRIL_ERR_NOT_INITIALISED, "dril_env_observe before dril_env_reset");
     if (!host_obs) return fail(h, DRIL_ERR_INVALID_ARG, "null host_obs");
     if (normalizing(h)) { int rc = observe_dev(h, update_stats != 0); if (rc) return rc; }
@@ -464,7 +483,7 @@ DRIL_EXPORT int32_t dril_env_observe(dril_handle* h, float* host_obs, int32_t up
     return sync(h);
 }
 DRIL_EXPORT int32_t dril_env_step(dril_handle* h, const void* actions, float* rewards, uint8_t* terminated, uint8_t* truncated, float* terminal_obs) {
-    NEED(h);
+    NEED(h); NOT_EXTERNAL(h, "dril_env_step");
     if (!h->env_ready) return fail(h, DRIL_ERR_NOT_INITIALISED, "dril_env_step before dril_env_reset");
     if (!actions) return fail(h, DRIL_ERR_INVALID_ARG, "null actions");
     const size_t E = h->cfg.n_envs;
@@ -483,19 +502,19 @@ DRIL_EXPORT int32_t dril_env_step(dril_handle* h, const void* actions, float* re
     return sync(h);
 }
 DRIL_EXPORT int32_t dril_env_get_state(dril_handle* h, float* state, int32_t* step_count) {
-    NEED(h); if (!state) return fail(h, DRIL_ERR_INVALID_ARG, "null state");
+    NEED(h); NOT_EXTERNAL(h, "dril_env_get_state"); if (!state) return fail(h, DRIL_ERR_INVALID_ARG, "null state");
     HIPCHK(h, hipMemcpyAsync(state, h->state, (size_t)h->cfg.n_envs * h->S * 4, hipMemcpyDeviceToHost, h->stream));
     if (step_count) HIPCHK(h, hipMemcpyAsync(step_count, h->step_count, (size_t)h->cfg.n_envs * 4, hipMemcpyDeviceToHost, h->stream));
     return sync(h);
 }
 DRIL_EXPORT int32_t dril_env_set_state(dril_handle* h, const float* state, const int32_t* step_count) {
-    NEED(h); if (!state) return fail(h, DRIL_ERR_INVALID_ARG, "null state");
+    NEED(h); NOT_EXTERNAL(h, "dril_env_set_state"); if (!state) return fail(h, DRIL_ERR_INVALID_ARG, "null state");
     HIPCHK(h, hipMemcpyAsync(h->state, state, (size_t)h->cfg.n_envs * h->S * 4, hipMemcpyHostToDevice, h->stream));
     if (step_count) HIPCHK(h, hipMemcpyAsync(h->step_count, step_count, (size_t)h->cfg.n_envs * 4, hipMemcpyHostToDevice, h->stream));
     return sync(h);
 }
 DRIL_EXPORT int32_t dril_norm_get_stats(dril_handle* h, float* obs_mean, float* obs_var, int64_t* obs_count, float* ret_mean, float* ret_var, int64_t* ret_count) {
-    NEED(h);
+    NEED(h); NOT_EXTERNAL(h, "dril_norm_get_stats");
     RmsState o, r;
     HIPCHK(h, hipMemcpyAsync(&o, h->obs_rms + h->obs_par, sizeof(o), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&r, h->ret_rms + h->ret_par, sizeof(r), hipMemcpyDeviceToHost, h->stream));
@@ -505,7 +524,7 @@ DRIL_EXPORT int32_t dril_norm_get_stats(dril_handle* h, float* obs_mean, float* 
     return DRIL_OK;
 }
 DRIL_EXPORT int32_t dril_norm_set_stats(dril_handle* h, const float* obs_mean, const float* obs_var, int64_t obs_count, float ret_mean, float ret_var, int64_t ret_count) {
-    NEED(h);
+    NEED(h); NOT_EXTERNAL(h, "dril_norm_set_stats");
     if (!obs_mean || !obs_var) return fail(h, DRIL_ERR_INVALID_ARG, "null statistics");
     RmsState o{}, r{};
     for (int d = 0; d < 8; ++d) { o.mean[d] = d < h->D ? obs_mean[d] : 0.f; o.var[d] = d < h->D ? obs_var[d] : 1.f; r.mean[d] = 0.f; r.var[d] = 1.f; }
@@ -549,7 +568,7 @@ int policy_host(dril_handle* h, const float* obs, int64_t B, const void* noise, 
     if (actions_in) PCHK(hipMemcpyAsync(d_act, actions, ab, hipMemcpyHostToDevice, h->stream));
     { int rcw = ensure_wimg(h); if (rcw) { cleanup(); return rcw; } }
     PolicyArgs a = policy_args(h, d_obs, B, d_noise, d_act, d_val, d_lp, d_ent, mode);
-    PCHK(launch_policy(h->cfg.env_kind, h->cfg.hidden1, a, 8 * h->num_cus, h->stream));
+    PCHK(run_policy(h, a));
     h->policy_calls += 1;
     if (values) PCHK(hipMemcpyAsync(values, d_val, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
     if (logp && mode != 2) PCHK(hipMemcpyAsync(logp, d_lp, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
@@ -657,7 +676,76 @@ int collect_rollout(dril_handle* h, double* fps, bool do_sync) {
     return do_sync ? sync(h) : DRIL_OK;
 }
 }  // namespace
-DRIL_EXPORT int32_t dril_collect_rollout(dril_handle* h, double* fps) { NEED(h); return collect_rollout(h, fps, true); }
+// ---- collect_trajectories over HOST envs (DRIL_ENV_EXTERNAL), trajectory.jl:22-78: the caller steps its envs, the device does the rest ----
+DRIL_EXPORT int32_t dril_ext_act(dril_handle* h, const float* obs, void* raw_actions, void* env_actions) {
+    NEED(h);
+    if (!h->external) return fail(h, DRIL_ERR_UNSUPPORTED, "dril_ext_act: the handle was not created with DRIL_ENV_EXTERNAL");
+    if (!obs) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ext_act: null obs");
+    if (h->ext_acted) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ext_act: the previous step has no dril_ext_record yet");
+    if (h->ext_t >= h->cfg.n_steps) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ext_act: n_steps env steps are recorded; call dril_ext_finish");
+    const size_t E = h->cfg.n_envs, D = h->D, A = h->A, ab = act_bytes_per(h), k = (size_t)h->ext_t * E;
+    HIPCHK(h, hipMemcpyAsync(h->obs + k * D, obs, E * D * 4, hipMemcpyHostToDevice, h->stream));                          // observation -> buffer, :46-47
+    const void* nz = h->noise_set ? (const void*)((const char*)h->noise_dev + k * (h->discrete ? 8 : 4 * A)) : nullptr;
+    PolicyArgs p = policy_args(h, h->obs + k * D, (int64_t)E, nz, (char*)h->act + k * ab, h->val + k, h->logp + k, nullptr, 0);     // get_action_and_values :41; raw action stored :48
+    HIPCHK(h, run_policy(h, p));
+    h->policy_calls += 1;
+    if (raw_actions) HIPCHK(h, hipMemcpyAsync(raw_actions, (char*)h->act + k * ab, E * ab, hipMemcpyDeviceToHost, h->stream));
+    if (env_actions) HIPCHK(h, hipMemcpyAsync(env_actions, (char*)h->act + k * ab, E * ab, hipMemcpyDeviceToHost, h->stream));
+    int rc = sync(h); if (rc) return rc;
+    if (env_actions && !h->discrete && h->cfg.ext_action_low < h->cfg.ext_action_high) {                                  // to_env(ClampAdapter) :42, default_adapters.jl:4-11; E * A floats, on the host
+        float* a = (float*)env_actions; const float lo = h->cfg.ext_action_low, hi = h->cfg.ext_action_high;
+        for (size_t i = 0; i < E * A; ++i) a[i] = a[i] < lo ? lo : (a[i] > hi ? hi : a[i]);
+    }
+    h->ext_acted = true;
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_ext_record(dril_handle* h, const float* rewards, const uint8_t* terminated, const uint8_t* truncated, const float* terminal_obs) {
+    NEED(h);
+    if (!h->external) return fail(h, DRIL_ERR_UNSUPPORTED, "dril_ext_record: the handle was not created with DRIL_ENV_EXTERNAL");
+    if (!rewards || !terminated || !truncated) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ext_record: null rewards / terminated / truncated");
+    if (!h->ext_acted) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ext_record without a preceding dril_ext_act");
+    const size_t E = h->cfg.n_envs, D = h->D, k = (size_t)h->ext_t * E;
+    std::vector<uint8_t> fl(E); std::vector<int> tr;
+    for (size_t e = 0; e < E; ++e) { fl[e] = (uint8_t)((terminated[e] ? 1 : 0) | (truncated[e] ? 2 : 0)); if (truncated[e]) tr.push_back((int)e); }
+    if (!tr.empty() && !terminal_obs) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ext_record: truncated envs need terminal_obs (infos[i][\"terminal_observation\"], multithreadedParallelEnv.jl:64-66)");
+    HIPCHK(h, hipMemcpyAsync(h->rew + k, rewards, E * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->flags + k, fl.data(), E, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->boot + k, 0, E * 4, h->stream));
+    std::vector<float> tobs, bv;
+    if (!tr.empty()) {                                                                // V(terminal_observation) of the truncated envs only, trajectory.jl:57-61
+        const size_t n = tr.size(); tobs.resize(n * D); bv.resize(n);
+        for (size_t j = 0; j < n; ++j) std::memcpy(&tobs[j * D], terminal_obs + (size_t)tr[j] * D, D * 4);
+        HIPCHK(h, hipMemcpyAsync(h->e_tobs, tobs.data(), n * D * 4, hipMemcpyHostToDevice, h->stream));
+        PolicyArgs p = policy_args(h, h->e_tobs, (int64_t)n, nullptr, nullptr, h->e_rew, nullptr, nullptr, 2);
+        HIPCHK(h, run_policy(h, p));
+        HIPCHK(h, hipMemcpyAsync(bv.data(), h->e_rew, n * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    int rc = sync(h); if (rc) return rc;                                              // fl / tobs are host temporaries: drain before they go out of scope
+    if (!tr.empty()) {
+        std::vector<float> row(E, 0.f);
+        for (size_t j = 0; j < tr.size(); ++j) row[tr[j]] = bv[j];
+        HIPCHK(h, hipMemcpyAsync(h->boot + k, row.data(), E * 4, hipMemcpyHostToDevice, h->stream));
+        rc = sync(h); if (rc) return rc;
+    }
+    h->ext_t += 1; h->ext_acted = false;
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_ext_finish(dril_handle* h, const float* last_obs) {
+    NEED(h);
+    if (!h->external) return fail(h, DRIL_ERR_UNSUPPORTED, "dril_ext_finish: the handle was not created with DRIL_ENV_EXTERNAL");
+    if (!last_obs) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ext_finish: null last_obs");
+    if (h->ext_acted || h->ext_t != h->cfg.n_steps) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ext_finish: the rollout needs exactly n_steps act/record pairs");
+    const size_t E = h->cfg.n_envs, D = h->D;
+    HIPCHK(h, hipMemcpyAsync(h->e_obs, last_obs, E * D * 4, hipMemcpyHostToDevice, h->stream));
+    PolicyArgs p = policy_args(h, h->e_obs, (int64_t)E, nullptr, nullptr, h->last_values, nullptr, nullptr, 2);          // V(new_obs) where the last step left the trajectory open, :65-70
+    HIPCHK(h, run_policy(h, p));
+    h->ext_t = 0; h->noise_set = false;
+    int rc = compute_gae(h); if (rc) return rc;                                       // compute_advantages! + returns, rollout_buffer.jl:83-87
+    return sync(h);
+}
+DRIL_EXPORT int32_t dril_ext_steps(const dril_handle* h) { return h ? h->ext_t : -1; }
+
+DRIL_EXPORT int32_t dril_collect_rollout(dril_handle* h, double* fps) { NEED(h); NOT_EXTERNAL(h, "dril_collect_rollout"); return collect_rollout(h, fps, true); }
 DRIL_EXPORT int32_t dril_debug_set_noise(dril_handle* h, const void* noise, size_t count) {
     NEED(h);
     if (!noise) { h->noise_set = false; return DRIL_OK; }
@@ -867,7 +955,7 @@ DRIL_EXPORT int32_t dril_apply_gradients(dril_handle* h, const float* grads, siz
 
 // ---- evaluate_agent (src/evaluation.jl:54-143) ------------------------------------------------------------
 DRIL_EXPORT int32_t dril_evaluate_agent(dril_handle* h, int32_t n_eval, int32_t deterministic, dril_eval_stats* out, float* ep_rewards, int32_t* ep_lengths) {
-    NEED(h);
+    NEED(h); NOT_EXTERNAL(h, "dril_evaluate_agent");
     if (n_eval < 1 || !out) return fail(h, DRIL_ERR_INVALID_ARG, "dril_evaluate_agent: n_eval_episodes >= 1 and out != NULL");
     const int E = h->cfg.n_envs;
     int rc = ensure_wimg(h); if (rc) return rc;
@@ -910,7 +998,7 @@ DRIL_EXPORT int32_t dril_evaluate_agent(dril_handle* h, int32_t n_eval, int32_t 
 
 // ---- train! ------------------------------------------------------------------------------------------
 DRIL_EXPORT int32_t dril_train(dril_handle* h, int64_t max_steps, dril_ppo_stats* stats, double* fps, int32_t* iterations_done) {
-    NEED(h);
+    NEED(h); NOT_EXTERNAL(h, "dril_train");
     const int64_t per_iter = (int64_t)h->cfg.n_steps * h->cfg.n_envs * h->cfg.world_size;
     const int64_t iterations = max_steps / per_iter;                                   // ppo.jl:117
     int32_t done = 0;

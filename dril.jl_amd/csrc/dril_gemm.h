@@ -1,0 +1,27 @@
+// dril_gemm.h — the generic strided fp32-MFMA contraction shared by the SAC path (dril_sac.hip) and the generic
+// (any obs / action / hidden width) on-policy path (dril_generic.hip).  Kernels in dril_gemm.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dril {
+
+// C[z](M x N) = epi(alpha * A[z](M x K) . B[z](K x N) + bias[z](M)), every operand addressed by element strides
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias; const float* aux;
+    int M, N, K;
+    int sAm, sAk, sBk, sBn, sCm, sCn;             // element strides
+    long long zA, zB, zC, zBias, zAux;            // batch (blockIdx.z) strides
+    int zdivB;                                    // B uses batch index z / zdivB (several nets reading one input)
+    int vecA, vecB;                               // operand has unit stride along k, 16-byte aligned rows and K % 4 == 0: float4 loads
+    int ones_n;                                   // B(:, N-1) == 1 (appends the bias column to a weight-gradient contraction)
+    int epi; float alpha;
+};
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_TANH = 2, EPI_MASK_RELU = 3, EPI_MASK_TANH = 4 };
+
+GemmArgs gemm_args();
+// one contraction, Z batches (blockIdx.z); picks the split-K / tile-parallel / LDS-tiled shape from the tile count
+hipError_t launch_gemm(GemmArgs g, int Z, hipStream_t s);
+// two independent contractions in one launch (a layer's [dW | db] and its dz): blockIdx.z < Za runs `a`
+hipError_t launch_gemm_pair(GemmArgs a, int Za, GemmArgs b, int Zb, hipStream_t s);
+
+}  // namespace dril

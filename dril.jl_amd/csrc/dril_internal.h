@@ -129,4 +129,13 @@ hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a,
 int slab_size_actor(int kind, int hidden);
 int slab_size_critic(int kind, int hidden);
 
+// generic (any obs / action / hidden width) on-policy path, dril_generic.hip; same argument blocks and slab format as the fused kernels
+struct GenericDims { int D, A, H1, H2, discrete; };
+struct GenericWs { float* p = nullptr; size_t cap = 0; };          // grow-only device workspace (floats), owned by the handle
+hipError_t generic_policy(const GenericDims& d, const PolicyArgs& a, GenericWs& ws, hipStream_t s);
+hipError_t generic_ppo_grad(const GenericDims& d, const GradArgs& a, GenericWs& ws, hipStream_t s);
+int generic_slab_size(const GenericDims& d, bool actor);
+int generic_pick_slabs(const GenericDims& d, int64_t count, int Gmax);   // slabs (row chunks) for a minibatch of `count` rows; < 1: does not fit
+void generic_ws_free(GenericWs& ws);
+
 }  // namespace dril

@@ -299,9 +299,20 @@ def make_config(env, n_envs: int, alg: PPO, layer: Optional[ActorCriticLayer] = 
     if layer is not None:
         c.hidden1, c.hidden2 = layer.hidden_dims
         c.log_std_init = layer.log_std_init
-    c.episode_len = env.max_steps
+    c.episode_len = getattr(env, "max_steps", 0)
     c.fixed_length_episodes = int(fixed_length_episodes)
     c.action_start = getattr(env, "action_start", 1)
+    if env.kind == capi.ENV_EXTERNAL:   # host envs: the spaces travel in the config (include/dril_hip.h, DRIL_ENV_EXTERNAL)
+        osp, asp = env.observation_space(), env.action_space()
+        c.ext_obs_dim = int(np.prod(osp.shape))
+        c.ext_discrete = int(isinstance(asp, Discrete))
+        if c.ext_discrete:
+            c.ext_action_dim, c.action_start = asp.n, asp.start
+        else:
+            c.ext_action_dim = int(np.prod(asp.shape))
+            lo, hi = np.unique(np.asarray(asp.low, np.float32)), np.unique(np.asarray(asp.high, np.float32))
+            # ClampAdapter on the device needs one (low, high) pair; per-dimension bounds are clamped by HostParallelEnv.act_ instead
+            c.ext_action_low, c.ext_action_high = (float(lo[0]), float(hi[0])) if lo.size == 1 and hi.size == 1 else (0.0, 0.0)
     c.gamma, c.gae_lambda, c.clip_range = alg.gamma, alg.gae_lambda, alg.clip_range
     c.has_clip_range_vf = int(alg.clip_range_vf is not None)
     c.clip_range_vf = alg.clip_range_vf or 0.0
@@ -456,6 +467,27 @@ class Handle:
         fps = C.c_double()
         self._chk(self.lib.dril_collect_rollout(self._h, C.byref(fps)))
         return fps.value
+
+    # rollout over host envs (DRIL_ENV_EXTERNAL), trajectory.jl:22-78
+    def ext_act(self, obs: np.ndarray):
+        """-> (raw policy actions, env-space actions) for one env step; obs is (E, D)"""
+        obs = np.ascontiguousarray(obs, np.float32).reshape(self.E, self.D)
+        raw = np.empty(self.E, np.int32) if self.discrete else np.empty((self.E, self.A), np.float32)
+        env_a = np.empty_like(raw)
+        self._chk(self.lib.dril_ext_act(self._h, self._p(obs), self._p(raw), self._p(env_a)))
+        return raw, env_a
+
+    def ext_record(self, rewards, terminated, truncated, terminal_obs=None):
+        r = np.ascontiguousarray(rewards, np.float32); te = np.ascontiguousarray(terminated, np.uint8); tr = np.ascontiguousarray(truncated, np.uint8)
+        to = None if terminal_obs is None else np.ascontiguousarray(terminal_obs, np.float32).reshape(self.E, self.D)
+        self._chk(self.lib.dril_ext_record(self._h, self._p(r), self._p(te), self._p(tr), self._p(to)))
+
+    def ext_finish(self, last_obs: np.ndarray):
+        o = np.ascontiguousarray(last_obs, np.float32).reshape(self.E, self.D)
+        self._chk(self.lib.dril_ext_finish(self._h, self._p(o)))
+
+    def ext_steps(self) -> int:
+        return int(self.lib.dril_ext_steps(self._h))
 
     def set_noise(self, noise: Optional[np.ndarray]):
         if noise is None:
@@ -635,6 +667,91 @@ class DeviceParallelEnv:
         return self._last_trunc
 
 
+class HostParallelEnv:
+    """`BroadcastedParallelEnv(envs)` (broadcastedParallelEnv.jl:41-66) over the CALLER'S OWN envs: any objects with the reference's
+    AbstractEnv verbs (interfaces/environments.jl:21-39) — `reset_()`, `act_(action) -> reward`, `observe()`, `terminated()`,
+    `truncated()`, `observation_space()`, `action_space()`, optional `get_info()`.  The envs step on the host; `train_` sends their
+    observations to the device once per step and runs everything else there (DRIL_ENV_EXTERNAL: dril_ext_act / _record / _finish,
+    generic kernels for any obs / action / hidden width)."""
+    kind = capi.ENV_EXTERNAL
+
+    def __init__(self, envs, *, seed: int = 42, device: int = 0, profile_events: bool = False):
+        self.envs, self.n_envs, self.seed = list(envs), len(envs), seed
+        self._kw = dict(device=device, profile_events=profile_events)
+        self.handle: Optional[Handle] = None
+        self._bound_key = None
+        self._last_term = np.zeros(self.n_envs, bool)
+        self._last_trunc = np.zeros(self.n_envs, bool)
+
+    def bind(self, alg: PPO, layer: Optional[ActorCriticLayer] = None) -> Handle:
+        key = (tuple(sorted(asdict(alg).items())), None if layer is None else (tuple(layer.hidden_dims), layer.log_std_init))
+        if self.handle is None or key != self._bound_key:
+            if self.handle is not None:
+                self.handle.close()
+            self.handle = Handle(make_config(self, self.n_envs, alg, layer, seed=self.seed, **self._kw))
+            self._bound_key = key
+        return self.handle
+
+    def number_of_envs(self) -> int:
+        return self.n_envs
+
+    def observation_space(self):
+        return self.envs[0].observation_space()
+
+    def action_space(self):
+        return self.envs[0].action_space()
+
+    def reset_(self):
+        for e in self.envs:
+            e.reset_()
+
+    def observe(self):
+        return [np.asarray(e.observe(), np.float32).ravel() for e in self.envs]
+
+    def act_(self, actions):
+        """-> (rewards, terminateds, truncateds, infos); auto-reset, `terminal_observation` only on truncation (:58-66)"""
+        assert len(actions) == self.n_envs
+        rewards = np.array([e.act_(a) for e, a in zip(self.envs, actions)], np.float32)
+        term = np.array([bool(e.terminated()) for e in self.envs]); trunc = np.array([bool(e.truncated()) for e in self.envs])   # before the reset
+        infos = [dict(e.get_info()) if hasattr(e, "get_info") else dict() for e in self.envs]
+        for i, e in enumerate(self.envs):
+            if trunc[i]:
+                infos[i]["terminal_observation"] = np.asarray(e.observe(), np.float32).ravel().copy()
+            if term[i] or trunc[i]:
+                e.reset_()
+        self._last_term, self._last_trunc = term, trunc
+        return rewards, term, trunc, infos
+
+    def terminated(self):
+        return self._last_term
+
+    def truncated(self):
+        return self._last_trunc
+
+
+def _host_rollout(h: Handle, env: HostParallelEnv) -> float:
+    """collect_trajectories (trajectory.jl:22-78) with the envs on the host and the agent on the device; -> fps (rollout_buffer.jl:60-64)"""
+    t0 = time.perf_counter()
+    asp = env.action_space()
+    new_obs = np.stack(env.observe())                                                # :32
+    for _ in range(h.T):
+        raw, ea = h.ext_act(new_obs)                                                 # get_action_and_values + to_env, :41-42
+        if isinstance(asp, Box) and h.cfg.ext_action_low >= h.cfg.ext_action_high:   # per-dimension bounds: ClampAdapter here (default_adapters.jl:4-11)
+            ea = np.clip(ea, np.asarray(asp.low, np.float32).reshape(1, -1), np.asarray(asp.high, np.float32).reshape(1, -1))
+        acts = list(ea) if h.discrete else [a.reshape(asp.shape) for a in ea]
+        rew, term, trunc, infos = env.act_(acts)                                     # :44
+        new_obs = np.stack(env.observe())                                            # :45
+        tobs = None
+        if trunc.any():
+            tobs = np.zeros((h.E, h.D), np.float32)
+            for i in np.nonzero(trunc)[0]:
+                tobs[i] = infos[i]["terminal_observation"]
+        h.ext_record(rew, term, trunc, tobs)                                         # :46-61
+    h.ext_finish(new_obs)                                                            # :65-70 + compute_advantages! + returns
+    return h.N / max(time.perf_counter() - t0, 1e-12)
+
+
+
 def MonitorWrapperEnv(env: DeviceParallelEnv, stats_window: int = 100) -> DeviceParallelEnv:
     """MonitorWrapperEnv(env, stats_window) (monitorWrapperEnv.jl:15-24): episode return/length statistics from the device
     done flags; `env.handle.monitor_stats()` gives what `log_stats` logs (env/ep_rew_mean, env/ep_len_mean)."""
@@ -698,7 +815,7 @@ def collect_rollout_(buffer: RolloutBuffer, agent: Agent, alg: PPO, env: DeviceP
     """collect_rollout!(rollout_buffer, agent, alg, env) -> (fps, success), rollout_buffer.jl:46-90."""
     h = env.bind(alg, agent.layer)
     h.set_params(flatten_params(agent.train_state.parameters))
-    fps = h.collect_rollout()
+    fps = _host_rollout(h, env) if isinstance(env, HostParallelEnv) else h.collect_rollout()
     buffer.observations = h.buffer(capi.BUF_OBSERVATIONS)
     acts = h.buffer(capi.BUF_ACTIONS)
     buffer.actions = acts.astype(np.int64) if h.discrete else acts  # eltype(Discrete{Int}) = Int64, spaces.jl:169
@@ -738,7 +855,7 @@ def train_(agent: Agent, env: DeviceParallelEnv, alg: PPO, max_steps: int, callb
         h.set_learning_rate(alg.learning_rate)  # Optimisers.adjust!, ppo.jl:155-156
         learn_stats["learning_rates"].append(alg.learning_rate)
         a = time.perf_counter()
-        fps = h.collect_rollout()  # ppo.jl:167
+        fps = _host_rollout(h, env) if isinstance(env, HostParallelEnv) else h.collect_rollout()  # ppo.jl:167
         b = time.perf_counter()
         st = h.ppo_update()  # ppo.jl:188-264
         c = time.perf_counter()

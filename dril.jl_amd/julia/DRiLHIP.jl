@@ -40,7 +40,8 @@ struct DrilConfig
     clip_obs::Float32; clip_reward::Float32; norm_gamma::Float32; norm_epsilon::Float32
     seed::UInt64
     device::Int32; rank::Int32; world_size::Int32; profile_events::Int32; monitor_window::Int32
-    reserved::NTuple{6, Int32}
+    ext_obs_dim::Int32; ext_action_dim::Int32; ext_discrete::Int32; ext_action_low::Float32; ext_action_high::Float32
+    reserved::NTuple{1, Int32}
 end
 
 # struct dril_ppo_stats
@@ -114,7 +115,7 @@ function make_config(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int}, log_
         0.9f0, 0.999f0, 1.0f-5, log_std_init,                    # Optimisers.Adam(eta, (0.9, 0.999), 1e-5): ppo.jl:64-66
         on * Int32(nget(:norm_obs, true)), on * Int32(nget(:norm_reward, true)), on * Int32(nget(:training, true)),
         Float32(nget(:clip_obs, 10)), Float32(nget(:clip_reward, 10)), Float32(nget(:gamma, 0.99)), Float32(nget(:epsilon, 1.0e-8)),
-        env.seed, env.device, 0, 1, 0, env.monitor_window, ntuple(_ -> Int32(0), 6))
+        env.seed, env.device, 0, 1, 0, env.monitor_window, 0, 0, 0, 0.0f0, 0.0f0, ntuple(_ -> Int32(0), 1))
 end
 
 "(re)create the handle when the algorithm / layer shape changes; Random.seed!(env, seed) + reset!(env) follow"

@@ -55,7 +55,13 @@ enum dril_env_kind {
      * action back with (a + 1) / (2/(high - low)) + low (:76-79,110-113) before the physics; the affine maps are fused into the env kernels */
     DRIL_ENV_PENDULUM_SCALED = 2,
     DRIL_ENV_MOUNTAINCAR = 3,            /* MountainCar-v0: D=2 (position, velocity), Discrete(3), reward -1/step, goal at 0.5, limit 200 */
-    DRIL_ENV_MOUNTAINCAR_CONTINUOUS = 4  /* MountainCarContinuous-v0: D=2, Box(-1,1), reward 100 at the goal (0.45) - 0.1 a^2, limit 999 */
+    DRIL_ENV_MOUNTAINCAR_CONTINUOUS = 4, /* MountainCarContinuous-v0: D=2, Box(-1,1), reward 100 at the goal (0.45) - 0.1 a^2, limit 999 */
+    /* any AbstractParallelEnv that lives on the HOST (the caller's own Julia envs, interfaces/environments.jl:21-39): observations come in and
+     * actions go out once per env step (dril_ext_act / dril_ext_record / dril_ext_finish below), everything else of the path — policy forward,
+     * sampling, rollout buffer, bootstrap values, GAE, the PPO update — runs on the device.  Spaces are given by ext_obs_dim / ext_action_dim /
+     * ext_discrete; any hidden_dims = [h1, h2] up to 1024.  The env verbs (dril_env_*), dril_collect_rollout, dril_train, dril_evaluate_agent
+     * and the wrappers fused into the env kernels (norm_*, monitor_window) belong to the device envs and return DRIL_ERR_UNSUPPORTED here */
+    DRIL_ENV_EXTERNAL = 5
 };
 
 /* ids for dril_buffer_copy_out / dril_buffer_copy_in (fields of RolloutBuffer,
@@ -95,7 +101,7 @@ typedef struct dril_config {
     int32_t env_kind;          /* enum dril_env_kind */
     int32_t n_envs;            /* E on THIS rank */
     int32_t n_steps;           /* T (PPO.n_steps) */
-    int32_t hidden1, hidden2;  /* hidden_dims = [hidden1, hidden2]; built: [64,64], [128,128], [256,256] */
+    int32_t hidden1, hidden2;  /* hidden_dims = [hidden1, hidden2]; built: [64,64], [128,128], [256,256]; DRIL_ENV_EXTERNAL: any h1, h2 <= 1024 */
     int32_t episode_len;       /* max_steps kwarg: 500 CartPole-v1, 200 Pendulum-v1 */
     int32_t fixed_length_episodes; /* 1: termination disabled (synthetic bench episodes) */
     int32_t action_start;      /* Discrete(n, start): src/spaces.jl:157-164 */
@@ -120,7 +126,12 @@ typedef struct dril_config {
     int32_t rank, world_size;  /* data-parallel position; global env index = rank*n_envs + local */
     int32_t profile_events;    /* 1: bracket hot kernels with HIP events (dril_profile_get) */
     int32_t monitor_window;    /* MonitorWrapperEnv(env, stats_window): > 0 tracks episode returns/lengths (monitorWrapperEnv.jl:15-24); 0 = no wrapper */
-    int32_t reserved[6];
+    /* DRIL_ENV_EXTERNAL only (ignored otherwise): observation_space = Box of ext_obs_dim floats (<= 1024); action_space =
+     * Discrete(ext_action_dim, action_start) when ext_discrete, else Box(ext_action_low, ext_action_high) of ext_action_dim floats (<= 64);
+     * the bounds feed ClampAdapter (default_adapters.jl:4-11); low >= high = no clamp */
+    int32_t ext_obs_dim, ext_action_dim, ext_discrete;
+    float ext_action_low, ext_action_high;
+    int32_t reserved[1];
 } dril_config;
 
 /* per-iteration means returned by dril_ppo_update; field names follow the
@@ -199,6 +210,23 @@ int32_t dril_evaluate_actions(dril_handle* h, const float* obs, const void* acti
                               float* values, float* logprobs, float* entropy);
 /* predict_values(layer, obs, ps, st): layer_methods.jl:57-61 */
 int32_t dril_predict_values(dril_handle* h, const float* obs, int64_t batch, float* values);
+
+/* ---- rollout over HOST envs (DRIL_ENV_EXTERNAL): collect_trajectories, trajectory.jl:22-78, one call pair per env step ------------
+ * for step in 1:n_steps
+ *     obs = observe(env)                                   # caller
+ *     dril_ext_act(h, obs, raw, env_actions)               # get_action_and_values :41 + to_env :42; obs/actions/values/logprobs -> buffer :46-51
+ *     rewards, terminateds, truncateds, infos = act!(env, env_actions)     # caller
+ *     dril_ext_record(h, rewards, terminateds, truncateds, terminal_obs)   # rewards/flags -> buffer; V(terminal_observation) for truncated envs :57-61
+ * end
+ * dril_ext_finish(h, observe(env))                         # V(new_obs) for unfinished trajectories :65-70, compute_advantages!, returns
+ * obs / terminal_obs / last_obs are (D x E) column-major host arrays; raw_actions (stored, pre-adapter) and env_actions (ClampAdapter /
+ * DiscreteAdapter applied) are i32(E) | f32(A x E), either may be NULL; terminal_obs may be NULL when no env was truncated; only the
+ * columns of truncated envs are read.  dril_debug_set_noise injects the sampling noise of the next n_steps dril_ext_act calls. */
+int32_t dril_ext_act(dril_handle* h, const float* obs, void* raw_actions, void* env_actions);
+int32_t dril_ext_record(dril_handle* h, const float* rewards, const uint8_t* terminated, const uint8_t* truncated, const float* terminal_obs);
+int32_t dril_ext_finish(dril_handle* h, const float* last_obs);
+/* env steps recorded since the last dril_ext_finish (0 .. n_steps) */
+int32_t dril_ext_steps(const dril_handle* h);
 
 /* ---- rollout --------------------------------------------------------------- */
 /* collect_rollout!(buffer, agent, alg, env): rollout_buffer.jl:46-90 =

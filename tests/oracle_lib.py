@@ -93,6 +93,10 @@ def lib() -> C.CDLL:
         L.orc_norm_get_stats.argtypes = [_P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         L.orc_monitor_get_stats.argtypes = [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.orc_evaluate_agent.argtypes = [_P, C.c_int32, C.c_int32, C.POINTER(capi.DrilEvalStats), _P, _P]
+        L.orc_ext_act.argtypes = [_P, _P, _P, _P, _P]
+        L.orc_ext_record.argtypes = [_P, _P, _P, _P, _P]
+        L.orc_ext_finish.argtypes = [_P, _P]
+        L.orc_ext_steps.argtypes = [_P]
         L.orc_destroy.argtypes = [_P]
         L.orc_reset_optimizer.argtypes = [_P]
         L.orc_set_num_threads.argtypes = [C.c_int]
@@ -116,6 +120,8 @@ class Oracle:
         assert rc == 0, rc
         self.discrete = cfg.env_kind in (capi.ENV_CARTPOLE, capi.ENV_MOUNTAINCAR)
         self.D, self.A, self.S = {capi.ENV_CARTPOLE: (4, 2, 4), capi.ENV_MOUNTAINCAR: (2, 3, 2), capi.ENV_MOUNTAINCAR_CONTINUOUS: (2, 1, 2)}.get(cfg.env_kind, (3, 1, 2))
+        if cfg.env_kind == capi.ENV_EXTERNAL:
+            self.discrete, self.D, self.A, self.S = bool(cfg.ext_discrete), cfg.ext_obs_dim, cfg.ext_action_dim, 0
         self.P = int(self.L.orc_param_count(self._h))
         self.E, self.T = cfg.n_envs, cfg.n_steps
         self.N = self.E * self.T
@@ -194,6 +200,24 @@ class Oracle:
         noise = np.ascontiguousarray(noise, np.float64 if self.discrete else np.float32)
         self._keep.append(noise)  # the oracle keeps the pointer until the next rollout
         self.L.orc_debug_set_noise(self._h, _p(noise), noise.size)
+
+    # rollout over host envs (DRIL_ENV_EXTERNAL); `noise` is the step's sampling noise (f64[E] | f32[E, A])
+    def ext_act(self, obs, noise):
+        obs = np.ascontiguousarray(obs, np.float32).reshape(self.E, self.D)
+        noise = np.ascontiguousarray(noise, np.float64 if self.discrete else np.float32)
+        raw = np.empty(self.E, np.int32) if self.discrete else np.empty((self.E, self.A), np.float32)
+        env_a = np.empty_like(raw)
+        assert self.L.orc_ext_act(self._h, _p(obs), _p(noise), _p(raw), _p(env_a)) == 0
+        return raw, env_a
+
+    def ext_record(self, rewards, terminated, truncated, terminal_obs=None):
+        r = np.ascontiguousarray(rewards, np.float32); te = np.ascontiguousarray(terminated, np.uint8); tr = np.ascontiguousarray(truncated, np.uint8)
+        to = None if terminal_obs is None else np.ascontiguousarray(terminal_obs, np.float32).reshape(self.E, self.D)
+        assert self.L.orc_ext_record(self._h, _p(r), _p(te), _p(tr), _p(to)) == 0
+
+    def ext_finish(self, last_obs):
+        o = np.ascontiguousarray(last_obs, np.float32).reshape(self.E, self.D)
+        assert self.L.orc_ext_finish(self._h, _p(o)) == 0
 
     def collect_rollout(self):
         fps = C.c_double()

@@ -1,0 +1,278 @@
+"""GPU (-m gpu): DRIL_ENV_EXTERNAL — the caller's own host envs with any obs / action / hidden width — through the C ABI vs the CPU oracle.
+The generic path runs layer by layer on the strided fp32-MFMA contraction (dril_generic.hip / dril_gemm.hip); same fp32 tolerances as
+test_gpu_parity.py.  One property test ties it to the fused path: with CartPole's spaces it must reproduce the fused kernels' rollout."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# (obs dim, action dim, discrete, hidden1, hidden2): odd sizes on purpose (no multiple of 4 / 32 anywhere), unequal hidden widths, wide nets
+SHAPES = [(6, 3, True, 64, 64), (11, 5, False, 48, 80), (1, 1, False, 7, 5), (33, 17, True, 100, 36), (8, 2, False, 256, 256), (128, 64, True, 32, 32)]
+
+
+def _ext_cfg(pkg, D, A, discrete, H1, H2, **kw):
+    c = pkg._capi.default_config(pkg._capi.ENV_EXTERNAL)
+    c.ext_obs_dim, c.ext_action_dim, c.ext_discrete, c.hidden1, c.hidden2 = D, A, int(discrete), H1, H2
+    c.ext_action_low, c.ext_action_high = -1.0, 1.0
+    c.n_envs, c.n_steps, c.batch_size = 2, 2, 2
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _params(P, seed, scale=0.3):
+    return (np.random.default_rng(seed).standard_normal(P) * scale).astype(np.float32)
+
+
+def _noise(rng, h, n):
+    return rng.random(n) if h.discrete else rng.standard_normal((n, h.A)).astype(np.float32)
+
+
+@pytest.mark.parametrize("D,A,discrete,H1,H2", SHAPES)
+def test_generic_forward_evaluate_predict(pkg, oracle_mod, D, A, discrete, H1, H2):
+    """layer(obs, ps, st), evaluate_actions, predict_values (layer_forward.jl:3-13,30-39; layer_methods.jl:28-61) for arbitrary spaces"""
+    cfg = _ext_cfg(pkg, D, A, discrete, H1, H2)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    assert (h.D, h.A, h.discrete) == (D, A, discrete)
+    net = lambda out: D * H1 + H1 + H1 * H2 + H2 + H2 * out + out
+    assert h.P == o.P == net(A) + net(1) + (0 if discrete else A)            # Lux.parameterlength, test/test_policies.jl:55-57
+    flat = _params(h.P, 1, 0.2); h.set_params(flat); o.set_params(flat)
+    assert np.array_equal(h.get_params(), flat)
+    rng = np.random.default_rng(D)
+    for B in (1, 37, 1000):
+        obs = rng.uniform(-2, 2, (B, D)).astype(np.float32); nz = _noise(rng, h, B)
+        ah, vh, lh = h.policy_forward(obs, nz); ao, vo, lo = o.policy_forward(obs, nz)
+        np.testing.assert_allclose(vh, vo, atol=5e-5, rtol=5e-5)
+        if discrete:
+            assert (ah == ao).mean() >= 0.99 and ah.min() >= cfg.action_start and ah.max() < cfg.action_start + A
+            same = ah == ao
+            np.testing.assert_allclose(lh[same], lo[same], atol=1e-4, rtol=1e-4)
+        else:
+            np.testing.assert_allclose(ah, ao, atol=5e-5, rtol=5e-5); np.testing.assert_allclose(lh, lo, atol=3e-4, rtol=3e-4)
+        ve, le, ee = h.evaluate_actions(obs, ao); vo2, lo2, eo2 = o.evaluate_actions(obs, ao)
+        np.testing.assert_allclose(ve, vo2, atol=5e-5, rtol=5e-5); np.testing.assert_allclose(le, lo2, atol=3e-4, rtol=3e-4)
+        np.testing.assert_allclose(ee, eo2, atol=1e-4, rtol=1e-4)
+        np.testing.assert_allclose(h.predict_values(obs), vo, atol=5e-5, rtol=5e-5)
+
+
+@pytest.mark.parametrize("variant", ["default", "ent_vfclip", "no_norm"])
+@pytest.mark.parametrize("D,A,discrete,H1,H2", SHAPES)
+def test_generic_ppo_loss_and_gradient(pkg, oracle_mod, D, A, discrete, H1, H2, variant):
+    """(alg::PPO)(...) ppo.jl:365-407 + its gradient through the generic path: loss within 1e-4 rel (north_star), gradient within fp32 noise"""
+    kw = {}
+    if variant == "ent_vfclip":
+        kw.update(ent_coef=0.01, has_clip_range_vf=1, clip_range_vf=0.3, clip_range=0.1)
+    if variant == "no_norm":
+        kw.update(normalize_advantage=0)
+    cfg = _ext_cfg(pkg, D, A, discrete, H1, H2, **kw)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 40, 0.2); h.set_params(flat); o.set_params(flat)
+    rng = np.random.default_rng(A)
+    for B in (2, 333, 20000):                                                        # 20000 rows: three row chunks (slabs), the last one ragged
+        obs = rng.uniform(-1, 1, (B, D)).astype(np.float32)
+        act = (rng.integers(0, A, B) + cfg.action_start).astype(np.int32) if discrete else rng.normal(0, 1, (B, A)).astype(np.float32)
+        adv, ret, ov = (rng.standard_normal(B).astype(np.float32) for _ in range(3))
+        lp = (o.evaluate_actions(obs, act)[1] + rng.normal(0, 0.1, B)).astype(np.float32)
+        lh, sh, gh = h.ppo_loss_grad(obs, act, adv, ret, lp, ov); lo, so, go = o.ppo_loss_grad(obs, act, adv, ret, lp, ov)
+        assert lh == pytest.approx(lo, rel=1e-4, abs=1e-6)
+        np.testing.assert_allclose(sh, so, rtol=3e-4, atol=3e-6)
+        assert np.linalg.norm(gh - go) <= 3e-4 * np.linalg.norm(go) + 1e-7
+        if not discrete:                                                             # the log_std gradient sits behind both nets
+            np.testing.assert_allclose(gh[-A:], go[-A:], rtol=2e-3, atol=2e-6)
+        lh2, _, gh2 = h.ppo_loss_grad(obs, act, adv, ret, lp, ov)
+        assert lh2 == lh and np.array_equal(gh, gh2)                                 # fixed summation order: bitwise reproducible
+
+
+class _ToyEnvs:
+    """E deterministic host envs with D-dim observations: x' = 0.9 x + 0.1 f(action) + drift, reward = -|x|^2 mean, terminated when |x_0| > 1.5,
+    truncated every `limit` steps (per-env phase); auto-reset + terminal_observation on truncation like BroadcastedParallelEnv"""
+
+    def __init__(self, E, D, A, discrete, limit, seed):
+        self.E, self.D, self.A, self.discrete, self.limit = E, D, A, discrete, limit
+        self.rng = np.random.default_rng(seed)
+        self.W = self.rng.standard_normal((A, D)).astype(np.float32) * 0.5
+        self.x = self.rng.uniform(-1, 1, (E, D)).astype(np.float32)
+        self.t = (np.arange(E) % limit).astype(np.int64)
+
+    def observe(self):
+        return self.x.copy()
+
+    def step(self, env_actions, action_start):
+        if self.discrete:
+            f = self.W[np.asarray(env_actions) - action_start]
+        else:
+            f = np.asarray(env_actions, np.float32).reshape(self.E, self.A) @ self.W
+        self.x = (0.9 * self.x + 0.3 * f + 0.01).astype(np.float32)
+        self.t += 1
+        rew = -(self.x ** 2).mean(axis=1).astype(np.float32)
+        term = np.abs(self.x[:, 0]) > 1.5
+        trunc = self.t >= self.limit
+        tobs = self.x.copy()
+        done = term | trunc
+        self.x[done] = self.rng.uniform(-1, 1, (int(done.sum()), self.D)).astype(np.float32)
+        self.t[done] = 0
+        return rew, term, trunc, tobs
+
+
+@pytest.mark.parametrize("D,A,discrete,H1,H2", [(6, 3, True, 64, 64), (11, 5, False, 48, 80), (33, 17, True, 100, 36)])
+def test_external_rollout_and_update_vs_oracle(pkg, oracle_mod, D, A, discrete, H1, H2):
+    """collect_trajectories over host envs (trajectory.jl:22-78) + GAE + the PPO update, step by step against the oracle: same observations in,
+    same actions out, same buffers, same parameters after update! (two iterations, so the second rollout runs on updated weights)"""
+    capi = pkg._capi
+    E, T = 24, 20
+    cfg = _ext_cfg(pkg, D, A, discrete, H1, H2, n_envs=E, n_steps=T, batch_size=E * T // 3, epochs=2, ent_coef=0.01)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 5, 0.15); h.set_params(flat); o.set_params(flat)
+    envs = _ToyEnvs(E, D, A, discrete, limit=7, seed=3)
+    rng = np.random.default_rng(0)
+    for it in range(2):
+        nz = _noise(rng, h, E * T)
+        h.set_noise(nz)
+        n_trunc = 0
+        for t in range(T):
+            obs = envs.observe()
+            raw_h, env_h = h.ext_act(obs); raw_o, env_o = o.ext_act(obs, nz[t * E:(t + 1) * E])
+            if discrete:
+                assert (raw_h == raw_o).all() and (env_h == raw_h).all()              # DiscreteAdapter is the identity, default_adapters.jl:34-38
+            else:
+                np.testing.assert_allclose(raw_h, raw_o, atol=1e-4, rtol=1e-4)
+                assert env_h.min() >= -1.0 and env_h.max() <= 1.0                    # ClampAdapter, default_adapters.jl:4-11
+                np.testing.assert_allclose(env_h, np.clip(raw_h, -1, 1), atol=0, rtol=0)
+            rew, term, trunc, tobs = envs.step(env_o, cfg.action_start)              # the oracle's actions drive the envs (both paths then see the same obs)
+            n_trunc += int(trunc.sum())
+            h.ext_record(rew, term, trunc, tobs if trunc.any() else None); o.ext_record(rew, term, trunc, tobs if trunc.any() else None)
+            assert h.ext_steps() == t + 1
+        assert n_trunc > 0
+        last = envs.observe()
+        h.ext_finish(last); o.ext_finish(last)
+        assert h.ext_steps() == 0
+        for which, tol in ((capi.BUF_OBSERVATIONS, 0), (capi.BUF_REWARDS, 0), (capi.BUF_VALUES, 1e-4), (capi.BUF_LOGPROBS, 3e-4), (capi.BUF_BOOTSTRAP, 1e-4),
+                           (capi.BUF_LAST_VALUES, 1e-4), (capi.BUF_ADVANTAGES, 1e-3), (capi.BUF_RETURNS, 1e-3)):
+            np.testing.assert_allclose(h.buffer(which), o.buffer(which), atol=tol, rtol=tol)
+        assert np.array_equal(h.buffer(capi.BUF_FLAGS), o.buffer(capi.BUF_FLAGS))
+        for which in (capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+            h.set_buffer(which, o.buffer(which))
+        perm = np.stack([np.random.default_rng(10 * it + e).permutation(E * T) for e in range(cfg.epochs)]).astype(np.int64)
+        h.set_permutation(perm); o.set_permutation(perm)
+        sh, so = h.ppo_update(), o.ppo_update()
+        assert sh.n_updates == so.n_updates == 6
+        assert sh.loss == pytest.approx(so.loss, rel=2e-4, abs=1e-6) and sh.grad_norm == pytest.approx(so.grad_norm, rel=1e-3)
+        assert sh.explained_variance == pytest.approx(so.explained_variance, abs=1e-3)
+        np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=3e-4, atol=3e-6)
+        h.set_params(o.get_params())
+
+
+def test_external_matches_the_fused_cartpole_path(pkg):
+    """property: with CartPole's spaces ([4] obs, Discrete(2), hidden [64,64]) the generic path fed by the device CartPole simulator through the
+    step-granular env verbs reproduces the fused rollout_kernel + ppo_grad_kernel path: same buffers, same update"""
+    capi = pkg._capi
+    E, T = 64, 32
+    common = dict(n_envs=E, n_steps=T, batch_size=E * T // 2, epochs=2, episode_len=9, seed=7)
+    cf = capi.default_config(capi.ENV_CARTPOLE)
+    cx = _ext_cfg(pkg, 4, 2, True, 64, 64)
+    for k, v in common.items():
+        setattr(cf, k, v); setattr(cx, k, v)
+    cx.action_start = cf.action_start
+    fused, sim, ext = pkg.Handle(cf), pkg.Handle(cf), pkg.Handle(cx)
+    flat = _params(fused.P, 3, 0.4)
+    assert ext.P == fused.P
+    for hh in (fused, sim, ext):
+        hh.set_params(flat)
+    nz = np.random.default_rng(1).random(E * T)
+    fused.env_reset(11); sim.env_reset(11)
+    fused.set_noise(nz); fused.collect_rollout()
+    ext.set_noise(nz)
+    for t in range(T):
+        raw, ea = ext.ext_act(sim.env_observe())
+        rew, term, trunc, tobs = sim.env_step(ea)
+        ext.ext_record(rew, term, trunc, tobs)
+    ext.ext_finish(sim.env_observe())
+    assert (ext.buffer(capi.BUF_ACTIONS) == fused.buffer(capi.BUF_ACTIONS)).all()
+    assert np.array_equal(ext.buffer(capi.BUF_FLAGS), fused.buffer(capi.BUF_FLAGS)) and (ext.buffer(capi.BUF_FLAGS) & 2).any()
+    for which, tol in ((capi.BUF_OBSERVATIONS, 1e-6), (capi.BUF_REWARDS, 0), (capi.BUF_VALUES, 2e-5), (capi.BUF_LOGPROBS, 2e-5), (capi.BUF_BOOTSTRAP, 2e-5),
+                       (capi.BUF_ADVANTAGES, 2e-4), (capi.BUF_RETURNS, 2e-4)):
+        np.testing.assert_allclose(ext.buffer(which), fused.buffer(which), atol=tol, rtol=tol)
+    for which in (capi.BUF_OBSERVATIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+        ext.set_buffer(which, fused.buffer(which))
+    perm = np.stack([np.random.default_rng(e).permutation(E * T) for e in range(2)]).astype(np.int64)
+    ext.set_permutation(perm); fused.set_permutation(perm)
+    se, sf = ext.ppo_update(), fused.ppo_update()
+    assert se.n_updates == sf.n_updates == 4 and se.loss == pytest.approx(sf.loss, rel=1e-4)
+    np.testing.assert_allclose(ext.get_params(), fused.get_params(), rtol=2e-4, atol=2e-6)
+
+
+def test_external_call_order_and_unsupported_verbs(pkg):
+    """the act / record / finish protocol is checked, the device-env verbs refuse an external handle, and nothing falls back silently"""
+    cfg = _ext_cfg(pkg, 5, 2, True, 16, 16, n_envs=3, n_steps=2, batch_size=6)
+    h = pkg.Handle(cfg)
+    h.set_params(_params(h.P, 0))
+    obs = np.zeros((3, 5), np.float32); z = np.zeros(3, np.float32); f = np.zeros(3, np.uint8)
+    with pytest.raises(pkg.DrilError):
+        h.ext_record(z, f, f)                                                        # record before act
+    h.ext_act(obs)
+    with pytest.raises(pkg.DrilError):
+        h.ext_act(obs)                                                               # act twice
+    with pytest.raises(pkg.DrilError):
+        h.ext_record(z, f, np.ones(3, np.uint8))                                     # truncated without terminal_obs
+    h.ext_record(z, f, f)
+    with pytest.raises(pkg.DrilError):
+        h.ext_finish(obs)                                                            # only 1 of 2 steps recorded
+    h.ext_act(obs); h.ext_record(z, f, f)
+    with pytest.raises(pkg.DrilError):
+        h.ext_act(obs)                                                               # rollout full
+    h.ext_finish(obs)
+    for call in (lambda: h.env_reset(0), h.env_observe, h.collect_rollout, lambda: h.train(12), lambda: h.evaluate_agent(1)):
+        with pytest.raises(pkg.DrilError) as e:
+            call()
+        assert e.value.code == pkg._capi.ERR_UNSUPPORTED
+    bad = _ext_cfg(pkg, 0, 2, True, 16, 16)
+    with pytest.raises(pkg.DrilError):
+        pkg.Handle(bad)
+    with pytest.raises(pkg.DrilError):
+        pkg.Handle(pkg._capi.default_config(pkg._capi.ENV_CARTPOLE)).ext_act(np.zeros((4, 4), np.float32))   # device-env handle
+
+
+class _PyPointEnv:
+    """a host env with the reference's AbstractEnv verbs: 2-D point, 6-dim observation, Box(-1,1)^2 action, reward = -distance to the origin"""
+
+    def __init__(self, pkg, seed):
+        self.pkg, self.rng, self.limit = pkg, np.random.default_rng(seed), 25
+        self.reset_()
+
+    def observation_space(self):
+        return self.pkg.Box(low=[-4.0] * 6, high=[4.0] * 6)
+
+    def action_space(self):
+        return self.pkg.Box(low=[-1.0, -1.0], high=[1.0, 1.0])
+
+    def reset_(self):
+        self.p = self.rng.uniform(-2, 2, 2).astype(np.float32); self.t = 0
+
+    def observe(self):
+        return np.concatenate([self.p, self.p ** 2 / 4, np.sin(self.p)]).astype(np.float32)
+
+    def act_(self, a):
+        self.p = np.clip(self.p + 0.3 * np.asarray(a, np.float32), -4, 4); self.t += 1
+        return float(-np.linalg.norm(self.p))
+
+    def terminated(self):
+        return bool(np.linalg.norm(self.p) < 0.1)
+
+    def truncated(self):
+        return self.t >= self.limit
+
+
+def test_train_on_host_envs_learns(pkg):
+    """train!(agent, env, alg, max_steps) over the caller's own Python envs (HostParallelEnv = BroadcastedParallelEnv): the mean reward per step
+    improves, statistics have the reference's keys, parameters come back to the agent"""
+    env = pkg.HostParallelEnv([_PyPointEnv(pkg, s) for s in range(16)], seed=0)
+    alg = pkg.PPO(n_steps=64, batch_size=256, epochs=6, learning_rate=1e-3, ent_coef=0.0)
+    agent = pkg.Agent(pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(48, 32), log_std_init=-0.5), alg, seed=0)
+    p0 = pkg.flatten_params(agent.train_state.parameters).copy()
+    buf = pkg.RolloutBuffer(alg.n_steps, 16, alg.gae_lambda, alg.gamma)
+    pkg.collect_rollout_(buf, agent, alg, env); r0 = float(buf.rewards.mean())
+    stats, timer = pkg.train_(agent, env, alg, 25 * 64 * 16)
+    assert len(stats["losses"]) == 25 and np.isfinite(stats["losses"]).all() and agent.gradient_updates == 25 * 6 * 4
+    pkg.collect_rollout_(buf, agent, alg, env); r1 = float(buf.rewards.mean())
+    assert r1 > r0 + 0.3, (r0, r1)
+    assert not np.array_equal(p0, pkg.flatten_params(agent.train_state.parameters))

@@ -8,14 +8,15 @@ import pytest
 import torch
 
 
-def _nets(flat, D, H, A, discrete):
+def _nets(flat, D, H, A, discrete, H2=None):
     """split the flat parameter vector (include/dril_hip.h layout) into torch tensors (out x in, column-major)"""
+    H2 = H if H2 is None else H2
     t = torch.tensor(flat, dtype=torch.float64, requires_grad=True)
     off = 0
     out = []
     for O in (A, 1):
         net = []
-        for (o, i) in ((H, D), (H, H), (O, H)):
+        for (o, i) in ((H, D), (H2, H), (O, H2)):
             W = t[off:off + o * i].reshape(i, o).T; off += o * i
             b = t[off:off + o]; off += o
             net.append((W, b))
@@ -33,7 +34,7 @@ def _mlp(net, x):
 def torch_ppo_loss(flat, cfg, obs, actions, adv, ret, old_logp, old_val, discrete, A):
     """(alg::PPO)(policy, ps, st, batch): src/algorithms/ppo.jl:365-407 written with torch ops (float64)."""
     D = obs.shape[1]
-    t, actor, critic, ls = _nets(flat, D, cfg.hidden1, A, discrete)
+    t, actor, critic, ls = _nets(flat, D, cfg.hidden1, A, discrete, cfg.hidden2)
     x = torch.tensor(obs, dtype=torch.float64)
     advt = torch.tensor(adv, dtype=torch.float64)
     if cfg.normalize_advantage:
@@ -97,6 +98,64 @@ def test_ppo_loss_and_gradient_vs_torch_autograd(oracle_mod, pkg, kind, B, varia
     assert 0.0 < stats[3] < 0.95                                  # a real fraction of ratios is clipped
     np.testing.assert_allclose(grads, tg, rtol=2e-3, atol=2e-6)
     assert np.linalg.norm(grads - tg) <= 1e-4 * np.linalg.norm(tg)
+
+
+def _ext_cfg(pkg, D, A, discrete, H1, H2):
+    c = pkg._capi.default_config(pkg._capi.ENV_EXTERNAL)
+    c.ext_obs_dim, c.ext_action_dim, c.ext_discrete, c.hidden1, c.hidden2, c.n_envs, c.n_steps = D, A, int(discrete), H1, H2, 2, 2
+    c.ext_action_low, c.ext_action_high = -1.0, 1.0
+    return c
+
+
+@pytest.mark.parametrize("D,A,discrete,H1,H2,B", [(6, 3, True, 64, 64, 100), (11, 5, False, 48, 80, 257), (33, 17, True, 20, 36, 64), (1, 1, False, 7, 5, 33)])
+def test_external_spaces_loss_and_gradient_vs_torch_autograd(oracle_mod, pkg, D, A, discrete, H1, H2, B):
+    """DRIL_ENV_EXTERNAL (host envs, any obs / action / hidden width): the oracle's loss and gradient for spaces the built-in env kinds do not
+    have — wide Categorical, multi-dimensional DiagGaussian with its log_std gradient, unequal hidden widths — against torch autograd"""
+    cfg = _ext_cfg(pkg, D, A, discrete, H1, H2); cfg.ent_coef = 0.01
+    o = oracle_mod.Oracle(cfg)
+    assert (o.D, o.A, o.discrete) == (D, A, discrete)
+    flat = (np.random.default_rng(B).standard_normal(o.P) * 0.25).astype(np.float32)
+    o.set_params(flat)
+    batch = make_batch(o, cfg, B, 3 + B, discrete, A)
+    loss, stats, grads = o.ppo_loss_grad(*batch)
+    tl, ts, tg = torch_ppo_loss(flat, cfg, *batch, discrete, A)
+    assert loss == pytest.approx(tl, rel=1e-4)
+    np.testing.assert_allclose(stats, ts, rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(grads, tg, rtol=2e-3, atol=2e-6)
+    assert np.linalg.norm(grads - tg) <= 1e-4 * np.linalg.norm(tg)
+
+
+def test_external_rollout_is_collect_trajectories(oracle_mod, pkg):
+    """pins the oracle's step-by-step host-env rollout (orc_ext_act / _record / _finish) to its collect_rollout, which the reference's buffer and
+    GAE tests pin (test/test_buffers.jl, test/test_gae.jl): an external context with CartPole's spaces, fed by a second context's CartPole
+    simulator through the env verbs, fills the same buffer — including V(terminal_observation) bootstraps and the rollout-end values"""
+    capi = pkg._capi
+    E, T = 12, 60
+    cf = capi.default_config(capi.ENV_CARTPOLE); cx = _ext_cfg(pkg, 4, 2, True, 64, 64)
+    for c in (cf, cx):
+        c.n_envs, c.n_steps, c.episode_len, c.batch_size = E, T, 16, E * T
+    cx.action_start = cf.action_start
+    full, sim, ext = oracle_mod.Oracle(cf), oracle_mod.Oracle(cf), oracle_mod.Oracle(cx)
+    assert ext.P == full.P
+    flat = (np.random.default_rng(0).standard_normal(full.P) * 0.4).astype(np.float32)
+    for o in (full, sim, ext):
+        o.set_params(flat)
+    nz = np.random.default_rng(1).random(E * T)
+    full.env_reset(5); sim.env_reset(5)
+    full.set_noise(nz); full.collect_rollout()
+    for t in range(T):
+        raw, ea = ext.ext_act(sim.env_observe(), nz[t * E:(t + 1) * E])
+        rew, term, trunc, tobs = sim.env_step(ea)
+        ext.ext_record(rew, term, trunc, tobs)
+    ext.ext_finish(sim.env_observe())
+    fl = ext.buffer(capi.BUF_FLAGS)
+    assert (fl & 1).any() and (fl & 2).any()                                          # terminations and truncations both occur
+    for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_REWARDS, capi.BUF_VALUES, capi.BUF_LOGPROBS, capi.BUF_FLAGS, capi.BUF_BOOTSTRAP,
+                  capi.BUF_ADVANTAGES, capi.BUF_RETURNS):
+        assert np.array_equal(ext.buffer(which), full.buffer(which)), which
+    lv_e, lv_f = ext.buffer(capi.BUF_LAST_VALUES), full.buffer(capi.BUF_LAST_VALUES)
+    open_end = fl[(T - 1) * E:] == 0                                                  # LAST_VALUES is read only where the last step left the trajectory open
+    assert np.array_equal(lv_e[open_end], lv_f[open_end])
 
 
 def test_grad_clip_and_adam_vs_torch(oracle_mod, pkg):
