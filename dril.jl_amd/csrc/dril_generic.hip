@@ -262,7 +262,7 @@ static size_t grad_floats_per_row(const GenericDims& d) { return (size_t)d.D + 3
 static int64_t grad_rows_max(const GenericDims& d) { return std::max<int64_t>((int64_t)(((size_t)1 << 29) / grad_floats_per_row(d)), 64); }   // <= 2 GiB of workspace per pass
 int generic_pick_slabs(const GenericDims& d, int64_t count, int Gmax) {
     if (count < 1 || Gmax < 1) return -1;
-    int64_t G = std::min<int64_t>(Gmax, std::max<int64_t>(1, (count + 8191) / 8192));
+    int64_t G = std::min<int64_t>(Gmax, std::max<int64_t>(1, (count + 511) / 512));          // >= 512 rows per slab; the weight-gradient contractions get H1*H2/1024 * G workgroups
     const int64_t need = (count + grad_rows_max(d) - 5) / (grad_rows_max(d) - 4);                     // a slab's rows (rounded up to 4) must fit one pass
     if (need > G) G = need;
     return G <= Gmax ? (int)G : -1;

@@ -281,6 +281,140 @@ function train!(agent::Agent, env::DeviceParallelEnv, alg::PPO{T}, max_steps::In
     return stats, to
 end
 
+# =============================================================================================================================
+# Host envs: ANY AbstractParallelEnv of the caller (their own Julia envs in a MultiThreadedParallelEnv / BroadcastedParallelEnv, wrapped or not)
+# with the agent on the device — DRIL_ENV_EXTERNAL (include/dril_hip.h): observations go in and actions come out once per env step
+# (dril_ext_act / dril_ext_record / dril_ext_finish); policy forward, sampling, the rollout buffer, bootstrap values, GAE and the PPO update
+# run on the GPU for any observation / action / hidden width.
+#     env = OnDevice(MultiThreadedParallelEnv([MyEnv() for _ in 1:64]))
+#     train!(agent, env, alg, max_steps)
+# =============================================================================================================================
+mutable struct OnDevice{E <: AbstractParallelEnv} <: AbstractParallelEnv
+    env::E
+    seed::UInt64
+    device::Int
+    handle::Ptr{Cvoid}
+    bound::Any
+end
+function OnDevice(env::AbstractParallelEnv; seed::Integer = 42, device::Integer = 0)
+    w = OnDevice(env, UInt64(seed), Int(device), C_NULL, nothing)
+    finalizer(e -> (e.handle != C_NULL && ccall((:dril_destroy, LIB[]), Int32, (Ptr{Cvoid},), e.handle); nothing), w)
+    return w
+end
+# the env verbs pass straight through, so every generic DRiL caller (evaluate_agent, callbacks, wrappers) keeps working on the wrapped env
+number_of_envs(w::OnDevice) = number_of_envs(w.env)
+observation_space(w::OnDevice) = observation_space(w.env)
+action_space(w::OnDevice) = action_space(w.env)
+reset!(w::OnDevice) = reset!(w.env)
+observe(w::OnDevice) = observe(w.env)
+act!(w::OnDevice, actions::AbstractVector) = act!(w.env, actions)
+DRiL.log_stats(w::OnDevice, logger::DRiL.AbstractTrainingLogger) = DRiL.log_stats(w.env, logger)
+
+function make_config(w::OnDevice, alg::PPO, hidden::Vector{Int}, log_std_init::Float32)
+    opt(x) = isnothing(x) ? (0.0f0, Int32(0)) : (Float32(x), Int32(1))
+    cvf, hcvf = opt(alg.clip_range_vf); mgn, hmgn = opt(alg.max_grad_norm); tkl, htkl = opt(alg.target_kl)
+    osp, asp = observation_space(w), action_space(w)
+    disc = asp isa Discrete
+    lo, hi = disc ? (0.0f0, 0.0f0) : (Float32(minimum(asp.low)), Float32(maximum(asp.high)))
+    uniform = !disc && all(==(lo), asp.low) && all(==(hi), asp.high)   # one (low, high) pair: ClampAdapter on the device; otherwise clamped in the rollout loop below
+    return DrilConfig(ABI_VERSION, Int32(5), number_of_envs(w), alg.n_steps, hidden[1], hidden[2], 0, Int32(0), disc ? Int32(asp.start) : Int32(1),
+        alg.gamma, alg.gae_lambda, alg.clip_range, cvf, hcvf, alg.ent_coef, alg.vf_coef, mgn, hmgn, tkl, htkl, Int32(alg.normalize_advantage),
+        alg.batch_size, alg.epochs, alg.learning_rate, 0.9f0, 0.999f0, 1.0f-5, log_std_init, 0, 0, 0, 10.0f0, 10.0f0, 0.99f0, 1.0f-8,
+        w.seed, w.device, 0, 1, 0, 0, Int32(prod(size(osp))), Int32(disc ? asp.n : prod(size(asp))), Int32(disc),
+        uniform ? lo : 0.0f0, uniform ? hi : 0.0f0, ntuple(_ -> Int32(0), 1))
+end
+function bind_agent!(w::OnDevice, agent, alg::PPO)
+    ps = agent.train_state.parameters
+    ls = haskey(ps, :log_std) ? Float32(ps.log_std[1]) : 0.0f0
+    key = (alg, hidden_dims_of(ps), ls)
+    if w.handle == C_NULL || w.bound != key
+        w.handle != C_NULL && ccall((:dril_destroy, LIB[]), Int32, (Ptr{Cvoid},), w.handle)
+        cfg = Ref(make_config(w, alg, key[2], ls)); h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:dril_create, LIB[]), Int32, (Ref{DrilConfig}, Ref{Ptr{Cvoid}}), cfg, h))
+        w.handle = h[]; w.bound = key
+    end
+    return w.handle
+end
+
+"collect_trajectories (trajectory.jl:22-78) with the envs on the host and the agent on the device; returns fps (rollout_buffer.jl:60-64)"
+function device_rollout!(w::OnDevice, alg::PPO)
+    E = number_of_envs(w); asp = action_space(w); disc = asp isa Discrete
+    D = prod(size(observation_space(w))); A = disc ? 1 : prod(size(asp))
+    obs = Matrix{Float32}(undef, D, E); tobs = zeros(Float32, D, E)
+    raw = disc ? Vector{Int32}(undef, E) : Matrix{Float32}(undef, A, E); ea = similar(raw)
+    rew = Vector{Float32}(undef, E); term = Vector{UInt8}(undef, E); trunc = Vector{UInt8}(undef, E)
+    pack!(dst, xs) = (for j in 1:E; dst[:, j] .= vec(xs[j]); end; dst)
+    t0 = time()
+    pack!(obs, observe(w.env))                                                                                     # :32
+    for _ in 1:alg.n_steps
+        GC.@preserve obs raw ea check(ccall((:dril_ext_act, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}, Ptr{Cvoid}), w.handle, obs, raw, ea), w.handle)   # :41-42
+        actions = disc ? [Int(ea[j]) for j in 1:E] : [clamp.(reshape(ea[:, j], size(asp)), asp.low, asp.high) for j in 1:E]   # per-dimension bounds too (ClampAdapter, default_adapters.jl:4-11)
+        r, te, tr, infos = act!(w.env, actions)                                                                    # :44
+        rew .= r; term .= te; trunc .= tr
+        for j in 1:E
+            tr[j] && haskey(infos[j], "terminal_observation") && (tobs[:, j] .= vec(infos[j]["terminal_observation"]))
+        end
+        GC.@preserve rew term trunc tobs check(ccall((:dril_ext_record, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float32}),
+            w.handle, rew, term, trunc, tobs), w.handle)                                                            # :46-61
+        pack!(obs, observe(w.env))                                                                                 # :45
+    end
+    GC.@preserve obs check(ccall((:dril_ext_finish, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}), w.handle, obs), w.handle)   # :65-70 + compute_advantages! + returns
+    return alg.n_steps * E / max(time() - t0, 1.0e-12)
+end
+
+function collect_rollout!(buf::RolloutBuffer, agent::Agent, alg::PPO, w::OnDevice; callbacks = nothing)
+    has_step_hooks(callbacks) && return collect_rollout!(buf, agent, alg, w.env; callbacks = callbacks)   # on_step hooks: the reference loop on the wrapped env
+    bind_agent!(w, agent, alg); push_params!(w, agent)
+    fps = device_rollout!(w, alg)
+    copy_out!(w, 0, buf.observations)
+    if action_space(w) isa Discrete
+        tmp = Vector{Int32}(undef, length(buf.rewards)); copy_out!(w, 1, tmp); buf.actions .= reshape(tmp, 1, :)
+    else
+        copy_out!(w, 1, buf.actions)
+    end
+    copy_out!(w, 2, buf.rewards); copy_out!(w, 3, buf.advantages); copy_out!(w, 4, buf.returns); copy_out!(w, 5, buf.logprobs); copy_out!(w, 6, buf.values)
+    return fps, true
+end
+
+function train!(agent::Agent, w::OnDevice, alg::PPO{T}, max_steps::Int; ad_type = nothing, callbacks = nothing) where {T}
+    has_step_hooks(callbacks) && return train!(agent, w.env, alg, max_steps; callbacks = callbacks)
+    to = TimerOutput()
+    E = number_of_envs(w)
+    @timeit to "setup" begin
+        bind_agent!(w, agent, alg); push_params!(w, agent)
+        iterations = max_steps ÷ (alg.n_steps * E)                     # ppo.jl:117
+        iterations == 0 && @warn "max_steps is less than n_steps * n_envs; there will be no training."
+    end
+    stats = NamedTuple{(:entropy_losses, :policy_losses, :value_losses, :approx_kl_divs, :clip_fractions, :losses,
+        :explained_variances, :fps, :grad_norms, :learning_rates)}(ntuple(_ -> Float32[], 10))
+    locals() = Dict{Symbol, Any}(:agent => agent, :env => w.env, :alg => alg, :max_steps => max_steps, :iterations => iterations)
+    !isnothing(callbacks) && !all(c -> DRiL.on_training_start(c, locals()), callbacks) && return nothing
+    @timeit to "training_loop" for i in 1:iterations
+        check(ccall((:dril_set_learning_rate, LIB[]), Int32, (Ptr{Cvoid}, Float32), w.handle, alg.learning_rate), w.handle)
+        push!(stats.learning_rates, alg.learning_rate)
+        !isnothing(callbacks) && !all(c -> DRiL.on_rollout_start(c, locals()), callbacks) && return nothing
+        fps = @timeit to "collect_rollout" device_rollout!(w, alg)
+        push!(stats.fps, fps); DRiL.add_step!(agent, alg.n_steps * E)
+        DRiL.increment_step!(agent.logger, alg.n_steps * E); DRiL.log_scalar!(agent.logger, "env/fps", fps)
+        DRiL.log_stats(w.env, agent.logger)
+        !isnothing(callbacks) && !all(c -> DRiL.on_rollout_end(c, locals()), callbacks) && return nothing
+        st = Ref{DrilPPOStats}()
+        @timeit to "epoch loop" check(ccall((:dril_ppo_update, LIB[]), Int32, (Ptr{Cvoid}, Ref{DrilPPOStats}), w.handle, st), w.handle)
+        s = st[]
+        push!(stats.entropy_losses, s.entropy_loss); push!(stats.policy_losses, s.policy_loss); push!(stats.value_losses, s.value_loss)
+        push!(stats.approx_kl_divs, s.approx_kl_div); push!(stats.clip_fractions, s.clip_fraction); push!(stats.losses, s.loss)
+        push!(stats.explained_variances, s.explained_variance); push!(stats.grad_norms, s.grad_norm)
+        for (k, v) in ("entropy_loss" => s.entropy_loss, "explained_variance" => s.explained_variance, "policy_loss" => s.policy_loss,
+            "value_loss" => s.value_loss, "approx_kl_div" => s.approx_kl_div, "clip_fraction" => s.clip_fraction, "loss" => s.loss,
+            "grad_norm" => s.grad_norm, "learning_rate" => alg.learning_rate)
+            DRiL.log_scalar!(agent.logger, "train/" * k, v)
+        end
+    end
+    pull_params!(w, agent)
+    !isnothing(callbacks) && !all(c -> DRiL.on_training_end(c, locals()), callbacks) && return nothing
+    return stats, to
+end
+
 # ---- normalisation statistics in the reference's JLD2 schema (normalizeWrapperEnv.jl:261-297) ----
 function norm_stats(env::DeviceParallelEnv)
     D = obs_dim(env); om = Vector{Float32}(undef, D); ov = Vector{Float32}(undef, D)
@@ -451,6 +585,6 @@ function train!(agent::Agent, env::DeviceParallelEnv, alg::DRiL.SAC{T}, max_step
     end
 end
 
-export DeviceParallelEnv
+export DeviceParallelEnv, OnDevice
 
 end # module
