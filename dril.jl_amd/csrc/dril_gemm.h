@@ -13,6 +13,7 @@ struct GemmArgs {
     long long zA, zB, zC, zBias, zAux;            // batch (blockIdx.z) strides
     int zdivB;                                    // B uses batch index z / zdivB (several nets reading one input)
     int vecA, vecB;                               // operand has unit stride along k, 16-byte aligned rows and K % 4 == 0: float4 loads
+    int vecBn;                                    // B has unit stride along n with 16-byte aligned rows: float4 runs along n (LDS-tiled kernel only)
     int ones_n;                                   // B(:, N-1) == 1 (appends the bias column to a weight-gradient contraction)
     int epi; float alpha;
 };

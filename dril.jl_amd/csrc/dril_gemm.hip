@@ -119,29 +119,55 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_kernel(GemmArgs g) {
 // sample row contiguous: 8 threads read one row's 128 B) into LDS with b128 stores and the waves read their MFMA operands back as one ds_read_b128 per
 // lane per 8 k.  The plain !SPLIT shape read every activation row straight from L2, 16 B per lane = 32 cache lines per wave instruction (56 us for
 // 512 x 512 x 4096); the next chunk's global loads are issued before the current chunk's MFMAs (register double buffer, one barrier pair per chunk).
-constexpr int kBigKc = 32, kBigStride = kBigKc + 4;
+constexpr int kBigKc = 32, kBigStride = kBigKc + 4, kBigNStride = 32 * kGemmWaves + 4;
+// Operand layouts in memory (element strides, host-checked): A is m-contiguous (a column-major weight: forward layers) or, with AK, k-contiguous
+// (the same weight read transposed: W' dz of the reverse pass); B is k-contiguous (one activation row per sample) or, with BN, n-contiguous (the
+// activation operand of a weight gradient, contraction over samples; its last column may be the synthetic ones column, g.ones_n).  Whatever the
+// layout, every global load instruction of a wave covers whole 64..128-byte runs and the chunk lands in LDS so that the MFMA operand reads are
+// conflict-free: k-contiguous rows [n][k + 4 pad] read back as ds_read_b128, or — BN — the chunk stays [k][n + 4 pad] and is read as 4 x ds_read_b32.
+template <bool AK, bool BN>
 __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_big_kernel(GemmArgs g) {
     __shared__ float red[kGemmWaves][16][kRedStride];
     __shared__ __attribute__((aligned(16))) float As[32][kBigStride];
-    __shared__ __attribute__((aligned(16))) float Xs[32 * kGemmWaves][kBigStride];
+    __shared__ __attribute__((aligned(16))) float Xs[32 * kGemmWaves * kBigStride];                  // [256][36] (k-contiguous B) or [32][260] (BN)
+    static_assert(32 * kGemmWaves * kBigStride >= kBigKc * kBigNStride, "the n-major chunk image must fit the same LDS block");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5, z = blockIdx.z;
     const float* __restrict__ A = g.A + (size_t)z * g.zA;
     const float* __restrict__ B = g.B + (size_t)(z / g.zdivB) * g.zB;
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32 * kGemmWaves;
-    // loader roles: X chunk = 256 rows x 8 float4 -> 4 float4 per thread; A chunk = 32 k x 32 m floats -> 2 floats per thread
+    // loader roles.  B k-contiguous: 256 rows x 8 float4 -> 4 float4 per thread (row i >> 3, k (i & 7) * 4).  BN: 32 k-rows x 64 float4 along n -> 4 per
+    // thread (k = (tid >> 6) + 8 j, n = (tid & 63) * 4).  A m-contiguous: 32 k x 32 m floats, 2 per thread (m = tid & 31, k = tid >> 5 and + 16).
+    // AK: 32 m-rows x 16 float2 along k, 1 float2 per thread (m = tid >> 4, k = (tid & 15) * 2).
     int xr[4], xk[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int i = tid + 512 * j; xr[j] = i >> 3; xk[j] = (i & 7) * 4; }
-    const int am = tid & 31, ak = tid >> 5;                                      // k = ak and ak + 16
+    for (int j = 0; j < 4; ++j) { const int i = tid + 512 * j; if (BN) { xr[j] = (tid >> 6) + 8 * j; xk[j] = (tid & 63) * 4; } else { xr[j] = i >> 3; xk[j] = (i & 7) * 4; } }
+    const int am = AK ? tid >> 4 : tid & 31, ak = AK ? (tid & 15) * 2 : tid >> 5;
+    const int n_real = g.N - (g.ones_n ? 1 : 0);                                                       // columns that exist in memory
     float4 xv[4]; float av[2];
     auto gload = [&](int kc) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + xr[j];
-            xv[j] = n < g.N ? *reinterpret_cast<const float4*>(B + (size_t)n * g.sBn + kc + xk[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+            if (BN) {
+                const int n = n0 + xk[j]; const float* row = B + (size_t)(kc + xr[j]) * g.sBk;
+                if (kc + xr[j] >= g.K) xv[j] = make_float4(0.f, 0.f, 0.f, 0.f);                       // ragged last chunk
+                else if (g.vecBn && n + 3 < n_real) xv[j] = *reinterpret_cast<const float4*>(row + n);
+                else {
+                    float t[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { const int mg = m0 + am; av[j] = mg < g.M ? A[(size_t)mg + (size_t)(kc + ak + 16 * j) * g.sAk] : 0.f; }
+                    for (int e = 0; e < 4; ++e) t[e] = (n + e < n_real) ? row[n + e] : ((g.ones_n && n + e == n_real) ? 1.0f : 0.0f);
+                    xv[j] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            } else {
+                const int n = n0 + xr[j];
+                xv[j] = (n < g.N && kc + xk[j] < g.K) ? *reinterpret_cast<const float4*>(B + (size_t)n * g.sBn + kc + xk[j]) : make_float4(0.f, 0.f, 0.f, 0.f);   // K % 4 == 0 (vecB)
+            }
+        }
+        const int mg = m0 + am;
+        if (AK) { av[0] = (mg < g.M && kc + ak < g.K) ? A[(size_t)mg * g.sAm + kc + ak] : 0.f; av[1] = (mg < g.M && kc + ak + 1 < g.K) ? A[(size_t)mg * g.sAm + kc + ak + 1] : 0.f; }
+        else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) av[j] = (mg < g.M && kc + ak + 16 * j < g.K) ? A[(size_t)mg + (size_t)(kc + ak + 16 * j) * g.sAk] : 0.f;
+        }
     };
     f32x16 acc;
 #pragma unroll
@@ -149,15 +175,22 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_big_kernel(GemmArgs 
     gload(0);
     for (int kc = 0; kc < g.K; kc += kBigKc) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&Xs[xr[j]][xk[j]]) = xv[j];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&Xs[BN ? xr[j] * kBigNStride + xk[j] : xr[j] * kBigStride + xk[j]]) = xv[j];
+        if (AK) { As[am][ak] = av[0]; As[am][ak + 1] = av[1]; }
+        else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) As[am][ak + 16 * j] = av[j];
+            for (int j = 0; j < 2; ++j) As[am][ak + 16 * j] = av[j];
+        }
         __syncthreads();
         if (kc + kBigKc < g.K) gload(kc + kBigKc);                               // next chunk in flight under this chunk's MFMAs
 #pragma unroll
         for (int q = 0; q < kBigKc / 8; ++q) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(&As[c][8 * q + 4 * h]);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(&Xs[32 * wave + c][8 * q + 4 * h]);
+            f32x4 b;
+            if (BN) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = Xs[(8 * q + 4 * h + t) * kBigNStride + 32 * wave + c];
+            } else b = *reinterpret_cast<const f32x4*>(&Xs[(32 * wave + c) * kBigStride + 8 * q + 4 * h]);
             acc = mfma32(a[0], b[0], acc); acc = mfma32(a[1], b[1], acc); acc = mfma32(a[2], b[2], acc); acc = mfma32(a[3], b[3], acc);
         }
         __syncthreads();
@@ -190,6 +223,7 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 bool gemm_prepare(GemmArgs& g) {
     g.vecA = g.sAk == 1 && g.sAm % 4 == 0 && g.K % 4 == 0 && aligned16(g.A) && g.zA % 4 == 0;
     g.vecB = !g.ones_n && g.sBk == 1 && g.sBn % 4 == 0 && g.K % 4 == 0 && aligned16(g.B) && g.zB % 4 == 0;
+    g.vecBn = g.sBn == 1 && g.sBk != 1 && g.sBk % 4 == 0 && aligned16(g.B) && g.zB % 4 == 0;        // n-contiguous operand: float4 runs along n (big kernel, BN)
     if (g.zdivB <= 0) g.zdivB = 1;
     return g.M > 0 && g.N > 0 && g.K > 0;
 }
@@ -210,7 +244,14 @@ hipError_t launch_gemm(GemmArgs g, int Z, hipStream_t s) {
     if (!gemm_prepare(g)) return hipErrorInvalidValue;
     const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
     if ((tn + kGemmWaves - 1) / kGemmWaves > 65535 || Z > 65535) return hipErrorInvalidValue;
-    if ((long long)tm * tn * Z >= 2048 && g.sAm == 1 && g.sBk == 1 && g.vecB && g.K % kBigKc == 0 && !g.ones_n) hipLaunchKernelGGL(sac_gemm_big_kernel, dim3(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), dim3(64 * kGemmWaves), 0, s, g);
+    const bool many = (long long)tm * tn * Z >= 2048 && g.K >= kBigKc;
+    const bool a_m = g.sAm == 1, a_k = !a_m && g.sAk == 1;                                             // A m-contiguous / k-contiguous
+    const bool b_k = g.sBk == 1 && g.vecB && !g.ones_n, b_n = !b_k && g.sBn == 1 && g.sBk != 1;        // B k-contiguous (float4 rows) / n-contiguous
+    const dim3 bgrid(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), bblock(64 * kGemmWaves);
+    if (many && a_m && b_k) hipLaunchKernelGGL((sac_gemm_big_kernel<false, false>), bgrid, bblock, 0, s, g);
+    else if (many && a_k && b_k) hipLaunchKernelGGL((sac_gemm_big_kernel<true, false>), bgrid, bblock, 0, s, g);
+    else if (many && a_m && b_n) hipLaunchKernelGGL((sac_gemm_big_kernel<false, true>), bgrid, bblock, 0, s, g);
+    else if (many && a_k && b_n) hipLaunchKernelGGL((sac_gemm_big_kernel<true, true>), bgrid, bblock, 0, s, g);
     else if ((long long)tm * tn * Z >= 2048) hipLaunchKernelGGL(sac_gemm_kernel<false>, dim3(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), dim3(64 * kGemmWaves), 0, s, g);
     else hipLaunchKernelGGL(sac_gemm_kernel<true>, dim3(tm, tn, Z), dim3(64 * kGemmWaves), 0, s, g);
     return hipGetLastError();

@@ -263,7 +263,7 @@ static int64_t grad_rows_max(const GenericDims& d) { return std::max<int64_t>((i
 int generic_pick_slabs(const GenericDims& d, int64_t count, int Gmax) {
     if (count < 1 || Gmax < 1) return -1;
     int64_t G = std::min<int64_t>(Gmax, std::max<int64_t>(1, (count + 511) / 512));          // >= 512 rows per slab; the weight-gradient contractions get H1*H2/1024 * G workgroups
-    const int64_t need = (count + grad_rows_max(d) - 5) / (grad_rows_max(d) - 4);                     // a slab's rows (rounded up to 4) must fit one pass
+    const int64_t need = (count + grad_rows_max(d) - 33) / (grad_rows_max(d) - 32);                   // a slab's rows (rounded up to 32) must fit one pass
     if (need > G) G = need;
     return G <= Gmax ? (int)G : -1;
 }
@@ -297,7 +297,7 @@ hipError_t generic_ppo_grad(const GenericDims& d, const GradArgs& a, GenericWs& 
     const int G = a.G;
     const size_t per_row = grad_floats_per_row(d);
     const int64_t Rmax = grad_rows_max(d);
-    int64_t Cr = (a.count + G - 1) / G; Cr = (Cr + 3) / 4 * 4;                                                  // rows per slab
+    int64_t Cr = (a.count + G - 1) / G; Cr = (Cr + 31) / 32 * 32;                                                // rows per slab (whole 32-deep contraction chunks)
     int Gp = (int)std::max<int64_t>(1, std::min<int64_t>(G, Rmax / Cr));                                       // slabs per pass
     if (Cr > Rmax) return hipErrorInvalidValue;                                                                 // the caller sizes G so that a chunk fits
     const int64_t R = (int64_t)Gp * Cr;

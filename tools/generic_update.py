@@ -50,6 +50,11 @@ def timed(h, label, fl):
     return dt
 
 
+import os
+if os.environ.get("GENERIC_SHAPE"):   # "D,A,discrete,H1,H2": only this shape (for rocprofv3 runs)
+    D, A, disc, H1, H2 = (int(x) for x in os.environ["GENERIC_SHAPE"].split(","))
+    timed(pkg.Handle(ext_cfg(D, A, bool(disc), H1, H2)), f"generic obs [{D}] {'Discrete' if disc else 'Box'}({A}) hidden [{H1},{H2}]", flops(D, A, H1, H2))
+    sys.exit(0)
 cf = capi.default_config(capi.ENV_CARTPOLE)
 cf.n_envs, cf.n_steps, cf.batch_size, cf.epochs, cf.profile_events = E, T, N // 32, 10, 1
 a = timed(pkg.Handle(cf), "fused   CartPole [4] Discrete(2) hidden [64,64]", flops(4, 2, 64, 64))
