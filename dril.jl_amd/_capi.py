@@ -140,6 +140,7 @@ _SIG = {
     "dril_monitor_get_stats": (C.c_int32, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "dril_policy_forward": (C.c_int32, [_P, _P, C.c_int64, _P, _P, _P, _P]),
     "dril_evaluate_actions": (C.c_int32, [_P, _P, _P, C.c_int64, _P, _P, _P]),
+    "dril_predict_actions": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _P, _P]),
     "dril_predict_values": (C.c_int32, [_P, _P, C.c_int64, _P]),
     "dril_ext_act": (C.c_int32, [_P, _P, _P, _P]),
     "dril_ext_record": (C.c_int32, [_P, _P, _P, _P, _P]),

@@ -554,7 +554,7 @@ DRIL_EXPORT int32_t dril_monitor_get_stats(dril_handle* h, float* ep_rew_mean, f
 // ---- policy on host batches ----------------------------------------------------------------------
 namespace {
 int policy_host(dril_handle* h, const float* obs, int64_t B, const void* noise, void* actions, bool actions_in, float* values, float* logp,
-                float* entropy, int mode) {
+                float* entropy, int mode, int deterministic = 0) {
     if (!obs || B < 1) return fail(h, DRIL_ERR_INVALID_ARG, "policy: null obs or batch < 1");
     float *d_obs = nullptr, *d_val = nullptr, *d_lp = nullptr, *d_ent = nullptr; void *d_noise = nullptr, *d_act = nullptr;
     const size_t ab = (size_t)B * act_bytes_per(h), nb = (size_t)B * (h->discrete ? 8 : 4 * (size_t)h->A);
@@ -568,6 +568,7 @@ int policy_host(dril_handle* h, const float* obs, int64_t B, const void* noise, 
     if (actions_in) PCHK(hipMemcpyAsync(d_act, actions, ab, hipMemcpyHostToDevice, h->stream));
     { int rcw = ensure_wimg(h); if (rcw) { cleanup(); return rcw; } }
     PolicyArgs a = policy_args(h, d_obs, B, d_noise, d_act, d_val, d_lp, d_ent, mode);
+    a.deterministic = deterministic;
     PCHK(run_policy(h, a));
     h->policy_calls += 1;
     if (values) PCHK(hipMemcpyAsync(values, d_val, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
@@ -586,6 +587,10 @@ DRIL_EXPORT int32_t dril_policy_forward(dril_handle* h, const float* obs, int64_
 DRIL_EXPORT int32_t dril_evaluate_actions(dril_handle* h, const float* obs, const void* actions, int64_t batch, float* values, float* logprobs, float* entropy) {
     NEED(h); if (!actions) return fail(h, DRIL_ERR_INVALID_ARG, "null actions");
     return policy_host(h, obs, batch, nullptr, const_cast<void*>(actions), true, values, logprobs, entropy, 1);
+}
+DRIL_EXPORT int32_t dril_predict_actions(dril_handle* h, const float* obs, int64_t batch, int32_t deterministic, const void* noise, void* actions) {
+    NEED(h); if (!actions) return fail(h, DRIL_ERR_INVALID_ARG, "null actions");
+    return policy_host(h, obs, batch, deterministic ? nullptr : noise, actions, false, nullptr, nullptr, nullptr, 0, deterministic ? 1 : 0);
 }
 DRIL_EXPORT int32_t dril_predict_values(dril_handle* h, const float* obs, int64_t batch, float* values) {
     NEED(h); return policy_host(h, obs, batch, nullptr, nullptr, false, values, nullptr, nullptr, 2);

@@ -456,6 +456,15 @@ class Handle:
         self._chk(self.lib.dril_evaluate_actions(self._h, self._p(obs), self._p(actions), B, self._p(val), self._p(lp), self._p(ent)))
         return val, lp, ent
 
+    def predict_actions(self, obs: np.ndarray, deterministic: bool = False, noise: Optional[np.ndarray] = None) -> np.ndarray:
+        obs = np.ascontiguousarray(obs, np.float32)
+        B = obs.shape[0]
+        act = np.empty(B, np.int32) if self.discrete else np.empty((B, self.A), np.float32)
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, np.float64 if self.discrete else np.float32)
+        self._chk(self.lib.dril_predict_actions(self._h, self._p(obs), B, int(deterministic), self._p(noise), self._p(act)))
+        return act
+
     def predict_values(self, obs: np.ndarray) -> np.ndarray:
         obs = np.ascontiguousarray(obs, np.float32)
         val = np.empty(obs.shape[0], np.float32)
@@ -884,7 +893,27 @@ def evaluate_agent(agent: Agent, env: DeviceParallelEnv, n_eval_episodes: int = 
     """evaluate_agent(agent, env; ...) (src/evaluation.jl:54-143)."""
     h = env.bind(agent.alg, agent.layer)
     h.set_params(flatten_params(agent.train_state.parameters))
-    stats, er, el = h.evaluate_agent(n_eval_episodes, deterministic)
+    if isinstance(env, HostParallelEnv):       # the reference loop on the caller's envs, predict_actions on the device (evaluation.jl:86-125)
+        asp = env.action_space()
+        er, el = [], []
+        cur_r, cur_l = np.zeros(env.n_envs, np.float32), np.zeros(env.n_envs, np.int64)
+        env.reset_()
+        obs = np.stack(env.observe())
+        while len(er) < n_eval_episodes:
+            raw = h.predict_actions(obs, deterministic)
+            acts = list(raw) if h.discrete else [np.clip(a, np.asarray(asp.low, np.float32), np.asarray(asp.high, np.float32)).reshape(asp.shape) for a in raw]
+            rew, term, trunc, _ = env.act_(acts)
+            cur_r += rew; cur_l += 1
+            obs = np.stack(env.observe())
+            for i in np.nonzero(term | trunc)[0]:
+                if len(er) < n_eval_episodes:
+                    er.append(float(cur_r[i])); el.append(int(cur_l[i]))
+                    cur_r[i] = 0; cur_l[i] = 0
+        er, el = np.asarray(er, np.float32), np.asarray(el, np.int64)
+        sd = lambda x: float(np.std(x, ddof=1)) if len(x) > 1 else float("nan")
+        stats = {"mean_reward": float(er.mean()), "std_reward": sd(er), "mean_length": float(el.mean()), "std_length": sd(el)}
+    else:
+        stats, er, el = h.evaluate_agent(n_eval_episodes, deterministic)
     if reward_threshold is not None and stats["mean_reward"] < reward_threshold:
         raise RuntimeError(f"Mean reward below threshold: {stats['mean_reward']:.2f} < {reward_threshold}")   # evaluation.jl:131-135
     return {k: stats[k] for k in ("mean_reward", "std_reward", "mean_length", "std_length")} if return_stats else (er, el)

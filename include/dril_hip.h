@@ -208,6 +208,10 @@ int32_t dril_policy_forward(dril_handle* h, const float* obs, int64_t batch, con
 /* evaluate_actions(layer, obs, actions, ps, st): layer_methods.jl:28-55 */
 int32_t dril_evaluate_actions(dril_handle* h, const float* obs, const void* actions, int64_t batch,
                               float* values, float* logprobs, float* entropy);
+/* predict_actions(layer, obs, ps, st; deterministic, rng): layer_methods.jl:3-26 — mode(d) when deterministic (argmax of the Categorical,
+ * categorical.jl:42-44; the mean of the DiagGaussian, diagGaussian.jl:45-47), else rand(d) with `noise` as in dril_policy_forward.
+ * actions are RAW policy actions (evaluate_agent passes them through to_env, evaluation.jl:92-93) */
+int32_t dril_predict_actions(dril_handle* h, const float* obs, int64_t batch, int32_t deterministic, const void* noise, void* actions);
 /* predict_values(layer, obs, ps, st): layer_methods.jl:57-61 */
 int32_t dril_predict_values(dril_handle* h, const float* obs, int64_t batch, float* values);
 

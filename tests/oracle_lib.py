@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
         L.orc_policy_forward.argtypes = [_P, _P, C.c_int64, _P, _P, _P, _P]
         L.orc_evaluate_actions.argtypes = [_P, _P, _P, C.c_int64, _P, _P, _P]
         L.orc_predict_values.argtypes = [_P, _P, C.c_int64, _P]
+        L.orc_predict_actions.argtypes = [_P, _P, C.c_int64, C.c_int32, _P, _P]
         L.orc_collect_rollout.argtypes = [_P, C.POINTER(C.c_double)]
         L.orc_debug_set_noise.argtypes = [_P, _P, C.c_size_t]
         L.orc_buffer_copy_out.argtypes = [_P, C.c_int32, _P, C.c_size_t]
@@ -187,6 +188,15 @@ class Oracle:
         val, lp, ent = (np.empty(B, np.float32) for _ in range(3))
         self.L.orc_evaluate_actions(self._h, _p(obs), _p(actions), B, _p(val), _p(lp), _p(ent))
         return val, lp, ent
+
+    def predict_actions(self, obs, deterministic=False, noise=None):
+        obs = np.ascontiguousarray(obs, np.float32)
+        B = obs.shape[0]
+        act = np.empty(B, np.int32) if self.discrete else np.empty((B, self.A), np.float32)
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, np.float64 if self.discrete else np.float32)
+        assert self.L.orc_predict_actions(self._h, _p(obs), B, int(deterministic), _p(noise), _p(act)) == 0
+        return act
 
     def predict_values(self, obs):
         obs = np.ascontiguousarray(obs, np.float32)

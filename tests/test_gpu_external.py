@@ -53,6 +53,13 @@ def test_generic_forward_evaluate_predict(pkg, oracle_mod, D, A, discrete, H1, H
         np.testing.assert_allclose(ve, vo2, atol=5e-5, rtol=5e-5); np.testing.assert_allclose(le, lo2, atol=3e-4, rtol=3e-4)
         np.testing.assert_allclose(ee, eo2, atol=1e-4, rtol=1e-4)
         np.testing.assert_allclose(h.predict_values(obs), vo, atol=5e-5, rtol=5e-5)
+        # predict_actions(...; deterministic) (layer_methods.jl:3-26): mode(d) / rand(d)
+        dh, do = h.predict_actions(obs, True), o.predict_actions(obs, True)
+        sh_, so_ = h.predict_actions(obs, False, nz), o.predict_actions(obs, False, nz)
+        if discrete:
+            assert (dh == do).mean() >= 0.99 and (sh_ == ah).all() and (so_ == ao).all()
+        else:
+            np.testing.assert_allclose(dh, do, atol=5e-5, rtol=5e-5); np.testing.assert_allclose(sh_, ah, atol=0, rtol=0)
 
 
 @pytest.mark.parametrize("variant", ["default", "ent_vfclip", "no_norm"])
@@ -276,3 +283,7 @@ def test_train_on_host_envs_learns(pkg):
     pkg.collect_rollout_(buf, agent, alg, env); r1 = float(buf.rewards.mean())
     assert r1 > r0 + 0.3, (r0, r1)
     assert not np.array_equal(p0, pkg.flatten_params(agent.train_state.parameters))
+    ev = pkg.evaluate_agent(agent, env, n_eval_episodes=12, deterministic=True)        # evaluation.jl:54-143 on the host envs, mode(d) from the device
+    assert set(ev) == {"mean_reward", "std_reward", "mean_length", "std_length"} and 1 <= ev["mean_length"] <= 25 and ev["mean_reward"] < 0
+    er, el = pkg.evaluate_agent(agent, env, n_eval_episodes=5, return_stats=False)
+    assert len(er) == len(el) == 5

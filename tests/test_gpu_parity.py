@@ -109,6 +109,12 @@ def test_policy_forward_evaluate_predict(pkg, oracle_mod, kind, B):
     np.testing.assert_allclose(le, lo2, atol=1e-4 if kind else 2e-5, rtol=1e-4)
     np.testing.assert_allclose(ee, eo2, atol=2e-5, rtol=2e-5)
     np.testing.assert_allclose(h.predict_values(obs), vo, atol=2e-5, rtol=2e-5)
+    # predict_actions(layer, obs, ps, st; deterministic) (layer_methods.jl:3-26): mode(d) = argmax / mean, rand(d) = the sampled action above
+    dh, do = h.predict_actions(obs, True), o.predict_actions(obs, True)
+    if h.discrete:
+        assert (dh == do).mean() >= 0.99 and np.array_equal(h.predict_actions(obs, False, noise), ah)
+    else:
+        np.testing.assert_allclose(dh, do, atol=2e-5, rtol=2e-5); np.testing.assert_allclose(h.predict_actions(obs, False, noise), ah, atol=0, rtol=0)
     # forward vs evaluate self-consistency, test/test_policies.jl:127-145
     np.testing.assert_allclose(h.evaluate_actions(obs, ah)[1], lh, atol=1e-5, rtol=1e-5)
 
