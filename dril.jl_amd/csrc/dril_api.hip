@@ -90,6 +90,7 @@ struct dril_handle {
     int grad_stagger = 0;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
     bool external = false; GenericDims gd{}; GenericWs gws; int ext_t = 0; bool ext_acted = false;   // DRIL_ENV_EXTERNAL: host envs, generic kernels
+    float* ext_stage_rew = nullptr; uint8_t* ext_stage_flags = nullptr;   // pinned [T][E] staging: dril_ext_record returns without draining the stream
     void* comm = nullptr;
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
     double prof_ms[DRIL_K_COUNT] = {0}; int64_t prof_n[DRIL_K_COUNT] = {0};
@@ -398,6 +399,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(dmalloc(&h->ret, N)); CCHK(dmalloc(&h->logp, N)); CCHK(dmalloc(&h->val, N)); CCHK(dmalloc(&h->boot, N)); CCHK(dmalloc(&h->flags, N));
     CCHK(dmalloc(&h->last_values, E));
     if (!ext && !std::getenv("DRIL_NO_RECORDS")) CCHK(dmalloc(&h->rec, 2 * N));
+    if (ext) { CCHK(hipHostMalloc((void**)&h->ext_stage_rew, N * 4)); CCHK(hipHostMalloc((void**)&h->ext_stage_flags, N)); }
     if (cfg->monitor_window > 0) {
         const size_t W = cfg->monitor_window;
         CCHK(dmalloc(&h->mon_cur_ret, E)); CCHK(dmalloc(&h->mon_cur_len, E)); CCHK(dmalloc(&h->ep_ret, N)); CCHK(dmalloc(&h->ep_len, N));
@@ -434,6 +436,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     generic_ws_free(h->gws);
+    if (h->ext_stage_rew) (void)hipHostFree(h->ext_stage_rew); if (h->ext_stage_flags) (void)hipHostFree(h->ext_stage_flags);
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
                     h->flags, h->last_values, h->noise_dev, h->perm_dev, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
@@ -694,9 +697,10 @@ DRIL_EXPORT int32_t dril_ext_act(dril_handle* h, const float* obs, void* raw_act
     PolicyArgs p = policy_args(h, h->obs + k * D, (int64_t)E, nz, (char*)h->act + k * ab, h->val + k, h->logp + k, nullptr, 0);     // get_action_and_values :41; raw action stored :48
     HIPCHK(h, run_policy(h, p));
     h->policy_calls += 1;
-    if (raw_actions) HIPCHK(h, hipMemcpyAsync(raw_actions, (char*)h->act + k * ab, E * ab, hipMemcpyDeviceToHost, h->stream));
-    if (env_actions) HIPCHK(h, hipMemcpyAsync(env_actions, (char*)h->act + k * ab, E * ab, hipMemcpyDeviceToHost, h->stream));
+    void* first = raw_actions ? raw_actions : env_actions;                             // one device-to-host copy; the second output is a host copy of it
+    if (first) HIPCHK(h, hipMemcpyAsync(first, (char*)h->act + k * ab, E * ab, hipMemcpyDeviceToHost, h->stream));
     int rc = sync(h); if (rc) return rc;
+    if (raw_actions && env_actions) std::memcpy(env_actions, raw_actions, E * ab);
     if (env_actions && !h->discrete && h->cfg.ext_action_low < h->cfg.ext_action_high) {                                  // to_env(ClampAdapter) :42, default_adapters.jl:4-11; E * A floats, on the host
         float* a = (float*)env_actions; const float lo = h->cfg.ext_action_low, hi = h->cfg.ext_action_high;
         for (size_t i = 0; i < E * A; ++i) a[i] = a[i] < lo ? lo : (a[i] > hi ? hi : a[i]);
@@ -710,28 +714,28 @@ DRIL_EXPORT int32_t dril_ext_record(dril_handle* h, const float* rewards, const 
     if (!rewards || !terminated || !truncated) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ext_record: null rewards / terminated / truncated");
     if (!h->ext_acted) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ext_record without a preceding dril_ext_act");
     const size_t E = h->cfg.n_envs, D = h->D, k = (size_t)h->ext_t * E;
-    std::vector<uint8_t> fl(E); std::vector<int> tr;
+    float* srew = h->ext_stage_rew + k; uint8_t* fl = h->ext_stage_flags + k;     // this step's slot of the pinned staging area: not reused before the next rollout
+    std::vector<int> tr;
     for (size_t e = 0; e < E; ++e) { fl[e] = (uint8_t)((terminated[e] ? 1 : 0) | (truncated[e] ? 2 : 0)); if (truncated[e]) tr.push_back((int)e); }
     if (!tr.empty() && !terminal_obs) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ext_record: truncated envs need terminal_obs (infos[i][\"terminal_observation\"], multithreadedParallelEnv.jl:64-66)");
-    HIPCHK(h, hipMemcpyAsync(h->rew + k, rewards, E * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->flags + k, fl.data(), E, hipMemcpyHostToDevice, h->stream));
+    std::memcpy(srew, rewards, E * 4);
+    HIPCHK(h, hipMemcpyAsync(h->rew + k, srew, E * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->flags + k, fl, E, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->boot + k, 0, E * 4, h->stream));
-    std::vector<float> tobs, bv;
     if (!tr.empty()) {                                                                // V(terminal_observation) of the truncated envs only, trajectory.jl:57-61
-        const size_t n = tr.size(); tobs.resize(n * D); bv.resize(n);
+        const size_t n = tr.size();
+        std::vector<float> tobs(n * D), bv(n), row(E, 0.f);
         for (size_t j = 0; j < n; ++j) std::memcpy(&tobs[j * D], terminal_obs + (size_t)tr[j] * D, D * 4);
         HIPCHK(h, hipMemcpyAsync(h->e_tobs, tobs.data(), n * D * 4, hipMemcpyHostToDevice, h->stream));
         PolicyArgs p = policy_args(h, h->e_tobs, (int64_t)n, nullptr, nullptr, h->e_rew, nullptr, nullptr, 2);
         HIPCHK(h, run_policy(h, p));
         HIPCHK(h, hipMemcpyAsync(bv.data(), h->e_rew, n * 4, hipMemcpyDeviceToHost, h->stream));
-    }
-    int rc = sync(h); if (rc) return rc;                                              // fl / tobs are host temporaries: drain before they go out of scope
-    if (!tr.empty()) {
-        std::vector<float> row(E, 0.f);
-        for (size_t j = 0; j < tr.size(); ++j) row[tr[j]] = bv[j];
+        int rc = sync(h); if (rc) return rc;                                          // host temporaries: drain before they go out of scope
+        for (size_t j = 0; j < n; ++j) row[tr[j]] = bv[j];
         HIPCHK(h, hipMemcpyAsync(h->boot + k, row.data(), E * 4, hipMemcpyHostToDevice, h->stream));
         rc = sync(h); if (rc) return rc;
     }
+    // no truncation: nothing to wait for — the copies read the pinned slot and complete behind the next dril_ext_act
     h->ext_t += 1; h->ext_acted = false;
     return DRIL_OK;
 }

@@ -46,6 +46,28 @@ hipError_t mlp_forward(const float* P, NetOff off, int in, int H1, int H2, int O
     return launch_gemm(g, 1, s);
 }
 
+// both nets of the ActorCriticLayer on the same rows: their first two layers have the same shapes, so each is ONE launch with blockIdx.z = net
+// (h1 / h2 hold the actor's activations followed by the critic's, n * H floats apart); the output layers differ in width and share a launch
+// through the pair kernel while the batch is small.  Halves the launch count of a rollout step / small minibatch (latency-bound there).
+hipError_t mlp_forward_both(const float* P, NetOff actor, NetOff critic, int in, int H1, int H2, int O, const float* X, int n, float* h1, float* h2,
+                            float* out, float* v, hipStream_t s) {
+    const long long zP = (long long)critic.w1 - actor.w1;                           // same layout in both nets up to the output layer
+    GemmArgs g = gemm_args();
+    g.A = P + actor.w1; g.sAm = 1; g.sAk = H1; g.zA = zP; g.B = X; g.sBk = 1; g.sBn = in; g.zB = 0; g.C = h1; g.sCm = 1; g.sCn = H1; g.zC = (long long)n * H1;
+    g.bias = P + actor.b1; g.zBias = zP; g.M = H1; g.N = n; g.K = in; g.epi = EPI_TANH;
+    hipError_t e = launch_gemm(g, 2, s); if (e != hipSuccess) return e;
+    g = gemm_args();
+    g.A = P + actor.w2; g.sAm = 1; g.sAk = H2; g.zA = zP; g.B = h1; g.sBk = 1; g.sBn = H1; g.zB = (long long)n * H1; g.C = h2; g.sCm = 1; g.sCn = H2; g.zC = (long long)n * H2;
+    g.bias = P + actor.b2; g.zBias = zP; g.M = H2; g.N = n; g.K = H1; g.epi = EPI_TANH;
+    e = launch_gemm(g, 2, s); if (e != hipSuccess) return e;
+    GemmArgs a = gemm_args(), c = gemm_args();
+    a.A = P + actor.w3; a.sAm = 1; a.sAk = O; a.B = h2; a.sBk = 1; a.sBn = H2; a.C = out; a.sCm = 1; a.sCn = O; a.bias = P + actor.b3; a.M = O; a.N = n; a.K = H2;
+    c.A = P + critic.w3; c.sAm = 1; c.sAk = 1; c.B = h2 + (size_t)n * H2; c.sBk = 1; c.sBn = H2; c.C = v; c.sCm = 1; c.sCn = 1; c.bias = P + critic.b3; c.M = 1; c.N = n; c.K = H2;
+    if (n <= 8192) return launch_gemm_pair(a, 1, c, 1, s);
+    e = launch_gemm(a, 1, s); if (e != hipSuccess) return e;
+    return launch_gemm(c, 1, s);
+}
+
 // ---- per-sample distribution math (runtime action width) ------------------------------------------------------------------------
 // Lux.softmax statistics of one logit row: max and sum(exp(z - max)); p_i = exp(z_i - m) / s (layer_forward.jl:141-149)
 __device__ inline void softmax_stats(const float* z, int A, float& m, float& s) {
@@ -224,29 +246,44 @@ __global__ __launch_bounds__(256) void generic_loss_head_kernel(LossHeadArgs g) 
     }
 }
 
-// reverse pass of one net over R = G * Cr rows: data gradients over all rows at once, parameter gradients per row chunk straight into the slabs
-hipError_t mlp_backward(const float* P, NetOff off, int in, int H1, int H2, int O, const float* X, const float* h1, const float* h2, const float* dOut,
-                        float* dz2, float* dz1, int64_t R, int Cr, int G, float* slabs, int slab_stride, hipStream_t s) {
+// reverse pass of one net over R = G * Cr rows: data gradients over all rows at once, parameter gradients per row chunk straight into the slabs.
+// The five contractions of a net, in dependency order: [dW3|db3], dz2, [dW2|db2], dz1, [dW1|db1]
+struct BackwardPlan { GemmArgs g[5]; int Z[5]; };
+BackwardPlan plan_backward(const float* P, NetOff off, int in, int H1, int H2, int O, const float* X, const float* h1, const float* h2, const float* dOut,
+                           float* dz2, float* dz1, int64_t R, int Cr, int G, float* slabs, int slab_stride) {
     const int base = off.w1;                                                         // slab offsets are relative to the net's first parameter
-    hipError_t e;
+    BackwardPlan p;
     GemmArgs w = gemm_args();                                                        // [dW3 | db3] = dOut . [h2' | 1]   (b sits right behind the column-major W)
     w.A = dOut; w.sAm = 1; w.sAk = O; w.zA = (long long)Cr * O; w.B = h2; w.sBk = H2; w.sBn = 1; w.zB = (long long)Cr * H2; w.ones_n = 1;
     w.C = slabs + (off.w3 - base); w.sCm = 1; w.sCn = O; w.zC = slab_stride; w.M = O; w.N = H2 + 1; w.K = Cr;
-    e = launch_gemm(w, G, s); if (e != hipSuccess) return e;
+    p.g[0] = w; p.Z[0] = G;
     GemmArgs g = gemm_args();                                                        // dz2 = (W3' dOut) .* (1 - h2^2)
     g.A = P + off.w3; g.sAm = O; g.sAk = 1; g.B = dOut; g.sBk = 1; g.sBn = O; g.C = dz2; g.sCm = 1; g.sCn = H2; g.aux = h2; g.M = H2; g.N = (int)R; g.K = O; g.epi = EPI_MASK_TANH;
-    e = launch_gemm(g, 1, s); if (e != hipSuccess) return e;
+    p.g[1] = g; p.Z[1] = 1;
     w = gemm_args();                                                                 // [dW2 | db2] = dz2 . [h1' | 1]
     w.A = dz2; w.sAm = 1; w.sAk = H2; w.zA = (long long)Cr * H2; w.B = h1; w.sBk = H1; w.sBn = 1; w.zB = (long long)Cr * H1; w.ones_n = 1;
     w.C = slabs + (off.w2 - base); w.sCm = 1; w.sCn = H2; w.zC = slab_stride; w.M = H2; w.N = H1 + 1; w.K = Cr;
-    e = launch_gemm(w, G, s); if (e != hipSuccess) return e;
+    p.g[2] = w; p.Z[2] = G;
     g = gemm_args();                                                                 // dz1 = (W2' dz2) .* (1 - h1^2)
     g.A = P + off.w2; g.sAm = H2; g.sAk = 1; g.B = dz2; g.sBk = 1; g.sBn = H2; g.C = dz1; g.sCm = 1; g.sCn = H1; g.aux = h1; g.M = H1; g.N = (int)R; g.K = H2; g.epi = EPI_MASK_TANH;
-    e = launch_gemm(g, 1, s); if (e != hipSuccess) return e;
+    p.g[3] = g; p.Z[3] = 1;
     w = gemm_args();                                                                 // [dW1 | db1] = dz1 . [x' | 1]
     w.A = dz1; w.sAm = 1; w.sAk = H1; w.zA = (long long)Cr * H1; w.B = X; w.sBk = in; w.sBn = 1; w.zB = (long long)Cr * in; w.ones_n = 1;
     w.C = slabs + (off.w1 - base); w.sCm = 1; w.sCn = H1; w.zC = slab_stride; w.M = H1; w.N = in + 1; w.K = Cr;
-    return launch_gemm(w, G, s);
+    p.g[4] = w; p.Z[4] = G;
+    return p;
+}
+long long tiles_of(const GemmArgs& g, int Z) { return (long long)((g.M + 31) / 32) * ((g.N + 31) / 32) * Z; }
+// both nets: stage i of the actor and stage i of the critic are independent, so while both are in the split-K regime (few output tiles) they share a
+// launch through the pair kernel: 5 launches instead of 10 for a small minibatch
+hipError_t run_backward_both(const BackwardPlan& a, const BackwardPlan& c, hipStream_t s) {
+    for (int i = 0; i < 5; ++i) {
+        hipError_t e;
+        if (tiles_of(a.g[i], a.Z[i]) + tiles_of(c.g[i], c.Z[i]) < 2048) e = launch_gemm_pair(a.g[i], a.Z[i], c.g[i], c.Z[i], s);
+        else { e = launch_gemm(a.g[i], a.Z[i], s); if (e == hipSuccess) e = launch_gemm(c.g[i], c.Z[i], s); }
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace
@@ -258,7 +295,7 @@ int generic_slab_size(const GenericDims& d, bool actor) {
     return (n.end + ((actor && !d.discrete) ? d.A : 0) + 8 + 3) / 4 * 4;
 }
 
-static size_t grad_floats_per_row(const GenericDims& d) { return (size_t)d.D + 3 * (size_t)d.A + 3 * ((size_t)d.H1 + d.H2) + 40; }
+static size_t grad_floats_per_row(const GenericDims& d) { return (size_t)d.D + 3 * (size_t)d.A + 4 * ((size_t)d.H1 + d.H2) + 40; }
 static int64_t grad_rows_max(const GenericDims& d) { return std::max<int64_t>((int64_t)(((size_t)1 << 29) / grad_floats_per_row(d)), 64); }   // <= 2 GiB of workspace per pass
 int generic_pick_slabs(const GenericDims& d, int64_t count, int Gmax) {
     if (count < 1 || Gmax < 1) return -1;
@@ -271,19 +308,20 @@ int generic_pick_slabs(const GenericDims& d, int64_t count, int Gmax) {
 hipError_t generic_policy(const GenericDims& d, const PolicyArgs& a, GenericWs& ws, hipStream_t s) {
     if (a.B <= 0) return hipSuccess;
     if (d.A > kMaxOut) return hipErrorInvalidValue;
-    const size_t per_row = (size_t)d.H1 + d.H2 + d.A + 1 + 8;
+    const size_t per_row = 2 * ((size_t)d.H1 + d.H2) + d.A + 1 + 8;
     int64_t Rmax = (int64_t)(((size_t)1 << 28) / per_row); Rmax = std::max<int64_t>(Rmax / 1024 * 1024, 1024);   // <= 1 GiB of activations per chunk
     const int64_t R = std::min<int64_t>(a.B, Rmax);
     hipError_t e = ws_reserve(ws, (size_t)R * per_row + 64); if (e != hipSuccess) return e;
     Carver c{ws.p};
-    float* h1 = c.take((size_t)R * d.H1); float* h2 = c.take((size_t)R * d.H2); float* out = c.take((size_t)R * d.A);
+    float* h1 = c.take((size_t)2 * R * d.H1); float* h2 = c.take((size_t)2 * R * d.H2); float* out = c.take((size_t)R * d.A);
     for (int64_t r0 = 0; r0 < a.B; r0 += R) {
         const int64_t n = std::min<int64_t>(R, a.B - r0);
         const float* X = a.obs + r0 * d.D;
         if (a.obs_out) { const int64_t cnt = n * d.D; generic_copy_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, s>>>(X, a.obs_out + r0 * d.D, cnt); }
-        if (a.values) { e = mlp_forward(a.params, a.critic, d.D, d.H1, d.H2, 1, X, (int)n, h1, h2, a.values + r0, s); if (e != hipSuccess) return e; }
+        if (a.values && a.mode != 2) { e = mlp_forward_both(a.params, a.actor, a.critic, d.D, d.H1, d.H2, d.A, X, (int)n, h1, h2, out, a.values + r0, s); if (e != hipSuccess) return e; }
+        else if (a.values) { e = mlp_forward(a.params, a.critic, d.D, d.H1, d.H2, 1, X, (int)n, h1, h2, a.values + r0, s); if (e != hipSuccess) return e; }
         if (a.mode == 2) continue;
-        e = mlp_forward(a.params, a.actor, d.D, d.H1, d.H2, d.A, X, (int)n, h1, h2, out, s); if (e != hipSuccess) return e;
+        if (!a.values) { e = mlp_forward(a.params, a.actor, d.D, d.H1, d.H2, d.A, X, (int)n, h1, h2, out, s); if (e != hipSuccess) return e; }
         PolicyHeadArgs hg{a, d.A, d.discrete, r0, n, out};
         generic_policy_head_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(hg);
         e = hipGetLastError(); if (e != hipSuccess) return e;
@@ -305,24 +343,23 @@ hipError_t generic_ppo_grad(const GenericDims& d, const GradArgs& a, GenericWs& 
     Carver c{ws.p};
     float* X = c.take((size_t)R * d.D); float* act = c.take((size_t)R * d.A); float* adv = c.take(R); float* lpo = c.take(R); float* ret = c.take(R);
     float* vold = c.take(R); float* valid = c.take(R);
-    float* h1a = c.take((size_t)R * d.H1); float* h2a = c.take((size_t)R * d.H2); float* outa = c.take((size_t)R * d.A);
-    float* h1c = c.take((size_t)R * d.H1); float* h2c = c.take((size_t)R * d.H2); float* v = c.take(R);
-    float* dout = c.take((size_t)R * d.A); float* dv = c.take(R); float* dlp = c.take(R); float* dz2 = c.take((size_t)R * d.H2); float* dz1 = c.take((size_t)R * d.H1);
+    float* h1a = c.take((size_t)2 * R * d.H1); float* h2a = c.take((size_t)2 * R * d.H2); float* outa = c.take((size_t)R * d.A); float* v = c.take(R);
+    float* dout = c.take((size_t)R * d.A); float* dv = c.take(R); float* dlp = c.take(R); float* dz2 = c.take((size_t)2 * R * d.H2); float* dz1 = c.take((size_t)2 * R * d.H1);   // actor's, then critic's
     for (int slab0 = 0; slab0 < G; slab0 += Gp) {
         const int Gn = std::min(Gp, G - slab0); const int64_t Rn = (int64_t)Gn * Cr, row0 = (int64_t)slab0 * Cr;
         GatherArgs ga{a, d.D, d.A, d.discrete, row0, Rn, X, act, adv, lpo, ret, vold, valid};
         const int64_t ge = Rn * (d.D + 1);
         generic_gather_kernel<<<(unsigned)((ge + 255) / 256), 256, 0, s>>>(ga);
         e = hipGetLastError(); if (e != hipSuccess) return e;
-        e = mlp_forward(a.params, a.actor, d.D, d.H1, d.H2, d.A, X, (int)Rn, h1a, h2a, outa, s); if (e != hipSuccess) return e;
-        e = mlp_forward(a.params, a.critic, d.D, d.H1, d.H2, 1, X, (int)Rn, h1c, h2c, v, s); if (e != hipSuccess) return e;
+        float* h1c = h1a + (size_t)Rn * d.H1; float* h2c = h2a + (size_t)Rn * d.H2;   // the critic's activations follow the actor's (mlp_forward_both)
+        e = mlp_forward_both(a.params, a.actor, a.critic, d.D, d.H1, d.H2, d.A, X, (int)Rn, h1a, h2a, outa, v, s); if (e != hipSuccess) return e;
         LossHeadArgs lh{a, d.A, d.discrete, Rn, Cr, slab0, outa, v, act, adv, lpo, ret, vold, valid, dout, dv, dlp};
         generic_loss_head_kernel<<<Gn, 256, 0, s>>>(lh);
         e = hipGetLastError(); if (e != hipSuccess) return e;
-        e = mlp_backward(a.params, a.actor, d.D, d.H1, d.H2, d.A, X, h1a, h2a, dout, dz2, dz1, Rn, (int)Cr, Gn, a.slabs_actor + (size_t)slab0 * a.slab_a, a.slab_a, s);
-        if (e != hipSuccess) return e;
-        e = mlp_backward(a.params, a.critic, d.D, d.H1, d.H2, 1, X, h1c, h2c, dv, dz2, dz1, Rn, (int)Cr, Gn, a.slabs_critic + (size_t)slab0 * a.slab_c, a.slab_c, s);
-        if (e != hipSuccess) return e;
+        const BackwardPlan pa = plan_backward(a.params, a.actor, d.D, d.H1, d.H2, d.A, X, h1a, h2a, dout, dz2, dz1, Rn, (int)Cr, Gn, a.slabs_actor + (size_t)slab0 * a.slab_a, a.slab_a);
+        const BackwardPlan pc = plan_backward(a.params, a.critic, d.D, d.H1, d.H2, 1, X, h1c, h2c, dv, dz2 + (size_t)Rn * d.H2, dz1 + (size_t)Rn * d.H1, Rn, (int)Cr, Gn,
+                                              a.slabs_critic + (size_t)slab0 * a.slab_c, a.slab_c);
+        e = run_backward_both(pa, pc, s); if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
