@@ -299,7 +299,10 @@ static size_t grad_floats_per_row(const GenericDims& d) { return (size_t)d.D + 3
 static int64_t grad_rows_max(const GenericDims& d) { return std::max<int64_t>((int64_t)(((size_t)1 << 29) / grad_floats_per_row(d)), 64); }   // <= 2 GiB of workspace per pass
 int generic_pick_slabs(const GenericDims& d, int64_t count, int Gmax) {
     if (count < 1 || Gmax < 1) return -1;
-    int64_t G = std::min<int64_t>(Gmax, std::max<int64_t>(1, (count + 511) / 512));          // >= 512 rows per slab; the weight-gradient contractions get H1*H2/1024 * G workgroups
+    // >= 512 rows per slab, up to Gmax slabs.  Fewer slabs for wide nets (sized so that the largest weight-gradient contraction has just 2048 or 4096
+    // output tiles) were measured slower (hidden 512: 38 / 49 vs 53 TFLOP/s) although grad_reduce_kernel then reads 8-16x fewer bytes: the contractions
+    // want the parallelism
+    int64_t G = std::min<int64_t>(Gmax, std::max<int64_t>(1, (count + 511) / 512));
     const int64_t need = (count + grad_rows_max(d) - 33) / (grad_rows_max(d) - 32);                   // a slab's rows (rounded up to 32) must fit one pass
     if (need > G) G = need;
     return G <= Gmax ? (int)G : -1;
