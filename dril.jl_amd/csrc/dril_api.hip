@@ -87,6 +87,7 @@ struct dril_handle {
     float4* rec = nullptr;   // packed minibatch records (see pack_records_kernel)
     RmsState *obs_rms = nullptr, *ret_rms = nullptr; int obs_par = 0, ret_par = 0;   // ping-pong RunningMeanStd pairs
     double* rms_partials = nullptr; int rms_blocks = 256; float* e_obs_raw = nullptr;
+    double* rms_red = nullptr;   // data-parallel: this step's partial sums folded to one row and summed over ranks
     int grad_stagger = 0;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
     bool external = false; GenericDims gd{}; GenericWs gws; int ext_t = 0; bool ext_acted = false;   // DRIL_ENV_EXTERNAL: host envs, generic kernels
@@ -182,14 +183,29 @@ int monitor_collect_rollout(dril_handle* h) {
     return DRIL_OK;
 }
 
+// data-parallel runs: NormalizeWrapperEnv's batch moments cover every env of the job (the reference has ONE vector env, normalizeWrapperEnv.jl:21-26):
+// this rank's partial table is folded to one row, RCCL sums the rows, and the apply kernels merge that row with n_stats = world * E.  One 128-byte
+// all-reduce per env step; every rank applies the identical update, so the running statistics stay bit-identical across ranks
+int global_partials(dril_handle* h, bool update, const double*& partials, int& nb, long long& n_stats) {
+    partials = h->rms_partials; n_stats = 0;
+    const int world = h->comm ? h->cfg.world_size : 1;
+    if (!update || !(world > 1 || (h->comm && h->force_allreduce))) return DRIL_OK;
+    HIPCHK(h, launch_fold_partials(h->rms_partials, nb, h->rms_red, h->stream));
+    int rc = rccl_allreduce(h, h->rms_red, 16, kNcclFloat64); if (rc) return rc;
+    partials = h->rms_red; nb = 1; n_stats = (long long)h->cfg.n_envs * world;
+    return DRIL_OK;
+}
+
 // ---- step-granular env verbs on device (NormalizeWrapperEnv.observe / act!, normalizeWrapperEnv.jl:123-165) ----
 int observe_dev(dril_handle* h, bool update_stats) {
     const int E = h->cfg.n_envs;
     int nb = (E + 255) / 256; if (nb > h->rms_blocks) nb = h->rms_blocks;
     HIPCHK(h, launch_obs_partials(h->cfg.env_kind, E, h->state, h->e_obs_raw, h->rms_partials, nb, h->stream));
     NormObsArgs a{};
-    a.E = E; a.D = h->D; a.update = (update_stats && h->cfg.norm_training && h->cfg.norm_obs) ? 1 : 0; a.nblocks = nb;
-    a.raw = h->e_obs_raw; a.partials = h->rms_partials; a.in = h->obs_rms + h->obs_par; a.out = h->obs_rms + (h->obs_par ^ 1);
+    a.E = E; a.D = h->D; a.update = (update_stats && h->cfg.norm_training && h->cfg.norm_obs) ? 1 : 0;
+    { int rcg = global_partials(h, a.update != 0, a.partials, nb, a.n_stats); if (rcg) return rcg; }
+    a.nblocks = nb;
+    a.raw = h->e_obs_raw; a.in = h->obs_rms + h->obs_par; a.out = h->obs_rms + (h->obs_par ^ 1);
     a.obs_n = h->e_obs; a.clip = h->cfg.clip_obs; a.eps = h->cfg.norm_epsilon; a.norm_obs = h->cfg.norm_obs;
     HIPCHK(h, launch_norm_obs_apply(a, h->stream));
     h->obs_par ^= 1;
@@ -205,8 +221,10 @@ int step_dev(dril_handle* h, const void* actions, float* rew_out, uint8_t* flags
     const int upd = (h->cfg.norm_reward && h->cfg.norm_training) ? 1 : 0;
     HIPCHK(h, launch_rew_partials(E, h->e_rew, h->disc_returns, h->cfg.norm_gamma, upd, h->rms_partials, nb, h->stream));
     NormRewArgs a{};
-    a.E = E; a.D = h->D; a.update = upd; a.nblocks = nb; a.norm_obs = h->cfg.norm_obs; a.norm_reward = h->cfg.norm_reward;
-    a.rew_raw = h->e_rew; a.partials = h->rms_partials; a.in = h->ret_rms + h->ret_par; a.out = h->ret_rms + (h->ret_par ^ 1);
+    a.E = E; a.D = h->D; a.update = upd; a.norm_obs = h->cfg.norm_obs; a.norm_reward = h->cfg.norm_reward;
+    { int rcg = global_partials(h, upd != 0, a.partials, nb, a.n_stats); if (rcg) return rcg; }
+    a.nblocks = nb;
+    a.rew_raw = h->e_rew; a.in = h->ret_rms + h->ret_par; a.out = h->ret_rms + (h->ret_par ^ 1);
     a.obs_stats = h->obs_rms + h->obs_par; a.rew_out = rew_out; a.disc_returns = h->disc_returns; a.term = h->e_term; a.trunc = h->e_trunc;
     a.tobs = h->e_tobs; a.clip_obs = h->cfg.clip_obs; a.clip_reward = h->cfg.clip_reward; a.eps = h->cfg.norm_epsilon; a.flags_out = flags_out;
     HIPCHK(h, launch_norm_rew_apply(a, h->stream));
@@ -415,7 +433,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
 #endif
     CCHK(dmalloc(&h->e_obs, E * h->D)); CCHK(dmalloc(&h->e_rew, E)); CCHK(dmalloc(&h->e_tobs, E * h->D)); CCHK(dmalloc(&h->e_term, E));
     CCHK(dmalloc(&h->e_trunc, E)); CCHK(hipMalloc(&h->e_act, E * act_bytes_per(h)));
-    CCHK(dmalloc(&h->e_obs_raw, E * h->D)); CCHK(dmalloc(&h->obs_rms, 2)); CCHK(dmalloc(&h->ret_rms, 2)); CCHK(dmalloc(&h->rms_partials, (size_t)h->rms_blocks * 16));
+    CCHK(dmalloc(&h->e_obs_raw, E * h->D)); CCHK(dmalloc(&h->obs_rms, 2)); CCHK(dmalloc(&h->ret_rms, 2)); CCHK(dmalloc(&h->rms_partials, (size_t)h->rms_blocks * 16)); CCHK(dmalloc(&h->rms_red, 16));
     { RmsState init[2]; for (auto& r : init) { for (int d = 0; d < 8; ++d) { r.mean[d] = 0.f; r.var[d] = 1.f; } r.count = 0; }   // RunningMeanStd{T}(shape): zeros, ones, 0 (normalizeWrapperEnv.jl:14-16)
       CCHK(hipMemcpy(h->obs_rms, init, sizeof(init), hipMemcpyHostToDevice)); CCHK(hipMemcpy(h->ret_rms, init, sizeof(init), hipMemcpyHostToDevice)); }
     CCHK(hipMemsetAsync(h->params, 0, P * 4, h->stream)); CCHK(hipMemsetAsync(h->boot, 0, N * 4, h->stream));
@@ -440,7 +458,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
                     h->flags, h->last_values, h->noise_dev, h->perm_dev, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
-                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->obs_rms, h->ret_rms, h->rms_partials, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
+                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
                     h->mon_ring_len, h->e_ep_len, h->mon_cnt, h->mon_meta, h->e_flags};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& p : h->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -631,8 +649,11 @@ int collect_rollout_stepwise(dril_handle* h) {
         if (h->mon_cur_ret) { s.mon_cur_ret = h->mon_cur_ret; s.mon_cur_len = h->mon_cur_len; s.ep_ret = h->ep_ret + k; s.ep_len = h->ep_len + k; }
         HIPCHK(h, launch_norm_step(h->cfg.env_kind, s, nb, h->stream));                              // to_env + act!, :43-44
         NormApplyArgs ap{};
-        ap.E = E; ap.D = D; ap.nblocks = nb; ap.update_obs = (h->cfg.norm_obs && h->cfg.norm_training) ? 1 : 0; ap.update_ret = s.update_ret;
-        ap.norm_obs = h->cfg.norm_obs; ap.norm_reward = h->cfg.norm_reward; ap.partials = h->rms_partials;
+        ap.E = E; ap.D = D; ap.update_obs = (h->cfg.norm_obs && h->cfg.norm_training) ? 1 : 0; ap.update_ret = s.update_ret;
+        ap.norm_obs = h->cfg.norm_obs; ap.norm_reward = h->cfg.norm_reward;
+        int nba = nb;
+        { int rcg = global_partials(h, ap.update_obs || ap.update_ret, ap.partials, nba, ap.n_stats); if (rcg) return rcg; }
+        ap.nblocks = nba;
         ap.obs_in = h->obs_rms + h->obs_par; ap.obs_out = h->obs_rms + (h->obs_par ^ 1); ap.ret_in = h->ret_rms + h->ret_par; ap.ret_out = h->ret_rms + (h->ret_par ^ 1);
         ap.rew_raw = h->e_rew; ap.rew_out = h->rew + k; ap.disc_returns = h->disc_returns; ap.term = h->e_term; ap.trunc = h->e_trunc; ap.tobs = h->e_tobs;
         ap.obs_raw = h->e_obs_raw; ap.obs_n = h->e_obs; ap.clip_obs = h->cfg.clip_obs; ap.clip_reward = h->cfg.clip_reward; ap.eps = h->cfg.norm_epsilon;

@@ -27,11 +27,13 @@ struct RmsState { float mean[8]; float var[8]; long long count; };
 struct NormObsArgs {
     int E, D, update, nblocks; const float* raw; const double* partials; const RmsState* in; RmsState* out;
     float* obs_n; float clip, eps; int norm_obs;
+    long long n_stats;   // envs behind the partial sums (0 = E: this rank only; world * E after the all-reduce of the folded row)
 };
 struct NormRewArgs {
     int E, D, update, nblocks, norm_obs, norm_reward; const float* rew_raw; const double* partials; const RmsState* in; RmsState* out;
     const RmsState* obs_stats; float* rew_out; float* disc_returns; const uint8_t* term; const uint8_t* trunc;
     float* tobs; float clip_obs, clip_reward, eps; uint8_t* flags_out;
+    long long n_stats;
 };
 
 struct RolloutArgs {
@@ -104,7 +106,9 @@ struct NormApplyArgs {
     const double* partials; const RmsState* obs_in; RmsState* obs_out; const RmsState* ret_in; RmsState* ret_out;
     const float* rew_raw; float* rew_out; float* disc_returns; const uint8_t* term; const uint8_t* trunc; float* tobs; const float* obs_raw; float* obs_n;
     float clip_obs, clip_reward, eps;
+    long long n_stats;
 };
+hipError_t launch_fold_partials(const double* partials, int nblocks, double* out16, hipStream_t s);
 hipError_t launch_norm_step(int kind, const NormStepArgs& a, int nblocks, hipStream_t s);
 hipError_t launch_norm_apply(const NormApplyArgs& a, hipStream_t s);
 hipError_t launch_obs_partials(int kind, int E, const float* state, float* raw, double* partials, int nblocks, hipStream_t s);

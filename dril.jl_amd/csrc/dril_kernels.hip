@@ -136,20 +136,29 @@ __device__ __forceinline__ void fold_partials16(const double* __restrict__ parti
     __syncthreads();
 }
 
+// data-parallel runs: the [nblocks][16] table of one rank's partial sums folded to ONE row, which RCCL then sums over ranks — the batch moments of
+// NormalizeWrapperEnv cover every env of the job, as in the reference's single vector env (normalizeWrapperEnv.jl:21-26,139-171)
+__global__ void fold_partials_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ out16) {
+    __shared__ double s_part[16][17], s_col[16];
+    fold_partials16(partials, nblocks, s_part, s_col);
+    if (threadIdx.x < 16) out16[threadIdx.x] = s_col[threadIdx.x];
+}
+
 __global__ void norm_obs_apply_kernel(NormObsArgs a) {
     __shared__ float s_mean[8], s_var[8];
     __shared__ double s_part[16][17], s_col[16];
     if (a.update) fold_partials16(a.partials, a.nblocks, s_part, s_col);
+    const long long nb_ = a.n_stats ? a.n_stats : a.E;          // envs behind the batch moments: all ranks' when the partials were all-reduced
     if (threadIdx.x < a.D) {
         const int d = threadIdx.x;
         float mean = a.in->mean[d], var = a.in->var[d];
         if (a.update) {
             const double s = s_col[2 * d], q = s_col[2 * d + 1];
-            const double bm = s / a.E; double bv = q / a.E - bm * bm; if (bv < 0) bv = 0;      // mean / var(corrected=false), :21-26
-            rms_merge(mean, var, a.in->count, (float)bm, (float)bv, a.E);
+            const double bm = s / nb_; double bv = q / nb_ - bm * bm; if (bv < 0) bv = 0;      // mean / var(corrected=false), :21-26
+            rms_merge(mean, var, a.in->count, (float)bm, (float)bv, nb_);
         }
         s_mean[d] = mean; s_var[d] = var;
-        if (blockIdx.x == 0) { a.out->mean[d] = mean; a.out->var[d] = var; if (d == 0) a.out->count = a.in->count + (a.update ? a.E : 0); }
+        if (blockIdx.x == 0) { a.out->mean[d] = mean; a.out->var[d] = var; if (d == 0) a.out->count = a.in->count + (a.update ? nb_ : 0); }
     }
     __syncthreads();
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.E * a.D; i += gridDim.x * blockDim.x) {
@@ -177,15 +186,16 @@ __global__ void norm_rew_apply_kernel(NormRewArgs a) {
     __shared__ float s_var;
     __shared__ double s_part[16][17], s_col[16];
     if (a.update) fold_partials16(a.partials, a.nblocks, s_part, s_col);
+    const long long nb_ = a.n_stats ? a.n_stats : a.E;
     if (threadIdx.x == 0) {
         float mean = a.in->mean[0], var = a.in->var[0];
         if (a.update) {
             const double s = s_col[0], q = s_col[1];
-            const double bm = s / a.E; double bv = q / a.E - bm * bm; if (bv < 0) bv = 0;
-            rms_merge(mean, var, a.in->count, (float)bm, (float)bv, a.E);
+            const double bm = s / nb_; double bv = q / nb_ - bm * bm; if (bv < 0) bv = 0;
+            rms_merge(mean, var, a.in->count, (float)bm, (float)bv, nb_);
         }
         s_var = var;
-        if (blockIdx.x == 0) { a.out->mean[0] = mean; a.out->var[0] = var; a.out->count = a.in->count + (a.update ? a.E : 0); }
+        if (blockIdx.x == 0) { a.out->mean[0] = mean; a.out->var[0] = var; a.out->count = a.in->count + (a.update ? nb_ : 0); }
     }
     __syncthreads();
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.E; e += gridDim.x * blockDim.x) {
@@ -255,6 +265,7 @@ __global__ void norm_apply_kernel(NormApplyArgs a) {
     __shared__ float s_mean_new[8], s_var_new[8], s_mean_old[8], s_var_old[8], s_rvar;
     __shared__ double s_part[16][17], s_col[16];
     if (a.update_ret || a.update_obs) fold_partials16(a.partials, a.nblocks, s_part, s_col);
+    const long long nb_ = a.n_stats ? a.n_stats : a.E;
     if (threadIdx.x <= a.D) {
         const int i = threadIdx.x;                       // 0: discounted returns, 1..D: observation dims
         const RmsState* in = i == 0 ? a.ret_in : a.obs_in;
@@ -265,13 +276,13 @@ __global__ void norm_apply_kernel(NormApplyArgs a) {
         if (upd) {
             const int col = i == 0 ? 0 : 2 * i;
             const double s = s_col[col], q = s_col[col + 1];
-            const double bm = s / a.E; double bv = q / a.E - bm * bm; if (bv < 0) bv = 0;
-            rms_merge(mean, var, in->count, (float)bm, (float)bv, a.E);
+            const double bm = s / nb_; double bv = q / nb_ - bm * bm; if (bv < 0) bv = 0;
+            rms_merge(mean, var, in->count, (float)bm, (float)bv, nb_);
         }
-        if (i == 0) { s_rvar = var; if (blockIdx.x == 0) { a.ret_out->mean[0] = mean; a.ret_out->var[0] = var; a.ret_out->count = in->count + (upd ? a.E : 0); } }
+        if (i == 0) { s_rvar = var; if (blockIdx.x == 0) { a.ret_out->mean[0] = mean; a.ret_out->var[0] = var; a.ret_out->count = in->count + (upd ? nb_ : 0); } }
         else {
             s_mean_new[d] = mean; s_var_new[d] = var; s_mean_old[d] = mean_old; s_var_old[d] = var_old;
-            if (blockIdx.x == 0) { a.obs_out->mean[d] = mean; a.obs_out->var[d] = var; if (d == 0) a.obs_out->count = in->count + (upd ? a.E : 0); }
+            if (blockIdx.x == 0) { a.obs_out->mean[d] = mean; a.obs_out->var[d] = var; if (d == 0) a.obs_out->count = in->count + (upd ? nb_ : 0); }
         }
     }
     __syncthreads();
@@ -2316,6 +2327,10 @@ template <int KIND, int H> static size_t grad_lds_bytes() {
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
+hipError_t launch_fold_partials(const double* partials, int nblocks, double* out16, hipStream_t s) {
+    fold_partials_kernel<<<1, 256, 0, s>>>(partials, nblocks, out16);
+    return hipGetLastError();
+}
 hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a, float* w2ta, hipStream_t s) {
     build_wimg_kernel<<<(H * H + 255) / 256, 256, 0, s>>>(params, off, H, w2a, w2ta);
     return hipGetLastError();

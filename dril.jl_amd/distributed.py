@@ -12,6 +12,9 @@ sharding maths can be exercised with torch.distributed/gloo on CPU (tests/test_d
     moments     (sum a, sum a^2, n) of the global minibatch: one 3-double all-reduce, then mean / corrected std (ppo.jl:350-356)
     gradient    each rank accumulates SUMS with the global 1/B folded in; ONE all-reduce of [grads | loss sums] (P + 8 floats)
     apply       identical norm / clip / KL check / Adam on every rank => replicas stay bit-identical
+    normalise   NormalizeWrapperEnv's batch moments cover every env of the job: per env step each rank folds its (sum x, sum x^2) per
+                statistic into one 16-double row, ONE all-reduce sums the rows, every rank merges mean / var(corrected = false) with
+                n = world * E into its RunningMeanStd (normalizeWrapperEnv.jl:21-50) => the statistics stay identical on all ranks
 """
 from __future__ import annotations
 
@@ -46,6 +49,29 @@ def global_moments(adv_local: np.ndarray, allreduce):
     mean = s / n
     var = max((q - s * mean) / (n - 1.0), 0.0)
     return np.float32(mean), np.float32(np.float32(np.sqrt(var)) + np.float32(1e-8)), int(n)
+
+
+def global_batch_moments(x_local: np.ndarray, allreduce):
+    """batch mean / var(corrected=false) / count over ALL ranks' rows of x (n_local, dims) from local sums — what the device path feeds
+    update_from_moments! (normalizeWrapperEnv.jl:21-50) in data-parallel runs (dril_api.hip: global_partials)"""
+    x = np.asarray(x_local, np.float32).reshape(len(x_local), -1).astype(np.float64)
+    row = allreduce(np.concatenate([x.sum(0), (x * x).sum(0), [float(x.shape[0])]]))
+    d = x.shape[1]; n = row[-1]
+    mean = row[:d] / n
+    var = np.maximum(row[d:2 * d] / n - mean * mean, 0.0)
+    return mean.astype(np.float32), var.astype(np.float32), int(n)
+
+
+def rms_merge(mean, var, count, bmean, bvar, bcount):
+    """update_from_moments! (normalizeWrapperEnv.jl:28-50) in f32"""
+    mean, var, bmean, bvar = (np.asarray(a, np.float32) for a in (mean, var, bmean, bvar))
+    if count == 0:
+        return bmean.copy(), bvar.copy(), bcount
+    tot = count + bcount
+    delta = bmean - mean
+    new_mean = mean + delta * np.float32(bcount) / np.float32(tot)
+    m2 = var * np.float32(count) + bvar * np.float32(bcount) + delta * delta * np.float32(count) * np.float32(bcount) / np.float32(tot)
+    return new_mean.astype(np.float32), (m2 / np.float32(tot)).astype(np.float32), tot
 
 
 def data_parallel_gradient(local_loss_grad, batch_local, n_global: int, allreduce):

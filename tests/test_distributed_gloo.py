@@ -53,7 +53,14 @@ def _worker(rank, world, port, q):
             og.set_params(o.get_params())
             grads, stats = D.data_parallel_gradient(lambda b: og.ppo_loss_grad(*b), batch, n, allreduce)
             o.apply_gradients(grads)                                        # identical on every rank
-    q.put((rank, o.get_params(), {k: v for k, v in bufs.items()}, [u.tolist() for u in used], st0))
+    # NormalizeWrapperEnv statistics over all ranks' envs: three env steps of (E, 3) observations
+    rms = (np.zeros(3, np.float32), np.ones(3, np.float32), 0); obs_steps = []
+    for step in range(3):
+        x = np.random.default_rng(1000 * rank + step).normal(step, 1 + rank, (E, 3)).astype(np.float32)
+        obs_steps.append(x)
+        bm, bv, n = D.global_batch_moments(x, allreduce)
+        rms = D.rms_merge(*rms, bm, bv, n)
+    q.put((rank, o.get_params(), {k: v for k, v in bufs.items()}, [u.tolist() for u in used], st0, rms, obs_steps))
     dist.barrier(); dist.destroy_process_group()
 
 
@@ -67,8 +74,17 @@ def test_data_parallel_update_equals_single_process(pkg, oracle_mod):
     res = sorted([q.get(timeout=240) for _ in range(2)], key=lambda r: r[0])
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    (r0, p0, b0, u0, s0), (r1, p1, b1, u1, s1) = res
+    (r0, p0, b0, u0, s0, rms0, x0), (r1, p1, b1, u1, s1, rms1, x1) = res
     assert np.array_equal(p0, p1)                                           # replicas stay bit-identical
+    # NormalizeWrapperEnv: both ranks hold the same RunningMeanStd, and it is the oracle's update! over the union of their envs per step
+    assert all(np.array_equal(a, b) for a, b in zip(rms0[:2], rms1[:2])) and rms0[2] == rms1[2] == 3 * 12
+    import ctypes as C
+    L = oracle_mod.lib(); pp = lambda a: a.ctypes.data_as(C.c_void_p)
+    mean, var, cnt = np.zeros(3, np.float32), np.ones(3, np.float32), C.c_int64(0)
+    for a, b in zip(x0, x1):
+        u = np.ascontiguousarray(np.concatenate([a, b]), np.float32)
+        L.orc_rms_update(pp(mean), pp(var), C.byref(cnt), 3, pp(u), u.shape[0])
+    np.testing.assert_allclose(rms0[0], mean, rtol=1e-5, atol=1e-6); np.testing.assert_allclose(rms0[1], var, rtol=1e-4, atol=1e-6)
     # env sharding: rank 1's env e is global env 6 + e => same reset state as a 12-env single process (seed + i)
     capi = pkg._capi
     cfg = capi.default_config(capi.ENV_CARTPOLE); cfg.n_envs, cfg.n_steps, cfg.seed = 12, 2, 11

@@ -365,15 +365,22 @@ def test_rccl_plumbing_single_rank(pkg, oracle_mod, monkeypatch):
 
 
 @pytest.mark.parametrize("kind,flags", [(1, (1, 1)), (0, (1, 1)), (1, (1, 0)), (1, (0, 1)), (2, (1, 1)), (3, (1, 1)), (4, (1, 1))])   # 2: Normalize(Parallel([Scaling(Pendulum)])); 3, 4: MountainCar
-def test_normalize_wrapper_rollout_matches_oracle(pkg, oracle_mod, kind, flags):
+@pytest.mark.parametrize("via_rccl", [False, True])
+def test_normalize_wrapper_rollout_matches_oracle(pkg, oracle_mod, kind, flags, via_rccl, monkeypatch):
     """NormalizeWrapperEnv on device (normalizeWrapperEnv.jl:21-50,123-197): running obs/return statistics (updated on EVERY
     observe, including the double update at a rollout boundary), normalised + clipped obs and rewards, normalised
-    terminal_observation for the truncation bootstrap — vs the oracle's line-by-line restatement."""
+    terminal_observation for the truncation bootstrap — vs the oracle's line-by-line restatement.
+    via_rccl: the data-parallel form of the statistics (partial sums folded to one row, summed over ranks by ncclAllReduce once per env
+    step, merged with n = world * E) on a 1-rank communicator must give the same numbers."""
     capi = pkg._capi
     E, T, L = 48, 30, 9
+    if via_rccl:
+        monkeypatch.setenv("DRIL_FORCE_ALLREDUCE", "1"); monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cfg = _cfg(pkg, kind, n_envs=E, n_steps=T, episode_len=L, batch_size=E * T // 2, epochs=1, norm_training=1, norm_obs=flags[0],
                norm_reward=flags[1], clip_obs=5.0, clip_reward=2.0)
     h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    if via_rccl:
+        h.comm_init(h.comm_unique_id())
     flat = _params(h.P, 31, 0.4); h.set_params(flat); o.set_params(flat)
     h.env_reset(9); o.env_reset(9)
     rng = np.random.default_rng(2)
