@@ -1,6 +1,7 @@
 // dril_gemm.hip — generic strided fp32 contraction on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate); see dril_gemm.h.
 // Written for the SAC update (~25 small dense contractions per gradient step) and reused by the generic on-policy path.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "dril_device.h"
@@ -212,6 +213,162 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_big_kernel(GemmArgs 
         C[ci] = gemm_epilogue(g, red[wave][rr][ll], mm, ci, bias, aux);
     }
 }
+// ---- the same LDS-tiled contraction on the bf16 matrix cores, fp32-equivalent by operand splitting ------------------------------------------------
+// Every staged f32 operand is cut into three bf16 pieces x = hi + mid + lo (upper 16 bits, exact remainder, twice: exact for a 24-bit mantissa) when
+// its chunk is written to LDS — once per element, whatever number of waves reads it — and a k16 step of a tile is six v_mfma_f32_32x32x16_bf16
+// (hi.hi hi.mid mid.hi mid.mid hi.lo lo.hi; the dropped partial products are <= 2^-23 relative; f32 accumulate).  profiles/r01_bf16_split_microbench.md:
+// 2.0x the rate of v_mfma_f32_32x32x2_f32 with pre-split operands, max error 1.0e-7 vs 1.5e-7 for the f32 MFMA chain — not a precision reduction.
+// LDS image per piece and k16 step: [h = k-half][row][8 bf16] — lane (row c, half h) reads its MFMA operand as ONE ds_read_b128 and consecutive lanes
+// read consecutive 16 bytes (conflict-free).  The epilogue's transposition buffer overlays the operand images.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// pieces of two values packed for one 32-bit LDS word: {b[31:16], a[31:16]} of each piece (v_perm_b32): 4 VALU per value + 1.5 per pair
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned ah = __float_as_uint(a) & 0xffff0000u, bh = __float_as_uint(b) & 0xffff0000u;
+    const float ar = a - __uint_as_float(ah), br = b - __uint_as_float(bh);
+    const unsigned am = __float_as_uint(ar) & 0xffff0000u, bm = __float_as_uint(br) & 0xffff0000u;
+    const float aq = ar - __uint_as_float(am), bq = br - __uint_as_float(bm);
+    hi = __builtin_amdgcn_perm(bh, ah, 0x07060302u); mid = __builtin_amdgcn_perm(bm, am, 0x07060302u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(bq), __float_as_uint(aq), 0x07060302u);
+}
+constexpr int kSplitRowsX = 32 * kGemmWaves;                                   // 256 n-rows per workgroup
+constexpr int kSplitXImg = 2 * 2 * kSplitRowsX * 8;                            // bf16 elements per piece: [k16 step][half][row][8]
+// MB = m-tiles per wave: the workgroup's output block is (32 MB) x 256.  One thin 32 x 256 block re-reads the activation chunk for every 32 output
+// rows — at hidden 512 the LDS-tiled kernels moved 6 TB/s through L2 and the bf16 form was no faster than the f32 one (87 vs 90 TFLOP/s); with
+// MB = 4 the same chunk feeds four tiles (43.7 FLOP per staged byte instead of 14.5) and the split is amortised over four times the MFMAs
+template <bool AK, bool BN, int MB>
+__global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_split_kernel(GemmArgs g) {
+    constexpr int kRowsA = 32 * MB, kSplitAImg = 2 * 2 * kRowsA * 8;
+    __shared__ __attribute__((aligned(16))) unsigned short Ap[3 * kSplitAImg];
+    __shared__ __attribute__((aligned(16))) unsigned short Xp[3 * kSplitXImg];                        // 48 KB; the f32 epilogue buffer (33 KB) overlays it
+    static_assert(sizeof(unsigned short) * 3 * kSplitXImg >= sizeof(float) * kGemmWaves * 16 * kRedStride, "epilogue buffer must fit the operand images");
+    float (*red)[16][kRedStride] = reinterpret_cast<float (*)[16][kRedStride]>(Xp);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5, z = blockIdx.z;
+    const float* __restrict__ A = g.A + (size_t)z * g.zA;
+    const float* __restrict__ B = g.B + (size_t)(z / g.zdivB) * g.zB;
+    const int m0 = blockIdx.x * kRowsA, n0 = blockIdx.y * 32 * kGemmWaves;
+    // loader roles: every thread owns 4 groups of (one n-row, 4 consecutive k) = one 8-byte LDS store per piece and group.  B k-contiguous: one float4 per
+    // group (8 lanes read one row's 128 B).  BN (n-contiguous): consecutive lanes take consecutive n and read the 4 k-rows as 4 coalesced scalar loads
+    int xr[4], xk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int i = tid + 512 * j; if (BN) { xr[j] = tid & 255; xk[j] = ((tid >> 8) + 2 * j) * 4; } else { xr[j] = i >> 3; xk[j] = (i & 7) * 4; } }
+    // A chunk = (32 MB) m x 32 k.  m-contiguous: element e = tid + 512 j, m = e % rows, k = e / rows (consecutive lanes, consecutive m), two per store
+    // pair (j, j + MB): k and k + 16 share an 8-k group?  no — stored as single bf16 each.  AK: pair e = tid + 512 j: m = e >> 4, k = (e & 15) * 2
+    const int n_real = g.N - (g.ones_n ? 1 : 0);
+    float4 xv[4]; float av[2 * MB];
+    auto gload = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (BN) {
+                const int n = n0 + xr[j];
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = kc + xk[j] + e;
+                    t[e] = (k < g.K && n < n_real) ? B[(size_t)k * g.sBk + n] : ((k < g.K && g.ones_n && n == n_real) ? 1.0f : 0.0f);
+                }
+                xv[j] = make_float4(t[0], t[1], t[2], t[3]);
+            } else {
+                const int n = n0 + xr[j];
+                xv[j] = (n < g.N && kc + xk[j] < g.K) ? *reinterpret_cast<const float4*>(B + (size_t)n * g.sBn + kc + xk[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            if (AK) {
+                const int e = tid + 512 * j, am = e >> 4, ak = (e & 15) * 2, mg = m0 + am;
+                av[2 * j] = (mg < g.M && kc + ak < g.K) ? A[(size_t)mg * g.sAm + kc + ak] : 0.f;
+                av[2 * j + 1] = (mg < g.M && kc + ak + 1 < g.K) ? A[(size_t)mg * g.sAm + kc + ak + 1] : 0.f;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = tid + 512 * (2 * j + u), am = e % kRowsA, ak = e / kRowsA, mg = m0 + am;
+                    av[2 * j + u] = (mg < g.M && kc + ak < g.K) ? A[(size_t)mg + (size_t)(kc + ak) * g.sAk] : 0.f;
+                }
+            }
+        }
+    };
+    // element (row, k in 0..31) of a piece image: [k >> 4][(k >> 3) & 1][row][k & 7]
+    auto xoff = [](int row, int k) { return (((k >> 4) * 2 + ((k >> 3) & 1)) * kSplitRowsX + row) * 8 + (k & 7); };
+    auto aoff = [](int row, int k) { return (((k >> 4) * 2 + ((k >> 3) & 1)) * kRowsA + row) * 8 + (k & 7); };
+    f32x16 acc[MB];
+#pragma unroll
+    for (int t = 0; t < MB; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // chunk order staggered by workgroup: all workgroups walking k = 0, 32, 64, ... in step touch, at any moment, only the 128-byte column block
+    // kc of every (power-of-two strided) operand row — a fraction of the memory channels; starting each workgroup at a different chunk spreads them
+    const int nchunks = (g.K + kBigKc - 1) / kBigKc, c0 = (int)((blockIdx.y * 7 + blockIdx.x * 3) % nchunks);
+    gload(c0 * kBigKc);
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int cn = c0 + ci + 1 >= nchunks ? c0 + ci + 1 - nchunks : c0 + ci + 1;   // next chunk (wraps)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                            // 4 consecutive k of one n-row (inside one 8-k group): one 8-byte store per piece
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split3_pair(xv[j].x, xv[j].y, h0, m0_, l0); split3_pair(xv[j].z, xv[j].w, h1, m1, l1);
+            const int o = xoff(xr[j], xk[j]);
+            *reinterpret_cast<uint2*>(&Xp[o]) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(&Xp[kSplitXImg + o]) = make_uint2(m0_, m1);
+            *reinterpret_cast<uint2*>(&Xp[2 * kSplitXImg + o]) = make_uint2(l0, l1);
+        }
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            unsigned ph, pm, pl;
+            split3_pair(av[2 * j], av[2 * j + 1], ph, pm, pl);
+            if (AK) {                                                            // two consecutive k of one m-row: one 4-byte store per piece
+                const int e = tid + 512 * j, o = aoff(e >> 4, (e & 15) * 2);
+                *reinterpret_cast<unsigned*>(&Ap[o]) = ph; *reinterpret_cast<unsigned*>(&Ap[kSplitAImg + o]) = pm; *reinterpret_cast<unsigned*>(&Ap[2 * kSplitAImg + o]) = pl;
+            } else {                                                             // two unrelated elements: single bf16 stores
+                const int e0 = tid + 512 * (2 * j), e1 = e0 + 512, o0 = aoff(e0 % kRowsA, e0 / kRowsA), o1 = aoff(e1 % kRowsA, e1 / kRowsA);
+                Ap[o0] = (unsigned short)ph; Ap[kSplitAImg + o0] = (unsigned short)pm; Ap[2 * kSplitAImg + o0] = (unsigned short)pl;
+                Ap[o1] = (unsigned short)(ph >> 16); Ap[kSplitAImg + o1] = (unsigned short)(pm >> 16); Ap[2 * kSplitAImg + o1] = (unsigned short)(pl >> 16);
+            }
+        }
+        __syncthreads();
+        if (ci + 1 < nchunks) gload(cn * kBigKc);                                // next chunk in flight under this chunk's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int xo = ((ks * 2 + h) * kSplitRowsX + 32 * wave + c) * 8;
+            const bf16x8 Bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Xp[xo]));
+            const bf16x8 Bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Xp[kSplitXImg + xo]));
+            const bf16x8 Bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Xp[2 * kSplitXImg + xo]));
+#pragma unroll
+            for (int t = 0; t < MB; ++t) {
+                const int ao = ((ks * 2 + h) * kRowsA + 32 * t + c) * 8;
+                const bf16x8 Ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Ap[ao]));
+                const bf16x8 Am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Ap[kSplitAImg + ao]));
+                const bf16x8 Al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Ap[2 * kSplitAImg + ao]));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[t], 0, 0, 0);   // small terms first
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ C = g.C + (size_t)z * g.zC;
+    const float* __restrict__ bias = g.bias ? g.bias + (size_t)z * g.zBias : nullptr;
+    const float* __restrict__ aux = g.aux ? g.aux + (size_t)z * g.zAux : nullptr;
+    const int tile_n = (int)blockIdx.y * kGemmWaves + wave;
+#pragma unroll
+    for (int t = 0; t < MB; ++t) {                                              // one m-tile at a time through the transposition buffer (the loop's last barrier freed the operand images)
+        if (t) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int e = lane + 64 * i, ml = e & 31, nl = e >> 5;
+            const int rr = (ml & 3) + 4 * (ml >> 3), ll = nl + 32 * ((ml >> 2) & 1);
+            const int mm = m0 + 32 * t + ml, nn = tile_n * 32 + nl;
+            if (mm >= g.M || nn >= g.N) continue;
+            const size_t ci = (size_t)mm * g.sCm + (size_t)nn * g.sCn;
+            C[ci] = gemm_epilogue(g, red[wave][rr][ll], mm, ci, bias, aux);
+        }
+    }
+}
 // two independent contractions in one launch (the weight-gradient and the data-gradient of one layer): blockIdx.z < za runs `a`
 struct GemmPair { GemmArgs a, b; int za; };
 __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_pair_kernel(GemmPair p) {
@@ -248,7 +405,20 @@ hipError_t launch_gemm(GemmArgs g, int Z, hipStream_t s) {
     const bool a_m = g.sAm == 1, a_k = !a_m && g.sAk == 1;                                             // A m-contiguous / k-contiguous
     const bool b_k = g.sBk == 1 && g.vecB && !g.ones_n, b_n = !b_k && g.sBn == 1 && g.sBk != 1;        // B k-contiguous (float4 rows) / n-contiguous
     const dim3 bgrid(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), bblock(64 * kGemmWaves);
-    if (many && a_m && b_k) hipLaunchKernelGGL((sac_gemm_big_kernel<false, false>), bgrid, bblock, 0, s, g);
+    static const bool f32_only = std::getenv("DRIL_GEMM_F32") != nullptr;                                // A/B knob: keep the large contractions on v_mfma_f32_32x32x2_f32
+    const bool split = many && !f32_only && g.K >= 64;
+    if (split && (a_m || a_k) && (b_k || b_n)) {
+        // rows per workgroup: as many as leave >= 2 workgroups per CU (a 4096-row collection forward has 256 blocks of 32 x 256: it stays at MB = 1)
+        int MB = 1;
+        for (int cand = 4; cand > 1; cand >>= 1) if (g.M >= 32 * cand && (long long)((g.M + 32 * cand - 1) / (32 * cand)) * bgrid.y * Z >= 512) { MB = cand; break; }
+        const dim3 sgrid((g.M + 32 * MB - 1) / (32 * MB), bgrid.y, Z);
+#define DRIL_SPLIT_LAUNCH(AKv, BNv) { if (MB == 4) hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 4>), sgrid, bblock, 0, s, g); \
+                                      else if (MB == 2) hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 2>), sgrid, bblock, 0, s, g); \
+                                      else hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 1>), sgrid, bblock, 0, s, g); }
+        if (a_m && b_k) DRIL_SPLIT_LAUNCH(false, false) else if (a_k && b_k) DRIL_SPLIT_LAUNCH(true, false) else if (a_m && b_n) DRIL_SPLIT_LAUNCH(false, true) else DRIL_SPLIT_LAUNCH(true, true)
+#undef DRIL_SPLIT_LAUNCH
+    }
+    else if (many && a_m && b_k) hipLaunchKernelGGL((sac_gemm_big_kernel<false, false>), bgrid, bblock, 0, s, g);
     else if (many && a_k && b_k) hipLaunchKernelGGL((sac_gemm_big_kernel<true, false>), bgrid, bblock, 0, s, g);
     else if (many && a_m && b_n) hipLaunchKernelGGL((sac_gemm_big_kernel<false, true>), bgrid, bblock, 0, s, g);
     else if (many && a_k && b_n) hipLaunchKernelGGL((sac_gemm_big_kernel<true, true>), bgrid, bblock, 0, s, g);
