@@ -406,7 +406,8 @@ hipError_t launch_gemm(GemmArgs g, int Z, hipStream_t s) {
     const bool b_k = g.sBk == 1 && g.vecB && !g.ones_n, b_n = !b_k && g.sBn == 1 && g.sBk != 1;        // B k-contiguous (float4 rows) / n-contiguous
     const dim3 bgrid(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), bblock(64 * kGemmWaves);
     static const bool f32_only = std::getenv("DRIL_GEMM_F32") != nullptr;                                // A/B knob: keep the large contractions on v_mfma_f32_32x32x2_f32
-    const bool split = many && !f32_only && g.K >= 64;
+    static const bool split_all = std::getenv("DRIL_GEMM_SPLIT") != nullptr;                              // A/B knob: also for callers that did not ask (SAC)
+    const bool split = many && !f32_only && (g.allow_split || split_all) && g.K >= 64;
     if (split && (a_m || a_k) && (b_k || b_n)) {
         // rows per workgroup: as many as leave >= 2 workgroups per CU (a 4096-row collection forward has 256 blocks of 32 x 256: it stays at MB = 1)
         int MB = 1;

@@ -16,6 +16,9 @@ namespace dril {
 
 namespace {
 
+// the generic path's contractions may use the bf16-split form of the LDS-tiled kernel (dril_gemm.hip)
+GemmArgs gargs() { GemmArgs g = gemm_args(); g.allow_split = 1; return g; }
+
 constexpr int kMaxOut = 64;
 constexpr float kLog2PiG = 1.8378770664093453f;
 
@@ -32,15 +35,15 @@ struct Carver { float* p; size_t used = 0; float* take(size_t n) { float* r = p 
 
 // out[n][O] = net(X[n][in]) with hidden activations kept (h1[n][H1], h2[n][H2]); activations are (features x n) column-major = one row per sample
 hipError_t mlp_forward(const float* P, NetOff off, int in, int H1, int H2, int O, const float* X, int n, float* h1, float* h2, float* out, hipStream_t s) {
-    GemmArgs g = gemm_args();                                                       // h1 = tanh(W1 x + b1), Lux.Dense layer_helpers.jl:33-41
+    GemmArgs g = gargs();                                                       // h1 = tanh(W1 x + b1), Lux.Dense layer_helpers.jl:33-41
     g.A = P + off.w1; g.sAm = 1; g.sAk = H1; g.B = X; g.sBk = 1; g.sBn = in; g.C = h1; g.sCm = 1; g.sCn = H1; g.bias = P + off.b1;
     g.M = H1; g.N = n; g.K = in; g.epi = EPI_TANH;
     hipError_t e = launch_gemm(g, 1, s); if (e != hipSuccess) return e;
-    g = gemm_args();                                                                // h2 = tanh(W2 h1 + b2)
+    g = gargs();                                                                // h2 = tanh(W2 h1 + b2)
     g.A = P + off.w2; g.sAm = 1; g.sAk = H2; g.B = h1; g.sBk = 1; g.sBn = H1; g.C = h2; g.sCm = 1; g.sCn = H2; g.bias = P + off.b2;
     g.M = H2; g.N = n; g.K = H1; g.epi = EPI_TANH;
     e = launch_gemm(g, 1, s); if (e != hipSuccess) return e;
-    g = gemm_args();                                                                // out = W3 h2 + b3
+    g = gargs();                                                                // out = W3 h2 + b3
     g.A = P + off.w3; g.sAm = 1; g.sAk = O; g.B = h2; g.sBk = 1; g.sBn = H2; g.C = out; g.sCm = 1; g.sCn = O; g.bias = P + off.b3;
     g.M = O; g.N = n; g.K = H2; g.epi = EPI_NONE;
     return launch_gemm(g, 1, s);
@@ -52,15 +55,15 @@ hipError_t mlp_forward(const float* P, NetOff off, int in, int H1, int H2, int O
 hipError_t mlp_forward_both(const float* P, NetOff actor, NetOff critic, int in, int H1, int H2, int O, const float* X, int n, float* h1, float* h2,
                             float* out, float* v, hipStream_t s) {
     const long long zP = (long long)critic.w1 - actor.w1;                           // same layout in both nets up to the output layer
-    GemmArgs g = gemm_args();
+    GemmArgs g = gargs();
     g.A = P + actor.w1; g.sAm = 1; g.sAk = H1; g.zA = zP; g.B = X; g.sBk = 1; g.sBn = in; g.zB = 0; g.C = h1; g.sCm = 1; g.sCn = H1; g.zC = (long long)n * H1;
     g.bias = P + actor.b1; g.zBias = zP; g.M = H1; g.N = n; g.K = in; g.epi = EPI_TANH;
     hipError_t e = launch_gemm(g, 2, s); if (e != hipSuccess) return e;
-    g = gemm_args();
+    g = gargs();
     g.A = P + actor.w2; g.sAm = 1; g.sAk = H2; g.zA = zP; g.B = h1; g.sBk = 1; g.sBn = H1; g.zB = (long long)n * H1; g.C = h2; g.sCm = 1; g.sCn = H2; g.zC = (long long)n * H2;
     g.bias = P + actor.b2; g.zBias = zP; g.M = H2; g.N = n; g.K = H1; g.epi = EPI_TANH;
     e = launch_gemm(g, 2, s); if (e != hipSuccess) return e;
-    GemmArgs a = gemm_args(), c = gemm_args();
+    GemmArgs a = gargs(), c = gargs();
     a.A = P + actor.w3; a.sAm = 1; a.sAk = O; a.B = h2; a.sBk = 1; a.sBn = H2; a.C = out; a.sCm = 1; a.sCn = O; a.bias = P + actor.b3; a.M = O; a.N = n; a.K = H2;
     c.A = P + critic.w3; c.sAm = 1; c.sAk = 1; c.B = h2 + (size_t)n * H2; c.sBk = 1; c.sBn = H2; c.C = v; c.sCm = 1; c.sCn = 1; c.bias = P + critic.b3; c.M = 1; c.N = n; c.K = H2;
     if (n <= 8192) return launch_gemm_pair(a, 1, c, 1, s);
@@ -253,21 +256,21 @@ BackwardPlan plan_backward(const float* P, NetOff off, int in, int H1, int H2, i
                            float* dz2, float* dz1, int64_t R, int Cr, int G, float* slabs, int slab_stride) {
     const int base = off.w1;                                                         // slab offsets are relative to the net's first parameter
     BackwardPlan p;
-    GemmArgs w = gemm_args();                                                        // [dW3 | db3] = dOut . [h2' | 1]   (b sits right behind the column-major W)
+    GemmArgs w = gargs();                                                        // [dW3 | db3] = dOut . [h2' | 1]   (b sits right behind the column-major W)
     w.A = dOut; w.sAm = 1; w.sAk = O; w.zA = (long long)Cr * O; w.B = h2; w.sBk = H2; w.sBn = 1; w.zB = (long long)Cr * H2; w.ones_n = 1;
     w.C = slabs + (off.w3 - base); w.sCm = 1; w.sCn = O; w.zC = slab_stride; w.M = O; w.N = H2 + 1; w.K = Cr;
     p.g[0] = w; p.Z[0] = G;
-    GemmArgs g = gemm_args();                                                        // dz2 = (W3' dOut) .* (1 - h2^2)
+    GemmArgs g = gargs();                                                        // dz2 = (W3' dOut) .* (1 - h2^2)
     g.A = P + off.w3; g.sAm = O; g.sAk = 1; g.B = dOut; g.sBk = 1; g.sBn = O; g.C = dz2; g.sCm = 1; g.sCn = H2; g.aux = h2; g.M = H2; g.N = (int)R; g.K = O; g.epi = EPI_MASK_TANH;
     p.g[1] = g; p.Z[1] = 1;
-    w = gemm_args();                                                                 // [dW2 | db2] = dz2 . [h1' | 1]
+    w = gargs();                                                                 // [dW2 | db2] = dz2 . [h1' | 1]
     w.A = dz2; w.sAm = 1; w.sAk = H2; w.zA = (long long)Cr * H2; w.B = h1; w.sBk = H1; w.sBn = 1; w.zB = (long long)Cr * H1; w.ones_n = 1;
     w.C = slabs + (off.w2 - base); w.sCm = 1; w.sCn = H2; w.zC = slab_stride; w.M = H2; w.N = H1 + 1; w.K = Cr;
     p.g[2] = w; p.Z[2] = G;
-    g = gemm_args();                                                                 // dz1 = (W2' dz2) .* (1 - h1^2)
+    g = gargs();                                                                 // dz1 = (W2' dz2) .* (1 - h1^2)
     g.A = P + off.w2; g.sAm = H2; g.sAk = 1; g.B = dz2; g.sBk = 1; g.sBn = H2; g.C = dz1; g.sCm = 1; g.sCn = H1; g.aux = h1; g.M = H1; g.N = (int)R; g.K = H2; g.epi = EPI_MASK_TANH;
     p.g[3] = g; p.Z[3] = 1;
-    w = gemm_args();                                                                 // [dW1 | db1] = dz1 . [x' | 1]
+    w = gargs();                                                                 // [dW1 | db1] = dz1 . [x' | 1]
     w.A = dz1; w.sAm = 1; w.sAk = H1; w.zA = (long long)Cr * H1; w.B = X; w.sBk = in; w.sBn = 1; w.zB = (long long)Cr * in; w.ones_n = 1;
     w.C = slabs + (off.w1 - base); w.sCm = 1; w.sCn = H1; w.zC = slab_stride; w.M = H1; w.N = in + 1; w.K = Cr;
     p.g[4] = w; p.Z[4] = G;
