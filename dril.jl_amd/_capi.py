@@ -70,7 +70,8 @@ class DrilSacConfig(C.Structure):
         ("train_freq", C.c_int32), ("gradient_steps", C.c_int32), ("target_update_interval", C.c_int32),
         ("auto_ent_coef", C.c_int32), ("ent_coef_init", C.c_float), ("auto_target_entropy", C.c_int32), ("target_entropy", C.c_float),
         ("learning_rate", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
-        ("seed", C.c_uint64), ("device", C.c_int32), ("profile_events", C.c_int32), ("reserved", C.c_int32 * 8),
+        ("seed", C.c_uint64), ("device", C.c_int32), ("profile_events", C.c_int32),
+        ("ext_obs_dim", C.c_int32), ("ext_action_dim", C.c_int32), ("ext_action_low", C.c_float), ("ext_action_high", C.c_float), ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -190,6 +191,7 @@ _SAC_SIG = {
     "predict_actions": (C.c_int32, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     "predict_q": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_int32, _P]),
     "collect_rollout": (C.c_int32, [_P, C.c_int32, C.c_int32, _PD]),
+    "ext_push": (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "debug_set_collect_noise": (C.c_int32, [_P, _P, C.c_size_t]),
     "replay_size": (C.c_int64, [_P]),
     "replay_capacity": (C.c_int64, [_P]),

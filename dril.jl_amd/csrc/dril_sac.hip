@@ -39,7 +39,7 @@ thread_local std::string g_sac_create_error;
 // =================================================================================================================
 // SquashedDiagGaussian (squashedDiagGaussian.jl:24-46) — per-sample scalar math, accurate libm
 // =================================================================================================================
-constexpr int kMaxA = 8;
+constexpr int kMaxA = 16;
 constexpr float kLog2Pi = 1.8378770664093453f;
 __device__ inline float softplus_f(float x) { return log1pf(expf(-fabsf(x))) + (x > 0.f ? x : 0.f); }   // Lux.softplus
 // a = tanh(mu + exp(ls) * noise); returns logpdf(d, a) (:36-46), g = atanh(clamp(a))
@@ -391,7 +391,7 @@ struct dril_sac_handle {
     SacScalars* sc = nullptr; float* stats = nullptr; float* stats_out = nullptr; int stats_cap = 0;
     double *ssq_c = nullptr, *ssq_a = nullptr; unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
     float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
-    float target_entropy = 0, act_hi = 2.0f;   // bound of the agent-facing action space: Box(-2,2), Box(-1,1) under ScalingWrapperEnv
+    float target_entropy = 0, act_lo = -2.0f, act_hi = 2.0f; bool external = false;   // bounds of the agent-facing action space: Box(-2,2), Box(-1,1) under ScalingWrapperEnv
     // env
     float* state = nullptr; int32_t* step_count = nullptr; uint32_t *episode = nullptr, *gstep = nullptr; float* disc_returns = nullptr;
     float *obs_cur = nullptr, *obs_nxt = nullptr, *e_rew = nullptr, *e_tobs = nullptr, *e_raw = nullptr, *e_envact = nullptr; uint8_t *e_term = nullptr, *e_trunc = nullptr;
@@ -425,6 +425,7 @@ int sfail(dril_sac_handle* h, int code, const std::string& msg) { if (h) h->err 
         return sfail(h, DRIL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
 #define SNEED(h) do { if (!(h)) return sfail(nullptr, DRIL_ERR_NOT_INITIALISED, "null handle"); (void)hipSetDevice((h)->cfg.device); } while (0)
 #define SDO(expr) do { int _rc = (expr); if (_rc != DRIL_OK) return _rc; } while (0)
+#define S_NOT_EXTERNAL(h, what) do { if ((h)->external) return sfail(h, DRIL_ERR_UNSUPPORTED, what ": the envs of DRIL_ENV_EXTERNAL live on the host (dril_sac_predict_actions + dril_sac_ext_push)"); } while (0)
 
 template <typename T> hipError_t smalloc(T** p, size_t n) {
     hipError_t e = hipMalloc((void**)p, (n ? n : 1) * sizeof(T));
@@ -442,7 +443,7 @@ int gemm(dril_sac_handle* h, GemmArgs g, int Z) {
 }
 
 // One net = {W1 b1 W2 b2 W3 b3} at `P + off` (+ z * zP for the second critic); activations are (features x n) column-major
-struct NetBufs { float* h1; float* h2; float* out; long long zh, zo; };   // [Z][n][H], [Z][n][O]
+struct NetBufs { float* h1; float* h2; float* out; long long zh, zo, zh2; };   // [Z][n][H1], [Z][n][O], [Z][n][H2]: batch strides of h1 / out / h2 (zh2 == 0: H1 == H2 shapes, use zh)
 int net_forward(dril_sac_handle* h, const float* P, NetOff off, long long zP, int in, int O, const float* X, int ldx, long long zX, int n,
                 NetBufs b, int Z, int zdivX = 1) {
     const int H1 = h->H1, H2 = h->H2, act = h->cfg.activation ? EPI_RELU : EPI_TANH;
@@ -452,10 +453,10 @@ int net_forward(dril_sac_handle* h, const float* P, NetOff off, long long zP, in
     SDO(gemm(h, g, Z));
     g = gemm_args();                                                                // h2 = act(W2 h1 + b2)
     g.A = P + off.w2; g.sAm = 1; g.sAk = H2; g.zA = zP; g.B = b.h1; g.sBk = 1; g.sBn = H1; g.zB = b.zh;
-    g.C = b.h2; g.sCm = 1; g.sCn = H2; g.zC = b.zh; g.bias = P + off.b2; g.zBias = zP; g.M = H2; g.N = n; g.K = H1; g.epi = act;
+    g.C = b.h2; g.sCm = 1; g.sCn = H2; g.zC = b.zh2 ? b.zh2 : b.zh; g.bias = P + off.b2; g.zBias = zP; g.M = H2; g.N = n; g.K = H1; g.epi = act;
     SDO(gemm(h, g, Z));
     g = gemm_args();                                                                // out = W3 h2 + b3
-    g.A = P + off.w3; g.sAm = 1; g.sAk = O; g.zA = zP; g.B = b.h2; g.sBk = 1; g.sBn = H2; g.zB = b.zh;
+    g.A = P + off.w3; g.sAm = 1; g.sAk = O; g.zA = zP; g.B = b.h2; g.sBk = 1; g.sBn = H2; g.zB = b.zh2 ? b.zh2 : b.zh;
     g.C = b.out; g.sCm = 1; g.sCn = O; g.zC = b.zo; g.bias = P + off.b3; g.zBias = zP; g.M = O; g.N = n; g.K = H2; g.epi = EPI_NONE;
     return gemm(h, g, Z);
 }
@@ -466,11 +467,11 @@ int net_backward(dril_sac_handle* h, const float* P, NetOff off, long long zP, i
     const long long zd = (long long)h->nq * H1;   // dz buffers are [2][nq][H] (H1 == H2 layouts are separate buffers)
     const bool big = (long long)((H2 + 31) / 32) * ((n + 31) / 32) * Z >= 2048;          // large batches: one launch per contraction (the pair kernel is the split-K shape)
     GemmArgs w, g;
-    w = gemm_args(); w.A = dOut; w.sAm = 1; w.sAk = O; w.zA = b.zo; w.B = b.h2; w.sBk = H2; w.sBn = 1; w.zB = b.zh; w.ones_n = 1;      // [dW3 | db3] = dOut . [h2' | 1]
+    w = gemm_args(); w.A = dOut; w.sAm = 1; w.sAk = O; w.zA = b.zo; w.B = b.h2; w.sBk = H2; w.sBn = 1; w.zB = b.zh2 ? b.zh2 : b.zh; w.ones_n = 1;      // [dW3 | db3] = dOut . [h2' | 1]
     w.C = G ? G + off.w3 : nullptr; w.sCm = 1; w.sCn = O; w.zC = zP; w.M = O; w.N = H2 + 1; w.K = n;
     g = gemm_args();                                                                // dz2 = (W3' dOut) .* act'(h2)
     g.A = P + off.w3; g.sAm = O; g.sAk = 1; g.zA = zP; g.B = dOut; g.sBk = 1; g.sBn = O; g.zB = b.zo;
-    g.C = h->dz2; g.sCm = 1; g.sCn = H2; g.zC = (long long)h->nq * H2; g.aux = b.h2; g.zAux = b.zh; g.M = H2; g.N = n; g.K = O; g.epi = mask;
+    g.C = h->dz2; g.sCm = 1; g.sCn = H2; g.zC = (long long)h->nq * H2; g.aux = b.h2; g.zAux = b.zh2 ? b.zh2 : b.zh; g.M = H2; g.N = n; g.K = O; g.epi = mask;
     if (G && !big) SDO(gemm_pair(h, w, Z, g, Z)); else { if (G) SDO(gemm(h, w, Z)); SDO(gemm(h, g, Z)); }
     w = gemm_args(); w.A = h->dz2; w.sAm = 1; w.sAk = H2; w.zA = (long long)h->nq * H2; w.B = b.h1; w.sBk = H1; w.sBn = 1; w.zB = b.zh; w.ones_n = 1;   // [dW2 | db2] = dz2 . [h1' | 1]
     w.C = G ? G + off.w2 : nullptr; w.sCm = 1; w.sCn = H2; w.zC = zP; w.M = H2; w.N = H1 + 1; w.K = n;
@@ -485,8 +486,8 @@ int net_backward(dril_sac_handle* h, const float* P, NetOff off, long long zP, i
     if (G && dX && !big) SDO(gemm_pair(h, w, Z, g, Z)); else { if (G) SDO(gemm(h, w, Z)); if (dX) SDO(gemm(h, g, Z)); }
     return DRIL_OK;
 }
-NetBufs actor_bufs(dril_sac_handle* h) { return NetBufs{h->ah1, h->ah2, h->mu, 0, 0}; }
-NetBufs q_bufs(dril_sac_handle* h, float* h1, float* h2, float* out) { return NetBufs{h1, h2, out, (long long)h->nq * h->H1, (long long)h->nq}; }
+NetBufs actor_bufs(dril_sac_handle* h) { return NetBufs{h->ah1, h->ah2, h->mu, 0, 0, 0}; }
+NetBufs q_bufs(dril_sac_handle* h, float* h1, float* h2, float* out) { return NetBufs{h1, h2, out, (long long)h->nq * h->H1, (long long)h->nq, (long long)h->nq * h->H2}; }
 
 int ssync(dril_sac_handle* h) { SHIP(h, hipStreamSynchronize(h->stream)); return DRIL_OK; }
 
@@ -552,7 +553,7 @@ int ensure_obs(dril_sac_handle* h) {
 int collect_step(dril_sac_handle* h, int use_random, const float* inj_noise) {
     const int E = h->cfg.n_envs, D = h->D, A = h->A;
     if (!use_random) SDO(net_forward(h, h->params, h->actor, 0, D, A, h->obs_cur, D, 0, E, actor_bufs(h), 1));          // predict_actions_raw :55
-    CollectHeadArgs ca{E, A, use_random, h->mu, h->params + h->log_std_off, inj_noise, h->gstep, h->env_seed0, -h->act_hi, h->act_hi, h->e_raw, h->e_envact};
+    CollectHeadArgs ca{E, A, use_random, h->mu, h->params + h->log_std_off, inj_noise, h->gstep, h->env_seed0, h->act_lo, h->act_hi, h->e_raw, h->e_envact};
     hipLaunchKernelGGL(sac_collect_head_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, ca);
     MonitorArgs mon{nullptr, nullptr, nullptr, nullptr, nullptr};
     SHIP(h, launch_env_step(h->cfg.env_kind, E, h->env_seed0, h->cfg.episode_len, 0, 0, h->e_envact, h->state, h->step_count, h->episode, h->gstep,
@@ -651,7 +652,7 @@ int params_from_device(dril_sac_handle* h, float* host, const float* dev) {
 // exported entry points (include/dril_sac.h)
 // =================================================================================================================
 DRIL_EXPORT int32_t dril_sac_config_default(dril_sac_config* c, int32_t env_kind) {
-    if (!c || (env_kind != DRIL_ENV_PENDULUM && env_kind != DRIL_ENV_PENDULUM_SCALED)) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "SAC needs a Box action space (sac.jl:74): env_kind must be DRIL_ENV_PENDULUM[_SCALED]");
+    if (!c || (env_kind != DRIL_ENV_PENDULUM && env_kind != DRIL_ENV_PENDULUM_SCALED && env_kind != DRIL_ENV_EXTERNAL)) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "SAC needs a Box action space (sac.jl:74): env_kind must be DRIL_ENV_PENDULUM[_SCALED] or DRIL_ENV_EXTERNAL");
     memset(c, 0, sizeof(*c));
     c->abi_version = DRIL_SAC_ABI_VERSION; c->env_kind = env_kind; c->n_envs = 1; c->episode_len = 200;
     c->hidden1 = 512; c->hidden2 = 512; c->activation = 1;
@@ -682,8 +683,11 @@ DRIL_EXPORT int32_t dril_sac_destroy(dril_sac_handle* h) {
 DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle** out) {
     if (!cfg || !out) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "null config / out pointer");
     if (cfg->abi_version != DRIL_SAC_ABI_VERSION) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "dril_sac_config.abi_version mismatch");
-    if (cfg->env_kind != DRIL_ENV_PENDULUM && cfg->env_kind != DRIL_ENV_PENDULUM_SCALED) return sfail(nullptr, DRIL_ERR_UNSUPPORTED, "SAC needs a Box action space (sac.jl:74): only DRIL_ENV_PENDULUM[_SCALED]");
-    if (cfg->n_envs <= 0 || cfg->episode_len <= 0 || cfg->batch_size <= 0 || cfg->buffer_capacity < cfg->n_envs || cfg->train_freq <= 0 || cfg->target_update_interval <= 0)
+    const bool ext = cfg->env_kind == DRIL_ENV_EXTERNAL;
+    if (!ext && cfg->env_kind != DRIL_ENV_PENDULUM && cfg->env_kind != DRIL_ENV_PENDULUM_SCALED) return sfail(nullptr, DRIL_ERR_UNSUPPORTED, "SAC needs a Box action space (sac.jl:74): DRIL_ENV_PENDULUM[_SCALED] or DRIL_ENV_EXTERNAL");
+    if (ext && (cfg->ext_obs_dim < 1 || cfg->ext_obs_dim > 1024 || cfg->ext_action_dim < 1 || cfg->ext_action_dim > kMaxA || !(cfg->ext_action_low < cfg->ext_action_high)))
+        return sfail(nullptr, DRIL_ERR_INVALID_ARG, "DRIL_ENV_EXTERNAL: ext_obs_dim 1..1024, ext_action_dim 1..16, ext_action_low < ext_action_high");
+    if (cfg->n_envs <= 0 || (!ext && cfg->episode_len <= 0) || cfg->batch_size <= 0 || cfg->buffer_capacity < cfg->n_envs || cfg->train_freq <= 0 || cfg->target_update_interval <= 0)
         return sfail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs, episode_len, batch_size, train_freq, target_update_interval must be positive and buffer_capacity >= n_envs");
     if (cfg->hidden1 <= 0 || cfg->hidden2 <= 0 || cfg->hidden1 % 4 || cfg->hidden2 % 4) return sfail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden dims must be positive multiples of 4");
     if (cfg->activation != 0 && cfg->activation != 1) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "activation: 0 tanh, 1 relu");
@@ -694,13 +698,14 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
 #define CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_sac_destroy(h); return sfail(nullptr, DRIL_ERR_HIP, m); } } while (0)
     CHK(hipSetDevice(cfg->device));
     CHK(hipStreamCreate(&h->stream));
-    const int D = h->D = 3, A = h->A = 1, S = h->S = 2, H1 = h->H1 = cfg->hidden1, H2 = h->H2 = cfg->hidden2, E = cfg->n_envs, B = cfg->batch_size, W = D + A;
+    const int D = h->D = ext ? cfg->ext_obs_dim : 3, A = h->A = ext ? cfg->ext_action_dim : 1, S = h->S = ext ? 0 : 2, H1 = h->H1 = cfg->hidden1, H2 = h->H2 = cfg->hidden2, E = cfg->n_envs, B = cfg->batch_size, W = D + A;
     h->Pa = D * H1 + H1 + H1 * H2 + H2 + H2 * A + A; h->Pq = W * H1 + H1 + H1 * H2 + H2 + H2 + 1; h->P = h->Pa + 2 * h->Pq + A;
     h->actor = net_off(0, D, H1, H2, A); h->Pqd = round4(h->Pq); h->q0 = net_off(round4(h->actor.end), W, H1, H2, 1);
     h->log_std_off = h->q0.w1 + 4 * h->Pqd; h->Pd = round4(h->log_std_off + A);      // device layout: actor | q1 | q2 | target q1 | target q2 | log_std
     h->nq = B; h->nmax = std::max(E, 2 * B);
     h->target_entropy = cfg->auto_target_entropy ? -(float)A : cfg->target_entropy;
-    h->act_hi = cfg->env_kind == DRIL_ENV_PENDULUM_SCALED ? 1.0f : 2.0f;
+    h->act_hi = cfg->env_kind == DRIL_ENV_PENDULUM_SCALED ? 1.0f : 2.0f; h->act_lo = -h->act_hi; h->external = ext;
+    if (ext) { h->act_lo = cfg->ext_action_low; h->act_hi = cfg->ext_action_high; }
     CHK(smalloc(&h->params, h->Pd)); CHK(smalloc(&h->adam_m, h->Pd)); CHK(smalloc(&h->adam_v, h->Pd));
     h->target = h->params + h->q0.w1 + 2 * h->Pqd;   // the targets sit right behind the critics so that one launch runs all four Q nets (blockIdx.z stride Pqd)
     CHK(smalloc(&h->g_critic, h->Pd)); CHK(smalloc(&h->g_actor, h->Pd)); CHK(smalloc(&h->sc, 1)); CHK(smalloc(&h->stats, 8));
@@ -774,14 +779,14 @@ DRIL_EXPORT int32_t dril_sac_reset_optimizer(dril_sac_handle* h) {
 }
 
 DRIL_EXPORT int32_t dril_sac_env_reset(dril_sac_handle* h, uint64_t seed) {
-    SNEED(h);
+    SNEED(h); S_NOT_EXTERNAL(h, "dril_sac_env_reset");
     h->env_seed0 = seed;
     SHIP(h, launch_env_reset(h->cfg.env_kind, h->cfg.n_envs, seed, h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->stream));
     h->env_ready = true; h->obs_valid = false;
     return ssync(h);
 }
 DRIL_EXPORT int32_t dril_sac_env_observe(dril_sac_handle* h, float* host_obs) {
-    SNEED(h); if (!host_obs) return sfail(h, DRIL_ERR_INVALID_ARG, "null observation buffer");
+    SNEED(h); S_NOT_EXTERNAL(h, "dril_sac_env_observe"); if (!host_obs) return sfail(h, DRIL_ERR_INVALID_ARG, "null observation buffer");
     SDO(ensure_obs(h)); SDO(ssync(h));
     SHIP(h, hipMemcpy(host_obs, h->obs_cur, (size_t)h->cfg.n_envs * h->D * 4, hipMemcpyDeviceToHost));
     return DRIL_OK;
@@ -809,7 +814,7 @@ DRIL_EXPORT int32_t dril_sac_action_log_prob(dril_sac_handle* h, const float* ob
         const int n = (int)std::min<int64_t>(h->nmax, batch - o);
         SDO(actor_chunk(h, obs + o * h->D, noise ? noise + o * h->A : nullptr, n, 0, o));
         hipLaunchKernelGGL(sac_squash_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, h->A, h->mu, h->params + h->log_std_off, h->s_noise, 0,
-                           -h->act_hi, h->act_hi, h->s_out, h->s_out2, (float*)nullptr);
+                           h->act_lo, h->act_hi, h->s_out, h->s_out2, (float*)nullptr);
         SDO(ssync(h));
         if (actions) SHIP(h, hipMemcpy(actions + o * h->A, h->s_out, (size_t)n * h->A * 4, hipMemcpyDeviceToHost));
         if (logp) SHIP(h, hipMemcpy(logp + o, h->s_out2, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -822,7 +827,7 @@ DRIL_EXPORT int32_t dril_sac_predict_actions(dril_sac_handle* h, const float* ob
         const int n = (int)std::min<int64_t>(h->nmax, batch - o);
         SDO(actor_chunk(h, obs + o * h->D, noise ? noise + o * h->A : nullptr, n, deterministic, o));
         hipLaunchKernelGGL(sac_squash_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, h->A, h->mu, h->params + h->log_std_off, h->s_noise, deterministic,
-                           -h->act_hi, h->act_hi, h->s_out, (float*)nullptr, h->s_out2);
+                           h->act_lo, h->act_hi, h->s_out, (float*)nullptr, h->s_out2);
         SDO(ssync(h));
         if (raw) SHIP(h, hipMemcpy(raw + o * h->A, h->s_out, (size_t)n * h->A * 4, hipMemcpyDeviceToHost));
         if (env) SHIP(h, hipMemcpy(env + o * h->A, h->s_out2, (size_t)n * h->A * 4, hipMemcpyDeviceToHost));
@@ -855,7 +860,32 @@ DRIL_EXPORT int32_t dril_sac_debug_set_collect_noise(dril_sac_handle* h, const f
     return DRIL_OK;
 }
 DRIL_EXPORT int32_t dril_sac_collect_rollout(dril_sac_handle* h, int32_t n_steps, int32_t use_random_actions, double* fps) {
-    SNEED(h); return collect(h, n_steps, use_random_actions != 0, fps);
+    SNEED(h); S_NOT_EXTERNAL(h, "dril_sac_collect_rollout"); return collect(h, n_steps, use_random_actions != 0, fps);
+}
+// one env step of the caller's host envs into the ring: the same push kernel as the device collection (truncated envs store their terminal observation)
+DRIL_EXPORT int32_t dril_sac_ext_push(dril_sac_handle* h, const float* obs, const float* stored_actions, const float* rewards, const uint8_t* terminated,
+                                      const uint8_t* truncated, const float* next_obs, const float* terminal_obs) {
+    SNEED(h);
+    if (!h->external) return sfail(h, DRIL_ERR_UNSUPPORTED, "dril_sac_ext_push: the handle was not created with DRIL_ENV_EXTERNAL");
+    if (!obs || !stored_actions || !rewards || !terminated || !truncated || !next_obs) return sfail(h, DRIL_ERR_INVALID_ARG, "dril_sac_ext_push: null pointer");
+    const size_t E = h->cfg.n_envs, D = h->D, A = h->A;
+    bool any_trunc = false; for (size_t e = 0; e < E; ++e) any_trunc = any_trunc || truncated[e] != 0;
+    if (any_trunc && !terminal_obs) return sfail(h, DRIL_ERR_INVALID_ARG, "dril_sac_ext_push: truncated envs need terminal_obs");
+    SHIP(h, hipMemcpyAsync(h->obs_cur, obs, E * D * 4, hipMemcpyHostToDevice, h->stream));
+    SHIP(h, hipMemcpyAsync(h->obs_nxt, next_obs, E * D * 4, hipMemcpyHostToDevice, h->stream));
+    SHIP(h, hipMemcpyAsync(h->e_raw, stored_actions, E * A * 4, hipMemcpyHostToDevice, h->stream));
+    SHIP(h, hipMemcpyAsync(h->e_rew, rewards, E * 4, hipMemcpyHostToDevice, h->stream));
+    SHIP(h, hipMemcpyAsync(h->e_term, terminated, E, hipMemcpyHostToDevice, h->stream));
+    SHIP(h, hipMemcpyAsync(h->e_trunc, truncated, E, hipMemcpyHostToDevice, h->stream));
+    if (any_trunc) SHIP(h, hipMemcpyAsync(h->e_tobs, terminal_obs, E * D * 4, hipMemcpyHostToDevice, h->stream));
+    const long long tail = (h->head + h->size) % h->cap;
+    PushArgs pa{(int)E, (int)D, (int)A, h->cap, tail, h->obs_cur, h->e_raw, h->e_rew, h->e_tobs, h->obs_nxt, h->e_term, h->e_trunc,
+                h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc};
+    hipLaunchKernelGGL(sac_push_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, h->stream, pa);
+    SHIP(h, hipGetLastError());
+    const long long over = h->size + (long long)E - h->cap;                                       // CircularBuffer: overwrite the oldest
+    if (over > 0) { h->head = (h->head + over) % h->cap; h->size = h->cap; } else h->size += (long long)E;
+    return ssync(h);                                                                              // the caller's arrays are pageable host memory: drain before returning
 }
 
 DRIL_EXPORT int64_t dril_sac_replay_size(const dril_sac_handle* h) { return h ? h->size : 0; }
@@ -928,7 +958,7 @@ DRIL_EXPORT int32_t dril_sac_get_last_grads(dril_sac_handle* h, float* gc, float
 
 DRIL_EXPORT int32_t dril_sac_train(dril_sac_handle* h, int64_t max_steps, dril_sac_stats* stats, int64_t stats_capacity, int64_t* n_updates_done,
                                    double* fps, int64_t fps_capacity, int32_t* iterations_done, int64_t* total_steps) {
-    SNEED(h);
+    SNEED(h); S_NOT_EXTERNAL(h, "dril_sac_train");
     const int64_t E = h->cfg.n_envs, tf = h->cfg.train_freq;
     const int64_t total_start = h->cfg.start_steps > 0 ? h->cfg.start_steps : tf * E;            // sac.jl:436
     const int64_t adjusted = std::max<int64_t>(1, total_start / E) * E;                           // :437

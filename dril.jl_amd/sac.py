@@ -135,11 +135,18 @@ def sac_unflatten_params(flat: np.ndarray, like: dict) -> dict:
 
 def make_sac_config(env, n_envs: int, alg: SAC, layer: SACLayer, *, seed: int = 42, device: int = 0,
                     profile_events: bool = False) -> DrilSacConfig:
-    if not isinstance(env, (PendulumEnv, ScalingWrapperEnv)):
+    external = getattr(env, "kind", None) == capi.ENV_EXTERNAL
+    if not external and not isinstance(env, (PendulumEnv, ScalingWrapperEnv)):
         raise NotImplementedError("SAC needs a Box action space (sac.jl:74); the device env with one is Pendulum-v1 (optionally under ScalingWrapperEnv)")
     c = DrilSacConfig()
     c.abi_version = capi.SAC_ABI_VERSION
-    c.env_kind, c.n_envs, c.episode_len = env.kind, n_envs, env.max_steps
+    c.env_kind, c.n_envs, c.episode_len = env.kind, n_envs, getattr(env, "max_steps", 0)
+    if external:     # host envs: the spaces travel in the config (include/dril_sac.h)
+        osp, asp = env.observation_space(), env.action_space()
+        lo, hi = np.unique(np.asarray(asp.low, np.float32)), np.unique(np.asarray(asp.high, np.float32))
+        if lo.size != 1 or hi.size != 1:
+            raise NotImplementedError("DRIL_ENV_EXTERNAL SAC: one (low, high) pair for all action dimensions (wrap the env in a ScalingWrapperEnv-style Box(-1, 1))")
+        c.ext_obs_dim, c.ext_action_dim, c.ext_action_low, c.ext_action_high = len(osp.low), len(asp.low), float(lo[0]), float(hi[0])
     c.hidden1, c.hidden2 = layer.hidden_dims
     c.activation = {"tanh": 0, "relu": 1}[layer.activation]
     c.buffer_capacity, c.start_steps, c.batch_size = alg.buffer_capacity, alg.start_steps, alg.batch_size
@@ -276,6 +283,13 @@ class SacHandle:
         self._chk(self._f("collect_rollout")(self._h, n_steps, int(use_random_actions), C.byref(fps)))
         return fps.value
 
+    def ext_push(self, obs, stored_actions, rewards, terminated, truncated, next_obs, terminal_obs=None):
+        """one env step of the caller's host envs into the replay ring (DRIL_ENV_EXTERNAL)"""
+        o, a, r, n = self._f32(obs), self._f32(stored_actions), self._f32(rewards), self._f32(next_obs)
+        te, tr = np.ascontiguousarray(terminated, np.uint8), np.ascontiguousarray(truncated, np.uint8)
+        to = None if terminal_obs is None else self._f32(terminal_obs)
+        self._chk(self._f("ext_push")(self._h, self._p(o), self._p(a), self._p(r), self._p(te), self._p(tr), self._p(n), self._p(to)))
+
     def set_collect_noise(self, noise):
         self._noise = self._f32(noise)       # the oracle keeps the pointer until the next collect call
         self._chk(self._f("debug_set_collect_noise")(self._h, self._p(self._noise), 0 if noise is None else self._noise.size))
@@ -392,6 +406,8 @@ def sac_train_(agent: SACAgent, env, alg: SAC, max_steps: int, *, replay_buffer:
     DeviceParallelEnv over PendulumEnv.  training_stats carries the fields of SACTrainingStats (sac.jl:243-257)."""
     if callbacks:
         raise NotImplementedError("callbacks need the step-granular path; not wired for SAC")
+    if getattr(env, "kind", None) == capi.ENV_EXTERNAL:
+        return _sac_train_host(agent, env, alg, max_steps, replay_buffer)
     t0 = time.perf_counter()
     rb = replay_buffer or ReplayBuffer(env.observation_space(), env.action_space(), alg.buffer_capacity)     # sac.jl:411
     cfg = make_sac_config(env.env, env.n_envs, alg, agent.layer, seed=env.seed, device=env._kw.get("device", 0), profile_events=env._kw.get("profile_events", False))
@@ -416,3 +432,67 @@ def sac_train_(agent: SACAgent, env, alg: SAC, max_steps: int, *, replay_buffer:
     agent.q_target_parameters = h.get_target_params()
     agent.log_ent_coef = h.get_log_ent_coef()
     return agent, rb, ts, {"training_loop": time.perf_counter() - t0, "iterations": iters}
+
+
+def _sac_train_host(agent: SACAgent, env, alg: SAC, max_steps: int, replay_buffer: Optional[ReplayBuffer] = None):
+    """train!(agent, replay_buffer, env, alg::SAC, max_steps) (sac.jl:428-559) over the caller's own envs (HostParallelEnv): the envs step on the
+    host, the policy, the replay ring and every gradient step live on the device (DRIL_ENV_EXTERNAL: dril_sac_predict_actions + dril_sac_ext_push)"""
+    t0 = time.perf_counter()
+    E, asp = env.n_envs, env.action_space()
+    rb = replay_buffer or ReplayBuffer(env.observation_space(), asp, alg.buffer_capacity)
+    cfg = make_sac_config(env, E, alg, agent.layer, seed=env.seed, device=env._kw.get("device", 0), profile_events=env._kw.get("profile_events", False))
+    h = rb.handle if rb.handle is not None else SacHandle(cfg)
+    rb.handle = h
+    h.set_params(sac_flatten_params(agent.parameters)); h.set_target_params(agent.q_target_parameters); h.set_log_ent_coef(agent.log_ent_coef)
+    rng = np.random.default_rng(env.seed)
+    low, high = np.float32(asp.low[0]), np.float32(asp.high[0])
+    total_start = alg.start_steps if alg.start_steps > 0 else alg.train_freq * E                    # sac.jl:456-458
+    adjusted = max(1, total_start // E) * E
+    n_steps = adjusted // E
+    iterations = int((max_steps - adjusted) / (alg.train_freq * E)) + 1                             # div truncates toward zero, :462
+    n_updates = get_gradient_steps(alg, alg.train_freq, E)
+    ts = {k: [] for k in _SAC_STAT_KEYS}
+    total = n_upd = 0
+    t_env = t_dev = 0.0
+    obs = np.stack(env.observe())
+    for it in range(max(iterations, 0)):
+        use_random = it == 0 and alg.start_steps > 0                                                # :487
+        a = time.perf_counter()
+        for _ in range(n_steps):                                                                    # collect_trajectories, off_policy_collection.jl:28-96
+            if use_random:
+                stored = env_act = rng.uniform(low, high, (E, h.A)).astype(np.float32)              # rand(rng, act_space): env space, stored as is (:50-53,72)
+            else:
+                b = time.perf_counter()
+                stored, env_act = h.predict_actions(obs)                                            # raw squashed action + to_env(TanhScaleAdapter), :55-58
+                t_dev += time.perf_counter() - b
+            rew, term, trunc, infos = env.act_([x.reshape(asp.shape) for x in env_act])             # :60
+            nobs = np.stack(env.observe())                                                          # :61
+            tobs = None
+            if trunc.any():
+                tobs = nobs.copy()
+                for i in np.nonzero(trunc)[0]:
+                    tobs[i] = infos[i]["terminal_observation"]
+            b = time.perf_counter()
+            h.ext_push(obs, stored, rew, term, trunc, nobs, tobs)                                   # push!(buffer, traj), replay_buffer.jl:98-114
+            t_dev += time.perf_counter() - b
+            obs = nobs
+        t_env += time.perf_counter() - a
+        ts["fps"].append(n_steps * E / max(time.perf_counter() - a, 1e-12))
+        total += n_steps * E
+        n_steps = alg.train_freq                                                                    # :520
+        if n_updates > 0:
+            b = time.perf_counter()
+            for s in h.update(n_updates):                                                           # :523-538
+                ts["actor_losses"].append(s.actor_loss); ts["critic_losses"].append(s.critic_loss)
+                if s.has_entropy_loss:
+                    ts["entropy_losses"].append(s.entropy_loss)
+                ts["entropy_coefficients"].append(s.entropy_coefficient); ts["q_values"].append(s.mean_q_values)
+                ts["learning_rates"].append(alg.learning_rate); ts["grad_norms"].append(s.grad_norm)
+            t_dev += time.perf_counter() - b
+            n_upd += n_updates
+    agent.steps_taken += total
+    agent.gradient_updates += n_upd
+    agent.parameters = sac_unflatten_params(h.get_params(), agent.parameters)
+    agent.q_target_parameters = h.get_target_params()
+    agent.log_ent_coef = h.get_log_ent_coef()
+    return agent, rb, ts, {"training_loop": time.perf_counter() - t0, "iterations": max(iterations, 0), "collect_rollout": t_env, "device": t_dev}

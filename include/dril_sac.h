@@ -49,7 +49,7 @@ enum dril_replay_id {
  * types (src/interfaces/entropy.jl) and the env ctor kwargs */
 typedef struct dril_sac_config {
     uint32_t abi_version;       /* DRIL_SAC_ABI_VERSION */
-    int32_t env_kind;           /* Box action space required (sac.jl:74): DRIL_ENV_PENDULUM */
+    int32_t env_kind;           /* Box action space required (sac.jl:74): DRIL_ENV_PENDULUM[_SCALED], or DRIL_ENV_EXTERNAL (the caller's host envs: ext_* below) */
     int32_t n_envs;
     int32_t episode_len;        /* max_steps kwarg: 200 Pendulum-v1 */
     int32_t hidden1, hidden2;   /* SACLayer hidden_dims, default [512, 512] (sac.jl:76); multiples of 32 */
@@ -70,7 +70,11 @@ typedef struct dril_sac_config {
     uint64_t seed;              /* env i is seeded seed + i (wrapper_utils.jl:39-44) */
     int32_t device;
     int32_t profile_events;
-    int32_t reserved[8];
+    /* DRIL_ENV_EXTERNAL only: observation_space = Box of ext_obs_dim floats (<= 1024), action_space = Box(ext_action_low, ext_action_high) of
+     * ext_action_dim floats (<= 16; the bounds feed TanhScaleAdapter, default_adapters.jl:13-21, and rand(action_space) of the start phase) */
+    int32_t ext_obs_dim, ext_action_dim;
+    float ext_action_low, ext_action_high;
+    int32_t reserved[4];
 } dril_sac_config;
 
 /* NamedTuple returned by update!(agent, alg::SAC, batch), sac.jl:395-403; one per gradient step */
@@ -137,6 +141,15 @@ int32_t dril_sac_collect_rollout(dril_sac_handle* h, int32_t n_steps, int32_t us
 /* injected noise for the NEXT collect call only, f32 [step][env][A]: standard normals for policy actions, uniforms in
  * [0,1) for random actions (rand(rng, act_space) = low + u * (high - low)); NULL clears */
 int32_t dril_sac_debug_set_collect_noise(dril_sac_handle* h, const float* noise, size_t count);
+
+/* ---- collection over HOST envs (DRIL_ENV_EXTERNAL): one env step of collect_trajectories (off_policy_collection.jl:28-96) + push! (replay_buffer.jl:98-114)
+ *   obs = observe(env);  dril_sac_predict_actions(h, obs, E, 0, noise, raw, env_actions)   (or rand(action_space) during the start phase, :50-53)
+ *   rewards, terminateds, truncateds, infos = act!(env, env_actions);  next_obs = observe(env)
+ *   dril_sac_ext_push(h, obs, stored_actions, rewards, terminateds, truncateds, next_obs, terminal_obs)
+ * stored_actions (A x E) are what the reference stores: the raw squashed policy action, or the env-space random action (:72); the next observation of a
+ * truncated env is its terminal_obs column (infos[i]["terminal_observation"], :75-79; may be NULL when no env was truncated).  n_envs transitions per call. */
+int32_t dril_sac_ext_push(dril_sac_handle* h, const float* obs, const float* stored_actions, const float* rewards, const uint8_t* terminated,
+                          const uint8_t* truncated, const float* next_obs, const float* terminal_obs);
 
 /* ---- replay buffer ---------------------------------------------------------------------------------------------- */
 int64_t dril_sac_replay_size(const dril_sac_handle* h);       /* length(buffer) */

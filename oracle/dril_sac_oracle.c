@@ -14,7 +14,7 @@
 #include "../include/dril_sac.h"
 
 typedef struct orc_sac {
-    dril_sac_config cfg; env_spec es; int D, A, H1, H2;
+    dril_sac_config cfg; env_spec es; int D, A, H1, H2; float act_lo, act_hi;   /* bounds of the agent-facing Box action space */
     net_layout actor, q[2]; size_t log_std_off, P, Pq;
     float *params, *adam_m, *adam_v, *target;
     float bt_actor[2], bt_critic[2];          /* running beta powers of the two groups of leaves (Optimisers keeps them per leaf) */
@@ -104,6 +104,7 @@ static void squashed_backward(const float* mu, const float* ls, const float* noi
 }
 
 /* ---- lifetime ------------------------------------------------------------------------------------------------------ */
+#define ORC_SAC_MAX_X 1048   /* Q-net input: obs (<= 1024, DRIL_ENV_EXTERNAL) ++ action (<= 16) */
 ORC_API int32_t orc_sac_config_default(dril_sac_config* c, int32_t env_kind) {
     memset(c, 0, sizeof(*c));
     c->abi_version = DRIL_SAC_ABI_VERSION; c->env_kind = env_kind; c->n_envs = 1; c->episode_len = env_kind == DRIL_ENV_PENDULUM ? 200 : 500;
@@ -120,8 +121,12 @@ ORC_API int32_t orc_sac_reset_optimizer(orc_sac* c) {
     c->ent_m = c->ent_v = 0; c->grad_updates = 0; return DRIL_OK;
 }
 ORC_API int32_t orc_sac_create(const dril_sac_config* cfg, orc_sac** out) {
-    if (!cfg || cfg->abi_version != DRIL_SAC_ABI_VERSION || (cfg->env_kind != DRIL_ENV_PENDULUM && cfg->env_kind != DRIL_ENV_PENDULUM_SCALED)) return DRIL_ERR_INVALID_ARG;
+    const int ext = cfg && cfg->env_kind == DRIL_ENV_EXTERNAL;
+    if (!cfg || cfg->abi_version != DRIL_SAC_ABI_VERSION || (!ext && cfg->env_kind != DRIL_ENV_PENDULUM && cfg->env_kind != DRIL_ENV_PENDULUM_SCALED)) return DRIL_ERR_INVALID_ARG;
+    if (ext && (cfg->ext_obs_dim < 1 || cfg->ext_obs_dim > 1024 || cfg->ext_action_dim < 1 || cfg->ext_action_dim > 16 || !(cfg->ext_action_low < cfg->ext_action_high))) return DRIL_ERR_INVALID_ARG;
     orc_sac* c = (orc_sac*)calloc(1, sizeof(orc_sac)); c->cfg = *cfg; c->es = spec_of(cfg->env_kind);
+    c->act_hi = act_bound(cfg->env_kind); c->act_lo = -c->act_hi;
+    if (ext) { c->es.kind = DRIL_ENV_EXTERNAL; c->es.D = cfg->ext_obs_dim; c->es.S = 0; c->es.A = cfg->ext_action_dim; c->es.discrete = 0; c->act_lo = cfg->ext_action_low; c->act_hi = cfg->ext_action_high; }
     const int D = c->D = c->es.D, A = c->A = c->es.A, H1 = c->H1 = cfg->hidden1, H2 = c->H2 = cfg->hidden2, E = cfg->n_envs;
     c->actor = net_at(0, D, H1, H2, A); c->q[0] = net_at(c->actor.end, D + A, H1, H2, 1); c->q[1] = net_at(c->q[0].end, D + A, H1, H2, 1);
     c->Pq = c->q[0].end - c->q[0].w1; c->log_std_off = c->q[1].end; c->P = c->log_std_off + A;
@@ -188,7 +193,7 @@ ORC_API int32_t orc_sac_action_log_prob(orc_sac* c, const float* obs, int64_t B,
  * scale_to_space spaces.jl:134-139 with Box(-2, 2) */
 ORC_API int32_t orc_sac_predict_actions(orc_sac* c, const float* obs, int64_t B, int32_t deterministic, const float* noise, float* raw, float* env) {
     const int D = c->D, A = c->A, act = c->cfg.activation;
-    const float high = act_bound(c->es.kind), low = -high;
+    const float high = c->act_hi, low = c->act_lo;
 #pragma omp parallel if (B >= 256)
     {
         float* h1 = (float*)malloc(4 * c->H1); float* h2 = (float*)malloc(4 * c->H2); float mu[ORC_MAX_OUT], a[ORC_MAX_OUT];
@@ -210,7 +215,7 @@ ORC_API int32_t orc_sac_predict_q(orc_sac* c, const float* obs, const float* act
     const int D = c->D, A = c->A, act = c->cfg.activation;
 #pragma omp parallel if (B >= 256)
     {
-        float* h1 = (float*)malloc(4 * c->H1); float* h2 = (float*)malloc(4 * c->H2); float x[2 * ORC_MAX_OBS];
+        float* h1 = (float*)malloc(4 * c->H1); float* h2 = (float*)malloc(4 * c->H2); float x[ORC_SAC_MAX_X];
 #pragma omp for schedule(static)
         for (int64_t b = 0; b < B; ++b) {
             memcpy(x, obs + b * D, D * 4); memcpy(x + D, actions + b * A, A * 4);
@@ -261,7 +266,7 @@ ORC_API int32_t orc_sac_collect_rollout(orc_sac* c, int32_t n_steps, int32_t use
     if (c->collect_noise && c->collect_noise_count != (size_t)n_steps * E * A) return DRIL_ERR_INVALID_ARG;
     float* obs = (float*)malloc((size_t)E * D * 4); float* nobs = (float*)malloc((size_t)E * D * 4); float* nz = (float*)malloc((size_t)E * A * 4);
     float* raw = (float*)malloc((size_t)E * A * 4); float* envact = (float*)malloc((size_t)E * A * 4);
-    const float high = act_bound(c->es.kind), low = -high;
+    const float high = c->act_hi, low = c->act_lo;
     orc_sac_env_observe(c, obs);                                                              /* :41 */
     for (int t = 0; t < n_steps; ++t) {
         if (c->collect_noise) memcpy(nz, c->collect_noise + (size_t)t * E * A, (size_t)E * A * 4);
@@ -290,6 +295,19 @@ ORC_API int32_t orc_sac_collect_rollout(orc_sac* c, int32_t n_steps, int32_t use
     c->collect_noise = NULL; c->collect_noise_count = 0;
     if (fps) *fps = 0.0;
     free(obs); free(nobs); free(nz); free(raw); free(envact);
+    return DRIL_OK;
+}
+
+/* one env step of the caller's host envs into the ring (DRIL_ENV_EXTERNAL): off_policy_collection.jl:63-92 + push! replay_buffer.jl:98-114 */
+ORC_API int32_t orc_sac_ext_push(orc_sac* c, const float* obs, const float* stored_actions, const float* rewards, const uint8_t* terminated,
+                                 const uint8_t* truncated, const float* next_obs, const float* terminal_obs) {
+    const int E = c->cfg.n_envs, D = c->D, A = c->A;
+    if (c->es.kind != DRIL_ENV_EXTERNAL) return DRIL_ERR_UNSUPPORTED;
+    for (int e = 0; e < E; ++e) {
+        if (truncated[e] && !terminal_obs) return DRIL_ERR_INVALID_ARG;
+        rb_push(c, obs + (size_t)e * D, stored_actions + (size_t)e * A, rewards[e], terminated[e], truncated[e],
+                truncated[e] ? terminal_obs + (size_t)e * D : next_obs + (size_t)e * D);
+    }
     return DRIL_OK;
 }
 
@@ -370,7 +388,7 @@ static void sac_one_update(orc_sac* c, int inj_slot, dril_sac_stats* out) {
     {
         double* Gl = (double*)calloc(c->P, 8); double cl = 0, qs = 0;
         float* h1 = (float*)malloc(4 * H1); float* h2 = (float*)malloc(4 * H2); float* dz2 = (float*)malloc(4 * H2); float* dz1 = (float*)malloc(4 * H1);
-        float x[2 * ORC_MAX_OBS];
+        float x[ORC_SAC_MAX_X];
 #pragma omp for schedule(static)
         for (int i = 0; i < B; ++i) {
             memcpy(x, obs + (size_t)i * D, D * 4); memcpy(x + D, actn + (size_t)i * A, A * 4);
@@ -399,7 +417,7 @@ static void sac_one_update(orc_sac* c, int inj_slot, dril_sac_stats* out) {
         double* Gl = (double*)calloc(c->P, 8); double al = 0;
         float* h1 = (float*)malloc(4 * H1); float* h2 = (float*)malloc(4 * H2); float* dz2 = (float*)malloc(4 * H2); float* dz1 = (float*)malloc(4 * H1);
         float* qh1 = (float*)malloc(4 * H1 * 2); float* qh2 = (float*)malloc(4 * H2 * 2);
-        float x[2 * ORC_MAX_OBS], mu[ORC_MAX_OUT], a[ORC_MAX_OUT], g[ORC_MAX_OUT], dx[2 * ORC_MAX_OBS], da[ORC_MAX_OUT], dmu[ORC_MAX_OUT];
+        float x[ORC_SAC_MAX_X], mu[ORC_MAX_OUT], a[ORC_MAX_OUT], g[ORC_MAX_OUT], dx[ORC_SAC_MAX_X], da[ORC_MAX_OUT], dmu[ORC_MAX_OUT];
 #pragma omp for schedule(static)
         for (int i = 0; i < B; ++i) {
             const float* o = obs + (size_t)i * D;

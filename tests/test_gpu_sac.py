@@ -48,7 +48,7 @@ def close(a, b, rtol=2e-5, atol=2e-5):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize("hidden,act", [((32, 32), "relu"), ((64, 32), "tanh"), ((512, 512), "relu")])
+@pytest.mark.parametrize("hidden,act", [((32, 32), "relu"), ((64, 32), "tanh"), ((24, 40), "tanh"), ((512, 512), "relu")])
 def test_layer_calls_match_oracle(pkg, hidden, act):
     """action_log_prob / predict_actions / predict_values(obs, actions) incl. target networks; batch sizes ragged w.r.t. the 32-wide tiles"""
     h, o, layer, _ = make_pair(pkg, hidden=hidden, act=act, B=48)
@@ -75,7 +75,7 @@ def test_layer_calls_match_oracle(pkg, hidden, act):
 
 @pytest.mark.parametrize("act,auto_ent,interval,hidden,B", [("relu", True, 1, (32, 32), 16), ("tanh", True, 2, (64, 32), 40),
                                                             ("relu", False, 1, (32, 32), 16), ("relu", True, 1, (512, 512), 256),
-                                                            ("tanh", True, 1, (40, 24), 7)])      # ragged: hidden dims and batch off every 32-wide tile
+                                                            ("tanh", True, 1, (40, 24), 7), ("relu", True, 1, (24, 40), 9)])      # ragged: hidden dims and batch off every 32-wide tile; H2 > H1 and H2 < H1
 def test_update_matches_oracle(pkg, act, auto_ent, interval, hidden, B):
     """three consecutive update! steps with injected batches: losses, both gradients, parameters, targets, log_ent_coef"""
     ent = pkg.AutoEntropyCoefficient(initial_value=0.7) if auto_ent else pkg.FixedEntropyCoefficient(0.3)
@@ -252,3 +252,130 @@ def test_training_is_bitwise_reproducible(pkg):
     for x, y in zip(a[:5], b[:5]):
         np.testing.assert_array_equal(x, y)
     assert np.isfinite(a[4]).all()
+
+
+# ---- DRIL_ENV_EXTERNAL: the caller's own host envs, any observation width, up to 16 action dimensions --------------------------------------
+class _HostSpaces:
+    def __init__(self, pkg, D, A, low=-1.0, high=1.0):
+        self.kind, self._o, self._a = pkg._capi.ENV_EXTERNAL, pkg.Box(low=(-10.0,) * D, high=(10.0,) * D), pkg.Box(low=(low,) * A, high=(high,) * A)
+
+    def observation_space(self):
+        return self._o
+
+    def action_space(self):
+        return self._a
+
+
+def make_ext_pair(pkg, D, A, E=8, hidden=(32, 32), B=16, cap=4096, act="relu", low=-1.0, high=1.0, **alg_kw):
+    env = _HostSpaces(pkg, D, A, low, high)
+    alg = pkg.SAC(batch_size=B, buffer_capacity=cap, **alg_kw)
+    layer = pkg.SACLayer(env.observation_space(), env.action_space(), hidden_dims=hidden, activation=act)
+    cfg = pkg.make_sac_config(env, E, alg, layer, seed=7)
+    return pkg.SacHandle(cfg), O.sac_oracle(cfg), layer, alg
+
+
+@pytest.mark.parametrize("D,A,hidden,B,act", [(11, 5, (24, 40), 16, "tanh"), (17, 6, (256, 256), 256, "relu"), (1, 16, (32, 32), 33, "relu"), (376, 16, (64, 64), 64, "relu")])
+def test_external_spaces_layer_calls_and_update(pkg, D, A, hidden, B, act):
+    """layer calls and three update! steps for spaces the Pendulum kind does not have (multi-dimensional squashed Gaussian, wide observations)"""
+    h, o, layer, alg = make_ext_pair(pkg, D, A, hidden=hidden, B=B, act=act, ent_coef=pkg.AutoEntropyCoefficient(initial_value=0.5), learning_rate=3e-3, tau=0.05,
+                                    low=-0.5, high=1.5)
+    assert (h.D, h.A, h.P) == (D, A, layer.parameterlength())
+    flat = init_params(pkg, layer, scale_out=10.0)
+    rng = np.random.default_rng(9)
+    rb = random_replay(rng, 300, D, A)
+    for x in (h, o):
+        x.set_params(flat); x.replay_fill(*rb)
+    obs = rng.uniform(-1, 1, (70, D)).astype(np.float32); nz = rng.standard_normal((70, A)).astype(np.float32)
+    (a1, l1), (a2, l2) = h.action_log_prob(obs, nz), o.action_log_prob(obs, nz)
+    close(a1, a2); close(l1, l2, rtol=1e-4, atol=1e-4 * A)
+    (r1, e1), (r2, e2) = h.predict_actions(obs, False, nz), o.predict_actions(obs, False, nz)
+    close(r1, r2); close(e1, e2)
+    assert e1.min() >= -0.5 - 1e-6 and e1.max() <= 1.5 + 1e-6                          # to_env(TanhScaleAdapter) onto Box(-0.5, 1.5), default_adapters.jl:13-21
+    close(h.predict_actions(obs, True)[1], o.predict_actions(obs, True)[1])
+    close(h.predict_q(obs, a2), o.predict_q(obs, a2), rtol=1e-4, atol=1e-4)
+    n_upd = 3
+    idx = rng.integers(0, 300, (n_upd, B)); nzs = [rng.normal(0, 1, (n_upd, B, A)).astype(np.float32) for _ in range(3)]
+    for k in range(n_upd):
+        st = []
+        for x in (h, o):
+            x.set_batches(1, idx[k:k + 1], *[z[k:k + 1] for z in nzs])
+            st.append(x.update(1)[0])
+        a, b = st
+        for f in ("critic_loss", "actor_loss", "entropy_loss", "mean_q_values", "grad_norm", "entropy_coefficient"):
+            assert getattr(a, f) == pytest.approx(getattr(b, f), rel=2e-4, abs=2e-5), (k, f)
+        # Adam turns a gradient entry near zero into a step of up to lr = 3e-3 in either direction: a handful of the 2e5 parameters may differ by a few 1e-5
+        close(h.get_params(), o.get_params(), rtol=3e-4, atol=1e-4)
+        close(h.get_target_params(), o.get_target_params(), rtol=3e-5, atol=1e-5)
+
+
+def test_external_push_matches_oracle_and_protocol(pkg):
+    """dril_sac_ext_push: same ring as the oracle's after wrapping pushes with truncations; device-env verbs refuse an external handle"""
+    capi = pkg._capi
+    E, D, A = 5, 7, 3
+    h, o, layer, alg = make_ext_pair(pkg, D, A, E=E, cap=23)
+    rng = np.random.default_rng(0)
+    for t in range(9):
+        obs, nobs, tobs = (rng.standard_normal((E, D)).astype(np.float32) for _ in range(3))
+        act = rng.uniform(-1, 1, (E, A)).astype(np.float32); rew = rng.standard_normal(E).astype(np.float32)
+        term = (rng.random(E) < 0.2); trunc = (rng.random(E) < 0.3) if t % 2 else np.zeros(E, bool)
+        for x in (h, o):
+            x.ext_push(obs, act, rew, term, trunc, nobs, tobs if trunc.any() else None)
+    assert h.replay_size() == o.replay_size() == 23
+    for which in (capi.RB_OBSERVATIONS, capi.RB_ACTIONS, capi.RB_REWARDS, capi.RB_TERMINATED, capi.RB_TRUNCATED, capi.RB_NEXT_OBSERVATIONS):
+        assert np.array_equal(h.replay(which), o.replay(which)), which
+    z = np.zeros(E, np.float32)
+    with pytest.raises(pkg.DrilError):
+        h.ext_push(np.zeros((E, D)), np.zeros((E, A)), z, z, np.ones(E), np.zeros((E, D)))       # truncated without terminal_obs
+    for call in (lambda: h.env_reset(1), h.env_observe, lambda: h.collect_rollout(1), lambda: h.train(100)):
+        with pytest.raises(pkg.DrilError) as e:
+            call()
+        assert e.value.code == capi.ERR_UNSUPPORTED
+    dev, _, _, _ = make_pair(pkg)
+    with pytest.raises(pkg.DrilError):
+        dev.ext_push(np.zeros((8, 3)), np.zeros((8, 1)), np.zeros(8), np.zeros(8), np.zeros(8), np.zeros((8, 3)))   # device-env handle
+
+
+class _PyPointEnv:
+    """host env with the reference's AbstractEnv verbs: 2-D point, 6-dim observation, Box(-1,1)^2 action, reward = -distance to the origin"""
+
+    def __init__(self, pkg, seed):
+        self.pkg, self.rng, self.limit = pkg, np.random.default_rng(seed), 25
+        self.reset_()
+
+    def observation_space(self):
+        return self.pkg.Box(low=(-4.0,) * 6, high=(4.0,) * 6)
+
+    def action_space(self):
+        return self.pkg.Box(low=(-1.0, -1.0), high=(1.0, 1.0))
+
+    def reset_(self):
+        self.p = self.rng.uniform(-2, 2, 2).astype(np.float32); self.t = 0
+
+    def observe(self):
+        return np.concatenate([self.p, self.p ** 2 / 4, np.sin(self.p)]).astype(np.float32)
+
+    def act_(self, a):
+        self.p = np.clip(self.p + 0.3 * np.asarray(a, np.float32), -4, 4); self.t += 1
+        return float(-np.linalg.norm(self.p))
+
+    def terminated(self):
+        return bool(np.linalg.norm(self.p) < 0.1)
+
+    def truncated(self):
+        return self.t >= self.limit
+
+
+def test_sac_trains_on_host_envs(pkg):
+    """train!(agent, replay_buffer, env, alg::SAC, max_steps) over the caller's Python envs (HostParallelEnv): schedule counts as in sac.jl:456-466,
+    transitions of the random start phase are stored in env space, the mean reward per step improves"""
+    E = 8
+    env = pkg.HostParallelEnv([_PyPointEnv(pkg, s) for s in range(E)], seed=0)
+    alg = pkg.SAC(start_steps=400, buffer_capacity=20000, batch_size=128, gradient_steps=4, learning_rate=1e-3)
+    agent = pkg.SACAgent(pkg.SACLayer(env.observation_space(), env.action_space(), hidden_dims=(64, 64)), alg, seed=0)
+    agent, rb, stats, timer = pkg.sac_train_(agent, env, alg, 6000)
+    iters = (6000 - 400) // E + 1
+    assert timer["iterations"] == iters and agent.steps_taken == 400 + E * (iters - 1) and agent.gradient_updates == 4 * iters == len(stats["critic_losses"])
+    r = rb.rewards
+    assert len(r) == agent.steps_taken and np.isfinite(stats["critic_losses"]).all()
+    assert r[-800:].mean() > r[:400].mean() + 0.5, (r[:400].mean(), r[-800:].mean())
+    assert np.abs(rb.actions[:400]).max() <= 1.0 and len(stats["entropy_losses"]) == 4 * iters

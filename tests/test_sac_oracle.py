@@ -23,6 +23,26 @@ def make(pkg, E=8, hidden=(32, 32), B=16, cap=4096, act="relu", **alg_kw):
     return O.sac_oracle(cfg), layer, alg
 
 
+class _HostSpaces:
+    """what make_sac_config needs of a HostParallelEnv: the DRIL_ENV_EXTERNAL kind and the two Box spaces"""
+
+    def __init__(self, pkg, D, A, low=-1.0, high=1.0):
+        self.kind, self._o, self._a = pkg._capi.ENV_EXTERNAL, pkg.Box(low=(-10.0,) * D, high=(10.0,) * D), pkg.Box(low=(low,) * A, high=(high,) * A)
+
+    def observation_space(self):
+        return self._o
+
+    def action_space(self):
+        return self._a
+
+
+def make_ext(pkg, D, A, E=8, hidden=(32, 32), B=16, cap=4096, act="relu", low=-1.0, high=1.0, **alg_kw):
+    env = _HostSpaces(pkg, D, A, low, high)
+    alg = pkg.SAC(batch_size=B, buffer_capacity=cap, **alg_kw)
+    layer = pkg.SACLayer(env.observation_space(), env.action_space(), hidden_dims=hidden, activation=act)
+    return O.sac_oracle(pkg.make_sac_config(env, E, alg, layer, seed=7)), layer, alg
+
+
 def init_params(pkg, layer, seed=0, scale_out=30.0):
     """orthogonal init, with the tiny output layers scaled up so that means / Q values are O(1) and every term of the losses matters"""
     ps = layer.initialparameters(np.random.default_rng(seed))
@@ -221,6 +241,65 @@ def test_update_matches_torch_autograd(pkg, act, auto_ent, interval):
         np.testing.assert_allclose(h.get_params(), T.flat(T.p), rtol=2e-4, atol=2e-6)
         np.testing.assert_allclose(h.get_target_params(), T.flat(T.target), rtol=2e-5, atol=1e-6)
         assert h.get_log_ent_coef() == pytest.approx(T.log_ent.item(), rel=1e-5, abs=1e-6)
+
+
+def test_external_spaces_update_matches_torch_autograd(pkg):
+    """DRIL_ENV_EXTERNAL (host envs): an 11-dim observation, a 5-dim action and unequal hidden widths — shapes the built-in Pendulum kind does not
+    have (multi-dimensional squashed Gaussian, target entropy -5) — against the same torch f64 autograd restatement"""
+    B, n_upd, D, A, H = 16, 2, 11, 5, (24, 40)
+    h, layer, alg = make_ext(pkg, D, A, hidden=H, B=B, act="tanh", ent_coef=pkg.AutoEntropyCoefficient(initial_value=0.5), learning_rate=3e-3, tau=0.05)
+    assert (h.D, h.A) == (D, A) and h.P == layer.parameterlength()
+    flat = init_params(pkg, layer, scale_out=10.0)
+    h.set_params(flat)
+    rng = np.random.default_rng(5)
+    rb = random_replay(rng, 64, D, A)
+    h.replay_fill(*rb)
+    idx = rng.integers(0, 64, (n_upd, B))
+    ne, nn, npi = (rng.normal(0, 1, (n_upd, B, A)).astype(np.float32) for _ in range(3))
+    T = TorchSAC(flat, D, A, H, "tanh", alg, math.log(0.5), -float(A))
+    for k in range(n_upd):
+        h.set_batches(1, idx[k:k + 1], ne[k:k + 1], nn[k:k + 1], npi[k:k + 1])
+        (st,) = h.update(1)
+        j = idx[k]
+        ref, gc, ga = T.update(rb[0][j], rb[1][j], rb[2][j], rb[3][j], rb[5][j], ne[k], nn[k], npi[k], True)
+        assert st.critic_loss == pytest.approx(ref["critic_loss"], rel=5e-5) and st.actor_loss == pytest.approx(ref["actor_loss"], rel=5e-5, abs=5e-6)
+        assert st.entropy_loss == pytest.approx(ref["entropy_loss"], rel=5e-5, abs=5e-6) and st.grad_norm == pytest.approx(ref["grad_norm"], rel=5e-5)
+        np.testing.assert_allclose(h.get_params(), T.flat(T.p), rtol=3e-4, atol=3e-6)
+        np.testing.assert_allclose(h.get_target_params(), T.flat(T.target), rtol=3e-5, atol=1e-6)
+
+
+def test_external_push_is_collect_rollout(pkg):
+    """pins orc_sac_ext_push (one host-env step into the ring) to orc_sac_collect_rollout: an external context with Pendulum's spaces, fed by the
+    on-policy oracle's Pendulum simulator through the env verbs, builds the same replay buffer — random start phase (env-space actions stored),
+    policy phase (raw squashed actions stored), truncated transitions with their terminal observation, ring overwrite"""
+    capi = pkg._capi
+    E, L, n_rand, n_pol = 6, 5, 4, 13
+    full, layer, alg = make(pkg, E=E, hidden=(16, 16), cap=80, max_steps=L)
+    ext, layer_x, _ = make_ext(pkg, 3, 1, E=E, hidden=(16, 16), cap=80, low=-2.0, high=2.0)
+    assert ext.P == full.P
+    flat = init_params(pkg, layer, scale_out=20.0)
+    full.set_params(flat); ext.set_params(flat)
+    cs = capi.default_config(capi.ENV_PENDULUM); cs.n_envs, cs.n_steps, cs.episode_len = E, 2, L
+    sim = O.Oracle(cs)
+    full.env_reset(7); sim.env_reset(7)
+    rng = np.random.default_rng(2)
+    u = rng.random((n_rand, E, 1)).astype(np.float32); z = rng.standard_normal((n_pol, E, 1)).astype(np.float32)
+    full.set_collect_noise(u); full.collect_rollout(n_rand, True)
+    full.set_collect_noise(z); full.collect_rollout(n_pol, False)
+    obs = sim.env_observe()
+    for t in range(n_rand + n_pol):
+        if t < n_rand:
+            stored = env_a = (-2.0 + u[t] * 4.0).astype(np.float32)                       # rand(rng, act_space) = low + u (high - low)
+        else:
+            stored, env_a = ext.predict_actions(obs, False, z[t - n_rand])
+        rew, term, trunc, tobs = sim.env_step(env_a)
+        nobs = sim.env_observe()
+        ext.ext_push(obs, stored, rew, term, trunc, nobs, tobs if trunc.any() else None)
+        obs = nobs
+    assert ext.replay_size() == full.replay_size() == 80 < (n_rand + n_pol) * E          # the ring wrapped
+    assert ext.replay(capi.RB_TRUNCATED).any()
+    for which in (capi.RB_OBSERVATIONS, capi.RB_ACTIONS, capi.RB_REWARDS, capi.RB_TERMINATED, capi.RB_TRUNCATED, capi.RB_NEXT_OBSERVATIONS):
+        assert np.array_equal(ext.replay(which), full.replay(which)), which
 
 
 def test_injected_batches_equal_one_call_or_many(pkg):
