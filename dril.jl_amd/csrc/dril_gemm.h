@@ -16,6 +16,7 @@ struct GemmArgs {
     int vecBn;                                    // B has unit stride along n with 16-byte aligned rows: float4 runs along n (LDS-tiled kernel only)
     int ones_n;                                   // B(:, N-1) == 1 (appends the bias column to a weight-gradient contraction)
     int epi; float alpha;
+    int dbg;                                      // DRIL_GEMM_DBG bits (diagnostic, results wrong): 1 no global operand loads after the first chunk, 2 no MFMA, 4 no epilogue, 8 no staging stores
     int allow_split;                              // large contractions may run on the bf16 matrix cores with fp32-equivalent 3-piece operand splitting (generic on-policy path; SAC keeps the f32 MFMA)
 };
 enum { EPI_NONE = 0, EPI_RELU = 1, EPI_TANH = 2, EPI_MASK_RELU = 3, EPI_MASK_TANH = 4 };

@@ -38,14 +38,38 @@ __device__ __forceinline__ void load_operand4(const float* __restrict__ P, int i
 // kGemmDepth chunks instead of one per chunk).  The epilogue goes through LDS so that global stores run along C's unit-stride axis
 // (m): a wave writes 2 x 128 contiguous bytes per instruction instead of 64 scattered words.
 constexpr int kGemmWaves = 8, kGemmDepth = 8, kRedStride = 65;
-__device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int mm, size_t ci, const float* __restrict__ bias, const float* __restrict__ aux) {
-    v *= g.alpha;
-    if (bias) v += bias[mm];
+__device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, float b, float y) {
+    v = v * g.alpha + b;
     if (g.epi == EPI_RELU) v = v > 0.f ? v : 0.f;
     else if (g.epi == EPI_TANH) v = tanhf(v);
-    else if (g.epi == EPI_MASK_RELU) v = aux[ci] > 0.f ? v : 0.f;
-    else if (g.epi == EPI_MASK_TANH) { const float y = aux[ci]; v *= 1.0f - y * y; }
+    else if (g.epi == EPI_MASK_RELU) v = y > 0.f ? v : 0.f;
+    else if (g.epi == EPI_MASK_TANH) v *= 1.0f - y * y;
     return v;
+}
+// one 32 x 32 output tile out of the LDS transposition buffer: lane -> 16 elements (row ml = lane & 31 fixed, 16 columns), stores along C's unit-stride axis.
+// Two phases on purpose: ALL bias / aux operand loads of the 16 elements are issued before the first store.  Interleaved (load, compute, store per element)
+// the compiler may not move element i+1's loads above element i's store, and every element then waits a full memory round trip: measured, that — not the
+// contraction — set the 190 us of a 512 x 32768 x 512 reverse-pass contraction in every blocking and on both MFMA types
+template <class F>
+__device__ __forceinline__ void store_tile(const GemmArgs& g, float* __restrict__ C, const float* __restrict__ bias, const float* __restrict__ aux,
+                                           int m_base, int n_base, int lane, F&& value) {
+    const int ml = lane & 31, mm = m_base + ml;
+    const bool m_ok = mm < g.M;
+    const float b = (bias && m_ok) ? bias[mm] : 0.f;
+    const bool need_aux = aux && (g.epi == EPI_MASK_RELU || g.epi == EPI_MASK_TANH);
+    float y[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int nn = n_base + (lane >> 5) + 2 * i;
+        y[i] = (need_aux && m_ok && nn < g.N) ? aux[(size_t)mm * g.sCm + (size_t)nn * g.sCn] : 0.f;
+    }
+    const int rr = (ml & 3) + 4 * (ml >> 3), lb = 32 * ((ml >> 2) & 1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int nl = (lane >> 5) + 2 * i, nn = n_base + nl;
+        if (!m_ok || nn >= g.N) continue;
+        C[(size_t)mm * g.sCm + (size_t)nn * g.sCn] = gemm_epilogue(g, value(rr, nl + lb), b, y[i]);
+    }
 }
 template <bool SPLIT>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)[kGemmWaves][16][kRedStride]) {
@@ -86,29 +110,26 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)
     const float* __restrict__ aux = g.aux ? g.aux + (size_t)z * g.zAux : nullptr;
     // element e of a 32x32 tile: m_local = e & 31 (fastest, C's unit stride), n_local = e >> 5; it sits in register rr of lane ll
     if (SPLIT) {
+        const bool need_aux = aux && (g.epi == EPI_MASK_RELU || g.epi == EPI_MASK_TANH);
+        const int ml = threadIdx.x & 31, mm = blockIdx.x * 32 + ml, rr = (ml & 3) + 4 * (ml >> 3), lb = 32 * ((ml >> 2) & 1);
+        const float b = (bias && mm < g.M) ? bias[mm] : 0.f;
+        float y[2]; bool ok[2]; size_t ci[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                                          // both operand loads before the first store (see store_tile)
+            const int nn = tile_n * 32 + (int)(threadIdx.x >> 5) + 16 * i;
+            ok[i] = mm < g.M && nn < g.N; ci[i] = (size_t)mm * g.sCm + (size_t)nn * g.sCn;
+            y[i] = (need_aux && ok[i]) ? aux[ci[i]] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int e = threadIdx.x + 512 * i, ml = e & 31, nl = e >> 5;
-            const int rr = (ml & 3) + 4 * (ml >> 3), ll = nl + 32 * ((ml >> 2) & 1);
-            const int mm = blockIdx.x * 32 + ml, nn = tile_n * 32 + nl;
-            if (mm >= g.M || nn >= g.N) continue;
+            if (!ok[i]) continue;
+            const int ll = (int)(threadIdx.x >> 5) + 16 * i + lb;
             float v = red[0][rr][ll];
 #pragma unroll
             for (int w = 1; w < kGemmWaves; ++w) v += red[w][rr][ll];                          // fixed order
-            const size_t ci = (size_t)mm * g.sCm + (size_t)nn * g.sCn;
-            C[ci] = gemm_epilogue(g, v, mm, ci, bias, aux);
+            C[ci[i]] = gemm_epilogue(g, v, b, y[i]);
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e = lane + 64 * i, ml = e & 31, nl = e >> 5;
-            const int rr = (ml & 3) + 4 * (ml >> 3), ll = nl + 32 * ((ml >> 2) & 1);
-            const int mm = blockIdx.x * 32 + ml, nn = tile_n * 32 + nl;
-            if (mm >= g.M || nn >= g.N) continue;
-            const size_t ci = (size_t)mm * g.sCm + (size_t)nn * g.sCn;
-            C[ci] = gemm_epilogue(g, red[wave][rr][ll], mm, ci, bias, aux);
-        }
-    }
+    } else store_tile(g, C, bias, aux, blockIdx.x * 32, tile_n * 32, lane, [&](int rr, int ll) { return red[wave][rr][ll]; });
 }
 template <bool SPLIT>
 __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_kernel(GemmArgs g) {
@@ -203,15 +224,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_big_kernel(GemmArgs 
     const float* __restrict__ bias = g.bias ? g.bias + (size_t)z * g.zBias : nullptr;
     const float* __restrict__ aux = g.aux ? g.aux + (size_t)z * g.zAux : nullptr;
     const int tile_n = (int)blockIdx.y * kGemmWaves + wave;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int e = lane + 64 * i, ml = e & 31, nl = e >> 5;
-        const int rr = (ml & 3) + 4 * (ml >> 3), ll = nl + 32 * ((ml >> 2) & 1);
-        const int mm = m0 + ml, nn = tile_n * 32 + nl;
-        if (mm >= g.M || nn >= g.N) continue;
-        const size_t ci = (size_t)mm * g.sCm + (size_t)nn * g.sCn;
-        C[ci] = gemm_epilogue(g, red[wave][rr][ll], mm, ci, bias, aux);
-    }
+    store_tile(g, C, bias, aux, m0, tile_n * 32, lane, [&](int rr, int ll) { return red[wave][rr][ll]; });
 }
 // ---- the same LDS-tiled contraction on the bf16 matrix cores, fp32-equivalent by operand splitting ------------------------------------------------
 // Every staged f32 operand is cut into three bf16 pieces x = hi + mid + lo (upper 16 bits, exact remainder, twice: exact for a 24-bit mantissa) when
@@ -231,34 +244,39 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsi
     hi = __builtin_amdgcn_perm(bh, ah, 0x07060302u); mid = __builtin_amdgcn_perm(bm, am, 0x07060302u);
     lo = __builtin_amdgcn_perm(__float_as_uint(bq), __float_as_uint(aq), 0x07060302u);
 }
-constexpr int kSplitRowsX = 32 * kGemmWaves;                                   // 256 n-rows per workgroup
-constexpr int kSplitXImg = 2 * 2 * kSplitRowsX * 8;                            // bf16 elements per piece: [k16 step][half][row][8]
 // MB = m-tiles per wave: the workgroup's output block is (32 MB) x 256.  One thin 32 x 256 block re-reads the activation chunk for every 32 output
 // rows — at hidden 512 the LDS-tiled kernels moved 6 TB/s through L2 and the bf16 form was no faster than the f32 one (87 vs 90 TFLOP/s); with
 // MB = 4 the same chunk feeds four tiles (43.7 FLOP per staged byte instead of 14.5) and the split is amortised over four times the MFMAs
-template <bool AK, bool BN, int MB>
+// WM = waves along m (1 or 2): with WM = 2 the workgroup spans 64 MB output rows and 128 activation rows — at MB = 8 that is ALL 512 rows of a hidden-512
+// layer, so every activation row is staged exactly once per contraction (weights are the re-read operand, and they live in L2)
+template <bool AK, bool BN, int MB, int WM>
 __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_split_kernel(GemmArgs g) {
-    constexpr int kRowsA = 32 * MB, kSplitAImg = 2 * 2 * kRowsA * 8;
+    constexpr int WN = kGemmWaves / WM, kRowsA = 32 * MB * WM, kSplitRowsX = 32 * WN;
+    constexpr int kSplitAImg = 2 * 2 * kRowsA * 8, kSplitXImg = 2 * 2 * kSplitRowsX * 8;           // bf16 elements per piece: [k16 step][half][row][8]
+    constexpr int NGX = kSplitRowsX / 64;                                                         // (row, 4 k) groups per thread of the activation chunk
+    constexpr int NPA = kRowsA / 32;                                                              // element pairs per thread of the weight chunk
+    constexpr bool kRedOnA = 3 * kSplitAImg > 3 * kSplitXImg;                                     // the f32 epilogue buffer (33 KB) overlays the larger image block
     __shared__ __attribute__((aligned(16))) unsigned short Ap[3 * kSplitAImg];
-    __shared__ __attribute__((aligned(16))) unsigned short Xp[3 * kSplitXImg];                        // 48 KB; the f32 epilogue buffer (33 KB) overlays it
-    static_assert(sizeof(unsigned short) * 3 * kSplitXImg >= sizeof(float) * kGemmWaves * 16 * kRedStride, "epilogue buffer must fit the operand images");
-    float (*red)[16][kRedStride] = reinterpret_cast<float (*)[16][kRedStride]>(Xp);
+    __shared__ __attribute__((aligned(16))) unsigned short Xp[3 * kSplitXImg];
+    static_assert(sizeof(unsigned short) * 3 * (kRedOnA ? kSplitAImg : kSplitXImg) >= sizeof(float) * kGemmWaves * 16 * kRedStride, "epilogue buffer must fit the operand images");
+    float (*red)[16][kRedStride] = reinterpret_cast<float (*)[16][kRedStride]>(kRedOnA ? Ap : Xp);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5, z = blockIdx.z;
+    const int wm = wave / WN, wn = wave % WN;
     const float* __restrict__ A = g.A + (size_t)z * g.zA;
     const float* __restrict__ B = g.B + (size_t)(z / g.zdivB) * g.zB;
-    const int m0 = blockIdx.x * kRowsA, n0 = blockIdx.y * 32 * kGemmWaves;
-    // loader roles: every thread owns 4 groups of (one n-row, 4 consecutive k) = one 8-byte LDS store per piece and group.  B k-contiguous: one float4 per
+    const int m0 = blockIdx.x * kRowsA, n0 = blockIdx.y * kSplitRowsX;
+    // loader roles: every thread owns NGX groups of (one n-row, 4 consecutive k) = one 8-byte LDS store per piece and group.  B k-contiguous: one float4 per
     // group (8 lanes read one row's 128 B).  BN (n-contiguous): consecutive lanes take consecutive n and read the 4 k-rows as 4 coalesced scalar loads
-    int xr[4], xk[4];
+    int xr[NGX], xk[NGX];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int i = tid + 512 * j; if (BN) { xr[j] = tid & 255; xk[j] = ((tid >> 8) + 2 * j) * 4; } else { xr[j] = i >> 3; xk[j] = (i & 7) * 4; } }
+    for (int j = 0; j < NGX; ++j) { const int i = tid + 512 * j; if (BN) { xr[j] = tid % kSplitRowsX; xk[j] = (tid / kSplitRowsX + (512 / kSplitRowsX) * j) * 4; } else { xr[j] = i >> 3; xk[j] = (i & 7) * 4; } }
     // A chunk = (32 MB) m x 32 k.  m-contiguous: element e = tid + 512 j, m = e % rows, k = e / rows (consecutive lanes, consecutive m), two per store
     // pair (j, j + MB): k and k + 16 share an 8-k group?  no — stored as single bf16 each.  AK: pair e = tid + 512 j: m = e >> 4, k = (e & 15) * 2
     const int n_real = g.N - (g.ones_n ? 1 : 0);
-    float4 xv[4]; float av[2 * MB];
+    float4 xv[NGX]; float av[2 * NPA];
     auto gload = [&](int kc) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NGX; ++j) {
             if (BN) {
                 const int n = n0 + xr[j];
                 float t[4];
@@ -274,7 +292,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_split_kernel(GemmArg
             }
         }
 #pragma unroll
-        for (int j = 0; j < MB; ++j) {
+        for (int j = 0; j < NPA; ++j) {
             if (AK) {
                 const int e = tid + 512 * j, am = e >> 4, ak = (e & 15) * 2, mg = m0 + am;
                 av[2 * j] = (mg < g.M && kc + ak < g.K) ? A[(size_t)mg * g.sAm + kc + ak] : 0.f;
@@ -302,8 +320,9 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_split_kernel(GemmArg
     gload(c0 * kBigKc);
     for (int ci = 0; ci < nchunks; ++ci) {
         const int cn = c0 + ci + 1 >= nchunks ? c0 + ci + 1 - nchunks : c0 + ci + 1;   // next chunk (wraps)
+        if (!(g.dbg & 8)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                                            // 4 consecutive k of one n-row (inside one 8-k group): one 8-byte store per piece
+        for (int j = 0; j < NGX; ++j) {                                          // 4 consecutive k of one n-row (inside one 8-k group): one 8-byte store per piece
             unsigned h0, m0_, l0, h1, m1, l1;
             split3_pair(xv[j].x, xv[j].y, h0, m0_, l0); split3_pair(xv[j].z, xv[j].w, h1, m1, l1);
             const int o = xoff(xr[j], xk[j]);
@@ -312,7 +331,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_split_kernel(GemmArg
             *reinterpret_cast<uint2*>(&Xp[2 * kSplitXImg + o]) = make_uint2(l0, l1);
         }
 #pragma unroll
-        for (int j = 0; j < MB; ++j) {
+        for (int j = 0; j < NPA; ++j) {
             unsigned ph, pm, pl;
             split3_pair(av[2 * j], av[2 * j + 1], ph, pm, pl);
             if (AK) {                                                            // two consecutive k of one m-row: one 4-byte store per piece
@@ -324,17 +343,19 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_split_kernel(GemmArg
                 Ap[o1] = (unsigned short)(ph >> 16); Ap[kSplitAImg + o1] = (unsigned short)(pm >> 16); Ap[2 * kSplitAImg + o1] = (unsigned short)(pl >> 16);
             }
         }
+        }
         __syncthreads();
-        if (ci + 1 < nchunks) gload(cn * kBigKc);                                // next chunk in flight under this chunk's MFMAs
+        if (ci + 1 < nchunks && !(g.dbg & 1)) gload(cn * kBigKc);                // next chunk in flight under this chunk's MFMAs
+        if (!(g.dbg & 2))
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int xo = ((ks * 2 + h) * kSplitRowsX + 32 * wave + c) * 8;
+            const int xo = ((ks * 2 + h) * kSplitRowsX + 32 * wn + c) * 8;
             const bf16x8 Bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Xp[xo]));
             const bf16x8 Bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Xp[kSplitXImg + xo]));
             const bf16x8 Bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Xp[2 * kSplitXImg + xo]));
 #pragma unroll
             for (int t = 0; t < MB; ++t) {
-                const int ao = ((ks * 2 + h) * kRowsA + 32 * t + c) * 8;
+                const int ao = ((ks * 2 + h) * kRowsA + 32 * (wm * MB + t) + c) * 8;
                 const bf16x8 Ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Ap[ao]));
                 const bf16x8 Am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Ap[kSplitAImg + ao]));
                 const bf16x8 Al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Ap[2 * kSplitAImg + ao]));
@@ -351,22 +372,15 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_split_kernel(GemmArg
     float* __restrict__ C = g.C + (size_t)z * g.zC;
     const float* __restrict__ bias = g.bias ? g.bias + (size_t)z * g.zBias : nullptr;
     const float* __restrict__ aux = g.aux ? g.aux + (size_t)z * g.zAux : nullptr;
-    const int tile_n = (int)blockIdx.y * kGemmWaves + wave;
+    const int tile_n = (int)blockIdx.y * WN + wn;
+    if (g.dbg & 4) { if (acc[0][0] == 123.456f) C[0] = 1.f; return; }
 #pragma unroll
     for (int t = 0; t < MB; ++t) {                                              // one m-tile at a time through the transposition buffer (the loop's last barrier freed the operand images)
         if (t) __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[t][r];
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int e = lane + 64 * i, ml = e & 31, nl = e >> 5;
-            const int rr = (ml & 3) + 4 * (ml >> 3), ll = nl + 32 * ((ml >> 2) & 1);
-            const int mm = m0 + 32 * t + ml, nn = tile_n * 32 + nl;
-            if (mm >= g.M || nn >= g.N) continue;
-            const size_t ci = (size_t)mm * g.sCm + (size_t)nn * g.sCn;
-            C[ci] = gemm_epilogue(g, red[wave][rr][ll], mm, ci, bias, aux);
-        }
+        store_tile(g, C, bias, aux, m0 + 32 * (wm * MB + t), tile_n * 32, lane, [&](int rr, int ll) { return red[wave][rr][ll]; });
     }
 }
 // two independent contractions in one launch (the weight-gradient and the data-gradient of one layer): blockIdx.z < za runs `a`
@@ -405,17 +419,24 @@ hipError_t launch_gemm(GemmArgs g, int Z, hipStream_t s) {
     const bool a_m = g.sAm == 1, a_k = !a_m && g.sAk == 1;                                             // A m-contiguous / k-contiguous
     const bool b_k = g.sBk == 1 && g.vecB && !g.ones_n, b_n = !b_k && g.sBn == 1 && g.sBk != 1;        // B k-contiguous (float4 rows) / n-contiguous
     const dim3 bgrid(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), bblock(64 * kGemmWaves);
+    static const int dbg_bits = std::getenv("DRIL_GEMM_DBG") ? std::atoi(std::getenv("DRIL_GEMM_DBG")) : 0; g.dbg = dbg_bits;
     static const bool f32_only = std::getenv("DRIL_GEMM_F32") != nullptr;                                // A/B knob: keep the large contractions on v_mfma_f32_32x32x2_f32
     static const bool split_all = std::getenv("DRIL_GEMM_SPLIT") != nullptr;                              // A/B knob: also for callers that did not ask (SAC)
     const bool split = many && !f32_only && (g.allow_split || split_all) && g.K >= 64;
     if (split && (a_m || a_k) && (b_k || b_n)) {
-        // rows per workgroup: as many as leave >= 2 workgroups per CU (a 4096-row collection forward has 256 blocks of 32 x 256: it stays at MB = 1)
+        // output rows per workgroup: 64 (two m-tiles per wave) when that still leaves >= 2 workgroups per CU, else 32 (a 4096-row collection forward has 256
+        // blocks of 32 x 256: it stays at MB = 1).  Taller blocks were built and measured (MB = 4, and full-height 256 / 512-row blocks that stage every
+        // activation row once): SLOWER — 65 / 57 vs 69 TFLOP/s at hidden 512 — because their registers / LDS leave one workgroup per CU, and with one
+        // workgroup the phases of a chunk do not overlap (ablation of a 512 x 32768 x 512 reverse-pass contraction, DRIL_GEMM_DBG: global loads 31 + staging
+        // 37 + MFMA 57 + epilogue 41 = 166 us vs 160 us measured: purely additive).  Two co-resident workgroups hide each other's phases.
+        static const int mb_cap = std::getenv("DRIL_GEMM_MB") ? std::atoi(std::getenv("DRIL_GEMM_MB")) : 2;   // A/B knob (1, 2, 4 are built)
         int MB = 1;
-        for (int cand = 4; cand > 1; cand >>= 1) if (g.M >= 32 * cand && (long long)((g.M + 32 * cand - 1) / (32 * cand)) * bgrid.y * Z >= 512) { MB = cand; break; }
+        const long long tn256 = (g.N + 255) / 256;
+        for (int cand = 4; cand > 1; cand >>= 1) if (cand <= mb_cap && g.M >= 32 * cand && (long long)((g.M + 32 * cand - 1) / (32 * cand)) * tn256 * Z >= 512) { MB = cand; break; }
         const dim3 sgrid((g.M + 32 * MB - 1) / (32 * MB), bgrid.y, Z);
-#define DRIL_SPLIT_LAUNCH(AKv, BNv) { if (MB == 4) hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 4>), sgrid, bblock, 0, s, g); \
-                                      else if (MB == 2) hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 2>), sgrid, bblock, 0, s, g); \
-                                      else hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 1>), sgrid, bblock, 0, s, g); }
+#define DRIL_SPLIT_LAUNCH(AKv, BNv) { if (MB == 4) hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 4, 1>), sgrid, bblock, 0, s, g); \
+                                      else if (MB == 2) hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 2, 1>), sgrid, bblock, 0, s, g); \
+                                      else hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 1, 1>), sgrid, bblock, 0, s, g); }
         if (a_m && b_k) DRIL_SPLIT_LAUNCH(false, false) else if (a_k && b_k) DRIL_SPLIT_LAUNCH(true, false) else if (a_m && b_n) DRIL_SPLIT_LAUNCH(false, true) else DRIL_SPLIT_LAUNCH(true, true)
 #undef DRIL_SPLIT_LAUNCH
     }
