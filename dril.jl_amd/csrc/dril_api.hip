@@ -90,7 +90,8 @@ struct dril_handle {
     double* rms_red = nullptr;   // data-parallel: this step's partial sums folded to one row and summed over ranks
     int grad_stagger = 0;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
-    bool external = false; GenericDims gd{}; GenericWs gws; int ext_t = 0; bool ext_acted = false;   // DRIL_ENV_EXTERNAL: host envs, generic kernels
+    bool external = false; bool generic = false; float* gen_tmp = nullptr;   // generic: layer-by-layer kernels (host envs, or a device env whose hidden_dims the fused kernels are not built for)
+    GenericDims gd{}; GenericWs gws; int ext_t = 0; bool ext_acted = false;   // DRIL_ENV_EXTERNAL: host envs, generic kernels
     float* ext_stage_rew = nullptr; uint8_t* ext_stage_flags = nullptr;   // pinned [T][E] staging: dril_ext_record returns without draining the stream
     void* comm = nullptr;
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
@@ -153,8 +154,15 @@ int ensure_wimg(dril_handle* h) {
 
 // fused per-kind kernels for the device envs, the layer-by-layer generic path for DRIL_ENV_EXTERNAL
 hipError_t run_policy(dril_handle* h, const PolicyArgs& a) {
-    if (h->external) return generic_policy(h->gd, a, h->gws, h->stream);
-    return launch_policy(h->cfg.env_kind, h->cfg.hidden1, a, 8 * h->num_cus, h->stream);
+    if (!h->generic) return launch_policy(h->cfg.env_kind, h->cfg.hidden1, a, 8 * h->num_cus, h->stream);
+    if (a.boot_where) {                       // V(terminal_observation) of the previous env step (fused into policy_kernel on the fused path): critic over all rows, kept where truncated
+        PolicyArgs b = a; b.obs = a.boot_obs; b.noise = nullptr; b.actions = nullptr; b.values = h->gen_tmp; b.logp = nullptr; b.entropy = nullptr; b.mode = 2;
+        b.obs_out = nullptr; b.boot_obs = nullptr; b.boot_where = nullptr; b.boot_out = nullptr; b.gstep = nullptr;
+        hipError_t e = generic_policy(h->gd, b, h->gws, h->stream); if (e != hipSuccess) return e;
+        e = generic_select(a.B, a.boot_where, h->gen_tmp, a.boot_out, h->stream); if (e != hipSuccess) return e;
+    }
+    PolicyArgs q = a; q.boot_obs = nullptr; q.boot_where = nullptr; q.boot_out = nullptr;
+    return generic_policy(h->gd, q, h->gws, h->stream);
 }
 #define NOT_EXTERNAL(h, what) do { if ((h)->external) return fail(h, DRIL_ERR_UNSUPPORTED, what ": the envs of DRIL_ENV_EXTERNAL live on the host (use dril_ext_act / dril_ext_record / dril_ext_finish)"); } while (0)
 
@@ -240,12 +248,12 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     const bool reduce = world > 1 || (h->comm && h->force_allreduce);   // force: exercise the RCCL path on one rank (tests)
     const int64_t tiles = (count + kTile - 1) / kTile;
     int G = h->wide ? (int)(tiles < h->Gmax ? tiles : h->Gmax) : (int)((tiles + 3) / 4); if (G > h->Gmax) G = h->Gmax; if (G < 1) G = 1;
-    if (h->external) { G = generic_pick_slabs(h->gd, count, h->Gmax); if (G < 1) return fail(h, DRIL_ERR_UNSUPPORTED, "minibatch too large for the generic path's workspace"); }
+    if (h->generic) { G = generic_pick_slabs(h->gd, count, h->Gmax); if (G < 1) return fail(h, DRIL_ERR_UNSUPPORTED, "minibatch too large for the generic path's workspace"); }
     { int rcw = ensure_wimg(h); if (rcw) return rcw; }
     const double* adv_stats = h->adv_stats;
     // launch-bound regime (the reference's default batch_size = 64): the advantage moments are computed inside the grad kernel and
     // reduce + norm + Adam run as one workgroup: 2 dependent launches per optimiser step instead of 6
-    const bool small = !reduce && !h->wide && !h->external && h->grad_layout == 1 && count <= 4096 && !std::getenv("DRIL_NO_SMALL_PATH");
+    const bool small = !reduce && !h->wide && !h->generic && h->grad_layout == 1 && count <= 4096 && !std::getenv("DRIL_NO_SMALL_PATH");
     if (h->cfg.normalize_advantage && pre_stats) adv_stats = pre_stats;   // per-epoch table (already all-reduced in data-parallel runs)
     else if (h->cfg.normalize_advantage && small) adv_stats = nullptr;
     else if (h->cfg.normalize_advantage) {
@@ -268,7 +276,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
     g.G = G; g.dbg = h->dbg; g.layout = h->grad_layout; g.stagger = h->grad_stagger; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
     prof_begin(h, DRIL_K_PPO_GRAD);
-    if (h->external) HIPCHK(h, generic_ppo_grad(h->gd, g, h->gws, h->stream));
+    if (h->generic) HIPCHK(h, generic_ppo_grad(h->gd, g, h->gws, h->stream));
     else HIPCHK(h, launch_ppo_grad(h->cfg.env_kind, h->cfg.hidden1, g, h->stream));
     prof_end(h);
     ReduceArgs r{};
@@ -367,7 +375,8 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (ext && (cfg->hidden1 < 1 || cfg->hidden1 > 1024 || cfg->hidden2 < 1 || cfg->hidden2 > 1024)) return fail(nullptr, DRIL_ERR_INVALID_ARG, "DRIL_ENV_EXTERNAL: hidden widths must be 1..1024");
     if (ext && (cfg->norm_obs || cfg->norm_reward || cfg->monitor_window)) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "DRIL_ENV_EXTERNAL: NormalizeWrapperEnv / MonitorWrapperEnv wrap the host env on the host");
     if (cfg->n_envs < 1 || cfg->n_steps < 1 || cfg->epochs < 0 || cfg->batch_size < 1) return fail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs/n_steps/batch_size must be positive");
-    if (!ext && (cfg->hidden1 != cfg->hidden2 || (cfg->hidden1 != 64 && cfg->hidden1 != 128 && cfg->hidden1 != 256))) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "hidden_dims: [64,64], [128,128] and [256,256] are built for the device envs");
+    const bool fused_shape = cfg->hidden1 == cfg->hidden2 && (cfg->hidden1 == 64 || cfg->hidden1 == 128 || cfg->hidden1 == 256);   // other hidden_dims: the generic kernels (any width up to 1024)
+    if (!ext && !fused_shape && (cfg->hidden1 < 1 || cfg->hidden1 > 1024 || cfg->hidden2 < 1 || cfg->hidden2 > 1024)) return fail(nullptr, DRIL_ERR_INVALID_ARG, "hidden widths must be 1..1024");
     if (cfg->monitor_window < 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "monitor_window must be >= 0");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad rank/world_size");
     if (cfg->batch_size % cfg->world_size != 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "batch_size must be divisible by world_size");
@@ -378,7 +387,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
         case DRIL_ENV_CARTPOLE: h->discrete = true; h->D = 4; h->A = 2; h->S = 4; break;
         case DRIL_ENV_MOUNTAINCAR: h->discrete = true; h->D = 2; h->A = 3; h->S = 2; break;
         case DRIL_ENV_MOUNTAINCAR_CONTINUOUS: h->discrete = false; h->D = 2; h->A = 1; h->S = 2; break;
-        case DRIL_ENV_EXTERNAL: h->discrete = cfg->ext_discrete != 0; h->D = cfg->ext_obs_dim; h->A = cfg->ext_action_dim; h->S = 0; h->external = true; break;
+        case DRIL_ENV_EXTERNAL: h->discrete = cfg->ext_discrete != 0; h->D = cfg->ext_obs_dim; h->A = cfg->ext_action_dim; h->S = 0; h->external = true; h->generic = true; break;
         default: h->discrete = false; h->D = 3; h->A = 1; h->S = 2; break;                    // Pendulum, ScalingWrapperEnv(Pendulum)
     }
     h->actor = net_off(0, h->D, cfg->hidden1, cfg->hidden2, h->A);
@@ -387,6 +396,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     h->P = h->critic.end + (h->discrete ? 0 : h->A);
     h->N = (int64_t)cfg->n_envs * cfg->n_steps; h->lr = cfg->learning_rate;
     h->gd = GenericDims{h->D, h->A, cfg->hidden1, cfg->hidden2, h->discrete ? 1 : 0};
+    if (!fused_shape || std::getenv("DRIL_FORCE_GENERIC")) h->generic = true;            // DRIL_FORCE_GENERIC: run a fused-shape handle on the generic kernels (A/B and parity tests)
     if (const char* e = std::getenv("DRIL_GRAD_LAYOUT")) h->grad_layout = std::atoi(e);
     if (const char* e = std::getenv("DRIL_FORCE_ALLREDUCE")) h->force_allreduce = std::atoi(e) != 0;
     if (const char* e = std::getenv("DRIL_FORCE_STEPWISE")) h->force_stepwise = std::atoi(e) != 0;
@@ -403,11 +413,11 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(dmalloc(&h->params, P)); CCHK(dmalloc(&h->adam_m, P)); CCHK(dmalloc(&h->adam_v, P)); CCHK(dmalloc(&h->bt, 4));
     CCHK(dmalloc(&h->flat, P + 8)); CCHK(dmalloc(&h->norm_out, 1));
     h->n_norm_partials = (int)((P + 31) / 32); CCHK(dmalloc(&h->norm_partials, h->n_norm_partials));
-    if (ext) { h->slab_a = generic_slab_size(h->gd, true); h->slab_c = generic_slab_size(h->gd, false); }
+    if (h->generic) { h->slab_a = generic_slab_size(h->gd, true); h->slab_c = generic_slab_size(h->gd, false); }
     else { h->slab_a = slab_size_actor(cfg->env_kind, cfg->hidden1); h->slab_c = slab_size_critic(cfg->env_kind, cfg->hidden1); }
-    h->wide = !ext && cfg->hidden1 > 64;
+    h->wide = !h->generic && cfg->hidden1 > 64;
     h->Gmax = (h->wide && cfg->hidden1 > 128) ? (h->num_cus / 2 > 0 ? h->num_cus / 2 : 1) : h->num_cus;   // H = 128: 4 waves and 77 KB LDS per workgroup, two workgroups per CU   // [64,64]: 2 workgroups per CU (actor + critic), 4 waves each; wide: 1 workgroup of H/32 waves per CU
-    if (ext) h->Gmax = std::getenv("DRIL_EXT_GMAX") ? std::atoi(std::getenv("DRIL_EXT_GMAX")) : 64;                                                         // generic path: one slab per row chunk of the minibatch
+    if (h->generic) h->Gmax = std::getenv("DRIL_EXT_GMAX") ? std::atoi(std::getenv("DRIL_EXT_GMAX")) : 64;                                                         // generic path: one slab per row chunk of the minibatch
     if (const char* e = std::getenv("DRIL_GRAD_GMAX")) { const int g = std::atoi(e); if (g > 0 && g < h->Gmax) h->Gmax = g; }   // diagnostic: fewer workgroups per net
     if (h->wide) { const size_t hh = (size_t)cfg->hidden1 * cfg->hidden1; CCHK(dmalloc(&h->w2a_actor, hh)); CCHK(dmalloc(&h->w2ta_actor, hh)); CCHK(dmalloc(&h->w2a_critic, hh)); CCHK(dmalloc(&h->w2ta_critic, hh)); }
     CCHK(dmalloc(&h->slabs_a, (size_t)h->Gmax * h->slab_a)); CCHK(dmalloc(&h->slabs_c, (size_t)h->Gmax * h->slab_c));
@@ -416,7 +426,8 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(dmalloc(&h->obs, N * h->D)); CCHK(hipMalloc(&h->act, N * act_bytes_per(h))); CCHK(dmalloc(&h->rew, N)); CCHK(dmalloc(&h->adv, N));
     CCHK(dmalloc(&h->ret, N)); CCHK(dmalloc(&h->logp, N)); CCHK(dmalloc(&h->val, N)); CCHK(dmalloc(&h->boot, N)); CCHK(dmalloc(&h->flags, N));
     CCHK(dmalloc(&h->last_values, E));
-    if (!ext && !std::getenv("DRIL_NO_RECORDS")) CCHK(dmalloc(&h->rec, 2 * N));
+    if (!h->generic && !std::getenv("DRIL_NO_RECORDS")) CCHK(dmalloc(&h->rec, 2 * N));
+    if (h->generic) CCHK(dmalloc(&h->gen_tmp, E));
     if (ext) { CCHK(hipHostMalloc((void**)&h->ext_stage_rew, N * 4)); CCHK(hipHostMalloc((void**)&h->ext_stage_flags, N)); }
     if (cfg->monitor_window > 0) {
         const size_t W = cfg->monitor_window;
@@ -458,7 +469,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
                     h->flags, h->last_values, h->noise_dev, h->perm_dev, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
-                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
+                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->gen_tmp, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
                     h->mon_ring_len, h->e_ep_len, h->mon_cnt, h->mon_meta, h->e_flags};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& p : h->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -639,7 +650,7 @@ int collect_rollout_stepwise(dril_handle* h) {
         PolicyArgs p = policy_args(h, h->e_obs, E, nz, (char*)h->act + k * ab, h->val + k, h->logp + k, nullptr, 0);
         p.gstep = h->gstep; p.env_seed0 = h->env_seed0; p.obs_out = h->obs + k * D;
         if (t > 0) { p.boot_obs = h->e_tobs; p.boot_where = h->e_trunc; p.boot_out = h->boot + (k - E); }   // :57-61 for step t-1
-        HIPCHK(h, launch_policy(h->cfg.env_kind, h->cfg.hidden1, p, 8 * h->num_cus, h->stream));   // get_action_and_values, :41
+        HIPCHK(h, run_policy(h, p));   // get_action_and_values, :41
         NormStepArgs s{};
         s.E = E; s.episode_len = h->cfg.episode_len; s.fixed_len = h->cfg.fixed_length_episodes; s.action_start = h->cfg.action_start;
         s.seed0 = h->env_seed0; s.gamma = h->cfg.norm_gamma; s.update_ret = (h->cfg.norm_reward && h->cfg.norm_training) ? 1 : 0;
@@ -662,14 +673,14 @@ int collect_rollout_stepwise(dril_handle* h) {
     }
     PolicyArgs l = policy_args(h, h->e_obs, E, nullptr, nullptr, h->last_values, nullptr, nullptr, 2);
     l.boot_obs = h->e_tobs; l.boot_where = h->e_trunc; l.boot_out = h->boot + (size_t)(T - 1) * E;
-    HIPCHK(h, launch_policy(h->cfg.env_kind, h->cfg.hidden1, l, 8 * h->num_cus, h->stream));       // V(new_obs) for rollout-limited tails, :65-70
+    HIPCHK(h, run_policy(h, l));       // V(new_obs) for rollout-limited tails, :65-70
     return monitor_collect_rollout(h);
 }
 
 int collect_rollout(dril_handle* h, double* fps, bool do_sync) {
     if (!h->env_ready) return fail(h, DRIL_ERR_NOT_INITIALISED, "dril_collect_rollout before dril_env_reset");
     { int rcw = ensure_wimg(h); if (rcw) return rcw; }
-    if (normalizing(h) || h->force_stepwise) {
+    if (normalizing(h) || h->force_stepwise || h->generic) {            // generic nets have no fused rollout kernel: step-granular launches
         const auto t0s = std::chrono::steady_clock::now();
         if (fps) HIPCHK(h, hipStreamSynchronize(h->stream));
         prof_begin(h, DRIL_K_ROLLOUT);
@@ -1001,7 +1012,7 @@ DRIL_EXPORT int32_t dril_evaluate_agent(dril_handle* h, int32_t n_eval, int32_t 
         PolicyArgs p = policy_args(h, h->e_obs, E, nullptr, h->e_act, nullptr, h->logp /*scratch*/, nullptr, 0);
         p.gstep = h->gstep; p.env_seed0 = h->env_seed0; p.deterministic = deterministic ? 1 : 0;
         p.logp = h->e_rew;                                                       // logprobs are not needed: park them in a scratch array
-        HIPCHK(h, launch_policy(h->cfg.env_kind, h->cfg.hidden1, p, 8 * h->num_cus, h->stream));   // predict_actions(agent, observations; deterministic), :92
+        HIPCHK(h, run_policy(h, p));   // predict_actions(agent, observations; deterministic), :92
         rc = step_dev(h, h->e_act, rew_n, nullptr); if (rc) return rc;           // act!(env, actions), :94
         HIPCHK(h, hipMemcpyAsync(rew.data(), raw ? h->e_rew : rew_n, (size_t)E * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipMemcpyAsync(term.data(), h->e_term, E, hipMemcpyDeviceToHost, h->stream));

@@ -112,6 +112,7 @@ __global__ void generic_policy_head_kernel(PolicyHeadArgs g) {
             } else {
                 double u;
                 if (a.noise) u = ((const double*)a.noise)[b];
+                else if (a.gstep) { const uint64_t k = a.env_seed0 + (uint64_t)b; uint32_t r[4]; philox4x32_10((uint32_t)k, (uint32_t)(k >> 32), a.gstep[b], 0, 1, 0, r); u = u01_f64(r[0], r[1]); }   // device envs: the env-keyed stream of rollout_kernel
                 else { uint32_t r[4]; philox4x32_10((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)b, (uint32_t)(b >> 32), 3, a.call_counter, r); u = u01_f64(r[0], r[1]); }
                 float cs = 0.f; act = A - 1;                                          // findfirst(cumsum(p) .>= u), categorical.jl:47-52
                 for (int k = 0; k < A; ++k) { cs += expf(z[k] - m) / s; if ((double)cs >= u) { act = k; break; } }
@@ -128,6 +129,7 @@ __global__ void generic_policy_head_kernel(PolicyHeadArgs g) {
             for (int k = 0; k < A; ++k) {
                 float n01;
                 if (a.noise) n01 = ((const float*)a.noise)[b * A + k];
+                else if (a.gstep) { const uint64_t kk = a.env_seed0 + (uint64_t)b; uint32_t r[4]; philox4x32_10((uint32_t)kk, (uint32_t)(kk >> 32), a.gstep[b], 0, 1, (uint32_t)(k / 2), r); n01 = (k & 1) ? randn_f32(r[2], r[3]) : randn_f32(r[0], r[1]); }
                 else { uint32_t r[4]; philox4x32_10((uint32_t)a.seed, (uint32_t)(a.seed >> 32), (uint32_t)b, (uint32_t)(b >> 32), 3 + 16 * (uint32_t)k, a.call_counter, r); n01 = randn_f32(r[0], r[1]); }
                 x[k] = a.deterministic ? z[k] : z[k] + expf(ls[k]) * n01;                // diagGaussian.jl:13-17, mode(d) = mean :45-47
             }
@@ -135,6 +137,10 @@ __global__ void generic_policy_head_kernel(PolicyHeadArgs g) {
         a.logp[b] = gauss_logpdf_rt(x, z, ls, A);
         if (a.mode == 1 && a.entropy) a.entropy[b] = gauss_entropy_rt(ls, A);
     }
+}
+__global__ void generic_select_kernel(int64_t n, const uint8_t* where, const float* src, float* dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && where[i]) dst[i] = src[i];
 }
 __global__ void generic_copy_kernel(const float* src, float* dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,6 +296,11 @@ hipError_t run_backward_both(const BackwardPlan& a, const BackwardPlan& c, hipSt
 }
 
 }  // namespace
+
+hipError_t generic_select(int64_t n, const uint8_t* where, const float* src, float* dst, hipStream_t s) {
+    generic_select_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, where, src, dst);
+    return hipGetLastError();
+}
 
 void generic_ws_free(GenericWs& ws) { if (ws.p) (void)hipFree(ws.p); ws.p = nullptr; ws.cap = 0; }
 

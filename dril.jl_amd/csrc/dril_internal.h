@@ -141,5 +141,6 @@ hipError_t generic_ppo_grad(const GenericDims& d, const GradArgs& a, GenericWs& 
 int generic_slab_size(const GenericDims& d, bool actor);
 int generic_pick_slabs(const GenericDims& d, int64_t count, int Gmax);   // slabs (row chunks) for a minibatch of `count` rows; < 1: does not fit
 void generic_ws_free(GenericWs& ws);
+hipError_t generic_select(int64_t n, const uint8_t* where, const float* src, float* dst, hipStream_t s);   // dst[i] = src[i] where where[i] != 0
 
 }  // namespace dril

@@ -101,7 +101,8 @@ typedef struct dril_config {
     int32_t env_kind;          /* enum dril_env_kind */
     int32_t n_envs;            /* E on THIS rank */
     int32_t n_steps;           /* T (PPO.n_steps) */
-    int32_t hidden1, hidden2;  /* hidden_dims = [hidden1, hidden2]; built: [64,64], [128,128], [256,256]; DRIL_ENV_EXTERNAL: any h1, h2 <= 1024 */
+    int32_t hidden1, hidden2;  /* hidden_dims = [hidden1, hidden2], 1..1024 each: [64,64], [128,128], [256,256] run the fused kernels, every other shape
+                                * (and DRIL_ENV_EXTERNAL) the generic layer-by-layer kernels */
     int32_t episode_len;       /* max_steps kwarg: 500 CartPole-v1, 200 Pendulum-v1 */
     int32_t fixed_length_episodes; /* 1: termination disabled (synthetic bench episodes) */
     int32_t action_start;      /* Discrete(n, start): src/spaces.jl:157-164 */

@@ -287,3 +287,70 @@ def test_train_on_host_envs_learns(pkg):
     assert set(ev) == {"mean_reward", "std_reward", "mean_length", "std_length"} and 1 <= ev["mean_length"] <= 25 and ev["mean_reward"] < 0
     er, el = pkg.evaluate_agent(agent, env, n_eval_episodes=5, return_stats=False)
     assert len(er) == len(el) == 5
+
+
+# ---- device envs with hidden_dims the fused kernels are not built for: the same generic kernels, step-granular rollout on the device -----------------
+@pytest.mark.parametrize("kind,H1,H2,norm", [(0, 32, 48, 0), (1, 100, 36, 1), (3, 64, 128, 0), (4, 512, 512, 0), (2, 24, 24, 1)])
+def test_device_env_with_other_hidden_dims(pkg, oracle_mod, kind, H1, H2, norm):
+    """CartPole / Pendulum / MountainCar with hidden_dims outside {[64,64], [128,128], [256,256]}: rollout (env-keyed or injected noise, truncation
+    bootstraps, NormalizeWrapperEnv) and the PPO update against the oracle"""
+    capi = pkg._capi
+    E, T = 40, 24
+    c = capi.default_config(kind)
+    for k, v in dict(n_envs=E, n_steps=T, episode_len=10, batch_size=E * T // 3, epochs=2, hidden1=H1, hidden2=H2, norm_training=norm, norm_obs=norm, norm_reward=norm).items():
+        setattr(c, k, v)
+    h, o = pkg.Handle(c), oracle_mod.Oracle(c)
+    flat = _params(h.P, 12, 0.08); h.set_params(flat); o.set_params(flat)
+    h.env_reset(4); o.env_reset(4)
+    nz = np.random.default_rng(0).random(E * T) if h.discrete else np.random.default_rng(0).standard_normal((E * T, h.A)).astype(np.float32)
+    h.set_noise(nz); o.set_noise(nz)
+    h.collect_rollout(); o.collect_rollout()
+    fl = o.buffer(capi.BUF_FLAGS)
+    assert (fl & 2).any()
+    if h.discrete:
+        same = (h.buffer(capi.BUF_ACTIONS).reshape(T, E) == o.buffer(capi.BUF_ACTIONS).reshape(T, E))
+        ok = np.cumprod(same, axis=0).astype(bool).all(axis=0)                        # envs whose action sequence never flipped on a rounding tie
+        assert ok.mean() >= 0.9
+    else:
+        ok = np.ones(E, bool)
+    for which, tol in ((capi.BUF_OBSERVATIONS, 2e-4), (capi.BUF_VALUES, 3e-4), (capi.BUF_LOGPROBS, 3e-4), (capi.BUF_REWARDS, 3e-4), (capi.BUF_ADVANTAGES, 3e-3), (capi.BUF_RETURNS, 3e-3)):
+        a, b = h.buffer(which).reshape(T, E, -1), o.buffer(which).reshape(T, E, -1)
+        np.testing.assert_allclose(a[:, ok], b[:, ok], atol=tol, rtol=tol)
+    tr = ((fl & 2) != 0).reshape(T, E) & ok[None, :]
+    np.testing.assert_allclose(h.buffer(capi.BUF_BOOTSTRAP).reshape(T, E)[tr], o.buffer(capi.BUF_BOOTSTRAP).reshape(T, E)[tr], atol=3e-4, rtol=3e-4)
+    for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+        h.set_buffer(which, o.buffer(which))
+    perm = np.stack([np.random.default_rng(e).permutation(E * T) for e in range(c.epochs)]).astype(np.int64)
+    h.set_permutation(perm); o.set_permutation(perm)
+    sh, so = h.ppo_update(), o.ppo_update()
+    assert sh.n_updates == so.n_updates == 6 and sh.loss == pytest.approx(so.loss, rel=2e-4, abs=1e-6)
+    np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=3e-4, atol=3e-6)
+    # the env-keyed Philox stream (no injected noise), train and evaluate_agent run on the same kernels
+    st, fps = h.train(2 * E * T)
+    assert len(st) == 2 and np.isfinite([s.loss for s in st]).all()
+    ev, er, el = h.evaluate_agent(5, True)
+    assert len(er) == 5 and (el >= 1).all() and (el <= 10).all()
+
+
+def test_forced_generic_equals_fused(pkg, monkeypatch):
+    """DRIL_FORCE_GENERIC=1 runs a [64,64] CartPole handle on the generic kernels: same rollout (same env-keyed noise) and update as the fused kernels"""
+    capi = pkg._capi
+    E, T = 64, 16
+    c = capi.default_config(capi.ENV_CARTPOLE)
+    c.n_envs, c.n_steps, c.batch_size, c.epochs, c.episode_len, c.seed = E, T, E * T // 2, 2, 9, 3
+    fused = pkg.Handle(c)
+    monkeypatch.setenv("DRIL_FORCE_GENERIC", "1")
+    gen = pkg.Handle(c)
+    monkeypatch.delenv("DRIL_FORCE_GENERIC")
+    flat = _params(fused.P, 3, 0.4)
+    for hh in (fused, gen):
+        hh.set_params(flat); hh.env_reset(11); hh.collect_rollout()
+    assert (gen.buffer(capi.BUF_ACTIONS) == fused.buffer(capi.BUF_ACTIONS)).mean() > 0.99
+    same = (gen.buffer(capi.BUF_ACTIONS).reshape(T, E) == fused.buffer(capi.BUF_ACTIONS).reshape(T, E)).all(axis=0)
+    for which, tol in ((capi.BUF_OBSERVATIONS, 1e-6), (capi.BUF_VALUES, 3e-5), (capi.BUF_LOGPROBS, 3e-5), (capi.BUF_ADVANTAGES, 3e-4)):
+        np.testing.assert_allclose(gen.buffer(which).reshape(T, E, -1)[:, same], fused.buffer(which).reshape(T, E, -1)[:, same], atol=tol, rtol=tol)
+    for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+        gen.set_buffer(which, fused.buffer(which))
+    sg, sf = gen.ppo_update(), fused.ppo_update()                                         # device-generated minibatch order: the same keyed bijection on both paths
+    assert sg.n_updates == sf.n_updates == 4 and sg.loss == pytest.approx(sf.loss, rel=1e-4)
+    np.testing.assert_allclose(gen.get_params(), fused.get_params(), rtol=2e-4, atol=2e-6)
