@@ -12,7 +12,7 @@ __graft_entry__.py / tests/conftest.py) under the module name `dril_jl_amd`.
 """
 from . import _capi  # noqa: F401
 from .host import (  # noqa: F401
-    Agent, ActorCriticLayer, Box, CartPoleEnv, ContinuousActorCriticLayer, DeviceParallelEnv, Discrete, HostParallelEnv,
+    AcrobotEnv, Agent, ActorCriticLayer, Box, CartPoleEnv, ContinuousActorCriticLayer, DeviceParallelEnv, Discrete, HostParallelEnv,
     DiscreteActorCriticLayer, DrilError, Handle, MonitorWrapperEnv, MountainCarContinuousEnv, MountainCarEnv, NormalizeWrapperEnv, PendulumEnv, PPO, RolloutBuffer, ScalingWrapperEnv, collect_rollout_,
     evaluate_agent, flatten_params, get_action_and_values, make_config, predict_values, train_, unflatten_params,
 )

@@ -131,11 +131,50 @@ template <> struct EnvSpec<1> { static constexpr int D = 3, S = 2, A = 1; static
 template <> struct EnvSpec<2> : EnvSpec<1> {};   // ScalingWrapperEnv(PendulumEnv()): same simulator, affine maps at the boundary
 template <> struct EnvSpec<3> { static constexpr int D = 2, S = 2, A = 3; static constexpr bool discrete = true; };    // MountainCar-v0: (position, velocity), Discrete(3)
 template <> struct EnvSpec<4> { static constexpr int D = 2, S = 2, A = 1; static constexpr bool discrete = false; };   // MountainCarContinuous-v0: Box(-1, 1)
+template <> struct EnvSpec<6> { static constexpr int D = 6, S = 4, A = 3; static constexpr bool discrete = true; };    // Acrobot-v1: (cos t1, sin t1, cos t2, sin t2, w1, w2), Discrete(3); generic kernels only (D > 4)
 // ScalingWrapperEnv (scalingWrapperEnv.jl): scale! :71-74 `(x - low) * sf - 1`, unscale! :76-79 `(x + 1) / sf + low`, sf = 2 / (high - low) :36-44
 __host__ __device__ inline float scale_to_unit(float x, float low, float high) { const float sf = 2.0f / (high - low); return (x - low) * sf - 1.0f; }
 __host__ __device__ inline float unscale_from_unit(float x, float low, float high) { const float sf = 2.0f / (high - low); return (x + 1.0f) / sf + low; }
 // bound of the agent-facing action space (ClampAdapter / TanhScaleAdapter act on action_space(env)): Box(-2,2), Box(-1,1) under the wrapper
 template <int KIND> __host__ __device__ constexpr float act_bound() { return (KIND == 2 || KIND == 4) ? 1.0f : 2.0f; }
+
+// Acrobot-v1 (Gymnasium, "book" dynamics): d(theta1, theta2, dtheta1, dtheta2)/dt under torque a on the second joint
+__host__ __device__ inline void acrobot_dsdt(const float* s, float a, float* ds) {
+    const float m1 = 1.0f, m2 = 1.0f, l1 = 1.0f, lc1 = 0.5f, lc2 = 0.5f, I1 = 1.0f, I2 = 1.0f, g = 9.8f, hpi = 1.57079632679489661923f;
+    const float t1 = s[0], t2 = s[1], w1 = s[2], w2 = s[3];
+    const float c2 = cosf(t2), s2 = sinf(t2);
+    const float d1 = m1 * lc1 * lc1 + m2 * (l1 * l1 + lc2 * lc2 + 2.0f * l1 * lc2 * c2) + I1 + I2;
+    const float d2 = m2 * (lc2 * lc2 + l1 * lc2 * c2) + I2;
+    const float phi2 = m2 * lc2 * g * cosf(t1 + t2 - hpi);
+    const float phi1 = -m2 * l1 * lc2 * w2 * w2 * s2 - 2.0f * m2 * l1 * lc2 * w2 * w1 * s2 + (m1 * lc1 + m2 * l1) * g * cosf(t1 - hpi) + phi2;
+    const float dd2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * w1 * w1 * s2 - phi2) / (m2 * lc2 * lc2 + I2 - d2 * d2 / d1);
+    const float dd1 = -(d2 * dd2 + phi1) / d1;
+    ds[0] = w1; ds[1] = w2; ds[2] = dd1; ds[3] = dd2;
+}
+__host__ __device__ inline float acrobot_wrap(float x) {            // wrap(x, -pi, pi): while loops of the Gymnasium helper
+    const float pi = 3.14159265358979323846f;
+    while (x > pi) x -= 2.0f * pi;
+    while (x < -pi) x += 2.0f * pi;
+    return x;
+}
+// one env step (dt = 0.2, one RK4 step); returns the reward, sets *terminated
+__host__ __device__ inline float acrobot_step(float* st, int act_i, bool fixed_len, bool* terminated) {
+    const float dt = 0.2f, a = (float)(act_i - 1), pi = 3.14159265358979323846f;
+    float k1[4], k2[4], k3[4], k4[4], y[4];
+    acrobot_dsdt(st, a, k1);
+    for (int i = 0; i < 4; ++i) y[i] = st[i] + 0.5f * dt * k1[i];
+    acrobot_dsdt(y, a, k2);
+    for (int i = 0; i < 4; ++i) y[i] = st[i] + 0.5f * dt * k2[i];
+    acrobot_dsdt(y, a, k3);
+    for (int i = 0; i < 4; ++i) y[i] = st[i] + dt * k3[i];
+    acrobot_dsdt(y, a, k4);
+    for (int i = 0; i < 4; ++i) y[i] = st[i] + dt / 6.0f * (k1[i] + 2.0f * k2[i] + 2.0f * k3[i] + k4[i]);
+    st[0] = acrobot_wrap(y[0]); st[1] = acrobot_wrap(y[1]);
+    st[2] = fminf(fmaxf(y[2], -4.0f * pi), 4.0f * pi); st[3] = fminf(fmaxf(y[3], -9.0f * pi), 9.0f * pi);
+    const bool term = -cosf(st[0]) - cosf(st[1] + st[0]) > 1.0f;
+    *terminated = fixed_len ? false : term;
+    return term ? 0.0f : -1.0f;
+}
 
 template <int KIND> __device__ inline void env_reset(uint64_t env_seed, uint32_t episode, float* st) {
     uint32_t r[4];
@@ -143,6 +182,9 @@ template <int KIND> __device__ inline void env_reset(uint64_t env_seed, uint32_t
     if (KIND == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) st[i] = u01_f32(r[i]) * 0.1f - 0.05f;
+    } else if (KIND == 6) {                                        // Acrobot: U(-0.1, 0.1)^4
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st[i] = u01_f32(r[i]) * 0.2f - 0.1f;
     } else if (KIND == 3 || KIND == 4) {                           // MountainCar: position ~ U(-0.6, -0.4), velocity 0
         st[0] = u01_f32(r[0]) * 0.2f - 0.6f; st[1] = 0.f;
     } else {
@@ -155,6 +197,7 @@ template <int KIND> __device__ inline void env_obs(const float* st, float* obs) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) obs[i] = st[i];
     } else if (KIND == 3 || KIND == 4) { obs[0] = st[0]; obs[1] = st[1]; }
+    else if (KIND == 6) { obs[0] = cosf(st[0]); obs[1] = sinf(st[0]); obs[2] = cosf(st[1]); obs[3] = sinf(st[1]); obs[4] = st[2]; obs[5] = st[3]; }
     else {
         obs[0] = cosf(st[0]); obs[1] = sinf(st[0]); obs[2] = st[1];
         if (KIND == 2) {                                           // observe(::ScalingWrapperEnv) :93-98 on Box((-1,-1,-8), (1,1,8))
@@ -164,6 +207,7 @@ template <int KIND> __device__ inline void env_obs(const float* st, float* obs) 
 }
 // one step; act_i is the env-space discrete action (0/1), act_f the env-space continuous action
 template <int KIND> __device__ inline float env_step(float* st, float act_f, int act_i, bool fixed_len, bool* terminated) {
+    if (KIND == 6) return acrobot_step(st, act_i, fixed_len, terminated);
     if (KIND == 0) {
         const float gravity = 9.8f, masspole = 0.1f, total_mass = 1.1f, length = 0.5f;
         const float polemass_length = 0.05f, force_mag = 10.0f, tau = 0.02f;

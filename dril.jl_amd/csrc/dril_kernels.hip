@@ -2340,6 +2340,7 @@ hipError_t launch_env_reset(int kind, int E, uint64_t seed0, float* state, int32
     const int blocks = (E + 255) / 256;
     if (kind == 0) env_reset_kernel<0><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
     else if (kind == 3 || kind == 4) env_reset_kernel<3><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
+    else if (kind == 6) env_reset_kernel<6><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
     else env_reset_kernel<1><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
     return hipGetLastError();
 }
@@ -2348,6 +2349,7 @@ hipError_t launch_env_observe(int kind, int E, const float* state, float* obs, h
     if (kind == 0) env_observe_kernel<0><<<blocks, 256, 0, s>>>(E, state, obs);
     else if (kind == 1) env_observe_kernel<1><<<blocks, 256, 0, s>>>(E, state, obs);
     else if (kind == 2) env_observe_kernel<2><<<blocks, 256, 0, s>>>(E, state, obs);
+    else if (kind == 6) env_observe_kernel<6><<<blocks, 256, 0, s>>>(E, state, obs);
     else env_observe_kernel<3><<<blocks, 256, 0, s>>>(E, state, obs);
     return hipGetLastError();
 }
@@ -2359,6 +2361,7 @@ hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int
     else if (kind == 1) env_step_kernel<1><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
     else if (kind == 2) env_step_kernel<2><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
     else if (kind == 3) env_step_kernel<3><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
+    else if (kind == 6) env_step_kernel<6><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
     else env_step_kernel<4><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
     return hipGetLastError();
 }
@@ -2371,7 +2374,7 @@ hipError_t launch_monitor_collect(const uint8_t* flags, const float* ep_ret, con
 
 hipError_t launch_norm_step(int kind, const NormStepArgs& a, int nblocks, hipStream_t s) {
     if (kind == 0) norm_step_kernel<0><<<nblocks, 256, 0, s>>>(a); else if (kind == 1) norm_step_kernel<1><<<nblocks, 256, 0, s>>>(a); else if (kind == 2) norm_step_kernel<2><<<nblocks, 256, 0, s>>>(a);
-    else if (kind == 3) norm_step_kernel<3><<<nblocks, 256, 0, s>>>(a); else norm_step_kernel<4><<<nblocks, 256, 0, s>>>(a);
+    else if (kind == 3) norm_step_kernel<3><<<nblocks, 256, 0, s>>>(a); else if (kind == 6) norm_step_kernel<6><<<nblocks, 256, 0, s>>>(a); else norm_step_kernel<4><<<nblocks, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 hipError_t launch_norm_apply(const NormApplyArgs& a, hipStream_t s) {
@@ -2383,6 +2386,7 @@ hipError_t launch_obs_partials(int kind, int E, const float* state, float* raw, 
     if (kind == 0) obs_partials_kernel<0><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
     else if (kind == 1) obs_partials_kernel<1><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
     else if (kind == 2) obs_partials_kernel<2><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
+    else if (kind == 6) obs_partials_kernel<6><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
     else obs_partials_kernel<3><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
     return hipGetLastError();
 }

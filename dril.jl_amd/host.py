@@ -98,6 +98,20 @@ class MountainCarEnv:
 
 
 @dataclass
+class AcrobotEnv:
+    """Acrobot-v1 (Gymnasium "book" dynamics; ClassicControlEnvironments.jl in the reference): six observation dims -> generic kernels"""
+    max_steps: int = 500
+    action_start: int = 1
+    kind: int = capi.ENV_ACROBOT
+
+    def observation_space(self):
+        return Box((-1.0, -1.0, -1.0, -1.0, -12.566371, -28.274334), (1.0, 1.0, 1.0, 1.0, 12.566371, 28.274334))
+
+    def action_space(self):
+        return Discrete(3, self.action_start)
+
+
+@dataclass
 class MountainCarContinuousEnv:
     """MountainCarContinuous-v0"""
     max_steps: int = 999
@@ -408,7 +422,7 @@ class Handle:
         return rew, term.astype(bool), trunc.astype(bool), tobs
 
     def env_get_state(self):
-        S = 4 if self.cfg.env_kind == capi.ENV_CARTPOLE else 2      # CartPole (x, x_dot, theta, theta_dot); Pendulum (theta, theta_dot); MountainCar (position, velocity)
+        S = 4 if self.cfg.env_kind in (capi.ENV_CARTPOLE, capi.ENV_ACROBOT) else 2      # CartPole / Acrobot (theta1, theta2, dtheta1, dtheta2); (x, x_dot, theta, theta_dot); Pendulum (theta, theta_dot); MountainCar (position, velocity)
         st = np.empty((self.E, S), np.float32)
         sc = np.empty(self.E, np.int32)
         self._chk(self.lib.dril_env_get_state(self._h, self._p(st), self._p(sc)))

@@ -61,7 +61,11 @@ enum dril_env_kind {
      * sampling, rollout buffer, bootstrap values, GAE, the PPO update — runs on the device.  Spaces are given by ext_obs_dim / ext_action_dim /
      * ext_discrete; any hidden_dims = [h1, h2] up to 1024.  The env verbs (dril_env_*), dril_collect_rollout, dril_train, dril_evaluate_agent
      * and the wrappers fused into the env kernels (norm_*, monitor_window) belong to the device envs and return DRIL_ERR_UNSUPPORTED here */
-    DRIL_ENV_EXTERNAL = 5
+    DRIL_ENV_EXTERNAL = 5,
+    /* Acrobot-v1 (Gymnasium "book" dynamics, one RK4 step of 0.2 s per env step): D=6 (cos t1, sin t1, cos t2, sin t2, w1, w2), Discrete(3) torques
+     * -1/0/+1, reward -1 per step (0 on reaching the height), limit 500.  A device env like the others; its six observation dims exceed the fused
+     * kernels' first-layer pairing, so it always runs on the generic kernels (any hidden_dims) */
+    DRIL_ENV_ACROBOT = 6
 };
 
 /* ids for dril_buffer_copy_out / dril_buffer_copy_in (fields of RolloutBuffer,

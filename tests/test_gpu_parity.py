@@ -60,7 +60,7 @@ def test_gae_random_vs_oracle(pkg, lib, oracle_mod):
         np.testing.assert_allclose(out[1], out[3], atol=1e-4, rtol=1e-5)
 
 
-@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])                 # 2 = ScalingWrapperEnv(Pendulum); 3 / 4 = MountainCar-v0 / MountainCarContinuous-v0
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 6])              # 2 = ScalingWrapperEnv(Pendulum); 3 / 4 = MountainCar-v0 / MountainCarContinuous-v0; 6 = Acrobot-v1
 def test_env_verbs_match_oracle(pkg, oracle_mod, kind):
     """reset!/observe/act! with auto-reset and terminal_observation (multithreadedParallelEnv.jl:12-74)"""
     cfg = _cfg(pkg, kind, n_envs=300, n_steps=4, episode_len=7, batch_size=4)
@@ -70,15 +70,15 @@ def test_env_verbs_match_oracle(pkg, oracle_mod, kind):
     rng = np.random.default_rng(1)
     saw_trunc = False
     for step in range(20):
-        np.testing.assert_allclose(h.env_observe(), o.env_observe(), atol=2e-6, rtol=2e-6)
+        np.testing.assert_allclose(h.env_observe(), o.env_observe(), atol=2e-6 if kind != 6 else 2e-5, rtol=2e-6 if kind != 6 else 2e-5)
         a = (rng.integers(0, h.A, cfg.n_envs) + cfg.action_start).astype(np.int32) if h.discrete else rng.uniform(-3, 3, (cfg.n_envs, 1)).astype(np.float32)
         rh, th, uh, oh = h.env_step(a); ro, to, uo, oo = o.env_step(a)
         np.testing.assert_array_equal(th, to); np.testing.assert_array_equal(uh, uo)
         np.testing.assert_allclose(rh, ro, atol=1e-5, rtol=1e-5)
-        np.testing.assert_allclose(oh[uh], oo[uo], atol=1e-5, rtol=1e-5)              # terminal_observation only where truncated
+        np.testing.assert_allclose(oh[uh], oo[uo], atol=1e-5 if kind != 6 else 1e-4, rtol=1e-5 if kind != 6 else 1e-4)              # terminal_observation only where truncated
         sh, ch = h.env_get_state(); so, co = o.env_get_state()
         np.testing.assert_array_equal(ch, co)
-        np.testing.assert_allclose(sh, so, atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(sh, so, atol=1e-5 if kind != 6 else 1e-4, rtol=1e-5 if kind != 6 else 1e-4)        # Acrobot: one RK4 step = 12 sin/cos per env step
         o.env_set_state(sh, ch)                                                       # teacher forcing: no drift accumulation
         saw_trunc |= bool(uh.any())
     assert saw_trunc

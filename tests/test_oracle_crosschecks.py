@@ -302,6 +302,79 @@ def test_mountaincar_physics_vs_gymnasium_equations(oracle_mod, pkg, kind):
     assert saw_goal and saw_wall
 
 
+def _acrobot_f64(s, a):
+    """Gymnasium acrobot.py in float64: _dsdt ("book"), rk4 over [0, 0.2], wrap, bound, termination, reward"""
+    m1 = m2 = l1 = 1.0; lc1 = lc2 = 0.5; I1 = I2 = 1.0; g = 9.8; pi = math.pi
+
+    def dsdt(y):
+        t1, t2, w1, w2 = y
+        d1 = m1 * lc1 ** 2 + m2 * (l1 ** 2 + lc2 ** 2 + 2 * l1 * lc2 * math.cos(t2)) + I1 + I2
+        d2 = m2 * (lc2 ** 2 + l1 * lc2 * math.cos(t2)) + I2
+        phi2 = m2 * lc2 * g * math.cos(t1 + t2 - pi / 2.0)
+        phi1 = -m2 * l1 * lc2 * w2 ** 2 * math.sin(t2) - 2 * m2 * l1 * lc2 * w2 * w1 * math.sin(t2) + (m1 * lc1 + m2 * l1) * g * math.cos(t1 - pi / 2) + phi2
+        dd2 = (a + d2 / d1 * phi1 - m2 * l1 * lc2 * w1 ** 2 * math.sin(t2) - phi2) / (m2 * lc2 ** 2 + I2 - d2 ** 2 / d1)
+        dd1 = -(d2 * dd2 + phi1) / d1
+        return np.array([w1, w2, dd1, dd2])
+
+    dt = 0.2
+    y0 = np.asarray(s, np.float64)
+    k1 = dsdt(y0); k2 = dsdt(y0 + dt / 2 * k1); k3 = dsdt(y0 + dt / 2 * k2); k4 = dsdt(y0 + dt * k3)
+    ns = y0 + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+    def wrap(x):
+        while x > pi:
+            x -= 2 * pi
+        while x < -pi:
+            x += 2 * pi
+        return x
+
+    ns[0], ns[1] = wrap(ns[0]), wrap(ns[1])
+    ns[2], ns[3] = min(max(ns[2], -4 * pi), 4 * pi), min(max(ns[3], -9 * pi), 9 * pi)
+    term = -math.cos(ns[0]) - math.cos(ns[1] + ns[0]) > 1.0
+    return ns, (0.0 if term else -1.0), term
+
+
+def test_acrobot_physics_vs_gymnasium_equations(oracle_mod, pkg):
+    """Acrobot-v1: reset distribution, one RK4 step of the book dynamics per env step, angle wrap, velocity bounds, the height
+    termination with reward 0, time limit + auto-reset"""
+    capi = pkg._capi
+    assert capi.default_config(capi.ENV_ACROBOT).episode_len == 500
+    cfg = capi.default_config(capi.ENV_ACROBOT); cfg.n_envs, cfg.n_steps, cfg.episode_len = 32, 4, 60
+    o = oracle_mod.Oracle(cfg); o.env_reset(5)
+    assert (o.D, o.A, o.discrete) == (6, 3, True)
+    st, _ = o.env_get_state()
+    assert st.shape == (32, 4) and np.all(np.abs(st) <= 0.1) and np.abs(st).max() > 0.05
+    obs = o.env_observe()
+    np.testing.assert_allclose(obs, np.stack([np.cos(st[:, 0]), np.sin(st[:, 0]), np.cos(st[:, 1]), np.sin(st[:, 1]), st[:, 2], st[:, 3]], 1), atol=1e-6)
+    rng = np.random.default_rng(0)
+    st[:3] = [[3.0, 0.1, 12.4, 1.0], [2.9, 0.2, 0.5, 28.0], [-3.1, -3.0, -12.5, -28.2]]      # next to the wrap and the velocity bounds, above the bar
+    o.env_set_state(st, np.zeros(32, np.int32))
+    saw_term = saw_wrap = saw_bound = False
+    for step in range(1, 70):
+        a = (rng.integers(0, 3, 32) + cfg.action_start).astype(np.int32)
+        if step > 8:
+            a[:16] = np.where(o.env_get_state()[0][:16, 2] > 0, cfg.action_start + 2, cfg.action_start)   # pump energy into half of the arms so that some reach the height
+        prev, psc = o.env_get_state()
+        rew, term, trunc, tobs = o.env_step(a)
+        cur, sc = o.env_get_state()
+        for e in range(32):
+            exp, r, tm = _acrobot_f64(prev[e], float(a[e] - cfg.action_start - 1))
+            height = -math.cos(exp[0]) - math.cos(exp[1] + exp[0])
+            edge = abs(height - 1.0) < 1e-4 or min(abs(abs(exp[0]) - math.pi), abs(abs(exp[1]) - math.pi)) < 1e-4    # f32 vs f64 may fall on either side
+            if not edge:
+                assert bool(term[e]) == tm and rew[e] == r
+            saw_term |= bool(term[e]); saw_wrap |= abs(exp[0] - prev[e][0]) > 3.0 or abs(exp[1] - prev[e][1]) > 3.0
+            saw_bound |= abs(abs(exp[2]) - 4 * math.pi) < 1e-9 or abs(abs(exp[3]) - 9 * math.pi) < 1e-9
+            assert bool(trunc[e]) == (psc[e] + 1 >= 60)
+            if term[e] or trunc[e]:
+                assert np.all(np.abs(cur[e]) <= 0.1) and sc[e] == 0                                   # auto-reset
+                if trunc[e] and not edge:
+                    np.testing.assert_allclose(tobs[e], [math.cos(exp[0]), math.sin(exp[0]), math.cos(exp[1]), math.sin(exp[1]), exp[2], exp[3]], rtol=2e-4, atol=2e-4)
+            elif not edge:
+                np.testing.assert_allclose(cur[e], exp, rtol=2e-4, atol=2e-4)
+    assert saw_term and saw_wrap and saw_bound
+
+
 def test_update_loop_control_flow(oracle_mod, pkg):
     """ppo.jl:205-254: partial last batch kept, target_kl early stop skips the apply and both loops."""
     capi = pkg._capi
