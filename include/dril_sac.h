@@ -49,7 +49,7 @@ enum dril_replay_id {
  * types (src/interfaces/entropy.jl) and the env ctor kwargs */
 typedef struct dril_sac_config {
     uint32_t abi_version;       /* DRIL_SAC_ABI_VERSION */
-    int32_t env_kind;           /* Box action space required (sac.jl:74): DRIL_ENV_PENDULUM[_SCALED], or DRIL_ENV_EXTERNAL (the caller's host envs: ext_* below) */
+    int32_t env_kind;           /* Box action space required (sac.jl:74): DRIL_ENV_PENDULUM[_SCALED], DRIL_ENV_MOUNTAINCAR_CONTINUOUS, or DRIL_ENV_EXTERNAL (host envs: ext_* below) */
     int32_t n_envs;
     int32_t episode_len;        /* max_steps kwarg: 200 Pendulum-v1 */
     int32_t hidden1, hidden2;   /* SACLayer hidden_dims, default [512, 512] (sac.jl:76); multiples of 32 */

@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 
 
 def make_pair(pkg, E=8, hidden=(32, 32), B=16, cap=4096, act="relu", seed=7, max_steps=200, scaled=False, **alg_kw):
-    env = pkg.PendulumEnv(max_steps=max_steps)
-    if scaled:
+    env = pkg.MountainCarContinuousEnv(max_steps=max_steps) if scaled == "mountaincar" else pkg.PendulumEnv(max_steps=max_steps)
+    if scaled is True:
         env = pkg.ScalingWrapperEnv(env)
     alg = pkg.SAC(batch_size=B, buffer_capacity=cap, **alg_kw)
     layer = pkg.SACLayer(env.observation_space(), env.action_space(), hidden_dims=hidden, activation=act)
@@ -128,7 +128,7 @@ def test_many_updates_in_one_call_and_reset_optimizer(pkg):
     close(h.get_params(), o.get_params(), rtol=2e-4, atol=5e-6)
 
 
-@pytest.mark.parametrize("scaled", [False, True])
+@pytest.mark.parametrize("scaled", [False, True, "mountaincar"])      # "mountaincar": MountainCarContinuous-v0 as the device env (D = 2, Box(-1, 1))
 def test_collect_matches_oracle(pkg, scaled):
     """off_policy_collection.jl:28-96 with injected noise: the replay contents agree field by field, through a truncation and a ring wrap;
     scaled = under ScalingWrapperEnv (TanhScaleAdapter then maps onto the wrapper's Box(-1, 1))"""
