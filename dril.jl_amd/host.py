@@ -752,12 +752,15 @@ class HostParallelEnv:
         return self._last_trunc
 
 
-def _host_rollout(h: Handle, env: HostParallelEnv) -> float:
-    """collect_trajectories (trajectory.jl:22-78) with the envs on the host and the agent on the device; -> fps (rollout_buffer.jl:60-64)"""
+def _host_rollout(h: Handle, env: HostParallelEnv, on_step=None):
+    """collect_trajectories (trajectory.jl:22-78) with the envs on the host and the agent on the device; -> fps (rollout_buffer.jl:60-64), or None
+    when an on_step callback stopped the collection (:34-39)"""
     t0 = time.perf_counter()
     asp = env.action_space()
     new_obs = np.stack(env.observe())                                                # :32
     for _ in range(h.T):
+        if on_step is not None and not on_step():
+            return None
         raw, ea = h.ext_act(new_obs)                                                 # get_action_and_values + to_env, :41-42
         if isinstance(asp, Box) and h.cfg.ext_action_low >= h.cfg.ext_action_high:   # per-dimension bounds: ClampAdapter here (default_adapters.jl:4-11)
             ea = np.clip(ea, np.asarray(asp.low, np.float32).reshape(1, -1), np.asarray(asp.high, np.float32).reshape(1, -1))
@@ -773,6 +776,33 @@ def _host_rollout(h: Handle, env: HostParallelEnv) -> float:
     h.ext_finish(new_obs)                                                            # :65-70 + compute_advantages! + returns
     return h.N / max(time.perf_counter() - t0, 1e-12)
 
+
+
+def _stepwise_rollout(h: Handle, env, on_step=None):
+    """collect_trajectories (trajectory.jl:22-78) over a DeviceParallelEnv through the step-granular env verbs — the path callbacks with an `on_step`
+    hook need; the buffer is assembled on the host and handed back for compute_advantages! (dril_compute_gae).  -> fps or None"""
+    t0 = time.perf_counter()
+    E, T, asp = h.E, h.T, env.action_space()
+    obs_b = np.empty((T * E, h.D), np.float32); act_b = np.empty(T * E, np.int32) if h.discrete else np.empty((T * E, h.A), np.float32)
+    rew_b, val_b, lp_b, boot_b = (np.zeros(T * E, np.float32) for _ in range(4)); fl_b = np.zeros(T * E, np.uint8)
+    new_obs = h.env_observe()                                                        # :32
+    for t in range(T):
+        if on_step is not None and not on_step():
+            return None
+        a, v, lp = h.policy_forward(new_obs)                                         # :41
+        ea = a if h.discrete else np.clip(a, np.asarray(asp.low, np.float32), np.asarray(asp.high, np.float32))   # to_env :42
+        rew, term, trunc, tobs = h.env_step(ea)                                      # :44
+        k = slice(t * E, (t + 1) * E)
+        obs_b[k], act_b[k], rew_b[k], val_b[k], lp_b[k] = new_obs, a, rew, v, lp     # :46-51
+        fl_b[k] = term.astype(np.uint8) | (trunc.astype(np.uint8) << 1)
+        if trunc.any():
+            boot_b[k][trunc] = h.predict_values(tobs[trunc])                         # :57-61
+        new_obs = h.env_observe()                                                    # :45
+    for which, arr in ((capi.BUF_OBSERVATIONS, obs_b), (capi.BUF_ACTIONS, act_b), (capi.BUF_REWARDS, rew_b), (capi.BUF_VALUES, val_b), (capi.BUF_LOGPROBS, lp_b),
+                       (capi.BUF_FLAGS, fl_b), (capi.BUF_BOOTSTRAP, boot_b), (capi.BUF_LAST_VALUES, h.predict_values(new_obs))):   # :65-70
+        h.set_buffer(which, arr)
+    h.compute_gae()                                                                  # rollout_buffer.jl:83-87
+    return h.N / max(time.perf_counter() - t0, 1e-12)
 
 
 def MonitorWrapperEnv(env: DeviceParallelEnv, stats_window: int = 100) -> DeviceParallelEnv:
@@ -861,9 +891,12 @@ _STAT_KEYS = ("entropy_losses", "policy_losses", "value_losses", "approx_kl_divs
 def train_(agent: Agent, env: DeviceParallelEnv, alg: PPO, max_steps: int, callbacks=None):
     """train!(agent, env, alg, max_steps) -> (learn_stats, timer).  learn_stats has the reference's keys
     (ppo.jl:301-312); `timer` holds the TimerOutputs section names (ppo.jl:109,154,167,205-207,239) with
-    wall seconds.  Callbacks with per-step hooks are not routed to the fused path."""
-    if callbacks:
-        raise NotImplementedError("callbacks need the step-granular path (dril_env_step); not wired in this round")
+    wall seconds.  `callbacks`: objects with any of on_training_start / on_rollout_start / on_step / on_rollout_end / on_training_end(locals) -> bool;
+    a false return stops the training and train_ returns None (ppo.jl:145-152).  An `on_step` hook routes the rollout through the step-granular
+    env verbs instead of the fused kernel."""
+    cbs = list(callbacks or [])
+    hook = lambda name, loc: all(getattr(c, name)(loc) for c in cbs if hasattr(c, name))   # a callback returning false stops the training (ppo.jl:145-152)
+    step_hooks = [c for c in cbs if hasattr(c, "on_step")]
     timer = {}
     t0 = time.perf_counter()
     h = env.bind(alg, agent.layer)
@@ -872,13 +905,28 @@ def train_(agent: Agent, env: DeviceParallelEnv, alg: PPO, max_steps: int, callb
     iterations = max_steps // per_iter  # ppo.jl:117
     timer["setup"] = time.perf_counter() - t0
     learn_stats = {k: [] for k in _STAT_KEYS}
+    loc = dict(agent=agent, env=env, alg=alg, iterations=iterations, total_steps=iterations * per_iter, max_steps=max_steps, n_steps=alg.n_steps, n_envs=env.n_envs,
+               roll_buffer=None, total_fps=learn_stats["fps"], callbacks=cbs)                  # the keys test/test_callbacks.jl:25-39 looks for in Base.@locals
+    if not hook("on_training_start", loc):
+        return None
     t1 = time.perf_counter()
     t_roll = t_upd = 0.0
-    for _ in range(iterations):
+    for i in range(iterations):
         h.set_learning_rate(alg.learning_rate)  # Optimisers.adjust!, ppo.jl:155-156
         learn_stats["learning_rates"].append(alg.learning_rate)
+        loc.update(i=i + 1, learning_rate=alg.learning_rate)
+        if not hook("on_rollout_start", loc):
+            return None
         a = time.perf_counter()
-        fps = _host_rollout(h, env) if isinstance(env, HostParallelEnv) else h.collect_rollout()  # ppo.jl:167
+        on_step = (lambda: all(c.on_step(loc) for c in step_hooks)) if step_hooks else None
+        if isinstance(env, HostParallelEnv):
+            fps = _host_rollout(h, env, on_step)
+        else:
+            fps = _stepwise_rollout(h, env, on_step) if on_step else h.collect_rollout()  # ppo.jl:167; on_step hooks need the step-granular path
+        if fps is None:
+            return None                                                                       # "Collecting trajectories stopped due to callback failure", trajectory.jl:34-39
+        if not hook("on_rollout_end", loc):
+            return None
         b = time.perf_counter()
         st = h.ppo_update()  # ppo.jl:188-264
         c = time.perf_counter()
@@ -899,6 +947,8 @@ def train_(agent: Agent, env: DeviceParallelEnv, alg: PPO, max_steps: int, callb
     timer["collect_rollout"] = t_roll
     timer["epoch loop"] = t_upd
     agent.train_state.parameters = unflatten_params(h.get_params(), agent.train_state.parameters)
+    if not hook("on_training_end", loc):
+        return None
     return learn_stats, timer
 
 

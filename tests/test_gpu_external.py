@@ -354,3 +354,68 @@ def test_forced_generic_equals_fused(pkg, monkeypatch):
     sg, sf = gen.ppo_update(), fused.ppo_update()                                         # device-generated minibatch order: the same keyed bijection on both paths
     assert sg.n_updates == sf.n_updates == 4 and sg.loss == pytest.approx(sf.loss, rel=1e-4)
     np.testing.assert_allclose(gen.get_params(), fused.get_params(), rtol=2e-4, atol=2e-6)
+
+
+# ---- callbacks (test/test_callbacks.jl): locals keys, early stops at every hook, on_step through the step-granular path ------------------------
+def test_callbacks_locals_and_early_stops(pkg):
+    def setup():
+        env = pkg.NormalizeWrapperEnv(pkg.MonitorWrapperEnv(pkg.DeviceParallelEnv(pkg.CartPoleEnv(max_steps=50), 8, seed=1)), gamma=0.99)
+        alg = pkg.PPO(ent_coef=0.1, n_steps=64, batch_size=64, epochs=2)
+        return pkg.Agent(pkg.ActorCriticLayer(env.observation_space(), env.action_space()), alg, seed=0), env, alg
+
+    seen = {}
+
+    class CheckLocals:
+        def on_training_start(self, loc):
+            seen["start"] = set(loc); return True
+
+        def on_rollout_start(self, loc):
+            seen.setdefault("rollout", set(loc)); return True
+
+    agent, env, alg = setup()
+    out = pkg.train_(agent, env, alg, 2 * 64 * 8, callbacks=[CheckLocals()])
+    assert out is not None and agent.steps_taken == 1024
+    assert {"agent", "env", "alg", "iterations", "total_steps", "max_steps", "n_steps", "n_envs", "roll_buffer", "total_fps", "callbacks"} <= seen["start"]   # :25-27
+    assert {"agent", "env", "alg", "iterations", "total_steps", "max_steps", "i", "learning_rate"} <= seen["rollout"]                                      # :36-39
+
+    class StopAt:
+        def __init__(self, name):
+            setattr(self, name, lambda loc: False)
+
+    for name in ("on_training_start", "on_rollout_start"):                       # test_callbacks.jl:70-88
+        agent, env, alg = setup()
+        assert pkg.train_(agent, env, alg, 3000, callbacks=[StopAt(name)]) is None and agent.steps_taken == 0
+
+    class OnStepStopEarly:                                                        # :91-99: the first rollout (64 x 8 = 512 steps) completes, the second stops at its first step
+        def __init__(self):
+            self.calls = 0
+
+        def on_step(self, loc):
+            self.calls += 1
+            return loc["agent"].steps_taken < 500
+
+    agent, env, alg = setup()
+    cb = OnStepStopEarly()
+    assert pkg.train_(agent, env, alg, 3000, callbacks=[cb]) is None
+    assert agent.steps_taken == 512 and cb.calls == 65 and agent.gradient_updates > 0
+
+
+def test_stepwise_rollout_fills_the_same_buffer_as_gae_oracle(pkg, oracle_mod):
+    """the step-granular rollout used for on_step callbacks leaves a consistent buffer: advantages / returns equal the oracle's GAE of the stored
+    rewards / values / flags / bootstraps, and logprobs / values equal evaluate_actions of the stored observations and actions"""
+    capi = pkg._capi
+    env = pkg.DeviceParallelEnv(pkg.PendulumEnv(max_steps=9), 12, seed=3)
+    alg = pkg.PPO(n_steps=20, batch_size=60, epochs=1)
+    agent = pkg.Agent(pkg.ActorCriticLayer(env.observation_space(), env.action_space()), alg, seed=0)
+    h = env.bind(alg, agent.layer); h.set_params(pkg.flatten_params(agent.train_state.parameters))
+    from dril_jl_amd.host import _stepwise_rollout
+    assert _stepwise_rollout(h, env, lambda: True) > 0
+    B = {n: h.buffer(getattr(capi, "BUF_" + n)) for n in ("OBSERVATIONS", "ACTIONS", "REWARDS", "VALUES", "LOGPROBS", "FLAGS", "BOOTSTRAP", "LAST_VALUES", "ADVANTAGES", "RETURNS")}
+    assert (B["FLAGS"] & 2).any()
+    v, lp, _ = h.evaluate_actions(B["OBSERVATIONS"], B["ACTIONS"])
+    np.testing.assert_allclose(v, B["VALUES"], atol=1e-5, rtol=1e-5); np.testing.assert_allclose(lp, B["LOGPROBS"], atol=1e-5, rtol=1e-5)
+    import ctypes as C
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    adv = np.zeros(240, np.float32); ret = np.zeros(240, np.float32)
+    assert oracle_mod.lib().orc_gae(12, 20, alg.gamma, alg.gae_lambda, p(B["REWARDS"]), p(B["VALUES"]), p(B["FLAGS"]), p(B["BOOTSTRAP"]), p(B["LAST_VALUES"]), p(adv), p(ret)) == 0
+    np.testing.assert_allclose(B["ADVANTAGES"], adv, atol=1e-4, rtol=1e-5); np.testing.assert_allclose(B["RETURNS"], ret, atol=1e-4, rtol=1e-5)
