@@ -3,7 +3,7 @@ on the CPU oracle — a data point for DESIGN.md (this size is launch-latency-bo
 import sys, time
 from pathlib import Path
 import numpy as np
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import __graft_entry__ as g
 pkg = g.load_package()
