@@ -314,6 +314,40 @@ def test_large_size_properties(pkg):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("config", ["configs[1]", "configs[2]"])
+def test_full_size_properties(pkg, config):
+    """BASELINE.json configs[1] (CartPole, [64,64]) and configs[2] (Pendulum, [256,256], NormalizeWrapperEnv) at FULL size (65 536 envs x 2048 steps = 134 217 728 samples, minibatch 4 194 304): size-independent properties —
+    the truncation pattern of the synthetic fixed-length episodes, returns = advantages + values over the whole buffer, bit-identical buffers on a
+    second rollout from the same seed (a checksum of the whole advantage buffer), ratio == 1 on the first minibatch, 32 optimiser steps per epoch"""
+    capi = pkg._capi
+    E, T = 65536, 2048
+    if config == "configs[1]":
+        cfg = _cfg(pkg, 0, n_envs=E, n_steps=T, episode_len=500, fixed_length_episodes=1, batch_size=E * T // 32, epochs=1); L = 500
+    else:
+        cfg = _cfg(pkg, 1, n_envs=E, n_steps=T, episode_len=200, batch_size=E * T // 32, epochs=1, hidden1=256, hidden2=256, norm_training=1, norm_obs=1, norm_reward=1); L = 200
+    flat = _params(9155 if config == "configs[1]" else 134147, 3, 0.3 if config == "configs[1]" else 0.05)
+    sums = []
+    for rep in range(2):
+        h = pkg.Handle(cfg); h.set_params(flat); h.env_reset(42)
+        h.collect_rollout()
+        adv = h.buffer(capi.BUF_ADVANTAGES)
+        sums.append((float(adv.astype(np.float64).sum()), int(np.frombuffer(adv.tobytes(), np.uint32).astype(np.uint64).sum())))   # value sum + bit-pattern checksum
+        if rep == 0:
+            fl = h.buffer(capi.BUF_FLAGS).reshape(T, E)
+            expect = np.zeros(T, np.uint8); expect[L - 1::L] = 2                    # Pendulum never terminates: every env truncates every 200 steps
+            assert (fl == expect[:, None]).all()
+            del fl
+            ret = h.buffer(capi.BUF_RETURNS); ret -= adv; ret -= h.buffer(capi.BUF_VALUES)
+            assert np.abs(ret).max() <= 1e-4 * max(1.0, float(np.abs(adv).max()))
+            del ret
+            st = h.ppo_update()
+            assert st.n_updates == 32 and np.isfinite([st.loss, st.grad_norm, st.explained_variance]).all()
+            assert st.ratio_first == pytest.approx(1.0, abs=1e-5)
+        del adv
+        h.close()
+    assert sums[0] == sums[1]
+
+
 def test_host_mirror_train(pkg):
     """the reference-shaped API end to end: Agent / ActorCriticLayer / PPO / DeviceParallelEnv / train_ / collect_rollout_"""
     env = pkg.DeviceParallelEnv(pkg.CartPoleEnv(), 64, seed=1)
