@@ -384,153 +384,6 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_split_kernel(GemmArg
         store_tile(g, C, bias, aux, m0 + 32 * (wm * MB + t), tile_n * 32, lane, [&](int rr, int ll) { return red[wave][rr][ll]; });
     }
 }
-// The same contraction with a two-slot LDS ring and two register sets: iteration i issues the global loads of chunk i + 2, runs the MFMAs of chunk i out of
-// slot i & 1 and, between the MFMA blocks of the same instruction stream, splits chunk i + 1 (loaded one iteration earlier) into slot (i + 1) & 1 — the bf16
-// matrix cores run beside the VALU, so the split, the LDS stores and the load latency hide under the MFMAs of ONE workgroup (120 KB LDS: one workgroup per CU).
-// One barrier per chunk.  The ablation of the single-slot kernel (loads 31 + staging 37 + MFMA 57 + epilogue 41 us, additive) is what this removes.
-template <bool AK, bool BN, int MB>
-__global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_ring_kernel(GemmArgs g) {
-    constexpr int WM = 1;
-    constexpr int WN = kGemmWaves / WM, kRowsA = 32 * MB * WM, kSplitRowsX = 32 * WN;
-    constexpr int kSplitAImg = 2 * 2 * kRowsA * 8, kSplitXImg = 2 * 2 * kSplitRowsX * 8;           // bf16 elements per piece: [k16 step][half][row][8]
-    constexpr int NGX = kSplitRowsX / 64;                                                         // (row, 4 k) groups per thread of the activation chunk
-    constexpr int NPA = kRowsA / 32;                                                              // element pairs per thread of the weight chunk
-    constexpr bool kRedOnA = 3 * kSplitAImg > 3 * kSplitXImg;                                     // the f32 epilogue buffer (33 KB) overlays the larger image block
-    __shared__ __attribute__((aligned(16))) unsigned short Ap_[2][3 * kSplitAImg];
-    __shared__ __attribute__((aligned(16))) unsigned short Xp_[2][3 * kSplitXImg];
-    static_assert(sizeof(unsigned short) * 3 * (kRedOnA ? kSplitAImg : kSplitXImg) >= sizeof(float) * kGemmWaves * 16 * kRedStride, "epilogue buffer must fit the operand images");
-    float (*red)[16][kRedStride] = reinterpret_cast<float (*)[16][kRedStride]>(kRedOnA ? Ap_[0] : Xp_[0]);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5, z = blockIdx.z;
-    const int wm = wave / WN, wn = wave % WN;
-    const float* __restrict__ A = g.A + (size_t)z * g.zA;
-    const float* __restrict__ B = g.B + (size_t)(z / g.zdivB) * g.zB;
-    const int m0 = blockIdx.x * kRowsA, n0 = blockIdx.y * kSplitRowsX;
-    // loader roles: every thread owns NGX groups of (one n-row, 4 consecutive k) = one 8-byte LDS store per piece and group.  B k-contiguous: one float4 per
-    // group (8 lanes read one row's 128 B).  BN (n-contiguous): consecutive lanes take consecutive n and read the 4 k-rows as 4 coalesced scalar loads
-    int xr[NGX], xk[NGX];
-#pragma unroll
-    for (int j = 0; j < NGX; ++j) { const int i = tid + 512 * j; if (BN) { xr[j] = tid % kSplitRowsX; xk[j] = (tid / kSplitRowsX + (512 / kSplitRowsX) * j) * 4; } else { xr[j] = i >> 3; xk[j] = (i & 7) * 4; } }
-    // A chunk = (32 MB) m x 32 k.  m-contiguous: element e = tid + 512 j, m = e % rows, k = e / rows (consecutive lanes, consecutive m), two per store
-    // pair (j, j + MB): k and k + 16 share an 8-k group?  no — stored as single bf16 each.  AK: pair e = tid + 512 j: m = e >> 4, k = (e & 15) * 2
-    const int n_real = g.N - (g.ones_n ? 1 : 0);
-    float4 xvs[2][NGX]; float avs[2][2 * NPA];                                   // two register sets: chunk i + 1 being split, chunk i + 2 in flight
-    auto gload = [&](int kc, float4 (&xv)[NGX], float (&av)[2 * NPA]) {
-#pragma unroll
-        for (int j = 0; j < NGX; ++j) {
-            if (BN) {
-                const int n = n0 + xr[j];
-                float t[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = kc + xk[j] + e;
-                    t[e] = (k < g.K && n < n_real) ? B[(size_t)k * g.sBk + n] : ((k < g.K && g.ones_n && n == n_real) ? 1.0f : 0.0f);
-                }
-                xv[j] = make_float4(t[0], t[1], t[2], t[3]);
-            } else {
-                const int n = n0 + xr[j];
-                xv[j] = (n < g.N && kc + xk[j] < g.K) ? *reinterpret_cast<const float4*>(B + (size_t)n * g.sBn + kc + xk[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NPA; ++j) {
-            if (AK) {
-                const int e = tid + 512 * j, am = e >> 4, ak = (e & 15) * 2, mg = m0 + am;
-                av[2 * j] = (mg < g.M && kc + ak < g.K) ? A[(size_t)mg * g.sAm + kc + ak] : 0.f;
-                av[2 * j + 1] = (mg < g.M && kc + ak + 1 < g.K) ? A[(size_t)mg * g.sAm + kc + ak + 1] : 0.f;
-            } else {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int e = tid + 512 * (2 * j + u), am = e % kRowsA, ak = e / kRowsA, mg = m0 + am;
-                    av[2 * j + u] = (mg < g.M && kc + ak < g.K) ? A[(size_t)mg + (size_t)(kc + ak) * g.sAk] : 0.f;
-                }
-            }
-        }
-    };
-    // element (row, k in 0..31) of a piece image: [k >> 4][(k >> 3) & 1][row][k & 7]
-    auto xoff = [](int row, int k) { return (((k >> 4) * 2 + ((k >> 3) & 1)) * kSplitRowsX + row) * 8 + (k & 7); };
-    auto aoff = [](int row, int k) { return (((k >> 4) * 2 + ((k >> 3) & 1)) * kRowsA + row) * 8 + (k & 7); };
-    f32x16 acc[MB];
-#pragma unroll
-    for (int t = 0; t < MB; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const int nchunks = (g.K + kBigKc - 1) / kBigKc, c0 = (int)((blockIdx.y * 7 + blockIdx.x * 3) % nchunks);   // staggered chunk order (see the single-slot kernel)
-    auto chunk_k = [&](int i) { int cc = c0 + i; if (cc >= nchunks) cc -= nchunks; return cc * kBigKc; };
-    // one staging unit: X group j (j < NGX) or A pair j - NGX, from register set (xv, av) into ring slot `slot`
-    auto stage_unit = [&](int u, int slot, const float4 (&xv)[NGX], const float (&av)[2 * NPA]) {
-        unsigned short* Xp = Xp_[slot]; unsigned short* Ap = Ap_[slot];
-        if (u < NGX) {
-            const int j = u;
-            unsigned h0, m0_, l0, h1, m1, l1;
-            split3_pair(xv[j].x, xv[j].y, h0, m0_, l0); split3_pair(xv[j].z, xv[j].w, h1, m1, l1);
-            const int o = xoff(xr[j], xk[j]);
-            *reinterpret_cast<uint2*>(&Xp[o]) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(&Xp[kSplitXImg + o]) = make_uint2(m0_, m1);
-            *reinterpret_cast<uint2*>(&Xp[2 * kSplitXImg + o]) = make_uint2(l0, l1);
-        } else {
-            const int j = u - NGX;
-            unsigned ph, pm, pl;
-            split3_pair(av[2 * j], av[2 * j + 1], ph, pm, pl);
-            if (AK) {
-                const int e = tid + 512 * j, o = aoff(e >> 4, (e & 15) * 2);
-                *reinterpret_cast<unsigned*>(&Ap[o]) = ph; *reinterpret_cast<unsigned*>(&Ap[kSplitAImg + o]) = pm; *reinterpret_cast<unsigned*>(&Ap[2 * kSplitAImg + o]) = pl;
-            } else {
-                const int e0 = tid + 512 * (2 * j), e1 = e0 + 512, o0 = aoff(e0 % kRowsA, e0 / kRowsA), o1 = aoff(e1 % kRowsA, e1 / kRowsA);
-                Ap[o0] = (unsigned short)ph; Ap[kSplitAImg + o0] = (unsigned short)pm; Ap[2 * kSplitAImg + o0] = (unsigned short)pl;
-                Ap[o1] = (unsigned short)(ph >> 16); Ap[kSplitAImg + o1] = (unsigned short)(pm >> 16); Ap[2 * kSplitAImg + o1] = (unsigned short)(pl >> 16);
-            }
-        }
-    };
-    constexpr int NU = NGX + NPA, NB = 2 * MB;                                    // staging units and MFMA blocks (6 MFMAs each) per chunk
-    // iteration i with compile-time parity P: slot P holds chunk i; register set P^1 holds chunk i + 1; set P receives chunk i + 2
-    auto iteration = [&](int i, auto parity) {
-        constexpr int P = decltype(parity)::value;
-        gload(chunk_k(i + 2 < nchunks ? i + 2 : 0), xvs[P], avs[P]);               // unconditional (past the end: a chunk nobody consumes): a branch here makes the wait below a vmcnt(0)
-        const unsigned short* Xp = Xp_[P]; const unsigned short* Ap = Ap_[P];
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            const int ks = blk / MB, t = blk % MB;
-            const int xo = ((ks * 2 + h) * kSplitRowsX + 32 * wn + c) * 8, ao = ((ks * 2 + h) * kRowsA + 32 * (wm * MB + t) + c) * 8;
-            const bf16x8 Bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Xp[xo]));
-            const bf16x8 Bm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Xp[kSplitXImg + xo]));
-            const bf16x8 Bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Xp[2 * kSplitXImg + xo]));
-            const bf16x8 Ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Ap[ao]));
-            const bf16x8 Am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Ap[kSplitAImg + ao]));
-            const bf16x8 Al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&Ap[2 * kSplitAImg + ao]));
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[t], 0, 0, 0);   // small terms first
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[t], 0, 0, 0);
-            // this block's share of the next chunk's split + LDS stores, issued behind its MFMAs (after the last chunk: into a slot nobody reads)
-#pragma unroll
-            for (int u = blk * NU / NB; u < (blk + 1) * NU / NB; ++u) stage_unit(u, P ^ 1, xvs[P ^ 1], avs[P ^ 1]);
-        }
-        __syncthreads();
-    };
-    gload(chunk_k(0), xvs[0], avs[0]);
-    gload(chunk_k(nchunks > 1 ? 1 : 0), xvs[1], avs[1]);
-#pragma unroll
-    for (int u = 0; u < NU; ++u) stage_unit(u, 0, xvs[0], avs[0]);                 // prologue: chunk 0 into slot 0 (set 0 is then free for chunk 2)
-    __syncthreads();
-    for (int i = 0; i < nchunks; i += 2) {
-        iteration(i, std::integral_constant<int, 0>{});
-        if (i + 1 < nchunks) iteration(i + 1, std::integral_constant<int, 1>{});
-    }
-    float* __restrict__ C = g.C + (size_t)z * g.zC;
-    const float* __restrict__ bias = g.bias ? g.bias + (size_t)z * g.zBias : nullptr;
-    const float* __restrict__ aux = g.aux ? g.aux + (size_t)z * g.zAux : nullptr;
-    const int tile_n = (int)blockIdx.y * WN + wn;
-#pragma unroll
-    for (int t = 0; t < MB; ++t) {                                              // one m-tile at a time through the transposition buffer (the loop's last barrier freed the operand images)
-        if (t) __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[t][r];
-        __syncthreads();
-        store_tile(g, C, bias, aux, m0 + 32 * (wm * MB + t), tile_n * 32, lane, [&](int rr, int ll) { return red[wave][rr][ll]; });
-    }
-}
 // two independent contractions in one launch (the weight-gradient and the data-gradient of one layer): blockIdx.z < za runs `a`
 struct GemmPair { GemmArgs a, b; int za; };
 __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_pair_kernel(GemmPair p) {
@@ -576,15 +429,16 @@ hipError_t launch_gemm(GemmArgs g, int Z, hipStream_t s) {
         // blocks of 32 x 256: it stays at MB = 1).  Taller blocks were built and measured (MB = 4, and full-height 256 / 512-row blocks that stage every
         // activation row once): SLOWER — 65 / 57 vs 69 TFLOP/s at hidden 512 — because their registers / LDS leave one workgroup per CU, and with one
         // workgroup the phases of a chunk do not overlap (ablation of a 512 x 32768 x 512 reverse-pass contraction, DRIL_GEMM_DBG: global loads 31 + staging
-        // 37 + MFMA 57 + epilogue 41 = 166 us vs 160 us measured: purely additive).  Two co-resident workgroups hide each other's phases.
+        // 37 + MFMA 57 + epilogue 41 = 166 us vs 160 us measured: purely additive).  Two co-resident workgroups hide each other's phases.  A two-slot LDS ring
+        // inside one workgroup (staging of chunk i + 1 interleaved with the MFMAs of chunk i, loads two chunks ahead; built, parity-green) was slower still (55):
+        // the split form reads 0.75 ds_read_b128 per MFMA (9 reads per 12 MFMAs of 32 cycles), ~2000 LDS cycles per chunk against 1536 MFMA cycles per SIMD —
+        // the kernel is LDS-read-bound, and the next step is 2 x 2 register tiling per wave (0.5 reads per MFMA), not more overlap.
         static const int mb_cap = std::getenv("DRIL_GEMM_MB") ? std::atoi(std::getenv("DRIL_GEMM_MB")) : 2;   // A/B knob (1, 2, 4 are built)
         int MB = 1;
         const long long tn256 = (g.N + 255) / 256;
         for (int cand = 4; cand > 1; cand >>= 1) if (cand <= mb_cap && g.M >= 32 * cand && (long long)((g.M + 32 * cand - 1) / (32 * cand)) * tn256 * Z >= 512) { MB = cand; break; }
         const dim3 sgrid((g.M + 32 * MB - 1) / (32 * MB), bgrid.y, Z);
-        static const bool ring = std::getenv("DRIL_GEMM_RING") != nullptr;
-#define DRIL_SPLIT_LAUNCH(AKv, BNv) { if (ring && MB == 2) hipLaunchKernelGGL((sac_gemm_ring_kernel<AKv, BNv, 2>), sgrid, bblock, 0, s, g); \
-                                      else if (MB == 4) hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 4, 1>), sgrid, bblock, 0, s, g); \
+#define DRIL_SPLIT_LAUNCH(AKv, BNv) { if (MB == 4) hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 4, 1>), sgrid, bblock, 0, s, g); \
                                       else if (MB == 2) hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 2, 1>), sgrid, bblock, 0, s, g); \
                                       else hipLaunchKernelGGL((sac_gemm_split_kernel<AKv, BNv, 1, 1>), sgrid, bblock, 0, s, g); }
         if (a_m && b_k) DRIL_SPLIT_LAUNCH(false, false) else if (a_k && b_k) DRIL_SPLIT_LAUNCH(true, false) else if (a_m && b_n) DRIL_SPLIT_LAUNCH(false, true) else DRIL_SPLIT_LAUNCH(true, true)
