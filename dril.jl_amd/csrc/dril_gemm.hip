@@ -251,7 +251,7 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsi
 // WM = waves along m (1 or 2): with WM = 2 the workgroup spans 64 MB output rows and 128 activation rows — at MB = 8 that is ALL 512 rows of a hidden-512
 // layer, so every activation row is staged exactly once per contraction (weights are the re-read operand, and they live in L2)
 template <bool AK, bool BN, int MB, int WM>
-__global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_split_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64 * kGemmWaves, 4) void sac_gemm_split_kernel(GemmArgs g) {   // 4 waves per SIMD = two workgroups per CU (<= 128 VGPRs): they hide each other's staging / epilogue phases
     constexpr int WN = kGemmWaves / WM, kRowsA = 32 * MB * WM, kSplitRowsX = 32 * WN;
     constexpr int kSplitAImg = 2 * 2 * kRowsA * 8, kSplitXImg = 2 * 2 * kSplitRowsX * 8;           // bf16 elements per piece: [k16 step][half][row][8]
     constexpr int NGX = kSplitRowsX / 64;                                                         // (row, 4 k) groups per thread of the activation chunk
