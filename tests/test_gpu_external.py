@@ -419,3 +419,34 @@ def test_stepwise_rollout_fills_the_same_buffer_as_gae_oracle(pkg, oracle_mod):
     adv = np.zeros(240, np.float32); ret = np.zeros(240, np.float32)
     assert oracle_mod.lib().orc_gae(12, 20, alg.gamma, alg.gae_lambda, p(B["REWARDS"]), p(B["VALUES"]), p(B["FLAGS"]), p(B["BOOTSTRAP"]), p(B["LAST_VALUES"]), p(adv), p(ret)) == 0
     np.testing.assert_allclose(B["ADVANTAGES"], adv, atol=1e-4, rtol=1e-5); np.testing.assert_allclose(B["RETURNS"], ret, atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("E,T,B,kw", [(1, 3, 10, {}), (5, 4, 7, {}), (3, 2, 6, dict(has_target_kl=1, target_kl=1e-6)), (2, 2, 4, dict(epochs=0)),
+                                      (4, 5, 20, dict(has_max_grad_norm=0, normalize_advantage=0))])
+def test_external_edge_sizes_and_control_flow(pkg, oracle_mod, E, T, B, kw):
+    """edge cases of the update loop on the generic path (ppo.jl:188-254): one env / one partial minibatch larger than the buffer, ragged last minibatch,
+    target_kl stopping both loops before the first apply, zero epochs, no gradient clipping / no advantage normalisation"""
+    capi = pkg._capi
+    cfg = _ext_cfg(pkg, 5, 3, True, 16, 24, n_envs=E, n_steps=T, batch_size=B, epochs=kw.pop("epochs", 2), **kw)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 2, 0.3); h.set_params(flat); o.set_params(flat)
+    rng = np.random.default_rng(E * 10 + T)
+    N = E * T
+    bufs = {capi.BUF_OBSERVATIONS: rng.standard_normal((N, 5)).astype(np.float32), capi.BUF_ACTIONS: (rng.integers(0, 3, N) + cfg.action_start).astype(np.int32),
+            capi.BUF_ADVANTAGES: rng.standard_normal(N).astype(np.float32), capi.BUF_RETURNS: rng.standard_normal(N).astype(np.float32),
+            capi.BUF_VALUES: rng.standard_normal(N).astype(np.float32)}
+    bufs[capi.BUF_LOGPROBS] = (o.evaluate_actions(bufs[capi.BUF_OBSERVATIONS], bufs[capi.BUF_ACTIONS])[1] + rng.normal(0, 0.2, N)).astype(np.float32)
+    for which, arr in bufs.items():
+        h.set_buffer(which, arr); o.set_buffer(which, arr)
+    if cfg.epochs:
+        perm = np.stack([np.random.default_rng(e).permutation(N) for e in range(cfg.epochs)]).astype(np.int64)
+        h.set_permutation(perm); o.set_permutation(perm)
+    sh, so = h.ppo_update(), o.ppo_update()
+    assert (sh.n_updates, sh.early_stopped, sh.nan_or_inf) == (so.n_updates, so.early_stopped, so.nan_or_inf)
+    if cfg.has_target_kl:
+        assert sh.early_stopped == 1 and sh.n_updates <= 1
+    if so.n_updates:
+        assert sh.loss == pytest.approx(so.loss, rel=2e-4, abs=1e-6) and sh.grad_norm == pytest.approx(so.grad_norm, rel=1e-3)
+    np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=3e-4, atol=3e-6)
+    if cfg.epochs == 0:
+        assert np.array_equal(h.get_params(), flat)
