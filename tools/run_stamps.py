@@ -7,7 +7,13 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as g
 pkg = g.load_package()
 capi = pkg._capi
-lib = capi.load_library(ROOT / "dril.jl_amd" / "csrc" / "libdril_hip_stamps.so")
+import subprocess
+_so = ROOT / "dril.jl_amd" / "csrc" / "libdril_hip_stamps.so"
+_src = [str(ROOT / "dril.jl_amd" / "csrc" / f) for f in ("dril_kernels.hip", "dril_api.hip", "dril_sac.hip", "dril_gemm.hip", "dril_generic.hip")]
+if not _so.exists():   # diagnostic build with per-phase s_memtime stamps (-DDRIL_STAMPS); never used for timing claims
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-fvisibility=hidden", "--offload-arch=gfx950", "-DDRIL_STAMPS", "-shared",
+                    "-o", str(_so), *_src, "-ldl", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+lib = capi.load_library(_so)
 wide = len(sys.argv) > 1 and sys.argv[1] == "wide"       # config 3 shape: Pendulum, [256,256]
 env = pkg.PendulumEnv(max_steps=200) if wide else pkg.CartPoleEnv(max_steps=500)
 E, T = 65536, (256 if wide else 2048)
