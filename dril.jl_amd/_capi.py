@@ -161,6 +161,9 @@ _SIG = {
     "dril_train": (C.c_int32, [_P, C.c_int64, _P, _P, C.POINTER(C.c_int32)]),
     "dril_comm_unique_id": (C.c_int32, [_P]),
     "dril_comm_init": (C.c_int32, [_P, _P]),
+    "dril_comm_ranks": (C.c_int32, [_P]),
+    "dril_comm_allreduce_calls": (C.c_int64, [_P]),
+    "dril_debug_comm_loopback": (C.c_int32, [C.POINTER(_P), C.c_int32]),
     "dril_profile_get": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dril_profile_reset": (C.c_int32, [_P]),
     "dril_kernel_name": (C.c_char_p, [C.c_int32]),

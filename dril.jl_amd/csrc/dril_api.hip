@@ -6,9 +6,11 @@
 
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -30,6 +32,7 @@ struct RcclApi {
     int (*CommInitRank)(void**, int, const void*, int) = nullptr;   // ncclUniqueId passed by value = 128-byte struct
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 struct NcclId { char bytes[128]; };
@@ -45,10 +48,34 @@ bool load_rccl(std::string& err) {
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
+    g_rccl.CommCount = (int (*)(void*, int*))dlsym(g_rccl.lib, "ncclCommCount");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) { err = "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclAllReduce"; return false; }
     return true;
 }
 constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0;
+
+// ---- debug loopback communicator -----------------------------------------------------------------
+// RCCL refuses two ranks on one device, so the data-parallel code of this file (every `reduce` branch below) could only be
+// executed on a multi-GPU node.  A loopback group joins n handles of ONE process on ONE device as ranks 0..n-1: the all-reduce
+// call sites, counts and dtypes are unchanged, only the transport differs — the ranks' host threads rendezvous, the last arriver
+// makes its stream wait for every rank's buffer, one kernel sums the n device buffers element-wise in rank order and writes the
+// sum back to all of them (every rank ends with bit-identical values, as after a ring all-reduce), and the other ranks' streams
+// wait for that kernel.  Each handle must be driven from its own host thread (dril_debug_comm_loopback, include/dril_hip.h).
+constexpr int kLoopMax = 8;
+struct LoopPtrs { void* p[kLoopMax]; };
+struct LoopGroup {
+    std::mutex mu; std::condition_variable cv;
+    int n = 0, arrived = 0, refs = 0; uint64_t gen = 0; int64_t calls = 0;
+    LoopPtrs bufs{}; hipEvent_t ready[kLoopMax] = {nullptr}; hipEvent_t done = nullptr;
+    size_t count = 0; int dtype = 0; bool mismatch = false, failed = false;
+};
+template <typename T> __global__ void loop_allreduce_kernel(LoopPtrs bufs, int n, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    T s = ((const T*)bufs.p[0])[i];
+    for (int r = 1; r < n; ++r) s += ((const T*)bufs.p[r])[i];      // fixed rank order: deterministic
+    for (int r = 0; r < n; ++r) ((T*)bufs.p[r])[i] = s;             // this thread has read element i of every rank before it writes any
+}
 
 struct ProfEvent { int kid; hipEvent_t a, b; };
 
@@ -94,6 +121,9 @@ struct dril_handle {
     GenericDims gd{}; GenericWs gws; int ext_t = 0; bool ext_acted = false;   // DRIL_ENV_EXTERNAL: host envs, generic kernels
     float* ext_stage_rew = nullptr; uint8_t* ext_stage_flags = nullptr;   // pinned [T][E] staging: dril_ext_record returns without draining the stream
     void* comm = nullptr;
+    LoopGroup* loop = nullptr;   // debug loopback communicator (dril_debug_comm_loopback)
+    int64_t allreduce_calls = 0;
+    bool no_small_path = false, no_epoch_moments = false;   // DRIL_NO_SMALL_PATH / DRIL_NO_EPOCH_MOMENTS, latched in dril_create
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
     double prof_ms[DRIL_K_COUNT] = {0}; int64_t prof_n[DRIL_K_COUNT] = {0};
     std::string err;
@@ -131,10 +161,50 @@ void prof_resolve(dril_handle* h) {   // stream must be drained
 }
 int sync(dril_handle* h) { HIPCHK(h, hipStreamSynchronize(h->stream)); prof_resolve(h); return DRIL_OK; }
 
+bool comm_ready(const dril_handle* h) { return h->comm != nullptr || h->loop != nullptr; }
+
+// the loopback transport of one all-reduce (see LoopGroup): called by every rank's host thread with the same count / dtype
+int loop_allreduce(dril_handle* h, void* buf, size_t count, int dtype) {
+    LoopGroup* g = h->loop; const int r = h->cfg.rank;
+    HIPCHK(h, hipEventRecord(g->ready[r], h->stream));                 // this rank's contribution is complete behind this event
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (g->failed) return fail(h, DRIL_ERR_RCCL, "loopback communicator: an earlier all-reduce failed");
+    const uint64_t my_gen = g->gen;
+    if (g->arrived == 0) { g->count = count; g->dtype = dtype; g->mismatch = false; }
+    else if (g->count != count || g->dtype != dtype) g->mismatch = true;
+    g->bufs.p[r] = buf;
+    if (++g->arrived == g->n) {
+        hipError_t e = hipSuccess;
+        for (int q = 0; q < g->n && e == hipSuccess; ++q) e = hipStreamWaitEvent(h->stream, g->ready[q], 0);
+        if (e == hipSuccess && !g->mismatch) {
+            const unsigned nb = (unsigned)((count + 255) / 256);
+            if (dtype == kNcclFloat64) loop_allreduce_kernel<double><<<nb, 256, 0, h->stream>>>(g->bufs, g->n, count);
+            else loop_allreduce_kernel<float><<<nb, 256, 0, h->stream>>>(g->bufs, g->n, count);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(g->done, h->stream);
+        if (e != hipSuccess || g->mismatch) g->failed = true;
+        g->arrived = 0; g->gen += 1; g->calls += 1;
+        g->cv.notify_all();
+        if (e != hipSuccess) return fail(h, DRIL_ERR_HIP, std::string("loopback all-reduce: ") + hipGetErrorString(e));
+    } else {
+        if (!g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->gen != my_gen; })) {
+            g->failed = true; g->arrived = 0; g->gen += 1; g->cv.notify_all();
+            return fail(h, DRIL_ERR_RCCL, "loopback all-reduce: the other ranks did not arrive within 120 s (every handle of the group needs its own host thread making the same calls)");
+        }
+        if (!g->failed) HIPCHK(h, hipStreamWaitEvent(h->stream, g->done, 0));
+    }
+    if (g->failed) return fail(h, DRIL_ERR_RCCL, g->mismatch ? "loopback all-reduce: the ranks disagree on count / dtype (they are not making the same calls)" : "loopback all-reduce failed on another rank");
+    return DRIL_OK;
+}
+
 int rccl_allreduce(dril_handle* h, void* buf, size_t count, int dtype) {
-    if (!h->comm) return DRIL_OK;
+    if (!comm_ready(h)) return DRIL_OK;
+    h->allreduce_calls += 1;
     prof_begin(h, DRIL_K_ALLREDUCE);
-    const int rc = g_rccl.AllReduce(buf, buf, count, dtype, kNcclSum, h->comm, h->stream);
+    int rc = 0;
+    if (h->loop) { const int lrc = loop_allreduce(h, buf, count, dtype); prof_end(h); return lrc; }
+    rc = g_rccl.AllReduce(buf, buf, count, dtype, kNcclSum, h->comm, h->stream);
     prof_end(h);
     if (rc != 0) return fail(h, DRIL_ERR_RCCL, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
     return DRIL_OK;
@@ -196,8 +266,8 @@ int monitor_collect_rollout(dril_handle* h) {
 // all-reduce per env step; every rank applies the identical update, so the running statistics stay bit-identical across ranks
 int global_partials(dril_handle* h, bool update, const double*& partials, int& nb, long long& n_stats) {
     partials = h->rms_partials; n_stats = 0;
-    const int world = h->comm ? h->cfg.world_size : 1;
-    if (!update || !(world > 1 || (h->comm && h->force_allreduce))) return DRIL_OK;
+    const int world = comm_ready(h) ? h->cfg.world_size : 1;
+    if (!update || !(world > 1 || (comm_ready(h) && h->force_allreduce))) return DRIL_OK;
     HIPCHK(h, launch_fold_partials(h->rms_partials, nb, h->rms_red, h->stream));
     int rc = rccl_allreduce(h, h->rms_red, 16, kNcclFloat64); if (rc) return rc;
     partials = h->rms_red; nb = 1; n_stats = (long long)h->cfg.n_envs * world;
@@ -244,8 +314,8 @@ int step_dev(dril_handle* h, const void* actions, float* rew_out, uint8_t* flags
 int ppo_step(dril_handle* h, const float* obs, const void* actions, const float* adv, const float* ret, const float* logp_old,
              const float* val_old, const int64_t* perm, int64_t pos0, int64_t count, int64_t N, uint64_t key, int bits,
              float* step_stats, bool apply, const float4* rec = nullptr, const double* pre_stats = nullptr) {
-    const int world = h->comm ? h->cfg.world_size : 1;
-    const bool reduce = world > 1 || (h->comm && h->force_allreduce);   // force: exercise the RCCL path on one rank (tests)
+    const int world = comm_ready(h) ? h->cfg.world_size : 1;
+    const bool reduce = world > 1 || (comm_ready(h) && h->force_allreduce);   // force: exercise the RCCL path on one rank (tests)
     const int64_t tiles = (count + kTile - 1) / kTile;
     int G = h->wide ? (int)(tiles < h->Gmax ? tiles : h->Gmax) : (int)((tiles + 3) / 4); if (G > h->Gmax) G = h->Gmax; if (G < 1) G = 1;
     if (h->generic) { G = generic_pick_slabs(h->gd, count, h->Gmax); if (G < 1) return fail(h, DRIL_ERR_UNSUPPORTED, "minibatch too large for the generic path's workspace"); }
@@ -253,7 +323,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     const double* adv_stats = h->adv_stats;
     // launch-bound regime (the reference's default batch_size = 64): the advantage moments are computed inside the grad kernel and
     // reduce + norm + Adam run as one workgroup: 2 dependent launches per optimiser step instead of 6
-    const bool small = !reduce && !h->wide && !h->generic && h->grad_layout == 1 && count <= 4096 && !std::getenv("DRIL_NO_SMALL_PATH");
+    const bool small = !reduce && !h->wide && !h->generic && h->grad_layout == 1 && count <= 4096 && !h->no_small_path;
     if (h->cfg.normalize_advantage && pre_stats) adv_stats = pre_stats;   // per-epoch table (already all-reduced in data-parallel runs)
     else if (h->cfg.normalize_advantage && small) adv_stats = nullptr;
     else if (h->cfg.normalize_advantage) {
@@ -404,6 +474,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (const char* e = std::getenv("DRIL_GRAD_PRIO")) h->grad_prio = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_STAGGER")) h->grad_stagger = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_SPLIT")) h->grad_split = std::atoi(e);
+    h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
     CCHK(hipSetDevice(cfg->device));
     hipDeviceProp_t prop; CCHK(hipGetDeviceProperties(&prop, cfg->device));
@@ -418,7 +489,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     else { h->slab_a = slab_size_actor(cfg->env_kind, cfg->hidden1); h->slab_c = slab_size_critic(cfg->env_kind, cfg->hidden1); }
     h->wide = !h->generic && cfg->hidden1 > 64;
     h->Gmax = (h->wide && cfg->hidden1 > 128) ? (h->num_cus / 2 > 0 ? h->num_cus / 2 : 1) : h->num_cus;   // H = 128: 4 waves and 77 KB LDS per workgroup, two workgroups per CU   // [64,64]: 2 workgroups per CU (actor + critic), 4 waves each; wide: 1 workgroup of H/32 waves per CU
-    if (h->generic) h->Gmax = std::getenv("DRIL_EXT_GMAX") ? std::atoi(std::getenv("DRIL_EXT_GMAX")) : 64;                                                         // generic path: one slab per row chunk of the minibatch
+    if (h->generic) { h->Gmax = std::getenv("DRIL_EXT_GMAX") ? std::atoi(std::getenv("DRIL_EXT_GMAX")) : 64; if (h->Gmax < 1) h->Gmax = 1; }                                                        // generic path: one slab per row chunk of the minibatch
     if (const char* e = std::getenv("DRIL_GRAD_GMAX")) { const int g = std::atoi(e); if (g > 0 && g < h->Gmax) h->Gmax = g; }   // diagnostic: fewer workgroups per net
     if (h->wide) { const size_t hh = (size_t)cfg->hidden1 * cfg->hidden1; CCHK(dmalloc(&h->w2a_actor, hh)); CCHK(dmalloc(&h->w2ta_actor, hh)); CCHK(dmalloc(&h->w2a_critic, hh)); CCHK(dmalloc(&h->w2ta_critic, hh)); }
     CCHK(dmalloc(&h->slabs_a, (size_t)h->Gmax * h->slab_a)); CCHK(dmalloc(&h->slabs_c, (size_t)h->Gmax * h->slab_c));
@@ -465,6 +536,12 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     if (!h) return DRIL_OK;
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    if (h->loop) {                                                   // the last handle to leave frees the group
+        LoopGroup* g = h->loop; bool last;
+        { std::lock_guard<std::mutex> lk(g->mu); last = --g->refs == 0; }
+        if (last) { for (int q = 0; q < g->n; ++q) if (g->ready[q]) hipEventDestroy(g->ready[q]); if (g->done) hipEventDestroy(g->done); delete g; }
+        h->loop = nullptr;
+    }
     generic_ws_free(h->gws);
     if (h->ext_stage_rew) (void)hipHostFree(h->ext_stage_rew); if (h->ext_stage_flags) (void)hipHostFree(h->ext_stage_flags);
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
@@ -846,8 +923,8 @@ DRIL_EXPORT int32_t dril_debug_set_permutation(dril_handle* h, const int64_t* pe
 
 namespace {
 int ppo_update(dril_handle* h, dril_ppo_stats* out) {
-    const int world = h->comm ? h->cfg.world_size : 1;
-    if (h->cfg.world_size > 1 && !h->comm) return fail(h, DRIL_ERR_NOT_INITIALISED, "world_size > 1 but dril_comm_init was not called");
+    const int world = comm_ready(h) ? h->cfg.world_size : 1;
+    if (h->cfg.world_size > 1 && !comm_ready(h)) return fail(h, DRIL_ERR_NOT_INITIALISED, "world_size > 1 but dril_comm_init was not called");
     const int64_t N = h->N, B = h->cfg.batch_size / h->cfg.world_size;
     const int64_t nb = (N + B - 1) / B;                       // partial last batch kept (MLUtils partial=true)
     const int64_t total_steps = nb * h->cfg.epochs;
@@ -863,7 +940,7 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
     for (int ep = 0; ep < h->cfg.epochs; ++ep) {
         const uint64_t key = perm_key(h->cfg.seed + (uint64_t)h->cfg.rank, h->update_counter, ep);
         const int64_t* perm = h->perm_count ? h->perm_dev + (size_t)ep * N : nullptr;
-        const bool epoch_moments = h->cfg.normalize_advantage && !perm && nb >= 2 && nb <= 2048 && !std::getenv("DRIL_NO_EPOCH_MOMENTS");
+        const bool epoch_moments = h->cfg.normalize_advantage && !perm && nb >= 2 && nb <= 2048 && !h->no_epoch_moments;
         if (epoch_moments) {
             if (nb > h->epoch_nb_cap) {
                 if (h->epoch_tables) hipFree(h->epoch_tables); if (h->epoch_stats) hipFree(h->epoch_stats);
@@ -874,7 +951,7 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
             prof_begin(h, DRIL_K_ADV_MOMENTS);
             HIPCHK(h, launch_epoch_moments(h->adv, N, B, (int)nb, key, bits, h->epoch_tables, h->epoch_blocks, h->epoch_stats, h->stop_flag, h->stream));
             prof_end(h);
-            if (world > 1 || (h->comm && h->force_allreduce)) {     // ONE all-reduce per epoch for the advantage moments of all its minibatches
+            if (world > 1 || (comm_ready(h) && h->force_allreduce)) {     // ONE all-reduce per epoch for the advantage moments of all its minibatches
                 int rca = rccl_allreduce(h, h->epoch_stats, (size_t)3 * nb, kNcclFloat64); if (rca) return rca;
             }
         }
@@ -1078,6 +1155,33 @@ DRIL_EXPORT int32_t dril_comm_init(dril_handle* h, const uint8_t id[128]) {
     if (rc != 0) { h->comm = nullptr; return fail(h, DRIL_ERR_RCCL, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error")); }
     return DRIL_OK;
 }
+
+DRIL_EXPORT int32_t dril_debug_comm_loopback(dril_handle** hs, int32_t n) {
+    if (!hs || n < 1 || n > kLoopMax) return fail(nullptr, DRIL_ERR_INVALID_ARG, "dril_debug_comm_loopback: 1..8 handles");
+    std::vector<bool> seen((size_t)n, false);
+    for (int i = 0; i < n; ++i) {
+        dril_handle* h = hs[i];
+        if (!h) return fail(nullptr, DRIL_ERR_INVALID_ARG, "dril_debug_comm_loopback: null handle");
+        if (comm_ready(h)) return fail(h, DRIL_ERR_INVALID_ARG, "dril_debug_comm_loopback: the handle already has a communicator");
+        if (h->cfg.world_size != n || h->cfg.rank < 0 || h->cfg.rank >= n || seen[h->cfg.rank]) return fail(h, DRIL_ERR_INVALID_ARG, "dril_debug_comm_loopback: the handles must be ranks 0..n-1 of world_size n, one each");
+        if (h->cfg.device != hs[0]->cfg.device) return fail(h, DRIL_ERR_INVALID_ARG, "dril_debug_comm_loopback: all handles must live on one device");
+        seen[h->cfg.rank] = true;
+    }
+    (void)hipSetDevice(hs[0]->cfg.device);
+    LoopGroup* g = new LoopGroup(); g->n = n; g->refs = n;
+    hipError_t e = hipEventCreateWithFlags(&g->done, hipEventDisableTiming);
+    for (int q = 0; q < n && e == hipSuccess; ++q) e = hipEventCreateWithFlags(&g->ready[q], hipEventDisableTiming);
+    if (e != hipSuccess) { for (int q = 0; q < n; ++q) if (g->ready[q]) hipEventDestroy(g->ready[q]); if (g->done) hipEventDestroy(g->done); delete g; return fail(hs[0], DRIL_ERR_HIP, hipGetErrorString(e)); }
+    for (int i = 0; i < n; ++i) hs[i]->loop = g;
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_comm_ranks(dril_handle* h) {
+    if (!h) return -1;
+    if (h->loop) return h->loop->n;
+    if (h->comm) { int c = -1; if (g_rccl.CommCount && g_rccl.CommCount(h->comm, &c) == 0) return c; return -1; }
+    return 1;
+}
+DRIL_EXPORT int64_t dril_comm_allreduce_calls(const dril_handle* h) { return h ? h->allreduce_calls : -1; }
 
 // ---- measurement ----------------------------------------------------------------------------------------
 DRIL_EXPORT int32_t dril_profile_get(dril_handle* h, int32_t kid, double* total_ms, int64_t* launches) {

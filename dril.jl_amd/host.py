@@ -606,6 +606,25 @@ class Handle:
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._chk(self.lib.dril_comm_init(self._h, buf))
 
+    def comm_ranks(self) -> int:
+        """ranks the communicator itself reports (ncclCommCount), 1 without a communicator"""
+        return int(self.lib.dril_comm_ranks(self._h))
+
+    def comm_allreduce_calls(self) -> int:
+        return int(self.lib.dril_comm_allreduce_calls(self._h))
+
+    @staticmethod
+    def comm_loopback(handles: Sequence["Handle"]):
+        """DEBUG / TEST: join handles (ranks 0..n-1 of one process, one device) into a loopback communicator; afterwards every handle
+        must be driven from its own thread (dril_debug_comm_loopback, include/dril_hip.h)"""
+        arr = (C.c_void_p * len(handles))(*[h._h for h in handles])
+        rc = handles[0].lib.dril_debug_comm_loopback(arr, len(handles))
+        if rc != capi.OK:
+            msg = b""
+            for h in handles:
+                msg = msg or (h.lib.dril_last_error(h._h) or b"")
+            raise DrilError(rc, (msg or handles[0].lib.dril_last_error(None) or b"").decode())
+
     # measurement
     def synchronize(self):
         self._chk(self.lib.dril_synchronize(self._h))

@@ -297,6 +297,18 @@ int32_t dril_comm_unique_id(uint8_t id[128]);
 /* RCCL communicator over cfg.world_size ranks; gradients and loss statistics are summed with one
  * ncclAllReduce per optimiser step on the handle's stream */
 int32_t dril_comm_init(dril_handle* h, const uint8_t id[128]);
+/* ranks the handle's communicator spans: ncclCommCount of the RCCL communicator (what RCCL itself saw, not cfg.world_size), the group
+ * size of a loopback communicator, 1 without a communicator, -1 on error */
+int32_t dril_comm_ranks(dril_handle* h);
+/* all-reduces this handle has issued since dril_create (every call site counts: advantage moments, [grads || 8 sums], the per-epoch
+ * moment table, NormalizeWrapperEnv's batch moments, the explained-variance sums) */
+int64_t dril_comm_allreduce_calls(const dril_handle* h);
+/* DEBUG / TEST: join n handles of THIS process, all on ONE device, with cfg.world_size == n and ranks 0..n-1, into a loopback
+ * communicator (RCCL refuses two ranks per device).  Every all-reduce call site, count and dtype of the data-parallel path is unchanged;
+ * the transport is an in-process rendezvous plus one kernel that sums the ranks' device buffers in rank order and writes the sum back to
+ * all of them.  Each handle must then be driven from its own host thread, all making the same sequence of calls; a rank that waits
+ * 120 s for the others fails with DRIL_ERR_RCCL.  (new: the reference has no distributed code) */
+int32_t dril_debug_comm_loopback(dril_handle** handles, int32_t n);
 
 /* ---- measurement ---------------------------------------------------------------- */
 /* accumulated HIP-event time and launch count of one kernel class since the last reset */

@@ -25,6 +25,22 @@ def _params(P, seed, scale=0.3):
     return (np.random.default_rng(seed).standard_normal(P) * scale).astype(np.float32)
 
 
+def _flip_report(o, cfg, obs, u, a_dev, a_orc, where=""):
+    """Discrete actions come from an inverse-CDF draw (categorical.jl:47-52: findfirst(cumsum(p) .>= u)); device and oracle compute p in fp32 with
+    different instruction sequences, so an action may differ only where u sits within fp32 rounding of a CDF edge.  Returns the number of
+    flips and asserts that EVERY flipped sample has |u - edge| <= 1e-6 (the oracle's probabilities give the edges); prints the count."""
+    flip = np.flatnonzero(np.asarray(a_dev).reshape(-1) != np.asarray(a_orc).reshape(-1))
+    if flip.size == 0:
+        return 0
+    ob = np.ascontiguousarray(np.asarray(obs, np.float32).reshape(-1, o.D)[flip])
+    probs = np.stack([np.exp(o.evaluate_actions(ob, np.full(flip.size, cfg.action_start + a, np.int32))[1].astype(np.float64)) for a in range(o.A)], axis=1)
+    edges = np.cumsum(probs, axis=1)[:, :-1]
+    margin = np.abs(edges - np.asarray(u, np.float64).reshape(-1)[flip][:, None]).min(axis=1)
+    print(f"[flips]{where} {flip.size} of {np.asarray(a_orc).size} actions differ; max |u - CDF edge| = {margin.max():.2e}")
+    assert margin.max() <= 1e-6, f"{where}: an action differs with u {margin.max():.3e} away from the nearest CDF edge"
+    return int(flip.size)
+
+
 @pytest.fixture(scope="module")
 def lib(hip):
     return hip
@@ -98,7 +114,8 @@ def test_policy_forward_evaluate_predict(pkg, oracle_mod, kind, B):
     np.testing.assert_allclose(vh, vo, atol=2e-5, rtol=2e-5)
     if h.discrete:
         same = ah == ao
-        assert same.mean() >= 0.995                       # an action may flip only when u sits within fp32 rounding of the CDF
+        _flip_report(o, cfg, obs, noise, ah, ao, f" policy_forward kind={kind} B={B}:")     # a flip needs u within 1e-6 of a CDF edge; count printed
+        assert same.mean() >= 0.995
         np.testing.assert_allclose(lh[same], lo[same], atol=2e-5, rtol=2e-5)
         assert set(np.unique(ah)) <= {cfg.action_start + i for i in range(h.A)}
     else:
@@ -146,6 +163,12 @@ def test_collect_rollout_matches_oracle(pkg, oracle_mod, kind, E, T, L, fixed):
             if h.discrete:
                 ok = np.cumprod((ah == ao).all(axis=2), axis=0).astype(bool)     # env matches up to its first action flip
                 assert ok.all(axis=0).mean() >= 0.98
+                if inject and rollout == 0:                                       # (injected noise covers the first rollout) the FIRST difference of an env must be a CDF-edge flip (later ones follow from diverged states)
+                    first = ok.copy(); first[1:] = ok[:-1]; first[0] = True       # steps whose inputs still agree
+                    fo_obs = o.buffer(capi.BUF_OBSERVATIONS).reshape(T, E, -1)
+                    sel = first & ~ok
+                    if sel.any():
+                        _flip_report(o, cfg, fo_obs[sel], noise.reshape(T, E)[sel], ah[sel], ao[sel], f" rollout kind={kind} E={E}:")
             else:
                 ok = np.ones((T, E), bool)
             for which, tol in ((capi.BUF_OBSERVATIONS, 2e-5), (capi.BUF_VALUES, 5e-5), (capi.BUF_LOGPROBS, 1e-4), (capi.BUF_REWARDS, 1e-4),
@@ -287,6 +310,54 @@ def test_device_permutation_matches_oracle_and_train_end_to_end(pkg, oracle_mod)
         assert a.loss == pytest.approx(b.loss, rel=2e-3, abs=1e-5)
         assert a.explained_variance == pytest.approx(b.explained_variance, rel=2e-3, abs=1e-4)
     np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=2e-3, atol=2e-5)
+
+
+def test_configs0_readme_quickstart_matches_oracle(pkg, oracle_mod):
+    """BASELINE.json configs[0] — the reference's README quick-start (/root/reference README.md:50-73): CartPole-v1, 4 envs, PPO() defaults
+    (n_steps 2048, batch_size 64, 10 epochs => 1 280 optimiser steps per iteration on the launch-bound small path: in-kernel advantage moments,
+    one-workgroup reduce + clip + Adam).  One full iteration with injected sampling noise and DataLoader order vs the oracle: every buffer
+    field, the learn_stats and the parameters after 1 280 Adam steps; then a second iteration on top (the env is not reset, Adam state carries)."""
+    capi = pkg._capi
+    env = pkg.CartPoleEnv(max_steps=500); alg = pkg.PPO()
+    layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space())
+    cfg = pkg.make_config(env, 4, alg, layer, seed=42)
+    assert (cfg.n_envs, cfg.n_steps, cfg.batch_size, cfg.epochs, cfg.hidden1, cfg.hidden2) == (4, 2048, 64, 10, 64, 64)
+    assert (cfg.learning_rate, cfg.clip_range, cfg.vf_coef, cfg.max_grad_norm) == pytest.approx((3e-4, 0.2, 0.5, 0.5))
+    E, T, N = 4, 2048, 8192
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = pkg.flatten_params(layer.initialparameters(np.random.default_rng(0)))       # orthogonal init, gains sqrt2 / 0.01 / 1 (layer_constructors.jl:61-65)
+    h.set_params(flat); o.set_params(flat); h.env_reset(42); o.env_reset(42)
+    rng = np.random.default_rng(7)
+    for it in range(2):
+        noise = rng.random(N)
+        h.set_noise(noise); o.set_noise(noise)
+        h.collect_rollout(); o.collect_rollout()
+        ah, ao = h.buffer(capi.BUF_ACTIONS).reshape(T, E), o.buffer(capi.BUF_ACTIONS).reshape(T, E)
+        ok = np.cumprod(ah == ao, axis=0).astype(bool)
+        first = ok.copy(); first[1:] = ok[:-1]; first[0] = True
+        sel = first & ~ok
+        nflip = _flip_report(o, cfg, o.buffer(capi.BUF_OBSERVATIONS).reshape(T, E, -1)[sel], noise.reshape(T, E)[sel], ah[sel], ao[sel], f" configs[0] iteration {it}:") if sel.any() else 0
+        full = ok.all(axis=0)
+        assert full.sum() >= 3, f"{nflip} CDF-edge flips diverged more than one of the 4 envs"
+        for which, tol in ((capi.BUF_OBSERVATIONS, 2e-5), (capi.BUF_VALUES, 5e-5), (capi.BUF_LOGPROBS, 1e-4), (capi.BUF_REWARDS, 0), (capi.BUF_ADVANTAGES, 1e-3), (capi.BUF_RETURNS, 1e-3)):
+            a, b = h.buffer(which).reshape(T, E, -1), o.buffer(which).reshape(T, E, -1)
+            np.testing.assert_allclose(a[:, full], b[:, full], atol=tol, rtol=tol)
+        np.testing.assert_array_equal(h.buffer(capi.BUF_FLAGS).reshape(T, E)[:, full], o.buffer(capi.BUF_FLAGS).reshape(T, E)[:, full])
+        assert (o.buffer(capi.BUF_FLAGS) & 1).any()                                     # real CartPole episodes: the pole falls
+        if not full.all():                                                              # a flipped env: continue from identical data so the UPDATE comparison stays exact
+            for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+                h.set_buffer(which, o.buffer(which))
+        perm = np.stack([np.random.default_rng(1000 * it + e).permutation(N) for e in range(cfg.epochs)]).astype(np.int64)
+        h.set_permutation(perm); o.set_permutation(perm)
+        sh, so = h.ppo_update(), o.ppo_update()
+        assert sh.n_updates == so.n_updates == 1280 and not sh.early_stopped
+        for f in ("policy_loss", "value_loss", "entropy_loss", "approx_kl_div", "clip_fraction", "loss", "grad_norm", "explained_variance", "ratio_first"):
+            assert getattr(sh, f) == pytest.approx(getattr(so, f), rel=2e-3, abs=5e-6), (it, f)
+        assert sh.loss == pytest.approx(so.loss, rel=1e-4 if it == 0 else 1e-3)          # north_star: PPO loss within 1e-4 rel (iteration 0: identical inputs)
+        np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=2e-3, atol=2e-5)
+        assert np.abs(h.get_params() - flat).max() > 1e-3                                # 1 280 Adam steps moved the weights
+        st, sc = h.env_get_state(); o.env_set_state(st, sc)
+        o.set_params(h.get_params())                                                     # iteration 1 starts from identical weights (Adam moments stay each side's own)
 
 
 def test_large_size_properties(pkg):
