@@ -33,6 +33,7 @@ FLOP_FWD_BWD = 3 * FLOP_FWD  # a16: backward ~ 2x forward
 def flop_fwd(D: int, H: int, A: int) -> int:
     return 2 * ((D * H + H * H + H * A) + (D * H + H * H + H))
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PMC_FILE = "r01_ppo_grad_pmc.json"  # HBM traffic (PMC) + rocprofv3 average of the dominant kernel on configs[1], with the commit it was taken at
 
 
 def cpu_baseline(pkg, seed: int) -> dict:
@@ -176,8 +177,7 @@ def main() -> None:
     env = pkg.CartPoleEnv(max_steps=500) if args.env == "cartpole" else pkg.PendulumEnv(max_steps=200)
     alg = pkg.PPO(n_steps=T, batch_size=B_global, epochs=args.epochs)
     layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(args.hidden, args.hidden))
-    device = int(os.environ.get("DRIL_DEVICE_OVERRIDE", local_rank))   # debugging aid only (several ranks on one card)
-    cfg = pkg.make_config(env, E, alg, layer, seed=42, fixed_length_episodes=True, device=device, rank=rank, world_size=world,
+    cfg = pkg.make_config(env, E, alg, layer, seed=42, fixed_length_episodes=True, device=local_rank, rank=rank, world_size=world,
                           profile_events=not args.no_events, normalize={} if args.normalize else None)
     h = pkg.Handle(cfg)
     h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(42))))   # random-init weights of the named architecture
@@ -221,6 +221,9 @@ def main() -> None:
                        "optimizer_steps_per_iteration": args.epochs * (-(-N_local * world // B_global)),
                        "episodes": f"fixed length {env.max_steps} (termination disabled)", "parallelism": f"dp{world} (env shards)"},
             "loss_last": last.loss, "n_updates_last": last.n_updates,
+            # what the communicator itself reports (ncclCommCount), not the launcher's WORLD_SIZE; 1 = no communicator (single GPU)
+            "rccl_ranks": h.comm_ranks(), "allreduce_calls": h.comm_allreduce_calls(),
+            "value_per_gpu": value / world,      # N = 1-equivalent figure, to be read against the N = 1 BENCH line
         }
         gk = prof.get("ppo_grad_kernel", {"total_ms": 0, "launches": 0})
         if gk["launches"]:
@@ -229,13 +232,18 @@ def main() -> None:
             avg_ms = gk["total_ms"] / gk["launches"]
             flops = (B_global // world) * 3 * flop_fwd(h.D, args.hidden, h.A)
             ach = flops / (avg_ms * 1e-3) / 1e12
-            traffic = None
-            pmc = ROOT / "profiles" / "r01_ppo_grad_pmc.json"
+            # traffic and the rocprofv3 average are NOT measured in this run (PMC needs its own rocprofv3 passes): they are replayed from the
+            # committed profile of exactly this workload, and the line says so (traffic_source: file + the commit the profile was taken at)
+            traffic = traffic_source = rocprof_ms = None
+            pmc = ROOT / "profiles" / PMC_FILE
             if pmc.exists() and args.env == "cartpole" and args.hidden == 64 and args.minibatches == 32 and E == 65536 and T == 2048:
-                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")   # PMC passes were taken on exactly this workload
+                rec = json.loads(pmc.read_text())
+                traffic, rocprof_ms = rec.get("hbm_bytes_per_launch"), rec.get("rocprof_avg_launch_ms")
+                traffic_source = f"replayed from profiles/{PMC_FILE} (rocprofv3 --pmc passes at commit {rec.get('commit', '?')}); not measured in this run"
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                               "traffic": traffic, "kernel": "ppo_grad_kernel", "avg_launch_ms": avg_ms, "launches": gk["launches"],
-                               "flops_per_launch": flops}
+                               "traffic": traffic, "traffic_source": traffic_source, "kernel": "ppo_grad_kernel", "avg_launch_ms": avg_ms,
+                               "avg_launch_ms_source": "HIP events on the library's stream around every launch of the timed region",
+                               "rocprof_avg_launch_ms": rocprof_ms, "launches": gk["launches"], "flops_per_launch": flops}
             out["kernel_ms_per_step"] = {k: v["total_ms"] / args.steps for k, v in prof.items() if v["launches"]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, 42)

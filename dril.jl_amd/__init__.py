@@ -14,7 +14,8 @@ from . import _capi  # noqa: F401
 from .host import (  # noqa: F401
     AcrobotEnv, Agent, ActorCriticLayer, Box, CartPoleEnv, ContinuousActorCriticLayer, DeviceParallelEnv, Discrete, HostParallelEnv,
     DiscreteActorCriticLayer, DrilError, Handle, MonitorWrapperEnv, MountainCarContinuousEnv, MountainCarEnv, NormalizeWrapperEnv, PendulumEnv, PPO, RolloutBuffer, ScalingWrapperEnv, collect_rollout_,
-    evaluate_agent, flatten_params, get_action_and_values, make_config, predict_values, train_, unflatten_params,
+    evaluate_agent, flatten_params, get_action_and_values, get_original_obs, get_original_rewards, make_config, predict_values, train_, unflatten_params,
+    unnormalize_obs_, unnormalize_rewards_, TRAINING_START_LOCALS, ROLLOUT_START_LOCALS, TIMER_SECTIONS,
 )
 from .sac import (  # noqa: F401
     SAC, AutoEntropyCoefficient, FixedEntropyCoefficient, ReplayBuffer, SACAgent, SACLayer, SacHandle, get_gradient_steps, make_sac_config,

@@ -138,6 +138,7 @@ _SIG = {
     "dril_env_set_state": (C.c_int32, [_P, _P, _P]),
     "dril_norm_get_stats": (C.c_int32, [_P, _P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)]),
     "dril_norm_set_stats": (C.c_int32, [_P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_int64]),
+    "dril_norm_get_original": (C.c_int32, [_P, _P, _P]),
     "dril_monitor_get_stats": (C.c_int32, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "dril_policy_forward": (C.c_int32, [_P, _P, C.c_int64, _P, _P, _P, _P]),
     "dril_evaluate_actions": (C.c_int32, [_P, _P, _P, C.c_int64, _P, _P, _P]),

@@ -61,13 +61,14 @@ def save_policy_params_and_state(agent, path, suffix: str = ".npz") -> str:
 
 
 def load_policy_params_and_state_(agent, alg, path, suffix: str = ".npz"):
-    """load_policy_params_and_state!(agent, alg, path): parameters and aux replace the agent's; a fresh optimiser is built on the next bind"""
+    """load_policy_params_and_state!(agent, alg, path) (ppo.jl:77-94): parameters and aux replace the agent's and a NEW TrainState is built
+    (`Lux.Training.TrainState(layer, parameters, states, make_optimizer(alg))` :88-91) — the Adam moments are not restored.  The device handle
+    keys its optimiser state to the TrainState object, so the next train_ on ANY already-bound env starts from zero moments (host._claim_optimizer)"""
     file_path = str(path) if str(path).endswith(suffix) else str(path) + suffix
     data = np.load(file_path, allow_pickle=False)
     params = _unflatten("parameters", data)
     if hasattr(agent, "train_state"):
-        agent.train_state.parameters = params
-        agent.train_state.step = 0
+        agent.train_state = type(agent.train_state)(parameters=params, step=0)
     else:
         agent.parameters = params
     if "aux/Q_target_parameters" in data.files:

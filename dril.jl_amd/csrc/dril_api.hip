@@ -113,10 +113,11 @@ struct dril_handle {
     int *mon_cnt = nullptr, *mon_meta = nullptr; uint8_t* e_flags = nullptr;
     float4* rec = nullptr;   // packed minibatch records (see pack_records_kernel)
     RmsState *obs_rms = nullptr, *ret_rms = nullptr; int obs_par = 0, ret_par = 0;   // ping-pong RunningMeanStd pairs
-    double* rms_partials = nullptr; int rms_blocks = 256; float* e_obs_raw = nullptr;
+    double* rms_partials = nullptr; int rms_blocks = 256; float* e_obs_raw = nullptr; float* e_rew_n = nullptr;   // e_obs_raw / e_rew: get_original_obs / get_original_rewards; e_rew_n: rewards as the wrapper delivers them
     double* rms_red = nullptr;   // data-parallel: this step's partial sums folded to one row and summed over ranks
     int grad_stagger = 0;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
+    int grad_variant = 2;   // hidden [64,64]: 0 = f32-MFMA ppo_grad_kernel, 1 / 2 = ppo_grad_split_kernel (bf16 x 3 operand splitting) at 2 / 1 waves per SIMD (env DRIL_GRAD_VARIANT)
     bool external = false; bool generic = false; float* gen_tmp = nullptr;   // generic: layer-by-layer kernels (host envs, or a device env whose hidden_dims the fused kernels are not built for)
     GenericDims gd{}; GenericWs gws; int ext_t = 0; bool ext_acted = false;   // DRIL_ENV_EXTERNAL: host envs, generic kernels
     float* ext_stage_rew = nullptr; uint8_t* ext_stage_flags = nullptr;   // pinned [T][E] staging: dril_ext_record returns without draining the stream
@@ -344,7 +345,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     g.clip_range = h->cfg.clip_range; g.ent_coef = h->cfg.ent_coef; g.vf_coef = h->cfg.vf_coef; g.clip_range_vf = h->cfg.clip_range_vf;
     g.has_clip_vf = h->cfg.has_clip_range_vf; g.normalize_adv = h->cfg.normalize_advantage; g.action_start = h->cfg.action_start;
     g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
-    g.G = G; g.dbg = h->dbg; g.layout = h->grad_layout; g.stagger = h->grad_stagger; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
+    g.G = G; g.dbg = h->dbg; g.layout = h->grad_layout; g.variant = h->grad_variant; g.stagger = h->grad_stagger; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
     prof_begin(h, DRIL_K_PPO_GRAD);
     if (h->generic) HIPCHK(h, generic_ppo_grad(h->gd, g, h->gws, h->stream));
     else HIPCHK(h, launch_ppo_grad(h->cfg.env_kind, h->cfg.hidden1, g, h->stream));
@@ -474,6 +475,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (const char* e = std::getenv("DRIL_GRAD_PRIO")) h->grad_prio = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_STAGGER")) h->grad_stagger = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_SPLIT")) h->grad_split = std::atoi(e);
+    if (const char* e = std::getenv("DRIL_GRAD_VARIANT")) { h->grad_variant = std::atoi(e); if (h->grad_variant < 0 || h->grad_variant > 2) h->grad_variant = 0; }
     h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
     CCHK(hipSetDevice(cfg->device));
@@ -489,6 +491,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     else { h->slab_a = slab_size_actor(cfg->env_kind, cfg->hidden1); h->slab_c = slab_size_critic(cfg->env_kind, cfg->hidden1); }
     h->wide = !h->generic && cfg->hidden1 > 64;
     h->Gmax = (h->wide && cfg->hidden1 > 128) ? (h->num_cus / 2 > 0 ? h->num_cus / 2 : 1) : h->num_cus;   // H = 128: 4 waves and 77 KB LDS per workgroup, two workgroups per CU   // [64,64]: 2 workgroups per CU (actor + critic), 4 waves each; wide: 1 workgroup of H/32 waves per CU
+    if (!h->generic && !h->wide && h->grad_variant == 2) h->Gmax = h->num_cus / 2 > 0 ? h->num_cus / 2 : 1;   // one 4-wave workgroup per CU (<= 512 registers per wave): G actor + G critic workgroups fill the chip once
     if (h->generic) { h->Gmax = std::getenv("DRIL_EXT_GMAX") ? std::atoi(std::getenv("DRIL_EXT_GMAX")) : 64; if (h->Gmax < 1) h->Gmax = 1; }                                                        // generic path: one slab per row chunk of the minibatch
     if (const char* e = std::getenv("DRIL_GRAD_GMAX")) { const int g = std::atoi(e); if (g > 0 && g < h->Gmax) h->Gmax = g; }   // diagnostic: fewer workgroups per net
     if (h->wide) { const size_t hh = (size_t)cfg->hidden1 * cfg->hidden1; CCHK(dmalloc(&h->w2a_actor, hh)); CCHK(dmalloc(&h->w2ta_actor, hh)); CCHK(dmalloc(&h->w2a_critic, hh)); CCHK(dmalloc(&h->w2ta_critic, hh)); }
@@ -516,7 +519,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
 #endif
     CCHK(dmalloc(&h->e_obs, E * h->D)); CCHK(dmalloc(&h->e_rew, E)); CCHK(dmalloc(&h->e_tobs, E * h->D)); CCHK(dmalloc(&h->e_term, E));
     CCHK(dmalloc(&h->e_trunc, E)); CCHK(hipMalloc(&h->e_act, E * act_bytes_per(h)));
-    CCHK(dmalloc(&h->e_obs_raw, E * h->D)); CCHK(dmalloc(&h->obs_rms, 2)); CCHK(dmalloc(&h->ret_rms, 2)); CCHK(dmalloc(&h->rms_partials, (size_t)h->rms_blocks * 16)); CCHK(dmalloc(&h->rms_red, 16));
+    CCHK(dmalloc(&h->e_obs_raw, E * h->D)); CCHK(dmalloc(&h->e_rew_n, E)); CCHK(dmalloc(&h->obs_rms, 2)); CCHK(dmalloc(&h->ret_rms, 2)); CCHK(dmalloc(&h->rms_partials, (size_t)h->rms_blocks * 16)); CCHK(dmalloc(&h->rms_red, 16));
     { RmsState init[2]; for (auto& r : init) { for (int d = 0; d < 8; ++d) { r.mean[d] = 0.f; r.var[d] = 1.f; } r.count = 0; }   // RunningMeanStd{T}(shape): zeros, ones, 0 (normalizeWrapperEnv.jl:14-16)
       CCHK(hipMemcpy(h->obs_rms, init, sizeof(init), hipMemcpyHostToDevice)); CCHK(hipMemcpy(h->ret_rms, init, sizeof(init), hipMemcpyHostToDevice)); }
     CCHK(hipMemsetAsync(h->params, 0, P * 4, h->stream)); CCHK(hipMemsetAsync(h->boot, 0, N * 4, h->stream));
@@ -547,7 +550,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
                     h->flags, h->last_values, h->noise_dev, h->perm_dev, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
-                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->gen_tmp, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
+                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->e_rew_n, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->gen_tmp, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
                     h->mon_ring_len, h->e_ep_len, h->mon_cnt, h->mon_meta, h->e_flags};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& p : h->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -599,7 +602,7 @@ DRIL_EXPORT int32_t dril_env_step(dril_handle* h, const void* actions, float* re
     const size_t E = h->cfg.n_envs;
     HIPCHK(h, hipMemcpyAsync(h->e_act, actions, E * act_bytes_per(h), hipMemcpyHostToDevice, h->stream));
     float* rew_dev = h->e_rew;
-    if (normalizing(h)) { rew_dev = h->e_obs_raw; int rc = step_dev(h, h->e_act, rew_dev, nullptr); if (rc) return rc; }   // e_obs_raw doubles as scratch for the normalised rewards
+    if (normalizing(h)) { rew_dev = h->e_rew_n; int rc = step_dev(h, h->e_act, rew_dev, nullptr); if (rc) return rc; }
     else {
         HIPCHK(h, launch_env_step(h->cfg.env_kind, (int)E, h->env_seed0, h->cfg.episode_len, h->cfg.fixed_length_episodes, h->cfg.action_start,
                                   h->e_act, h->state, h->step_count, h->episode, h->gstep, h->e_rew, h->e_term, h->e_trunc, h->e_tobs, monitor_step_args(h), h->stream));
@@ -641,6 +644,14 @@ DRIL_EXPORT int32_t dril_norm_set_stats(dril_handle* h, const float* obs_mean, c
     o.count = obs_count; r.mean[0] = ret_mean; r.var[0] = ret_var; r.count = ret_count;
     HIPCHK(h, hipMemcpyAsync(h->obs_rms + h->obs_par, &o, sizeof(o), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->ret_rms + h->ret_par, &r, sizeof(r), hipMemcpyHostToDevice, h->stream));
+    return sync(h);
+}
+
+DRIL_EXPORT int32_t dril_norm_get_original(dril_handle* h, float* obs, float* rewards) {
+    NEED(h); NOT_EXTERNAL(h, "dril_norm_get_original");
+    if (!normalizing(h)) return fail(h, DRIL_ERR_NOT_INITIALISED, "NormalizeWrapperEnv is off (cfg.norm_obs == cfg.norm_reward == 0)");
+    if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->e_obs_raw, (size_t)h->cfg.n_envs * h->D * 4, hipMemcpyDeviceToHost, h->stream));
+    if (rewards) HIPCHK(h, hipMemcpyAsync(rewards, h->e_rew, (size_t)h->cfg.n_envs * 4, hipMemcpyDeviceToHost, h->stream));
     return sync(h);
 }
 
@@ -1083,7 +1094,7 @@ DRIL_EXPORT int32_t dril_evaluate_agent(dril_handle* h, int32_t n_eval, int32_t 
     h->env_ready = true;
     const bool raw = h->mon_cur_ret != nullptr;                                  // monitored: infos[i]["episode"]["r"] is the raw return
     std::vector<float> rew(E), cur_r(E, 0.f), er; std::vector<uint8_t> term(E), trunc(E); std::vector<int32_t> cur_l(E, 0), el;
-    float* rew_n = h->e_obs_raw;                                                 // scratch for wrapper-delivered rewards (see dril_env_step)
+    float* rew_n = h->e_rew_n;                                                   // wrapper-delivered rewards (see dril_env_step)
     rc = observe_dev(h, true); if (rc) return rc;                                // observations = observe(env), :88
     int steps = 0;
     while ((int)er.size() < n_eval) {

@@ -123,6 +123,41 @@ __device__ __forceinline__ float tanh_f32(float x) {
 constexpr float kTanhScale = 2.8853900817779268f;
 
 // ---------------------------------------------------------------------------------------------
+// fp32-equivalent contraction on the bf16 matrix cores: every f32 operand is cut into three bf16 pieces x = hi + mid + lo (upper 16 bits, exact
+// remainder, twice: exact for a 24-bit mantissa) and a k16 step of a 32x32 tile is six v_mfma_f32_32x32x16_bf16 (hi.hi hi.mid mid.hi mid.mid hi.lo lo.hi;
+// the three dropped partial products are <= 2^-23 relative; f32 accumulate).  profiles/r01_bf16_split_microbench.md: 2.0x the rate of
+// v_mfma_f32_32x32x2_f32 with pre-split operands, max error 1.0e-7 vs 1.5e-7 for the f32 MFMA chain — not a precision reduction, and the matrix pipe
+// runs BESIDE the VALU where the f32 MFMA runs ON its lanes (profiles/r01_mfma_valu_microbench.md)
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// pieces of two values packed for one 32-bit word: {b[31:16], a[31:16]} of each piece (v_perm_b32): 4 VALU per value + 1.5 per pair
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned ah = __float_as_uint(a) & 0xffff0000u, bh = __float_as_uint(b) & 0xffff0000u;
+    const float ar = a - __uint_as_float(ah), br = b - __uint_as_float(bh);
+    const unsigned am = __float_as_uint(ar) & 0xffff0000u, bm = __float_as_uint(br) & 0xffff0000u;
+    const float aq = ar - __uint_as_float(am), bq = br - __uint_as_float(bm);
+    hi = __builtin_amdgcn_perm(bh, ah, 0x07060302u); mid = __builtin_amdgcn_perm(bm, am, 0x07060302u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(bq), __float_as_uint(aq), 0x07060302u);
+}
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+// one k16 step of the split product, small terms first
+__device__ __forceinline__ f32x16 mfma_split6(bf16x8 Ah, bf16x8 Am, bf16x8 Al, bf16x8 Bh, bf16x8 Bm, bf16x8 Bl, f32x16 acc) {
+    acc = mfma_bf16(Al, Bh, acc); acc = mfma_bf16(Ah, Bl, acc); acc = mfma_bf16(Am, Bm, acc);
+    acc = mfma_bf16(Am, Bh, acc); acc = mfma_bf16(Ah, Bm, acc); acc = mfma_bf16(Ah, Bh, acc);
+    return acc;
+}
+// ds_read_b64_tr_b16: per 16-lane group a block of 4 rows x 16 columns of 16-bit elements is delivered column-major — lane 4q+p of the group gives the
+// address of row q, columns 4p..4p+3; lane i receives column i, row q in element q (cdna_hip_programming.md T10).  EXEC must be all ones.
+__device__ __forceinline__ s16x4 lds_read_tr16(const char* lds_base, int byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_base + byte_off));
+}
+__device__ __forceinline__ bf16x8 frag8(s16x4 a, s16x4 b) { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7)); }
+__device__ __forceinline__ bf16x8 frag8(u32x2 a, u32x2 b) { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3)); }
+
+// ---------------------------------------------------------------------------------------------
 // environments
 // ---------------------------------------------------------------------------------------------
 template <int KIND> struct EnvSpec;

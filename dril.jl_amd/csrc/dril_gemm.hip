@@ -234,17 +234,7 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_big_kernel(GemmArgs 
 // 2.0x the rate of v_mfma_f32_32x32x2_f32 with pre-split operands, max error 1.0e-7 vs 1.5e-7 for the f32 MFMA chain — not a precision reduction.
 // LDS image per piece and k16 step: [h = k-half][row][8 bf16] — lane (row c, half h) reads its MFMA operand as ONE ds_read_b128 and consecutive lanes
 // read consecutive 16 bytes (conflict-free).  The epilogue's transposition buffer overlays the operand images.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// pieces of two values packed for one 32-bit LDS word: {b[31:16], a[31:16]} of each piece (v_perm_b32): 4 VALU per value + 1.5 per pair
-__device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-    const unsigned ah = __float_as_uint(a) & 0xffff0000u, bh = __float_as_uint(b) & 0xffff0000u;
-    const float ar = a - __uint_as_float(ah), br = b - __uint_as_float(bh);
-    const unsigned am = __float_as_uint(ar) & 0xffff0000u, bm = __float_as_uint(br) & 0xffff0000u;
-    const float aq = ar - __uint_as_float(am), bq = br - __uint_as_float(bm);
-    hi = __builtin_amdgcn_perm(bh, ah, 0x07060302u); mid = __builtin_amdgcn_perm(bm, am, 0x07060302u);
-    lo = __builtin_amdgcn_perm(__float_as_uint(bq), __float_as_uint(aq), 0x07060302u);
-}
+// bf16x8 / u32x4 / split3_pair: dril_device.h
 // MB = m-tiles per wave: the workgroup's output block is (32 MB) x 256.  One thin 32 x 256 block re-reads the activation chunk for every 32 output
 // rows — at hidden 512 the LDS-tiled kernels moved 6 TB/s through L2 and the bf16 form was no faster than the f32 one (87 vs 90 TFLOP/s); with
 // MB = 4 the same chunk feeds four tiles (43.7 FLOP per staged byte instead of 14.5) and the split is amortised over four times the MFMAs

@@ -792,7 +792,7 @@ __global__ void pack_records_kernel(int64_t N, const float* __restrict__ obs, co
 // one lane's share of a minibatch tile (DataLoader gather, ppo.jl:188-195).  Loaded one tile AHEAD of its use so the
 // random-gather latency (~2 us under load, fully exposed in v1: 23 % of wave time in s_waitcnt) hides under the
 // previous tile's MFMAs; the loop body issues no other vector-memory op, so the loads stay in flight until first use.
-template <int O> struct TileIn { float xk[2]; float s0, s1; int act; float xa[O]; bool valid; float4 raw; float s1c; };   // s1c: old value (dual kernel, clip_range_vf)
+template <int O> struct TileIn { float xk[2]; float s0, s1; int act; float xa[O]; bool valid; float4 raw; };
 
 template <int KIND, int O, int HEAD, bool REC>
 __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64_t ntiles, int c, int h, TileIn<O>& t) {
@@ -810,7 +810,6 @@ __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64
         // lane (sample, h) loads half h of the record; t.raw is exchanged between the half-waves at first use (unpack_tile)
         t.raw = a.rec[2 * idx + h];
         if (HEAD == HEAD_VALUE && a.has_clip_vf) t.s1 = a.val_old[idx];
-        t.s1c = (a.layout == 2 && a.has_clip_vf) ? a.val_old[idx] : 0.f;
         return;
     }
 #pragma unroll
@@ -1210,182 +1209,328 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_kernel(GradArgs a) {
 }
 
 // =============================================================================================
-// ppo_grad_dual_kernel (GradArgs.layout == 2) — ONE wave runs BOTH nets on the same 32-sample tile, software-pipelined so that
-// the matrix-core stages of one net sit in the same scheduling region as the VALU / LDS stages of the other:
-//     region 1:  critic.back(k-1) [dh1, dW2, dW1: 144 MFMA]   +   actor.front(k) [L1, tanh, L2: 64 MFMA, head, dW3, dz2]
-//     region 2:  actor.back(k)    [144 MFMA]                  +   critic.front(k)
-// One workgroup (4 waves = 1 wave per SIMD, up to 512 registers) per CU holds both weight images and both per-wave scratch sets in
-// LDS (157 KB).  Versus two co-resident single-net workgroups (ppo_grad_kernel) the overlap no longer depends on how the hardware
-// happens to arbitrate two independent waves, and the minibatch record is gathered once for both nets instead of twice.
+// ppo_grad_split_kernel — the same fused forward + loss + backward with the three H x H contractions of a tile (L2 forward, dh1 = W2' dz2,
+// dW2 += dz2 h1': 192 of the 212 MFMAs of ppo_grad_kernel) on the bf16 matrix cores with fp32-equivalent 3-piece operand splitting
+// (dril_device.h: six v_mfma_f32_32x32x16_bf16 per k16 step, f32 accumulate).  Per tile and net 3 x 48 bf16 MFMAs x 32 cycles = 4.6 k cycles of
+// matrix pipe instead of 12.3 k cycles of f32 MFMA on the VALU's lanes; the splits (h1 and dz2: 64 elements per lane) cost ~350 VALU instructions.
+//
+// LDS plan (H = 64; <= 80 KB per workgroup so that an actor and a critic workgroup still share a CU):
+//   * ONE weight image serves both W2 (row reads, L2 forward) and W2' (transposed reads, dh1): three pieces of [64 rows = h2 unit][64 cols = h1 unit]
+//     bf16, 128-byte rows, the 8-byte chunk ch of row r stored at chunk ch ^ gw(r), gw = bits (r1 r2 r3 r4) of r.  Row reads (ds_read_b64: lanes =
+//     32 consecutive rows, one chunk) and transposed reads (ds_read_b64_tr_b16: 4 rows x 8 chunks per half-wave) are both conflict-free on it
+//     (tools/lds_layout_check.py).  Staged pre-scaled by kTanhScale like the f32 images; dh1 folds the 1 / kTanhScale into its tanh' mask.
+//   * activations enter a product that sums over HIDDEN UNITS straight from registers: the packed pieces of an accumulator tile (registers 8s..8s+7
+//     of k-step s) ARE the B operand — element j of lane half h is unit 16s + 8(j>>2) + 4h + (j&3), and the A operand's two 8-byte chunk reads
+//     follow that order.
+//   * products that sum over SAMPLES (dW2) need the transpose: every lane stores its packed pieces (registers 4g..4g+3 = 8 bytes) at
+//     [its sample][unit 8g + 4h] of a per-wave [32 samples][64 units] bf16 image (chunk ^ swap-bits-1,3(sample)), read back with
+//     ds_read_b64_tr_b16: 12 KB per wave for three pieces, used in turn for h2 (f32, output-layer gradient), h1', dz2', dz1 (f32, first-layer gradient).
+//   * db2 = rowsum(dz2) costs no pass of its own: dz2 = (W3' dz) .* (1 - h2^2), so db2[u] = sum_o W3[o][u] * S[o][u] with
+//     S[o][u] = sum_n dz[o][n] (1 - h2[u][n]^2), accumulated beside dW3 (same operands, already in registers) and multiplied by W3 once, in the epilogue.
 // =============================================================================================
-template <int H, int O> struct GradAcc {
-    static constexpr int MT = H / 32;
-    f32x16 dW2[MT][MT]; f32x4 dW1[H / 16]; float dW3a[O][MT], db2p[MT], db3p[O], dlsp[O], st[5];
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int i = 0; i < H / 16; ++i) dW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            db2p[i] = 0.f;
-#pragma unroll
-            for (int j = 0; j < MT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dW2[i][j][r] = 0.f;
-        }
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            db3p[o] = 0.f; dlsp[o] = 0.f;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) dW3a[o][m] = 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 5; ++i) st[i] = 0.f;
-    }
+template <int D, int H, int O> struct NetLdsSplit {
+    static_assert(H == 64, "the split kernel is laid out for hidden_dims [64,64]");
+    static constexpr int DP = 4, OP = (O + 3) / 4 * 4;
+    static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, SMALL_END = (B3 + OP + 3) / 4 * 4;
+    static constexpr int W2P = SMALL_END;                    // three pieces x [64][64] bf16 = 3 x 8192 bytes
+    static constexpr int END = W2P + 3 * H * H / 2;          // in floats
 };
-template <int H> struct GradTile {
-    static constexpr int MT = H / 32;
-    f32x16 h1[MT], h2[MT]; float xk[2];      // after front(): h1 = layer-1 activations, h2 = dz2
-    __device__ __forceinline__ void zero() {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { h1[m][r] = 0.f; h2[m][r] = 0.f; }
-        xk[0] = xk[1] = 0.f;
-    }
+template <int D, int H, int O> struct GradScratchSplit {
+    static constexpr int T = 0;                              // 12288 bytes: three [32][64] bf16 piece images, or one [H][kTS] f32 image
+    static constexpr int XI = T + 3 * 32 * H / 2;
+    static constexpr int ZI = XI + (D + 2) * kTS;
+    static constexpr int SIZE = ZI + O * kTS;
+    static_assert(H * kTS <= 3 * 32 * H / 2, "the f32 image must fit the piece images' space");
 };
+__device__ __forceinline__ int w2img_gw(int r) { return (((r >> 1) & 1) << 3) | (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 4) & 1); }
+__device__ __forceinline__ int timg_gs(int r) { return (((r >> 1) & 1) << 3) | (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1) | (r & 1); }
 
-// grad_front_a: layers 1-2 of one net on one tile (h1, h2 in registers, h2 image in LDS); grad_front_b: output layer, loss head,
-// output-layer backward — leaves h1 and dz2 (in t.h2) for grad_back
 template <int D, int H, int O>
-__device__ __forceinline__ void grad_front_a(const float* __restrict__ wl, float* __restrict__ T, const float (&xin)[2], GradTile<H>& t, int lane) {
-    constexpr int MT = H / 32;
-    using L = NetLds<D, H, H, O>;
-    t.xk[0] = xin[0]; t.xk[1] = xin[1];
-    struct { float xk[2]; } cur{{xin[0], xin[1]}};
-    float xk[2] = {cur.xk[0], cur.xk[1]};
-    dense_first<H, MT>(wl + L::W1T, wl + L::B1, xk, t.h1, lane);
-    tanh_tiles(t.h1);
-#pragma unroll
-    for (int mo = 0; mo < MT; ++mo) {
-        const int o_ = lane & 31, h_ = lane >> 5;
-        f32x16 accm;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B2 + 32 * mo + 8 * q + 4 * h_);
-            accm[4 * q + 0] = b[0]; accm[4 * q + 1] = b[1]; accm[4 * q + 2] = b[2]; accm[4 * q + 3] = b[3];
-        }
-        const float* wrow = wl + L::W2S + (32 * mo + o_) * L::WS1 + 4 * h_;
-        f32x4 avs[MT * 4];                                            // all A operands of the chain up front
-#pragma unroll
-        for (int gg = 0; gg < MT * 4; ++gg) avs[gg] = *reinterpret_cast<const f32x4*>(wrow + 32 * (gg / 4) + 8 * (gg % 4));
-#pragma unroll
-        for (int gg = 0; gg < MT * 4; ++gg) {
-            const int mi = gg / 4, q = gg % 4;
-            accm = mfma32(avs[gg][0], t.h1[mi][4 * q + 0], accm); accm = mfma32(avs[gg][1], t.h1[mi][4 * q + 1], accm);
-            accm = mfma32(avs[gg][2], t.h1[mi][4 * q + 2], accm); accm = mfma32(avs[gg][3], t.h1[mi][4 * q + 3], accm);
-        }
-        t.h2[mo] = accm;
-        tanh16(t.h2[mo]);
+__device__ inline void stage_net_split(float* lds, const float* __restrict__ P, NetOff n, int tid, int nthreads) {
+    using L = NetLdsSplit<D, H, O>;
+    for (int i = tid; i < L::DP * H; i += nthreads) { const int o = i % H, k = i / H; lds[L::W1T + k * H + o] = k < D ? kTanhScale * P[n.w1 + o + k * H] : 0.0f; }
+    for (int i = tid; i < H; i += nthreads) { lds[L::B1 + i] = kTanhScale * P[n.b1 + i]; lds[L::B2 + i] = kTanhScale * P[n.b2 + i]; }
+    for (int i = tid; i < O * H; i += nthreads) { const int o = i % O, k = i / O; lds[L::W3S + o * H + k] = P[n.w3 + i]; }
+    for (int i = tid; i < L::OP; i += nthreads) lds[L::B3 + i] = i < O ? P[n.b3 + i] : 0.0f;
+    char* img = reinterpret_cast<char*>(lds + L::W2P);
+    for (int i = tid; i < H * H / 2; i += nthreads) {         // pair (k, k+1) of row o: W2 is column-major (out x in), so consecutive threads read consecutive o
+        const int o = i % H, kp = i / H;
+        unsigned hi, mid, lo;
+        split3_pair(kTanhScale * P[n.w2 + o + H * (2 * kp)], kTanhScale * P[n.w2 + o + H * (2 * kp + 1)], hi, mid, lo);
+        const int byte = o * 128 + ((((kp >> 1) ^ w2img_gw(o)) & 15) << 3) + ((kp & 1) << 2);
+        *reinterpret_cast<unsigned*>(img + byte) = hi; *reinterpret_cast<unsigned*>(img + 8192 + byte) = mid; *reinterpret_cast<unsigned*>(img + 16384 + byte) = lo;
     }
-    store_image<MT>(T, t.h2, lane);
 }
-template <int D, int H, int O, int HEAD>
-__device__ __forceinline__ void grad_front_b(const GradArgs& a, const float* __restrict__ wl, float* __restrict__ T, float* __restrict__ ZI,
-                                             const TileIn<O>& cur, const float* ls, float adv_mean, float adv_inv, GradAcc<H, O>& acc, GradTile<H>& t, int lane) {
-    constexpr int MT = H / 32;
-    using L = NetLds<D, H, H, O>;
-    const int c = lane & 31, h = lane >> 5;
-    float out[O], dz[O];
-    dense_out<MT, O, H>(wl + L::W3S, wl + L::B3, t.h2, out, lane);
-    loss_head<O, HEAD>(a, cur, out, cur.valid, h == 0, ls, adv_mean, adv_inv, dz, acc.st, acc.dlsp);
-#pragma unroll
-    for (int o = 0; o < O; ++o) { if (h == 0) { acc.db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
-    {   // dW3 += dz * h2' over samples (h2 read back transposed: hidden on the lane)
-        f32x16 Bh2[MT];
-#pragma unroll
-        for (int mj = 0; mj < MT; ++mj) Bh2[mj] = load_operand(T, mj, lane);
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            float s[MT];
-#pragma unroll
-            for (int mj = 0; mj < MT; ++mj) s[mj] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 z = *reinterpret_cast<const f32x4*>(ZI + o * kTS + 16 * h + 4 * q);
-#pragma unroll
-                for (int mj = 0; mj < MT; ++mj) {
-                    s[mj] = fmaf(Bh2[mj][4 * q + 0], z[0], s[mj]); s[mj] = fmaf(Bh2[mj][4 * q + 1], z[1], s[mj]);
-                    s[mj] = fmaf(Bh2[mj][4 * q + 2], z[2], s[mj]); s[mj] = fmaf(Bh2[mj][4 * q + 3], z[3], s[mj]);
-                }
-            }
-#pragma unroll
-            for (int mj = 0; mj < MT; ++mj) acc.dW3a[o][mj] += s[mj];
-        }
-    }
-    // dz2 = (W3' dz) .* (1 - h2^2), in h2's registers
+
+// packed bf16 pieces of an activation set in accumulator layout: P[piece][m][t] = (register 2t, register 2t + 1) of m-tile m
+template <int MT> struct Pieces { unsigned p[3][MT][8]; };
+template <int MT> __device__ __forceinline__ void split_tiles(const f32x16 (&X)[MT], Pieces<MT>& P) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float dh[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 8; ++t) split3_pair(X[m][2 * t], X[m][2 * t + 1], P.p[0][m][t], P.p[1][m][t], P.p[2][m][t]);
+}
+template <int MT> __device__ __forceinline__ bf16x8 piece_frag(const Pieces<MT>& P, int piece, int m, int s) {
+    const u32x4 v = {P.p[piece][m][4 * s + 0], P.p[piece][m][4 * s + 1], P.p[piece][m][4 * s + 2], P.p[piece][m][4 * s + 3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// transposed piece images [32 samples][64 units]: lane (sample c, half h) stores registers 4g..4g+3 of m-tile m (units 32m + 8g + 4h ..+3) as one 8-byte chunk
+template <int MT> __device__ __forceinline__ void store_pieces_T(char* T, const Pieces<MT>& P, int lane) {
+    const int c = lane & 31, h = lane >> 5;
+    const int base = c * 128 + (((h ^ timg_gs(c)) & 15) << 3);
 #pragma unroll
-            for (int o = 0; o < O; ++o) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * m + 8 * q + 4 * h);
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(w[cc], dz[o], dh[cc]);
+        for (int g = 0; g < 4; ++g) {
+            const int a = base ^ (64 * m + 16 * g);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x2*>(T + 4096 * pc + a) = u32x2{P.p[pc][m][2 * g], P.p[pc][m][2 * g + 1]};
+        }
+}
+// MFMA operand (A or B) of unit tile m, k16 step s of a contraction over samples: lane (unit 32m + (lane&31), half h) gets samples 16s + 8h + j
+__device__ __forceinline__ int timg_read_base(int lane) {
+    const int h = lane >> 5, gm = (lane >> 4) & 1, e = lane & 15, q = e >> 2, p = e & 3;
+    return (8 * h + q) * 128 + ((((4 * gm + p) ^ (8 * (q >> 1) + 2 * h + (q & 1))) & 15) << 3);
+}
+__device__ __forceinline__ bf16x8 load_frag_T(const char* T, int rbase, int piece, int m, int s) {
+    const int a = (rbase ^ (64 * m)) + 2048 * s + 4096 * piece;
+    return frag8(lds_read_tr16(T, a), lds_read_tr16(T, a ^ (512 | 32)));
+}
+
+template <int KIND, int H, int O, int HEAD, bool REC>
+__device__ __forceinline__ void grad_body_split(const GradArgs& a, float* smem) {
+    constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
+    using L = NetLdsSplit<D, H, O>;
+    using SC = GradScratchSplit<D, H, O>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
+    float* wl = smem;
+    const char* Wimg = reinterpret_cast<const char*>(smem + L::W2P);
+    float* T = smem + L::END + wave * SC::SIZE + SC::T;
+    char* Tb = reinterpret_cast<char*>(T);
+    float* XI = smem + L::END + wave * SC::SIZE + SC::XI;
+    float* ZI = smem + L::END + wave * SC::SIZE + SC::ZI;
+    stage_net_split<D, H, O>(wl, a.params, off, tid, blockDim.x);
+    for (int i = lane; i < (D + 2) * kTS; i += 64) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
+    __syncthreads();
+
+    // advantage normalisation constants (ppo.jl:350-356): mean, corrected std, eps added to the std
+    float adv_mean = 0.f, adv_den = 1.f;
+    if (HEAD != HEAD_VALUE && a.normalize_adv) {
+        double s, q, n;
+        if (a.inline_moments) {
+            double* shd = reinterpret_cast<double*>(smem + ((L::END + 1) & ~1));      // per-wave scratch, not yet in use
+            double ls_ = 0, lq_ = 0;
+            for (int64_t i2 = tid; i2 < a.count; i2 += blockDim.x) {
+                const int64_t p2 = a.pos0 + i2;
+                const int64_t gi = a.perm ? a.perm[p2] : (a.perm_bits ? perm_index(p2, a.N, a.perm_key, a.perm_bits) : p2);
+                const int64_t li2 = gi - a.idx_lo;
+                if (li2 >= 0 && li2 < a.n_local) { const float v = REC ? a.rec[2 * li2 + 1].y : a.adv[li2]; ls_ += v; lq_ += (double)v * v; }
+            }
+            shd[tid] = ls_; shd[256 + tid] = lq_;
+            __syncthreads();
+            for (int st_ = 128; st_ > 0; st_ >>= 1) { if (tid < st_) { shd[tid] += shd[tid + st_]; shd[256 + tid] += shd[256 + tid + st_]; } __syncthreads(); }
+            s = shd[0]; q = shd[256]; n = (double)a.count;
+            __syncthreads();
+        } else { s = a.adv_stats[0]; q = a.adv_stats[1]; n = a.adv_stats[2]; }
+        const double mean = s / n;
+        double var = (q - s * mean) / (n - 1.0);
+        if (var < 0) var = 0;
+        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
+    }
+    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
+    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
+    float lsr[kLsMax];
+#pragma unroll
+    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
+    if (HEAD == HEAD_GAUSSIAN) {
+#pragma unroll
+        for (int o = 0; o < O; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
+    }
+    const float* ls = lsr;
+
+    f32x16 dW2[MT][MT];
+    f32x4 dW1[H / 16];
+    float dW3a[O][MT], dS[O][MT], db3p[O], dlsp[O], st[5];
+#pragma unroll
+    for (int i = 0; i < H / 16; ++i) dW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dW2[i][j][r] = 0.f;
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        db3p[o] = 0.f; dlsp[o] = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { dW3a[o][m] = 0.f; dS[o][m] = 0.f; }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) st[i] = 0.f;
+
+    // lane constants of the LDS images
+    const int wf_base = c * 128 + (((h ^ w2img_gw(c)) & 15) << 3);                          // W2 row read: row 32 mo + c, chunk (8 mi + 4 s + 2 rho + h) ^ gw
+    const int e16 = lane & 15, tq = e16 >> 2, tp = e16 & 3, tg = (lane >> 4) & 1;
+    const int wt_base = (4 * h + tq) * 128 + ((((4 * tg + tp) ^ (8 * (tq >> 1) + 4 * h)) & 15) << 3);   // W2' transposed read: rows 32 mi + 16 s + 8 rho + 4 h + q, chunk 8 mk + 4 g + p
+    const int tr_base = timg_read_base(lane);
+    constexpr float kInvTanhScale = 1.0f / kTanhScale;
+
+    const int g = a.layout ? (int)(blockIdx.x % a.G) : (int)(blockIdx.x >> 1);
+    const int64_t ntiles = (a.count + kTile - 1) / kTile;
+    const int64_t tstride = (int64_t)a.G * 4, first = (int64_t)g * 4 + wave;
+    TileIn<O> cur, nxt;
+    int64_t tile = first;
+    if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
+    for (; tile < ntiles; tile += tstride) {
+        load_tile<KIND, O, HEAD, REC>(a, tile + tstride, ntiles, c, h, nxt);      // prefetch the next tile's gathers
+        unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
+        const bool valid = cur.valid;
+        float xk[2] = {cur.xk[0], cur.xk[1]};
+        // ---- forward ----
+        f32x16 h1[MT], h2[MT];
+        float out[O], dz[O];
+        dense_first<H, MT>(wl + L::W1T, wl + L::B1, xk, h1, lane);
+        tanh_tiles(h1);
+        Pieces<MT> P1;
+        split_tiles<MT>(h1, P1);
+#pragma unroll
+        for (int mo = 0; mo < MT; ++mo) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B2 + 32 * mo + 8 * q + 4 * h);
+                acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
             }
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) { const float hv = t.h2[m][4 * q + cc]; t.h2[m][4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int a0 = (wf_base ^ (64 * mi + 32 * s)) + 4096 * mo;
+                    bf16x8 A[3];
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        A[pc] = frag8(*reinterpret_cast<const u32x2*>(Wimg + 8192 * pc + a0), *reinterpret_cast<const u32x2*>(Wimg + 8192 * pc + (a0 ^ 16)));
+                    acc = mfma_split6(A[0], A[1], A[2], piece_frag<MT>(P1, 0, mi, s), piece_frag<MT>(P1, 1, mi, s), piece_frag<MT>(P1, 2, mi, s), acc);
+                }
+            tanh16(acc);
+            h2[mo] = acc;
         }
-}
-// hidden-layer backward of one net on one tile: dh1 = W2' dz2, dz1, dW2 += dz2 h1', db2, dW1 | db1 += dz1 [x; 1]'
-template <int D, int H, int O>
-__device__ __forceinline__ void grad_back(const float* __restrict__ wl, float* __restrict__ T, float* __restrict__ XI, GradAcc<H, O>& acc, GradTile<H>& t, int lane) {
-    constexpr int MT = H / 32;
-    using L = NetLds<D, H, H, O>;
-    const int c = lane & 31, h = lane >> 5;
-    store_image<MT>(T, t.h1, lane);
-    f32x16 g1[MT];
+        store_image<MT>(T, h2, lane);          // f32 image for the output-layer gradient; the round trip hides under the head below
+        dense_out<MT, O, H>(wl + L::W3S, wl + L::B3, h2, out, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- loss head (ppo.jl:377-404) and dLoss/dout ----
+        loss_head<O, HEAD>(a, cur, out, valid, h == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- output layer backward: dW3 += dz h2' and S += dz (1 - h2^2)' over samples (h2 read back transposed: hidden unit on the lane) ----
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        g1[m] = dense_mfma_tile<MT, false>(wl + L::W2T, L::WS2, nullptr, t.h2, m, lane);
+        for (int o = 0; o < O; ++o) { if (h == 0) { db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g1[m][r] = g1[m][r] * (1.0f - t.h1[m][r] * t.h1[m][r]);
-    }
-    {
-        f32x16 Bh[MT];
+        for (int mj = 0; mj < MT; ++mj) {
+            const f32x16 Bh2 = load_operand(T, mj, lane);
+            f32x16 Bm;
 #pragma unroll
-        for (int mj = 0; mj < MT; ++mj) Bh[mj] = load_operand(T, mj, lane);
-        store_image<MT>(T, t.h2, lane);                                    // dz2 image
+            for (int k = 0; k < 16; ++k) Bm[k] = fmaf(-Bh2[k], Bh2[k], 1.0f);
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const f32x16 Az = load_operand(T, mi, lane);
-            acc.db2p[mi] += sum16(Az);
+            for (int o = 0; o < O; ++o) {
+                float acc = 0.f, accs = 0.f;
 #pragma unroll
-            for (int mj = 0; mj < MT; ++mj) acc.dW2[mi][mj] = mfma_outer(Az, Bh[mj], acc.dW2[mi][mj]);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 z = *reinterpret_cast<const f32x4*>(ZI + o * kTS + 16 * h + 4 * q);   // broadcast within the half-wave
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) { acc = fmaf(Bh2[4 * q + cc], z[cc], acc); accs = fmaf(Bm[4 * q + cc], z[cc], accs); }
+                }
+                dW3a[o][mj] += acc; dS[o][mj] += accs;
+            }
         }
-    }
-    store_image<MT>(T, g1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- h1' piece images (the LDS unit executes a wave's accesses in order, so the reads above precede these writes) ----
+        store_pieces_T<MT>(Tb, P1, lane);
+        // ---- dz2 = (W3' dz) .* (1 - h2^2), in h2's registers ----
 #pragma unroll
-    for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? t.xk[s] : 0.f; }
-    {
-        const int j = lane & 15;
-        float bx[8];
-        load_row8(XI, j <= D ? j : D + 1, lane, bx);
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int mt = 0; mt < H / 16; ++mt) {
-            float az[8];
-            load_row8(T, 16 * mt + j, lane, az);
+            for (int q = 0; q < 4; ++q) {
+                float dh[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc.dW1[mt] = mfma16(az[k], bx[k], acc.dW1[mt]);
+                for (int o = 0; o < O; ++o) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * m + 8 * q + 4 * h);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(w[cc], dz[o], dh[cc]);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) { const float hv = h2[m][4 * q + cc]; h2[m][4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
+            }
+        Pieces<MT> P2;
+        split_tiles<MT>(h2, P2);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dh1 = W2' dz2 (A: transposed reads of the weight image) ; dz1 = dh1 .* (1 - h1^2) ----
+        f32x16 g1[MT];
+#pragma unroll
+        for (int mk = 0; mk < MT; ++mk) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int a0 = (wt_base ^ (64 * mk + 2048 * s + 8 * s)) + 4096 * mi;
+                    bf16x8 A[3];
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) A[pc] = frag8(lds_read_tr16(Wimg, 8192 * pc + a0), lds_read_tr16(Wimg, 8192 * pc + (a0 ^ (1024 | 16))));
+                    acc = mfma_split6(A[0], A[1], A[2], piece_frag<MT>(P2, 0, mi, s), piece_frag<MT>(P2, 1, mi, s), piece_frag<MT>(P2, 2, mi, s), acc);
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float t2 = h1[mk][r] * h1[mk][r]; g1[mk][r] = acc[r] * fmaf(-t2, kInvTanhScale, kInvTanhScale); }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dW2 += dz2 h1' over the 32 samples: B fragments from the h1' images, then the dz2' images take their place ----
+        {
+            bf16x8 Bf[MT][2][3];
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) Bf[mj][s][pc] = load_frag_T(Tb, tr_base, pc, mj, s);
+            store_pieces_T<MT>(Tb, P2, lane);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 Ah = load_frag_T(Tb, tr_base, 0, mi, s), Am = load_frag_T(Tb, tr_base, 1, mi, s), Al = load_frag_T(Tb, tr_base, 2, mi, s);
+#pragma unroll
+                    for (int mj = 0; mj < MT; ++mj) dW2[mi][mj] = mfma_split6(Ah, Am, Al, Bf[mj][s][0], Bf[mj][s][1], Bf[mj][s][2], dW2[mi][mj]);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dW1 | db1 += dz1 * [x; 1]' (f32, v_mfma_f32_16x16x4_f32: K = 4 samples per step) ----
+        store_image<MT>(T, g1, lane);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }
+        {
+            const int j = lane & 15;
+            float bx[8];
+            load_row8(XI, j <= D ? j : D + 1, lane, bx);
+#pragma unroll
+            for (int mt = 0; mt < H / 16; ++mt) {
+                float az[8];
+                load_row8(T, 16 * mt + j, lane, az);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dW1[mt] = mfma16(az[k], bx[k], dW1[mt]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
     }
-}
-// 4 waves -> one slab (fixed wave order => deterministic); same slab layout as grad_body's epilogue
-template <int D, int H, int O, int HEAD>
-__device__ __forceinline__ void grad_slab(float* __restrict__ red, float* __restrict__ slab, int SL, const GradAcc<H, O>& acc, int tid, int wave, int lane) {
-    constexpr int MT = H / 32;
-    const int c = lane & 31, h = lane >> 5;
+
+    // ---- epilogue: 4 waves -> one slab (fixed wave order => deterministic) ----
+    __syncthreads();
+    float* red = smem + L::END;
+    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
     const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
     const int o_ls = o_b3 + O, o_st = SL - 8;
     for (int i = tid; i < SL; i += blockDim.x) red[i] = 0.f;
@@ -1393,396 +1538,57 @@ __device__ __forceinline__ void grad_slab(float* __restrict__ red, float* __rest
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
+            for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = 32 * mi + rowfn(r, h);
 #pragma unroll
-                    for (int mj = 0; mj < MT; ++mj) red[o_w2 + row + (32 * mj + c) * H] += acc.dW2[mi][mj][r];
+                    for (int mj = 0; mj < MT; ++mj) red[o_w2 + row + (32 * mj + c) * H] += dW2[mi][mj][r];
                 }
-                const float b2 = acc.db2p[mi] + __shfl_xor(acc.db2p[mi], 32);
-                if (h == 0) red[o_b2 + 32 * mi + c] += b2;
-            }
 #pragma unroll
             for (int mt = 0; mt < H / 16; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 16 * mt + 4 * (lane >> 4) + r, col = lane & 15;
-                    if (col < D) red[o_w1 + row + col * H] += acc.dW1[mt][r];
-                    else if (col == D) red[o_b1 + row] += acc.dW1[mt][r];
+                    if (col < D) red[o_w1 + row + col * H] += dW1[mt][r];
+                    else if (col == D) red[o_b1 + row] += dW1[mt][r];
                 }
 #pragma unroll
-            for (int o = 0; o < O; ++o) {
+            for (int m = 0; m < MT; ++m) {
+                float b2 = 0.f;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float v = acc.dW3a[o][m] + __shfl_xor(acc.dW3a[o][m], 32);
+                for (int o = 0; o < O; ++o) {
+                    const float v = dW3a[o][m] + __shfl_xor(dW3a[o][m], 32);      // the two halves hold different samples
+                    const float sv = dS[o][m] + __shfl_xor(dS[o][m], 32);
                     if (h == 0) red[o_w3 + o + (32 * m + c) * O] += v;
+                    b2 = fmaf(wl[L::W3S + o * H + 32 * m + c], sv, b2);            // db2[u] = sum_o W3[o][u] S[o][u]
                 }
-                const float b3 = half_sum(acc.db3p[o]);
-                if (lane == 0) red[o_b3 + o] += b3;
-                if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(acc.dlsp[o]); if (lane == 0) red[o_ls + o] += l; }
+                if (h == 0) red[o_b2 + 32 * m + c] += b2;
             }
 #pragma unroll
-            for (int k = 0; k < 5; ++k) { const float v = half_sum(acc.st[k]); if (lane == 0) red[o_st + k] += v; }
+            for (int o = 0; o < O; ++o) {
+                const float b3 = half_sum(db3p[o]);
+                if (lane == 0) red[o_b3 + o] += b3;
+                if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (lane == 0) red[o_ls + o] += l; }
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (lane == 0) red[o_st + k] += v; }
         }
         __syncthreads();
     }
+    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
     for (int i = tid; i < SL; i += blockDim.x) slab[i] = red[i];
-    __syncthreads();
 }
 
-// scheduling hint for a region that holds one net's matrix-core stage and the other net's VALU stage: ask for N x {1 MFMA, V VALU}
-// (sched_group_barrier masks: 0x008 MFMA, 0x002 VALU incl. transcendental); LDS ops are left to float.
-// Measured (profiles/r01_dual_kernel.md): without hints the scheduler keeps the two nets' stages almost sequential (96 TFLOP/s, no
-// spills); with 144 x {1, 4} it interleaves for ~40 MFMAs, then falls back, and the longer live ranges spill 72 VGPRs (83 TFLOP/s).
-// Hints are therefore OFF (N = 0); the two-workgroup layout (111 TFLOP/s) stays the default.
-constexpr int kDualMfma = 0, kDualValuPerMfma = 4;
-template <int N, int V> __device__ __forceinline__ void mfma_valu_pipeline() {
-#pragma unroll
-    for (int i = 0; i < N; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, V, 0); }
-}
-
-template <int KIND, int H> struct DualLds {
-    static constexpr int D = EnvSpec<KIND>::D, OA = EnvSpec<KIND>::A;
-    using LA = NetLds<D, H, H, OA>; using LC = NetLds<D, H, H, 1>;
-    using SA = GradScratch<D, H, OA>; using SC = GradScratch<D, H, 1>;
-    static constexpr int WA = 0, WC = (LA::BWD_END + 3) / 4 * 4, SCR = WC + (LC::BWD_END + 3) / 4 * 4;
-    static constexpr int PER_WAVE = SA::SIZE + SC::SIZE;
-    static constexpr int SIZE = SCR + 4 * PER_WAVE;
-    static_assert(sizeof(float) * SIZE <= 160 * 1024, "dual-net workgroup must fit the 160 KB LDS of one CU");
-    static_assert(4 * PER_WAVE >= 2 * (2 * H * H + 8 * H), "the epilogue's slab image overlays the per-wave scratch");
-};
-
-template <int KIND, int H>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ppo_grad_dual_kernel(GradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (*a.stop_flag) return;
-    constexpr int D = EnvSpec<KIND>::D, OA = EnvSpec<KIND>::A;
-    constexpr int HEADA = EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN;
-    using DL = DualLds<KIND, H>;
-    using SA = typename DL::SA; using SC = typename DL::SC;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    float* wlA = smem + DL::WA; float* wlC = smem + DL::WC;
-    float* scr = smem + DL::SCR + wave * DL::PER_WAVE;
-    float *TA = scr + SA::T, *XIA = scr + SA::XI, *ZIA = scr + SA::ZI;
-    float *TC = scr + SA::SIZE + SC::T, *XIC = scr + SA::SIZE + SC::XI, *ZIC = scr + SA::SIZE + SC::ZI;
-    stage_net<D, H, H, OA, true>(wlA, a.params, a.actor, tid, blockDim.x);
-    stage_net<D, H, H, 1, true>(wlC, a.params, a.critic, tid, blockDim.x);
-    for (int i = lane; i < DL::PER_WAVE; i += 64) scr[i] = 0.f;                       // images start at zero: the pipeline's first critic.back() adds nothing
-    __builtin_amdgcn_s_waitcnt(0);
-    for (int i = lane; i < (D + 2) * kTS; i += 64) { const float v = (i / kTS == D) ? 1.0f : 0.0f; XIA[i] = v; XIC[i] = v; }
-    __syncthreads();
-
-    float adv_mean = 0.f, adv_den = 1.f;                                              // ppo.jl:350-356
-    if (a.normalize_adv) {
-        const double s = a.adv_stats[0], q = a.adv_stats[1], n = a.adv_stats[2];
-        const double mean = s / n;
-        double var = (q - s * mean) / (n - 1.0);
-        if (var < 0) var = 0;
-        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
-    }
-    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
-    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
-    constexpr bool LS_GAUSS = HEADA == HEAD_GAUSSIAN; constexpr int LS_N = OA;
-    // log_std hoisted into scalar registers: a per-tile global load would sit in the in-order vmcnt queue between the prefetched
-    // gathers and their first use and drain them every tile (Pendulum [64,64]: 91 -> TFLOP/s below)
-    float lsr[kLsMax];
-#pragma unroll
-    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
-    if (LS_GAUSS) {
-#pragma unroll
-        for (int o = 0; o < LS_N; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
-    }
-    const float* ls = lsr;
-
-    GradAcc<H, OA> accA; GradAcc<H, 1> accC; accA.zero(); accC.zero();
-    GradTile<H> tA, tC; tA.zero(); tC.zero();
-    const int g = blockIdx.x;
-    const int64_t ntiles = (a.count + kTile - 1) / kTile, tstride = (int64_t)a.G * 4;
-    int64_t tile = (int64_t)g * 4 + wave;
-    TileIn<OA> cur, nxt;
-    if (tile < ntiles) load_tile<KIND, OA, HEADA, true>(a, tile, ntiles, c, h, cur);
-    for (; tile < ntiles; tile += tstride) {
-        load_tile<KIND, OA, HEADA, true>(a, tile + tstride, ntiles, c, h, nxt);      // prefetch the next tile's record (one gather serves both nets)
-        // unpack: the two half-waves exchange the record halves (see unpack_tile)
-        float lo[4], hi[4];
-        {
-            const float v[4] = {cur.raw.x, cur.raw.y, cur.raw.z, cur.raw.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned u = __float_as_uint(v[i]);
-                const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-                lo[i] = __uint_as_float(r[0]); hi[i] = __uint_as_float(r[1]);
-            }
-        }
-        cur.xk[0] = h ? lo[1] : lo[0]; cur.xk[1] = h ? lo[3] : lo[2];
-        cur.s0 = hi[1]; cur.s1 = hi[2];
-        if (HEADA == HEAD_CATEGORICAL) cur.act = __float_as_int(hi[0]) - a.action_start; else cur.xa[0] = hi[0];
-        TileIn<1> curC; curC.xk[0] = cur.xk[0]; curC.xk[1] = cur.xk[1]; curC.s0 = hi[3]; curC.s1 = cur.s1c; curC.valid = cur.valid; curC.act = 0;
-        __builtin_amdgcn_sched_barrier(0);
-        // region 1a: actor layers 1-2;  1b: actor head + output-layer backward (VALU / LDS) under critic.back(k-1) (144 MFMA)
-        grad_front_a<D, H, OA>(wlA, TA, cur.xk, tA, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        grad_front_b<D, H, OA, HEADA>(a, wlA, TA, ZIA, cur, ls, adv_mean, adv_inv, accA, tA, lane);
-        grad_back<D, H, 1>(wlC, TC, XIC, accC, tC, lane);
-        mfma_valu_pipeline<kDualMfma, kDualValuPerMfma>();
-        __builtin_amdgcn_sched_barrier(0);
-        // region 2a: critic layers 1-2;  2b: critic head + output-layer backward under actor.back(k)
-        grad_front_a<D, H, 1>(wlC, TC, curC.xk, tC, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        grad_front_b<D, H, 1, HEAD_VALUE>(a, wlC, TC, ZIC, curC, ls, adv_mean, adv_inv, accC, tC, lane);
-        grad_back<D, H, OA>(wlA, TA, XIA, accA, tA, lane);
-        mfma_valu_pipeline<kDualMfma, kDualValuPerMfma>();
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-    }
-    grad_back<D, H, 1>(wlC, TC, XIC, accC, tC, lane);                                   // drain: critic.back(last)
-    __syncthreads();
-    float* red = smem + DL::SCR;
-    grad_slab<D, H, OA, HEADA>(red, a.slabs_actor + (size_t)g * a.slab_a, a.slab_a, accA, tid, wave, lane);
-    grad_slab<D, H, 1, HEAD_VALUE>(red, a.slabs_critic + (size_t)g * a.slab_c, a.slab_c, accC, tid, wave, lane);
-}
-
-// =============================================================================================
-// ppo_grad_pipe_kernel (GradArgs.layout == 3) — one net per workgroup like ppo_grad_kernel, but ONE wave per SIMD (up to 512
-// registers) and the tile loop software-pipelined: the hidden-layer backward of tile k-1 (144 MFMA: dh1, dW2, dW1) runs in the same
-// instruction stream as the output layer / loss head / output-layer backward of tile k (VALU + LDS), with the VALU work cut into
-// chunks that are issued from INSIDE the MFMA group loops (one chunk after every 4 MFMAs) — the overlap is fixed by program order
-// instead of depending on how the hardware arbitrates two independent waves.
-// =============================================================================================
-template <int I> struct IC { static constexpr int value = I; };
-template <class Fn, int... Is> __device__ __forceinline__ void static_for_impl(Fn&& fn, std::integer_sequence<int, Is...>) { (fn(IC<Is>{}), ...); }
-template <int N, class Fn> __device__ __forceinline__ void static_for(Fn&& fn) { static_for_impl(fn, std::make_integer_sequence<int, N>{}); }
-
-// the VALU / LDS stage of one tile as a list of chunks; run<I>() executes chunk I (no-op past the end)
-template <int D, int H, int O, int HEAD> struct FrontB {
-    static constexpr int MT = H / 32;
-    using L = NetLds<D, H, H, O>;
-    static constexpr int C_OUT = 0, C_RED = MT, C_HEAD = MT + 1, C_ZI = MT + 2, C_W3 = MT + 3, C_Z2 = C_W3 + 4 * O, N = C_Z2 + 4 * MT;
-    const GradArgs& a; const float* wl; float* T; float* ZI; const TileIn<O>& cur; const float* ls; float adv_mean, adv_inv;
-    GradAcc<H, O>& acc; GradTile<H>& t; int lane, c, h;
-    float part[O], out[O], dz[O]; f32x16 Bh2[MT];
-    f32x4 w3[O][MT][4], zv[O][4];                                 // W3 rows of the lane's 16 hidden units (used twice: output layer and dz2), dz broadcast vectors
-    __device__ __forceinline__ void preload() {                   // issue the weight reads before the MFMA stage they hide under
-#pragma unroll
-        for (int o = 0; o < O; ++o)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w3[o][m][q] = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * m + 8 * q + 4 * h);
-    }
-    __device__ __forceinline__ FrontB(const GradArgs& a_, const float* wl_, float* T_, float* ZI_, const TileIn<O>& cur_, const float* ls_, float am, float ai,
-                                      GradAcc<H, O>& acc_, GradTile<H>& t_, int lane_)
-        : a(a_), wl(wl_), T(T_), ZI(ZI_), cur(cur_), ls(ls_), adv_mean(am), adv_inv(ai), acc(acc_), t(t_), lane(lane_), c(lane_ & 31), h(lane_ >> 5) {}
-    template <int I> __device__ __forceinline__ void run() {
-        if constexpr (I >= C_OUT && I < C_RED) {                     // output layer, m-tile I: partial sums over the lane's 16 hidden rows
-            constexpr int mo = I - C_OUT;
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                float s = mo == 0 ? 0.f : part[o];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 w = w3[o][mo][q];
-                    s = fmaf(w[0], t.h2[mo][4 * q + 0], s); s = fmaf(w[1], t.h2[mo][4 * q + 1], s);
-                    s = fmaf(w[2], t.h2[mo][4 * q + 2], s); s = fmaf(w[3], t.h2[mo][4 * q + 3], s);
-                }
-                part[o] = s;
-            }
-        } else if constexpr (I == C_RED) {
-#pragma unroll
-            for (int o = 0; o < O; ++o) out[o] = part[o] + __shfl_xor(part[o], 32) + wl[L::B3 + o];
-        } else if constexpr (I == C_HEAD) {
-            loss_head<O, HEAD>(a, cur, out, cur.valid, h == 0, ls, adv_mean, adv_inv, dz, acc.st, acc.dlsp);
-        } else if constexpr (I == C_ZI) {
-#pragma unroll
-            for (int o = 0; o < O; ++o) { if (h == 0) { acc.db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
-#pragma unroll
-            for (int mj = 0; mj < MT; ++mj) Bh2[mj] = load_operand(T, mj, lane);
-        } else if constexpr (I >= C_W3 && I < C_Z2) {                // dW3[o] += dz[o] * h2' over the samples 16h + 4q .. +3
-            constexpr int o = (I - C_W3) / 4, q = (I - C_W3) % 4;
-            if constexpr (I == C_W3) {
-#pragma unroll
-                for (int oo = 0; oo < O; ++oo)
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) zv[oo][qq] = *reinterpret_cast<const f32x4*>(ZI + oo * kTS + 16 * h + 4 * qq);
-            }
-            const f32x4 z = zv[o][q];
-#pragma unroll
-            for (int mj = 0; mj < MT; ++mj) {
-                float s = acc.dW3a[o][mj];
-                s = fmaf(Bh2[mj][4 * q + 0], z[0], s); s = fmaf(Bh2[mj][4 * q + 1], z[1], s);
-                s = fmaf(Bh2[mj][4 * q + 2], z[2], s); s = fmaf(Bh2[mj][4 * q + 3], z[3], s);
-                acc.dW3a[o][mj] = s;
-            }
-        } else if constexpr (I >= C_Z2 && I < N) {                   // dz2 = (W3' dz) .* (1 - h2^2), in h2's registers
-            constexpr int m = (I - C_Z2) / 4, q = (I - C_Z2) % 4;
-            float dh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                const f32x4 w = w3[o][m][q];
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(w[cc], dz[o], dh[cc]);
-            }
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) { const float hv = t.h2[m][4 * q + cc]; t.h2[m][4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
-        }
-    }
-    template <int FROM> __device__ __forceinline__ void run_rest() { static_for<(N > FROM ? N - FROM : 0)>([&](auto ic) __attribute__((always_inline)) { run<FROM + decltype(ic)::value>(); }); }
-};
-struct NoSteps { template <int I> __device__ __forceinline__ void run() {} __device__ __forceinline__ void preload() {} };
-
-// grad_back with one step of `S` issued after every group of 4 MFMAs (36 groups: dh1 16, dW2 16, dW1 4)
-template <int D, int H, int O, class S>
-__device__ __forceinline__ void grad_back_steps(const float* __restrict__ wl, float* __restrict__ T, float* __restrict__ XI, GradAcc<H, O>& acc, GradTile<H>& t, int lane, S& steps) {
-    constexpr int MT = H / 32;
-    static_assert(MT == 2, "group numbering below assumes H = 64");
-    using L = NetLds<D, H, H, O>;
-    const int c = lane & 31, h = lane >> 5;
-    store_image<MT>(T, t.h1, lane);
-    f32x16 g1[MT];
-    static_for<MT>([&](auto im) __attribute__((always_inline)) {
-        constexpr int m = decltype(im)::value;
-        f32x16 accm;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accm[r] = 0.f;
-        const float* wrow = wl + L::W2T + (32 * m + (lane & 31)) * L::WS2 + 4 * h;
-        f32x4 avs[MT * 4];                                            // all A operands of the chain up front: one exposed LDS round trip per 32 MFMAs instead of one per 4
-#pragma unroll
-        for (int gg = 0; gg < MT * 4; ++gg) avs[gg] = *reinterpret_cast<const f32x4*>(wrow + 32 * (gg / 4) + 8 * (gg % 4));
-        if (m == 0) steps.preload();
-        static_for<MT * 4>([&](auto ig) __attribute__((always_inline)) {
-            constexpr int g = decltype(ig)::value, mi = g / 4, q = g % 4;
-            const f32x4 av = avs[g];
-            accm = mfma32(av[0], t.h2[mi][4 * q + 0], accm); accm = mfma32(av[1], t.h2[mi][4 * q + 1], accm);
-            accm = mfma32(av[2], t.h2[mi][4 * q + 2], accm); accm = mfma32(av[3], t.h2[mi][4 * q + 3], accm);
-            steps.template run<m * 8 + g>();
-        });
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g1[m][r] = accm[r] * (1.0f - t.h1[m][r] * t.h1[m][r]);
-    });
-    f32x16 Bh[MT];
-#pragma unroll
-    for (int mj = 0; mj < MT; ++mj) Bh[mj] = load_operand(T, mj, lane);
-    store_image<MT>(T, t.h2, lane);                                    // dz2 image
-    static_for<MT>([&](auto imi) __attribute__((always_inline)) {
-        constexpr int mi = decltype(imi)::value;
-        const f32x16 Az = load_operand(T, mi, lane);
-        acc.db2p[mi] += sum16(Az);
-        static_for<MT * 4>([&](auto ig) __attribute__((always_inline)) {
-            constexpr int g = decltype(ig)::value, mj = g / 4, qq = g % 4;
-#pragma unroll
-            for (int kk = 4 * qq; kk < 4 * qq + 4; ++kk) acc.dW2[mi][mj] = mfma32(Az[kk], Bh[mj][kk], acc.dW2[mi][mj]);
-            steps.template run<16 + mi * 8 + g>();
-        });
-    });
-    store_image<MT>(T, g1, lane);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? t.xk[s] : 0.f; }
-    {
-        const int j = lane & 15;
-        float bx[8];
-        load_row8(XI, j <= D ? j : D + 1, lane, bx);
-        float azs[H / 16][8];
-#pragma unroll
-        for (int mt = 0; mt < H / 16; ++mt) load_row8(T, 16 * mt + j, lane, azs[mt]);
-        static_for<H / 16>([&](auto imt) __attribute__((always_inline)) {
-            constexpr int mt = decltype(imt)::value;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc.dW1[mt] = mfma16(azs[mt][k], bx[k], acc.dW1[mt]);
-            steps.template run<32 + mt>();
-        });
-    }
-}
-
-template <int D, int H, int O> struct PipeLds {
-    using L = NetLds<D, H, H, O>; using SC = GradScratch<D, H, O>;
-    static constexpr int SCR = (L::BWD_END + 3) / 4 * 4;
-    static constexpr int PER_WAVE = SC::SIZE + H * kTS;              // back-stage image + XI + ZI, plus the front-stage image
-    static constexpr int SIZE = SCR + 4 * PER_WAVE;
-};
-
-template <int KIND, int H, int O, int HEAD>
-__device__ __forceinline__ void grad_body_pipe(const GradArgs& a, float* smem) {
-    constexpr int D = EnvSpec<KIND>::D;
-    using PL = PipeLds<D, H, O>; using SC = typename PL::SC;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
-    float* wl = smem;
-    float* scr = smem + PL::SCR + wave * PL::PER_WAVE;
-    float *TB = scr + SC::T, *XI = scr + SC::XI, *ZI = scr + SC::ZI, *TF = scr + SC::SIZE;
-    stage_net<D, H, H, O, true>(wl, a.params, off, tid, blockDim.x);
-    for (int i = lane; i < PL::PER_WAVE; i += 64) scr[i] = 0.f;        // the first back() of the pipeline runs on zero images
-    __builtin_amdgcn_s_waitcnt(0);
-    for (int i = lane; i < (D + 2) * kTS; i += 64) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
-    __syncthreads();
-    float adv_mean = 0.f, adv_den = 1.f;
-    if (HEAD != HEAD_VALUE && a.normalize_adv) {
-        const double s = a.adv_stats[0], q = a.adv_stats[1], n = a.adv_stats[2];
-        const double mean = s / n;
-        double var = (q - s * mean) / (n - 1.0);
-        if (var < 0) var = 0;
-        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
-    }
-    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
-    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
-    constexpr bool LS_GAUSS = HEAD == HEAD_GAUSSIAN; constexpr int LS_N = O;
-    // log_std hoisted into scalar registers: a per-tile global load would sit in the in-order vmcnt queue between the prefetched
-    // gathers and their first use and drain them every tile (Pendulum [64,64]: 91 -> TFLOP/s below)
-    float lsr[kLsMax];
-#pragma unroll
-    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
-    if (LS_GAUSS) {
-#pragma unroll
-        for (int o = 0; o < LS_N; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
-    }
-    const float* ls = lsr;
-
-    GradAcc<H, O> acc; acc.zero();
-    GradTile<H> tp, tn; tp.zero();
-    const int g = (int)(blockIdx.x % a.G);
-    const int64_t ntiles = (a.count + kTile - 1) / kTile, tstride = (int64_t)a.G * 4;
-    int64_t tile = (int64_t)g * 4 + wave;
-    TileIn<O> cur, nxt;
-    if (tile < ntiles) load_tile<KIND, O, HEAD, true>(a, tile, ntiles, c, h, cur);
-    for (; tile < ntiles; tile += tstride) {
-        load_tile<KIND, O, HEAD, true>(a, tile + tstride, ntiles, c, h, nxt);
-        unpack_tile<KIND, O, HEAD, true>(a, h, cur);
-        __builtin_amdgcn_sched_barrier(0);
-        grad_front_a<D, H, O>(wl, TF, cur.xk, tn, lane);                 // layers 1-2 of tile k (64 MFMA) + h2 image
-        __builtin_amdgcn_sched_barrier(0);
-        {   // hidden-layer backward of tile k-1 (144 MFMA) with the head / output-layer backward of tile k issued between the MFMA groups
-            FrontB<D, H, O, HEAD> fb(a, wl, TF, ZI, cur, ls, adv_mean, adv_inv, acc, tn, lane);
-            grad_back_steps<D, H, O>(wl, TB, XI, acc, tp, lane, fb);
-            fb.template run_rest<36>();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < H / 32; ++m) { tp.h1[m] = tn.h1[m]; tp.h2[m] = tn.h2[m]; }
-        tp.xk[0] = tn.xk[0]; tp.xk[1] = tn.xk[1];
-        cur = nxt;
-    }
-    { NoSteps ns; grad_back_steps<D, H, O>(wl, TB, XI, acc, tp, lane, ns); }   // drain: back(last tile)
-    __syncthreads();
-    float* red = smem + PL::SCR;
-    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
-    grad_slab<D, H, O, HEAD>(red, (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL, SL, acc, tid, wave, lane);
-}
-template <int KIND, int H>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void ppo_grad_pipe_kernel(GradArgs a) {
+// WPS = waves per SIMD the register budget is planned for: 2 = an actor and a critic workgroup share a CU (<= 256 registers), 1 = one workgroup per CU (<= 512)
+template <int KIND, int H, bool REC, int WPS>
+__global__ __launch_bounds__(256, WPS) void ppo_grad_split_kernel(GradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (*a.stop_flag) return;
     constexpr int A = EnvSpec<KIND>::A;
-    if (blockIdx.x < (unsigned)a.G) grad_body_pipe<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN>(a, smem);
-    else grad_body_pipe<KIND, H, 1, HEAD_VALUE>(a, smem);
-}
-template <int KIND, int H> static size_t grad_pipe_lds_bytes() {
-    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
-    constexpr int wa = PipeLds<D, H, A>::SIZE, wc = PipeLds<D, H, 1>::SIZE;
-    return sizeof(float) * (wa > wc ? wa : wc);
+    const bool actor = a.layout ? (blockIdx.x < (unsigned)a.G) : ((blockIdx.x & 1) == 0);
+    if (actor) grad_body_split<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN, REC>(a, smem);
+    else grad_body_split<KIND, H, 1, HEAD_VALUE, REC>(a, smem);
 }
 
 // =============================================================================================
@@ -2459,6 +2265,12 @@ hipError_t launch_moments_finalize(const double* partials, int nblocks, double* 
     return hipGetLastError();
 }
 
+template <int KIND, int H> static size_t grad_split_lds_bytes() {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
+    constexpr int wa = NetLdsSplit<D, H, A>::END + 4 * GradScratchSplit<D, H, A>::SIZE;
+    constexpr int wc = NetLdsSplit<D, H, 1>::END + 4 * GradScratchSplit<D, H, 1>::SIZE;
+    return sizeof(float) * (wa > wc ? wa : wc);
+}
 template <int KIND, int H> static size_t grad_wide_lds_bytes() {
     constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
     constexpr int wa = WideScratch<D, H, A>::SIZE, wc = WideScratch<D, H, 1>::SIZE;
@@ -2489,30 +2301,19 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
 #undef CALLWK
         return hipGetLastError();
     }
-    if (a.layout == 3 && a.rec && hidden == 64 && kind <= 2) {
-#define CALLP(K)                                                                                              \
+    if (a.variant && hidden == 64) {              // bf16 matrix cores, fp32-equivalent operand splitting
+#define CALLS(K, R, W)                                                                                        \
     {                                                                                                         \
-        const size_t lds = grad_pipe_lds_bytes<K, 64>();                                                      \
+        const size_t lds = grad_split_lds_bytes<K, 64>();                                                     \
         static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_pipe_kernel<K, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_split_kernel<K, 64, R, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e; attr_set = true; }                                                 \
-        ppo_grad_pipe_kernel<K, 64><<<2 * a.G, 256, lds, s>>>(a);                                             \
+        ppo_grad_split_kernel<K, 64, R, W><<<2 * a.G, 256, lds, s>>>(a);                                      \
     }
-        if (kind == 0) CALLP(0) else CALLP(1)
-#undef CALLP
-        return hipGetLastError();
-    }
-    if (a.layout == 2 && a.rec && hidden == 64 && kind <= 2) {
-#define CALLD(K)                                                                                              \
-    {                                                                                                         \
-        const size_t lds = sizeof(float) * DualLds<K, 64>::SIZE;                                              \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_dual_kernel<K, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e; attr_set = true; }                                                 \
-        ppo_grad_dual_kernel<K, 64><<<a.G, 256, lds, s>>>(a);                                                 \
-    }
-        if (kind == 0) CALLD(0) else CALLD(1)
-#undef CALLD
+#define CALLSK(K) { if (a.variant == 2) { if (a.rec) CALLS(K, true, 1) else CALLS(K, false, 1) } else { if (a.rec) CALLS(K, true, 2) else CALLS(K, false, 2) } }
+        if (kind == 0) CALLSK(0) else if (kind == 3) CALLSK(3) else if (kind == 4) CALLSK(4) else CALLSK(1)
+#undef CALLSK
+#undef CALLS
         return hipGetLastError();
     }
 #define CALL(K, HH) { if (a.rec) CALLR(K, HH, true) else CALLR(K, HH, false) }

@@ -446,6 +446,12 @@ class Handle:
         self._chk(self.lib.dril_norm_get_stats(self._h, self._p(om), self._p(ov), C.byref(oc), C.byref(rm), C.byref(rv), C.byref(rc)))
         return dict(obs_mean=om, obs_var=ov, obs_count=oc.value, ret_mean=rm.value, ret_var=rv.value, ret_count=rc.value)
 
+    def norm_get_original(self):
+        """-> (get_original_obs, get_original_rewards), normalizeWrapperEnv.jl:220-222"""
+        obs = np.empty((self.E, self.D), np.float32); rew = np.empty(self.E, np.float32)
+        self._chk(self.lib.dril_norm_get_original(self._h, self._p(obs), self._p(rew)))
+        return obs, rew
+
     def norm_set_stats(self, obs_mean, obs_var, obs_count, ret_mean, ret_var, ret_count):
         om = np.ascontiguousarray(obs_mean, np.float32); ov = np.ascontiguousarray(obs_var, np.float32)
         self._chk(self.lib.dril_norm_set_stats(self._h, self._p(om), self._p(ov), int(obs_count), float(ret_mean), float(ret_var), int(ret_count)))
@@ -844,6 +850,33 @@ def NormalizeWrapperEnv(env: DeviceParallelEnv, *, training: bool = True, norm_o
     return env
 
 
+def unnormalize_obs_(obs: np.ndarray, env: DeviceParallelEnv) -> np.ndarray:
+    """unnormalize_obs!(obs, env) (normalizeWrapperEnv.jl:200-210): obs * sqrt(var + eps) + mean with the wrapper's running statistics, in place"""
+    kw = env._kw["normalize"]
+    if kw is None or not kw["norm_obs"]:
+        return obs
+    st = env.handle.norm_get_stats()
+    obs *= np.sqrt(st["obs_var"] + np.float32(kw["epsilon"])); obs += st["obs_mean"]
+    return obs
+
+
+def unnormalize_rewards_(rewards: np.ndarray, env: DeviceParallelEnv) -> np.ndarray:
+    """unnormalize_rewards!(rewards, env) (normalizeWrapperEnv.jl:212-218): rewards * sqrt(var(returns) + eps), in place"""
+    kw = env._kw["normalize"]
+    if kw is None or not kw["norm_reward"]:
+        return rewards
+    rewards *= np.sqrt(np.float32(env.handle.norm_get_stats()["ret_var"]) + np.float32(kw["epsilon"]))
+    return rewards
+
+
+def get_original_obs(env: DeviceParallelEnv) -> np.ndarray:
+    return env.handle.norm_get_original()[0]
+
+
+def get_original_rewards(env: DeviceParallelEnv) -> np.ndarray:
+    return env.handle.norm_get_original()[1]
+
+
 # --------------------------------------------------------------------------------------------
 # RolloutBuffer + collect_rollout! (src/buffers/rollout_buffer.jl)
 # --------------------------------------------------------------------------------------------
@@ -920,55 +953,93 @@ def train_(agent: Agent, env: DeviceParallelEnv, alg: PPO, max_steps: int, callb
     t0 = time.perf_counter()
     h = env.bind(alg, agent.layer)
     h.set_params(flatten_params(agent.train_state.parameters))
+    _claim_optimizer(h, agent)
     per_iter = alg.n_steps * env.n_envs * h.cfg.world_size
     iterations = max_steps // per_iter  # ppo.jl:117
     timer["setup"] = time.perf_counter() - t0
     learn_stats = {k: [] for k in _STAT_KEYS}
-    loc = dict(agent=agent, env=env, alg=alg, iterations=iterations, total_steps=iterations * per_iter, max_steps=max_steps, n_steps=alg.n_steps, n_envs=env.n_envs,
-               roll_buffer=None, total_fps=learn_stats["fps"], callbacks=cbs)                  # the keys test/test_callbacks.jl:25-39 looks for in Base.@locals
-    if not hook("on_training_start", loc):
-        return None
-    t1 = time.perf_counter()
-    t_roll = t_upd = 0.0
-    for i in range(iterations):
-        h.set_learning_rate(alg.learning_rate)  # Optimisers.adjust!, ppo.jl:155-156
-        learn_stats["learning_rates"].append(alg.learning_rate)
-        loc.update(i=i + 1, learning_rate=alg.learning_rate)
-        if not hook("on_rollout_start", loc):
+    loc = dict.fromkeys(TRAINING_START_LOCALS)                                                # the keys test/test_callbacks.jl:25-27 looks for in Base.@locals
+    loc.update(agent=agent, env=env, alg=alg, iterations=iterations, total_steps=iterations * per_iter, max_steps=max_steps, n_steps=alg.n_steps,
+               n_envs=env.n_envs, roll_buffer=None, total_fps=learn_stats["fps"], callbacks=cbs, learn_stats=learn_stats)
+    prof0 = h.profile() if h.cfg.profile_events else None
+    try:
+        if not hook("on_training_start", loc):
             return None
-        a = time.perf_counter()
-        on_step = (lambda: all(c.on_step(loc) for c in step_hooks)) if step_hooks else None
-        if isinstance(env, HostParallelEnv):
-            fps = _host_rollout(h, env, on_step)
-        else:
-            fps = _stepwise_rollout(h, env, on_step) if on_step else h.collect_rollout()  # ppo.jl:167; on_step hooks need the step-granular path
-        if fps is None:
-            return None                                                                       # "Collecting trajectories stopped due to callback failure", trajectory.jl:34-39
-        if not hook("on_rollout_end", loc):
+        t1 = time.perf_counter()
+        t_roll = t_upd = 0.0
+        for i in range(iterations):
+            h.set_learning_rate(alg.learning_rate)  # Optimisers.adjust!, ppo.jl:155-156
+            learn_stats["learning_rates"].append(alg.learning_rate)
+            loc.update(i=i + 1, learning_rate=alg.learning_rate)                              # ROLLOUT_START_LOCALS, test_callbacks.jl:36-39
+            if not hook("on_rollout_start", loc):
+                return None
+            a = time.perf_counter()
+            on_step = (lambda: all(c.on_step(loc) for c in step_hooks)) if step_hooks else None
+            if isinstance(env, HostParallelEnv):
+                fps = _host_rollout(h, env, on_step)
+            else:
+                fps = _stepwise_rollout(h, env, on_step) if on_step else h.collect_rollout()  # ppo.jl:167; on_step hooks need the step-granular path
+            if fps is None:
+                return None                                                                   # "Collecting trajectories stopped due to callback failure", trajectory.jl:34-39
+            loc.update(fps=fps)
+            if not hook("on_rollout_end", loc):
+                return None
+            b = time.perf_counter()
+            st = h.ppo_update()  # ppo.jl:188-264
+            c = time.perf_counter()
+            t_roll += b - a
+            t_upd += c - b
+            agent.steps_taken += per_iter
+            agent.gradient_updates += st.n_updates
+            learn_stats["fps"].append(fps)
+            learn_stats["entropy_losses"].append(st.entropy_loss)
+            learn_stats["policy_losses"].append(st.policy_loss)
+            learn_stats["value_losses"].append(st.value_loss)
+            learn_stats["approx_kl_divs"].append(st.approx_kl_div)
+            learn_stats["clip_fractions"].append(st.clip_fraction)
+            learn_stats["losses"].append(st.loss)
+            learn_stats["explained_variances"].append(st.explained_variance)
+            learn_stats["grad_norms"].append(st.grad_norm)
+        timer["training_loop"] = time.perf_counter() - t1
+        timer["collect_rollout"] = t_roll
+        timer["epoch loop"] = t_upd
+        timer.update(_timer_sections(h, prof0, t_upd))
+        if not hook("on_training_end", loc):
             return None
-        b = time.perf_counter()
-        st = h.ppo_update()  # ppo.jl:188-264
-        c = time.perf_counter()
-        t_roll += b - a
-        t_upd += c - b
-        agent.steps_taken += per_iter
-        agent.gradient_updates += st.n_updates
-        learn_stats["fps"].append(fps)
-        learn_stats["entropy_losses"].append(st.entropy_loss)
-        learn_stats["policy_losses"].append(st.policy_loss)
-        learn_stats["value_losses"].append(st.value_loss)
-        learn_stats["approx_kl_divs"].append(st.approx_kl_div)
-        learn_stats["clip_fractions"].append(st.clip_fraction)
-        learn_stats["losses"].append(st.loss)
-        learn_stats["explained_variances"].append(st.explained_variance)
-        learn_stats["grad_norms"].append(st.grad_norm)
-    timer["training_loop"] = time.perf_counter() - t1
-    timer["collect_rollout"] = t_roll
-    timer["epoch loop"] = t_upd
-    agent.train_state.parameters = unflatten_params(h.get_params(), agent.train_state.parameters)
-    if not hook("on_training_end", loc):
-        return None
-    return learn_stats, timer
+        return learn_stats, timer
+    finally:
+        # the reference mutates agent.train_state in place at every optimiser step (ppo.jl:239), so after an early stop by a callback
+        # (ppo.jl:145-152,170-176) the agent holds the partially trained weights: every exit path copies the device parameters back
+        agent.train_state.parameters = unflatten_params(h.get_params(), agent.train_state.parameters)
+
+
+# keys of Base.@locals the reference's callback test reads (test/test_callbacks.jl:25-27 at training start, :36-39 at rollout start);
+# the Julia shim builds its Dict from the same two lists (tools/check_shim.py asserts that they cannot drift)
+TRAINING_START_LOCALS = ("agent", "env", "alg", "iterations", "total_steps", "max_steps", "n_steps", "n_envs", "roll_buffer", "total_fps", "callbacks", "learn_stats")
+ROLLOUT_START_LOCALS = ("i", "learning_rate")
+# TimerOutputs sections of the reference's train! (ppo.jl:109,154,167,205-207,239) and the device timings that fill them
+TIMER_SECTIONS = ("setup", "training_loop", "collect_rollout", "epoch loop", "batch loop", "compute_gradients", "apply_gradients")
+
+
+def _timer_sections(h: Handle, prof0, t_upd: float) -> dict:
+    """"batch loop" / "compute_gradients" / "apply_gradients" (ppo.jl:206-207,239): with cfg.profile_events the HIP-event totals of the kernels that
+    stand in for them (dril_profile_get); without, only the enclosing wall time is known and the three sections report it as an upper bound"""
+    if prof0 is None:
+        return {"batch loop": t_upd, "compute_gradients": float("nan"), "apply_gradients": float("nan")}
+    p1 = h.profile()
+    ms = lambda *names: sum(p1[n]["total_ms"] - prof0[n]["total_ms"] for n in names) * 1e-3
+    grad = ms("adv_moments_kernel", "ppo_grad_kernel", "grad_reduce_kernel", "ncclAllReduce")
+    apply = ms("adam_kernel")
+    return {"batch loop": grad + apply, "compute_gradients": grad, "apply_gradients": apply}
+
+
+def _claim_optimizer(h: Handle, agent) -> None:
+    """The device handle holds the Adam moments that belong to ONE TrainState (Lux.Training.TrainState carries optimizer_state, ppo.jl:52-53).
+    A different TrainState on the same handle — a fresh agent, or the new TrainState load_policy_params_and_state! builds (ppo.jl:77-94) — starts
+    from a fresh optimiser; consecutive train_ calls on the same TrainState keep their moments, like the reference"""
+    if getattr(h, "_opt_owner", None) is not agent.train_state:
+        h.reset_optimizer()
+        h._opt_owner = agent.train_state
 
 
 def evaluate_agent(agent: Agent, env: DeviceParallelEnv, n_eval_episodes: int = 10, deterministic: bool = True,

@@ -198,6 +198,9 @@ int32_t dril_norm_get_stats(dril_handle* h, float* obs_mean, float* obs_var, int
                             float* ret_mean, float* ret_var, int64_t* ret_count);
 int32_t dril_norm_set_stats(dril_handle* h, const float* obs_mean, const float* obs_var, int64_t obs_count,
                             float ret_mean, float ret_var, int64_t ret_count);
+/* get_original_obs(env) / get_original_rewards(env) (normalizeWrapperEnv.jl:220-222): the un-normalised observations (D x E) of the last
+ * observe and the un-normalised rewards (E) of the last act! through the step-granular verbs; either pointer may be NULL */
+int32_t dril_norm_get_original(dril_handle* h, float* obs, float* rewards);
 
 /* MonitorWrapperEnv: mean return / length over the last `monitor_window` finished episodes (log_stats, monitorWrapperEnv.jl:64-70)
  * and the number of episodes currently in the window; rewards are the RAW env rewards (the monitor sits inside the normaliser) */
