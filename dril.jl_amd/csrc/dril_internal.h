@@ -68,7 +68,7 @@ struct GradArgs {
     int prio, split_pct;   // tuning knobs: static wave priority + share of tiles for the high-priority half
     int inline_moments;   // small minibatches: every actor workgroup computes the advantage moments itself (adv_stats == nullptr), saving two launches per optimiser step
     int layout;   // 0: actor/critic workgroups interleaved by blockIdx parity, 1: first G blocks actor, next G critic
-    int variant;  // hidden 64: 0 = ppo_grad_kernel (f32 MFMA), 1 = ppo_grad_split_kernel planned for 2 waves per SIMD, 2 = the same planned for 1 wave per SIMD
+    int variant;  // hidden 64: 0 = ppo_grad_kernel (f32 MFMA, two workgroups per CU), 1 = ppo_grad_split_kernel (bf16 x 3 operand splitting, one workgroup per CU), 2 = the same with two tiles in flight per wave
     const int* stop_flag;
     NetOff actor, critic;
 };

@@ -10,8 +10,10 @@
 #     agent = Agent(layer, alg; verbose = 0)
 #     learn_stats, to = train!(agent, env, alg, 10 * 2048 * 65_536)
 #
-# NOTE: the build image has no Julia runtime, so this file is syntax-reviewed only; every behaviour it relies on is
-# exercised through the same C symbols by the Python ctypes mirror (dril.jl_amd/host.py, tests/test_gpu_parity.py).
+# STATUS: EXPERIMENTAL — the build image has no Julia runtime, so this file has never executed.  What stands in for a run: tools/check_shim.py (parses this
+# file and the reference's sources: per-argument method specificity of every method added to a DRiL generic function, the callback-locals keys against
+# test/test_callbacks.jl and the Python mirror, every ccall symbol against include/*.h) and the Python ctypes mirror (dril.jl_amd/host.py), which drives
+# the same C symbols in the same order under tests/ on the GPU.  A maintainer with Julia should first run the CI snippet of INTEGRATION.md §6.
 module DRiLHIP
 
 using DRiL
@@ -20,6 +22,20 @@ import DRiL: train!, collect_rollout!, observe, act!, reset!, terminated, trunca
              observation_space, action_space, get_info
 using Random
 using TimerOutputs
+
+# The FIRST argument of every `train!` method below is the reference method's own first-argument type, verbatim (src/algorithms/ppo.jl:100-107,
+# src/algorithms/sac.jl:417-423): then the env argument alone decides specificity (DeviceParallelEnv / OnDevice <: AbstractParallelEnv), the shim's
+# method is strictly more specific and dispatch is unambiguous.  (Round 1 declared `agent::Agent`: wider in argument 1, narrower in argument 2 =>
+# MethodError: ambiguous.)  tools/check_shim.py parses both files and checks every argument pair; INTEGRATION.md §2 has the table.
+const PPOAgent = Agent{<:DRiL.AbstractActorCriticLayer, <:PPO, <:DRiL.AbstractActionAdapter, <:Random.AbstractRNG, <:DRiL.AbstractTrainingLogger, <:Any}
+const SACAgent = Agent{<:DRiL.ContinuousActorCriticLayer, <:DRiL.SAC, <:DRiL.AbstractActionAdapter, <:Random.AbstractRNG, <:DRiL.AbstractTrainingLogger, <:Any}
+
+# keys of `Base.@locals` the reference's callback test reads (test/test_callbacks.jl:25-27 at training start, :36-39 at rollout start).  The Python
+# mirror (dril.jl_amd/host.py) holds the same two tuples; tools/check_shim.py asserts that the three lists (test, mirror, shim) agree.
+const TRAINING_START_LOCALS = (:agent, :env, :alg, :iterations, :total_steps, :max_steps, :n_steps, :n_envs, :roll_buffer, :total_fps, :callbacks, :learn_stats)
+const ROLLOUT_START_LOCALS = (:i, :learning_rate)
+# TimerOutputs sections of the reference's train! (ppo.jl:109,154,167,205-207,239)
+const TIMER_SECTIONS = ("setup", "training_loop", "collect_rollout", "epoch loop", "batch loop", "compute_gradients", "apply_gradients")
 
 const LIB = Ref{String}(joinpath(@__DIR__, "..", "csrc", "libdril_hip.so"))
 const ABI_VERSION = UInt32(1)
@@ -73,6 +89,8 @@ mutable struct DeviceParallelEnv <: AbstractParallelEnv
     bound::Any                     # (alg, hidden_dims, log_std_init) the handle was created for
     last_terminated::Vector{Bool}
     last_truncated::Vector{Bool}
+    optimizer_owner::Any           # the TrainState whose Adam moments the handle holds (see train!)
+    last_kernel_seconds::Dict{String, Float64}
 end
 
 function DeviceParallelEnv(kind::Symbol, n_envs::Integer; max_steps::Integer = (kind === :CartPole || kind === :Acrobot) ? 500 : kind === :MountainCarContinuous ? 999 : 200,
@@ -80,7 +98,7 @@ function DeviceParallelEnv(kind::Symbol, n_envs::Integer; max_steps::Integer = (
         normalize::Union{Nothing, NamedTuple} = nothing)
     haskey(ENV_KINDS, kind) || error("unknown device env $kind")
     env = DeviceParallelEnv(kind, n_envs, max_steps, UInt64(seed), fixed_length_episodes, device, monitor_window, normalize,
-        C_NULL, nothing, fill(false, n_envs), fill(false, n_envs))
+        C_NULL, nothing, fill(false, n_envs), fill(false, n_envs), nothing, Dict{String, Float64}())
     finalizer(e -> (e.handle != C_NULL && ccall((:dril_destroy, LIB[]), Int32, (Ptr{Cvoid},), e.handle); nothing), env)
     return env
 end
@@ -115,7 +133,7 @@ function make_config(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int}, log_
         0.9f0, 0.999f0, 1.0f-5, log_std_init,                    # Optimisers.Adam(eta, (0.9, 0.999), 1e-5): ppo.jl:64-66
         on * Int32(nget(:norm_obs, true)), on * Int32(nget(:norm_reward, true)), on * Int32(nget(:training, true)),
         Float32(nget(:clip_obs, 10)), Float32(nget(:clip_reward, 10)), Float32(nget(:gamma, 0.99)), Float32(nget(:epsilon, 1.0e-8)),
-        env.seed, env.device, 0, 1, 0, env.monitor_window, 0, 0, 0, 0.0f0, 0.0f0, ntuple(_ -> Int32(0), 1))
+        env.seed, env.device, 0, 1, 1, env.monitor_window, 0, 0, 0, 0.0f0, 0.0f0, ntuple(_ -> Int32(0), 1))   # profile_events = 1: HIP-event kernel times fill the TimerOutput sections
 end
 
 "(re)create the handle when the algorithm / layer shape changes; Random.seed!(env, seed) + reset!(env) follow"
@@ -126,7 +144,7 @@ function bind!(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int} = [64, 64],
         cfg = Ref(make_config(env, alg, hidden, log_std_init))
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:dril_create, LIB[]), Int32, (Ref{DrilConfig}, Ref{Ptr{Cvoid}}), cfg, h))
-        env.handle = h[]; env.bound = key
+        env.handle = h[]; env.bound = key; env.optimizer_owner = nothing
         check(ccall((:dril_env_reset, LIB[]), Int32, (Ptr{Cvoid}, UInt64), env.handle, env.seed), env.handle)
     end
     return env.handle
@@ -201,6 +219,24 @@ function hidden_dims_of(ps)
     h = mlp_of(ps.actor_head)
     return [size(h.layer_1.weight, 1), size(h.layer_2.weight, 1)]
 end
+first_dense(l) = hasproperty(l, :activation) ? l : first_dense(first(l.layers))
+"""
+The C ABI carries `hidden_dims = [h1, h2]` and tanh (include/dril_hip.h, dril_config); the reference accepts any depth and activation
+(layer_constructors.jl:6-10,55-56, layer_helpers.jl:27-57).  Anything else is REJECTED here — round 1 read layer_1..layer_3 unconditionally and
+would have mis-flattened a deeper net silently.
+"""
+function check_supported_layer(agent)
+    ps = agent.train_state.parameters
+    for (name, head) in ((:actor_head, mlp_of(ps.actor_head)), (:critic_head, mlp_of(ps.critic_head)))
+        keys(head) == (:layer_1, :layer_2, :layer_3) ||
+            error("DRiLHIP: $name has layers $(keys(head)); the device path supports exactly two hidden layers (hidden_dims = [h1, h2]). Use DRiL's CPU train! for this layer.")
+    end
+    act = first_dense(agent.layer.actor_head).activation
+    (act === tanh || nameof(act) === :tanh_fast) ||
+        error("DRiLHIP: activation $(act) is not supported on the device PPO path (tanh only). Use DRiL's CPU train! for this layer.")
+    size(mlp_of(ps.actor_head).layer_2.weight, 1) == size(mlp_of(ps.critic_head).layer_2.weight, 1) || error("DRiLHIP: actor and critic must share hidden_dims")
+    return nothing
+end
 function push_params!(env, agent)
     flat = flatten_params(agent.train_state.parameters)
     GC.@preserve flat check(ccall((:dril_set_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), env.handle, flat, length(flat)), env.handle)
@@ -211,6 +247,7 @@ function pull_params!(env, agent)
     scatter_params!(agent.train_state.parameters, flat)
 end
 function bind_agent!(env::DeviceParallelEnv, agent, alg::PPO)
+    check_supported_layer(agent)
     ps = agent.train_state.parameters
     ls = haskey(ps, :log_std) ? Float32(ps.log_std[1]) : 0.0f0
     bind!(env, alg, hidden_dims_of(ps), ls)
@@ -242,43 +279,127 @@ function copy_out!(env, which::Integer, dst::Array)
 end
 
 # ---- train!(agent, env::DeviceParallelEnv, alg::PPO, max_steps)  (src/algorithms/ppo.jl:100-325) ----
-function train!(agent::Agent, env::DeviceParallelEnv, alg::PPO{T}, max_steps::Int; ad_type = nothing, callbacks = nothing) where {T}
-    has_step_hooks(callbacks) && error("on_step callbacks need the step-granular path: call DRiL's generic train! on the env verbs")
+"lazy host view of the device rollout buffer: `locals[:roll_buffer].advantages` etc. copy out on demand (a real RolloutBuffer of 65 536 x 2048 steps is 6 GB of host memory)"
+struct DeviceRolloutBuffer
+    env::Any
+end
+const BUFFER_IDS = (observations = 0, actions = 1, rewards = 2, advantages = 3, returns = 4, logprobs = 5, values = 6)
+function Base.getproperty(b::DeviceRolloutBuffer, f::Symbol)
+    f === :env && return getfield(b, :env)
+    haskey(BUFFER_IDS, f) || error("RolloutBuffer has no field $f")
+    env = getfield(b, :env); h = env.handle
+    N = ccall((:dril_obs_dim, LIB[]), Int32, (Ptr{Cvoid},), h)          # placeholder read keeps the handle alive for the size queries below
+    D = Int(N); E = number_of_envs(env); T = env.bound[1].n_steps
+    disc = ccall((:dril_is_discrete, LIB[]), Int32, (Ptr{Cvoid},), h) != 0
+    A = disc ? 1 : Int(ccall((:dril_action_dim, LIB[]), Int32, (Ptr{Cvoid},), h))
+    dst = f === :observations ? Matrix{Float32}(undef, D, E * T) : f === :actions ? (disc ? Matrix{Int32}(undef, 1, E * T) : Matrix{Float32}(undef, A, E * T)) : Vector{Float32}(undef, E * T)
+    copy_out!(env, BUFFER_IDS[f], dst)
+    return dst
+end
+
+"seconds of HIP-event time per kernel class since the last reset (dril_profile_get; cfg.profile_events = 1)"
+function kernel_seconds(h)
+    out = Dict{String, Float64}()
+    for kid in 0:6
+        ms = Ref{Float64}(0); n = Ref{Int64}(0)
+        ccall((:dril_profile_get, LIB[]), Int32, (Ptr{Cvoid}, Int32, Ref{Float64}, Ref{Int64}), h, kid, ms, n) == 0 || continue
+        out[unsafe_string(ccall((:dril_kernel_name, LIB[]), Cstring, (Int32,), kid))] = ms[] * 1.0e-3
+    end
+    return out
+end
+"""
+"batch loop" / "compute_gradients" / "apply_gradients" (ppo.jl:206-207,239) have no host-side extent here — the whole epoch x minibatch loop is ONE
+library call — so their times come from the device: HIP events around the kernels that stand in for them.  TimerOutputs has no public API for adding a
+measured duration, so this writes the section's `accumulated_data` directly; any failure (a TimerOutputs version with another layout) leaves the
+TimerOutput as it was and the numbers stay available from `env.last_kernel_seconds`.
+"""
+function add_device_sections!(to::TimerOutput, secs::Dict{String, Float64}, nsteps::Int)
+    grad = get(secs, "adv_moments_kernel", 0.0) + get(secs, "ppo_grad_kernel", 0.0) + get(secs, "grad_reduce_kernel", 0.0) + get(secs, "ncclAllReduce", 0.0)
+    apply = get(secs, "adam_kernel", 0.0)
+    try
+        loop = to.inner_timers["training_loop"].inner_timers["epoch loop"]
+        function section!(parent, name, seconds)
+            t = get!(() -> TimerOutput(name), parent.inner_timers, name)
+            d = t.accumulated_data
+            t.accumulated_data = TimerOutputs.TimeData(d.ncalls + nsteps, d.time + round(Int64, seconds * 1.0e9), d.allocs)
+            return t
+        end
+        bl = section!(loop, "batch loop", grad + apply)
+        section!(bl, "compute_gradients", grad); section!(bl, "apply_gradients", apply)
+    catch err
+        @debug "DRiLHIP: could not add the device sections to the TimerOutput" err
+    end
+    return (; compute_gradients = grad, apply_gradients = apply)
+end
+
+function train!(agent::PPOAgent, env::DeviceParallelEnv, alg::PPO{T}, max_steps::Int; ad_type = nothing, callbacks = nothing) where {T}
+    if has_step_hooks(callbacks)
+        # on_step hooks fire once per env step inside the rollout (trajectory.jl:34-39; test/test_callbacks.jl:91-99 expects a stop at exactly 512 steps):
+        # run the REFERENCE's own train! over this env's step-granular verbs (observe / act! above) — slow path, semantics preserved (SURVEY.md §8b)
+        kw = isnothing(ad_type) ? (; callbacks = callbacks) : (; ad_type = ad_type, callbacks = callbacks)
+        return invoke(train!, Tuple{PPOAgent, AbstractParallelEnv, PPO{T}, Int}, agent, env, alg, max_steps; kw...)
+    end
     to = TimerOutput()
+    n_steps = alg.n_steps; n_envs = env.n_envs
+    local iterations, total_steps
     @timeit to "setup" begin
         bind_agent!(env, agent, alg); push_params!(env, agent)
-        iterations = max_steps ÷ (alg.n_steps * env.n_envs)            # ppo.jl:117
-        iterations == 0 && @warn "max_steps is less than n_steps * n_envs; there will be no training."
-    end
-    stats = NamedTuple{(:entropy_losses, :policy_losses, :value_losses, :approx_kl_divs, :clip_fractions, :losses,
-        :explained_variances, :fps, :grad_norms, :learning_rates)}(ntuple(_ -> Float32[], 10))
-    locals() = Dict{Symbol, Any}(:agent => agent, :env => env, :alg => alg, :max_steps => max_steps, :iterations => iterations)
-    !isnothing(callbacks) && !all(c -> DRiL.on_training_start(c, locals()), callbacks) && return nothing       # ppo.jl:145-152
-    @timeit to "training_loop" for i in 1:iterations
-        check(ccall((:dril_set_learning_rate, LIB[]), Int32, (Ptr{Cvoid}, Float32), env.handle, alg.learning_rate), env.handle)  # ppo.jl:155-156
-        push!(stats.learning_rates, alg.learning_rate)
-        !isnothing(callbacks) && !all(c -> DRiL.on_rollout_start(c, locals()), callbacks) && return nothing
-        fps = Ref{Float64}(0)
-        @timeit to "collect_rollout" check(ccall((:dril_collect_rollout, LIB[]), Int32, (Ptr{Cvoid}, Ref{Float64}), env.handle, fps), env.handle)
-        push!(stats.fps, fps[]); DRiL.add_step!(agent, alg.n_steps * env.n_envs)
-        DRiL.increment_step!(agent.logger, alg.n_steps * env.n_envs); DRiL.log_scalar!(agent.logger, "env/fps", fps[])
-        DRiL.log_stats(env, agent.logger)                                                                   # ppo.jl:177
-        !isnothing(callbacks) && !all(c -> DRiL.on_rollout_end(c, locals()), callbacks) && return nothing
-        st = Ref{DrilPPOStats}()
-        @timeit to "epoch loop" check(ccall((:dril_ppo_update, LIB[]), Int32, (Ptr{Cvoid}, Ref{DrilPPOStats}), env.handle, st), env.handle)
-        s = st[]
-        push!(stats.entropy_losses, s.entropy_loss); push!(stats.policy_losses, s.policy_loss); push!(stats.value_losses, s.value_loss)
-        push!(stats.approx_kl_divs, s.approx_kl_div); push!(stats.clip_fractions, s.clip_fraction); push!(stats.losses, s.loss)
-        push!(stats.explained_variances, s.explained_variance); push!(stats.grad_norms, s.grad_norm)
-        for (k, v) in ("entropy_loss" => s.entropy_loss, "explained_variance" => s.explained_variance, "policy_loss" => s.policy_loss,
-            "value_loss" => s.value_loss, "approx_kl_div" => s.approx_kl_div, "clip_fraction" => s.clip_fraction, "loss" => s.loss,
-            "grad_norm" => s.grad_norm, "learning_rate" => alg.learning_rate)
-            DRiL.log_scalar!(agent.logger, "train/" * k, v)                                                    # ppo.jl:286-294
+        # the handle's Adam moments belong to ONE TrainState (Lux.Training.TrainState carries optimizer_state, ppo.jl:52-53): a different one — another agent, or
+        # the TrainState load_policy_params_and_state! rebuilds (ppo.jl:77-94) — starts from a fresh optimiser; repeated train! calls on the same one continue
+        if env.optimizer_owner !== agent.train_state
+            check(ccall((:dril_reset_optimizer, LIB[]), Int32, (Ptr{Cvoid},), env.handle), env.handle)
+            env.optimizer_owner = agent.train_state
         end
+        ccall((:dril_profile_reset, LIB[]), Int32, (Ptr{Cvoid},), env.handle)
+        iterations = max_steps ÷ (n_steps * n_envs)                    # ppo.jl:117
+        iterations == 0 && @warn "max_steps is less than n_steps * n_envs; there will be no training."
+        total_steps = iterations * n_steps * n_envs
     end
-    pull_params!(env, agent)                                           # agent.train_state.parameters now hold the trained weights
-    !isnothing(callbacks) && !all(c -> DRiL.on_training_end(c, locals()), callbacks) && return nothing
-    return stats, to
+    learn_stats = NamedTuple{(:entropy_losses, :policy_losses, :value_losses, :approx_kl_divs, :clip_fractions, :losses,
+        :explained_variances, :fps, :grad_norms, :learning_rates)}(ntuple(_ -> Float32[], 10))
+    total_fps = learn_stats.fps; roll_buffer = DeviceRolloutBuffer(env)
+    i = 0; learning_rate = alg.learning_rate
+    # the Dict the reference builds with Base.@locals (ppo.jl:145-152): every key of TRAINING_START_LOCALS always, those of ROLLOUT_START_LOCALS inside the loop
+    locals() = Dict{Symbol, Any}(:agent => agent, :env => env, :alg => alg, :iterations => iterations, :total_steps => total_steps, :max_steps => max_steps,
+        :n_steps => n_steps, :n_envs => n_envs, :roll_buffer => roll_buffer, :total_fps => total_fps, :callbacks => callbacks, :learn_stats => learn_stats,
+        :i => i, :learning_rate => learning_rate, :to => to)
+    fire(f) = isnothing(callbacks) || all(c -> f(c, locals()), callbacks)
+    n_updates = 0
+    try
+        fire(DRiL.on_training_start) || return nothing                                                         # ppo.jl:145-152
+        @timeit to "training_loop" for it in 1:iterations
+            i = it
+            check(ccall((:dril_set_learning_rate, LIB[]), Int32, (Ptr{Cvoid}, Float32), env.handle, learning_rate), env.handle)  # ppo.jl:155-156
+            push!(learn_stats.learning_rates, learning_rate)
+            fire(DRiL.on_rollout_start) || return nothing
+            fps = Ref{Float64}(0)
+            @timeit to "collect_rollout" check(ccall((:dril_collect_rollout, LIB[]), Int32, (Ptr{Cvoid}, Ref{Float64}), env.handle, fps), env.handle)
+            push!(total_fps, fps[]); DRiL.add_step!(agent, n_steps * n_envs)
+            DRiL.increment_step!(agent.logger, n_steps * n_envs); DRiL.log_scalar!(agent.logger, "env/fps", fps[])
+            DRiL.log_stats(env, agent.logger)                                                                   # ppo.jl:177
+            fire(DRiL.on_rollout_end) || return nothing
+            st = Ref{DrilPPOStats}()
+            @timeit to "epoch loop" check(ccall((:dril_ppo_update, LIB[]), Int32, (Ptr{Cvoid}, Ref{DrilPPOStats}), env.handle, st), env.handle)
+            s = st[]; n_updates += s.n_updates
+            DRiL.add_gradient_update!(agent, Int(s.n_updates))
+            push!(learn_stats.entropy_losses, s.entropy_loss); push!(learn_stats.policy_losses, s.policy_loss); push!(learn_stats.value_losses, s.value_loss)
+            push!(learn_stats.approx_kl_divs, s.approx_kl_div); push!(learn_stats.clip_fractions, s.clip_fraction); push!(learn_stats.losses, s.loss)
+            push!(learn_stats.explained_variances, s.explained_variance); push!(learn_stats.grad_norms, s.grad_norm)
+            for (k, v) in ("entropy_loss" => s.entropy_loss, "explained_variance" => s.explained_variance, "policy_loss" => s.policy_loss,
+                "value_loss" => s.value_loss, "approx_kl_div" => s.approx_kl_div, "clip_fraction" => s.clip_fraction, "loss" => s.loss,
+                "grad_norm" => s.grad_norm, "learning_rate" => learning_rate)
+                DRiL.log_scalar!(agent.logger, "train/" * k, v)                                                    # ppo.jl:286-294
+            end
+        end
+        env.last_kernel_seconds = kernel_seconds(env.handle)
+        add_device_sections!(to, env.last_kernel_seconds, n_updates)
+        fire(DRiL.on_training_end) || return nothing
+        return learn_stats, to
+    finally
+        # the reference mutates agent.train_state in place at every optimiser step (ppo.jl:239): after ANY exit — normal, or a callback that stopped the run
+        # (ppo.jl:145-152,170-176) — the agent holds the weights trained so far
+        pull_params!(env, agent)
+    end
 end
 
 # =============================================================================================================================
@@ -295,9 +416,10 @@ mutable struct OnDevice{E <: AbstractParallelEnv} <: AbstractParallelEnv
     device::Int
     handle::Ptr{Cvoid}
     bound::Any
+    optimizer_owner::Any
 end
 function OnDevice(env::AbstractParallelEnv; seed::Integer = 42, device::Integer = 0)
-    w = OnDevice(env, UInt64(seed), Int(device), C_NULL, nothing)
+    w = OnDevice(env, UInt64(seed), Int(device), C_NULL, nothing, nothing)
     finalizer(e -> (e.handle != C_NULL && ccall((:dril_destroy, LIB[]), Int32, (Ptr{Cvoid},), e.handle); nothing), w)
     return w
 end
@@ -324,6 +446,7 @@ function make_config(w::OnDevice, alg::PPO, hidden::Vector{Int}, log_std_init::F
         uniform ? lo : 0.0f0, uniform ? hi : 0.0f0, ntuple(_ -> Int32(0), 1))
 end
 function bind_agent!(w::OnDevice, agent, alg::PPO)
+    check_supported_layer(agent)
     ps = agent.train_state.parameters
     ls = haskey(ps, :log_std) ? Float32(ps.log_std[1]) : 0.0f0
     key = (alg, hidden_dims_of(ps), ls)
@@ -331,7 +454,7 @@ function bind_agent!(w::OnDevice, agent, alg::PPO)
         w.handle != C_NULL && ccall((:dril_destroy, LIB[]), Int32, (Ptr{Cvoid},), w.handle)
         cfg = Ref(make_config(w, alg, key[2], ls)); h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:dril_create, LIB[]), Int32, (Ref{DrilConfig}, Ref{Ptr{Cvoid}}), cfg, h))
-        w.handle = h[]; w.bound = key
+        w.handle = h[]; w.bound = key; w.optimizer_owner = nothing
     end
     return w.handle
 end
@@ -376,43 +499,62 @@ function collect_rollout!(buf::RolloutBuffer, agent::Agent, alg::PPO, w::OnDevic
     return fps, true
 end
 
-function train!(agent::Agent, w::OnDevice, alg::PPO{T}, max_steps::Int; ad_type = nothing, callbacks = nothing) where {T}
-    has_step_hooks(callbacks) && return train!(agent, w.env, alg, max_steps; callbacks = callbacks)
+function train!(agent::PPOAgent, w::OnDevice, alg::PPO{T}, max_steps::Int; ad_type = nothing, callbacks = nothing) where {T}
+    if has_step_hooks(callbacks)                                       # on_step hooks: the reference's own loop on the wrapped env
+        kw = isnothing(ad_type) ? (; callbacks = callbacks) : (; ad_type = ad_type, callbacks = callbacks)
+        return train!(agent, w.env, alg, max_steps; kw...)
+    end
     to = TimerOutput()
-    E = number_of_envs(w)
+    n_steps = alg.n_steps; n_envs = number_of_envs(w)
+    local iterations, total_steps
     @timeit to "setup" begin
         bind_agent!(w, agent, alg); push_params!(w, agent)
-        iterations = max_steps ÷ (alg.n_steps * E)                     # ppo.jl:117
-        iterations == 0 && @warn "max_steps is less than n_steps * n_envs; there will be no training."
-    end
-    stats = NamedTuple{(:entropy_losses, :policy_losses, :value_losses, :approx_kl_divs, :clip_fractions, :losses,
-        :explained_variances, :fps, :grad_norms, :learning_rates)}(ntuple(_ -> Float32[], 10))
-    locals() = Dict{Symbol, Any}(:agent => agent, :env => w.env, :alg => alg, :max_steps => max_steps, :iterations => iterations)
-    !isnothing(callbacks) && !all(c -> DRiL.on_training_start(c, locals()), callbacks) && return nothing
-    @timeit to "training_loop" for i in 1:iterations
-        check(ccall((:dril_set_learning_rate, LIB[]), Int32, (Ptr{Cvoid}, Float32), w.handle, alg.learning_rate), w.handle)
-        push!(stats.learning_rates, alg.learning_rate)
-        !isnothing(callbacks) && !all(c -> DRiL.on_rollout_start(c, locals()), callbacks) && return nothing
-        fps = @timeit to "collect_rollout" device_rollout!(w, alg)
-        push!(stats.fps, fps); DRiL.add_step!(agent, alg.n_steps * E)
-        DRiL.increment_step!(agent.logger, alg.n_steps * E); DRiL.log_scalar!(agent.logger, "env/fps", fps)
-        DRiL.log_stats(w.env, agent.logger)
-        !isnothing(callbacks) && !all(c -> DRiL.on_rollout_end(c, locals()), callbacks) && return nothing
-        st = Ref{DrilPPOStats}()
-        @timeit to "epoch loop" check(ccall((:dril_ppo_update, LIB[]), Int32, (Ptr{Cvoid}, Ref{DrilPPOStats}), w.handle, st), w.handle)
-        s = st[]
-        push!(stats.entropy_losses, s.entropy_loss); push!(stats.policy_losses, s.policy_loss); push!(stats.value_losses, s.value_loss)
-        push!(stats.approx_kl_divs, s.approx_kl_div); push!(stats.clip_fractions, s.clip_fraction); push!(stats.losses, s.loss)
-        push!(stats.explained_variances, s.explained_variance); push!(stats.grad_norms, s.grad_norm)
-        for (k, v) in ("entropy_loss" => s.entropy_loss, "explained_variance" => s.explained_variance, "policy_loss" => s.policy_loss,
-            "value_loss" => s.value_loss, "approx_kl_div" => s.approx_kl_div, "clip_fraction" => s.clip_fraction, "loss" => s.loss,
-            "grad_norm" => s.grad_norm, "learning_rate" => alg.learning_rate)
-            DRiL.log_scalar!(agent.logger, "train/" * k, v)
+        if w.optimizer_owner !== agent.train_state
+            check(ccall((:dril_reset_optimizer, LIB[]), Int32, (Ptr{Cvoid},), w.handle), w.handle)
+            w.optimizer_owner = agent.train_state
         end
+        iterations = max_steps ÷ (n_steps * n_envs)                    # ppo.jl:117
+        iterations == 0 && @warn "max_steps is less than n_steps * n_envs; there will be no training."
+        total_steps = iterations * n_steps * n_envs
     end
-    pull_params!(w, agent)
-    !isnothing(callbacks) && !all(c -> DRiL.on_training_end(c, locals()), callbacks) && return nothing
-    return stats, to
+    learn_stats = NamedTuple{(:entropy_losses, :policy_losses, :value_losses, :approx_kl_divs, :clip_fractions, :losses,
+        :explained_variances, :fps, :grad_norms, :learning_rates)}(ntuple(_ -> Float32[], 10))
+    total_fps = learn_stats.fps; roll_buffer = DeviceRolloutBuffer(w)
+    i = 0; learning_rate = alg.learning_rate
+    locals() = Dict{Symbol, Any}(:agent => agent, :env => w.env, :alg => alg, :iterations => iterations, :total_steps => total_steps, :max_steps => max_steps,
+        :n_steps => n_steps, :n_envs => n_envs, :roll_buffer => roll_buffer, :total_fps => total_fps, :callbacks => callbacks, :learn_stats => learn_stats,
+        :i => i, :learning_rate => learning_rate, :to => to)
+    fire(f) = isnothing(callbacks) || all(c -> f(c, locals()), callbacks)
+    try
+        fire(DRiL.on_training_start) || return nothing
+        @timeit to "training_loop" for it in 1:iterations
+            i = it
+            check(ccall((:dril_set_learning_rate, LIB[]), Int32, (Ptr{Cvoid}, Float32), w.handle, learning_rate), w.handle)
+            push!(learn_stats.learning_rates, learning_rate)
+            fire(DRiL.on_rollout_start) || return nothing
+            fps = @timeit to "collect_rollout" device_rollout!(w, alg)
+            push!(total_fps, fps); DRiL.add_step!(agent, n_steps * n_envs)
+            DRiL.increment_step!(agent.logger, n_steps * n_envs); DRiL.log_scalar!(agent.logger, "env/fps", fps)
+            DRiL.log_stats(w.env, agent.logger)
+            fire(DRiL.on_rollout_end) || return nothing
+            st = Ref{DrilPPOStats}()
+            @timeit to "epoch loop" check(ccall((:dril_ppo_update, LIB[]), Int32, (Ptr{Cvoid}, Ref{DrilPPOStats}), w.handle, st), w.handle)
+            s = st[]
+            DRiL.add_gradient_update!(agent, Int(s.n_updates))
+            push!(learn_stats.entropy_losses, s.entropy_loss); push!(learn_stats.policy_losses, s.policy_loss); push!(learn_stats.value_losses, s.value_loss)
+            push!(learn_stats.approx_kl_divs, s.approx_kl_div); push!(learn_stats.clip_fractions, s.clip_fraction); push!(learn_stats.losses, s.loss)
+            push!(learn_stats.explained_variances, s.explained_variance); push!(learn_stats.grad_norms, s.grad_norm)
+            for (k, v) in ("entropy_loss" => s.entropy_loss, "explained_variance" => s.explained_variance, "policy_loss" => s.policy_loss,
+                "value_loss" => s.value_loss, "approx_kl_div" => s.approx_kl_div, "clip_fraction" => s.clip_fraction, "loss" => s.loss,
+                "grad_norm" => s.grad_norm, "learning_rate" => learning_rate)
+                DRiL.log_scalar!(agent.logger, "train/" * k, v)
+            end
+        end
+        fire(DRiL.on_training_end) || return nothing
+        return learn_stats, to
+    finally
+        pull_params!(w, agent)                                          # every exit path: the agent holds the weights trained so far (ppo.jl:239)
+    end
 end
 
 # ---- normalisation statistics in the reference's JLD2 schema (normalizeWrapperEnv.jl:261-297) ----
@@ -538,8 +680,12 @@ end
 Same contract as `train!(agent, replay_buffer, env, alg::SAC, max_steps)` (sac.jl:414-549) with the ReplayBuffer resident on the device
 (second return value `nothing`; read it through `dril_sac_replay_copy_out`).  Callbacks with `on_step` hooks are not supported on this path.
 """
-function train!(agent::Agent, env::DeviceParallelEnv, alg::DRiL.SAC{T}, max_steps::Int; ad_type = nothing, callbacks = nothing) where {T}
-    has_step_hooks(callbacks) && error("on_step callbacks need the step-granular path: use DRiL's generic train! on the env verbs")
+function train!(agent::SACAgent, env::DeviceParallelEnv, alg::DRiL.SAC, max_steps::Int; ad_type = nothing, callbacks = nothing)
+    T = typeof(alg.learning_rate)
+    if has_step_hooks(callbacks)      # on_step hooks: the reference's own train! over this env's step-granular verbs
+        kw = isnothing(ad_type) ? (; callbacks = callbacks) : (; ad_type = ad_type, callbacks = callbacks)
+        return invoke(train!, Tuple{SACAgent, AbstractParallelEnv, DRiL.SAC, Int}, agent, env, alg, max_steps; kw...)
+    end
     to = TimerOutput()
     cfg = Ref(sac_config(env, alg, agent)); hp = Ref{Ptr{Cvoid}}(C_NULL)
     sac_check(ccall((:dril_sac_create, LIB[]), Int32, (Ref{DrilSacConfig}, Ref{Ptr{Cvoid}}), cfg, hp)); h = hp[]
@@ -605,8 +751,12 @@ function sac_config(w::OnDevice, alg::DRiL.SAC, agent)
         Int32(prod(size(osp))), Int32(prod(size(asp))), lo, hi, ntuple(_ -> Int32(0), 4))
 end
 
-function train!(agent::Agent, w::OnDevice, alg::DRiL.SAC{T}, max_steps::Int; ad_type = nothing, callbacks = nothing) where {T}
-    has_step_hooks(callbacks) && error("on_step callbacks need the reference loop: call train! on the wrapped env")
+function train!(agent::SACAgent, w::OnDevice, alg::DRiL.SAC, max_steps::Int; ad_type = nothing, callbacks = nothing)
+    T = typeof(alg.learning_rate)
+    if has_step_hooks(callbacks)      # on_step hooks: the reference's own loop on the wrapped env
+        kw = isnothing(ad_type) ? (; callbacks = callbacks) : (; ad_type = ad_type, callbacks = callbacks)
+        return train!(agent, w.env, alg, max_steps; kw...)
+    end
     to = TimerOutput()
     cfg = Ref(sac_config(w, alg, agent)); hp = Ref{Ptr{Cvoid}}(C_NULL)
     sac_check(ccall((:dril_sac_create, LIB[]), Int32, (Ref{DrilSacConfig}, Ref{Ptr{Cvoid}}), cfg, hp)); h = hp[]

@@ -1,0 +1,48 @@
+"""CPU: static checks of the Julia shim (tools/check_shim.py) — the image has no Julia, so dispatch specificity, the callback-locals keys and the
+ccall surface are verified by parsing DRiLHIP.jl against the reference's sources (when present) and include/*.h."""
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+TOOL = ROOT / "tools" / "check_shim.py"
+SHIM = ROOT / "dril.jl_amd" / "julia" / "DRiLHIP.jl"
+
+
+def _run(*args):
+    return subprocess.run([sys.executable, str(TOOL), *args], capture_output=True, text=True)
+
+
+def test_shim_passes_static_checks():
+    r = _run()
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "check_shim: ok" in r.stdout
+
+
+def test_checker_catches_the_round1_ambiguity(tmp_path):
+    """round 1 declared `train!(agent::Agent, env::DeviceParallelEnv, ...)`: wider than the reference in argument 1, narrower in argument 2"""
+    if not Path("/root/reference/src").exists():
+        import pytest
+        pytest.skip("needs the reference sources")
+    bad = tmp_path / "DRiLHIP.jl"
+    text = SHIM.read_text()
+    assert "function train!(agent::PPOAgent, env::DeviceParallelEnv" in text
+    bad.write_text(text.replace("function train!(agent::PPOAgent, env::DeviceParallelEnv", "function train!(agent::Agent, env::DeviceParallelEnv"))
+    r = _run("--shim", str(bad))
+    assert r.returncode == 1 and "AMBIGUOUS" in r.stdout, r.stdout
+
+
+def test_checker_catches_a_missing_locals_key(tmp_path):
+    bad = tmp_path / "DRiLHIP.jl"
+    bad.write_text(SHIM.read_text().replace(":roll_buffer, :total_fps, :callbacks, :learn_stats)", ":total_fps, :callbacks, :learn_stats)"))
+    r = _run("--shim", str(bad))
+    assert r.returncode == 1 and "TRAINING_START_LOCALS" in r.stdout, r.stdout
+
+
+def test_locals_lists_match_the_python_mirror(pkg):
+    import re
+    text = SHIM.read_text()
+    keys = lambda name: tuple(re.findall(r":(\w+)", re.search(r"const " + name + r"\s*=\s*\(([^)]*)\)", text).group(1)))
+    assert keys("TRAINING_START_LOCALS") == pkg.TRAINING_START_LOCALS and keys("ROLLOUT_START_LOCALS") == pkg.ROLLOUT_START_LOCALS
+    sections = tuple(re.findall(r'"([^"]+)"', re.search(r"const TIMER_SECTIONS\s*=\s*\(([^)]*)\)", text).group(1)))
+    assert sections == pkg.TIMER_SECTIONS
