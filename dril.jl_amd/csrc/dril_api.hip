@@ -117,7 +117,7 @@ struct dril_handle {
     double* rms_red = nullptr;   // data-parallel: this step's partial sums folded to one row and summed over ranks
     int grad_stagger = 0;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
-    int grad_variant = 2;   // hidden [64,64]: 0 = f32-MFMA ppo_grad_kernel, 1 = ppo_grad_split_kernel (bf16 x 3 operand splitting, one workgroup per CU), 2 = the same with two tiles in flight per wave (env DRIL_GRAD_VARIANT)
+    int grad_variant = -1;  // hidden [64,64]: 0 = f32-MFMA ppo_grad_kernel, 1 = ppo_grad_split_kernel (bf16 x 3 operand splitting, one workgroup per CU), -1 = by minibatch size (env DRIL_GRAD_VARIANT)
     bool external = false; bool generic = false; float* gen_tmp = nullptr;   // generic: layer-by-layer kernels (host envs, or a device env whose hidden_dims the fused kernels are not built for)
     GenericDims gd{}; GenericWs gws; int ext_t = 0; bool ext_acted = false;   // DRIL_ENV_EXTERNAL: host envs, generic kernels
     float* ext_stage_rew = nullptr; uint8_t* ext_stage_flags = nullptr;   // pinned [T][E] staging: dril_ext_record returns without draining the stream
@@ -319,6 +319,13 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     const bool reduce = world > 1 || (comm_ready(h) && h->force_allreduce);   // force: exercise the RCCL path on one rank (tests)
     const int64_t tiles = (count + kTile - 1) / kTile;
     int G = h->wide ? (int)(tiles < h->Gmax ? tiles : h->Gmax) : (int)((tiles + 3) / 4); if (G > h->Gmax) G = h->Gmax; if (G < 1) G = 1;
+    // hidden [64,64]: large minibatches run the bf16-split kernel (one 4-wave workgroup per CU: G actor + G critic workgroups fill the chip once); small ones keep
+    // the f32 kernel, whose weight staging is cheaper (no operand split per workgroup) and which the launch-bound small path is tuned for
+    int variant = 0;
+    if (!h->wide && !h->generic) {
+        variant = h->grad_variant >= 0 ? h->grad_variant : (tiles >= 16 * (int64_t)h->num_cus ? 1 : 0);
+        if (variant == 1) { const int gm = h->num_cus / 2 > 0 ? h->num_cus / 2 : 1; if (G > gm) G = gm; }
+    }
     if (h->generic) { G = generic_pick_slabs(h->gd, count, h->Gmax); if (G < 1) return fail(h, DRIL_ERR_UNSUPPORTED, "minibatch too large for the generic path's workspace"); }
     { int rcw = ensure_wimg(h); if (rcw) return rcw; }
     const double* adv_stats = h->adv_stats;
@@ -345,7 +352,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     g.clip_range = h->cfg.clip_range; g.ent_coef = h->cfg.ent_coef; g.vf_coef = h->cfg.vf_coef; g.clip_range_vf = h->cfg.clip_range_vf;
     g.has_clip_vf = h->cfg.has_clip_range_vf; g.normalize_adv = h->cfg.normalize_advantage; g.action_start = h->cfg.action_start;
     g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
-    g.G = G; g.dbg = h->dbg; g.layout = h->grad_layout; g.variant = h->grad_variant; g.stagger = h->grad_stagger; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
+    g.G = G; g.dbg = h->dbg; g.layout = h->grad_layout; g.variant = variant; g.stagger = h->grad_stagger; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
     prof_begin(h, DRIL_K_PPO_GRAD);
     if (h->generic) HIPCHK(h, generic_ppo_grad(h->gd, g, h->gws, h->stream));
     else HIPCHK(h, launch_ppo_grad(h->cfg.env_kind, h->cfg.hidden1, g, h->stream));
@@ -475,7 +482,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (const char* e = std::getenv("DRIL_GRAD_PRIO")) h->grad_prio = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_STAGGER")) h->grad_stagger = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_SPLIT")) h->grad_split = std::atoi(e);
-    if (const char* e = std::getenv("DRIL_GRAD_VARIANT")) { h->grad_variant = std::atoi(e); if (h->grad_variant < 0 || h->grad_variant > 3) h->grad_variant = 0; }
+    if (const char* e = std::getenv("DRIL_GRAD_VARIANT")) { h->grad_variant = std::atoi(e); if (h->grad_variant < -1 || h->grad_variant > 1) h->grad_variant = -1; }
     h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
     CCHK(hipSetDevice(cfg->device));
@@ -491,7 +498,6 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     else { h->slab_a = slab_size_actor(cfg->env_kind, cfg->hidden1); h->slab_c = slab_size_critic(cfg->env_kind, cfg->hidden1); }
     h->wide = !h->generic && cfg->hidden1 > 64;
     h->Gmax = (h->wide && cfg->hidden1 > 128) ? (h->num_cus / 2 > 0 ? h->num_cus / 2 : 1) : h->num_cus;   // H = 128: 4 waves and 77 KB LDS per workgroup, two workgroups per CU   // [64,64]: 2 workgroups per CU (actor + critic), 4 waves each; wide: 1 workgroup of H/32 waves per CU
-    if (!h->generic && !h->wide && (h->grad_variant == 1 || h->grad_variant == 2)) h->Gmax = h->num_cus / 2 > 0 ? h->num_cus / 2 : 1;   // one 4-wave workgroup per CU (<= 512 registers per wave): G actor + G critic workgroups fill the chip once
     if (h->generic) { h->Gmax = std::getenv("DRIL_EXT_GMAX") ? std::atoi(std::getenv("DRIL_EXT_GMAX")) : 64; if (h->Gmax < 1) h->Gmax = 1; }                                                        // generic path: one slab per row chunk of the minibatch
     if (const char* e = std::getenv("DRIL_GRAD_GMAX")) { const int g = std::atoi(e); if (g > 0 && g < h->Gmax) h->Gmax = g; }   // diagnostic: fewer workgroups per net
     if (h->wide) { const size_t hh = (size_t)cfg->hidden1 * cfg->hidden1; CCHK(dmalloc(&h->w2a_actor, hh)); CCHK(dmalloc(&h->w2ta_actor, hh)); CCHK(dmalloc(&h->w2a_critic, hh)); CCHK(dmalloc(&h->w2ta_critic, hh)); }

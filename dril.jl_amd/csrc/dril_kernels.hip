@@ -1237,7 +1237,8 @@ template <int D, int H, int O> struct NetLdsSplit {
 };
 template <int D, int H, int O> struct GradScratchSplit {
     static constexpr int T = 0;                              // 12288 bytes: three [32][64] bf16 piece images, or one [H][kTS] f32 image
-    static constexpr int XI = T + 3 * 32 * H / 2;
+    static constexpr int T2 = T + 3 * 32 * H / 2;            // the dz1 f32 image has a place of its own: dW1 (f32 MFMA on the VALU's lanes) runs beside dW2 (matrix pipe)
+    static constexpr int XI = T2 + H * kTS;
     static constexpr int ZI = XI + (D + 2) * kTS;
     static constexpr int SIZE = ZI + O * kTS;
     static_assert(H * kTS <= 3 * 32 * H / 2, "the f32 image must fit the piece images' space");
@@ -1297,20 +1298,20 @@ __device__ __forceinline__ bf16x8 load_frag_T(const char* T, int rbase, int piec
     return frag8(lds_read_tr16(T, a), lds_read_tr16(T, a ^ (512 | 32)));
 }
 
-// ---- the tile loop as six stages, so that two tiles can be in flight in one wave (PIPE) ------------------------------------------------------------------
+// ---- the tile loop as six stages --------------------------------------------------------------------------------------------------------------------------
 // S1 (VALU)  unpack, L1 (f32 MFMA, 4), tanh, split h1                     S4 (matrix) dh1 (48 bf16 MFMA), tanh' mask -> dz1
 // S2 (matrix) L2 (48 bf16 MFMA), tanh, h2 image                            S5 (matrix) h1' fragments, dz2' images, dW2 (48 bf16 MFMA)
 // S3 (VALU)  L3, loss head, dW3 / S, h1' images, dz2, split dz2            S6 (VALU lanes) dz1 image, dW1 | db1 (f32 16x16x4 MFMA, 32)
-// With ONE wave per SIMD (the register budget of this kernel) nothing else hides a stage's latency, and a lone wave issues a VALU instruction only every
-// 4 cycles; the pipelined loop keeps tile B one stage behind tile A, so that every scheduling region pairs a matrix-pipe stage of one tile with a VALU
-// stage of the other (A.S2|B.S1, A.S3|B.S2, A.S4|B.S3, A.S5|B.S4, A.S6|B.S5, B.S6|A'.S1); both tiles add into the same accumulators.
+// Register budget: ONE wave per SIMD (400 registers, no spills).  Every form with two waves per SIMD or two tiles in flight per wave spills, and a scratch
+// reload's s_waitcnt vmcnt waits behind the prefetched minibatch gather (vmcnt retires in order): measured 73 - 107 TFLOP/s against 118 for this one
+// (profiles/r02_split_kernel.md).
 template <int MT, int O> struct TileCtx {
     TileIn<O> cur, nxt;
     float xk[2]; bool valid;
     f32x16 h1[MT], h2[MT], g1[MT];
     Pieces<MT> P1, P2;
     float dz[O];
-    float* T; char* Tb; float* XI; float* ZI;
+    float* T; char* Tb; float* T2; float* XI; float* ZI;
 };
 template <int H, int O> struct SplitAcc {
     static constexpr int MT = H / 32;
@@ -1444,7 +1445,7 @@ struct SplitStages {
             }
     }
     static __device__ __forceinline__ void s6(const SplitEnv& e, Ctx& t, Acc& A) {   // dW1 | db1 += dz1 * [x; 1]' (f32, v_mfma_f32_16x16x4_f32: K = 4 samples per step)
-        store_image<MT>(t.T, t.g1, e.lane);
+        store_image<MT>(t.T2, t.g1, e.lane);
 #pragma unroll
         for (int s = 0; s < 2; ++s) { const int d = 2 * s + e.h; t.XI[(d < D ? d : D + 1) * kTS + e.c] = d < D ? t.xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
         const int j = e.lane & 15;
@@ -1453,16 +1454,16 @@ struct SplitStages {
 #pragma unroll
         for (int mt = 0; mt < H / 16; ++mt) {
             float az[8];
-            load_row8(t.T, 16 * mt + j, e.lane, az);
+            load_row8(t.T2, 16 * mt + j, e.lane, az);
 #pragma unroll
             for (int k = 0; k < 8; ++k) A.dW1[mt] = mfma16(az[k], bx[k], A.dW1[mt]);
         }
     }
 };
 
-template <int KIND, int H, int O, int HEAD, bool REC, bool PIPE>
+template <int KIND, int H, int O, int HEAD, bool REC>
 __device__ __forceinline__ void grad_body_split(const GradArgs& a, float* smem) {
-    constexpr int D = EnvSpec<KIND>::D, MT = H / 32, NCTX = PIPE ? 2 : 1;
+    constexpr int D = EnvSpec<KIND>::D, MT = H / 32, NCTX = 1;
     using L = NetLdsSplit<D, H, O>;
     using SC = GradScratchSplit<D, H, O>;
     using ST = SplitStages<KIND, H, O, HEAD, REC>;
@@ -1539,8 +1540,8 @@ __device__ __forceinline__ void grad_body_split(const GradArgs& a, float* smem) 
     const int64_t ntiles = (a.count + kTile - 1) / kTile;
     const int64_t tstride = (int64_t)a.G * 4, first = (int64_t)g * 4 + wave;
     typename ST::Ctx ta;
-    ta.T = scratch + SC::T; ta.Tb = reinterpret_cast<char*>(ta.T); ta.XI = scratch + SC::XI; ta.ZI = scratch + SC::ZI;
-    if (!PIPE) {
+    ta.T = scratch + SC::T; ta.Tb = reinterpret_cast<char*>(ta.T); ta.T2 = scratch + SC::T2; ta.XI = scratch + SC::XI; ta.ZI = scratch + SC::ZI;
+    {
         int64_t tile = first;
         load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, ta.nxt);       // a tile index past the end loads an all-invalid tile
         for (; tile < ntiles; tile += tstride) {
@@ -1548,26 +1549,7 @@ __device__ __forceinline__ void grad_body_split(const GradArgs& a, float* smem) 
             ST::s2(e, ta); __builtin_amdgcn_sched_barrier(0);
             ST::s3(a, e, ta, A); __builtin_amdgcn_sched_barrier(0);
             ST::s4(e, ta); __builtin_amdgcn_sched_barrier(0);
-            ST::s5(e, ta, A); __builtin_amdgcn_sched_barrier(0);
-            ST::s6(e, ta, A); __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-        typename ST::Ctx tb;
-        tb.T = scratch + SC::SIZE + SC::T; tb.Tb = reinterpret_cast<char*>(tb.T); tb.XI = scratch + SC::SIZE + SC::XI; tb.ZI = scratch + SC::SIZE + SC::ZI;
-        // tiles first, first + stride, ... alternate between the two contexts; a context whose tile index is past the end works on an all-invalid tile
-        // (every contribution is exactly zero), so the last pair needs no special case
-        int64_t tile = first;
-        load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, ta.nxt);
-        load_tile<KIND, O, HEAD, REC>(a, tile + tstride, ntiles, c, h, tb.nxt);
-        if (tile < ntiles) ST::s1(a, e, ta, tile + 2 * tstride, ntiles);
-        for (; tile < ntiles; tile += 2 * tstride) {
-            __builtin_amdgcn_sched_barrier(0);
-            ST::s2(e, ta); ST::s1(a, e, tb, tile + 3 * tstride, ntiles); __builtin_amdgcn_sched_barrier(0);
-            ST::s3(a, e, ta, A); ST::s2(e, tb); __builtin_amdgcn_sched_barrier(0);
-            ST::s4(e, ta); ST::s3(a, e, tb, A); __builtin_amdgcn_sched_barrier(0);
-            ST::s5(e, ta, A); ST::s4(e, tb); __builtin_amdgcn_sched_barrier(0);
-            ST::s6(e, ta, A); ST::s5(e, tb, A); __builtin_amdgcn_sched_barrier(0);
-            ST::s6(e, tb, A); ST::s1(a, e, ta, tile + 4 * tstride, ntiles);     // the next pair's first stage (an all-invalid tile after the last pair)
+            ST::s5(e, ta, A); ST::s6(e, ta, A); __builtin_amdgcn_sched_barrier(0);    // one region: the f32 MFMAs of dW1 fill the VALU lanes under dW2's matrix-pipe chain
         }
     }
 
@@ -1624,349 +1606,15 @@ __device__ __forceinline__ void grad_body_split(const GradArgs& a, float* smem) 
     for (int i = tid; i < SL; i += blockDim.x) slab[i] = red[i];
 }
 
-// one 4-wave workgroup per CU (<= 512 registers per wave); PIPE: two tiles in flight per wave
-template <int KIND, int H, bool REC, bool PIPE>
+// one 4-wave workgroup per CU (<= 512 registers per wave)
+template <int KIND, int H, bool REC>
 __global__ __launch_bounds__(256, 1) void ppo_grad_split_kernel(GradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (*a.stop_flag) return;
     constexpr int A = EnvSpec<KIND>::A;
     const bool actor = a.layout ? (blockIdx.x < (unsigned)a.G) : ((blockIdx.x & 1) == 0);
-    if (actor) grad_body_split<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN, REC, PIPE>(a, smem);
-    else grad_body_split<KIND, H, 1, HEAD_VALUE, REC, PIPE>(a, smem);
-}
-
-template <int KIND, int H, int O, int HEAD, bool REC>
-__device__ __forceinline__ void grad_body_hybrid(const GradArgs& a, float* smem) {
-    constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
-    using L = NetLdsSplit<D, H, O>;
-    using SC = GradScratch<D, H, O>;
-    const int tid = threadIdx.x, lane = tid & 63;
-    // threadIdx.x / 64 IS wave-uniform but hipcc cannot prove it: readfirstlane moves the wave id - and every tile index,
-    // LDS base and loop bound derived from it - into SGPRs (v3 spilled those to scratch, and each scratch reload's
-    // s_waitcnt vmcnt(0) drained the prefetched gathers: profiles/r01 stamps, "out+head" 7.0k cycles)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
-    float* wl = smem;
-    const char* Wimg = reinterpret_cast<const char*>(smem + L::W2P);
-    float* T = smem + L::END + wave * SC::SIZE + SC::T;
-    float* XI = smem + L::END + wave * SC::SIZE + SC::XI;
-    float* ZI = smem + L::END + wave * SC::SIZE + SC::ZI;
-    stage_net_split<D, H, O>(wl, a.params, off, tid, blockDim.x);
-    for (int i = lane; i < (D + 2) * kTS; i += 64) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
-    __syncthreads();
-
-    // advantage normalisation constants (ppo.jl:350-356): mean, corrected std, eps added to the std
-    float adv_mean = 0.f, adv_den = 1.f;
-    if (HEAD != HEAD_VALUE && a.normalize_adv) {
-        double s, q, n;
-        if (a.inline_moments) {
-            // small minibatch: sum A and A^2 of the whole minibatch here (same index map as load_tile), fixed-order tree => every workgroup gets the same bits
-            double* shd = reinterpret_cast<double*>(smem + ((L::END + 1) & ~1));      // per-wave scratch, not yet in use
-            double ls_ = 0, lq_ = 0;
-            for (int64_t i2 = tid; i2 < a.count; i2 += blockDim.x) {
-                const int64_t p2 = a.pos0 + i2;
-                const int64_t gi = a.perm ? a.perm[p2] : (a.perm_bits ? perm_index(p2, a.N, a.perm_key, a.perm_bits) : p2);
-                const int64_t li2 = gi - a.idx_lo;
-                if (li2 >= 0 && li2 < a.n_local) { const float v = REC ? a.rec[2 * li2 + 1].y : a.adv[li2]; ls_ += v; lq_ += (double)v * v; }
-            }
-            shd[tid] = ls_; shd[256 + tid] = lq_;
-            __syncthreads();
-            for (int st_ = 128; st_ > 0; st_ >>= 1) { if (tid < st_) { shd[tid] += shd[tid + st_]; shd[256 + tid] += shd[256 + tid + st_]; } __syncthreads(); }
-            s = shd[0]; q = shd[256]; n = (double)a.count;
-            __syncthreads();
-        } else { s = a.adv_stats[0]; q = a.adv_stats[1]; n = a.adv_stats[2]; }
-        const double mean = s / n;
-        double var = (q - s * mean) / (n - 1.0);
-        if (var < 0) var = 0;
-        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
-    }
-    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
-    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
-    constexpr bool LS_GAUSS = HEAD == HEAD_GAUSSIAN; constexpr int LS_N = O;
-    // log_std hoisted into scalar registers: a per-tile global load would sit in the in-order vmcnt queue between the prefetched
-    // gathers and their first use and drain them every tile (Pendulum [64,64]: 91 -> TFLOP/s below)
-    float lsr[kLsMax];
-#pragma unroll
-    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
-    if (LS_GAUSS) {
-#pragma unroll
-        for (int o = 0; o < LS_N; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
-    }
-    const float* ls = lsr;
-    const int wf_base = c * 128 + (((h ^ w2img_gw(c)) & 15) << 3);                          // W2 row read (ppo_grad_split_kernel's weight image)
-    const int e16 = lane & 15, tq = e16 >> 2, tp = e16 & 3, tg = (lane >> 4) & 1;
-    const int wt_base = (4 * h + tq) * 128 + ((((4 * tg + tp) ^ (8 * (tq >> 1) + 4 * h)) & 15) << 3);   // W2' transposed read
-    constexpr float kInvTanhScale = 1.0f / kTanhScale;
-
-    f32x16 dW2[MT][MT];
-    f32x4 dW1[H / 16];                                             // 16x16x4 tiles: rows = hidden, cols = [x | 1 | 0...]
-    float dW3a[O][MT], db2p[MT], db3p[O], dlsp[O], st[5];
-#pragma unroll
-    for (int i = 0; i < H / 16; ++i) dW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        db2p[i] = 0.f;
-#pragma unroll
-        for (int j = 0; j < MT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dW2[i][j][r] = 0.f;
-    }
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-        db3p[o] = 0.f; dlsp[o] = 0.f;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) dW3a[o][m] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) st[i] = 0.f;
-
-    const int g = a.layout ? (int)(blockIdx.x % a.G) : (int)(blockIdx.x >> 1);
-    const int64_t ntiles_all = (a.count + kTile - 1) / kTile;
-    // static priority experiment: co-resident workgroups (g of the actor, g of the critic) get opposite priorities;
-    // the high-priority half of each net takes split_pct % of the tiles (deterministic partition)
-    int64_t tile0 = 0, ntiles = ntiles_all, tstride = (int64_t)a.G * 4, first = (int64_t)g * 4 + wave;
-    if (a.prio == 2) { if (HEAD == HEAD_VALUE) __builtin_amdgcn_s_setprio(1); }          // younger (second-dispatched) workgroups only
-    else if (a.prio == 3) { if (HEAD != HEAD_VALUE) __builtin_amdgcn_s_setprio(1); }
-    else if (a.prio && a.G >= 2 && (a.G & 1) == 0) {
-        const bool hi = ((g & 1) == 0) == (HEAD != HEAD_VALUE);
-        const int64_t nh = ntiles_all * a.split_pct / 100;
-        tile0 = hi ? 0 : nh; ntiles = hi ? nh : ntiles_all;
-        tstride = (int64_t)(a.G / 2) * 4; first = tile0 + (int64_t)(g >> 1) * 4 + wave;
-        if (hi) __builtin_amdgcn_s_setprio(1);
-    }
-    TileIn<O> cur, nxt;
-    int64_t tile = first;
-    if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
-    if (HEAD == HEAD_VALUE && a.stagger > 0) {                      // start the critic workgroups out of phase with their co-resident actor workgroups
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);      // 127 * 64 clocks each
-    }
-#ifdef DRIL_STAMPS
-    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
-#endif
-    for (; tile < ntiles; tile += tstride) {
-        load_tile<KIND, O, HEAD, REC>(a, tile + tstride, ntiles, c, h, nxt);      // prefetch the next tile's gathers
-        unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
-        const bool valid = cur.valid;
-        float xk[2] = {cur.xk[0], cur.xk[1]};
-        STAMP(0);
-        // ---- forward ----
-        f32x16 h1[MT], h2[MT];
-        float out[O], dz[O];
-        dense_first<H, MT>(wl + L::W1T, wl + L::B1, xk, h1, lane);
-        tanh_tiles(h1);
-        STAMP(1);
-        {   // L2 on the bf16 matrix cores: B = the packed pieces of h1 straight from its accumulator registers, A = row reads of the weight image
-            Pieces<MT> P1;
-            split_tiles<MT>(h1, P1);
-#pragma unroll
-            for (int mo = 0; mo < MT; ++mo) {
-                f32x16 acc;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B2 + 32 * mo + 8 * q + 4 * h);
-                    acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
-                }
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const int a0 = (wf_base ^ (64 * mi + 32 * s)) + 4096 * mo;
-                        bf16x8 A[3];
-#pragma unroll
-                        for (int pc = 0; pc < 3; ++pc)
-                            A[pc] = frag8(*reinterpret_cast<const u32x2*>(Wimg + 8192 * pc + a0), *reinterpret_cast<const u32x2*>(Wimg + 8192 * pc + (a0 ^ 16)));
-                        acc = mfma_split6(A[0], A[1], A[2], piece_frag<MT>(P1, 0, mi, s), piece_frag<MT>(P1, 1, mi, s), piece_frag<MT>(P1, 2, mi, s), acc);
-                    }
-                tanh16(acc);
-                h2[mo] = acc;
-            }
-        }
-        store_image<MT>(T, h2, lane);          // early: the LDS write -> read round trip hides under the head below
-        STAMP(2);
-        dense_out<MT, O, H>(wl + L::W3S, wl + L::B3, h2, out, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- loss head (ppo.jl:377-404) and dLoss/dout ----
-        loss_head<O, HEAD>(a, cur, out, valid, h == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
-        STAMP(3);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- output layer backward: dW3 += dz * h2' over samples (h2 read back transposed: hidden on the lane) ----
-#pragma unroll
-        for (int o = 0; o < O; ++o) { if (h == 0) { db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
-        {
-            f32x16 Bh2[MT];
-#pragma unroll
-            for (int mj = 0; mj < MT; ++mj) Bh2[mj] = load_operand(T, mj, lane);
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                float acc[MT];
-#pragma unroll
-                for (int mj = 0; mj < MT; ++mj) acc[mj] = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 z = *reinterpret_cast<const f32x4*>(ZI + o * kTS + 16 * h + 4 * q);   // broadcast within the half-wave
-#pragma unroll
-                    for (int mj = 0; mj < MT; ++mj) {
-                        acc[mj] = fmaf(Bh2[mj][4 * q + 0], z[0], acc[mj]); acc[mj] = fmaf(Bh2[mj][4 * q + 1], z[1], acc[mj]);
-                        acc[mj] = fmaf(Bh2[mj][4 * q + 2], z[2], acc[mj]); acc[mj] = fmaf(Bh2[mj][4 * q + 3], z[3], acc[mj]);
-                    }
-                }
-#pragma unroll
-                for (int mj = 0; mj < MT; ++mj) dW3a[o][mj] += acc[mj];
-            }
-        }
-        STAMP(4);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- dz2 = (W3' dz) .* (1 - h2^2), in h2's registers ----
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float dh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int o = 0; o < O; ++o) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * m + 8 * q + 4 * h);
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(w[cc], dz[o], dh[cc]);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { const float hv = h2[m][4 * q + cc]; h2[m][4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
-            }
-        STAMP(5);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- h1 image (the LDS unit executes a wave's accesses in order, so the Bh2 reads above precede these writes) ----
-        store_image<MT>(T, h1, lane);
-        // ---- dh1 = W2' dz2 ; dz1 = dh1 .* (1 - h1^2) ----
-        f32x16 g1[MT];
-        {   // dh1 on the bf16 matrix cores: B = the packed pieces of dz2, A = transposed reads of the same weight image (staged x kTanhScale: undone in the mask)
-            Pieces<MT> P2;
-            split_tiles<MT>(h2, P2);
-#pragma unroll
-            for (int mk = 0; mk < MT; ++mk) {
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const int a0 = (wt_base ^ (64 * mk + 2048 * s + 8 * s)) + 4096 * mi;
-                        bf16x8 A[3];
-#pragma unroll
-                        for (int pc = 0; pc < 3; ++pc) A[pc] = frag8(lds_read_tr16(Wimg, 8192 * pc + a0), lds_read_tr16(Wimg, 8192 * pc + (a0 ^ (1024 | 16))));
-                        acc = mfma_split6(A[0], A[1], A[2], piece_frag<MT>(P2, 0, mi, s), piece_frag<MT>(P2, 1, mi, s), piece_frag<MT>(P2, 2, mi, s), acc);
-                    }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { const float t2 = h1[mk][r] * h1[mk][r]; g1[mk][r] = acc[r] * fmaf(-t2, kInvTanhScale, kInvTanhScale); }
-            }
-        }
-        STAMP(6);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- dW2 += dz2 * h1' ; db2 += rowsum(dz2) ----
-        {
-            f32x16 Bh[MT];
-#pragma unroll
-            for (int mj = 0; mj < MT; ++mj) Bh[mj] = load_operand(T, mj, lane);
-            store_image<MT>(T, h2, lane);                                      // dz2 image
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const f32x16 Az = load_operand(T, mi, lane);
-                db2p[mi] += sum16(Az);
-#pragma unroll
-                for (int mj = 0; mj < MT; ++mj) dW2[mi][mj] = mfma_outer(Az, Bh[mj], dW2[mi][mj]);
-            }
-        }
-        STAMP(7);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- dW1 | db1 += dz1 * [x; 1]' ----
-        store_image<MT>(T, g1, lane);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
-        {   // v_mfma_f32_16x16x4_f32: M = 16 hidden rows, N = 16 columns [x_0..x_{D-1}, 1, 0...], K = 4 samples per step
-            const int j = lane & 15;
-            float bx[8];
-            load_row8(XI, j <= D ? j : D + 1, lane, bx);
-#pragma unroll
-            for (int mt = 0; mt < H / 16; ++mt) {
-                float az[8];
-                load_row8(T, 16 * mt + j, lane, az);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) dW1[mt] = mfma16(az[k], bx[k], dW1[mt]);
-            }
-        }
-        STAMP(8);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-    }
-#ifdef DRIL_STAMPS
-    if (lane == 0 && a.dbg) {
-        unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
-        for (int k = 0; k < 10; ++k) o[k] = stamp_acc[k];
-        o[10] = (unsigned long long)((ntiles - first + tstride - 1) / tstride); o[11] = HEAD;
-    }
-#endif
-
-    // ---- epilogue: 4 waves -> one slab (fixed wave order => deterministic) ----
-    __syncthreads();
-    float* red = smem + L::END;
-    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
-    const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
-    const int o_ls = o_b3 + O, o_st = SL - 8;
-    for (int i = tid; i < SL; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * mi + rowfn(r, h);
-#pragma unroll
-                    for (int mj = 0; mj < MT; ++mj) red[o_w2 + row + (32 * mj + c) * H] += dW2[mi][mj][r];
-                }
-                const float b2 = db2p[mi] + __shfl_xor(db2p[mi], 32);
-                if (h == 0) red[o_b2 + 32 * mi + c] += b2;
-            }
-#pragma unroll
-            for (int mt = 0; mt < H / 16; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * mt + 4 * (lane >> 4) + r, col = lane & 15;
-                    if (col < D) red[o_w1 + row + col * H] += dW1[mt][r];
-                    else if (col == D) red[o_b1 + row] += dW1[mt][r];
-                }
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float v = dW3a[o][m] + __shfl_xor(dW3a[o][m], 32);      // the two halves hold different samples
-                    if (h == 0) red[o_w3 + o + (32 * m + c) * O] += v;
-                }
-                const float b3 = half_sum(db3p[o]);
-                if (lane == 0) red[o_b3 + o] += b3;
-                if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (lane == 0) red[o_ls + o] += l; }
-            }
-#pragma unroll
-            for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (lane == 0) red[o_st + k] += v; }
-        }
-        __syncthreads();
-    }
-    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
-    for (int i = tid; i < SL; i += blockDim.x) slab[i] = red[i];
-}
-
-// ppo_grad_hybrid_kernel — ppo_grad_kernel's structure (an actor and a critic workgroup per CU, 2 waves per SIMD, f32 transposes and f32-MFMA weight gradients)
-// with the two contractions that read W2 — L2 forward and dh1 = W2' dz2 — on the bf16 matrix cores (3-piece operand splitting, ppo_grad_split_kernel's
-// dual-use weight image).  It needs the split kernel's extra registers only where they are short-lived (the pieces of h1 die with L2, those of dz2 with dh1).
-template <int KIND, int H, bool REC>
-__global__ __launch_bounds__(256, 2) void ppo_grad_hybrid_kernel(GradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (*a.stop_flag) return;
-    constexpr int A = EnvSpec<KIND>::A;
-    const bool actor = a.layout ? (blockIdx.x < (unsigned)a.G) : ((blockIdx.x & 1) == 0);
-    if (actor) grad_body_hybrid<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN, REC>(a, smem);
-    else grad_body_hybrid<KIND, H, 1, HEAD_VALUE, REC>(a, smem);
+    if (actor) grad_body_split<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN, REC>(a, smem);
+    else grad_body_split<KIND, H, 1, HEAD_VALUE, REC>(a, smem);
 }
 
 // =============================================================================================
@@ -2643,16 +2291,10 @@ hipError_t launch_moments_finalize(const double* partials, int nblocks, double* 
     return hipGetLastError();
 }
 
-template <int KIND, int H, bool PIPE> static size_t grad_split_lds_bytes() {
-    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A, N = PIPE ? 8 : 4;
+template <int KIND, int H> static size_t grad_split_lds_bytes() {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A, N = 4;
     constexpr int wa = NetLdsSplit<D, H, A>::END + N * GradScratchSplit<D, H, A>::SIZE;
     constexpr int wc = NetLdsSplit<D, H, 1>::END + N * GradScratchSplit<D, H, 1>::SIZE;
-    return sizeof(float) * (wa > wc ? wa : wc);
-}
-template <int KIND, int H> static size_t grad_hybrid_lds_bytes() {
-    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
-    constexpr int wa = NetLdsSplit<D, H, A>::END + 4 * GradScratch<D, H, A>::SIZE;
-    constexpr int wc = NetLdsSplit<D, H, 1>::END + 4 * GradScratch<D, H, 1>::SIZE;
     return sizeof(float) * (wa > wc ? wa : wc);
 }
 template <int KIND, int H> static size_t grad_wide_lds_bytes() {
@@ -2685,31 +2327,16 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
 #undef CALLWK
         return hipGetLastError();
     }
-    if (a.variant == 3 && hidden == 64) {         // L2 forward + dh1 on the bf16 matrix cores, the rest as ppo_grad_kernel
-#define CALLH(K, R)                                                                                           \
-    {                                                                                                         \
-        const size_t lds = grad_hybrid_lds_bytes<K, 64>();                                                    \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_hybrid_kernel<K, 64, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e; attr_set = true; }                                                 \
-        ppo_grad_hybrid_kernel<K, 64, R><<<2 * a.G, 256, lds, s>>>(a);                                        \
-    }
-#define CALLHK(K) { if (a.rec) CALLH(K, true) else CALLH(K, false) }
-        if (kind == 0) CALLHK(0) else if (kind == 3) CALLHK(3) else if (kind == 4) CALLHK(4) else CALLHK(1)
-#undef CALLHK
-#undef CALLH
-        return hipGetLastError();
-    }
     if (a.variant && hidden == 64) {              // bf16 matrix cores, fp32-equivalent operand splitting
-#define CALLS(K, R, W)                                                                                        \
+#define CALLS(K, R)                                                                                           \
     {                                                                                                         \
-        const size_t lds = grad_split_lds_bytes<K, 64, W>();                                                  \
+        const size_t lds = grad_split_lds_bytes<K, 64>();                                                     \
         static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_split_kernel<K, 64, R, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_split_kernel<K, 64, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e; attr_set = true; }                                                 \
-        ppo_grad_split_kernel<K, 64, R, W><<<2 * a.G, 256, lds, s>>>(a);                                      \
+        ppo_grad_split_kernel<K, 64, R><<<2 * a.G, 256, lds, s>>>(a);                                         \
     }
-#define CALLSK(K) { if (a.variant == 2) { if (a.rec) CALLS(K, true, true) else CALLS(K, false, true) } else { if (a.rec) CALLS(K, true, false) else CALLS(K, false, false) } }
+#define CALLSK(K) { if (a.rec) CALLS(K, true) else CALLS(K, false) }
         if (kind == 0) CALLSK(0) else if (kind == 3) CALLSK(3) else if (kind == 4) CALLSK(4) else CALLSK(1)
 #undef CALLSK
 #undef CALLS
