@@ -117,6 +117,7 @@ struct dril_handle {
     double* rms_red = nullptr;   // data-parallel: this step's partial sums folded to one row and summed over ranks
     int grad_stagger = 0;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
+    int grad_actor_pct = 0;   // ppo_grad_split_kernel: share (%) of the CUs given to the actor workgroups; 0 = by head (env DRIL_GRAD_ACTOR_PCT)
     int grad_variant = -1;  // hidden [64,64]: 0 = f32-MFMA ppo_grad_kernel, 1 = ppo_grad_split_kernel (bf16 x 3 operand splitting, one workgroup per CU), -1 = by minibatch size (env DRIL_GRAD_VARIANT)
     bool external = false; bool generic = false; float* gen_tmp = nullptr;   // generic: layer-by-layer kernels (host envs, or a device env whose hidden_dims the fused kernels are not built for)
     GenericDims gd{}; GenericWs gws; int ext_t = 0; bool ext_acted = false;   // DRIL_ENV_EXTERNAL: host envs, generic kernels
@@ -326,6 +327,15 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
         variant = h->grad_variant >= 0 ? h->grad_variant : (tiles >= 16 * (int64_t)h->num_cus ? 1 : 0);
         if (variant == 1) { const int gm = h->num_cus / 2 > 0 ? h->num_cus / 2 : 1; if (G > gm) G = gm; }
     }
+    // the split kernel runs one workgroup per CU and the actor's tile costs more than the critic's (stamps: 17.5 k vs 15.5 k cycles with the
+    // Categorical head; measured optimum 52-54 % of the CUs for the actor with it, 50 % with the DiagGaussian head): when the grid fills the chip, the CUs are divided in that proportion instead of half and half
+    int Gc = G;
+    if (variant == 1 && 2 * G >= h->num_cus && h->num_cus >= 8) {
+        const int pct = h->grad_actor_pct ? h->grad_actor_pct : (h->discrete ? 53 : 50);
+        int ga = (h->num_cus * pct + 50) / 100; if (ga < 1) ga = 1; if (ga > h->num_cus - 1) ga = h->num_cus - 1;
+        G = ga; Gc = h->num_cus - ga;
+        if (G > h->Gmax) G = h->Gmax; if (Gc > h->Gmax) Gc = h->Gmax;
+    }
     if (h->generic) { G = generic_pick_slabs(h->gd, count, h->Gmax); if (G < 1) return fail(h, DRIL_ERR_UNSUPPORTED, "minibatch too large for the generic path's workspace"); }
     { int rcw = ensure_wimg(h); if (rcw) return rcw; }
     const double* adv_stats = h->adv_stats;
@@ -352,13 +362,13 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     g.clip_range = h->cfg.clip_range; g.ent_coef = h->cfg.ent_coef; g.vf_coef = h->cfg.vf_coef; g.clip_range_vf = h->cfg.clip_range_vf;
     g.has_clip_vf = h->cfg.has_clip_range_vf; g.normalize_adv = h->cfg.normalize_advantage; g.action_start = h->cfg.action_start;
     g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
-    g.G = G; g.dbg = h->dbg; g.layout = h->grad_layout; g.variant = variant; g.stagger = h->grad_stagger; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
+    g.G = G; g.Gc = Gc; g.dbg = h->dbg; g.layout = h->grad_layout; g.variant = variant; g.stagger = h->grad_stagger; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
     prof_begin(h, DRIL_K_PPO_GRAD);
     if (h->generic) HIPCHK(h, generic_ppo_grad(h->gd, g, h->gws, h->stream));
     else HIPCHK(h, launch_ppo_grad(h->cfg.env_kind, h->cfg.hidden1, g, h->stream));
     prof_end(h);
     ReduceArgs r{};
-    r.slabs_actor = h->slabs_a; r.slabs_critic = h->slabs_c; r.slab_a = h->slab_a; r.slab_c = h->slab_c; r.G = G;
+    r.slabs_actor = h->slabs_a; r.slabs_critic = h->slabs_c; r.slab_a = h->slab_a; r.slab_c = h->slab_c; r.G = G; r.Gc = Gc;
     r.P = h->P; r.Pa = h->Pa; r.Pc = h->Pc; r.flat = h->flat; r.norm_partials = h->norm_partials; r.n_samples_local = (double)count;
     r.stop_flag = h->stop_flag;
     if (small && apply && h->P <= 16384 && G <= 32) {
@@ -482,6 +492,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (const char* e = std::getenv("DRIL_GRAD_PRIO")) h->grad_prio = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_STAGGER")) h->grad_stagger = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_SPLIT")) h->grad_split = std::atoi(e);
+    if (const char* e = std::getenv("DRIL_GRAD_ACTOR_PCT")) { h->grad_actor_pct = std::atoi(e); if (h->grad_actor_pct < 10 || h->grad_actor_pct > 90) h->grad_actor_pct = 0; }
     if (const char* e = std::getenv("DRIL_GRAD_VARIANT")) { h->grad_variant = std::atoi(e); if (h->grad_variant < -1 || h->grad_variant > 1) h->grad_variant = -1; }
     h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
@@ -990,7 +1001,9 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
     {   // shares of the LAST grad launch, averaged over waves, per head
         std::vector<unsigned long long> d((size_t)2 * h->Gmax * 4 * 12);
         hipMemcpy(d.data(), h->dbg, d.size() * 8, hipMemcpyDeviceToHost);
-        const char* names[] = {"gather/loop", "L1+tanh", "L2+tanh", "out+head", "dW3 block", "dz2", "h1img+dh1+dz1", "dW2 block", "dW1 block"};
+        const char* names_f32[] = {"gather/loop", "L1+tanh", "L2+tanh", "out+head", "dW3 block", "dz2", "h1img+dh1+dz1", "dW2 block", "dW1 block"};
+        const char* names_split[] = {"S1 unpack+L1+tanh+split", "S2 L2+tanh+h2 img", "S3 head+dW3+dz2+split", "S4 dh1+mask", "S5+S6 dW2+dW1", "-", "-", "-", "-"};
+        const char** names = std::getenv("DRIL_GRAD_VARIANT") && std::atoi(std::getenv("DRIL_GRAD_VARIANT")) == 0 ? names_f32 : names_split;
         for (int head = 0; head < 3; ++head) {
             double acc[10] = {0}; double tiles = 0; int nw = 0;
             for (size_t w = 0; w < d.size() / 12; ++w) if (d[w * 12 + 10] > 0 && (int)d[w * 12 + 11] == head) { for (int k = 0; k < 10; ++k) acc[k] += (double)d[w * 12 + k]; tiles += (double)d[w * 12 + 10]; ++nw; }

@@ -63,6 +63,7 @@ struct GradArgs {
     float invB, clip_range, ent_coef, vf_coef, clip_range_vf;
     int has_clip_vf, normalize_adv, action_start, log_std_off;
     float* slabs_actor; float* slabs_critic; int slab_a, slab_c, G;
+    int Gc;       // critic workgroups (== G except in ppo_grad_split_kernel, whose one-workgroup-per-CU grid is divided between the nets by their measured cost per tile)
     unsigned long long* dbg;   // -DDRIL_STAMPS diagnostic buffer (12 x u64 per wave), else unused
     int stagger;   // tuning knob: start-up delay of the critic workgroups, in units of 8128 clocks
     int prio, split_pct;   // tuning knobs: static wave priority + share of tiles for the high-priority half
@@ -74,7 +75,7 @@ struct GradArgs {
 };
 
 struct ReduceArgs {
-    const float* slabs_actor; const float* slabs_critic; int slab_a, slab_c, G;
+    const float* slabs_actor; const float* slabs_critic; int slab_a, slab_c, G, Gc;   // G actor slabs, Gc critic slabs
     int P, Pa, Pc; float* flat; double* norm_partials; double n_samples_local; const int* stop_flag;
 };
 

@@ -1536,21 +1536,32 @@ __device__ __forceinline__ void grad_body_split(const GradArgs& a, float* smem) 
 #pragma unroll
     for (int i = 0; i < 5; ++i) A.st[i] = 0.f;
 
-    const int g = a.layout ? (int)(blockIdx.x % a.G) : (int)(blockIdx.x >> 1);
+    const int g = HEAD == HEAD_VALUE ? (int)blockIdx.x - a.G : (int)blockIdx.x;            // the first G workgroups run the actor, the next Gc the critic
     const int64_t ntiles = (a.count + kTile - 1) / kTile;
-    const int64_t tstride = (int64_t)a.G * 4, first = (int64_t)g * 4 + wave;
+    const int64_t tstride = (int64_t)(HEAD == HEAD_VALUE ? a.Gc : a.G) * 4, first = (int64_t)g * 4 + wave;
     typename ST::Ctx ta;
     ta.T = scratch + SC::T; ta.Tb = reinterpret_cast<char*>(ta.T); ta.T2 = scratch + SC::T2; ta.XI = scratch + SC::XI; ta.ZI = scratch + SC::ZI;
     {
         int64_t tile = first;
         load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, ta.nxt);       // a tile index past the end loads an all-invalid tile
+#ifdef DRIL_STAMPS
+        unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
+#endif
         for (; tile < ntiles; tile += tstride) {
-            ST::s1(a, e, ta, tile + tstride, ntiles); __builtin_amdgcn_sched_barrier(0);
-            ST::s2(e, ta); __builtin_amdgcn_sched_barrier(0);
-            ST::s3(a, e, ta, A); __builtin_amdgcn_sched_barrier(0);
-            ST::s4(e, ta); __builtin_amdgcn_sched_barrier(0);
-            ST::s5(e, ta, A); ST::s6(e, ta, A); __builtin_amdgcn_sched_barrier(0);    // one region: the f32 MFMAs of dW1 fill the VALU lanes under dW2's matrix-pipe chain
+            ST::s1(a, e, ta, tile + tstride, ntiles); __builtin_amdgcn_sched_barrier(0); STAMP(0);
+            ST::s2(e, ta); __builtin_amdgcn_sched_barrier(0); STAMP(1);
+            ST::s3(a, e, ta, A); __builtin_amdgcn_sched_barrier(0); STAMP(2);
+            ST::s4(e, ta); __builtin_amdgcn_sched_barrier(0); STAMP(3);
+            ST::s5(e, ta, A); ST::s6(e, ta, A); __builtin_amdgcn_sched_barrier(0); STAMP(4);    // one region: the f32 MFMAs of dW1 fill the VALU lanes under dW2's matrix-pipe chain
         }
+#ifdef DRIL_STAMPS
+        if (lane == 0 && a.dbg) {
+            unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
+            for (int k = 0; k < 10; ++k) o[k] = stamp_acc[k];
+            o[10] = (unsigned long long)((ntiles - first + tstride - 1) / tstride); o[11] = HEAD;
+        }
+#endif
     }
 
     // ---- epilogue: 4 waves -> one slab (fixed wave order => deterministic) ----
@@ -1612,7 +1623,7 @@ __global__ __launch_bounds__(256, 1) void ppo_grad_split_kernel(GradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (*a.stop_flag) return;
     constexpr int A = EnvSpec<KIND>::A;
-    const bool actor = a.layout ? (blockIdx.x < (unsigned)a.G) : ((blockIdx.x & 1) == 0);
+    const bool actor = blockIdx.x < (unsigned)a.G;
     if (actor) grad_body_split<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN, REC>(a, smem);
     else grad_body_split<KIND, H, 1, HEAD_VALUE, REC>(a, smem);
 }
@@ -1949,11 +1960,12 @@ __global__ __launch_bounds__(1024) void grad_reduce_kernel(ReduceArgs a) {
     float acc = 0.f;
     if (p < a.P) {
         const float* base; int stride, offp;
+        int Gn = a.G;
         if (p < a.Pa) { base = a.slabs_actor; stride = a.slab_a; offp = p; }
-        else if (p < a.Pa + a.Pc) { base = a.slabs_critic; stride = a.slab_c; offp = p - a.Pa; }
+        else if (p < a.Pa + a.Pc) { base = a.slabs_critic; stride = a.slab_c; offp = p - a.Pa; Gn = a.Gc; }
         else { base = a.slabs_actor; stride = a.slab_a; offp = a.Pa + (p - a.Pa - a.Pc); }   // log_std grads sit after the actor net
 #pragma unroll 8
-        for (int g = grp; g < a.G; g += 32) acc += base[(size_t)g * stride + offp];
+        for (int g = grp; g < Gn; g += 32) acc += base[(size_t)g * stride + offp];
     }
     part[grp][pl] = acc;
     __syncthreads();
@@ -1971,7 +1983,7 @@ __global__ __launch_bounds__(1024) void grad_reduce_kernel(ReduceArgs a) {
         float sacc = 0.f;
         if (threadIdx.x < 256) {
             if (k < 5) { for (int g = sg; g < a.G; g += 32) sacc += a.slabs_actor[(size_t)g * a.slab_a + a.slab_a - 8 + k]; }
-            else if (k == 5) { for (int g = sg; g < a.G; g += 32) sacc += a.slabs_critic[(size_t)g * a.slab_c + a.slab_c - 8]; }
+            else if (k == 5) { for (int g = sg; g < a.Gc; g += 32) sacc += a.slabs_critic[(size_t)g * a.slab_c + a.slab_c - 8]; }
             part[sg][k] = sacc;
         }
         __syncthreads();
@@ -2047,11 +2059,12 @@ __global__ __launch_bounds__(1024) void ppo_finish_small_kernel(ReduceArgs r, Ad
         gacc[k] = 0.f; mo[k] = 0.f; vo[k] = 0.f; po[k] = 0.f;
         if (p < r.P) {
             const float* base; int stride, offp;
+            int Gn = r.G;
             if (p < r.Pa) { base = r.slabs_actor; stride = r.slab_a; offp = p; }
-            else if (p < r.Pa + r.Pc) { base = r.slabs_critic; stride = r.slab_c; offp = p - r.Pa; }
+            else if (p < r.Pa + r.Pc) { base = r.slabs_critic; stride = r.slab_c; offp = p - r.Pa; Gn = r.Gc; }
             else { base = r.slabs_actor; stride = r.slab_a; offp = r.Pa + (p - r.Pa - r.Pc); }
             float acc = 0.f;
-            for (int g = 0; g < r.G; ++g) acc += base[(size_t)g * stride + offp];      // fixed order
+            for (int g = 0; g < Gn; ++g) acc += base[(size_t)g * stride + offp];      // fixed order
             gacc[k] = acc; r.flat[p] = acc; ss += (double)acc * (double)acc;
             mo[k] = a.m[p]; vo[k] = a.v[p]; po[k] = a.params[p];                        // optimiser state in flight under the norm reduction
         }
@@ -2059,7 +2072,7 @@ __global__ __launch_bounds__(1024) void ppo_finish_small_kernel(ReduceArgs r, Ad
     if (tid < 8) {
         double t = 0;
         if (tid < 5) { for (int g = 0; g < r.G; ++g) t += (double)r.slabs_actor[(size_t)g * r.slab_a + r.slab_a - 8 + tid]; }
-        else if (tid == 5) { for (int g = 0; g < r.G; ++g) t += (double)r.slabs_critic[(size_t)g * r.slab_c + r.slab_c - 8]; }
+        else if (tid == 5) { for (int g = 0; g < r.Gc; ++g) t += (double)r.slabs_critic[(size_t)g * r.slab_c + r.slab_c - 8]; }
         else if (tid == 6) t = r.n_samples_local;
         stf[tid] = (float)t; r.flat[r.P + tid] = (float)t;
     }
@@ -2334,7 +2347,7 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
         static bool attr_set = false;                                                                         \
         if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_split_kernel<K, 64, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e; attr_set = true; }                                                 \
-        ppo_grad_split_kernel<K, 64, R><<<2 * a.G, 256, lds, s>>>(a);                                         \
+        ppo_grad_split_kernel<K, 64, R><<<a.G + a.Gc, 256, lds, s>>>(a);                                         \
     }
 #define CALLSK(K) { if (a.rec) CALLS(K, true) else CALLS(K, false) }
         if (kind == 0) CALLSK(0) else if (kind == 3) CALLSK(3) else if (kind == 4) CALLSK(4) else CALLSK(1)
