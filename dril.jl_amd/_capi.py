@@ -13,7 +13,7 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "csrc" / "libdril_hip.so"
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ENV_CARTPOLE, ENV_PENDULUM, ENV_PENDULUM_SCALED, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONTINUOUS, ENV_EXTERNAL, ENV_ACROBOT = 0, 1, 2, 3, 4, 5, 6
 (BUF_OBSERVATIONS, BUF_ACTIONS, BUF_REWARDS, BUF_ADVANTAGES, BUF_RETURNS, BUF_LOGPROBS, BUF_VALUES,
  BUF_FLAGS, BUF_BOOTSTRAP, BUF_LAST_VALUES) = range(10)
@@ -40,7 +40,8 @@ class DrilConfig(C.Structure):
         ("seed", C.c_uint64), ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
         ("profile_events", C.c_int32), ("monitor_window", C.c_int32),
         ("ext_obs_dim", C.c_int32), ("ext_action_dim", C.c_int32), ("ext_discrete", C.c_int32),
-        ("ext_action_low", C.c_float), ("ext_action_high", C.c_float), ("reserved", C.c_int32 * 1),
+        ("ext_action_low", C.c_float), ("ext_action_high", C.c_float),
+        ("n_hidden", C.c_int32), ("hidden", C.c_int32 * 4), ("activation", C.c_int32), ("reserved", C.c_int32 * 1),
     ]
 
 

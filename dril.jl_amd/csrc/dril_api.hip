@@ -460,17 +460,22 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (cfg->env_kind < DRIL_ENV_CARTPOLE || cfg->env_kind > DRIL_ENV_ACROBOT) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
     const bool ext = cfg->env_kind == DRIL_ENV_EXTERNAL;
     if (ext && (cfg->ext_obs_dim < 1 || cfg->ext_obs_dim > 1024 || cfg->ext_action_dim < 1 || cfg->ext_action_dim > 64)) return fail(nullptr, DRIL_ERR_INVALID_ARG, "DRIL_ENV_EXTERNAL: ext_obs_dim must be 1..1024 and ext_action_dim 1..64");
-    if (ext && (cfg->hidden1 < 1 || cfg->hidden1 > 1024 || cfg->hidden2 < 1 || cfg->hidden2 > 1024)) return fail(nullptr, DRIL_ERR_INVALID_ARG, "DRIL_ENV_EXTERNAL: hidden widths must be 1..1024");
+    // hidden_dims / activation: n_hidden == 0 is the two-layer form (hidden1, hidden2); otherwise hidden[0 .. n_hidden-1]
+    if (cfg->n_hidden < 0 || cfg->n_hidden > kMaxHidden) return fail(nullptr, DRIL_ERR_INVALID_ARG, "n_hidden must be 0 (hidden1 / hidden2) or 1..4");
+    if (cfg->activation != 0 && cfg->activation != 1) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "activation must be 0 (tanh) or 1 (relu)");
+    int nh = cfg->n_hidden ? cfg->n_hidden : 2, hd[kMaxHidden] = {cfg->hidden1, cfg->hidden2, 0, 0};
+    if (cfg->n_hidden) for (int l = 0; l < nh; ++l) hd[l] = cfg->hidden[l];
+    for (int l = 0; l < nh; ++l) if (hd[l] < 1 || hd[l] > 1024) return fail(nullptr, DRIL_ERR_INVALID_ARG, "hidden widths must be 1..1024");
     if (ext && (cfg->norm_obs || cfg->norm_reward || cfg->monitor_window)) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "DRIL_ENV_EXTERNAL: NormalizeWrapperEnv / MonitorWrapperEnv wrap the host env on the host");
     if (cfg->n_envs < 1 || cfg->n_steps < 1 || cfg->epochs < 0 || cfg->batch_size < 1) return fail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs/n_steps/batch_size must be positive");
-    const bool fused_shape = cfg->hidden1 == cfg->hidden2 && (cfg->hidden1 == 64 || cfg->hidden1 == 128 || cfg->hidden1 == 256);   // other hidden_dims: the generic kernels (any width up to 1024)
-    if (!ext && !fused_shape && (cfg->hidden1 < 1 || cfg->hidden1 > 1024 || cfg->hidden2 < 1 || cfg->hidden2 > 1024)) return fail(nullptr, DRIL_ERR_INVALID_ARG, "hidden widths must be 1..1024");
+    const bool fused_shape = nh == 2 && cfg->activation == 0 && hd[0] == hd[1] && (hd[0] == 64 || hd[0] == 128 || hd[0] == 256);   // everything else: the generic kernels (any depth <= 4, any width <= 1024, tanh / relu)
     if (cfg->monitor_window < 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "monitor_window must be >= 0");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad rank/world_size");
     if (cfg->batch_size % cfg->world_size != 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "batch_size must be divisible by world_size");
     dril_handle* h = nullptr;
     try { h = new dril_handle(); } catch (...) { return fail(nullptr, DRIL_ERR_INVALID_ARG, "out of host memory"); }
     h->cfg = *cfg;
+    h->cfg.hidden1 = hd[0]; h->cfg.hidden2 = nh > 1 ? hd[1] : hd[0];   // the fused kernels read hidden1 (only reached with two equal layers)
     switch (cfg->env_kind) {
         case DRIL_ENV_CARTPOLE: h->discrete = true; h->D = 4; h->A = 2; h->S = 4; break;
         case DRIL_ENV_MOUNTAINCAR: h->discrete = true; h->D = 2; h->A = 3; h->S = 2; break;
@@ -479,12 +484,16 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
         case DRIL_ENV_EXTERNAL: h->discrete = cfg->ext_discrete != 0; h->D = cfg->ext_obs_dim; h->A = cfg->ext_action_dim; h->S = 0; h->external = true; h->generic = true; break;
         default: h->discrete = false; h->D = 3; h->A = 1; h->S = 2; break;                    // Pendulum, ScalingWrapperEnv(Pendulum)
     }
-    h->actor = net_off(0, h->D, cfg->hidden1, cfg->hidden2, h->A);
-    h->critic = net_off(h->actor.end, h->D, cfg->hidden1, cfg->hidden2, 1);
+    h->gd = GenericDims{h->D, h->A, nh, {hd[0], hd[1], hd[2], hd[3]}, h->discrete ? 1 : 0, cfg->activation};
+    if (nh == 2) { h->actor = net_off(0, h->D, hd[0], hd[1], h->A); h->critic = net_off(h->actor.end, h->D, hd[0], hd[1], 1); }
+    else {                                                                            // other depths exist on the generic path only, which reads just the first offset and the end of a net
+        std::memset(&h->actor, 0, sizeof(h->actor)); std::memset(&h->critic, 0, sizeof(h->critic));
+        h->actor.w1 = 0; h->actor.end = generic_net_size(h->gd, h->A);
+        h->critic.w1 = h->actor.end; h->critic.end = h->actor.end + generic_net_size(h->gd, 1);
+    }
     h->Pa = h->actor.end; h->Pc = h->critic.end - h->actor.end; h->log_std_off = h->critic.end;
     h->P = h->critic.end + (h->discrete ? 0 : h->A);
     h->N = (int64_t)cfg->n_envs * cfg->n_steps; h->lr = cfg->learning_rate;
-    h->gd = GenericDims{h->D, h->A, cfg->hidden1, cfg->hidden2, h->discrete ? 1 : 0};
     if (!fused_shape || std::getenv("DRIL_FORCE_GENERIC")) h->generic = true;            // DRIL_FORCE_GENERIC: run a fused-shape handle on the generic kernels (A/B and parity tests)
     if (const char* e = std::getenv("DRIL_GRAD_LAYOUT")) h->grad_layout = std::atoi(e);
     if (const char* e = std::getenv("DRIL_FORCE_ALLREDUCE")) h->force_allreduce = std::atoi(e) != 0;
@@ -506,12 +515,12 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(dmalloc(&h->flat, P + 8)); CCHK(dmalloc(&h->norm_out, 1));
     h->n_norm_partials = (int)((P + 31) / 32); CCHK(dmalloc(&h->norm_partials, h->n_norm_partials));
     if (h->generic) { h->slab_a = generic_slab_size(h->gd, true); h->slab_c = generic_slab_size(h->gd, false); }
-    else { h->slab_a = slab_size_actor(cfg->env_kind, cfg->hidden1); h->slab_c = slab_size_critic(cfg->env_kind, cfg->hidden1); }
-    h->wide = !h->generic && cfg->hidden1 > 64;
-    h->Gmax = (h->wide && cfg->hidden1 > 128) ? (h->num_cus / 2 > 0 ? h->num_cus / 2 : 1) : h->num_cus;   // H = 128: 4 waves and 77 KB LDS per workgroup, two workgroups per CU   // [64,64]: 2 workgroups per CU (actor + critic), 4 waves each; wide: 1 workgroup of H/32 waves per CU
+    else { h->slab_a = slab_size_actor(cfg->env_kind, hd[0]); h->slab_c = slab_size_critic(cfg->env_kind, hd[0]); }
+    h->wide = !h->generic && hd[0] > 64;
+    h->Gmax = (h->wide && hd[0] > 128) ? (h->num_cus / 2 > 0 ? h->num_cus / 2 : 1) : h->num_cus;   // H = 128: 4 waves and 77 KB LDS per workgroup, two workgroups per CU   // [64,64]: 2 workgroups per CU (actor + critic), 4 waves each; wide: 1 workgroup of H/32 waves per CU
     if (h->generic) { h->Gmax = std::getenv("DRIL_EXT_GMAX") ? std::atoi(std::getenv("DRIL_EXT_GMAX")) : 64; if (h->Gmax < 1) h->Gmax = 1; }                                                        // generic path: one slab per row chunk of the minibatch
     if (const char* e = std::getenv("DRIL_GRAD_GMAX")) { const int g = std::atoi(e); if (g > 0 && g < h->Gmax) h->Gmax = g; }   // diagnostic: fewer workgroups per net
-    if (h->wide) { const size_t hh = (size_t)cfg->hidden1 * cfg->hidden1; CCHK(dmalloc(&h->w2a_actor, hh)); CCHK(dmalloc(&h->w2ta_actor, hh)); CCHK(dmalloc(&h->w2a_critic, hh)); CCHK(dmalloc(&h->w2ta_critic, hh)); }
+    if (h->wide) { const size_t hh = (size_t)hd[0] * hd[0]; CCHK(dmalloc(&h->w2a_actor, hh)); CCHK(dmalloc(&h->w2ta_actor, hh)); CCHK(dmalloc(&h->w2a_critic, hh)); CCHK(dmalloc(&h->w2ta_critic, hh)); }
     CCHK(dmalloc(&h->slabs_a, (size_t)h->Gmax * h->slab_a)); CCHK(dmalloc(&h->slabs_c, (size_t)h->Gmax * h->slab_c));
     CCHK(dmalloc(&h->state, E * h->S)); CCHK(dmalloc(&h->step_count, E)); CCHK(dmalloc(&h->episode, E)); CCHK(dmalloc(&h->gstep, E));
     CCHK(dmalloc(&h->disc_returns, E));
@@ -1229,4 +1238,4 @@ DRIL_EXPORT const char* dril_kernel_name(int32_t kid) {
     static const char* names[] = {"rollout_kernel", "gae_kernel", "adv_moments_kernel", "ppo_grad_kernel", "grad_reduce_kernel", "adam_kernel", "ncclAllReduce"};
     return (kid >= 0 && kid < DRIL_K_COUNT) ? names[kid] : "?";
 }
-DRIL_EXPORT const char* dril_version(void) { return "dril_hip 0.1 (gfx950, abi 1)"; }
+DRIL_EXPORT const char* dril_version(void) { return "dril_hip 0.2 (gfx950, abi 2)"; }

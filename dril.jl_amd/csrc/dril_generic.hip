@@ -33,41 +33,58 @@ hipError_t ws_reserve(GenericWs& ws, size_t floats) {
 }
 struct Carver { float* p; size_t used = 0; float* take(size_t n) { float* r = p + used; used += (n + 3) & ~(size_t)3; return r; } };   // 16-byte aligned pieces
 
-// out[n][O] = net(X[n][in]) with hidden activations kept (h1[n][H1], h2[n][H2]); activations are (features x n) column-major = one row per sample
-hipError_t mlp_forward(const float* P, NetOff off, int in, int H1, int H2, int O, const float* X, int n, float* h1, float* h2, float* out, hipStream_t s) {
-    GemmArgs g = gargs();                                                       // h1 = tanh(W1 x + b1), Lux.Dense layer_helpers.jl:33-41
-    g.A = P + off.w1; g.sAm = 1; g.sAk = H1; g.B = X; g.sBk = 1; g.sBn = in; g.C = h1; g.sCm = 1; g.sCn = H1; g.bias = P + off.b1;
-    g.M = H1; g.N = n; g.K = in; g.epi = EPI_TANH;
-    hipError_t e = launch_gemm(g, 1, s); if (e != hipSuccess) return e;
-    g = gargs();                                                                // h2 = tanh(W2 h1 + b2)
-    g.A = P + off.w2; g.sAm = 1; g.sAk = H2; g.B = h1; g.sBk = 1; g.sBn = H1; g.C = h2; g.sCm = 1; g.sCn = H2; g.bias = P + off.b2;
-    g.M = H2; g.N = n; g.K = H1; g.epi = EPI_TANH;
-    e = launch_gemm(g, 1, s); if (e != hipSuccess) return e;
-    g = gargs();                                                                // out = W3 h2 + b3
-    g.A = P + off.w3; g.sAm = 1; g.sAk = O; g.B = h2; g.sBk = 1; g.sBn = H2; g.C = out; g.sCm = 1; g.sCn = O; g.bias = P + off.b3;
-    g.M = O; g.N = n; g.K = H2; g.epi = EPI_NONE;
-    return launch_gemm(g, 1, s);
+// one net's layout inside the flat parameter vector: layer l (0 .. nh) has W at w[l] (out x in, column-major) and b at b[l]
+struct NetLay { int nl; int in[kMaxHidden + 1], out[kMaxHidden + 1], w[kMaxHidden + 1], b[kMaxHidden + 1]; int end; };
+NetLay net_lay(const GenericDims& d, int base, int O) {
+    NetLay n; n.nl = d.nh + 1; int off = base;
+    for (int l = 0; l < n.nl; ++l) {
+        n.in[l] = l == 0 ? d.D : d.H[l - 1]; n.out[l] = l == d.nh ? O : d.H[l];
+        n.w[l] = off; off += n.in[l] * n.out[l]; n.b[l] = off; off += n.out[l];
+    }
+    n.end = off;
+    return n;
+}
+int hidden_sum(const GenericDims& d) { int s = 0; for (int l = 0; l < d.nh; ++l) s += d.H[l]; return s; }
+// hidden activations of `nets` nets over R rows live in ONE buffer: layer l's block starts at hoff(l) * nets * R floats; inside it net z follows net z - 1
+// (R * H[l] floats apart), one row per sample — the layout mlp_forward_both's batched launches write and the reverse pass reads
+size_t hoff(const GenericDims& d, int l) { size_t s = 0; for (int k = 0; k < l; ++k) s += (size_t)d.H[k]; return s; }
+int act_epi(const GenericDims& d) { return d.act ? EPI_RELU : EPI_TANH; }
+int mask_epi(const GenericDims& d) { return d.act ? EPI_MASK_RELU : EPI_MASK_TANH; }
+
+// out[n][O] = net(X[n][D]) with every hidden activation kept in hb (layer l at hb + hoff(l) * n): Dense(in => h, act) ... Dense(h_nh => out), layer_helpers.jl:27-57
+hipError_t mlp_forward(const GenericDims& d, const float* P, const NetLay& L, const float* X, int n, float* hb, float* out, hipStream_t s) {
+    const float* in = X;
+    for (int l = 0; l < L.nl; ++l) {
+        float* dst = l == d.nh ? out : hb + hoff(d, l) * (size_t)n;
+        GemmArgs g = gargs();                                                       // y = act(W x + b), Lux.Dense
+        g.A = P + L.w[l]; g.sAm = 1; g.sAk = L.out[l]; g.B = in; g.sBk = 1; g.sBn = L.in[l]; g.C = dst; g.sCm = 1; g.sCn = L.out[l]; g.bias = P + L.b[l];
+        g.M = L.out[l]; g.N = n; g.K = L.in[l]; g.epi = l == d.nh ? EPI_NONE : act_epi(d);
+        hipError_t e = launch_gemm(g, 1, s); if (e != hipSuccess) return e;
+        in = dst;
+    }
+    return hipSuccess;
 }
 
-// both nets of the ActorCriticLayer on the same rows: their first two layers have the same shapes, so each is ONE launch with blockIdx.z = net
-// (h1 / h2 hold the actor's activations followed by the critic's, n * H floats apart); the output layers differ in width and share a launch
-// through the pair kernel while the batch is small.  Halves the launch count of a rollout step / small minibatch (latency-bound there).
-hipError_t mlp_forward_both(const float* P, NetOff actor, NetOff critic, int in, int H1, int H2, int O, const float* X, int n, float* h1, float* h2,
-                            float* out, float* v, hipStream_t s) {
-    const long long zP = (long long)critic.w1 - actor.w1;                           // same layout in both nets up to the output layer
-    GemmArgs g = gargs();
-    g.A = P + actor.w1; g.sAm = 1; g.sAk = H1; g.zA = zP; g.B = X; g.sBk = 1; g.sBn = in; g.zB = 0; g.C = h1; g.sCm = 1; g.sCn = H1; g.zC = (long long)n * H1;
-    g.bias = P + actor.b1; g.zBias = zP; g.M = H1; g.N = n; g.K = in; g.epi = EPI_TANH;
-    hipError_t e = launch_gemm(g, 2, s); if (e != hipSuccess) return e;
-    g = gargs();
-    g.A = P + actor.w2; g.sAm = 1; g.sAk = H2; g.zA = zP; g.B = h1; g.sBk = 1; g.sBn = H1; g.zB = (long long)n * H1; g.C = h2; g.sCm = 1; g.sCn = H2; g.zC = (long long)n * H2;
-    g.bias = P + actor.b2; g.zBias = zP; g.M = H2; g.N = n; g.K = H1; g.epi = EPI_TANH;
-    e = launch_gemm(g, 2, s); if (e != hipSuccess) return e;
+// both nets of the ActorCriticLayer on the same rows: their hidden layers have the same shapes, so each is ONE launch with blockIdx.z = net
+// (layer l's block of hb holds the actor's activations followed by the critic's, n * H[l] floats apart); the output layers differ in width and share a
+// launch through the pair kernel while the batch is small.  Halves the launch count of a rollout step / small minibatch (latency-bound there).
+hipError_t mlp_forward_both(const GenericDims& d, const float* P, const NetLay& La, const NetLay& Lc, const float* X, int n, float* hb, float* out, float* v, hipStream_t s) {
+    const long long zP = (long long)Lc.w[0] - La.w[0];                              // same layout in both nets up to the output layer
+    const float* in = X; long long zin = 0;
+    for (int l = 0; l < d.nh; ++l) {
+        float* dst = hb + hoff(d, l) * 2 * (size_t)n;
+        GemmArgs g = gargs();
+        g.A = P + La.w[l]; g.sAm = 1; g.sAk = La.out[l]; g.zA = zP; g.B = in; g.sBk = 1; g.sBn = La.in[l]; g.zB = zin; g.C = dst; g.sCm = 1; g.sCn = La.out[l]; g.zC = (long long)n * La.out[l];
+        g.bias = P + La.b[l]; g.zBias = zP; g.M = La.out[l]; g.N = n; g.K = La.in[l]; g.epi = act_epi(d);
+        hipError_t e = launch_gemm(g, 2, s); if (e != hipSuccess) return e;
+        in = dst; zin = (long long)n * La.out[l];
+    }
+    const int l = d.nh, Hl = La.in[l];
     GemmArgs a = gargs(), c = gargs();
-    a.A = P + actor.w3; a.sAm = 1; a.sAk = O; a.B = h2; a.sBk = 1; a.sBn = H2; a.C = out; a.sCm = 1; a.sCn = O; a.bias = P + actor.b3; a.M = O; a.N = n; a.K = H2;
-    c.A = P + critic.w3; c.sAm = 1; c.sAk = 1; c.B = h2 + (size_t)n * H2; c.sBk = 1; c.sBn = H2; c.C = v; c.sCm = 1; c.sCn = 1; c.bias = P + critic.b3; c.M = 1; c.N = n; c.K = H2;
+    a.A = P + La.w[l]; a.sAm = 1; a.sAk = La.out[l]; a.B = in; a.sBk = 1; a.sBn = Hl; a.C = out; a.sCm = 1; a.sCn = La.out[l]; a.bias = P + La.b[l]; a.M = La.out[l]; a.N = n; a.K = Hl;
+    c.A = P + Lc.w[l]; c.sAm = 1; c.sAk = 1; c.B = in + zin; c.sBk = 1; c.sBn = Hl; c.C = v; c.sCm = 1; c.sCn = 1; c.bias = P + Lc.b[l]; c.M = 1; c.N = n; c.K = Hl;
     if (n <= 8192) return launch_gemm_pair(a, 1, c, 1, s);
-    e = launch_gemm(a, 1, s); if (e != hipSuccess) return e;
+    hipError_t e = launch_gemm(a, 1, s); if (e != hipSuccess) return e;
     return launch_gemm(c, 1, s);
 }
 
@@ -237,7 +254,7 @@ __global__ __launch_bounds__(256) void generic_loss_head_kernel(LossHeadArgs g) 
     if (tid < 3) slab_a[a.slab_a - 3 + tid] = 0.f;
     if (tid >= 1 && tid < 8) slab_c[a.slab_c - 8 + tid] = 0.f;
     if (!g.discrete) {                                                                // dLoss/dlog_std_k = sum_rows dlogp (d^2 exp(-2 ls) - 1) + dent, one dim at a time
-        const int Pa = a.actor.end - a.actor.w1;
+        const int Pa = a.actor.end - a.actor.w1;   // the actor net's parameter count (any depth): log_std gradients sit right behind it in the slab
         for (int k = 0; k < A; ++k) {
             const float iv = expf(-2.0f * ls[k]);
             double acc = 0;
@@ -256,37 +273,35 @@ __global__ __launch_bounds__(256) void generic_loss_head_kernel(LossHeadArgs g) 
 }
 
 // reverse pass of one net over R = G * Cr rows: data gradients over all rows at once, parameter gradients per row chunk straight into the slabs.
-// The five contractions of a net, in dependency order: [dW3|db3], dz2, [dW2|db2], dz1, [dW1|db1]
-struct BackwardPlan { GemmArgs g[5]; int Z[5]; };
-BackwardPlan plan_backward(const float* P, NetOff off, int in, int H1, int H2, int O, const float* X, const float* h1, const float* h2, const float* dOut,
-                           float* dz2, float* dz1, int64_t R, int Cr, int G, float* slabs, int slab_stride) {
-    const int base = off.w1;                                                         // slab offsets are relative to the net's first parameter
-    BackwardPlan p;
-    GemmArgs w = gargs();                                                        // [dW3 | db3] = dOut . [h2' | 1]   (b sits right behind the column-major W)
-    w.A = dOut; w.sAm = 1; w.sAk = O; w.zA = (long long)Cr * O; w.B = h2; w.sBk = H2; w.sBn = 1; w.zB = (long long)Cr * H2; w.ones_n = 1;
-    w.C = slabs + (off.w3 - base); w.sCm = 1; w.sCn = O; w.zC = slab_stride; w.M = O; w.N = H2 + 1; w.K = Cr;
-    p.g[0] = w; p.Z[0] = G;
-    GemmArgs g = gargs();                                                        // dz2 = (W3' dOut) .* (1 - h2^2)
-    g.A = P + off.w3; g.sAm = O; g.sAk = 1; g.B = dOut; g.sBk = 1; g.sBn = O; g.C = dz2; g.sCm = 1; g.sCn = H2; g.aux = h2; g.M = H2; g.N = (int)R; g.K = O; g.epi = EPI_MASK_TANH;
-    p.g[1] = g; p.Z[1] = 1;
-    w = gargs();                                                                 // [dW2 | db2] = dz2 . [h1' | 1]
-    w.A = dz2; w.sAm = 1; w.sAk = H2; w.zA = (long long)Cr * H2; w.B = h1; w.sBk = H1; w.sBn = 1; w.zB = (long long)Cr * H1; w.ones_n = 1;
-    w.C = slabs + (off.w2 - base); w.sCm = 1; w.sCn = H2; w.zC = slab_stride; w.M = H2; w.N = H1 + 1; w.K = Cr;
-    p.g[2] = w; p.Z[2] = G;
-    g = gargs();                                                                 // dz1 = (W2' dz2) .* (1 - h1^2)
-    g.A = P + off.w2; g.sAm = H2; g.sAk = 1; g.B = dz2; g.sBk = 1; g.sBn = H2; g.C = dz1; g.sCm = 1; g.sCn = H1; g.aux = h1; g.M = H1; g.N = (int)R; g.K = H2; g.epi = EPI_MASK_TANH;
-    p.g[3] = g; p.Z[3] = 1;
-    w = gargs();                                                                 // [dW1 | db1] = dz1 . [x' | 1]
-    w.A = dz1; w.sAm = 1; w.sAk = H1; w.zA = (long long)Cr * H1; w.B = X; w.sBk = in; w.sBn = 1; w.zB = (long long)Cr * in; w.ones_n = 1;
-    w.C = slabs + (off.w1 - base); w.sCm = 1; w.sCn = H1; w.zC = slab_stride; w.M = H1; w.N = in + 1; w.K = Cr;
-    p.g[4] = w; p.Z[4] = G;
+// The 2 (nh + 1) - 1 contractions of a net, in dependency order: [dW_L|db_L], dz_{L-1}, [dW_{L-1}|db_{L-1}], ..., dz_1, [dW_1|db_1]
+constexpr int kMaxStages = 2 * (kMaxHidden + 1) - 1;
+struct BackwardPlan { GemmArgs g[kMaxStages]; int Z[kMaxStages]; int n; };
+// hb: this net's hidden activations, layer l at hb[l] (R rows x H[l]); dz: scratch of the same shapes; dOut: R x O
+BackwardPlan plan_backward(const GenericDims& d, const float* P, const NetLay& L, const float* X, const float* const* hb, float* const* dz, const float* dOut,
+                           int64_t R, int Cr, int G, float* slabs, int slab_stride) {
+    const int base = L.w[0];                                                         // slab offsets are relative to the net's first parameter
+    BackwardPlan p; p.n = 0;
+    const float* up = dOut;                                                          // gradient w.r.t. the pre-activation of layer l
+    for (int l = d.nh; l >= 0; --l) {
+        const int O = L.out[l], I = L.in[l];
+        const float* xin = l == 0 ? X : hb[l - 1];
+        GemmArgs w = gargs();                                                        // [dW_l | db_l] = up . [x_in' | 1]   (b sits right behind the column-major W)
+        w.A = up; w.sAm = 1; w.sAk = O; w.zA = (long long)Cr * O; w.B = xin; w.sBk = I; w.sBn = 1; w.zB = (long long)Cr * I; w.ones_n = 1;
+        w.C = slabs + (L.w[l] - base); w.sCm = 1; w.sCn = O; w.zC = slab_stride; w.M = O; w.N = I + 1; w.K = Cr;
+        p.g[p.n] = w; p.Z[p.n] = G; ++p.n;
+        if (l == 0) break;
+        GemmArgs g = gargs();                                                        // dz_{l-1} = (W_l' up) .* act'(h_{l-1})
+        g.A = P + L.w[l]; g.sAm = O; g.sAk = 1; g.B = up; g.sBk = 1; g.sBn = O; g.C = dz[l - 1]; g.sCm = 1; g.sCn = I; g.aux = hb[l - 1]; g.M = I; g.N = (int)R; g.K = O; g.epi = mask_epi(d);
+        p.g[p.n] = g; p.Z[p.n] = 1; ++p.n;
+        up = dz[l - 1];
+    }
     return p;
 }
 long long tiles_of(const GemmArgs& g, int Z) { return (long long)((g.M + 31) / 32) * ((g.N + 31) / 32) * Z; }
 // both nets: stage i of the actor and stage i of the critic are independent, so while both are in the split-K regime (few output tiles) they share a
-// launch through the pair kernel: 5 launches instead of 10 for a small minibatch
+// launch through the pair kernel: half the launches for a small minibatch
 hipError_t run_backward_both(const BackwardPlan& a, const BackwardPlan& c, hipStream_t s) {
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < a.n; ++i) {
         hipError_t e;
         if (tiles_of(a.g[i], a.Z[i]) + tiles_of(c.g[i], c.Z[i]) < 2048) e = launch_gemm_pair(a.g[i], a.Z[i], c.g[i], c.Z[i], s);
         else { e = launch_gemm(a.g[i], a.Z[i], s); if (e == hipSuccess) e = launch_gemm(c.g[i], c.Z[i], s); }
@@ -304,12 +319,12 @@ hipError_t generic_select(int64_t n, const uint8_t* where, const float* src, flo
 
 void generic_ws_free(GenericWs& ws) { if (ws.p) (void)hipFree(ws.p); ws.p = nullptr; ws.cap = 0; }
 
+int generic_net_size(const GenericDims& d, int out) { return net_lay(d, 0, out).end; }
 int generic_slab_size(const GenericDims& d, bool actor) {
-    const NetOff n = net_off(0, d.D, d.H1, d.H2, actor ? d.A : 1);
-    return (n.end + ((actor && !d.discrete) ? d.A : 0) + 8 + 3) / 4 * 4;
+    return (generic_net_size(d, actor ? d.A : 1) + ((actor && !d.discrete) ? d.A : 0) + 8 + 3) / 4 * 4;
 }
 
-static size_t grad_floats_per_row(const GenericDims& d) { return (size_t)d.D + 3 * (size_t)d.A + 4 * ((size_t)d.H1 + d.H2) + 40; }
+static size_t grad_floats_per_row(const GenericDims& d) { return (size_t)d.D + 3 * (size_t)d.A + 4 * (size_t)hidden_sum(d) + 40; }
 static int64_t grad_rows_max(const GenericDims& d) { return std::max<int64_t>((int64_t)(((size_t)1 << 29) / grad_floats_per_row(d)), 64); }   // <= 2 GiB of workspace per pass
 int generic_pick_slabs(const GenericDims& d, int64_t count, int Gmax) {
     if (count < 1 || Gmax < 1) return -1;
@@ -325,20 +340,21 @@ int generic_pick_slabs(const GenericDims& d, int64_t count, int Gmax) {
 hipError_t generic_policy(const GenericDims& d, const PolicyArgs& a, GenericWs& ws, hipStream_t s) {
     if (a.B <= 0) return hipSuccess;
     if (d.A > kMaxOut) return hipErrorInvalidValue;
-    const size_t per_row = 2 * ((size_t)d.H1 + d.H2) + d.A + 1 + 8;
+    const size_t per_row = 2 * (size_t)hidden_sum(d) + d.A + 1 + 8;
+    const NetLay La = net_lay(d, a.actor.w1, d.A), Lc = net_lay(d, a.critic.w1, 1);
     int64_t Rmax = (int64_t)(((size_t)1 << 28) / per_row); Rmax = std::max<int64_t>(Rmax / 1024 * 1024, 1024);   // <= 1 GiB of activations per chunk
     const int64_t R = std::min<int64_t>(a.B, Rmax);
     hipError_t e = ws_reserve(ws, (size_t)R * per_row + 64); if (e != hipSuccess) return e;
     Carver c{ws.p};
-    float* h1 = c.take((size_t)2 * R * d.H1); float* h2 = c.take((size_t)2 * R * d.H2); float* out = c.take((size_t)R * d.A);
+    float* hb = c.take((size_t)2 * R * hidden_sum(d)); float* out = c.take((size_t)R * d.A);
     for (int64_t r0 = 0; r0 < a.B; r0 += R) {
         const int64_t n = std::min<int64_t>(R, a.B - r0);
         const float* X = a.obs + r0 * d.D;
         if (a.obs_out) { const int64_t cnt = n * d.D; generic_copy_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, s>>>(X, a.obs_out + r0 * d.D, cnt); }
-        if (a.values && a.mode != 2) { e = mlp_forward_both(a.params, a.actor, a.critic, d.D, d.H1, d.H2, d.A, X, (int)n, h1, h2, out, a.values + r0, s); if (e != hipSuccess) return e; }
-        else if (a.values) { e = mlp_forward(a.params, a.critic, d.D, d.H1, d.H2, 1, X, (int)n, h1, h2, a.values + r0, s); if (e != hipSuccess) return e; }
+        if (a.values && a.mode != 2) { e = mlp_forward_both(d, a.params, La, Lc, X, (int)n, hb, out, a.values + r0, s); if (e != hipSuccess) return e; }
+        else if (a.values) { e = mlp_forward(d, a.params, Lc, X, (int)n, hb, a.values + r0, s); if (e != hipSuccess) return e; }
         if (a.mode == 2) continue;
-        if (!a.values) { e = mlp_forward(a.params, a.actor, d.D, d.H1, d.H2, d.A, X, (int)n, h1, h2, out, s); if (e != hipSuccess) return e; }
+        if (!a.values) { e = mlp_forward(d, a.params, La, X, (int)n, hb, out, s); if (e != hipSuccess) return e; }
         PolicyHeadArgs hg{a, d.A, d.discrete, r0, n, out};
         generic_policy_head_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(hg);
         e = hipGetLastError(); if (e != hipSuccess) return e;
@@ -360,22 +376,27 @@ hipError_t generic_ppo_grad(const GenericDims& d, const GradArgs& a, GenericWs& 
     Carver c{ws.p};
     float* X = c.take((size_t)R * d.D); float* act = c.take((size_t)R * d.A); float* adv = c.take(R); float* lpo = c.take(R); float* ret = c.take(R);
     float* vold = c.take(R); float* valid = c.take(R);
-    float* h1a = c.take((size_t)2 * R * d.H1); float* h2a = c.take((size_t)2 * R * d.H2); float* outa = c.take((size_t)R * d.A); float* v = c.take(R);
-    float* dout = c.take((size_t)R * d.A); float* dv = c.take(R); float* dlp = c.take(R); float* dz2 = c.take((size_t)2 * R * d.H2); float* dz1 = c.take((size_t)2 * R * d.H1);   // actor's, then critic's
+    const int HS = hidden_sum(d);
+    const NetLay La = net_lay(d, a.actor.w1, d.A), Lc = net_lay(d, a.critic.w1, 1);
+    float* hb = c.take((size_t)2 * R * HS); float* outa = c.take((size_t)R * d.A); float* v = c.take(R);
+    float* dout = c.take((size_t)R * d.A); float* dv = c.take(R); float* dlp = c.take(R); float* dzb = c.take((size_t)2 * R * HS);   // per layer: the actor's rows, then the critic's
     for (int slab0 = 0; slab0 < G; slab0 += Gp) {
         const int Gn = std::min(Gp, G - slab0); const int64_t Rn = (int64_t)Gn * Cr, row0 = (int64_t)slab0 * Cr;
         GatherArgs ga{a, d.D, d.A, d.discrete, row0, Rn, X, act, adv, lpo, ret, vold, valid};
         const int64_t ge = Rn * (d.D + 1);
         generic_gather_kernel<<<(unsigned)((ge + 255) / 256), 256, 0, s>>>(ga);
         e = hipGetLastError(); if (e != hipSuccess) return e;
-        float* h1c = h1a + (size_t)Rn * d.H1; float* h2c = h2a + (size_t)Rn * d.H2;   // the critic's activations follow the actor's (mlp_forward_both)
-        e = mlp_forward_both(a.params, a.actor, a.critic, d.D, d.H1, d.H2, d.A, X, (int)Rn, h1a, h2a, outa, v, s); if (e != hipSuccess) return e;
+        e = mlp_forward_both(d, a.params, La, Lc, X, (int)Rn, hb, outa, v, s); if (e != hipSuccess) return e;
+        const float* ha[kMaxHidden]; const float* hc[kMaxHidden]; float* dza[kMaxHidden]; float* dzc[kMaxHidden];
+        for (int l = 0; l < d.nh; ++l) {                                               // layer l's block: the actor's rows, then the critic's (mlp_forward_both)
+            ha[l] = hb + hoff(d, l) * 2 * (size_t)Rn; hc[l] = ha[l] + (size_t)Rn * d.H[l];
+            dza[l] = dzb + hoff(d, l) * 2 * (size_t)Rn; dzc[l] = dza[l] + (size_t)Rn * d.H[l];
+        }
         LossHeadArgs lh{a, d.A, d.discrete, Rn, Cr, slab0, outa, v, act, adv, lpo, ret, vold, valid, dout, dv, dlp};
         generic_loss_head_kernel<<<Gn, 256, 0, s>>>(lh);
         e = hipGetLastError(); if (e != hipSuccess) return e;
-        const BackwardPlan pa = plan_backward(a.params, a.actor, d.D, d.H1, d.H2, d.A, X, h1a, h2a, dout, dz2, dz1, Rn, (int)Cr, Gn, a.slabs_actor + (size_t)slab0 * a.slab_a, a.slab_a);
-        const BackwardPlan pc = plan_backward(a.params, a.critic, d.D, d.H1, d.H2, 1, X, h1c, h2c, dv, dz2 + (size_t)Rn * d.H2, dz1 + (size_t)Rn * d.H1, Rn, (int)Cr, Gn,
-                                              a.slabs_critic + (size_t)slab0 * a.slab_c, a.slab_c);
+        const BackwardPlan pa = plan_backward(d, a.params, La, X, ha, dza, dout, Rn, (int)Cr, Gn, a.slabs_actor + (size_t)slab0 * a.slab_a, a.slab_a);
+        const BackwardPlan pc = plan_backward(d, a.params, Lc, X, hc, dzc, dv, Rn, (int)Cr, Gn, a.slabs_critic + (size_t)slab0 * a.slab_c, a.slab_c);
         e = run_backward_both(pa, pc, s); if (e != hipSuccess) return e;
     }
     return hipSuccess;

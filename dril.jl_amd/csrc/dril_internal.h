@@ -136,7 +136,11 @@ int slab_size_actor(int kind, int hidden);
 int slab_size_critic(int kind, int hidden);
 
 // generic (any obs / action / hidden width) on-policy path, dril_generic.hip; same argument blocks and slab format as the fused kernels
-struct GenericDims { int D, A, H1, H2, discrete; };
+constexpr int kMaxHidden = 4;
+// any-depth MLP of the generic path: nh hidden layers of widths H[0..nh-1], activation act (0 tanh, 1 relu); layer l (0-based, nh + 1 layers) maps
+// dim(l) -> dim(l + 1) with dim(0) = D, dim(l) = H[l-1], dim(nh + 1) = out
+struct GenericDims { int D, A, nh, H[kMaxHidden], discrete, act; };
+int generic_net_size(const GenericDims& d, int out);   // parameters of one net {W_1 b_1 ... W_{nh+1} b_{nh+1}}
 struct GenericWs { float* p = nullptr; size_t cap = 0; };          // grow-only device workspace (floats), owned by the handle
 hipError_t generic_policy(const GenericDims& d, const PolicyArgs& a, GenericWs& ws, hipStream_t s);
 hipError_t generic_ppo_grad(const GenericDims& d, const GradArgs& a, GenericWs& ws, hipStream_t s);

@@ -208,8 +208,16 @@ class ActorCriticLayer:
     (layer_helpers.jl:13-25)."""
     observation_space: Box
     action_space: object
-    hidden_dims: Sequence[int] = (64, 64)
+    hidden_dims: Sequence[int] = (64, 64)      # any length 1..4 (get_mlp, layer_helpers.jl:27-57); two equal layers of 64 / 128 / 256 with tanh run the fused kernels
     log_std_init: float = 0.0
+    activation: str = "tanh"                   # "tanh" (the reference's default, layer_constructors.jl:8,56) or "relu"
+
+    def __post_init__(self):
+        self.hidden_dims = tuple(int(h) for h in self.hidden_dims)
+        if not 1 <= len(self.hidden_dims) <= 4:
+            raise ValueError("hidden_dims: 1..4 hidden layers are supported on the device path")
+        if self.activation not in ("tanh", "relu"):
+            raise ValueError("activation: tanh or relu")
 
     @property
     def discrete(self) -> bool:
@@ -225,20 +233,20 @@ class ActorCriticLayer:
 
     def parameterlength(self) -> int:
         """Lux.parameterlength (test/test_policies.jl:55-57)."""
-        d, (h1, h2), a = self.obs_dim, self.hidden_dims, self.actor_out
-        net = lambda o: d * h1 + h1 + h1 * h2 + h2 + h2 * o + o
+        a = self.actor_out
+
+        def net(o):
+            dims = (self.obs_dim, *self.hidden_dims, o)
+            return sum(i * j + j for i, j in zip(dims[:-1], dims[1:]))
         return net(a) + net(1) + (0 if self.discrete else a)
 
     def initialparameters(self, rng: np.random.Generator) -> dict:
         """Lux.initialparameters: orthogonal gains sqrt(2) / 0.01 / 1.0, zero bias (layer_constructors.jl:16-20,61-65)."""
-        d, (h1, h2) = self.obs_dim, self.hidden_dims
-
         def mlp(out, out_gain):
-            return {
-                "layer_1": {"weight": _orthogonal(rng, h1, d, math.sqrt(2.0)), "bias": np.zeros(h1, np.float32)},
-                "layer_2": {"weight": _orthogonal(rng, h2, h1, math.sqrt(2.0)), "bias": np.zeros(h2, np.float32)},
-                "layer_3": {"weight": _orthogonal(rng, out, h2, out_gain), "bias": np.zeros(out, np.float32)},
-            }
+            dims = (self.obs_dim, *self.hidden_dims, out)
+            n = len(dims) - 1
+            return {f"layer_{l + 1}": {"weight": _orthogonal(rng, dims[l + 1], dims[l], out_gain if l == n - 1 else math.sqrt(2.0)),
+                                       "bias": np.zeros(dims[l + 1], np.float32)} for l in range(n)}
 
         ps = {"feature_extractor": {}, "actor_head": mlp(self.actor_out, 0.01), "critic_head": mlp(1, 1.0)}
         if not self.discrete:
@@ -250,11 +258,16 @@ DiscreteActorCriticLayer = ActorCriticLayer
 ContinuousActorCriticLayer = ActorCriticLayer
 
 
+def _layer_keys(head: dict) -> list:
+    """layer_1 .. layer_n in order (Lux.Chain names its layers layer_k, layer_lux.jl:31-39)"""
+    return sorted((k for k in head if k.startswith("layer_")), key=lambda k: int(k.split("_")[1]))
+
+
 def flatten_params(ps: dict) -> np.ndarray:
     """Lux NamedTuple -> the flat layout of dril_set_params (weights column-major out x in)."""
     parts = []
     for head in ("actor_head", "critic_head"):
-        for l in ("layer_1", "layer_2", "layer_3"):
+        for l in _layer_keys(ps[head]):
             parts.append(np.asarray(ps[head][l]["weight"], np.float32).ravel(order="F"))
             parts.append(np.asarray(ps[head][l]["bias"], np.float32).ravel())
     if "log_std" in ps:
@@ -266,7 +279,7 @@ def unflatten_params(flat: np.ndarray, like: dict) -> dict:
     out = {"feature_extractor": {}, "actor_head": {}, "critic_head": {}}
     off = 0
     for head in ("actor_head", "critic_head"):
-        for l in ("layer_1", "layer_2", "layer_3"):
+        for l in _layer_keys(like[head]):
             w = like[head][l]["weight"]
             n = w.size
             out[head][l] = {"weight": flat[off:off + n].reshape(w.shape, order="F").copy()}
@@ -311,7 +324,13 @@ def make_config(env, n_envs: int, alg: PPO, layer: Optional[ActorCriticLayer] = 
     c = capi.default_config(env.kind)
     c.n_envs, c.n_steps = n_envs, alg.n_steps
     if layer is not None:
-        c.hidden1, c.hidden2 = layer.hidden_dims
+        hd = tuple(layer.hidden_dims)
+        c.hidden1, c.hidden2 = hd[0], hd[1] if len(hd) > 1 else hd[0]
+        if len(hd) != 2 or getattr(layer, "activation", "tanh") != "tanh":            # dril_config v2: any depth / relu (n_hidden == 0 is the two-layer tanh form)
+            c.n_hidden = len(hd)
+            for i, w in enumerate(hd):
+                c.hidden[i] = w
+            c.activation = 1 if layer.activation == "relu" else 0
         c.log_std_init = layer.log_std_init
     c.episode_len = getattr(env, "max_steps", 0)
     c.fixed_length_episodes = int(fixed_length_episodes)
@@ -669,7 +688,7 @@ class DeviceParallelEnv:
 
     # binding: one handle carries env + agent + alg state; (re)created when the alg/layer shape changes
     def bind(self, alg: PPO, layer: Optional[ActorCriticLayer] = None) -> Handle:
-        key = (tuple(sorted(asdict(alg).items())), None if layer is None else (tuple(layer.hidden_dims), layer.log_std_init),
+        key = (tuple(sorted(asdict(alg).items())), None if layer is None else (tuple(layer.hidden_dims), layer.log_std_init, getattr(layer, "activation", "tanh")),
                None if self._kw["normalize"] is None else tuple(sorted(self._kw["normalize"].items())), self._kw["monitor_window"])
         if self.handle is None or key != self._bound_key:
             if self.handle is not None:
@@ -732,7 +751,7 @@ class HostParallelEnv:
         self._last_trunc = np.zeros(self.n_envs, bool)
 
     def bind(self, alg: PPO, layer: Optional[ActorCriticLayer] = None) -> Handle:
-        key = (tuple(sorted(asdict(alg).items())), None if layer is None else (tuple(layer.hidden_dims), layer.log_std_init))
+        key = (tuple(sorted(asdict(alg).items())), None if layer is None else (tuple(layer.hidden_dims), layer.log_std_init, getattr(layer, "activation", "tanh")))
         if self.handle is None or key != self._bound_key:
             if self.handle is not None:
                 self.handle.close()

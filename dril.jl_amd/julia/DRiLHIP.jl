@@ -38,7 +38,7 @@ const ROLLOUT_START_LOCALS = (:i, :learning_rate)
 const TIMER_SECTIONS = ("setup", "training_loop", "collect_rollout", "epoch loop", "batch loop", "compute_gradients", "apply_gradients")
 
 const LIB = Ref{String}(joinpath(@__DIR__, "..", "csrc", "libdril_hip.so"))
-const ABI_VERSION = UInt32(1)
+const ABI_VERSION = UInt32(2)
 
 # struct dril_config (include/dril_hip.h) — isbits, C layout
 struct DrilConfig
@@ -57,6 +57,7 @@ struct DrilConfig
     seed::UInt64
     device::Int32; rank::Int32; world_size::Int32; profile_events::Int32; monitor_window::Int32
     ext_obs_dim::Int32; ext_action_dim::Int32; ext_discrete::Int32; ext_action_low::Float32; ext_action_high::Float32
+    n_hidden::Int32; hidden::NTuple{4, Int32}; activation::Int32        # any-depth hidden_dims / relu (n_hidden == 0: hidden1, hidden2, tanh)
     reserved::NTuple{1, Int32}
 end
 
@@ -120,28 +121,30 @@ function check(rc::Int32, h = C_NULL)
     error("libdril_hip status $rc: $(last_error(h))")
 end
 
-function make_config(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int}, log_std_init::Float32)
+layer_fields(hidden::Vector{Int}, act::Int32) = (length(hidden) == 2 && act == 0) ? (Int32(0), ntuple(_ -> Int32(0), 4), Int32(0)) :
+    (Int32(length(hidden)), ntuple(i -> i <= length(hidden) ? Int32(hidden[i]) : Int32(0), 4), act)
+function make_config(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int}, log_std_init::Float32, act::Int32 = Int32(0))
     opt(x) = isnothing(x) ? (0.0f0, Int32(0)) : (Float32(x), Int32(1))
     cvf, hcvf = opt(alg.clip_range_vf); mgn, hmgn = opt(alg.max_grad_norm); tkl, htkl = opt(alg.target_kl)
     start = is_discrete(env) ? Int32(action_space(env).start) : Int32(1)
     nz = env.normalize
     nget(k, d) = isnothing(nz) ? d : get(nz, k, d)
     on = isnothing(nz) ? Int32(0) : Int32(1)
-    return DrilConfig(ABI_VERSION, ENV_KINDS[env.kind], env.n_envs, alg.n_steps, hidden[1], hidden[2], env.max_steps,
+    return DrilConfig(ABI_VERSION, ENV_KINDS[env.kind], env.n_envs, alg.n_steps, hidden[1], hidden[min(2, end)], env.max_steps,
         Int32(env.fixed_length_episodes), start, alg.gamma, alg.gae_lambda, alg.clip_range, cvf, hcvf, alg.ent_coef,
         alg.vf_coef, mgn, hmgn, tkl, htkl, Int32(alg.normalize_advantage), alg.batch_size, alg.epochs, alg.learning_rate,
         0.9f0, 0.999f0, 1.0f-5, log_std_init,                    # Optimisers.Adam(eta, (0.9, 0.999), 1e-5): ppo.jl:64-66
         on * Int32(nget(:norm_obs, true)), on * Int32(nget(:norm_reward, true)), on * Int32(nget(:training, true)),
         Float32(nget(:clip_obs, 10)), Float32(nget(:clip_reward, 10)), Float32(nget(:gamma, 0.99)), Float32(nget(:epsilon, 1.0e-8)),
-        env.seed, env.device, 0, 1, 1, env.monitor_window, 0, 0, 0, 0.0f0, 0.0f0, ntuple(_ -> Int32(0), 1))   # profile_events = 1: HIP-event kernel times fill the TimerOutput sections
+        env.seed, env.device, 0, 1, 1, env.monitor_window, 0, 0, 0, 0.0f0, 0.0f0, layer_fields(hidden, act)..., ntuple(_ -> Int32(0), 1))   # profile_events = 1: HIP-event kernel times fill the TimerOutput sections
 end
 
 "(re)create the handle when the algorithm / layer shape changes; Random.seed!(env, seed) + reset!(env) follow"
-function bind!(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int} = [64, 64], log_std_init::Float32 = 0.0f0)
-    key = (alg, hidden, log_std_init)
+function bind!(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int} = [64, 64], log_std_init::Float32 = 0.0f0, act::Int32 = Int32(0))
+    key = (alg, hidden, log_std_init, act)
     if env.handle == C_NULL || env.bound != key
         env.handle != C_NULL && ccall((:dril_destroy, LIB[]), Int32, (Ptr{Cvoid},), env.handle)
-        cfg = Ref(make_config(env, alg, hidden, log_std_init))
+        cfg = Ref(make_config(env, alg, hidden, log_std_init, act))
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:dril_create, LIB[]), Int32, (Ref{DrilConfig}, Ref{Ptr{Cvoid}}), cfg, h))
         env.handle = h[]; env.bound = key; env.optimizer_owner = nothing
@@ -194,10 +197,11 @@ truncated(env::DeviceParallelEnv) = env.last_truncated
 get_info(env::DeviceParallelEnv) = [Dict{String, Any}() for _ in 1:env.n_envs]
 
 # ---- parameters: Lux NamedTuple <-> flat f32 (layout: include/dril_hip.h, dril_set_params) ----
-mlp_of(head) = haskey(head, :layer_3) ? head : head.layer_1             # Box actions: Chain(chain, ReshapeLayer), layer_helpers.jl:77
+mlp_of(head) = hasproperty(head.layer_1, :weight) ? head : head.layer_1   # Box actions: Chain(chain, ReshapeLayer) nests the MLP one level down (layer_helpers.jl:77)
+dense_keys(mlp) = sort!(collect(keys(mlp)); by = k -> parse(Int, last(split(String(k), "_"))))     # layer_1 .. layer_{n+1} in order
 function flatten_params(ps)
     parts = Vector{Float32}[]
-    for head in (mlp_of(ps.actor_head), mlp_of(ps.critic_head)), l in (:layer_1, :layer_2, :layer_3)
+    for head in (mlp_of(ps.actor_head), mlp_of(ps.critic_head)), l in dense_keys(head)
         push!(parts, vec(getproperty(head, l).weight)); push!(parts, vec(getproperty(head, l).bias))   # W is (out x in) column-major
     end
     haskey(ps, :log_std) && push!(parts, vec(ps.log_std))
@@ -205,7 +209,7 @@ function flatten_params(ps)
 end
 function scatter_params!(ps, flat::Vector{Float32})
     off = 0
-    for head in (mlp_of(ps.actor_head), mlp_of(ps.critic_head)), l in (:layer_1, :layer_2, :layer_3)
+    for head in (mlp_of(ps.actor_head), mlp_of(ps.critic_head)), l in dense_keys(head)
         for arr in (getproperty(head, l).weight, getproperty(head, l).bias)
             n = length(arr); copyto!(arr, 1, flat, off + 1, n); off += n
         end
@@ -216,26 +220,25 @@ function scatter_params!(ps, flat::Vector{Float32})
     return ps
 end
 function hidden_dims_of(ps)
-    h = mlp_of(ps.actor_head)
-    return [size(h.layer_1.weight, 1), size(h.layer_2.weight, 1)]
+    h = mlp_of(ps.actor_head); ks = dense_keys(h)
+    return [size(getproperty(h, k).weight, 1) for k in ks[1:end-1]]
 end
 first_dense(l) = hasproperty(l, :activation) ? l : first_dense(first(l.layers))
 """
-The C ABI carries `hidden_dims = [h1, h2]` and tanh (include/dril_hip.h, dril_config); the reference accepts any depth and activation
-(layer_constructors.jl:6-10,55-56, layer_helpers.jl:27-57).  Anything else is REJECTED here — round 1 read layer_1..layer_3 unconditionally and
-would have mis-flattened a deeper net silently.
+The C ABI (include/dril_hip.h, dril_config v2) carries `hidden_dims` of length 1..4 and tanh / relu; the reference accepts any depth and activation
+(layer_constructors.jl:6-10,55-56, layer_helpers.jl:27-57).  Anything else is REJECTED here with a clear message — round 1 read layer_1..layer_3
+unconditionally and would have mis-flattened a deeper net silently.  Returns the activation code of dril_config.
 """
 function check_supported_layer(agent)
     ps = agent.train_state.parameters
-    for (name, head) in ((:actor_head, mlp_of(ps.actor_head)), (:critic_head, mlp_of(ps.critic_head)))
-        keys(head) == (:layer_1, :layer_2, :layer_3) ||
-            error("DRiLHIP: $name has layers $(keys(head)); the device path supports exactly two hidden layers (hidden_dims = [h1, h2]). Use DRiL's CPU train! for this layer.")
-    end
+    ha, hc = hidden_dims_of(ps), [size(getproperty(mlp_of(ps.critic_head), k).weight, 1) for k in dense_keys(mlp_of(ps.critic_head))[1:end-1]]
+    1 <= length(ha) <= 4 || error("DRiLHIP: hidden_dims of length $(length(ha)); the device path supports 1..4 hidden layers. Use DRiL's CPU train! for this layer.")
+    ha == hc || error("DRiLHIP: actor and critic must share hidden_dims (got $ha and $hc)")
+    all(h -> 1 <= h <= 1024, ha) || error("DRiLHIP: hidden widths must be 1..1024")
     act = first_dense(agent.layer.actor_head).activation
-    (act === tanh || nameof(act) === :tanh_fast) ||
-        error("DRiLHIP: activation $(act) is not supported on the device PPO path (tanh only). Use DRiL's CPU train! for this layer.")
-    size(mlp_of(ps.actor_head).layer_2.weight, 1) == size(mlp_of(ps.critic_head).layer_2.weight, 1) || error("DRiLHIP: actor and critic must share hidden_dims")
-    return nothing
+    (act === tanh || nameof(act) === :tanh_fast) && return Int32(0)
+    (nameof(act) === :relu) && return Int32(1)
+    error("DRiLHIP: activation $(act) is not supported on the device PPO path (tanh, relu). Use DRiL's CPU train! for this layer.")
 end
 function push_params!(env, agent)
     flat = flatten_params(agent.train_state.parameters)
@@ -247,10 +250,10 @@ function pull_params!(env, agent)
     scatter_params!(agent.train_state.parameters, flat)
 end
 function bind_agent!(env::DeviceParallelEnv, agent, alg::PPO)
-    check_supported_layer(agent)
+    act = check_supported_layer(agent)
     ps = agent.train_state.parameters
     ls = haskey(ps, :log_std) ? Float32(ps.log_std[1]) : 0.0f0
-    bind!(env, alg, hidden_dims_of(ps), ls)
+    bind!(env, alg, hidden_dims_of(ps), ls, act)
 end
 
 # ---- collect_rollout!(::RolloutBuffer, agent, alg, env::DeviceParallelEnv)  (src/buffers/rollout_buffer.jl:46-90) ----
@@ -432,27 +435,27 @@ observe(w::OnDevice) = observe(w.env)
 act!(w::OnDevice, actions::AbstractVector) = act!(w.env, actions)
 DRiL.log_stats(w::OnDevice, logger::DRiL.AbstractTrainingLogger) = DRiL.log_stats(w.env, logger)
 
-function make_config(w::OnDevice, alg::PPO, hidden::Vector{Int}, log_std_init::Float32)
+function make_config(w::OnDevice, alg::PPO, hidden::Vector{Int}, log_std_init::Float32, act::Int32 = Int32(0))
     opt(x) = isnothing(x) ? (0.0f0, Int32(0)) : (Float32(x), Int32(1))
     cvf, hcvf = opt(alg.clip_range_vf); mgn, hmgn = opt(alg.max_grad_norm); tkl, htkl = opt(alg.target_kl)
     osp, asp = observation_space(w), action_space(w)
     disc = asp isa Discrete
     lo, hi = disc ? (0.0f0, 0.0f0) : (Float32(minimum(asp.low)), Float32(maximum(asp.high)))
     uniform = !disc && all(==(lo), asp.low) && all(==(hi), asp.high)   # one (low, high) pair: ClampAdapter on the device; otherwise clamped in the rollout loop below
-    return DrilConfig(ABI_VERSION, Int32(5), number_of_envs(w), alg.n_steps, hidden[1], hidden[2], 0, Int32(0), disc ? Int32(asp.start) : Int32(1),
+    return DrilConfig(ABI_VERSION, Int32(5), number_of_envs(w), alg.n_steps, hidden[1], hidden[min(2, end)], 0, Int32(0), disc ? Int32(asp.start) : Int32(1),
         alg.gamma, alg.gae_lambda, alg.clip_range, cvf, hcvf, alg.ent_coef, alg.vf_coef, mgn, hmgn, tkl, htkl, Int32(alg.normalize_advantage),
         alg.batch_size, alg.epochs, alg.learning_rate, 0.9f0, 0.999f0, 1.0f-5, log_std_init, 0, 0, 0, 10.0f0, 10.0f0, 0.99f0, 1.0f-8,
         w.seed, w.device, 0, 1, 0, 0, Int32(prod(size(osp))), Int32(disc ? asp.n : prod(size(asp))), Int32(disc),
-        uniform ? lo : 0.0f0, uniform ? hi : 0.0f0, ntuple(_ -> Int32(0), 1))
+        uniform ? lo : 0.0f0, uniform ? hi : 0.0f0, layer_fields(hidden, act)..., ntuple(_ -> Int32(0), 1))
 end
 function bind_agent!(w::OnDevice, agent, alg::PPO)
-    check_supported_layer(agent)
+    act = check_supported_layer(agent)
     ps = agent.train_state.parameters
     ls = haskey(ps, :log_std) ? Float32(ps.log_std[1]) : 0.0f0
-    key = (alg, hidden_dims_of(ps), ls)
+    key = (alg, hidden_dims_of(ps), ls, act)
     if w.handle == C_NULL || w.bound != key
         w.handle != C_NULL && ccall((:dril_destroy, LIB[]), Int32, (Ptr{Cvoid},), w.handle)
-        cfg = Ref(make_config(w, alg, key[2], ls)); h = Ref{Ptr{Cvoid}}(C_NULL)
+        cfg = Ref(make_config(w, alg, key[2], ls, act)); h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:dril_create, LIB[]), Int32, (Ref{DrilConfig}, Ref{Ptr{Cvoid}}), cfg, h))
         w.handle = h[]; w.bound = key; w.optimizer_owner = nothing
     end

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DRIL_ABI_VERSION 1u
+#define DRIL_ABI_VERSION 2u   /* 2: n_hidden / hidden[] / activation (any-depth MLPs, relu) */
 
 typedef struct dril_handle dril_handle;
 
@@ -105,8 +105,8 @@ typedef struct dril_config {
     int32_t env_kind;          /* enum dril_env_kind */
     int32_t n_envs;            /* E on THIS rank */
     int32_t n_steps;           /* T (PPO.n_steps) */
-    int32_t hidden1, hidden2;  /* hidden_dims = [hidden1, hidden2], 1..1024 each: [64,64], [128,128], [256,256] run the fused kernels, every other shape
-                                * (and DRIL_ENV_EXTERNAL) the generic layer-by-layer kernels */
+    int32_t hidden1, hidden2;  /* hidden_dims = [hidden1, hidden2], 1..1024 each, when n_hidden == 0 (below): [64,64], [128,128], [256,256] with tanh run the
+                                * fused kernels, every other shape (and DRIL_ENV_EXTERNAL) the generic layer-by-layer kernels */
     int32_t episode_len;       /* max_steps kwarg: 500 CartPole-v1, 200 Pendulum-v1 */
     int32_t fixed_length_episodes; /* 1: termination disabled (synthetic bench episodes) */
     int32_t action_start;      /* Discrete(n, start): src/spaces.jl:157-164 */
@@ -136,6 +136,11 @@ typedef struct dril_config {
      * the bounds feed ClampAdapter (default_adapters.jl:4-11); low >= high = no clamp */
     int32_t ext_obs_dim, ext_action_dim, ext_discrete;
     float ext_action_low, ext_action_high;
+    /* ActorCriticLayer(...; hidden_dims, activation) in full (src/layers/layer_constructors.jl:6-10,55-56; get_mlp layer_helpers.jl:27-57 builds
+     * Dense(in => h_1, act), ..., Dense(h_{n-1} => h_n, act), Dense(h_n => out)): n_hidden = length(hidden_dims) in 1..4 with hidden[0..n_hidden-1]
+     * (1..1024 each), or 0 = the two-layer form hidden1 / hidden2 above.  activation: 0 tanh (the reference's default), 1 relu.  Every shape other
+     * than two equal tanh layers of 64 / 128 / 256 runs the generic kernels.  Parameter layout per net: {W_1 b_1 ... W_{n+1} b_{n+1}} */
+    int32_t n_hidden, hidden[4], activation;
     int32_t reserved[1];
 } dril_config;
 
@@ -171,7 +176,7 @@ int64_t dril_param_count(const dril_handle* h); /* Lux.parameterlength, layer_lu
 
 /* ---- parameters: agent.train_state.parameters <-> flat f32 -----------------
  * layout: actor_head {W1(H1xD) b1 W2(H2xH1) b2 W3(AoutxH2) b3}, critic_head {W1 b1 W2 b2 W3(1xH2) b3},
- * then log_std(A) for Box actions (layer_lux.jl:4-39); every W column-major (out x in) */
+ * then log_std(A) for Box actions (layer_lux.jl:4-39); every W column-major (out x in).  With n_hidden layers: {W_1 b_1 ... W_{n+1} b_{n+1}} per head */
 int32_t dril_set_params(dril_handle* h, const float* flat, size_t n);
 int32_t dril_get_params(dril_handle* h, float* flat, size_t n);
 /* fresh optimiser state (load_policy_params_and_state! rebuilds Adam, ppo.jl:77-94) */

@@ -13,9 +13,18 @@
  */
 #include "../include/dril_sac.h"
 
+/* SACLayer nets are always two hidden layers here (sac.jl:76-77: hidden_dims = [512, 512]); the on-policy oracle's layout is any-depth */
+typedef struct { int D, H1, H2, O; size_t w1, b1, w2, b2, w3, b3, end; } sac_net;
+static sac_net sac_net_at(size_t base, int D, int H1, int H2, int O) {
+    sac_net n; n.D = D; n.H1 = H1; n.H2 = H2; n.O = O;
+    n.w1 = base; n.b1 = n.w1 + (size_t)H1 * D; n.w2 = n.b1 + H1; n.b2 = n.w2 + (size_t)H2 * H1;
+    n.w3 = n.b2 + H2; n.b3 = n.w3 + (size_t)O * H2; n.end = n.b3 + O;
+    return n;
+}
+
 typedef struct orc_sac {
     dril_sac_config cfg; env_spec es; int D, A, H1, H2; float act_lo, act_hi;   /* bounds of the agent-facing Box action space */
-    net_layout actor, q[2]; size_t log_std_off, P, Pq;
+    sac_net actor, q[2]; size_t log_std_off, P, Pq;
     float *params, *adam_m, *adam_v, *target;
     float bt_actor[2], bt_critic[2];          /* running beta powers of the two groups of leaves (Optimisers keeps them per leaf) */
     float log_ent, ent_m, ent_v, ent_bt[2];   /* ent_train_state, sac.jl:176-178 */
@@ -37,7 +46,7 @@ static void dense_a(const float* W, const float* b, int out, int in, const float
     if (act == 0) for (int o = 0; o < out; ++o) y[o] = tanhf(y[o]);
     else if (act == 1) for (int o = 0; o < out; ++o) y[o] = y[o] > 0.0f ? y[o] : 0.0f;
 }
-static void mlp_fwd_a(const float* P, const net_layout* n, const float* x, float* h1, float* h2, float* out, int act) {
+static void mlp_fwd_a(const float* P, const sac_net* n, const float* x, float* h1, float* h2, float* out, int act) {
     dense_a(P + n->w1, P + n->b1, n->H1, n->D, x, h1, act);
     dense_a(P + n->w2, P + n->b2, n->H2, n->H1, h1, h2, act);
     dense_a(P + n->w3, P + n->b3, n->O, n->H2, h2, out, -1);
@@ -45,7 +54,7 @@ static void mlp_fwd_a(const float* P, const net_layout* n, const float* x, float
 static inline float dact(float h, int act) { return act == 0 ? 1.0f - h * h : (h > 0.0f ? 1.0f : 0.0f); }
 /* reverse pass of one sample given dL/dout; accumulates parameter gradients into G (f64, flat layout of P; may be NULL) and
  * writes dL/dx into dx (may be NULL) */
-static void mlp_bwd_a(const float* P, const net_layout* n, const float* x, const float* h1, const float* h2, const float* dout,
+static void mlp_bwd_a(const float* P, const sac_net* n, const float* x, const float* h1, const float* h2, const float* dout,
                       double* G, float* dx, float* dz2, float* dz1, int act) {
     const int H1 = n->H1, H2 = n->H2, O = n->O, D = n->D;
     for (int j = 0; j < H2; ++j) {
@@ -128,7 +137,7 @@ ORC_API int32_t orc_sac_create(const dril_sac_config* cfg, orc_sac** out) {
     c->act_hi = act_bound(cfg->env_kind); c->act_lo = -c->act_hi;
     if (ext) { c->es.kind = DRIL_ENV_EXTERNAL; c->es.D = cfg->ext_obs_dim; c->es.S = 0; c->es.A = cfg->ext_action_dim; c->es.discrete = 0; c->act_lo = cfg->ext_action_low; c->act_hi = cfg->ext_action_high; }
     const int D = c->D = c->es.D, A = c->A = c->es.A, H1 = c->H1 = cfg->hidden1, H2 = c->H2 = cfg->hidden2, E = cfg->n_envs;
-    c->actor = net_at(0, D, H1, H2, A); c->q[0] = net_at(c->actor.end, D + A, H1, H2, 1); c->q[1] = net_at(c->q[0].end, D + A, H1, H2, 1);
+    c->actor = sac_net_at(0, D, H1, H2, A); c->q[0] = sac_net_at(c->actor.end, D + A, H1, H2, 1); c->q[1] = sac_net_at(c->q[0].end, D + A, H1, H2, 1);
     c->Pq = c->q[0].end - c->q[0].w1; c->log_std_off = c->q[1].end; c->P = c->log_std_off + A;
     c->params = (float*)calloc(c->P, 4); c->adam_m = (float*)calloc(c->P, 4); c->adam_v = (float*)calloc(c->P, 4);
     c->target = (float*)calloc(2 * c->Pq, 4); c->g_critic = (float*)calloc(c->P, 4); c->g_actor = (float*)calloc(c->P, 4);
@@ -220,7 +229,7 @@ ORC_API int32_t orc_sac_predict_q(orc_sac* c, const float* obs, const float* act
         for (int64_t b = 0; b < B; ++b) {
             memcpy(x, obs + b * D, D * 4); memcpy(x + D, actions + b * A, A * 4);
             for (int k = 0; k < 2; ++k) {
-                if (use_target) { net_layout n = net_at((size_t)k * c->Pq, D + A, c->H1, c->H2, 1); mlp_fwd_a(c->target, &n, x, h1, h2, q + b * 2 + k, act); }
+                if (use_target) { sac_net n = sac_net_at((size_t)k * c->Pq, D + A, c->H1, c->H2, 1); mlp_fwd_a(c->target, &n, x, h1, h2, q + b * 2 + k, act); }
                 else mlp_fwd_a(c->params, &c->q[k], x, h1, h2, q + b * 2 + k, act);
             }
         }

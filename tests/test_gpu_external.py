@@ -332,6 +332,89 @@ def test_device_env_with_other_hidden_dims(pkg, oracle_mod, kind, H1, H2, norm):
     assert len(er) == 5 and (el >= 1).all() and (el <= 10).all()
 
 
+# ---- ActorCriticLayer(...; hidden_dims, activation) in full: any depth 1..4 and relu (dril_config v2) on the generic kernels ------------------------------
+@pytest.mark.parametrize("kind,hidden,act,norm", [(0, (48,), 0, 0), (1, (40, 24, 56), 0, 1), (0, (32, 32, 16, 8), 1, 0), (1, (64, 64), 1, 0), (3, (96, 20, 33), 1, 0), (4, (128, 128, 128), 0, 0)])
+def test_any_depth_and_relu_on_device(pkg, oracle_mod, kind, hidden, act, norm):
+    """hidden_dims of length 1, 3, 4 and relu (the reference accepts any, layer_constructors.jl:6-10,55-56; layer_helpers.jl:27-57) on device envs: forward /
+    evaluate / loss + gradient / rollout (truncation bootstraps, NormalizeWrapperEnv) / update against the oracle, whose any-depth MLP is pinned to torch
+    autograd (tests/test_oracle_crosschecks.py::test_any_depth_and_relu_vs_torch_autograd)"""
+    capi = pkg._capi
+    E, T = 40, 24
+    c = capi.default_config(kind)
+    for k, v in dict(n_envs=E, n_steps=T, episode_len=10, batch_size=E * T // 3, epochs=2, norm_training=norm, norm_obs=norm, norm_reward=norm, ent_coef=0.01,
+                     n_hidden=len(hidden), activation=act).items():
+        setattr(c, k, v)
+    for i, w in enumerate(hidden):
+        c.hidden[i] = w
+    h, o = pkg.Handle(c), oracle_mod.Oracle(c)
+    assert h.P == o.P
+    flat = _params(h.P, 12, 0.15); h.set_params(flat); o.set_params(flat)
+    # layer(obs, ps, st), evaluate_actions, predict_values
+    rng = np.random.default_rng(3)
+    B = 333
+    obs = rng.uniform(-1.5, 1.5, (B, h.D)).astype(np.float32)
+    noise = rng.random(B) if h.discrete else rng.standard_normal((B, h.A)).astype(np.float32)
+    ah, vh, lh = h.policy_forward(obs, noise); ao, vo, lo = o.policy_forward(obs, noise)
+    np.testing.assert_allclose(vh, vo, atol=5e-5, rtol=5e-5)
+    same = (ah == ao) if h.discrete else np.ones(B, bool)
+    assert same.mean() >= 0.99
+    np.testing.assert_allclose(lh[same], lo[same], atol=1e-4, rtol=1e-4)
+    ve, le, ee = h.evaluate_actions(obs, ao); vo2, lo2, eo2 = o.evaluate_actions(obs, ao)
+    np.testing.assert_allclose(le, lo2, atol=1e-4, rtol=1e-4); np.testing.assert_allclose(ee, eo2, atol=5e-5, rtol=5e-5)
+    # (alg::PPO)(...) and its gradient, every layer
+    act_b = (rng.integers(0, h.A, B) + c.action_start).astype(np.int32) if h.discrete else rng.normal(0, 1, (B, h.A)).astype(np.float32)
+    adv, ret, ov = (rng.standard_normal(B).astype(np.float32) for _ in range(3))
+    lp = (o.evaluate_actions(obs, act_b)[1] + rng.normal(0, 0.1, B)).astype(np.float32)
+    lh_, sh_, gh = h.ppo_loss_grad(obs, act_b, adv, ret, lp, ov); lo_, so_, go = o.ppo_loss_grad(obs, act_b, adv, ret, lp, ov)
+    assert lh_ == pytest.approx(lo_, rel=1e-4)
+    np.testing.assert_allclose(sh_, so_, rtol=3e-4, atol=3e-6)
+    assert np.linalg.norm(gh - go) <= 3e-4 * np.linalg.norm(go)
+    if act:
+        assert (gh == 0).sum() < gh.size // 2                                          # relu: dead units give exact zeros, but not everywhere
+    # rollout + update
+    h.env_reset(4); o.env_reset(4)
+    nz = np.random.default_rng(0).random(E * T) if h.discrete else np.random.default_rng(0).standard_normal((E * T, h.A)).astype(np.float32)
+    h.set_noise(nz); o.set_noise(nz)
+    h.collect_rollout(); o.collect_rollout()
+    fl = o.buffer(capi.BUF_FLAGS)
+    assert (fl & 2).any()
+    if h.discrete:
+        ok = np.cumprod(h.buffer(capi.BUF_ACTIONS).reshape(T, E) == o.buffer(capi.BUF_ACTIONS).reshape(T, E), axis=0).astype(bool).all(axis=0)
+        assert ok.mean() >= 0.9
+    else:
+        ok = np.ones(E, bool)
+    for which, tol in ((capi.BUF_OBSERVATIONS, 2e-4), (capi.BUF_VALUES, 3e-4), (capi.BUF_LOGPROBS, 3e-4), (capi.BUF_REWARDS, 3e-4), (capi.BUF_ADVANTAGES, 3e-3), (capi.BUF_RETURNS, 3e-3)):
+        a, b = h.buffer(which).reshape(T, E, -1), o.buffer(which).reshape(T, E, -1)
+        np.testing.assert_allclose(a[:, ok], b[:, ok], atol=tol, rtol=tol)
+    for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+        h.set_buffer(which, o.buffer(which))
+    perm = np.stack([np.random.default_rng(e).permutation(E * T) for e in range(c.epochs)]).astype(np.int64)
+    h.set_permutation(perm); o.set_permutation(perm)
+    sh, so = h.ppo_update(), o.ppo_update()
+    assert sh.n_updates == so.n_updates == 6 and sh.loss == pytest.approx(so.loss, rel=2e-4, abs=1e-6)
+    np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=3e-4, atol=3e-6)
+
+
+def test_relu_three_layer_agent_learns_through_the_mirror(pkg):
+    """the host mirror carries hidden_dims / activation end to end: ActorCriticLayer(...; hidden_dims = [32, 32, 32], activation = relu) trains on CartPole"""
+    env = pkg.DeviceParallelEnv(pkg.CartPoleEnv(max_steps=200), 256, seed=1)
+    alg = pkg.PPO(n_steps=64, batch_size=2048, epochs=4, learning_rate=1e-3)
+    layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(32, 32, 32), activation="relu")
+    agent = pkg.Agent(layer, alg, seed=0)
+    assert layer.parameterlength() == pkg.flatten_params(agent.train_state.parameters).size
+    assert sorted(agent.train_state.parameters["actor_head"]) == ["layer_1", "layer_2", "layer_3", "layer_4"]
+    base = pkg.evaluate_agent(agent, env, n_eval_episodes=64, deterministic=True)
+    stats, _ = pkg.train_(agent, env, alg, 30 * 64 * 256)
+    assert np.isfinite(stats["losses"]).all()
+    trained = pkg.evaluate_agent(agent, env, n_eval_episodes=64, deterministic=True)
+    print(f"[relu 3-layer] CartPole mean episode reward {base['mean_reward']:.1f} -> {trained['mean_reward']:.1f}")
+    assert trained["mean_reward"] > max(2 * base["mean_reward"], 80.0)
+    with pytest.raises(ValueError):
+        pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(8, 8, 8, 8, 8))
+    with pytest.raises(ValueError):
+        pkg.ActorCriticLayer(env.observation_space(), env.action_space(), activation="gelu")
+
+
 def test_forced_generic_equals_fused(pkg, monkeypatch):
     """DRIL_FORCE_GENERIC=1 runs a [64,64] CartPole handle on the generic kernels: same rollout (same env-keyed noise) and update as the fused kernels"""
     capi = pkg._capi

@@ -8,15 +8,21 @@ import pytest
 import torch
 
 
-def _nets(flat, D, H, A, discrete, H2=None):
-    """split the flat parameter vector (include/dril_hip.h layout) into torch tensors (out x in, column-major)"""
-    H2 = H if H2 is None else H2
+def _hidden_of(cfg):
+    """hidden_dims and activation carried by a dril_config (n_hidden == 0: the two-layer tanh form)"""
+    hd = [cfg.hidden[i] for i in range(cfg.n_hidden)] if cfg.n_hidden else [cfg.hidden1, cfg.hidden2]
+    return hd, (torch.relu if cfg.activation else torch.tanh)
+
+
+def _nets(flat, D, hidden, A, discrete):
+    """split the flat parameter vector (include/dril_hip.h layout: {W_1 b_1 ... W_{n+1} b_{n+1}} per net) into torch tensors (out x in, column-major)"""
     t = torch.tensor(flat, dtype=torch.float64, requires_grad=True)
     off = 0
     out = []
     for O in (A, 1):
         net = []
-        for (o, i) in ((H, D), (H2, H), (O, H2)):
+        dims = [D, *hidden, O]
+        for i, o in zip(dims[:-1], dims[1:]):
             W = t[off:off + o * i].reshape(i, o).T; off += o * i
             b = t[off:off + o]; off += o
             net.append((W, b))
@@ -25,22 +31,24 @@ def _nets(flat, D, H, A, discrete, H2=None):
     return t, out[0], out[1], ls
 
 
-def _mlp(net, x):
-    h = torch.tanh(x @ net[0][0].T + net[0][1])
-    h = torch.tanh(h @ net[1][0].T + net[1][1])
-    return h @ net[2][0].T + net[2][1]
+def _mlp(net, x, act=torch.tanh):
+    h = x
+    for W, b in net[:-1]:
+        h = act(h @ W.T + b)
+    return h @ net[-1][0].T + net[-1][1]
 
 
 def torch_ppo_loss(flat, cfg, obs, actions, adv, ret, old_logp, old_val, discrete, A):
     """(alg::PPO)(policy, ps, st, batch): src/algorithms/ppo.jl:365-407 written with torch ops (float64)."""
     D = obs.shape[1]
-    t, actor, critic, ls = _nets(flat, D, cfg.hidden1, A, discrete, cfg.hidden2)
+    hidden, act = _hidden_of(cfg)
+    t, actor, critic, ls = _nets(flat, D, hidden, A, discrete)
     x = torch.tensor(obs, dtype=torch.float64)
     advt = torch.tensor(adv, dtype=torch.float64)
     if cfg.normalize_advantage:
         advt = (advt - advt.mean()) / (advt.std(unbiased=True) + 1e-8)      # ppo.jl:350-356
-    out = _mlp(actor, x)
-    values = _mlp(critic, x)[:, 0]
+    out = _mlp(actor, x, act)
+    values = _mlp(critic, x, act)[:, 0]
     if discrete:
         p = torch.softmax(out, dim=1)
         a = torch.tensor(actions - cfg.action_start, dtype=torch.long)
@@ -98,6 +106,29 @@ def test_ppo_loss_and_gradient_vs_torch_autograd(oracle_mod, pkg, kind, B, varia
     assert 0.0 < stats[3] < 0.95                                  # a real fraction of ratios is clipped
     np.testing.assert_allclose(grads, tg, rtol=2e-3, atol=2e-6)
     assert np.linalg.norm(grads - tg) <= 1e-4 * np.linalg.norm(tg)
+
+
+@pytest.mark.parametrize("kind,hidden,act,B", [(0, (48,), 0, 100), (1, (40, 24, 56), 0, 257), (0, (32, 32, 16, 8), 1, 64), (1, (64, 64), 1, 129), (3, (96, 20, 33), 1, 77)])
+def test_any_depth_and_relu_vs_torch_autograd(oracle_mod, pkg, kind, hidden, act, B):
+    """ActorCriticLayer(...; hidden_dims, activation) beyond two tanh layers (layer_constructors.jl:6-10,55-56; get_mlp layer_helpers.jl:27-57): the oracle's
+    any-depth MLP (1 to 4 hidden layers, tanh / relu) — loss, statistics and every layer's gradient against torch autograd"""
+    cfg = pkg._capi.default_config(kind); cfg.n_envs, cfg.n_steps = 2, 2; cfg.ent_coef = 0.01
+    cfg.n_hidden = len(hidden); cfg.activation = act
+    for i, h in enumerate(hidden):
+        cfg.hidden[i] = h
+    o = oracle_mod.Oracle(cfg)
+    dims = lambda O: [o.D, *hidden, O]
+    P = sum(i * j + j for O in (o.A, 1) for i, j in zip(dims(O)[:-1], dims(O)[1:])) + (0 if o.discrete else o.A)
+    assert o.P == P
+    flat = (np.random.default_rng(B).standard_normal(o.P) * 0.3).astype(np.float32)
+    o.set_params(flat)
+    batch = make_batch(o, cfg, B, 5 + B, o.discrete, o.A)
+    loss, stats, grads = o.ppo_loss_grad(*batch)
+    tl, ts, tg = torch_ppo_loss(flat, cfg, *batch, o.discrete, o.A)
+    assert loss == pytest.approx(tl, rel=1e-4)
+    np.testing.assert_allclose(stats, ts, rtol=2e-4, atol=2e-6)
+    assert np.linalg.norm(grads - tg) <= 1e-4 * np.linalg.norm(tg)
+    np.testing.assert_allclose(grads, tg, rtol=5e-3, atol=5e-6)
 
 
 def _ext_cfg(pkg, D, A, discrete, H1, H2):
