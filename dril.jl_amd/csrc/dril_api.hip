@@ -336,7 +336,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
         G = ga; Gc = h->num_cus - ga;
         if (G > h->Gmax) G = h->Gmax; if (Gc > h->Gmax) Gc = h->Gmax;
     }
-    if (h->generic) { G = generic_pick_slabs(h->gd, count, h->Gmax); if (G < 1) return fail(h, DRIL_ERR_UNSUPPORTED, "minibatch too large for the generic path's workspace"); }
+    if (h->generic) { G = generic_pick_slabs(h->gd, count, h->Gmax); if (G < 1) return fail(h, DRIL_ERR_UNSUPPORTED, "minibatch too large for the generic path's workspace"); Gc = G; }
     { int rcw = ensure_wimg(h); if (rcw) return rcw; }
     const double* adv_stats = h->adv_stats;
     // launch-bound regime (the reference's default batch_size = 64): the advantage moments are computed inside the grad kernel and

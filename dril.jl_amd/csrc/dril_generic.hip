@@ -45,17 +45,16 @@ NetLay net_lay(const GenericDims& d, int base, int O) {
     return n;
 }
 int hidden_sum(const GenericDims& d) { int s = 0; for (int l = 0; l < d.nh; ++l) s += d.H[l]; return s; }
-// hidden activations of `nets` nets over R rows live in ONE buffer: layer l's block starts at hoff(l) * nets * R floats; inside it net z follows net z - 1
-// (R * H[l] floats apart), one row per sample — the layout mlp_forward_both's batched launches write and the reverse pass reads
-size_t hoff(const GenericDims& d, int l) { size_t s = 0; for (int k = 0; k < l; ++k) s += (size_t)d.H[k]; return s; }
+// hidden activations: one 16-byte-aligned block per layer (hb[l]); inside a block net z follows net z - 1 (n * H[l] floats apart), one row per sample —
+// the layout mlp_forward_both's batched launches write and the reverse pass reads
 int act_epi(const GenericDims& d) { return d.act ? EPI_RELU : EPI_TANH; }
 int mask_epi(const GenericDims& d) { return d.act ? EPI_MASK_RELU : EPI_MASK_TANH; }
 
-// out[n][O] = net(X[n][D]) with every hidden activation kept in hb (layer l at hb + hoff(l) * n): Dense(in => h, act) ... Dense(h_nh => out), layer_helpers.jl:27-57
-hipError_t mlp_forward(const GenericDims& d, const float* P, const NetLay& L, const float* X, int n, float* hb, float* out, hipStream_t s) {
+// out[n][O] = net(X[n][D]) with every hidden activation kept (layer l in hb[l]): Dense(in => h, act) ... Dense(h_nh => out), layer_helpers.jl:27-57
+hipError_t mlp_forward(const GenericDims& d, const float* P, const NetLay& L, const float* X, int n, float* const* hb, float* out, hipStream_t s) {
     const float* in = X;
     for (int l = 0; l < L.nl; ++l) {
-        float* dst = l == d.nh ? out : hb + hoff(d, l) * (size_t)n;
+        float* dst = l == d.nh ? out : hb[l];
         GemmArgs g = gargs();                                                       // y = act(W x + b), Lux.Dense
         g.A = P + L.w[l]; g.sAm = 1; g.sAk = L.out[l]; g.B = in; g.sBk = 1; g.sBn = L.in[l]; g.C = dst; g.sCm = 1; g.sCn = L.out[l]; g.bias = P + L.b[l];
         g.M = L.out[l]; g.N = n; g.K = L.in[l]; g.epi = l == d.nh ? EPI_NONE : act_epi(d);
@@ -68,11 +67,11 @@ hipError_t mlp_forward(const GenericDims& d, const float* P, const NetLay& L, co
 // both nets of the ActorCriticLayer on the same rows: their hidden layers have the same shapes, so each is ONE launch with blockIdx.z = net
 // (layer l's block of hb holds the actor's activations followed by the critic's, n * H[l] floats apart); the output layers differ in width and share a
 // launch through the pair kernel while the batch is small.  Halves the launch count of a rollout step / small minibatch (latency-bound there).
-hipError_t mlp_forward_both(const GenericDims& d, const float* P, const NetLay& La, const NetLay& Lc, const float* X, int n, float* hb, float* out, float* v, hipStream_t s) {
+hipError_t mlp_forward_both(const GenericDims& d, const float* P, const NetLay& La, const NetLay& Lc, const float* X, int n, float* const* hb, float* out, float* v, hipStream_t s) {
     const long long zP = (long long)Lc.w[0] - La.w[0];                              // same layout in both nets up to the output layer
     const float* in = X; long long zin = 0;
     for (int l = 0; l < d.nh; ++l) {
-        float* dst = hb + hoff(d, l) * 2 * (size_t)n;
+        float* dst = hb[l];
         GemmArgs g = gargs();
         g.A = P + La.w[l]; g.sAm = 1; g.sAk = La.out[l]; g.zA = zP; g.B = in; g.sBk = 1; g.sBn = La.in[l]; g.zB = zin; g.C = dst; g.sCm = 1; g.sCn = La.out[l]; g.zC = (long long)n * La.out[l];
         g.bias = P + La.b[l]; g.zBias = zP; g.M = La.out[l]; g.N = n; g.K = La.in[l]; g.epi = act_epi(d);
@@ -324,7 +323,7 @@ int generic_slab_size(const GenericDims& d, bool actor) {
     return (generic_net_size(d, actor ? d.A : 1) + ((actor && !d.discrete) ? d.A : 0) + 8 + 3) / 4 * 4;
 }
 
-static size_t grad_floats_per_row(const GenericDims& d) { return (size_t)d.D + 3 * (size_t)d.A + 4 * (size_t)hidden_sum(d) + 40; }
+static size_t grad_floats_per_row(const GenericDims& d) { return (size_t)d.D + 3 * (size_t)d.A + 4 * (size_t)hidden_sum(d) + 40 + 8 * kMaxHidden; }
 static int64_t grad_rows_max(const GenericDims& d) { return std::max<int64_t>((int64_t)(((size_t)1 << 29) / grad_floats_per_row(d)), 64); }   // <= 2 GiB of workspace per pass
 int generic_pick_slabs(const GenericDims& d, int64_t count, int Gmax) {
     if (count < 1 || Gmax < 1) return -1;
@@ -340,13 +339,14 @@ int generic_pick_slabs(const GenericDims& d, int64_t count, int Gmax) {
 hipError_t generic_policy(const GenericDims& d, const PolicyArgs& a, GenericWs& ws, hipStream_t s) {
     if (a.B <= 0) return hipSuccess;
     if (d.A > kMaxOut) return hipErrorInvalidValue;
-    const size_t per_row = 2 * (size_t)hidden_sum(d) + d.A + 1 + 8;
+    const size_t per_row = 2 * (size_t)hidden_sum(d) + d.A + 1 + 8 + 4 * kMaxHidden;
     const NetLay La = net_lay(d, a.actor.w1, d.A), Lc = net_lay(d, a.critic.w1, 1);
     int64_t Rmax = (int64_t)(((size_t)1 << 28) / per_row); Rmax = std::max<int64_t>(Rmax / 1024 * 1024, 1024);   // <= 1 GiB of activations per chunk
     const int64_t R = std::min<int64_t>(a.B, Rmax);
     hipError_t e = ws_reserve(ws, (size_t)R * per_row + 64); if (e != hipSuccess) return e;
     Carver c{ws.p};
-    float* hb = c.take((size_t)2 * R * hidden_sum(d)); float* out = c.take((size_t)R * d.A);
+    float* hb[kMaxHidden]; for (int l = 0; l < d.nh; ++l) hb[l] = c.take((size_t)2 * R * d.H[l]);
+    float* out = c.take((size_t)R * d.A);
     for (int64_t r0 = 0; r0 < a.B; r0 += R) {
         const int64_t n = std::min<int64_t>(R, a.B - r0);
         const float* X = a.obs + r0 * d.D;
@@ -376,10 +376,11 @@ hipError_t generic_ppo_grad(const GenericDims& d, const GradArgs& a, GenericWs& 
     Carver c{ws.p};
     float* X = c.take((size_t)R * d.D); float* act = c.take((size_t)R * d.A); float* adv = c.take(R); float* lpo = c.take(R); float* ret = c.take(R);
     float* vold = c.take(R); float* valid = c.take(R);
-    const int HS = hidden_sum(d);
     const NetLay La = net_lay(d, a.actor.w1, d.A), Lc = net_lay(d, a.critic.w1, 1);
-    float* hb = c.take((size_t)2 * R * HS); float* outa = c.take((size_t)R * d.A); float* v = c.take(R);
-    float* dout = c.take((size_t)R * d.A); float* dv = c.take(R); float* dlp = c.take(R); float* dzb = c.take((size_t)2 * R * HS);   // per layer: the actor's rows, then the critic's
+    float* hb[kMaxHidden]; float* dzb[kMaxHidden];                                                              // per layer: the actor's rows, then the critic's
+    for (int l = 0; l < d.nh; ++l) { hb[l] = c.take((size_t)2 * R * d.H[l]); dzb[l] = c.take((size_t)2 * R * d.H[l]); }
+    float* outa = c.take((size_t)R * d.A); float* v = c.take(R);
+    float* dout = c.take((size_t)R * d.A); float* dv = c.take(R); float* dlp = c.take(R);
     for (int slab0 = 0; slab0 < G; slab0 += Gp) {
         const int Gn = std::min(Gp, G - slab0); const int64_t Rn = (int64_t)Gn * Cr, row0 = (int64_t)slab0 * Cr;
         GatherArgs ga{a, d.D, d.A, d.discrete, row0, Rn, X, act, adv, lpo, ret, vold, valid};
@@ -389,8 +390,8 @@ hipError_t generic_ppo_grad(const GenericDims& d, const GradArgs& a, GenericWs& 
         e = mlp_forward_both(d, a.params, La, Lc, X, (int)Rn, hb, outa, v, s); if (e != hipSuccess) return e;
         const float* ha[kMaxHidden]; const float* hc[kMaxHidden]; float* dza[kMaxHidden]; float* dzc[kMaxHidden];
         for (int l = 0; l < d.nh; ++l) {                                               // layer l's block: the actor's rows, then the critic's (mlp_forward_both)
-            ha[l] = hb + hoff(d, l) * 2 * (size_t)Rn; hc[l] = ha[l] + (size_t)Rn * d.H[l];
-            dza[l] = dzb + hoff(d, l) * 2 * (size_t)Rn; dzc[l] = dza[l] + (size_t)Rn * d.H[l];
+            ha[l] = hb[l]; hc[l] = ha[l] + (size_t)Rn * d.H[l];
+            dza[l] = dzb[l]; dzc[l] = dza[l] + (size_t)Rn * d.H[l];
         }
         LossHeadArgs lh{a, d.A, d.discrete, Rn, Cr, slab0, outa, v, act, adv, lpo, ret, vold, valid, dout, dv, dlp};
         generic_loss_head_kernel<<<Gn, 256, 0, s>>>(lh);
