@@ -6,8 +6,8 @@
     ReplayBuffer(obs_space, act_space, capacity)                src/buffers/replay_buffer.jl
     sac_train_(agent, env, alg, max_steps)                      sac.jl:406-549  ->  (agent, replay_buffer, training_stats, timer)
 
-`SacHandle` types one dril_sac_handle*; it takes the ctypes library and symbol prefix as arguments so that tests can drive the
-CPU oracle ("orc_sac_") through the very same wrapper.  The product default is libdril_hip.so — there is no fallback.
+`SacHandle` types one dril_sac_handle* of libdril_hip.so — there is no fallback and no way to point it elsewhere; the parity tests drive the
+CPU oracle ("orc_sac_" symbols, same signatures) through a subclass that lives in tests/oracle_lib.py.
 """
 from __future__ import annotations
 
@@ -166,19 +166,18 @@ def make_sac_config(env, n_envs: int, alg: SAC, layer: SACLayer, *, seed: int = 
 # --------------------------------------------------------------------------------------------
 # typed wrapper of one dril_sac_handle*
 # --------------------------------------------------------------------------------------------
-def _type_lib(lib: C.CDLL, prefix: str):
-    for name, (res, args) in capi._SAC_SIG.items():
-        fn = getattr(lib, prefix + name, None)
-        if fn is not None:
-            fn.restype, fn.argtypes = res, args
-
-
 class SacHandle:
-    def __init__(self, cfg: DrilSacConfig, lib: Optional[C.CDLL] = None, prefix: str = "dril_sac_"):
-        self.lib = lib or capi.load_library()
-        self.prefix = prefix
-        if lib is not None:
-            _type_lib(lib, prefix)
+    """typed wrapper of one dril_sac_handle* of libdril_hip.so (there is no other backend: the CPU oracle is driven by a subclass that lives under tests/)"""
+    _PREFIX = "dril_sac_"
+
+    @classmethod
+    def _load(cls) -> C.CDLL:
+        return capi.load_library()
+
+    def __init__(self, cfg: DrilSacConfig):
+        self.lib = self._load()
+        self.prefix = self._PREFIX
+        prefix = self.prefix
         self.cfg = cfg
         self._h = C.c_void_p()
         rc = self._f("create")(C.byref(cfg), C.byref(self._h))

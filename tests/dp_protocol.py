@@ -1,4 +1,6 @@
-"""Data-parallel protocol of the PPO update, stated on the host.
+"""TEST INFRASTRUCTURE (moved out of the product package in round 2: nothing in the product imports it).
+
+Data-parallel protocol of the PPO update, stated on the host.
 
 libdril_hip.so runs this protocol in C++ on its own stream (dril_api.hip: ppo_step) with RCCL all-reduces; this
 module states the same protocol over a pluggable `allreduce(np.ndarray) -> np.ndarray` (sum over ranks) so that the

@@ -324,4 +324,16 @@ def sac_oracle(cfg):
     L.orc_polyak_update.argtypes = [_P, _P, C.c_size_t, C.c_float]
     L.orc_sac_schedule.restype = None
     L.orc_sac_schedule.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.POINTER(C.c_int64)] * 4
-    return _pkg.SacHandle(cfg, lib=L, prefix="orc_sac_")
+    for name, (res, args) in _pkg._capi._SAC_SIG.items():
+        fn = getattr(L, "orc_sac_" + name, None)
+        if fn is not None:
+            fn.restype, fn.argtypes = res, args
+
+    class OracleSacHandle(_pkg.SacHandle):
+        """the product's typed wrapper pointed at the CPU oracle's symbols — test infrastructure, which is why the switch lives here and not in the package"""
+        _PREFIX = "orc_sac_"
+
+        @classmethod
+        def _load(cls):
+            return L
+    return OracleSacHandle(cfg)

@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the data-parallel protocol of the PPO update (dril.jl_amd/distributed.py, mirrored in C++ by
+"""CPU, world_size 2, gloo: the data-parallel protocol of the PPO update (tests/dp_protocol.py — a host statement of what dril_api.hip does in C++; the LIBRARY's own world_size > 1 code is executed by tests/test_gpu_dataparallel.py; mirrored in C++ by
 dril_api.hip: ppo_step) reproduces the single-process result.  The compute backend here is the CPU oracle (the checker);
 the all-reduce is torch.distributed over gloo on 127.0.0.1."""
 import os
@@ -20,7 +20,7 @@ def _worker(rank, world, port, q):
     import __graft_entry__ as g
     pkg = g.load_package()
     import oracle_lib
-    from dril_jl_amd import distributed as D
+    import dp_protocol as D
     dist.init_process_group("gloo", rank=rank, world_size=world)
     capi = pkg._capi
 
@@ -112,7 +112,7 @@ def test_env_shards_are_seeded_by_global_index(pkg, oracle_mod):
         c = capi.default_config(capi.ENV_CARTPOLE); c.n_envs, c.n_steps, c.rank, c.world_size, c.batch_size = 4, 2, rank, 2, 2
         s = oracle_mod.Oracle(c); s.env_reset(77)
         assert np.array_equal(s.env_get_state()[0], full[4 * rank:4 * rank + 4])
-    from dril_jl_amd import distributed as D
+    import dp_protocol as D
     assert D.env_seed(77, 1, 4, 2) == 77 + 6 and D.local_batch_size(64, 8) == 8
     with pytest.raises(ValueError):
         D.local_batch_size(10, 4)
