@@ -26,5 +26,7 @@ GemmArgs gemm_args();
 hipError_t launch_gemm(GemmArgs g, int Z, hipStream_t s);
 // two independent contractions in one launch (a layer's [dW | db] and its dz): blockIdx.z < Za runs `a`
 hipError_t launch_gemm_pair(GemmArgs a, int Za, GemmArgs b, int Zb, hipStream_t s);
+// up to four independent contractions in one launch (the split-K shape, like the pair): contraction i runs Zs[i] batches
+hipError_t launch_gemm_multi(const GemmArgs* gs, const int* Zs, int n, hipStream_t s);
 
 }  // namespace dril

@@ -73,13 +73,13 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, float* __restrict_
     }
 }
 template <bool SPLIT>
-__device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)[kGemmWaves][16][kRedStride]) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)[kGemmWaves][16][kRedStride], int bx = (int)blockIdx.x, int by = (int)blockIdx.y) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
     const float* __restrict__ A = g.A + (size_t)z * g.zA;
     const float* __restrict__ B = g.B + (size_t)(z / g.zdivB) * g.zB;
-    const int tile_n = SPLIT ? (int)blockIdx.y : (int)blockIdx.y * kGemmWaves + wave;
-    if (SPLIT && ((int)blockIdx.x * 32 >= g.M || tile_n * 32 >= g.N)) return;                  // pair launches: the grid covers the larger problem
-    const int m = blockIdx.x * 32 + c, n = tile_n * 32 + c;
+    const int tile_n = SPLIT ? by : by * kGemmWaves + wave;
+    if (SPLIT && (bx * 32 >= g.M || tile_n * 32 >= g.N)) return;                               // pair launches: the grid covers the larger problem
+    const int m = bx * 32 + c, n = tile_n * 32 + c;
     const int Q = (g.K + 7) >> 3, Qw = SPLIT ? (Q + kGemmWaves - 1) / kGemmWaves : Q, q0 = SPLIT ? wave * Qw : 0, q1 = min(Q, q0 + Qw);
     const bool ones = g.ones_n && n == g.N - 1;
     f32x16 acc;
@@ -112,7 +112,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)
     // element e of a 32x32 tile: m_local = e & 31 (fastest, C's unit stride), n_local = e >> 5; it sits in register rr of lane ll
     if (SPLIT) {
         const bool need_aux = aux && (g.epi == EPI_MASK_RELU || g.epi == EPI_MASK_TANH);
-        const int ml = threadIdx.x & 31, mm = blockIdx.x * 32 + ml, rr = (ml & 3) + 4 * (ml >> 3), lb = 32 * ((ml >> 2) & 1);
+        const int ml = threadIdx.x & 31, mm = bx * 32 + ml, rr = (ml & 3) + 4 * (ml >> 3), lb = 32 * ((ml >> 2) & 1);
         const float b = (bias && mm < g.M) ? bias[mm] : 0.f;
         float y[2]; bool ok[2]; size_t ci[2];
 #pragma unroll
@@ -130,7 +130,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)
             for (int w = 1; w < kGemmWaves; ++w) v += red[w][rr][ll];                          // fixed order
             C[ci[i]] = gemm_epilogue(g, v, b, y[i]);
         }
-    } else store_tile(g, C, bias, aux, blockIdx.x * 32, tile_n * 32, lane, [&](int rr, int ll) { return red[wave][rr][ll]; });
+    } else store_tile(g, C, bias, aux, bx * 32, tile_n * 32, lane, [&](int rr, int ll) { return red[wave][rr][ll]; });
 }
 template <bool SPLIT>
 __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_kernel(GemmArgs g) {
@@ -381,6 +381,20 @@ __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_pair_kernel(GemmPair
     if ((int)blockIdx.z < p.za) gemm_body<true>(p.a, blockIdx.z, red); else gemm_body<true>(p.b, (int)blockIdx.z - p.za, red);
 }
 
+// up to four independent contractions in one launch (a net's [dW3|db3], [dW2|db2] and dz1 of the reverse pass): blockIdx.z picks the contraction
+struct GemmMulti { GemmArgs g[4]; int end[4], tm[4], tn[4]; int n; };   // flat grid: blocks [end[i-1], end[i]) run contraction i, tile (bx, by) of batch z
+__global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_multi_kernel(GemmMulti p) {
+    __shared__ float red[kGemmWaves][16][kRedStride];
+    const int b = blockIdx.x;
+    const int i = b < p.end[0] ? 0 : b < p.end[1] ? 1 : b < p.end[2] ? 2 : 3;
+    const int local = b - (i ? p.end[i - 1] : 0), per = p.tm[i] * p.tn[i];
+    const int z = local / per, r = local - z * per, by = r / p.tm[i], bx = r - by * p.tm[i];
+    if (i == 0) gemm_body<true>(p.g[0], z, red, bx, by);
+    else if (i == 1) gemm_body<true>(p.g[1], z, red, bx, by);
+    else if (i == 2) gemm_body<true>(p.g[2], z, red, bx, by);
+    else gemm_body<true>(p.g[3], z, red, bx, by);
+}
+
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 bool gemm_prepare(GemmArgs& g) {
     g.vecA = g.sAk == 1 && g.sAm % 4 == 0 && g.K % 4 == 0 && aligned16(g.A) && g.zA % 4 == 0;
@@ -400,6 +414,20 @@ hipError_t launch_gemm_pair(GemmArgs a, int Za, GemmArgs b, int Zb, hipStream_t 
     const int tm = std::max((a.M + 31) / 32, (b.M + 31) / 32), tn = std::max((a.N + 31) / 32, (b.N + 31) / 32);
     if (tn > 65535 || Za + Zb > 65535) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sac_gemm_pair_kernel, dim3(tm, tn, Za + Zb), dim3(64 * kGemmWaves), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_gemm_multi(const GemmArgs* gs, const int* Zs, int n, hipStream_t s) {
+    if (n < 1 || n > 4) return hipErrorInvalidValue;
+    GemmMulti p; p.n = n; long long total = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < n) {
+            p.g[i] = gs[i]; if (!gemm_prepare(p.g[i])) return hipErrorInvalidValue;
+            p.tm[i] = (p.g[i].M + 31) / 32; p.tn[i] = (p.g[i].N + 31) / 32; total += (long long)p.tm[i] * p.tn[i] * Zs[i];
+        } else { p.g[i] = gs[0]; p.tm[i] = p.tn[i] = 1; }
+        p.end[i] = (int)total;
+    }
+    if (total > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sac_gemm_multi_kernel, dim3((unsigned)total), dim3(64 * kGemmWaves), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_gemm(GemmArgs g, int Z, hipStream_t s) {

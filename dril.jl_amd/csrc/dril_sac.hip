@@ -218,6 +218,208 @@ __global__ __launch_bounds__(256) void sac_squash_bwd_kernel(SquashBwdArgs g) {
     for (int a = 0; a < g.A; ++a) { const double t = block_sum(dls[a], sh); if (threadIdx.x == 0) g.g_log_std[a] = (float)t; }
 }
 
+// =================================================================================================================
+// Fused heads.  A net's OUTPUT layer has one (Q nets) or A (actor) rows: as a contraction it is one launch of ~4.5 us for a few hundred dot
+// products, and so is the first stage of the reverse pass (K = 1).  The kernels below do the output-layer dot products, the per-sample loss head and
+// the first reverse stage dz2 = (W3' dOut) .* act'(h2) in ONE launch, one wave per sample (lanes stride the hidden units, fixed-order butterfly sum =>
+// deterministic), per-block partial sums of the batch statistics folded in index order by the block that finishes last.  25 -> 19 dependent
+// launches per update!.
+// =================================================================================================================
+constexpr int kHeadSamplesPerBlock = 1;   // one workgroup per sample: the dot products of a sample run on separate waves, so a head is ~3 dependent memory round trips
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+// dot of two contiguous, 16-byte-aligned rows of H floats (H % 4 == 0): every lane's float4 loads are issued before the first use
+__device__ __forceinline__ float wave_dot(const float* __restrict__ w, const float* __restrict__ x, int H, int lane) {
+    float s = 0.f;
+    for (int u = lane; u < H / 4; u += 64) {
+        const float4 a = reinterpret_cast<const float4*>(w)[u], b = reinterpret_cast<const float4*>(x)[u];
+        s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+    }
+    return wave_sum(s);
+}
+// dot of a strided weight row (element u at w[u * stride]) with a contiguous activation row
+__device__ __forceinline__ float wave_dot_strided(const float* __restrict__ w, int stride, const float* __restrict__ x, int H, int lane) {
+    float s = 0.f;
+    for (int u = lane; u < H; u += 64) s = fmaf(w[(size_t)u * stride], x[u], s);
+    return wave_sum(s);
+}
+__device__ __forceinline__ float act_deriv(float hval, int relu) { return relu ? (hval > 0.f ? 1.0f : 0.0f) : 1.0f - hval * hval; }
+// last-block fold of per-block values (double, index order): `mine` is this block's value (valid in thread 0); returns true in the block that finished
+// last, with the totals in tot[0..NV) (all threads)
+template <int NV>
+__device__ __forceinline__ bool fold_partials(const double (&mine)[NV], double* partials, unsigned int* counter, double (&tot)[NV], double* sh) {
+    __shared__ bool last;
+    const int t = threadIdx.x;
+    if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) partials[(size_t)blockIdx.x * NV + k] = mine[k];
+        __threadfence(); last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return false;
+    __threadfence();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {                                             // all 256 threads fetch (one round trip), fixed-order tree: deterministic
+        double a = 0;
+        for (unsigned b = t; b < gridDim.x; b += 256) a += ((volatile const double*)partials)[(size_t)b * NV + k];
+        tot[k] = block_sum(a, sh);
+    }
+    if (t == 0) *counter = 0u;
+    return true;
+}
+
+// actor output layer on (obs | next obs) + entropy-coefficient step + next actions + the actor-loss sample: net_forward's third launch + sac_ent_next_kernel
+struct ActorHeadFusedArgs {
+    EntNextArgs e; const float* ah2; int H2; const float* W3; const float* b3;   // W3 (A x H2) column-major: row a strided by A
+    float* mu_out; double* partials; unsigned int* counter;
+};
+__global__ __launch_bounds__(256) void sac_actor_out_ent_kernel(ActorHeadFusedArgs f) {
+    __shared__ double sh[256];
+    __shared__ float mus[2][kMaxA];
+    __shared__ double ssum;
+    const EntNextArgs& g = f.e;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = blockIdx.x;
+    float ls[kMaxA]; for (int a = 0; a < g.A; ++a) ls[a] = g.log_std[a];
+    // phase 1: mu = W3 h2 + b3 for row i (obs) and row B + i (next obs): (row, a) pairs over the four waves
+    for (int p = wave; p < 2 * g.A; p += 4) {
+        const int row = p / g.A, a = p - row * g.A;
+        const float d = wave_dot_strided(f.W3 + a, g.A, f.ah2 + (size_t)(row * g.B + i) * f.H2, f.H2, lane) + f.b3[a];
+        if (lane == 0) { mus[row][a] = d; f.mu_out[(size_t)(row * g.B + i) * g.A + a] = d; }
+    }
+    if (threadIdx.x == 0) ssum = 0.0;
+    __syncthreads();
+    if (threadIdx.x < 3) {                                                       // phase 2: the three squashed samples of the row on three threads (libm-heavy scalar math)
+        const int which = threadIdx.x;
+        float a_[kMaxA], gg[kMaxA];
+        if (which == 0) { if (g.auto_ent) ssum = (double)(squashed_sample_logp(mus[0], ls, g.ne + (size_t)i * g.A, g.A, a_, gg) + g.target_entropy); }
+        else if (which == 1) {
+            g.nlp[i] = squashed_sample_logp(mus[1], ls, g.nn + (size_t)i * g.A, g.A, a_, gg);
+            for (int d = 0; d < g.D; ++d) g.xq_next[(size_t)i * (g.D + g.A) + d] = g.xa[(size_t)(g.B + i) * g.D + d];
+            for (int a = 0; a < g.A; ++a) g.xq_next[(size_t)i * (g.D + g.A) + g.D + a] = a_[a];
+        } else {
+            g.lp_pi[i] = squashed_sample_logp(mus[0], ls, g.np + (size_t)i * g.A, g.A, a_, gg);
+            for (int d = 0; d < g.D; ++d) g.xq_pi[(size_t)i * (g.D + g.A) + d] = g.xa[(size_t)i * g.D + d];
+            for (int a = 0; a < g.A; ++a) { g.xq_pi[(size_t)i * (g.D + g.A) + g.D + a] = a_[a]; g.a_pi[i * g.A + a] = a_[a]; g.g_pi[i * g.A + a] = gg[a]; }
+        }
+    }
+    __syncthreads();
+    double mine[1] = {ssum}, tot[1];
+    if (!fold_partials<1>(mine, f.partials, f.counter, tot, sh)) return;
+    if (threadIdx.x == 0) {
+        float le = g.sc->log_ent;
+        if (g.auto_ent) {
+            const float cc = (float)(tot[0] / g.B);
+            g.stats[2] = -(le * cc);                                                          // loss = -(log_ent_coef * c), sac.jl:330
+            const float gr = -cc;
+            const float m = g.b1 * g.sc->ent_m + (1.0f - g.b1) * gr, v = g.b2 * g.sc->ent_v + (1.0f - g.b2) * gr * gr;
+            g.sc->ent_m = m; g.sc->ent_v = v;
+            le -= m / (1.0f - g.bt1) / (sqrtf(v / (1.0f - g.bt2)) + g.eps) * g.lr;           // Optimisers.Adam
+            g.sc->log_ent = le;
+        }
+        g.sc->alpha = expf(le);
+        g.stats[4] = g.sc->alpha;                                                             // :391
+    }
+}
+
+// Q output layers (Z nets: the two critics, and with Z = 4 the two targets behind them) + loss head + dz2 of the two critics
+struct QHeadFusedArgs {
+    int B, H2, nq, relu, Z; long long zP, zh2;     // net z: W3 / b3 at P + w3 + z * zP, h2 at qh2 + z * zh2
+    const float* P; int w3, b3; const float* qh2;
+    float* q_out;          // [Z][nq]
+    float* dz2;            // [2][nq][H2]
+    // critic head (mode 0) / actor head (mode 1)
+    int mode; const float *rew, *nlp, *lp_pi; const uint8_t* term; const SacScalars* sc; float gamma;
+    float* dq; float* stats; double* partials; unsigned int* counter;
+};
+__global__ __launch_bounds__(256) void sac_q_out_head_kernel(QHeadFusedArgs g) {
+    __shared__ double sh[256];
+    __shared__ float qs[4], dqs[2];
+    __shared__ double part[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = blockIdx.x;
+    if (wave < g.Z) {                                                          // one wave per net: q_z = W3_z . h2_z + b3_z
+        const float q = wave_dot(g.P + g.w3 + wave * g.zP, g.qh2 + wave * g.zh2 + (size_t)i * g.H2, g.H2, lane) + g.P[g.b3 + wave * g.zP];
+        if (lane == 0) { qs[wave] = q; g.q_out[(size_t)wave * g.nq + i] = q; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float alpha = g.sc->alpha;
+        float dq0, dq1; double s0 = 0, s1 = 0;
+        if (g.mode == 0) {                                                    // Bellman target + critic loss (sac_critic_loss :136-150)
+            const float mn = qs[2] < qs[3] ? qs[2] : qs[3];
+            const float y = g.term[i] ? g.rew[i] : g.rew[i] + g.gamma * (mn - alpha * g.nlp[i]);
+            const float d0 = qs[0] - y, d1 = qs[1] - y;
+            dq0 = d0 / (float)g.B; dq1 = d1 / (float)g.B;
+            s0 = 0.5 * (double)d0 * d0 / g.B + 0.5 * (double)d1 * d1 / g.B; s1 = (double)qs[0] + (double)qs[1];
+        } else {                                                              // actor loss (:102-104): min over the critics
+            const int km = qs[1] < qs[0] ? 1 : 0;
+            dq0 = km == 0 ? -1.0f / (float)g.B : 0.f; dq1 = km == 1 ? -1.0f / (float)g.B : 0.f;
+            s0 = ((double)alpha * g.lp_pi[i] - (km ? qs[1] : qs[0])) / g.B;
+        }
+        dqs[0] = dq0; dqs[1] = dq1; g.dq[i] = dq0; g.dq[g.nq + i] = dq1; part[0] = s0; part[1] = s1;
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < 2 * g.H2; u += 256) {                        // dz2 = (W3' dq) .* act'(h2): the first stage of the reverse pass (K = 1)
+        const int k = u >= g.H2, j = u - k * g.H2;
+        g.dz2[((size_t)k * g.nq + i) * g.H2 + j] = g.P[g.w3 + k * g.zP + j] * dqs[k] * act_deriv(g.qh2[k * g.zh2 + (size_t)i * g.H2 + j], g.relu);
+    }
+    double mine[2] = {part[0], part[1]}, tot[2];
+    if (!fold_partials<2>(mine, g.partials, g.counter, tot, sh)) return;
+    if (threadIdx.x == 0) {
+        if (g.mode == 0) { g.stats[1] = (float)tot[0]; g.stats[3] = (float)(tot[1] / (2.0 * g.B)); }
+        else g.stats[0] = (float)tot[0];
+    }
+}
+
+// action columns of dx = W1' dz1 of both critics + reverse of the squashed sample + dz2 of the ACTOR: net_backward's last launch (dX), sac_squash_bwd_kernel
+// and the first stage of the actor's reverse pass
+struct SquashFusedArgs {
+    SquashBwdArgs s; int H1, H2, relu, nq; const float* P; int qw1; long long zP;   // critic k: W1 (H1 x (D+A)) column-major at P + qw1 + k * zP
+    const float* dz1;      // [2][nq][H1]
+    const float* aW3; const float* ah2; float* adz2;   // actor: W3 (A x H2), h2 [.][H2], dz2 out [nq][H2]
+    double* partials; unsigned int* counter;
+};
+__global__ __launch_bounds__(256) void sac_dx_squash_kernel(SquashFusedArgs f) {
+    __shared__ double sh[256];
+    __shared__ float das[2][kMaxA], dmus[kMaxA];
+    __shared__ double dlss[kMaxA];
+    const SquashBwdArgs& g = f.s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = blockIdx.x;
+    const float alpha = g.sc->alpha, eps = 1.0e-6f, lo = -1.0f + eps, hi = 1.0f - eps;
+    for (int p = wave; p < 2 * g.A; p += 4) {                                  // d Q_k / d action_a = W1_k[:, D + a] . dz1_k: (critic, a) pairs over the four waves
+        const int kk = p / g.A, a = p - kk * g.A;
+        const float d = wave_dot(f.P + f.qw1 + kk * f.zP + (size_t)(g.D + a) * f.H1, f.dz1 + ((size_t)kk * f.nq + i) * f.H1, f.H1, lane);
+        if (lane == 0) das[kk][a] = d;
+    }
+    __syncthreads();
+    if (threadIdx.x < g.A) {
+        const int a = threadIdx.x;
+        const float dlogp = alpha / (float)g.B, da = das[0][a] + das[1][a];
+        const float ls = g.log_std[a], sig = expf(ls), e2 = expf(-2.0f * ls);
+        const float x = g.a_pi[i * g.A + a], gg = g.g_pi[i * g.A + a], mu = g.mu[(size_t)i * g.A + a], d = gg - mu;
+        const float inside = (x >= lo && x <= hi) ? 1.0f : 0.0f;
+        const float dlp_dg = -d * e2 + 2.0f * tanhf(gg);
+        const float du = dlogp * dlp_dg * inside + da * (1.0f - x * x);
+        const float dm = dlogp * (d * e2) + du;
+        dmus[a] = dm; g.dmu[(size_t)i * g.A + a] = dm;
+        dlss[a] = (double)(dlogp * (-1.0f + d * d * e2) + du * sig * g.np[i * g.A + a]);
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < f.H2; u += 256) {                            // actor dz2 = (W3' dmu) .* act'(h2)
+        float t = 0.f;
+        for (int a = 0; a < g.A; ++a) t = fmaf(f.aW3[a + (size_t)u * g.A], dmus[a], t);
+        f.adz2[(size_t)i * f.H2 + u] = t * act_deriv(f.ah2[(size_t)i * f.H2 + u], f.relu);
+    }
+    for (int a = 0; a < g.A; ++a) {                                            // log_std gradient: one dimension at a time through the same fold (A is small)
+        double mine[1] = {dlss[a]}, tot[1];
+        const bool last = fold_partials<1>(mine, f.partials + (size_t)a * gridDim.x, f.counter + a, tot, sh);
+        if (last && threadIdx.x == 0) g.g_log_std[a] = (float)tot[0];
+        __syncthreads();
+    }
+}
+
 // ---- Optimisers.Adam on a parameter range; grads == nullptr applies ZERO gradients (zero_critic_grads! then apply_gradients,
 // sac.jl:381-382: the moments decay and the parameters keep moving along the remaining momentum) ---------------------------
 struct AdamRangeArgs { float* p; float* m; float* v; const float* g; int n; float lr, b1, b2, eps, bt1, bt2; double* sumsq_partials; };
@@ -390,6 +592,7 @@ struct dril_sac_handle {
     float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *target = nullptr, *g_critic = nullptr, *g_actor = nullptr;
     SacScalars* sc = nullptr; float* stats = nullptr; float* stats_out = nullptr; int stats_cap = 0;
     double *ssq_c = nullptr, *ssq_a = nullptr; unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
+    double* head_partials = nullptr; unsigned int* head_counter = nullptr; bool fused_heads = true;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
     float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
     float target_entropy = 0, act_lo = -2.0f, act_hi = 2.0f; bool external = false;   // bounds of the agent-facing action space: Box(-2,2), Box(-1,1) under ScalingWrapperEnv
     // env
@@ -445,7 +648,7 @@ int gemm(dril_sac_handle* h, GemmArgs g, int Z) {
 // One net = {W1 b1 W2 b2 W3 b3} at `P + off` (+ z * zP for the second critic); activations are (features x n) column-major
 struct NetBufs { float* h1; float* h2; float* out; long long zh, zo, zh2; };   // [Z][n][H1], [Z][n][O], [Z][n][H2]: batch strides of h1 / out / h2 (zh2 == 0: H1 == H2 shapes, use zh)
 int net_forward(dril_sac_handle* h, const float* P, NetOff off, long long zP, int in, int O, const float* X, int ldx, long long zX, int n,
-                NetBufs b, int Z, int zdivX = 1) {
+                NetBufs b, int Z, int zdivX = 1, bool hidden_only = false) {
     const int H1 = h->H1, H2 = h->H2, act = h->cfg.activation ? EPI_RELU : EPI_TANH;
     GemmArgs g = gemm_args();                                                       // h1 = act(W1 x + b1)
     g.A = P + off.w1; g.sAm = 1; g.sAk = H1; g.zA = zP; g.B = X; g.sBk = 1; g.sBn = ldx; g.zB = zX; g.zdivB = zdivX;
@@ -455,14 +658,16 @@ int net_forward(dril_sac_handle* h, const float* P, NetOff off, long long zP, in
     g.A = P + off.w2; g.sAm = 1; g.sAk = H2; g.zA = zP; g.B = b.h1; g.sBk = 1; g.sBn = H1; g.zB = b.zh;
     g.C = b.h2; g.sCm = 1; g.sCn = H2; g.zC = b.zh2 ? b.zh2 : b.zh; g.bias = P + off.b2; g.zBias = zP; g.M = H2; g.N = n; g.K = H1; g.epi = act;
     SDO(gemm(h, g, Z));
+    if (hidden_only) return DRIL_OK;                                                // the output layer is folded into the fused head kernel that follows
     g = gemm_args();                                                                // out = W3 h2 + b3
     g.A = P + off.w3; g.sAm = 1; g.sAk = O; g.zA = zP; g.B = b.h2; g.sBk = 1; g.sBn = H2; g.zB = b.zh2 ? b.zh2 : b.zh;
     g.C = b.out; g.sCm = 1; g.sCn = O; g.zC = b.zo; g.bias = P + off.b3; g.zBias = zP; g.M = O; g.N = n; g.K = H2; g.epi = EPI_NONE;
     return gemm(h, g, Z);
 }
 // reverse pass given dOut [Z][n][O]: parameter gradients into G (same layout as P; null = skip) and/or dX [Z][n][in] (null = skip)
+// have_dz2: the fused head kernel already wrote dz2 = (W3' dOut) .* act'(h2); then [dW3|db3], [dW2|db2] and dz1 share ONE launch (three independent contractions)
 int net_backward(dril_sac_handle* h, const float* P, NetOff off, long long zP, int in, int O, const float* X, int ldx, long long zX, int n,
-                 NetBufs b, const float* dOut, float* G, float* dX, int Z) {
+                 NetBufs b, const float* dOut, float* G, float* dX, int Z, bool have_dz2 = false) {
     const int H1 = h->H1, H2 = h->H2, mask = h->cfg.activation ? EPI_MASK_RELU : EPI_MASK_TANH;
     const long long zd = (long long)h->nq * H1;   // dz buffers are [2][nq][H] (H1 == H2 layouts are separate buffers)
     const bool big = (long long)((H2 + 31) / 32) * ((n + 31) / 32) * Z >= 2048;          // large batches: one launch per contraction (the pair kernel is the split-K shape)
@@ -472,13 +677,15 @@ int net_backward(dril_sac_handle* h, const float* P, NetOff off, long long zP, i
     g = gemm_args();                                                                // dz2 = (W3' dOut) .* act'(h2)
     g.A = P + off.w3; g.sAm = O; g.sAk = 1; g.zA = zP; g.B = dOut; g.sBk = 1; g.sBn = O; g.zB = b.zo;
     g.C = h->dz2; g.sCm = 1; g.sCn = H2; g.zC = (long long)h->nq * H2; g.aux = b.h2; g.zAux = b.zh2 ? b.zh2 : b.zh; g.M = H2; g.N = n; g.K = O; g.epi = mask;
-    if (G && !big) SDO(gemm_pair(h, w, Z, g, Z)); else { if (G) SDO(gemm(h, w, Z)); SDO(gemm(h, g, Z)); }
+    GemmArgs w3 = w;
+    if (!have_dz2) { if (G && !big) SDO(gemm_pair(h, w, Z, g, Z)); else { if (G) SDO(gemm(h, w, Z)); SDO(gemm(h, g, Z)); } }
     w = gemm_args(); w.A = h->dz2; w.sAm = 1; w.sAk = H2; w.zA = (long long)h->nq * H2; w.B = b.h1; w.sBk = H1; w.sBn = 1; w.zB = b.zh; w.ones_n = 1;   // [dW2 | db2] = dz2 . [h1' | 1]
     w.C = G ? G + off.w2 : nullptr; w.sCm = 1; w.sCn = H2; w.zC = zP; w.M = H2; w.N = H1 + 1; w.K = n;
     g = gemm_args();                                                                // dz1 = (W2' dz2) .* act'(h1)
     g.A = P + off.w2; g.sAm = H2; g.sAk = 1; g.zA = zP; g.B = h->dz2; g.sBk = 1; g.sBn = H2; g.zB = (long long)h->nq * H2;
     g.C = h->dz1; g.sCm = 1; g.sCn = H1; g.zC = zd; g.aux = b.h1; g.zAux = b.zh; g.M = H1; g.N = n; g.K = H2; g.epi = mask;
-    if (G && !big) SDO(gemm_pair(h, w, Z, g, Z)); else { if (G) SDO(gemm(h, w, Z)); SDO(gemm(h, g, Z)); }
+    if (have_dz2 && G && !big) { const GemmArgs gs[3] = {w3, w, g}; const int zs[3] = {Z, Z, Z}; SHIP(h, launch_gemm_multi(gs, zs, 3, h->stream)); }
+    else { if (have_dz2 && G) SDO(gemm(h, w3, Z)); if (G && !big) SDO(gemm_pair(h, w, Z, g, Z)); else { if (G) SDO(gemm(h, w, Z)); SDO(gemm(h, g, Z)); } }
     w = gemm_args(); w.A = h->dz1; w.sAm = 1; w.sAk = H1; w.zA = zd; w.B = X; w.sBk = ldx; w.sBn = 1; w.zB = zX; w.ones_n = 1;          // [dW1 | db1] = dz1 . [x' | 1]
     w.C = G ? G + off.w1 : nullptr; w.sCm = 1; w.sCn = H1; w.zC = zP; w.M = H1; w.N = in + 1; w.K = n;
     g = gemm_args(); g.A = P + off.w1; g.sAm = H1; g.sAk = 1; g.zA = zP; g.B = h->dz1; g.sBk = 1; g.sBn = H1; g.zB = zd;               // dx = W1' dz1
@@ -508,29 +715,64 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
                   slot >= 0 && h->inj_nn ? h->inj_nn + (size_t)slot * B * A : nullptr, slot >= 0 && h->inj_np ? h->inj_np + (size_t)slot * B * A : nullptr,
                   rng, h->xa, h->xq, h->b_rew, h->b_ne, h->b_nn, h->b_np, h->b_term};
     hipLaunchKernelGGL(sac_gather_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, ga);
-    // actor means of (obs | next obs) in one pass: the entropy constant (:318-325) and the actor loss (:101) share the obs half,
-    // the critic target (:131) uses the next-obs half; the actor parameters do not change until the actor step
-    SDO(net_forward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, 2 * B, actor_bufs(h), 1));
+    const int relu = h->cfg.activation ? 1 : 0, hb = (B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock;
     EntNextArgs en{B, D, A, h->mu, h->params + h->log_std_off, h->b_ne, h->b_nn, h->xa, h->xq_next, h->b_nlp, h->b_np, h->xq_pi, h->a_pi, h->g_pi, h->lp_pi, h->sc, h->target_entropy,
                    h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->bt_ent[0], h->bt_ent[1], h->cfg.auto_ent_coef, h->stats};
-    hipLaunchKernelGGL(sac_ent_next_kernel, dim3(1), dim3(256), 0, h->stream, en);
-    if (h->cfg.auto_ent_coef) { h->bt_ent[0] *= h->cfg.adam_beta1; h->bt_ent[1] *= h->cfg.adam_beta2; }
-    // critic: target values with the target networks (:133-135), current values (:117), loss head, reverse pass, Adam (:362)
-    // all four Q nets in one pass: z = 0,1 the critics on (obs, action), z = 2,3 the targets on (next obs, next action)
-    SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, (long long)h->nq * W, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), 4, 2));
-    CriticHeadArgs ch{B, h->q_next, h->q_cur, h->b_rew, h->b_nlp, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats};
-    hipLaunchKernelGGL(sac_critic_head_kernel, dim3(1), dim3(256), 0, h->stream, ch);
-    SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), h->dq, h->g_critic, nullptr, 2));
-    SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, h->ssq_c, h->adam_blocks_c));
-    h->bt_critic[0] *= h->cfg.adam_beta1; h->bt_critic[1] *= h->cfg.adam_beta2;
-    // actor (:93-105) with the UPDATED critics: sample, values, loss head, input gradients of the critics, squash reverse, actor reverse
-    SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), 2));
-    ActorHeadArgs ah{B, h->q_pi, h->lp_pi, h->sc, h->dq, h->stats};
-    hipLaunchKernelGGL(sac_actor_head_kernel, dim3(1), dim3(256), 0, h->stream, ah);
-    SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), h->dq, nullptr, h->dxq, 2));
     SquashBwdArgs sb{B, D, A, h->mu, h->params + h->log_std_off, h->b_np, h->a_pi, h->g_pi, h->dxq, h->sc, h->dmu, h->g_actor + h->log_std_off};
-    hipLaunchKernelGGL(sac_squash_bwd_kernel, dim3(1), dim3(256), 0, h->stream, sb);
-    SDO(net_backward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, B, actor_bufs(h), h->dmu, h->g_actor, nullptr, 1));
+    if (h->fused_heads) {
+        // actor means of (obs | next obs): hidden layers as contractions, then output layer + entropy-coefficient step + next actions + the actor-loss sample in one launch
+        SDO(net_forward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, 2 * B, actor_bufs(h), 1, 1, true));
+        ActorHeadFusedArgs af{en, h->ah2, h->H2, h->params + h->actor.w3, h->params + h->actor.b3, h->mu, h->head_partials, h->head_counter};
+        hipLaunchKernelGGL(sac_actor_out_ent_kernel, dim3(hb), dim3(256), 0, h->stream, af);
+        if (h->cfg.auto_ent_coef) { h->bt_ent[0] *= h->cfg.adam_beta1; h->bt_ent[1] *= h->cfg.adam_beta2; }
+        // critic: all four Q nets' hidden layers in one pass (z = 0,1 the critics on (obs, action), z = 2,3 the targets on (next obs, next action)), then output
+        // layers + Bellman target + loss head + dz2 of the critics in one launch; [dW3|db3], [dW2|db2], dz1 in one launch; [dW1|db1]; Adam (:362)
+        SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, (long long)h->nq * W, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), 4, 2, true));
+        QHeadFusedArgs qc{B, h->H2, h->nq, relu, 4, h->Pqd, (long long)h->nq * h->H2, h->params, h->q0.w3, h->q0.b3, h->qh2, h->q_cur, h->dz2,
+                          0, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats, h->head_partials, h->head_counter};
+        hipLaunchKernelGGL(sac_q_out_head_kernel, dim3(hb), dim3(256), 0, h->stream, qc);
+        SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), h->dq, h->g_critic, nullptr, 2, true));
+        SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, h->ssq_c, h->adam_blocks_c));
+        h->bt_critic[0] *= h->cfg.adam_beta1; h->bt_critic[1] *= h->cfg.adam_beta2;
+        // actor (:93-105) with the UPDATED critics: hidden layers, then output layers + loss head + dz2 in one launch; dz1; then the action columns of W1' dz1, the
+        // reverse of the squashed sample and the actor's dz2 in one launch; the actor's [dW3|db3], [dW2|db2], dz1 in one launch; [dW1|db1]
+        SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), 2, 1, true));
+        QHeadFusedArgs qp{B, h->H2, h->nq, relu, 2, h->Pqd, (long long)h->nq * h->H2, h->params, h->q0.w3, h->q0.b3, h->qh2, h->q_pi, h->dz2,
+                          1, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats, h->head_partials, h->head_counter};
+        hipLaunchKernelGGL(sac_q_out_head_kernel, dim3(hb), dim3(256), 0, h->stream, qp);
+        {   // dz1 = (W2' dz2) .* act'(h1) of both critics (no parameter gradients on this pass: Zygote differentiates the actor loss w.r.t. the actor only)
+            const int H1 = h->H1, H2 = h->H2;
+            GemmArgs g = gemm_args();
+            g.A = h->params + h->q0.w2; g.sAm = H2; g.sAk = 1; g.zA = h->Pqd; g.B = h->dz2; g.sBk = 1; g.sBn = H2; g.zB = (long long)h->nq * H2;
+            g.C = h->dz1; g.sCm = 1; g.sCn = H1; g.zC = (long long)h->nq * H1; g.aux = h->qh1; g.zAux = (long long)h->nq * H1; g.M = H1; g.N = B; g.K = H2;
+            g.epi = relu ? EPI_MASK_RELU : EPI_MASK_TANH;
+            SDO(gemm(h, g, 2));
+        }
+        SquashFusedArgs sf{sb, h->H1, h->H2, relu, h->nq, h->params, h->q0.w1, h->Pqd, h->dz1, h->params + h->actor.w3, h->ah2, h->dz2, h->head_partials, h->head_counter};
+        hipLaunchKernelGGL(sac_dx_squash_kernel, dim3(hb), dim3(256), 0, h->stream, sf);
+        SDO(net_backward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, B, actor_bufs(h), h->dmu, h->g_actor, nullptr, 1, true));
+    } else {
+        // actor means of (obs | next obs) in one pass: the entropy constant (:318-325) and the actor loss (:101) share the obs half,
+        // the critic target (:131) uses the next-obs half; the actor parameters do not change until the actor step
+        SDO(net_forward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, 2 * B, actor_bufs(h), 1));
+        hipLaunchKernelGGL(sac_ent_next_kernel, dim3(1), dim3(256), 0, h->stream, en);
+        if (h->cfg.auto_ent_coef) { h->bt_ent[0] *= h->cfg.adam_beta1; h->bt_ent[1] *= h->cfg.adam_beta2; }
+        // critic: target values with the target networks (:133-135), current values (:117), loss head, reverse pass, Adam (:362)
+        // all four Q nets in one pass: z = 0,1 the critics on (obs, action), z = 2,3 the targets on (next obs, next action)
+        SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, (long long)h->nq * W, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), 4, 2));
+        CriticHeadArgs ch{B, h->q_next, h->q_cur, h->b_rew, h->b_nlp, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats};
+        hipLaunchKernelGGL(sac_critic_head_kernel, dim3(1), dim3(256), 0, h->stream, ch);
+        SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), h->dq, h->g_critic, nullptr, 2));
+        SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, h->ssq_c, h->adam_blocks_c));
+        h->bt_critic[0] *= h->cfg.adam_beta1; h->bt_critic[1] *= h->cfg.adam_beta2;
+        // actor (:93-105) with the UPDATED critics: sample, values, loss head, input gradients of the critics, squash reverse, actor reverse
+        SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), 2));
+        ActorHeadArgs ah{B, h->q_pi, h->lp_pi, h->sc, h->dq, h->stats};
+        hipLaunchKernelGGL(sac_actor_head_kernel, dim3(1), dim3(256), 0, h->stream, ah);
+        SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), h->dq, nullptr, h->dxq, 2));
+        hipLaunchKernelGGL(sac_squash_bwd_kernel, dim3(1), dim3(256), 0, h->stream, sb);
+        SDO(net_backward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, B, actor_bufs(h), h->dmu, h->g_actor, nullptr, 1));
+    }
     // apply_gradients(train_state, actor_loss_grad) :382 + target networks :385-389 + statistics: one launch
     const int do_polyak = h->grad_updates % h->cfg.target_update_interval == 0;
     StepEndArgs se{h->params, h->adam_m, h->adam_v, h->g_actor, round4(h->actor.end), h->log_std_off, A, h->q0.w1, 2 * h->Pqd,
@@ -668,7 +910,7 @@ DRIL_EXPORT int32_t dril_sac_destroy(dril_sac_handle* h) {
     if (!h) return DRIL_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->g_critic, h->g_actor, h->sc, h->stats, h->stats_out, h->ssq_c, h->ssq_a, h->counter,
+    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->g_critic, h->g_actor, h->sc, h->stats, h->stats_out, h->ssq_c, h->ssq_a, h->counter, h->head_partials, h->head_counter,
                     h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->obs_cur, h->obs_nxt, h->e_rew, h->e_tobs, h->e_raw, h->e_envact, h->e_term, h->e_trunc,
                     h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc, h->xa, h->ah1, h->ah2, h->mu, h->xq, h->xq_pi,
                     h->qh1, h->qh2, h->q_cur, h->q_pi, h->dq, h->dz2, h->dz1, h->dxq, h->dmu, h->b_rew, h->b_ne, h->b_nn, h->b_np,
@@ -711,6 +953,8 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     CHK(smalloc(&h->g_critic, h->Pd)); CHK(smalloc(&h->g_actor, h->Pd)); CHK(smalloc(&h->sc, 1)); CHK(smalloc(&h->stats, 8));
     h->adam_blocks_c = std::min(256, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(256, ((h->actor.end + 3) / 4 + 2 * h->Pqd / 4 + 255) / 256);   // <= one workgroup per CU: every block pays a 9-barrier tree reduction
     CHK(smalloc(&h->ssq_c, h->adam_blocks_c)); CHK(smalloc(&h->ssq_a, h->end_blocks)); CHK(smalloc(&h->counter, 1));
+    CHK(smalloc(&h->head_partials, (size_t)kMaxA * 2 * ((B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock + 1))); CHK(smalloc(&h->head_counter, kMaxA + 1));
+    h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr;
     CHK(smalloc(&h->state, (size_t)E * S)); CHK(smalloc(&h->step_count, E)); CHK(smalloc(&h->episode, E)); CHK(smalloc(&h->gstep, E)); CHK(smalloc(&h->disc_returns, E));
     CHK(smalloc(&h->obs_cur, (size_t)E * D)); CHK(smalloc(&h->obs_nxt, (size_t)E * D)); CHK(smalloc(&h->e_rew, E)); CHK(smalloc(&h->e_tobs, (size_t)E * D));
     CHK(smalloc(&h->e_raw, (size_t)E * A)); CHK(smalloc(&h->e_envact, (size_t)E * A)); CHK(smalloc(&h->e_term, E)); CHK(smalloc(&h->e_trunc, E));
