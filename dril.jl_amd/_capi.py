@@ -169,6 +169,7 @@ _SIG = {
     "dril_profile_get": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dril_profile_reset": (C.c_int32, [_P]),
     "dril_kernel_name": (C.c_char_p, [C.c_int32]),
+    "dril_grad_kernel_info": (C.c_char_p, [_P]),
     "dril_version": (C.c_char_p, []),
 }
 # every symbol include/dril_sac.h declares, keyed by the name WITHOUT its "dril_sac_" prefix (the CPU oracle exports the same

@@ -118,6 +118,7 @@ struct dril_handle {
     int grad_stagger = 0;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
     int grad_actor_pct = 0;   // ppo_grad_split_kernel: share (%) of the CUs given to the actor workgroups; 0 = by head (env DRIL_GRAD_ACTOR_PCT)
+    int last_variant = -1;  // which gradient kernel the last optimiser step ran: 0 f32 fused, 1 bf16-split fused, 2 wide, 3 generic (dril_grad_kernel_info)
     int grad_variant = -1;  // hidden [64,64]: 0 = f32-MFMA ppo_grad_kernel, 1 = ppo_grad_split_kernel (bf16 x 3 operand splitting, one workgroup per CU), -1 = by minibatch size (env DRIL_GRAD_VARIANT)
     bool external = false; bool generic = false; float* gen_tmp = nullptr;   // generic: layer-by-layer kernels (host envs, or a device env whose hidden_dims the fused kernels are not built for)
     GenericDims gd{}; GenericWs gws; int ext_t = 0; bool ext_acted = false;   // DRIL_ENV_EXTERNAL: host envs, generic kernels
@@ -338,6 +339,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     }
     if (h->generic) { G = generic_pick_slabs(h->gd, count, h->Gmax); if (G < 1) return fail(h, DRIL_ERR_UNSUPPORTED, "minibatch too large for the generic path's workspace"); Gc = G; }
     { int rcw = ensure_wimg(h); if (rcw) return rcw; }
+    h->last_variant = h->generic ? 3 : h->wide ? 2 : variant;
     const double* adv_stats = h->adv_stats;
     // launch-bound regime (the reference's default batch_size = 64): the advantage moments are computed inside the grad kernel and
     // reduce + norm + Adam run as one workgroup: 2 dependent launches per optimiser step instead of 6
@@ -1237,5 +1239,15 @@ DRIL_EXPORT int32_t dril_profile_reset(dril_handle* h) {
 DRIL_EXPORT const char* dril_kernel_name(int32_t kid) {
     static const char* names[] = {"rollout_kernel", "gae_kernel", "adv_moments_kernel", "ppo_grad_kernel", "grad_reduce_kernel", "adam_kernel", "ncclAllReduce"};
     return (kid >= 0 && kid < DRIL_K_COUNT) ? names[kid] : "?";
+}
+DRIL_EXPORT const char* dril_grad_kernel_info(const dril_handle* h) {
+    if (!h) return "?";
+    switch (h->last_variant) {
+        case 0: return "ppo_grad_kernel: f32 (v_mfma_f32_32x32x2_f32)";
+        case 1: return "ppo_grad_split_kernel: f32 (bf16x3 split, f32 accumulate; v_mfma_f32_32x32x16_bf16 x 6 per k16 step, input layer on v_mfma_f32_32x32x2_f32)";
+        case 2: return "ppo_grad_wide_kernel: f32 (v_mfma_f32_32x32x2_f32)";
+        case 3: return "generic path: f32 contractions (sac_gemm_*; large ones bf16x3 split, f32 accumulate)";
+        default: return "none yet";
+    }
 }
 DRIL_EXPORT const char* dril_version(void) { return "dril_hip 0.2 (gfx950, abi 2)"; }

@@ -635,6 +635,10 @@ class Handle:
         """ranks the communicator itself reports (ncclCommCount), 1 without a communicator"""
         return int(self.lib.dril_comm_ranks(self._h))
 
+    def grad_kernel_info(self) -> str:
+        """"<kernel>: <arithmetic>" of the last optimiser step's gradient kernel"""
+        return self.lib.dril_grad_kernel_info(self._h).decode()
+
     def comm_allreduce_calls(self) -> int:
         return int(self.lib.dril_comm_allreduce_calls(self._h))
 

@@ -323,6 +323,9 @@ int32_t dril_debug_comm_loopback(dril_handle** handles, int32_t n);
 int32_t dril_profile_get(dril_handle* h, int32_t kernel_id, double* total_ms, int64_t* launches);
 int32_t dril_profile_reset(dril_handle* h);
 const char* dril_kernel_name(int32_t kernel_id);
+/* which gradient kernel the handle's LAST optimiser step ran and the arithmetic it computes in ("<kernel>: <arithmetic>"; "none yet" before the
+ * first step): hidden [64,64] picks between the f32-MFMA kernel and the bf16x3-split kernel by minibatch size */
+const char* dril_grad_kernel_info(const dril_handle* h);
 const char* dril_version(void);
 
 #ifdef __cplusplus

@@ -40,7 +40,7 @@ def host_threads() -> int:
 def ensure_built():
     srcs = [ROOT / "oracle" / "dril_oracle.c", ROOT / "oracle" / "dril_sac_oracle.c", ROOT / "include" / "dril_hip.h", ROOT / "include" / "dril_sac.h"]
     if not SO.exists() or SO.stat().st_mtime < max(p.stat().st_mtime for p in srcs):
-        subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True)
+        subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, stdout=sys.stderr)   # never on stdout: bench.py prints ONE JSON line there
 
 
 def lib() -> C.CDLL:
