@@ -117,7 +117,7 @@ struct dril_handle {
     double* rms_red = nullptr;   // data-parallel: this step's partial sums folded to one row and summed over ranks
     int grad_stagger = 0;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
-    int grad_actor_pct = 0;   // ppo_grad_split_kernel: share (%) of the CUs given to the actor workgroups; 0 = by head (env DRIL_GRAD_ACTOR_PCT)
+    int grad_actor_pct = 0;   // ppo_grad_split_kernel: share (per mille) of the CUs given to the actor workgroups; 0 = by head (env DRIL_GRAD_ACTOR_PERMILLE)
     int last_variant = -1;  // which gradient kernel the last optimiser step ran: 0 f32 fused, 1 bf16-split fused, 2 wide, 3 generic (dril_grad_kernel_info)
     int grad_variant = -1;  // hidden [64,64]: 0 = f32-MFMA ppo_grad_kernel, 1 = ppo_grad_split_kernel (bf16 x 3 operand splitting, one workgroup per CU), -1 = by minibatch size (env DRIL_GRAD_VARIANT)
     bool external = false; bool generic = false; float* gen_tmp = nullptr;   // generic: layer-by-layer kernels (host envs, or a device env whose hidden_dims the fused kernels are not built for)
@@ -332,8 +332,8 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     // Categorical head; measured optimum 52-54 % of the CUs for the actor with it, 50 % with the DiagGaussian head): when the grid fills the chip, the CUs are divided in that proportion instead of half and half
     int Gc = G;
     if (variant == 1 && 2 * G >= h->num_cus && h->num_cus >= 8) {
-        const int pct = h->grad_actor_pct ? h->grad_actor_pct : (h->discrete ? 53 : 50);
-        int ga = (h->num_cus * pct + 50) / 100; if (ga < 1) ga = 1; if (ga > h->num_cus - 1) ga = h->num_cus - 1;
+        const int pml = h->grad_actor_pct ? h->grad_actor_pct : (h->discrete ? 540 : 500);      // per mille
+        int ga = (h->num_cus * pml + 500) / 1000; if (ga < 1) ga = 1; if (ga > h->num_cus - 1) ga = h->num_cus - 1;
         G = ga; Gc = h->num_cus - ga;
         if (G > h->Gmax) G = h->Gmax; if (Gc > h->Gmax) Gc = h->Gmax;
     }
@@ -503,7 +503,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (const char* e = std::getenv("DRIL_GRAD_PRIO")) h->grad_prio = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_STAGGER")) h->grad_stagger = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_SPLIT")) h->grad_split = std::atoi(e);
-    if (const char* e = std::getenv("DRIL_GRAD_ACTOR_PCT")) { h->grad_actor_pct = std::atoi(e); if (h->grad_actor_pct < 10 || h->grad_actor_pct > 90) h->grad_actor_pct = 0; }
+    if (const char* e = std::getenv("DRIL_GRAD_ACTOR_PERMILLE")) { h->grad_actor_pct = std::atoi(e); if (h->grad_actor_pct < 100 || h->grad_actor_pct > 900) h->grad_actor_pct = 0; }
     if (const char* e = std::getenv("DRIL_GRAD_VARIANT")) { h->grad_variant = std::atoi(e); if (h->grad_variant < -1 || h->grad_variant > 1) h->grad_variant = -1; }
     h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
@@ -1013,7 +1013,7 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
         std::vector<unsigned long long> d((size_t)2 * h->Gmax * 4 * 12);
         hipMemcpy(d.data(), h->dbg, d.size() * 8, hipMemcpyDeviceToHost);
         const char* names_f32[] = {"gather/loop", "L1+tanh", "L2+tanh", "out+head", "dW3 block", "dz2", "h1img+dh1+dz1", "dW2 block", "dW1 block"};
-        const char* names_split[] = {"S1 unpack+L1+tanh+split", "S2 L2+tanh+h2 img", "S3 head+dW3+dz2+split", "S4 dh1+mask", "S5+S6 dW2+dW1", "-", "-", "-", "-"};
+        const char* names_split[] = {"S1 unpack+L1", "S2 tanh+split+L2+tanh", "S3 L3+head+dW3", "S4 dz2+split+dh1+mask", "S5 dW2", "S6 dz1 img+dW1", "-", "-", "-"};
         const char** names = std::getenv("DRIL_GRAD_VARIANT") && std::atoi(std::getenv("DRIL_GRAD_VARIANT")) == 0 ? names_f32 : names_split;
         for (int head = 0; head < 3; ++head) {
             double acc[10] = {0}; double tiles = 0; int nw = 0;

@@ -1236,11 +1236,10 @@ template <int D, int H, int O> struct NetLdsSplit {
     static constexpr int END = W2P + 3 * H * H / 2;          // in floats
 };
 template <int D, int H, int O> struct GradScratchSplit {
-    static constexpr int T = 0;                              // 12288 bytes: three [32][64] bf16 piece images, or one [H][kTS] f32 image
-    static constexpr int T2 = T + 3 * 32 * H / 2;            // the dz1 f32 image has a place of its own: dW1 (f32 MFMA on the VALU's lanes) runs beside dW2 (matrix pipe)
-    static constexpr int XI = T2 + H * kTS;
-    static constexpr int ZI = XI + (D + 2) * kTS;
-    static constexpr int SIZE = ZI + O * kTS;
+    static constexpr int T = 0;                              // 12288 bytes: the h1' piece images (three [32 samples][64 units] bf16)
+    static constexpr int T3 = T + 3 * 32 * H / 2;            // 12288 bytes: the dz2' piece images; after dW2 has consumed them the dz1 f32 image [H][kTS] (9216 bytes) for dW1
+    static constexpr int XI = T3 + 3 * 32 * H / 2;
+    static constexpr int SIZE = XI + (D + 2) * kTS;
     static_assert(H * kTS <= 3 * 32 * H / 2, "the f32 image must fit the piece images' space");
 };
 __device__ __forceinline__ int w2img_gw(int r) { return (((r >> 1) & 1) << 3) | (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 4) & 1); }
@@ -1263,31 +1262,6 @@ __device__ inline void stage_net_split(float* lds, const float* __restrict__ P, 
     }
 }
 
-// packed bf16 pieces of an activation set in accumulator layout: P[piece][m][t] = (register 2t, register 2t + 1) of m-tile m
-template <int MT> struct Pieces { unsigned p[3][MT][8]; };
-template <int MT> __device__ __forceinline__ void split_tiles(const f32x16 (&X)[MT], Pieces<MT>& P) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) split3_pair(X[m][2 * t], X[m][2 * t + 1], P.p[0][m][t], P.p[1][m][t], P.p[2][m][t]);
-}
-template <int MT> __device__ __forceinline__ bf16x8 piece_frag(const Pieces<MT>& P, int piece, int m, int s) {
-    const u32x4 v = {P.p[piece][m][4 * s + 0], P.p[piece][m][4 * s + 1], P.p[piece][m][4 * s + 2], P.p[piece][m][4 * s + 3]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-// transposed piece images [32 samples][64 units]: lane (sample c, half h) stores registers 4g..4g+3 of m-tile m (units 32m + 8g + 4h ..+3) as one 8-byte chunk
-template <int MT> __device__ __forceinline__ void store_pieces_T(char* T, const Pieces<MT>& P, int lane) {
-    const int c = lane & 31, h = lane >> 5;
-    const int base = c * 128 + (((h ^ timg_gs(c)) & 15) << 3);
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int a = base ^ (64 * m + 16 * g);
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x2*>(T + 4096 * pc + a) = u32x2{P.p[pc][m][2 * g], P.p[pc][m][2 * g + 1]};
-        }
-}
 // MFMA operand (A or B) of unit tile m, k16 step s of a contraction over samples: lane (unit 32m + (lane&31), half h) gets samples 16s + 8h + j
 __device__ __forceinline__ int timg_read_base(int lane) {
     const int h = lane >> 5, gm = (lane >> 4) & 1, e = lane & 15, q = e >> 2, p = e & 3;
@@ -1299,165 +1273,222 @@ __device__ __forceinline__ bf16x8 load_frag_T(const char* T, int rbase, int piec
 }
 
 // ---- the tile loop as six stages --------------------------------------------------------------------------------------------------------------------------
-// S1 (VALU)  unpack, L1 (f32 MFMA, 4), tanh, split h1                     S4 (matrix) dh1 (48 bf16 MFMA), tanh' mask -> dz1
-// S2 (matrix) L2 (48 bf16 MFMA), tanh, h2 image                            S5 (matrix) h1' fragments, dz2' images, dW2 (48 bf16 MFMA)
-// S3 (VALU)  L3, loss head, dW3 / S, h1' images, dz2, split dz2            S6 (VALU lanes) dz1 image, dW1 | db1 (f32 16x16x4 MFMA, 32)
-// Register budget: ONE wave per SIMD (400 registers, no spills).  Every form with two waves per SIMD or two tiles in flight per wave spills, and a scratch
-// reload's s_waitcnt vmcnt waits behind the prefetched minibatch gather (vmcnt retires in order): measured 73 - 107 TFLOP/s against 118 for this one
-// (profiles/r02_split_kernel.md).
+// S1  unpack, prefetch of the next tile, L1 (f32 MFMA, 4)                         S4  per k16 step: dz2 (8 registers), split, piece image, dh1 MFMAs (48); mask -> dz1
+// S2  per k16 step: tanh + split of 8 registers of h1, piece image, L2 MFMAs      S5  dW2 (48 bf16 MFMA): both operands as transposed fragments of the piece images
+//     (48 bf16 MFMA, both output m-tiles); tanh -> h2                             S6  dz1 f32 image; dW1 as 32 rank-1 updates (v_mfma_f32_4x4x1_16B_f32: lane = hidden unit,
+// S3  L3, loss head, per-lane dW3 accumulation                                         4 input components per instruction), db1 = row sum on the VALU
+// One wave per SIMD (<= 512 registers).  What the profile of this kernel says (profiles/r02_split_kernel.md): with ONE wave per SIMD the matrix pipe and the VALU do not
+// run beside each other — an interleaved instruction stream is issued in order and v_fma / v_exp stall behind the wave's own MFMA (microbenchmark mfma_bf16_valu:
+// 16 v_fma after every bf16 MFMA cost 69 instead of 34 + 35 cycles; two waves per SIMD hide them completely) — so a tile costs MFMA + VALU, and the stages below are
+// written to execute FEWER VALU / LDS instructions rather than to overlap them: activation pieces are produced a k16 step at a time and go straight to their image
+// (12 registers live instead of 96), the output-layer gradient and the bias gradients are per-lane accumulations reduced once in the epilogue (no f32 h2 image,
+// no second pass over it), and dW1 runs on the 4x4x1 MFMA (256 instead of 1024 cycles on the VALU's lanes).
 template <int MT, int O> struct TileCtx {
     TileIn<O> cur, nxt;
     float xk[2]; bool valid;
     f32x16 h1[MT], h2[MT], g1[MT];
-    Pieces<MT> P1, P2;
     float dz[O];
-    float* T; char* Tb; float* T2; float* XI; float* ZI;
+    char* Tb; char* T3b; float* T3; float* XI;
 };
-template <int H, int O> struct SplitAcc {
-    static constexpr int MT = H / 32;
-    f32x16 dW2[MT][MT]; f32x4 dW1[H / 16]; float dW3a[O][MT], dS[O][MT], db3p[O], dlsp[O], st[5];
+template <int H, int O, int D> struct SplitAcc {
+    static constexpr int MT = H / 32, ND = (D + 3) / 4;
+    f32x16 dW2[MT][MT];
+    f32x16 dW3[O][MT];        // per lane: sum over this lane's samples of dz[o] * h2[unit]; summed over the 32 lanes of a half in the epilogue
+    f32x16 db2[MT];           // per lane: sum of dz2[unit]
+    f32x4 dW1[ND][2];         // lane 4b + j, register i: dW1[unit 4b + i][component 4nd + j] (two accumulators: even / odd samples)
+    float db1;                // lane = unit
+    float db3p[O], dlsp[O], st[5];
 };
-struct SplitEnv { float* wl; const char* Wimg; int lane, c, h, wf_base, wt_base, tr_base; const float* ls; float adv_mean, adv_inv; };
+struct SplitEnv { float* wl; const char* Wimg; int lane, c, h, wf_base, wt_base, tr_base, ts_base; const float* ls; float adv_mean, adv_inv; };
+
+// transposed piece images [32 samples][64 units]: lane (sample c, half h) stores registers 4g..4g+3 of m-tile m (units 32m + 8g + 4h ..+3) as one 8-byte chunk;
+// ts_base = c * 128 + (((h ^ gs(c)) & 15) << 3); pc[piece][t] = packed registers (8s + 2t, 8s + 2t + 1) of the k16 step s
+__device__ __forceinline__ void store_piece_chunk(char* T, int ts_base, int m, int s, const unsigned (&pc)[3][4]) {
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+        const int a = ts_base ^ (64 * m + 16 * (2 * s + gg));
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(T + 4096 * p + a) = u32x2{pc[p][2 * gg], pc[p][2 * gg + 1]};
+    }
+}
+__device__ __forceinline__ u32x2 lds_read_u32x2(const char* p) { return *reinterpret_cast<const u32x2*>(p); }
+// acc += a . b with the accumulator pinned to AGPRs and updated in place
+__device__ __forceinline__ void mfma_acc_agpr(f32x16& acc, bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ bf16x8 chunk_frag(const unsigned (&pc)[3][4], int p) { return __builtin_bit_cast(bf16x8, u32x4{pc[p][0], pc[p][1], pc[p][2], pc[p][3]}); }
+// v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 blocks; lane 4b + i gives A[i] and B[i] of block b, register r of lane 4b + j receives D[r][j]
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
 template <int KIND, int H, int O, int HEAD, bool REC>
 struct SplitStages {
-    static constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
+    static constexpr int D = EnvSpec<KIND>::D, MT = H / 32, ND = (D + 3) / 4;
     using L = NetLdsSplit<D, H, O>;
     using Ctx = TileCtx<MT, O>;
-    using Acc = SplitAcc<H, O>;
+    using Acc = SplitAcc<H, O, D>;
 
     static __device__ __forceinline__ void s1(const GradArgs& a, const SplitEnv& e, Ctx& t, int64_t next_tile, int64_t ntiles) {
         t.cur = t.nxt;
         unpack_tile<KIND, O, HEAD, REC>(a, e.h, t.cur);
-        load_tile<KIND, O, HEAD, REC>(a, next_tile, ntiles, e.c, e.h, t.nxt);      // prefetch this context's next tile: consumed five stages from now
+        load_tile<KIND, O, HEAD, REC>(a, next_tile, ntiles, e.c, e.h, t.nxt);      // prefetch the next tile: consumed one whole tile from now
         t.valid = t.cur.valid; t.xk[0] = t.cur.xk[0]; t.xk[1] = t.cur.xk[1];
-        dense_first<H, MT>(e.wl + L::W1T, e.wl + L::B1, t.xk, t.h1, e.lane);
-        tanh_tiles(t.h1);
-        split_tiles<MT>(t.h1, t.P1);
+        dense_first<H, MT>(e.wl + L::W1T, e.wl + L::B1, t.xk, t.h1, e.lane);        // pre-activations (scaled by kTanhScale)
     }
     static __device__ __forceinline__ void s2(const SplitEnv& e, Ctx& t) {
+        f32x16 acc[MT];
 #pragma unroll
-        for (int mo = 0; mo < MT; ++mo) {
-            f32x16 acc;
+        for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(e.wl + L::B2 + 32 * mo + 8 * q + 4 * e.h);
-                acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+                acc[mo][4 * q + 0] = b[0]; acc[mo][4 * q + 1] = b[1]; acc[mo][4 * q + 2] = b[2]; acc[mo][4 * q + 3] = b[3];
             }
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int a0 = (e.wf_base ^ (64 * mi + 32 * s)) + 4096 * mo;
-                    bf16x8 A[3];
-#pragma unroll
-                    for (int pc = 0; pc < 3; ++pc)
-                        A[pc] = frag8(*reinterpret_cast<const u32x2*>(e.Wimg + 8192 * pc + a0), *reinterpret_cast<const u32x2*>(e.Wimg + 8192 * pc + (a0 ^ 16)));
-                    acc = mfma_split6(A[0], A[1], A[2], piece_frag<MT>(t.P1, 0, mi, s), piece_frag<MT>(t.P1, 1, mi, s), piece_frag<MT>(t.P1, 2, mi, s), acc);
-                }
-            tanh16(acc);
-            t.h2[mo] = acc;
-        }
-        store_image<MT>(t.T, t.h2, e.lane);    // f32 image for the output-layer gradient
-    }
-    static __device__ __forceinline__ void s3(const GradArgs& a, const SplitEnv& e, Ctx& t, Acc& A) {
-        float out[O];
-        dense_out<MT, O, H>(e.wl + L::W3S, e.wl + L::B3, t.h2, out, e.lane);
-        // loss head (ppo.jl:377-404) and dLoss/dout
-        loss_head<O, HEAD>(a, t.cur, out, t.valid, e.h == 0, e.ls, e.adv_mean, e.adv_inv, t.dz, A.st, A.dlsp);
-        // output layer backward: dW3 += dz h2' and S += dz (1 - h2^2)' over samples (h2 read back transposed: hidden unit on the lane)
-#pragma unroll
-        for (int o = 0; o < O; ++o) { if (e.h == 0) { A.db3p[o] += t.dz[o]; t.ZI[o * kTS + e.c] = t.dz[o]; } }
-#pragma unroll
-        for (int mj = 0; mj < MT; ++mj) {
-            const f32x16 Bh2 = load_operand(t.T, mj, e.lane);
-            f32x16 Bm;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) Bm[k] = fmaf(-Bh2[k], Bh2[k], 1.0f);
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                float acc = 0.f, accs = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 z = *reinterpret_cast<const f32x4*>(t.ZI + o * kTS + 16 * e.h + 4 * q);   // broadcast within the half-wave
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) { acc = fmaf(Bh2[4 * q + cc], z[cc], acc); accs = fmaf(Bm[4 * q + cc], z[cc], accs); }
-                }
-                A.dW3a[o][mj] += acc; A.dS[o][mj] += accs;
-            }
-        }
-        // h1' piece images (the LDS unit executes a wave's accesses in order, so the reads above precede these writes)
-        store_pieces_T<MT>(t.Tb, t.P1, e.lane);
-        // dz2 = (W3' dz) .* (1 - h2^2), in h2's registers
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float dh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int o = 0; o < O; ++o) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(e.wl + L::W3S + o * H + 32 * m + 8 * q + 4 * e.h);
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(w[cc], t.dz[o], dh[cc]);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { const float hv = t.h2[m][4 * q + cc]; t.h2[m][4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
-            }
-        split_tiles<MT>(t.h2, t.P2);
-    }
-    static __device__ __forceinline__ void s4(const SplitEnv& e, Ctx& t) {      // dh1 = W2' dz2 (A: transposed reads of the weight image); dz1 = dh1 .* (1 - h1^2)
-        constexpr float kInvTanhScale = 1.0f / kTanhScale;
-#pragma unroll
-        for (int mk = 0; mk < MT; ++mk) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int a0 = (e.wt_base ^ (64 * mk + 2048 * s + 8 * s)) + 4096 * mi;
-                    bf16x8 A[3];
-#pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) A[pc] = frag8(lds_read_tr16(e.Wimg, 8192 * pc + a0), lds_read_tr16(e.Wimg, 8192 * pc + (a0 ^ (1024 | 16))));
-                    acc = mfma_split6(A[0], A[1], A[2], piece_frag<MT>(t.P2, 0, mi, s), piece_frag<MT>(t.P2, 1, mi, s), piece_frag<MT>(t.P2, 2, mi, s), acc);
-                }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float t2 = t.h1[mk][r] * t.h1[mk][r]; t.g1[mk][r] = acc[r] * fmaf(-t2, kInvTanhScale, kInvTanhScale); }
-        }
-    }
-    static __device__ __forceinline__ void s5(const SplitEnv& e, Ctx& t, Acc& A) {   // dW2 += dz2 h1' over the 32 samples
-        bf16x8 Bf[MT][2][3];
-#pragma unroll
-        for (int mj = 0; mj < MT; ++mj)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) Bf[mj][s][pc] = load_frag_T(t.Tb, e.tr_base, pc, mj, s);
-        store_pieces_T<MT>(t.Tb, t.P2, e.lane);                                       // the dz2' images take the h1' images' place
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 Ah = load_frag_T(t.Tb, e.tr_base, 0, mi, s), Am = load_frag_T(t.Tb, e.tr_base, 1, mi, s), Al = load_frag_T(t.Tb, e.tr_base, 2, mi, s);
+                bf16x8 Aw[MT][3];                                                   // weight fragments first: their LDS latency runs under the chunk's VALU work
 #pragma unroll
-                for (int mj = 0; mj < MT; ++mj) A.dW2[mi][mj] = mfma_split6(Ah, Am, Al, Bf[mj][s][0], Bf[mj][s][1], Bf[mj][s][2], A.dW2[mi][mj]);
+                for (int mo = 0; mo < MT; ++mo) {
+                    const int a0 = (e.wf_base ^ (64 * mi + 32 * s)) + 4096 * mo;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        Aw[mo][p] = frag8(lds_read_u32x2(e.Wimg + 8192 * p + a0), lds_read_u32x2(e.Wimg + 8192 * p + (a0 ^ 16)));
+                }
+                __builtin_amdgcn_sched_barrier(0);                                  // pin the requests here (the scheduler otherwise sinks them to their first use)
+                float ex[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ex[i] = __builtin_amdgcn_exp2f(t.h1[mi][8 * s + i]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ex[i] = __builtin_amdgcn_rcpf(ex[i] + 1.0f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) t.h1[mi][8 * s + i] = fmaf(-2.0f, ex[i], 1.0f);
+                unsigned pc[3][4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) split3_pair(t.h1[mi][8 * s + 2 * tt], t.h1[mi][8 * s + 2 * tt + 1], pc[0][tt], pc[1][tt], pc[2][tt]);
+                store_piece_chunk(t.Tb, e.ts_base, mi, s, pc);                      // h1' images for dW2
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo) acc[mo] = mfma_split6(Aw[mo][0], Aw[mo][1], Aw[mo][2], chunk_frag(pc, 0), chunk_frag(pc, 1), chunk_frag(pc, 2), acc[mo]);
+            }
+#pragma unroll
+        for (int mo = 0; mo < MT; ++mo) { tanh16(acc[mo]); t.h2[mo] = acc[mo]; }
+    }
+    static __device__ __forceinline__ void s3(const GradArgs& a, const SplitEnv& e, Ctx& t, Acc& A) {
+        float out[O];
+        dense_out<MT, O, H>(e.wl + L::W3S, e.wl + L::B3, t.h2, out, e.lane);
+        loss_head<O, HEAD>(a, t.cur, out, t.valid, e.h == 0, e.ls, e.adv_mean, e.adv_inv, t.dz, A.st, A.dlsp);   // ppo.jl:377-404 and dLoss/dout
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            if (e.h == 0) A.db3p[o] += t.dz[o];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) A.dW3[o][m] += t.dz[o] * t.h2[m];          // dW3[o][unit] += dz[o][sample] h2[unit][sample]: the lane IS the sample
+        }
+    }
+    static __device__ __forceinline__ void s4(const SplitEnv& e, Ctx& t, Acc& A) {  // dz2 = (W3' dz) .* (1 - h2^2); dh1 = W2' dz2 (A: transposed reads of the weight image); dz1 = dh1 .* (1 - h1^2)
+        constexpr float kInvTanhScale = 1.0f / kTanhScale;
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mk = 0; mk < MT; ++mk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mk][r] = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 Aw[MT][3];
+#pragma unroll
+                for (int mk = 0; mk < MT; ++mk) {
+                    const int a0 = (e.wt_base ^ (64 * mk + 2048 * s + 8 * s)) + 4096 * mi;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) Aw[mk][p] = frag8(lds_read_tr16(e.Wimg, 8192 * p + a0), lds_read_tr16(e.Wimg, 8192 * p + (a0 ^ (1024 | 16))));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float z[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float dh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int o = 0; o < O; ++o) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(e.wl + L::W3S + o * H + 32 * mi + 8 * (2 * s + q) + 4 * e.h);
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(w[cc], t.dz[o], dh[cc]);
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) { const float hv = t.h2[mi][8 * s + 4 * q + cc]; z[4 * q + cc] = dh[cc] * fmaf(-hv, hv, 1.0f); }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) A.db2[mi][8 * s + i] += z[i];
+                unsigned pc[3][4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) split3_pair(z[2 * tt], z[2 * tt + 1], pc[0][tt], pc[1][tt], pc[2][tt]);
+                store_piece_chunk(t.T3b, e.ts_base, mi, s, pc);                     // dz2' images for dW2
+#pragma unroll
+                for (int mk = 0; mk < MT; ++mk) acc[mk] = mfma_split6(Aw[mk][0], Aw[mk][1], Aw[mk][2], chunk_frag(pc, 0), chunk_frag(pc, 1), chunk_frag(pc, 2), acc[mk]);
+            }
+#pragma unroll
+        for (int mk = 0; mk < MT; ++mk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float t2 = t.h1[mk][r] * t.h1[mk][r]; t.g1[mk][r] = acc[mk][r] * fmaf(-t2, kInvTanhScale, kInvTanhScale); }
+    }
+    static __device__ __forceinline__ void s5(const SplitEnv& e, Ctx& t, Acc& A) {   // dW2 += dz2 h1' over the 32 samples
+        bf16x8 Bf[2][MT][3], Af[2][MT][3];                                             // all 24 fragments are requested before the first MFMA (96 registers; nothing else is live here)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) { Bf[s][m][p] = load_frag_T(t.Tb, e.tr_base, p, m, s); Af[s][m][p] = load_frag_T(t.T3b, e.tr_base, p, m, s); }
+        __builtin_amdgcn_sched_barrier(0);
+        // The dW2 accumulators are touched by nothing but these MFMAs and the epilogue: they live in AGPRs, in place (mfma_acc_agpr).  The rest of the file is compiled
+        // with MFMA results in VGPRs (Makefile: -amdgpu-mfma-vgpr-form) because the VALU consumes them; for THESE 64 registers that would mean parking them in AGPRs
+        // between tiles and moving them in and out around every S5 (128 v_accvgpr moves per tile).  Round robin over the four accumulators: a dependent MFMA is
+        // issued three MFMAs after its predecessor, so no software wait state is needed between them.
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int term = 0; term < 6; ++term) {
+                // small terms first, as in mfma_split6: (A piece, B piece) = (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+                const int pa = term == 0 ? 2 : (term == 2 || term == 3) ? 1 : 0, pb = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int mj = 0; mj < MT; ++mj) mfma_acc_agpr(A.dW2[mi][mj], Af[s][mi][pa], Bf[s][mj][pb]);
             }
     }
-    static __device__ __forceinline__ void s6(const SplitEnv& e, Ctx& t, Acc& A) {   // dW1 | db1 += dz1 * [x; 1]' (f32, v_mfma_f32_16x16x4_f32: K = 4 samples per step)
-        store_image<MT>(t.T2, t.g1, e.lane);
+    // dW1 += dz1 x' as rank-1 updates per sample; db1 += row sum of dz1.  In two parts: the images are written right after dW2 (s6a), and read back one stage later, after
+    // the NEXT tile's S1 (s6b) — the LDS write -> read round trip runs under that stage instead of stalling the wave
+    static __device__ __forceinline__ void s6a(const SplitEnv& e, Ctx& t) {
+        store_image<MT>(t.T3, t.g1, e.lane);                                          // the dz1 f32 image takes the dz2' images' place (dW2 has consumed them: same wave, LDS in order)
 #pragma unroll
         for (int s = 0; s < 2; ++s) { const int d = 2 * s + e.h; t.XI[(d < D ? d : D + 1) * kTS + e.c] = d < D ? t.xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
-        const int j = e.lane & 15;
-        float bx[8];
-        load_row8(t.XI, j <= D ? j : D + 1, e.lane, bx);
+    }
+    struct DW1In { float az[32]; f32x4 x[ND][8]; };
+    static __device__ __forceinline__ void s6b_load(const SplitEnv& e, Ctx& t, DW1In& in) {
 #pragma unroll
-        for (int mt = 0; mt < H / 16; ++mt) {
-            float az[8];
-            load_row8(t.T2, 16 * mt + j, e.lane, az);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) A.dW1[mt] = mfma16(az[k], bx[k], A.dW1[mt]);
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(t.T3 + e.lane * kTS + 4 * q);
+            in.az[4 * q] = v[0]; in.az[4 * q + 1] = v[1]; in.az[4 * q + 2] = v[2]; in.az[4 * q + 3] = v[3];
         }
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd) {
+            const int d = 4 * nd + (e.lane & 3);
+            const float* xr = t.XI + (d < D ? d : D + 1) * kTS;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) in.x[nd][q] = *reinterpret_cast<const f32x4*>(xr + 4 * q);
+        }
+    }
+    static __device__ __forceinline__ void s6b_math(const DW1In& in, Acc& A) {
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                A.dW1[nd][0] = mfma4(in.az[4 * q], in.x[nd][q][0], A.dW1[nd][0]); A.dW1[nd][1] = mfma4(in.az[4 * q + 1], in.x[nd][q][1], A.dW1[nd][1]);
+                A.dW1[nd][0] = mfma4(in.az[4 * q + 2], in.x[nd][q][2], A.dW1[nd][0]); A.dW1[nd][1] = mfma4(in.az[4 * q + 3], in.x[nd][q][3], A.dW1[nd][1]);
+            }
+        float s8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s8[i] = (in.az[i] + in.az[8 + i]) + (in.az[16 + i] + in.az[24 + i]);
+        A.db1 += ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     }
 };
 
@@ -1474,7 +1505,8 @@ __device__ __forceinline__ void grad_body_split(const GradArgs& a, float* smem) 
     float* wl = smem;
     float* scratch = smem + L::END + wave * (NCTX * SC::SIZE);
     stage_net_split<D, H, O>(wl, a.params, off, tid, blockDim.x);
-    for (int i = lane; i < NCTX * SC::SIZE; i += 64) { const int j = i % SC::SIZE - SC::XI; if (j >= 0 && j < (D + 2) * kTS) scratch[i] = (j / kTS == D) ? 1.0f : 0.0f; }
+    for (int i = lane; i < (D + 2) * kTS; i += 64) scratch[SC::XI + i] = (i / kTS == D) ? 1.0f : 0.0f;
+    for (int i = lane; i < H * kTS; i += 64) scratch[SC::T3 + i] = 0.0f;     // the first tile's S6b reads the (empty) dz1 image of "the tile before"
     __syncthreads();
 
     // advantage normalisation constants (ppo.jl:350-356): mean, corrected std, eps added to the std
@@ -1517,21 +1549,28 @@ __device__ __forceinline__ void grad_body_split(const GradArgs& a, float* smem) 
     { const int e16 = lane & 15, tq = e16 >> 2, tp = e16 & 3, tg = (lane >> 4) & 1;
       e.wt_base = (4 * h + tq) * 128 + ((((4 * tg + tp) ^ (8 * (tq >> 1) + 4 * h)) & 15) << 3); }   // W2' transposed read: rows 32 mi + 16 s + 8 rho + 4 h + q, chunk 8 mk + 4 g + p
     e.tr_base = timg_read_base(lane);
+    e.ts_base = c * 128 + (((h ^ timg_gs(c)) & 15) << 3);
 
-    SplitAcc<H, O> A;
+    SplitAcc<H, O, D> A;
 #pragma unroll
-    for (int i = 0; i < H / 16; ++i) A.dW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MT; ++i) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int r = 0; r < 16; ++r) A.db2[i][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) A.dW2[i][j][r] = 0.f;
+    }
+#pragma unroll
+    for (int nd = 0; nd < (D + 3) / 4; ++nd) { A.dW1[nd][0] = f32x4{0.f, 0.f, 0.f, 0.f}; A.dW1[nd][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    A.db1 = 0.f;
 #pragma unroll
     for (int o = 0; o < O; ++o) {
         A.db3p[o] = 0.f; A.dlsp[o] = 0.f;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) { A.dW3a[o][m] = 0.f; A.dS[o][m] = 0.f; }
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) A.dW3[o][m][r] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) A.st[i] = 0.f;
@@ -1540,7 +1579,7 @@ __device__ __forceinline__ void grad_body_split(const GradArgs& a, float* smem) 
     const int64_t ntiles = (a.count + kTile - 1) / kTile;
     const int64_t tstride = (int64_t)(HEAD == HEAD_VALUE ? a.Gc : a.G) * 4, first = (int64_t)g * 4 + wave;
     typename ST::Ctx ta;
-    ta.T = scratch + SC::T; ta.Tb = reinterpret_cast<char*>(ta.T); ta.T2 = scratch + SC::T2; ta.XI = scratch + SC::XI; ta.ZI = scratch + SC::ZI;
+    ta.Tb = reinterpret_cast<char*>(scratch + SC::T); ta.T3 = scratch + SC::T3; ta.T3b = reinterpret_cast<char*>(ta.T3); ta.XI = scratch + SC::XI;
     {
         int64_t tile = first;
         load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, ta.nxt);       // a tile index past the end loads an all-invalid tile
@@ -1549,12 +1588,17 @@ __device__ __forceinline__ void grad_body_split(const GradArgs& a, float* smem) 
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
 #endif
         for (; tile < ntiles; tile += tstride) {
+            typename ST::DW1In w1;
+            ST::s6b_load(e, ta, w1); __builtin_amdgcn_sched_barrier(0);               // dW1 of the previous tile (zeros before the first): operands requested before S1, consumed after it
             ST::s1(a, e, ta, tile + tstride, ntiles); __builtin_amdgcn_sched_barrier(0); STAMP(0);
+            ST::s6b_math(w1, A); __builtin_amdgcn_sched_barrier(0); STAMP(5);
             ST::s2(e, ta); __builtin_amdgcn_sched_barrier(0); STAMP(1);
             ST::s3(a, e, ta, A); __builtin_amdgcn_sched_barrier(0); STAMP(2);
-            ST::s4(e, ta); __builtin_amdgcn_sched_barrier(0); STAMP(3);
-            ST::s5(e, ta, A); ST::s6(e, ta, A); __builtin_amdgcn_sched_barrier(0); STAMP(4);    // one region: the f32 MFMAs of dW1 fill the VALU lanes under dW2's matrix-pipe chain
+            ST::s4(e, ta, A); __builtin_amdgcn_sched_barrier(0); STAMP(3);
+            ST::s5(e, ta, A); __builtin_amdgcn_sched_barrier(0); STAMP(4);
+            ST::s6a(e, ta); __builtin_amdgcn_sched_barrier(0);
         }
+        if (first < ntiles) { typename ST::DW1In w1; ST::s6b_load(e, ta, w1); ST::s6b_math(w1, A); }   // the last tile's dW1
 #ifdef DRIL_STAMPS
         if (lane == 0 && a.dbg) {
             unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
@@ -1583,25 +1627,23 @@ __device__ __forceinline__ void grad_body_split(const GradArgs& a, float* smem) 
                     for (int mj = 0; mj < MT; ++mj) red[o_w2 + row + (32 * mj + c) * H] += A.dW2[mi][mj][r];
                 }
 #pragma unroll
-            for (int mt = 0; mt < H / 16; ++mt)
+            for (int nd = 0; nd < (D + 3) / 4; ++nd)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * mt + 4 * (lane >> 4) + r, col = lane & 15;
-                    if (col < D) red[o_w1 + row + col * H] += A.dW1[mt][r];
-                    else if (col == D) red[o_b1 + row] += A.dW1[mt][r];
+                for (int i = 0; i < 4; ++i) {                                          // 4x4x1 blocks: lane 4b + j, register i = dW1[unit 4b + i][component 4 nd + j]
+                    const int row = 4 * (lane >> 2) + i, col = 4 * nd + (lane & 3);
+                    if (col < D) red[o_w1 + row + col * H] += A.dW1[nd][0][i] + A.dW1[nd][1][i];
                 }
+            red[o_b1 + lane] += A.db1;                                                 // lane = unit
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                float b2 = 0.f;
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int o = 0; o < O; ++o) {
-                    const float v = A.dW3a[o][m] + __shfl_xor(A.dW3a[o][m], 32);      // the two halves hold different samples
-                    const float sv = A.dS[o][m] + __shfl_xor(A.dS[o][m], 32);
-                    if (h == 0) red[o_w3 + o + (32 * m + c) * O] += v;
-                    b2 = fmaf(wl[L::W3S + o * H + 32 * m + c], sv, b2);                // db2[u] = sum_o W3[o][u] S[o][u]
+                for (int r = 0; r < 16; ++r) {                                         // per-lane sums over samples -> sum over the 32 lanes of each half (the halves hold different units)
+                    const int unit = 32 * m + rowfn(r, h);
+                    const float b2 = half_sum(A.db2[m][r]);
+                    if (c == 0) red[o_b2 + unit] += b2;
+#pragma unroll
+                    for (int o = 0; o < O; ++o) { const float v = half_sum(A.dW3[o][m][r]); if (c == 0) red[o_w3 + o + unit * O] += v; }
                 }
-                if (h == 0) red[o_b2 + 32 * m + c] += b2;
-            }
 #pragma unroll
             for (int o = 0; o < O; ++o) {
                 const float b3 = half_sum(A.db3p[o]);
