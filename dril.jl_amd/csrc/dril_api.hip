@@ -328,11 +328,11 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
         variant = h->grad_variant >= 0 ? h->grad_variant : (tiles >= 16 * (int64_t)h->num_cus ? 1 : 0);
         if (variant == 1) { const int gm = h->num_cus / 2 > 0 ? h->num_cus / 2 : 1; if (G > gm) G = gm; }
     }
-    // the split kernel runs one workgroup per CU and the actor's tile costs more than the critic's (stamps: 17.5 k vs 15.5 k cycles with the
-    // Categorical head; measured optimum 52-54 % of the CUs for the actor with it, 50 % with the DiagGaussian head): when the grid fills the chip, the CUs are divided in that proportion instead of half and half
+    // the split kernel runs one workgroup per CU and the actor's tile costs more than the critic's (stamps: 15.7 k vs 14.2 k cycles with the
+    // Categorical head; measured optimum 53 % of the CUs for the actor with it, 50 % with the DiagGaussian head): when the grid fills the chip, the CUs are divided in that proportion instead of half and half
     int Gc = G;
     if (variant == 1 && 2 * G >= h->num_cus && h->num_cus >= 8) {
-        const int pml = h->grad_actor_pct ? h->grad_actor_pct : (h->discrete ? 540 : 500);      // per mille
+        const int pml = h->grad_actor_pct ? h->grad_actor_pct : (h->discrete ? 530 : 500);      // per mille
         int ga = (h->num_cus * pml + 500) / 1000; if (ga < 1) ga = 1; if (ga > h->num_cus - 1) ga = h->num_cus - 1;
         G = ga; Gc = h->num_cus - ga;
         if (G > h->Gmax) G = h->Gmax; if (Gc > h->Gmax) Gc = h->Gmax;
