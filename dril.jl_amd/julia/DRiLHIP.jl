@@ -13,7 +13,7 @@
 # STATUS: EXPERIMENTAL — the build image has no Julia runtime, so this file has never executed.  What stands in for a run: tools/check_shim.py (parses this
 # file and the reference's sources: per-argument method specificity of every method added to a DRiL generic function, the callback-locals keys against
 # test/test_callbacks.jl and the Python mirror, every ccall symbol against include/*.h) and the Python ctypes mirror (dril.jl_amd/host.py), which drives
-# the same C symbols in the same order under tests/ on the GPU.  A maintainer with Julia should first run the CI snippet of INTEGRATION.md §6.
+# the same C symbols in the same order under tests/ on the GPU.  A maintainer with Julia should first run the CI snippet of INTEGRATION.md §7.
 module DRiLHIP
 
 using DRiL
@@ -26,7 +26,7 @@ using TimerOutputs
 # The FIRST argument of every `train!` method below is the reference method's own first-argument type, verbatim (src/algorithms/ppo.jl:100-107,
 # src/algorithms/sac.jl:417-423): then the env argument alone decides specificity (DeviceParallelEnv / OnDevice <: AbstractParallelEnv), the shim's
 # method is strictly more specific and dispatch is unambiguous.  (Round 1 declared `agent::Agent`: wider in argument 1, narrower in argument 2 =>
-# MethodError: ambiguous.)  tools/check_shim.py parses both files and checks every argument pair; INTEGRATION.md §2 has the table.
+# MethodError: ambiguous.)  tools/check_shim.py parses both files and checks every argument pair; INTEGRATION.md §7 has the table.
 const PPOAgent = Agent{<:DRiL.AbstractActorCriticLayer, <:PPO, <:DRiL.AbstractActionAdapter, <:Random.AbstractRNG, <:DRiL.AbstractTrainingLogger, <:Any}
 const SACAgent = Agent{<:DRiL.ContinuousActorCriticLayer, <:DRiL.SAC, <:DRiL.AbstractActionAdapter, <:Random.AbstractRNG, <:DRiL.AbstractTrainingLogger, <:Any}
 
