@@ -108,6 +108,7 @@ struct dril_handle {
     bool force_allreduce = false, force_stepwise = false;
     double *epoch_tables = nullptr, *epoch_stats = nullptr; int epoch_blocks = 512, epoch_nb_cap = 0;   // per-epoch advantage moments
     float *w2a_actor = nullptr, *w2ta_actor = nullptr, *w2a_critic = nullptr, *w2ta_critic = nullptr; bool wide = false, wimg_dirty = true;   // wide nets (H > 64)
+    void *w2p_actor = nullptr, *w2tp_actor = nullptr, *w2p_critic = nullptr, *w2tp_critic = nullptr;   // wide nets: pre-split bf16 fragment streams of W2 / W2' (ppo_grad_wide_split_kernel)
     // MonitorWrapperEnv (cfg.monitor_window > 0)
     float *mon_cur_ret = nullptr, *ep_ret = nullptr, *mon_ring_ret = nullptr, *e_ep_ret = nullptr; int32_t *mon_cur_len = nullptr, *ep_len = nullptr, *mon_ring_len = nullptr, *e_ep_len = nullptr;
     int *mon_cnt = nullptr, *mon_meta = nullptr; uint8_t* e_flags = nullptr;
@@ -217,10 +218,17 @@ bool normalizing(const dril_handle* h) { return h->cfg.norm_obs || h->cfg.norm_r
 size_t act_bytes_per(const dril_handle* h) { return h->discrete ? 4 : 4 * (size_t)h->A; }
 
 // wide nets: (re)build the pre-tiled W2 / W2' images after every parameter change (enqueued on the handle's stream)
+// wide nets: 1 = ppo_grad_wide_split_kernel (bf16 matrix cores), 0 = the f32-MFMA ppo_grad_wide_kernel (DRIL_GRAD_VARIANT; records are needed by the split form)
+// default by measurement (profiles/r02_wide_split.md): hidden 256 runs the split form (183 vs 118 TFLOP/s), hidden 128 keeps the f32 kernel (93 vs 113)
+int wide_variant(const dril_handle* h) { return (h->wide && h->rec && (h->grad_variant < 0 ? (h->cfg.hidden1 >= 256 ? 1 : 0) : h->grad_variant)) ? 1 : 0; }
 int ensure_wimg(dril_handle* h) {
     if (!h->wide || !h->wimg_dirty) return DRIL_OK;
     HIPCHK(h, launch_build_wimg(h->params, h->actor, h->cfg.hidden1, h->w2a_actor, h->w2ta_actor, h->stream));
     HIPCHK(h, launch_build_wimg(h->params, h->critic, h->cfg.hidden1, h->w2a_critic, h->w2ta_critic, h->stream));
+    if (wide_variant(h)) {
+        HIPCHK(h, launch_build_wimg_split(h->params, h->actor, h->cfg.hidden1, h->w2p_actor, h->w2tp_actor, h->stream));
+        HIPCHK(h, launch_build_wimg_split(h->params, h->critic, h->cfg.hidden1, h->w2p_critic, h->w2tp_critic, h->stream));
+    }
     h->wimg_dirty = false;
     return DRIL_OK;
 }
@@ -324,6 +332,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     // hidden [64,64]: large minibatches run the bf16-split kernel (one 4-wave workgroup per CU: G actor + G critic workgroups fill the chip once); small ones keep
     // the f32 kernel, whose weight staging is cheaper (no operand split per workgroup) and which the launch-bound small path is tuned for
     int variant = 0;
+    if (h->wide) variant = (wide_variant(h) && rec) ? 1 : 0;
     if (!h->wide && !h->generic) {
         variant = h->grad_variant >= 0 ? h->grad_variant : (tiles >= 16 * (int64_t)h->num_cus ? 1 : 0);
         if (variant == 1) { const int gm = h->num_cus / 2 > 0 ? h->num_cus / 2 : 1; if (G > gm) G = gm; }
@@ -339,7 +348,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     }
     if (h->generic) { G = generic_pick_slabs(h->gd, count, h->Gmax); if (G < 1) return fail(h, DRIL_ERR_UNSUPPORTED, "minibatch too large for the generic path's workspace"); Gc = G; }
     { int rcw = ensure_wimg(h); if (rcw) return rcw; }
-    h->last_variant = h->generic ? 3 : h->wide ? 2 : variant;
+    h->last_variant = h->generic ? 3 : h->wide ? (variant ? 4 : 2) : variant;
     const double* adv_stats = h->adv_stats;
     // launch-bound regime (the reference's default batch_size = 64): the advantage moments are computed inside the grad kernel and
     // reduce + norm + Adam run as one workgroup: 2 dependent launches per optimiser step instead of 6
@@ -359,6 +368,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     GradArgs g{};
     g.params = h->params; g.obs = obs; g.actions = actions; g.adv = adv; g.ret = ret; g.logp_old = logp_old; g.val_old = val_old;
     g.perm = perm; g.pos0 = pos0; g.count = count; g.N = N; g.idx_lo = 0; g.n_local = N; g.perm_key = key; g.perm_bits = bits;
+    g.w2p_actor = (const u32x4*)h->w2p_actor; g.w2tp_actor = (const u32x4*)h->w2tp_actor; g.w2p_critic = (const u32x4*)h->w2p_critic; g.w2tp_critic = (const u32x4*)h->w2tp_critic;
     g.rec = rec; g.w2a_actor = h->w2a_actor; g.w2ta_actor = h->w2ta_actor; g.w2a_critic = h->w2a_critic; g.w2ta_critic = h->w2ta_critic;
     g.adv_stats = adv_stats; g.inline_moments = (h->cfg.normalize_advantage && adv_stats == nullptr) ? 1 : 0; g.invB = 1.0f / (float)(count * world);
     g.clip_range = h->cfg.clip_range; g.ent_coef = h->cfg.ent_coef; g.vf_coef = h->cfg.vf_coef; g.clip_range_vf = h->cfg.clip_range_vf;
@@ -522,6 +532,8 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     h->Gmax = (h->wide && hd[0] > 128) ? (h->num_cus / 2 > 0 ? h->num_cus / 2 : 1) : h->num_cus;   // H = 128: 4 waves and 77 KB LDS per workgroup, two workgroups per CU   // [64,64]: 2 workgroups per CU (actor + critic), 4 waves each; wide: 1 workgroup of H/32 waves per CU
     if (h->generic) { h->Gmax = std::getenv("DRIL_EXT_GMAX") ? std::atoi(std::getenv("DRIL_EXT_GMAX")) : 64; if (h->Gmax < 1) h->Gmax = 1; }                                                        // generic path: one slab per row chunk of the minibatch
     if (const char* e = std::getenv("DRIL_GRAD_GMAX")) { const int g = std::atoi(e); if (g > 0 && g < h->Gmax) h->Gmax = g; }   // diagnostic: fewer workgroups per net
+    if (h->wide) { const size_t pb = (size_t)hd[0] * hd[0] * 6;    // three bf16 pieces per element
+        CCHK(hipMalloc(&h->w2p_actor, pb)); CCHK(hipMalloc(&h->w2tp_actor, pb)); CCHK(hipMalloc(&h->w2p_critic, pb)); CCHK(hipMalloc(&h->w2tp_critic, pb)); }
     if (h->wide) { const size_t hh = (size_t)hd[0] * hd[0]; CCHK(dmalloc(&h->w2a_actor, hh)); CCHK(dmalloc(&h->w2ta_actor, hh)); CCHK(dmalloc(&h->w2a_critic, hh)); CCHK(dmalloc(&h->w2ta_critic, hh)); }
     CCHK(dmalloc(&h->slabs_a, (size_t)h->Gmax * h->slab_a)); CCHK(dmalloc(&h->slabs_c, (size_t)h->Gmax * h->slab_c));
     CCHK(dmalloc(&h->state, E * h->S)); CCHK(dmalloc(&h->step_count, E)); CCHK(dmalloc(&h->episode, E)); CCHK(dmalloc(&h->gstep, E));
@@ -578,7 +590,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
                     h->flags, h->last_values, h->noise_dev, h->perm_dev, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
-                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->e_rew_n, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->gen_tmp, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
+                    h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->e_rew_n, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->gen_tmp, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->w2p_actor, h->w2tp_actor, h->w2p_critic, h->w2tp_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
                     h->mon_ring_len, h->e_ep_len, h->mon_cnt, h->mon_meta, h->e_flags};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& p : h->prof_pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -1246,6 +1258,7 @@ DRIL_EXPORT const char* dril_grad_kernel_info(const dril_handle* h) {
         case 0: return "ppo_grad_kernel: f32 (v_mfma_f32_32x32x2_f32)";
         case 1: return "ppo_grad_split_kernel: f32 (bf16x3 split, f32 accumulate; v_mfma_f32_32x32x16_bf16 x 6 per k16 step, input layer on v_mfma_f32_32x32x2_f32)";
         case 2: return "ppo_grad_wide_kernel: f32 (v_mfma_f32_32x32x2_f32)";
+        case 4: return "ppo_grad_wide_split_kernel: f32 (bf16x3 split, f32 accumulate; v_mfma_f32_32x32x16_bf16 x 6 per k16 step, input layer and dW1 on f32 MFMAs)";
         case 3: return "generic path: f32 contractions (sac_gemm_*; large ones bf16x3 split, f32 accumulate)";
         default: return "none yet";
     }

@@ -58,6 +58,7 @@ struct GradArgs {
     const float* logp_old; const float* val_old;
     const int64_t* perm; int64_t pos0, count, N, idx_lo, n_local; uint64_t perm_key; int perm_bits;
     const float* w2a_actor; const float* w2ta_actor; const float* w2a_critic; const float* w2ta_critic;   // wide nets: pre-tiled W2 / W2' images
+    const u32x4* w2p_actor; const u32x4* w2tp_actor; const u32x4* w2p_critic; const u32x4* w2tp_critic;   // wide nets, bf16-split form: pre-split fragment streams
     const float4* rec;   // packed minibatch records [N][2] x float4: {obs0..3} {action bits, adv, logp_old, ret}; null = gather from the SoA buffers
     const double* adv_stats;
     float invB, clip_range, ent_coef, vf_coef, clip_range_vf;
@@ -132,6 +133,7 @@ hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_finish_small(const ReduceArgs& r, const AdamArgs& a, hipStream_t s);   // grad_reduce + norm + Adam in one workgroup (few slabs)
 hipError_t launch_explained_var(const float* val, const float* ret, int64_t N, double* partials, int nblocks, hipStream_t s);
 hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a, float* w2ta, hipStream_t s);
+hipError_t launch_build_wimg_split(const float* params, NetOff off, int H, void* w2p, void* w2tp, hipStream_t s);
 int slab_size_actor(int kind, int hidden);
 int slab_size_critic(int kind, int hidden);
 

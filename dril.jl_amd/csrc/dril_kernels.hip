@@ -1987,6 +1987,387 @@ __global__ __launch_bounds__(H * 2, 2) void ppo_grad_wide_kernel(GradArgs a) {
 }
 
 // =============================================================================================
+// ppo_grad_wide_split_kernel — ppo_grad_wide_kernel with its three H x H contractions on the bf16 matrix cores (fp32-equivalent 3-piece operand
+// splitting, dril_device.h).  Same decomposition (a workgroup of H/32 waves owns a 32-sample tile, wave w the m-tile w of every layer and the
+// 32 x H slice of dW2), same four workgroup barriers per tile; what changes is the operand plumbing:
+//   * W2 / W2' stream from L2 as PRE-SPLIT bf16 fragments (build_wimg_split_kernel, once per optimiser step): [(mo*MT + mi)*2 + s][piece][lane][8 bf16],
+//     one 16-byte load per lane, piece and k16 step; 1.5 x the bytes of the f32 stream for a third of the matrix-pipe time.
+//   * activations: every wave splits its own 16 registers once and writes the packed pieces into ONE workgroup image per activation set,
+//     [piece][32 samples][H units] bf16, 16-byte chunk ch of row n stored at ch ^ g(n), g(n) = ((n & 3) << 2) | ((n >> 2) & 3).  The same image gives the
+//     B operand of a product that sums over units (ds_read_b128 along the row: 8 consecutive units of one sample) and both operands of the product
+//     that sums over samples (ds_read_b64_tr_b16: 4 samples x 16 units per 16-lane group); row reads, transposed reads and the 8-byte stores are all
+//     bank-conflict-free under that swizzle (the 4 rows of a transposed read land in the 4 different 64-byte windows, 16 consecutive rows in 16 different chunks).
+//     Two images (h1, dz2) of 192 H bytes replace the four f32 images XA, XB, TA and half of TB.
+//   * no AGPRs: at two waves per SIMD the allocator gives a function that uses ANY AGPR only 128 VGPRs; the 128 dW2 accumulators are VGPR-form MFMA results like the rest.
+// =============================================================================================
+template <int D, int H, int O> struct WideSplitScratch {
+    static constexpr int MT = H / 32;
+    static constexpr int SMALL = NetLdsSmall<D, H, O>::END;
+    static constexpr int P1 = (SMALL + 3) / 4 * 4;          // h1 pieces: 3 x 32 x H bf16 = 48 H floats
+    static constexpr int P2 = P1 + 48 * H;                  // dz2 pieces
+    static constexpr int TB = P2 + 48 * H;                  // per-wave rows [H][kTS] f32: h2', then dz2' (bias gradient), then dz1'
+    static constexpr int XI = TB + H * kTS;                 // [D+2][kTS]
+    static constexpr int ZI = XI + (D + 2) * kTS;           // [MT waves][O][kTS]
+    static constexpr int PO = ZI + MT * O * kTS;            // [MT waves][O][32] output-layer partial sums
+    static constexpr int SIZE = PO + MT * O * 32;
+};
+__device__ __forceinline__ int wimg_g(int n) { return ((n & 3) << 2) | ((n >> 2) & 3); }
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+// pre-split fragment streams of one net: forward A[i][k] = kTanhScale W2[32mo + i][k], reverse A[i][k] = W2[k][32mo + i]; k = 32mi + 16s + 8(lane>>5) + j
+__global__ void build_wimg_split_kernel(const float* __restrict__ P, NetOff off, int H, u32x4* __restrict__ w2p, u32x4* __restrict__ w2tp) {
+    const int MT = H / 32, total = MT * MT * 2 * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, s = (idx >> 6) & 1, mi = (idx >> 7) % MT, mo = (idx >> 7) / MT;
+        const int i = 32 * mo + (lane & 31), k0 = 32 * mi + 16 * s + 8 * (lane >> 5);
+        unsigned f[3][4], b[3][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = k0 + 2 * t;
+            split3_pair(kTanhScale * P[off.w2 + i + (size_t)k * H], kTanhScale * P[off.w2 + i + (size_t)(k + 1) * H], f[0][t], f[1][t], f[2][t]);   // W2[o][k] (column-major out x in)
+            split3_pair(P[off.w2 + k + (size_t)i * H], P[off.w2 + k + 1 + (size_t)i * H], b[0][t], b[1][t], b[2][t]);                               // W2'[i][k] = W2[k][i]
+        }
+        const size_t base = ((size_t)((mo * MT + mi) * 2 + s) * 3) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { w2p[base + (size_t)p * 64] = u32x4{f[p][0], f[p][1], f[p][2], f[p][3]}; w2tp[base + (size_t)p * 64] = u32x4{b[p][0], b[p][1], b[p][2], b[p][3]}; }
+    }
+}
+
+// split the 16 registers of m-tile w (accumulator layout) and store the packed pieces: registers 4g..4g+3 = units 32w + 8g + 4h .. +3 of sample c = one 8-byte chunk
+template <int H>
+__device__ __forceinline__ void store_tile_pieces(char* pimg, int w, const f32x16& x, int lane) {
+    constexpr int RB = 2 * H, PS = 32 * RB;
+    const int c = lane & 31, h = lane >> 5, rowb = c * RB + 8 * h, gsw = wimg_g(c);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned hi[2], mid[2], lo[2];
+        split3_pair(x[4 * g], x[4 * g + 1], hi[0], mid[0], lo[0]); split3_pair(x[4 * g + 2], x[4 * g + 3], hi[1], mid[1], lo[1]);
+        const int a = rowb + (((4 * w + g) ^ gsw) << 4);
+        *reinterpret_cast<u32x2*>(pimg + a) = u32x2{hi[0], hi[1]}; *reinterpret_cast<u32x2*>(pimg + PS + a) = u32x2{mid[0], mid[1]}; *reinterpret_cast<u32x2*>(pimg + 2 * PS + a) = u32x2{lo[0], lo[1]};
+    }
+}
+// the inverse of store_tile_pieces for the lane's own chunks: x = hi + mid + lo (exact)
+template <int H>
+__device__ __forceinline__ void load_tile_pieces(const char* pimg, int w, f32x16& x, int lane) {
+    constexpr int RB = 2 * H, PS = 32 * RB;
+    const int c = lane & 31, h = lane >> 5, rowb = c * RB + 8 * h, gsw = wimg_g(c);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int a = rowb + (((4 * w + g) ^ gsw) << 4);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(pimg + a), mid = *reinterpret_cast<const u32x2*>(pimg + PS + a), lo = *reinterpret_cast<const u32x2*>(pimg + 2 * PS + a);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            x[4 * g + 2 * t] = (__uint_as_float(hi[t] << 16) + __uint_as_float(mid[t] << 16)) + __uint_as_float(lo[t] << 16);
+            x[4 * g + 2 * t + 1] = (__uint_as_float(hi[t] & 0xffff0000u) + __uint_as_float(mid[t] & 0xffff0000u)) + __uint_as_float(lo[t] & 0xffff0000u);
+        }
+    }
+}
+// operand of a product that sums over SAMPLES: lane (unit 32m + (lane & 31), half kh) gets samples 16s + 8kh + j of its unit; tbase from wide_tr_base
+template <int H>
+__device__ __forceinline__ int wide_tr_base(int lane) {
+    constexpr int RB = 2 * H;
+    const int kh = lane >> 5, gm = (lane >> 4) & 1, e = lane & 15, q = e >> 2, p = e & 3, n = 8 * kh + q;
+    return n * RB + ((((2 * gm + (p >> 1)) ^ wimg_g(n)) & 15) << 4) + 8 * (p & 1);
+}
+template <int H>
+__device__ __forceinline__ bf16x8 load_frag_wide_T(const char* pimg, int tbase, int piece, int m, int s) {
+    constexpr int RB = 2 * H, PS = 32 * RB;
+    const int a = (tbase ^ (64 * m)) + 16 * s * RB + piece * PS;
+    return frag8(lds_read_tr16(pimg, a), lds_read_tr16(pimg, (a ^ 16) + 4 * RB));     // samples +0..3, +4..7: the row's chunk swizzle flips bit 0 with (n >> 2) & 1
+}
+__device__ __forceinline__ void wide_split_preload(const u32x4* __restrict__ wimg, int MTv, int mo, int lane, u32x4 (&af)[2][3]) {
+    const u32x4* base = wimg + ((size_t)mo * MTv * 6) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[s][p] = base[(size_t)(s * 3 + p) * 64];
+}
+// output m-tile mo of Y = W X: W as pre-split fragments from L2 (af arrives preloaded with m-tile 0's, each refilled in place right after its MFMAs), X from the piece image
+template <int H, bool BIAS>
+__device__ __forceinline__ f32x16 dense_tile_split(const u32x4* __restrict__ wimg, const float* __restrict__ bias, const char* pimg, int mo, int lane, u32x4 (&af)[2][3]) {
+    constexpr int MT = H / 32, RB = 2 * H, PS = 32 * RB;
+    const int c = lane & 31, h = lane >> 5, rowb = c * RB, gsw = wimg_g(c);
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (BIAS) b = *reinterpret_cast<const f32x4*>(bias + 32 * mo + 8 * q + 4 * h);
+        acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+    }
+    const u32x4* base = wimg + ((size_t)mo * MT * 6) * 64 + lane;
+#pragma unroll 1
+    for (int mi = 0; mi < MT; ++mi) {
+        const u32x4* nextp = base + (size_t)((mi + 1 < MT ? mi + 1 : mi) * 6) * 64;   // the last iteration re-reads its own fragments (in bounds, unused)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int a = rowb + (((4 * mi + 2 * s + h) ^ gsw) << 4);
+            bf16x8 B[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) B[p] = *reinterpret_cast<const bf16x8*>(pimg + p * PS + a);
+            acc = mfma_split6(__builtin_bit_cast(bf16x8, af[s][0]), __builtin_bit_cast(bf16x8, af[s][1]), __builtin_bit_cast(bf16x8, af[s][2]), B[0], B[1], B[2], acc);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[s][p] = nextp[(size_t)(s * 3 + p) * 64];
+        }
+    }
+    return acc;
+}
+
+template <int KIND, int H, int O, int HEAD>
+__device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* smem) {
+    constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
+    constexpr bool REC = true;
+    using L = NetLdsSmall<D, H, O>;
+    using SC = WideSplitScratch<D, H, O>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // this wave's m-tile
+    const int c = lane & 31, h = lane >> 5;
+    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
+    const u32x4* w2p = HEAD == HEAD_VALUE ? a.w2p_critic : a.w2p_actor;
+    const u32x4* w2tp = HEAD == HEAD_VALUE ? a.w2tp_critic : a.w2tp_actor;
+    float* wl = smem;
+    char* P1 = reinterpret_cast<char*>(smem + SC::P1); char* P2 = reinterpret_cast<char*>(smem + SC::P2);
+    float* TB = smem + SC::TB; float* XI = smem + SC::XI; float* ZI = smem + SC::ZI + w * O * kTS; float* PO = smem + SC::PO;
+    stage_net_small<D, H, O>(wl, a.params, off, tid, blockDim.x);
+    for (int i = tid; i < (D + 2) * kTS; i += blockDim.x) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
+    __syncthreads();
+
+    float adv_mean = 0.f, adv_den = 1.f;
+    if (HEAD != HEAD_VALUE && a.normalize_adv) {
+        const double s = a.adv_stats[0], q = a.adv_stats[1], n = a.adv_stats[2];
+        const double mean = s / n;
+        double var = (q - s * mean) / (n - 1.0);
+        if (var < 0) var = 0;
+        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
+    }
+    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
+    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
+    float lsr[kLsMax];
+#pragma unroll
+    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
+    if (HEAD == HEAD_GAUSSIAN) {
+#pragma unroll
+        for (int o = 0; o < O; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
+    }
+    const float* ls = lsr;
+    const int tbase = wide_tr_base<H>(lane);
+
+    f32x16 dW2[MT];                                                  // rows 32w.., all H columns
+    f32x4 dW1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    float dW3a[O], db2p = 0.f, db3p[O], dlsp[O], st[5];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW2[j][r] = 0.f;
+#pragma unroll
+    for (int o = 0; o < O; ++o) { dW3a[o] = 0.f; db3p[o] = 0.f; dlsp[o] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) st[i] = 0.f;
+
+    const int g = a.layout ? (int)(blockIdx.x % a.G) : (int)(blockIdx.x >> 1);
+    const int64_t ntiles = (a.count + kTile - 1) / kTile;
+    TileIn<O> cur, nxt;
+    int64_t tile = g;
+    if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
+#ifdef DRIL_STAMPS
+    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
+#endif
+    for (; tile < ntiles; tile += a.G) {
+        unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
+        const bool valid = cur.valid;
+        const float xk[2] = {cur.xk[0], cur.xk[1]};
+        // ---- h1 tile w; its pieces into the workgroup image ----
+        f32x16 h1w;
+        {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B1 + 32 * w + 8 * q + 4 * h);
+                h1w[4 * q + 0] = b[0]; h1w[4 * q + 1] = b[1]; h1w[4 * q + 2] = b[2]; h1w[4 * q + 3] = b[3];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
+            tanh16(h1w);
+        }
+        // `opaque(lane)`: the image addresses are lane constants, and hoisted out of the tile loop as loop invariants they hold ~60 registers for the whole kernel (they cost 2-3 VALU to rebuild)
+        store_tile_pieces<H>(P1, w, h1w, opaque(lane));
+        if (w == 0) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
+        }
+        STAMP(0);
+        u32x4 afw[2][3];
+        wide_split_preload(w2p, MT, w, lane, afw);                                    // first W2 fragments in flight across the barrier
+        __syncthreads();                                                              // B1: P1, XI complete
+        STAMP(1);
+        load_tile<KIND, O, HEAD, REC>(a, tile + a.G, ntiles, c, h, nxt);              // after the barrier (see ppo_grad_wide_kernel)
+        // ---- h2 tile w ----
+        f32x16 h2w = dense_tile_split<H, true>(w2p, wl + L::B2, P1, w, opaque(lane), afw);
+        tanh16(h2w);
+        STAMP(2);
+        // ---- output layer: partial over this wave's rows, summed across waves through LDS ----
+        float out[O], dz[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float p = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
+                p = fmaf(wv[0], h2w[4 * q + 0], p); p = fmaf(wv[1], h2w[4 * q + 1], p);
+                p = fmaf(wv[2], h2w[4 * q + 2], p); p = fmaf(wv[3], h2w[4 * q + 3], p);
+            }
+            p += __shfl_xor(p, 32);
+            if (h == 0) PO[(w * O + o) * 32 + c] = p;
+        }
+        store_image_tile(TB, w, h2w, lane);                                            // h2' (own rows; only this wave reads them)
+        __syncthreads();                                                              // B2: PO complete
+        STAMP(3);
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float v = wl[L::B3 + o];
+#pragma unroll
+            for (int ww = 0; ww < MT; ++ww) v += PO[(ww * O + o) * 32 + c];            // fixed order: every wave gets the same bits
+            out[o] = v;
+        }
+        loss_head<O, HEAD>(a, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
+        // ---- dW3 (own rows) ----
+#pragma unroll
+        for (int o = 0; o < O; ++o) { if (h == 0) { if (w == 0) db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
+        {
+            const f32x16 Bh2 = load_operand(TB, w, lane);
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 z = *reinterpret_cast<const f32x4*>(ZI + o * kTS + 16 * h + 4 * q);
+                    acc = fmaf(Bh2[4 * q + 0], z[0], acc); acc = fmaf(Bh2[4 * q + 1], z[1], acc);
+                    acc = fmaf(Bh2[4 * q + 2], z[2], acc); acc = fmaf(Bh2[4 * q + 3], z[3], acc);
+                }
+                dW3a[o] += acc;
+            }
+        }
+        // ---- dz2 tile w (in h2w's registers); its pieces into the workgroup image; the f32 transposed copy (own rows) gives db2 ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float dh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(wv[cc], dz[o], dh[cc]);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
+        }
+        store_tile_pieces<H>(P2, w, h2w, opaque(lane));
+        store_image_tile(TB, w, h2w, lane);                                            // dz2' (after the Bh2 read: same wave, LDS in order)
+        wide_split_preload(w2tp, MT, w, lane, afw);                                   // first W2' fragments in flight across the barrier
+        STAMP(4);
+        __syncthreads();                                                              // B3: P2 complete
+        STAMP(5);
+        // ---- dh1 tile w = W2' dz2 ; dz1 ----
+        f32x16 g1 = dense_tile_split<H, false>(w2tp, nullptr, P2, w, opaque(lane), afw);
+        {
+            f32x16 h1r;
+            load_tile_pieces<H>(P1, w, h1r, opaque(lane));                                     // h1 tile w rebuilt from its own pieces (hi + mid + lo is exact): 16 registers less across both MFMA chains
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g1[r] = g1[r] * (1.0f - h1r[r] * h1r[r]);
+        }
+        STAMP(6);
+        // ---- db2 from the f32 transposed copy; then dW1 | db1 (own rows) BEFORE dW2, so that dz1 is dead while the 128 accumulators are being updated ----
+        {
+            const f32x16 Az32 = load_operand(TB, w, lane);
+            db2p += sum16(Az32);
+        }
+        store_image_tile(TB, w, g1, lane);
+        {
+            const int j = lane & 15;
+            float bx[8];
+            load_row8(XI, j <= D ? j : D + 1, lane, bx);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float az[8];
+                load_row8(TB, 32 * w + 16 * t + j, lane, az);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dW1[t] = mfma16(az[k], bx[k], dW1[t]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(7);
+        // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the piece images) ----
+        {
+            const int tb = opaque(tbase);
+            bf16x8 Az[2][3];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<H>(P2, tb, p, w, s);
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj) {
+                bf16x8 Bh[2][3];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<H>(P1, tb, p, mj, s);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split6(Az[s][0], Az[s][1], Az[s][2], Bh[s][0], Bh[s][1], Bh[s][2], dW2[mj]);
+                __builtin_amdgcn_sched_barrier(0);                                    // keep the next m-tile's fragment requests behind these MFMAs (hoisted, they spill)
+            }
+        }
+        __syncthreads();                                                              // B4: P1 / P2 / PO / XI free for the next tile
+        STAMP(8);
+        cur = nxt;
+    }
+#ifdef DRIL_STAMPS
+    if (lane == 0 && a.dbg) {
+        unsigned long long* o_ = a.dbg + ((size_t)(blockIdx.x % (2 * a.G)) * 4 + (w & 3)) * 12;
+        if (w < 4) { for (int k = 0; k < 10; ++k) o_[k] = stamp_acc[k]; o_[10] = (unsigned long long)((ntiles - g + a.G - 1) / a.G); o_[11] = HEAD; }
+    }
+#endif
+
+    // ---- epilogue: every wave owns distinct gradient rows -> straight to the workgroup's slab ----
+    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
+    const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
+    const int o_ls = o_b3 + O, o_st = SL - 8;
+    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
+#pragma unroll
+    for (int mj = 0; mj < MT; ++mj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H] = dW2[mj][r];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 32 * w + 16 * t + 4 * (lane >> 4) + r, col = lane & 15;
+            if (col < D) slab[o_w1 + row + col * H] = dW1[t][r];
+            else if (col == D) slab[o_b1 + row] = dW1[t][r];
+        }
+    { const float b2 = db2p + __shfl_xor(db2p, 32); if (h == 0) slab[o_b2 + 32 * w + c] = b2; }
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        const float v = dW3a[o] + __shfl_xor(dW3a[o], 32);
+        if (h == 0) slab[o_w3 + o + (32 * w + c) * O] = v;
+        const float b3 = half_sum(db3p[o]);
+        if (w == 0 && lane == 0) slab[o_b3 + o] = b3;
+        if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (w == 0 && lane == 0) slab[o_ls + o] = l; }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (w == 0 && lane == 0) slab[o_st + k] = v; }
+    if (w == 0 && lane < 3) slab[o_st + 5 + lane] = 0.f;
+    for (int i = (HEAD == HEAD_GAUSSIAN ? o_ls + O : o_ls) + tid; i < o_st; i += blockDim.x) slab[i] = 0.f;   // padding
+}
+
+template <int KIND, int H>
+__global__ __launch_bounds__(H * 2, 2) void ppo_grad_wide_split_kernel(GradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (*a.stop_flag) return;
+    constexpr int A = EnvSpec<KIND>::A;
+    const bool actor = a.layout ? (blockIdx.x < (unsigned)a.G) : ((blockIdx.x & 1) == 0);
+    if (actor) grad_body_wide_split<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN>(a, smem);
+    else grad_body_wide_split<KIND, H, 1, HEAD_VALUE>(a, smem);
+}
+
+// =============================================================================================
 // slab reduction -> flat [grads | stats] buffer; norm; clip + KL check + Adam
 // flat layout: params order (actor net, critic net, log_std) then 8 stats:
 //   0 sum(-min term)  1 sum(entropy)  2 sum(clipped)  3 sum(kl)  4 sum(ratio)  5 sum((V-R)^2)  6 n_samples  7 unused
@@ -2218,6 +2599,11 @@ hipError_t launch_fold_partials(const double* partials, int nblocks, double* out
     fold_partials_kernel<<<1, 256, 0, s>>>(partials, nblocks, out16);
     return hipGetLastError();
 }
+hipError_t launch_build_wimg_split(const float* params, NetOff off, int H, void* w2p, void* w2tp, hipStream_t s) {
+    const int total = (H / 32) * (H / 32) * 2 * 64;
+    build_wimg_split_kernel<<<(total + 255) / 256, 256, 0, s>>>(params, off, H, (u32x4*)w2p, (u32x4*)w2tp);
+    return hipGetLastError();
+}
 hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a, float* w2ta, hipStream_t s) {
     build_wimg_kernel<<<(H * H + 255) / 256, 256, 0, s>>>(params, off, H, w2a, w2ta);
     return hipGetLastError();
@@ -2357,6 +2743,11 @@ template <int KIND, int H> static size_t grad_wide_lds_bytes() {
     constexpr int wa = WideScratch<D, H, A>::SIZE, wc = WideScratch<D, H, 1>::SIZE;
     return sizeof(float) * (wa > wc ? wa : wc);
 }
+template <int KIND, int H> static size_t grad_wide_split_lds_bytes() {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
+    constexpr int wa = WideSplitScratch<D, H, A>::SIZE, wc = WideSplitScratch<D, H, 1>::SIZE;
+    return sizeof(float) * (wa > wc ? wa : wc);
+}
 hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t s) {
 #define CALLR(K, HH, R)                                                                                       \
     {                                                                                                         \
@@ -2373,6 +2764,21 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
         if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wide_kernel<K, HH, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e; attr_set = true; }                                                 \
         ppo_grad_wide_kernel<K, HH, R><<<2 * a.G, HH * 2, lds, s>>>(a);                                       \
+    }
+    if (hidden > 64 && a.variant && a.rec) {      // wide nets on the bf16 matrix cores
+#define CALLWS(K, HH)                                                                                         \
+    {                                                                                                         \
+        const size_t lds = grad_wide_split_lds_bytes<K, HH>();                                                \
+        static bool attr_set = false;                                                                         \
+        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wide_split_kernel<K, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e; attr_set = true; }                                                 \
+        ppo_grad_wide_split_kernel<K, HH><<<2 * a.G, HH * 2, lds, s>>>(a);                                    \
+    }
+#define CALLWSH(K) { if (hidden == 256) CALLWS(K, 256) else if (hidden == 128) CALLWS(K, 128) else return hipErrorInvalidValue; }
+        if (kind == 0) CALLWSH(0) else if (kind == 3) CALLWSH(3) else if (kind == 4) CALLWSH(4) else CALLWSH(1)
+#undef CALLWSH
+#undef CALLWS
+        return hipGetLastError();
     }
     if (hidden > 64) {
 #define CALLWK(K, HH) { if (a.rec) CALLW(K, HH, true) else CALLW(K, HH, false) }
