@@ -1228,6 +1228,9 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_kernel(GradArgs a) {
 //   * db2 = rowsum(dz2) costs no pass of its own: dz2 = (W3' dz) .* (1 - h2^2), so db2[u] = sum_o W3[o][u] * S[o][u] with
 //     S[o][u] = sum_n dz[o][n] (1 - h2[u][n]^2), accumulated beside dW3 (same operands, already in registers) and multiplied by W3 once, in the epilogue.
 // =============================================================================================
+// a lane constant the optimiser cannot see through: image addresses derived from it are rebuilt per tile (2-3 VALU) instead of being hoisted out of the tile loop as
+// loop invariants, where they occupy registers for the whole kernel (ppo_grad_wide_split_kernel: 92 -> 12 spilled registers)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 template <int D, int H, int O> struct NetLdsSplit {
     static_assert(H == 64, "the split kernel is laid out for hidden_dims [64,64]");
     static constexpr int DP = 4, OP = (O + 3) / 4 * 4;
@@ -2012,7 +2015,6 @@ template <int D, int H, int O> struct WideSplitScratch {
     static constexpr int SIZE = PO + MT * O * 32;
 };
 __device__ __forceinline__ int wimg_g(int n) { return ((n & 3) << 2) | ((n >> 2) & 3); }
-__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 // pre-split fragment streams of one net: forward A[i][k] = kTanhScale W2[32mo + i][k], reverse A[i][k] = W2[k][32mo + i]; k = 32mi + 16s + 8(lane>>5) + j
 __global__ void build_wimg_split_kernel(const float* __restrict__ P, NetOff off, int H, u32x4* __restrict__ w2p, u32x4* __restrict__ w2tp) {
