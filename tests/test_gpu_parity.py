@@ -825,10 +825,10 @@ def test_scaling_wrapper_is_pendulum_in_other_units(pkg):
 
 @pytest.mark.parametrize("kind", [0, 1, 3, 4])
 def test_grad_kernel_variants_agree(pkg, oracle_mod, monkeypatch, kind):
-    """hidden [64,64] has two update kernels: ppo_grad_kernel (exact f32 MFMA chain; small minibatches) and ppo_grad_split_kernel (the three H x H
-    contractions on the bf16 matrix cores with 3-piece operand splitting, f32 accumulate; large minibatches).  Forced onto the same rollout and DataLoader
-    order (DRIL_GRAD_VARIANT) they must give the same loss / gradient norm / parameters to fp32 noise, each within the oracle tolerances, and each must
-    be bitwise reproducible"""
+    """hidden [64,64] has three update kernels: ppo_grad_kernel (exact f32 MFMA chain; small minibatches), ppo_grad_split_kernel (the three H x H
+    contractions on the bf16 matrix cores with 3-piece operand splitting, f32 accumulate; one wave per tile) and ppo_grad_pair_kernel (the same arithmetic,
+    two waves per tile; large minibatches).  Forced onto the same rollout and DataLoader order (DRIL_GRAD_VARIANT) they must give the same loss / gradient
+    norm / parameters to fp32 noise, each within the oracle tolerances, and each must be bitwise reproducible"""
     capi = pkg._capi
     E, T = 32, 40
     cfg = _cfg(pkg, kind, n_envs=E, n_steps=T, episode_len=11, batch_size=320, epochs=2, ent_coef=0.01)
@@ -839,7 +839,7 @@ def test_grad_kernel_variants_agree(pkg, oracle_mod, monkeypatch, kind):
     perm = np.stack([np.random.default_rng(7 + e).permutation(E * T) for e in range(2)]).astype(np.int64)
     o.set_permutation(perm); so = o.ppo_update()
     res = {}
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         monkeypatch.setenv("DRIL_GRAD_VARIANT", str(variant))
         runs = []
         for rep in range(2):
@@ -853,8 +853,9 @@ def test_grad_kernel_variants_agree(pkg, oracle_mod, monkeypatch, kind):
         assert runs[0][0] == pytest.approx(so.loss, rel=1e-4) and runs[0][1] == pytest.approx(so.grad_norm, rel=5e-4)
         np.testing.assert_allclose(runs[0][2], o.get_params(), rtol=2e-4, atol=3e-6)
         res[variant] = runs[0]
-    assert res[0][0] == pytest.approx(res[1][0], rel=1e-5) and res[0][1] == pytest.approx(res[1][1], rel=1e-5)
-    np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-4, atol=2e-6)
+    for v in (1, 2):
+        assert res[0][0] == pytest.approx(res[v][0], rel=1e-5) and res[0][1] == pytest.approx(res[v][1], rel=1e-5)
+        np.testing.assert_allclose(res[0][2], res[v][2], rtol=1e-4, atol=2e-6)
 
 
 @pytest.mark.parametrize("kind,B", [(0, 4096), (1, 1000), (0, 33)])
@@ -873,3 +874,26 @@ def test_split_kernel_loss_and_gradient(pkg, oracle_mod, monkeypatch, kind, B):
         assert np.linalg.norm(gh - go) <= 2e-4 * np.linalg.norm(go)
         lh2, _, gh2 = h.ppo_loss_grad(*batch)
         assert lh2 == lh and np.array_equal(gh, gh2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [0, 1])
+def test_pair_kernel_at_bench_scale_matches_the_f32_kernel(pkg, monkeypatch, kind):
+    """ppo_grad_pair_kernel on a chip-filling minibatch (4 096 tiles: every workgroup slot of the device, unequal actor / critic pair counts, the default size rule):
+    rollout + one update of 2 epochs x 2 minibatches against the exact-f32 kernel on the same seed — loss, gradient norm and parameters to fp32 noise; the
+    library must report the pair kernel for the default and the f32 kernel when forced"""
+    res = {}
+    for variant in ("-1", "0"):
+        monkeypatch.setenv("DRIL_GRAD_VARIANT", variant)
+        env = pkg.CartPoleEnv(max_steps=500) if kind == 0 else pkg.PendulumEnv(max_steps=200)
+        E, T = 2048, 128
+        alg = pkg.PPO(n_steps=T, batch_size=E * T // 2, epochs=2)
+        layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space())
+        h = pkg.Handle(pkg.make_config(env, E, alg, layer, seed=3, fixed_length_episodes=True))
+        h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(5))))
+        h.env_reset(3); h.collect_rollout(); st = h.ppo_update()
+        res[variant] = (h.get_params().copy(), st.loss, st.grad_norm, h.grad_kernel_info().split(":")[0])
+        h.close()
+    assert res["-1"][3] == "ppo_grad_pair_kernel" and res["0"][3] == "ppo_grad_kernel"
+    assert res["-1"][1] == pytest.approx(res["0"][1], rel=1e-5) and res["-1"][2] == pytest.approx(res["0"][2], rel=1e-5)
+    np.testing.assert_allclose(res["-1"][0], res["0"][0], rtol=1e-4, atol=2e-6)
