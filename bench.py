@@ -246,10 +246,11 @@ def main() -> None:
                 traffic_source = f"replayed from profiles/{PMC_FILE} (rocprofv3 --pmc passes at commit {rec.get('commit', '?')}); not measured in this run"
             info = h.grad_kernel_info()                  # "<kernel>: <arithmetic>" of the kernel the last optimiser step actually ran
             kname, arith = info.split(": ", 1)
-            out["dtype"] = "f32 (bf16x3 split, f32 accumulate)" if "split" in kname else "f32"
+            split = "bf16x3" in arith                    # ppo_grad_split_kernel / ppo_grad_pair_kernel / ppo_grad_wide_split_kernel
+            out["dtype"] = "f32 (bf16x3 split, f32 accumulate)" if split else "f32"
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                               "split_ceiling": PEAK_BF16_SPLIT6_TFLOPS if "split" in kname else None,
-                               "split_ceiling_note": "dense bf16 MFMA peak / 6 MFMAs per fp32-equivalent product; frac stays against the f32-MFMA peak" if "split" in kname else None,
+                               "split_ceiling": PEAK_BF16_SPLIT6_TFLOPS if split else None,
+                               "split_ceiling_note": "dense bf16 MFMA peak / 6 MFMAs per fp32-equivalent product; frac stays against the f32-MFMA peak" if split else None,
                                "arithmetic": arith,
                                "traffic": traffic, "traffic_source": traffic_source, "kernel": kname, "avg_launch_ms": avg_ms,
                                "avg_launch_ms_source": "HIP events on the library's stream around every launch of the timed region",
