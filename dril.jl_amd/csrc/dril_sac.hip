@@ -107,6 +107,56 @@ __global__ void sac_gather_kernel(GatherArgs g) {
     g.rew[i] = g.rb_rew[slot]; g.term[i] = g.rb_term[slot];
 }
 
+// one sample's first layer h1[u] = act(W1[u, :] . x + b1[u]) for all H1 units by the 256 threads of a block; W1 (H1 x in) column-major; x in shared memory
+constexpr int kFusedL1MaxIn = 16;    // the per-sample form re-reads W1 per block: only for small inputs (Pendulum: 3 / 4); wider nets keep the contraction
+__device__ __forceinline__ void first_layer_row(const float* __restrict__ W1, const float* __restrict__ b1, const float* x, int in, int H1, int relu, float* __restrict__ h1) {
+    for (int u = threadIdx.x; u < H1; u += blockDim.x) {
+        float acc = b1[u];
+        for (int k = 0; k < in; ++k) acc = fmaf(W1[u + (size_t)k * H1], x[k], acc);
+        h1[u] = relu ? (acc > 0.f ? acc : 0.f) : tanhf(acc);
+    }
+}
+// get_data_loader + the first layer of the actor on (obs | next obs) and of the two critics on (obs, stored action): sac_gather_kernel + the first launch of two
+// net_forward calls.  One block per sample.
+struct GatherL1Args {
+    GatherArgs g; int H1, relu;
+    const float *aW1, *ab1; float* ah1;                       // actor: W1 (H1 x D), b1; h1 [2B][H1]
+    const float* P; int qw1, qb1; long long zP; long long zh; float* qh1;   // critic z: W1 at P + qw1 + z * zP; h1 [Z][nq][H1] with batch stride zh
+};
+__global__ __launch_bounds__(256) void sac_gather_l1_kernel(GatherL1Args f) {
+    __shared__ float xs[2][kFusedL1MaxIn], xqs[kFusedL1MaxIn];
+    const GatherArgs& g = f.g;
+    const int i = blockIdx.x, W = g.D + g.A;
+    if (threadIdx.x == 0) {
+        long long j;
+        if (g.inj_idx) j = g.inj_idx[i];
+        else {
+            uint32_t o[4];
+            philox4x32_10((uint32_t)g.rng.key, (uint32_t)(g.rng.key >> 32), (uint32_t)g.rng.u, (uint32_t)(g.rng.u >> 32), 4u, (uint32_t)i, o);
+            j = (long long)(u01_f64(o[0], o[1]) * (double)g.size); if (j >= g.size) j = g.size - 1;
+        }
+        const long long slot = (g.head + j) % g.cap;
+        for (int d = 0; d < g.D; ++d) {
+            const float o = g.rb_obs[slot * g.D + d], n = g.rb_next[slot * g.D + d];
+            g.xa[(size_t)i * g.D + d] = o; g.xq[(size_t)i * W + d] = o; g.xa[(size_t)(g.B + i) * g.D + d] = n;
+            xs[0][d] = o; xs[1][d] = n; xqs[d] = o;
+        }
+        for (int a = 0; a < g.A; ++a) {
+            const float act = g.rb_act[slot * g.A + a];
+            g.xq[(size_t)i * W + g.D + a] = act; xqs[g.D + a] = act;
+            g.ne[i * g.A + a] = g.inj_ne ? g.inj_ne[i * g.A + a] : sac_noise(g.rng, 5, i, a);
+            g.nn[i * g.A + a] = g.inj_nn ? g.inj_nn[i * g.A + a] : sac_noise(g.rng, 6, i, a);
+            g.np[i * g.A + a] = g.inj_np ? g.inj_np[i * g.A + a] : sac_noise(g.rng, 7, i, a);
+        }
+        g.rew[i] = g.rb_rew[slot]; g.term[i] = g.rb_term[slot];
+    }
+    __syncthreads();
+    first_layer_row(f.aW1, f.ab1, xs[0], g.D, f.H1, f.relu, f.ah1 + (size_t)i * f.H1);
+    first_layer_row(f.aW1, f.ab1, xs[1], g.D, f.H1, f.relu, f.ah1 + (size_t)(g.B + i) * f.H1);
+#pragma unroll
+    for (int z = 0; z < 2; ++z) first_layer_row(f.P + f.qw1 + z * f.zP, f.P + f.qb1 + z * f.zP, xqs, W, f.H1, f.relu, f.qh1 + z * f.zh + (size_t)i * f.H1);
+}
+
 // device scalars shared by the kernels of one gradient step
 struct SacScalars { float log_ent, ent_m, ent_v, alpha; };
 
@@ -275,6 +325,8 @@ __device__ __forceinline__ bool fold_partials(const double (&mine)[NV], double* 
 struct ActorHeadFusedArgs {
     EntNextArgs e; const float* ah2; int H2; const float* W3; const float* b3;   // W3 (A x H2) column-major: row a strided by A
     float* mu_out; double* partials; unsigned int* counter;
+    // first layer of the two TARGET critics on (next obs, next action), when the input is narrow (first_l1 != 0): z = 2, 3 of the four-net forward
+    int first_l1, H1, relu; const float* P; int qw1, qb1; long long zP, zh; float* qh1;
 };
 __global__ __launch_bounds__(256) void sac_actor_out_ent_kernel(ActorHeadFusedArgs f) {
     __shared__ double sh[256];
@@ -306,6 +358,13 @@ __global__ __launch_bounds__(256) void sac_actor_out_ent_kernel(ActorHeadFusedAr
         }
     }
     __syncthreads();
+    if (f.first_l1) {                                                             // thread 1 wrote this sample's (next obs, next action) row above
+        __shared__ float xn[kFusedL1MaxIn];
+        if (threadIdx.x < g.D + g.A) xn[threadIdx.x] = g.xq_next[(size_t)i * (g.D + g.A) + threadIdx.x];
+        __syncthreads();
+#pragma unroll
+        for (int z = 2; z < 4; ++z) first_layer_row(f.P + f.qw1 + z * f.zP, f.P + f.qb1 + z * f.zP, xn, g.D + g.A, f.H1, f.relu, f.qh1 + z * f.zh + (size_t)i * f.H1);
+    }
     double mine[1] = {ssum}, tot[1];
     if (!fold_partials<1>(mine, f.partials, f.counter, tot, sh)) return;
     if (threadIdx.x == 0) {
@@ -648,12 +707,14 @@ int gemm(dril_sac_handle* h, GemmArgs g, int Z) {
 // One net = {W1 b1 W2 b2 W3 b3} at `P + off` (+ z * zP for the second critic); activations are (features x n) column-major
 struct NetBufs { float* h1; float* h2; float* out; long long zh, zo, zh2; };   // [Z][n][H1], [Z][n][O], [Z][n][H2]: batch strides of h1 / out / h2 (zh2 == 0: H1 == H2 shapes, use zh)
 int net_forward(dril_sac_handle* h, const float* P, NetOff off, long long zP, int in, int O, const float* X, int ldx, long long zX, int n,
-                NetBufs b, int Z, int zdivX = 1, bool hidden_only = false) {
+                NetBufs b, int Z, int zdivX = 1, bool hidden_only = false, bool first_done = false) {
     const int H1 = h->H1, H2 = h->H2, act = h->cfg.activation ? EPI_RELU : EPI_TANH;
     GemmArgs g = gemm_args();                                                       // h1 = act(W1 x + b1)
+    if (!first_done) {
     g.A = P + off.w1; g.sAm = 1; g.sAk = H1; g.zA = zP; g.B = X; g.sBk = 1; g.sBn = ldx; g.zB = zX; g.zdivB = zdivX;
     g.C = b.h1; g.sCm = 1; g.sCn = H1; g.zC = b.zh; g.bias = P + off.b1; g.zBias = zP; g.M = H1; g.N = n; g.K = in; g.epi = act;
     SDO(gemm(h, g, Z));
+    }
     g = gemm_args();                                                                // h2 = act(W2 h1 + b2)
     g.A = P + off.w2; g.sAm = 1; g.sAk = H2; g.zA = zP; g.B = b.h1; g.sBk = 1; g.sBn = H1; g.zB = b.zh;
     g.C = b.h2; g.sCm = 1; g.sCn = H2; g.zC = b.zh2 ? b.zh2 : b.zh; g.bias = P + off.b2; g.zBias = zP; g.M = H2; g.N = n; g.K = H1; g.epi = act;
@@ -714,20 +775,26 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
                   slot >= 0 && h->inj_idx ? h->inj_idx + (size_t)slot * B : nullptr, slot >= 0 && h->inj_ne ? h->inj_ne + (size_t)slot * B * A : nullptr,
                   slot >= 0 && h->inj_nn ? h->inj_nn + (size_t)slot * B * A : nullptr, slot >= 0 && h->inj_np ? h->inj_np + (size_t)slot * B * A : nullptr,
                   rng, h->xa, h->xq, h->b_rew, h->b_ne, h->b_nn, h->b_np, h->b_term};
-    hipLaunchKernelGGL(sac_gather_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, ga);
+    const int relu_ = h->cfg.activation ? 1 : 0;
+    const bool l1 = h->fused_heads && W <= kFusedL1MaxIn;      // narrow inputs: first layers inside the gather / head kernels (two launches less)
+    if (l1) {
+        GatherL1Args gl{ga, h->H1, relu_, h->params + h->actor.w1, h->params + h->actor.b1, h->ah1, h->params, h->q0.w1, h->q0.b1, h->Pqd, (long long)h->nq * h->H1, h->qh1};
+        hipLaunchKernelGGL(sac_gather_l1_kernel, dim3(B), dim3(256), 0, h->stream, gl);
+    } else hipLaunchKernelGGL(sac_gather_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, ga);
     const int relu = h->cfg.activation ? 1 : 0, hb = (B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock;
     EntNextArgs en{B, D, A, h->mu, h->params + h->log_std_off, h->b_ne, h->b_nn, h->xa, h->xq_next, h->b_nlp, h->b_np, h->xq_pi, h->a_pi, h->g_pi, h->lp_pi, h->sc, h->target_entropy,
                    h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->bt_ent[0], h->bt_ent[1], h->cfg.auto_ent_coef, h->stats};
     SquashBwdArgs sb{B, D, A, h->mu, h->params + h->log_std_off, h->b_np, h->a_pi, h->g_pi, h->dxq, h->sc, h->dmu, h->g_actor + h->log_std_off};
     if (h->fused_heads) {
         // actor means of (obs | next obs): hidden layers as contractions, then output layer + entropy-coefficient step + next actions + the actor-loss sample in one launch
-        SDO(net_forward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, 2 * B, actor_bufs(h), 1, 1, true));
-        ActorHeadFusedArgs af{en, h->ah2, h->H2, h->params + h->actor.w3, h->params + h->actor.b3, h->mu, h->head_partials, h->head_counter};
+        SDO(net_forward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, 2 * B, actor_bufs(h), 1, 1, true, l1));
+        ActorHeadFusedArgs af{en, h->ah2, h->H2, h->params + h->actor.w3, h->params + h->actor.b3, h->mu, h->head_partials, h->head_counter,
+                              l1 ? 1 : 0, h->H1, relu, h->params, h->q0.w1, h->q0.b1, h->Pqd, (long long)h->nq * h->H1, h->qh1};
         hipLaunchKernelGGL(sac_actor_out_ent_kernel, dim3(hb), dim3(256), 0, h->stream, af);
         if (h->cfg.auto_ent_coef) { h->bt_ent[0] *= h->cfg.adam_beta1; h->bt_ent[1] *= h->cfg.adam_beta2; }
         // critic: all four Q nets' hidden layers in one pass (z = 0,1 the critics on (obs, action), z = 2,3 the targets on (next obs, next action)), then output
         // layers + Bellman target + loss head + dz2 of the critics in one launch; [dW3|db3], [dW2|db2], dz1 in one launch; [dW1|db1]; Adam (:362)
-        SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, (long long)h->nq * W, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), 4, 2, true));
+        SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, (long long)h->nq * W, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), 4, 2, true, l1));
         QHeadFusedArgs qc{B, h->H2, h->nq, relu, 4, h->Pqd, (long long)h->nq * h->H2, h->params, h->q0.w3, h->q0.b3, h->qh2, h->q_cur, h->dz2,
                           0, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats, h->head_partials, h->head_counter};
         hipLaunchKernelGGL(sac_q_out_head_kernel, dim3(hb), dim3(256), 0, h->stream, qc);
