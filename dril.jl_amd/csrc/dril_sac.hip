@@ -651,7 +651,7 @@ struct dril_sac_handle {
     float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *target = nullptr, *g_critic = nullptr, *g_actor = nullptr;
     SacScalars* sc = nullptr; float* stats = nullptr; float* stats_out = nullptr; int stats_cap = 0;
     double *ssq_c = nullptr, *ssq_a = nullptr; unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
-    double* head_partials = nullptr; unsigned int* head_counter = nullptr; bool fused_heads = true;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
+    double* head_partials = nullptr; unsigned int* head_counter = nullptr; bool fused_heads = true; bool trace_enqueue = false;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
     float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
     float target_entropy = 0, act_lo = -2.0f, act_hi = 2.0f; bool external = false;   // bounds of the agent-facing action space: Box(-2,2), Box(-1,1) under ScalingWrapperEnv
     // env
@@ -917,7 +917,7 @@ int run_updates(dril_sac_handle* h, int n_updates, bool injected, dril_sac_stats
     if (h->cfg.profile_events) hipEventRecord(h->ev_b, h->stream);
     const auto t_enq1 = std::chrono::steady_clock::now();
     SDO(ssync(h));
-    if (getenv("DRIL_SAC_TRACE_ENQUEUE")) {
+    if (h->trace_enqueue) {
         const auto t_done = std::chrono::steady_clock::now();
         fprintf(stderr, "[dril_sac] %d update(s): enqueue %.1f us, until drained %.1f us\n", n_updates,
                 std::chrono::duration<double, std::micro>(t_enq1 - t_enq0).count(), std::chrono::duration<double, std::micro>(t_done - t_enq0).count());
@@ -1021,7 +1021,7 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     h->adam_blocks_c = std::min(256, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(256, ((h->actor.end + 3) / 4 + 2 * h->Pqd / 4 + 255) / 256);   // <= one workgroup per CU: every block pays a 9-barrier tree reduction
     CHK(smalloc(&h->ssq_c, h->adam_blocks_c)); CHK(smalloc(&h->ssq_a, h->end_blocks)); CHK(smalloc(&h->counter, 1));
     CHK(smalloc(&h->head_partials, (size_t)kMaxA * 2 * ((B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock + 1))); CHK(smalloc(&h->head_counter, kMaxA + 1));
-    h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr;
+    h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr; h->trace_enqueue = std::getenv("DRIL_SAC_TRACE_ENQUEUE") != nullptr;   // latched here: no getenv on the update path
     CHK(smalloc(&h->state, (size_t)E * S)); CHK(smalloc(&h->step_count, E)); CHK(smalloc(&h->episode, E)); CHK(smalloc(&h->gstep, E)); CHK(smalloc(&h->disc_returns, E));
     CHK(smalloc(&h->obs_cur, (size_t)E * D)); CHK(smalloc(&h->obs_nxt, (size_t)E * D)); CHK(smalloc(&h->e_rew, E)); CHK(smalloc(&h->e_tobs, (size_t)E * D));
     CHK(smalloc(&h->e_raw, (size_t)E * A)); CHK(smalloc(&h->e_envact, (size_t)E * A)); CHK(smalloc(&h->e_term, E)); CHK(smalloc(&h->e_trunc, E));
