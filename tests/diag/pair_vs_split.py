@@ -12,8 +12,8 @@ for env_name in ("cartpole", "pendulum"):
     for v in ("0", "1", "2"):
         os.environ["DRIL_GRAD_VARIANT"] = v
         env = pkg.CartPoleEnv(max_steps=500) if env_name == "cartpole" else pkg.PendulumEnv(max_steps=200)
-        E, T = 2048, 256
-        alg = pkg.PPO(n_steps=T, batch_size=E * T // 2, epochs=2)
+        E, T = (int(os.environ.get("DIAG_E", "2048")), int(os.environ.get("DIAG_T", "256")))
+        alg = pkg.PPO(n_steps=T, batch_size=E * T // int(os.environ.get("DIAG_MB", "2")), epochs=2)
         layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space())
         cfg = pkg.make_config(env, E, alg, layer, seed=3, fixed_length_episodes=True)
         h = pkg.Handle(cfg)
