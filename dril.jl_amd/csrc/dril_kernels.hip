@@ -2403,7 +2403,7 @@ __device__ __forceinline__ bf16x8 load_frag_W_T(const char* wimg, int tbase, int
 template <int KIND, int O, int HEAD>
 __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     constexpr int D = EnvSpec<KIND>::D, H = 64, MT = 2;
-    constexpr bool REC = true;
+    constexpr bool REC = true, kKeepH1 = HEAD == HEAD_VALUE;
     constexpr float kInvTanhScale = 1.0f / kTanhScale;
     using L = PairLds<D, O>;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2490,6 +2490,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
         const bool valid = cur.valid;
         const float xk[2] = {cur.xk[0], cur.xk[1]};
         // ---- h1 tile w; its pieces into the pair's image ----
+        f32x16 h1k;                                                                   // kept across the tile where the registers allow it (the critic), rebuilt from the pieces elsewhere
         {
             f32x16 h1w;
 #pragma unroll
@@ -2501,6 +2502,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
             tanh16(h1w);
             store_tile_pieces<64>(P1, w, h1w, opaque(lane));
+            if (kKeepH1) h1k = h1w;
         }
         STAMP(0);
         __syncthreads();                                                              // B1: the pair's h1 image complete
@@ -2585,7 +2587,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
                 g1 = mfma_split6(A[0], A[1], A[2], B[0], B[1], B[2], g1);
             }
             f32x16 h1r;
-            load_tile_pieces<64>(P1, w, h1r, lo_);                                      // h1 tile w rebuilt from its own pieces (exact)
+            if (kKeepH1) h1r = h1k; else load_tile_pieces<64>(P1, w, h1r, lo_);         // h1 tile w rebuilt from its own pieces (exact)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[r] = g1[r] * fmaf(-t2, kInvTanhScale, kInvTanhScale); }
         }
