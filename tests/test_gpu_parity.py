@@ -823,15 +823,15 @@ def test_scaling_wrapper_is_pendulum_in_other_units(pkg):
     assert np.abs(obs).max() <= 1.0 + 1e-6                                                  # every observation inside the wrapper's Box(-1, 1)
 
 
-@pytest.mark.parametrize("kind", [0, 1, 3, 4])
-def test_grad_kernel_variants_agree(pkg, oracle_mod, monkeypatch, kind):
+@pytest.mark.parametrize("kind,B", [(0, 320), (1, 320), (3, 320), (4, 320), (0, 300), (1, 77)])   # 300 / 77: partial tiles and a ragged last minibatch on every kernel
+def test_grad_kernel_variants_agree(pkg, oracle_mod, monkeypatch, kind, B):
     """hidden [64,64] has three update kernels: ppo_grad_kernel (exact f32 MFMA chain; small minibatches), ppo_grad_split_kernel (the three H x H
     contractions on the bf16 matrix cores with 3-piece operand splitting, f32 accumulate; one wave per tile) and ppo_grad_pair_kernel (the same arithmetic,
     two waves per tile; large minibatches).  Forced onto the same rollout and DataLoader order (DRIL_GRAD_VARIANT) they must give the same loss / gradient
     norm / parameters to fp32 noise, each within the oracle tolerances, and each must be bitwise reproducible"""
     capi = pkg._capi
     E, T = 32, 40
-    cfg = _cfg(pkg, kind, n_envs=E, n_steps=T, episode_len=11, batch_size=320, epochs=2, ent_coef=0.01)
+    cfg = _cfg(pkg, kind, n_envs=E, n_steps=T, episode_len=11, batch_size=B, epochs=2, ent_coef=0.01)
     o = oracle_mod.Oracle(cfg)
     flat = _params(o.P, 3, 0.4); o.set_params(flat); o.env_reset(4)
     noise = np.random.default_rng(1).random(E * T) if o.discrete else np.random.default_rng(1).standard_normal((E * T, o.A)).astype(np.float32)
