@@ -424,12 +424,8 @@ __global__ __launch_bounds__(256) void sac_q_out_head_kernel(QHeadFusedArgs g) {
         const int k = u >= g.H2, j = u - k * g.H2;
         g.dz2[((size_t)k * g.nq + i) * g.H2 + j] = g.P[g.w3 + k * g.zP + j] * dqs[k] * act_deriv(g.qh2[k * g.zh2 + (size_t)i * g.H2 + j], g.relu);
     }
-    double mine[2] = {part[0], part[1]}, tot[2];
-    if (!fold_partials<2>(mine, g.partials, g.counter, tot, sh)) return;
-    if (threadIdx.x == 0) {
-        if (g.mode == 0) { g.stats[1] = (float)tot[0]; g.stats[3] = (float)(tot[1] / (2.0 * g.B)); }
-        else g.stats[0] = (float)tot[0];
-    }
+    // the sums feed statistics only: per-block values, folded by sac_step_end_kernel (no atomics, no second phase here)
+    if (threadIdx.x == 0) { g.partials[(size_t)blockIdx.x * 2] = part[0]; g.partials[(size_t)blockIdx.x * 2 + 1] = part[1]; }
 }
 
 // action columns of dx = W1' dz1 of both critics + reverse of the squashed sample + dz2 of the ACTOR: net_backward's last launch (dX), sac_squash_bwd_kernel
@@ -471,12 +467,7 @@ __global__ __launch_bounds__(256) void sac_dx_squash_kernel(SquashFusedArgs f) {
         for (int a = 0; a < g.A; ++a) t = fmaf(f.aW3[a + (size_t)u * g.A], dmus[a], t);
         f.adz2[(size_t)i * f.H2 + u] = t * act_deriv(f.ah2[(size_t)i * f.H2 + u], f.relu);
     }
-    for (int a = 0; a < g.A; ++a) {                                            // log_std gradient: one dimension at a time through the same fold (A is small)
-        double mine[1] = {dlss[a]}, tot[1];
-        const bool last = fold_partials<1>(mine, f.partials + (size_t)a * gridDim.x, f.counter + a, tot, sh);
-        if (last && threadIdx.x == 0) g.g_log_std[a] = (float)tot[0];
-        __syncthreads();
-    }
+    if (threadIdx.x < g.A) f.partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = dlss[threadIdx.x];   // log_std gradient: per-sample terms, summed by sac_step_end_kernel right before its Adam step
 }
 
 // ---- Optimisers.Adam on a parameter range; grads == nullptr applies ZERO gradients (zero_critic_grads! then apply_gradients,
@@ -501,7 +492,10 @@ struct StepEndArgs {
     float *p, *m, *v; const float* g_actor; int n_actor, ls_off, n_ls, q_off, n_q;
     float lr, b1, b2, eps, bt1_a, bt2_a, bt1_c, bt2_c;
     float* target; float tau; int do_polyak;
-    const double* ssq_c; int nblk_c; double* ssq_a; unsigned int* counter; const float* stats; float* out;
+    const double* ssq_c; int nblk_c; double* ssq_a; unsigned int* counter; float* stats; float* out;
+    // deferred sums of the fused head kernels (nhead = 0: the unfused sequence wrote stats / the log_std gradient itself): per-sample rows [nhead][2] of the critic and
+    // actor loss heads, [n_ls][nhead] of the log_std gradient
+    int nhead, B; const double *hp_critic, *hp_actor, *hp_ls; float* g_ls;
 };
 __device__ __forceinline__ float adam_one(float* p, float* m, float* v, int i, float gi, float lr, float b1, float b2, float eps, float bt1, float bt2) {
     const float mm = b1 * m[i] + (1.0f - b1) * gi, vv = b2 * v[i] + (1.0f - b2) * gi * gi;
@@ -542,8 +536,17 @@ __global__ __launch_bounds__(256) void sac_step_end_kernel(StepEndArgs a) {
             }
         }
     }
+    if (blockIdx.x == 0 && a.nhead) {                                                          // log_std gradient = sum of the per-sample terms (fixed order)
+        for (int d = 0; d < a.n_ls; ++d) {
+            double t = 0;
+            for (int i = threadIdx.x; i < a.nhead; i += 256) t += a.hp_ls[(size_t)d * a.nhead + i];
+            t = block_sum(t, sh);
+            if (threadIdx.x == 0) a.g_ls[d] = (float)t;
+            __syncthreads();
+        }
+    }
     if (blockIdx.x == 0 && threadIdx.x < a.n_ls) {                                              // log_std: a handful of scalars
-        const int j = a.ls_off + threadIdx.x; const float gi = a.g_actor[j];
+        const int j = a.ls_off + threadIdx.x; const float gi = a.nhead ? a.g_ls[threadIdx.x] : a.g_actor[j];
         adam_one(a.p, a.m, a.v, j, gi, a.lr, a.b1, a.b2, a.eps, a.bt1_a, a.bt2_a);
         ss += (double)gi * gi;
     }
@@ -560,6 +563,12 @@ __global__ __launch_bounds__(256) void sac_step_end_kernel(StepEndArgs a) {
     for (int i = threadIdx.x; i < a.nblk_c; i += 256) c += ((volatile const double*)a.ssq_c)[i];
     for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) g += ((volatile double*)a.ssq_a)[i];
     c = block_sum(c, sh); g = block_sum(g, sh);
+    if (a.nhead) {                                                                              // statistics of the fused loss heads
+        double c0 = 0, c1 = 0, p0 = 0;
+        for (int i = threadIdx.x; i < a.nhead; i += 256) { c0 += a.hp_critic[2 * i]; c1 += a.hp_critic[2 * i + 1]; p0 += a.hp_actor[2 * i]; }
+        c0 = block_sum(c0, sh); c1 = block_sum(c1, sh); p0 = block_sum(p0, sh);
+        if (threadIdx.x == 0) { a.stats[1] = (float)c0; a.stats[3] = (float)(c1 / (2.0 * a.B)); a.stats[0] = (float)p0; }
+    }
     if (threadIdx.x == 0) {
         a.out[0] = a.stats[0]; a.out[1] = a.stats[1]; a.out[2] = a.stats[2]; a.out[3] = a.stats[3]; a.out[4] = a.stats[4];
         a.out[5] = (float)sqrt(c + g);                                                        // sac.jl:393
@@ -788,7 +797,8 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
     if (h->fused_heads) {
         // actor means of (obs | next obs): hidden layers as contractions, then output layer + entropy-coefficient step + next actions + the actor-loss sample in one launch
         SDO(net_forward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, 2 * B, actor_bufs(h), 1, 1, true, l1));
-        ActorHeadFusedArgs af{en, h->ah2, h->H2, h->params + h->actor.w3, h->params + h->actor.b3, h->mu, h->head_partials, h->head_counter,
+        double* hp_critic = h->head_partials; double* hp_actor = hp_critic + 2 * (size_t)hb; double* hp_ls = hp_actor + 2 * (size_t)hb; double* hp_ent = hp_ls + (size_t)kMaxA * hb;   // one region per head kernel
+        ActorHeadFusedArgs af{en, h->ah2, h->H2, h->params + h->actor.w3, h->params + h->actor.b3, h->mu, hp_ent, h->head_counter,
                               l1 ? 1 : 0, h->H1, relu, h->params, h->q0.w1, h->q0.b1, h->Pqd, (long long)h->nq * h->H1, h->qh1};
         hipLaunchKernelGGL(sac_actor_out_ent_kernel, dim3(hb), dim3(256), 0, h->stream, af);
         if (h->cfg.auto_ent_coef) { h->bt_ent[0] *= h->cfg.adam_beta1; h->bt_ent[1] *= h->cfg.adam_beta2; }
@@ -796,7 +806,7 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
         // layers + Bellman target + loss head + dz2 of the critics in one launch; [dW3|db3], [dW2|db2], dz1 in one launch; [dW1|db1]; Adam (:362)
         SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, (long long)h->nq * W, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), 4, 2, true, l1));
         QHeadFusedArgs qc{B, h->H2, h->nq, relu, 4, h->Pqd, (long long)h->nq * h->H2, h->params, h->q0.w3, h->q0.b3, h->qh2, h->q_cur, h->dz2,
-                          0, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats, h->head_partials, h->head_counter};
+                          0, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats, hp_critic, h->head_counter};
         hipLaunchKernelGGL(sac_q_out_head_kernel, dim3(hb), dim3(256), 0, h->stream, qc);
         SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), h->dq, h->g_critic, nullptr, 2, true));
         SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, h->ssq_c, h->adam_blocks_c));
@@ -805,7 +815,7 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
         // reverse of the squashed sample and the actor's dz2 in one launch; the actor's [dW3|db3], [dW2|db2], dz1 in one launch; [dW1|db1]
         SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), 2, 1, true));
         QHeadFusedArgs qp{B, h->H2, h->nq, relu, 2, h->Pqd, (long long)h->nq * h->H2, h->params, h->q0.w3, h->q0.b3, h->qh2, h->q_pi, h->dz2,
-                          1, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats, h->head_partials, h->head_counter};
+                          1, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats, hp_actor, h->head_counter};
         hipLaunchKernelGGL(sac_q_out_head_kernel, dim3(hb), dim3(256), 0, h->stream, qp);
         {   // dz1 = (W2' dz2) .* act'(h1) of both critics (no parameter gradients on this pass: Zygote differentiates the actor loss w.r.t. the actor only)
             const int H1 = h->H1, H2 = h->H2;
@@ -815,7 +825,7 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
             g.epi = relu ? EPI_MASK_RELU : EPI_MASK_TANH;
             SDO(gemm(h, g, 2));
         }
-        SquashFusedArgs sf{sb, h->H1, h->H2, relu, h->nq, h->params, h->q0.w1, h->Pqd, h->dz1, h->params + h->actor.w3, h->ah2, h->dz2, h->head_partials, h->head_counter};
+        SquashFusedArgs sf{sb, h->H1, h->H2, relu, h->nq, h->params, h->q0.w1, h->Pqd, h->dz1, h->params + h->actor.w3, h->ah2, h->dz2, hp_ls, h->head_counter};
         hipLaunchKernelGGL(sac_dx_squash_kernel, dim3(hb), dim3(256), 0, h->stream, sf);
         SDO(net_backward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, B, actor_bufs(h), h->dmu, h->g_actor, nullptr, 1, true));
     } else {
@@ -844,7 +854,8 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
     const int do_polyak = h->grad_updates % h->cfg.target_update_interval == 0;
     StepEndArgs se{h->params, h->adam_m, h->adam_v, h->g_actor, round4(h->actor.end), h->log_std_off, A, h->q0.w1, 2 * h->Pqd,
                    h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->bt_actor[0], h->bt_actor[1], h->bt_critic[0], h->bt_critic[1],
-                   h->target, h->cfg.tau, do_polyak, h->ssq_c, h->adam_blocks_c, h->ssq_a, h->counter, h->stats, out};
+                   h->target, h->cfg.tau, do_polyak, h->ssq_c, h->adam_blocks_c, h->ssq_a, h->counter, h->stats, out,
+                   h->fused_heads ? hb : 0, B, h->head_partials, h->head_partials + 2 * (size_t)hb, h->head_partials + 4 * (size_t)hb, h->g_actor + h->log_std_off};
     hipLaunchKernelGGL(sac_step_end_kernel, dim3(h->end_blocks), dim3(256), 0, h->stream, se);
     SHIP(h, hipGetLastError());
     h->bt_actor[0] *= h->cfg.adam_beta1; h->bt_actor[1] *= h->cfg.adam_beta2;
@@ -1020,7 +1031,7 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     CHK(smalloc(&h->g_critic, h->Pd)); CHK(smalloc(&h->g_actor, h->Pd)); CHK(smalloc(&h->sc, 1)); CHK(smalloc(&h->stats, 8));
     h->adam_blocks_c = std::min(256, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(256, ((h->actor.end + 3) / 4 + 2 * h->Pqd / 4 + 255) / 256);   // <= one workgroup per CU: every block pays a 9-barrier tree reduction
     CHK(smalloc(&h->ssq_c, h->adam_blocks_c)); CHK(smalloc(&h->ssq_a, h->end_blocks)); CHK(smalloc(&h->counter, 1));
-    CHK(smalloc(&h->head_partials, (size_t)kMaxA * 2 * ((B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock + 1))); CHK(smalloc(&h->head_counter, kMaxA + 1));
+    CHK(smalloc(&h->head_partials, (size_t)(2 * kMaxA + 8) * ((B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock + 1))); CHK(smalloc(&h->head_counter, kMaxA + 1));   // doubles: [critic 2 | actor 2 | log_std kMaxA | entropy 2] x blocks
     h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr; h->trace_enqueue = std::getenv("DRIL_SAC_TRACE_ENQUEUE") != nullptr;   // latched here: no getenv on the update path
     CHK(smalloc(&h->state, (size_t)E * S)); CHK(smalloc(&h->step_count, E)); CHK(smalloc(&h->episode, E)); CHK(smalloc(&h->gstep, E)); CHK(smalloc(&h->disc_returns, E));
     CHK(smalloc(&h->obs_cur, (size_t)E * D)); CHK(smalloc(&h->obs_nxt, (size_t)E * D)); CHK(smalloc(&h->e_rew, E)); CHK(smalloc(&h->e_tobs, (size_t)E * D));
