@@ -365,22 +365,9 @@ __global__ __launch_bounds__(256) void sac_actor_out_ent_kernel(ActorHeadFusedAr
 #pragma unroll
         for (int z = 2; z < 4; ++z) first_layer_row(f.P + f.qw1 + z * f.zP, f.P + f.qb1 + z * f.zP, xn, g.D + g.A, f.H1, f.relu, f.qh1 + z * f.zh + (size_t)i * f.H1);
     }
-    double mine[1] = {ssum}, tot[1];
-    if (!fold_partials<1>(mine, f.partials, f.counter, tot, sh)) return;
-    if (threadIdx.x == 0) {
-        float le = g.sc->log_ent;
-        if (g.auto_ent) {
-            const float cc = (float)(tot[0] / g.B);
-            g.stats[2] = -(le * cc);                                                          // loss = -(log_ent_coef * c), sac.jl:330
-            const float gr = -cc;
-            const float m = g.b1 * g.sc->ent_m + (1.0f - g.b1) * gr, v = g.b2 * g.sc->ent_v + (1.0f - g.b2) * gr * gr;
-            g.sc->ent_m = m; g.sc->ent_v = v;
-            le -= m / (1.0f - g.bt1) / (sqrtf(v / (1.0f - g.bt2)) + g.eps) * g.lr;           // Optimisers.Adam
-            g.sc->log_ent = le;
-        }
-        g.sc->alpha = expf(le);
-        g.stats[4] = g.sc->alpha;                                                             // :391
-    }
+    // the entropy-coefficient step itself (mean over the batch, scalar Adam) runs at the head of the next kernel that needs alpha (sac_q_out_head_kernel, mode 0):
+    // every one of its blocks sums these B per-sample terms in the same order — cheaper than a grid-wide fold here (an atomic ticket, a fence and a second phase: ~7 us)
+    if (threadIdx.x == 0) f.partials[i] = ssum;
 }
 
 // Q output layers (Z nets: the two critics, and with Z = 4 the two targets behind them) + loss head + dz2 of the two critics
@@ -392,19 +379,39 @@ struct QHeadFusedArgs {
     // critic head (mode 0) / actor head (mode 1)
     int mode; const float *rew, *nlp, *lp_pi; const uint8_t* term; const SacScalars* sc; float gamma;
     float* dq; float* stats; double* partials; unsigned int* counter;
+    // mode 0 also takes the entropy-coefficient step (sac.jl:313-343): `sc` is the state before it, `sc_next` receives the state after it (block 0), every block uses it in registers;
+    // mode 1 and the later kernels are handed sc_next as their `sc`
+    const double* ent_terms; SacScalars* sc_next; int auto_ent; float ent_lr, ent_b1, ent_b2, ent_eps, ent_bt1, ent_bt2;
 };
 __global__ __launch_bounds__(256) void sac_q_out_head_kernel(QHeadFusedArgs g) {
     __shared__ double sh[256];
     __shared__ float qs[4], dqs[2];
     __shared__ double part[2];
+    __shared__ float alpha_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = blockIdx.x;
+    if (g.mode == 0) {
+        double t = 0;
+        if (g.auto_ent) { for (int k = threadIdx.x; k < g.B; k += 256) t += g.ent_terms[k]; t = block_sum(t, sh); }   // fixed order: the same bits in every block
+        if (threadIdx.x == 0) {
+            float le = g.sc->log_ent, m = g.sc->ent_m, v = g.sc->ent_v, loss = 0.f;
+            if (g.auto_ent) {
+                const float cc = (float)(t / g.B);
+                loss = -(le * cc);                                                                // loss = -(log_ent_coef * c), sac.jl:330
+                const float gr = -cc;
+                m = g.ent_b1 * m + (1.0f - g.ent_b1) * gr; v = g.ent_b2 * v + (1.0f - g.ent_b2) * gr * gr;
+                le -= m / (1.0f - g.ent_bt1) / (sqrtf(v / (1.0f - g.ent_bt2)) + g.ent_eps) * g.ent_lr;   // Optimisers.Adam
+            }
+            alpha_s = expf(le);
+            if (blockIdx.x == 0) { g.sc_next->log_ent = le; g.sc_next->ent_m = m; g.sc_next->ent_v = v; g.sc_next->alpha = alpha_s; if (g.auto_ent) g.stats[2] = loss; g.stats[4] = alpha_s; }   // :391
+        }
+    } else if (threadIdx.x == 0) alpha_s = g.sc->alpha;
     if (wave < g.Z) {                                                          // one wave per net: q_z = W3_z . h2_z + b3_z
         const float q = wave_dot(g.P + g.w3 + wave * g.zP, g.qh2 + wave * g.zh2 + (size_t)i * g.H2, g.H2, lane) + g.P[g.b3 + wave * g.zP];
         if (lane == 0) { qs[wave] = q; g.q_out[(size_t)wave * g.nq + i] = q; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float alpha = g.sc->alpha;
+        const float alpha = alpha_s;
         float dq0, dq1; double s0 = 0, s1 = 0;
         if (g.mode == 0) {                                                    // Bellman target + critic loss (sac_critic_loss :136-150)
             const float mn = qs[2] < qs[3] ? qs[2] : qs[3];
@@ -660,6 +667,7 @@ struct dril_sac_handle {
     float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *target = nullptr, *g_critic = nullptr, *g_actor = nullptr;
     SacScalars* sc = nullptr; float* stats = nullptr; float* stats_out = nullptr; int stats_cap = 0;
     double *ssq_c = nullptr, *ssq_a = nullptr; unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
+    SacScalars* sc_next = nullptr;   // ping-pong partner of `sc` (fused heads: the entropy step writes the new state here, then the two are swapped)
     double* head_partials = nullptr; unsigned int* head_counter = nullptr; bool fused_heads = true; bool trace_enqueue = false;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
     float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
     float target_entropy = 0, act_lo = -2.0f, act_hi = 2.0f; bool external = false;   // bounds of the agent-facing action space: Box(-2,2), Box(-1,1) under ScalingWrapperEnv
@@ -794,7 +802,9 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
     EntNextArgs en{B, D, A, h->mu, h->params + h->log_std_off, h->b_ne, h->b_nn, h->xa, h->xq_next, h->b_nlp, h->b_np, h->xq_pi, h->a_pi, h->g_pi, h->lp_pi, h->sc, h->target_entropy,
                    h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->bt_ent[0], h->bt_ent[1], h->cfg.auto_ent_coef, h->stats};
     SquashBwdArgs sb{B, D, A, h->mu, h->params + h->log_std_off, h->b_np, h->a_pi, h->g_pi, h->dxq, h->sc, h->dmu, h->g_actor + h->log_std_off};
+    const float ent_bt1 = h->bt_ent[0], ent_bt2 = h->bt_ent[1];
     if (h->fused_heads) {
+        sb.sc = h->sc_next;                                                           // the state after this update's entropy step (written by the critic head kernel)
         // actor means of (obs | next obs): hidden layers as contractions, then output layer + entropy-coefficient step + next actions + the actor-loss sample in one launch
         SDO(net_forward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, 2 * B, actor_bufs(h), 1, 1, true, l1));
         double* hp_critic = h->head_partials; double* hp_actor = hp_critic + 2 * (size_t)hb; double* hp_ls = hp_actor + 2 * (size_t)hb; double* hp_ent = hp_ls + (size_t)kMaxA * hb;   // one region per head kernel
@@ -806,7 +816,8 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
         // layers + Bellman target + loss head + dz2 of the critics in one launch; [dW3|db3], [dW2|db2], dz1 in one launch; [dW1|db1]; Adam (:362)
         SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, (long long)h->nq * W, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), 4, 2, true, l1));
         QHeadFusedArgs qc{B, h->H2, h->nq, relu, 4, h->Pqd, (long long)h->nq * h->H2, h->params, h->q0.w3, h->q0.b3, h->qh2, h->q_cur, h->dz2,
-                          0, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats, hp_critic, h->head_counter};
+                          0, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats, hp_critic, h->head_counter,
+                          hp_ent, h->sc_next, h->cfg.auto_ent_coef, h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, ent_bt1, ent_bt2};
         hipLaunchKernelGGL(sac_q_out_head_kernel, dim3(hb), dim3(256), 0, h->stream, qc);
         SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), h->dq, h->g_critic, nullptr, 2, true));
         SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, h->ssq_c, h->adam_blocks_c));
@@ -815,7 +826,8 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
         // reverse of the squashed sample and the actor's dz2 in one launch; the actor's [dW3|db3], [dW2|db2], dz1 in one launch; [dW1|db1]
         SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), 2, 1, true));
         QHeadFusedArgs qp{B, h->H2, h->nq, relu, 2, h->Pqd, (long long)h->nq * h->H2, h->params, h->q0.w3, h->q0.b3, h->qh2, h->q_pi, h->dz2,
-                          1, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats, hp_actor, h->head_counter};
+                          1, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc_next, h->cfg.gamma, h->dq, h->stats, hp_actor, h->head_counter,
+                          nullptr, nullptr, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         hipLaunchKernelGGL(sac_q_out_head_kernel, dim3(hb), dim3(256), 0, h->stream, qp);
         {   // dz1 = (W2' dz2) .* act'(h1) of both critics (no parameter gradients on this pass: Zygote differentiates the actor loss w.r.t. the actor only)
             const int H1 = h->H1, H2 = h->H2;
@@ -828,6 +840,7 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
         SquashFusedArgs sf{sb, h->H1, h->H2, relu, h->nq, h->params, h->q0.w1, h->Pqd, h->dz1, h->params + h->actor.w3, h->ah2, h->dz2, hp_ls, h->head_counter};
         hipLaunchKernelGGL(sac_dx_squash_kernel, dim3(hb), dim3(256), 0, h->stream, sf);
         SDO(net_backward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, B, actor_bufs(h), h->dmu, h->g_actor, nullptr, 1, true));
+        std::swap(h->sc, h->sc_next);                                                 // h->sc is the current state again for whoever reads it next
     } else {
         // actor means of (obs | next obs) in one pass: the entropy constant (:318-325) and the actor loss (:101) share the obs half,
         // the critic target (:131) uses the next-obs half; the actor parameters do not change until the actor step
@@ -988,7 +1001,7 @@ DRIL_EXPORT int32_t dril_sac_destroy(dril_sac_handle* h) {
     if (!h) return DRIL_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->g_critic, h->g_actor, h->sc, h->stats, h->stats_out, h->ssq_c, h->ssq_a, h->counter, h->head_partials, h->head_counter,
+    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->g_critic, h->g_actor, h->sc, h->sc_next, h->stats, h->stats_out, h->ssq_c, h->ssq_a, h->counter, h->head_partials, h->head_counter,
                     h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->obs_cur, h->obs_nxt, h->e_rew, h->e_tobs, h->e_raw, h->e_envact, h->e_term, h->e_trunc,
                     h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc, h->xa, h->ah1, h->ah2, h->mu, h->xq, h->xq_pi,
                     h->qh1, h->qh2, h->q_cur, h->q_pi, h->dq, h->dz2, h->dz1, h->dxq, h->dmu, h->b_rew, h->b_ne, h->b_nn, h->b_np,
@@ -1028,7 +1041,7 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     if (ext) { h->act_lo = cfg->ext_action_low; h->act_hi = cfg->ext_action_high; }
     CHK(smalloc(&h->params, h->Pd)); CHK(smalloc(&h->adam_m, h->Pd)); CHK(smalloc(&h->adam_v, h->Pd));
     h->target = h->params + h->q0.w1 + 2 * h->Pqd;   // the targets sit right behind the critics so that one launch runs all four Q nets (blockIdx.z stride Pqd)
-    CHK(smalloc(&h->g_critic, h->Pd)); CHK(smalloc(&h->g_actor, h->Pd)); CHK(smalloc(&h->sc, 1)); CHK(smalloc(&h->stats, 8));
+    CHK(smalloc(&h->g_critic, h->Pd)); CHK(smalloc(&h->g_actor, h->Pd)); CHK(smalloc(&h->sc, 1)); CHK(smalloc(&h->sc_next, 1)); CHK(smalloc(&h->stats, 8));
     h->adam_blocks_c = std::min(256, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(256, ((h->actor.end + 3) / 4 + 2 * h->Pqd / 4 + 255) / 256);   // <= one workgroup per CU: every block pays a 9-barrier tree reduction
     CHK(smalloc(&h->ssq_c, h->adam_blocks_c)); CHK(smalloc(&h->ssq_a, h->end_blocks)); CHK(smalloc(&h->counter, 1));
     CHK(smalloc(&h->head_partials, (size_t)(2 * kMaxA + 8) * ((B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock + 1))); CHK(smalloc(&h->head_counter, kMaxA + 1));   // doubles: [critic 2 | actor 2 | log_std kMaxA | entropy 2] x blocks
