@@ -499,7 +499,7 @@ struct StepEndArgs {
     float *p, *m, *v; const float* g_actor; int n_actor, ls_off, n_ls, q_off, n_q;
     float lr, b1, b2, eps, bt1_a, bt2_a, bt1_c, bt2_c;
     float* target; float tau; int do_polyak;
-    const double* ssq_c; int nblk_c; double* ssq_a; unsigned int* counter; float* stats; float* out;
+    double* ssq_a; float* stats; float* out;   // ssq_a: this update's row of squared-gradient partials, [end blocks] (the critic's partials sit in front of it)
     // deferred sums of the fused head kernels (nhead = 0: the unfused sequence wrote stats / the log_std gradient itself): per-sample rows [nhead][2] of the critic and
     // actor loss heads, [n_ls][nhead] of the log_std gradient
     int nhead, B; const double *hp_critic, *hp_actor, *hp_ls; float* g_ls;
@@ -524,7 +524,6 @@ __device__ __forceinline__ float4 adam_vec(float* p, float* m, float* v, int i, 
 // n_actor and n_q are multiples of 4 (the device layout pads every net to 16 bytes; pads hold zero parameters and zero gradients)
 __global__ __launch_bounds__(256) void sac_step_end_kernel(StepEndArgs a) {
     __shared__ double sh[256];
-    __shared__ bool last;
     const int va = a.n_actor / 4, vq = a.n_q / 4;
     double ss = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < va + vq; i += gridDim.x * 256) {
@@ -558,29 +557,15 @@ __global__ __launch_bounds__(256) void sac_step_end_kernel(StepEndArgs a) {
         ss += (double)gi * gi;
     }
     ss = block_sum(ss, sh);
-    if (threadIdx.x == 0) {
-        a.ssq_a[blockIdx.x] = ss;
-        __threadfence();
-        last = atomicAdd(a.counter, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    double c = 0, g = 0;
-    for (int i = threadIdx.x; i < a.nblk_c; i += 256) c += ((volatile const double*)a.ssq_c)[i];
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) g += ((volatile double*)a.ssq_a)[i];
-    c = block_sum(c, sh); g = block_sum(g, sh);
+    if (threadIdx.x == 0) a.ssq_a[blockIdx.x] = ss;          // squared-gradient partial of this block: summed on the host with the critic's (sac.jl:393) — no grid-wide fold for a statistic
+    if (blockIdx.x != 0) return;
     if (a.nhead) {                                                                              // statistics of the fused loss heads
         double c0 = 0, c1 = 0, p0 = 0;
         for (int i = threadIdx.x; i < a.nhead; i += 256) { c0 += a.hp_critic[2 * i]; c1 += a.hp_critic[2 * i + 1]; p0 += a.hp_actor[2 * i]; }
         c0 = block_sum(c0, sh); c1 = block_sum(c1, sh); p0 = block_sum(p0, sh);
         if (threadIdx.x == 0) { a.stats[1] = (float)c0; a.stats[3] = (float)(c1 / (2.0 * a.B)); a.stats[0] = (float)p0; }
     }
-    if (threadIdx.x == 0) {
-        a.out[0] = a.stats[0]; a.out[1] = a.stats[1]; a.out[2] = a.stats[2]; a.out[3] = a.stats[3]; a.out[4] = a.stats[4];
-        a.out[5] = (float)sqrt(c + g);                                                        // sac.jl:393
-        *a.counter = 0u;
-    }
+    if (threadIdx.x == 0) { a.out[0] = a.stats[0]; a.out[1] = a.stats[1]; a.out[2] = a.stats[2]; a.out[3] = a.stats[3]; a.out[4] = a.stats[4]; a.out[5] = 0.f; }
 }
 
 // ---- collection (off_policy_collection.jl:28-96) ---------------------------------------------------------------------------
@@ -666,7 +651,8 @@ struct dril_sac_handle {
     hipStream_t stream = nullptr;
     float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *target = nullptr, *g_critic = nullptr, *g_actor = nullptr;
     SacScalars* sc = nullptr; float* stats = nullptr; float* stats_out = nullptr; int stats_cap = 0;
-    double *ssq_c = nullptr, *ssq_a = nullptr; unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
+    double* ssq_rows = nullptr;   // [stats_cap][adam_blocks_c + end_blocks] squared-gradient partials per update, summed on the host (grad_norm statistic)
+    unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
     SacScalars* sc_next = nullptr;   // ping-pong partner of `sc` (fused heads: the entropy step writes the new state here, then the two are swapped)
     double* head_partials = nullptr; unsigned int* head_counter = nullptr; bool fused_heads = true; bool trace_enqueue = false;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
     float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
@@ -786,6 +772,7 @@ int adam_range(dril_sac_handle* h, int lo, int n, const float* grads, const floa
 
 // one update!(agent, alg, batch): sac.jl:299-404.  `slot` = index into the injected batches (-1 = Philox), `out` = device stats row
 int sac_one_update(dril_sac_handle* h, int slot, float* out) {
+    double* ssq_row = h->ssq_rows + (size_t)((out - h->stats_out) / 8) * (h->adam_blocks_c + h->end_blocks);   // this update's squared-gradient partials: [critic Adam blocks | end blocks]
     const int B = h->cfg.batch_size, D = h->D, A = h->A, W = D + A;
     const SacRng rng{h->cfg.seed ^ 0x5ac5ac5ac5ac5ac5ull, h->update_counter};
     GatherArgs ga{B, D, A, h->cap, h->head, h->size, h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term,
@@ -820,7 +807,7 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
                           hp_ent, h->sc_next, h->cfg.auto_ent_coef, h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, ent_bt1, ent_bt2};
         hipLaunchKernelGGL(sac_q_out_head_kernel, dim3(hb), dim3(256), 0, h->stream, qc);
         SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), h->dq, h->g_critic, nullptr, 2, true));
-        SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, h->ssq_c, h->adam_blocks_c));
+        SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, ssq_row, h->adam_blocks_c));
         h->bt_critic[0] *= h->cfg.adam_beta1; h->bt_critic[1] *= h->cfg.adam_beta2;
         // actor (:93-105) with the UPDATED critics: hidden layers, then output layers + loss head + dz2 in one launch; dz1; then the action columns of W1' dz1, the
         // reverse of the squashed sample and the actor's dz2 in one launch; the actor's [dW3|db3], [dW2|db2], dz1 in one launch; [dW1|db1]
@@ -853,7 +840,7 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
         CriticHeadArgs ch{B, h->q_next, h->q_cur, h->b_rew, h->b_nlp, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats};
         hipLaunchKernelGGL(sac_critic_head_kernel, dim3(1), dim3(256), 0, h->stream, ch);
         SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), h->dq, h->g_critic, nullptr, 2));
-        SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, h->ssq_c, h->adam_blocks_c));
+        SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, ssq_row, h->adam_blocks_c));
         h->bt_critic[0] *= h->cfg.adam_beta1; h->bt_critic[1] *= h->cfg.adam_beta2;
         // actor (:93-105) with the UPDATED critics: sample, values, loss head, input gradients of the critics, squash reverse, actor reverse
         SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), 2));
@@ -867,7 +854,7 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
     const int do_polyak = h->grad_updates % h->cfg.target_update_interval == 0;
     StepEndArgs se{h->params, h->adam_m, h->adam_v, h->g_actor, round4(h->actor.end), h->log_std_off, A, h->q0.w1, 2 * h->Pqd,
                    h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->bt_actor[0], h->bt_actor[1], h->bt_critic[0], h->bt_critic[1],
-                   h->target, h->cfg.tau, do_polyak, h->ssq_c, h->adam_blocks_c, h->ssq_a, h->counter, h->stats, out,
+                   h->target, h->cfg.tau, do_polyak, ssq_row + h->adam_blocks_c, h->stats, out,
                    h->fused_heads ? hb : 0, B, h->head_partials, h->head_partials + 2 * (size_t)hb, h->head_partials + 4 * (size_t)hb, h->g_actor + h->log_std_off};
     hipLaunchKernelGGL(sac_step_end_kernel, dim3(h->end_blocks), dim3(256), 0, h->stream, se);
     SHIP(h, hipGetLastError());
@@ -922,7 +909,9 @@ int collect(dril_sac_handle* h, int n_steps, int use_random, double* fps) {
 int ensure_stats(dril_sac_handle* h, int n) {
     if (n <= h->stats_cap) return DRIL_OK;
     if (h->stats_out) hipFree(h->stats_out);
-    SHIP(h, smalloc(&h->stats_out, (size_t)n * 8)); h->stats_cap = n;
+    if (h->ssq_rows) hipFree(h->ssq_rows);
+    h->stats_out = nullptr; h->ssq_rows = nullptr;
+    SHIP(h, smalloc(&h->stats_out, (size_t)n * 8)); SHIP(h, smalloc(&h->ssq_rows, (size_t)n * (h->adam_blocks_c + h->end_blocks))); h->stats_cap = n;
     return DRIL_OK;
 }
 void fill_stats(const dril_sac_handle* h, const float* rows, int n, dril_sac_stats* out) {
@@ -950,6 +939,10 @@ int run_updates(dril_sac_handle* h, int n_updates, bool injected, dril_sac_stats
     if (out) {
         std::vector<float> rows((size_t)n_updates * 8);
         SHIP(h, hipMemcpy(rows.data(), h->stats_out, rows.size() * 4, hipMemcpyDeviceToHost));
+        const int nb = h->adam_blocks_c + h->end_blocks;
+        std::vector<double> ssq((size_t)n_updates * nb);
+        SHIP(h, hipMemcpy(ssq.data(), h->ssq_rows, ssq.size() * 8, hipMemcpyDeviceToHost));
+        for (int k = 0; k < n_updates; ++k) { double t = 0; for (int b = 0; b < nb; ++b) t += ssq[(size_t)k * nb + b]; rows[(size_t)k * 8 + 5] = (float)sqrt(t); }   // grad_norm, sac.jl:393 (index order: deterministic)
         fill_stats(h, rows.data(), n_updates, out);
     }
     return DRIL_OK;
@@ -1001,7 +994,7 @@ DRIL_EXPORT int32_t dril_sac_destroy(dril_sac_handle* h) {
     if (!h) return DRIL_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->g_critic, h->g_actor, h->sc, h->sc_next, h->stats, h->stats_out, h->ssq_c, h->ssq_a, h->counter, h->head_partials, h->head_counter,
+    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->g_critic, h->g_actor, h->sc, h->sc_next, h->stats, h->stats_out, h->ssq_rows, h->counter, h->head_partials, h->head_counter,
                     h->state, h->step_count, h->episode, h->gstep, h->disc_returns, h->obs_cur, h->obs_nxt, h->e_rew, h->e_tobs, h->e_raw, h->e_envact, h->e_term, h->e_trunc,
                     h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc, h->xa, h->ah1, h->ah2, h->mu, h->xq, h->xq_pi,
                     h->qh1, h->qh2, h->q_cur, h->q_pi, h->dq, h->dz2, h->dz1, h->dxq, h->dmu, h->b_rew, h->b_ne, h->b_nn, h->b_np,
@@ -1043,7 +1036,7 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     h->target = h->params + h->q0.w1 + 2 * h->Pqd;   // the targets sit right behind the critics so that one launch runs all four Q nets (blockIdx.z stride Pqd)
     CHK(smalloc(&h->g_critic, h->Pd)); CHK(smalloc(&h->g_actor, h->Pd)); CHK(smalloc(&h->sc, 1)); CHK(smalloc(&h->sc_next, 1)); CHK(smalloc(&h->stats, 8));
     h->adam_blocks_c = std::min(256, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(256, ((h->actor.end + 3) / 4 + 2 * h->Pqd / 4 + 255) / 256);   // <= one workgroup per CU: every block pays a 9-barrier tree reduction
-    CHK(smalloc(&h->ssq_c, h->adam_blocks_c)); CHK(smalloc(&h->ssq_a, h->end_blocks)); CHK(smalloc(&h->counter, 1));
+    CHK(smalloc(&h->counter, 1));
     CHK(smalloc(&h->head_partials, (size_t)(2 * kMaxA + 8) * ((B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock + 1))); CHK(smalloc(&h->head_counter, kMaxA + 1));   // doubles: [critic 2 | actor 2 | log_std kMaxA | entropy 2] x blocks
     h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr; h->trace_enqueue = std::getenv("DRIL_SAC_TRACE_ENQUEUE") != nullptr;   // latched here: no getenv on the update path
     CHK(smalloc(&h->state, (size_t)E * S)); CHK(smalloc(&h->step_count, E)); CHK(smalloc(&h->episode, E)); CHK(smalloc(&h->gstep, E)); CHK(smalloc(&h->disc_returns, E));
