@@ -897,3 +897,24 @@ def test_pair_kernel_at_bench_scale_matches_the_f32_kernel(pkg, monkeypatch, kin
     assert res["-1"][3] == "ppo_grad_pair_kernel" and res["0"][3] == "ppo_grad_kernel"
     assert res["-1"][1] == pytest.approx(res["0"][1], rel=1e-5) and res["-1"][2] == pytest.approx(res["0"][2], rel=1e-5)
     np.testing.assert_allclose(res["-1"][0], res["0"][0], rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_wide_split_kernel_matches_the_f32_wide_kernel(pkg, monkeypatch):
+    """hidden [256,256] (BASELINE configs[2] shape): ppo_grad_wide_split_kernel (default) against ppo_grad_wide_kernel (DRIL_GRAD_VARIANT=0) on the same seed — rollout under
+    NormalizeWrapperEnv + one update of 2 epochs x 2 minibatches of 2 048 tiles: loss, gradient norm and parameters to fp32 noise"""
+    res = {}
+    for variant in ("-1", "0"):
+        monkeypatch.setenv("DRIL_GRAD_VARIANT", variant)
+        env = pkg.PendulumEnv(max_steps=200)
+        E, T = 2048, 64
+        alg = pkg.PPO(n_steps=T, batch_size=E * T // 2, epochs=2)
+        layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(256, 256))
+        h = pkg.Handle(pkg.make_config(env, E, alg, layer, seed=3, fixed_length_episodes=True, normalize={}))
+        h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(5))))
+        h.env_reset(3); h.collect_rollout(); st = h.ppo_update()
+        res[variant] = (h.get_params().copy(), st.loss, st.grad_norm, h.grad_kernel_info().split(":")[0])
+        h.close()
+    assert res["-1"][3] == "ppo_grad_wide_split_kernel" and res["0"][3] == "ppo_grad_wide_kernel"
+    assert res["-1"][1] == pytest.approx(res["0"][1], rel=1e-5) and res["-1"][2] == pytest.approx(res["0"][2], rel=1e-5)
+    np.testing.assert_allclose(res["-1"][0], res["0"][0], rtol=1e-4, atol=2e-6)
