@@ -12,6 +12,9 @@
 // with only 128..272 output tiles per contraction the chip is filled by K-parallelism, not by tiles.  Bias rides in the forward
 // epilogue; [dW | db] come out of one contraction by appending a ones column to the activation operand (the flat parameter
 // layout stores b right behind the column-major W, i.e. [W | b] is one (out x (in+1)) column-major matrix).
+#ifndef DRIL_SAC_ADAM_BLOCKS
+#define DRIL_SAC_ADAM_BLOCKS 1024
+#endif
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -479,31 +482,6 @@ __global__ __launch_bounds__(256) void sac_dx_squash_kernel(SquashFusedArgs f) {
 
 // ---- Optimisers.Adam on a parameter range; grads == nullptr applies ZERO gradients (zero_critic_grads! then apply_gradients,
 // sac.jl:381-382: the moments decay and the parameters keep moving along the remaining momentum) ---------------------------
-struct AdamRangeArgs { float* p; float* m; float* v; const float* g; int n; float lr, b1, b2, eps, bt1, bt2; double* sumsq_partials; };
-__global__ __launch_bounds__(256) void sac_adam_kernel(AdamRangeArgs a) {
-    __shared__ double sh[256];
-    double ss = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
-        const float gi = a.g ? a.g[i] : 0.f;
-        const float m = a.b1 * a.m[i] + (1.0f - a.b1) * gi, v = a.b2 * a.v[i] + (1.0f - a.b2) * gi * gi;
-        a.m[i] = m; a.v[i] = v;
-        a.p[i] -= m / (1.0f - a.bt1) / (sqrtf(v / (1.0f - a.bt2)) + a.eps) * a.lr;
-        ss += (double)gi * gi;
-    }
-    if (a.sumsq_partials) { ss = block_sum(ss, sh); if (threadIdx.x == 0) a.sumsq_partials[blockIdx.x] = ss; }
-}
-// End of one update!: apply_gradients(train_state, actor_loss_grad) (sac.jl:382 — actor_head and log_std with their gradients, the
-// critic leaves with the ZERO arrays zero_critic_grads! left, :381), polyak_update! of the targets (:385-389, optimization_utils.jl:3-6)
-// and the step's statistics, in ONE launch.  The block that finishes last sums the per-block partials in index order (deterministic).
-struct StepEndArgs {
-    float *p, *m, *v; const float* g_actor; int n_actor, ls_off, n_ls, q_off, n_q;
-    float lr, b1, b2, eps, bt1_a, bt2_a, bt1_c, bt2_c;
-    float* target; float tau; int do_polyak;
-    double* ssq_a; float* stats; float* out;   // ssq_a: this update's row of squared-gradient partials, [end blocks] (the critic's partials sit in front of it)
-    // deferred sums of the fused head kernels (nhead = 0: the unfused sequence wrote stats / the log_std gradient itself): per-sample rows [nhead][2] of the critic and
-    // actor loss heads, [n_ls][nhead] of the log_std gradient
-    int nhead, B; const double *hp_critic, *hp_actor, *hp_ls; float* g_ls;
-};
 __device__ __forceinline__ float adam_one(float* p, float* m, float* v, int i, float gi, float lr, float b1, float b2, float eps, float bt1, float bt2) {
     const float mm = b1 * m[i] + (1.0f - b1) * gi, vv = b2 * v[i] + (1.0f - b2) * gi * gi;
     m[i] = mm; v[i] = vv;
@@ -521,6 +499,41 @@ __device__ __forceinline__ float4 adam_vec(float* p, float* m, float* v, int i, 
     *reinterpret_cast<float4*>(p + i) = pp; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
     return pp;
 }
+constexpr int kSacAdamBlocks = DRIL_SAC_ADAM_BLOCKS;   // grid cap of the two elementwise optimiser kernels (measured: see the Makefile-free default below)
+struct AdamRangeArgs { float* p; float* m; float* v; const float* g; int n; float lr, b1, b2, eps, bt1, bt2; double* sumsq_partials; };
+__global__ __launch_bounds__(256) void sac_adam_kernel(AdamRangeArgs a) {
+    __shared__ double sh[256];
+    double ss = 0;
+    const bool vec = (a.n & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(a.m) | reinterpret_cast<uintptr_t>(a.v) | reinterpret_cast<uintptr_t>(a.g)) & 15) == 0;
+    if (vec) {                                                                      // the padded device layout: 16-byte rows
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n / 4; i += gridDim.x * 256) {
+            const float4 g = a.g ? *reinterpret_cast<const float4*>(a.g + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            adam_vec(a.p, a.m, a.v, 4 * i, g, a.lr, a.b1, a.b2, a.eps, a.bt1, a.bt2);
+            ss += (double)g.x * g.x + (double)g.y * g.y + (double)g.z * g.z + (double)g.w * g.w;
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
+            const float gi = a.g ? a.g[i] : 0.f;
+            const float m = a.b1 * a.m[i] + (1.0f - a.b1) * gi, v = a.b2 * a.v[i] + (1.0f - a.b2) * gi * gi;
+            a.m[i] = m; a.v[i] = v;
+            a.p[i] -= m / (1.0f - a.bt1) / (sqrtf(v / (1.0f - a.bt2)) + a.eps) * a.lr;
+            ss += (double)gi * gi;
+        }
+    }
+    if (a.sumsq_partials) { ss = block_sum(ss, sh); if (threadIdx.x == 0) a.sumsq_partials[blockIdx.x] = ss; }
+}
+// End of one update!: apply_gradients(train_state, actor_loss_grad) (sac.jl:382 — actor_head and log_std with their gradients, the
+// critic leaves with the ZERO arrays zero_critic_grads! left, :381), polyak_update! of the targets (:385-389, optimization_utils.jl:3-6)
+// and the step's statistics, in ONE launch.  The block that finishes last sums the per-block partials in index order (deterministic).
+struct StepEndArgs {
+    float *p, *m, *v; const float* g_actor; int n_actor, ls_off, n_ls, q_off, n_q;
+    float lr, b1, b2, eps, bt1_a, bt2_a, bt1_c, bt2_c;
+    float* target; float tau; int do_polyak;
+    double* ssq_a; float* stats; float* out;   // ssq_a: this update's row of squared-gradient partials, [end blocks] (the critic's partials sit in front of it)
+    // deferred sums of the fused head kernels (nhead = 0: the unfused sequence wrote stats / the log_std gradient itself): per-sample rows [nhead][2] of the critic and
+    // actor loss heads, [n_ls][nhead] of the log_std gradient
+    int nhead, B; const double *hp_critic, *hp_actor, *hp_ls; float* g_ls;
+};
 // n_actor and n_q are multiples of 4 (the device layout pads every net to 16 bytes; pads hold zero parameters and zero gradients)
 __global__ __launch_bounds__(256) void sac_step_end_kernel(StepEndArgs a) {
     __shared__ double sh[256];
@@ -1035,7 +1048,7 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     CHK(smalloc(&h->params, h->Pd)); CHK(smalloc(&h->adam_m, h->Pd)); CHK(smalloc(&h->adam_v, h->Pd));
     h->target = h->params + h->q0.w1 + 2 * h->Pqd;   // the targets sit right behind the critics so that one launch runs all four Q nets (blockIdx.z stride Pqd)
     CHK(smalloc(&h->g_critic, h->Pd)); CHK(smalloc(&h->g_actor, h->Pd)); CHK(smalloc(&h->sc, 1)); CHK(smalloc(&h->sc_next, 1)); CHK(smalloc(&h->stats, 8));
-    h->adam_blocks_c = std::min(256, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(256, ((h->actor.end + 3) / 4 + 2 * h->Pqd / 4 + 255) / 256);   // <= one workgroup per CU: every block pays a 9-barrier tree reduction
+    h->adam_blocks_c = std::min(kSacAdamBlocks, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(kSacAdamBlocks, ((h->actor.end + 3) / 4 + 2 * h->Pqd / 4 + 255) / 256);   // elementwise optimiser kernels: up to 1 024 blocks (no grid-wide fold is left in them; 256 -> 1 024: update! 0.174 -> 0.168 ms)
     CHK(smalloc(&h->counter, 1));
     CHK(smalloc(&h->head_partials, (size_t)(2 * kMaxA + 8) * ((B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock + 1))); CHK(smalloc(&h->head_counter, kMaxA + 1));   // doubles: [critic 2 | actor 2 | log_std kMaxA | entropy 2] x blocks
     h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr; h->trace_enqueue = std::getenv("DRIL_SAC_TRACE_ENQUEUE") != nullptr;   // latched here: no getenv on the update path
