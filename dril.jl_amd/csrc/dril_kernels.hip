@@ -415,16 +415,95 @@ template <int D> __device__ __forceinline__ void pair_obs(const float (&obs)[D],
     }
 }
 
+template <int D, int H, int O> struct NetLdsSplit {
+    static_assert(H == 64, "the split kernel is laid out for hidden_dims [64,64]");
+    static constexpr int DP = 4, OP = (O + 3) / 4 * 4;
+    static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, SMALL_END = (B3 + OP + 3) / 4 * 4;
+    static constexpr int W2P = SMALL_END;                    // three pieces x [64][64] bf16 = 3 x 8192 bytes
+    static constexpr int END = W2P + 3 * H * H / 2;          // in floats
+};
+__device__ __forceinline__ int w2img_gw(int r) { return (((r >> 1) & 1) << 3) | (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 4) & 1); }
+__device__ __forceinline__ int timg_gs(int r) { return (((r >> 1) & 1) << 3) | (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1) | (r & 1); }
+
+template <int D, int H, int O>
+__device__ inline void stage_net_split(float* lds, const float* __restrict__ P, NetOff n, int tid, int nthreads) {
+    using L = NetLdsSplit<D, H, O>;
+    for (int i = tid; i < L::DP * H; i += nthreads) { const int o = i % H, k = i / H; lds[L::W1T + k * H + o] = k < D ? kTanhScale * P[n.w1 + o + k * H] : 0.0f; }
+    for (int i = tid; i < H; i += nthreads) { lds[L::B1 + i] = kTanhScale * P[n.b1 + i]; lds[L::B2 + i] = kTanhScale * P[n.b2 + i]; }
+    for (int i = tid; i < O * H; i += nthreads) { const int o = i % O, k = i / O; lds[L::W3S + o * H + k] = P[n.w3 + i]; }
+    for (int i = tid; i < L::OP; i += nthreads) lds[L::B3 + i] = i < O ? P[n.b3 + i] : 0.0f;
+    char* img = reinterpret_cast<char*>(lds + L::W2P);
+    for (int i = tid; i < H * H / 2; i += nthreads) {         // pair (k, k+1) of row o: W2 is column-major (out x in), so consecutive threads read consecutive o
+        const int o = i % H, kp = i / H;
+        unsigned hi, mid, lo;
+        split3_pair(kTanhScale * P[n.w2 + o + H * (2 * kp)], kTanhScale * P[n.w2 + o + H * (2 * kp + 1)], hi, mid, lo);
+        const int byte = o * 128 + ((((kp >> 1) ^ w2img_gw(o)) & 15) << 3) + ((kp & 1) << 2);
+        *reinterpret_cast<unsigned*>(img + byte) = hi; *reinterpret_cast<unsigned*>(img + 8192 + byte) = mid; *reinterpret_cast<unsigned*>(img + 16384 + byte) = lo;
+    }
+}
+
+__device__ __forceinline__ bf16x8 chunk_frag(const unsigned (&pc)[3][4], int p) { return __builtin_bit_cast(bf16x8, u32x4{pc[p][0], pc[p][1], pc[p][2], pc[p][3]}); }
+// ---- forward of one [64,64] net on the bf16 matrix cores (fp32-equivalent 3-piece split, as the gradient kernels): rollout_kernel / policy_kernel ----------------
+// L1 on the f32 MFMA (K = 4), tanh and split of h1 a k16 step at a time, L2 as six v_mfma_f32_32x32x16_bf16 per step against the swizzled W2 piece image, tanh, L3 on
+// the VALU.  Against the f32-MFMA forward (64 x 64 cycles on the VALU's lanes per net and tile) this is 48 x 32 cycles of matrix pipe + ~180 VALU instructions.
+template <int D, int H, int O>
+__device__ __forceinline__ void net_forward_split(const float* __restrict__ lds, const float (&xk)[2], float (&out)[O], int lane) {
+    using L = NetLdsSplit<D, H, O>;
+    constexpr int MT = H / 32;
+    const int c = lane & 31, h = lane >> 5;
+    const char* Wimg = reinterpret_cast<const char*>(lds + L::W2P);
+    const int wf_base = c * 128 + (((h ^ w2img_gw(c)) & 15) << 3);
+    f32x16 h1[MT], acc[MT];
+    dense_first<H, MT>(lds + L::W1T, lds + L::B1, xk, h1, lane);
+#pragma unroll
+    for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + L::B2 + 32 * mo + 8 * q + 4 * h);
+            acc[mo][4 * q + 0] = b[0]; acc[mo][4 * q + 1] = b[1]; acc[mo][4 * q + 2] = b[2]; acc[mo][4 * q + 3] = b[3];
+        }
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float ex[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ex[i] = __builtin_amdgcn_exp2f(h1[mi][8 * s + i]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ex[i] = fmaf(-2.0f, __builtin_amdgcn_rcpf(ex[i] + 1.0f), 1.0f);
+            unsigned pc[3][4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) split3_pair(ex[2 * tt], ex[2 * tt + 1], pc[0][tt], pc[1][tt], pc[2][tt]);
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo) {
+                const int a0 = (wf_base ^ (64 * mi + 32 * s)) + 4096 * mo;
+                bf16x8 A[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    A[p] = frag8(*reinterpret_cast<const u32x2*>(Wimg + 8192 * p + a0), *reinterpret_cast<const u32x2*>(Wimg + 8192 * p + (a0 ^ 16)));
+                acc[mo] = mfma_split6(A[0], A[1], A[2], chunk_frag(pc, 0), chunk_frag(pc, 1), chunk_frag(pc, 2), acc[mo]);
+            }
+        }
+#pragma unroll
+    for (int mo = 0; mo < MT; ++mo) tanh16(acc[mo]);
+    dense_out<MT, O, H>(lds + L::W3S, lds + L::B3, acc, out, lane);
+}
+#ifndef DRIL_FWD_SPLIT
+#define DRIL_FWD_SPLIT 1     // 0: the f32-MFMA forward in rollout_kernel / policy_kernel (A/B)
+#endif
 // forward of one net for a 32-sample tile: LDS-resident weights (H = 64) or the wide path (W2 streamed from L2)
 template <int D, int H, int O, bool WIDE>
 __device__ __forceinline__ void eval_net(const float* __restrict__ lds, const float* __restrict__ w2a, const float (&xk)[2], float (&out)[O], int lane) {
     if constexpr (WIDE) net_forward_wide<D, H, O>(lds, w2a, xk, out, lane);
+    else if constexpr (DRIL_FWD_SPLIT) net_forward_split<D, H, O>(lds, xk, out, lane);
     else { f32x16 h1[H / 32], h2[H / 32]; net_forward<D, H, H, O>(lds, xk, h1, h2, out, lane); }
 }
-template <int D, int H, int O, bool WIDE> struct FwdLds { static constexpr int SIZE = WIDE ? NetLdsSmall<D, H, O>::END : NetLds<D, H, H, O>::FWD_END; };
+template <int D, int H, int O, bool WIDE> struct FwdLds { static constexpr int SIZE = WIDE ? NetLdsSmall<D, H, O>::END : DRIL_FWD_SPLIT ? (NetLdsSplit<D, 64, O>::END + 3) / 4 * 4 : NetLds<D, H, H, O>::FWD_END; };
 template <int D, int H, int O, bool WIDE>
 __device__ __forceinline__ void stage_fwd(float* lds, const float* __restrict__ P, NetOff n, int tid, int nthreads) {
-    if constexpr (WIDE) stage_net_small<D, H, O>(lds, P, n, tid, nthreads); else stage_net<D, H, H, O, false>(lds, P, n, tid, nthreads);
+    if constexpr (WIDE) stage_net_small<D, H, O>(lds, P, n, tid, nthreads);
+    else if constexpr (DRIL_FWD_SPLIT) stage_net_split<D, H, O>(lds, P, n, tid, nthreads);
+    else stage_net<D, H, H, O, false>(lds, P, n, tid, nthreads);
 }
 // pre-tile W2 and W2' of one net for the wide path (see dril_device.h "wide nets")
 __global__ void build_wimg_kernel(const float* __restrict__ P, NetOff off, int H, float* __restrict__ w2a, float* __restrict__ w2ta) {
@@ -1231,13 +1310,6 @@ __global__ __launch_bounds__(256, 2) void ppo_grad_kernel(GradArgs a) {
 // a lane constant the optimiser cannot see through: image addresses derived from it are rebuilt per tile (2-3 VALU) instead of being hoisted out of the tile loop as
 // loop invariants, where they occupy registers for the whole kernel (ppo_grad_wide_split_kernel: 92 -> 12 spilled registers)
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
-template <int D, int H, int O> struct NetLdsSplit {
-    static_assert(H == 64, "the split kernel is laid out for hidden_dims [64,64]");
-    static constexpr int DP = 4, OP = (O + 3) / 4 * 4;
-    static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, SMALL_END = (B3 + OP + 3) / 4 * 4;
-    static constexpr int W2P = SMALL_END;                    // three pieces x [64][64] bf16 = 3 x 8192 bytes
-    static constexpr int END = W2P + 3 * H * H / 2;          // in floats
-};
 template <int D, int H, int O> struct GradScratchSplit {
     static constexpr int T = 0;                              // 12288 bytes: the h1' piece images (three [32 samples][64 units] bf16)
     static constexpr int T3 = T + 3 * 32 * H / 2;            // 12288 bytes: the dz2' piece images; after dW2 has consumed them the dz1 f32 image [H][kTS] (9216 bytes) for dW1
@@ -1245,26 +1317,6 @@ template <int D, int H, int O> struct GradScratchSplit {
     static constexpr int SIZE = XI + (D + 2) * kTS;
     static_assert(H * kTS <= 3 * 32 * H / 2, "the f32 image must fit the piece images' space");
 };
-__device__ __forceinline__ int w2img_gw(int r) { return (((r >> 1) & 1) << 3) | (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 4) & 1); }
-__device__ __forceinline__ int timg_gs(int r) { return (((r >> 1) & 1) << 3) | (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1) | (r & 1); }
-
-template <int D, int H, int O>
-__device__ inline void stage_net_split(float* lds, const float* __restrict__ P, NetOff n, int tid, int nthreads) {
-    using L = NetLdsSplit<D, H, O>;
-    for (int i = tid; i < L::DP * H; i += nthreads) { const int o = i % H, k = i / H; lds[L::W1T + k * H + o] = k < D ? kTanhScale * P[n.w1 + o + k * H] : 0.0f; }
-    for (int i = tid; i < H; i += nthreads) { lds[L::B1 + i] = kTanhScale * P[n.b1 + i]; lds[L::B2 + i] = kTanhScale * P[n.b2 + i]; }
-    for (int i = tid; i < O * H; i += nthreads) { const int o = i % O, k = i / O; lds[L::W3S + o * H + k] = P[n.w3 + i]; }
-    for (int i = tid; i < L::OP; i += nthreads) lds[L::B3 + i] = i < O ? P[n.b3 + i] : 0.0f;
-    char* img = reinterpret_cast<char*>(lds + L::W2P);
-    for (int i = tid; i < H * H / 2; i += nthreads) {         // pair (k, k+1) of row o: W2 is column-major (out x in), so consecutive threads read consecutive o
-        const int o = i % H, kp = i / H;
-        unsigned hi, mid, lo;
-        split3_pair(kTanhScale * P[n.w2 + o + H * (2 * kp)], kTanhScale * P[n.w2 + o + H * (2 * kp + 1)], hi, mid, lo);
-        const int byte = o * 128 + ((((kp >> 1) ^ w2img_gw(o)) & 15) << 3) + ((kp & 1) << 2);
-        *reinterpret_cast<unsigned*>(img + byte) = hi; *reinterpret_cast<unsigned*>(img + 8192 + byte) = mid; *reinterpret_cast<unsigned*>(img + 16384 + byte) = lo;
-    }
-}
-
 // MFMA operand (A or B) of unit tile m, k16 step s of a contraction over samples: lane (unit 32m + (lane&31), half h) gets samples 16s + 8h + j
 __device__ __forceinline__ int timg_read_base(int lane) {
     const int h = lane >> 5, gm = (lane >> 4) & 1, e = lane & 15, q = e >> 2, p = e & 3;
@@ -1319,7 +1371,6 @@ __device__ __forceinline__ u32x2 lds_read_u32x2(const char* p) { return *reinter
 __device__ __forceinline__ void mfma_acc_agpr(f32x16& acc, bf16x8 a, bf16x8 b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ bf16x8 chunk_frag(const unsigned (&pc)[3][4], int p) { return __builtin_bit_cast(bf16x8, u32x4{pc[p][0], pc[p][1], pc[p][2], pc[p][3]}); }
 // v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 blocks; lane 4b + i gives A[i] and B[i] of block b, register r of lane 4b + j receives D[r][j]
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
