@@ -144,14 +144,13 @@ __global__ __launch_bounds__(256) void sac_gather_l1_kernel(GatherL1Args f) {
             g.xa[(size_t)i * g.D + d] = o; g.xq[(size_t)i * W + d] = o; g.xa[(size_t)(g.B + i) * g.D + d] = n;
             xs[0][d] = o; xs[1][d] = n; xqs[d] = o;
         }
-        for (int a = 0; a < g.A; ++a) {
-            const float act = g.rb_act[slot * g.A + a];
-            g.xq[(size_t)i * W + g.D + a] = act; xqs[g.D + a] = act;
-            g.ne[i * g.A + a] = g.inj_ne ? g.inj_ne[i * g.A + a] : sac_noise(g.rng, 5, i, a);
-            g.nn[i * g.A + a] = g.inj_nn ? g.inj_nn[i * g.A + a] : sac_noise(g.rng, 6, i, a);
-            g.np[i * g.A + a] = g.inj_np ? g.inj_np[i * g.A + a] : sac_noise(g.rng, 7, i, a);
-        }
+        for (int a = 0; a < g.A; ++a) { const float act = g.rb_act[slot * g.A + a]; g.xq[(size_t)i * W + g.D + a] = act; xqs[g.D + a] = act; }
         g.rew[i] = g.rb_rew[slot]; g.term[i] = g.rb_term[slot];
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + 3 * g.A) {                    // the three noise arrays of the step on their own threads (a Philox block + a normal transform each), in another wave
+        const int q = threadIdx.x - 64, which = q / g.A, a = q - which * g.A;
+        const float* inj = which == 0 ? g.inj_ne : which == 1 ? g.inj_nn : g.inj_np;
+        float* dst = which == 0 ? g.ne : which == 1 ? g.nn : g.np;
+        dst[i * g.A + a] = inj ? inj[i * g.A + a] : sac_noise(g.rng, 5 + which, i, a);
     }
     __syncthreads();
     first_layer_row(f.aW1, f.ab1, xs[0], g.D, f.H1, f.relu, f.ah1 + (size_t)i * f.H1);
