@@ -219,8 +219,8 @@ size_t act_bytes_per(const dril_handle* h) { return h->discrete ? 4 : 4 * (size_
 
 // wide nets: (re)build the pre-tiled W2 / W2' images after every parameter change (enqueued on the handle's stream)
 // wide nets: 1 = ppo_grad_wide_split_kernel (bf16 matrix cores), 0 = the f32-MFMA ppo_grad_wide_kernel (DRIL_GRAD_VARIANT; records are needed by the split form)
-// default by measurement (profiles/r02_wide_split.md): hidden 256 runs the split form (183 vs 118 TFLOP/s), hidden 128 keeps the f32 kernel (93 vs 113)
-int wide_variant(const dril_handle* h) { return (h->wide && h->rec && (h->grad_variant < 0 ? (h->cfg.hidden1 >= 256 ? 1 : 0) : h->grad_variant)) ? 1 : 0; }
+// default by measurement (profiles/r02_wide_split.md): the split form for both wide widths (hidden 256: 176-183 vs 118 TFLOP/s; hidden 128: 151 vs 113.5)
+int wide_variant(const dril_handle* h) { return (h->wide && h->rec && (h->grad_variant < 0 ? 1 : h->grad_variant)) ? 1 : 0; }
 // hidden [64,64], DRIL_GRAD_VARIANT=2 (experiment): the wide split kernel's decomposition at H = 64 — two waves per tile, four workgroups per CU
 bool pair_variant(const dril_handle* h) { return !h->wide && !h->generic && (h->grad_variant == 2 || h->grad_variant < 0) && h->rec; }
 int ensure_wimg(dril_handle* h) {
@@ -344,7 +344,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     // the split kernel runs one workgroup per CU and the actor's tile costs more than the critic's (stamps: 15.7 k vs 14.2 k cycles with the
     // Categorical head; measured optimum 53 % of the CUs for the actor with it, 50 % with the DiagGaussian head): when the grid fills the chip, the CUs are divided in that proportion instead of half and half
     int Gc = G;
-    if (variant == 1 && 2 * G >= h->num_cus && h->num_cus >= 8) {
+    if (variant == 1 && !h->wide && 2 * G >= h->num_cus && h->num_cus >= 8) {   // (the wide kernels use one G for both nets)
         const int pml = h->grad_actor_pct ? h->grad_actor_pct : (h->discrete ? 530 : 500);      // per mille
         int ga = (h->num_cus * pml + 500) / 1000; if (ga < 1) ga = 1; if (ga > h->num_cus - 1) ga = h->num_cus - 1;
         G = ga; Gc = h->num_cus - ga;

@@ -900,17 +900,20 @@ def test_pair_kernel_at_bench_scale_matches_the_f32_kernel(pkg, monkeypatch, kin
 
 
 @pytest.mark.gpu
-def test_wide_split_kernel_matches_the_f32_wide_kernel(pkg, monkeypatch):
-    """hidden [256,256] (BASELINE configs[2] shape): ppo_grad_wide_split_kernel (default) against ppo_grad_wide_kernel (DRIL_GRAD_VARIANT=0) on the same seed — rollout under
-    NormalizeWrapperEnv + one update of 2 epochs x 2 minibatches of 2 048 tiles: loss, gradient norm and parameters to fp32 noise"""
+@pytest.mark.parametrize("kind,H,E", [(1, 256, 2048), (0, 256, 4096), (0, 128, 4096), (1, 128, 4096)])
+def test_wide_split_kernel_matches_the_f32_wide_kernel(pkg, monkeypatch, kind, H, E):
+    """hidden [256,256] (BASELINE configs[2] shape) and [128,128]: ppo_grad_wide_split_kernel (default) against ppo_grad_wide_kernel (DRIL_GRAD_VARIANT=0) on the same seed —
+    rollout (Pendulum: under NormalizeWrapperEnv) + one update of 2 epochs x 2 minibatches: loss, gradient norm and parameters to fp32 noise.  The E = 4096 cases fill
+    the chip (every workgroup slot; the Categorical head among them: the grid-size rules of the [64,64] kernels must not leak into the wide ones — they once did, and the
+    critic lost 8 of its 128 slabs)"""
     res = {}
     for variant in ("-1", "0"):
         monkeypatch.setenv("DRIL_GRAD_VARIANT", variant)
-        env = pkg.PendulumEnv(max_steps=200)
-        E, T = 2048, 64
+        env = pkg.PendulumEnv(max_steps=200) if kind == 1 else pkg.CartPoleEnv(max_steps=500)
+        T = 64
         alg = pkg.PPO(n_steps=T, batch_size=E * T // 2, epochs=2)
-        layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(256, 256))
-        h = pkg.Handle(pkg.make_config(env, E, alg, layer, seed=3, fixed_length_episodes=True, normalize={}))
+        layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(H, H))
+        h = pkg.Handle(pkg.make_config(env, E, alg, layer, seed=3, fixed_length_episodes=True, normalize={} if kind == 1 else None))
         h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(5))))
         h.env_reset(3); h.collect_rollout(); st = h.ppo_update()
         res[variant] = (h.get_params().copy(), st.loss, st.grad_norm, h.grad_kernel_info().split(":")[0])

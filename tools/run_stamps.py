@@ -18,7 +18,9 @@ wide = len(sys.argv) > 1 and sys.argv[1] == "wide"       # config 3 shape: Pendu
 env = pkg.PendulumEnv(max_steps=200) if wide else pkg.CartPoleEnv(max_steps=500)
 E, T = 65536, (256 if wide else 2048)
 alg = pkg.PPO(n_steps=T, batch_size=E * T // (4 if wide else 32), epochs=1)
-layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(256, 256) if wide else (64, 64))
+import os
+HW = int(os.environ.get("STAMPS_HIDDEN", "256"))
+layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(HW, HW) if wide else (64, 64))
 cfg = pkg.make_config(env, E, alg, layer, seed=42, fixed_length_episodes=True)
 h = pkg.Handle(cfg, lib)
 h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(42))))
