@@ -119,7 +119,7 @@ struct dril_handle {
     int grad_stagger = 0;
     int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
     int grad_actor_pct = 0;   // ppo_grad_split_kernel: share (per mille) of the CUs given to the actor workgroups; 0 = by head (env DRIL_GRAD_ACTOR_PERMILLE)
-    int last_variant = -1;  // which gradient kernel the last optimiser step ran: 0 f32 fused, 1 bf16-split fused, 2 wide, 3 generic (dril_grad_kernel_info)
+    int last_variant = -1;  // which gradient kernel the last optimiser step ran: 0 ppo_grad_kernel, 1 ppo_grad_split_kernel, 2 ppo_grad_wide_kernel, 3 generic path, 4 ppo_grad_wide_split_kernel, 5 ppo_grad_pair_kernel (dril_grad_kernel_info)
     int grad_variant = -1;  // hidden [64,64]: 0 = f32-MFMA ppo_grad_kernel, 1 = ppo_grad_split_kernel (bf16 x 3 operand splitting, one wave per tile, one workgroup per CU), 2 = ppo_grad_pair_kernel (same arithmetic, two waves per tile, two waves per SIMD), -1 = by minibatch size: 2 for large, 0 for small (env DRIL_GRAD_VARIANT)
     bool external = false; bool generic = false; float* gen_tmp = nullptr;   // generic: layer-by-layer kernels (host envs, or a device env whose hidden_dims the fused kernels are not built for)
     GenericDims gd{}; GenericWs gws; int ext_t = 0; bool ext_acted = false;   // DRIL_ENV_EXTERNAL: host envs, generic kernels
@@ -340,6 +340,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
         if (variant == 2 && !(pair_variant(h) && rec)) variant = tiles >= 16 * (int64_t)h->num_cus ? 1 : 0;   // the pair kernel reads packed records
         if (variant == 2) { G = (int)(tiles < h->Gmax ? tiles : h->Gmax) & ~1; if (G < 2) G = 2; }   // pairs per net (even: two pairs per workgroup)
         if (variant == 1) { const int gm = h->num_cus / 2 > 0 ? h->num_cus / 2 : 1; if (G > gm) G = gm; }
+        if (variant == 0 && G > h->num_cus) G = h->num_cus;                                   // Gmax is sized for the pair kernel's slabs; the f32 kernel runs two workgroups per CU
     }
     // the split kernel runs one workgroup per CU and the actor's tile costs more than the critic's (stamps: 15.7 k vs 14.2 k cycles with the
     // Categorical head; measured optimum 53 % of the CUs for the actor with it, 50 % with the DiagGaussian head): when the grid fills the chip, the CUs are divided in that proportion instead of half and half
