@@ -90,6 +90,8 @@ def _same_stats(a, b):
     (0, 64, 24, 128, 2, {"has_target_kl": 1, "target_kl": 0.003}),   # KL early stop decided identically on every rank
     (0, 4096, 64, 262144, 2, {}),                             # bench-scale minibatches: 4 096 tiles per rank = ppo_grad_pair_kernel with the unequal pair split, through the all-reduce
     (1, 4096, 64, 131072, 2, {"ent_coef": 0.01}),            # the same with DiagGaussian and two minibatches per epoch (2 048 tiles per rank: every pair gets tiles, the second pairs one fewer)
+    (0, 2048, 32, 65536, 2, {"hidden1": 256, "hidden2": 256}),   # wide nets: ppo_grad_wide_split_kernel (Categorical head) through the all-reduce
+    (1, 2048, 32, 65536, 2, {"hidden1": 128, "hidden2": 128, "ent_coef": 0.01}),
 ])
 def test_two_ranks_equal_one_handle_over_the_union(pkg, oracle_mod, kind, E, T, B, world, kw):
     """rollout (no communication) + update with an injected DataLoader order: per-step advantage-moment all-reduce (3 doubles),
