@@ -11,7 +11,9 @@ import os
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "csrc" / "libdril_hip.so"
+# DRIL_HIP_LIBRARY: another build of the SAME library (diagnostic builds such as the stamps build or the negative-control build of the
+# split-arithmetic tests); it must still be a gfx950 libdril_hip — there is no CPU implementation to point this at
+LIB_PATH = Path(os.environ["DRIL_HIP_LIBRARY"]) if os.environ.get("DRIL_HIP_LIBRARY") else PKG_DIR / "csrc" / "libdril_hip.so"
 
 ABI_VERSION = 2
 ENV_CARTPOLE, ENV_PENDULUM, ENV_PENDULUM_SCALED, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONTINUOUS, ENV_EXTERNAL, ENV_ACROBOT = 0, 1, 2, 3, 4, 5, 6

@@ -337,7 +337,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     if (h->wide) variant = (wide_variant(h) && rec) ? 1 : 0;
     if (!h->wide && !h->generic) {
         variant = h->grad_variant >= 0 ? h->grad_variant : (tiles >= 16 * (int64_t)h->num_cus ? 2 : 0);   // large minibatches: the pair kernel (1 = the one-wave-per-tile split kernel)
-        if (variant == 2 && !(pair_variant(h) && rec)) variant = tiles >= 16 * (int64_t)h->num_cus ? 1 : 0;   // the pair kernel reads packed records
+        if (variant == 2 && !(pair_variant(h) && rec && h->Gmax >= 2)) variant = tiles >= 16 * (int64_t)h->num_cus ? 1 : 0;   // the pair kernel reads packed records and needs two slabs per workgroup (DRIL_GRAD_GMAX=1: not the pair kernel)
         if (variant == 2) { G = (int)(tiles < h->Gmax ? tiles : h->Gmax) & ~1; if (G < 2) G = 2; }   // pairs per net (even: two pairs per workgroup)
         if (variant == 1) { const int gm = h->num_cus / 2 > 0 ? h->num_cus / 2 : 1; if (G > gm) G = gm; }
         if (variant == 0 && G > h->num_cus) G = h->num_cus;                                   // Gmax is sized for the pair kernel's slabs; the f32 kernel runs two workgroups per CU
@@ -386,6 +386,12 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     g.has_clip_vf = h->cfg.has_clip_range_vf; g.normalize_adv = h->cfg.normalize_advantage; g.action_start = h->cfg.action_start;
     g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
     g.G = G; g.Gc = Gc; g.dbg = h->dbg; g.layout = h->grad_layout; g.variant = variant; g.stagger = h->grad_stagger; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
+    // host-side preconditions of the gradient kernels: a violated one would be a device fault (null advantage moments in a kernel without in-kernel
+    // moments — the SIGABRT of profiles/r02_split_kernel.md "the abort of 09:41" —, a slab index past the Gmax slabs that were allocated); only a status code
+    // may cross the ABI
+    const bool kernel_has_inline_moments = !h->wide && !h->generic && variant != 2;
+    if (g.normalize_adv && !adv_stats && !kernel_has_inline_moments) return fail(h, DRIL_ERR_INVALID_ARG, "ppo_step: advantage moments missing for a gradient kernel without in-kernel moments");
+    if (G < 1 || Gc < 1 || G > h->Gmax || Gc > h->Gmax || (variant == 2 && !h->wide && !h->generic && ((G | Gc) & 1))) return fail(h, DRIL_ERR_INVALID_ARG, "ppo_step: gradient grid does not fit the slab buffers");
     prof_begin(h, DRIL_K_PPO_GRAD);
     if (h->generic) HIPCHK(h, generic_ppo_grad(h->gd, g, h->gws, h->stream));
     else HIPCHK(h, launch_ppo_grad(h->cfg.env_kind, h->cfg.hidden1, g, h->stream));
@@ -1090,16 +1096,19 @@ DRIL_EXPORT int32_t dril_ppo_loss_grad(dril_handle* h, const float* obs, const v
     if (!obs || !actions || !advantages || !returns || !old_logprobs || !old_values || batch < 1) return fail(h, DRIL_ERR_INVALID_ARG, "dril_ppo_loss_grad: bad argument");
     if (h->cfg.world_size > 1) return fail(h, DRIL_ERR_UNSUPPORTED, "dril_ppo_loss_grad is a single-rank parity entry point");
     const size_t B = (size_t)batch;
-    float *d_obs = nullptr, *d_adv = nullptr, *d_ret = nullptr, *d_lp = nullptr, *d_val = nullptr; void* d_act = nullptr;
-    auto cleanup = [&]() { hipFree(d_obs); hipFree(d_adv); hipFree(d_ret); hipFree(d_lp); hipFree(d_val); hipFree(d_act); };
+    float *d_obs = nullptr, *d_adv = nullptr, *d_ret = nullptr, *d_lp = nullptr, *d_val = nullptr; void* d_act = nullptr; float4* d_rec = nullptr;
+    auto cleanup = [&]() { hipFree(d_obs); hipFree(d_adv); hipFree(d_ret); hipFree(d_lp); hipFree(d_val); hipFree(d_act); hipFree(d_rec); };
 #define LCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(h, DRIL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
     LCHK(dmalloc(&d_obs, B * h->D)); LCHK(dmalloc(&d_adv, B)); LCHK(dmalloc(&d_ret, B)); LCHK(dmalloc(&d_lp, B)); LCHK(dmalloc(&d_val, B)); LCHK(hipMalloc(&d_act, B * act_bytes_per(h)));
     LCHK(hipMemcpyAsync(d_obs, obs, B * h->D * 4, hipMemcpyHostToDevice, h->stream)); LCHK(hipMemcpyAsync(d_adv, advantages, B * 4, hipMemcpyHostToDevice, h->stream));
     LCHK(hipMemcpyAsync(d_ret, returns, B * 4, hipMemcpyHostToDevice, h->stream)); LCHK(hipMemcpyAsync(d_lp, old_logprobs, B * 4, hipMemcpyHostToDevice, h->stream));
     LCHK(hipMemcpyAsync(d_val, old_values, B * 4, hipMemcpyHostToDevice, h->stream)); LCHK(hipMemcpyAsync(d_act, actions, B * act_bytes_per(h), hipMemcpyHostToDevice, h->stream));
     LCHK(hipMemsetAsync(h->stop_flag, 0, 4, h->stream));
+    // the same packed records dril_ppo_update builds, so that this parity entry point runs the kernel the size rule picks for `batch` in production
+    // (the pair / wide split kernels read records only)
+    if (h->rec) { LCHK(dmalloc(&d_rec, 2 * B)); LCHK(launch_pack_records(h->cfg.env_kind, batch, d_obs, d_act, d_adv, d_lp, d_ret, d_rec, h->stream)); }
 #undef LCHK
-    int rc = ppo_step(h, d_obs, d_act, d_adv, d_ret, d_lp, d_val, nullptr, 0, batch, batch, 0, /*bits=0: identity order*/ 0, nullptr, false);
+    int rc = ppo_step(h, d_obs, d_act, d_adv, d_ret, d_lp, d_val, nullptr, 0, batch, batch, 0, /*bits=0: identity order*/ 0, nullptr, false, d_rec);
     std::vector<float> flat((size_t)h->P + 8);
     if (!rc) { hipError_t e = hipMemcpyAsync(flat.data(), h->flat, flat.size() * 4, hipMemcpyDeviceToHost, h->stream); if (e != hipSuccess) rc = fail(h, DRIL_ERR_HIP, hipGetErrorString(e)); }
     if (!rc) rc = sync(h);

@@ -123,7 +123,7 @@ __device__ __forceinline__ float tanh_f32(float x) {
 constexpr float kTanhScale = 2.8853900817779268f;
 
 // ---------------------------------------------------------------------------------------------
-// fp32-equivalent contraction on the bf16 matrix cores: every f32 operand is cut into three bf16 pieces x = hi + mid + lo (upper 16 bits, exact
+// fp32-equivalent contraction on the bf16 matrix cores: every f32 operand is cut into three bf16 pieces x = hi + mid + lo (nearest bf16, exact
 // remainder, twice: exact for a 24-bit mantissa) and a k16 step of a 32x32 tile is six v_mfma_f32_32x32x16_bf16 (hi.hi hi.mid mid.hi mid.mid hi.lo lo.hi;
 // the three dropped partial products are <= 2^-23 relative; f32 accumulate).  profiles/r01_bf16_split_microbench.md: 2.0x the rate of
 // v_mfma_f32_32x32x2_f32 with pre-split operands, max error 1.0e-7 vs 1.5e-7 for the f32 MFMA chain — not a precision reduction, and the matrix pipe
@@ -133,19 +133,33 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-// pieces of two values packed for one 32-bit word: {b[31:16], a[31:16]} of each piece (v_perm_b32): 4 VALU per value + 1.5 per pair
+// pieces of two values packed for one 32-bit word, {piece of b, piece of a} in the high / low half.  ROUND-TO-NEAREST pieces (v_cvt_pk_bf16_f32, one instruction
+// per pair and piece): hi = rn(x), mid = rn(x - hi), lo = rn(x - hi - mid); both remainders are exact in f32 and lo is exact for a 24-bit mantissa, so
+// x = hi + mid + lo.  Round 2 cut the pieces by TRUNCATION (mask + v_perm_b32, the same 11 VALU per pair): every remainder then has the sign of x, the three
+// dropped partial products (mid.lo, lo.mid, lo.lo: up to 2 x 2^-24 relative) all pull a product toward zero, and the f64 error budget of
+// tests/test_gpu_split_arith.py measured it — dW2 shrunk by 2.1e-7 of itself, 2.6x the f32 kernel's distance from the float64 gradient.  Nearest rounding makes
+// the remainders half as large and signed at random: the dropped terms are <= 2^-26 relative and unbiased (profiles/r03_split_arith.md).
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-    const unsigned ah = __float_as_uint(a) & 0xffff0000u, bh = __float_as_uint(b) & 0xffff0000u;
-    const float ar = a - __uint_as_float(ah), br = b - __uint_as_float(bh);
-    const unsigned am = __float_as_uint(ar) & 0xffff0000u, bm = __float_as_uint(br) & 0xffff0000u;
-    const float aq = ar - __uint_as_float(am), bq = br - __uint_as_float(bm);
-    hi = __builtin_amdgcn_perm(bh, ah, 0x07060302u); mid = __builtin_amdgcn_perm(bm, am, 0x07060302u);
-    lo = __builtin_amdgcn_perm(__float_as_uint(bq), __float_as_uint(aq), 0x07060302u);
+    hi = cvt_pk_bf16(a, b);
+    const float ar = a - __uint_as_float(hi << 16), br = b - __uint_as_float(hi & 0xffff0000u);
+    mid = cvt_pk_bf16(ar, br);
+    const float aq = ar - __uint_as_float(mid << 16), bq = br - __uint_as_float(mid & 0xffff0000u);
+    lo = cvt_pk_bf16(aq, bq);
 }
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 // one k16 step of the split product, small terms first
+// -DDRIL_DEBUG_DROP_LO (libdril_hip_droplo.so, the NEGATIVE CONTROL of tests/test_gpu_split_arith.py, never the product): the two products with a `lo`
+// piece are left out, i.e. a two-piece split (2^-16 relative) — the error-budget tests must FAIL on that build, which is what gives them power
 __device__ __forceinline__ f32x16 mfma_split6(bf16x8 Ah, bf16x8 Am, bf16x8 Al, bf16x8 Bh, bf16x8 Bm, bf16x8 Bl, f32x16 acc) {
-    acc = mfma_bf16(Al, Bh, acc); acc = mfma_bf16(Ah, Bl, acc); acc = mfma_bf16(Am, Bm, acc);
+#ifndef DRIL_DEBUG_DROP_LO
+    acc = mfma_bf16(Al, Bh, acc); acc = mfma_bf16(Ah, Bl, acc);
+#endif
+    acc = mfma_bf16(Am, Bm, acc);
     acc = mfma_bf16(Am, Bh, acc); acc = mfma_bf16(Ah, Bm, acc); acc = mfma_bf16(Ah, Bh, acc);
     return acc;
 }

@@ -1,0 +1,130 @@
+"""GPU (-m gpu): the bf16 x 3 operand split of the update kernels, at the minibatch sizes where the size rule selects those kernels,
+(1) directly against the CPU oracle (ppo.jl:365-407 + hand-written backward), (2) against a float64 gradient with an error budget relative to
+the exact-f32 kernel, (3) with a negative control: the same library built with the `lo` pieces dropped (a two-piece split, 2^-16 relative)
+must BREAK the budget — which is what shows that (2) can tell a 24-bit product from a 16-bit one.
+
+Tolerances: loss 1e-4 rel (BASELINE.json north_star), gradient within 2e-4 of its norm, as for the f32 kernel in tests/test_gpu_parity.py.
+"""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import split_budget
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+BUFS = ("BUF_OBSERVATIONS", "BUF_ACTIONS", "BUF_ADVANTAGES", "BUF_RETURNS", "BUF_LOGPROBS", "BUF_VALUES")
+
+
+def _cfg(pkg, kind, **kw):
+    c = pkg._capi.default_config(kind)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _batch(oracle, cfg, B, seed):
+    rng = np.random.default_rng(seed)
+    obs = rng.uniform(-1, 1, (B, oracle.D)).astype(np.float32)
+    act = (rng.integers(0, oracle.A, B) + cfg.action_start).astype(np.int32) if oracle.discrete else rng.normal(0, 1, (B, oracle.A)).astype(np.float32)
+    adv, ret, ov = (rng.standard_normal(B).astype(np.float32) for _ in range(3))
+    _, lp, _ = oracle.evaluate_actions(obs, act)
+    return obs, act, adv, ret, (lp + rng.normal(0, 0.1, B)).astype(np.float32), ov
+
+
+EXPECTED = {64: "ppo_grad_pair_kernel", 128: "ppo_grad_wide_split_kernel", 256: "ppo_grad_wide_split_kernel"}
+
+
+@pytest.mark.parametrize("kind,H,B,variant", [
+    (0, 64, 131072, "default"),            # 4 096 tiles = 16 tiles per CU: the smallest minibatch the size rule gives to the pair kernel
+    (1, 64, 131072, "ent_vfclip"),
+    (0, 64, 262144 + 45, "ent_vfclip"),    # multi-trip loop with unequal actor / critic pair counts and a ragged last tile
+    (1, 64, 262144, "default"),
+    (3, 64, 131072 + 1, "default"),        # MountainCar: Categorical(3), D = 2
+    (1, 256, 32768, "default"),            # configs[2] shape: 8 tiles per workgroup of the chip-filling grid
+    (0, 256, 16384 + 19, "ent_vfclip"),
+    (0, 128, 32768, "default"),
+    (1, 128, 32768 + 7, "ent_vfclip"),
+])
+def test_selected_kernel_loss_and_gradient_vs_oracle(pkg, oracle_mod, kind, H, B, variant):
+    """dril_ppo_loss_grad with the library's own kernel selection (asserted through dril_grad_kernel_info) against orc_ppo_loss_grad"""
+    kw = dict(n_envs=2, n_steps=2, batch_size=2, hidden1=H, hidden2=H)
+    if variant == "ent_vfclip":
+        kw.update(ent_coef=0.01, has_clip_range_vf=1, clip_range_vf=0.3, clip_range=0.1)
+    cfg = _cfg(pkg, kind, **kw)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = (np.random.default_rng(50 + kind).standard_normal(h.P) * (0.25 if H == 64 else 0.08)).astype(np.float32)
+    h.set_params(flat); o.set_params(flat)
+    batch = _batch(o, cfg, B, 3)
+    lh, sh, gh = h.ppo_loss_grad(*batch); lo, so, go = o.ppo_loss_grad(*batch)
+    assert h.grad_kernel_info().split(":")[0] == EXPECTED[H]
+    assert lh == pytest.approx(lo, rel=1e-4)
+    np.testing.assert_allclose(sh, so, rtol=2e-4, atol=2e-6)
+    rel = np.linalg.norm(gh - go) / np.linalg.norm(go)
+    print(f"[split vs oracle] kind {kind} H {H} B {B}: loss rel {abs(lh - lo) / abs(lo):.2e}, |dg|/|g| {rel:.2e}")
+    assert rel <= 2e-4
+    lh2, _, gh2 = h.ppo_loss_grad(*batch)
+    assert lh2 == lh and np.array_equal(gh, gh2)                     # deterministic slabs
+
+
+@pytest.mark.parametrize("kind,H,E,T", [(0, 64, 2048, 128), (1, 64, 2048, 128), (1, 256, 512, 64), (0, 128, 512, 64)])
+def test_selected_kernel_update_vs_oracle(pkg, oracle_mod, kind, H, E, T):
+    """one dril_ppo_update (2 epochs x 2 minibatches of N/2 samples: 131 072 at hidden 64, i.e. the pair kernel by the size rule) on the oracle's rollout and an
+    injected DataLoader order: statistics and parameters after four Adam steps against orc_ppo_update"""
+    capi = pkg._capi
+    N = E * T
+    cfg = _cfg(pkg, kind, n_envs=E, n_steps=T, batch_size=N // 2, epochs=2, episode_len=25, hidden1=H, hidden2=H, ent_coef=0.01)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = (np.random.default_rng(60 + kind).standard_normal(h.P) * (0.3 if H == 64 else 0.08)).astype(np.float32)
+    h.set_params(flat); o.set_params(flat)
+    o.env_reset(5); o.collect_rollout()
+    for name in BUFS:
+        h.set_buffer(getattr(capi, name), o.buffer(getattr(capi, name)))
+    perm = np.stack([np.random.default_rng(e).permutation(N) for e in range(2)]).astype(np.int64)
+    h.set_permutation(perm); o.set_permutation(perm)
+    sh, so = h.ppo_update(), o.ppo_update()
+    assert h.grad_kernel_info().split(":")[0] == EXPECTED[H]
+    assert (sh.n_updates, sh.early_stopped) == (so.n_updates, so.early_stopped) == (4, 0)
+    for f in ("policy_loss", "value_loss", "entropy_loss", "approx_kl_div", "clip_fraction", "loss", "grad_norm", "explained_variance", "ratio_first"):
+        assert getattr(sh, f) == pytest.approx(getattr(so, f), rel=5e-4, abs=2e-6), f
+    assert sh.loss == pytest.approx(so.loss, rel=1e-4)
+    np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=2e-4, atol=3e-6)
+
+
+BUDGET_CASES = [(0, 64, 4096, 2), (1, 64, 4096, 2), (0, 64, 131072, None), (1, 64, 131072, None), (1, 256, 8192, None), (0, 128, 8192, None)]
+
+
+@pytest.mark.parametrize("kind,H,B,forced", BUDGET_CASES)
+def test_split_error_budget_vs_float64(pkg, oracle_mod, kind, H, B, forced):
+    """‖g_split − g_f64‖ <= 2 ‖g_f32kernel − g_f64‖ and the same for the loss; the dW2 error has no bias beyond its spread and no shrinkage (split_budget.within_budget)"""
+    m = split_budget.measure(pkg, oracle_mod, kind, H, B, forced)
+    print("[budget]", json.dumps(m))
+    assert m["kernel_split"] == EXPECTED[H] and m["kernel_f32"] in ("ppo_grad_kernel", "ppo_grad_wide_kernel")
+    ok_grad, ok_loss, ok_bias = split_budget.within_budget(m)
+    assert ok_grad, (m["grad_err_split"], m["grad_err_f32"])
+    assert ok_loss, (m["loss_err_split"], m["loss_err_f32"])
+    assert ok_bias, (m["dW2_mean_err_split"], m["dW2_std_err_split"], m["dW2_shrink_split"], m["dW2_shrink_f32"])
+    assert m["grad_err_split"] <= 5e-7                                    # absolute: fp32-level agreement with float64 (measured 0.9 - 1.6e-7, profiles/r03_split_arith.md)
+
+
+def test_negative_control_two_piece_split_breaks_the_budget(pkg):
+    """the same measurement on libdril_hip_droplo.so (mfma_split6 without its two `lo` products = a two-piece split): the gradient criterion of the budget test
+    must FAIL for every case — a test that a 2^-16 product passes would prove nothing about 2^-23"""
+    so = ROOT / "dril.jl_amd" / "csrc" / "libdril_hip_droplo.so"
+    assert so.exists(), f"{so} missing: __graft_entry__.build() compiles it"
+    env = dict(os.environ, DRIL_HIP_LIBRARY=str(so))
+    env.pop("DRIL_GRAD_VARIANT", None)
+    cases = [c for c in BUDGET_CASES if c[2] <= 8192]
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "split_budget.py"), json.dumps(cases)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ms = json.loads(r.stdout.strip().splitlines()[-1])
+    for m in ms:
+        print("[negative control]", json.dumps(m))
+        ok_grad, _, _ = split_budget.within_budget(m)
+        assert not ok_grad, m
+        assert m["grad_err_split"] > 5.0 * m["grad_err_f32"]              # and not marginally

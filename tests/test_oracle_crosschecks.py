@@ -14,9 +14,9 @@ def _hidden_of(cfg):
     return hd, (torch.relu if cfg.activation else torch.tanh)
 
 
-def _nets(flat, D, hidden, A, discrete):
+def _nets(flat, D, hidden, A, discrete, dtype=torch.float64):
     """split the flat parameter vector (include/dril_hip.h layout: {W_1 b_1 ... W_{n+1} b_{n+1}} per net) into torch tensors (out x in, column-major)"""
-    t = torch.tensor(flat, dtype=torch.float64, requires_grad=True)
+    t = torch.tensor(flat, dtype=dtype, requires_grad=True)
     off = 0
     out = []
     for O in (A, 1):
@@ -38,13 +38,14 @@ def _mlp(net, x, act=torch.tanh):
     return h @ net[-1][0].T + net[-1][1]
 
 
-def torch_ppo_loss(flat, cfg, obs, actions, adv, ret, old_logp, old_val, discrete, A):
-    """(alg::PPO)(policy, ps, st, batch): src/algorithms/ppo.jl:365-407 written with torch ops (float64)."""
+def torch_ppo_loss(flat, cfg, obs, actions, adv, ret, old_logp, old_val, discrete, A, dtype=torch.float64):
+    """(alg::PPO)(policy, ps, st, batch): src/algorithms/ppo.jl:365-407 written with torch ops (float64; dtype=torch.float32 = the precision the reference
+    itself computes in: Float32 tensors, Float32 BLAS sums)."""
     D = obs.shape[1]
     hidden, act = _hidden_of(cfg)
-    t, actor, critic, ls = _nets(flat, D, hidden, A, discrete)
-    x = torch.tensor(obs, dtype=torch.float64)
-    advt = torch.tensor(adv, dtype=torch.float64)
+    t, actor, critic, ls = _nets(flat, D, hidden, A, discrete, dtype)
+    x = torch.tensor(obs, dtype=dtype)
+    advt = torch.tensor(adv, dtype=dtype)
     if cfg.normalize_advantage:
         advt = (advt - advt.mean()) / (advt.std(unbiased=True) + 1e-8)      # ppo.jl:350-356
     out = _mlp(actor, x, act)
@@ -55,22 +56,22 @@ def torch_ppo_loss(flat, cfg, obs, actions, adv, ret, old_logp, old_val, discret
         logp = torch.log(p.gather(1, a[:, None])[:, 0])
         ent = -(p * torch.log(p)).sum(1)
     else:
-        xa = torch.tensor(actions, dtype=torch.float64)
+        xa = torch.tensor(actions, dtype=dtype)
         k = A
         logp = -0.5 * (2 * ls.sum() + ((xa - out) ** 2 * torch.exp(-2 * ls)).sum(1) + k * math.log(2 * math.pi))
         ent = (0.5 * k * (1 + math.log(2 * math.pi)) + ls.sum()).expand(x.shape[0])
     if cfg.has_clip_range_vf:
-        ov = torch.tensor(old_val, dtype=torch.float64)
+        ov = torch.tensor(old_val, dtype=dtype)
         values = ov + torch.clamp(values - ov, -cfg.clip_range_vf, cfg.clip_range_vf)
-    r = torch.exp(logp - torch.tensor(old_logp, dtype=torch.float64))
+    r = torch.exp(logp - torch.tensor(old_logp, dtype=dtype))
     rc = torch.clamp(r, 1 - cfg.clip_range, 1 + cfg.clip_range)
     p_loss = -torch.minimum(r * advt, rc * advt).mean()
     ent_loss = -ent.mean()
-    v_loss = ((values - torch.tensor(ret, dtype=torch.float64)) ** 2).mean()
+    v_loss = ((values - torch.tensor(ret, dtype=dtype)) ** 2).mean()
     loss = p_loss + cfg.ent_coef * ent_loss + cfg.vf_coef * v_loss
     loss.backward()
-    lr = logp - torch.tensor(old_logp, dtype=torch.float64)
-    stats = [p_loss.item(), v_loss.item(), ent_loss.item(), (r != rc).double().mean().item(),
+    lr = logp - torch.tensor(old_logp, dtype=dtype)
+    stats = [p_loss.item(), v_loss.item(), ent_loss.item(), (r != rc).to(dtype).mean().item(),
              (torch.exp(lr) - 1 - lr).mean().item(), ent.mean().item(), r.mean().item()]
     return loss.item(), np.array(stats), t.grad.numpy()
 
@@ -404,6 +405,52 @@ def test_acrobot_physics_vs_gymnasium_equations(oracle_mod, pkg):
             elif not edge:
                 np.testing.assert_allclose(cur[e], exp, rtol=2e-4, atol=2e-4)
     assert saw_term and saw_wrap and saw_bound
+
+
+def f64_ppo_update(flat, cfg, bufs, perm, discrete, A, max_steps=None, dtype=np.float64):
+    """The epoch x minibatch loop of train! (ppo.jl:205-239) carried in FLOAT64 end to end: torch-f64 autograd for the loss gradient, global-norm clip
+    (optimization_utils.jl:74-107, no eps), Adam(eps = cfg.adam_eps) with the bias-corrected form of SURVEY a19.  bufs = (obs (N, D), actions, adv, ret, logp, val);
+    perm (epochs, N).  Returns the float64 parameters after all (or max_steps) optimiser steps — the yardstick for how far fp32 rounding carries a long update
+    (the configs[0] test measures the oracle's and the device's distance from it).  dtype=np.float32 carries the SAME loop in Float32 throughout (torch-f32
+    autograd, f32 Adam state): the reference's own precision (PPO{Float32}, Float32 BLAS sums) — the yardstick for what "as close as the reference itself" means
+    after 1 280 sequential Adam steps."""
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    obs, act, adv, ret, lp, val = bufs
+    p = np.asarray(flat, dtype).copy(); m = np.zeros_like(p); v = np.zeros_like(p)
+    b1, b2, t = dtype(cfg.adam_beta1), dtype(cfg.adam_beta2), 0
+    one, lr, eps = dtype(1), dtype(cfg.learning_rate), dtype(cfg.adam_eps)
+    N, B = adv.shape[0], int(cfg.batch_size)
+    for ep in range(perm.shape[0]):
+        for k in range(0, N, B):
+            idx = perm[ep, k:k + B]
+            _, _, g = torch_ppo_loss(p, cfg, obs[idx], act[idx], adv[idx], ret[idx], lp[idx], val[idx], discrete, A, tdt)
+            norm = np.sqrt((g * g).sum(dtype=dtype))
+            if cfg.has_max_grad_norm and norm > cfg.max_grad_norm:
+                g = g * (dtype(cfg.max_grad_norm) / norm)
+            t += 1
+            m = b1 * m + (one - b1) * g; v = b2 * v + (one - b2) * g * g
+            p = p - lr * (m / (one - b1 ** dtype(t))) / (np.sqrt(v / (one - b2 ** dtype(t))) + eps)
+            if max_steps is not None and t >= max_steps:
+                return p
+    return p
+
+
+def test_f64_update_loop_matches_oracle_on_a_short_update(oracle_mod, pkg):
+    """pins the float64 yardstick itself: 24 optimiser steps (3 epochs x 8 minibatches) of the oracle against f64_ppo_update at the short-update tolerance"""
+    capi = pkg._capi
+    cfg = capi.default_config(0); cfg.n_envs, cfg.n_steps, cfg.batch_size, cfg.epochs, cfg.episode_len = 8, 64, 64, 3, 30
+    o = oracle_mod.Oracle(cfg)
+    flat = (np.random.default_rng(2).standard_normal(o.P) * 0.3).astype(np.float32)
+    o.set_params(flat); o.env_reset(3); o.collect_rollout()
+    N = 8 * 64
+    bufs = tuple(o.buffer(w).reshape(N, -1) if w == capi.BUF_OBSERVATIONS else o.buffer(w).reshape(N) for w in
+                 (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES))
+    perm = np.stack([np.random.default_rng(e).permutation(N) for e in range(3)]).astype(np.int64)
+    o.set_permutation(perm); st = o.ppo_update()
+    assert st.n_updates == 24
+    p64 = f64_ppo_update(flat, cfg, bufs, perm, o.discrete, o.A)
+    np.testing.assert_allclose(o.get_params(), p64, rtol=2e-4, atol=3e-6)
+    assert np.abs(p64 - flat).max() > 1e-3
 
 
 def test_update_loop_control_flow(oracle_mod, pkg):
