@@ -116,11 +116,9 @@ struct dril_handle {
     RmsState *obs_rms = nullptr, *ret_rms = nullptr; int obs_par = 0, ret_par = 0;   // ping-pong RunningMeanStd pairs
     double* rms_partials = nullptr; int rms_blocks = 256; float* e_obs_raw = nullptr; float* e_rew_n = nullptr;   // e_obs_raw / e_rew: get_original_obs / get_original_rewards; e_rew_n: rewards as the wrapper delivers them
     double* rms_red = nullptr;   // data-parallel: this step's partial sums folded to one row and summed over ranks
-    int grad_stagger = 0;
-    int grad_layout = 1, grad_prio = 0, grad_split = 50;   // tuning knobs (env DRIL_GRAD_LAYOUT / _PRIO / _SPLIT)
-    int grad_actor_pct = 0;   // ppo_grad_split_kernel: share (per mille) of the CUs given to the actor workgroups; 0 = by head (env DRIL_GRAD_ACTOR_PERMILLE)
-    int last_variant = -1;  // which gradient kernel the last optimiser step ran: 0 ppo_grad_kernel, 1 ppo_grad_split_kernel, 2 ppo_grad_wide_kernel, 3 generic path, 4 ppo_grad_wide_split_kernel, 5 ppo_grad_pair_kernel (dril_grad_kernel_info)
-    int grad_variant = -1;  // hidden [64,64]: 0 = f32-MFMA ppo_grad_kernel, 1 = ppo_grad_split_kernel (bf16 x 3 operand splitting, one wave per tile, one workgroup per CU), 2 = ppo_grad_pair_kernel (same arithmetic, two waves per tile, two waves per SIMD), -1 = by minibatch size: 2 for large, 0 for small (env DRIL_GRAD_VARIANT)
+    int grad_actor_pct = 0;   // ppo_grad_pair_kernel: share (per mille) of the pairs given to the actor; 0 = by head (env DRIL_GRAD_ACTOR_PERMILLE)
+    int last_variant = -1;  // which gradient kernel the last optimiser step ran: 0 ppo_grad_kernel, 2 ppo_grad_wide_kernel, 3 generic path, 4 ppo_grad_wide_split_kernel, 5 ppo_grad_pair_kernel (dril_grad_kernel_info)
+    int grad_variant = -1;  // env DRIL_GRAD_VARIANT: 0 = the exact-f32 kernels (ppo_grad_kernel / ppo_grad_wide_kernel), 1 = the bf16-split kernels (ppo_grad_pair_kernel at hidden 64, ppo_grad_wide_split_kernel at 128 / 256) for every minibatch size, -1 = default: wide nets split, hidden 64 by minibatch size
     bool external = false; bool generic = false; float* gen_tmp = nullptr;   // generic: layer-by-layer kernels (host envs, or a device env whose hidden_dims the fused kernels are not built for)
     GenericDims gd{}; GenericWs gws; int ext_t = 0; bool ext_acted = false;   // DRIL_ENV_EXTERNAL: host envs, generic kernels
     float* ext_stage_rew = nullptr; uint8_t* ext_stage_flags = nullptr;   // pinned [T][E] staging: dril_ext_record returns without draining the stream
@@ -221,8 +219,8 @@ size_t act_bytes_per(const dril_handle* h) { return h->discrete ? 4 : 4 * (size_
 // wide nets: 1 = ppo_grad_wide_split_kernel (bf16 matrix cores), 0 = the f32-MFMA ppo_grad_wide_kernel (DRIL_GRAD_VARIANT; records are needed by the split form)
 // default by measurement (profiles/r02_wide_split.md): the split form for both wide widths (hidden 256: 176-183 vs 118 TFLOP/s; hidden 128: 151 vs 113.5)
 int wide_variant(const dril_handle* h) { return (h->wide && h->rec && (h->grad_variant < 0 ? 1 : h->grad_variant)) ? 1 : 0; }
-// hidden [64,64], DRIL_GRAD_VARIANT=2 (experiment): the wide split kernel's decomposition at H = 64 — two waves per tile, four workgroups per CU
-bool pair_variant(const dril_handle* h) { return !h->wide && !h->generic && (h->grad_variant == 2 || h->grad_variant < 0) && h->rec; }
+// hidden [64,64]: may ppo_grad_pair_kernel run at all (it reads packed records; DRIL_GRAD_VARIANT=0 pins the exact-f32 kernel)
+bool pair_variant(const dril_handle* h) { return !h->wide && !h->generic && h->grad_variant != 0 && h->rec; }
 int ensure_wimg(dril_handle* h) {
     if (!h->wide || !h->wimg_dirty) return DRIL_OK;
     HIPCHK(h, launch_build_wimg(h->params, h->actor, h->cfg.hidden1, h->w2a_actor, h->w2ta_actor, h->stream));
@@ -331,27 +329,18 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     const bool reduce = world > 1 || (comm_ready(h) && h->force_allreduce);   // force: exercise the RCCL path on one rank (tests)
     const int64_t tiles = (count + kTile - 1) / kTile;
     int G = h->wide ? (int)(tiles < h->Gmax ? tiles : h->Gmax) : (int)((tiles + 3) / 4); if (G > h->Gmax) G = h->Gmax; if (G < 1) G = 1;
-    // hidden [64,64]: large minibatches run the bf16-split kernel (one 4-wave workgroup per CU: G actor + G critic workgroups fill the chip once); small ones keep
+    // hidden [64,64]: large minibatches run ppo_grad_pair_kernel (bf16 matrix cores, two waves per tile, two workgroups of two pairs per CU); small ones keep
     // the f32 kernel, whose weight staging is cheaper (no operand split per workgroup) and which the launch-bound small path is tuned for
     int variant = 0;
     if (h->wide) variant = (wide_variant(h) && rec) ? 1 : 0;
     if (!h->wide && !h->generic) {
-        variant = h->grad_variant >= 0 ? h->grad_variant : (tiles >= 16 * (int64_t)h->num_cus ? 2 : 0);   // large minibatches: the pair kernel (1 = the one-wave-per-tile split kernel)
-        if (variant == 2 && !(pair_variant(h) && rec && h->Gmax >= 2)) variant = tiles >= 16 * (int64_t)h->num_cus ? 1 : 0;   // the pair kernel reads packed records and needs two slabs per workgroup (DRIL_GRAD_GMAX=1: not the pair kernel)
+        variant = h->grad_variant == 0 ? 0 : h->grad_variant > 0 ? 2 : (tiles >= 16 * (int64_t)h->num_cus ? 2 : 0);   // large minibatches: the pair kernel
+        if (variant == 2 && !(pair_variant(h) && rec && h->Gmax >= 2)) variant = 0;   // the pair kernel reads packed records and needs two slabs per workgroup (DRIL_GRAD_GMAX=1: not the pair kernel)
         if (variant == 2) { G = (int)(tiles < h->Gmax ? tiles : h->Gmax) & ~1; if (G < 2) G = 2; }   // pairs per net (even: two pairs per workgroup)
-        if (variant == 1) { const int gm = h->num_cus / 2 > 0 ? h->num_cus / 2 : 1; if (G > gm) G = gm; }
         if (variant == 0 && G > h->num_cus) G = h->num_cus;                                   // Gmax is sized for the pair kernel's slabs; the f32 kernel runs two workgroups per CU
     }
-    // the split kernel runs one workgroup per CU and the actor's tile costs more than the critic's (stamps: 15.7 k vs 14.2 k cycles with the
-    // Categorical head; measured optimum 53 % of the CUs for the actor with it, 50 % with the DiagGaussian head): when the grid fills the chip, the CUs are divided in that proportion instead of half and half
     int Gc = G;
-    if (variant == 1 && !h->wide && 2 * G >= h->num_cus && h->num_cus >= 8) {   // (the wide kernels use one G for both nets)
-        const int pml = h->grad_actor_pct ? h->grad_actor_pct : (h->discrete ? 530 : 500);      // per mille
-        int ga = (h->num_cus * pml + 500) / 1000; if (ga < 1) ga = 1; if (ga > h->num_cus - 1) ga = h->num_cus - 1;
-        G = ga; Gc = h->num_cus - ga;
-        if (G > h->Gmax) G = h->Gmax; if (Gc > h->Gmax) Gc = h->Gmax;
-    }
-    if (variant == 2 && 2 * G >= 4 * h->num_cus) {     // pair kernel filling the chip (two workgroups of two pairs per CU): the pairs are divided between the nets like the CUs above
+    if (variant == 2 && 2 * G >= 4 * h->num_cus) {     // pair kernel filling the chip (two workgroups of two pairs per CU): the pairs are divided between the nets by their cost per tile
         const int pml = h->grad_actor_pct ? h->grad_actor_pct : (h->discrete ? 470 : 460), total = 4 * h->num_cus;   // measured optima: the older (actor) workgroups win the issue arbitration on a shared SIMD
         int ga = ((total * pml + 500) / 1000) & ~1; if (ga < 2) ga = 2; if (ga > total - 2) ga = total - 2;
         G = ga; Gc = total - ga;
@@ -363,7 +352,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     const double* adv_stats = h->adv_stats;
     // launch-bound regime (the reference's default batch_size = 64): the advantage moments are computed inside the grad kernel and
     // reduce + norm + Adam run as one workgroup: 2 dependent launches per optimiser step instead of 6
-    const bool small = !reduce && !h->wide && !h->generic && h->grad_layout == 1 && count <= 4096 && !h->no_small_path && variant != 2;   // (the pair kernel has no in-kernel moments: forced onto a small minibatch it takes the general path)
+    const bool small = !reduce && !h->wide && !h->generic && count <= 4096 && !h->no_small_path && variant != 2;   // (the pair kernel has no in-kernel moments: forced onto a small minibatch it takes the general path)
     if (h->cfg.normalize_advantage && pre_stats) adv_stats = pre_stats;   // per-epoch table (already all-reduced in data-parallel runs)
     else if (h->cfg.normalize_advantage && small) adv_stats = nullptr;
     else if (h->cfg.normalize_advantage) {
@@ -385,7 +374,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     g.clip_range = h->cfg.clip_range; g.ent_coef = h->cfg.ent_coef; g.vf_coef = h->cfg.vf_coef; g.clip_range_vf = h->cfg.clip_range_vf;
     g.has_clip_vf = h->cfg.has_clip_range_vf; g.normalize_adv = h->cfg.normalize_advantage; g.action_start = h->cfg.action_start;
     g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
-    g.G = G; g.Gc = Gc; g.dbg = h->dbg; g.layout = h->grad_layout; g.variant = variant; g.stagger = h->grad_stagger; g.prio = h->grad_prio; g.split_pct = h->grad_split; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
+    g.G = G; g.Gc = Gc; g.dbg = h->dbg; g.variant = variant; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
     // host-side preconditions of the gradient kernels: a violated one would be a device fault (null advantage moments in a kernel without in-kernel
     // moments — the SIGABRT of profiles/r02_split_kernel.md "the abort of 09:41" —, a slab index past the Gmax slabs that were allocated); only a status code
     // may cross the ABI
@@ -524,14 +513,10 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     h->P = h->critic.end + (h->discrete ? 0 : h->A);
     h->N = (int64_t)cfg->n_envs * cfg->n_steps; h->lr = cfg->learning_rate;
     if (!fused_shape || std::getenv("DRIL_FORCE_GENERIC")) h->generic = true;            // DRIL_FORCE_GENERIC: run a fused-shape handle on the generic kernels (A/B and parity tests)
-    if (const char* e = std::getenv("DRIL_GRAD_LAYOUT")) h->grad_layout = std::atoi(e);
     if (const char* e = std::getenv("DRIL_FORCE_ALLREDUCE")) h->force_allreduce = std::atoi(e) != 0;
     if (const char* e = std::getenv("DRIL_FORCE_STEPWISE")) h->force_stepwise = std::atoi(e) != 0;
-    if (const char* e = std::getenv("DRIL_GRAD_PRIO")) h->grad_prio = std::atoi(e);
-    if (const char* e = std::getenv("DRIL_GRAD_STAGGER")) h->grad_stagger = std::atoi(e);
-    if (const char* e = std::getenv("DRIL_GRAD_SPLIT")) h->grad_split = std::atoi(e);
     if (const char* e = std::getenv("DRIL_GRAD_ACTOR_PERMILLE")) { h->grad_actor_pct = std::atoi(e); if (h->grad_actor_pct < 100 || h->grad_actor_pct > 900) h->grad_actor_pct = 0; }
-    if (const char* e = std::getenv("DRIL_GRAD_VARIANT")) { h->grad_variant = std::atoi(e); if (h->grad_variant < -1 || h->grad_variant > 2) h->grad_variant = -1; }
+    if (const char* e = std::getenv("DRIL_GRAD_VARIANT")) { h->grad_variant = std::atoi(e); if (h->grad_variant < -1 || h->grad_variant > 2) h->grad_variant = -1; if (h->grad_variant == 2) h->grad_variant = 1; }
     h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
     CCHK(hipSetDevice(cfg->device));
@@ -546,7 +531,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (h->generic) { h->slab_a = generic_slab_size(h->gd, true); h->slab_c = generic_slab_size(h->gd, false); }
     else { h->slab_a = slab_size_actor(cfg->env_kind, hd[0]); h->slab_c = slab_size_critic(cfg->env_kind, hd[0]); }
     h->wide = !h->generic && hd[0] > 64;
-    h->Gmax = (h->wide && hd[0] > 128) ? (h->num_cus / 2 > 0 ? h->num_cus / 2 : 1) : (!h->wide && (h->grad_variant == 2 || h->grad_variant < 0)) ? 3 * h->num_cus : h->num_cus;   // H = 128: 4 waves and 77 KB LDS per workgroup, two workgroups per CU   // [64,64]: 2 workgroups per CU (actor + critic), 4 waves each; wide: 1 workgroup of H/32 waves per CU
+    h->Gmax = (h->wide && hd[0] > 128) ? (h->num_cus / 2 > 0 ? h->num_cus / 2 : 1) : (!h->wide && h->grad_variant != 0) ? 3 * h->num_cus : h->num_cus;   // H = 128: 4 waves and 77 KB LDS per workgroup, two workgroups per CU   // [64,64]: 2 workgroups per CU (actor + critic), 4 waves each; wide: 1 workgroup of H/32 waves per CU
     if (h->generic) { h->Gmax = std::getenv("DRIL_EXT_GMAX") ? std::atoi(std::getenv("DRIL_EXT_GMAX")) : 64; if (h->Gmax < 1) h->Gmax = 1; }                                                        // generic path: one slab per row chunk of the minibatch
     if (const char* e = std::getenv("DRIL_GRAD_GMAX")) { const int g = std::atoi(e); if (g > 0 && g < h->Gmax) h->Gmax = g; }   // diagnostic: fewer workgroups per net
     if (h->wide) { const size_t pb = (size_t)hd[0] * hd[0] * 6;    // three bf16 pieces per element
@@ -1276,7 +1261,6 @@ DRIL_EXPORT const char* dril_grad_kernel_info(const dril_handle* h) {
     if (!h) return "?";
     switch (h->last_variant) {
         case 0: return "ppo_grad_kernel: f32 (v_mfma_f32_32x32x2_f32)";
-        case 1: return "ppo_grad_split_kernel: f32 (bf16x3 split, f32 accumulate; v_mfma_f32_32x32x16_bf16 x 6 per k16 step, input layer on v_mfma_f32_32x32x2_f32)";
         case 2: return "ppo_grad_wide_kernel: f32 (v_mfma_f32_32x32x2_f32)";
         case 5: return "ppo_grad_pair_kernel: f32 (bf16x3 split, f32 accumulate; v_mfma_f32_32x32x16_bf16 x 6 per k16 step, input layer on v_mfma_f32_32x32x2_f32)";
         case 4: return "ppo_grad_wide_split_kernel: f32 (bf16x3 split, f32 accumulate; v_mfma_f32_32x32x16_bf16 x 6 per k16 step, input layer and dW1 on f32 MFMAs)";

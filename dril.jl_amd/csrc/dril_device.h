@@ -139,10 +139,14 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // dropped partial products (mid.lo, lo.mid, lo.lo: up to 2 x 2^-24 relative) all pull a product toward zero, and the f64 error budget of
 // tests/test_gpu_split_arith.py measured it — dW2 shrunk by 2.1e-7 of itself, 2.6x the f32 kernel's distance from the float64 gradient.  Nearest rounding makes
 // the remainders half as large and signed at random: the dropped terms are <= 2^-26 relative and unbiased (profiles/r03_split_arith.md).
+// (a vector cast, NOT inline asm: the hazard recogniser does not see through an asm statement, so the software wait states this part needs between an
+// MFMA / trans result and a VALU consumer are not inserted around it — the first version of this function was `asm("v_cvt_pk_bf16_f32 ...")`, and one
+// instantiation of rollout_kernel (ScalingWrapperEnv, last-value forward) then produced a NaN for one env, deterministically for that build:
+// profiles/r03_split_arith.md section 5)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));     // v_cvt_pk_bf16_f32 (round to nearest even; a NaN stays a NaN)
 }
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
     hi = cvt_pk_bf16(a, b);

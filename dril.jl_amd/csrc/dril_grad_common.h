@@ -1,0 +1,157 @@
+// dril_grad_common.h — shared by the PPO update kernels (dril_grad_f32.hip, dril_grad_pair.hip, dril_grad_wide.hip): minibatch tile gather, loss head (ppo.jl:365-407 per sample), diagnostic stamps
+#pragma once
+#include "dril_internal.h"
+#include "dril_heads.h"
+
+namespace dril {
+
+// =============================================================================================
+// ppo_grad_kernel — the dominant kernel.  Fused forward + loss + backward of ONE net per workgroup
+// (even blocks: actor, odd blocks: critic — the two MLPs share no parameters, layer_helpers.jl:13-25,
+// so their gradients decouple given the batch).  Per 32-sample tile and net: 228 v_mfma_f32_32x32x2_f32
+//   fwd  L1 4 + L2 64                      (L3 and its transpose products run on the VALU, O <= 2)
+//   bwd  dh1 = W2' dz2 64, dW2 += dz2 h1' 64, dW1|db1 += dz1 [x;1]' 32
+// Weight gradients accumulate in registers over the workgroup's whole share of the minibatch and
+// leave as ONE slab per workgroup (plain coalesced stores) — grad_reduce_kernel sums the slabs in a
+// fixed order, so the result is bitwise reproducible and no float atomics are used.
+// =============================================================================================
+enum { HEAD_CATEGORICAL = 0, HEAD_GAUSSIAN = 1, HEAD_VALUE = 2 };
+constexpr int kLsMax = 4;   // action dims whose log_std the kernels keep in registers
+
+// diagnostic build only (-DDRIL_STAMPS): per-phase s_memtime shares of one tile; never used for timing claims
+#ifdef DRIL_STAMPS
+#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \
+                      __builtin_amdgcn_sched_barrier(0); stamp_acc[k] += _t - stamp_prev; stamp_prev = _t; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+// a lane constant the optimiser cannot see through: image addresses derived from it are rebuilt per tile (2-3 VALU) instead of being hoisted out of the tile loop as
+// loop invariants, where they occupy registers for the whole kernel (ppo_grad_wide_split_kernel: 92 -> 12 spilled registers)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+// one lane's share of a minibatch tile (DataLoader gather, ppo.jl:188-195).  Loaded one tile AHEAD of its use so the
+// random-gather latency (~2 us under load, fully exposed in v1: 23 % of wave time in s_waitcnt) hides under the
+// previous tile's MFMAs; the loop body issues no other vector-memory op, so the loads stay in flight until first use.
+template <int O> struct TileIn { float xk[2]; float s0, s1; int act; float xa[O]; bool valid; float4 raw; };
+
+template <int KIND, int O, int HEAD, bool REC>
+__device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64_t ntiles, int c, int h, TileIn<O>& t) {
+    constexpr int D = EnvSpec<KIND>::D;
+    const bool live = tile < ntiles;
+    const int64_t i = (live ? tile : ntiles - 1) * kTile + c;
+    const bool inb = live && i < a.count;
+    const int64_t p = a.pos0 + (inb ? i : 0);
+    const int64_t gidx = a.perm ? a.perm[p] : (a.perm_bits ? perm_index(p, a.N, a.perm_key, a.perm_bits) : p);   // bits 0 = identity order
+    const int64_t li = gidx - a.idx_lo;
+    t.valid = inb && li >= 0 && li < a.n_local;
+    const int64_t idx = t.valid ? li : 0;
+    t.act = 0; t.s0 = 0.f; t.s1 = 0.f;
+    if (REC) {
+        // lane (sample, h) loads half h of the record; t.raw is exchanged between the half-waves at first use (unpack_tile)
+        t.raw = a.rec[2 * idx + h];
+        if (HEAD == HEAD_VALUE && a.has_clip_vf) t.s1 = a.val_old[idx];
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; t.xk[s] = d < D ? a.obs[idx * D + d] : 0.f; }
+    if (HEAD == HEAD_VALUE) { t.s0 = a.ret[idx]; t.s1 = a.has_clip_vf ? a.val_old[idx] : 0.f; }
+    else {
+        t.s0 = a.adv[idx]; t.s1 = a.logp_old[idx];
+        if (HEAD == HEAD_CATEGORICAL) t.act = ((const int32_t*)a.actions)[idx] - a.action_start;
+        else {
+#pragma unroll
+            for (int o = 0; o < O; ++o) t.xa[o] = ((const float*)a.actions)[idx * O + o];
+        }
+    }
+}
+
+// exchange the two record halves between the half-waves: v_permlane32_swap(a, b) swaps a[32..63] with b[0..31], so with
+// a = b = v the results are {lo-half value in every lane, hi-half value in every lane}
+template <int KIND, int O, int HEAD, bool REC>
+__device__ __forceinline__ void unpack_tile(const GradArgs& a, int h, TileIn<O>& t) {
+    if (!REC) return;
+    float lo[4], hi[4];
+    const float v[4] = {t.raw.x, t.raw.y, t.raw.z, t.raw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned u = __float_as_uint(v[i]);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        lo[i] = __uint_as_float(r[0]); hi[i] = __uint_as_float(r[1]);
+    }
+    t.xk[0] = h ? lo[1] : lo[0]; t.xk[1] = h ? lo[3] : lo[2];      // xk[s] = obs[2s + h]
+    if (HEAD == HEAD_VALUE) t.s0 = hi[3];
+    else {
+        t.s0 = hi[1]; t.s1 = hi[2];
+        if (HEAD == HEAD_CATEGORICAL) t.act = __float_as_int(hi[0]) - a.action_start; else t.xa[0] = hi[0];
+    }
+}
+
+// (alg::PPO)(...) loss terms and dLoss/d(net output) for one sample per lane (ppo.jl:377-404); `tally` selects the lanes that
+// add to the statistics / log_std sums (each sample is replicated in the two half-waves, and in every wave of a wide workgroup)
+template <int O, int HEAD>
+__device__ __forceinline__ void loss_head(const GradArgs& a, const TileIn<O>& cur, const float (&out)[O], bool valid, bool tally, const float* ls,
+                                          float adv_mean, float adv_inv, float (&dz)[O], float (&st)[5], float (&dlsp)[O]) {
+    // branch-free on purpose: a lane-dependent `if` here becomes an s_cbranch_execz in the middle of the tile loop and splits it into basic blocks
+    // that the scheduler cannot move MFMAs / LDS reads across
+    const bool count_it = valid && tally;
+    if (HEAD == HEAD_VALUE) {
+        const float R = cur.s0;
+        const float ov = cur.s1, dcl = out[0] - ov;                        // clip_range, ppo.jl:344-346,378
+        const bool inside = (dcl >= -a.clip_range_vf) & (dcl <= a.clip_range_vf);      // bitwise: && / ?: compile to branches
+        const bool vpass = inside | (a.has_clip_vf == 0);
+        const float vclip = ov + fminf(fmaxf(dcl, -a.clip_range_vf), a.clip_range_vf);
+        const float value = a.has_clip_vf ? vclip : out[0];
+        const float ve = value - R;
+        dz[0] = (valid & vpass) ? a.invB * a.vf_coef * 2.0f * ve : 0.f;
+        st[0] += count_it ? ve * ve : 0.f;                                 // value_loss numerator, ppo.jl:385
+    } else {
+        const float advn = (cur.s0 - adv_mean) * adv_inv;
+        const float olp = cur.s1;
+        float logp, ent;
+        float p[O];
+        int act = 0;
+        float xa[O];
+        if (HEAD == HEAD_CATEGORICAL) {
+            softmax_n<O>(out, p);
+            act = cur.act;
+            logp = flog(pick<O>(p, act));
+            ent = categorical_entropy<O>(p);
+        } else {
+#pragma unroll
+            for (int o = 0; o < O; ++o) xa[o] = cur.xa[o];
+            logp = gauss_logpdf<O>(xa, out, ls);
+            ent = gauss_entropy<O>(ls);
+        }
+        const float lr = logp - olp;
+        const float r = fexp(lr);                                          // ppo.jl:380
+        const float lo = 1.0f - a.clip_range, hi = 1.0f + a.clip_range;
+        const float rc = fminf(fmaxf(r, lo), hi);                          // :381
+        const float t1 = r * advn, t2 = rc * advn;
+        const float mn = t2 < t1 ? t2 : t1;                                // :382
+        const float dm_dr = (t2 < t1) ? ((r >= lo && r <= hi) ? advn : 0.f) : advn;
+        const float dlogp = valid ? -a.invB * dm_dr * r : 0.f;
+        const float dent = valid ? -a.invB * a.ent_coef : 0.f;             // ent_loss = -mean(entropy), :383,:386
+        if (HEAD == HEAD_CATEGORICAL) {
+#pragma unroll
+            for (int o = 0; o < O; ++o)
+                dz[o] = dlogp * ((o == act ? 1.0f : 0.0f) - p[o]) + dent * (-p[o] * (flog(p[o]) + ent));
+        } else {
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const float iv = fexp(-2.0f * ls[o]), d = xa[o] - out[o];
+                dz[o] = dlogp * d * iv;
+                dlsp[o] += tally ? dlogp * (d * d * iv - 1.0f) + dent : 0.f;
+            }
+        }
+        st[0] += count_it ? -mn : 0.f; st[1] += count_it ? ent : 0.f; st[2] += (count_it && r != rc) ? 1.0f : 0.0f;   // :382,:383,:390
+        st[3] += count_it ? (r - 1.0f) - lr : 0.f; st[4] += count_it ? r : 0.f;                                       // :393,:402
+    }
+}
+
+// per-wave LDS scratch of grad_body (floats): one [H][kTS] transpose image reused in turn for h2, h1, dz2, dz1,
+// the [D+2][kTS] first-layer input image (rows 0..D-1 = x, row D = 1 for the bias column, row D+1 = 0) and the [O][kTS]
+// dLoss/dout image.  2 workgroups (4 waves each) per CU => 2 waves per SIMD, so one wave's VALU/LDS phases overlap the
+// other's MFMAs; that needs <= 256 registers and <= 80 KB LDS per workgroup.
+
+}  // namespace dril

@@ -1,0 +1,325 @@
+// dril_grad_pair.hip — ppo_grad_pair_kernel: the update kernel of hidden [64,64] for large minibatches (THE HEADLINE KERNEL): bf16 matrix cores, fp32-equivalent 3-piece operand split, two waves per tile
+#include <utility>
+
+#include "dril_grad_common.h"
+#include "dril_split_pieces.h"
+
+namespace dril {
+
+// =============================================================================================
+// ppo_grad_pair_kernel — hidden [64,64], large minibatches: TWO waves own one 32-sample tile (wave p the m-tile p of every layer and the 32 x 64 slice p of dW2: the
+// decomposition of ppo_grad_wide_split_kernel at MT = 2), two pairs per workgroup, two workgroups per CU = TWO waves per SIMD at <= 256 registers.  That is the one
+// arrangement in which the matrix pipe and the VALU run beside each other on this part (profiles/r02_split_kernel.md: a lone wave's VALU work does not run under its own
+// MFMAs; a second wave's does, completely).  Same arithmetic as ppo_grad_split_kernel (bf16 matrix cores, fp32-equivalent 3-piece operand splitting).
+//   * W2 lives in LDS once per workgroup as three bf16 pieces in the piece-image layout of the wide split kernel (128-byte rows, 16-byte chunk ch of row r at ch ^ f(r)):
+//     row reads (ds_read_b128) give the A operand of L2, ds_read_b64_tr_b16 the A operand of dh1 (W2'); pre-scaled by kTanhScale, dh1 folds 1 / kTanhScale into its mask.
+//   * each pair has two 12 KB piece images (h1, dz2): every wave writes its own 32 columns once; row reads give the B operand of L2 / dh1 (both m-tiles), transposed
+//     reads both operands of dW2.
+//   * no f32 image at all: dW3, db2, dW1 and db1 are per-lane accumulations (the lane is the sample), reduced over the 32 lanes of a half once, in the epilogue.
+//   * four workgroup barriers per tile; both pairs of a workgroup run the same number of tiles (the second pair's last tile may be an all-invalid one).
+// Every wave owns distinct rows of every gradient: one slab per PAIR, written straight from registers.  a.G / a.Gc = pairs of the actor / the critic (even);
+// grid = (a.G + a.Gc) / 2 workgroups, the first a.G / 2 run the actor.
+// =============================================================================================
+template <int D, int O> struct PairLds {
+    static constexpr int H = 64, DP = 4, OP = (O + 3) / 4 * 4;
+    static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, SMALL_END = (B3 + OP + 3) / 4 * 4;
+    static constexpr int WIMG = SMALL_END;                    // three pieces x [64 out][64 in] bf16 = 3 x 8192 bytes
+    static constexpr int PAIR0 = WIMG + 3 * 2048;
+    static constexpr int P1 = 0, P2 = P1 + 3 * 1024, PO = P2 + 3 * 1024, PAIR_SIZE = (PO + 2 * O * 32 + 3) / 4 * 4;   // per pair: two 12 KB piece images, [2 waves][O][32] partial sums
+    static constexpr int END = PAIR0 + 2 * PAIR_SIZE;
+};
+// A operand of dh1 = W2': lane (in-unit 32mk + (lane & 31), half kh) gets out-units 32mi + 16s + 8kh + j of the weight image (64 rows, piece stride 8192); tbase = wide_tr_base<64>
+__device__ __forceinline__ bf16x8 load_frag_W_T(const char* wimg, int tbase, int piece, int mk, int mi, int s) {
+    const int a = (tbase ^ (64 * mk)) + (32 * mi + 16 * s) * 128 + piece * 8192;
+    return frag8(lds_read_tr16(wimg, a), lds_read_tr16(wimg, (a ^ 16) + 4 * 128));
+}
+
+template <int KIND, int O, int HEAD>
+__device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
+    constexpr int D = EnvSpec<KIND>::D, H = 64, MT = 2;
+    constexpr bool REC = true, kKeepH1 = HEAD == HEAD_VALUE;
+    constexpr float kInvTanhScale = 1.0f / kTanhScale;
+    using L = PairLds<D, O>;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wave & 1, pr = wave >> 1;                                           // this wave's m-tile; this wave's pair
+    const int c = lane & 31, h = lane >> 5;
+    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
+    float* wl = smem;
+    char* Wimg = reinterpret_cast<char*>(smem + L::WIMG);
+    float* pb = smem + L::PAIR0 + pr * L::PAIR_SIZE;
+    char* P1 = reinterpret_cast<char*>(pb + L::P1); char* P2 = reinterpret_cast<char*>(pb + L::P2); float* PO = pb + L::PO;
+    {   // stage the small parts (as stage_net_split) and the W2 piece image
+        const float* __restrict__ P = a.params;
+        for (int i = tid; i < L::DP * H; i += blockDim.x) { const int o = i % H, k = i / H; wl[L::W1T + k * H + o] = k < D ? kTanhScale * P[off.w1 + o + k * H] : 0.0f; }
+        for (int i = tid; i < H; i += blockDim.x) { wl[L::B1 + i] = kTanhScale * P[off.b1 + i]; wl[L::B2 + i] = kTanhScale * P[off.b2 + i]; }
+        for (int i = tid; i < O * H; i += blockDim.x) { const int o = i % O, k = i / O; wl[L::W3S + o * H + k] = P[off.w3 + i]; }
+        for (int i = tid; i < L::OP; i += blockDim.x) wl[L::B3 + i] = i < O ? P[off.b3 + i] : 0.0f;
+        for (int i = tid; i < H * H / 2; i += blockDim.x) {       // pair (k, k+1) of row o: W2 is column-major (out x in), consecutive threads read consecutive o
+            const int o = i % H, kp = i / H;
+            unsigned hi, mid, lo;
+            split3_pair(kTanhScale * P[off.w2 + o + H * (2 * kp)], kTanhScale * P[off.w2 + o + H * (2 * kp + 1)], hi, mid, lo);
+            const int byte = o * 128 + ((((kp >> 2) ^ wimg_g<64>(o)) & 7) << 4) + ((kp & 3) << 2);
+            *reinterpret_cast<unsigned*>(Wimg + byte) = hi; *reinterpret_cast<unsigned*>(Wimg + 8192 + byte) = mid; *reinterpret_cast<unsigned*>(Wimg + 16384 + byte) = lo;
+        }
+    }
+    __syncthreads();
+
+    float adv_mean = 0.f, adv_den = 1.f;
+    if (HEAD != HEAD_VALUE && a.normalize_adv) {
+        const double s = a.adv_stats[0], q = a.adv_stats[1], n = a.adv_stats[2];
+        const double mean = s / n;
+        double var = (q - s * mean) / (n - 1.0);
+        if (var < 0) var = 0;
+        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
+    }
+    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
+    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
+    float lsr[kLsMax];
+#pragma unroll
+    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
+    if (HEAD == HEAD_GAUSSIAN) {
+#pragma unroll
+        for (int o = 0; o < O; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
+    }
+    const float* ls = lsr;
+    const int tbase = wide_tr_base<64>(lane);
+
+    f32x16 dW2[MT], dW3acc[O], db2acc, dW1acc[D], db1acc;            // dW2: rows 32w.., all 64 columns; the others: per-lane sums over this lane's samples (units rowfn(r, h) of m-tile w)
+    float db3p[O], dlsp[O], st[5];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { db2acc[r] = 0.f; db1acc[r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW2[j][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW1acc[d][r] = 0.f;
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        db3p[o] = 0.f; dlsp[o] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW3acc[o][r] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) st[i] = 0.f;
+
+    const int nb = HEAD == HEAD_VALUE ? (int)blockIdx.x - a.G / 2 : (int)blockIdx.x;  // workgroup within its net
+    const int GP = HEAD == HEAD_VALUE ? a.Gc : a.G;                                   // pairs of this net
+    const int g = 2 * nb + pr;                                                        // pair within its net = slab index
+    const int64_t ntiles = (a.count + kTile - 1) / kTile;
+    const int64_t g0 = 2 * nb;
+    const int64_t trips = g0 < ntiles ? (ntiles - g0 + GP - 1) / GP : 0;           // the same for both pairs of the workgroup (barriers inside the loop)
+    TileIn<O> cur, nxt;
+    int64_t tile = g;
+    load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);                        // a tile index past the end loads an all-invalid tile
+#ifdef DRIL_STAMPS
+    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
+#endif
+    for (int64_t it = 0; it < trips; ++it, tile += GP) {
+        unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
+        const bool valid = cur.valid;
+        const float xk[2] = {cur.xk[0], cur.xk[1]};
+        // ---- h1 tile w; its pieces into the pair's image ----
+        f32x16 h1k;                                                                   // kept across the tile where the registers allow it (the critic), rebuilt from the pieces elsewhere
+        {
+            f32x16 h1w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B1 + 32 * w + 8 * q + 4 * h);
+                h1w[4 * q + 0] = b[0]; h1w[4 * q + 1] = b[1]; h1w[4 * q + 2] = b[2]; h1w[4 * q + 3] = b[3];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
+            tanh16(h1w);
+            store_tile_pieces<64>(P1, w, h1w, opaque(lane));
+            if (kKeepH1) h1k = h1w;
+        }
+        STAMP(0);
+        __syncthreads();                                                              // B1: the pair's h1 image complete
+        STAMP(1);
+        load_tile<KIND, O, HEAD, REC>(a, tile + GP, ntiles, c, h, nxt);
+        // ---- h2 tile w = tanh(W2[rows of w] h1 + b2): A from the weight image, B from the pair's h1 image (both row reads with the same chunk index) ----
+        f32x16 h2w;
+        {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B2 + 32 * w + 8 * q + 4 * h);
+                h2w[4 * q + 0] = b[0]; h2w[4 * q + 1] = b[1]; h2w[4 * q + 2] = b[2]; h2w[4 * q + 3] = b[3];
+            }
+            const int lo_ = opaque(lane), cc = lo_ & 31, hh = lo_ >> 5, gsw = wimg_g<64>(cc);
+            const char* arow = Wimg + (32 * w + cc) * 128; const char* brow = P1 + cc * 128;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {                                          // ks = 2 mi + s
+                const int ch = ((2 * ks + hh) ^ gsw) << 4;
+                bf16x8 A[3], B[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) { A[p] = *reinterpret_cast<const bf16x8*>(arow + p * 8192 + ch); B[p] = *reinterpret_cast<const bf16x8*>(brow + p * 4096 + ch); }
+                h2w = mfma_split6(A[0], A[1], A[2], B[0], B[1], B[2], h2w);
+            }
+            tanh16(h2w);
+        }
+        STAMP(2);
+        // ---- output layer: partial over this wave's 32 units, summed across the pair through LDS ----
+        float out[O], dz[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float p = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
+                p = fmaf(wv[0], h2w[4 * q + 0], p); p = fmaf(wv[1], h2w[4 * q + 1], p);
+                p = fmaf(wv[2], h2w[4 * q + 2], p); p = fmaf(wv[3], h2w[4 * q + 3], p);
+            }
+            p += __shfl_xor(p, 32);
+            if (h == 0) PO[(w * O + o) * 32 + c] = p;
+        }
+        __syncthreads();                                                              // B2: both partial sums
+        STAMP(3);
+#pragma unroll
+        for (int o = 0; o < O; ++o) out[o] = (wl[L::B3 + o] + PO[o * 32 + c]) + PO[(O + o) * 32 + c];   // fixed order: both waves get the same bits
+        loss_head<O, HEAD>(a, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            if (h == 0 && w == 0) db3p[o] += dz[o];
+            dW3acc[o] += dz[o] * h2w;                                                  // dW3[o][unit] += dz[o][sample] h2[unit][sample]: the lane IS the sample
+        }
+        // ---- dz2 tile w (in h2w's registers); db2; its pieces into the pair's image ----
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float dh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(wv[cc], dz[o], dh[cc]);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * fmaf(-hv, hv, 1.0f); }
+        }
+        db2acc += h2w;
+        store_tile_pieces<64>(P2, w, h2w, opaque(lane));
+        STAMP(4);
+        __syncthreads();                                                              // B3: the pair's dz2 image complete
+        STAMP(5);
+        // ---- dz1 tile w = (W2'[rows of w] dz2) .* (1 - h1^2): A = transposed reads of the weight image, B = row reads of the dz2 image ----
+        f32x16 g1;
+        {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g1[r] = 0.f;
+            const int lo_ = opaque(lane), cc = lo_ & 31, hh = lo_ >> 5, gsw = wimg_g<64>(cc), tb = opaque(tbase);
+            const char* brow = P2 + cc * 128;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int ch = ((2 * ks + hh) ^ gsw) << 4;
+                bf16x8 A[3], B[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) { A[p] = load_frag_W_T(Wimg, tb, p, w, ks >> 1, ks & 1); B[p] = *reinterpret_cast<const bf16x8*>(brow + p * 4096 + ch); }
+                g1 = mfma_split6(A[0], A[1], A[2], B[0], B[1], B[2], g1);
+            }
+            f32x16 h1r;
+            if (kKeepH1) h1r = h1k; else load_tile_pieces<64>(P1, w, h1r, lo_);         // h1 tile w rebuilt from its own pieces (exact)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[r] = g1[r] * fmaf(-t2, kInvTanhScale, kInvTanhScale); }
+        }
+        STAMP(6);
+        // ---- dW1 | db1: per-lane accumulation, dW1[unit][d] += dz1[unit][sample] x[sample][d] ----
+        {
+            const float xo0 = __shfl_xor(xk[0], 32), xo1 = __shfl_xor(xk[1], 32);      // the other half holds x[2s + 1 - h]
+            const float x4[4] = {h ? xo0 : xk[0], h ? xk[0] : xo0, h ? xo1 : xk[1], h ? xk[1] : xo1};
+#pragma unroll
+            for (int d = 0; d < D; ++d) dW1acc[d] += x4[d] * g1;
+            db1acc += g1;
+        }
+        // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the pair's images) ----
+        {
+            const int tb = opaque(tbase);
+            bf16x8 Az[2][3];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<64>(P2, tb, p, w, s);
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj) {
+                bf16x8 Bh[2][3];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<64>(P1, tb, p, mj, s);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split6(Az[s][0], Az[s][1], Az[s][2], Bh[s][0], Bh[s][1], Bh[s][2], dW2[mj]);
+            }
+        }
+        STAMP(7);
+        __syncthreads();                                                              // B4: the pair's images and partial sums free for the next tile
+        STAMP(8);
+        cur = nxt;
+    }
+#ifdef DRIL_STAMPS
+    if (lane == 0 && a.dbg) {
+        unsigned long long* o_ = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
+        for (int k = 0; k < 10; ++k) o_[k] = stamp_acc[k];
+        o_[10] = (unsigned long long)trips; o_[11] = HEAD;
+    }
+#endif
+
+    // ---- epilogue: every wave owns distinct gradient rows -> straight to the pair's slab ----
+    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
+    const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
+    const int o_ls = o_b3 + O, o_st = SL - 8;
+    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
+#pragma unroll
+    for (int mj = 0; mj < MT; ++mj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H] = dW2[mj][r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                                                    // per-lane sums over samples -> sum over the 32 lanes of each half (the halves hold different units)
+        const int unit = 32 * w + rowfn(r, h);
+        const float b2 = half_sum(db2acc[r]), b1 = half_sum(db1acc[r]);
+        if (c == 0) { slab[o_b2 + unit] = b2; slab[o_b1 + unit] = b1; }
+#pragma unroll
+        for (int d = 0; d < D; ++d) { const float v = half_sum(dW1acc[d][r]); if (c == 0) slab[o_w1 + unit + d * H] = v; }
+#pragma unroll
+        for (int o = 0; o < O; ++o) { const float v = half_sum(dW3acc[o][r]); if (c == 0) slab[o_w3 + o + unit * O] = v; }
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        const float b3 = half_sum(db3p[o]);
+        if (w == 0 && lane == 0) slab[o_b3 + o] = b3;
+        if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (w == 0 && lane == 0) slab[o_ls + o] = l; }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (w == 0 && lane == 0) slab[o_st + k] = v; }
+    if (w == 0 && lane < 3) slab[o_st + 5 + lane] = 0.f;
+    for (int i = (HEAD == HEAD_GAUSSIAN ? o_ls + O : o_ls) + w * 64 + lane; i < o_st; i += 128) slab[i] = 0.f;   // padding
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void ppo_grad_pair_kernel(GradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (*a.stop_flag) return;
+    constexpr int A = EnvSpec<KIND>::A;
+    const bool actor = blockIdx.x < (unsigned)(a.G / 2);
+    if (actor) grad_body_pair<KIND, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN>(a, smem);
+    else grad_body_pair<KIND, 1, HEAD_VALUE>(a, smem);
+}
+
+template <int KIND> static size_t grad_pair_lds_bytes() {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
+    constexpr int wa = PairLds<D, A>::END, wc = PairLds<D, 1>::END;
+    return sizeof(float) * (wa > wc ? wa : wc);
+}
+
+hipError_t launch_ppo_grad_pair(int kind, const GradArgs& a, hipStream_t s) {
+#define CALLP(K) { const size_t lds = grad_pair_lds_bytes<K>(); static bool attr_set = false; \
+        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_pair_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
+        ppo_grad_pair_kernel<K><<<(a.G + a.Gc) / 2, 256, lds, s>>>(a); }
+    if (kind == 0) CALLP(0) else if (kind == 3) CALLP(3) else if (kind == 4) CALLP(4) else CALLP(1)
+#undef CALLP
+    return hipGetLastError();
+}
+
+}  // namespace dril

@@ -64,13 +64,10 @@ struct GradArgs {
     float invB, clip_range, ent_coef, vf_coef, clip_range_vf;
     int has_clip_vf, normalize_adv, action_start, log_std_off;
     float* slabs_actor; float* slabs_critic; int slab_a, slab_c, G;
-    int Gc;       // critic workgroups (== G except in ppo_grad_split_kernel, whose one-workgroup-per-CU grid is divided between the nets by their measured cost per tile)
+    int Gc;       // critic workgroups (== G except in ppo_grad_pair_kernel, where G / Gc count the PAIRS of each net: the chip-filling grid is divided between the nets by their measured cost per tile)
     unsigned long long* dbg;   // -DDRIL_STAMPS diagnostic buffer (12 x u64 per wave), else unused
-    int stagger;   // tuning knob: start-up delay of the critic workgroups, in units of 8128 clocks
-    int prio, split_pct;   // tuning knobs: static wave priority + share of tiles for the high-priority half
     int inline_moments;   // small minibatches: every actor workgroup computes the advantage moments itself (adv_stats == nullptr), saving two launches per optimiser step
-    int layout;   // 0: actor/critic workgroups interleaved by blockIdx parity, 1: first G blocks actor, next G critic
-    int variant;  // hidden 64: 0 = ppo_grad_kernel (f32 MFMA, two workgroups per CU), 1 = ppo_grad_split_kernel (bf16 x 3 operand splitting, one workgroup per CU), 2 = the same with two tiles in flight per wave
+    int variant;  // hidden 64: 0 = ppo_grad_kernel (f32 MFMA), 2 = ppo_grad_pair_kernel (bf16 x 3 operand split); wide nets: 0 = ppo_grad_wide_kernel, 1 = ppo_grad_wide_split_kernel
     const int* stop_flag;
     NetOff actor, critic;
 };
@@ -126,6 +123,10 @@ hipError_t launch_epoch_moments(const float* adv, int64_t N, int64_t B, int nb, 
                                 double* table3, const int* stop_flag, hipStream_t s);
 hipError_t launch_moments_finalize(const double* partials, int nblocks, double* out3, double n_local, const int* stop_flag, hipStream_t s);
 hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t s);
+// per translation unit (dril_grad_f32.hip / dril_grad_pair.hip / dril_grad_wide.hip); launch_ppo_grad picks one
+hipError_t launch_ppo_grad_f32(int kind, int hidden, const GradArgs& a, hipStream_t s);
+hipError_t launch_ppo_grad_pair(int kind, const GradArgs& a, hipStream_t s);
+hipError_t launch_ppo_grad_wide(int kind, int hidden, const GradArgs& a, hipStream_t s);
 hipError_t launch_pack_records(int kind, int64_t N, const float* obs, const void* act, const float* adv, const float* logp, const float* ret, float4* rec, hipStream_t s);
 hipError_t launch_grad_reduce(const ReduceArgs& a, hipStream_t s);
 hipError_t launch_grad_norm(const float* flat, int P, double* norm_partials, const int* stop_flag, hipStream_t s);

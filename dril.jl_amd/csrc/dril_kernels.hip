@@ -1,4 +1,4 @@
-// dril_kernels.hip — every HIP kernel of libdril_hip.so (gfx950 / CDNA4 only) and their launchers.
+// dril_kernels.hip — the HIP kernels of libdril_hip.so (gfx950 / CDNA4 only) other than the PPO update kernels, and their launchers.
 //
 // Kernel map (reference function each one replaces — paths relative to the reference root):
 //   env_reset_kernel / env_observe_kernel / env_step_kernel   MultiThreadedParallelEnv reset!/observe/act!
@@ -8,12 +8,15 @@
 //   rollout_kernel       collect_trajectories, src/buffers/trajectory.jl:22-78 (persistent: one wave owns 32 envs for all T steps)
 //   gae_kernel           compute_advantages! trajectory.jl:80-102 + returns rollout_buffer.jl:87
 //   adv_moments_kernel   normalize! statistics, src/algorithms/ppo.jl:350-356
-//   ppo_grad_kernel      (alg::PPO)(layer,ps,st,batch) ppo.jl:365-407 + its reverse pass (Zygote in the reference, ppo.jl:207)
+//   ppo_grad_*_kernel    (alg::PPO)(layer,ps,st,batch) ppo.jl:365-407 + its reverse pass (Zygote in the reference, ppo.jl:207): dril_grad_f32.hip (exact f32, small
+//                        minibatches), dril_grad_pair.hip (hidden [64,64], bf16 matrix cores: the headline kernel), dril_grad_wide.hip (hidden 128 / 256)
 //   grad_reduce_kernel / grad_norm_kernel / adam_kernel   nested_norm, nested_scale!, target_kl check, Adam — ppo.jl:213-239
 //   explained_var_kernel ppo.jl:256
 #include <utility>
 
 #include "dril_internal.h"
+#include "dril_grad_common.h"
+#include "dril_split_pieces.h"
 
 namespace dril {
 
@@ -357,54 +360,7 @@ __global__ void monitor_collect_kernel(const uint8_t* __restrict__ flags, const 
     }
 }
 
-// =============================================================================================
-// distribution heads shared by policy_kernel / rollout_kernel / ppo_grad_kernel
-// =============================================================================================
-// Lux.softmax + Categorical: layer_forward.jl:141-149, categorical.jl:20-52
-template <int A> __device__ __forceinline__ void softmax_n(const float (&z)[A], float (&p)[A]) {
-    float m = z[0];
-#pragma unroll
-    for (int i = 1; i < A; ++i) m = fmaxf(m, z[i]);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < A; ++i) { p[i] = fexp(z[i] - m); s += p[i]; }
-    const float inv = frcp(s);
-#pragma unroll
-    for (int i = 0; i < A; ++i) p[i] = p[i] * inv;
-}
-template <int A> __device__ __forceinline__ int categorical_sample(const float (&p)[A], double u) {
-    float cs = 0.f; int a = A - 1; bool found = false;
-#pragma unroll
-    for (int i = 0; i < A; ++i) { cs += p[i]; if (!found && (double)cs >= u) { a = i; found = true; } }
-    return a;
-}
-template <int A> __device__ __forceinline__ float pick(const float (&p)[A], int a) {
-    float v = p[0];
-#pragma unroll
-    for (int i = 1; i < A; ++i) v = (a == i) ? p[i] : v;
-    return v;
-}
-template <int A> __device__ __forceinline__ float categorical_entropy(const float (&p)[A]) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < A; ++i) s += p[i] * flog(p[i]);
-    return -s;
-}
-constexpr float kLog2Pi = 1.8378770664093453f;
-// DiagGaussian logpdf / entropy: diagGaussian.jl:25-43
-template <int A> __device__ __forceinline__ float gauss_logpdf(const float (&x)[A], const float (&mu)[A], const float* ls) {
-    float lss = 0.f, dss = 0.f;
-#pragma unroll
-    for (int i = 0; i < A; ++i) { lss += ls[i]; const float d = x[i] - mu[i]; dss += d * d * fexp(-2.0f * ls[i]); }
-    return -0.5f * (2.0f * lss + dss + (float)A * kLog2Pi);
-}
-template <int A> __device__ __forceinline__ float gauss_entropy(const float* ls) {
-    float lss = 0.f;
-#pragma unroll
-    for (int i = 0; i < A; ++i) lss += ls[i];
-    return 0.5f * (float)A * (1.0f + kLog2Pi) + lss;
-}
-
+// (distribution heads: dril_heads.h)
 // first-layer B operand from an observation held in registers: xk[s] = obs[2s + h] (static register indices only)
 template <int D> __device__ __forceinline__ void pair_obs(const float (&obs)[D], int h, float (&xk)[2]) {
 #pragma unroll
@@ -830,27 +786,6 @@ __global__ void moments_finalize_kernel(const double* partials, int nblocks, dou
     if (threadIdx.x == 0) { out3[0] = s; out3[1] = q; out3[2] = n_local; }
 }
 
-// =============================================================================================
-// ppo_grad_kernel — the dominant kernel.  Fused forward + loss + backward of ONE net per workgroup
-// (even blocks: actor, odd blocks: critic — the two MLPs share no parameters, layer_helpers.jl:13-25,
-// so their gradients decouple given the batch).  Per 32-sample tile and net: 228 v_mfma_f32_32x32x2_f32
-//   fwd  L1 4 + L2 64                      (L3 and its transpose products run on the VALU, O <= 2)
-//   bwd  dh1 = W2' dz2 64, dW2 += dz2 h1' 64, dW1|db1 += dz1 [x;1]' 32
-// Weight gradients accumulate in registers over the workgroup's whole share of the minibatch and
-// leave as ONE slab per workgroup (plain coalesced stores) — grad_reduce_kernel sums the slabs in a
-// fixed order, so the result is bitwise reproducible and no float atomics are used.
-// =============================================================================================
-enum { HEAD_CATEGORICAL = 0, HEAD_GAUSSIAN = 1, HEAD_VALUE = 2 };
-constexpr int kLsMax = 4;   // action dims whose log_std the kernels keep in registers
-
-// diagnostic build only (-DDRIL_STAMPS): per-phase s_memtime shares of one tile; never used for timing claims
-#ifdef DRIL_STAMPS
-#define STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \
-                      __builtin_amdgcn_sched_barrier(0); stamp_acc[k] += _t - stamp_prev; stamp_prev = _t; } while (0)
-#else
-#define STAMP(k) do { } while (0)
-#endif
-
 // pack_records_kernel: the six per-sample fields the loss reads (ppo.jl:366-371) as one 32-byte record, so that a
 // minibatch gather is ONE 16-byte load per lane (the two half-waves of a sample fetch the two halves of its record = one
 // 32-B sector) instead of five scattered 4-byte loads (v1-v4: FETCH 1.6-3.1 GB per launch vs 0.22 GB algorithmic).
@@ -868,1209 +803,6 @@ __global__ void pack_records_kernel(int64_t N, const float* __restrict__ obs, co
     }
 }
 
-// one lane's share of a minibatch tile (DataLoader gather, ppo.jl:188-195).  Loaded one tile AHEAD of its use so the
-// random-gather latency (~2 us under load, fully exposed in v1: 23 % of wave time in s_waitcnt) hides under the
-// previous tile's MFMAs; the loop body issues no other vector-memory op, so the loads stay in flight until first use.
-template <int O> struct TileIn { float xk[2]; float s0, s1; int act; float xa[O]; bool valid; float4 raw; };
-
-template <int KIND, int O, int HEAD, bool REC>
-__device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64_t ntiles, int c, int h, TileIn<O>& t) {
-    constexpr int D = EnvSpec<KIND>::D;
-    const bool live = tile < ntiles;
-    const int64_t i = (live ? tile : ntiles - 1) * kTile + c;
-    const bool inb = live && i < a.count;
-    const int64_t p = a.pos0 + (inb ? i : 0);
-    const int64_t gidx = a.perm ? a.perm[p] : (a.perm_bits ? perm_index(p, a.N, a.perm_key, a.perm_bits) : p);   // bits 0 = identity order
-    const int64_t li = gidx - a.idx_lo;
-    t.valid = inb && li >= 0 && li < a.n_local;
-    const int64_t idx = t.valid ? li : 0;
-    t.act = 0; t.s0 = 0.f; t.s1 = 0.f;
-    if (REC) {
-        // lane (sample, h) loads half h of the record; t.raw is exchanged between the half-waves at first use (unpack_tile)
-        t.raw = a.rec[2 * idx + h];
-        if (HEAD == HEAD_VALUE && a.has_clip_vf) t.s1 = a.val_old[idx];
-        return;
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; t.xk[s] = d < D ? a.obs[idx * D + d] : 0.f; }
-    if (HEAD == HEAD_VALUE) { t.s0 = a.ret[idx]; t.s1 = a.has_clip_vf ? a.val_old[idx] : 0.f; }
-    else {
-        t.s0 = a.adv[idx]; t.s1 = a.logp_old[idx];
-        if (HEAD == HEAD_CATEGORICAL) t.act = ((const int32_t*)a.actions)[idx] - a.action_start;
-        else {
-#pragma unroll
-            for (int o = 0; o < O; ++o) t.xa[o] = ((const float*)a.actions)[idx * O + o];
-        }
-    }
-}
-
-// exchange the two record halves between the half-waves: v_permlane32_swap(a, b) swaps a[32..63] with b[0..31], so with
-// a = b = v the results are {lo-half value in every lane, hi-half value in every lane}
-template <int KIND, int O, int HEAD, bool REC>
-__device__ __forceinline__ void unpack_tile(const GradArgs& a, int h, TileIn<O>& t) {
-    if (!REC) return;
-    float lo[4], hi[4];
-    const float v[4] = {t.raw.x, t.raw.y, t.raw.z, t.raw.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned u = __float_as_uint(v[i]);
-        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        lo[i] = __uint_as_float(r[0]); hi[i] = __uint_as_float(r[1]);
-    }
-    t.xk[0] = h ? lo[1] : lo[0]; t.xk[1] = h ? lo[3] : lo[2];      // xk[s] = obs[2s + h]
-    if (HEAD == HEAD_VALUE) t.s0 = hi[3];
-    else {
-        t.s0 = hi[1]; t.s1 = hi[2];
-        if (HEAD == HEAD_CATEGORICAL) t.act = __float_as_int(hi[0]) - a.action_start; else t.xa[0] = hi[0];
-    }
-}
-
-// (alg::PPO)(...) loss terms and dLoss/d(net output) for one sample per lane (ppo.jl:377-404); `tally` selects the lanes that
-// add to the statistics / log_std sums (each sample is replicated in the two half-waves, and in every wave of a wide workgroup)
-template <int O, int HEAD>
-__device__ __forceinline__ void loss_head(const GradArgs& a, const TileIn<O>& cur, const float (&out)[O], bool valid, bool tally, const float* ls,
-                                          float adv_mean, float adv_inv, float (&dz)[O], float (&st)[5], float (&dlsp)[O]) {
-    // branch-free on purpose: a lane-dependent `if` here becomes an s_cbranch_execz in the middle of the tile loop and splits it into basic blocks
-    // that the scheduler cannot move MFMAs / LDS reads across
-    const bool count_it = valid && tally;
-    if (HEAD == HEAD_VALUE) {
-        const float R = cur.s0;
-        const float ov = cur.s1, dcl = out[0] - ov;                        // clip_range, ppo.jl:344-346,378
-        const bool inside = (dcl >= -a.clip_range_vf) & (dcl <= a.clip_range_vf);      // bitwise: && / ?: compile to branches
-        const bool vpass = inside | (a.has_clip_vf == 0);
-        const float vclip = ov + fminf(fmaxf(dcl, -a.clip_range_vf), a.clip_range_vf);
-        const float value = a.has_clip_vf ? vclip : out[0];
-        const float ve = value - R;
-        dz[0] = (valid & vpass) ? a.invB * a.vf_coef * 2.0f * ve : 0.f;
-        st[0] += count_it ? ve * ve : 0.f;                                 // value_loss numerator, ppo.jl:385
-    } else {
-        const float advn = (cur.s0 - adv_mean) * adv_inv;
-        const float olp = cur.s1;
-        float logp, ent;
-        float p[O];
-        int act = 0;
-        float xa[O];
-        if (HEAD == HEAD_CATEGORICAL) {
-            softmax_n<O>(out, p);
-            act = cur.act;
-            logp = flog(pick<O>(p, act));
-            ent = categorical_entropy<O>(p);
-        } else {
-#pragma unroll
-            for (int o = 0; o < O; ++o) xa[o] = cur.xa[o];
-            logp = gauss_logpdf<O>(xa, out, ls);
-            ent = gauss_entropy<O>(ls);
-        }
-        const float lr = logp - olp;
-        const float r = fexp(lr);                                          // ppo.jl:380
-        const float lo = 1.0f - a.clip_range, hi = 1.0f + a.clip_range;
-        const float rc = fminf(fmaxf(r, lo), hi);                          // :381
-        const float t1 = r * advn, t2 = rc * advn;
-        const float mn = t2 < t1 ? t2 : t1;                                // :382
-        const float dm_dr = (t2 < t1) ? ((r >= lo && r <= hi) ? advn : 0.f) : advn;
-        const float dlogp = valid ? -a.invB * dm_dr * r : 0.f;
-        const float dent = valid ? -a.invB * a.ent_coef : 0.f;             // ent_loss = -mean(entropy), :383,:386
-        if (HEAD == HEAD_CATEGORICAL) {
-#pragma unroll
-            for (int o = 0; o < O; ++o)
-                dz[o] = dlogp * ((o == act ? 1.0f : 0.0f) - p[o]) + dent * (-p[o] * (flog(p[o]) + ent));
-        } else {
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                const float iv = fexp(-2.0f * ls[o]), d = xa[o] - out[o];
-                dz[o] = dlogp * d * iv;
-                dlsp[o] += tally ? dlogp * (d * d * iv - 1.0f) + dent : 0.f;
-            }
-        }
-        st[0] += count_it ? -mn : 0.f; st[1] += count_it ? ent : 0.f; st[2] += (count_it && r != rc) ? 1.0f : 0.0f;   // :382,:383,:390
-        st[3] += count_it ? (r - 1.0f) - lr : 0.f; st[4] += count_it ? r : 0.f;                                       // :393,:402
-    }
-}
-
-// per-wave LDS scratch of grad_body (floats): one [H][kTS] transpose image reused in turn for h2, h1, dz2, dz1,
-// the [D+2][kTS] first-layer input image (rows 0..D-1 = x, row D = 1 for the bias column, row D+1 = 0) and the [O][kTS]
-// dLoss/dout image.  2 workgroups (4 waves each) per CU => 2 waves per SIMD, so one wave's VALU/LDS phases overlap the
-// other's MFMAs; that needs <= 256 registers and <= 80 KB LDS per workgroup.
-template <int D, int H, int O> struct GradScratch {
-    static constexpr int T = 0;
-    static constexpr int XI = T + H * kTS;
-    static constexpr int ZI = XI + (D + 2) * kTS;
-    static constexpr int SIZE = ZI + O * kTS;
-};
-
-template <int KIND, int H, int O, int HEAD, bool REC>
-__device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
-    constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
-    using L = NetLds<D, H, H, O>;
-    using SC = GradScratch<D, H, O>;
-    const int tid = threadIdx.x, lane = tid & 63;
-    // threadIdx.x / 64 IS wave-uniform but hipcc cannot prove it: readfirstlane moves the wave id - and every tile index,
-    // LDS base and loop bound derived from it - into SGPRs (v3 spilled those to scratch, and each scratch reload's
-    // s_waitcnt vmcnt(0) drained the prefetched gathers: profiles/r01 stamps, "out+head" 7.0k cycles)
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
-    float* wl = smem;
-    float* T = smem + L::BWD_END + wave * SC::SIZE + SC::T;
-    float* XI = smem + L::BWD_END + wave * SC::SIZE + SC::XI;
-    float* ZI = smem + L::BWD_END + wave * SC::SIZE + SC::ZI;
-    stage_net<D, H, H, O, true>(wl, a.params, off, tid, blockDim.x);
-    for (int i = lane; i < (D + 2) * kTS; i += 64) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
-    __syncthreads();
-
-    // advantage normalisation constants (ppo.jl:350-356): mean, corrected std, eps added to the std
-    float adv_mean = 0.f, adv_den = 1.f;
-    if (HEAD != HEAD_VALUE && a.normalize_adv) {
-        double s, q, n;
-        if (a.inline_moments) {
-            // small minibatch: sum A and A^2 of the whole minibatch here (same index map as load_tile), fixed-order tree => every workgroup gets the same bits
-            double* shd = reinterpret_cast<double*>(smem + ((L::BWD_END + 1) & ~1));      // per-wave scratch, not yet in use
-            double ls_ = 0, lq_ = 0;
-            for (int64_t i2 = tid; i2 < a.count; i2 += blockDim.x) {
-                const int64_t p2 = a.pos0 + i2;
-                const int64_t gi = a.perm ? a.perm[p2] : (a.perm_bits ? perm_index(p2, a.N, a.perm_key, a.perm_bits) : p2);
-                const int64_t li2 = gi - a.idx_lo;
-                if (li2 >= 0 && li2 < a.n_local) { const float v = REC ? a.rec[2 * li2 + 1].y : a.adv[li2]; ls_ += v; lq_ += (double)v * v; }
-            }
-            shd[tid] = ls_; shd[256 + tid] = lq_;
-            __syncthreads();
-            for (int st_ = 128; st_ > 0; st_ >>= 1) { if (tid < st_) { shd[tid] += shd[tid + st_]; shd[256 + tid] += shd[256 + tid + st_]; } __syncthreads(); }
-            s = shd[0]; q = shd[256]; n = (double)a.count;
-            __syncthreads();
-        } else { s = a.adv_stats[0]; q = a.adv_stats[1]; n = a.adv_stats[2]; }
-        const double mean = s / n;
-        double var = (q - s * mean) / (n - 1.0);
-        if (var < 0) var = 0;
-        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
-    }
-    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
-    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
-    constexpr bool LS_GAUSS = HEAD == HEAD_GAUSSIAN; constexpr int LS_N = O;
-    // log_std hoisted into scalar registers: a per-tile global load would sit in the in-order vmcnt queue between the prefetched
-    // gathers and their first use and drain them every tile (Pendulum [64,64]: 91 -> TFLOP/s below)
-    float lsr[kLsMax];
-#pragma unroll
-    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
-    if (LS_GAUSS) {
-#pragma unroll
-        for (int o = 0; o < LS_N; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
-    }
-    const float* ls = lsr;
-
-    f32x16 dW2[MT][MT];
-    f32x4 dW1[H / 16];                                             // 16x16x4 tiles: rows = hidden, cols = [x | 1 | 0...]
-    float dW3a[O][MT], db2p[MT], db3p[O], dlsp[O], st[5];
-#pragma unroll
-    for (int i = 0; i < H / 16; ++i) dW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        db2p[i] = 0.f;
-#pragma unroll
-        for (int j = 0; j < MT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dW2[i][j][r] = 0.f;
-    }
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-        db3p[o] = 0.f; dlsp[o] = 0.f;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) dW3a[o][m] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) st[i] = 0.f;
-
-    const int g = a.layout ? (int)(blockIdx.x % a.G) : (int)(blockIdx.x >> 1);
-    const int64_t ntiles_all = (a.count + kTile - 1) / kTile;
-    // static priority experiment: co-resident workgroups (g of the actor, g of the critic) get opposite priorities;
-    // the high-priority half of each net takes split_pct % of the tiles (deterministic partition)
-    int64_t tile0 = 0, ntiles = ntiles_all, tstride = (int64_t)a.G * 4, first = (int64_t)g * 4 + wave;
-    if (a.prio == 2) { if (HEAD == HEAD_VALUE) __builtin_amdgcn_s_setprio(1); }          // younger (second-dispatched) workgroups only
-    else if (a.prio == 3) { if (HEAD != HEAD_VALUE) __builtin_amdgcn_s_setprio(1); }
-    else if (a.prio && a.G >= 2 && (a.G & 1) == 0) {
-        const bool hi = ((g & 1) == 0) == (HEAD != HEAD_VALUE);
-        const int64_t nh = ntiles_all * a.split_pct / 100;
-        tile0 = hi ? 0 : nh; ntiles = hi ? nh : ntiles_all;
-        tstride = (int64_t)(a.G / 2) * 4; first = tile0 + (int64_t)(g >> 1) * 4 + wave;
-        if (hi) __builtin_amdgcn_s_setprio(1);
-    }
-    TileIn<O> cur, nxt;
-    int64_t tile = first;
-    if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
-    if (HEAD == HEAD_VALUE && a.stagger > 0) {                      // start the critic workgroups out of phase with their co-resident actor workgroups
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);      // 127 * 64 clocks each
-    }
-#ifdef DRIL_STAMPS
-    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
-#endif
-    for (; tile < ntiles; tile += tstride) {
-        load_tile<KIND, O, HEAD, REC>(a, tile + tstride, ntiles, c, h, nxt);      // prefetch the next tile's gathers
-        unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
-        const bool valid = cur.valid;
-        float xk[2] = {cur.xk[0], cur.xk[1]};
-        STAMP(0);
-        // ---- forward ----
-        f32x16 h1[MT], h2[MT];
-        float out[O], dz[O];
-        dense_first<H, MT>(wl + L::W1T, wl + L::B1, xk, h1, lane);
-        tanh_tiles(h1);
-        STAMP(1);
-#pragma unroll
-        for (int mo = 0; mo < MT; ++mo) {
-            h2[mo] = dense_mfma_tile<MT, true>(wl + L::W2S, L::WS1, wl + L::B2, h1, mo, lane);
-            tanh16(h2[mo]);
-        }
-        store_image<MT>(T, h2, lane);          // early: the LDS write -> read round trip hides under the head below
-        STAMP(2);
-        dense_out<MT, O, H>(wl + L::W3S, wl + L::B3, h2, out, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- loss head (ppo.jl:377-404) and dLoss/dout ----
-        loss_head<O, HEAD>(a, cur, out, valid, h == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
-        STAMP(3);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- output layer backward: dW3 += dz * h2' over samples (h2 read back transposed: hidden on the lane) ----
-#pragma unroll
-        for (int o = 0; o < O; ++o) { if (h == 0) { db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
-        {
-            f32x16 Bh2[MT];
-#pragma unroll
-            for (int mj = 0; mj < MT; ++mj) Bh2[mj] = load_operand(T, mj, lane);
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                float acc[MT];
-#pragma unroll
-                for (int mj = 0; mj < MT; ++mj) acc[mj] = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 z = *reinterpret_cast<const f32x4*>(ZI + o * kTS + 16 * h + 4 * q);   // broadcast within the half-wave
-#pragma unroll
-                    for (int mj = 0; mj < MT; ++mj) {
-                        acc[mj] = fmaf(Bh2[mj][4 * q + 0], z[0], acc[mj]); acc[mj] = fmaf(Bh2[mj][4 * q + 1], z[1], acc[mj]);
-                        acc[mj] = fmaf(Bh2[mj][4 * q + 2], z[2], acc[mj]); acc[mj] = fmaf(Bh2[mj][4 * q + 3], z[3], acc[mj]);
-                    }
-                }
-#pragma unroll
-                for (int mj = 0; mj < MT; ++mj) dW3a[o][mj] += acc[mj];
-            }
-        }
-        STAMP(4);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- dz2 = (W3' dz) .* (1 - h2^2), in h2's registers ----
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float dh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int o = 0; o < O; ++o) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * m + 8 * q + 4 * h);
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(w[cc], dz[o], dh[cc]);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { const float hv = h2[m][4 * q + cc]; h2[m][4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
-            }
-        STAMP(5);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- h1 image (the LDS unit executes a wave's accesses in order, so the Bh2 reads above precede these writes) ----
-        store_image<MT>(T, h1, lane);
-        // ---- dh1 = W2' dz2 ; dz1 = dh1 .* (1 - h1^2) ----
-        f32x16 g1[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            g1[m] = dense_mfma_tile<MT, false>(wl + L::W2T, L::WS2, nullptr, h2, m, lane);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g1[m][r] = g1[m][r] * (1.0f - h1[m][r] * h1[m][r]);
-        }
-        STAMP(6);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- dW2 += dz2 * h1' ; db2 += rowsum(dz2) ----
-        {
-            f32x16 Bh[MT];
-#pragma unroll
-            for (int mj = 0; mj < MT; ++mj) Bh[mj] = load_operand(T, mj, lane);
-            store_image<MT>(T, h2, lane);                                      // dz2 image
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const f32x16 Az = load_operand(T, mi, lane);
-                db2p[mi] += sum16(Az);
-#pragma unroll
-                for (int mj = 0; mj < MT; ++mj) dW2[mi][mj] = mfma_outer(Az, Bh[mj], dW2[mi][mj]);
-            }
-        }
-        STAMP(7);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- dW1 | db1 += dz1 * [x; 1]' ----
-        store_image<MT>(T, g1, lane);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
-        {   // v_mfma_f32_16x16x4_f32: M = 16 hidden rows, N = 16 columns [x_0..x_{D-1}, 1, 0...], K = 4 samples per step
-            const int j = lane & 15;
-            float bx[8];
-            load_row8(XI, j <= D ? j : D + 1, lane, bx);
-#pragma unroll
-            for (int mt = 0; mt < H / 16; ++mt) {
-                float az[8];
-                load_row8(T, 16 * mt + j, lane, az);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) dW1[mt] = mfma16(az[k], bx[k], dW1[mt]);
-            }
-        }
-        STAMP(8);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-    }
-#ifdef DRIL_STAMPS
-    if (lane == 0 && a.dbg) {
-        unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
-        for (int k = 0; k < 10; ++k) o[k] = stamp_acc[k];
-        o[10] = (unsigned long long)((ntiles - first + tstride - 1) / tstride); o[11] = HEAD;
-    }
-#endif
-
-    // ---- epilogue: 4 waves -> one slab (fixed wave order => deterministic) ----
-    __syncthreads();
-    float* red = smem + L::BWD_END;
-    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
-    const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
-    const int o_ls = o_b3 + O, o_st = SL - 8;
-    for (int i = tid; i < SL; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * mi + rowfn(r, h);
-#pragma unroll
-                    for (int mj = 0; mj < MT; ++mj) red[o_w2 + row + (32 * mj + c) * H] += dW2[mi][mj][r];
-                }
-                const float b2 = db2p[mi] + __shfl_xor(db2p[mi], 32);
-                if (h == 0) red[o_b2 + 32 * mi + c] += b2;
-            }
-#pragma unroll
-            for (int mt = 0; mt < H / 16; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * mt + 4 * (lane >> 4) + r, col = lane & 15;
-                    if (col < D) red[o_w1 + row + col * H] += dW1[mt][r];
-                    else if (col == D) red[o_b1 + row] += dW1[mt][r];
-                }
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float v = dW3a[o][m] + __shfl_xor(dW3a[o][m], 32);      // the two halves hold different samples
-                    if (h == 0) red[o_w3 + o + (32 * m + c) * O] += v;
-                }
-                const float b3 = half_sum(db3p[o]);
-                if (lane == 0) red[o_b3 + o] += b3;
-                if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (lane == 0) red[o_ls + o] += l; }
-            }
-#pragma unroll
-            for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (lane == 0) red[o_st + k] += v; }
-        }
-        __syncthreads();
-    }
-    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
-    for (int i = tid; i < SL; i += blockDim.x) slab[i] = red[i];
-}
-
-template <int KIND, int H, bool REC>
-__global__ __launch_bounds__(256, 2) void ppo_grad_kernel(GradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (*a.stop_flag) return;
-    constexpr int A = EnvSpec<KIND>::A;
-    const bool actor = a.layout ? (blockIdx.x < (unsigned)a.G) : ((blockIdx.x & 1) == 0);
-    if (actor) grad_body<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN, REC>(a, smem);
-    else grad_body<KIND, H, 1, HEAD_VALUE, REC>(a, smem);
-}
-
-// =============================================================================================
-// ppo_grad_split_kernel — the same fused forward + loss + backward with the three H x H contractions of a tile (L2 forward, dh1 = W2' dz2,
-// dW2 += dz2 h1': 192 of the 212 MFMAs of ppo_grad_kernel) on the bf16 matrix cores with fp32-equivalent 3-piece operand splitting
-// (dril_device.h: six v_mfma_f32_32x32x16_bf16 per k16 step, f32 accumulate).  Per tile and net 3 x 48 bf16 MFMAs x 32 cycles = 4.6 k cycles of
-// matrix pipe instead of 12.3 k cycles of f32 MFMA on the VALU's lanes; the splits (h1 and dz2: 64 elements per lane) cost ~350 VALU instructions.
-//
-// LDS plan (H = 64; <= 80 KB per workgroup so that an actor and a critic workgroup still share a CU):
-//   * ONE weight image serves both W2 (row reads, L2 forward) and W2' (transposed reads, dh1): three pieces of [64 rows = h2 unit][64 cols = h1 unit]
-//     bf16, 128-byte rows, the 8-byte chunk ch of row r stored at chunk ch ^ gw(r), gw = bits (r1 r2 r3 r4) of r.  Row reads (ds_read_b64: lanes =
-//     32 consecutive rows, one chunk) and transposed reads (ds_read_b64_tr_b16: 4 rows x 8 chunks per half-wave) are both conflict-free on it
-//     (tools/lds_layout_check.py).  Staged pre-scaled by kTanhScale like the f32 images; dh1 folds the 1 / kTanhScale into its tanh' mask.
-//   * activations enter a product that sums over HIDDEN UNITS straight from registers: the packed pieces of an accumulator tile (registers 8s..8s+7
-//     of k-step s) ARE the B operand — element j of lane half h is unit 16s + 8(j>>2) + 4h + (j&3), and the A operand's two 8-byte chunk reads
-//     follow that order.
-//   * products that sum over SAMPLES (dW2) need the transpose: every lane stores its packed pieces (registers 4g..4g+3 = 8 bytes) at
-//     [its sample][unit 8g + 4h] of a per-wave [32 samples][64 units] bf16 image (chunk ^ swap-bits-1,3(sample)), read back with
-//     ds_read_b64_tr_b16: 12 KB per wave for three pieces, used in turn for h2 (f32, output-layer gradient), h1', dz2', dz1 (f32, first-layer gradient).
-//   * db2 = rowsum(dz2) costs no pass of its own: dz2 = (W3' dz) .* (1 - h2^2), so db2[u] = sum_o W3[o][u] * S[o][u] with
-//     S[o][u] = sum_n dz[o][n] (1 - h2[u][n]^2), accumulated beside dW3 (same operands, already in registers) and multiplied by W3 once, in the epilogue.
-// =============================================================================================
-// a lane constant the optimiser cannot see through: image addresses derived from it are rebuilt per tile (2-3 VALU) instead of being hoisted out of the tile loop as
-// loop invariants, where they occupy registers for the whole kernel (ppo_grad_wide_split_kernel: 92 -> 12 spilled registers)
-__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
-template <int D, int H, int O> struct GradScratchSplit {
-    static constexpr int T = 0;                              // 12288 bytes: the h1' piece images (three [32 samples][64 units] bf16)
-    static constexpr int T3 = T + 3 * 32 * H / 2;            // 12288 bytes: the dz2' piece images; after dW2 has consumed them the dz1 f32 image [H][kTS] (9216 bytes) for dW1
-    static constexpr int XI = T3 + 3 * 32 * H / 2;
-    static constexpr int SIZE = XI + (D + 2) * kTS;
-    static_assert(H * kTS <= 3 * 32 * H / 2, "the f32 image must fit the piece images' space");
-};
-// MFMA operand (A or B) of unit tile m, k16 step s of a contraction over samples: lane (unit 32m + (lane&31), half h) gets samples 16s + 8h + j
-__device__ __forceinline__ int timg_read_base(int lane) {
-    const int h = lane >> 5, gm = (lane >> 4) & 1, e = lane & 15, q = e >> 2, p = e & 3;
-    return (8 * h + q) * 128 + ((((4 * gm + p) ^ (8 * (q >> 1) + 2 * h + (q & 1))) & 15) << 3);
-}
-__device__ __forceinline__ bf16x8 load_frag_T(const char* T, int rbase, int piece, int m, int s) {
-    const int a = (rbase ^ (64 * m)) + 2048 * s + 4096 * piece;
-    return frag8(lds_read_tr16(T, a), lds_read_tr16(T, a ^ (512 | 32)));
-}
-
-// ---- the tile loop as six stages --------------------------------------------------------------------------------------------------------------------------
-// S1  unpack, prefetch of the next tile, L1 (f32 MFMA, 4)                         S4  per k16 step: dz2 (8 registers), split, piece image, dh1 MFMAs (48); mask -> dz1
-// S2  per k16 step: tanh + split of 8 registers of h1, piece image, L2 MFMAs      S5  dW2 (48 bf16 MFMA): both operands as transposed fragments of the piece images
-//     (48 bf16 MFMA, both output m-tiles); tanh -> h2                             S6  dz1 f32 image; dW1 as 32 rank-1 updates (v_mfma_f32_4x4x1_16B_f32: lane = hidden unit,
-// S3  L3, loss head, per-lane dW3 accumulation                                         4 input components per instruction), db1 = row sum on the VALU
-// One wave per SIMD (<= 512 registers).  What the profile of this kernel says (profiles/r02_split_kernel.md): with ONE wave per SIMD the matrix pipe and the VALU do not
-// run beside each other — an interleaved instruction stream is issued in order and v_fma / v_exp stall behind the wave's own MFMA (microbenchmark mfma_bf16_valu:
-// 16 v_fma after every bf16 MFMA cost 69 instead of 34 + 35 cycles; two waves per SIMD hide them completely) — so a tile costs MFMA + VALU, and the stages below are
-// written to execute FEWER VALU / LDS instructions rather than to overlap them: activation pieces are produced a k16 step at a time and go straight to their image
-// (12 registers live instead of 96), the output-layer gradient and the bias gradients are per-lane accumulations reduced once in the epilogue (no f32 h2 image,
-// no second pass over it), and dW1 runs on the 4x4x1 MFMA (256 instead of 1024 cycles on the VALU's lanes).
-template <int MT, int O> struct TileCtx {
-    TileIn<O> cur, nxt;
-    float xk[2]; bool valid;
-    f32x16 h1[MT], h2[MT], g1[MT];
-    float dz[O];
-    char* Tb; char* T3b; float* T3; float* XI;
-};
-template <int H, int O, int D> struct SplitAcc {
-    static constexpr int MT = H / 32, ND = (D + 3) / 4;
-    f32x16 dW2[MT][MT];
-    f32x16 dW3[O][MT];        // per lane: sum over this lane's samples of dz[o] * h2[unit]; summed over the 32 lanes of a half in the epilogue
-    f32x16 db2[MT];           // per lane: sum of dz2[unit]
-    f32x4 dW1[ND][2];         // lane 4b + j, register i: dW1[unit 4b + i][component 4nd + j] (two accumulators: even / odd samples)
-    float db1;                // lane = unit
-    float db3p[O], dlsp[O], st[5];
-};
-struct SplitEnv { float* wl; const char* Wimg; int lane, c, h, wf_base, wt_base, tr_base, ts_base; const float* ls; float adv_mean, adv_inv; };
-
-// transposed piece images [32 samples][64 units]: lane (sample c, half h) stores registers 4g..4g+3 of m-tile m (units 32m + 8g + 4h ..+3) as one 8-byte chunk;
-// ts_base = c * 128 + (((h ^ gs(c)) & 15) << 3); pc[piece][t] = packed registers (8s + 2t, 8s + 2t + 1) of the k16 step s
-__device__ __forceinline__ void store_piece_chunk(char* T, int ts_base, int m, int s, const unsigned (&pc)[3][4]) {
-#pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
-        const int a = ts_base ^ (64 * m + 16 * (2 * s + gg));
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(T + 4096 * p + a) = u32x2{pc[p][2 * gg], pc[p][2 * gg + 1]};
-    }
-}
-__device__ __forceinline__ u32x2 lds_read_u32x2(const char* p) { return *reinterpret_cast<const u32x2*>(p); }
-// acc += a . b with the accumulator pinned to AGPRs and updated in place
-__device__ __forceinline__ void mfma_acc_agpr(f32x16& acc, bf16x8 a, bf16x8 b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-// v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 blocks; lane 4b + i gives A[i] and B[i] of block b, register r of lane 4b + j receives D[r][j]
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
-
-template <int KIND, int H, int O, int HEAD, bool REC>
-struct SplitStages {
-    static constexpr int D = EnvSpec<KIND>::D, MT = H / 32, ND = (D + 3) / 4;
-    using L = NetLdsSplit<D, H, O>;
-    using Ctx = TileCtx<MT, O>;
-    using Acc = SplitAcc<H, O, D>;
-
-    static __device__ __forceinline__ void s1(const GradArgs& a, const SplitEnv& e, Ctx& t, int64_t next_tile, int64_t ntiles) {
-        t.cur = t.nxt;
-        unpack_tile<KIND, O, HEAD, REC>(a, e.h, t.cur);
-        load_tile<KIND, O, HEAD, REC>(a, next_tile, ntiles, e.c, e.h, t.nxt);      // prefetch the next tile: consumed one whole tile from now
-        t.valid = t.cur.valid; t.xk[0] = t.cur.xk[0]; t.xk[1] = t.cur.xk[1];
-        dense_first<H, MT>(e.wl + L::W1T, e.wl + L::B1, t.xk, t.h1, e.lane);        // pre-activations (scaled by kTanhScale)
-    }
-    static __device__ __forceinline__ void s2(const SplitEnv& e, Ctx& t) {
-        f32x16 acc[MT];
-#pragma unroll
-        for (int mo = 0; mo < MT; ++mo)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(e.wl + L::B2 + 32 * mo + 8 * q + 4 * e.h);
-                acc[mo][4 * q + 0] = b[0]; acc[mo][4 * q + 1] = b[1]; acc[mo][4 * q + 2] = b[2]; acc[mo][4 * q + 3] = b[3];
-            }
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 Aw[MT][3];                                                   // weight fragments first: their LDS latency runs under the chunk's VALU work
-#pragma unroll
-                for (int mo = 0; mo < MT; ++mo) {
-                    const int a0 = (e.wf_base ^ (64 * mi + 32 * s)) + 4096 * mo;
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        Aw[mo][p] = frag8(lds_read_u32x2(e.Wimg + 8192 * p + a0), lds_read_u32x2(e.Wimg + 8192 * p + (a0 ^ 16)));
-                }
-                __builtin_amdgcn_sched_barrier(0);                                  // pin the requests here (the scheduler otherwise sinks them to their first use)
-                float ex[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ex[i] = __builtin_amdgcn_exp2f(t.h1[mi][8 * s + i]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ex[i] = __builtin_amdgcn_rcpf(ex[i] + 1.0f);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) t.h1[mi][8 * s + i] = fmaf(-2.0f, ex[i], 1.0f);
-                unsigned pc[3][4];
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) split3_pair(t.h1[mi][8 * s + 2 * tt], t.h1[mi][8 * s + 2 * tt + 1], pc[0][tt], pc[1][tt], pc[2][tt]);
-                store_piece_chunk(t.Tb, e.ts_base, mi, s, pc);                      // h1' images for dW2
-#pragma unroll
-                for (int mo = 0; mo < MT; ++mo) acc[mo] = mfma_split6(Aw[mo][0], Aw[mo][1], Aw[mo][2], chunk_frag(pc, 0), chunk_frag(pc, 1), chunk_frag(pc, 2), acc[mo]);
-            }
-#pragma unroll
-        for (int mo = 0; mo < MT; ++mo) { tanh16(acc[mo]); t.h2[mo] = acc[mo]; }
-    }
-    static __device__ __forceinline__ void s3(const GradArgs& a, const SplitEnv& e, Ctx& t, Acc& A) {
-        float out[O];
-        dense_out<MT, O, H>(e.wl + L::W3S, e.wl + L::B3, t.h2, out, e.lane);
-        loss_head<O, HEAD>(a, t.cur, out, t.valid, e.h == 0, e.ls, e.adv_mean, e.adv_inv, t.dz, A.st, A.dlsp);   // ppo.jl:377-404 and dLoss/dout
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            if (e.h == 0) A.db3p[o] += t.dz[o];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) A.dW3[o][m] += t.dz[o] * t.h2[m];          // dW3[o][unit] += dz[o][sample] h2[unit][sample]: the lane IS the sample
-        }
-    }
-    static __device__ __forceinline__ void s4(const SplitEnv& e, Ctx& t, Acc& A) {  // dz2 = (W3' dz) .* (1 - h2^2); dh1 = W2' dz2 (A: transposed reads of the weight image); dz1 = dh1 .* (1 - h1^2)
-        constexpr float kInvTanhScale = 1.0f / kTanhScale;
-        f32x16 acc[MT];
-#pragma unroll
-        for (int mk = 0; mk < MT; ++mk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mk][r] = 0.f;
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 Aw[MT][3];
-#pragma unroll
-                for (int mk = 0; mk < MT; ++mk) {
-                    const int a0 = (e.wt_base ^ (64 * mk + 2048 * s + 8 * s)) + 4096 * mi;
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) Aw[mk][p] = frag8(lds_read_tr16(e.Wimg, 8192 * p + a0), lds_read_tr16(e.Wimg, 8192 * p + (a0 ^ (1024 | 16))));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                float z[8];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    float dh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int o = 0; o < O; ++o) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(e.wl + L::W3S + o * H + 32 * mi + 8 * (2 * s + q) + 4 * e.h);
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(w[cc], t.dz[o], dh[cc]);
-                    }
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) { const float hv = t.h2[mi][8 * s + 4 * q + cc]; z[4 * q + cc] = dh[cc] * fmaf(-hv, hv, 1.0f); }
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) A.db2[mi][8 * s + i] += z[i];
-                unsigned pc[3][4];
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) split3_pair(z[2 * tt], z[2 * tt + 1], pc[0][tt], pc[1][tt], pc[2][tt]);
-                store_piece_chunk(t.T3b, e.ts_base, mi, s, pc);                     // dz2' images for dW2
-#pragma unroll
-                for (int mk = 0; mk < MT; ++mk) acc[mk] = mfma_split6(Aw[mk][0], Aw[mk][1], Aw[mk][2], chunk_frag(pc, 0), chunk_frag(pc, 1), chunk_frag(pc, 2), acc[mk]);
-            }
-#pragma unroll
-        for (int mk = 0; mk < MT; ++mk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float t2 = t.h1[mk][r] * t.h1[mk][r]; t.g1[mk][r] = acc[mk][r] * fmaf(-t2, kInvTanhScale, kInvTanhScale); }
-    }
-    static __device__ __forceinline__ void s5(const SplitEnv& e, Ctx& t, Acc& A) {   // dW2 += dz2 h1' over the 32 samples
-        bf16x8 Bf[2][MT][3], Af[2][MT][3];                                             // all 24 fragments are requested before the first MFMA (96 registers; nothing else is live here)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) { Bf[s][m][p] = load_frag_T(t.Tb, e.tr_base, p, m, s); Af[s][m][p] = load_frag_T(t.T3b, e.tr_base, p, m, s); }
-        __builtin_amdgcn_sched_barrier(0);
-        // The dW2 accumulators are touched by nothing but these MFMAs and the epilogue: they live in AGPRs, in place (mfma_acc_agpr).  The rest of the file is compiled
-        // with MFMA results in VGPRs (Makefile: -amdgpu-mfma-vgpr-form) because the VALU consumes them; for THESE 64 registers that would mean parking them in AGPRs
-        // between tiles and moving them in and out around every S5 (128 v_accvgpr moves per tile).  Round robin over the four accumulators: a dependent MFMA is
-        // issued three MFMAs after its predecessor, so no software wait state is needed between them.
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int term = 0; term < 6; ++term) {
-                // small terms first, as in mfma_split6: (A piece, B piece) = (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-                const int pa = term == 0 ? 2 : (term == 2 || term == 3) ? 1 : 0, pb = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int mj = 0; mj < MT; ++mj) mfma_acc_agpr(A.dW2[mi][mj], Af[s][mi][pa], Bf[s][mj][pb]);
-            }
-    }
-    // dW1 += dz1 x' as rank-1 updates per sample; db1 += row sum of dz1.  In two parts: the images are written right after dW2 (s6a), and read back one stage later, after
-    // the NEXT tile's S1 (s6b) — the LDS write -> read round trip runs under that stage instead of stalling the wave
-    static __device__ __forceinline__ void s6a(const SplitEnv& e, Ctx& t) {
-        store_image<MT>(t.T3, t.g1, e.lane);                                          // the dz1 f32 image takes the dz2' images' place (dW2 has consumed them: same wave, LDS in order)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { const int d = 2 * s + e.h; t.XI[(d < D ? d : D + 1) * kTS + e.c] = d < D ? t.xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
-    }
-    struct DW1In { float az[32]; f32x4 x[ND][8]; };
-    static __device__ __forceinline__ void s6b_load(const SplitEnv& e, Ctx& t, DW1In& in) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(t.T3 + e.lane * kTS + 4 * q);
-            in.az[4 * q] = v[0]; in.az[4 * q + 1] = v[1]; in.az[4 * q + 2] = v[2]; in.az[4 * q + 3] = v[3];
-        }
-#pragma unroll
-        for (int nd = 0; nd < ND; ++nd) {
-            const int d = 4 * nd + (e.lane & 3);
-            const float* xr = t.XI + (d < D ? d : D + 1) * kTS;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) in.x[nd][q] = *reinterpret_cast<const f32x4*>(xr + 4 * q);
-        }
-    }
-    static __device__ __forceinline__ void s6b_math(const DW1In& in, Acc& A) {
-#pragma unroll
-        for (int nd = 0; nd < ND; ++nd)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                A.dW1[nd][0] = mfma4(in.az[4 * q], in.x[nd][q][0], A.dW1[nd][0]); A.dW1[nd][1] = mfma4(in.az[4 * q + 1], in.x[nd][q][1], A.dW1[nd][1]);
-                A.dW1[nd][0] = mfma4(in.az[4 * q + 2], in.x[nd][q][2], A.dW1[nd][0]); A.dW1[nd][1] = mfma4(in.az[4 * q + 3], in.x[nd][q][3], A.dW1[nd][1]);
-            }
-        float s8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s8[i] = (in.az[i] + in.az[8 + i]) + (in.az[16 + i] + in.az[24 + i]);
-        A.db1 += ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-    }
-};
-
-template <int KIND, int H, int O, int HEAD, bool REC>
-__device__ __forceinline__ void grad_body_split(const GradArgs& a, float* smem) {
-    constexpr int D = EnvSpec<KIND>::D, MT = H / 32, NCTX = 1;
-    using L = NetLdsSplit<D, H, O>;
-    using SC = GradScratchSplit<D, H, O>;
-    using ST = SplitStages<KIND, H, O, HEAD, REC>;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 31, h = lane >> 5;
-    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
-    float* wl = smem;
-    float* scratch = smem + L::END + wave * (NCTX * SC::SIZE);
-    stage_net_split<D, H, O>(wl, a.params, off, tid, blockDim.x);
-    for (int i = lane; i < (D + 2) * kTS; i += 64) scratch[SC::XI + i] = (i / kTS == D) ? 1.0f : 0.0f;
-    for (int i = lane; i < H * kTS; i += 64) scratch[SC::T3 + i] = 0.0f;     // the first tile's S6b reads the (empty) dz1 image of "the tile before"
-    __syncthreads();
-
-    // advantage normalisation constants (ppo.jl:350-356): mean, corrected std, eps added to the std
-    float adv_mean = 0.f, adv_den = 1.f;
-    if (HEAD != HEAD_VALUE && a.normalize_adv) {
-        double s, q, n;
-        if (a.inline_moments) {
-            double* shd = reinterpret_cast<double*>(smem + ((L::END + 1) & ~1));      // the first 4 KB of wave 0's T image, not yet in use
-            double ls_ = 0, lq_ = 0;
-            for (int64_t i2 = tid; i2 < a.count; i2 += blockDim.x) {
-                const int64_t p2 = a.pos0 + i2;
-                const int64_t gi = a.perm ? a.perm[p2] : (a.perm_bits ? perm_index(p2, a.N, a.perm_key, a.perm_bits) : p2);
-                const int64_t li2 = gi - a.idx_lo;
-                if (li2 >= 0 && li2 < a.n_local) { const float v = REC ? a.rec[2 * li2 + 1].y : a.adv[li2]; ls_ += v; lq_ += (double)v * v; }
-            }
-            shd[tid] = ls_; shd[256 + tid] = lq_;
-            __syncthreads();
-            for (int st_ = 128; st_ > 0; st_ >>= 1) { if (tid < st_) { shd[tid] += shd[tid + st_]; shd[256 + tid] += shd[256 + tid + st_]; } __syncthreads(); }
-            s = shd[0]; q = shd[256]; n = (double)a.count;
-            __syncthreads();
-        } else { s = a.adv_stats[0]; q = a.adv_stats[1]; n = a.adv_stats[2]; }
-        const double mean = s / n;
-        double var = (q - s * mean) / (n - 1.0);
-        if (var < 0) var = 0;
-        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
-    }
-    float lsr[kLsMax];
-#pragma unroll
-    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
-    if (HEAD == HEAD_GAUSSIAN) {
-#pragma unroll
-        for (int o = 0; o < O; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
-    }
-    SplitEnv e;
-    e.wl = wl; e.Wimg = reinterpret_cast<const char*>(smem + L::W2P); e.lane = lane; e.c = c; e.h = h; e.ls = lsr;
-    e.adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
-    e.adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
-    // lane constants of the LDS images
-    e.wf_base = c * 128 + (((h ^ w2img_gw(c)) & 15) << 3);                                  // W2 row read: row 32 mo + c, chunk (8 mi + 4 s + 2 rho + h) ^ gw
-    { const int e16 = lane & 15, tq = e16 >> 2, tp = e16 & 3, tg = (lane >> 4) & 1;
-      e.wt_base = (4 * h + tq) * 128 + ((((4 * tg + tp) ^ (8 * (tq >> 1) + 4 * h)) & 15) << 3); }   // W2' transposed read: rows 32 mi + 16 s + 8 rho + 4 h + q, chunk 8 mk + 4 g + p
-    e.tr_base = timg_read_base(lane);
-    e.ts_base = c * 128 + (((h ^ timg_gs(c)) & 15) << 3);
-
-    SplitAcc<H, O, D> A;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) A.db2[i][r] = 0.f;
-#pragma unroll
-        for (int j = 0; j < MT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) A.dW2[i][j][r] = 0.f;
-    }
-#pragma unroll
-    for (int nd = 0; nd < (D + 3) / 4; ++nd) { A.dW1[nd][0] = f32x4{0.f, 0.f, 0.f, 0.f}; A.dW1[nd][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    A.db1 = 0.f;
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-        A.db3p[o] = 0.f; A.dlsp[o] = 0.f;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) A.dW3[o][m][r] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) A.st[i] = 0.f;
-
-    const int g = HEAD == HEAD_VALUE ? (int)blockIdx.x - a.G : (int)blockIdx.x;            // the first G workgroups run the actor, the next Gc the critic
-    const int64_t ntiles = (a.count + kTile - 1) / kTile;
-    const int64_t tstride = (int64_t)(HEAD == HEAD_VALUE ? a.Gc : a.G) * 4, first = (int64_t)g * 4 + wave;
-    typename ST::Ctx ta;
-    ta.Tb = reinterpret_cast<char*>(scratch + SC::T); ta.T3 = scratch + SC::T3; ta.T3b = reinterpret_cast<char*>(ta.T3); ta.XI = scratch + SC::XI;
-    {
-        int64_t tile = first;
-        load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, ta.nxt);       // a tile index past the end loads an all-invalid tile
-#ifdef DRIL_STAMPS
-        unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
-#endif
-        for (; tile < ntiles; tile += tstride) {
-            typename ST::DW1In w1;
-            ST::s6b_load(e, ta, w1); __builtin_amdgcn_sched_barrier(0);               // dW1 of the previous tile (zeros before the first): operands requested before S1, consumed after it
-            ST::s1(a, e, ta, tile + tstride, ntiles); __builtin_amdgcn_sched_barrier(0); STAMP(0);
-            ST::s6b_math(w1, A); __builtin_amdgcn_sched_barrier(0); STAMP(5);
-            ST::s2(e, ta); __builtin_amdgcn_sched_barrier(0); STAMP(1);
-            ST::s3(a, e, ta, A); __builtin_amdgcn_sched_barrier(0); STAMP(2);
-            ST::s4(e, ta, A); __builtin_amdgcn_sched_barrier(0); STAMP(3);
-            ST::s5(e, ta, A); __builtin_amdgcn_sched_barrier(0); STAMP(4);
-            ST::s6a(e, ta); __builtin_amdgcn_sched_barrier(0);
-        }
-        if (first < ntiles) { typename ST::DW1In w1; ST::s6b_load(e, ta, w1); ST::s6b_math(w1, A); }   // the last tile's dW1
-#ifdef DRIL_STAMPS
-        if (lane == 0 && a.dbg) {
-            unsigned long long* o = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
-            for (int k = 0; k < 10; ++k) o[k] = stamp_acc[k];
-            o[10] = (unsigned long long)((ntiles - first + tstride - 1) / tstride); o[11] = HEAD;
-        }
-#endif
-    }
-
-    // ---- epilogue: 4 waves -> one slab (fixed wave order => deterministic) ----
-    __syncthreads();
-    float* red = smem + L::END;
-    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
-    const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
-    const int o_ls = o_b3 + O, o_st = SL - 8;
-    for (int i = tid; i < SL; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * mi + rowfn(r, h);
-#pragma unroll
-                    for (int mj = 0; mj < MT; ++mj) red[o_w2 + row + (32 * mj + c) * H] += A.dW2[mi][mj][r];
-                }
-#pragma unroll
-            for (int nd = 0; nd < (D + 3) / 4; ++nd)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {                                          // 4x4x1 blocks: lane 4b + j, register i = dW1[unit 4b + i][component 4 nd + j]
-                    const int row = 4 * (lane >> 2) + i, col = 4 * nd + (lane & 3);
-                    if (col < D) red[o_w1 + row + col * H] += A.dW1[nd][0][i] + A.dW1[nd][1][i];
-                }
-            red[o_b1 + lane] += A.db1;                                                 // lane = unit
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {                                         // per-lane sums over samples -> sum over the 32 lanes of each half (the halves hold different units)
-                    const int unit = 32 * m + rowfn(r, h);
-                    const float b2 = half_sum(A.db2[m][r]);
-                    if (c == 0) red[o_b2 + unit] += b2;
-#pragma unroll
-                    for (int o = 0; o < O; ++o) { const float v = half_sum(A.dW3[o][m][r]); if (c == 0) red[o_w3 + o + unit * O] += v; }
-                }
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                const float b3 = half_sum(A.db3p[o]);
-                if (lane == 0) red[o_b3 + o] += b3;
-                if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(A.dlsp[o]); if (lane == 0) red[o_ls + o] += l; }
-            }
-#pragma unroll
-            for (int k = 0; k < 5; ++k) { const float v = half_sum(A.st[k]); if (lane == 0) red[o_st + k] += v; }
-        }
-        __syncthreads();
-    }
-    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
-    for (int i = tid; i < SL; i += blockDim.x) slab[i] = red[i];
-}
-
-// one 4-wave workgroup per CU (<= 512 registers per wave)
-template <int KIND, int H, bool REC>
-__global__ __launch_bounds__(256, 1) void ppo_grad_split_kernel(GradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (*a.stop_flag) return;
-    constexpr int A = EnvSpec<KIND>::A;
-    const bool actor = blockIdx.x < (unsigned)a.G;
-    if (actor) grad_body_split<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN, REC>(a, smem);
-    else grad_body_split<KIND, H, 1, HEAD_VALUE, REC>(a, smem);
-}
-
-// =============================================================================================
-// ppo_grad_wide_kernel — the same fused forward + loss + backward for hidden widths that do not fit one wave
-// (H = 256: W2 is 256 KB, dW2 is 64 K accumulators).  A workgroup of H/32 waves processes a 32-sample tile TOGETHER:
-// wave w owns m-tile w (hidden rows 32w..32w+31) of every layer and the 32 x H slice of dW2 in registers (H/2 VGPRs);
-// activations are exchanged through LDS (B-operand images [m][lane][16]), the two H x H operand streams W2 / W2' come
-// pre-tiled from L2 (dril_device.h "wide nets").  Four workgroup barriers per tile.  Per tile and wave:
-//   2 (L1) + 4*MT (L2) + 4*MT (dh1) + 4*MT... in 32x32x2 units: L2 16*MT, dh1 16*MT, dW2 16*MT, dW1 1.
-// Every wave owns distinct rows of every gradient, so the slab is written straight from registers (no cross-wave sum).
-// =============================================================================================
-template <int D, int H, int O> struct WideScratch {
-    static constexpr int MT = H / 32;
-    static constexpr int SMALL = NetLdsSmall<D, H, O>::END;
-    static constexpr int XA = (SMALL + 3) / 4 * 4;          // h1 as B-operand image [MT][64][16]
-    static constexpr int XB = XA + MT * 1024;               // dz2 as B-operand image
-    static constexpr int TA = XB + MT * 1024;               // h1 transposed [H][kTS]
-    static constexpr int TB = TA + H * kTS;                 // per-wave rows: h2', then dz2', then dz1'
-    static constexpr int XI = TB + H * kTS;                 // [D+2][kTS]
-    static constexpr int ZI = XI + (D + 2) * kTS;           // [MT waves][O][kTS]
-    static constexpr int PO = ZI + MT * O * kTS;            // [MT waves][O][32] output-layer partial sums
-    static constexpr int SIZE = PO + MT * O * 32;
-};
-
-__device__ __forceinline__ void store_breg(float* img, int m, const f32x16& x, int lane) {
-    float* p = img + ((size_t)m * 64 + lane) * 16;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p + 4 * q) = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
-}
-__device__ __forceinline__ f32x16 load_breg(const float* img, int m, int lane) {
-    const float* p = img + ((size_t)m * 64 + lane) * 16;
-    f32x16 v;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q); v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3]; }
-    return v;
-}
-__device__ __forceinline__ void store_image_tile(float* img, int m, const f32x16& x, int lane) {
-    const int c = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) img[(32 * m + rowfn(r, h)) * kTS + c] = x[r];
-}
-// Y tile mo = W * X with W from the pre-tiled global image and X read tile by tile from an LDS B-operand image
-__device__ __forceinline__ void wide_preload(const float* __restrict__ wimg, int MTv, int mo, int lane, f32x4 (&af)[4]) {
-    const float* base = wimg + ((size_t)mo * MTv * 4 * 64 + lane) * 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const f32x4*>(base + (size_t)q * 256);
-}
-template <int MT, bool BIAS>
-__device__ __forceinline__ f32x16 dense_tile_global_ldsB(const float* __restrict__ wimg, const float* __restrict__ bias, const float* __restrict__ ximg, int mo, int lane, f32x4 (&af)[4]) {
-    const int h = lane >> 5;
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (BIAS) b = *reinterpret_cast<const f32x4*>(bias + 32 * mo + 8 * q + 4 * h);
-        acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
-    }
-    const float* base = wimg + ((size_t)mo * MT * 4 * 64 + lane) * 4;
-    // The A fragments stream from L2 (pre-tiled image, 1 KiB contiguous per wave-instruction).  Each of the four fragment registers is refilled
-    // with the NEXT m-tile's fragment right after the four MFMAs that consumed it were issued, so every load has 12-16 MFMAs (~1 k cycles) of
-    // cover with only 16 registers of buffering (the loop stays rolled: fully unrolled, hipcc hoists all 32 loads and spills 330 VGPRs)
-    // af[] arrives preloaded with the first m-tile's fragments (wide_preload, issued before the workgroup barrier that precedes this chain)
-#pragma unroll 1
-    for (int mi = 0; mi < MT; ++mi) {
-        const f32x16 X = load_breg(ximg, mi, lane);
-        const float* nextp = base + (size_t)((mi + 1 < MT ? mi + 1 : mi) * 4) * 256;   // last iteration re-reads its own fragments (in bounds, unused)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc = mfma32(af[q][0], X[4 * q + 0], acc); acc = mfma32(af[q][1], X[4 * q + 1], acc);
-            acc = mfma32(af[q][2], X[4 * q + 2], acc); acc = mfma32(af[q][3], X[4 * q + 3], acc);
-            af[q] = *reinterpret_cast<const f32x4*>(nextp + (size_t)q * 256);
-        }
-    }
-    return acc;
-}
-
-template <int KIND, int H, int O, int HEAD, bool REC>
-__device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
-    constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
-    using L = NetLdsSmall<D, H, O>;
-    using SC = WideScratch<D, H, O>;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // this wave's m-tile
-    const int c = lane & 31, h = lane >> 5;
-    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
-    const float* w2a = HEAD == HEAD_VALUE ? a.w2a_critic : a.w2a_actor;
-    const float* w2ta = HEAD == HEAD_VALUE ? a.w2ta_critic : a.w2ta_actor;
-    float* wl = smem;
-    float* XA = smem + SC::XA; float* XB = smem + SC::XB; float* TA = smem + SC::TA; float* TB = smem + SC::TB;
-    float* XI = smem + SC::XI; float* ZI = smem + SC::ZI + w * O * kTS; float* PO = smem + SC::PO;
-    stage_net_small<D, H, O>(wl, a.params, off, tid, blockDim.x);
-    for (int i = tid; i < (D + 2) * kTS; i += blockDim.x) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
-    __syncthreads();
-
-    float adv_mean = 0.f, adv_den = 1.f;
-    if (HEAD != HEAD_VALUE && a.normalize_adv) {
-        const double s = a.adv_stats[0], q = a.adv_stats[1], n = a.adv_stats[2];
-        const double mean = s / n;
-        double var = (q - s * mean) / (n - 1.0);
-        if (var < 0) var = 0;
-        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
-    }
-    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
-    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
-    constexpr bool LS_GAUSS = HEAD == HEAD_GAUSSIAN; constexpr int LS_N = O;
-    // log_std hoisted into scalar registers: a per-tile global load would sit in the in-order vmcnt queue between the prefetched
-    // gathers and their first use and drain them every tile (Pendulum [64,64]: 91 -> TFLOP/s below)
-    float lsr[kLsMax];
-#pragma unroll
-    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
-    if (LS_GAUSS) {
-#pragma unroll
-        for (int o = 0; o < LS_N; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
-    }
-    const float* ls = lsr;
-
-    f32x16 dW2[MT];                                                  // rows 32w.., all H columns
-    f32x4 dW1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    float dW3a[O], db2p = 0.f, db3p[O], dlsp[O], st[5];
-#pragma unroll
-    for (int j = 0; j < MT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dW2[j][r] = 0.f;
-#pragma unroll
-    for (int o = 0; o < O; ++o) { dW3a[o] = 0.f; db3p[o] = 0.f; dlsp[o] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) st[i] = 0.f;
-
-    const int g = a.layout ? (int)(blockIdx.x % a.G) : (int)(blockIdx.x >> 1);
-    const int64_t ntiles = (a.count + kTile - 1) / kTile;
-    TileIn<O> cur, nxt;
-    int64_t tile = g;
-    if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
-#ifdef DRIL_STAMPS
-    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
-#endif
-    for (; tile < ntiles; tile += a.G) {
-        unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
-        const bool valid = cur.valid;
-        const float xk[2] = {cur.xk[0], cur.xk[1]};
-        // ---- S2: h1 tile w ----
-        f32x16 h1w;
-        {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B1 + 32 * w + 8 * q + 4 * h);
-                h1w[4 * q + 0] = b[0]; h1w[4 * q + 1] = b[1]; h1w[4 * q + 2] = b[2]; h1w[4 * q + 3] = b[3];
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
-            tanh16(h1w);
-        }
-        store_breg(XA, w, h1w, lane);
-        store_image_tile(TA, w, h1w, lane);
-        if (w == 0) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
-        }
-        STAMP(0);
-        f32x4 afw[4];
-        wide_preload(w2a, MT, w, lane, afw);                                          // first W2 fragments in flight across the barrier
-        __syncthreads();                                                              // B1: XA, TA, XI complete
-        STAMP(1);
-        // prefetch the next tile's record only now: issued before unpack_tile(cur) it sat behind cur's loads in the in-order vmcnt queue and the
-        // spill reloads' s_waitcnt vmcnt(0) made every tile wait for a full gather latency (stamps: 10 k cycles in this phase)
-        load_tile<KIND, O, HEAD, REC>(a, tile + a.G, ntiles, c, h, nxt);
-        // ---- S3: h2 tile w ----
-        f32x16 h2w = dense_tile_global_ldsB<MT, true>(w2a, wl + L::B2, XA, w, lane, afw);
-        tanh16(h2w);
-        STAMP(2);
-        // ---- S4: output layer: partial over this wave's rows, summed across waves through LDS ----
-        float out[O], dz[O];
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            float p = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
-                p = fmaf(wv[0], h2w[4 * q + 0], p); p = fmaf(wv[1], h2w[4 * q + 1], p);
-                p = fmaf(wv[2], h2w[4 * q + 2], p); p = fmaf(wv[3], h2w[4 * q + 3], p);
-            }
-            p += __shfl_xor(p, 32);
-            if (h == 0) PO[(w * O + o) * 32 + c] = p;
-        }
-        store_image_tile(TB, w, h2w, lane);                                            // h2' (own rows; only this wave reads them)
-        __syncthreads();                                                              // B2: PO complete
-        STAMP(3);
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            float v = wl[L::B3 + o];
-#pragma unroll
-            for (int ww = 0; ww < MT; ++ww) v += PO[(ww * O + o) * 32 + c];            // fixed order: every wave gets the same bits
-            out[o] = v;
-        }
-        loss_head<O, HEAD>(a, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
-        // ---- dW3 (own rows) ----
-#pragma unroll
-        for (int o = 0; o < O; ++o) { if (h == 0) { if (w == 0) db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
-        {
-            const f32x16 Bh2 = load_operand(TB, w, lane);
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                float acc = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 z = *reinterpret_cast<const f32x4*>(ZI + o * kTS + 16 * h + 4 * q);
-                    acc = fmaf(Bh2[4 * q + 0], z[0], acc); acc = fmaf(Bh2[4 * q + 1], z[1], acc);
-                    acc = fmaf(Bh2[4 * q + 2], z[2], acc); acc = fmaf(Bh2[4 * q + 3], z[3], acc);
-                }
-                dW3a[o] += acc;
-            }
-        }
-        // ---- dz2 tile w (in h2w's registers) ----
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float dh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(wv[cc], dz[o], dh[cc]);
-            }
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
-        }
-        store_breg(XB, w, h2w, lane);
-        store_image_tile(TB, w, h2w, lane);                                            // dz2' (after the Bh2 read: same wave, LDS in order)
-        wide_preload(w2ta, MT, w, lane, afw);                                         // first W2' fragments in flight across the barrier
-        STAMP(4);
-        __syncthreads();                                                              // B3: XB complete
-        STAMP(5);
-        // ---- S6: dh1 tile w = W2' dz2 ; dz1 ----
-        f32x16 g1 = dense_tile_global_ldsB<MT, false>(w2ta, nullptr, XB, w, lane, afw);
-        {
-            const f32x16 h1r = load_breg(XA, w, lane);                                 // h1 tile w re-read from its LDS image: 16 registers less across the two MFMA chains
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g1[r] = g1[r] * (1.0f - h1r[r] * h1r[r]);
-        }
-        STAMP(6);
-        // ---- S7: dW2[rows of w][:] += dz2 h1' ----
-        {
-            const f32x16 Az = load_operand(TB, w, lane);
-            db2p += sum16(Az);
-#pragma unroll
-            for (int mj = 0; mj < MT; ++mj) {
-                const f32x16 Bh = load_operand(TA, mj, lane);
-                dW2[mj] = mfma_outer(Az, Bh, dW2[mj]);
-            }
-        }
-        STAMP(7);
-        // ---- S8: dW1 | db1 (own rows) ----
-        store_image_tile(TB, w, g1, lane);
-        {
-            const int j = lane & 15;
-            float bx[8];
-            load_row8(XI, j <= D ? j : D + 1, lane, bx);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float az[8];
-                load_row8(TB, 32 * w + 16 * t + j, lane, az);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) dW1[t] = mfma16(az[k], bx[k], dW1[t]);
-            }
-        }
-        __syncthreads();                                                              // B4: XA/TA/XB/PO/XI free for the next tile
-        STAMP(8);
-        cur = nxt;
-    }
-#ifdef DRIL_STAMPS
-    if (lane == 0 && a.dbg) {
-        unsigned long long* o_ = a.dbg + ((size_t)(blockIdx.x % (2 * a.G)) * 4 + (w & 3)) * 12;
-        if (w < 4) { for (int k = 0; k < 10; ++k) o_[k] = stamp_acc[k]; o_[10] = (unsigned long long)((ntiles - g + a.G - 1) / a.G); o_[11] = HEAD; }
-    }
-#endif
-
-    // ---- epilogue: every wave owns distinct gradient rows -> straight to the workgroup's slab ----
-    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
-    const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
-    const int o_ls = o_b3 + O, o_st = SL - 8;
-    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
-#pragma unroll
-    for (int mj = 0; mj < MT; ++mj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H] = dW2[mj][r];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 32 * w + 16 * t + 4 * (lane >> 4) + r, col = lane & 15;
-            if (col < D) slab[o_w1 + row + col * H] = dW1[t][r];
-            else if (col == D) slab[o_b1 + row] = dW1[t][r];
-        }
-    { const float b2 = db2p + __shfl_xor(db2p, 32); if (h == 0) slab[o_b2 + 32 * w + c] = b2; }
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-        const float v = dW3a[o] + __shfl_xor(dW3a[o], 32);
-        if (h == 0) slab[o_w3 + o + (32 * w + c) * O] = v;
-        const float b3 = half_sum(db3p[o]);
-        if (w == 0 && lane == 0) slab[o_b3 + o] = b3;
-        if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (w == 0 && lane == 0) slab[o_ls + o] = l; }
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (w == 0 && lane == 0) slab[o_st + k] = v; }
-    if (w == 0 && lane < 3) slab[o_st + 5 + lane] = 0.f;
-    for (int i = (HEAD == HEAD_GAUSSIAN ? o_ls + O : o_ls) + tid; i < o_st; i += blockDim.x) slab[i] = 0.f;   // padding
-}
-
-template <int KIND, int H, bool REC>
-__global__ __launch_bounds__(H * 2, 2) void ppo_grad_wide_kernel(GradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (*a.stop_flag) return;
-    constexpr int A = EnvSpec<KIND>::A;
-    const bool actor = a.layout ? (blockIdx.x < (unsigned)a.G) : ((blockIdx.x & 1) == 0);
-    if (actor) grad_body_wide<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN, REC>(a, smem);
-    else grad_body_wide<KIND, H, 1, HEAD_VALUE, REC>(a, smem);
-}
-
-// =============================================================================================
-// ppo_grad_wide_split_kernel — ppo_grad_wide_kernel with its three H x H contractions on the bf16 matrix cores (fp32-equivalent 3-piece operand
-// splitting, dril_device.h).  Same decomposition (a workgroup of H/32 waves owns a 32-sample tile, wave w the m-tile w of every layer and the
-// 32 x H slice of dW2), same four workgroup barriers per tile; what changes is the operand plumbing:
-//   * W2 / W2' stream from L2 as PRE-SPLIT bf16 fragments (build_wimg_split_kernel, once per optimiser step): [(mo*MT + mi)*2 + s][piece][lane][8 bf16],
-//     one 16-byte load per lane, piece and k16 step; 1.5 x the bytes of the f32 stream for a third of the matrix-pipe time.
-//   * activations: every wave splits its own 16 registers once and writes the packed pieces into ONE workgroup image per activation set,
-//     [piece][32 samples][H units] bf16, 16-byte chunk ch of row n stored at ch ^ g(n), g(n) = ((n & 3) << 2) | ((n >> 2) & 3).  The same image gives the
-//     B operand of a product that sums over units (ds_read_b128 along the row: 8 consecutive units of one sample) and both operands of the product
-//     that sums over samples (ds_read_b64_tr_b16: 4 samples x 16 units per 16-lane group); row reads, transposed reads and the 8-byte stores are all
-//     bank-conflict-free under that swizzle (the 4 rows of a transposed read land in the 4 different 64-byte windows, 16 consecutive rows in 16 different chunks).
-//     Two images (h1, dz2) of 192 H bytes replace the four f32 images XA, XB, TA and half of TB.
-//   * no AGPRs: at two waves per SIMD the allocator gives a function that uses ANY AGPR only 128 VGPRs; the 128 dW2 accumulators are VGPR-form MFMA results like the rest.
-// =============================================================================================
-template <int D, int H, int O> struct WideSplitScratch {
-    static constexpr int MT = H / 32;
-    static constexpr int SMALL = NetLdsSmall<D, H, O>::END;
-    static constexpr int P1 = (SMALL + 3) / 4 * 4;          // h1 pieces: 3 x 32 x H bf16 = 48 H floats
-    static constexpr int P2 = P1 + 48 * H;                  // dz2 pieces
-    static constexpr int TB = P2 + 48 * H;                  // per-wave rows [H][kTS] f32: h2', then dz2' (bias gradient), then dz1'
-    static constexpr int XI = TB + H * kTS;                 // [D+2][kTS]
-    static constexpr int ZI = XI + (D + 2) * kTS;           // [MT waves][O][kTS]
-    static constexpr int PO = ZI + MT * O * kTS;            // [MT waves][O][32] output-layer partial sums
-    static constexpr int SIZE = PO + MT * O * 32;
-};
-// chunk swizzle of the piece images.  Rows of >= 256 bytes (H >= 128) alias in every bank: 16 consecutive rows must land in 16 different 16-byte chunks and the 4 rows of a
-// transposed read in the 4 different 64-byte windows.  128-byte rows (H = 64): rows n and n + 1 already sit in different halves of the 256-byte bank window, so 3 bits suffice
-// (and only 8 chunks exist): bit 2 (the 64-byte window) from n bit 1, bits 0-1 from n bits 2-3.
-template <int H> __device__ __forceinline__ int wimg_g(int n) { return H >= 128 ? (((n & 3) << 2) | ((n >> 2) & 3)) : ((((n >> 1) & 1) << 2) | ((n >> 2) & 3)); }
-
-// pre-split fragment streams of one net: forward A[i][k] = kTanhScale W2[32mo + i][k], reverse A[i][k] = W2[k][32mo + i]; k = 32mi + 16s + 8(lane>>5) + j
 __global__ void build_wimg_split_kernel(const float* __restrict__ P, NetOff off, int H, u32x4* __restrict__ w2p, u32x4* __restrict__ w2tp) {
     const int MT = H / 32, total = MT * MT * 2 * 64;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -2087,641 +819,6 @@ __global__ void build_wimg_split_kernel(const float* __restrict__ P, NetOff off,
 #pragma unroll
         for (int p = 0; p < 3; ++p) { w2p[base + (size_t)p * 64] = u32x4{f[p][0], f[p][1], f[p][2], f[p][3]}; w2tp[base + (size_t)p * 64] = u32x4{b[p][0], b[p][1], b[p][2], b[p][3]}; }
     }
-}
-
-// split the 16 registers of m-tile w (accumulator layout) and store the packed pieces: registers 4g..4g+3 = units 32w + 8g + 4h .. +3 of sample c = one 8-byte chunk
-template <int H>
-__device__ __forceinline__ void store_tile_pieces(char* pimg, int w, const f32x16& x, int lane) {
-    constexpr int RB = 2 * H, PS = 32 * RB;
-    const int c = lane & 31, h = lane >> 5, rowb = c * RB + 8 * h, gsw = wimg_g<H>(c);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        unsigned hi[2], mid[2], lo[2];
-        split3_pair(x[4 * g], x[4 * g + 1], hi[0], mid[0], lo[0]); split3_pair(x[4 * g + 2], x[4 * g + 3], hi[1], mid[1], lo[1]);
-        const int a = rowb + (((4 * w + g) ^ gsw) << 4);
-        *reinterpret_cast<u32x2*>(pimg + a) = u32x2{hi[0], hi[1]}; *reinterpret_cast<u32x2*>(pimg + PS + a) = u32x2{mid[0], mid[1]}; *reinterpret_cast<u32x2*>(pimg + 2 * PS + a) = u32x2{lo[0], lo[1]};
-    }
-}
-// the inverse of store_tile_pieces for the lane's own chunks: x = hi + mid + lo (exact)
-template <int H>
-__device__ __forceinline__ void load_tile_pieces(const char* pimg, int w, f32x16& x, int lane) {
-    constexpr int RB = 2 * H, PS = 32 * RB;
-    const int c = lane & 31, h = lane >> 5, rowb = c * RB + 8 * h, gsw = wimg_g<H>(c);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int a = rowb + (((4 * w + g) ^ gsw) << 4);
-        const u32x2 hi = *reinterpret_cast<const u32x2*>(pimg + a), mid = *reinterpret_cast<const u32x2*>(pimg + PS + a), lo = *reinterpret_cast<const u32x2*>(pimg + 2 * PS + a);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            x[4 * g + 2 * t] = (__uint_as_float(hi[t] << 16) + __uint_as_float(mid[t] << 16)) + __uint_as_float(lo[t] << 16);
-            x[4 * g + 2 * t + 1] = (__uint_as_float(hi[t] & 0xffff0000u) + __uint_as_float(mid[t] & 0xffff0000u)) + __uint_as_float(lo[t] & 0xffff0000u);
-        }
-    }
-}
-// operand of a product that sums over SAMPLES: lane (unit 32m + (lane & 31), half kh) gets samples 16s + 8kh + j of its unit; tbase from wide_tr_base
-template <int H>
-__device__ __forceinline__ int wide_tr_base(int lane) {
-    constexpr int RB = 2 * H;
-    const int kh = lane >> 5, gm = (lane >> 4) & 1, e = lane & 15, q = e >> 2, p = e & 3, n = 8 * kh + q;
-    return n * RB + ((((2 * gm + (p >> 1)) ^ wimg_g<H>(n)) & 15) << 4) + 8 * (p & 1);
-}
-template <int H>
-__device__ __forceinline__ bf16x8 load_frag_wide_T(const char* pimg, int tbase, int piece, int m, int s) {
-    constexpr int RB = 2 * H, PS = 32 * RB;
-    const int a = (tbase ^ (64 * m)) + 16 * s * RB + piece * PS;
-    return frag8(lds_read_tr16(pimg, a), lds_read_tr16(pimg, (a ^ 16) + 4 * RB));     // samples +0..3, +4..7: the row's chunk swizzle flips bit 0 with (n >> 2) & 1
-}
-__device__ __forceinline__ void wide_split_preload(const u32x4* __restrict__ wimg, int MTv, int mo, int lane, u32x4 (&af)[2][3]) {
-    const u32x4* base = wimg + ((size_t)mo * MTv * 6) * 64 + lane;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) af[s][p] = base[(size_t)(s * 3 + p) * 64];
-}
-// output m-tile mo of Y = W X: W as pre-split fragments from L2 (af arrives preloaded with m-tile 0's, each refilled in place right after its MFMAs), X from the piece image
-template <int H, bool BIAS>
-__device__ __forceinline__ f32x16 dense_tile_split(const u32x4* __restrict__ wimg, const float* __restrict__ bias, const char* pimg, int mo, int lane, u32x4 (&af)[2][3]) {
-    constexpr int MT = H / 32, RB = 2 * H, PS = 32 * RB;
-    const int c = lane & 31, h = lane >> 5, rowb = c * RB, gsw = wimg_g<H>(c);
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (BIAS) b = *reinterpret_cast<const f32x4*>(bias + 32 * mo + 8 * q + 4 * h);
-        acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
-    }
-    const u32x4* base = wimg + ((size_t)mo * MT * 6) * 64 + lane;
-#pragma unroll 1
-    for (int mi = 0; mi < MT; ++mi) {
-        const u32x4* nextp = base + (size_t)((mi + 1 < MT ? mi + 1 : mi) * 6) * 64;   // the last iteration re-reads its own fragments (in bounds, unused)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int a = rowb + (((4 * mi + 2 * s + h) ^ gsw) << 4);
-            bf16x8 B[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) B[p] = *reinterpret_cast<const bf16x8*>(pimg + p * PS + a);
-            acc = mfma_split6(__builtin_bit_cast(bf16x8, af[s][0]), __builtin_bit_cast(bf16x8, af[s][1]), __builtin_bit_cast(bf16x8, af[s][2]), B[0], B[1], B[2], acc);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) af[s][p] = nextp[(size_t)(s * 3 + p) * 64];
-        }
-    }
-    return acc;
-}
-
-template <int KIND, int H, int O, int HEAD>
-__device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* smem) {
-    constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
-    constexpr bool REC = true;
-    using L = NetLdsSmall<D, H, O>;
-    using SC = WideSplitScratch<D, H, O>;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // this wave's m-tile
-    const int c = lane & 31, h = lane >> 5;
-    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
-    const u32x4* w2p = HEAD == HEAD_VALUE ? a.w2p_critic : a.w2p_actor;
-    const u32x4* w2tp = HEAD == HEAD_VALUE ? a.w2tp_critic : a.w2tp_actor;
-    float* wl = smem;
-    char* P1 = reinterpret_cast<char*>(smem + SC::P1); char* P2 = reinterpret_cast<char*>(smem + SC::P2);
-    float* TB = smem + SC::TB; float* XI = smem + SC::XI; float* ZI = smem + SC::ZI + w * O * kTS; float* PO = smem + SC::PO;
-    stage_net_small<D, H, O>(wl, a.params, off, tid, blockDim.x);
-    for (int i = tid; i < (D + 2) * kTS; i += blockDim.x) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
-    __syncthreads();
-
-    float adv_mean = 0.f, adv_den = 1.f;
-    if (HEAD != HEAD_VALUE && a.normalize_adv) {
-        const double s = a.adv_stats[0], q = a.adv_stats[1], n = a.adv_stats[2];
-        const double mean = s / n;
-        double var = (q - s * mean) / (n - 1.0);
-        if (var < 0) var = 0;
-        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
-    }
-    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
-    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
-    float lsr[kLsMax];
-#pragma unroll
-    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
-    if (HEAD == HEAD_GAUSSIAN) {
-#pragma unroll
-        for (int o = 0; o < O; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
-    }
-    const float* ls = lsr;
-    const int tbase = wide_tr_base<H>(lane);
-
-    f32x16 dW2[MT];                                                  // rows 32w.., all H columns
-    f32x4 dW1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    float dW3a[O], db2p = 0.f, db3p[O], dlsp[O], st[5];
-#pragma unroll
-    for (int j = 0; j < MT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dW2[j][r] = 0.f;
-#pragma unroll
-    for (int o = 0; o < O; ++o) { dW3a[o] = 0.f; db3p[o] = 0.f; dlsp[o] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) st[i] = 0.f;
-
-    const int g = a.layout ? (int)(blockIdx.x % a.G) : (int)(blockIdx.x >> 1);
-    const int64_t ntiles = (a.count + kTile - 1) / kTile;
-    TileIn<O> cur, nxt;
-    int64_t tile = g;
-    if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
-#ifdef DRIL_STAMPS
-    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
-#endif
-    for (; tile < ntiles; tile += a.G) {
-        unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
-        const bool valid = cur.valid;
-        const float xk[2] = {cur.xk[0], cur.xk[1]};
-        // ---- h1 tile w; its pieces into the workgroup image ----
-        f32x16 h1w;
-        {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B1 + 32 * w + 8 * q + 4 * h);
-                h1w[4 * q + 0] = b[0]; h1w[4 * q + 1] = b[1]; h1w[4 * q + 2] = b[2]; h1w[4 * q + 3] = b[3];
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
-            tanh16(h1w);
-        }
-        // `opaque(lane)`: the image addresses are lane constants, and hoisted out of the tile loop as loop invariants they hold ~60 registers for the whole kernel (they cost 2-3 VALU to rebuild)
-        store_tile_pieces<H>(P1, w, h1w, opaque(lane));
-        if (w == 0) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
-        }
-        STAMP(0);
-        u32x4 afw[2][3];
-        wide_split_preload(w2p, MT, w, lane, afw);                                    // first W2 fragments in flight across the barrier
-        __syncthreads();                                                              // B1: P1, XI complete
-        STAMP(1);
-        load_tile<KIND, O, HEAD, REC>(a, tile + a.G, ntiles, c, h, nxt);              // after the barrier (see ppo_grad_wide_kernel)
-        // ---- h2 tile w ----
-        f32x16 h2w = dense_tile_split<H, true>(w2p, wl + L::B2, P1, w, opaque(lane), afw);
-        tanh16(h2w);
-        STAMP(2);
-        // ---- output layer: partial over this wave's rows, summed across waves through LDS ----
-        float out[O], dz[O];
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            float p = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
-                p = fmaf(wv[0], h2w[4 * q + 0], p); p = fmaf(wv[1], h2w[4 * q + 1], p);
-                p = fmaf(wv[2], h2w[4 * q + 2], p); p = fmaf(wv[3], h2w[4 * q + 3], p);
-            }
-            p += __shfl_xor(p, 32);
-            if (h == 0) PO[(w * O + o) * 32 + c] = p;
-        }
-        store_image_tile(TB, w, h2w, lane);                                            // h2' (own rows; only this wave reads them)
-        __syncthreads();                                                              // B2: PO complete
-        STAMP(3);
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            float v = wl[L::B3 + o];
-#pragma unroll
-            for (int ww = 0; ww < MT; ++ww) v += PO[(ww * O + o) * 32 + c];            // fixed order: every wave gets the same bits
-            out[o] = v;
-        }
-        loss_head<O, HEAD>(a, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
-        // ---- dW3 (own rows) ----
-#pragma unroll
-        for (int o = 0; o < O; ++o) { if (h == 0) { if (w == 0) db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
-        {
-            const f32x16 Bh2 = load_operand(TB, w, lane);
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                float acc = 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 z = *reinterpret_cast<const f32x4*>(ZI + o * kTS + 16 * h + 4 * q);
-                    acc = fmaf(Bh2[4 * q + 0], z[0], acc); acc = fmaf(Bh2[4 * q + 1], z[1], acc);
-                    acc = fmaf(Bh2[4 * q + 2], z[2], acc); acc = fmaf(Bh2[4 * q + 3], z[3], acc);
-                }
-                dW3a[o] += acc;
-            }
-        }
-        // ---- dz2 tile w (in h2w's registers); its pieces into the workgroup image; the f32 transposed copy (own rows) gives db2 ----
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float dh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(wv[cc], dz[o], dh[cc]);
-            }
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
-        }
-        store_tile_pieces<H>(P2, w, h2w, opaque(lane));
-        store_image_tile(TB, w, h2w, lane);                                            // dz2' (after the Bh2 read: same wave, LDS in order)
-        wide_split_preload(w2tp, MT, w, lane, afw);                                   // first W2' fragments in flight across the barrier
-        STAMP(4);
-        __syncthreads();                                                              // B3: P2 complete
-        STAMP(5);
-        // ---- dh1 tile w = W2' dz2 ; dz1 ----
-        f32x16 g1 = dense_tile_split<H, false>(w2tp, nullptr, P2, w, opaque(lane), afw);
-        {
-            f32x16 h1r;
-            load_tile_pieces<H>(P1, w, h1r, opaque(lane));                                     // h1 tile w rebuilt from its own pieces (hi + mid + lo is exact): 16 registers less across both MFMA chains
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g1[r] = g1[r] * (1.0f - h1r[r] * h1r[r]);
-        }
-        STAMP(6);
-        // ---- db2 from the f32 transposed copy; then dW1 | db1 (own rows) BEFORE dW2, so that dz1 is dead while the 128 accumulators are being updated ----
-        {
-            const f32x16 Az32 = load_operand(TB, w, lane);
-            db2p += sum16(Az32);
-        }
-        store_image_tile(TB, w, g1, lane);
-        {
-            const int j = lane & 15;
-            float bx[8];
-            load_row8(XI, j <= D ? j : D + 1, lane, bx);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float az[8];
-                load_row8(TB, 32 * w + 16 * t + j, lane, az);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) dW1[t] = mfma16(az[k], bx[k], dW1[t]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        STAMP(7);
-        // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the piece images) ----
-        {
-            const int tb = opaque(tbase);
-            bf16x8 Az[2][3];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<H>(P2, tb, p, w, s);
-#pragma unroll
-            for (int mj = 0; mj < MT; ++mj) {
-                bf16x8 Bh[2][3];
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<H>(P1, tb, p, mj, s);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split6(Az[s][0], Az[s][1], Az[s][2], Bh[s][0], Bh[s][1], Bh[s][2], dW2[mj]);
-                __builtin_amdgcn_sched_barrier(0);                                    // keep the next m-tile's fragment requests behind these MFMAs (hoisted, they spill)
-            }
-        }
-        __syncthreads();                                                              // B4: P1 / P2 / PO / XI free for the next tile
-        STAMP(8);
-        cur = nxt;
-    }
-#ifdef DRIL_STAMPS
-    if (lane == 0 && a.dbg) {
-        unsigned long long* o_ = a.dbg + ((size_t)(blockIdx.x % (2 * a.G)) * 4 + (w & 3)) * 12;
-        if (w < 4) { for (int k = 0; k < 10; ++k) o_[k] = stamp_acc[k]; o_[10] = (unsigned long long)((ntiles - g + a.G - 1) / a.G); o_[11] = HEAD; }
-    }
-#endif
-
-    // ---- epilogue: every wave owns distinct gradient rows -> straight to the workgroup's slab ----
-    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
-    const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
-    const int o_ls = o_b3 + O, o_st = SL - 8;
-    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
-#pragma unroll
-    for (int mj = 0; mj < MT; ++mj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H] = dW2[mj][r];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 32 * w + 16 * t + 4 * (lane >> 4) + r, col = lane & 15;
-            if (col < D) slab[o_w1 + row + col * H] = dW1[t][r];
-            else if (col == D) slab[o_b1 + row] = dW1[t][r];
-        }
-    { const float b2 = db2p + __shfl_xor(db2p, 32); if (h == 0) slab[o_b2 + 32 * w + c] = b2; }
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-        const float v = dW3a[o] + __shfl_xor(dW3a[o], 32);
-        if (h == 0) slab[o_w3 + o + (32 * w + c) * O] = v;
-        const float b3 = half_sum(db3p[o]);
-        if (w == 0 && lane == 0) slab[o_b3 + o] = b3;
-        if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (w == 0 && lane == 0) slab[o_ls + o] = l; }
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (w == 0 && lane == 0) slab[o_st + k] = v; }
-    if (w == 0 && lane < 3) slab[o_st + 5 + lane] = 0.f;
-    for (int i = (HEAD == HEAD_GAUSSIAN ? o_ls + O : o_ls) + tid; i < o_st; i += blockDim.x) slab[i] = 0.f;   // padding
-}
-
-template <int KIND, int H>
-__global__ __launch_bounds__(H * 2, 2) void ppo_grad_wide_split_kernel(GradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (*a.stop_flag) return;
-    constexpr int A = EnvSpec<KIND>::A;
-    const bool actor = a.layout ? (blockIdx.x < (unsigned)a.G) : ((blockIdx.x & 1) == 0);
-    if (actor) grad_body_wide_split<KIND, H, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN>(a, smem);
-    else grad_body_wide_split<KIND, H, 1, HEAD_VALUE>(a, smem);
-}
-
-// =============================================================================================
-// ppo_grad_pair_kernel — hidden [64,64], large minibatches: TWO waves own one 32-sample tile (wave p the m-tile p of every layer and the 32 x 64 slice p of dW2: the
-// decomposition of ppo_grad_wide_split_kernel at MT = 2), two pairs per workgroup, two workgroups per CU = TWO waves per SIMD at <= 256 registers.  That is the one
-// arrangement in which the matrix pipe and the VALU run beside each other on this part (profiles/r02_split_kernel.md: a lone wave's VALU work does not run under its own
-// MFMAs; a second wave's does, completely).  Same arithmetic as ppo_grad_split_kernel (bf16 matrix cores, fp32-equivalent 3-piece operand splitting).
-//   * W2 lives in LDS once per workgroup as three bf16 pieces in the piece-image layout of the wide split kernel (128-byte rows, 16-byte chunk ch of row r at ch ^ f(r)):
-//     row reads (ds_read_b128) give the A operand of L2, ds_read_b64_tr_b16 the A operand of dh1 (W2'); pre-scaled by kTanhScale, dh1 folds 1 / kTanhScale into its mask.
-//   * each pair has two 12 KB piece images (h1, dz2): every wave writes its own 32 columns once; row reads give the B operand of L2 / dh1 (both m-tiles), transposed
-//     reads both operands of dW2.
-//   * no f32 image at all: dW3, db2, dW1 and db1 are per-lane accumulations (the lane is the sample), reduced over the 32 lanes of a half once, in the epilogue.
-//   * four workgroup barriers per tile; both pairs of a workgroup run the same number of tiles (the second pair's last tile may be an all-invalid one).
-// Every wave owns distinct rows of every gradient: one slab per PAIR, written straight from registers.  a.G / a.Gc = pairs of the actor / the critic (even);
-// grid = (a.G + a.Gc) / 2 workgroups, the first a.G / 2 run the actor.
-// =============================================================================================
-template <int D, int O> struct PairLds {
-    static constexpr int H = 64, DP = 4, OP = (O + 3) / 4 * 4;
-    static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, SMALL_END = (B3 + OP + 3) / 4 * 4;
-    static constexpr int WIMG = SMALL_END;                    // three pieces x [64 out][64 in] bf16 = 3 x 8192 bytes
-    static constexpr int PAIR0 = WIMG + 3 * 2048;
-    static constexpr int P1 = 0, P2 = P1 + 3 * 1024, PO = P2 + 3 * 1024, PAIR_SIZE = (PO + 2 * O * 32 + 3) / 4 * 4;   // per pair: two 12 KB piece images, [2 waves][O][32] partial sums
-    static constexpr int END = PAIR0 + 2 * PAIR_SIZE;
-};
-// A operand of dh1 = W2': lane (in-unit 32mk + (lane & 31), half kh) gets out-units 32mi + 16s + 8kh + j of the weight image (64 rows, piece stride 8192); tbase = wide_tr_base<64>
-__device__ __forceinline__ bf16x8 load_frag_W_T(const char* wimg, int tbase, int piece, int mk, int mi, int s) {
-    const int a = (tbase ^ (64 * mk)) + (32 * mi + 16 * s) * 128 + piece * 8192;
-    return frag8(lds_read_tr16(wimg, a), lds_read_tr16(wimg, (a ^ 16) + 4 * 128));
-}
-
-template <int KIND, int O, int HEAD>
-__device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
-    constexpr int D = EnvSpec<KIND>::D, H = 64, MT = 2;
-    constexpr bool REC = true, kKeepH1 = HEAD == HEAD_VALUE;
-    constexpr float kInvTanhScale = 1.0f / kTanhScale;
-    using L = PairLds<D, O>;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wave & 1, pr = wave >> 1;                                           // this wave's m-tile; this wave's pair
-    const int c = lane & 31, h = lane >> 5;
-    const NetOff off = HEAD == HEAD_VALUE ? a.critic : a.actor;
-    float* wl = smem;
-    char* Wimg = reinterpret_cast<char*>(smem + L::WIMG);
-    float* pb = smem + L::PAIR0 + pr * L::PAIR_SIZE;
-    char* P1 = reinterpret_cast<char*>(pb + L::P1); char* P2 = reinterpret_cast<char*>(pb + L::P2); float* PO = pb + L::PO;
-    {   // stage the small parts (as stage_net_split) and the W2 piece image
-        const float* __restrict__ P = a.params;
-        for (int i = tid; i < L::DP * H; i += blockDim.x) { const int o = i % H, k = i / H; wl[L::W1T + k * H + o] = k < D ? kTanhScale * P[off.w1 + o + k * H] : 0.0f; }
-        for (int i = tid; i < H; i += blockDim.x) { wl[L::B1 + i] = kTanhScale * P[off.b1 + i]; wl[L::B2 + i] = kTanhScale * P[off.b2 + i]; }
-        for (int i = tid; i < O * H; i += blockDim.x) { const int o = i % O, k = i / O; wl[L::W3S + o * H + k] = P[off.w3 + i]; }
-        for (int i = tid; i < L::OP; i += blockDim.x) wl[L::B3 + i] = i < O ? P[off.b3 + i] : 0.0f;
-        for (int i = tid; i < H * H / 2; i += blockDim.x) {       // pair (k, k+1) of row o: W2 is column-major (out x in), consecutive threads read consecutive o
-            const int o = i % H, kp = i / H;
-            unsigned hi, mid, lo;
-            split3_pair(kTanhScale * P[off.w2 + o + H * (2 * kp)], kTanhScale * P[off.w2 + o + H * (2 * kp + 1)], hi, mid, lo);
-            const int byte = o * 128 + ((((kp >> 2) ^ wimg_g<64>(o)) & 7) << 4) + ((kp & 3) << 2);
-            *reinterpret_cast<unsigned*>(Wimg + byte) = hi; *reinterpret_cast<unsigned*>(Wimg + 8192 + byte) = mid; *reinterpret_cast<unsigned*>(Wimg + 16384 + byte) = lo;
-        }
-    }
-    __syncthreads();
-
-    float adv_mean = 0.f, adv_den = 1.f;
-    if (HEAD != HEAD_VALUE && a.normalize_adv) {
-        const double s = a.adv_stats[0], q = a.adv_stats[1], n = a.adv_stats[2];
-        const double mean = s / n;
-        double var = (q - s * mean) / (n - 1.0);
-        if (var < 0) var = 0;
-        adv_mean = (float)mean; adv_den = (float)sqrt(var) + 1.0e-8f;
-    }
-    adv_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, adv_mean)));
-    const float adv_inv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / adv_den)));
-    float lsr[kLsMax];
-#pragma unroll
-    for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
-    if (HEAD == HEAD_GAUSSIAN) {
-#pragma unroll
-        for (int o = 0; o < O; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
-    }
-    const float* ls = lsr;
-    const int tbase = wide_tr_base<64>(lane);
-
-    f32x16 dW2[MT], dW3acc[O], db2acc, dW1acc[D], db1acc;            // dW2: rows 32w.., all 64 columns; the others: per-lane sums over this lane's samples (units rowfn(r, h) of m-tile w)
-    float db3p[O], dlsp[O], st[5];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { db2acc[r] = 0.f; db1acc[r] = 0.f; }
-#pragma unroll
-    for (int j = 0; j < MT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dW2[j][r] = 0.f;
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dW1acc[d][r] = 0.f;
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-        db3p[o] = 0.f; dlsp[o] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dW3acc[o][r] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) st[i] = 0.f;
-
-    const int nb = HEAD == HEAD_VALUE ? (int)blockIdx.x - a.G / 2 : (int)blockIdx.x;  // workgroup within its net
-    const int GP = HEAD == HEAD_VALUE ? a.Gc : a.G;                                   // pairs of this net
-    const int g = 2 * nb + pr;                                                        // pair within its net = slab index
-    const int64_t ntiles = (a.count + kTile - 1) / kTile;
-    const int64_t g0 = 2 * nb;
-    const int64_t trips = g0 < ntiles ? (ntiles - g0 + GP - 1) / GP : 0;           // the same for both pairs of the workgroup (barriers inside the loop)
-    TileIn<O> cur, nxt;
-    int64_t tile = g;
-    load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);                        // a tile index past the end loads an all-invalid tile
-#ifdef DRIL_STAMPS
-    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
-#endif
-    for (int64_t it = 0; it < trips; ++it, tile += GP) {
-        unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
-        const bool valid = cur.valid;
-        const float xk[2] = {cur.xk[0], cur.xk[1]};
-        // ---- h1 tile w; its pieces into the pair's image ----
-        f32x16 h1k;                                                                   // kept across the tile where the registers allow it (the critic), rebuilt from the pieces elsewhere
-        {
-            f32x16 h1w;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B1 + 32 * w + 8 * q + 4 * h);
-                h1w[4 * q + 0] = b[0]; h1w[4 * q + 1] = b[1]; h1w[4 * q + 2] = b[2]; h1w[4 * q + 3] = b[3];
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
-            tanh16(h1w);
-            store_tile_pieces<64>(P1, w, h1w, opaque(lane));
-            if (kKeepH1) h1k = h1w;
-        }
-        STAMP(0);
-        __syncthreads();                                                              // B1: the pair's h1 image complete
-        STAMP(1);
-        load_tile<KIND, O, HEAD, REC>(a, tile + GP, ntiles, c, h, nxt);
-        // ---- h2 tile w = tanh(W2[rows of w] h1 + b2): A from the weight image, B from the pair's h1 image (both row reads with the same chunk index) ----
-        f32x16 h2w;
-        {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B2 + 32 * w + 8 * q + 4 * h);
-                h2w[4 * q + 0] = b[0]; h2w[4 * q + 1] = b[1]; h2w[4 * q + 2] = b[2]; h2w[4 * q + 3] = b[3];
-            }
-            const int lo_ = opaque(lane), cc = lo_ & 31, hh = lo_ >> 5, gsw = wimg_g<64>(cc);
-            const char* arow = Wimg + (32 * w + cc) * 128; const char* brow = P1 + cc * 128;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {                                          // ks = 2 mi + s
-                const int ch = ((2 * ks + hh) ^ gsw) << 4;
-                bf16x8 A[3], B[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) { A[p] = *reinterpret_cast<const bf16x8*>(arow + p * 8192 + ch); B[p] = *reinterpret_cast<const bf16x8*>(brow + p * 4096 + ch); }
-                h2w = mfma_split6(A[0], A[1], A[2], B[0], B[1], B[2], h2w);
-            }
-            tanh16(h2w);
-        }
-        STAMP(2);
-        // ---- output layer: partial over this wave's 32 units, summed across the pair through LDS ----
-        float out[O], dz[O];
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            float p = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
-                p = fmaf(wv[0], h2w[4 * q + 0], p); p = fmaf(wv[1], h2w[4 * q + 1], p);
-                p = fmaf(wv[2], h2w[4 * q + 2], p); p = fmaf(wv[3], h2w[4 * q + 3], p);
-            }
-            p += __shfl_xor(p, 32);
-            if (h == 0) PO[(w * O + o) * 32 + c] = p;
-        }
-        __syncthreads();                                                              // B2: both partial sums
-        STAMP(3);
-#pragma unroll
-        for (int o = 0; o < O; ++o) out[o] = (wl[L::B3 + o] + PO[o * 32 + c]) + PO[(O + o) * 32 + c];   // fixed order: both waves get the same bits
-        loss_head<O, HEAD>(a, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            if (h == 0 && w == 0) db3p[o] += dz[o];
-            dW3acc[o] += dz[o] * h2w;                                                  // dW3[o][unit] += dz[o][sample] h2[unit][sample]: the lane IS the sample
-        }
-        // ---- dz2 tile w (in h2w's registers); db2; its pieces into the pair's image ----
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float dh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int o = 0; o < O; ++o) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(wv[cc], dz[o], dh[cc]);
-            }
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * fmaf(-hv, hv, 1.0f); }
-        }
-        db2acc += h2w;
-        store_tile_pieces<64>(P2, w, h2w, opaque(lane));
-        STAMP(4);
-        __syncthreads();                                                              // B3: the pair's dz2 image complete
-        STAMP(5);
-        // ---- dz1 tile w = (W2'[rows of w] dz2) .* (1 - h1^2): A = transposed reads of the weight image, B = row reads of the dz2 image ----
-        f32x16 g1;
-        {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g1[r] = 0.f;
-            const int lo_ = opaque(lane), cc = lo_ & 31, hh = lo_ >> 5, gsw = wimg_g<64>(cc), tb = opaque(tbase);
-            const char* brow = P2 + cc * 128;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int ch = ((2 * ks + hh) ^ gsw) << 4;
-                bf16x8 A[3], B[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) { A[p] = load_frag_W_T(Wimg, tb, p, w, ks >> 1, ks & 1); B[p] = *reinterpret_cast<const bf16x8*>(brow + p * 4096 + ch); }
-                g1 = mfma_split6(A[0], A[1], A[2], B[0], B[1], B[2], g1);
-            }
-            f32x16 h1r;
-            if (kKeepH1) h1r = h1k; else load_tile_pieces<64>(P1, w, h1r, lo_);         // h1 tile w rebuilt from its own pieces (exact)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[r] = g1[r] * fmaf(-t2, kInvTanhScale, kInvTanhScale); }
-        }
-        STAMP(6);
-        // ---- dW1 | db1: per-lane accumulation, dW1[unit][d] += dz1[unit][sample] x[sample][d] ----
-        {
-            const float xo0 = __shfl_xor(xk[0], 32), xo1 = __shfl_xor(xk[1], 32);      // the other half holds x[2s + 1 - h]
-            const float x4[4] = {h ? xo0 : xk[0], h ? xk[0] : xo0, h ? xo1 : xk[1], h ? xk[1] : xo1};
-#pragma unroll
-            for (int d = 0; d < D; ++d) dW1acc[d] += x4[d] * g1;
-            db1acc += g1;
-        }
-        // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the pair's images) ----
-        {
-            const int tb = opaque(tbase);
-            bf16x8 Az[2][3];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<64>(P2, tb, p, w, s);
-#pragma unroll
-            for (int mj = 0; mj < MT; ++mj) {
-                bf16x8 Bh[2][3];
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<64>(P1, tb, p, mj, s);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split6(Az[s][0], Az[s][1], Az[s][2], Bh[s][0], Bh[s][1], Bh[s][2], dW2[mj]);
-            }
-        }
-        STAMP(7);
-        __syncthreads();                                                              // B4: the pair's images and partial sums free for the next tile
-        STAMP(8);
-        cur = nxt;
-    }
-#ifdef DRIL_STAMPS
-    if (lane == 0 && a.dbg) {
-        unsigned long long* o_ = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
-        for (int k = 0; k < 10; ++k) o_[k] = stamp_acc[k];
-        o_[10] = (unsigned long long)trips; o_[11] = HEAD;
-    }
-#endif
-
-    // ---- epilogue: every wave owns distinct gradient rows -> straight to the pair's slab ----
-    const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
-    const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
-    const int o_ls = o_b3 + O, o_st = SL - 8;
-    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
-#pragma unroll
-    for (int mj = 0; mj < MT; ++mj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H] = dW2[mj][r];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {                                                    // per-lane sums over samples -> sum over the 32 lanes of each half (the halves hold different units)
-        const int unit = 32 * w + rowfn(r, h);
-        const float b2 = half_sum(db2acc[r]), b1 = half_sum(db1acc[r]);
-        if (c == 0) { slab[o_b2 + unit] = b2; slab[o_b1 + unit] = b1; }
-#pragma unroll
-        for (int d = 0; d < D; ++d) { const float v = half_sum(dW1acc[d][r]); if (c == 0) slab[o_w1 + unit + d * H] = v; }
-#pragma unroll
-        for (int o = 0; o < O; ++o) { const float v = half_sum(dW3acc[o][r]); if (c == 0) slab[o_w3 + o + unit * O] = v; }
-    }
-#pragma unroll
-    for (int o = 0; o < O; ++o) {
-        const float b3 = half_sum(db3p[o]);
-        if (w == 0 && lane == 0) slab[o_b3 + o] = b3;
-        if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (w == 0 && lane == 0) slab[o_ls + o] = l; }
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (w == 0 && lane == 0) slab[o_st + k] = v; }
-    if (w == 0 && lane < 3) slab[o_st + 5 + lane] = 0.f;
-    for (int i = (HEAD == HEAD_GAUSSIAN ? o_ls + O : o_ls) + w * 64 + lane; i < o_st; i += 128) slab[i] = 0.f;   // padding
-}
-
-template <int KIND>
-__global__ __launch_bounds__(256, 2) void ppo_grad_pair_kernel(GradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (*a.stop_flag) return;
-    constexpr int A = EnvSpec<KIND>::A;
-    const bool actor = blockIdx.x < (unsigned)(a.G / 2);
-    if (actor) grad_body_pair<KIND, A, EnvSpec<KIND>::discrete ? HEAD_CATEGORICAL : HEAD_GAUSSIAN>(a, smem);
-    else grad_body_pair<KIND, 1, HEAD_VALUE>(a, smem);
 }
 
 // =============================================================================================
@@ -2912,13 +1009,6 @@ __global__ void explained_var_kernel(const float* val, const float* ret, int64_t
 template <int KIND, int H, bool WIDE> static size_t fwd_lds_bytes() {
     return sizeof(float) * (FwdLds<EnvSpec<KIND>::D, H, EnvSpec<KIND>::A, WIDE>::SIZE + FwdLds<EnvSpec<KIND>::D, H, 1, WIDE>::SIZE);
 }
-template <int KIND, int H> static size_t grad_lds_bytes() {
-    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
-    constexpr int wa = NetLds<D, H, H, A>::BWD_END + 4 * GradScratch<D, H, A>::SIZE;
-    constexpr int wc = NetLds<D, H, H, 1>::BWD_END + 4 * GradScratch<D, H, 1>::SIZE;
-    return sizeof(float) * (wa > wc ? wa : wc);
-}
-
 // kind 2 (ScalingWrapperEnv(Pendulum)) shares every kernel that never touches the simulator with kind 1
 #define DRIL_DISPATCH(kind, hidden, CALL)                                            \
     do {                                                                             \
@@ -3089,96 +1179,11 @@ hipError_t launch_moments_finalize(const double* partials, int nblocks, double* 
     return hipGetLastError();
 }
 
-template <int KIND, int H> static size_t grad_split_lds_bytes() {
-    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A, N = 4;
-    constexpr int wa = NetLdsSplit<D, H, A>::END + N * GradScratchSplit<D, H, A>::SIZE;
-    constexpr int wc = NetLdsSplit<D, H, 1>::END + N * GradScratchSplit<D, H, 1>::SIZE;
-    return sizeof(float) * (wa > wc ? wa : wc);
-}
-template <int KIND, int H> static size_t grad_wide_lds_bytes() {
-    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
-    constexpr int wa = WideScratch<D, H, A>::SIZE, wc = WideScratch<D, H, 1>::SIZE;
-    return sizeof(float) * (wa > wc ? wa : wc);
-}
-template <int KIND> static size_t grad_pair_lds_bytes() {
-    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
-    constexpr int wa = PairLds<D, A>::END, wc = PairLds<D, 1>::END;
-    return sizeof(float) * (wa > wc ? wa : wc);
-}
-template <int KIND, int H> static size_t grad_wide_split_lds_bytes() {
-    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
-    constexpr int wa = WideSplitScratch<D, H, A>::SIZE, wc = WideSplitScratch<D, H, 1>::SIZE;
-    return sizeof(float) * (wa > wc ? wa : wc);
-}
+// the update kernels live in their own translation units (dril_grad_f32.hip, dril_grad_pair.hip, dril_grad_wide.hip)
 hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t s) {
-#define CALLR(K, HH, R)                                                                                       \
-    {                                                                                                         \
-        const size_t lds = grad_lds_bytes<K, HH>();                                                           \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<K, HH, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e; attr_set = true; }                                                 \
-        ppo_grad_kernel<K, HH, R><<<2 * a.G, 256, lds, s>>>(a);                                               \
-    }
-#define CALLW(K, HH, R)                                                                                       \
-    {                                                                                                         \
-        const size_t lds = grad_wide_lds_bytes<K, HH>();                                                      \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wide_kernel<K, HH, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e; attr_set = true; }                                                 \
-        ppo_grad_wide_kernel<K, HH, R><<<2 * a.G, HH * 2, lds, s>>>(a);                                       \
-    }
-    if (hidden == 64 && a.variant == 2 && a.rec) {   // two waves per tile, two waves per SIMD
-#define CALLP(K) { const size_t lds = grad_pair_lds_bytes<K>(); static bool attr_set = false; \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_pair_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
-        ppo_grad_pair_kernel<K><<<(a.G + a.Gc) / 2, 256, lds, s>>>(a); }
-        if (kind == 0) CALLP(0) else if (kind == 3) CALLP(3) else if (kind == 4) CALLP(4) else CALLP(1)
-#undef CALLP
-        return hipGetLastError();
-    }
-    if (hidden > 64 && a.variant && a.rec) {      // wide nets on the bf16 matrix cores
-#define CALLWS(K, HH)                                                                                         \
-    {                                                                                                         \
-        const size_t lds = grad_wide_split_lds_bytes<K, HH>();                                                \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wide_split_kernel<K, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e; attr_set = true; }                                                 \
-        ppo_grad_wide_split_kernel<K, HH><<<2 * a.G, HH * 2, lds, s>>>(a);                                    \
-    }
-#define CALLWSH(K) { if (hidden == 256) CALLWS(K, 256) else if (hidden == 128) CALLWS(K, 128) else return hipErrorInvalidValue; }
-        if (kind == 0) CALLWSH(0) else if (kind == 3) CALLWSH(3) else if (kind == 4) CALLWSH(4) else CALLWSH(1)
-#undef CALLWSH
-#undef CALLWS
-        return hipGetLastError();
-    }
-    if (hidden > 64) {
-#define CALLWK(K, HH) { if (a.rec) CALLW(K, HH, true) else CALLW(K, HH, false) }
-#define CALLWH(K) { if (hidden == 256) CALLWK(K, 256) else if (hidden == 128) CALLWK(K, 128) else return hipErrorInvalidValue; }
-        if (kind == 0) CALLWH(0) else if (kind == 3) CALLWH(3) else if (kind == 4) CALLWH(4) else CALLWH(1)
-#undef CALLWH
-#undef CALLWK
-        return hipGetLastError();
-    }
-    if (a.variant && hidden == 64) {              // bf16 matrix cores, fp32-equivalent operand splitting
-#define CALLS(K, R)                                                                                           \
-    {                                                                                                         \
-        const size_t lds = grad_split_lds_bytes<K, 64>();                                                     \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_split_kernel<K, 64, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e; attr_set = true; }                                                 \
-        ppo_grad_split_kernel<K, 64, R><<<a.G + a.Gc, 256, lds, s>>>(a);                                         \
-    }
-#define CALLSK(K) { if (a.rec) CALLS(K, true) else CALLS(K, false) }
-        if (kind == 0) CALLSK(0) else if (kind == 3) CALLSK(3) else if (kind == 4) CALLSK(4) else CALLSK(1)
-#undef CALLSK
-#undef CALLS
-        return hipGetLastError();
-    }
-#define CALL(K, HH) { if (a.rec) CALLR(K, HH, true) else CALLR(K, HH, false) }
-    DRIL_DISPATCH(kind, hidden, CALL);
-#undef CALL
-#undef CALLR
-#undef CALLW
-    return hipGetLastError();
+    if (hidden > 64) return launch_ppo_grad_wide(kind, hidden, a, s);
+    if (hidden == 64 && a.variant == 2 && a.rec) return launch_ppo_grad_pair(kind, a, s);   // two waves per tile, two waves per SIMD
+    return launch_ppo_grad_f32(kind, hidden, a, s);
 }
 
 hipError_t launch_pack_records(int kind, int64_t N, const float* obs, const void* act, const float* adv, const float* logp, const float* ret, float4* rec, hipStream_t s) {
