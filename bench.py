@@ -37,7 +37,18 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16,
 # an fp32-equivalent contraction on the bf16 matrix cores is SIX bf16 MFMAs per product (3-piece operand split): its own ceiling in
 # delivered-f32 flops.  Reported beside `peak` (which stays the f32-MFMA figure the judge prices against) as roofline.split_ceiling.
 PEAK_BF16_SPLIT6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6
-PMC_FILE = "r02_ppo_grad_pmc.json"  # HBM traffic (PMC) + rocprofv3 average of the dominant kernel on configs[1], with the commit it was taken at
+PMC_FILE = "r03_ppo_grad_pmc.json"  # HBM traffic (PMC) + rocprofv3 average of the dominant kernel on configs[1], with the commit it was taken at
+
+
+def mfma_roofline(ach_tflops: float, arith: str) -> dict:
+    """peak / frac of a dense-contraction kernel.  A kernel that computes its fp32-equivalent products as SIX bf16 MFMAs (3-piece operand split) is priced against
+    ITS pipe: dense bf16 peak / 6 = 419.4 TFLOP/s of delivered f32 flops; the figure against the f32-MFMA peak (157.3, the pipe the exact-f32 kernels run on and the
+    roof SURVEY.md section 8d names) is kept beside it as frac_vs_f32_peak — it may exceed 1 and is never `frac`."""
+    split = "bf16x3" in arith
+    peak = PEAK_BF16_SPLIT6_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    return {"bound": "mfma", "achieved": ach_tflops, "peak": peak, "unit": "TFLOP/s", "frac": ach_tflops / peak,
+            "peak_note": ("dense bf16 MFMA peak 2516.6 / 6 MFMAs per fp32-equivalent product" if split else "dense f32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+            "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "frac_vs_f32_peak": ach_tflops / PEAK_F32_MFMA_TFLOPS, "arithmetic": arith}
 
 
 def cpu_baseline(pkg, seed: int) -> dict:
@@ -77,40 +88,37 @@ def sac_flops(D: int, A: int, H: int, B: int, E: int) -> tuple:
     return upd, E * fa
 
 
-def main_sac(args) -> None:
+def run_sac(pkg, *, steps: int, warmup: int, iters: int, E: int = 4096, H: int = 512, events: bool = True, cpu: bool = True) -> dict:
     """BASELINE.json configs[4]: SAC on Pendulum-v1, n_envs = 4096, SACLayer [512,512] relu, SAC() defaults (batch 256, train_freq 1,
-    gradient_steps 1).  One bench "step" = --sac-iters iterations of train!'s loop body (sac.jl:464-535): collect one env step over all
+    gradient_steps 1).  One bench "step" = `iters` iterations of train!'s loop body (sac.jl:464-535): collect one env step over all
     envs into the device replay ring, then one update!.  Single GPU (the path has one learner; N > 1 would be replicas)."""
-    pkg = g.load_package()
-    pkg._capi.load_library()
-    E, H, B = args.n_envs if args.n_envs != 65536 else 4096, args.hidden if args.hidden != 64 else 512, 256
+    B = 256
     env = pkg.PendulumEnv(max_steps=200)
     alg = pkg.SAC(batch_size=B, buffer_capacity=1_000_000)
     layer = pkg.SACLayer(env.observation_space(), env.action_space(), hidden_dims=(H, H))
-    cfg = pkg.make_sac_config(env, E, alg, layer, seed=42, profile_events=not args.no_events)
+    cfg = pkg.make_sac_config(env, E, alg, layer, seed=42, profile_events=events)
     h = pkg.SacHandle(cfg)
     flat = pkg.sac_flatten_params(layer.initialparameters(np.random.default_rng(42)))
     h.set_params(flat); h.env_reset(42)
     h.collect_rollout(max(1, alg.start_steps // E), True)          # train!'s first, random-action collection (sac.jl:436-440)
-    iters = args.sac_iters
 
     # the loop body of train! without its per-iteration host bookkeeping: collect 1 step, 1 update (both enqueue-only until their sync)
     def iteration():
         h.collect_rollout(alg.train_freq, False)
         h.update(pkg.get_gradient_steps(alg, alg.train_freq, E))
 
-    for _ in range(args.warmup * iters):
+    for _ in range(warmup * iters):
         iteration()
     h.profile_reset()
     t0 = time.perf_counter()
-    for _ in range(args.steps * iters):
+    for _ in range(steps * iters):
         iteration()
     dt = time.perf_counter() - t0
     prof = h.profile()
-    n_it = args.steps * iters
+    n_it = steps * iters
     f_upd, f_col = sac_flops(3, 1, H, B, E)
     out = {"metric": "env-steps/s (SAC collect + update!) at n_envs=4096", "value": E * n_it / dt, "unit": "env-steps/s", "n_gpus": 1,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+           "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"Pendulum-v1 configs[4]: SAC, device-resident envs + replay ring, SACLayer hidden_dims=[{H},{H}] relu, batch {B}, "
                                   f"train_freq 1, gradient_steps 1; one step = {iters} iterations of (1 env step x {E} envs, 1 update!)",
@@ -118,10 +126,10 @@ def main_sac(args) -> None:
     if prof["updates"]:
         u_ms, c_ms = prof["update_ms"] / prof["updates"], prof["collect_ms"] / max(1, prof["collect_steps"])
         ach = (f_upd + f_col) / ((u_ms + c_ms) * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                           "kernel": "sac_gemm_kernel (all launches of one iteration; HIP events around update! and around the collection step)",
-                           "update_ms": u_ms, "collect_step_ms": c_ms, "flops_per_update": f_upd, "flops_per_collect_step": f_col}
-    if not args.no_cpu_baseline:
+        out["roofline"] = dict(mfma_roofline(ach, "f32 (v_mfma_f32_32x32x2_f32)"), traffic=None,
+                               kernel="sac_gemm_kernel (all launches of one iteration; HIP events around update! and around the collection step)",
+                               update_ms=u_ms, collect_step_ms=c_ms, flops_per_update=f_upd, flops_per_collect_step=f_col)
+    if cpu:
         sys.path.insert(0, str(ROOT / "tests"))
         import oracle_lib
         ccfg = pkg.make_sac_config(env, E, pkg.SAC(batch_size=B, buffer_capacity=200_000), layer, seed=42)
@@ -134,8 +142,105 @@ def main_sac(args) -> None:
         dtc = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": E * n / dtc, "unit": "env-steps/s", "cores": int(oracle_lib.lib().orc_num_threads()), "kind": "port",
                                "sample": f"C/OpenMP oracle: {n} iterations of (1 env step x {E} envs, 1 update! at batch {B}) in {dtc:.2f}s"}
-    print(json.dumps(out), flush=True)
     h.close()
+    return out
+
+
+def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int, epochs: int, normalize: bool, steps: int, warmup: int, events: bool = True,
+            batch_size: int | None = None, fixed_length: bool = True, label: str = "", rank: int = 0, local_rank: int = 0, world: int = 1, dist=None) -> dict | None:
+    """one PPO workload: `warmup` untimed iterations, then exactly `steps` iterations (rollout + GAE + epochs x minibatches update) between a barrier +
+    stream synchronisation on both sides, max over ranks; returns the result dict on rank 0."""
+    N_local = E * T
+    B_global = batch_size if batch_size else (N_local // minibatches) * world
+    env = pkg.CartPoleEnv(max_steps=500) if env_name == "cartpole" else pkg.PendulumEnv(max_steps=200)
+    alg = pkg.PPO(n_steps=T, batch_size=B_global, epochs=epochs)
+    layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(hidden, hidden))
+    cfg = pkg.make_config(env, E, alg, layer, seed=42, fixed_length_episodes=fixed_length, device=local_rank, rank=rank, world_size=world,
+                          profile_events=events, normalize={} if normalize else None)
+    h = pkg.Handle(cfg)
+    h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(42))))   # random-init weights of the named architecture
+    if world > 1:
+        uid = [h.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        h.comm_init(uid[0])
+    h.env_reset(42)
+
+    def iteration():
+        h.set_learning_rate(alg.learning_rate)
+        h.lib.dril_collect_rollout(h._h, None)      # no fps query: keeps the iteration free of host syncs until the update's end
+        return h.ppo_update()
+
+    for _ in range(warmup):
+        iteration()
+    h.synchronize(); h.profile_reset()
+    if dist: dist.barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = iteration()
+    h.synchronize()
+    if dist: dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    prof = h.profile()
+    out = None
+    if rank == 0:
+        total_env_steps = N_local * world * steps
+        value = total_env_steps / dt
+        out = {
+            "metric": f"env-steps/s (rollout+PPO update) at n_envs={E}", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (label or (("CartPole-v1 configs[1]" if env_name == "cartpole" else "Pendulum-v1 configs[2]" + (" + NormalizeWrapperEnv" if normalize else ""))))
+                                   + f": device-resident envs, ActorCritic hidden_dims=[{hidden},{hidden}], PPO rollout + update",
+                       "n_envs_per_gpu": E, "n_steps": T, "epochs": epochs, "batch_size": B_global,
+                       "optimizer_steps_per_iteration": epochs * (-(-N_local * world // B_global)),
+                       "episodes": f"fixed length {env.max_steps} (termination disabled)" if fixed_length else f"real episodes (time limit {env.max_steps})",
+                       "parallelism": f"dp{world} (env shards)"},
+            "loss_last": last.loss, "n_updates_last": last.n_updates,
+            # what the communicator itself reports (ncclCommCount), not the launcher's WORLD_SIZE; 1 = no communicator (single GPU)
+            "rccl_ranks": h.comm_ranks(), "allreduce_calls": h.comm_allreduce_calls(),
+            "value_per_gpu": value / world,      # N = 1-equivalent figure, to be read against the N = 1 BENCH line
+        }
+        gk = prof.get("ppo_grad_kernel", {"total_ms": 0, "launches": 0})
+        if gk["launches"]:
+            # dominant kernel: the gradient kernel. ALGORITHMIC flops per launch = B_local samples x 3 x forward flops (fwd + bwd of both MLPs,
+            # SURVEY.md §8 a16: 53 376 at [64,64]); duration = HIP events on the library's stream around each launch in the timed region.
+            avg_ms = gk["total_ms"] / gk["launches"]
+            flops = (B_global // world) * 3 * flop_fwd(h.D, hidden, h.A)
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            # traffic and the rocprofv3 average are NOT measured in this run (PMC needs its own rocprofv3 passes): they are replayed from the
+            # committed profile of exactly this workload, and the line says so (traffic_source: file + the commit the profile was taken at)
+            traffic = traffic_source = rocprof_ms = None
+            pmc = ROOT / "profiles" / PMC_FILE
+            if pmc.exists() and env_name == "cartpole" and hidden == 64 and minibatches == 32 and E == 65536 and T == 2048 and not batch_size:
+                rec = json.loads(pmc.read_text())
+                traffic, rocprof_ms = rec.get("hbm_bytes_per_launch"), rec.get("rocprof_avg_launch_ms")
+                traffic_source = f"replayed from profiles/{PMC_FILE} (rocprofv3 --pmc passes at commit {rec.get('commit', '?')}); not measured in this run"
+            info = h.grad_kernel_info()                  # "<kernel>: <arithmetic>" of the kernel the last optimiser step actually ran
+            kname, arith = info.split(": ", 1)
+            out["dtype"] = "f32 (bf16x3 split, f32 accumulate)" if "bf16x3" in arith else "f32"
+            out["roofline"] = dict(mfma_roofline(ach, arith), traffic=traffic, traffic_source=traffic_source, kernel=kname, avg_launch_ms=avg_ms,
+                                   avg_launch_ms_source="HIP events on the library's stream around every launch of the timed region",
+                                   rocprof_avg_launch_ms=rocprof_ms, launches=gk["launches"], flops_per_launch=flops,
+                                   record_bytes_per_launch=(B_global // world) * 64)      # one 32-byte record per sample and net (the algorithmic gather volume of the record path)
+            out["kernel_ms_per_step"] = {k: v["total_ms"] / steps for k, v in prof.items() if v["launches"]}
+    h.close()
+    return out
+
+
+def secondary_runs(pkg) -> list:
+    """short, timed runs of the other single-GPU configs of BASELINE.json beside the headline line (a driver-observed number for each):
+    configs[2] Pendulum [256,256] + NormalizeWrapperEnv at full size (1 warm-up + 2 iterations), configs[4] SAC (1 + 2 steps of 500 iterations),
+    configs[0] the reference's README quick-start (4 envs, PPO() defaults, real CartPole episodes).  Each entry has its own config / roofline."""
+    out = []
+    out.append(run_ppo(pkg, env_name="pendulum", E=65536, T=2048, hidden=256, minibatches=32, epochs=10, normalize=True, steps=2, warmup=1))
+    out.append(run_sac(pkg, steps=2, warmup=1, iters=500, cpu=False))
+    out.append(run_ppo(pkg, env_name="cartpole", E=4, T=2048, hidden=64, minibatches=0, epochs=10, normalize=False, steps=5, warmup=2, batch_size=64, fixed_length=False,
+                       label="CartPole-v1 configs[0] (README quick-start: MultiThreadedParallelEnv n_envs=4, PPO() defaults, batch_size 64)"))
+    return out
 
 
 def main() -> None:
@@ -153,113 +258,38 @@ def main() -> None:
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--normalize", action="store_true", help="NormalizeWrapperEnv on device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of configs[2] / configs[4] / configs[0] appended to the default line")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
+    pkg = g.load_package()           # loads libdril_hip.so first (binds /opt/rocm's HIP runtime); no CPU fallback exists
+    pkg._capi.load_library()
     if args.algo == "sac":
         if args.gpus != 1:
             raise SystemExit("--algo sac is a single-learner path: --gpus 1 only")
-        return main_sac(args)
+        print(json.dumps(run_sac(pkg, steps=args.steps, warmup=args.warmup, iters=args.sac_iters, E=args.n_envs if args.n_envs != 65536 else 4096,
+                                 H=args.hidden if args.hidden != 64 else 512, events=not args.no_events, cpu=not args.no_cpu_baseline)), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
-    pkg = g.load_package()           # loads libdril_hip.so first (binds /opt/rocm's HIP runtime); no CPU fallback exists
-    capi = pkg._capi
-    capi.load_library()
-
     dist = None
     if world > 1:
         import torch.distributed as dist  # rendezvous / barrier only; never touches torch.cuda
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    E, T = args.n_envs, args.n_steps
-    N_local = E * T
-    B_global = (N_local // args.minibatches) * world
-    env = pkg.CartPoleEnv(max_steps=500) if args.env == "cartpole" else pkg.PendulumEnv(max_steps=200)
-    alg = pkg.PPO(n_steps=T, batch_size=B_global, epochs=args.epochs)
-    layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(args.hidden, args.hidden))
-    cfg = pkg.make_config(env, E, alg, layer, seed=42, fixed_length_episodes=True, device=local_rank, rank=rank, world_size=world,
-                          profile_events=not args.no_events, normalize={} if args.normalize else None)
-    h = pkg.Handle(cfg)
-    h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(42))))   # random-init weights of the named architecture
-    if world > 1:
-        uid = [h.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        h.comm_init(uid[0])
-    h.env_reset(42)
-
-    def iteration():
-        h.set_learning_rate(alg.learning_rate)
-        h.lib.dril_collect_rollout(h._h, None)      # no fps query: keeps the iteration free of host syncs until the update's end
-        return h.ppo_update()
-
-    for _ in range(args.warmup):
-        iteration()
-    h.synchronize(); h.profile_reset()
-    if dist: dist.barrier()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = iteration()
-    h.synchronize()
-    if dist: dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-    prof = h.profile()
-
+    out = run_ppo(pkg, env_name=args.env, E=args.n_envs, T=args.n_steps, hidden=args.hidden, minibatches=args.minibatches, epochs=args.epochs, normalize=args.normalize,
+                  steps=args.steps, warmup=args.warmup, events=not args.no_events, rank=rank, local_rank=local_rank, world=world, dist=dist)
     if rank == 0:
-        total_env_steps = N_local * world * args.steps
-        value = total_env_steps / dt
-        out = {
-            "metric": "env-steps/s (rollout+PPO update) at n_envs=65536", "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("CartPole-v1 configs[1]" if args.env == "cartpole" else "Pendulum-v1 configs[2]" + (" + NormalizeWrapperEnv" if args.normalize else ""))
-                                   + f": device-resident envs, ActorCritic hidden_dims=[{args.hidden},{args.hidden}], PPO rollout + update",
-                       "n_envs_per_gpu": E, "n_steps": T, "epochs": args.epochs, "batch_size": B_global,
-                       "optimizer_steps_per_iteration": args.epochs * (-(-N_local * world // B_global)),
-                       "episodes": f"fixed length {env.max_steps} (termination disabled)", "parallelism": f"dp{world} (env shards)"},
-            "loss_last": last.loss, "n_updates_last": last.n_updates,
-            # what the communicator itself reports (ncclCommCount), not the launcher's WORLD_SIZE; 1 = no communicator (single GPU)
-            "rccl_ranks": h.comm_ranks(), "allreduce_calls": h.comm_allreduce_calls(),
-            "value_per_gpu": value / world,      # N = 1-equivalent figure, to be read against the N = 1 BENCH line
-        }
-        gk = prof.get("ppo_grad_kernel", {"total_ms": 0, "launches": 0})
-        if gk["launches"]:
-            # dominant kernel: ppo_grad_kernel. ALGORITHMIC flops per launch = B_local samples x 53 376 (fwd + bwd of both MLPs,
-            # SURVEY.md §8 a16); duration = HIP events on the library's stream around each launch in the timed region.
-            avg_ms = gk["total_ms"] / gk["launches"]
-            flops = (B_global // world) * 3 * flop_fwd(h.D, args.hidden, h.A)
-            ach = flops / (avg_ms * 1e-3) / 1e12
-            # traffic and the rocprofv3 average are NOT measured in this run (PMC needs its own rocprofv3 passes): they are replayed from the
-            # committed profile of exactly this workload, and the line says so (traffic_source: file + the commit the profile was taken at)
-            traffic = traffic_source = rocprof_ms = None
-            pmc = ROOT / "profiles" / PMC_FILE
-            if pmc.exists() and args.env == "cartpole" and args.hidden == 64 and args.minibatches == 32 and E == 65536 and T == 2048:
-                rec = json.loads(pmc.read_text())
-                traffic, rocprof_ms = rec.get("hbm_bytes_per_launch"), rec.get("rocprof_avg_launch_ms")
-                traffic_source = f"replayed from profiles/{PMC_FILE} (rocprofv3 --pmc passes at commit {rec.get('commit', '?')}); not measured in this run"
-            info = h.grad_kernel_info()                  # "<kernel>: <arithmetic>" of the kernel the last optimiser step actually ran
-            kname, arith = info.split(": ", 1)
-            split = "bf16x3" in arith                    # ppo_grad_split_kernel / ppo_grad_pair_kernel / ppo_grad_wide_split_kernel
-            out["dtype"] = "f32 (bf16x3 split, f32 accumulate)" if split else "f32"
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                               "split_ceiling": PEAK_BF16_SPLIT6_TFLOPS if split else None,
-                               "split_ceiling_note": "dense bf16 MFMA peak / 6 MFMAs per fp32-equivalent product; frac stays against the f32-MFMA peak" if split else None,
-                               "arithmetic": arith,
-                               "traffic": traffic, "traffic_source": traffic_source, "kernel": kname, "avg_launch_ms": avg_ms,
-                               "avg_launch_ms_source": "HIP events on the library's stream around every launch of the timed region",
-                               "rocprof_avg_launch_ms": rocprof_ms, "launches": gk["launches"], "flops_per_launch": flops}
-            out["kernel_ms_per_step"] = {k: v["total_ms"] / args.steps for k, v in prof.items() if v["launches"]}
+        default_workload = (args.env, args.n_envs, args.n_steps, args.hidden, args.minibatches, args.epochs, args.normalize) == ("cartpole", 65536, 2048, 64, 32, 10, False)
+        out["metric"] = "env-steps/s (rollout+PPO update) at n_envs=65536" if args.n_envs == 65536 else out["metric"]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, 42)
+        if world == 1 and default_workload and not args.no_secondary:
+            out["secondary"] = secondary_runs(pkg)
         print(json.dumps(out), flush=True)
-    h.close()
     if dist:
         dist.destroy_process_group()
 
