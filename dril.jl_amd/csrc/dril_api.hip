@@ -126,6 +126,7 @@ struct dril_handle {
     LoopGroup* loop = nullptr;   // debug loopback communicator (dril_debug_comm_loopback)
     int64_t allreduce_calls = 0;
     bool no_small_path = false, no_epoch_moments = false;   // DRIL_NO_SMALL_PATH / DRIL_NO_EPOCH_MOMENTS, latched in dril_create
+    bool no_persistent = false; uint64_t* epoch_keys = nullptr; int epoch_keys_cap = 0;   // ppo_update_small_kernel (batch_size <= 64): DRIL_NO_PERSISTENT_UPDATE; per-epoch DataLoader keys on the device
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
     double prof_ms[DRIL_K_COUNT] = {0}; int64_t prof_n[DRIL_K_COUNT] = {0};
     std::string err;
@@ -517,6 +518,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (const char* e = std::getenv("DRIL_FORCE_STEPWISE")) h->force_stepwise = std::atoi(e) != 0;
     if (const char* e = std::getenv("DRIL_GRAD_ACTOR_PERMILLE")) { h->grad_actor_pct = std::atoi(e); if (h->grad_actor_pct < 100 || h->grad_actor_pct > 900) h->grad_actor_pct = 0; }
     if (const char* e = std::getenv("DRIL_GRAD_VARIANT")) { h->grad_variant = std::atoi(e); if (h->grad_variant < -1 || h->grad_variant > 2) h->grad_variant = -1; if (h->grad_variant == 2) h->grad_variant = 1; }
+    h->no_persistent = std::getenv("DRIL_NO_PERSISTENT_UPDATE") != nullptr;
     h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
     CCHK(hipSetDevice(cfg->device));
@@ -591,7 +593,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     if (h->ext_stage_rew) (void)hipHostFree(h->ext_stage_rew); if (h->ext_stage_flags) (void)hipHostFree(h->ext_stage_flags);
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
-                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
+                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->epoch_keys, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
                     h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->e_rew_n, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->gen_tmp, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->w2p_actor, h->w2tp_actor, h->w2p_critic, h->w2tp_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
                     h->mon_ring_len, h->e_ep_len, h->mon_cnt, h->mon_meta, h->e_flags};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -990,7 +992,53 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
     const int bits = perm_bits(N);
     if (h->rec) HIPCHK(h, launch_pack_records(h->cfg.env_kind, N, h->obs, h->act, h->adv, h->logp, h->ret, h->rec, h->stream));
     int64_t step = 0;
-    for (int ep = 0; ep < h->cfg.epochs; ++ep) {
+    // the reference's default PPO() (batch_size = 64) on hidden [64,64]: every optimiser step of the iteration inside ONE persistent workgroup (dril_update_small.hip);
+    // single-rank only (a data-parallel run all-reduces between the gradient and the step)
+    const bool persistent = !h->wide && !h->generic && world == 1 && !(comm_ready(h) && h->force_allreduce) && h->rec && B >= 2 && B <= 64 && h->P <= 512 * 18 &&
+                            !h->no_persistent && !h->no_small_path && h->grad_variant < 0 && total_steps > 0;   // (DRIL_GRAD_VARIANT pins one of the per-step kernels)
+    if (persistent) {
+        if (h->cfg.epochs > h->epoch_keys_cap) {
+            if (h->epoch_keys) hipFree(h->epoch_keys);
+            h->epoch_keys = nullptr; HIPCHK(h, dmalloc(&h->epoch_keys, (size_t)h->cfg.epochs)); h->epoch_keys_cap = h->cfg.epochs;
+        }
+        std::vector<uint64_t> keys((size_t)h->cfg.epochs);
+        for (int ep = 0; ep < h->cfg.epochs; ++ep) keys[ep] = perm_key(h->cfg.seed + (uint64_t)h->cfg.rank, h->update_counter, ep);
+        HIPCHK(h, hipMemcpyAsync(h->epoch_keys, keys.data(), keys.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));                                    // (keys is a stack-lifetime host buffer)
+        SmallUpdateArgs u{};
+        u.params = h->params; u.adam_m = h->adam_m; u.adam_v = h->adam_v; u.bt = h->bt; u.step_parity = (int)(h->adam_steps & 1);
+        u.rec = h->rec; u.val_old = h->val; u.perm = h->perm_count ? h->perm_dev : nullptr; u.keys = h->epoch_keys; u.perm_bits = bits;
+        u.N = N; u.B = B; u.nb = (int)nb; u.step_stats = h->step_stats; u.norm_out = h->norm_out; u.nan_flag = h->nan_flag; u.stop_flag = h->stop_flag;
+        u.lr = h->lr; u.beta1 = h->cfg.adam_beta1; u.beta2 = h->cfg.adam_beta2; u.eps = h->cfg.adam_eps; u.max_grad_norm = h->cfg.max_grad_norm;
+        u.target_kl = h->cfg.target_kl; u.ent_coef = h->cfg.ent_coef; u.vf_coef = h->cfg.vf_coef; u.clip_range = h->cfg.clip_range; u.clip_range_vf = h->cfg.clip_range_vf;
+        u.has_max_grad_norm = h->cfg.has_max_grad_norm; u.has_target_kl = h->cfg.has_target_kl; u.has_clip_vf = h->cfg.has_clip_range_vf;
+        u.normalize_adv = h->cfg.normalize_advantage; u.action_start = h->cfg.action_start; u.P = h->P; u.Pa = h->Pa; u.Pc = h->Pc; u.dbg = h->dbg;
+        const int64_t chunk = 16384;                                                   // optimiser steps per launch (a bound on one kernel's run time, ~0.1 s)
+        for (int64_t s0 = 0; s0 < total_steps; s0 += chunk) {
+            u.step0 = (int)s0; u.nsteps = (int)(total_steps - s0 < chunk ? total_steps - s0 : chunk);
+            u.step_parity = s0 == 0 ? (int)(h->adam_steps & 1) : 0;                  // (the kernel leaves both ping-pong slots of the beta powers equal)
+            prof_begin(h, DRIL_K_PPO_GRAD);
+            HIPCHK(h, launch_ppo_update_small(h->cfg.env_kind, u, h->stream));
+            prof_end(h);
+        }
+        h->adam_steps += total_steps; h->wimg_dirty = true; h->last_variant = 6;
+#ifdef DRIL_STAMPS
+        {   // per-phase s_memtime ticks of the last launch, per wave
+            hipStreamSynchronize(h->stream);
+            std::vector<unsigned long long> d(8 * 16);
+            hipMemcpy(d.data(), h->dbg, d.size() * 8, hipMemcpyDeviceToHost);
+            const char* nm[16] = {"top: moments + barrier", "L1 + tanh + h1 pieces", "wait B1", "L2 + tanh + out partial", "wait B2", "head + dW3 + dz2 + pieces", "wait B3", "dh1 + dW2", "wait B4",
+                                  "slab epilogue", "wait B5", "m/v loads + g + norm", "stats + Adam + p copy", "wait B7", "staging", "-"};
+            for (int wv = 0; wv < 8; wv += 4) {
+                double tot = 0; for (int k = 0; k < 15; ++k) tot += (double)d[wv * 16 + k];
+                fprintf(stderr, "[small stamps] wave %d: %.0f ticks per step (100 MHz: %.2f us)\n", wv, tot / (double)total_steps, tot / (double)total_steps / 100.0);
+                for (int k = 0; k < 15; ++k) fprintf(stderr, "   %-28s %8.0f ticks/step  %5.1f %%\n", nm[k], (double)d[wv * 16 + k] / (double)total_steps, 100.0 * (double)d[wv * 16 + k] / tot);
+            }
+        }
+#endif
+        step = total_steps;
+    }
+    for (int ep = 0; ep < h->cfg.epochs && !persistent; ++ep) {
         const uint64_t key = perm_key(h->cfg.seed + (uint64_t)h->cfg.rank, h->update_counter, ep);
         const int64_t* perm = h->perm_count ? h->perm_dev + (size_t)ep * N : nullptr;
         const bool epoch_moments = h->cfg.normalize_advantage && !perm && nb >= 2 && nb <= 2048 && !h->no_epoch_moments;
@@ -1262,6 +1310,7 @@ DRIL_EXPORT const char* dril_grad_kernel_info(const dril_handle* h) {
     switch (h->last_variant) {
         case 0: return "ppo_grad_kernel: f32 (v_mfma_f32_32x32x2_f32)";
         case 2: return "ppo_grad_wide_kernel: f32 (v_mfma_f32_32x32x2_f32)";
+        case 6: return "ppo_update_small_kernel: f32 (bf16x3 split, f32 accumulate; v_mfma_f32_32x32x16_bf16 x 6 per k16 step, input layer on v_mfma_f32_32x32x2_f32; persistent workgroup, all optimiser steps of the iteration in one launch)";
         case 5: return "ppo_grad_pair_kernel: f32 (bf16x3 split, f32 accumulate; v_mfma_f32_32x32x16_bf16 x 6 per k16 step, input layer on v_mfma_f32_32x32x2_f32)";
         case 4: return "ppo_grad_wide_split_kernel: f32 (bf16x3 split, f32 accumulate; v_mfma_f32_32x32x16_bf16 x 6 per k16 step, input layer and dW1 on f32 MFMAs)";
         case 3: return "generic path: f32 contractions (sac_gemm_*; large ones bf16x3 split, f32 accumulate)";

@@ -638,4 +638,36 @@ __device__ __forceinline__ float half_sum(float v) {
     return v;
 }
 
+// DPP move: lanes disabled by the bank mask (banks = groups of 4 lanes within a row of 16) keep `old`
+template <int CTRL, int BANK = 0xf> __device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, BANK, false));
+}
+// sums of the 16 registers of x over the 32 lanes of each half-wave, as a reduce-scatter on the VALU (DPP): out[i] = sum over the half of x[4 i + (lane & 3)],
+// valid in every lane.  The two quad steps halve the register count while they add (lane bit b keeps the registers whose index has bit b set and receives its
+// partner's copy of them), the remaining steps are butterflies on four registers: 60 VALU + 4 LDS-crossbar permutes instead of 16 x 5 permutes with their waits
+// (tools/micro/dpp_reduce.hip checks it against a plain sum).  EXEC must be all ones.
+__device__ __forceinline__ void half_reduce16(const f32x16& x, int lane, float (&out)[4]) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        // (the two elements as opaque scalars: otherwise LLVM folds `b0 ? x[2i+1] : x[2i]` into a vector element with a VARIABLE index = a 16-way compare / select chain)
+        float e = x[2 * i], o = x[2 * i + 1];
+        asm volatile("" : "+v"(e), "+v"(o));
+        const float keep = b0 ? o : e, send = b0 ? e : o;
+        y[i] = keep + dpp_mov<0xB1>(0.f, send);                                       // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float keep = b1 ? y[2 * i + 1] : y[2 * i], send = b1 ? y[2 * i] : y[2 * i + 1]; out[i] = keep + dpp_mov<0x4E>(0.f, send); }   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float t = dpp_mov<0x104, 0x5>(0.f, out[i]);        // row_shl:4 -> the lanes of banks 0 and 2 receive lane + 4
+        t = dpp_mov<0x114, 0xa>(t, out[i]);                // row_shr:4 -> the lanes of banks 1 and 3 receive lane - 4
+        out[i] += t;
+        out[i] += dpp_mov<0x128>(0.f, out[i]);             // row_ror:8 = lane ^ 8
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] += __shfl_xor(out[i], 16);   // the other row of the half
+}
+
 }  // namespace dril

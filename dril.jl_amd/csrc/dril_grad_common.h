@@ -30,6 +30,19 @@ constexpr int kLsMax = 4;   // action dims whose log_std the kernels keep in reg
 // loop invariants, where they occupy registers for the whole kernel (ppo_grad_wide_split_kernel: 92 -> 12 spilled registers)
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
+// sum of one double per thread over the workgroup (fixed order: wave butterflies, then the waves in index order); sh = 16 doubles of LDS; two barriers inside
+__device__ __forceinline__ double block_sum_f64(double v, double* sh) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double s = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+    return s;
+}
+
 // one lane's share of a minibatch tile (DataLoader gather, ppo.jl:188-195).  Loaded one tile AHEAD of its use so the
 // random-gather latency (~2 us under load, fully exposed in v1: 23 % of wave time in s_waitcnt) hides under the
 // previous tile's MFMAs; the loop body issues no other vector-memory op, so the loads stay in flight until first use.

@@ -72,6 +72,21 @@ struct GradArgs {
     NetOff actor, critic;
 };
 
+// ppo_update_small_kernel (dril_update_small.hip): a run of optimiser steps [step0, step0 + nsteps) of the epochs x minibatches sequence in one persistent workgroup
+struct SmallUpdateArgs {
+    float* params; float* adam_m; float* adam_v; float* bt; int step_parity;
+    const float4* rec; const float* val_old;
+    const int64_t* perm;          // injected DataLoader order [epochs][N], or null: the keyed bijection with keys[epoch]
+    const uint64_t* keys; int perm_bits;
+    int64_t N, B; int nb, step0, nsteps;
+    float* step_stats; float* norm_out; int* nan_flag; int* stop_flag;
+    float lr, beta1, beta2, eps, max_grad_norm, target_kl, ent_coef, vf_coef, clip_range, clip_range_vf;
+    int has_max_grad_norm, has_target_kl, has_clip_vf, normalize_adv, action_start;
+    int P, Pa, Pc;
+    unsigned long long* dbg;      // -DDRIL_STAMPS diagnostic buffer (16 x u64 per wave), else unused
+};
+hipError_t launch_ppo_update_small(int kind, const SmallUpdateArgs& a, hipStream_t s);
+
 struct ReduceArgs {
     const float* slabs_actor; const float* slabs_critic; int slab_a, slab_c, G, Gc;   // G actor slabs, Gc critic slabs
     int P, Pa, Pc; float* flat; double* norm_partials; double n_samples_local; const int* stop_flag;

@@ -84,7 +84,6 @@ __global__ void env_step_kernel(int E, uint64_t seed0, int episode_len, int fixe
 // *_partials (per-block f64 sums) and *_apply (every block folds the partials in the same order and merges; block 0
 // persists the new RunningMeanStd into the other half of the ping-pong state).
 // =============================================================================================
-__device__ __forceinline__ double block_sum_f64(double v, double* sh);
 
 template <int KIND>
 __global__ void obs_partials_kernel(int E, const float* __restrict__ state, float* __restrict__ raw, double* __restrict__ partials) {
@@ -720,17 +719,6 @@ __global__ void gae_kernel(int E, int T, float gamma, float lam, const float* __
 // =============================================================================================
 // advantage moments of one minibatch (normalize!, ppo.jl:350-356): per-block f64 partials, fixed-order finalize
 // =============================================================================================
-__device__ __forceinline__ double block_sum_f64(double v, double* sh) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) sh[wave] = v;
-    __syncthreads();
-    double s = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
-    return s;
-}
 __global__ void adv_moments_kernel(MomentsArgs a) {
     __shared__ double sh[16];
     if (*a.stop_flag) return;

@@ -9,15 +9,13 @@ pkg = g.load_package()
 capi = pkg._capi
 import subprocess
 _so = ROOT / "dril.jl_amd" / "csrc" / "libdril_hip_stamps.so"
-_src = [str(ROOT / "dril.jl_amd" / "csrc" / f) for f in ("dril_kernels.hip", "dril_api.hip", "dril_sac.hip", "dril_gemm.hip", "dril_generic.hip")]
-if not _so.exists():   # diagnostic build with per-phase s_memtime stamps (-DDRIL_STAMPS); never used for timing claims
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-fvisibility=hidden", "--offload-arch=gfx950", "-DDRIL_STAMPS", "-shared",
-                    "-o", str(_so), *_src, "-ldl", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+subprocess.run(["make", "-C", str(ROOT / "dril.jl_amd" / "csrc"), "-j8", "stamps"], check=True, stdout=sys.stderr)   # diagnostic build (-DDRIL_STAMPS); never used for timing claims
 lib = capi.load_library(_so)
 wide = len(sys.argv) > 1 and sys.argv[1] == "wide"       # config 3 shape: Pendulum, [256,256]
+small = len(sys.argv) > 1 and sys.argv[1] == "small"     # configs[0] shape: 4 envs, PPO() defaults (the persistent small-minibatch kernel)
 env = pkg.PendulumEnv(max_steps=200) if wide else pkg.CartPoleEnv(max_steps=500)
-E, T = 65536, (256 if wide else 2048)
-alg = pkg.PPO(n_steps=T, batch_size=E * T // (4 if wide else 32), epochs=1)
+E, T = (4 if small else 65536), (256 if wide else 2048)
+alg = pkg.PPO() if small else pkg.PPO(n_steps=T, batch_size=E * T // (4 if wide else 32), epochs=1)
 import os
 HW = int(os.environ.get("STAMPS_HIDDEN", "256"))
 layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(HW, HW) if wide else (64, 64))
