@@ -126,7 +126,7 @@ struct dril_handle {
     LoopGroup* loop = nullptr;   // debug loopback communicator (dril_debug_comm_loopback)
     int64_t allreduce_calls = 0;
     bool no_small_path = false, no_epoch_moments = false;   // DRIL_NO_SMALL_PATH / DRIL_NO_EPOCH_MOMENTS, latched in dril_create
-    bool no_persistent = false; uint64_t* epoch_keys = nullptr; int epoch_keys_cap = 0;   // ppo_update_small_kernel (batch_size <= 64): DRIL_NO_PERSISTENT_UPDATE; per-epoch DataLoader keys on the device
+    bool no_persistent = false; uint64_t* epoch_keys = nullptr; int epoch_keys_cap = 0; int64_t small_chunk = 16384;   // ppo_update_small_kernel (batch_size <= 64): DRIL_NO_PERSISTENT_UPDATE; per-epoch DataLoader keys on the device
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
     double prof_ms[DRIL_K_COUNT] = {0}; int64_t prof_n[DRIL_K_COUNT] = {0};
     std::string err;
@@ -519,6 +519,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (const char* e = std::getenv("DRIL_GRAD_ACTOR_PERMILLE")) { h->grad_actor_pct = std::atoi(e); if (h->grad_actor_pct < 100 || h->grad_actor_pct > 900) h->grad_actor_pct = 0; }
     if (const char* e = std::getenv("DRIL_GRAD_VARIANT")) { h->grad_variant = std::atoi(e); if (h->grad_variant < -1 || h->grad_variant > 2) h->grad_variant = -1; if (h->grad_variant == 2) h->grad_variant = 1; }
     h->no_persistent = std::getenv("DRIL_NO_PERSISTENT_UPDATE") != nullptr;
+    if (const char* e = std::getenv("DRIL_SMALL_CHUNK")) { const long c = std::atol(e); if (c > 0) h->small_chunk = c; }   // optimiser steps per launch of ppo_update_small_kernel (tests: launch boundaries)
     h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
     CCHK(hipSetDevice(cfg->device));
@@ -1013,7 +1014,7 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
         u.target_kl = h->cfg.target_kl; u.ent_coef = h->cfg.ent_coef; u.vf_coef = h->cfg.vf_coef; u.clip_range = h->cfg.clip_range; u.clip_range_vf = h->cfg.clip_range_vf;
         u.has_max_grad_norm = h->cfg.has_max_grad_norm; u.has_target_kl = h->cfg.has_target_kl; u.has_clip_vf = h->cfg.has_clip_range_vf;
         u.normalize_adv = h->cfg.normalize_advantage; u.action_start = h->cfg.action_start; u.P = h->P; u.Pa = h->Pa; u.Pc = h->Pc; u.dbg = h->dbg;
-        const int64_t chunk = 16384;                                                   // optimiser steps per launch (a bound on one kernel's run time, ~0.1 s)
+        const int64_t chunk = h->small_chunk;                                          // optimiser steps per launch (16 384: a bound on one kernel's run time, ~0.2 s)
         for (int64_t s0 = 0; s0 < total_steps; s0 += chunk) {
             u.step0 = (int)s0; u.nsteps = (int)(total_steps - s0 < chunk ? total_steps - s0 : chunk);
             u.step_parity = s0 == 0 ? (int)(h->adam_steps & 1) : 0;                  // (the kernel leaves both ping-pong slots of the beta powers equal)
@@ -1027,8 +1028,8 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
             hipStreamSynchronize(h->stream);
             std::vector<unsigned long long> d(8 * 16);
             hipMemcpy(d.data(), h->dbg, d.size() * 8, hipMemcpyDeviceToHost);
-            const char* nm[16] = {"top: moments + barrier", "L1 + tanh + h1 pieces", "wait B1", "L2 + tanh + out partial", "wait B2", "head + dW3 + dz2 + pieces", "wait B3", "dh1 + dW2", "wait B4",
-                                  "slab epilogue", "wait B5", "m/v loads + g + norm", "stats + Adam + p copy", "wait B7", "staging", "-"};
+            const char* nm[16] = {"top: moments + barrier", "L1 + tanh + h1 pieces", "wait B1", "L2 + tanh + out partial", "wait B2", "head + dW3 + dz2 + pieces", "wait B3", "dh1 + dW1 + dW2", "wait B4",
+                                  "dW2 overlay", "wait B5", "g + norm", "stats + Adam + images", "-", "-", "-"};
             for (int wv = 0; wv < 8; wv += 4) {
                 double tot = 0; for (int k = 0; k < 15; ++k) tot += (double)d[wv * 16 + k];
                 fprintf(stderr, "[small stamps] wave %d: %.0f ticks per step (100 MHz: %.2f us)\n", wv, tot / (double)total_steps, tot / (double)total_steps / 100.0);

@@ -20,7 +20,7 @@ namespace dril {
 template <int D, int O> struct SmallNet {                     // one net's weights in LDS (floats), rebuilt from the parameters every optimiser step
     static constexpr int H = 64, DP = 4, OP = (O + 3) / 4 * 4;
     static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, SMALL_END = (B3 + OP + 3) / 4 * 4;
-    static constexpr int WIMG = SMALL_END, END = WIMG + 3 * 2048;   // three pieces x [64 out][64 in] bf16
+    static constexpr int LS = SMALL_END, WIMG = LS + 4, END = WIMG + 3 * 2048;   // log_std copy (actor, continuous heads); three pieces x [64 out][64 in] bf16
 };
 template <int D, int OMAX> struct SmallPair {                 // one pair's area (floats)
     static constexpr int P1 = 0, P2 = P1 + 3 * 1024, PO = P2 + 3 * 1024;                 // two 12 KB piece images, [2 waves][O][32] output partial sums
@@ -42,38 +42,6 @@ __device__ __forceinline__ bf16x8 small_frag_W_T(const char* wimg, int tbase, in
     return frag8(lds_read_tr16(wimg, a), lds_read_tr16(wimg, (a ^ 16) + 4 * 128));
 }
 
-// LDS offset (in floats, inside a pair area) of parameter q of a net with O outputs: the include/dril_hip.h order {W1 b1 W2 b2 W3 b3} (each W column-major out x in)
-template <int D, int O, int OMAX>
-__device__ __forceinline__ int small_slab_off(int q) {
-    using S = SmallPair<D, OMAX>;
-    constexpr int H = 64, n_w1 = H * D, n_b1 = n_w1 + H, n_w2 = n_b1 + H * H, n_b2 = n_w2 + H, n_w3 = n_b2 + O * H;
-    if (q < n_w1) return S::G_W1 + q;
-    if (q < n_b1) return S::G_B1 + (q - n_w1);
-    if (q < n_w2) { const int i = q - n_b1; return S::S_W2 + (i & 63) * 65 + (i >> 6); }     // W2[o + 64 k] -> row o, column k
-    if (q < n_b2) return S::G_B2 + (q - n_w2);
-    if (q < n_w3) return S::G_W3 + (q - n_b2);
-    return S::G_B3 + (q - n_w3);
-}
-
-// rebuild one net's LDS images from the parameter copy in the area of the net's pair 0: the staging of grad_body_pair, reading LDS instead of global memory
-template <int D, int O, int OMAX>
-__device__ __forceinline__ void small_stage_net(float* wl, const float* sl, int t, int nt) {
-    using L = SmallNet<D, O>; using S = SmallPair<D, OMAX>;
-    constexpr int H = 64;
-    char* Wimg = reinterpret_cast<char*>(wl + L::WIMG);
-    for (int i = t; i < L::DP * H; i += nt) { const int o = i % H, k = i / H; wl[L::W1T + k * H + o] = k < D ? kTanhScale * sl[S::G_W1 + o + k * H] : 0.0f; }
-    for (int i = t; i < H; i += nt) { wl[L::B1 + i] = kTanhScale * sl[S::G_B1 + i]; wl[L::B2 + i] = kTanhScale * sl[S::G_B2 + i]; }
-    for (int i = t; i < O * H; i += nt) { const int o = i % O, k = i / O; wl[L::W3S + o * H + k] = sl[S::G_W3 + i]; }
-    for (int i = t; i < L::OP; i += nt) wl[L::B3 + i] = i < O ? sl[S::G_B3 + i] : 0.0f;
-    for (int i = t; i < H * H / 2; i += nt) {                 // pair (k, k+1) of row o
-        const int o = i % H, kp = i / H;
-        unsigned hi, mid, lo;
-        split3_pair(kTanhScale * sl[S::S_W2 + o * 65 + 2 * kp], kTanhScale * sl[S::S_W2 + o * 65 + 2 * kp + 1], hi, mid, lo);
-        const int byte = o * 128 + ((((kp >> 2) ^ wimg_g<64>(o)) & 7) << 4) + ((kp & 3) << 2);
-        *reinterpret_cast<unsigned*>(Wimg + byte) = hi; *reinterpret_cast<unsigned*>(Wimg + 8192 + byte) = mid; *reinterpret_cast<unsigned*>(Wimg + 16384 + byte) = lo;
-    }
-}
-
 // one 32-sample tile of one net on a pair of waves: forward, loss head, reverse pass; the pair's gradient goes into its slab overlay.  Barriers are workgroup-wide
 // (all eight waves execute the same sequence).
 template <int KIND, int O, int HEAD, int OMAX>
@@ -84,7 +52,7 @@ template <int KIND, int O, int HEAD, int OMAX>
 #define SMALL_STAMP_PARAMS
 #define SMALL_STAMP_ARGS
 #endif
-__device__ __forceinline__ void small_tile(const GradArgs& ga, float* wl, float* pb, TileIn<O>& cur, float adv_mean, float adv_inv, const float* ls, int lane, int w SMALL_STAMP_PARAMS) {
+__device__ __forceinline__ void small_tile(const GradArgs& ga, float* wl, float* pb, TileIn<O>& cur, const float* mom, int normalize_adv, const float* ls, int lane, int w SMALL_STAMP_PARAMS) {
     constexpr int D = EnvSpec<KIND>::D, H = 64, MT = 2;
     constexpr float kInvTanhScale = 1.0f / kTanhScale;
     using L = SmallNet<D, O>; using S = SmallPair<D, OMAX>;
@@ -153,6 +121,7 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* wl, float*
     float st[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, dlsp[O];
 #pragma unroll
     for (int o = 0; o < O; ++o) dlsp[o] = 0.f;
+    const float adv_mean = (HEAD != HEAD_VALUE && normalize_adv) ? mom[0] : 0.f, adv_inv = (HEAD != HEAD_VALUE && normalize_adv) ? mom[1] : 1.f;   // written by the critic's first wave before B1
     loss_head<O, HEAD>(ga, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
     float* gq = pb;                                                                   // the pair's small-gradient words
     const int u4 = 32 * w + 4 * h + (c & 3);                                          // unit of register 4 i + (c & 3): u4 + 8 i (rowfn)
@@ -277,17 +246,45 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
     return v;
 }
+// sum over the 64 lanes on the VALU (DPP) + two LDS-crossbar permutes; every lane gets the total
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += dpp_mov<0xB1>(0.f, v); v += dpp_mov<0x4E>(0.f, v);
+    float t = dpp_mov<0x104, 0x5>(0.f, v); t = dpp_mov<0x114, 0xa>(t, v); v += t;
+    v += dpp_mov<0x128>(0.f, v);
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    return v;
+}
+
+// small parameters of one net (everything but W2) in the order {W1 | b1 | b2 | W3 | b3}: flat parameter index, gradient word in the pair area, staged word in the
+// net's LDS block and the scale of the staged copy (the forward images are pre-scaled by kTanhScale)
+template <int D, int O, int OMAX>
+__device__ __forceinline__ void small_param_map(int r, int& flat, int& goff, int& dst, float& scale) {
+    using L = SmallNet<D, O>; using S = SmallPair<D, OMAX>;
+    constexpr int H = 64, n_w1 = H * D, n_b1 = n_w1 + H, n_w2 = n_b1 + H * H, n_b2 = n_w2 + H, n_w3 = n_b2 + O * H;
+    if (r < n_w1) { flat = r; goff = S::G_W1 + r; dst = L::W1T + r; scale = kTanhScale; return; }
+    r -= n_w1;
+    if (r < H) { flat = n_w1 + r; goff = S::G_B1 + r; dst = L::B1 + r; scale = kTanhScale; return; }
+    r -= H;
+    if (r < H) { flat = n_w2 + r; goff = S::G_B2 + r; dst = L::B2 + r; scale = kTanhScale; return; }
+    r -= H;
+    if (r < O * H) { flat = n_b2 + r; goff = S::G_W3 + r; dst = L::W3S + (r % O) * H + r / O; scale = 1.0f; return; }   // W3[o + O k] -> row o of the staged copy
+    r -= O * H;
+    flat = n_w3 + r; goff = S::G_B3 + r; dst = L::B3 + r; scale = 1.0f;
+}
 
 template <int KIND>
 __global__ __launch_bounds__(512, 1) void ppo_update_small_kernel(SmallUpdateArgs a) {
     constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A, H = 64, OMAX = A;
     constexpr bool DISC = EnvSpec<KIND>::discrete;
     constexpr int AHEAD = DISC ? HEAD_CATEGORICAL : HEAD_GAUSSIAN;
-    constexpr int KMAX = 18;                                                          // parameters per thread: P <= 512 * 18 = 9 216 (checked by the host)
     using LA = SmallNet<D, A>; using LC = SmallNet<D, 1>; using S = SmallPair<D, OMAX>;
+    constexpr int NSA = H * (D + 2 + A) + A, NSC = H * (D + 2 + 1) + 1, NLS = DISC ? 0 : A;    // small parameters of the actor / the critic, log_std
+    static_assert(NSA + NSC + NLS <= 1024, "two small parameters per thread");
+    constexpr int WOFF = H * D + H;                                                    // W2 inside a net's parameters
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ double shd[16];
+    __shared__ float shf[16];
     __shared__ float stf[8];
+    __shared__ float mom[2];
     if (*a.stop_flag) return;
     float* wl_a = smem; float* wl_c = smem + LA::END;
     float* pairs = smem + LA::END + LC::END;                                          // [net][pair] areas
@@ -298,34 +295,59 @@ __global__ __launch_bounds__(512, 1) void ppo_update_small_kernel(SmallUpdateArg
     float* pb = pairs + (net * 2 + pr) * S::SIZE;
     float* sl_a0 = pairs, *sl_a1 = pairs + S::SIZE, *sl_c0 = pairs + 2 * S::SIZE, *sl_c1 = pairs + 3 * S::SIZE;
 
-    // ---- the thread's parameters, Adam moments (registers for the whole launch) and their LDS offsets (two 16-bit offsets per register) ----
-    float pp[KMAX], pm[KMAX], pv[KMAX]; unsigned poff2[KMAX / 2];
+    // ---- ownership: the thread keeps, for the whole launch and in registers, the parameters and Adam moments of
+    //        W2 pairs (o, 2 kp), (o, 2 kp + 1) with o = tid & 63, kp = (tid >> 6) + 8 j, j = 0..3, of BOTH nets (16 + 16 parameters: all 8 192 of them), and
+    //        two small parameters (index tid and tid + 512 of {actor small | critic small | log_std}).
+    //      After Adam the owner writes the staged form itself: the three bf16 pieces of a W2 pair into the net's weight image, a small parameter (scaled) into its
+    //      staged word — no f32 copy of the parameters goes through LDS and no separate staging pass exists.
+    const int wo = tid & 63, wk = tid >> 6;
+    float wp[2][4][2], wm[2][4][2], wv[2][4][2];                                       // [net][j][element of the pair]
+    float sp[2], sm[2], sv[2], sscale[2]; int sflat[2], sgoff[2], sdst[2];             // small parameters (sflat < 0: none)
+    auto publish_pair = [&](int n, int j) {
+        char* Wimg = reinterpret_cast<char*>((n ? wl_c + LC::WIMG : wl_a + LA::WIMG));
+        const int kp = wk + 8 * j;
+        unsigned hi, mid, lo;
+        split3_pair(kTanhScale * wp[n][j][0], kTanhScale * wp[n][j][1], hi, mid, lo);
+        const int byte = wo * 128 + ((((kp >> 2) ^ wimg_g<64>(wo)) & 7) << 4) + ((kp & 3) << 2);
+        *reinterpret_cast<unsigned*>(Wimg + byte) = hi; *reinterpret_cast<unsigned*>(Wimg + 8192 + byte) = mid; *reinterpret_cast<unsigned*>(Wimg + 16384 + byte) = lo;
+    };
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const int p = tid + 512 * k;
-        pp[k] = 0.f; pm[k] = 0.f; pv[k] = 0.f;
-        unsigned off = 0xffffu;
-        if (p < a.P) {
-            pp[k] = a.params[p]; pm[k] = a.adam_m[p]; pv[k] = a.adam_v[p];
-            if (p < a.Pa) off = small_slab_off<D, A, OMAX>(p);
-            else if (p < a.Pa + a.Pc) off = 2 * S::SIZE + small_slab_off<D, 1, OMAX>(p - a.Pa);
-            else off = S::G_LS + (p - a.Pa - a.Pc);                                  // log_std gradients sit with the actor's small gradients
-            pairs[off] = pp[k];
-        }
-        if (k & 1) poff2[k >> 1] |= off << 16; else poff2[k >> 1] = off;
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int p = (n ? a.Pa : 0) + WOFF + wo + 64 * (2 * (wk + 8 * j) + e);
+                wp[n][j][e] = a.params[p]; wm[n][j][e] = a.adam_m[p]; wv[n][j][e] = a.adam_v[p];
+            }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int si = tid + 512 * q;
+        sflat[q] = -1; sgoff[q] = 0; sdst[q] = 0; sscale[q] = 1.0f; sp[q] = 0.f; sm[q] = 0.f; sv[q] = 0.f;
+        if (si < NSA) { int f; small_param_map<D, A, OMAX>(si, f, sgoff[q], sdst[q], sscale[q]); sflat[q] = f; }
+        else if (si < NSA + NSC) { int f; small_param_map<D, 1, OMAX>(si - NSA, f, sgoff[q], sdst[q], sscale[q]); sflat[q] = a.Pa + f; sgoff[q] += 2 * S::SIZE; sdst[q] += LA::END; }
+        else if (si < NSA + NSC + NLS) { const int i = si - NSA - NSC; sflat[q] = a.Pa + a.Pc + i; sgoff[q] = S::G_LS + i; sdst[q] = LA::LS + i; }
+        if (sflat[q] >= 0) { sp[q] = a.params[sflat[q]]; sm[q] = a.adam_m[sflat[q]]; sv[q] = a.adam_v[sflat[q]]; }
     }
+    for (int i = tid; i < LA::DP * H; i += 512) { wl_a[LA::W1T + i] = 0.f; wl_c[LC::W1T + i] = 0.f; }   // rows k >= D of the first-layer images stay zero
+    for (int i = tid; i < LA::OP; i += 512) wl_a[LA::B3 + i] = 0.f;
+    for (int i = tid; i < LC::OP; i += 512) wl_c[LC::B3 + i] = 0.f;
+    lds_barrier();
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) publish_pair(n, j);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) if (sflat[q] >= 0) smem[sdst[q]] = sscale[q] * sp[q];
     const float* bt_in = a.bt + 2 * (a.step_parity & 1);
     float bt1 = bt_in[0], bt2 = bt_in[1];
-    lds_barrier();
-    small_stage_net<D, A, OMAX>(wl_a, sl_a0, tid, 512);
-    small_stage_net<D, 1, OMAX>(wl_c, sl_c0, tid, 512);
-    lds_barrier();
 
     GradArgs ga{};                                                                    // what unpack_tile / loss_head read
     ga.clip_range = a.clip_range; ga.ent_coef = a.ent_coef; ga.vf_coef = a.vf_coef; ga.clip_range_vf = a.clip_range_vf; ga.has_clip_vf = a.has_clip_vf;
     ga.normalize_adv = a.normalize_adv; ga.action_start = a.action_start;
 
-    // gather of step s: this lane's half record of sample 32 pr + c, and (actor waves) the advantage of sample `lane` for the minibatch moments
+    // gather of step s: this lane's half record of sample 32 pr + c, and (critic waves, which have the lighter tile) the advantage of sample `lane` for the
+    // minibatch moments
     auto sample_index = [&](int ep, int64_t pos) -> int64_t {
         return a.perm ? a.perm[(int64_t)ep * a.N + pos] : perm_index(pos, a.N, a.keys[ep], a.perm_bits);
     };
@@ -339,11 +361,10 @@ __global__ __launch_bounds__(512, 1) void ppo_update_small_kernel(SmallUpdateArg
         raw_n = a.rec[2 * idx + h];
         vold_n = (net == 1 && a.has_clip_vf) ? a.val_old[idx] : 0.f;
         adv_n = 0.f;
-        if (net == 0 && a.normalize_adv && lane < count) adv_n = a.rec[2 * sample_index(ep, pos0 + lane) + 1].y;
+        if (net == 1 && a.normalize_adv && lane < count) adv_n = a.rec[2 * sample_index(ep, pos0 + lane) + 1].y;
     };
     const int s_end = a.step0 + a.nsteps;
     if (a.step0 < s_end) gather(a.step0);
-
 #ifdef DRIL_STAMPS
     unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
@@ -355,53 +376,71 @@ __global__ __launch_bounds__(512, 1) void ppo_update_small_kernel(SmallUpdateArg
         // ---- this step's inputs out of the prefetch registers; the next step's gathers go out now and land under this step's arithmetic ----
         const float4 raw = raw_n; const float vold = vold_n, advl = adv_n; const bool valid = valid_n;
         if (s + 1 < s_end) gather(s + 1);
-        float adv_mean = 0.f, adv_inv = 1.f;
-        if (net == 0 && a.normalize_adv) {                                            // normalize!(advantages) per minibatch, ppo.jl:350-356 (corrected std + 1e-8)
-            const double sm = wave_sum_f64((double)advl), sq = wave_sum_f64((double)advl * (double)advl), n = (double)count;
-            const double mean = sm / n;
-            double var = (sq - sm * mean) / (n - 1.0);
+        if (net == 1 && a.normalize_adv) {                                            // normalize!(advantages) per minibatch, ppo.jl:350-356 (corrected std + 1e-8)
+            const double sm_ = wave_sum_f64((double)advl), sq = wave_sum_f64((double)advl * (double)advl), n = (double)count;
+            const double mean = sm_ / n;
+            double var = (sq - sm_ * mean) / (n - 1.0);
             if (var < 0) var = 0;
-            adv_mean = (float)mean; adv_inv = 1.0f / ((float)sqrt(var) + 1.0e-8f);
+            if (tid == 256) { mom[0] = (float)mean; mom[1] = 1.0f / ((float)sqrt(var) + 1.0e-8f); }   // read by the actor after the second barrier of the tile
         }
         float lsr[kLsMax];
 #pragma unroll
-        for (int o = 0; o < kLsMax; ++o) lsr[o] = (!DISC && o < A) ? sl_a0[S::G_LS + o] : 0.f;   // log_std: its parameter copy lives in the actor's slab area
-        lds_barrier();                                                                // (staging complete; the dW2 overlay becomes images again)
+        for (int o = 0; o < kLsMax; ++o) lsr[o] = 0.f;
+        lds_barrier();                                                                // (weight images and staged parameters of the previous step complete; the dW2 overlay becomes images again)
+        if (!DISC) {
+#pragma unroll
+            for (int o = 0; o < A; ++o) lsr[o] = wl_a[LA::LS + o];
+        }
         STAMP(0);
         if (net == 0) {
             TileIn<A> cur; cur.raw = raw; cur.valid = valid; cur.s0 = 0.f; cur.s1 = 0.f; cur.act = 0;
-            small_tile<KIND, A, AHEAD, OMAX>(ga, wl_a, pb, cur, adv_mean, adv_inv, lsr, lane, w SMALL_STAMP_ARGS);
+            small_tile<KIND, A, AHEAD, OMAX>(ga, wl_a, pb, cur, mom, a.normalize_adv, lsr, lane, w SMALL_STAMP_ARGS);
         } else {
             TileIn<1> cur; cur.raw = raw; cur.valid = valid; cur.s0 = 0.f; cur.s1 = vold; cur.act = 0;
-            small_tile<KIND, 1, HEAD_VALUE, OMAX>(ga, wl_c, pb, cur, 0.f, 1.f, lsr, lane, w SMALL_STAMP_ARGS);
+            small_tile<KIND, 1, HEAD_VALUE, OMAX>(ga, wl_c, pb, cur, mom, 0, lsr, lane, w SMALL_STAMP_ARGS);
         }
         STAMP(9);
         lds_barrier();                                                                // B5: all four pairs' gradients complete
         STAMP(10);
-        // ---- optimiser phase: every thread owns KMAX parameters ----
-        float g[KMAX]; double ss = 0;
+        // ---- optimiser phase ----
+        float gw[2][4][2], gs[2]; double ss = 0;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const unsigned off = (k & 1) ? (poff2[k >> 1] >> 16) : (poff2[k >> 1] & 0xffffu);
-            g[k] = 0.f;
-            if (off != 0xffffu) {
-                g[k] = pairs[off] + pairs[off + S::SIZE];                             // pair 0 + pair 1 of the parameter's net (log_std: of the actor), fixed order
-                ss += (double)g[k] * (double)g[k];
-            }
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int off = 2 * n * S::SIZE + S::S_W2 + wo * 65 + 2 * (wk + 8 * j) + e;
+                    const float g = pairs[off] + pairs[off + S::SIZE];               // pair 0 + pair 1 of the net, fixed order
+                    gw[n][j][e] = g; ss += (double)g * (double)g;
+                }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float g = sflat[q] >= 0 ? pairs[sgoff[q]] + pairs[sgoff[q] + S::SIZE] : 0.f;
+            gs[q] = g; ss += (double)g * (double)g;
         }
-        if (tid < 8) {
+        if (tid >= 448 && tid < 456) {                                                // the statistics sums (the last critic wave has the least to do)
+            const int k = tid - 448;
             float t = 0.f;
-            if (tid < 5) t = sl_a0[S::G_ST + tid] + sl_a1[S::G_ST + tid];
-            else if (tid == 5) t = sl_c0[S::G_ST] + sl_c1[S::G_ST];
-            else if (tid == 6) t = (float)count;
-            stf[tid] = t;
+            if (k < 5) t = sl_a0[S::G_ST + k] + sl_a1[S::G_ST + k];
+            else if (k == 5) t = sl_c0[S::G_ST] + sl_c1[S::G_ST];
+            else if (k == 6) t = (float)count;
+            stf[k] = t;
         }
-        const float norm = sqrtf((float)block_sum_f64(ss, shd));                       // (its two barriers also publish stf)
+        {   // |g|^2: per thread in f64, per wave on the VALU, the eight waves in index order
+            const float wsum = wave_sum_f32((float)ss);
+            if (lane == 0) shf[wave] = wsum;
+        }
+        lds_barrier();
+        double tot = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot += (double)shf[k];
+        const float norm = sqrtf((float)tot);
         STAMP(11);
         const float n = stf[6], kl = stf[3] / n;
         const bool bad = !(norm == norm) || isinf(norm);                              // NaN / Inf anywhere poisons the norm (ppo.jl:213-214)
         const bool kl_stop = a.has_target_kl && kl > 1.5f * a.target_kl;              // ppo.jl:235-238: skip this apply, stop
-        if (tid == 0) {
+        if (tid == 448) {
             float* o = a.step_stats + (size_t)s * 16;
             const float pl = stf[0] / n, ent = stf[1] / n, vl = stf[5] / n;
             o[0] = pl; o[1] = vl; o[2] = -ent; o[3] = stf[2] / n; o[4] = kl; o[5] = ent; o[6] = stf[4] / n;
@@ -415,38 +454,43 @@ __global__ __launch_bounds__(512, 1) void ppo_update_small_kernel(SmallUpdateArg
         const float scale = (a.has_max_grad_norm && norm > a.max_grad_norm) ? a.max_grad_norm / norm : 1.0f;   // optimization_utils.jl:98-107
         // bias corrections once per step (every thread the same value); per parameter one hardware reciprocal and one hardware square root (1 ulp each: the update is
         // lr x O(1), so their error is ~1e-11 absolute — far below one ulp of a parameter) instead of three IEEE divisions and an IEEE square root (~40 instructions)
-        const float ic1 = 1.0f / (1.0f - bt1), ic2 = 1.0f / (1.0f - bt2);
+        const float ic1 = 1.0f / (1.0f - bt1), ic2 = 1.0f / (1.0f - bt2), omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
+        auto adam = [&](float g, float& p, float& m, float& v) {                       // Optimisers.Adam, eps = 1e-5 (ppo.jl:64-66)
+            g = g * scale;
+            m = a.beta1 * m + omb1 * g; v = a.beta2 * v + omb2 * g * g;
+            p = p - (m * ic1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ic2) + a.eps) * a.lr;
+        };
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const unsigned off = (k & 1) ? (poff2[k >> 1] >> 16) : (poff2[k >> 1] & 0xffffu);
-            if (off != 0xffffu) {
-                float gk = g[k];
-                if (scale != 1.0f) gk = gk * scale;
-                const float m = a.beta1 * pm[k] + (1.0f - a.beta1) * gk;
-                const float v = a.beta2 * pv[k] + (1.0f - a.beta2) * gk * gk;
-                pm[k] = m; pv[k] = v;
-                pp[k] = pp[k] - (m * ic1) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v * ic2) + a.eps) * a.lr;   // Optimisers.Adam, eps = 1e-5 (ppo.jl:64-66)
-                pairs[off] = pp[k];                                                   // the new parameter, where the staging reads it
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                adam(gw[n][j][0], wp[n][j][0], wm[n][j][0], wv[n][j][0]); adam(gw[n][j][1], wp[n][j][1], wm[n][j][1], wv[n][j][1]);
+                publish_pair(n, j);
             }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            adam(gs[q], sp[q], sm[q], sv[q]);
+            if (sflat[q] >= 0) smem[sdst[q]] = sscale[q] * sp[q];
         }
         bt1 *= a.beta1; bt2 *= a.beta2;
         STAMP(12);
-        lds_barrier();                                                                // B7: parameter copies complete
-        STAMP(13);
-        small_stage_net<D, A, OMAX>(wl_a, sl_a0, tid, 512);
-        small_stage_net<D, 1, OMAX>(wl_c, sl_c0, tid, 512);
-        STAMP(14);
-        // (the barrier at the top of the next step separates this staging from the next image stores and the next reads of the weight images)
+        // (the barrier at the top of the next step separates these image stores from the next reads of the weight images and from the next image stores)
     }
 #ifdef DRIL_STAMPS
     if (lane == 0 && a.dbg) { for (int k = 0; k < 16; ++k) a.dbg[wave * 16 + k] = stamp_acc[k]; }
 #endif
     // ---- state back to global memory ----
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const int p = tid + 512 * k;
-        if (p < a.P) { a.params[p] = pp[k]; a.adam_m[p] = pm[k]; a.adam_v[p] = pv[k]; }
-    }
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int p = (n ? a.Pa : 0) + WOFF + wo + 64 * (2 * (wk + 8 * j) + e);
+                a.params[p] = wp[n][j][e]; a.adam_m[p] = wm[n][j][e]; a.adam_v[p] = wv[n][j][e];
+            }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) if (sflat[q] >= 0) { a.params[sflat[q]] = sp[q]; a.adam_m[sflat[q]] = sm[q]; a.adam_v[sflat[q]] = sv[q]; }
     if (tid == 0) { a.bt[0] = bt1; a.bt[1] = bt2; a.bt[2] = bt1; a.bt[3] = bt2; }     // both ping-pong slots: the host's step parity no longer matters
 }
 

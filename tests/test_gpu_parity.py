@@ -975,3 +975,78 @@ def test_forced_pair_kernel_on_small_minibatches(pkg, oracle_mod, monkeypatch, B
     batch = _batch(o, cfg, B, 1)                                                     # and through the parity entry point (no DataLoader order)
     lh, _, gh = h.ppo_loss_grad(*batch); lo, _, go = o.ppo_loss_grad(*batch)
     assert lh == pytest.approx(lo, rel=1e-4) and np.linalg.norm(gh - go) <= 2e-4 * np.linalg.norm(go)
+
+
+@pytest.mark.parametrize("kind,E,T,B,kw", [
+    (0, 16, 24, 64, {}),
+    (0, 16, 24, 48, {"has_target_kl": 1, "target_kl": 0.002}),                         # the KL stop inside the persistent loop: skip that apply, stop (ppo.jl:235-238)
+    (0, 8, 16, 32, {"has_clip_range_vf": 1, "clip_range_vf": 0.2, "ent_coef": 0.01}),
+    (1, 8, 16, 20, {"ent_coef": 0.01}),                                                # DiagGaussian: the log_std parameter and its staged copy
+    (3, 10, 13, 50, {}),                                                               # N = 130: a ragged last minibatch of 30
+    (0, 4, 1024, 2, {"epochs": 5}),                                                    # 10 240 optimiser steps of 2 samples
+])
+def test_persistent_small_update_matches_oracle(pkg, oracle_mod, monkeypatch, kind, E, T, B, kw):
+    """ppo_update_small_kernel (batch_size <= 64: the reference's default PPO()): all optimiser steps of an iteration in one persistent workgroup, against the oracle
+    on identical buffers and an injected DataLoader order; the first case also against the per-step path (DRIL_NO_PERSISTENT_UPDATE) on the same data"""
+    capi = pkg._capi
+    kw = dict(kw); epochs = kw.pop("epochs", 3)
+    cfg = _cfg(pkg, kind, n_envs=E, n_steps=T, batch_size=B, epochs=epochs, episode_len=11, **kw)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 77, 0.3); h.set_params(flat); o.set_params(flat)
+    o.env_reset(5); o.collect_rollout()
+    bufs = (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES)
+    for which in bufs:
+        h.set_buffer(which, o.buffer(which))
+    N = E * T
+    perm = np.stack([np.random.default_rng(e).permutation(N) for e in range(cfg.epochs)]).astype(np.int64)
+    h.set_permutation(perm); o.set_permutation(perm)
+    sh, so = h.ppo_update(), o.ppo_update()
+    assert h.grad_kernel_info().split(":")[0] == "ppo_update_small_kernel"
+    assert (sh.n_updates, sh.early_stopped) == (so.n_updates, so.early_stopped)
+    if "has_target_kl" in kw:
+        assert sh.early_stopped and sh.n_updates < cfg.epochs * -(-N // B)
+    long_run = sh.n_updates > 5000
+    if long_run:                                                                       # thousands of 2-sample steps on a non-smooth loss: the update as a whole (see the configs[0] test)
+        dh, do = h.get_params().astype(np.float64) - flat, o.get_params().astype(np.float64) - flat
+        rel = np.linalg.norm(dh - do) / np.linalg.norm(do)
+        print(f"[persistent, {sh.n_updates} steps of {B} samples] relative difference of the update {rel:.2e}; mean loss {sh.loss:.5f} vs {so.loss:.5f}")
+        assert rel <= 0.1 and sh.loss == pytest.approx(so.loss, rel=0.1) and sh.value_loss == pytest.approx(so.value_loss, rel=0.05)
+    else:
+        for f in ("policy_loss", "value_loss", "entropy_loss", "approx_kl_div", "clip_fraction", "loss", "grad_norm", "explained_variance", "ratio_first"):
+            assert getattr(sh, f) == pytest.approx(getattr(so, f), rel=5e-4, abs=2e-6), f
+        assert sh.loss == pytest.approx(so.loss, rel=1e-4)
+        np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=2e-4, atol=3e-6)
+    if B == 64:
+        monkeypatch.setenv("DRIL_NO_PERSISTENT_UPDATE", "1")
+        h2 = pkg.Handle(cfg); h2.set_params(flat)
+        for which in bufs:
+            h2.set_buffer(which, o.buffer(which))
+        h2.set_permutation(perm); s2 = h2.ppo_update()
+        assert h2.grad_kernel_info().split(":")[0] == "ppo_grad_kernel"
+        assert s2.loss == pytest.approx(sh.loss, rel=1e-5)
+        np.testing.assert_allclose(h2.get_params(), h.get_params(), rtol=1e-4, atol=2e-6)
+    # the optimiser state left in global memory is the state the next update starts from: a second update on the same data stays with the oracle
+    if not long_run and "has_target_kl" not in kw:
+        sh2, so2 = h.ppo_update(), o.ppo_update()
+        assert sh2.loss == pytest.approx(so2.loss, rel=2e-4)
+        np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=4e-4, atol=6e-6)
+
+
+def test_persistent_small_update_across_launch_boundaries(pkg, oracle_mod, monkeypatch):
+    """the persistent kernel runs at most DRIL_SMALL_CHUNK (default 16 384) optimiser steps per launch; parameters, Adam moments and the beta powers pass from one
+    launch to the next through global memory.  48 steps in one launch and in launches of 5 must agree BITWISE (same arithmetic, same order)"""
+    capi = pkg._capi
+    cfg = _cfg(pkg, 0, n_envs=16, n_steps=24, batch_size=24, epochs=3, episode_len=11, ent_coef=0.01)
+    o = oracle_mod.Oracle(cfg)
+    flat = _params(o.P, 7, 0.3); o.set_params(flat); o.env_reset(5); o.collect_rollout()
+    res = []
+    for chunk in (None, "5"):
+        if chunk: monkeypatch.setenv("DRIL_SMALL_CHUNK", chunk)
+        h = pkg.Handle(cfg); h.set_params(flat)
+        for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+            h.set_buffer(which, o.buffer(which))
+        sts = [h.ppo_update(), h.ppo_update()]                                        # twice: the device DataLoader order, update counter 0 and 1
+        assert h.grad_kernel_info().split(":")[0] == "ppo_update_small_kernel" and sts[0].n_updates == 48
+        res.append((h.get_params(), [(st.loss, st.grad_norm, st.approx_kl_div) for st in sts]))
+        h.close()
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
