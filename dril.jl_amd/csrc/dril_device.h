@@ -64,7 +64,28 @@ __host__ __device__ inline uint64_t mix_bij(uint64_t x, uint64_t key, int bits) 
     }
     return x;
 }
+// the same map in 32-bit arithmetic for bits <= 32 (every buffer up to 4 G samples): the low `bits` bits of a product / sum depend only on the low bits of the
+// operands, so truncating the constants and working modulo 2^32 gives the identical permutation — with one v_mul_lo_u32 per multiply instead of the four
+// quarter-rate multiplies + carries of an emulated 64-bit product (the gather of every update kernel evaluates this once per lane and tile: ~1 000 -> ~250 cycles)
+__host__ __device__ inline uint32_t mix_bij32(uint32_t x, uint64_t key, int bits) {
+    const uint32_t mask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+    const int s = bits / 2 > 0 ? bits / 2 : 1, s2 = s + 1 < bits ? s + 1 : s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        x ^= (uint32_t)(key >> (r * 13)) & mask;
+        x = (x * 0x7F4A7C15u + 0xD192ED03u) & mask;
+        x ^= x >> s;
+        x = (x * 0x1CE4E5B9u) & mask;
+        x ^= x >> s2;
+    }
+    return x;
+}
 __host__ __device__ inline int64_t perm_index(int64_t p, int64_t n, uint64_t key, int bits) {
+    if (bits <= 32) {
+        uint32_t x = (uint32_t)p;
+        do { x = mix_bij32(x, key, bits); } while ((int64_t)x >= n);
+        return (int64_t)x;
+    }
     uint64_t x = (uint64_t)p;
     do { x = mix_bij(x, key, bits); } while ((int64_t)x >= n);
     return (int64_t)x;
@@ -98,8 +119,33 @@ __host__ __device__ inline uint64_t mix_bij_inv(uint64_t x, uint64_t key, int bi
     }
     return x;
 }
+__host__ __device__ inline uint32_t unxorshift32(uint32_t y, int s, int bits) {
+    uint32_t x = y;
+    for (int sh = s; sh < bits; sh += s) x ^= y >> sh;
+    return x;
+}
+__host__ __device__ inline uint32_t mix_bij_inv32(uint32_t x, uint64_t key, int bits) {   // inverse of mix_bij32 (the inverses modulo 2^64 reduce to those modulo 2^32)
+    const uint32_t mask = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+    const int s = bits / 2 > 0 ? bits / 2 : 1;
+    const int s2 = s + 1 < bits ? s + 1 : s;
+    constexpr uint32_t I1 = (uint32_t)mul_inverse(0x9E3779B97F4A7C15ull), I2 = (uint32_t)mul_inverse(0xBF58476D1CE4E5B9ull);
+#pragma unroll
+    for (int r = 3; r >= 0; --r) {
+        x = unxorshift32(x, s2, bits);
+        x = (x * I2) & mask;
+        x = unxorshift32(x, s, bits);
+        x = ((x - 0xD192ED03u) * I1) & mask;
+        x ^= (uint32_t)(key >> (r * 13)) & mask;
+    }
+    return x;
+}
 // position in the epoch order of buffer index idx (inverse of perm_index; cycle walking inverts by walking backwards)
 __host__ __device__ inline int64_t perm_position(int64_t idx, int64_t n, uint64_t key, int bits) {
+    if (bits <= 32) {
+        uint32_t x32 = (uint32_t)idx;
+        do { x32 = mix_bij_inv32(x32, key, bits); } while ((int64_t)x32 >= n);
+        return (int64_t)x32;
+    }
     uint64_t x = (uint64_t)idx;
     do { x = mix_bij_inv(x, key, bits); } while ((int64_t)x >= n);
     return (int64_t)x;
@@ -454,15 +500,28 @@ __device__ __forceinline__ void dense_first(const float* __restrict__ W1T, const
 }
 
 // stage-wise over the 16 registers of a tile so the five dependent ops of one element interleave with the other
-// fifteen (the element-by-element form left s_nop bubbles after every v_exp/v_rcp: stamps, profiles/r01_v3)
+// fifteen (the element-by-element form left s_nop bubbles after every v_exp/v_rcp: stamps, profiles/r01_v3).
+// Element-wise loops, not f32x16 arithmetic: a vector expression is legalised into v_pk_add_f32 / v_pk_fma_f32 whatever -fno-slp-vectorize says, and beside MFMAs
+// the packed forms are the slower ones (MI355X_MICROARCH.md; ppo_grad_pair_kernel, same box, alternating runs: 149.6 / 150.2 packed vs 151.1 / 152.8 TFLOP/s scalar)
 __device__ __forceinline__ void tanh16(f32x16& x) {
     f32x16 t;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t[i] = __builtin_amdgcn_exp2f(x[i]);        // x is pre-scaled by kTanhScale
-    t = t + 1.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = t[i] + 1.0f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t[i] = __builtin_amdgcn_rcpf(t[i]);
-    x = 1.0f - 2.0f * t;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = fmaf(-2.0f, t[i], 1.0f);
+}
+// acc += s * x and acc += x on sixteen registers, as scalar v_fma_f32 / v_add_f32 (see tanh16)
+__device__ __forceinline__ void fma16(f32x16& acc, float s, const f32x16& x) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = fmaf(s, x[i], acc[i]);
+}
+__device__ __forceinline__ void add16(f32x16& acc, const f32x16& x) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = acc[i] + x[i];
 }
 template <int M> __device__ __forceinline__ void tanh_tiles(f32x16 (&X)[M]) {
 #pragma unroll

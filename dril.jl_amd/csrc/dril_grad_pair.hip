@@ -185,7 +185,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
 #pragma unroll
         for (int o = 0; o < O; ++o) {
             if (h == 0 && w == 0) db3p[o] += dz[o];
-            dW3acc[o] += dz[o] * h2w;                                                  // dW3[o][unit] += dz[o][sample] h2[unit][sample]: the lane IS the sample
+            fma16(dW3acc[o], dz[o], h2w);                                                  // dW3[o][unit] += dz[o][sample] h2[unit][sample]: the lane IS the sample
         }
         // ---- dz2 tile w (in h2w's registers); db2; its pieces into the pair's image ----
 #pragma unroll
@@ -200,7 +200,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * fmaf(-hv, hv, 1.0f); }
         }
-        db2acc += h2w;
+        add16(db2acc, h2w);
         store_tile_pieces<64>(P2, w, h2w, opaque(lane));
         STAMP(4);
         __syncthreads();                                                              // B3: the pair's dz2 image complete
@@ -231,8 +231,8 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             const float xo0 = __shfl_xor(xk[0], 32), xo1 = __shfl_xor(xk[1], 32);      // the other half holds x[2s + 1 - h]
             const float x4[4] = {h ? xo0 : xk[0], h ? xk[0] : xo0, h ? xo1 : xk[1], h ? xk[1] : xo1};
 #pragma unroll
-            for (int d = 0; d < D; ++d) dW1acc[d] += x4[d] * g1;
-            db1acc += g1;
+            for (int d = 0; d < D; ++d) fma16(dW1acc[d], x4[d], g1);
+            add16(db1acc, g1);
         }
         // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the pair's images) ----
         {

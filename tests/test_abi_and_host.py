@@ -166,3 +166,17 @@ def test_sac_struct_layout_and_defaults(pkg, tmp_path):
     h = C.c_void_p()
     assert lib.dril_sac_create(None, C.byref(h)) == pkg._capi.ERR_INVALID_ARG
     assert b"null" in lib.dril_sac_last_error(None)
+
+
+def test_keyed_bijection_32bit_form(tmp_path):
+    """the DataLoader order of the device (perm_index / perm_position, dril_device.h) has a 32-bit fast path for buffers of up to 2^32 samples: it must be the
+    SAME permutation as the 64-bit form (and its inverse the same inverse), for every width and for ragged sizes with cycle walking"""
+    import subprocess
+    root = Path(__file__).resolve().parents[1]
+    src = (root / "dril.jl_amd" / "csrc" / "dril_device.h").read_text()
+    a = src.index("// keyed bijection on [0, n)"); b = src.index("// ---------------------------------------------------------------------------------------------\n// math")
+    (tmp_path / "perm32_extract.inc").write_text(src[a:b])
+    exe = tmp_path / "perm32_check"
+    subprocess.run(["g++", "-O2", "-I", str(tmp_path), "-o", str(exe), str(root / "tests" / "perm32_check.cpp")], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout + r.stderr
