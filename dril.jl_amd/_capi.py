@@ -133,6 +133,8 @@ _SIG = {
     "dril_set_params": (C.c_int32, [_P, _P, C.c_size_t]),
     "dril_get_params": (C.c_int32, [_P, _P, C.c_size_t]),
     "dril_reset_optimizer": (C.c_int32, [_P]),
+    "dril_get_optimizer_state": (C.c_int32, [_P, _P, _P, C.c_size_t, _P, C.POINTER(C.c_int64)]),
+    "dril_set_optimizer_state": (C.c_int32, [_P, _P, _P, C.c_size_t, _P, C.c_int64]),
     "dril_set_learning_rate": (C.c_int32, [_P, C.c_float]),
     "dril_env_reset": (C.c_int32, [_P, C.c_uint64]),
     "dril_env_observe": (C.c_int32, [_P, _P, C.c_int32]),

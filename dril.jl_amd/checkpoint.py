@@ -62,11 +62,16 @@ def save_policy_params_and_state(agent, path, suffix: str = ".npz") -> str:
 
 def load_policy_params_and_state_(agent, alg, path, suffix: str = ".npz"):
     """load_policy_params_and_state!(agent, alg, path) (ppo.jl:77-94): parameters and aux replace the agent's and a NEW TrainState is built
-    (`Lux.Training.TrainState(layer, parameters, states, make_optimizer(alg))` :88-91) — the Adam moments are not restored.  The device handle
-    keys its optimiser state to the TrainState object, so the next train_ on ANY already-bound env starts from zero moments (host._claim_optimizer)"""
+    (`Lux.Training.TrainState(layer, parameters, states, make_optimizer(alg))` :88-91) — the Adam moments are not restored: the new TrainState carries
+    optimizer_state = None and the next train_ starts from zero moments on whatever env it runs.  `agent.layer = data["layer"]` (ppo.jl:90): the stored layer
+    description must describe the agent's layer — a checkpoint of another architecture raises instead of loading into mismatched shapes"""
     file_path = str(path) if str(path).endswith(suffix) else str(path) + suffix
     data = np.load(file_path, allow_pickle=False)
     params = _unflatten("parameters", data)
+    stored, mine = json.loads(str(data["layer"])), json.loads(_layer_desc(agent.layer))
+    for k in ("type", "hidden_dims", "activation"):
+        if k in stored and k in mine and stored[k] != mine[k]:
+            raise ValueError(f"checkpoint {file_path} was written for a layer with {k} = {stored[k]!r}; this agent's layer has {mine[k]!r} (ppo.jl:90 replaces agent.layer with the stored one)")
     if hasattr(agent, "train_state"):
         agent.train_state = type(agent.train_state)(parameters=params, step=0)
     else:

@@ -621,6 +621,27 @@ DRIL_EXPORT int32_t dril_get_params(dril_handle* h, float* flat, size_t n) {
 }
 DRIL_EXPORT int32_t dril_reset_optimizer(dril_handle* h) { NEED(h); return reset_optimizer(h); }
 DRIL_EXPORT int32_t dril_set_learning_rate(dril_handle* h, float lr) { NEED(h); h->lr = lr; return DRIL_OK; }
+DRIL_EXPORT int32_t dril_get_optimizer_state(dril_handle* h, float* m, float* v, size_t n, float* beta_powers, int64_t* steps) {
+    NEED(h);
+    if (!m || !v || !beta_powers || n != (size_t)h->P) return fail(h, DRIL_ERR_INVALID_ARG, "dril_get_optimizer_state: n != dril_param_count or null pointer");
+    float bt[4];
+    HIPCHK(h, hipMemcpyAsync(m, h->adam_m, n * 4, hipMemcpyDeviceToHost, h->stream)); HIPCHK(h, hipMemcpyAsync(v, h->adam_v, n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(bt, h->bt, sizeof(bt), hipMemcpyDeviceToHost, h->stream));
+    int rc = sync(h); if (rc) return rc;
+    const int slot = 2 * (int)(h->adam_steps & 1);                                     // the slot the NEXT step reads (ping-pong)
+    beta_powers[0] = bt[slot]; beta_powers[1] = bt[slot + 1];
+    if (steps) *steps = h->adam_steps;
+    return DRIL_OK;
+}
+DRIL_EXPORT int32_t dril_set_optimizer_state(dril_handle* h, const float* m, const float* v, size_t n, const float* beta_powers, int64_t steps) {
+    NEED(h);
+    if (!m || !v || !beta_powers || n != (size_t)h->P || steps < 0) return fail(h, DRIL_ERR_INVALID_ARG, "dril_set_optimizer_state: n != dril_param_count, null pointer or negative step count");
+    const float bt[4] = {beta_powers[0], beta_powers[1], beta_powers[0], beta_powers[1]};
+    HIPCHK(h, hipMemcpyAsync(h->adam_m, m, n * 4, hipMemcpyHostToDevice, h->stream)); HIPCHK(h, hipMemcpyAsync(h->adam_v, v, n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->bt, bt, sizeof(bt), hipMemcpyHostToDevice, h->stream));
+    h->adam_steps = steps;
+    return sync(h);
+}
 
 // ---- env verbs -----------------------------------------------------------------------------------
 DRIL_EXPORT int32_t dril_env_reset(dril_handle* h, uint64_t seed) {

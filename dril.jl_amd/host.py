@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import sys
 import time
 from dataclasses import dataclass, field, asdict
 from typing import Optional, Sequence
@@ -294,8 +295,13 @@ def unflatten_params(flat: np.ndarray, like: dict) -> dict:
 
 @dataclass
 class TrainState:
+    """Lux.Training.TrainState (ppo.jl:52-53): parameters + optimizer_state.  optimizer_state is the Adam leaf state of Optimisers.jl flattened in the parameter
+    layout — {"m", "v": float32 (P), "beta_powers": (beta1^t, beta2^t), "steps": t} — or None for a fresh optimiser (what `Agent(...)` and
+    load_policy_params_and_state! build, ppo.jl:77-94).  train_ moves it into the device handle on entry and back on every exit, so the moments follow the
+    TrainState from env to env and through a re-created handle, as they follow the Julia object."""
     parameters: dict
     step: int = 0
+    optimizer_state: Optional[dict] = None
 
 
 @dataclass
@@ -418,6 +424,20 @@ class Handle:
 
     def reset_optimizer(self):
         self._chk(self.lib.dril_reset_optimizer(self._h))
+
+    def get_optimizer_state(self) -> dict:
+        m, v, bp, steps = np.empty(self.P, np.float32), np.empty(self.P, np.float32), np.empty(2, np.float32), C.c_int64()
+        self._chk(self.lib.dril_get_optimizer_state(self._h, self._p(m), self._p(v), m.size, self._p(bp), C.byref(steps)))
+        return {"m": m, "v": v, "beta_powers": (float(bp[0]), float(bp[1])), "steps": int(steps.value)}
+
+    def set_optimizer_state(self, st: Optional[dict]):
+        if st is None:
+            return self.reset_optimizer()
+        m, v = np.ascontiguousarray(st["m"], np.float32), np.ascontiguousarray(st["v"], np.float32)
+        if m.size != self.P or v.size != self.P:
+            raise ValueError(f"optimizer_state holds {m.size} parameters, the layer has {self.P}: it belongs to another layer")
+        bp = np.asarray(st["beta_powers"], np.float32)
+        self._chk(self.lib.dril_set_optimizer_state(self._h, self._p(m), self._p(v), m.size, self._p(bp), int(st["steps"])))
 
     def set_learning_rate(self, lr: float):
         self._chk(self.lib.dril_set_learning_rate(self._h, lr))
@@ -976,7 +996,7 @@ def train_(agent: Agent, env: DeviceParallelEnv, alg: PPO, max_steps: int, callb
     t0 = time.perf_counter()
     h = env.bind(alg, agent.layer)
     h.set_params(flatten_params(agent.train_state.parameters))
-    _claim_optimizer(h, agent)
+    h.set_optimizer_state(agent.train_state.optimizer_state)                                   # the TrainState owns the Adam moments (ppo.jl:52-53), not the env's handle
     per_iter = alg.n_steps * env.n_envs * h.cfg.world_size
     iterations = max_steps // per_iter  # ppo.jl:117
     timer["setup"] = time.perf_counter() - t0
@@ -985,6 +1005,7 @@ def train_(agent: Agent, env: DeviceParallelEnv, alg: PPO, max_steps: int, callb
     loc.update(agent=agent, env=env, alg=alg, iterations=iterations, total_steps=iterations * per_iter, max_steps=max_steps, n_steps=alg.n_steps,
                n_envs=env.n_envs, roll_buffer=None, total_fps=learn_stats["fps"], callbacks=cbs, learn_stats=learn_stats)
     prof0 = h.profile() if h.cfg.profile_events else None
+    primary = None
     try:
         if not hook("on_training_start", loc):
             return None
@@ -1030,10 +1051,19 @@ def train_(agent: Agent, env: DeviceParallelEnv, alg: PPO, max_steps: int, callb
         if not hook("on_training_end", loc):
             return None
         return learn_stats, timer
+    except BaseException as e:
+        primary = e
+        raise
     finally:
         # the reference mutates agent.train_state in place at every optimiser step (ppo.jl:239), so after an early stop by a callback
         # (ppo.jl:145-152,170-176) the agent holds the partially trained weights: every exit path copies the device parameters back
-        agent.train_state.parameters = unflatten_params(h.get_params(), agent.train_state.parameters)
+        # (guarded: a device error on the way out must not mask the exception that brought us here)
+        try:
+            agent.train_state.parameters = unflatten_params(h.get_params(), agent.train_state.parameters)
+            agent.train_state.optimizer_state = h.get_optimizer_state()
+        except DrilError:
+            if primary is None:
+                raise
 
 
 # keys of Base.@locals the reference's callback test reads (test/test_callbacks.jl:25-27 at training start, :36-39 at rollout start);
@@ -1054,15 +1084,6 @@ def _timer_sections(h: Handle, prof0, t_upd: float) -> dict:
     grad = ms("adv_moments_kernel", "ppo_grad_kernel", "grad_reduce_kernel", "ncclAllReduce")
     apply = ms("adam_kernel")
     return {"batch loop": grad + apply, "compute_gradients": grad, "apply_gradients": apply}
-
-
-def _claim_optimizer(h: Handle, agent) -> None:
-    """The device handle holds the Adam moments that belong to ONE TrainState (Lux.Training.TrainState carries optimizer_state, ppo.jl:52-53).
-    A different TrainState on the same handle — a fresh agent, or the new TrainState load_policy_params_and_state! builds (ppo.jl:77-94) — starts
-    from a fresh optimiser; consecutive train_ calls on the same TrainState keep their moments, like the reference"""
-    if getattr(h, "_opt_owner", None) is not agent.train_state:
-        h.reset_optimizer()
-        h._opt_owner = agent.train_state
 
 
 def evaluate_agent(agent: Agent, env: DeviceParallelEnv, n_eval_episodes: int = 10, deterministic: bool = True,

@@ -181,6 +181,12 @@ int32_t dril_set_params(dril_handle* h, const float* flat, size_t n);
 int32_t dril_get_params(dril_handle* h, float* flat, size_t n);
 /* fresh optimiser state (load_policy_params_and_state! rebuilds Adam, ppo.jl:77-94) */
 int32_t dril_reset_optimizer(dril_handle* h);
+/* the optimiser state itself — what Lux.Training.TrainState carries as optimizer_state between train! calls (ppo.jl:52-53,239; Optimisers.Adam leaf state
+ * (mt, vt, betat)): first and second moments in the parameter layout of dril_get_params, the running products (beta1^t, beta2^t) and the number of applied
+ * steps.  The handle keeps this state between dril_train / dril_ppo_update calls; get / set move it with a TrainState from one handle to another (another
+ * env, a re-created handle).  n = dril_param_count; beta_powers = 2 floats. */
+int32_t dril_get_optimizer_state(dril_handle* h, float* m, float* v, size_t n, float* beta_powers, int64_t* steps);
+int32_t dril_set_optimizer_state(dril_handle* h, const float* m, const float* v, size_t n, const float* beta_powers, int64_t steps);
 /* Optimisers.adjust!(train_state, lr) ppo.jl:155-156 */
 int32_t dril_set_learning_rate(dril_handle* h, float lr);
 

@@ -204,3 +204,59 @@ def test_unnormalize_round_trips(pkg):
     un = pkg.unnormalize_rewards_(last.copy(), env)
     assert np.abs(un - last_original).max() < 1e-4
     assert (last_original <= 0).all() and (last_original > -17).all()              # Pendulum costs
+
+
+def test_optimizer_state_follows_the_train_state_across_envs(pkg, tmp_path):
+    """Lux.Training.TrainState carries optimizer_state (ppo.jl:52-53,239): the SAME agent trained on env A, then on env B, continues with its Adam moments — it does
+    not restart from zero because the handle changed (round-2 advisor).  A TrainState without optimizer_state (a loaded checkpoint, ppo.jl:88-91) starts cold and
+    ends somewhere else.  A checkpoint written for another architecture is refused (ppo.jl:90 replaces agent.layer with the stored one; here the shapes would
+    silently mismatch)."""
+    import copy
+    alg = pkg.PPO(n_steps=16, batch_size=64, epochs=2, learning_rate=1e-3)
+    E = 16
+    mk_env = lambda: pkg.DeviceParallelEnv(pkg.CartPoleEnv(max_steps=50), E, seed=9)
+    mk_agent = lambda: pkg.Agent(pkg.ActorCriticLayer(pkg.CartPoleEnv().observation_space(), pkg.CartPoleEnv().action_space()), alg, seed=4)
+    per = alg.n_steps * E
+    agent = mk_agent()
+    assert agent.train_state.optimizer_state is None
+    assert pkg.train_(agent, mk_env(), alg, per) is not None
+    st1 = agent.train_state.optimizer_state
+    assert st1["steps"] == 2 * 4 and np.abs(st1["m"]).max() > 0 and st1["beta_powers"] == pytest.approx((0.9 ** 9, 0.999 ** 9), rel=1e-5)
+    cold = copy.deepcopy(agent); cold.train_state.optimizer_state = None            # same weights, fresh optimiser
+    assert pkg.train_(agent, mk_env(), alg, per) is not None                        # a NEW env = a new handle: the moments arrive with the TrainState
+    assert pkg.train_(cold, mk_env(), alg, per) is not None                         # identical env, identical rollout (same weights, same seed), zero moments
+    st2 = agent.train_state.optimizer_state
+    assert st2["steps"] == 16 and st2["beta_powers"] == pytest.approx((0.9 ** 17, 0.999 ** 17), rel=1e-5)
+    assert cold.train_state.optimizer_state["steps"] == 8
+    warm_p, cold_p = pkg.flatten_params(agent.train_state.parameters), pkg.flatten_params(cold.train_state.parameters)
+    assert np.isfinite(warm_p).all() and np.abs(warm_p - cold_p).max() > 1e-4        # the carried moments changed the update
+
+    small = pkg.Agent(pkg.ActorCriticLayer(pkg.CartPoleEnv().observation_space(), pkg.CartPoleEnv().action_space(), hidden_dims=(32, 32)), alg, seed=1)
+    path = pkg.save_policy_params_and_state(small, tmp_path / "small")
+    with pytest.raises(ValueError):
+        pkg.load_policy_params_and_state_(mk_agent(), alg, path)
+    loaded = pkg.load_policy_params_and_state_(mk_agent(), alg, pkg.save_policy_params_and_state(agent, tmp_path / "agent"))
+    assert loaded.train_state.optimizer_state is None                               # ppo.jl:88-91: a fresh optimiser
+
+
+def test_optimizer_state_round_trip_through_the_abi(pkg, oracle_mod):
+    """dril_get_optimizer_state / dril_set_optimizer_state: moments, beta powers and step count move to a second handle, which then continues bit-identically"""
+    capi = pkg._capi
+    cfg = capi.default_config(0); cfg.n_envs, cfg.n_steps, cfg.batch_size, cfg.epochs, cfg.episode_len = 16, 24, 128, 3, 11
+    o = oracle_mod.Oracle(cfg)
+    flat = (np.random.default_rng(5).standard_normal(o.P) * 0.3).astype(np.float32); o.set_params(flat); o.env_reset(5); o.collect_rollout()
+    bufs = (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES)
+    perm = np.stack([np.random.default_rng(e).permutation(16 * 24) for e in range(3)]).astype(np.int64)
+    def fresh():
+        h = pkg.Handle(cfg); h.set_params(flat)
+        for w in bufs: h.set_buffer(w, o.buffer(w))
+        h.set_permutation(perm)
+        return h
+    a = fresh(); a.ppo_update(); st = a.get_optimizer_state(); p1 = a.get_params(); a.ppo_update(); want = a.get_params()
+    assert st["steps"] == 9 and st["beta_powers"] == pytest.approx((0.9 ** 10, 0.999 ** 10), rel=1e-5)
+    b = fresh(); b.set_params(p1); b.set_optimizer_state(st); b.ppo_update()
+    np.testing.assert_array_equal(b.get_params(), want)
+    c = fresh(); c.set_params(p1); c.ppo_update()                                   # zero moments from the same weights: a different result
+    assert not np.array_equal(c.get_params(), want)
+    with pytest.raises(ValueError):
+        b.set_optimizer_state({"m": st["m"][:-1], "v": st["v"][:-1], "beta_powers": st["beta_powers"], "steps": 1})
