@@ -277,6 +277,9 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     if world > 1:
+        # RCCL across processes needs dmabuf IPC on this platform (legacy IPC: hipIpcGetMemHandle "invalid argument"); ROCr reads this at its initialisation, i.e.
+        # before the library's first HIP call — dril_create sets it too when it is the process's first HIP user (README "Multi-GPU")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist  # rendezvous / barrier only; never touches torch.cuda
         dist.init_process_group("gloo", rank=rank, world_size=world)
 

@@ -521,6 +521,11 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     h->no_persistent = std::getenv("DRIL_NO_PERSISTENT_UPDATE") != nullptr;
     if (const char* e = std::getenv("DRIL_SMALL_CHUNK")) { const long c = std::atol(e); if (c > 0) h->small_chunk = c; }   // optimiser steps per launch of ppo_update_small_kernel (tests: launch boundaries)
     h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
+    // Multi-process RCCL on this platform needs dmabuf IPC: with the legacy IPC mode (the ROCr default) `hipIpcGetMemHandle` fails with "invalid argument" on a
+    // host driver that only supports dmabuf, and ncclCommInitRank / the first collective across processes dies with it.  The ROCr runtime reads the variable
+    // when it initialises, i.e. at this process's first HIP call — which for a DRiL user is normally the hipSetDevice below.  It is only set if the caller left it
+    // unset (bench.py and the tests export it themselves; a process that already touched HIP before dril_create must export it on its own: README "Multi-GPU").
+    if (cfg->world_size > 1) setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", /*overwrite=*/0);
 #define CCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_destroy(h); return fail(nullptr, DRIL_ERR_HIP, m); } } while (0)
     CCHK(hipSetDevice(cfg->device));
     hipDeviceProp_t prop; CCHK(hipGetDeviceProperties(&prop, cfg->device));

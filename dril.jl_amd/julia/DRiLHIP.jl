@@ -10,7 +10,8 @@
 #     agent = Agent(layer, alg; verbose = 0)
 #     learn_stats, to = train!(agent, env, alg, 10 * 2048 * 65_536)
 #
-# STATUS: EXPERIMENTAL — the build image has no Julia runtime, so this file has never executed.  What stands in for a run: tools/check_shim.py (parses this
+# Files: this one (C structs, DeviceParallelEnv, parameters, collect_rollout! / train! for PPO) + DRiLHIP_host_envs.jl (OnDevice) + DRiLHIP_extras.jl + DRiLHIP_sac.jl.
+# STATUS: EXPERIMENTAL — the build image has no Julia runtime, so these files have never executed (runtests.jl beside them is the first thing to run).  What stands in for a run: tools/check_shim.py (parses this
 # file and the reference's sources: per-argument method specificity of every method added to a DRiL generic function, the callback-locals keys against
 # test/test_callbacks.jl and the Python mirror, every ccall symbol against include/*.h) and the Python ctypes mirror (dril.jl_amd/host.py), which drives
 # the same C symbols in the same order under tests/ on the GPU.  A maintainer with Julia should first run the CI snippet of INTEGRATION.md §7.
@@ -249,6 +250,51 @@ function pull_params!(env, agent)
     GC.@preserve flat check(ccall((:dril_get_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), env.handle, flat, length(flat)), env.handle)
     scatter_params!(agent.train_state.parameters, flat)
 end
+# ---- optimiser state: Lux.Training.TrainState.optimizer_state <-> dril_get/set_optimizer_state ----
+# Optimisers.setup(Adam(...), ps) mirrors the parameter tree with `Leaf(rule, state)` nodes; Adam's leaf state is `(mt, vt, betat)` with betat = (beta1^t, beta2^t)
+# STARTING at (beta1, beta2) (Optimisers.jl `init(o::Adam, x) = (zero(x), zero(x), o.beta)`), i.e. exactly the library's `beta_powers`.  The moments are
+# flattened in the order of flatten_params.  Anything that does not look like that (another rule, a frozen leaf, a different Optimisers layout) makes
+# `adam_leaves` return nothing and the shim falls back to the ownership rule below: a handle keeps its moments for the TrainState it last trained.
+function adam_leaves(agent)
+    os = agent.train_state.optimizer_state; ps = agent.train_state.parameters
+    leaves = Any[]
+    try
+        for (hp, ho) in ((mlp_of(ps.actor_head), mlp_of(os.actor_head)), (mlp_of(ps.critic_head), mlp_of(os.critic_head))), l in dense_keys(hp)
+            push!(leaves, getproperty(ho, l).weight); push!(leaves, getproperty(ho, l).bias)
+        end
+        haskey(ps, :log_std) && push!(leaves, os.log_std)
+        all(lf -> hasproperty(lf, :state) && lf.state isa Tuple && length(lf.state) == 3 && lf.state[3] isa Tuple, leaves) || return nothing
+    catch
+        return nothing
+    end
+    return leaves
+end
+function push_optimizer_state!(env, agent)
+    leaves = adam_leaves(agent)
+    leaves === nothing && return false
+    m = reduce(vcat, [vec(Float32.(lf.state[1])) for lf in leaves]); v = reduce(vcat, [vec(Float32.(lf.state[2])) for lf in leaves])
+    bt = Float32[leaves[1].state[3][1], leaves[1].state[3][2]]
+    b1 = Float32(agent.alg isa PPO ? 0.9 : 0.9)                                   # Optimisers.Adam default beta (ppo.jl:64-66 passes eta and epsilon only)
+    steps = bt[1] >= b1 ? Int64(0) : Int64(round(log(bt[1]) / log(b1))) - 1         # betat = beta^(t + 1)
+    GC.@preserve m v bt check(ccall((:dril_set_optimizer_state, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Csize_t, Ptr{Float32}, Int64),
+        env.handle, m, v, length(m), bt, max(steps, 0)), env.handle)
+    return true
+end
+function pull_optimizer_state!(env, agent)
+    leaves = adam_leaves(agent)
+    leaves === nothing && return false
+    n = ccall((:dril_param_count, LIB[]), Int64, (Ptr{Cvoid},), env.handle)
+    m = Vector{Float32}(undef, n); v = Vector{Float32}(undef, n); bt = Vector{Float32}(undef, 2); steps = Ref{Int64}(0)
+    GC.@preserve m v bt check(ccall((:dril_get_optimizer_state, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Csize_t, Ptr{Float32}, Ref{Int64}),
+        env.handle, m, v, n, bt, steps), env.handle)
+    off = 0
+    for lf in leaves
+        mt, vt, _ = lf.state; k = length(mt)
+        copyto!(mt, 1, m, off + 1, k); copyto!(vt, 1, v, off + 1, k); off += k
+        lf.state = (mt, vt, (oftype(lf.state[3][1], bt[1]), oftype(lf.state[3][2], bt[2])))      # Leaf is a mutable struct (Optimisers >= 0.3)
+    end
+    return true
+end
 function bind_agent!(env::DeviceParallelEnv, agent, alg::PPO)
     act = check_supported_layer(agent)
     ps = agent.train_state.parameters
@@ -351,10 +397,13 @@ function train!(agent::PPOAgent, env::DeviceParallelEnv, alg::PPO{T}, max_steps:
         bind_agent!(env, agent, alg); push_params!(env, agent)
         # the handle's Adam moments belong to ONE TrainState (Lux.Training.TrainState carries optimizer_state, ppo.jl:52-53): a different one — another agent, or
         # the TrainState load_policy_params_and_state! rebuilds (ppo.jl:77-94) — starts from a fresh optimiser; repeated train! calls on the same one continue
-        if env.optimizer_owner !== agent.train_state
+        # The Adam moments belong to the TrainState (Lux.Training.TrainState carries optimizer_state, ppo.jl:52-53,239): they are pushed into the handle here and
+        # pulled back on every exit, so they follow the agent from env to env.  If the optimiser tree is not the Adam tree this shim understands, the older rule
+        # applies: the handle keeps the moments of the TrainState it last trained and any other TrainState starts from a fresh optimiser (ppo.jl:77-94).
+        if !push_optimizer_state!(env, agent) && env.optimizer_owner !== agent.train_state
             check(ccall((:dril_reset_optimizer, LIB[]), Int32, (Ptr{Cvoid},), env.handle), env.handle)
-            env.optimizer_owner = agent.train_state
         end
+        env.optimizer_owner = agent.train_state
         ccall((:dril_profile_reset, LIB[]), Int32, (Ptr{Cvoid},), env.handle)
         iterations = max_steps ÷ (n_steps * n_envs)                    # ppo.jl:117
         iterations == 0 && @warn "max_steps is less than n_steps * n_envs; there will be no training."
@@ -404,431 +453,14 @@ function train!(agent::PPOAgent, env::DeviceParallelEnv, alg::PPO{T}, max_steps:
         # the reference mutates agent.train_state in place at every optimiser step (ppo.jl:239): after ANY exit — normal, or a callback that stopped the run
         # (ppo.jl:145-152,170-176) — the agent holds the weights trained so far
         pull_params!(env, agent)
+        pull_optimizer_state!(env, agent)
     end
 end
 
-# =============================================================================================================================
-# Host envs: ANY AbstractParallelEnv of the caller (their own Julia envs in a MultiThreadedParallelEnv / BroadcastedParallelEnv, wrapped or not)
-# with the agent on the device — DRIL_ENV_EXTERNAL (include/dril_hip.h): observations go in and actions come out once per env step
-# (dril_ext_act / dril_ext_record / dril_ext_finish); policy forward, sampling, the rollout buffer, bootstrap values, GAE and the PPO update
-# run on the GPU for any observation / action / hidden width.
-#     env = OnDevice(MultiThreadedParallelEnv([MyEnv() for _ in 1:64]))
-#     train!(agent, env, alg, max_steps)
-# =============================================================================================================================
-mutable struct OnDevice{E <: AbstractParallelEnv} <: AbstractParallelEnv
-    env::E
-    seed::UInt64
-    device::Int
-    handle::Ptr{Cvoid}
-    bound::Any
-    optimizer_owner::Any
-end
-function OnDevice(env::AbstractParallelEnv; seed::Integer = 42, device::Integer = 0)
-    w = OnDevice(env, UInt64(seed), Int(device), C_NULL, nothing, nothing)
-    finalizer(e -> (e.handle != C_NULL && ccall((:dril_destroy, LIB[]), Int32, (Ptr{Cvoid},), e.handle); nothing), w)
-    return w
-end
-# the env verbs pass straight through, so every generic DRiL caller (evaluate_agent, callbacks, wrappers) keeps working on the wrapped env
-number_of_envs(w::OnDevice) = number_of_envs(w.env)
-observation_space(w::OnDevice) = observation_space(w.env)
-action_space(w::OnDevice) = action_space(w.env)
-reset!(w::OnDevice) = reset!(w.env)
-observe(w::OnDevice) = observe(w.env)
-act!(w::OnDevice, actions::AbstractVector) = act!(w.env, actions)
-DRiL.log_stats(w::OnDevice, logger::DRiL.AbstractTrainingLogger) = DRiL.log_stats(w.env, logger)
 
-function make_config(w::OnDevice, alg::PPO, hidden::Vector{Int}, log_std_init::Float32, act::Int32 = Int32(0))
-    opt(x) = isnothing(x) ? (0.0f0, Int32(0)) : (Float32(x), Int32(1))
-    cvf, hcvf = opt(alg.clip_range_vf); mgn, hmgn = opt(alg.max_grad_norm); tkl, htkl = opt(alg.target_kl)
-    osp, asp = observation_space(w), action_space(w)
-    disc = asp isa Discrete
-    lo, hi = disc ? (0.0f0, 0.0f0) : (Float32(minimum(asp.low)), Float32(maximum(asp.high)))
-    uniform = !disc && all(==(lo), asp.low) && all(==(hi), asp.high)   # one (low, high) pair: ClampAdapter on the device; otherwise clamped in the rollout loop below
-    return DrilConfig(ABI_VERSION, Int32(5), number_of_envs(w), alg.n_steps, hidden[1], hidden[min(2, end)], 0, Int32(0), disc ? Int32(asp.start) : Int32(1),
-        alg.gamma, alg.gae_lambda, alg.clip_range, cvf, hcvf, alg.ent_coef, alg.vf_coef, mgn, hmgn, tkl, htkl, Int32(alg.normalize_advantage),
-        alg.batch_size, alg.epochs, alg.learning_rate, 0.9f0, 0.999f0, 1.0f-5, log_std_init, 0, 0, 0, 10.0f0, 10.0f0, 0.99f0, 1.0f-8,
-        w.seed, w.device, 0, 1, 0, 0, Int32(prod(size(osp))), Int32(disc ? asp.n : prod(size(asp))), Int32(disc),
-        uniform ? lo : 0.0f0, uniform ? hi : 0.0f0, layer_fields(hidden, act)..., ntuple(_ -> Int32(0), 1))
-end
-function bind_agent!(w::OnDevice, agent, alg::PPO)
-    act = check_supported_layer(agent)
-    ps = agent.train_state.parameters
-    ls = haskey(ps, :log_std) ? Float32(ps.log_std[1]) : 0.0f0
-    key = (alg, hidden_dims_of(ps), ls, act)
-    if w.handle == C_NULL || w.bound != key
-        w.handle != C_NULL && ccall((:dril_destroy, LIB[]), Int32, (Ptr{Cvoid},), w.handle)
-        cfg = Ref(make_config(w, alg, key[2], ls, act)); h = Ref{Ptr{Cvoid}}(C_NULL)
-        check(ccall((:dril_create, LIB[]), Int32, (Ref{DrilConfig}, Ref{Ptr{Cvoid}}), cfg, h))
-        w.handle = h[]; w.bound = key; w.optimizer_owner = nothing
-    end
-    return w.handle
-end
-
-"collect_trajectories (trajectory.jl:22-78) with the envs on the host and the agent on the device; returns fps (rollout_buffer.jl:60-64)"
-function device_rollout!(w::OnDevice, alg::PPO)
-    E = number_of_envs(w); asp = action_space(w); disc = asp isa Discrete
-    D = prod(size(observation_space(w))); A = disc ? 1 : prod(size(asp))
-    obs = Matrix{Float32}(undef, D, E); tobs = zeros(Float32, D, E)
-    raw = disc ? Vector{Int32}(undef, E) : Matrix{Float32}(undef, A, E); ea = similar(raw)
-    rew = Vector{Float32}(undef, E); term = Vector{UInt8}(undef, E); trunc = Vector{UInt8}(undef, E)
-    pack!(dst, xs) = (for j in 1:E; dst[:, j] .= vec(xs[j]); end; dst)
-    t0 = time()
-    pack!(obs, observe(w.env))                                                                                     # :32
-    for _ in 1:alg.n_steps
-        GC.@preserve obs raw ea check(ccall((:dril_ext_act, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Cvoid}, Ptr{Cvoid}), w.handle, obs, raw, ea), w.handle)   # :41-42
-        actions = disc ? [Int(ea[j]) for j in 1:E] : [clamp.(reshape(ea[:, j], size(asp)), asp.low, asp.high) for j in 1:E]   # per-dimension bounds too (ClampAdapter, default_adapters.jl:4-11)
-        r, te, tr, infos = act!(w.env, actions)                                                                    # :44
-        rew .= r; term .= te; trunc .= tr
-        for j in 1:E
-            tr[j] && haskey(infos[j], "terminal_observation") && (tobs[:, j] .= vec(infos[j]["terminal_observation"]))
-        end
-        GC.@preserve rew term trunc tobs check(ccall((:dril_ext_record, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float32}),
-            w.handle, rew, term, trunc, tobs), w.handle)                                                            # :46-61
-        pack!(obs, observe(w.env))                                                                                 # :45
-    end
-    GC.@preserve obs check(ccall((:dril_ext_finish, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}), w.handle, obs), w.handle)   # :65-70 + compute_advantages! + returns
-    return alg.n_steps * E / max(time() - t0, 1.0e-12)
-end
-
-function collect_rollout!(buf::RolloutBuffer, agent::Agent, alg::PPO, w::OnDevice; callbacks = nothing)
-    has_step_hooks(callbacks) && return collect_rollout!(buf, agent, alg, w.env; callbacks = callbacks)   # on_step hooks: the reference loop on the wrapped env
-    bind_agent!(w, agent, alg); push_params!(w, agent)
-    fps = device_rollout!(w, alg)
-    copy_out!(w, 0, buf.observations)
-    if action_space(w) isa Discrete
-        tmp = Vector{Int32}(undef, length(buf.rewards)); copy_out!(w, 1, tmp); buf.actions .= reshape(tmp, 1, :)
-    else
-        copy_out!(w, 1, buf.actions)
-    end
-    copy_out!(w, 2, buf.rewards); copy_out!(w, 3, buf.advantages); copy_out!(w, 4, buf.returns); copy_out!(w, 5, buf.logprobs); copy_out!(w, 6, buf.values)
-    return fps, true
-end
-
-function train!(agent::PPOAgent, w::OnDevice, alg::PPO{T}, max_steps::Int; ad_type = nothing, callbacks = nothing) where {T}
-    if has_step_hooks(callbacks)                                       # on_step hooks: the reference's own loop on the wrapped env
-        kw = isnothing(ad_type) ? (; callbacks = callbacks) : (; ad_type = ad_type, callbacks = callbacks)
-        return train!(agent, w.env, alg, max_steps; kw...)
-    end
-    to = TimerOutput()
-    n_steps = alg.n_steps; n_envs = number_of_envs(w)
-    local iterations, total_steps
-    @timeit to "setup" begin
-        bind_agent!(w, agent, alg); push_params!(w, agent)
-        if w.optimizer_owner !== agent.train_state
-            check(ccall((:dril_reset_optimizer, LIB[]), Int32, (Ptr{Cvoid},), w.handle), w.handle)
-            w.optimizer_owner = agent.train_state
-        end
-        iterations = max_steps ÷ (n_steps * n_envs)                    # ppo.jl:117
-        iterations == 0 && @warn "max_steps is less than n_steps * n_envs; there will be no training."
-        total_steps = iterations * n_steps * n_envs
-    end
-    learn_stats = NamedTuple{(:entropy_losses, :policy_losses, :value_losses, :approx_kl_divs, :clip_fractions, :losses,
-        :explained_variances, :fps, :grad_norms, :learning_rates)}(ntuple(_ -> Float32[], 10))
-    total_fps = learn_stats.fps; roll_buffer = DeviceRolloutBuffer(w)
-    i = 0; learning_rate = alg.learning_rate
-    locals() = Dict{Symbol, Any}(:agent => agent, :env => w.env, :alg => alg, :iterations => iterations, :total_steps => total_steps, :max_steps => max_steps,
-        :n_steps => n_steps, :n_envs => n_envs, :roll_buffer => roll_buffer, :total_fps => total_fps, :callbacks => callbacks, :learn_stats => learn_stats,
-        :i => i, :learning_rate => learning_rate, :to => to)
-    fire(f) = isnothing(callbacks) || all(c -> f(c, locals()), callbacks)
-    try
-        fire(DRiL.on_training_start) || return nothing
-        @timeit to "training_loop" for it in 1:iterations
-            i = it
-            check(ccall((:dril_set_learning_rate, LIB[]), Int32, (Ptr{Cvoid}, Float32), w.handle, learning_rate), w.handle)
-            push!(learn_stats.learning_rates, learning_rate)
-            fire(DRiL.on_rollout_start) || return nothing
-            fps = @timeit to "collect_rollout" device_rollout!(w, alg)
-            push!(total_fps, fps); DRiL.add_step!(agent, n_steps * n_envs)
-            DRiL.increment_step!(agent.logger, n_steps * n_envs); DRiL.log_scalar!(agent.logger, "env/fps", fps)
-            DRiL.log_stats(w.env, agent.logger)
-            fire(DRiL.on_rollout_end) || return nothing
-            st = Ref{DrilPPOStats}()
-            @timeit to "epoch loop" check(ccall((:dril_ppo_update, LIB[]), Int32, (Ptr{Cvoid}, Ref{DrilPPOStats}), w.handle, st), w.handle)
-            s = st[]
-            DRiL.add_gradient_update!(agent, Int(s.n_updates))
-            push!(learn_stats.entropy_losses, s.entropy_loss); push!(learn_stats.policy_losses, s.policy_loss); push!(learn_stats.value_losses, s.value_loss)
-            push!(learn_stats.approx_kl_divs, s.approx_kl_div); push!(learn_stats.clip_fractions, s.clip_fraction); push!(learn_stats.losses, s.loss)
-            push!(learn_stats.explained_variances, s.explained_variance); push!(learn_stats.grad_norms, s.grad_norm)
-            for (k, v) in ("entropy_loss" => s.entropy_loss, "explained_variance" => s.explained_variance, "policy_loss" => s.policy_loss,
-                "value_loss" => s.value_loss, "approx_kl_div" => s.approx_kl_div, "clip_fraction" => s.clip_fraction, "loss" => s.loss,
-                "grad_norm" => s.grad_norm, "learning_rate" => learning_rate)
-                DRiL.log_scalar!(agent.logger, "train/" * k, v)
-            end
-        end
-        fire(DRiL.on_training_end) || return nothing
-        return learn_stats, to
-    finally
-        pull_params!(w, agent)                                          # every exit path: the agent holds the weights trained so far (ppo.jl:239)
-    end
-end
-
-# ---- normalisation statistics in the reference's JLD2 schema (normalizeWrapperEnv.jl:261-297) ----
-function norm_stats(env::DeviceParallelEnv)
-    D = obs_dim(env); om = Vector{Float32}(undef, D); ov = Vector{Float32}(undef, D)
-    oc = Ref{Int64}(0); rm = Ref{Float32}(0); rv = Ref{Float32}(0); rc = Ref{Int64}(0)
-    GC.@preserve om ov check(ccall((:dril_norm_get_stats, LIB[]), Int32,
-        (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ref{Int64}, Ref{Float32}, Ref{Float32}, Ref{Int64}), handle(env), om, ov, oc, rm, rv, rc), env.handle)
-    return (; obs_mean = om, obs_var = ov, obs_count = Int(oc[]), ret_mean = fill(rm[]), ret_var = fill(rv[]), ret_count = Int(rc[]))
-end
-function DRiL.save_normalization_stats(env::DeviceParallelEnv, filepath::String)
-    s = norm_stats(env); nz = env.normalize
-    return DRiL.save(filepath, Dict("obs_mean" => s.obs_mean, "obs_var" => s.obs_var, "obs_count" => s.obs_count,
-        "ret_mean" => s.ret_mean, "ret_var" => s.ret_var, "ret_count" => s.ret_count,
-        "clip_obs" => Float32(get(nz, :clip_obs, 10)), "clip_reward" => Float32(get(nz, :clip_reward, 10)),
-        "gamma" => Float32(get(nz, :gamma, 0.99)), "epsilon" => Float32(get(nz, :epsilon, 1.0e-8))))
-end
-function DRiL.load_normalization_stats!(env::DeviceParallelEnv, filepath::String)
-    st = DRiL.load(filepath)
-    om = Float32.(st["obs_mean"]); ov = Float32.(st["obs_var"])
-    GC.@preserve om ov check(ccall((:dril_norm_set_stats, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Int64, Float32, Float32, Int64),
-        handle(env), om, ov, st["obs_count"], Float32(first(st["ret_mean"])), Float32(first(st["ret_var"])), st["ret_count"]), env.handle)
-    return env
-end
-
-# ---- evaluate_agent(agent, env::DeviceParallelEnv; ...)  (src/evaluation.jl:54-143) ----
-struct DrilEvalStats
-    mean_reward::Float64; std_reward::Float64; mean_length::Float64; std_length::Float64
-    n_episodes::Int32; n_steps::Int32
-end
-function DRiL.evaluate_agent(agent, env::DeviceParallelEnv; n_eval_episodes::Int = 10, deterministic::Bool = true,
-        reward_threshold::Union{Nothing, Real} = nothing, return_stats::Bool = true, warn::Bool = true, kwargs...)
-    bind_agent!(env, agent, agent.algorithm); push_params!(env, agent)
-    st = Ref{DrilEvalStats}(); er = Vector{Float32}(undef, n_eval_episodes); el = Vector{Int32}(undef, n_eval_episodes)
-    GC.@preserve er el check(ccall((:dril_evaluate_agent, LIB[]), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{DrilEvalStats}, Ptr{Float32}, Ptr{Int32}),
-        env.handle, n_eval_episodes, deterministic, st, er, el), env.handle)
-    s = st[]
-    if reward_threshold !== nothing && s.mean_reward < reward_threshold
-        error("Mean reward below threshold: $(round(s.mean_reward, digits = 2)) < $(reward_threshold)")            # evaluation.jl:131-135
-    end
-    return return_stats ? (; mean_reward = s.mean_reward, std_reward = s.std_reward, mean_length = s.mean_length, std_length = s.std_length) :
-        (er, Int.(el))
-end
-
-
-# =====================================================================================================================
-# SAC: train!(agent, env::DeviceParallelEnv, alg::SAC, max_steps)  (src/algorithms/sac.jl:406-549) over include/dril_sac.h
-# =====================================================================================================================
-# struct dril_sac_config / dril_sac_stats (include/dril_sac.h) — isbits, C layout
-struct DrilSacConfig
-    abi_version::UInt32; env_kind::Int32; n_envs::Int32; episode_len::Int32
-    hidden1::Int32; hidden2::Int32; activation::Int32
-    buffer_capacity::Int64; start_steps::Int32; batch_size::Int32
-    tau::Float32; gamma::Float32
-    train_freq::Int32; gradient_steps::Int32; target_update_interval::Int32
-    auto_ent_coef::Int32; ent_coef_init::Float32; auto_target_entropy::Int32; target_entropy::Float32
-    learning_rate::Float32; adam_beta1::Float32; adam_beta2::Float32; adam_eps::Float32
-    seed::UInt64; device::Int32; profile_events::Int32
-    ext_obs_dim::Int32; ext_action_dim::Int32; ext_action_low::Float32; ext_action_high::Float32
-    reserved::NTuple{4, Int32}
-end
-struct DrilSacStats
-    actor_loss::Float32; critic_loss::Float32; entropy_loss::Float32; mean_q_values::Float32; entropy_coefficient::Float32; grad_norm::Float32
-    has_entropy_loss::Int32; reserved::Int32
-end
-sac_check(rc::Int32, h = C_NULL) = rc == 0 ? nothing :
-    error("libdril_hip (SAC) status $rc: " * unsafe_string(ccall((:dril_sac_last_error, LIB[]), Cstring, (Ptr{Cvoid},), h)))
-
-# ContinuousActorCriticLayer{QCritic}: actor_head = Chain(mlp, ReshapeLayer), critic_head = Parallel(vcat, mlp, mlp) (layer_helpers.jl:77,100-112)
-function sac_flatten_params(ps)
-    parts = Vector{Float32}[]
-    for head in (mlp_of(ps.actor_head), ps.critic_head.layer_1, ps.critic_head.layer_2), l in (:layer_1, :layer_2, :layer_3)
-        push!(parts, vec(getproperty(head, l).weight)); push!(parts, vec(getproperty(head, l).bias))
-    end
-    push!(parts, vec(ps.log_std))
-    return reduce(vcat, parts)
-end
-function sac_scatter_params!(ps, flat::Vector{Float32})
-    off = 0
-    for head in (mlp_of(ps.actor_head), ps.critic_head.layer_1, ps.critic_head.layer_2), l in (:layer_1, :layer_2, :layer_3)
-        for arr in (getproperty(head, l).weight, getproperty(head, l).bias)
-            n = length(arr); copyto!(arr, 1, flat, off + 1, n); off += n
-        end
-    end
-    copyto!(ps.log_std, 1, flat, off + 1, length(ps.log_std))
-    return ps
-end
-function sac_flatten_targets(tp)
-    parts = Vector{Float32}[]
-    for head in (tp.critic_head.layer_1, tp.critic_head.layer_2), l in (:layer_1, :layer_2, :layer_3)
-        push!(parts, vec(getproperty(head, l).weight)); push!(parts, vec(getproperty(head, l).bias))
-    end
-    return reduce(vcat, parts)
-end
-function sac_scatter_targets!(tp, flat::Vector{Float32})
-    off = 0
-    for head in (tp.critic_head.layer_1, tp.critic_head.layer_2), l in (:layer_1, :layer_2, :layer_3)
-        for arr in (getproperty(head, l).weight, getproperty(head, l).bias)
-            n = length(arr); copyto!(arr, 1, flat, off + 1, n); off += n
-        end
-    end
-    return tp
-end
-
-function sac_config(env::DeviceParallelEnv, alg::DRiL.SAC, agent)
-    is_discrete(env) && error("SAC needs a Box action space (sac.jl:74): DeviceParallelEnv(:Pendulum | :ScaledPendulum | :MountainCarContinuous, ...)")
-    hd = hidden_dims_of(agent.train_state.parameters)
-    act = agent.layer.actor_head.layers[1].layers[1].activation === DRiL.Lux.relu ? Int32(1) : Int32(0)   # SACLayer default relu (sac.jl:77)
-    ec = alg.ent_coef
-    auto = ec isa DRiL.AutoEntropyCoefficient
-    auto_t = auto && ec.target isa DRiL.AutoEntropyTarget
-    return DrilSacConfig(UInt32(1), ENV_KINDS[env.kind], env.n_envs, env.max_steps, hd[1], hd[2], act,
-        alg.buffer_capacity, alg.start_steps, alg.batch_size, alg.tau, alg.gamma, alg.train_freq, alg.gradient_steps, alg.target_update_interval,
-        Int32(auto), auto ? Float32(ec.initial_value) : Float32(ec.coef), Int32(auto ? auto_t : true),
-        auto && !auto_t ? Float32(ec.target.target) : 0.0f0,
-        alg.learning_rate, 0.9f0, 0.999f0, 1.0f-8,                                                # Optimisers.Adam(lr) defaults, agent_methods.jl:116-118
-        env.seed, env.device, Int32(0), 0, 0, 0.0f0, 0.0f0, ntuple(_ -> Int32(0), 4))
-end
-
-"""
-    train!(agent, env::DeviceParallelEnv, alg::SAC, max_steps) -> (agent, nothing, training_stats, to)
-
-Same contract as `train!(agent, replay_buffer, env, alg::SAC, max_steps)` (sac.jl:414-549) with the ReplayBuffer resident on the device
-(second return value `nothing`; read it through `dril_sac_replay_copy_out`).  Callbacks with `on_step` hooks are not supported on this path.
-"""
-function train!(agent::SACAgent, env::DeviceParallelEnv, alg::DRiL.SAC, max_steps::Int; ad_type = nothing, callbacks = nothing)
-    T = typeof(alg.learning_rate)
-    if has_step_hooks(callbacks)      # on_step hooks: the reference's own train! over this env's step-granular verbs
-        kw = isnothing(ad_type) ? (; callbacks = callbacks) : (; ad_type = ad_type, callbacks = callbacks)
-        return invoke(train!, Tuple{SACAgent, AbstractParallelEnv, DRiL.SAC, Int}, agent, env, alg, max_steps; kw...)
-    end
-    to = TimerOutput()
-    cfg = Ref(sac_config(env, alg, agent)); hp = Ref{Ptr{Cvoid}}(C_NULL)
-    sac_check(ccall((:dril_sac_create, LIB[]), Int32, (Ref{DrilSacConfig}, Ref{Ptr{Cvoid}}), cfg, hp)); h = hp[]
-    try
-        flat = sac_flatten_params(agent.train_state.parameters); tgt = sac_flatten_targets(agent.aux.Q_target_parameters)
-        GC.@preserve flat tgt begin
-            sac_check(ccall((:dril_sac_set_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h, flat, length(flat)), h)
-            sac_check(ccall((:dril_sac_set_target_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h, tgt, length(tgt)), h)
-        end
-        sac_check(ccall((:dril_sac_set_log_ent_coef, LIB[]), Int32, (Ptr{Cvoid}, Float32), h, first(agent.aux.ent_train_state.parameters.log_ent_coef)), h)
-        sac_check(ccall((:dril_sac_env_reset, LIB[]), Int32, (Ptr{Cvoid}, UInt64), h, env.seed), h)
-        n_envs = env.n_envs                                                                       # schedule: sac.jl:436-447
-        total_start = alg.start_steps > 0 ? alg.start_steps : alg.train_freq * n_envs
-        adjusted = max(1, div(total_start, n_envs)) * n_envs
-        iterations = div(max_steps - adjusted, alg.train_freq * n_envs) + 1
-        n_upd = DRiL.get_gradient_steps(alg, alg.train_freq, n_envs)
-        cap = max(1, iterations * n_upd)
-        st = Vector{DrilSacStats}(undef, cap); fps = Vector{Float64}(undef, max(1, iterations))
-        nu = Ref{Int64}(0); it = Ref{Int32}(0); tot = Ref{Int64}(0)
-        !isnothing(callbacks) && !all(c -> DRiL.on_training_start(c, Dict{Symbol, Any}(:agent => agent, :env => env, :alg => alg)), callbacks) && return agent, nothing, DRiL.SACTrainingStats{T}()
-        @timeit to "training_loop" GC.@preserve st fps sac_check(ccall((:dril_sac_train, LIB[]), Int32,
-            (Ptr{Cvoid}, Int64, Ptr{DrilSacStats}, Int64, Ref{Int64}, Ptr{Float64}, Int64, Ref{Int32}, Ref{Int64}),
-            h, max_steps, st, cap, nu, fps, length(fps), it, tot), h)
-        ts = DRiL.SACTrainingStats{T}()                                                            # sac.jl:243-257
-        for k in 1:min(nu[], cap)
-            s = st[k]
-            push!(ts.actor_losses, s.actor_loss); push!(ts.critic_losses, s.critic_loss); s.has_entropy_loss != 0 && push!(ts.entropy_losses, s.entropy_loss)
-            push!(ts.entropy_coefficients, s.entropy_coefficient); push!(ts.q_values, s.mean_q_values); push!(ts.learning_rates, alg.learning_rate)
-            push!(ts.grad_norms, s.grad_norm)
-        end
-        append!(ts.fps, T.(fps[1:it[]]))
-        DRiL.add_step!(agent, tot[])
-        GC.@preserve flat tgt begin
-            sac_check(ccall((:dril_sac_get_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h, flat, length(flat)), h)
-            sac_check(ccall((:dril_sac_get_target_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h, tgt, length(tgt)), h)
-        end
-        sac_scatter_params!(agent.train_state.parameters, flat); sac_scatter_targets!(agent.aux.Q_target_parameters, tgt)
-        le = Ref{Float32}(0); sac_check(ccall((:dril_sac_get_log_ent_coef, LIB[]), Int32, (Ptr{Cvoid}, Ref{Float32}), h, le), h)
-        agent.aux.ent_train_state.parameters.log_ent_coef[1] = le[]
-        !isnothing(callbacks) && all(c -> DRiL.on_training_end(c, Dict{Symbol, Any}(:agent => agent, :env => env, :alg => alg)), callbacks)
-        return agent, nothing, ts, to
-    finally
-        ccall((:dril_sac_destroy, LIB[]), Int32, (Ptr{Cvoid},), h)
-    end
-end
-
-# ---- SAC over host envs: train!(agent, OnDevice(env), alg::SAC, max_steps)  (sac.jl:428-559 with the collection loop of off_policy_collection.jl:28-96) ----
-function sac_config(w::OnDevice, alg::DRiL.SAC, agent)
-    osp, asp = observation_space(w), action_space(w)
-    asp isa Box || error("SAC needs a Box action space (sac.jl:74)")
-    lo, hi = Float32(minimum(asp.low)), Float32(maximum(asp.high))
-    (all(==(lo), asp.low) && all(==(hi), asp.high)) || error("DRIL_ENV_EXTERNAL SAC: one (low, high) pair for all action dimensions (wrap the env in ScalingWrapperEnv)")
-    hd = hidden_dims_of(agent.train_state.parameters)
-    act = agent.layer.actor_head.layers[1].layers[1].activation === DRiL.Lux.relu ? Int32(1) : Int32(0)
-    ec = alg.ent_coef
-    auto = ec isa DRiL.AutoEntropyCoefficient
-    auto_t = auto && ec.target isa DRiL.AutoEntropyTarget
-    return DrilSacConfig(UInt32(1), Int32(5), number_of_envs(w), 0, hd[1], hd[2], act,
-        alg.buffer_capacity, alg.start_steps, alg.batch_size, alg.tau, alg.gamma, alg.train_freq, alg.gradient_steps, alg.target_update_interval,
-        Int32(auto), auto ? Float32(ec.initial_value) : Float32(ec.coef), Int32(auto ? auto_t : true),
-        auto && !auto_t ? Float32(ec.target.target) : 0.0f0,
-        alg.learning_rate, 0.9f0, 0.999f0, 1.0f-8, w.seed, w.device, Int32(0),
-        Int32(prod(size(osp))), Int32(prod(size(asp))), lo, hi, ntuple(_ -> Int32(0), 4))
-end
-
-function train!(agent::SACAgent, w::OnDevice, alg::DRiL.SAC, max_steps::Int; ad_type = nothing, callbacks = nothing)
-    T = typeof(alg.learning_rate)
-    if has_step_hooks(callbacks)      # on_step hooks: the reference's own loop on the wrapped env
-        kw = isnothing(ad_type) ? (; callbacks = callbacks) : (; ad_type = ad_type, callbacks = callbacks)
-        return train!(agent, w.env, alg, max_steps; kw...)
-    end
-    to = TimerOutput()
-    cfg = Ref(sac_config(w, alg, agent)); hp = Ref{Ptr{Cvoid}}(C_NULL)
-    sac_check(ccall((:dril_sac_create, LIB[]), Int32, (Ref{DrilSacConfig}, Ref{Ptr{Cvoid}}), cfg, hp)); h = hp[]
-    try
-        flat = sac_flatten_params(agent.train_state.parameters); tgt = sac_flatten_targets(agent.aux.Q_target_parameters)
-        GC.@preserve flat tgt begin
-            sac_check(ccall((:dril_sac_set_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h, flat, length(flat)), h)
-            sac_check(ccall((:dril_sac_set_target_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h, tgt, length(tgt)), h)
-        end
-        sac_check(ccall((:dril_sac_set_log_ent_coef, LIB[]), Int32, (Ptr{Cvoid}, Float32), h, first(agent.aux.ent_train_state.parameters.log_ent_coef)), h)
-        E = number_of_envs(w); asp = action_space(w); D = prod(size(observation_space(w))); A = prod(size(asp))
-        total_start = alg.start_steps > 0 ? alg.start_steps : alg.train_freq * E                  # sac.jl:456-466
-        adjusted = max(1, div(total_start, E)) * E
-        n_steps = div(adjusted, E)
-        iterations = div(max_steps - adjusted, alg.train_freq * E) + 1
-        n_upd = DRiL.get_gradient_steps(alg, alg.train_freq, E)
-        ts = DRiL.SACTrainingStats{T}()
-        obs = Matrix{Float32}(undef, D, E); nobs = similar(obs); tobs = zeros(Float32, D, E)
-        raw = Matrix{Float32}(undef, A, E); ea = similar(raw)
-        rew = Vector{Float32}(undef, E); term = Vector{UInt8}(undef, E); trunc = Vector{UInt8}(undef, E)
-        st = Vector{DrilSacStats}(undef, max(1, n_upd))
-        pack!(dst, xs) = (for j in 1:E; dst[:, j] .= vec(xs[j]); end; dst)
-        pack!(obs, observe(w.env))
-        @timeit to "training_loop" for it in 1:iterations
-            use_random = it == 1 && alg.start_steps > 0                                           # :487
-            t0 = time()
-            @timeit to "collect_rollout" for _ in 1:n_steps                                       # collect_trajectories, off_policy_collection.jl:28-96
-                if use_random
-                    for j in 1:E; ea[:, j] .= vec(rand(agent.rng, asp)); end; raw .= ea               # rand(rng, act_space): env space, stored as is (:50-53,72)
-                else
-                    GC.@preserve obs raw ea sac_check(ccall((:dril_sac_predict_actions, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Int64, Int32, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}),
-                        h, obs, E, 0, C_NULL, raw, ea), h)                                         # predict_actions_raw + to_env(TanhScaleAdapter), :55-58
-                end
-                r, te, tr, infos = act!(w.env, [reshape(ea[:, j], size(asp)) for j in 1:E])       # :60
-                pack!(nobs, observe(w.env))                                                        # :61
-                rew .= r; term .= te; trunc .= tr
-                for j in 1:E
-                    tr[j] && haskey(infos[j], "terminal_observation") && (tobs[:, j] .= vec(infos[j]["terminal_observation"]))
-                end
-                GC.@preserve obs raw rew term trunc nobs tobs sac_check(ccall((:dril_sac_ext_push, LIB[]), Int32,
-                    (Ptr{Cvoid}, Ptr{Float32}, Ptr{Float32}, Ptr{Float32}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float32}, Ptr{Float32}), h, obs, raw, rew, term, trunc, nobs, tobs), h)   # push!(buffer, traj), replay_buffer.jl:98-114
-                obs, nobs = nobs, obs
-            end
-            push!(ts.fps, T(n_steps * E / max(time() - t0, 1.0e-12))); DRiL.add_step!(agent, n_steps * E)
-            n_steps = alg.train_freq                                                               # :520
-            if n_upd > 0
-                @timeit to "gradient_updates" GC.@preserve st sac_check(ccall((:dril_sac_update, LIB[]), Int32, (Ptr{Cvoid}, Int32, Ptr{DrilSacStats}), h, n_upd, st), h)   # :523-538
-                for k in 1:n_upd
-                    s = st[k]
-                    push!(ts.actor_losses, s.actor_loss); push!(ts.critic_losses, s.critic_loss); s.has_entropy_loss != 0 && push!(ts.entropy_losses, s.entropy_loss)
-                    push!(ts.entropy_coefficients, s.entropy_coefficient); push!(ts.q_values, s.mean_q_values); push!(ts.learning_rates, alg.learning_rate)
-                    push!(ts.grad_norms, s.grad_norm)
-                end
-            end
-        end
-        GC.@preserve flat tgt begin
-            sac_check(ccall((:dril_sac_get_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h, flat, length(flat)), h)
-            sac_check(ccall((:dril_sac_get_target_params, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Csize_t), h, tgt, length(tgt)), h)
-        end
-        sac_scatter_params!(agent.train_state.parameters, flat); sac_scatter_targets!(agent.aux.Q_target_parameters, tgt)
-        le = Ref{Float32}(0); sac_check(ccall((:dril_sac_get_log_ent_coef, LIB[]), Int32, (Ptr{Cvoid}, Ref{Float32}), h, le), h)
-        agent.aux.ent_train_state.parameters.log_ent_coef[1] = le[]
-        return agent, nothing, ts, to
-    finally
-        ccall((:dril_sac_destroy, LIB[]), Int32, (Ptr{Cvoid},), h)
-    end
-end
+include("DRiLHIP_host_envs.jl")     # OnDevice(env::AbstractParallelEnv): host envs, generic kernels
+include("DRiLHIP_extras.jl")        # normalisation statistics, evaluate_agent
+include("DRiLHIP_sac.jl")           # SAC
 
 export DeviceParallelEnv, OnDevice
 

@@ -25,6 +25,8 @@ def test_checker_catches_the_round1_ambiguity(tmp_path):
         import pytest
         pytest.skip("needs the reference sources")
     bad = tmp_path / "DRiLHIP.jl"
+    import shutil
+    for f in SHIM.parent.glob("DRiLHIP_*.jl"): shutil.copy(f, tmp_path / f.name)
     text = SHIM.read_text()
     assert "function train!(agent::PPOAgent, env::DeviceParallelEnv" in text
     bad.write_text(text.replace("function train!(agent::PPOAgent, env::DeviceParallelEnv", "function train!(agent::Agent, env::DeviceParallelEnv"))
@@ -33,6 +35,8 @@ def test_checker_catches_the_round1_ambiguity(tmp_path):
 
 
 def test_checker_catches_a_missing_locals_key(tmp_path):
+    import shutil
+    for f in SHIM.parent.glob("DRiLHIP_*.jl"): shutil.copy(f, tmp_path / f.name)
     bad = tmp_path / "DRiLHIP.jl"
     bad.write_text(SHIM.read_text().replace(":roll_buffer, :total_fps, :callbacks, :learn_stats)", ":total_fps, :callbacks, :learn_stats)"))
     r = _run("--shim", str(bad))

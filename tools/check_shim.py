@@ -21,6 +21,15 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 SHIM = ROOT / "dril.jl_amd" / "julia" / "DRiLHIP.jl"
+
+
+def read_shim(path: Path) -> str:
+    """the shim with its `include("file.jl")` lines replaced by the files' text (DRiLHIP.jl includes its host-env, extras and SAC parts)"""
+    text = path.read_text()
+    def sub(m):
+        f = path.parent / m.group(1)
+        return f.read_text() if f.exists() else m.group(0)
+    return re.sub(r'^include\("([^"]+)"\).*$', sub, text, flags=re.M)
 REF = Path("/root/reference")
 
 BUILTIN_PARENTS = {"Int": "Signed", "Int64": "Signed", "Int32": "Signed", "Signed": "Integer", "Integer": "Real", "Real": "Number", "Number": "Any",
@@ -156,7 +165,7 @@ def aliases_of(src: str) -> dict:
 
 def check_dispatch(markdown: bool) -> list[str]:
     errors = []
-    shim = SHIM.read_text()
+    shim = read_shim(SHIM)
     if not REF.exists():
         print("dispatch: /root/reference is absent here — skipped"); return errors
     ref = julia_sources(REF / "src")
@@ -205,7 +214,7 @@ def check_dispatch(markdown: bool) -> list[str]:
 
 def check_locals() -> list[str]:
     errors = []
-    shim = SHIM.read_text()
+    shim = read_shim(SHIM)
     tup = lambda name, text: tuple(re.findall(r":?\"?(\w+)\"?", re.search(name + r"\s*=\s*\(([^)]*)\)", text).group(1)))
     host = (ROOT / "dril.jl_amd" / "host.py").read_text()
     for name in ("TRAINING_START_LOCALS", "ROLLOUT_START_LOCALS"):
@@ -236,7 +245,7 @@ def check_locals() -> list[str]:
 
 def check_abi() -> list[str]:
     errors = []
-    shim = SHIM.read_text()
+    shim = read_shim(SHIM)
     headers = "\n".join(p.read_text() for p in sorted((ROOT / "include").glob("*.h")))
     declared = set(re.findall(r"\b(dril_\w+)\s*\(", headers))
     used = set(re.findall(r"ccall\(\(:(\w+),\s*LIB\[\]\)", shim))
