@@ -209,7 +209,10 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
             # dominant kernel: the gradient kernel. ALGORITHMIC flops per launch = B_local samples x 3 x forward flops (fwd + bwd of both MLPs,
             # 53 376 at [64,64]); duration = HIP events on the library's stream around each launch in the timed region.
             avg_ms = gk["total_ms"] / gk["launches"]
+            info = h.grad_kernel_info()                  # "<kernel>: <arithmetic>" of the kernel the last optimiser step actually ran
             flops = (B_global // world) * 3 * flop_fwd(h.D, hidden, h.A)
+            if info.startswith("ppo_update_small_kernel"):   # one launch = a run of optimiser steps (all of an iteration's, up to 16 384): every sample of the buffer, `epochs` times
+                flops = N_local * epochs * 3 * flop_fwd(h.D, hidden, h.A) * steps // gk["launches"]
             ach = flops / (avg_ms * 1e-3) / 1e12
             # traffic and the rocprofv3 average are NOT measured in this run (PMC needs its own rocprofv3 passes): they are replayed from the
             # committed profile of exactly this workload, and the line says so (traffic_source: file + the commit the profile was taken at)
@@ -219,7 +222,6 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
                 rec = json.loads(pmc.read_text())
                 traffic, rocprof_ms = rec.get("hbm_bytes_per_launch"), rec.get("rocprof_avg_launch_ms")
                 traffic_source = f"replayed from profiles/{PMC_FILE} (rocprofv3 --pmc passes at commit {rec.get('commit', '?')}); not measured in this run"
-            info = h.grad_kernel_info()                  # "<kernel>: <arithmetic>" of the kernel the last optimiser step actually ran
             kname, arith = info.split(": ", 1)
             out["dtype"] = "f32 (bf16x3 split, f32 accumulate)" if "bf16x3" in arith else "f32"
             out["roofline"] = dict(mfma_roofline(ach, arith), traffic=traffic, traffic_source=traffic_source, kernel=kname, avg_launch_ms=avg_ms,
