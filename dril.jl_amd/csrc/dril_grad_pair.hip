@@ -29,9 +29,9 @@ template <int D, int O> struct PairLds {
     static constexpr int END = PAIR0 + 2 * PAIR_SIZE;
 };
 // A operand of dh1 = W2': lane (in-unit 32mk + (lane & 31), half kh) gets out-units 32mi + 16s + 8kh + j of the weight image (64 rows, piece stride 8192); tbase = wide_tr_base<64>
-__device__ __forceinline__ bf16x8 load_frag_W_T(const char* wimg, int tbase, int piece, int mk, int mi, int s) {
-    const int a = (tbase ^ (64 * mk)) + (32 * mi + 16 * s) * 128 + piece * 8192;
-    return frag8(lds_read_tr16(wimg, a), lds_read_tr16(wimg, (a ^ 16) + 4 * 128));
+__device__ __forceinline__ bf16x8 load_frag_W_T(const char* wimg, int tmk, int tmk16, int piece, int mi, int s) {   // tmk = tbase ^ (64 mk), tmk16 = tmk ^ 16 (see load_frag_wide_T)
+    const int off = (32 * mi + 16 * s) * 128 + piece * 8192;
+    return frag8(lds_read_tr16(wimg, tmk + off), lds_read_tr16(wimg, tmk16 + off + 4 * 128));
 }
 
 template <int KIND, int O, int HEAD>
@@ -210,14 +210,14 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) g1[r] = 0.f;
-            const int lo_ = opaque(lane), cc = lo_ & 31, hh = lo_ >> 5, gsw = wimg_g<64>(cc), tb = opaque(tbase);
+            const int lo_ = opaque(lane), cc = lo_ & 31, hh = lo_ >> 5, gsw = wimg_g<64>(cc), tbw = opaque(tbase) ^ (64 * w), tbw16 = tbw ^ 16;
             const char* brow = P2 + cc * 128;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int ch = ((2 * ks + hh) ^ gsw) << 4;
                 bf16x8 A[3], B[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) { A[p] = load_frag_W_T(Wimg, tb, p, w, ks >> 1, ks & 1); B[p] = *reinterpret_cast<const bf16x8*>(brow + p * 4096 + ch); }
+                for (int p = 0; p < 3; ++p) { A[p] = load_frag_W_T(Wimg, tbw, tbw16, p, ks >> 1, ks & 1); B[p] = *reinterpret_cast<const bf16x8*>(brow + p * 4096 + ch); }
                 g1 = mfma_split6(A[0], A[1], A[2], B[0], B[1], B[2], g1);
             }
             f32x16 h1r;
@@ -236,19 +236,20 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
         }
         // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the pair's images) ----
         {
-            const int tb = opaque(tbase);
+            const int tb = opaque(tbase), tbw = tb ^ (64 * w), tbw16 = tbw ^ 16;
             bf16x8 Az[2][3];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<64>(P2, tb, p, w, s);
+                for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<64>(P2, tbw, tbw16, p, s);
 #pragma unroll
             for (int mj = 0; mj < MT; ++mj) {
                 bf16x8 Bh[2][3];
+                const int tbj = tb ^ (64 * mj), tbj16 = tbj ^ 16;
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<64>(P1, tb, p, mj, s);
+                    for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<64>(P1, tbj, tbj16, p, s);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split6(Az[s][0], Az[s][1], Az[s][2], Bh[s][0], Bh[s][1], Bh[s][2], dW2[mj]);
             }

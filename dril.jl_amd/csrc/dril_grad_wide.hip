@@ -570,19 +570,20 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
         STAMP(7);
         // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the piece images) ----
         {
-            const int tb = opaque(tbase);
+            const int tb = opaque(tbase), tbw = tb ^ (64 * w), tbw16 = tbw ^ 16;
             bf16x8 Az[2][3];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<H>(P2, tb, p, w, s);
+                for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<H>(P2, tbw, tbw16, p, s);
 #pragma unroll
             for (int mj = 0; mj < MT; ++mj) {
                 bf16x8 Bh[2][3];
+                const int tbj = tb ^ (64 * mj), tbj16 = tbj ^ 16;
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<H>(P1, tb, p, mj, s);
+                    for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<H>(P1, tbj, tbj16, p, s);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split6(Az[s][0], Az[s][1], Az[s][2], Bh[s][0], Bh[s][1], Bh[s][2], dW2[mj]);
                 __builtin_amdgcn_sched_barrier(0);                                    // keep the next m-tile's fragment requests behind these MFMAs (hoisted, they spill)

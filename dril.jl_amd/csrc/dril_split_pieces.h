@@ -44,11 +44,16 @@ __device__ __forceinline__ int wide_tr_base(int lane) {
     const int kh = lane >> 5, gm = (lane >> 4) & 1, e = lane & 15, q = e >> 2, p = e & 3, n = 8 * kh + q;
     return n * RB + ((((2 * gm + (p >> 1)) ^ wimg_g<H>(n)) & 15) << 4) + 8 * (p & 1);
 }
+// tm = tbase ^ (64 m) selects the m-tile (units 32 m ..), tm16 = tm ^ 16 the second half of the fragment (samples + 4 .. + 7: the row's chunk swizzle flips bit 0 with
+// (n >> 2) & 1).  Both are passed in so that every ds_read_b64_tr_b16 of a phase is `register + immediate`: the offsets of (s, piece) are multiples of 2 048 bytes, which
+// cannot carry into bit 4, so ((tm + off) ^ 16) == (tm ^ 16) + off — an identity the compiler cannot know, and without it every fragment half cost an add and a xor
+// (60 VALU per wave and tile of ppo_grad_pair_kernel, round 3)
 template <int H>
-__device__ __forceinline__ bf16x8 load_frag_wide_T(const char* pimg, int tbase, int piece, int m, int s) {
+__device__ __forceinline__ bf16x8 load_frag_wide_T(const char* pimg, int tm, int tm16, int piece, int s) {
     constexpr int RB = 2 * H, PS = 32 * RB;
-    const int a = (tbase ^ (64 * m)) + 16 * s * RB + piece * PS;
-    return frag8(lds_read_tr16(pimg, a), lds_read_tr16(pimg, (a ^ 16) + 4 * RB));     // samples +0..3, +4..7: the row's chunk swizzle flips bit 0 with (n >> 2) & 1
+    const int off = 16 * s * RB + piece * PS;
+    static_assert((16 * RB) % 32 == 0 && PS % 32 == 0, "offsets must leave bits 0-4 alone");
+    return frag8(lds_read_tr16(pimg, tm + off), lds_read_tr16(pimg, tm16 + off + 4 * RB));
 }
 
 }  // namespace dril

@@ -36,10 +36,10 @@ template <int D, int OMAX> struct SmallPair {                 // one pair's area
 // workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also wait for the statistics row's global store
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// A operand of dh1 = W2' (transposed reads of the weight image): as load_frag_W_T of dril_grad_pair.hip
-__device__ __forceinline__ bf16x8 small_frag_W_T(const char* wimg, int tbase, int piece, int mk, int mi, int s) {
-    const int a = (tbase ^ (64 * mk)) + (32 * mi + 16 * s) * 128 + piece * 8192;
-    return frag8(lds_read_tr16(wimg, a), lds_read_tr16(wimg, (a ^ 16) + 4 * 128));
+// A operand of dh1 = W2' (transposed reads of the weight image): as load_frag_W_T of dril_grad_pair.hip (tmk = tbase ^ (64 mk), tmk16 = tmk ^ 16)
+__device__ __forceinline__ bf16x8 small_frag_W_T(const char* wimg, int tmk, int tmk16, int piece, int mi, int s) {
+    const int off = (32 * mi + 16 * s) * 128 + piece * 8192;
+    return frag8(lds_read_tr16(wimg, tmk + off), lds_read_tr16(wimg, tmk16 + off + 4 * 128));
 }
 
 // one 32-sample tile of one net on a pair of waves: forward, loss head, reverse pass; the pair's gradient goes into its slab overlay.  Barriers are workgroup-wide
@@ -178,14 +178,14 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* wl, float*
     {
 #pragma unroll
         for (int r = 0; r < 16; ++r) g1[r] = 0.f;
-        const int lo_ = opaque(lane), cc = lo_ & 31, hh = lo_ >> 5, gsw = wimg_g<64>(cc), tb = opaque(tbase);
+        const int lo_ = opaque(lane), cc = lo_ & 31, hh = lo_ >> 5, gsw = wimg_g<64>(cc), tbw = opaque(tbase) ^ (64 * w), tbw16 = tbw ^ 16;
         const char* brow = P2 + cc * 128;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int ch = ((2 * ks + hh) ^ gsw) << 4;
             bf16x8 A[3], B[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) { A[p] = small_frag_W_T(Wimg, tb, p, w, ks >> 1, ks & 1); B[p] = *reinterpret_cast<const bf16x8*>(brow + p * 4096 + ch); }
+            for (int p = 0; p < 3; ++p) { A[p] = small_frag_W_T(Wimg, tbw, tbw16, p, ks >> 1, ks & 1); B[p] = *reinterpret_cast<const bf16x8*>(brow + p * 4096 + ch); }
             g1 = mfma_split6(A[0], A[1], A[2], B[0], B[1], B[2], g1);
         }
 #pragma unroll
@@ -215,19 +215,20 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* wl, float*
         for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dW2[j][r] = 0.f;
-        const int tb = opaque(tbase);
+        const int tb = opaque(tbase), tbw = tb ^ (64 * w), tbw16 = tbw ^ 16;
         bf16x8 Az[2][3];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<64>(P2, tb, p, w, s);
+            for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<64>(P2, tbw, tbw16, p, s);
 #pragma unroll
         for (int mj = 0; mj < MT; ++mj) {
             bf16x8 Bh[2][3];
+            const int tbj = tb ^ (64 * mj), tbj16 = tbj ^ 16;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<64>(P1, tb, p, mj, s);
+                for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<64>(P1, tbj, tbj16, p, s);
 #pragma unroll
             for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split6(Az[s][0], Az[s][1], Az[s][2], Bh[s][0], Bh[s][1], Bh[s][2], dW2[mj]);
         }
