@@ -97,6 +97,7 @@ struct dril_handle {
     void* act = nullptr; uint8_t* flags = nullptr;
     void* noise_dev = nullptr; bool noise_set = false;
     int64_t* perm_dev = nullptr; size_t perm_count = 0;
+    int64_t* epoch_index = nullptr; bool no_epoch_index = false;   // the device DataLoader order of the current epoch, written out (large minibatches; DRIL_NO_EPOCH_INDEX)
     double *adv_partials = nullptr, *adv_stats = nullptr, *ev_partials = nullptr; int adv_blocks = 0, ev_blocks = 0;
     float* step_stats = nullptr; int step_stats_cap = 0;
     int *stop_flag = nullptr, *nan_flag = nullptr;
@@ -518,7 +519,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (const char* e = std::getenv("DRIL_FORCE_STEPWISE")) h->force_stepwise = std::atoi(e) != 0;
     if (const char* e = std::getenv("DRIL_GRAD_ACTOR_PERMILLE")) { h->grad_actor_pct = std::atoi(e); if (h->grad_actor_pct < 100 || h->grad_actor_pct > 900) h->grad_actor_pct = 0; }
     if (const char* e = std::getenv("DRIL_GRAD_VARIANT")) { h->grad_variant = std::atoi(e); if (h->grad_variant < -1 || h->grad_variant > 2) h->grad_variant = -1; if (h->grad_variant == 2) h->grad_variant = 1; }
-    h->no_persistent = std::getenv("DRIL_NO_PERSISTENT_UPDATE") != nullptr;
+    h->no_persistent = std::getenv("DRIL_NO_PERSISTENT_UPDATE") != nullptr; { const char* e = std::getenv("DRIL_NO_EPOCH_INDEX"); h->no_epoch_index = e && std::atoi(e) != 0; }
     if (const char* e = std::getenv("DRIL_SMALL_CHUNK")) { const long c = std::atol(e); if (c > 0) h->small_chunk = c; }   // optimiser steps per launch of ppo_update_small_kernel (tests: launch boundaries)
     h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
     // Multi-process RCCL on this platform needs dmabuf IPC: with the legacy IPC mode (the ROCr default) `hipIpcGetMemHandle` fails with "invalid argument" on a
@@ -599,7 +600,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     if (h->ext_stage_rew) (void)hipHostFree(h->ext_stage_rew); if (h->ext_stage_flags) (void)hipHostFree(h->ext_stage_flags);
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
-                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->epoch_keys, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
+                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->epoch_index, h->epoch_keys, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
                     h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->e_rew_n, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->gen_tmp, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->w2p_actor, h->w2tp_actor, h->w2p_critic, h->w2tp_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
                     h->mon_ring_len, h->e_ep_len, h->mon_cnt, h->mon_meta, h->e_flags};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -1069,6 +1070,15 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
         const uint64_t key = perm_key(h->cfg.seed + (uint64_t)h->cfg.rank, h->update_counter, ep);
         const int64_t* perm = h->perm_count ? h->perm_dev + (size_t)ep * N : nullptr;
         const bool epoch_moments = h->cfg.normalize_advantage && !perm && nb >= 2 && nb <= 2048 && !h->no_epoch_moments;
+        // chip-filling minibatches of the fused kernels: the epoch's order as an index array (the update kernels then read 8 bytes per sample instead of evaluating the
+        // keyed bijection per lane, wave, net and tile)
+        const bool index_array = !perm && !h->generic && !h->no_epoch_index && (B + kTile - 1) / kTile >= 16 * (int64_t)h->num_cus;
+        if (index_array) {
+            if (!h->epoch_index) HIPCHK(h, dmalloc(&h->epoch_index, (size_t)N));
+            prof_begin(h, DRIL_K_ADV_MOMENTS);
+            HIPCHK(h, launch_epoch_index(N, key, bits, h->epoch_index, h->stream));
+            prof_end(h);
+        }
         if (epoch_moments) {
             if (nb > h->epoch_nb_cap) {
                 if (h->epoch_tables) hipFree(h->epoch_tables); if (h->epoch_stats) hipFree(h->epoch_stats);
@@ -1085,7 +1095,7 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
         }
         for (int64_t k = 0; k < nb; ++k, ++step) {
             const int64_t pos0 = k * B, count = (pos0 + B <= N) ? B : N - pos0;
-            int rc = ppo_step(h, h->obs, h->act, h->adv, h->ret, h->logp, h->val, perm, pos0, count, N, key, bits, h->step_stats + step * 16, true, h->rec,
+            int rc = ppo_step(h, h->obs, h->act, h->adv, h->ret, h->logp, h->val, index_array ? h->epoch_index : perm, pos0, count, N, key, bits, h->step_stats + step * 16, true, h->rec,
                               epoch_moments ? h->epoch_stats + 3 * k : nullptr);
             if (rc) return rc;
         }

@@ -86,6 +86,7 @@ struct SmallUpdateArgs {
     unsigned long long* dbg;      // -DDRIL_STAMPS diagnostic buffer (16 x u64 per wave), else unused
 };
 hipError_t launch_ppo_update_small(int kind, const SmallUpdateArgs& a, hipStream_t s);
+hipError_t launch_epoch_index(int64_t N, uint64_t key, int bits, int64_t* out, hipStream_t s);
 
 struct ReduceArgs {
     const float* slabs_actor; const float* slabs_critic; int slab_a, slab_c, G, Gc;   // G actor slabs, Gc critic slabs

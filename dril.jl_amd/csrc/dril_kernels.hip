@@ -1174,6 +1174,16 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
     return launch_ppo_grad_f32(kind, hidden, a, s);
 }
 
+// the DataLoader order of one epoch written out once: position -> buffer index (perm_index evaluated N times here instead of once per lane, wave, net and tile inside the
+// update kernels, where it costs ~35 VALU of an issue-bound loop; 8 bytes per sample, read back coalesced)
+__global__ void epoch_index_kernel(int64_t N, uint64_t key, int bits, int64_t* __restrict__ out) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) out[p] = perm_index(p, N, key, bits);
+}
+hipError_t launch_epoch_index(int64_t N, uint64_t key, int bits, int64_t* out, hipStream_t s) {
+    int blocks = (int)((N + 255) / 256); if (blocks > 8192) blocks = 8192;
+    epoch_index_kernel<<<blocks, 256, 0, s>>>(N, key, bits, out);
+    return hipGetLastError();
+}
 hipError_t launch_pack_records(int kind, int64_t N, const float* obs, const void* act, const float* adv, const float* logp, const float* ret, float4* rec, hipStream_t s) {
     int blocks = (int)((N + 255) / 256); if (blocks > 8192) blocks = 8192;
     if (kind == 0) pack_records_kernel<0><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);

@@ -1050,3 +1050,20 @@ def test_persistent_small_update_across_launch_boundaries(pkg, oracle_mod, monke
         res.append((h.get_params(), [(st.loss, st.grad_norm, st.approx_kl_div) for st in sts]))
         h.close()
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+
+
+def test_epoch_index_array_is_the_same_dataloader_order(pkg, monkeypatch):
+    """chip-filling minibatches read the epoch's DataLoader order from an index array written once per epoch (epoch_index_kernel) instead of evaluating the keyed
+    bijection inside the update kernel: the same order, hence bitwise the same update as with DRIL_NO_EPOCH_INDEX=1"""
+    res = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("DRIL_NO_EPOCH_INDEX", off)
+        env = pkg.CartPoleEnv(max_steps=500)
+        E, T = 2048, 128
+        alg = pkg.PPO(n_steps=T, batch_size=E * T // 2, epochs=2)
+        layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space())
+        h = pkg.Handle(pkg.make_config(env, E, alg, layer, seed=3, fixed_length_episodes=True))
+        h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(5))))
+        h.env_reset(3); h.collect_rollout(); st = h.ppo_update()
+        res.append((h.get_params().copy(), st.loss, st.grad_norm)); h.close()
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2] and np.array_equal(res[0][0], res[1][0])
