@@ -697,6 +697,10 @@ __device__ __forceinline__ float half_sum(float v) {
     return v;
 }
 
+// workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() also waits for every global store in flight (vmcnt(0)), which a
+// kernel that exchanges through LDS but streams its results to global memory must not do once per step (rollout_duo_kernel, ppo_update_small_kernel)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // DPP move: lanes disabled by the bank mask (banks = groups of 4 lanes within a row of 16) keep `old`
 template <int CTRL, int BANK = 0xf> __device__ __forceinline__ float dpp_mov(float old, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, BANK, false));

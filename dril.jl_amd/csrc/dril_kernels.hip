@@ -12,6 +12,7 @@
 //                        minibatches), dril_grad_pair.hip (hidden [64,64], bf16 matrix cores: the headline kernel), dril_grad_wide.hip (hidden 128 / 256)
 //   grad_reduce_kernel / grad_norm_kernel / adam_kernel   nested_norm, nested_scale!, target_kl check, Adam — ppo.jl:213-239
 //   explained_var_kernel ppo.jl:256
+#include <cstdlib>
 #include <utility>
 
 #include "dril_internal.h"
@@ -684,6 +685,156 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
 }
 
 // =============================================================================================
+// rollout_duo_kernel — collect_trajectories (trajectory.jl:22-78) for env counts that do not fill the chip (E <= 16 384: the reference's own scale is 4 envs).  In
+// rollout_kernel ONE wave walks both nets for its 32 envs, step after step: with a handful of envs the rollout is a single dependent chain of ~10 k cycles per env step
+// (critic forward -> actor forward -> sample -> physics).  Here a tile of 32 envs has TWO waves: wave 0 runs the actor, the sampling and the simulator, wave 1 the critic
+// (value of every observation, V(terminal_observation) of truncated steps, the last values), one step behind through a double-buffered observation slot in LDS and ONE
+// barrier per env step.  Same device functions as rollout_kernel (eval_net, env_step, heads), so every stored number is bit-identical to the one-wave kernel.
+// =============================================================================================
+template <int KIND, int H>
+__global__ __launch_bounds__(128, 2) void rollout_duo_kernel(RolloutArgs a) {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A, S = EnvSpec<KIND>::S;
+    constexpr bool DISC = EnvSpec<KIND>::discrete;
+    constexpr int LA = FwdLds<D, H, A, false>::SIZE, LC = FwdLds<D, H, 1, false>::SIZE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* la = smem; float* lc = smem + LA;
+    float* slot = smem + LA + LC;                                       // [2 parities][obs D x 32 | terminal obs D x 32 | truncated flag 32]
+    constexpr int SLOT = (2 * D + 1) * 32;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    stage_fwd<D, H, A, false>(la, a.params, a.actor, tid, blockDim.x);
+    stage_fwd<D, H, 1, false>(lc, a.params, a.critic, tid, blockDim.x);
+    const int c = lane & 31, h = lane >> 5;
+    const int e_raw = blockIdx.x * kTile + c;
+    const bool valid = e_raw < a.E;
+    const int e = valid ? e_raw : a.E - 1;
+    const bool writer = valid && h == 0;
+    if (wave == 0) {
+        // ================= actor + simulator =================
+        const uint64_t env_seed = a.env_seed0 + (uint64_t)e;
+        float st[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) st[i] = a.state[(size_t)e * S + i];
+        int sc = a.step_count[e];
+        uint32_t ep = a.episode[e], gs = a.gstep[e];
+        float obs[D];
+        env_obs<KIND>(st, obs);
+        if (h == 0) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) slot[i * 32 + c] = obs[i];     // parity 0: the observation of step 0
+        }
+        float lsr[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!DISC) {
+#pragma unroll
+            for (int i = 0; i < (A < 4 ? A : 4); ++i) lsr[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + i])));
+        }
+        const float* ls = lsr;
+        float mon_ret = a.mon_cur_ret ? a.mon_cur_ret[e] : 0.f;
+        int mon_len = a.mon_cur_len ? a.mon_cur_len[e] : 0;
+        __syncthreads();                                                // weights staged, slot 0 published
+        for (int t = 0; t < a.T; ++t) {
+            const size_t k = (size_t)t * a.E + e;
+            int zoff = 0; asm volatile("" : "+v"(zoff));
+            const float* la_t = la + zoff;
+            float xk[2];
+            pair_obs<D>(obs, h, xk);
+            float out[A];
+            eval_net<D, H, A, false>(la_t, a.w2a_actor, xk, out, lane);
+            int act_env = 0; float actf_env = 0.f; float logp;
+            if (DISC) {
+                float p[A]; softmax_n<A>(out, p);
+                double u;
+                if (a.noise) u = ((const double*)a.noise)[k];
+                else { uint32_t r[4]; philox4x32_10((uint32_t)env_seed, (uint32_t)(env_seed >> 32), gs, 0, 1, 0, r); u = u01_f64(r[0], r[1]); }
+                const int act = categorical_sample<A>(p, u);
+                logp = flog(pick<A>(p, act));
+                act_env = act;
+                if (writer) ((int32_t*)a.act)[k] = act + a.action_start;
+            } else {
+                float x[A];
+#pragma unroll
+                for (int i = 0; i < A; ++i) {
+                    float z;
+                    if (a.noise) z = ((const float*)a.noise)[k * A + i];
+                    else { uint32_t r[4]; philox4x32_10((uint32_t)env_seed, (uint32_t)(env_seed >> 32), gs, 0, 1, (uint32_t)(i / 2), r); z = (i & 1) ? randn_f32(r[2], r[3]) : randn_f32(r[0], r[1]); }
+                    x[i] = out[i] + fexp(ls[i]) * z;
+                    if (writer) ((float*)a.act)[k * A + i] = x[i];
+                }
+                logp = gauss_logpdf<A>(x, out, ls);
+                actf_env = fminf(fmaxf(x[0], -act_bound<KIND>()), act_bound<KIND>());
+            }
+            if (writer) {
+                if (D == 4) *reinterpret_cast<float4*>(a.obs + k * 4) = make_float4(obs[0], obs[1], obs[2], obs[3]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) a.obs[k * D + i] = obs[i];
+                }
+                a.logp[k] = logp;
+            }
+            bool term;
+            const float rew = env_step<KIND>(st, actf_env, act_env, a.fixed_len != 0, &term);
+            sc += 1; gs += 1;
+            const bool trunc = sc >= a.episode_len;
+            float* sl = slot + ((t + 1) & 1) * SLOT;                    // what the critic reads during step t + 1
+            if (h == 0) {
+                float tobs[D]; env_obs<KIND>(st, tobs);                 // terminal_observation (only read where truncated)
+#pragma unroll
+                for (int i = 0; i < D; ++i) sl[(D + i) * 32 + c] = tobs[i];
+                sl[2 * D * 32 + c] = (trunc && valid) ? 1.0f : 0.0f;
+            }
+            mon_ret += rew; mon_len += 1;
+            if (term || trunc) {
+                ep += 1; sc = 0; env_reset<KIND>(env_seed, ep, st);
+                if (writer && a.ep_ret) { a.ep_ret[k] = mon_ret; a.ep_len[k] = mon_len; }
+                mon_ret = 0.f; mon_len = 0;
+            }
+            if (writer) { a.rew[k] = rew; a.flags[k] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0)); }
+            env_obs<KIND>(st, obs);
+            if (h == 0) {
+#pragma unroll
+                for (int i = 0; i < D; ++i) sl[i * 32 + c] = obs[i];
+            }
+            lds_barrier();                                              // step t published; the critic is done with the other slot (LDS only: the buffer stores stay in flight)
+        }
+        if (writer) {
+#pragma unroll
+            for (int i = 0; i < S; ++i) a.state[(size_t)e * S + i] = st[i];
+            a.step_count[e] = sc; a.episode[e] = ep; a.gstep[e] = gs;
+            if (a.mon_cur_ret) { a.mon_cur_ret[e] = mon_ret; a.mon_cur_len[e] = mon_len; }
+        }
+    } else {
+        // ================= critic: V(obs_t), V(terminal_observation) of step t - 1, the last values =================
+        __syncthreads();
+        for (int t = 0; t <= a.T; ++t) {
+            const float* sl = slot + (t & 1) * SLOT;
+            int zoff = 0; asm volatile("" : "+v"(zoff));
+            const float* lc_t = lc + zoff;
+            float obs[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) obs[i] = sl[i * 32 + c];
+            float xk[2], v[1];
+            pair_obs<D>(obs, h, xk);
+            eval_net<D, H, 1, false>(lc_t, a.w2a_critic, xk, v, lane);
+            if (t < a.T) { if (writer) a.val[(size_t)t * a.E + e] = v[0]; }
+            else if (writer) a.last_values[e] = v[0];                  // V(new_obs) for rollout-limited trajectories, trajectory.jl:65-70
+            if (t > 0) {
+                const bool trunc = sl[2 * D * 32 + c] != 0.0f;          // of step t - 1
+                if (__any(trunc)) {                                     // V(terminal_observation), trajectory.jl:57-61
+                    float tobs[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) tobs[i] = sl[(D + i) * 32 + c];
+                    float tk[2], bv[1];
+                    pair_obs<D>(tobs, h, tk);
+                    eval_net<D, H, 1, false>(lc_t, a.w2a_critic, tk, bv, lane);
+                    if (writer && trunc) a.boot[(size_t)(t - 1) * a.E + e] = bv[0];
+                }
+            }
+            if (t < a.T) lds_barrier();
+        }
+    }
+}
+
+// =============================================================================================
 // gae_kernel: one thread per env, backward scan over the time-major buffer (coalesced 256 B rows)
 // =============================================================================================
 __global__ void gae_kernel(int E, int T, float gamma, float lam, const float* __restrict__ rew,
@@ -1131,7 +1282,21 @@ hipError_t launch_policy(int kind, int hidden, const PolicyArgs& a, int max_bloc
     return hipGetLastError();
 }
 
+template <int KIND, int H> static size_t duo_lds_bytes() {
+    constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
+    return sizeof(float) * (FwdLds<D, H, A, false>::SIZE + FwdLds<D, H, 1, false>::SIZE + 2 * (2 * D + 1) * 32);
+}
 hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_t s) {
+    static const bool no_duo = std::getenv("DRIL_NO_ROLLOUT_DUO") != nullptr;          // A/B knob
+    if (hidden == 64 && a.E <= 16384 && !no_duo && kind >= 0 && kind <= 4) {                                      // env counts that leave SIMDs idle: two waves per tile of 32 envs
+        const int blocks = (a.E + kTile - 1) / kTile;
+#define CALLD(K) { const size_t lds = duo_lds_bytes<K, 64>(); static bool attr_set = false; \
+            if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)rollout_duo_kernel<K, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
+            rollout_duo_kernel<K, 64><<<blocks, 128, lds, s>>>(a); }
+        if (kind == 0) CALLD(0) else if (kind == 1) CALLD(1) else if (kind == 2) CALLD(2) else if (kind == 3) CALLD(3) else CALLD(4)
+#undef CALLD
+        return hipGetLastError();
+    }
     const int blocks = (a.E + 4 * kTile - 1) / (4 * kTile);
 #define CALL(K, HH)                                                                                           \
     {                                                                                                         \

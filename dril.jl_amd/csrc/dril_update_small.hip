@@ -33,9 +33,6 @@ template <int D, int OMAX> struct SmallPair {                 // one pair's area
     static constexpr int S_W2 = 0;
     static_assert(S_W2 + 64 * 65 <= PO, "the dW2 overlay must stay inside the two piece images");
 };
-// workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also wait for the statistics row's global store
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // A operand of dh1 = W2' (transposed reads of the weight image): as load_frag_W_T of dril_grad_pair.hip (tmk = tbase ^ (64 mk), tmk16 = tmk ^ 16)
 __device__ __forceinline__ bf16x8 small_frag_W_T(const char* wimg, int tmk, int tmk16, int piece, int mi, int s) {
     const int off = (32 * mi + 16 * s) * 128 + piece * 8192;
