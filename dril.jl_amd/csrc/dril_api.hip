@@ -222,7 +222,7 @@ size_t act_bytes_per(const dril_handle* h) { return h->discrete ? 4 : 4 * (size_
 // default by measurement (profiles/r02_wide_split.md): the split form for both wide widths (hidden 256: 176-183 vs 118 TFLOP/s; hidden 128: 151 vs 113.5)
 int wide_variant(const dril_handle* h) { return (h->wide && h->rec && (h->grad_variant < 0 ? 1 : h->grad_variant)) ? 1 : 0; }
 // hidden [64,64]: may ppo_grad_pair_kernel run at all (it reads packed records; DRIL_GRAD_VARIANT=0 pins the exact-f32 kernel)
-bool pair_variant(const dril_handle* h) { return !h->wide && !h->generic && h->grad_variant != 0 && h->rec; }
+bool pair_variant(const dril_handle* h) { return !h->wide && !h->generic && h->grad_variant != 0 && h->rec && h->D <= 4; }   // (D > 4: 96 dW1 accumulators do not fit the pair kernel's 256 registers — the f32 kernel runs every size)
 int ensure_wimg(dril_handle* h) {
     if (!h->wide || !h->wimg_dirty) return DRIL_OK;
     HIPCHK(h, launch_build_wimg(h->params, h->actor, h->cfg.hidden1, h->w2a_actor, h->w2ta_actor, h->stream));
@@ -500,7 +500,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
         case DRIL_ENV_CARTPOLE: h->discrete = true; h->D = 4; h->A = 2; h->S = 4; break;
         case DRIL_ENV_MOUNTAINCAR: h->discrete = true; h->D = 2; h->A = 3; h->S = 2; break;
         case DRIL_ENV_MOUNTAINCAR_CONTINUOUS: h->discrete = false; h->D = 2; h->A = 1; h->S = 2; break;
-        case DRIL_ENV_ACROBOT: h->discrete = true; h->D = 6; h->A = 3; h->S = 4; h->generic = true; break;   // six observation dims: generic kernels for every hidden_dims
+        case DRIL_ENV_ACROBOT: h->discrete = true; h->D = 6; h->A = 3; h->S = 4; h->generic = !(nh == 2 && hd[0] == 64 && hd[1] == 64 && cfg->activation == 0); break;   // six observation dims: fused at hidden [64,64] tanh (four first-layer k-steps, round 3: forward / rollout kernels + the exact-f32 update kernel), generic kernels for every other hidden_dims
         case DRIL_ENV_EXTERNAL: h->discrete = cfg->ext_discrete != 0; h->D = cfg->ext_obs_dim; h->A = cfg->ext_action_dim; h->S = 0; h->external = true; h->generic = true; break;
         default: h->discrete = false; h->D = 3; h->A = 1; h->S = 2; break;                    // Pendulum, ScalingWrapperEnv(Pendulum)
     }
@@ -552,7 +552,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(dmalloc(&h->obs, N * h->D)); CCHK(hipMalloc(&h->act, N * act_bytes_per(h))); CCHK(dmalloc(&h->rew, N)); CCHK(dmalloc(&h->adv, N));
     CCHK(dmalloc(&h->ret, N)); CCHK(dmalloc(&h->logp, N)); CCHK(dmalloc(&h->val, N)); CCHK(dmalloc(&h->boot, N)); CCHK(dmalloc(&h->flags, N));
     CCHK(dmalloc(&h->last_values, E));
-    if (!h->generic && !std::getenv("DRIL_NO_RECORDS")) CCHK(dmalloc(&h->rec, 2 * N));
+    if (!h->generic && !std::getenv("DRIL_NO_RECORDS")) CCHK(dmalloc(&h->rec, (size_t)(h->D <= 4 ? 2 : 3) * N));   // packed minibatch records: 2 (D <= 4) or 3 (D <= 8) float4 per sample
     if (h->generic) CCHK(dmalloc(&h->gen_tmp, E));
     if (ext) { CCHK(hipHostMalloc((void**)&h->ext_stage_rew, N * 4)); CCHK(hipHostMalloc((void**)&h->ext_stage_flags, N)); }
     if (cfg->monitor_window > 0) {
@@ -1022,7 +1022,7 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
     int64_t step = 0;
     // the reference's default PPO() (batch_size = 64) on hidden [64,64]: every optimiser step of the iteration inside ONE persistent workgroup (dril_update_small.hip);
     // single-rank only (a data-parallel run all-reduces between the gradient and the step)
-    const bool persistent = !h->wide && !h->generic && world == 1 && !(comm_ready(h) && h->force_allreduce) && h->rec && B >= 2 && B <= 64 && h->P <= 512 * 18 &&
+    const bool persistent = !h->wide && !h->generic && h->D <= 4 && world == 1 && !(comm_ready(h) && h->force_allreduce) && h->rec && B >= 2 && B <= 64 && h->P <= 512 * 18 &&
                             !h->no_persistent && !h->no_small_path && h->grad_variant < 0 && total_steps > 0;   // (DRIL_GRAD_VARIANT pins one of the per-step kernels)
     if (persistent) {
         if (h->cfg.epochs > h->epoch_keys_cap) {
@@ -1176,7 +1176,7 @@ DRIL_EXPORT int32_t dril_ppo_loss_grad(dril_handle* h, const float* obs, const v
     LCHK(hipMemsetAsync(h->stop_flag, 0, 4, h->stream));
     // the same packed records dril_ppo_update builds, so that this parity entry point runs the kernel the size rule picks for `batch` in production
     // (the pair / wide split kernels read records only)
-    if (h->rec) { LCHK(dmalloc(&d_rec, 2 * B)); LCHK(launch_pack_records(h->cfg.env_kind, batch, d_obs, d_act, d_adv, d_lp, d_ret, d_rec, h->stream)); }
+    if (h->rec) { LCHK(dmalloc(&d_rec, (size_t)(h->D <= 4 ? 2 : 3) * B)); LCHK(launch_pack_records(h->cfg.env_kind, batch, d_obs, d_act, d_adv, d_lp, d_ret, d_rec, h->stream)); }
 #undef LCHK
     int rc = ppo_step(h, d_obs, d_act, d_adv, d_ret, d_lp, d_val, nullptr, 0, batch, batch, 0, /*bits=0: identity order*/ 0, nullptr, false, d_rec);
     std::vector<float> flat((size_t)h->P + 8);

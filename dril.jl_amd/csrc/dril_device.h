@@ -363,9 +363,13 @@ __host__ __device__ inline NetOff net_off(int base, int D, int H1, int H2, int O
     n.w3 = n.b2 + H2; n.b3 = n.w3 + O * H2; n.end = n.b3 + O; return n;
 }
 
+// first layer: the observation enters as KS k-steps of v_mfma_f32_32x32x2_f32, k-step s carrying components (2s, 2s + 1) on the two half-waves: two steps for D <= 4
+// (every env kind of rounds 1-2), four for D <= 8 (round 3: Acrobot-v1, D = 6).  DP = padded observation width = rows of the W1T image.
+template <int D> struct FirstLayer { static constexpr int KS = D <= 4 ? 2 : 4, DP = 2 * KS; static_assert(D <= 8, "observation dims > 8 run on the generic kernels"); };
+
 // LDS image of one net (offsets in floats; every block starts on a 16-byte boundary)
 template <int D, int H1, int H2, int O> struct NetLds {
-    static constexpr int DP = 4;                        // obs dim padded to the MFMA k-pairing (D <= 4)
+    static constexpr int DP = FirstLayer<D>::DP;         // obs dim padded to the MFMA k-pairing
     static constexpr int WS1 = H1 + kWPad;              // row stride of W2S ([out=H2][in=H1])
     static constexpr int WS2 = H2 + kWPad;              // row stride of W2T ([in=H1][out=H2])
     static constexpr int OP = (O + 3) / 4 * 4;
@@ -378,7 +382,7 @@ template <int D, int H1, int H2, int O> struct NetLds {
     static constexpr int FWD_END = B3 + OP;
     static constexpr int W2T = FWD_END;                 // [H1][WS2]  W2T[k][o] = W2[o][k]   (backward only)
     static constexpr int BWD_END = W2T + H1 * WS2;
-    static_assert(D <= DP, "obs dim > 4 needs a wider first-layer pairing");
+    static_assert(D <= DP, "obs dim beyond the first-layer pairing");
     static_assert(H1 % 32 == 0 && H2 % 32 == 0, "hidden widths must be multiples of 32");
 };
 
@@ -480,10 +484,10 @@ __device__ __forceinline__ void load_row8(const float* img, int row, int lane, f
     v[0] = t0[0]; v[1] = t0[1]; v[2] = t0[2]; v[3] = t0[3]; v[4] = t1[0]; v[5] = t1[1]; v[6] = t1[2]; v[7] = t1[3];
 }
 
-// first layer: K = DP = 4 -> two k-steps; xk[s] = obs[2s + (lane>>5)] of sample (lane&31)
-template <int H1, int MO>
+// first layer: K = DP -> KS k-steps; xk[s] = obs[2s + (lane>>5)] of sample (lane&31)
+template <int H1, int MO, int KS>
 __device__ __forceinline__ void dense_first(const float* __restrict__ W1T, const float* __restrict__ bias,
-                                            const float (&xk)[2], f32x16 (&Y)[MO], int lane) {
+                                            const float (&xk)[KS], f32x16 (&Y)[MO], int lane) {
     const int o = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int mo = 0; mo < MO; ++mo) {
@@ -494,7 +498,7 @@ __device__ __forceinline__ void dense_first(const float* __restrict__ W1T, const
             acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) acc = mfma32(W1T[(2 * s + h) * H1 + 32 * mo + o], xk[s], acc);
+        for (int s = 0; s < KS; ++s) acc = mfma32(W1T[(2 * s + h) * H1 + 32 * mo + o], xk[s], acc);
         Y[mo] = acc;
     }
 }
@@ -556,10 +560,10 @@ __device__ __forceinline__ void dense_out(const float* __restrict__ W3S, const f
 
 // full forward of one net for a 32-sample tile
 template <int D, int H1, int H2, int O>
-__device__ __forceinline__ void net_forward(const float* __restrict__ lds, const float (&xk)[2], f32x16 (&h1)[H1 / 32],
+__device__ __forceinline__ void net_forward(const float* __restrict__ lds, const float (&xk)[FirstLayer<D>::KS], f32x16 (&h1)[H1 / 32],
                                             f32x16 (&h2)[H2 / 32], float (&out)[O], int lane) {
     using L = NetLds<D, H1, H2, O>;
-    dense_first<H1, H1 / 32>(lds + L::W1T, lds + L::B1, xk, h1, lane);
+    dense_first<H1, H1 / 32, FirstLayer<D>::KS>(lds + L::W1T, lds + L::B1, xk, h1, lane);
     tanh_tiles(h1);
     dense_mfma<H1 / 32, H2 / 32, true>(lds + L::W2S, L::WS1, lds + L::B2, h1, h2, lane);
     tanh_tiles(h2);
@@ -570,7 +574,7 @@ __device__ __forceinline__ void net_forward(const float* __restrict__ lds, const
 // H x H operand streams live in global memory PRE-TILED in MFMA A-operand order, [(mo*MT + mi)*4 + q][lane][4]: one
 // wave-instruction reads 1 KiB contiguous and the image (0.5 MB per net) stays L2-resident.  Small parts stay in LDS.
 template <int D, int H, int O> struct NetLdsSmall {
-    static constexpr int DP = 4, OP = (O + 3) / 4 * 4;
+    static constexpr int DP = FirstLayer<D>::DP, OP = (O + 3) / 4 * 4;
     static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, END = B3 + OP;
 };
 template <int D, int H, int O>
@@ -608,13 +612,13 @@ __device__ __forceinline__ f32x16 dense_tile_global(const float* __restrict__ wi
 }
 // forward of a wide net for one 32-sample tile: h1 stays in registers (H/2 VGPRs), h2 is consumed m-tile by m-tile
 template <int D, int H, int O>
-__device__ __forceinline__ void net_forward_wide(const float* __restrict__ lds, const float* __restrict__ w2a, const float (&xk)[2],
+__device__ __forceinline__ void net_forward_wide(const float* __restrict__ lds, const float* __restrict__ w2a, const float (&xk)[FirstLayer<D>::KS],
                                                  float (&out)[O], int lane) {
     using L = NetLdsSmall<D, H, O>;
     constexpr int MT = H / 32;
     const int h = lane >> 5;
     f32x16 h1[MT];
-    dense_first<H, MT>(lds + L::W1T, lds + L::B1, xk, h1, lane);
+    dense_first<H, MT, FirstLayer<D>::KS>(lds + L::W1T, lds + L::B1, xk, h1, lane);
     tanh_tiles(h1);
     float part[O];
 #pragma unroll

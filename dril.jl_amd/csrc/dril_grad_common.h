@@ -46,11 +46,13 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
 // one lane's share of a minibatch tile (DataLoader gather, ppo.jl:188-195).  Loaded one tile AHEAD of its use so the
 // random-gather latency (~2 us under load, fully exposed in v1: 23 % of wave time in s_waitcnt) hides under the
 // previous tile's MFMAs; the loop body issues no other vector-memory op, so the loads stay in flight until first use.
-template <int O> struct TileIn { float xk[2]; float s0, s1; int act; float xa[O]; bool valid; float4 raw; };
+// packed minibatch records: RS float4 per sample — {obs0..3}{action bits, adv, logp_old, ret} for D <= 4, {obs0..3}{obs4..7}{scalars} for D <= 8
+template <int D> struct RecLayout { static constexpr int RS = D <= 4 ? 2 : 3; };
+template <int O, int KS = 2> struct TileIn { float xk[KS]; float s0, s1; int act; float xa[O]; bool valid; float4 raw; float4 raw2; };   // raw2: the scalar quad of a 3-quad record (KS = 4) only
 
 template <int KIND, int O, int HEAD, bool REC>
-__device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64_t ntiles, int c, int h, TileIn<O>& t) {
-    constexpr int D = EnvSpec<KIND>::D;
+__device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64_t ntiles, int c, int h, TileIn<O, FirstLayer<EnvSpec<KIND>::D>::KS>& t) {
+    constexpr int D = EnvSpec<KIND>::D, KS = FirstLayer<D>::KS, RS = RecLayout<D>::RS;
     const bool live = tile < ntiles;
     const int64_t i = (live ? tile : ntiles - 1) * kTile + c;
     const bool inb = live && i < a.count;
@@ -61,13 +63,15 @@ __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64
     const int64_t idx = t.valid ? li : 0;
     t.act = 0; t.s0 = 0.f; t.s1 = 0.f;
     if (REC) {
-        // lane (sample, h) loads half h of the record; t.raw is exchanged between the half-waves at first use (unpack_tile)
-        t.raw = a.rec[2 * idx + h];
+        // lane (sample, h) loads quad h of the record; t.raw is exchanged between the half-waves at first use (unpack_tile).  Three-quad records (D > 4): the two
+        // half-waves load the two observation quads and every lane the scalar quad
+        t.raw = a.rec[RS * idx + h];
+        if (RS == 3) t.raw2 = a.rec[RS * idx + 2];
         if (HEAD == HEAD_VALUE && a.has_clip_vf) t.s1 = a.val_old[idx];
         return;
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; t.xk[s] = d < D ? a.obs[idx * D + d] : 0.f; }
+    for (int s = 0; s < KS; ++s) { const int d = 2 * s + h; t.xk[s] = d < D ? a.obs[idx * D + d] : 0.f; }
     if (HEAD == HEAD_VALUE) { t.s0 = a.ret[idx]; t.s1 = a.has_clip_vf ? a.val_old[idx] : 0.f; }
     else {
         t.s0 = a.adv[idx]; t.s1 = a.logp_old[idx];
@@ -82,8 +86,9 @@ __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64
 // exchange the two record halves between the half-waves: v_permlane32_swap(a, b) swaps a[32..63] with b[0..31], so with
 // a = b = v the results are {lo-half value in every lane, hi-half value in every lane}
 template <int KIND, int O, int HEAD, bool REC>
-__device__ __forceinline__ void unpack_tile(const GradArgs& a, int h, TileIn<O>& t) {
+__device__ __forceinline__ void unpack_tile(const GradArgs& a, int h, TileIn<O, FirstLayer<EnvSpec<KIND>::D>::KS>& t) {
     if (!REC) return;
+    constexpr int KS = FirstLayer<EnvSpec<KIND>::D>::KS;
     float lo[4], hi[4];
     const float v[4] = {t.raw.x, t.raw.y, t.raw.z, t.raw.w};
 #pragma unroll
@@ -93,17 +98,22 @@ __device__ __forceinline__ void unpack_tile(const GradArgs& a, int h, TileIn<O>&
         lo[i] = __uint_as_float(r[0]); hi[i] = __uint_as_float(r[1]);
     }
     t.xk[0] = h ? lo[1] : lo[0]; t.xk[1] = h ? lo[3] : lo[2];      // xk[s] = obs[2s + h]
-    if (HEAD == HEAD_VALUE) t.s0 = hi[3];
+    float sc[4] = {hi[0], hi[1], hi[2], hi[3]};                    // {action bits, adv, logp_old, ret}
+    if (KS == 4) {                                                 // three-quad record: hi = obs4..7, the scalars came with raw2
+        t.xk[KS - 2] = h ? hi[1] : hi[0]; t.xk[KS - 1] = h ? hi[3] : hi[2];
+        sc[0] = t.raw2.x; sc[1] = t.raw2.y; sc[2] = t.raw2.z; sc[3] = t.raw2.w;
+    }
+    if (HEAD == HEAD_VALUE) t.s0 = sc[3];
     else {
-        t.s0 = hi[1]; t.s1 = hi[2];
-        if (HEAD == HEAD_CATEGORICAL) t.act = __float_as_int(hi[0]) - a.action_start; else t.xa[0] = hi[0];
+        t.s0 = sc[1]; t.s1 = sc[2];
+        if (HEAD == HEAD_CATEGORICAL) t.act = __float_as_int(sc[0]) - a.action_start; else t.xa[0] = sc[0];
     }
 }
 
 // (alg::PPO)(...) loss terms and dLoss/d(net output) for one sample per lane (ppo.jl:377-404); `tally` selects the lanes that
 // add to the statistics / log_std sums (each sample is replicated in the two half-waves, and in every wave of a wide workgroup)
-template <int O, int HEAD>
-__device__ __forceinline__ void loss_head(const GradArgs& a, const TileIn<O>& cur, const float (&out)[O], bool valid, bool tally, const float* ls,
+template <int O, int HEAD, int KS>
+__device__ __forceinline__ void loss_head(const GradArgs& a, const TileIn<O, KS>& cur, const float (&out)[O], bool valid, bool tally, const float* ls,
                                           float adv_mean, float adv_inv, float (&dz)[O], float (&st)[5], float (&dlsp)[O]) {
     // branch-free on purpose: a lane-dependent `if` here becomes an s_cbranch_execz in the middle of the tile loop and splits it into basic blocks
     // that the scheduler cannot move MFMAs / LDS reads across

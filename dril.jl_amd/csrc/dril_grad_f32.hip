@@ -44,7 +44,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
                 const int64_t p2 = a.pos0 + i2;
                 const int64_t gi = a.perm ? a.perm[p2] : (a.perm_bits ? perm_index(p2, a.N, a.perm_key, a.perm_bits) : p2);
                 const int64_t li2 = gi - a.idx_lo;
-                if (li2 >= 0 && li2 < a.n_local) { const float v = REC ? a.rec[2 * li2 + 1].y : a.adv[li2]; ls_ += v; lq_ += (double)v * v; }
+                if (li2 >= 0 && li2 < a.n_local) { const float v = REC ? a.rec[RecLayout<D>::RS * li2 + RecLayout<D>::RS - 1].y : a.adv[li2]; ls_ += v; lq_ += (double)v * v; }
             }
             shd[tid] = ls_; shd[256 + tid] = lq_;
             __syncthreads();
@@ -96,7 +96,8 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
     const int g = (int)(blockIdx.x % a.G);                          // the first G workgroups run the actor, the next G the critic
     const int64_t ntiles = (a.count + kTile - 1) / kTile;
     const int64_t tstride = (int64_t)a.G * 4, first = (int64_t)g * 4 + wave;
-    TileIn<O> cur, nxt;
+    constexpr int KS = FirstLayer<D>::KS;
+    TileIn<O, KS> cur, nxt;
     int64_t tile = first;
     if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
 #ifdef DRIL_STAMPS
@@ -107,12 +108,14 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
         load_tile<KIND, O, HEAD, REC>(a, tile + tstride, ntiles, c, h, nxt);      // prefetch the next tile's gathers
         unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
         const bool valid = cur.valid;
-        float xk[2] = {cur.xk[0], cur.xk[1]};
+        float xk[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xk[s] = cur.xk[s];
         STAMP(0);
         // ---- forward ----
         f32x16 h1[MT], h2[MT];
         float out[O], dz[O];
-        dense_first<H, MT>(wl + L::W1T, wl + L::B1, xk, h1, lane);
+        dense_first<H, MT, KS>(wl + L::W1T, wl + L::B1, xk, h1, lane);
         tanh_tiles(h1);
         STAMP(1);
 #pragma unroll
@@ -203,7 +206,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
         // ---- dW1 | db1 += dz1 * [x; 1]' ----
         store_image<MT>(T, g1, lane);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
+        for (int s = 0; s < KS; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
         {   // v_mfma_f32_16x16x4_f32: M = 16 hidden rows, N = 16 columns [x_0..x_{D-1}, 1, 0...], K = 4 samples per step
             const int j = lane & 15;
             float bx[8];
@@ -301,6 +304,7 @@ template <int KIND, int H> static size_t grad_lds_bytes() {
         else if (((kind) == 1 || (kind) == 2) && (hidden) == 64) { CALL(1, 64); }    \
         else if ((kind) == 3 && (hidden) == 64) { CALL(3, 64); }                     \
         else if ((kind) == 4 && (hidden) == 64) { CALL(4, 64); }                     \
+        else if ((kind) == 6 && (hidden) == 64) { CALL(6, 64); }                     \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 

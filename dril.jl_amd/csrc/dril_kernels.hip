@@ -362,9 +362,9 @@ __global__ void monitor_collect_kernel(const uint8_t* __restrict__ flags, const 
 
 // (distribution heads: dril_heads.h)
 // first-layer B operand from an observation held in registers: xk[s] = obs[2s + h] (static register indices only)
-template <int D> __device__ __forceinline__ void pair_obs(const float (&obs)[D], int h, float (&xk)[2]) {
+template <int D> __device__ __forceinline__ void pair_obs(const float (&obs)[D], int h, float (&xk)[FirstLayer<D>::KS]) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < FirstLayer<D>::KS; ++s) {
         const float v0 = (2 * s < D) ? obs[(2 * s < D) ? 2 * s : 0] : 0.f;
         const float v1 = (2 * s + 1 < D) ? obs[(2 * s + 1 < D) ? 2 * s + 1 : 0] : 0.f;
         xk[s] = h ? v1 : v0;
@@ -373,7 +373,7 @@ template <int D> __device__ __forceinline__ void pair_obs(const float (&obs)[D],
 
 template <int D, int H, int O> struct NetLdsSplit {
     static_assert(H == 64, "the split kernel is laid out for hidden_dims [64,64]");
-    static constexpr int DP = 4, OP = (O + 3) / 4 * 4;
+    static constexpr int DP = FirstLayer<D>::DP, OP = (O + 3) / 4 * 4;
     static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, SMALL_END = (B3 + OP + 3) / 4 * 4;
     static constexpr int W2P = SMALL_END;                    // three pieces x [64][64] bf16 = 3 x 8192 bytes
     static constexpr int END = W2P + 3 * H * H / 2;          // in floats
@@ -403,14 +403,14 @@ __device__ __forceinline__ bf16x8 chunk_frag(const unsigned (&pc)[3][4], int p) 
 // L1 on the f32 MFMA (K = 4), tanh and split of h1 a k16 step at a time, L2 as six v_mfma_f32_32x32x16_bf16 per step against the swizzled W2 piece image, tanh, L3 on
 // the VALU.  Against the f32-MFMA forward (64 x 64 cycles on the VALU's lanes per net and tile) this is 48 x 32 cycles of matrix pipe + ~180 VALU instructions.
 template <int D, int H, int O>
-__device__ __forceinline__ void net_forward_split(const float* __restrict__ lds, const float (&xk)[2], float (&out)[O], int lane) {
+__device__ __forceinline__ void net_forward_split(const float* __restrict__ lds, const float (&xk)[FirstLayer<D>::KS], float (&out)[O], int lane) {
     using L = NetLdsSplit<D, H, O>;
     constexpr int MT = H / 32;
     const int c = lane & 31, h = lane >> 5;
     const char* Wimg = reinterpret_cast<const char*>(lds + L::W2P);
     const int wf_base = c * 128 + (((h ^ w2img_gw(c)) & 15) << 3);
     f32x16 h1[MT], acc[MT];
-    dense_first<H, MT>(lds + L::W1T, lds + L::B1, xk, h1, lane);
+    dense_first<H, MT, FirstLayer<D>::KS>(lds + L::W1T, lds + L::B1, xk, h1, lane);
 #pragma unroll
     for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
@@ -449,7 +449,7 @@ __device__ __forceinline__ void net_forward_split(const float* __restrict__ lds,
 #endif
 // forward of one net for a 32-sample tile: LDS-resident weights (H = 64) or the wide path (W2 streamed from L2)
 template <int D, int H, int O, bool WIDE>
-__device__ __forceinline__ void eval_net(const float* __restrict__ lds, const float* __restrict__ w2a, const float (&xk)[2], float (&out)[O], int lane) {
+__device__ __forceinline__ void eval_net(const float* __restrict__ lds, const float* __restrict__ w2a, const float (&xk)[FirstLayer<D>::KS], float (&out)[O], int lane) {
     if constexpr (WIDE) net_forward_wide<D, H, O>(lds, w2a, xk, out, lane);
     else if constexpr (DRIL_FWD_SPLIT) net_forward_split<D, H, O>(lds, xk, out, lane);
     else { f32x16 h1[H / 32], h2[H / 32]; net_forward<D, H, H, O>(lds, xk, h1, h2, out, lane); }
@@ -496,20 +496,20 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void policy_kernel(PolicyArgs a)
         if (a.boot_where) {                                                        // V(terminal_observation) of the previous env step
             const bool tr = valid && a.boot_where[bb] != 0;
             if (__any(tr)) {
-                float tk[2];
+                float tk[FirstLayer<D>::KS];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; tk[s] = d < D ? a.boot_obs[bb * D + d] : 0.f; }
+                for (int s = 0; s < FirstLayer<D>::KS; ++s) { const int d = 2 * s + h; tk[s] = d < D ? a.boot_obs[bb * D + d] : 0.f; }
                 float bv[1];
                 eval_net<D, H, 1, WIDE>(lc, a.w2a_critic, tk, bv, lane);
                 if (tr && h == 0) a.boot_out[b] = bv[0];
             }
         }
-        float xk[2];
+        float xk[FirstLayer<D>::KS];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; xk[s] = d < D ? a.obs[bb * D + d] : 0.f; }
+        for (int s = 0; s < FirstLayer<D>::KS; ++s) { const int d = 2 * s + h; xk[s] = d < D ? a.obs[bb * D + d] : 0.f; }
         if (a.obs_out && valid) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; if (d < D) a.obs_out[b * D + d] = xk[s]; }
+            for (int s = 0; s < FirstLayer<D>::KS; ++s) { const int d = 2 * s + h; if (d < D) a.obs_out[b * D + d] = xk[s]; }
         }
         float v[1];
         eval_net<D, H, 1, WIDE>(lc, a.w2a_critic, xk, v, lane);
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
         // ds_reads into VGPRs (which spilled at the 256-register budget of 2 waves/SIMD)
         int zoff = 0; asm volatile("" : "+v"(zoff));
         const float* la_t = la + zoff; const float* lc_t = lc + zoff;
-        float xk[2];
+        float xk[FirstLayer<D>::KS];
         pair_obs<D>(obs, h, xk);
         float v[1], out[A];
         eval_net<D, H, 1, WIDE>(lc_t, a.w2a_critic, xk, v, lane);
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
         const bool trunc = sc >= a.episode_len;
         if (__any(trunc && valid)) {                                         // V(terminal_observation), trajectory.jl:57-61
             float tobs[D]; env_obs<KIND>(st, tobs);
-            float tk[2];
+            float tk[FirstLayer<D>::KS];
             pair_obs<D>(tobs, h, tk);
             float bv[1];
             eval_net<D, H, 1, WIDE>(lc_t, a.w2a_critic, tk, bv, lane);
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
         env_obs<KIND>(st, obs);                                              // observe(env), trajectory.jl:45
     }
     {   // V(new_obs) for rollout-limited trajectories, trajectory.jl:65-70 (computed for every env; GAE uses it when needed)
-        float xk[2];
+        float xk[FirstLayer<D>::KS];
         pair_obs<D>(obs, h, xk);
         float v[1];
         eval_net<D, H, 1, WIDE>(lc, a.w2a_critic, xk, v, lane);
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(128, 2) void rollout_duo_kernel(RolloutArgs a) {
             const size_t k = (size_t)t * a.E + e;
             int zoff = 0; asm volatile("" : "+v"(zoff));
             const float* la_t = la + zoff;
-            float xk[2];
+            float xk[FirstLayer<D>::KS];
             pair_obs<D>(obs, h, xk);
             float out[A];
             eval_net<D, H, A, false>(la_t, a.w2a_actor, xk, out, lane);
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(128, 2) void rollout_duo_kernel(RolloutArgs a) {
             float obs[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) obs[i] = sl[i * 32 + c];
-            float xk[2], v[1];
+            float xk[FirstLayer<D>::KS], v[1];
             pair_obs<D>(obs, h, xk);
             eval_net<D, H, 1, false>(lc_t, a.w2a_critic, xk, v, lane);
             if (t < a.T) { if (writer) a.val[(size_t)t * a.E + e] = v[0]; }
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(128, 2) void rollout_duo_kernel(RolloutArgs a) {
                     float tobs[D];
 #pragma unroll
                     for (int i = 0; i < D; ++i) tobs[i] = sl[(D + i) * 32 + c];
-                    float tk[2], bv[1];
+                    float tk[FirstLayer<D>::KS], bv[1];
                     pair_obs<D>(tobs, h, tk);
                     eval_net<D, H, 1, false>(lc_t, a.w2a_critic, tk, bv, lane);
                     if (writer && trunc) a.boot[(size_t)(t - 1) * a.E + e] = bv[0];
@@ -931,14 +931,15 @@ __global__ void moments_finalize_kernel(const double* partials, int nblocks, dou
 template <int KIND>
 __global__ void pack_records_kernel(int64_t N, const float* __restrict__ obs, const void* __restrict__ act, const float* __restrict__ adv,
                                     const float* __restrict__ logp, const float* __restrict__ ret, float4* __restrict__ rec) {
-    constexpr int D = EnvSpec<KIND>::D;
+    constexpr int D = EnvSpec<KIND>::D, RS = RecLayout<D>::RS;          // D <= 4: {obs0..3}{scalars}; D <= 8: {obs0..3}{obs4..7}{scalars}
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int d = 0; d < D; ++d) o[d] = obs[n * D + d];
         const float a = EnvSpec<KIND>::discrete ? __int_as_float(((const int32_t*)act)[n]) : ((const float*)act)[n];
-        rec[2 * n] = make_float4(o[0], o[1], o[2], o[3]);
-        rec[2 * n + 1] = make_float4(a, adv[n], logp[n], ret[n]);
+        rec[RS * n] = make_float4(o[0], o[1], o[2], o[3]);
+        if (RS == 3) rec[RS * n + 1] = make_float4(o[4], o[5], o[6], o[7]);
+        rec[RS * n + RS - 1] = make_float4(a, adv[n], logp[n], ret[n]);
     }
 }
 
@@ -1167,6 +1168,7 @@ template <int KIND, int H, bool WIDE> static size_t fwd_lds_bytes() {
         else if ((kind) == 1 || (kind) == 2) DRIL_DISPATCH_H(1, hidden, CALL)        \
         else if ((kind) == 3) DRIL_DISPATCH_H(3, hidden, CALL)                       \
         else if ((kind) == 4) DRIL_DISPATCH_H(4, hidden, CALL)                       \
+        else if ((kind) == 6 && (hidden) == 64) { CALL(6, 64); }                     \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
@@ -1178,6 +1180,7 @@ template <int KIND, int H, bool WIDE> static size_t fwd_lds_bytes() {
         else if ((kind) == 2) DRIL_DISPATCH_H(2, hidden, CALL)                       \
         else if ((kind) == 3) DRIL_DISPATCH_H(3, hidden, CALL)                       \
         else if ((kind) == 4) DRIL_DISPATCH_H(4, hidden, CALL)                       \
+        else if ((kind) == 6 && (hidden) == 64) { CALL(6, 64); }                     \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
@@ -1288,12 +1291,12 @@ template <int KIND, int H> static size_t duo_lds_bytes() {
 }
 hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_t s) {
     static const bool no_duo = std::getenv("DRIL_NO_ROLLOUT_DUO") != nullptr;          // A/B knob
-    if (hidden == 64 && a.E <= 16384 && !no_duo && kind >= 0 && kind <= 4) {                                      // env counts that leave SIMDs idle: two waves per tile of 32 envs
+    if (hidden == 64 && a.E <= 16384 && !no_duo && ((kind >= 0 && kind <= 4) || kind == 6)) {                                      // env counts that leave SIMDs idle: two waves per tile of 32 envs
         const int blocks = (a.E + kTile - 1) / kTile;
 #define CALLD(K) { const size_t lds = duo_lds_bytes<K, 64>(); static bool attr_set = false; \
             if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)rollout_duo_kernel<K, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
             rollout_duo_kernel<K, 64><<<blocks, 128, lds, s>>>(a); }
-        if (kind == 0) CALLD(0) else if (kind == 1) CALLD(1) else if (kind == 2) CALLD(2) else if (kind == 3) CALLD(3) else CALLD(4)
+        if (kind == 0) CALLD(0) else if (kind == 1) CALLD(1) else if (kind == 2) CALLD(2) else if (kind == 3) CALLD(3) else if (kind == 6) CALLD(6) else CALLD(4)
 #undef CALLD
         return hipGetLastError();
     }
@@ -1354,6 +1357,7 @@ hipError_t launch_pack_records(int kind, int64_t N, const float* obs, const void
     if (kind == 0) pack_records_kernel<0><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
     else if (kind == 3) pack_records_kernel<3><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
     else if (kind == 4) pack_records_kernel<4><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
+    else if (kind == 6) pack_records_kernel<6><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
     else pack_records_kernel<1><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
     return hipGetLastError();
 }
@@ -1383,6 +1387,7 @@ static void kind_dims(int kind, int& D, int& A, bool& disc) {
         case 0: D = 4; A = 2; disc = true; break;
         case 3: D = 2; A = 3; disc = true; break;
         case 4: D = 2; A = 1; disc = false; break;
+        case 6: D = 6; A = 3; disc = true; break;
         default: D = 3; A = 1; disc = false; break;
     }
 }

@@ -290,7 +290,7 @@ def test_train_on_host_envs_learns(pkg):
 
 
 # ---- device envs with hidden_dims the fused kernels are not built for: the same generic kernels, step-granular rollout on the device -----------------
-@pytest.mark.parametrize("kind,H1,H2,norm", [(0, 32, 48, 0), (1, 100, 36, 1), (3, 64, 128, 0), (4, 512, 512, 0), (2, 24, 24, 1), (6, 64, 64, 0), (6, 48, 32, 1)])   # 6 = Acrobot-v1: six observation dims, always generic
+@pytest.mark.parametrize("kind,H1,H2,norm", [(0, 32, 48, 0), (1, 100, 36, 1), (3, 64, 128, 0), (4, 512, 512, 0), (2, 24, 24, 1), (6, 64, 64, 0), (6, 48, 32, 1)])   # 6 = Acrobot-v1 (six observation dims): fused at [64,64] since round 3, generic for other hidden_dims
 def test_device_env_with_other_hidden_dims(pkg, oracle_mod, kind, H1, H2, norm):
     """CartPole / Pendulum / MountainCar with hidden_dims outside {[64,64], [128,128], [256,256]}: rollout (env-keyed or injected noise, truncation
     bootstraps, NormalizeWrapperEnv) and the PPO update against the oracle"""

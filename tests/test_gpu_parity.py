@@ -100,7 +100,7 @@ def test_env_verbs_match_oracle(pkg, oracle_mod, kind):
     assert saw_trunc
 
 
-@pytest.mark.parametrize("kind,B", [(0, 1), (0, 31), (0, 32), (0, 1000), (1, 65), (1, 4096), (3, 333), (4, 97)])
+@pytest.mark.parametrize("kind,B", [(0, 1), (0, 31), (0, 32), (0, 1000), (1, 65), (1, 4096), (3, 333), (4, 97), (6, 1), (6, 777)])   # 6 = Acrobot-v1: six observation dims = four first-layer k-steps
 def test_policy_forward_evaluate_predict(pkg, oracle_mod, kind, B):
     """layer(obs,ps,st), evaluate_actions, predict_values (layer_forward.jl:3-39, layer_methods.jl:28-61)"""
     cfg = _cfg(pkg, kind, n_envs=2, n_steps=2, batch_size=2)
@@ -144,7 +144,7 @@ def _rollout_pair(pkg, oracle_mod, kind, E, T, L, seed, fixed=False):
     return cfg, h, o
 
 
-@pytest.mark.parametrize("kind,E,T,L,fixed", [(0, 64, 48, 500, False), (0, 100, 40, 9, True), (1, 33, 50, 12, False), (0, 1, 5, 3, False), (2, 40, 30, 12, False), (3, 70, 40, 15, False), (4, 33, 24, 10, False)])
+@pytest.mark.parametrize("kind,E,T,L,fixed", [(0, 64, 48, 500, False), (0, 100, 40, 9, True), (1, 33, 50, 12, False), (0, 1, 5, 3, False), (2, 40, 30, 12, False), (3, 70, 40, 15, False), (4, 33, 24, 10, False), (6, 50, 30, 9, False)])
 def test_collect_rollout_matches_oracle(pkg, oracle_mod, kind, E, T, L, fixed):
     """collect_rollout! (rollout_buffer.jl:46-90): every buffer field vs the trajectory-based oracle, with injected
     sampling noise and with the shared Philox stream; includes terminations, mid-rollout truncations with
@@ -207,7 +207,8 @@ def _batch(oracle, cfg, B, seed):
 
 
 @pytest.mark.parametrize("kind,B,variant", [(0, 64, "default"), (0, 33, "default"), (0, 4096, "ent_vfclip"), (0, 65536, "default"),
-                                             (1, 64, "default"), (1, 1000, "ent_vfclip"), (0, 200, "no_norm"), (3, 500, "ent_vfclip"), (4, 129, "default")])
+                                             (1, 64, "default"), (1, 1000, "ent_vfclip"), (0, 200, "no_norm"), (3, 500, "ent_vfclip"), (4, 129, "default"),
+                                             (6, 64, "default"), (6, 1001, "ent_vfclip"), (6, 131072 + 5, "default")])   # Acrobot (D = 6): three-quad records, the exact-f32 kernel for every size
 def test_ppo_loss_and_gradient(pkg, oracle_mod, kind, B, variant):
     """(alg::PPO)(...) ppo.jl:365-407 + gradient: loss within 1e-4 rel (north_star), gradient within fp32 noise"""
     kw = dict(n_envs=2, n_steps=2, batch_size=2)
@@ -259,6 +260,8 @@ def test_apply_gradients_clip_adam_nan(pkg, oracle_mod):
     (2, 12, 20, 60, {}),                                   # ScalingWrapperEnv(Pendulum): the update shares the Pendulum kernels
     (3, 12, 20, 60, {"ent_coef": 0.01}),                   # MountainCar-v0: Categorical over 3 actions, D = 2
     (4, 12, 20, 48, {}),                                   # MountainCarContinuous-v0
+    (6, 12, 20, 60, {"ent_coef": 0.01}),                   # Acrobot-v1 on the fused kernels (D = 6)
+    (6, 64, 32, 512, {}),
     (0, 16, 24, 96, {"has_target_kl": 1, "target_kl": 0.002}),
     (0, 16, 24, 384, {"has_clip_range_vf": 1, "clip_range_vf": 0.2}),
 ])
