@@ -63,8 +63,8 @@ enum dril_env_kind {
      * and the wrappers fused into the env kernels (norm_*, monitor_window) belong to the device envs and return DRIL_ERR_UNSUPPORTED here */
     DRIL_ENV_EXTERNAL = 5,
     /* Acrobot-v1 (Gymnasium "book" dynamics, one RK4 step of 0.2 s per env step): D=6 (cos t1, sin t1, cos t2, sin t2, w1, w2), Discrete(3) torques
-     * -1/0/+1, reward -1 per step (0 on reaching the height), limit 500.  A device env like the others; its six observation dims exceed the fused
-     * kernels' first-layer pairing, so it always runs on the generic kernels (any hidden_dims) */
+     * -1/0/+1, reward -1 per step (0 on reaching the height), limit 500.  A device env like the others; hidden_dims [64,64] run the fused kernels (four
+     * first-layer k-steps for its six observation dims, the exact-f32 update kernel), any other hidden_dims the generic kernels */
     DRIL_ENV_ACROBOT = 6
 };
 
