@@ -20,14 +20,50 @@ namespace dril {
 // Every wave owns distinct rows of every gradient: one slab per PAIR, written straight from registers.  a.G / a.Gc = pairs of the actor / the critic (even);
 // grid = (a.G + a.Gc) / 2 workgroups, the first a.G / 2 run the actor.
 // =============================================================================================
+// Every image starts at a multiple of 512 bytes of LDS (the dynamic segment itself is declared 1 KB-aligned).  Then bits 4-6 of a swizzled address ARE the chunk field
+// chunk ^ g(row), and stepping the chunk by a constant is an XOR of the whole address with that constant — one VALU per access, the image and piece offsets going into
+// the instruction's immediate, instead of xor / shift / add / add (round 3: - 60 VALU per wave and tile)
 template <int D, int O> struct PairLds {
     static constexpr int H = 64, DP = 4, OP = (O + 3) / 4 * 4;
-    static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, SMALL_END = (B3 + OP + 3) / 4 * 4;
+    static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, SMALL_END = (B3 + OP + 127) / 128 * 128;
     static constexpr int WIMG = SMALL_END;                    // three pieces x [64 out][64 in] bf16 = 3 x 8192 bytes
     static constexpr int PAIR0 = WIMG + 3 * 2048;
-    static constexpr int P1 = 0, P2 = P1 + 3 * 1024, PO = P2 + 3 * 1024, PAIR_SIZE = (PO + 2 * O * 32 + 3) / 4 * 4;   // per pair: two 12 KB piece images, [2 waves][O][32] partial sums
+    static constexpr int P1 = 0, P2 = P1 + 3 * 1024, PO = P2 + 3 * 1024, PAIR_SIZE = (PO + 2 * O * 32 + 127) / 128 * 128;   // per pair: two 12 KB piece images, [2 waves][O][32] partial sums
     static constexpr int END = PAIR0 + 2 * PAIR_SIZE;
+    static_assert((4 * WIMG) % 512 == 0 && (4 * PAIR0) % 512 == 0 && (4 * PAIR_SIZE) % 512 == 0 && (4 * P2) % 512 == 0, "image bases must be multiples of 512 bytes");
 };
+typedef __attribute__((address_space(3))) char lds_char;
+template <class T> __device__ __forceinline__ T pl_read(const lds_char* lds, int byte) { return *reinterpret_cast<const __attribute__((address_space(3))) T*>(lds + byte); }
+template <class T> __device__ __forceinline__ void pl_write(lds_char* lds, int byte, T v) { *reinterpret_cast<__attribute__((address_space(3))) T*>(lds + byte) = v; }
+// the lane's own chunks of m-tile w of a pair image (store_tile_pieces / load_tile_pieces of dril_split_pieces.h in the XOR form): t = pair base + row + chunk 4w of the
+// row + 8 (lane >> 5); IMG = byte offset of the image within the pair's block
+template <int IMG> __device__ __forceinline__ void pair_store_pieces(lds_char* lds, int t, const f32x16& x) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned hi[2], mid[2], lo[2];
+        split3_pair(x[4 * g], x[4 * g + 1], hi[0], mid[0], lo[0]); split3_pair(x[4 * g + 2], x[4 * g + 3], hi[1], mid[1], lo[1]);
+        const int a = t ^ (g << 4);
+        pl_write(lds, a + IMG, u32x2{hi[0], hi[1]}); pl_write(lds, a + IMG + 4096, u32x2{mid[0], mid[1]}); pl_write(lds, a + IMG + 8192, u32x2{lo[0], lo[1]});
+    }
+}
+template <int IMG> __device__ __forceinline__ void pair_load_pieces(const lds_char* lds, int t, f32x16& x) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int a = t ^ (g << 4);
+        const u32x2 hi = pl_read<u32x2>(lds, a + IMG), mid = pl_read<u32x2>(lds, a + IMG + 4096), lo = pl_read<u32x2>(lds, a + IMG + 8192);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            x[4 * g + 2 * k] = (__uint_as_float(hi[k] << 16) + __uint_as_float(mid[k] << 16)) + __uint_as_float(lo[k] << 16);
+            x[4 * g + 2 * k + 1] = (__uint_as_float(hi[k] & 0xffff0000u) + __uint_as_float(mid[k] & 0xffff0000u)) + __uint_as_float(lo[k] & 0xffff0000u);
+        }
+    }
+}
+// both half-waves get v(lower half) + v(upper half), in that order: one v_permlane32_swap instead of an LDS-crossbar permute (ds_bpermute + its address + its wait)
+__device__ __forceinline__ float both_halves_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 // A operand of dh1 = W2': lane (in-unit 32mk + (lane & 31), half kh) gets out-units 32mi + 16s + 8kh + j of the weight image (64 rows, piece stride 8192); tbase = wide_tr_base<64>
 __device__ __forceinline__ bf16x8 load_frag_W_T(const char* wimg, int tmk, int tmk16, int piece, int mi, int s) {   // tmk = tbase ^ (64 mk), tmk16 = tmk ^ 16 (see load_frag_wide_T)
     const int off = (32 * mi + 16 * s) * 128 + piece * 8192;
@@ -84,6 +120,13 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     }
     const float* ls = lsr;
     const int tbase = wide_tr_base<64>(lane);
+    lds_char* lds = (lds_char*)smem;
+    constexpr int kWimgB = 4 * L::WIMG, kP1B = 4 * L::P1, kP2B = 4 * L::P2;
+    const int pairB = 4 * (L::PAIR0 + pr * L::PAIR_SIZE);                                                 // byte offset of this pair's block (wave-uniform)
+    const int rowc = c * 128 + ((h ^ wimg_g<64>(c)) << 4);                                                // row c, chunk h of the row: row reads step the chunk by 2 ks
+    const int rowP = pairB + rowc;                                                                        // ... in a pair image (B operand of L2 / dh1)
+    const int rowW = rowc + 4096 * w;                                                                     // ... in the weight image, rows 32 w .. (A operand of L2)
+    const int ownT = pairB + c * 128 + 8 * h + (((4 * w) ^ wimg_g<64>(c)) << 4);                          // the lane's own chunk 4 w + g of row c (pair_store_pieces)
 
     f32x16 dW2[MT], dW3acc[O], db2acc, dW1acc[D], db1acc;            // dW2: rows 32w.., all 64 columns; the others: per-lane sums over this lane's samples (units rowfn(r, h) of m-tile w)
     float db3p[O], dlsp[O], st[5];
@@ -135,7 +178,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
             tanh16(h1w);
-            store_tile_pieces<64>(P1, w, h1w, opaque(lane));
+            pair_store_pieces<kP1B>(lds, opaque(ownT), h1w);
             if (kKeepH1) h1k = h1w;
         }
         STAMP(0);
@@ -150,14 +193,13 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B2 + 32 * w + 8 * q + 4 * h);
                 h2w[4 * q + 0] = b[0]; h2w[4 * q + 1] = b[1]; h2w[4 * q + 2] = b[2]; h2w[4 * q + 3] = b[3];
             }
-            const int lo_ = opaque(lane), cc = lo_ & 31, hh = lo_ >> 5, gsw = wimg_g<64>(cc);
-            const char* arow = Wimg + (32 * w + cc) * 128; const char* brow = P1 + cc * 128;
+            const int ra = opaque(rowW), rb = opaque(rowP);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {                                          // ks = 2 mi + s
-                const int ch = ((2 * ks + hh) ^ gsw) << 4;
+            for (int ks = 0; ks < 4; ++ks) {                                          // ks = 2 mi + s: chunk 2 ks + h of the row
+                const int ak = ra ^ (ks << 5), bk = rb ^ (ks << 5);
                 bf16x8 A[3], B[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) { A[p] = *reinterpret_cast<const bf16x8*>(arow + p * 8192 + ch); B[p] = *reinterpret_cast<const bf16x8*>(brow + p * 4096 + ch); }
+                for (int p = 0; p < 3; ++p) { A[p] = pl_read<bf16x8>(lds, ak + kWimgB + p * 8192); B[p] = pl_read<bf16x8>(lds, bk + kP1B + p * 4096); }
                 h2w = mfma_split6(A[0], A[1], A[2], B[0], B[1], B[2], h2w);
             }
             tanh16(h2w);
@@ -174,8 +216,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
                 p = fmaf(wv[0], h2w[4 * q + 0], p); p = fmaf(wv[1], h2w[4 * q + 1], p);
                 p = fmaf(wv[2], h2w[4 * q + 2], p); p = fmaf(wv[3], h2w[4 * q + 3], p);
             }
-            p += __shfl_xor(p, 32);
-            if (h == 0) PO[(w * O + o) * 32 + c] = p;
+            PO[(w * O + o) * 32 + c] = both_halves_sum(p);                                // both half-waves write the same bits to the same word
         }
         __syncthreads();                                                              // B2: both partial sums
         STAMP(3);
@@ -201,7 +242,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * fmaf(-hv, hv, 1.0f); }
         }
         add16(db2acc, h2w);
-        store_tile_pieces<64>(P2, w, h2w, opaque(lane));
+        pair_store_pieces<kP2B>(lds, opaque(ownT), h2w);
         STAMP(4);
         __syncthreads();                                                              // B3: the pair's dz2 image complete
         STAMP(5);
@@ -210,26 +251,30 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) g1[r] = 0.f;
-            const int lo_ = opaque(lane), cc = lo_ & 31, hh = lo_ >> 5, gsw = wimg_g<64>(cc), tbw = opaque(tbase) ^ (64 * w), tbw16 = tbw ^ 16;
-            const char* brow = P2 + cc * 128;
+            const int rb = opaque(rowP), tbw = opaque(tbase) ^ (64 * w), tbw16 = tbw ^ 16;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int ch = ((2 * ks + hh) ^ gsw) << 4;
+                const int bk = rb ^ (ks << 5);
                 bf16x8 A[3], B[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) { A[p] = load_frag_W_T(Wimg, tbw, tbw16, p, ks >> 1, ks & 1); B[p] = *reinterpret_cast<const bf16x8*>(brow + p * 4096 + ch); }
+                for (int p = 0; p < 3; ++p) { A[p] = load_frag_W_T(Wimg, tbw, tbw16, p, ks >> 1, ks & 1); B[p] = pl_read<bf16x8>(lds, bk + kP2B + p * 4096); }
                 g1 = mfma_split6(A[0], A[1], A[2], B[0], B[1], B[2], g1);
             }
             f32x16 h1r;
-            if (kKeepH1) h1r = h1k; else load_tile_pieces<64>(P1, w, h1r, lo_);         // h1 tile w rebuilt from its own pieces (exact)
+            if (kKeepH1) h1r = h1k; else pair_load_pieces<kP1B>(lds, opaque(ownT), h1r);   // h1 tile w rebuilt from its own pieces (exact)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[r] = g1[r] * fmaf(-t2, kInvTanhScale, kInvTanhScale); }
         }
         STAMP(6);
         // ---- dW1 | db1: per-lane accumulation, dW1[unit][d] += dz1[unit][sample] x[sample][d] ----
         {
-            const float xo0 = __shfl_xor(xk[0], 32), xo1 = __shfl_xor(xk[1], 32);      // the other half holds x[2s + 1 - h]
-            const float x4[4] = {h ? xo0 : xk[0], h ? xk[0] : xo0, h ? xo1 : xk[1], h ? xk[1] : xo1};
+            float x4[4];                                                               // xk[s] = x[2 s + h]: the lower half's value is x[2 s], the upper half's x[2 s + 1]
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned u = __float_as_uint(xk[s]);
+                const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                x4[2 * s] = __uint_as_float(r[0]); x4[2 * s + 1] = __uint_as_float(r[1]);
+            }
 #pragma unroll
             for (int d = 0; d < D; ++d) fma16(dW1acc[d], x4[d], g1);
             add16(db1acc, g1);
@@ -300,7 +345,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
 
 template <int KIND>
 __global__ __launch_bounds__(256, 2) void ppo_grad_pair_kernel(GradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(1024))) float smem[];          // PairLds: XOR addressing needs 512-byte image bases
     if (*a.stop_flag) return;
     constexpr int A = EnvSpec<KIND>::A;
     const bool actor = blockIdx.x < (unsigned)(a.G / 2);
