@@ -32,38 +32,6 @@ template <int D, int O> struct PairLds {
     static constexpr int END = PAIR0 + 2 * PAIR_SIZE;
     static_assert((4 * WIMG) % 512 == 0 && (4 * PAIR0) % 512 == 0 && (4 * PAIR_SIZE) % 512 == 0 && (4 * P2) % 512 == 0, "image bases must be multiples of 512 bytes");
 };
-typedef __attribute__((address_space(3))) char lds_char;
-template <class T> __device__ __forceinline__ T pl_read(const lds_char* lds, int byte) { return *reinterpret_cast<const __attribute__((address_space(3))) T*>(lds + byte); }
-template <class T> __device__ __forceinline__ void pl_write(lds_char* lds, int byte, T v) { *reinterpret_cast<__attribute__((address_space(3))) T*>(lds + byte) = v; }
-// the lane's own chunks of m-tile w of a pair image (store_tile_pieces / load_tile_pieces of dril_split_pieces.h in the XOR form): t = pair base + row + chunk 4w of the
-// row + 8 (lane >> 5); IMG = byte offset of the image within the pair's block
-template <int IMG> __device__ __forceinline__ void pair_store_pieces(lds_char* lds, int t, const f32x16& x) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        unsigned hi[2], mid[2], lo[2];
-        split3_pair(x[4 * g], x[4 * g + 1], hi[0], mid[0], lo[0]); split3_pair(x[4 * g + 2], x[4 * g + 3], hi[1], mid[1], lo[1]);
-        const int a = t ^ (g << 4);
-        pl_write(lds, a + IMG, u32x2{hi[0], hi[1]}); pl_write(lds, a + IMG + 4096, u32x2{mid[0], mid[1]}); pl_write(lds, a + IMG + 8192, u32x2{lo[0], lo[1]});
-    }
-}
-template <int IMG> __device__ __forceinline__ void pair_load_pieces(const lds_char* lds, int t, f32x16& x) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int a = t ^ (g << 4);
-        const u32x2 hi = pl_read<u32x2>(lds, a + IMG), mid = pl_read<u32x2>(lds, a + IMG + 4096), lo = pl_read<u32x2>(lds, a + IMG + 8192);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            x[4 * g + 2 * k] = (__uint_as_float(hi[k] << 16) + __uint_as_float(mid[k] << 16)) + __uint_as_float(lo[k] << 16);
-            x[4 * g + 2 * k + 1] = (__uint_as_float(hi[k] & 0xffff0000u) + __uint_as_float(mid[k] & 0xffff0000u)) + __uint_as_float(lo[k] & 0xffff0000u);
-        }
-    }
-}
-// both half-waves get v(lower half) + v(upper half), in that order: one v_permlane32_swap instead of an LDS-crossbar permute (ds_bpermute + its address + its wait)
-__device__ __forceinline__ float both_halves_sum(float v) {
-    const unsigned u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 // A operand of dh1 = W2': lane (in-unit 32mk + (lane & 31), half kh) gets out-units 32mi + 16s + 8kh + j of the weight image (64 rows, piece stride 8192); tbase = wide_tr_base<64>
 __device__ __forceinline__ bf16x8 load_frag_W_T(const char* wimg, int tmk, int tmk16, int piece, int mi, int s) {   // tmk = tbase ^ (64 mk), tmk16 = tmk ^ 16 (see load_frag_wide_T)
     const int off = (32 * mi + 16 * s) * 128 + piece * 8192;

@@ -37,6 +37,41 @@ __device__ __forceinline__ void load_tile_pieces(const char* pimg, int w, f32x16
         }
     }
 }
+// ---- XOR form of the swizzled addresses (ppo_grad_pair_kernel, ppo_update_small_kernel; round 3).  When every image starts at a multiple of 512 bytes of LDS, bits 4-6
+// of a swizzled address ARE the chunk field chunk ^ g(row), and stepping the chunk by a constant is an XOR of the whole address with that constant: one VALU per
+// access, image and piece offsets in the instruction's immediate, instead of xor / shift / add / add.  Addresses are byte offsets into the dynamic LDS segment.
+typedef __attribute__((address_space(3))) char lds_char;
+template <class T> __device__ __forceinline__ T pl_read(const lds_char* lds, int byte) { return *reinterpret_cast<const __attribute__((address_space(3))) T*>(lds + byte); }
+template <class T> __device__ __forceinline__ void pl_write(lds_char* lds, int byte, T v) { *reinterpret_cast<__attribute__((address_space(3))) T*>(lds + byte) = v; }
+// the lane's own chunks of m-tile w of a pair image (store_tile_pieces / load_tile_pieces of dril_split_pieces.h in the XOR form): t = pair base + row + chunk 4w of the
+// row + 8 (lane >> 5); IMG = byte offset of the image within the pair's block
+template <int IMG> __device__ __forceinline__ void pair_store_pieces(lds_char* lds, int t, const f32x16& x) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned hi[2], mid[2], lo[2];
+        split3_pair(x[4 * g], x[4 * g + 1], hi[0], mid[0], lo[0]); split3_pair(x[4 * g + 2], x[4 * g + 3], hi[1], mid[1], lo[1]);
+        const int a = t ^ (g << 4);
+        pl_write(lds, a + IMG, u32x2{hi[0], hi[1]}); pl_write(lds, a + IMG + 4096, u32x2{mid[0], mid[1]}); pl_write(lds, a + IMG + 8192, u32x2{lo[0], lo[1]});
+    }
+}
+template <int IMG> __device__ __forceinline__ void pair_load_pieces(const lds_char* lds, int t, f32x16& x) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int a = t ^ (g << 4);
+        const u32x2 hi = pl_read<u32x2>(lds, a + IMG), mid = pl_read<u32x2>(lds, a + IMG + 4096), lo = pl_read<u32x2>(lds, a + IMG + 8192);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            x[4 * g + 2 * k] = (__uint_as_float(hi[k] << 16) + __uint_as_float(mid[k] << 16)) + __uint_as_float(lo[k] << 16);
+            x[4 * g + 2 * k + 1] = (__uint_as_float(hi[k] & 0xffff0000u) + __uint_as_float(mid[k] & 0xffff0000u)) + __uint_as_float(lo[k] & 0xffff0000u);
+        }
+    }
+}
+// both half-waves get v(lower half) + v(upper half), in that order: one v_permlane32_swap instead of an LDS-crossbar permute (ds_bpermute + its address + its wait)
+__device__ __forceinline__ float both_halves_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 // operand of a product that sums over SAMPLES: lane (unit 32m + (lane & 31), half kh) gets samples 16s + 8kh + j of its unit; tbase from wide_tr_base
 template <int H>
 __device__ __forceinline__ int wide_tr_base(int lane) {
