@@ -127,7 +127,7 @@ struct dril_handle {
     LoopGroup* loop = nullptr;   // debug loopback communicator (dril_debug_comm_loopback)
     int64_t allreduce_calls = 0;
     bool no_small_path = false, no_epoch_moments = false;   // DRIL_NO_SMALL_PATH / DRIL_NO_EPOCH_MOMENTS, latched in dril_create
-    bool no_persistent = false; uint64_t* epoch_keys = nullptr; int epoch_keys_cap = 0; int64_t small_chunk = 16384;   // ppo_update_small_kernel (batch_size <= 64): DRIL_NO_PERSISTENT_UPDATE; per-epoch DataLoader keys on the device
+    bool no_persistent = false; unsigned long long* small_xchg = nullptr; uint64_t* epoch_keys = nullptr; int epoch_keys_cap = 0; int64_t small_chunk = 16384;   // ppo_update_small_kernel (batch_size <= 64): DRIL_NO_PERSISTENT_UPDATE; per-epoch DataLoader keys on the device
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
     double prof_ms[DRIL_K_COUNT] = {0}; int64_t prof_n[DRIL_K_COUNT] = {0};
     std::string err;
@@ -600,7 +600,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     if (h->ext_stage_rew) (void)hipHostFree(h->ext_stage_rew); if (h->ext_stage_flags) (void)hipHostFree(h->ext_stage_flags);
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
-                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->epoch_index, h->epoch_keys, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
+                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->epoch_index, h->epoch_keys, h->small_xchg, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
                     h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->e_rew_n, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->gen_tmp, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->w2p_actor, h->w2tp_actor, h->w2p_critic, h->w2tp_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
                     h->mon_ring_len, h->e_ep_len, h->mon_cnt, h->mon_meta, h->e_flags};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -1041,6 +1041,8 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
         u.target_kl = h->cfg.target_kl; u.ent_coef = h->cfg.ent_coef; u.vf_coef = h->cfg.vf_coef; u.clip_range = h->cfg.clip_range; u.clip_range_vf = h->cfg.clip_range_vf;
         u.has_max_grad_norm = h->cfg.has_max_grad_norm; u.has_target_kl = h->cfg.has_target_kl; u.has_clip_vf = h->cfg.has_clip_range_vf;
         u.normalize_adv = h->cfg.normalize_advantage; u.action_start = h->cfg.action_start; u.P = h->P; u.Pa = h->Pa; u.Pc = h->Pc; u.dbg = h->dbg;
+        if (!h->small_xchg) HIPCHK(h, dmalloc(&h->small_xchg, (size_t)kSmallXchgWords));
+        u.xchg = h->small_xchg;
         const int64_t chunk = h->small_chunk;                                          // optimiser steps per launch (16 384: a bound on one kernel's run time, ~0.2 s)
         for (int64_t s0 = 0; s0 < total_steps; s0 += chunk) {
             u.step0 = (int)s0; u.nsteps = (int)(total_steps - s0 < chunk ? total_steps - s0 : chunk);

@@ -709,13 +709,14 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int CTRL, int BANK = 0xf> __device__ __forceinline__ float dpp_mov(float old, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, BANK, false));
 }
-// sums of the 16 registers of x over the 32 lanes of each half-wave, as a reduce-scatter on the VALU (DPP): out[i] = sum over the half of x[4 i + (lane & 3)],
-// valid in every lane.  The two quad steps halve the register count while they add (lane bit b keeps the registers whose index has bit b set and receives its
-// partner's copy of them), the remaining steps are butterflies on four registers: 60 VALU + 4 LDS-crossbar permutes instead of 16 x 5 permutes with their waits
-// (tools/micro/dpp_reduce.hip checks it against a plain sum).  EXEC must be all ones.
-__device__ __forceinline__ void half_reduce16(const f32x16& x, int lane, float (&out)[4]) {
-    const bool b0 = lane & 1, b1 = lane & 2;
-    float y[8];
+// sums of the 16 registers of x over the 32 lanes of each half-wave, as a complete reduce-scatter on the VALU: lane l returns the sum over its half of x[l & 15] (every
+// value twice per half: lanes l and l ^ 16).  Each step halves the register count while it adds — lane bit b keeps the registers whose index has bit b set and receives
+// its partner's copy of them (quad_perm for lane bits 0 and 1, row_shl / row_shr:4 under bank masks for bit 2, row_ror:8 for bit 3) — and the two rows of a half
+// meet in one v_permlane16_swap: ~52 VALU and no LDS-crossbar permute (first form of round 3: scatter to four registers, then butterflies and four ds_bpermute:
+// 60 VALU + 4 permutes with their waits).  tools/micro/dpp_reduce2.hip checks it against a plain sum.  EXEC must be all ones.
+__device__ __forceinline__ float half_reduce16_lane(const f32x16& x, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+    float y[8], z[4], u[2];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         // (the two elements as opaque scalars: otherwise LLVM folds `b0 ? x[2i+1] : x[2i]` into a vector element with a VARIABLE index = a 16-way compare / select chain)
@@ -725,16 +726,19 @@ __device__ __forceinline__ void half_reduce16(const f32x16& x, int lane, float (
         y[i] = keep + dpp_mov<0xB1>(0.f, send);                                       // quad_perm [1,0,3,2]
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const float keep = b1 ? y[2 * i + 1] : y[2 * i], send = b1 ? y[2 * i] : y[2 * i + 1]; out[i] = keep + dpp_mov<0x4E>(0.f, send); }   // quad_perm [2,3,0,1]
+    for (int i = 0; i < 4; ++i) { const float keep = b1 ? y[2 * i + 1] : y[2 * i], send = b1 ? y[2 * i] : y[2 * i + 1]; z[i] = keep + dpp_mov<0x4E>(0.f, send); }   // quad_perm [2,3,0,1]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float t = dpp_mov<0x104, 0x5>(0.f, out[i]);        // row_shl:4 -> the lanes of banks 0 and 2 receive lane + 4
-        t = dpp_mov<0x114, 0xa>(t, out[i]);                // row_shr:4 -> the lanes of banks 1 and 3 receive lane - 4
-        out[i] += t;
-        out[i] += dpp_mov<0x128>(0.f, out[i]);             // row_ror:8 = lane ^ 8
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b2 ? z[2 * i + 1] : z[2 * i], send = b2 ? z[2 * i] : z[2 * i + 1];
+        float t = dpp_mov<0x104, 0x5>(0.f, send);          // row_shl:4 -> the lanes of banks 0 and 2 receive lane + 4
+        t = dpp_mov<0x114, 0xa>(t, send);                  // row_shr:4 -> the lanes of banks 1 and 3 receive lane - 4
+        u[i] = keep + t;
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out[i] += __shfl_xor(out[i], 16);   // the other row of the half
+    const float keep = b3 ? u[1] : u[0], send = b3 ? u[0] : u[1];
+    const float v = keep + dpp_mov<0x128>(0.f, send);      // row_ror:8 = lane ^ 8
+    const unsigned q = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(q, q, false, false);               // {even row's value in both rows of the half, odd row's value in both}
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 }  // namespace dril

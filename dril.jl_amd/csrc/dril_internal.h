@@ -84,7 +84,9 @@ struct SmallUpdateArgs {
     int has_max_grad_norm, has_target_kl, has_clip_vf, normalize_adv, action_start;
     int P, Pa, Pc;
     unsigned long long* dbg;      // -DDRIL_STAMPS diagnostic buffer (16 x u64 per wave), else unused
+    unsigned long long* xchg;     // kSmallXchgWords words {sequence, value}: the messages between the actor's and the critic's workgroup (zeroed by the launcher)
 };
+constexpr int kSmallXchgWords = 4 * 16;
 hipError_t launch_ppo_update_small(int kind, const SmallUpdateArgs& a, hipStream_t s);
 hipError_t launch_epoch_index(int64_t N, uint64_t key, int bits, int64_t* out, hipStream_t s);
 
