@@ -1042,7 +1042,7 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
         u.has_max_grad_norm = h->cfg.has_max_grad_norm; u.has_target_kl = h->cfg.has_target_kl; u.has_clip_vf = h->cfg.has_clip_range_vf;
         u.normalize_adv = h->cfg.normalize_advantage; u.action_start = h->cfg.action_start; u.P = h->P; u.Pa = h->Pa; u.Pc = h->Pc; u.dbg = h->dbg;
         if (!h->small_xchg) HIPCHK(h, dmalloc(&h->small_xchg, (size_t)kSmallXchgWords));
-        u.xchg = h->small_xchg;
+        u.xchg = h->small_xchg; u.debug_solo = std::getenv("DRIL_SMALL_DEBUG_SOLO") != nullptr;
         const int64_t chunk = h->small_chunk;                                          // optimiser steps per launch (16 384: a bound on one kernel's run time, ~0.2 s)
         for (int64_t s0 = 0; s0 < total_steps; s0 += chunk) {
             u.step0 = (int)s0; u.nsteps = (int)(total_steps - s0 < chunk ? total_steps - s0 : chunk);
@@ -1156,6 +1156,7 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
         out->explained_variance = (float)(1.0 - var_d / var_r); out->ratio_first = ratio_first;
         out->n_updates = n_upd; out->early_stopped = stopped; out->nan_or_inf = nan;
     }
+    if (nan == 2) return fail(h, DRIL_ERR_HIP, "ppo_update_small_kernel: the partner workgroup did not answer within the spin limit (its two workgroups must be resident together); DRIL_NO_PERSISTENT_UPDATE=1 selects the per-step kernels");
     if (nan) return fail(h, DRIL_ERR_NAN_IN_GRADS, "gradient contains nan or is not finite (ppo.jl:213-214)");
     return DRIL_OK;
 }
@@ -1213,6 +1214,7 @@ DRIL_EXPORT int32_t dril_apply_gradients(dril_handle* h, const float* grads, siz
     HIPCHK(h, hipMemcpyAsync(&nan, h->nan_flag, 4, hipMemcpyDeviceToHost, h->stream));
     int rc = sync(h); if (rc) return rc;
     if (grad_norm) *grad_norm = norm;
+    if (nan == 2) return fail(h, DRIL_ERR_HIP, "ppo_update_small_kernel: the partner workgroup did not answer within the spin limit (its two workgroups must be resident together); DRIL_NO_PERSISTENT_UPDATE=1 selects the per-step kernels");
     if (nan) return fail(h, DRIL_ERR_NAN_IN_GRADS, "gradient contains nan or is not finite (ppo.jl:213-214)");
     return DRIL_OK;
 }

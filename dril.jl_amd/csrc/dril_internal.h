@@ -84,6 +84,7 @@ struct SmallUpdateArgs {
     int has_max_grad_norm, has_target_kl, has_clip_vf, normalize_adv, action_start;
     int P, Pa, Pc;
     unsigned long long* dbg;      // -DDRIL_STAMPS diagnostic buffer (16 x u64 per wave), else unused
+    int debug_solo;               // DRIL_SMALL_DEBUG_SOLO (tests): launch the actor's workgroup alone — it must give up waiting and report, not hang
     unsigned long long* xchg;     // kSmallXchgWords words {sequence, value}: the messages between the actor's and the critic's workgroup (zeroed by the launcher)
 };
 constexpr int kSmallXchgWords = 4 * 16;

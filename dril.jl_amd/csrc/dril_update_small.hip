@@ -292,7 +292,7 @@ __device__ __forceinline__ void small_param_map(int r, int& flat, int& goff, int
 // Exchange 0 (before the first step) carries the first minibatch's moments.  Two slots suffice: a role publishes message k + 2 only after it has seen message k + 1 of
 // the other role, which that role published after reading message k.  The launcher zeroes the buffer (sequence 0 = nothing yet).
 constexpr int kMsgWords = 16;
-constexpr unsigned kSpinLimit = 1u << 22;      // ~ seconds; reached only if the partner workgroup never runs (then: stop flag, nan flag = 2, both workgroups leave)
+constexpr unsigned kSpinLimit = 1u << 20;      // ~ a second (a step is 8 us); reached only if the partner workgroup never runs (then: stop flag, nan flag = 2, both workgroups leave)
 // wave 0 of a workgroup: publish shx[0..15], wait for the partner's message k, fetch it into xin[0..15]; false = gave up waiting
 __device__ __forceinline__ bool small_exchange(unsigned long long* xchg, int role, unsigned k, const float* shx, float* xin, int lane) {
     unsigned long long* mine = xchg + (role * 2 + (k & 1)) * kMsgWords;
@@ -560,7 +560,7 @@ hipError_t launch_ppo_update_small(int kind, const SmallUpdateArgs& a, hipStream
     { hipError_t e = hipMemsetAsync(a.xchg, 0, sizeof(unsigned long long) * kSmallXchgWords, s); if (e != hipSuccess) return e; }   // sequence number 0 = no message yet
 #define CALLU(K) { const size_t lds = update_small_lds_bytes<K>(); static bool attr_set = false; \
         if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_update_small_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
-        ppo_update_small_kernel<K><<<kSmallGrid, 256, lds, s>>>(a); }
+        ppo_update_small_kernel<K><<<a.debug_solo ? 1 : kSmallGrid, 256, lds, s>>>(a); }
     if (kind == 0) CALLU(0) else if (kind == 3) CALLU(3) else if (kind == 4) CALLU(4) else CALLU(1)
 #undef CALLU
     return hipGetLastError();

@@ -1055,6 +1055,30 @@ def test_persistent_small_update_across_launch_boundaries(pkg, oracle_mod, monke
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
 
 
+def test_persistent_small_update_gives_up_instead_of_hanging(pkg, oracle_mod, monkeypatch):
+    """the persistent update is TWO workgroups (actor | critic) that exchange one message per optimiser step through L2.  If the partner never runs, a workgroup
+    must leave after a bounded wait and the call must return a status code — never hang the device.  DRIL_SMALL_DEBUG_SOLO launches the actor's workgroup alone:
+    the update fails with DRIL_ERR_HIP within seconds, leaves the parameters untouched, and the same handle trains normally afterwards"""
+    import time
+    capi = pkg._capi
+    cfg = _cfg(pkg, 0, n_envs=8, n_steps=16, batch_size=32, epochs=1, episode_len=11)
+    o = oracle_mod.Oracle(cfg)
+    flat = _params(o.P, 3, 0.3); o.set_params(flat); o.env_reset(5); o.collect_rollout()
+    monkeypatch.setenv("DRIL_SMALL_DEBUG_SOLO", "1")
+    h = pkg.Handle(cfg); h.set_params(flat)
+    for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+        h.set_buffer(which, o.buffer(which))
+    t0 = time.time()
+    with pytest.raises(Exception) as ei:
+        h.ppo_update()
+    assert time.time() - t0 < 30.0 and "partner workgroup" in str(ei.value)
+    assert np.array_equal(h.get_params(), flat)
+    monkeypatch.delenv("DRIL_SMALL_DEBUG_SOLO")
+    st = h.ppo_update()                                                               # the knob is read per update: both workgroups again
+    assert st.n_updates == 4 and np.isfinite(st.loss) and not np.array_equal(h.get_params(), flat)
+    h.close()
+
+
 def test_epoch_index_array_is_the_same_dataloader_order(pkg, monkeypatch):
     """chip-filling minibatches read the epoch's DataLoader order from an index array written once per epoch (epoch_index_kernel) instead of evaluating the keyed
     bijection inside the update kernel: the same order, hence bitwise the same update as with DRIL_NO_EPOCH_INDEX=1"""
