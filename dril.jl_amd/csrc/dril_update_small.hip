@@ -440,22 +440,22 @@ __device__ __forceinline__ void small_net_loop(const SmallUpdateArgs& a, float* 
         lds_barrier();                                                                // B5: both pairs' gradients complete
         STAMP(10);
         // ---- optimiser phase, first part: this net's gradient and its share of |g|^2 ----
-        float gw[8][2], gs[3]; double ss = 0;
+        float gw[8][2], gs[3]; float ss = 0.f;                                         // 19 squares per thread in f32 (fixed order), 64 threads by DPP, 8 waves in index order
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const int off = S::S_W2 + wo * 65 + 2 * (wk + 4 * j) + e;
                 const float g = pairs[off] + pairs[off + S::SIZE];                   // pair 0 + pair 1, fixed order
-                gw[j][e] = g; ss += (double)g * (double)g;
+                gw[j][e] = g; ss = fmaf(g, g, ss);
             }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const float g = sflat[q] >= 0 ? pairs[sgoff[q]] + pairs[sgoff[q] + S::SIZE] : 0.f;
-            gs[q] = g; ss += (double)g * (double)g;
+            gs[q] = g; ss = fmaf(g, g, ss);
         }
-        {   // |g|^2: per thread in f64, per wave on the VALU, the waves of both workgroups in index order after the exchange
-            const float wsum = wave_sum_f32((float)ss);
+        {   // |g|^2: per thread and per wave on the VALU, the waves of both workgroups in index order after the exchange
+            const float wsum = wave_sum_f32(ss);
             if (lane == 0) shx[wave] = wsum;
         }
         if (wave == 3 && lane < 8) {                                                  // the statistics sums of the minibatch (the last wave has the least to do here)
@@ -474,12 +474,12 @@ __device__ __forceinline__ void small_net_loop(const SmallUpdateArgs& a, float* 
             alive = false; break;
         }
         const float* xa = ROLE == 0 ? shx : xin; const float* xc = ROLE == 0 ? xin : shx;   // the actor's and the critic's message
-        double tot = 0;
+        float tot = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) tot += (double)xa[k];
+        for (int k = 0; k < 4; ++k) tot += xa[k];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) tot += (double)xc[k];
-        const float norm = sqrtf((float)tot);
+        for (int k = 0; k < 4; ++k) tot += xc[k];
+        const float norm = __builtin_amdgcn_sqrtf(tot);                                 // (1 ulp; NaN / Inf pass through to the test below)
         const float n = (float)count, inv_n = 1.0f / n, kl = xa[4 + 3] * inv_n;
         const bool bad = !(norm == norm) || isinf(norm);                              // NaN / Inf anywhere poisons the norm (ppo.jl:213-214)
         const bool kl_stop = a.has_target_kl && kl > 1.5f * a.target_kl;              // ppo.jl:235-238: skip this apply, stop
@@ -495,7 +495,7 @@ __device__ __forceinline__ void small_net_loop(const SmallUpdateArgs& a, float* 
         }
         if (ROLE == 0 && tid == 0) { mom[0] = xc[5]; mom[1] = xc[6]; }                  // the next minibatch's advantage moments (read after the next top barrier)
         if (bad || kl_stop) break;                                                    // uniform in both workgroups: every thread computed the same norm / kl
-        const float scale = (a.has_max_grad_norm && norm > a.max_grad_norm) ? a.max_grad_norm / norm : 1.0f;   // optimization_utils.jl:98-107
+        const float scale = (a.has_max_grad_norm && norm > a.max_grad_norm) ? a.max_grad_norm * __builtin_amdgcn_rcpf(norm) : 1.0f;   // optimization_utils.jl:98-107
         // bias corrections once per step (every thread the same value); per parameter one hardware reciprocal and one hardware square root (1 ulp each: the update is
         // lr x O(1), so their error is ~1e-11 absolute — far below one ulp of a parameter) instead of three IEEE divisions and an IEEE square root (~40 instructions)
         const float ic1 = __builtin_amdgcn_rcpf(1.0f - bt1), ic2 = __builtin_amdgcn_rcpf(1.0f - bt2), omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
