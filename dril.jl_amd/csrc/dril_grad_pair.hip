@@ -8,9 +8,10 @@ namespace dril {
 
 // =============================================================================================
 // ppo_grad_pair_kernel — hidden [64,64], large minibatches: TWO waves own one 32-sample tile (wave p the m-tile p of every layer and the 32 x 64 slice p of dW2: the
-// decomposition of ppo_grad_wide_split_kernel at MT = 2), two pairs per workgroup, two workgroups per CU = TWO waves per SIMD at <= 256 registers.  That is the one
-// arrangement in which the matrix pipe and the VALU run beside each other on this part (profiles/r02_split_kernel.md: a lone wave's VALU work does not run under its own
-// MFMAs; a second wave's does, completely).  Same arithmetic as ppo_grad_split_kernel (bf16 matrix cores, fp32-equivalent 3-piece operand splitting).
+// decomposition of ppo_grad_wide_split_kernel at MT = 2), two pairs per workgroup, two workgroups per CU = TWO waves per SIMD at <= 256 registers: the second wave
+// covers the first one's LDS round trips, barriers and dependency stalls.  (It does NOT hide the vector work behind the MFMAs, as round 2 believed: matrix-pipe time and
+// vector-ALU time add on a SIMD, also across waves — profiles/r03_pair_kernel_notes.md.)  Same arithmetic as the one-wave split kernel of round 2 (bf16 matrix cores,
+// fp32-equivalent 3-piece operand splitting).
 //   * W2 lives in LDS once per workgroup as three bf16 pieces in the piece-image layout of the wide split kernel (128-byte rows, 16-byte chunk ch of row r at ch ^ f(r)):
 //     row reads (ds_read_b128) give the A operand of L2, ds_read_b64_tr_b16 the A operand of dh1 (W2'); pre-scaled by kTanhScale, dh1 folds 1 / kTanhScale into its mask.
 //   * each pair has two 12 KB piece images (h1, dz2): every wave writes its own 32 columns once; row reads give the B operand of L2 / dh1 (both m-tiles), transposed
