@@ -1020,7 +1020,7 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
     const int bits = perm_bits(N);
     if (h->rec) HIPCHK(h, launch_pack_records(h->cfg.env_kind, N, h->obs, h->act, h->adv, h->logp, h->ret, h->rec, h->stream));
     int64_t step = 0;
-    // the reference's default PPO() (batch_size = 64) on hidden [64,64]: every optimiser step of the iteration inside ONE persistent workgroup (dril_update_small.hip);
+    // the reference's default PPO() (batch_size = 64) on hidden [64,64]: every optimiser step of the iteration inside ONE launch of two persistent workgroups, one per net (dril_update_small.hip);
     // single-rank only (a data-parallel run all-reduces between the gradient and the step)
     const bool persistent = !h->wide && !h->generic && h->D <= 4 && world == 1 && !(comm_ready(h) && h->force_allreduce) && h->rec && B >= 2 && B <= 64 && h->P <= 512 * 18 &&
                             !h->no_persistent && !h->no_small_path && h->grad_variant < 0 && total_steps > 0;   // (DRIL_GRAD_VARIANT pins one of the per-step kernels)

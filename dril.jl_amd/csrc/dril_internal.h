@@ -72,7 +72,7 @@ struct GradArgs {
     NetOff actor, critic;
 };
 
-// ppo_update_small_kernel (dril_update_small.hip): a run of optimiser steps [step0, step0 + nsteps) of the epochs x minibatches sequence in one persistent workgroup
+// ppo_update_small_kernel (dril_update_small.hip): a run of optimiser steps [step0, step0 + nsteps) of the epochs x minibatches sequence in one launch of two persistent workgroups (actor, critic)
 struct SmallUpdateArgs {
     float* params; float* adam_m; float* adam_v; float* bt; int step_parity;
     const float4* rec; const float* val_old;
