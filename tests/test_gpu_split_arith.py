@@ -72,6 +72,42 @@ def test_selected_kernel_loss_and_gradient_vs_oracle(pkg, oracle_mod, kind, H, B
     assert lh2 == lh and np.array_equal(gh, gh2)                     # deterministic slabs
 
 
+@pytest.mark.parametrize("kind,H,variant", [(0, 64, "ent_vfclip"), (1, 64, "default"), (1, 256, "default")])
+def test_full_size_minibatch_is_the_weighted_mean_of_its_halves(pkg, kind, H, variant):
+    """the headline minibatch size of BASELINE configs[1] / configs[2] (B = 65 536 x 2048 / 32 = 4 194 304 samples per launch: 256 tiles per pair of ppo_grad_pair_kernel,
+    the multi-trip loop with the unequal actor / critic division of the chip) is too large for the oracle to be the checker in a test, but the loss is a MEAN over the
+    minibatch (ppo.jl:382-386), so with normalize_advantage off loss / statistics / gradient of the whole minibatch must be the sample-weighted mean of those of two
+    unequal parts — each of which is the size the direct oracle tests above cover per tile, run through different tile -> pair assignments and slab reductions.
+    f32 sums in different orders: loss and gradient to 2e-6 of their size (measured: loss 1e-9 ... 6e-8, gradient 1.1e-7 ... 1.4e-7 of its norm; tests/diag/full_size_additivity.py)"""
+    B = 4194304
+    kw = dict(n_envs=2, n_steps=2, batch_size=2, hidden1=H, hidden2=H, normalize_advantage=0)
+    if variant == "ent_vfclip":
+        kw.update(ent_coef=0.01, has_clip_range_vf=1, clip_range_vf=0.3, clip_range=0.1)
+    cfg = _cfg(pkg, kind, **kw)
+    h = pkg.Handle(cfg)
+    rng = np.random.default_rng(5)
+    flat = rng.uniform(-0.3, 0.3, h.P).astype(np.float32) if H == 64 else rng.uniform(-0.08, 0.08, h.P).astype(np.float32)
+    h.set_params(flat)
+    D, A, disc = h.D, h.A, h.discrete
+    obs = rng.uniform(-1, 1, (B, D)).astype(np.float32)
+    act = (rng.integers(0, A, B) + cfg.action_start).astype(np.int32) if disc else rng.normal(0, 1, (B, A)).astype(np.float32)
+    adv, ret, ov = (rng.standard_normal(B).astype(np.float32) for _ in range(3))
+    olp = rng.normal(-0.7, 0.1, B).astype(np.float32)                                  # old log-probabilities near those of a fresh policy: ratios on both sides of the clip
+    n1 = 1572864 + 37                                                                 # unequal parts, the first one with a ragged last tile
+    full = h.ppo_loss_grad(obs, act, adv, ret, olp, ov)
+    assert h.grad_kernel_info().split(":")[0] == EXPECTED[H]
+    parts = [h.ppo_loss_grad(obs[a:b], act[a:b], adv[a:b], ret[a:b], olp[a:b], ov[a:b]) for a, b in ((0, n1), (n1, B))]
+    w = np.array([n1, B - n1], np.float64) / B
+    loss = w[0] * parts[0][0] + w[1] * parts[1][0]
+    stats = w[0] * parts[0][1].astype(np.float64) + w[1] * parts[1][1].astype(np.float64)
+    grad = w[0] * parts[0][2].astype(np.float64) + w[1] * parts[1][2].astype(np.float64)
+    assert np.isfinite(full[0]) and abs(full[0] - loss) <= 2e-6 * max(1.0, abs(loss))
+    np.testing.assert_allclose(full[1], stats, rtol=2e-5, atol=2e-6)
+    gn = np.linalg.norm(grad)
+    assert gn > 0 and np.linalg.norm(full[2].astype(np.float64) - grad) <= 2e-6 * gn
+    h.close()
+
+
 @pytest.mark.parametrize("kind,H,E,T", [(0, 64, 2048, 128), (1, 64, 2048, 128), (1, 256, 512, 64), (0, 128, 512, 64)])
 def test_selected_kernel_update_vs_oracle(pkg, oracle_mod, kind, H, E, T):
     """one dril_ppo_update (2 epochs x 2 minibatches of N/2 samples: 131 072 at hidden 64, i.e. the pair kernel by the size rule) on the oracle's rollout and an
