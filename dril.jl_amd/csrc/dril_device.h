@@ -213,6 +213,36 @@ __device__ __forceinline__ f32x16 mfma_split6(bf16x8 Ah, bf16x8 Am, bf16x8 Al, b
     acc = mfma_bf16(Am, Bh, acc); acc = mfma_bf16(Ah, Bm, acc); acc = mfma_bf16(Ah, Bh, acc);
     return acc;
 }
+// ---------------------------------------------------------------------------------------------
+// the same on f16 pieces (round 3, ppo_grad_pair_kernel): x S = hi + lo with hi = rn_f16(x S), lo = rn_f16(x S - hi) (both roundings to nearest: hi carries 11 bits, the
+// exact remainder has at most 13 and lo keeps 11 of them, so |x S - hi - lo| <= 2^-24 |x S| — the relative precision of an f32 rounding — as long as lo stays a NORMAL
+// f16, i.e. |x S| >= 2^-14 2^11 = 0.125; below that the error is an absolute 2^-25.  The power-of-two scale S moves the operand range there: activations (|h| < 1) use
+// kActScale, the staged weights kWScale, the gradient tiles 4 / invB rounded up to a power of two.  A k16 step of a 32x32 tile is THREE v_mfma_f32_32x32x16_f16
+// (lo.hi, hi.lo, hi.hi; the dropped lo.lo is <= 2^-24 relative; f32 accumulate) instead of six bf16 ones, and a pair of values splits in 6 VALU instead of 11.
+// Against a float64 gradient this arithmetic is 1.05 - 1.2 x as far as the exact-f32 kernel (the six-product bf16 form 0.85 - 1.1 x, a four-product bf16 form
+// 12 - 39 x): tests/test_gpu_split_arith.py, profiles/r03_split_arith.md section 6.
+// f16 has a RANGE: |x S| > 65 504 overflows.  The scales leave |w| < 350 for weights, a factor ~ 4 000 over a typical gradient tile; an overflow becomes Inf / NaN in
+// the gradient and is reported like any non-finite gradient (ppo.jl:213-214), never silently wrong.
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+constexpr float kActScale = 256.0f, kWScale = 64.0f;
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, f16x2_t));       // v_cvt_pk_f16_f32 (round to nearest even)
+}
+__device__ __forceinline__ void split2_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = cvt_pk_f16(a, b);
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, hi);
+    lo = cvt_pk_f16(a - (float)h[0], b - (float)h[1]);                                            // exact remainders (Sterbenz), rounded once
+}
+__device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+// one k16 step of the two-piece product, small terms first.  -DDRIL_DEBUG_DROP_LO (negative control): hi.hi only, an 11-bit product
+__device__ __forceinline__ f32x16 mfma_split3(f16x8 Ah, f16x8 Al, f16x8 Bh, f16x8 Bl, f32x16 acc) {
+#ifndef DRIL_DEBUG_DROP_LO
+    acc = mfma_f16(Al, Bh, acc); acc = mfma_f16(Ah, Bl, acc);
+#endif
+    return mfma_f16(Ah, Bh, acc);
+}
 // ds_read_b64_tr_b16: per 16-lane group a block of 4 rows x 16 columns of 16-bit elements is delivered column-major — lane 4q+p of the group gives the
 // address of row q, columns 4p..4p+3; lane i receives column i, row q in element q (cdna_hip_programming.md T10).  EXEC must be all ones.
 __device__ __forceinline__ s16x4 lds_read_tr16(const char* lds_base, int byte_off) {
@@ -517,6 +547,19 @@ __device__ __forceinline__ void tanh16(f32x16& x) {
     for (int i = 0; i < 16; ++i) t[i] = __builtin_amdgcn_rcpf(t[i]);
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[i] = fmaf(-2.0f, t[i], 1.0f);
+}
+// tanh16 for the f16-piece kernels: the argument is x CIN (CIN = 1: none; undoes the operand scales of the product that made x), the result kActScale tanh —
+// the scale rides in the constants of the last fma
+template <bool SCALE_IN> __device__ __forceinline__ void tanh16_scaled(f32x16& x, float cin) {
+    f32x16 t;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = __builtin_amdgcn_exp2f(SCALE_IN ? x[i] * cin : x[i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = t[i] + 1.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = __builtin_amdgcn_rcpf(t[i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = fmaf(-2.0f * kActScale, t[i], kActScale);
 }
 // acc += s * x and acc += x on sixteen registers, as scalar v_fma_f32 / v_add_f32 (see tanh16)
 __device__ __forceinline__ void fma16(f32x16& acc, float s, const f32x16& x) {

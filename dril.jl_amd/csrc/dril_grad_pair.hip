@@ -26,17 +26,17 @@ namespace dril {
 // the instruction's immediate, instead of xor / shift / add / add (round 3: - 60 VALU per wave and tile)
 template <int D, int O> struct PairLds {
     static constexpr int H = 64, DP = 4, OP = (O + 3) / 4 * 4;
-    static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, SMALL_END = (B3 + OP + 127) / 128 * 128;
-    static constexpr int WIMG = SMALL_END;                    // three pieces x [64 out][64 in] bf16 = 3 x 8192 bytes
-    static constexpr int PAIR0 = WIMG + 3 * 2048;
-    static constexpr int P1 = 0, P2 = P1 + 3 * 1024, PO = P2 + 3 * 1024, PAIR_SIZE = (PO + 2 * O * 32 + 127) / 128 * 128;   // per pair: two 12 KB piece images, [2 waves][O][32] partial sums
+    static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, W3B = W3S + O * H, B3 = W3B + O * H, SMALL_END = (B3 + OP + 127) / 128 * 128;   // W3S = W3 / kActScale (forward), W3B = W3 / kActScale^2 (dh)
+    static constexpr int WIMG = SMALL_END;                    // two f16 pieces x [64 out][64 in] = 2 x 8192 bytes
+    static constexpr int PAIR0 = WIMG + 2 * 2048;
+    static constexpr int P1 = 0, P2 = P1 + 2 * 1024, PO = P2 + 2 * 1024, PAIR_SIZE = (PO + 2 * O * 32 + 127) / 128 * 128;   // per pair: two 8 KB piece images, [2 waves][O][32] partial sums
     static constexpr int END = PAIR0 + 2 * PAIR_SIZE;
     static_assert((4 * WIMG) % 512 == 0 && (4 * PAIR0) % 512 == 0 && (4 * PAIR_SIZE) % 512 == 0 && (4 * P2) % 512 == 0, "image bases must be multiples of 512 bytes");
 };
 // A operand of dh1 = W2': lane (in-unit 32mk + (lane & 31), half kh) gets out-units 32mi + 16s + 8kh + j of the weight image (64 rows, piece stride 8192); tbase = wide_tr_base<64>
-__device__ __forceinline__ bf16x8 load_frag_W_T(const char* wimg, int tmk, int tmk16, int piece, int mi, int s) {   // tmk = tbase ^ (64 mk), tmk16 = tmk ^ 16 (see load_frag_wide_T)
+__device__ __forceinline__ f16x8 load_frag_W_T(const char* wimg, int tmk, int tmk16, int piece, int mi, int s) {   // tmk = tbase ^ (64 mk), tmk16 = tmk ^ 16 (see load_frag_wide_T)
     const int off = (32 * mi + 16 * s) * 128 + piece * 8192;
-    return frag8(lds_read_tr16(wimg, tmk + off), lds_read_tr16(wimg, tmk16 + off + 4 * 128));
+    return __builtin_bit_cast(f16x8, frag8(lds_read_tr16(wimg, tmk + off), lds_read_tr16(wimg, tmk16 + off + 4 * 128)));
 }
 
 template <int KIND, int O, int HEAD>
@@ -57,15 +57,15 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     {   // stage the small parts (as stage_net_split) and the W2 piece image
         const float* __restrict__ P = a.params;
         for (int i = tid; i < L::DP * H; i += blockDim.x) { const int o = i % H, k = i / H; wl[L::W1T + k * H + o] = k < D ? kTanhScale * P[off.w1 + o + k * H] : 0.0f; }
-        for (int i = tid; i < H; i += blockDim.x) { wl[L::B1 + i] = kTanhScale * P[off.b1 + i]; wl[L::B2 + i] = kTanhScale * P[off.b2 + i]; }
-        for (int i = tid; i < O * H; i += blockDim.x) { const int o = i % O, k = i / O; wl[L::W3S + o * H + k] = P[off.w3 + i]; }
+        for (int i = tid; i < H; i += blockDim.x) { wl[L::B1 + i] = kTanhScale * P[off.b1 + i]; wl[L::B2 + i] = (kTanhScale * kWScale * kActScale) * P[off.b2 + i]; }   // b2 starts the SCALED accumulator of L2
+        for (int i = tid; i < O * H; i += blockDim.x) { const int o = i % O, k = i / O; const float w3 = P[off.w3 + i]; wl[L::W3S + o * H + k] = w3 * (1.0f / kActScale); wl[L::W3B + o * H + k] = w3 * (1.0f / (kActScale * kActScale)); }
         for (int i = tid; i < L::OP; i += blockDim.x) wl[L::B3 + i] = i < O ? P[off.b3 + i] : 0.0f;
         for (int i = tid; i < H * H / 2; i += blockDim.x) {       // pair (k, k+1) of row o: W2 is column-major (out x in), consecutive threads read consecutive o
             const int o = i % H, kp = i / H;
-            unsigned hi, mid, lo;
-            split3_pair(kTanhScale * P[off.w2 + o + H * (2 * kp)], kTanhScale * P[off.w2 + o + H * (2 * kp + 1)], hi, mid, lo);
+            unsigned hi, lo;
+            split2_pair((kTanhScale * kWScale) * P[off.w2 + o + H * (2 * kp)], (kTanhScale * kWScale) * P[off.w2 + o + H * (2 * kp + 1)], hi, lo);
             const int byte = o * 128 + ((((kp >> 2) ^ wimg_g<64>(o)) & 7) << 4) + ((kp & 3) << 2);
-            *reinterpret_cast<unsigned*>(Wimg + byte) = hi; *reinterpret_cast<unsigned*>(Wimg + 8192 + byte) = mid; *reinterpret_cast<unsigned*>(Wimg + 16384 + byte) = lo;
+            *reinterpret_cast<unsigned*>(Wimg + byte) = hi; *reinterpret_cast<unsigned*>(Wimg + 8192 + byte) = lo;
         }
     }
     __syncthreads();
@@ -89,6 +89,10 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     }
     const float* ls = lsr;
     const int tbase = wide_tr_base<64>(lane);
+    // gradient tiles are split as dz2 SG with SG = 2^(exponent of 1 / invB + 3): 4 ... 8 / invB, a power of two (every scale is undone exactly in the epilogue)
+    const float sg = __uint_as_float((((__float_as_uint(1.0f / a.invB) >> 23) & 0xffu) + 3u) << 23);
+    const float inv_sg = 1.0f / sg;
+    GradArgs as = a; as.invB = a.invB * sg;                                            // what loss_head multiplies dLoss/dout with
     lds_char* lds = (lds_char*)smem;
     constexpr int kWimgB = 4 * L::WIMG, kP1B = 4 * L::P1, kP2B = 4 * L::P2;
     const int pairB = 4 * (L::PAIR0 + pr * L::PAIR_SIZE);                                                 // byte offset of this pair's block (wave-uniform)
@@ -146,8 +150,8 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
-            tanh16(h1w);
-            pair_store_pieces<kP1B>(lds, opaque(ownT), h1w);
+            tanh16_scaled<false>(h1w, 1.0f);                                              // kActScale h1
+            pair_store_pieces2<kP1B>(lds, opaque(ownT), h1w);
             if (kKeepH1) h1k = h1w;
         }
         STAMP(0);
@@ -166,12 +170,12 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {                                          // ks = 2 mi + s: chunk 2 ks + h of the row
                 const int ak = ra ^ (ks << 5), bk = rb ^ (ks << 5);
-                bf16x8 A[3], B[3];
+                f16x8 A[2], B[2];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) { A[p] = pl_read<bf16x8>(lds, ak + kWimgB + p * 8192); B[p] = pl_read<bf16x8>(lds, bk + kP1B + p * 4096); }
-                h2w = mfma_split6(A[0], A[1], A[2], B[0], B[1], B[2], h2w);
+                for (int p = 0; p < 2; ++p) { A[p] = pl_read<f16x8>(lds, ak + kWimgB + p * 8192); B[p] = pl_read<f16x8>(lds, bk + kP1B + p * 4096); }
+                h2w = mfma_split3(A[0], A[1], B[0], B[1], h2w);
             }
-            tanh16(h2w);
+            tanh16_scaled<true>(h2w, 1.0f / (kWScale * kActScale));                        // kActScale h2
         }
         STAMP(2);
         // ---- output layer: partial over this wave's 32 units, summed across the pair through LDS ----
@@ -191,7 +195,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
         STAMP(3);
 #pragma unroll
         for (int o = 0; o < O; ++o) out[o] = (wl[L::B3 + o] + PO[o * 32 + c]) + PO[(O + o) * 32 + c];   // fixed order: both waves get the same bits
-        loss_head<O, HEAD>(a, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
+        loss_head<O, HEAD>(as, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);     // dz = SG dLoss/dout
 #pragma unroll
         for (int o = 0; o < O; ++o) {
             if (h == 0 && w == 0) db3p[o] += dz[o];
@@ -203,15 +207,15 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             float dh[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int o = 0; o < O; ++o) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3B + o * H + 32 * w + 8 * q + 4 * h);
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(wv[cc], dz[o], dh[cc]);
             }
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * fmaf(-hv, hv, 1.0f); }
+            for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * fmaf(-hv, hv, kActScale * kActScale); }   // (W3 / S^2 . dz SG) (S^2 - (S h2)^2) = SG dz2
         }
         add16(db2acc, h2w);
-        pair_store_pieces<kP2B>(lds, opaque(ownT), h2w);
+        pair_store_pieces2<kP2B>(lds, opaque(ownT), h2w);
         STAMP(4);
         __syncthreads();                                                              // B3: the pair's dz2 image complete
         STAMP(5);
@@ -224,15 +228,16 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int bk = rb ^ (ks << 5);
-                bf16x8 A[3], B[3];
+                f16x8 A[2], B[2];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) { A[p] = load_frag_W_T(Wimg, tbw, tbw16, p, ks >> 1, ks & 1); B[p] = pl_read<bf16x8>(lds, bk + kP2B + p * 4096); }
-                g1 = mfma_split6(A[0], A[1], A[2], B[0], B[1], B[2], g1);
+                for (int p = 0; p < 2; ++p) { A[p] = load_frag_W_T(Wimg, tbw, tbw16, p, ks >> 1, ks & 1); B[p] = pl_read<f16x8>(lds, bk + kP2B + p * 4096); }
+                g1 = mfma_split3(A[0], A[1], B[0], B[1], g1);
             }
             f32x16 h1r;
-            if (kKeepH1) h1r = h1k; else pair_load_pieces<kP1B>(lds, opaque(ownT), h1r);   // h1 tile w rebuilt from its own pieces (exact)
+            if (kKeepH1) h1r = h1k; else pair_load_pieces2<kP1B>(lds, opaque(ownT), h1r);  // kActScale h1 of tile w back from its own pieces (to 2^-24)
+            constexpr float c0 = kInvTanhScale / kWScale, c1 = c0 / (kActScale * kActScale);   // g1 = (kTanhScale kWScale W2' . SG dz2) (1 - h1^2) / (kTanhScale kWScale) = SG dz1
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[r] = g1[r] * fmaf(-t2, kInvTanhScale, kInvTanhScale); }
+            for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[r] = g1[r] * fmaf(-t2, c1, c0); }
         }
         STAMP(6);
         // ---- dW1 | db1: per-lane accumulation, dW1[unit][d] += dz1[unit][sample] x[sample][d] ----
@@ -251,21 +256,21 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
         // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the pair's images) ----
         {
             const int tb = opaque(tbase), tbw = tb ^ (64 * w), tbw16 = tbw ^ 16;
-            bf16x8 Az[2][3];
+            f16x8 Az[2][2];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<64>(P2, tbw, tbw16, p, s);
+                for (int p = 0; p < 2; ++p) Az[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<64>(P2, tbw, tbw16, p, s));
 #pragma unroll
             for (int mj = 0; mj < MT; ++mj) {
-                bf16x8 Bh[2][3];
+                f16x8 Bh[2][2];
                 const int tbj = tb ^ (64 * mj), tbj16 = tbj ^ 16;
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<64>(P1, tbj, tbj16, p, s);
+                    for (int p = 0; p < 2; ++p) Bh[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<64>(P1, tbj, tbj16, p, s));
 #pragma unroll
-                for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split6(Az[s][0], Az[s][1], Az[s][2], Bh[s][0], Bh[s][1], Bh[s][2], dW2[mj]);
+                for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split3(Az[s][0], Az[s][1], Bh[s][0], Bh[s][1], dW2[mj]);   // (SG dz2)(kActScale h1)'
             }
         }
         STAMP(7);
@@ -286,25 +291,26 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
     const int o_ls = o_b3 + O, o_st = SL - 8;
     float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
+    const float inv_sa = inv_sg * (1.0f / kActScale);                                  // products with an activation operand carry SG kActScale, the others SG (powers of two: exact)
 #pragma unroll
     for (int mj = 0; mj < MT; ++mj)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H] = dW2[mj][r];
+        for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H] = dW2[mj][r] * inv_sa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {                                                    // per-lane sums over samples -> sum over the 32 lanes of each half (the halves hold different units)
         const int unit = 32 * w + rowfn(r, h);
-        const float b2 = half_sum(db2acc[r]), b1 = half_sum(db1acc[r]);
+        const float b2 = half_sum(db2acc[r]) * inv_sg, b1 = half_sum(db1acc[r]) * inv_sg;
         if (c == 0) { slab[o_b2 + unit] = b2; slab[o_b1 + unit] = b1; }
 #pragma unroll
-        for (int d = 0; d < D; ++d) { const float v = half_sum(dW1acc[d][r]); if (c == 0) slab[o_w1 + unit + d * H] = v; }
+        for (int d = 0; d < D; ++d) { const float v = half_sum(dW1acc[d][r]) * inv_sg; if (c == 0) slab[o_w1 + unit + d * H] = v; }
 #pragma unroll
-        for (int o = 0; o < O; ++o) { const float v = half_sum(dW3acc[o][r]); if (c == 0) slab[o_w3 + o + unit * O] = v; }
+        for (int o = 0; o < O; ++o) { const float v = half_sum(dW3acc[o][r]) * inv_sa; if (c == 0) slab[o_w3 + o + unit * O] = v; }
     }
 #pragma unroll
     for (int o = 0; o < O; ++o) {
-        const float b3 = half_sum(db3p[o]);
+        const float b3 = half_sum(db3p[o]) * inv_sg;
         if (w == 0 && lane == 0) slab[o_b3 + o] = b3;
-        if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (w == 0 && lane == 0) slab[o_ls + o] = l; }
+        if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]) * inv_sg; if (w == 0 && lane == 0) slab[o_ls + o] = l; }
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (w == 0 && lane == 0) slab[o_st + k] = v; }

@@ -66,6 +66,29 @@ template <int IMG> __device__ __forceinline__ void pair_load_pieces(const lds_ch
         }
     }
 }
+// the two-piece f16 forms of the same (ppo_grad_pair_kernel): pieces at a + IMG and a + IMG + 4096
+template <int IMG> __device__ __forceinline__ void pair_store_pieces2(lds_char* lds, int t, const f32x16& x) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned hi[2], lo[2];
+        split2_pair(x[4 * g], x[4 * g + 1], hi[0], lo[0]); split2_pair(x[4 * g + 2], x[4 * g + 3], hi[1], lo[1]);
+        const int a = t ^ (g << 4);
+        pl_write(lds, a + IMG, u32x2{hi[0], hi[1]}); pl_write(lds, a + IMG + 4096, u32x2{lo[0], lo[1]});
+    }
+}
+template <int IMG> __device__ __forceinline__ void pair_load_pieces2(const lds_char* lds, int t, f32x16& x) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int a = t ^ (g << 4);
+        const u32x2 hi = pl_read<u32x2>(lds, a + IMG), lo = pl_read<u32x2>(lds, a + IMG + 4096);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned hk = k ? hi.y : hi.x, lk = k ? lo.y : lo.x;                         // (NOT __builtin_bit_cast(f16x2_t, hi[k]): hipcc 7.2 folds that to element 0 for every k)
+            const f16x2_t h = __builtin_bit_cast(f16x2_t, hk), l = __builtin_bit_cast(f16x2_t, lk);
+            x[4 * g + 2 * k] = (float)h[0] + (float)l[0]; x[4 * g + 2 * k + 1] = (float)h[1] + (float)l[1];     // the value that was split, to 2^-24 relative
+        }
+    }
+}
 // both half-waves get v(lower half) + v(upper half), in that order: one v_permlane32_swap instead of an LDS-crossbar permute (ds_bpermute + its address + its wait)
 __device__ __forceinline__ float both_halves_sum(float v) {
     const unsigned u = __float_as_uint(v);
