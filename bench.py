@@ -44,10 +44,14 @@ def mfma_roofline(ach_tflops: float, arith: str) -> dict:
     """peak / frac of a dense-contraction kernel.  A kernel that computes its fp32-equivalent products as SIX bf16 MFMAs (3-piece operand split) is priced against
     ITS pipe: dense bf16 peak / 6 = 419.4 TFLOP/s of delivered f32 flops; the figure against the f32-MFMA peak (157.3, the pipe the exact-f32 kernels run on and the
     roof SURVEY.md section 8d names) is kept beside it as frac_vs_f32_peak — it may exceed 1 and is never `frac`."""
-    split = "bf16x3" in arith
-    peak = PEAK_BF16_SPLIT6_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    if "f16x2" in arith:          # two-piece f16 operands: three f16 MFMAs per fp32-equivalent product
+        peak, note = PEAK_BF16_SPLIT6_TFLOPS * 2.0, "dense f16 MFMA peak 2516.6 / 3 MFMAs per fp32-equivalent product"
+    elif "bf16x3" in arith:
+        peak, note = PEAK_BF16_SPLIT6_TFLOPS, "dense bf16 MFMA peak 2516.6 / 6 MFMAs per fp32-equivalent product"
+    else:
+        peak, note = PEAK_F32_MFMA_TFLOPS, "dense f32 MFMA peak (v_mfma_f32_32x32x2_f32)"
     return {"bound": "mfma", "achieved": ach_tflops, "peak": peak, "unit": "TFLOP/s", "frac": ach_tflops / peak,
-            "peak_note": ("dense bf16 MFMA peak 2516.6 / 6 MFMAs per fp32-equivalent product" if split else "dense f32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+            "peak_note": note,
             "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "frac_vs_f32_peak": ach_tflops / PEAK_F32_MFMA_TFLOPS, "arithmetic": arith}
 
 
@@ -223,7 +227,7 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
                 traffic, rocprof_ms = rec.get("hbm_bytes_per_launch"), rec.get("rocprof_avg_launch_ms")
                 traffic_source = f"replayed from profiles/{PMC_FILE} (rocprofv3 --pmc passes at commit {rec.get('commit', '?')}); not measured in this run"
             kname, arith = info.split(": ", 1)
-            out["dtype"] = "f32 (bf16x3 split, f32 accumulate)" if "bf16x3" in arith else "f32"
+            out["dtype"] = "f32 (f16x2 split, f32 accumulate)" if "f16x2" in arith else "f32 (bf16x3 split, f32 accumulate)" if "bf16x3" in arith else "f32"
             out["roofline"] = dict(mfma_roofline(ach, arith), traffic=traffic, traffic_source=traffic_source, kernel=kname, avg_launch_ms=avg_ms,
                                    avg_launch_ms_source="HIP events on the library's stream around every launch of the timed region",
                                    rocprof_avg_launch_ms=rocprof_ms, launches=gk["launches"], flops_per_launch=flops,

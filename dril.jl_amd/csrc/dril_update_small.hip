@@ -23,11 +23,11 @@ namespace dril {
 // one net's weights in LDS (floats), rewritten from the owners' registers every optimiser step; the weight image starts at a multiple of 512 bytes (XOR addressing)
 template <int D, int O> struct SmallNet {
     static constexpr int H = 64, DP = 4, OP = (O + 3) / 4 * 4;
-    static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, LS = (B3 + OP + 3) / 4 * 4;   // LS: log_std copy (actor, continuous heads)
-    static constexpr int WIMG = (LS + 4 + 127) / 128 * 128, END = WIMG + 3 * 2048;                                                // three pieces x [64 out][64 in] bf16
+    static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, W3B = W3S + O * H, B3 = W3B + O * H, LS = (B3 + OP + 3) / 4 * 4;   // W3S = W3 / kActScale (forward), W3B = W3 / kActScale^2 (dh); LS: log_std copy (actor, continuous heads)
+    static constexpr int WIMG = (LS + 4 + 127) / 128 * 128, END = WIMG + 2 * 2048;                                                // two f16 pieces x [64 out][64 in]
 };
 template <int D, int O> struct SmallPair {                    // one pair's area (floats), a multiple of 512 bytes
-    static constexpr int P1 = 0, P2 = P1 + 3 * 1024, PO = P2 + 3 * 1024;                 // two 12 KB piece images, [2 waves][O][32] output partial sums
+    static constexpr int P1 = 0, P2 = P1 + 2 * 1024, PO = 4224;                          // two 8 KB piece images (f16 x 2 pieces; the dW2 overlay needs 64 x 65 floats: a gap follows P2), [2 waves][O][32] output partial sums
     // small gradients of the pair's tile in parameter order {W1 (o + 64 k) | b1 | b2 | W3 (o + O k) | b3 | log_std | 8 statistics}; never overlaid by the images
     static constexpr int G_W1 = PO + 2 * O * 32, G_B1 = G_W1 + 64 * D, G_B2 = G_B1 + 64, G_W3 = G_B2 + 64, G_B3 = G_W3 + 64 * O, G_LS = G_B3 + 4, G_ST = G_LS + 4;
     static constexpr int SIZE = (G_ST + 8 + 127) / 128 * 128;
@@ -37,9 +37,9 @@ template <int D, int O> struct SmallPair {                    // one pair's area
     static_assert(S_W2 + 64 * 65 <= PO, "the dW2 overlay must stay inside the two piece images");
 };
 // A operand of dh1 = W2' (transposed reads of the weight image): as load_frag_W_T of dril_grad_pair.hip (tmk = tbase ^ (64 mk), tmk16 = tmk ^ 16)
-__device__ __forceinline__ bf16x8 small_frag_W_T(const char* wimg, int tmk, int tmk16, int piece, int mi, int s) {
+__device__ __forceinline__ f16x8 small_frag_W_T(const char* wimg, int tmk, int tmk16, int piece, int mi, int s) {
     const int off = (32 * mi + 16 * s) * 128 + piece * 8192;
-    return frag8(lds_read_tr16(wimg, tmk + off), lds_read_tr16(wimg, tmk16 + off + 4 * 128));
+    return __builtin_bit_cast(f16x8, frag8(lds_read_tr16(wimg, tmk + off), lds_read_tr16(wimg, tmk16 + off + 4 * 128)));
 }
 
 // one 32-sample tile of one net on a pair of waves: forward, loss head, reverse pass; the pair's gradient goes into its slab overlay.  Barriers are workgroup-wide
@@ -52,7 +52,7 @@ __device__ __forceinline__ bf16x8 small_frag_W_T(const char* wimg, int tmk, int 
 #define SMALL_STAMP_ARGS
 #endif
 template <int KIND, int O, int HEAD>
-__device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, float* pb, int pairB, TileIn<O>& cur, const float* mom, int normalize_adv, const float* ls, int lane, int w SMALL_STAMP_PARAMS) {
+__device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, float* pb, int pairB, TileIn<O>& cur, const float* mom, int normalize_adv, const float* ls, int lane, int w, float inv_sg SMALL_STAMP_PARAMS) {   // ga.invB carries the gradient scale SG (dril_device.h: f16 pieces), inv_sg = 1 / SG
     constexpr int D = EnvSpec<KIND>::D, H = 64, MT = 2;
     constexpr float kInvTanhScale = 1.0f / kTanhScale;
     using L = SmallNet<D, O>; using S = SmallPair<D, O>;
@@ -71,6 +71,7 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
     unpack_tile<KIND, O, HEAD, true>(ga, h, cur);
     const bool valid = cur.valid;
     const float xk[2] = {cur.xk[0], cur.xk[1]};
+    const float inv_sa = inv_sg * (1.0f / kActScale);                                    // products with an activation operand carry SG kActScale, the others SG
     // ---- h1 tile w; its pieces into the pair's image ----
     f32x16 h1k;
     {
@@ -81,8 +82,8 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) h1k = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1k);
-        tanh16(h1k);
-        pair_store_pieces<kP1B>(lds, ownT, h1k);
+        tanh16_scaled<false>(h1k, 1.0f);                                              // kActScale h1
+        pair_store_pieces2<kP1B>(lds, ownT, h1k);
     }
     STAMP(1);
     lds_barrier();                                                                    // B1: the pair's h1 image complete
@@ -96,21 +97,21 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
             h2w[4 * q + 0] = b[0]; h2w[4 * q + 1] = b[1]; h2w[4 * q + 2] = b[2]; h2w[4 * q + 3] = b[3];
         }
         // one wave per SIMD: nobody else covers an LDS round trip, so the fragments of k16 step ks + 1 are requested before the six MFMAs of step ks (pinned)
-        bf16x8 A[2][3], B[2][3];
+        f16x8 A[2][2], B[2][2];
         auto fetch = [&](int ks) {                                                    // chunk 2 ks + h of the row
             const int ak = rowW ^ (ks << 5), bk = rowP ^ (ks << 5);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) { A[ks & 1][p] = pl_read<bf16x8>(lds, ak + kWimgB + p * 8192); B[ks & 1][p] = pl_read<bf16x8>(lds, bk + kP1B + p * 4096); }
+            for (int p = 0; p < 2; ++p) { A[ks & 1][p] = pl_read<f16x8>(lds, ak + kWimgB + p * 8192); B[ks & 1][p] = pl_read<f16x8>(lds, bk + kP1B + p * 4096); }
         };
         fetch(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) fetch(ks + 1);
             __builtin_amdgcn_sched_barrier(0);
-            h2w = mfma_split6(A[ks & 1][0], A[ks & 1][1], A[ks & 1][2], B[ks & 1][0], B[ks & 1][1], B[ks & 1][2], h2w);
+            h2w = mfma_split3(A[ks & 1][0], A[ks & 1][1], B[ks & 1][0], B[ks & 1][1], h2w);
             __builtin_amdgcn_sched_barrier(0);
         }
-        tanh16(h2w);
+        tanh16_scaled<true>(h2w, 1.0f / (kWScale * kActScale));                        // kActScale h2
     }
     // ---- output layer: partial over this wave's 32 units, summed across the pair through LDS ----
     float out[O], dz[O];
@@ -138,7 +139,7 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
     float* gq = pb;                                                                   // the pair's small-gradient words
 #pragma unroll
     for (int o = 0; o < O; ++o) {                                                     // dW3[o][unit] = sum over samples (lanes) of dz[o] h2[unit]
-        const float v = half_reduce16_lane(dz[o] * h2w, lane);
+        const float v = half_reduce16_lane(dz[o] * h2w, lane) * inv_sa;               // (SG dz)(kActScale h2)
         if (writer) gq[S::G_W3 + o + runit * O] = v;
     }
     {   // b3 / log_std gradients and the five statistics: one register each of a sixteen-register reduction (lane l receives scalar l & 15)
@@ -147,7 +148,7 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
         for (int r = 0; r < 16; ++r) sc[r] = 0.f;
         const bool tal = h == 0 && w == 0;                                            // each sample once: the first half-wave of the pair's first wave
 #pragma unroll
-        for (int o = 0; o < O; ++o) { sc[o] = tal ? dz[o] : 0.f; if (HEAD == HEAD_GAUSSIAN) sc[4 + o] = dlsp[o]; }
+        for (int o = 0; o < O; ++o) { sc[o] = tal ? dz[o] * inv_sg : 0.f; if (HEAD == HEAD_GAUSSIAN) sc[4 + o] = dlsp[o] * inv_sg; }
 #pragma unroll
         for (int k = 0; k < 5; ++k) sc[8 + k] = st[k];
         const float v = half_reduce16_lane(sc, lane);
@@ -164,18 +165,18 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
         float dh[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int o = 0; o < O; ++o) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3B + o * H + 32 * w + 8 * q + 4 * h);
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(wv[cc], dz[o], dh[cc]);
         }
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * fmaf(-hv, hv, 1.0f); }
+        for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * fmaf(-hv, hv, kActScale * kActScale); }   // = SG dz2
     }
     {
-        const float v = half_reduce16_lane(h2w, lane);
+        const float v = half_reduce16_lane(h2w, lane) * inv_sg;
         if (writer) gq[S::G_B2 + runit] = v;
     }
-    pair_store_pieces<kP2B>(lds, ownT, h2w);
+    pair_store_pieces2<kP2B>(lds, ownT, h2w);
     STAMP(5);
     lds_barrier();                                                                    // B3: the pair's dz2 image complete
     STAMP(6);
@@ -185,22 +186,23 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) g1[r] = 0.f;
         const int tbw = tbase ^ (64 * w), tbw16 = tbw ^ 16;
-        bf16x8 A[2][3], B[2][3];
+        f16x8 A[2][2], B[2][2];
         auto fetch = [&](int ks) {
             const int bk = rowP ^ (ks << 5);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) { A[ks & 1][p] = small_frag_W_T(Wimg, tbw, tbw16, p, ks >> 1, ks & 1); B[ks & 1][p] = pl_read<bf16x8>(lds, bk + kP2B + p * 4096); }
+            for (int p = 0; p < 2; ++p) { A[ks & 1][p] = small_frag_W_T(Wimg, tbw, tbw16, p, ks >> 1, ks & 1); B[ks & 1][p] = pl_read<f16x8>(lds, bk + kP2B + p * 4096); }
         };
         fetch(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) fetch(ks + 1);
             __builtin_amdgcn_sched_barrier(0);
-            g1 = mfma_split6(A[ks & 1][0], A[ks & 1][1], A[ks & 1][2], B[ks & 1][0], B[ks & 1][1], B[ks & 1][2], g1);
+            g1 = mfma_split3(A[ks & 1][0], A[ks & 1][1], B[ks & 1][0], B[ks & 1][1], g1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        constexpr float c0 = kInvTanhScale / kWScale, c1 = c0 / (kActScale * kActScale);   // g1 = (kTanhScale kWScale W2' . SG dz2) (1 - h1^2) / (kTanhScale kWScale) = SG dz1
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float t2 = h1k[r] * h1k[r]; g1[r] = g1[r] * fmaf(-t2, kInvTanhScale, kInvTanhScale); }
+        for (int r = 0; r < 16; ++r) { const float t2 = h1k[r] * h1k[r]; g1[r] = g1[r] * fmaf(-t2, c1, c0); }
     }
     {   // db1 and dW1: per-lane products summed over the samples
         float x4[4];                                                                  // xk[s] = x[2 s + h]: the lower half's value is x[2 s], the upper half's x[2 s + 1]
@@ -210,11 +212,11 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
             const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             x4[2 * s] = __uint_as_float(r[0]); x4[2 * s + 1] = __uint_as_float(r[1]);
         }
-        const float v1 = half_reduce16_lane(g1, lane);
+        const float v1 = half_reduce16_lane(g1, lane) * inv_sg;
         if (writer) gq[S::G_B1 + runit] = v1;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const float v = half_reduce16_lane(x4[d] * g1, lane);
+            const float v = half_reduce16_lane(x4[d] * g1, lane) * inv_sg;
             if (writer) gq[S::G_W1 + runit + d * H] = v;
         }
     }
@@ -226,21 +228,21 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) dW2[j][r] = 0.f;
         const int tb = tbase, tbw = tb ^ (64 * w), tbw16 = tbw ^ 16;
-        bf16x8 Az[2][3];
+        f16x8 Az[2][2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<64>(P2, tbw, tbw16, p, s);
+            for (int p = 0; p < 2; ++p) Az[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<64>(P2, tbw, tbw16, p, s));
 #pragma unroll
         for (int mj = 0; mj < MT; ++mj) {
-            bf16x8 Bh[2][3];
+            f16x8 Bh[2][2];
             const int tbj = tb ^ (64 * mj), tbj16 = tbj ^ 16;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<64>(P1, tbj, tbj16, p, s);
+                for (int p = 0; p < 2; ++p) Bh[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<64>(P1, tbj, tbj16, p, s));
 #pragma unroll
-            for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split6(Az[s][0], Az[s][1], Az[s][2], Bh[s][0], Bh[s][1], Bh[s][2], dW2[mj]);
+            for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split3(Az[s][0], Az[s][1], Bh[s][0], Bh[s][1], dW2[mj]);   // (SG dz2)(kActScale h1)'
         }
     }
     STAMP(7);
@@ -249,7 +251,7 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
 #pragma unroll
     for (int mj = 0; mj < MT; ++mj)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pb[S::S_W2 + (32 * w + rowfn(r, h)) * 65 + 32 * mj + c] = dW2[mj][r];
+        for (int r = 0; r < 16; ++r) pb[S::S_W2 + (32 * w + rowfn(r, h)) * 65 + 32 * mj + c] = dW2[mj][r] * inv_sa;
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -276,9 +278,9 @@ __device__ __forceinline__ void small_param_map(int r, int& flat, int& goff, int
     r -= n_w1;
     if (r < H) { flat = n_w1 + r; goff = S::G_B1 + r; dst = L::B1 + r; scale = kTanhScale; return; }
     r -= H;
-    if (r < H) { flat = n_w2 + r; goff = S::G_B2 + r; dst = L::B2 + r; scale = kTanhScale; return; }
+    if (r < H) { flat = n_w2 + r; goff = S::G_B2 + r; dst = L::B2 + r; scale = kTanhScale * kWScale * kActScale; return; }   // b2 starts the SCALED accumulator of L2
     r -= H;
-    if (r < O * H) { flat = n_b2 + r; goff = S::G_W3 + r; dst = L::W3S + (r % O) * H + r / O; scale = 1.0f; return; }   // W3[o + O k] -> row o of the staged copy
+    if (r < O * H) { flat = n_b2 + r; goff = S::G_W3 + r; dst = L::W3S + (r % O) * H + r / O; scale = 1.0f / kActScale; return; }   // W3[o + O k] -> row o of the staged copies (W3S; W3B = the same word + L::W3B - L::W3S, / kActScale again)
     r -= O * H;
     flat = n_w3 + r; goff = S::G_B3 + r; dst = L::B3 + r; scale = 1.0f;
 }
@@ -338,10 +340,10 @@ __device__ __forceinline__ void small_net_loop(const SmallUpdateArgs& a, float* 
     lds_char* lds = (lds_char*)smem;
     const int wbyte = 4 * L::WIMG + wo * 128 + (wimg_g<64>(wo) << 4) + 4 * wk;          // pair kp = wk + 4 j: chunk j ^ g(o) of row o, word wk — the XOR form again
     auto publish_pair = [&](int j) {
-        unsigned hi, mid, lo;
-        split3_pair(kTanhScale * wp[j][0], kTanhScale * wp[j][1], hi, mid, lo);
+        unsigned hi, lo;
+        split2_pair((kTanhScale * kWScale) * wp[j][0], (kTanhScale * kWScale) * wp[j][1], hi, lo);
         const int byte = wbyte ^ (j << 4);
-        pl_write(lds, byte, hi); pl_write(lds, byte + 8192, mid); pl_write(lds, byte + 16384, lo);
+        pl_write(lds, byte, hi); pl_write(lds, byte + 8192, lo);
     };
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -363,8 +365,13 @@ __device__ __forceinline__ void small_net_loop(const SmallUpdateArgs& a, float* 
     lds_barrier();
 #pragma unroll
     for (int j = 0; j < 8; ++j) publish_pair(j);
+    auto publish_small = [&](int q) {
+        if (sflat[q] < 0) return;
+        smem[sdst[q]] = sscale[q] * sp[q];
+        if (sdst[q] >= L::W3S && sdst[q] < L::W3B) smem[sdst[q] + (L::W3B - L::W3S)] = sp[q] * (1.0f / (kActScale * kActScale));   // the dh copy of W3
+    };
 #pragma unroll
-    for (int q = 0; q < 3; ++q) if (sflat[q] >= 0) smem[sdst[q]] = sscale[q] * sp[q];
+    for (int q = 0; q < 3; ++q) publish_small(q);
     const float* bt_in = a.bt + 2 * (a.step_parity & 1);
     float bt1 = bt_in[0], bt2 = bt_in[1];
 
@@ -419,7 +426,9 @@ __device__ __forceinline__ void small_net_loop(const SmallUpdateArgs& a, float* 
 #endif
     for (int s = a.step0; s < s_end && alive; ++s) {
         const int64_t count = count_of(s);
-        ga.invB = 1.0f / (float)count;
+        const float invB = 1.0f / (float)count;
+        const float sg = __uint_as_float((((__float_as_uint((float)count) >> 23) & 0xffu) + 3u) << 23), inv_sg = 1.0f / sg;   // gradient tiles are split as SG dz2, SG = 4 ... 8 x count, a power of two
+        ga.invB = invB * sg;                                                          // what loss_head multiplies dLoss/dout with
         // ---- this step's inputs out of the prefetch registers; the next step's gathers go out now and land under this step's arithmetic ----
         const float4 raw = raw_n; const float vold = vold_n; const bool valid = valid_n;
         if (s + 1 < s_end) gather(s + 1);
@@ -434,7 +443,7 @@ __device__ __forceinline__ void small_net_loop(const SmallUpdateArgs& a, float* 
         STAMP(0);
         {
             TileIn<O> cur; cur.raw = raw; cur.valid = valid; cur.s0 = 0.f; cur.s1 = ROLE == 1 ? vold : 0.f; cur.act = 0;
-            small_tile<KIND, O, HEAD>(ga, smem, pb, pairB, cur, mom, ROLE == 0 ? a.normalize_adv : 0, lsr, lane, w SMALL_STAMP_ARGS);
+            small_tile<KIND, O, HEAD>(ga, smem, pb, pairB, cur, mom, ROLE == 0 ? a.normalize_adv : 0, lsr, lane, w, inv_sg SMALL_STAMP_ARGS);
         }
         STAMP(9);
         lds_barrier();                                                                // B5: both pairs' gradients complete
@@ -512,7 +521,7 @@ __device__ __forceinline__ void small_net_loop(const SmallUpdateArgs& a, float* 
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             adam(gs[q], sp[q], sm[q], sv[q]);
-            if (sflat[q] >= 0) smem[sdst[q]] = sscale[q] * sp[q];
+            publish_small(q);
         }
         bt1 *= a.beta1; bt2 *= a.beta2;
         STAMP(12);
