@@ -339,26 +339,27 @@ __global__ __launch_bounds__(H * 2, 2) void ppo_grad_wide_kernel(GradArgs a) {
 template <int D, int H, int O> struct WideSplitScratch {
     static constexpr int MT = H / 32;
     static constexpr int SMALL = NetLdsSmall<D, H, O>::END;
-    static constexpr int P1 = (SMALL + 3) / 4 * 4;          // h1 pieces: 3 x 32 x H bf16 = 48 H floats
-    static constexpr int P2 = P1 + 48 * H;                  // dz2 pieces
-    static constexpr int TB = P2 + 48 * H;                  // per-wave rows [H][kTS] f32: h2', then dz2' (bias gradient), then dz1'
+    static constexpr int P1 = (SMALL + 3) / 4 * 4;          // h1 pieces: 2 x 32 x H f16 = 32 H floats
+    static constexpr int P2 = P1 + 32 * H;                  // dz2 pieces
+    static constexpr int TB = P2 + 32 * H;                  // per-wave rows [H][kTS] f32: h2', then dz2' (bias gradient), then dz1'
     static constexpr int XI = TB + H * kTS;                 // [D+2][kTS]
     static constexpr int ZI = XI + (D + 2) * kTS;           // [MT waves][O][kTS]
     static constexpr int PO = ZI + MT * O * kTS;            // [MT waves][O][32] output-layer partial sums
-    static constexpr int SIZE = PO + MT * O * 32;
+    static constexpr int W3B = PO + MT * O * 32;            // W3 / kActScale^2 (dh); the staged W3S is W3 / kActScale (output layer on kActScale h2)
+    static constexpr int SIZE = W3B + O * H;
 };
 // chunk swizzle of the piece images.  Rows of >= 256 bytes (H >= 128) alias in every bank: 16 consecutive rows must land in 16 different 16-byte chunks and the 4 rows of a
 // transposed read in the 4 different 64-byte windows.  128-byte rows (H = 64): rows n and n + 1 already sit in different halves of the 256-byte bank window, so 3 bits suffice
-__device__ __forceinline__ void wide_split_preload(const u32x4* __restrict__ wimg, int MTv, int mo, int lane, u32x4 (&af)[2][3]) {
-    const u32x4* base = wimg + ((size_t)mo * MTv * 6) * 64 + lane;
+__device__ __forceinline__ void wide_split_preload(const u32x4* __restrict__ wimg, int MTv, int mo, int lane, u32x4 (&af)[2][2]) {
+    const u32x4* base = wimg + ((size_t)mo * MTv * 4) * 64 + lane;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[s][p] = base[(size_t)(s * 3 + p) * 64];
+        for (int p = 0; p < 2; ++p) af[s][p] = base[(size_t)(s * 2 + p) * 64];
 }
 // output m-tile mo of Y = W X: W as pre-split fragments from L2 (af arrives preloaded with m-tile 0's, each refilled in place right after its MFMAs), X from the piece image
 template <int H, bool BIAS>
-__device__ __forceinline__ f32x16 dense_tile_split(const u32x4* __restrict__ wimg, const float* __restrict__ bias, const char* pimg, int mo, int lane, u32x4 (&af)[2][3]) {
+__device__ __forceinline__ f32x16 dense_tile_split(const u32x4* __restrict__ wimg, const float* __restrict__ bias, const char* pimg, int mo, int lane, u32x4 (&af)[2][2]) {
     constexpr int MT = H / 32, RB = 2 * H, PS = 32 * RB;
     const int c = lane & 31, h = lane >> 5, rowb = c * RB, gsw = wimg_g<H>(c);
     f32x16 acc;
@@ -368,19 +369,19 @@ __device__ __forceinline__ f32x16 dense_tile_split(const u32x4* __restrict__ wim
         if (BIAS) b = *reinterpret_cast<const f32x4*>(bias + 32 * mo + 8 * q + 4 * h);
         acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
     }
-    const u32x4* base = wimg + ((size_t)mo * MT * 6) * 64 + lane;
+    const u32x4* base = wimg + ((size_t)mo * MT * 4) * 64 + lane;
 #pragma unroll 1
     for (int mi = 0; mi < MT; ++mi) {
-        const u32x4* nextp = base + (size_t)((mi + 1 < MT ? mi + 1 : mi) * 6) * 64;   // the last iteration re-reads its own fragments (in bounds, unused)
+        const u32x4* nextp = base + (size_t)((mi + 1 < MT ? mi + 1 : mi) * 4) * 64;   // the last iteration re-reads its own fragments (in bounds, unused)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int a = rowb + (((4 * mi + 2 * s + h) ^ gsw) << 4);
-            bf16x8 B[3];
+            f16x8 B[2];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) B[p] = *reinterpret_cast<const bf16x8*>(pimg + p * PS + a);
-            acc = mfma_split6(__builtin_bit_cast(bf16x8, af[s][0]), __builtin_bit_cast(bf16x8, af[s][1]), __builtin_bit_cast(bf16x8, af[s][2]), B[0], B[1], B[2], acc);
+            for (int p = 0; p < 2; ++p) B[p] = *reinterpret_cast<const f16x8*>(pimg + p * PS + a);
+            acc = mfma_split3(__builtin_bit_cast(f16x8, af[s][0]), __builtin_bit_cast(f16x8, af[s][1]), B[0], B[1], acc);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[s][p] = nextp[(size_t)(s * 3 + p) * 64];
+            for (int p = 0; p < 2; ++p) af[s][p] = nextp[(size_t)(s * 2 + p) * 64];
         }
     }
     return acc;
@@ -401,7 +402,15 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
     float* wl = smem;
     char* P1 = reinterpret_cast<char*>(smem + SC::P1); char* P2 = reinterpret_cast<char*>(smem + SC::P2);
     float* TB = smem + SC::TB; float* XI = smem + SC::XI; float* ZI = smem + SC::ZI + w * O * kTS; float* PO = smem + SC::PO;
-    stage_net_small<D, H, O>(wl, a.params, off, tid, blockDim.x);
+    // staged small parameters in the scales of the f16-piece arithmetic (dril_device.h): b2 starts the SCALED accumulator of L2, W3S = W3 / kActScale for the output layer
+    // (its operand is kActScale h2), W3B = W3 / kActScale^2 for dh
+    {
+        const float* __restrict__ P = a.params;
+        for (int i = tid; i < L::DP * H; i += blockDim.x) { const int o = i % H, k = i / H; wl[L::W1T + k * H + o] = k < D ? kTanhScale * P[off.w1 + o + k * H] : 0.0f; }
+        for (int i = tid; i < H; i += blockDim.x) { wl[L::B1 + i] = kTanhScale * P[off.b1 + i]; wl[L::B2 + i] = (kTanhScale * kWScale * kActScale) * P[off.b2 + i]; }
+        for (int i = tid; i < O * H; i += blockDim.x) { const int o = i % O, k = i / O; const float w3 = P[off.w3 + i]; wl[L::W3S + o * H + k] = w3 * (1.0f / kActScale); smem[SC::W3B + o * H + k] = w3 * (1.0f / (kActScale * kActScale)); }
+        for (int i = tid; i < L::OP; i += blockDim.x) wl[L::B3 + i] = i < O ? P[off.b3 + i] : 0.0f;
+    }
     for (int i = tid; i < (D + 2) * kTS; i += blockDim.x) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
     __syncthreads();
 
@@ -424,6 +433,11 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
     }
     const float* ls = lsr;
     const int tbase = wide_tr_base<H>(lane);
+    // gradient tiles are split as dz2 SG with SG = 2^(exponent of 1 / invB + 3): 4 ... 8 / invB, a power of two; every scale is undone exactly in the epilogue
+    const float sg = __uint_as_float((((__float_as_uint(1.0f / a.invB) >> 23) & 0xffu) + 3u) << 23);
+    const float inv_sg = 1.0f / sg, inv_sa = inv_sg * (1.0f / kActScale);
+    GradArgs as = a; as.invB = a.invB * sg;                                            // what loss_head multiplies dLoss/dout with
+    const float* W3B = smem + SC::W3B;
 
     f32x16 dW2[MT];                                                  // rows 32w.., all H columns
     f32x4 dW1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -460,23 +474,23 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
-            tanh16(h1w);
+            tanh16_scaled<false>(h1w, 1.0f);                                          // kActScale h1
         }
         // `opaque(lane)`: the image addresses are lane constants, and hoisted out of the tile loop as loop invariants they hold ~60 registers for the whole kernel (they cost 2-3 VALU to rebuild)
-        store_tile_pieces<H>(P1, w, h1w, opaque(lane));
+        store_tile_pieces2<H>(P1, w, h1w, opaque(lane));
         if (w == 0) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
         }
         STAMP(0);
-        u32x4 afw[2][3];
+        u32x4 afw[2][2];
         wide_split_preload(w2p, MT, w, lane, afw);                                    // first W2 fragments in flight across the barrier
         __syncthreads();                                                              // B1: P1, XI complete
         STAMP(1);
         load_tile<KIND, O, HEAD, REC>(a, tile + a.G, ntiles, c, h, nxt);              // after the barrier (see ppo_grad_wide_kernel)
         // ---- h2 tile w ----
         f32x16 h2w = dense_tile_split<H, true>(w2p, wl + L::B2, P1, w, opaque(lane), afw);
-        tanh16(h2w);
+        tanh16_scaled<true>(h2w, 1.0f / (kWScale * kActScale));                        // kActScale h2
         STAMP(2);
         // ---- output layer: partial over this wave's rows, summed across waves through LDS ----
         float out[O], dz[O];
@@ -502,7 +516,7 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
             for (int ww = 0; ww < MT; ++ww) v += PO[(ww * O + o) * 32 + c];            // fixed order: every wave gets the same bits
             out[o] = v;
         }
-        loss_head<O, HEAD>(a, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);
+        loss_head<O, HEAD>(as, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);     // dz = SG dLoss/dout
         // ---- dW3 (own rows) ----
 #pragma unroll
         for (int o = 0; o < O; ++o) { if (h == 0) { if (w == 0) db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
@@ -526,14 +540,14 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
             float dh[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int o = 0; o < O; ++o) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(W3B + o * H + 32 * w + 8 * q + 4 * h);
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(wv[cc], dz[o], dh[cc]);
             }
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * (1.0f - hv * hv); }
+            for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * fmaf(-hv, hv, kActScale * kActScale); }   // = SG dz2
         }
-        store_tile_pieces<H>(P2, w, h2w, opaque(lane));
+        store_tile_pieces2<H>(P2, w, h2w, opaque(lane));
         store_image_tile(TB, w, h2w, lane);                                            // dz2' (after the Bh2 read: same wave, LDS in order)
         wide_split_preload(w2tp, MT, w, lane, afw);                                   // first W2' fragments in flight across the barrier
         STAMP(4);
@@ -543,9 +557,10 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
         f32x16 g1 = dense_tile_split<H, false>(w2tp, nullptr, P2, w, opaque(lane), afw);
         {
             f32x16 h1r;
-            load_tile_pieces<H>(P1, w, h1r, opaque(lane));                                     // h1 tile w rebuilt from its own pieces (hi + mid + lo is exact): 16 registers less across both MFMA chains
+            load_tile_pieces2<H>(P1, w, h1r, opaque(lane));                                    // kActScale h1 of tile w back from its own pieces (to 2^-24): 16 registers less across both MFMA chains
+            constexpr float c0 = 1.0f / kWScale, c1 = c0 / (kActScale * kActScale);             // g1 = (kWScale W2' . SG dz2) (1 - h1^2) / kWScale = SG dz1
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g1[r] = g1[r] * (1.0f - h1r[r] * h1r[r]);
+            for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[r] = g1[r] * fmaf(-t2, c1, c0); }
         }
         STAMP(6);
         // ---- db2 from the f32 transposed copy; then dW1 | db1 (own rows) BEFORE dW2, so that dz1 is dead while the 128 accumulators are being updated ----
@@ -571,21 +586,21 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
         // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the piece images) ----
         {
             const int tb = opaque(tbase), tbw = tb ^ (64 * w), tbw16 = tbw ^ 16;
-            bf16x8 Az[2][3];
+            f16x8 Az[2][2];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) Az[s][p] = load_frag_wide_T<H>(P2, tbw, tbw16, p, s);
+                for (int p = 0; p < 2; ++p) Az[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<H>(P2, tbw, tbw16, p, s));
 #pragma unroll
             for (int mj = 0; mj < MT; ++mj) {
-                bf16x8 Bh[2][3];
+                f16x8 Bh[2][2];
                 const int tbj = tb ^ (64 * mj), tbj16 = tbj ^ 16;
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) Bh[s][p] = load_frag_wide_T<H>(P1, tbj, tbj16, p, s);
+                    for (int p = 0; p < 2; ++p) Bh[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<H>(P1, tbj, tbj16, p, s));
 #pragma unroll
-                for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split6(Az[s][0], Az[s][1], Az[s][2], Bh[s][0], Bh[s][1], Bh[s][2], dW2[mj]);
+                for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split3(Az[s][0], Az[s][1], Bh[s][0], Bh[s][1], dW2[mj]);   // (SG dz2)(kActScale h1)'
                 __builtin_amdgcn_sched_barrier(0);                                    // keep the next m-tile's fragment requests behind these MFMAs (hoisted, they spill)
             }
         }
@@ -608,23 +623,23 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
 #pragma unroll
     for (int mj = 0; mj < MT; ++mj)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H] = dW2[mj][r];
+        for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H] = dW2[mj][r] * inv_sa;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 32 * w + 16 * t + 4 * (lane >> 4) + r, col = lane & 15;
-            if (col < D) slab[o_w1 + row + col * H] = dW1[t][r];
-            else if (col == D) slab[o_b1 + row] = dW1[t][r];
+            if (col < D) slab[o_w1 + row + col * H] = dW1[t][r] * inv_sg;
+            else if (col == D) slab[o_b1 + row] = dW1[t][r] * inv_sg;
         }
-    { const float b2 = db2p + __shfl_xor(db2p, 32); if (h == 0) slab[o_b2 + 32 * w + c] = b2; }
+    { const float b2 = (db2p + __shfl_xor(db2p, 32)) * inv_sg; if (h == 0) slab[o_b2 + 32 * w + c] = b2; }
 #pragma unroll
     for (int o = 0; o < O; ++o) {
-        const float v = dW3a[o] + __shfl_xor(dW3a[o], 32);
+        const float v = (dW3a[o] + __shfl_xor(dW3a[o], 32)) * inv_sa;
         if (h == 0) slab[o_w3 + o + (32 * w + c) * O] = v;
-        const float b3 = half_sum(db3p[o]);
+        const float b3 = half_sum(db3p[o]) * inv_sg;
         if (w == 0 && lane == 0) slab[o_b3 + o] = b3;
-        if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]); if (w == 0 && lane == 0) slab[o_ls + o] = l; }
+        if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]) * inv_sg; if (w == 0 && lane == 0) slab[o_ls + o] = l; }
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (w == 0 && lane == 0) slab[o_st + k] = v; }

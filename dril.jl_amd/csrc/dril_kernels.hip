@@ -943,21 +943,22 @@ __global__ void pack_records_kernel(int64_t N, const float* __restrict__ obs, co
     }
 }
 
+// pre-split fragment streams of ppo_grad_wide_split_kernel: two f16 pieces per weight (dril_device.h), forward kTanhScale kWScale W2, reverse kWScale W2'
 __global__ void build_wimg_split_kernel(const float* __restrict__ P, NetOff off, int H, u32x4* __restrict__ w2p, u32x4* __restrict__ w2tp) {
     const int MT = H / 32, total = MT * MT * 2 * 64;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int lane = idx & 63, s = (idx >> 6) & 1, mi = (idx >> 7) % MT, mo = (idx >> 7) / MT;
         const int i = 32 * mo + (lane & 31), k0 = 32 * mi + 16 * s + 8 * (lane >> 5);
-        unsigned f[3][4], b[3][4];
+        unsigned f[2][4], b[2][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int k = k0 + 2 * t;
-            split3_pair(kTanhScale * P[off.w2 + i + (size_t)k * H], kTanhScale * P[off.w2 + i + (size_t)(k + 1) * H], f[0][t], f[1][t], f[2][t]);   // W2[o][k] (column-major out x in)
-            split3_pair(P[off.w2 + k + (size_t)i * H], P[off.w2 + k + 1 + (size_t)i * H], b[0][t], b[1][t], b[2][t]);                               // W2'[i][k] = W2[k][i]
+            split2_pair((kTanhScale * kWScale) * P[off.w2 + i + (size_t)k * H], (kTanhScale * kWScale) * P[off.w2 + i + (size_t)(k + 1) * H], f[0][t], f[1][t]);   // W2[o][k] (column-major out x in)
+            split2_pair(kWScale * P[off.w2 + k + (size_t)i * H], kWScale * P[off.w2 + k + 1 + (size_t)i * H], b[0][t], b[1][t]);                                   // W2'[i][k] = W2[k][i]
         }
-        const size_t base = ((size_t)((mo * MT + mi) * 2 + s) * 3) * 64 + lane;
+        const size_t base = ((size_t)((mo * MT + mi) * 2 + s) * 2) * 64 + lane;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { w2p[base + (size_t)p * 64] = u32x4{f[p][0], f[p][1], f[p][2], f[p][3]}; w2tp[base + (size_t)p * 64] = u32x4{b[p][0], b[p][1], b[p][2], b[p][3]}; }
+        for (int p = 0; p < 2; ++p) { w2p[base + (size_t)p * 64] = u32x4{f[p][0], f[p][1], f[p][2], f[p][3]}; w2tp[base + (size_t)p * 64] = u32x4{b[p][0], b[p][1], b[p][2], b[p][3]}; }
     }
 }
 

@@ -95,6 +95,35 @@ __device__ __forceinline__ float both_halves_sum(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// two-piece f16 forms (ppo_grad_wide_split_kernel since the end of round 3; dril_device.h "the same on f16 pieces"): pieces at a and PS + a
+template <int H>
+__device__ __forceinline__ void store_tile_pieces2(char* pimg, int w, const f32x16& x, int lane) {
+    constexpr int RB = 2 * H, PS = 32 * RB;
+    const int c = lane & 31, h = lane >> 5, rowb = c * RB + 8 * h, gsw = wimg_g<H>(c);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        unsigned hi[2], lo[2];
+        split2_pair(x[4 * g], x[4 * g + 1], hi[0], lo[0]); split2_pair(x[4 * g + 2], x[4 * g + 3], hi[1], lo[1]);
+        const int a = rowb + (((4 * w + g) ^ gsw) << 4);
+        *reinterpret_cast<u32x2*>(pimg + a) = u32x2{hi[0], hi[1]}; *reinterpret_cast<u32x2*>(pimg + PS + a) = u32x2{lo[0], lo[1]};
+    }
+}
+template <int H>
+__device__ __forceinline__ void load_tile_pieces2(const char* pimg, int w, f32x16& x, int lane) {
+    constexpr int RB = 2 * H, PS = 32 * RB;
+    const int c = lane & 31, h = lane >> 5, rowb = c * RB + 8 * h, gsw = wimg_g<H>(c);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int a = rowb + (((4 * w + g) ^ gsw) << 4);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(pimg + a), lo = *reinterpret_cast<const u32x2*>(pimg + PS + a);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned hk = k ? hi.y : hi.x, lk = k ? lo.y : lo.x;                         // (not __builtin_bit_cast(f16x2_t, hi[k]): see pair_load_pieces2)
+            const f16x2_t hh = __builtin_bit_cast(f16x2_t, hk), ll = __builtin_bit_cast(f16x2_t, lk);
+            x[4 * g + 2 * k] = (float)hh[0] + (float)ll[0]; x[4 * g + 2 * k + 1] = (float)hh[1] + (float)ll[1];
+        }
+    }
+}
 // operand of a product that sums over SAMPLES: lane (unit 32m + (lane & 31), half kh) gets samples 16s + 8kh + j of its unit; tbase from wide_tr_base
 template <int H>
 __device__ __forceinline__ int wide_tr_base(int lane) {
