@@ -375,8 +375,8 @@ template <int D, int H, int O> struct NetLdsSplit {
     static_assert(H == 64, "the split kernel is laid out for hidden_dims [64,64]");
     static constexpr int DP = FirstLayer<D>::DP, OP = (O + 3) / 4 * 4;
     static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, B3 = W3S + O * H, SMALL_END = (B3 + OP + 3) / 4 * 4;
-    static constexpr int W2P = SMALL_END;                    // three pieces x [64][64] bf16 = 3 x 8192 bytes
-    static constexpr int END = W2P + 3 * H * H / 2;          // in floats
+    static constexpr int W2P = SMALL_END;                    // two f16 pieces x [64][64] = 2 x 8192 bytes
+    static constexpr int END = W2P + 2 * H * H / 2;          // in floats
 };
 __device__ __forceinline__ int w2img_gw(int r) { return (((r >> 1) & 1) << 3) | (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 4) & 1); }
 __device__ __forceinline__ int timg_gs(int r) { return (((r >> 1) & 1) << 3) | (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1) | (r & 1); }
@@ -385,23 +385,24 @@ template <int D, int H, int O>
 __device__ inline void stage_net_split(float* lds, const float* __restrict__ P, NetOff n, int tid, int nthreads) {
     using L = NetLdsSplit<D, H, O>;
     for (int i = tid; i < L::DP * H; i += nthreads) { const int o = i % H, k = i / H; lds[L::W1T + k * H + o] = k < D ? kTanhScale * P[n.w1 + o + k * H] : 0.0f; }
-    for (int i = tid; i < H; i += nthreads) { lds[L::B1 + i] = kTanhScale * P[n.b1 + i]; lds[L::B2 + i] = kTanhScale * P[n.b2 + i]; }
+    for (int i = tid; i < H; i += nthreads) { lds[L::B1 + i] = kTanhScale * P[n.b1 + i]; lds[L::B2 + i] = (kTanhScale * kWScale * kActScale) * P[n.b2 + i]; }   // b2 starts the SCALED accumulator of L2 (f16 pieces, dril_device.h)
     for (int i = tid; i < O * H; i += nthreads) { const int o = i % O, k = i / O; lds[L::W3S + o * H + k] = P[n.w3 + i]; }
     for (int i = tid; i < L::OP; i += nthreads) lds[L::B3 + i] = i < O ? P[n.b3 + i] : 0.0f;
     char* img = reinterpret_cast<char*>(lds + L::W2P);
     for (int i = tid; i < H * H / 2; i += nthreads) {         // pair (k, k+1) of row o: W2 is column-major (out x in), so consecutive threads read consecutive o
         const int o = i % H, kp = i / H;
-        unsigned hi, mid, lo;
-        split3_pair(kTanhScale * P[n.w2 + o + H * (2 * kp)], kTanhScale * P[n.w2 + o + H * (2 * kp + 1)], hi, mid, lo);
+        unsigned hi, lo;
+        split2_pair((kTanhScale * kWScale) * P[n.w2 + o + H * (2 * kp)], (kTanhScale * kWScale) * P[n.w2 + o + H * (2 * kp + 1)], hi, lo);
         const int byte = o * 128 + ((((kp >> 1) ^ w2img_gw(o)) & 15) << 3) + ((kp & 1) << 2);
-        *reinterpret_cast<unsigned*>(img + byte) = hi; *reinterpret_cast<unsigned*>(img + 8192 + byte) = mid; *reinterpret_cast<unsigned*>(img + 16384 + byte) = lo;
+        *reinterpret_cast<unsigned*>(img + byte) = hi; *reinterpret_cast<unsigned*>(img + 8192 + byte) = lo;
     }
 }
 
-__device__ __forceinline__ bf16x8 chunk_frag(const unsigned (&pc)[3][4], int p) { return __builtin_bit_cast(bf16x8, u32x4{pc[p][0], pc[p][1], pc[p][2], pc[p][3]}); }
-// ---- forward of one [64,64] net on the bf16 matrix cores (fp32-equivalent 3-piece split, as the gradient kernels): rollout_kernel / policy_kernel ----------------
-// L1 on the f32 MFMA (K = 4), tanh and split of h1 a k16 step at a time, L2 as six v_mfma_f32_32x32x16_bf16 per step against the swizzled W2 piece image, tanh, L3 on
-// the VALU.  Against the f32-MFMA forward (64 x 64 cycles on the VALU's lanes per net and tile) this is 48 x 32 cycles of matrix pipe + ~180 VALU instructions.
+__device__ __forceinline__ f16x8 chunk_frag(const unsigned (&pc)[2][4], int p) { return __builtin_bit_cast(f16x8, u32x4{pc[p][0], pc[p][1], pc[p][2], pc[p][3]}); }
+// ---- forward of one [64,64] net on the f16 matrix cores (fp32-equivalent two-piece split, as the gradient kernels; dril_device.h): rollout_kernel / policy_kernel -----
+// L1 on the f32 MFMA (K = 4), tanh and split of kActScale h1 a k16 step at a time, L2 as three v_mfma_f32_32x32x16_f16 per step against the swizzled W2 piece image
+// (kTanhScale kWScale W2), the scales undone before the second tanh, L3 on the VALU.  Against the f32-MFMA forward (64 x 64 cycles on the VALU's lanes per net and
+// tile) this is 24 x 32 cycles of matrix pipe + ~150 VALU instructions (round 2 - 3: three bf16 pieces, 48 MFMAs).
 template <int D, int H, int O>
 __device__ __forceinline__ void net_forward_split(const float* __restrict__ lds, const float (&xk)[FirstLayer<D>::KS], float (&out)[O], int lane) {
     using L = NetLdsSplit<D, H, O>;
@@ -426,22 +427,26 @@ __device__ __forceinline__ void net_forward_split(const float* __restrict__ lds,
 #pragma unroll
             for (int i = 0; i < 8; ++i) ex[i] = __builtin_amdgcn_exp2f(h1[mi][8 * s + i]);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ex[i] = fmaf(-2.0f, __builtin_amdgcn_rcpf(ex[i] + 1.0f), 1.0f);
-            unsigned pc[3][4];
+            for (int i = 0; i < 8; ++i) ex[i] = fmaf(-2.0f * kActScale, __builtin_amdgcn_rcpf(ex[i] + 1.0f), kActScale);   // kActScale h1
+            unsigned pc[2][4];
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) split3_pair(ex[2 * tt], ex[2 * tt + 1], pc[0][tt], pc[1][tt], pc[2][tt]);
+            for (int tt = 0; tt < 4; ++tt) split2_pair(ex[2 * tt], ex[2 * tt + 1], pc[0][tt], pc[1][tt]);
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo) {
                 const int a0 = (wf_base ^ (64 * mi + 32 * s)) + 4096 * mo;
-                bf16x8 A[3];
+                f16x8 A[2];
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    A[p] = frag8(*reinterpret_cast<const u32x2*>(Wimg + 8192 * p + a0), *reinterpret_cast<const u32x2*>(Wimg + 8192 * p + (a0 ^ 16)));
-                acc[mo] = mfma_split6(A[0], A[1], A[2], chunk_frag(pc, 0), chunk_frag(pc, 1), chunk_frag(pc, 2), acc[mo]);
+                for (int p = 0; p < 2; ++p)
+                    A[p] = __builtin_bit_cast(f16x8, frag8(*reinterpret_cast<const u32x2*>(Wimg + 8192 * p + a0), *reinterpret_cast<const u32x2*>(Wimg + 8192 * p + (a0 ^ 16))));
+                acc[mo] = mfma_split3(A[0], A[1], chunk_frag(pc, 0), chunk_frag(pc, 1), acc[mo]);
             }
         }
 #pragma unroll
-    for (int mo = 0; mo < MT; ++mo) tanh16(acc[mo]);
+    for (int mo = 0; mo < MT; ++mo) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mo][i] *= 1.0f / (kWScale * kActScale);       // the operand scales of L2 (powers of two: exact)
+        tanh16(acc[mo]);
+    }
     dense_out<MT, O, H>(lds + L::W3S, lds + L::B3, acc, out, lane);
 }
 #ifndef DRIL_FWD_SPLIT

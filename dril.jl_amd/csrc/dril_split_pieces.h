@@ -1,72 +1,20 @@
-// dril_split_pieces.h — bf16 piece images of activation tiles in LDS (row reads + ds_read_b64_tr_b16 transposed reads) shared by ppo_grad_wide_split_kernel, ppo_grad_pair_kernel and build_wimg_split_kernel
+// dril_split_pieces.h — f16 piece images of activation tiles in LDS (row reads + ds_read_b64_tr_b16 transposed reads) shared by ppo_grad_wide_split_kernel, ppo_grad_pair_kernel and build_wimg_split_kernel
 #pragma once
 #include "dril_internal.h"
 
 namespace dril {
 
-// (and only 8 chunks exist): bit 2 (the 64-byte window) from n bit 1, bits 0-1 from n bits 2-3.
+// chunk swizzle g(row) of the piece images: rows of >= 256 bytes (H >= 128) use four bits, 128-byte rows (H = 64; only 8 chunks exist) bit 2 (the 64-byte window) from n bit 1, bits 0-1 from n bits 2-3
 template <int H> __device__ __forceinline__ int wimg_g(int n) { return H >= 128 ? (((n & 3) << 2) | ((n >> 2) & 3)) : ((((n >> 1) & 1) << 2) | ((n >> 2) & 3)); }
 
-// pre-split fragment streams of one net: forward A[i][k] = kTanhScale W2[32mo + i][k], reverse A[i][k] = W2[k][32mo + i]; k = 32mi + 16s + 8(lane>>5) + j
-// split the 16 registers of m-tile w (accumulator layout) and store the packed pieces: registers 4g..4g+3 = units 32w + 8g + 4h .. +3 of sample c = one 8-byte chunk
-template <int H>
-__device__ __forceinline__ void store_tile_pieces(char* pimg, int w, const f32x16& x, int lane) {
-    constexpr int RB = 2 * H, PS = 32 * RB;
-    const int c = lane & 31, h = lane >> 5, rowb = c * RB + 8 * h, gsw = wimg_g<H>(c);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        unsigned hi[2], mid[2], lo[2];
-        split3_pair(x[4 * g], x[4 * g + 1], hi[0], mid[0], lo[0]); split3_pair(x[4 * g + 2], x[4 * g + 3], hi[1], mid[1], lo[1]);
-        const int a = rowb + (((4 * w + g) ^ gsw) << 4);
-        *reinterpret_cast<u32x2*>(pimg + a) = u32x2{hi[0], hi[1]}; *reinterpret_cast<u32x2*>(pimg + PS + a) = u32x2{mid[0], mid[1]}; *reinterpret_cast<u32x2*>(pimg + 2 * PS + a) = u32x2{lo[0], lo[1]};
-    }
-}
-// the inverse of store_tile_pieces for the lane's own chunks: x = hi + mid + lo (exact)
-template <int H>
-__device__ __forceinline__ void load_tile_pieces(const char* pimg, int w, f32x16& x, int lane) {
-    constexpr int RB = 2 * H, PS = 32 * RB;
-    const int c = lane & 31, h = lane >> 5, rowb = c * RB + 8 * h, gsw = wimg_g<H>(c);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int a = rowb + (((4 * w + g) ^ gsw) << 4);
-        const u32x2 hi = *reinterpret_cast<const u32x2*>(pimg + a), mid = *reinterpret_cast<const u32x2*>(pimg + PS + a), lo = *reinterpret_cast<const u32x2*>(pimg + 2 * PS + a);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            x[4 * g + 2 * t] = (__uint_as_float(hi[t] << 16) + __uint_as_float(mid[t] << 16)) + __uint_as_float(lo[t] << 16);
-            x[4 * g + 2 * t + 1] = (__uint_as_float(hi[t] & 0xffff0000u) + __uint_as_float(mid[t] & 0xffff0000u)) + __uint_as_float(lo[t] & 0xffff0000u);
-        }
-    }
-}
 // ---- XOR form of the swizzled addresses (ppo_grad_pair_kernel, ppo_update_small_kernel; round 3).  When every image starts at a multiple of 512 bytes of LDS, bits 4-6
 // of a swizzled address ARE the chunk field chunk ^ g(row), and stepping the chunk by a constant is an XOR of the whole address with that constant: one VALU per
 // access, image and piece offsets in the instruction's immediate, instead of xor / shift / add / add.  Addresses are byte offsets into the dynamic LDS segment.
 typedef __attribute__((address_space(3))) char lds_char;
 template <class T> __device__ __forceinline__ T pl_read(const lds_char* lds, int byte) { return *reinterpret_cast<const __attribute__((address_space(3))) T*>(lds + byte); }
 template <class T> __device__ __forceinline__ void pl_write(lds_char* lds, int byte, T v) { *reinterpret_cast<__attribute__((address_space(3))) T*>(lds + byte) = v; }
-// the lane's own chunks of m-tile w of a pair image (store_tile_pieces / load_tile_pieces of dril_split_pieces.h in the XOR form): t = pair base + row + chunk 4w of the
-// row + 8 (lane >> 5); IMG = byte offset of the image within the pair's block
-template <int IMG> __device__ __forceinline__ void pair_store_pieces(lds_char* lds, int t, const f32x16& x) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        unsigned hi[2], mid[2], lo[2];
-        split3_pair(x[4 * g], x[4 * g + 1], hi[0], mid[0], lo[0]); split3_pair(x[4 * g + 2], x[4 * g + 3], hi[1], mid[1], lo[1]);
-        const int a = t ^ (g << 4);
-        pl_write(lds, a + IMG, u32x2{hi[0], hi[1]}); pl_write(lds, a + IMG + 4096, u32x2{mid[0], mid[1]}); pl_write(lds, a + IMG + 8192, u32x2{lo[0], lo[1]});
-    }
-}
-template <int IMG> __device__ __forceinline__ void pair_load_pieces(const lds_char* lds, int t, f32x16& x) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int a = t ^ (g << 4);
-        const u32x2 hi = pl_read<u32x2>(lds, a + IMG), mid = pl_read<u32x2>(lds, a + IMG + 4096), lo = pl_read<u32x2>(lds, a + IMG + 8192);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            x[4 * g + 2 * k] = (__uint_as_float(hi[k] << 16) + __uint_as_float(mid[k] << 16)) + __uint_as_float(lo[k] << 16);
-            x[4 * g + 2 * k + 1] = (__uint_as_float(hi[k] & 0xffff0000u) + __uint_as_float(mid[k] & 0xffff0000u)) + __uint_as_float(lo[k] & 0xffff0000u);
-        }
-    }
-}
-// the two-piece f16 forms of the same (ppo_grad_pair_kernel): pieces at a + IMG and a + IMG + 4096
+// the lane's own chunks of m-tile w of a pair image (two f16 pieces, at a + IMG and a + IMG + 4096): t = pair base + row + chunk 4w of the row + 8 (lane >> 5);
+// IMG = byte offset of the image within the pair's block (ppo_grad_pair_kernel, ppo_update_small_kernel)
 template <int IMG> __device__ __forceinline__ void pair_store_pieces2(lds_char* lds, int t, const f32x16& x) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
