@@ -169,6 +169,7 @@ __device__ __forceinline__ float tanh_f32(float x) {
 constexpr float kTanhScale = 2.8853900817779268f;
 
 // ---------------------------------------------------------------------------------------------
+// (rounds 2 - 3; since the end of round 3 only the generic contractions of dril_gemm.hip, whose operands have any range — the fused kernels use the f16 form below)
 // fp32-equivalent contraction on the bf16 matrix cores: every f32 operand is cut into three bf16 pieces x = hi + mid + lo (nearest bf16, exact
 // remainder, twice: exact for a 24-bit mantissa) and a k16 step of a 32x32 tile is six v_mfma_f32_32x32x16_bf16 (hi.hi hi.mid mid.hi mid.mid hi.lo lo.hi;
 // the three dropped partial products are <= 2^-23 relative; f32 accumulate).  profiles/r01_bf16_split_microbench.md: 2.0x the rate of
@@ -219,8 +220,8 @@ __device__ __forceinline__ f32x16 mfma_split6(bf16x8 Ah, bf16x8 Am, bf16x8 Al, b
 // f16, i.e. |x S| >= 2^-14 2^11 = 0.125; below that the error is an absolute 2^-25.  The power-of-two scale S moves the operand range there: activations (|h| < 1) use
 // kActScale, the staged weights kWScale, the gradient tiles 4 / invB rounded up to a power of two.  A k16 step of a 32x32 tile is THREE v_mfma_f32_32x32x16_f16
 // (lo.hi, hi.lo, hi.hi; the dropped lo.lo is <= 2^-24 relative; f32 accumulate) instead of six bf16 ones, and a pair of values splits in 6 VALU instead of 11.
-// Against a float64 gradient this arithmetic is 1.05 - 1.2 x as far as the exact-f32 kernel (the six-product bf16 form 0.85 - 1.1 x, a four-product bf16 form
-// 12 - 39 x): tests/test_gpu_split_arith.py, profiles/r03_split_arith.md section 6.
+// Against a float64 gradient this arithmetic is 0.97 - 1.16 x as far as the exact-f32 kernel on the device (the six-product bf16 form 0.85 - 1.04 x, a
+// four-product bf16 form 12 - 39 x, hi.hi alone 1 000 - 5 700 x): tests/test_gpu_split_arith.py, profiles/r03_split_arith.md section 6.
 // f16 has a RANGE: |x S| > 65 504 overflows.  The scales leave |w| < 350 for weights, a factor ~ 4 000 over a typical gradient tile; an overflow becomes Inf / NaN in
 // the gradient and is reported like any non-finite gradient (ppo.jl:213-214), never silently wrong.
 // ---------------------------------------------------------------------------------------------

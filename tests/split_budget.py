@@ -1,15 +1,16 @@
-"""Error budget of the bf16 x 3 operand split against a float64 gradient (test infrastructure).
+"""Error budget of the operand split against a float64 gradient (test infrastructure).
 
-The update kernels that run on the bf16 matrix cores (ppo_grad_pair_kernel, ppo_grad_wide_split_kernel) cut every f32 operand of the H x H
-contractions into three bf16 pieces and keep six of the nine piece products.  `measure` runs one minibatch through
+The update kernels that run on the 16-bit matrix cores (ppo_grad_pair_kernel, ppo_grad_wide_split_kernel) cut every f32 operand of the H x H
+contractions into pieces — two f16 pieces and three of the four piece products since the end of round 3 (dril_device.h), three bf16 pieces and
+six of nine before.  `measure` runs one minibatch through
   * the split kernel (what the size rule / the default selects, or forced),
   * the exact-f32 kernel of the same handle shape (DRIL_GRAD_VARIANT=0),
   * a float64 torch-autograd restatement of ppo.jl:365-407 (tests/test_oracle_crosschecks.py),
-and reports each kernel's distance from the float64 gradient, the loss errors, and the signed statistics of the dW2 error (truncation splitting drops
+and reports each kernel's distance from the float64 gradient, the loss errors, and the signed statistics of the dW2 error (a split by truncation drops
 one-signed terms: a bias would show as a non-zero mean / a shrinkage of the gradient).
 
 Run as a script it prints the numbers as one JSON line; tests/test_gpu_split_arith.py starts it with DRIL_HIP_LIBRARY pointing at the
-negative-control build (libdril_hip_droplo.so: `lo` pieces dropped) and requires the budget to be BROKEN there.
+negative-control build (libdril_hip_droplo.so: the `lo` products dropped) and requires the budget to be BROKEN there.
 """
 from __future__ import annotations
 

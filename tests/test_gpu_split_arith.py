@@ -1,7 +1,9 @@
-"""GPU (-m gpu): the bf16 x 3 operand split of the update kernels, at the minibatch sizes where the size rule selects those kernels,
+"""GPU (-m gpu): the operand split of the update kernels — since the end of round 3 TWO f16 pieces and three products per k16 step (dril_device.h; rounds 2 - 3:
+three bf16 pieces, six products) — at the minibatch sizes where the size rule selects those kernels,
 (1) directly against the CPU oracle (ppo.jl:365-407 + hand-written backward), (2) against a float64 gradient with an error budget relative to
-the exact-f32 kernel, (3) with a negative control: the same library built with the `lo` pieces dropped (a two-piece split, 2^-16 relative)
-must BREAK the budget — which is what shows that (2) can tell a 24-bit product from a 16-bit one.
+the exact-f32 kernel, (3) with a negative control: the same library built with the `lo` products dropped (an 11-bit product; 16-bit in the bf16 form)
+must BREAK the budget — which is what shows that (2) can tell a 24-bit product from a shorter one, (4) at the full minibatch size of the headline
+config through additivity.
 
 Tolerances: loss 1e-4 rel (BASELINE.json north_star), gradient within 2e-4 of its norm, as for the f32 kernel in tests/test_gpu_parity.py.
 """
@@ -145,12 +147,12 @@ def test_split_error_budget_vs_float64(pkg, oracle_mod, kind, H, B, forced):
     assert ok_grad, (m["grad_err_split"], m["grad_err_f32"])
     assert ok_loss, (m["loss_err_split"], m["loss_err_f32"])
     assert ok_bias, (m["dW2_mean_err_split"], m["dW2_std_err_split"], m["dW2_shrink_split"], m["dW2_shrink_f32"])
-    assert m["grad_err_split"] <= 5e-7                                    # absolute: fp32-level agreement with float64 (measured 0.9 - 1.6e-7, profiles/r03_split_arith.md)
+    assert m["grad_err_split"] <= 5e-7                                    # absolute: fp32-level agreement with float64 (measured 1.0 - 1.5e-7, profiles/r03_split_arith.md section 6)
 
 
 def test_negative_control_two_piece_split_breaks_the_budget(pkg):
-    """the same measurement on libdril_hip_droplo.so (mfma_split6 without its two `lo` products = a two-piece split): the gradient criterion of the budget test
-    must FAIL for every case — a test that a 2^-16 product passes would prove nothing about 2^-23"""
+    """the same measurement on libdril_hip_droplo.so (mfma_split3 without its two `lo` products = hi.hi only, an 11-bit product): the gradient criterion of the
+    budget test must FAIL for every case — a test that a short product passes would prove nothing about 2^-24"""
     so = ROOT / "dril.jl_amd" / "csrc" / "libdril_hip_droplo.so"
     assert so.exists(), f"{so} missing: __graft_entry__.build() compiles it"
     env = dict(os.environ, DRIL_HIP_LIBRARY=str(so))
