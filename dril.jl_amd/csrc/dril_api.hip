@@ -343,7 +343,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     }
     int Gc = G;
     if (variant == 2 && 2 * G >= 4 * h->num_cus) {     // pair kernel filling the chip (two workgroups of two pairs per CU): the pairs are divided between the nets by their cost per tile
-        const int pml = h->grad_actor_pct ? h->grad_actor_pct : (h->discrete ? 485 : 450), total = 4 * h->num_cus;   // measured optima (re-swept at the end of round 3): the older (actor) workgroups win the issue arbitration on a shared SIMD
+        const int pml = h->grad_actor_pct ? h->grad_actor_pct : (h->discrete ? 500 : 450), total = 4 * h->num_cus;   // measured optima (re-swept on the f16 arithmetic at the end of round 3): the older (actor) workgroups win the issue arbitration on a shared SIMD
         int ga = ((total * pml + 500) / 1000) & ~1; if (ga < 2) ga = 2; if (ga > total - 2) ga = total - 2;
         G = ga; Gc = total - ga;
         if (G > h->Gmax) G = h->Gmax & ~1; if (Gc > h->Gmax) Gc = h->Gmax & ~1;

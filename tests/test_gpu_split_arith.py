@@ -74,6 +74,50 @@ def test_selected_kernel_loss_and_gradient_vs_oracle(pkg, oracle_mod, kind, H, B
     assert lh2 == lh and np.array_equal(gh, gh2)                     # deterministic slabs
 
 
+@pytest.mark.parametrize("kind,H,scale", [(0, 64, 3e-3), (1, 64, 3e-3), (0, 64, 1.0), (1, 64, 1.0), (1, 256, 1e-3), (0, 128, 1.0)])
+def test_f16_pieces_across_the_operand_range(pkg, oracle_mod, kind, H, scale):
+    """the f16 pieces have a RANGE (dril_device.h): operands are scaled so that weights of O(0.1) and activations / gradient tiles of O(1) sit where hi AND lo are
+    normal f16 numbers.  Away from that — weights 100 x smaller (every `lo` piece subnormal: the representation error becomes an absolute 2^-25 of the scaled value)
+    or 4 x larger (saturated tanh units, pre-activations of tens; beyond that the Categorical head itself produces 0 log 0) — the gradient must still agree with the
+    oracle to the tolerance of the other parity tests"""
+    B = 131072 if H == 64 else 32768
+    cfg = _cfg(pkg, kind, n_envs=2, n_steps=2, batch_size=2, hidden1=H, hidden2=H, ent_coef=0.01)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = (np.random.default_rng(77 + kind).standard_normal(h.P) * scale * (1.0 if H == 64 else 0.3)).astype(np.float32)
+    h.set_params(flat); o.set_params(flat)
+    batch = _batch(o, cfg, B, 9)
+    lh, sh, gh = h.ppo_loss_grad(*batch); lo, so, go = o.ppo_loss_grad(*batch)
+    assert h.grad_kernel_info().split(":")[0] == EXPECTED[H]
+    rel = np.linalg.norm(gh - go) / np.linalg.norm(go)
+    print(f"[range] kind {kind} H {H} weight scale {scale}: loss rel {abs(lh - lo) / abs(lo):.2e}, |dg|/|g| {rel:.2e}")
+    assert lh == pytest.approx(lo, rel=1e-4) and rel <= 2e-4
+
+
+def test_f16_overflow_is_a_reported_non_finite_gradient(pkg, oracle_mod):
+    """what f32 has and the f16 pieces do not is range: a staged weight beyond ~ 350 overflows its hi piece.  The documented behaviour is the
+    reference's for a non-finite gradient — an error (ppo.jl:213-214), never a silently wrong update; the exact-f32 kernels (DRIL_GRAD_VARIANT=0) take the same weights"""
+    capi = pkg._capi
+    cfg = _cfg(pkg, 0, n_envs=4096, n_steps=64, batch_size=4096 * 64 // 2, epochs=1, episode_len=25)
+    o = oracle_mod.Oracle(cfg)
+    flat = (np.random.default_rng(5).standard_normal(o.P) * 0.3).astype(np.float32)
+    o.set_params(flat); o.env_reset(3); o.collect_rollout()
+    big = flat.copy(); big[4 * 64 + 64 + 5] = 1000.0                                  # one W2 entry of the actor
+    for variant, fails in ((None, True), ("0", False)):
+        with split_budget.grad_variant(variant):
+            h = pkg.Handle(cfg)
+        h.set_params(big)
+        for which in BUFS:
+            h.set_buffer(getattr(capi, which), o.buffer(getattr(capi, which)))
+        if fails:
+            with pytest.raises(Exception) as ei:
+                h.ppo_update()
+            assert "nan" in str(ei.value).lower() and h.grad_kernel_info().split(":")[0] == "ppo_grad_pair_kernel"
+        else:
+            st = h.ppo_update()
+            assert np.isfinite(st.loss) and np.isfinite(st.grad_norm) and h.grad_kernel_info().split(":")[0] == "ppo_grad_kernel"
+        h.close()
+
+
 @pytest.mark.parametrize("kind,H,variant", [(0, 64, "ent_vfclip"), (1, 64, "default"), (1, 256, "default")])
 def test_full_size_minibatch_is_the_weighted_mean_of_its_halves(pkg, kind, H, variant):
     """the headline minibatch size of BASELINE configs[1] / configs[2] (B = 65 536 x 2048 / 32 = 4 194 304 samples per launch: 256 tiles per pair of ppo_grad_pair_kernel,
