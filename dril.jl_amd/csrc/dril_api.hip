@@ -222,6 +222,9 @@ size_t act_bytes_per(const dril_handle* h) { return h->discrete ? 4 : 4 * (size_
 // default by measurement (profiles/r02_wide_split.md): the split form for both wide widths (hidden 256: 176-183 vs 118 TFLOP/s; hidden 128: 151 vs 113.5)
 int wide_variant(const dril_handle* h) { return (h->wide && h->rec && (h->grad_variant < 0 ? 1 : h->grad_variant)) ? 1 : 0; }
 // hidden [64,64]: may ppo_grad_pair_kernel run at all (it reads packed records; DRIL_GRAD_VARIANT=0 pins the exact-f32 kernel)
+// minibatches of at least this many 32-sample tiles per CU run ppo_grad_pair_kernel (measured on the f16 arithmetic, 256 CUs: 65 536 samples 50.7 us against 64.8 us on the
+// exact-f32 kernel, 16 384 samples 42.2 against 39.0; with the bf16 x 3 arithmetic of rounds 2 - 3 the crossover was at 16 tiles per CU)
+constexpr int kPairTilesPerCu = 8;
 bool pair_variant(const dril_handle* h) { return !h->wide && !h->generic && h->grad_variant != 0 && h->rec && h->D <= 4; }   // (D > 4: 96 dW1 accumulators do not fit the pair kernel's 256 registers — the f32 kernel runs every size)
 int ensure_wimg(dril_handle* h) {
     if (!h->wide || !h->wimg_dirty) return DRIL_OK;
@@ -336,7 +339,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     int variant = 0;
     if (h->wide) variant = (wide_variant(h) && rec) ? 1 : 0;
     if (!h->wide && !h->generic) {
-        variant = h->grad_variant == 0 ? 0 : h->grad_variant > 0 ? 2 : (tiles >= 16 * (int64_t)h->num_cus ? 2 : 0);   // large minibatches: the pair kernel
+        variant = h->grad_variant == 0 ? 0 : h->grad_variant > 0 ? 2 : (tiles >= kPairTilesPerCu * (int64_t)h->num_cus ? 2 : 0);   // large minibatches: the pair kernel
         if (variant == 2 && !(pair_variant(h) && rec && h->Gmax >= 2)) variant = 0;   // the pair kernel reads packed records and needs two slabs per workgroup (DRIL_GRAD_GMAX=1: not the pair kernel)
         if (variant == 2) { G = (int)(tiles < h->Gmax ? tiles : h->Gmax) & ~1; if (G < 2) G = 2; }   // pairs per net (even: two pairs per workgroup)
         if (variant == 0 && G > h->num_cus) G = h->num_cus;                                   // Gmax is sized for the pair kernel's slabs; the f32 kernel runs two workgroups per CU
@@ -1074,7 +1077,7 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
         const bool epoch_moments = h->cfg.normalize_advantage && !perm && nb >= 2 && nb <= 2048 && !h->no_epoch_moments;
         // chip-filling minibatches of the fused kernels: the epoch's order as an index array (the update kernels then read 8 bytes per sample instead of evaluating the
         // keyed bijection per lane, wave, net and tile)
-        const bool index_array = !perm && !h->generic && !h->no_epoch_index && (B + kTile - 1) / kTile >= 16 * (int64_t)h->num_cus;
+        const bool index_array = !perm && !h->generic && !h->no_epoch_index && (B + kTile - 1) / kTile >= kPairTilesPerCu * (int64_t)h->num_cus;
         if (index_array) {
             if (!h->epoch_index) HIPCHK(h, dmalloc(&h->epoch_index, (size_t)N));
             prof_begin(h, DRIL_K_ADV_MOMENTS);

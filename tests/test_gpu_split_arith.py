@@ -43,7 +43,9 @@ EXPECTED = {64: "ppo_grad_pair_kernel", 128: "ppo_grad_wide_split_kernel", 256: 
 
 
 @pytest.mark.parametrize("kind,H,B,variant", [
-    (0, 64, 131072, "default"),            # 4 096 tiles = 16 tiles per CU: the smallest minibatch the size rule gives to the pair kernel
+    (0, 64, 65536, "default"),             # 2 048 tiles = 8 tiles per CU: the smallest minibatch the size rule gives to the pair kernel (one tile per pair)
+    (1, 64, 65536 + 33, "ent_vfclip"),
+    (0, 64, 131072, "default"),
     (1, 64, 131072, "ent_vfclip"),
     (0, 64, 262144 + 45, "ent_vfclip"),    # multi-trip loop with unequal actor / critic pair counts and a ragged last tile
     (1, 64, 262144, "default"),
