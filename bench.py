@@ -34,16 +34,17 @@ def flop_fwd(D: int, H: int, A: int) -> int:
     return 2 * ((D * H + H * H + H * A) + (D * H + H * H + H))
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
-# an fp32-equivalent contraction on the bf16 matrix cores is SIX bf16 MFMAs per product (3-piece operand split): its own ceiling in
-# delivered-f32 flops.  Reported beside `peak` (which stays the f32-MFMA figure the judge prices against) as roofline.split_ceiling.
+# an fp32-equivalent contraction on the 16-bit matrix cores spends several MFMAs per product: SIX bf16 ones with three-piece operands (the generic contractions; the fused
+# kernels until the end of round 3), THREE f16 ones with two-piece operands (the fused kernels since) — the kernel's own ceiling in delivered f32 flops
+# is the dense 16-bit peak (the same for f16 and bf16) over that count
 PEAK_BF16_SPLIT6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6
 PMC_FILE = "r03_ppo_grad_pmc.json"  # HBM traffic (PMC) + rocprofv3 average of the dominant kernel on configs[1], with the commit it was taken at
 
 
 def mfma_roofline(ach_tflops: float, arith: str) -> dict:
-    """peak / frac of a dense-contraction kernel.  A kernel that computes its fp32-equivalent products as SIX bf16 MFMAs (3-piece operand split) is priced against
-    ITS pipe: dense bf16 peak / 6 = 419.4 TFLOP/s of delivered f32 flops; the figure against the f32-MFMA peak (157.3, the pipe the exact-f32 kernels run on and the
-    roof SURVEY.md section 8d names) is kept beside it as frac_vs_f32_peak — it may exceed 1 and is never `frac`."""
+    """peak / frac of a dense-contraction kernel.  A kernel that computes its fp32-equivalent products as THREE f16 MFMAs (two-piece operand split) or SIX bf16 MFMAs (three-piece
+    split) is priced against ITS pipe: dense 16-bit peak / 3 = 838.9 or / 6 = 419.4 TFLOP/s of delivered f32 flops; the figure against the f32-MFMA peak (157.3, the pipe the exact-f32
+    kernels run on and the roof SURVEY.md section 8d names) is kept beside it as frac_vs_f32_peak — it may exceed 1 and is never `frac`."""
     if "f16x2" in arith:          # two-piece f16 operands: three f16 MFMAs per fp32-equivalent product
         peak, note = PEAK_BF16_SPLIT6_TFLOPS * 2.0, "dense f16 MFMA peak 2516.6 / 3 MFMAs per fp32-equivalent product"
     elif "bf16x3" in arith:

@@ -356,7 +356,7 @@ function kernel_seconds(h)
     end
     return out
 end
-"which gradient kernel the last optimiser step ran and the arithmetic it computes in, e.g. \"ppo_grad_pair_kernel: f32 (bf16x3 split, f32 accumulate; ...)\" (dril_grad_kernel_info)"
+"which gradient kernel the last optimiser step ran and the arithmetic it computes in, e.g. \"ppo_grad_pair_kernel: f32 (f16x2 split, f32 accumulate; ...)\" (dril_grad_kernel_info)"
 grad_kernel_info(env::DeviceParallelEnv) = unsafe_string(ccall((:dril_grad_kernel_info, LIB[]), Cstring, (Ptr{Cvoid},), env.handle))
 """
 "batch loop" / "compute_gradients" / "apply_gradients" (ppo.jl:206-207,239) have no host-side extent here — the whole epoch x minibatch loop is ONE
