@@ -109,6 +109,7 @@ struct dril_handle {
     bool force_allreduce = false, force_stepwise = false;
     double *epoch_tables = nullptr, *epoch_stats = nullptr; int epoch_blocks = 512, epoch_nb_cap = 0;   // per-epoch advantage moments
     float *w2a_actor = nullptr, *w2ta_actor = nullptr, *w2a_critic = nullptr, *w2ta_critic = nullptr; bool wide = false, wimg_dirty = true;   // wide nets (H > 64)
+    void *w2pf_actor = nullptr, *w2pf_critic = nullptr;   // wide nets: the forward stream in the k-order of a register B operand (net_forward_wide_split)
     void *w2p_actor = nullptr, *w2tp_actor = nullptr, *w2p_critic = nullptr, *w2tp_critic = nullptr;   // wide nets: pre-split bf16 fragment streams of W2 / W2' (ppo_grad_wide_split_kernel)
     // MonitorWrapperEnv (cfg.monitor_window > 0)
     float *mon_cur_ret = nullptr, *ep_ret = nullptr, *mon_ring_ret = nullptr, *e_ep_ret = nullptr; int32_t *mon_cur_len = nullptr, *ep_len = nullptr, *mon_ring_len = nullptr, *e_ep_len = nullptr;
@@ -230,9 +231,9 @@ int ensure_wimg(dril_handle* h) {
     if (!h->wide || !h->wimg_dirty) return DRIL_OK;
     HIPCHK(h, launch_build_wimg(h->params, h->actor, h->cfg.hidden1, h->w2a_actor, h->w2ta_actor, h->stream));
     HIPCHK(h, launch_build_wimg(h->params, h->critic, h->cfg.hidden1, h->w2a_critic, h->w2ta_critic, h->stream));
-    if (wide_variant(h)) {
-        HIPCHK(h, launch_build_wimg_split(h->params, h->actor, h->cfg.hidden1, h->w2p_actor, h->w2tp_actor, h->stream));
-        HIPCHK(h, launch_build_wimg_split(h->params, h->critic, h->cfg.hidden1, h->w2p_critic, h->w2tp_critic, h->stream));
+    if (wide_variant(h) || DRIL_FWD_SPLIT) {      // the pre-split f16 fragment streams: ppo_grad_wide_split_kernel, and the forward of rollout / policy kernels
+        HIPCHK(h, launch_build_wimg_split(h->params, h->actor, h->cfg.hidden1, h->w2p_actor, h->w2tp_actor, h->w2pf_actor, h->stream));
+        HIPCHK(h, launch_build_wimg_split(h->params, h->critic, h->cfg.hidden1, h->w2p_critic, h->w2tp_critic, h->w2pf_critic, h->stream));
     }
     h->wimg_dirty = false;
     return DRIL_OK;
@@ -257,7 +258,8 @@ PolicyArgs policy_args(dril_handle* h, const float* obs, int64_t B, const void* 
     PolicyArgs a{};
     a.params = h->params; a.obs = obs; a.B = B; a.noise = noise; a.actions = actions; a.values = values; a.logp = logp; a.entropy = entropy;
     a.mode = mode; a.action_start = h->cfg.action_start; a.log_std_off = h->log_std_off; a.seed = h->cfg.seed; a.call_counter = h->policy_calls;
-    a.actor = h->actor; a.critic = h->critic; a.w2a_actor = h->w2a_actor; a.w2a_critic = h->w2a_critic;
+    a.actor = h->actor; a.critic = h->critic;
+    a.w2a_actor = DRIL_FWD_SPLIT ? (const float*)h->w2pf_actor : h->w2a_actor; a.w2a_critic = DRIL_FWD_SPLIT ? (const float*)h->w2pf_critic : h->w2a_critic;   // wide nets: W2 operand of the forward
     return a;
 }
 
@@ -547,7 +549,8 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (h->generic) { h->Gmax = std::getenv("DRIL_EXT_GMAX") ? std::atoi(std::getenv("DRIL_EXT_GMAX")) : 64; if (h->Gmax < 1) h->Gmax = 1; }                                                        // generic path: one slab per row chunk of the minibatch
     if (const char* e = std::getenv("DRIL_GRAD_GMAX")) { const int g = std::atoi(e); if (g > 0 && g < h->Gmax) h->Gmax = g; }   // diagnostic: fewer workgroups per net
     if (h->wide) { const size_t pb = (size_t)hd[0] * hd[0] * 6;    // three bf16 pieces per element
-        CCHK(hipMalloc(&h->w2p_actor, pb)); CCHK(hipMalloc(&h->w2tp_actor, pb)); CCHK(hipMalloc(&h->w2p_critic, pb)); CCHK(hipMalloc(&h->w2tp_critic, pb)); }
+        CCHK(hipMalloc(&h->w2p_actor, pb)); CCHK(hipMalloc(&h->w2tp_actor, pb)); CCHK(hipMalloc(&h->w2p_critic, pb)); CCHK(hipMalloc(&h->w2tp_critic, pb));
+        CCHK(hipMalloc(&h->w2pf_actor, pb)); CCHK(hipMalloc(&h->w2pf_critic, pb)); }
     if (h->wide) { const size_t hh = (size_t)hd[0] * hd[0]; CCHK(dmalloc(&h->w2a_actor, hh)); CCHK(dmalloc(&h->w2ta_actor, hh)); CCHK(dmalloc(&h->w2a_critic, hh)); CCHK(dmalloc(&h->w2ta_critic, hh)); }
     CCHK(dmalloc(&h->slabs_a, (size_t)h->Gmax * h->slab_a)); CCHK(dmalloc(&h->slabs_c, (size_t)h->Gmax * h->slab_c));
     CCHK(dmalloc(&h->state, E * h->S)); CCHK(dmalloc(&h->step_count, E)); CCHK(dmalloc(&h->episode, E)); CCHK(dmalloc(&h->gstep, E));
@@ -603,7 +606,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     if (h->ext_stage_rew) (void)hipHostFree(h->ext_stage_rew); if (h->ext_stage_flags) (void)hipHostFree(h->ext_stage_flags);
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
-                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->epoch_index, h->epoch_keys, h->small_xchg, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
+                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->epoch_index, h->epoch_keys, h->small_xchg, h->w2pf_actor, h->w2pf_critic, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
                     h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->e_rew_n, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->gen_tmp, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->w2p_actor, h->w2tp_actor, h->w2p_critic, h->w2tp_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
                     h->mon_ring_len, h->e_ep_len, h->mon_cnt, h->mon_meta, h->e_flags};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -862,7 +865,7 @@ int collect_rollout(dril_handle* h, double* fps, bool do_sync) {
     a.noise = h->noise_set ? h->noise_dev : nullptr;
     a.E = h->cfg.n_envs; a.T = h->cfg.n_steps; a.episode_len = h->cfg.episode_len; a.fixed_len = h->cfg.fixed_length_episodes;
     a.action_start = h->cfg.action_start; a.log_std_off = h->log_std_off; a.env_seed0 = h->env_seed0; a.actor = h->actor; a.critic = h->critic;
-    a.w2a_actor = h->w2a_actor; a.w2a_critic = h->w2a_critic;
+    a.w2a_actor = DRIL_FWD_SPLIT ? (const float*)h->w2pf_actor : h->w2a_actor; a.w2a_critic = DRIL_FWD_SPLIT ? (const float*)h->w2pf_critic : h->w2a_critic;
     a.mon_cur_ret = h->mon_cur_ret; a.mon_cur_len = h->mon_cur_len; a.ep_ret = h->ep_ret; a.ep_len = h->ep_len;
     const auto t0 = std::chrono::steady_clock::now();
     if (fps) HIPCHK(h, hipStreamSynchronize(h->stream));

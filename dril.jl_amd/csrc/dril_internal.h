@@ -5,6 +5,10 @@
 
 #include "dril_device.h"
 
+#ifndef DRIL_FWD_SPLIT
+#define DRIL_FWD_SPLIT 1     // 0: the f32-MFMA forward in rollout_kernel / policy_kernel (A/B build); 1: the f16 two-piece forward (the W2 operand of wide nets is then the
+                             // pre-split fragment stream w2p, which the host passes in the w2a fields of PolicyArgs / RolloutArgs)
+#endif
 namespace dril {
 
 struct PolicyArgs {
@@ -153,7 +157,7 @@ hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_finish_small(const ReduceArgs& r, const AdamArgs& a, hipStream_t s);   // grad_reduce + norm + Adam in one workgroup (few slabs)
 hipError_t launch_explained_var(const float* val, const float* ret, int64_t N, double* partials, int nblocks, hipStream_t s);
 hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a, float* w2ta, hipStream_t s);
-hipError_t launch_build_wimg_split(const float* params, NetOff off, int H, void* w2p, void* w2tp, hipStream_t s);
+hipError_t launch_build_wimg_split(const float* params, NetOff off, int H, void* w2p, void* w2tp, void* w2pf, hipStream_t s);
 int slab_size_actor(int kind, int hidden);
 int slab_size_critic(int kind, int hidden);
 

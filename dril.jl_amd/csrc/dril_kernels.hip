@@ -449,13 +449,81 @@ __device__ __forceinline__ void net_forward_split(const float* __restrict__ lds,
     }
     dense_out<MT, O, H>(lds + L::W3S, lds + L::B3, acc, out, lane);
 }
-#ifndef DRIL_FWD_SPLIT
-#define DRIL_FWD_SPLIT 1     // 0: the f32-MFMA forward in rollout_kernel / policy_kernel (A/B)
-#endif
+// ---- forward of a wide net (hidden 128 / 256) for one 32-sample tile on the f16 matrix cores: kActScale h1 as two f16 pieces in registers (the same 16 registers per
+// m-tile the f32 form holds), W2 from L2 as a pre-split fragment stream (build_wimg_split_kernel: [(mo MT + mi) 2 + s][piece][lane], kTanhScale kWScale W2, 4 bytes per
+// weight like the f32 stream; in the k-order of a REGISTER B operand: accumulator registers 8 s .. 8 s + 7 of half-wave h are units 4 h .. 4 h + 3 and 8 + 4 h .. 8 + 4 h + 3
+// of the k16 step, not 8 h .. 8 h + 7 as in the LDS-image operand of the update kernel — hence its own stream, w2pf), three MFMAs per k16 step instead of sixteen v_mfma_f32_32x32x2_f32; each fragment register is refilled
+// right after the MFMAs that consumed it, across m-tile boundaries too
+template <int D, int H, int O>
+__device__ __forceinline__ void net_forward_wide_split(const float* __restrict__ lds, const u32x4* __restrict__ w2p, const float (&xk)[FirstLayer<D>::KS],
+                                                       float (&out)[O], int lane) {
+    using L = NetLdsSmall<D, H, O>;
+    constexpr int MT = H / 32;
+    const int h = lane >> 5;
+    u32x4 pcs[MT][2][2];                                              // [input m-tile][k16 step][piece]: the B operands of L2
+    {
+        f32x16 h1[MT];
+        dense_first<H, MT, FirstLayer<D>::KS>(lds + L::W1T, lds + L::B1, xk, h1, lane);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            tanh16_scaled<false>(h1[mi], 1.0f);                       // kActScale h1
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) split2_pair(h1[mi][8 * s + 2 * tt], h1[mi][8 * s + 2 * tt + 1], hi[tt], lo[tt]);
+                pcs[mi][s][0] = u32x4{hi[0], hi[1], hi[2], hi[3]}; pcs[mi][s][1] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+            }
+        }
+    }
+    float part[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) part[o] = 0.f;
+    const u32x4* fbase = w2p + lane;
+    constexpr int F = MT * MT * 4;
+    u32x4 af[4];                                                      // (s, piece) = (0, hi) (0, lo) (1, hi) (1, lo) of the current (mo, mi)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) af[q] = fbase[(size_t)q * 64];
+#pragma unroll 1
+    for (int mo = 0; mo < MT; ++mo) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + L::B2 + 32 * mo + 8 * q + 4 * h);   // staged as kTanhScale b2
+            acc[4 * q + 0] = b[0] * (kWScale * kActScale); acc[4 * q + 1] = b[1] * (kWScale * kActScale); acc[4 * q + 2] = b[2] * (kWScale * kActScale); acc[4 * q + 3] = b[3] * (kWScale * kActScale);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                acc = mfma_split3(__builtin_bit_cast(f16x8, af[2 * s]), __builtin_bit_cast(f16x8, af[2 * s + 1]), __builtin_bit_cast(f16x8, pcs[mi][s][0]), __builtin_bit_cast(f16x8, pcs[mi][s][1]), acc);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    int f = (mo * MT + mi) * 4 + 2 * s + p + 4; f = f < F ? f : F - 4 + 2 * s + p;   // the tail re-reads the last fragments (in bounds, unused)
+                    af[2 * s + p] = fbase[(size_t)f * 64];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] *= 1.0f / (kWScale * kActScale);       // the operand scales of L2 (powers of two: exact)
+        tanh16(acc);
+#pragma unroll
+        for (int o = 0; o < O; ++o)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(lds + L::W3S + o * H + 32 * mo + 8 * q + 4 * h);
+                part[o] = fmaf(w[0], acc[4 * q + 0], part[o]); part[o] = fmaf(w[1], acc[4 * q + 1], part[o]);
+                part[o] = fmaf(w[2], acc[4 * q + 2], part[o]); part[o] = fmaf(w[3], acc[4 * q + 3], part[o]);
+            }
+    }
+#pragma unroll
+    for (int o = 0; o < O; ++o) out[o] = part[o] + __shfl_xor(part[o], 32) + lds[L::B3 + o];
+}
 // forward of one net for a 32-sample tile: LDS-resident weights (H = 64) or the wide path (W2 streamed from L2)
 template <int D, int H, int O, bool WIDE>
 __device__ __forceinline__ void eval_net(const float* __restrict__ lds, const float* __restrict__ w2a, const float (&xk)[FirstLayer<D>::KS], float (&out)[O], int lane) {
-    if constexpr (WIDE) net_forward_wide<D, H, O>(lds, w2a, xk, out, lane);
+    if constexpr (WIDE && DRIL_FWD_SPLIT) net_forward_wide_split<D, H, O>(lds, reinterpret_cast<const u32x4*>(w2a), xk, out, lane);
+    else if constexpr (WIDE) net_forward_wide<D, H, O>(lds, w2a, xk, out, lane);
     else if constexpr (DRIL_FWD_SPLIT) net_forward_split<D, H, O>(lds, xk, out, lane);
     else { f32x16 h1[H / 32], h2[H / 32]; net_forward<D, H, H, O>(lds, xk, h1, h2, out, lane); }
 }
@@ -949,21 +1017,23 @@ __global__ void pack_records_kernel(int64_t N, const float* __restrict__ obs, co
 }
 
 // pre-split fragment streams of ppo_grad_wide_split_kernel: two f16 pieces per weight (dril_device.h), forward kTanhScale kWScale W2, reverse kWScale W2'
-__global__ void build_wimg_split_kernel(const float* __restrict__ P, NetOff off, int H, u32x4* __restrict__ w2p, u32x4* __restrict__ w2tp) {
+__global__ void build_wimg_split_kernel(const float* __restrict__ P, NetOff off, int H, u32x4* __restrict__ w2p, u32x4* __restrict__ w2tp, u32x4* __restrict__ w2pf) {
     const int MT = H / 32, total = MT * MT * 2 * 64;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int lane = idx & 63, s = (idx >> 6) & 1, mi = (idx >> 7) % MT, mo = (idx >> 7) / MT;
         const int i = 32 * mo + (lane & 31), k0 = 32 * mi + 16 * s + 8 * (lane >> 5);
-        unsigned f[2][4], b[2][4];
+        unsigned f[2][4], b[2][4], g[2][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int k = k0 + 2 * t;
+            const int kf = 32 * mi + 16 * s + 8 * (t >> 1) + 4 * (lane >> 5) + 2 * (t & 1);                                                                             // register-B order of the forward kernels (net_forward_wide_split)
+            split2_pair((kTanhScale * kWScale) * P[off.w2 + i + (size_t)kf * H], (kTanhScale * kWScale) * P[off.w2 + i + (size_t)(kf + 1) * H], g[0][t], g[1][t]);
             split2_pair((kTanhScale * kWScale) * P[off.w2 + i + (size_t)k * H], (kTanhScale * kWScale) * P[off.w2 + i + (size_t)(k + 1) * H], f[0][t], f[1][t]);   // W2[o][k] (column-major out x in)
             split2_pair(kWScale * P[off.w2 + k + (size_t)i * H], kWScale * P[off.w2 + k + 1 + (size_t)i * H], b[0][t], b[1][t]);                                   // W2'[i][k] = W2[k][i]
         }
         const size_t base = ((size_t)((mo * MT + mi) * 2 + s) * 2) * 64 + lane;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) { w2p[base + (size_t)p * 64] = u32x4{f[p][0], f[p][1], f[p][2], f[p][3]}; w2tp[base + (size_t)p * 64] = u32x4{b[p][0], b[p][1], b[p][2], b[p][3]}; }
+        for (int p = 0; p < 2; ++p) { w2p[base + (size_t)p * 64] = u32x4{f[p][0], f[p][1], f[p][2], f[p][3]}; w2tp[base + (size_t)p * 64] = u32x4{b[p][0], b[p][1], b[p][2], b[p][3]}; w2pf[base + (size_t)p * 64] = u32x4{g[p][0], g[p][1], g[p][2], g[p][3]}; }
     }
 }
 
@@ -1194,9 +1264,9 @@ hipError_t launch_fold_partials(const double* partials, int nblocks, double* out
     fold_partials_kernel<<<1, 256, 0, s>>>(partials, nblocks, out16);
     return hipGetLastError();
 }
-hipError_t launch_build_wimg_split(const float* params, NetOff off, int H, void* w2p, void* w2tp, hipStream_t s) {
+hipError_t launch_build_wimg_split(const float* params, NetOff off, int H, void* w2p, void* w2tp, void* w2pf, hipStream_t s) {
     const int total = (H / 32) * (H / 32) * 2 * 64;
-    build_wimg_split_kernel<<<(total + 255) / 256, 256, 0, s>>>(params, off, H, (u32x4*)w2p, (u32x4*)w2tp);
+    build_wimg_split_kernel<<<(total + 255) / 256, 256, 0, s>>>(params, off, H, (u32x4*)w2p, (u32x4*)w2tp, (u32x4*)w2pf);
     return hipGetLastError();
 }
 hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a, float* w2ta, hipStream_t s) {
