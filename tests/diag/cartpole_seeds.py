@@ -4,7 +4,8 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import __graft_entry__ as g
 pkg = g.load_package()
-n_envs, iters = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 30
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+n_envs = int(sys.argv[2]) if len(sys.argv) > 2 else 256      # 4096: minibatches of 131 072 samples = ppo_grad_pair_kernel (DRIL_GRAD_VARIANT=0: the exact-f32 kernel)
 out = []
 for seed in range(10):
     env = pkg.MonitorWrapperEnv(pkg.DeviceParallelEnv(pkg.CartPoleEnv(max_steps=500), n_envs, seed=seed), stats_window=100)
@@ -12,4 +13,4 @@ for seed in range(10):
     agent = pkg.Agent(pkg.ActorCriticLayer(env.observation_space(), env.action_space()), alg, seed=seed)
     pkg.train_(agent, env, alg, iters * alg.n_steps * n_envs)
     out.append(round(pkg.evaluate_agent(agent, env, n_eval_episodes=20)["mean_reward"], 1))
-print("final rewards over seeds 0..9:", out, "mean %.1f" % (sum(out) / len(out)))
+print("n_envs", n_envs, "final rewards over seeds 0..9:", out, "mean %.1f" % (sum(out) / len(out)))
