@@ -226,7 +226,7 @@ int wide_variant(const dril_handle* h) { return (h->wide && h->rec && (h->grad_v
 // minibatches of at least this many 32-sample tiles per CU run ppo_grad_pair_kernel (measured on the f16 arithmetic, 256 CUs: 65 536 samples 50.7 us against 64.8 us on the
 // exact-f32 kernel, 16 384 samples 42.2 against 39.0; with the bf16 x 3 arithmetic of rounds 2 - 3 the crossover was at 16 tiles per CU)
 constexpr int kPairTilesPerCu = 8;
-bool pair_variant(const dril_handle* h) { return !h->wide && !h->generic && h->grad_variant != 0 && h->rec && h->D <= 4; }   // (D > 4: 96 dW1 accumulators do not fit the pair kernel's 256 registers — the f32 kernel runs every size)
+bool pair_variant(const dril_handle* h) { return !h->wide && !h->generic && h->grad_variant != 0 && h->rec && h->D <= 8; }   // (D > 4, Acrobot: dW1 / db1 through a third piece image on the matrix cores — 16 (D + 1) per-lane accumulators would not fit)
 int ensure_wimg(dril_handle* h) {
     if (!h->wide || !h->wimg_dirty) return DRIL_OK;
     HIPCHK(h, launch_build_wimg(h->params, h->actor, h->cfg.hidden1, h->w2a_actor, h->w2ta_actor, h->stream));

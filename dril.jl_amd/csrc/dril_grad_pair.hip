@@ -25,11 +25,13 @@ namespace dril {
 // chunk ^ g(row), and stepping the chunk by a constant is an XOR of the whole address with that constant — one VALU per access, the image and piece offsets going into
 // the instruction's immediate, instead of xor / shift / add / add (round 3: - 60 VALU per wave and tile)
 template <int D, int O> struct PairLds {
-    static constexpr int H = 64, DP = 4, OP = (O + 3) / 4 * 4;
+    static constexpr int H = 64, DP = FirstLayer<D>::DP, OP = (O + 3) / 4 * 4;
+    static constexpr bool WIDE_IN = D > 4;                   // observations of 5 .. 8 components: dW1 / db1 on the matrix cores (below), four first-layer k-steps
     static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, W3B = W3S + O * H, B3 = W3B + O * H, SMALL_END = (B3 + OP + 127) / 128 * 128;   // W3S = W3 / kActScale (forward), W3B = W3 / kActScale^2 (dh)
     static constexpr int WIMG = SMALL_END;                    // two f16 pieces x [64 out][64 in] = 2 x 8192 bytes
     static constexpr int PAIR0 = WIMG + 2 * 2048;
-    static constexpr int P1 = 0, P2 = P1 + 2 * 1024, PO = P2 + 2 * 1024, PAIR_SIZE = (PO + 2 * O * 32 + 127) / 128 * 128;   // per pair: two 8 KB piece images, [2 waves][O][32] partial sums
+    // per pair: two 8 KB piece images (h1, dz2), [2 waves][O][32] partial sums; D > 4: a third piece image (dz1, 8 KB) and the observation image (two f16 pieces x [32 samples][32 columns])
+    static constexpr int P1 = 0, P2 = P1 + 2 * 1024, P3 = P2 + 2 * 1024, XI = P3 + (WIDE_IN ? 2 * 1024 : 0), PO = XI + (WIDE_IN ? 2 * 512 : 0), PAIR_SIZE = (PO + 2 * O * 32 + 127) / 128 * 128;
     static constexpr int END = PAIR0 + 2 * PAIR_SIZE;
     static_assert((4 * WIMG) % 512 == 0 && (4 * PAIR0) % 512 == 0 && (4 * PAIR_SIZE) % 512 == 0 && (4 * P2) % 512 == 0, "image bases must be multiples of 512 bytes");
 };
@@ -68,6 +70,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             *reinterpret_cast<unsigned*>(Wimg + byte) = hi; *reinterpret_cast<unsigned*>(Wimg + 8192 + byte) = lo;
         }
     }
+    if (L::WIDE_IN) { for (int i = tid; i < 2 * L::PAIR_SIZE; i += blockDim.x) { const int q = i % L::PAIR_SIZE; if (q >= L::XI && q < L::PO) smem[L::PAIR0 + i] = 0.f; } }
     __syncthreads();
 
     float adv_mean = 0.f, adv_den = 1.f;
@@ -94,14 +97,19 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     const float inv_sg = 1.0f / sg;
     GradArgs as = a; as.invB = a.invB * sg;                                            // what loss_head multiplies dLoss/dout with
     lds_char* lds = (lds_char*)smem;
-    constexpr int kWimgB = 4 * L::WIMG, kP1B = 4 * L::P1, kP2B = 4 * L::P2;
+    constexpr int kWimgB = 4 * L::WIMG, kP1B = 4 * L::P1, kP2B = 4 * L::P2, kP3B = 4 * L::P3;
+    constexpr int KS = FirstLayer<D>::KS;
+    constexpr bool WIDE_IN = L::WIDE_IN;
+    constexpr float kObsScale = 16.0f;                                                  // D > 4: the observation image holds 16 x (|x| < 4 000: Acrobot's largest component is 28.3)
     const int pairB = 4 * (L::PAIR0 + pr * L::PAIR_SIZE);                                                 // byte offset of this pair's block (wave-uniform)
     const int rowc = c * 128 + ((h ^ wimg_g<64>(c)) << 4);                                                // row c, chunk h of the row: row reads step the chunk by 2 ks
     const int rowP = pairB + rowc;                                                                        // ... in a pair image (B operand of L2 / dh1)
     const int rowW = rowc + 4096 * w;                                                                     // ... in the weight image, rows 32 w .. (A operand of L2)
     const int ownT = pairB + c * 128 + 8 * h + (((4 * w) ^ wimg_g<64>(c)) << 4);                          // the lane's own chunk 4 w + g of row c (pair_store_pieces)
 
-    f32x16 dW2[MT], dW3acc[O], db2acc, dW1acc[D], db1acc;            // dW2: rows 32w.., all 64 columns; the others: per-lane sums over this lane's samples (units rowfn(r, h) of m-tile w)
+    f32x16 dW2[MT], dW3acc[O], db2acc, dW1acc[WIDE_IN ? 1 : D], db1acc;   // dW2: rows 32w.., all 64 columns; the others: per-lane sums over this lane's samples (units rowfn(r, h) of m-tile w)
+    // D > 4: dW1acc[0] is an MFMA accumulator — rows = this wave's units, column n = observation component n (n < D) | the bias (n = D): dz1' x [x | 1] on the matrix cores,
+    // because 16 (D + 1) per-lane accumulators do not fit beside the others; db1acc is unused
     float db3p[O], dlsp[O], st[5];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { db2acc[r] = 0.f; db1acc[r] = 0.f; }
@@ -110,7 +118,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dW2[j][r] = 0.f;
 #pragma unroll
-    for (int d = 0; d < D; ++d)
+    for (int d = 0; d < (WIDE_IN ? 1 : D); ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dW1acc[d][r] = 0.f;
 #pragma unroll
@@ -128,7 +136,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     const int64_t ntiles = (a.count + kTile - 1) / kTile;
     const int64_t g0 = 2 * nb;
     const int64_t trips = g0 < ntiles ? (ntiles - g0 + GP - 1) / GP : 0;           // the same for both pairs of the workgroup (barriers inside the loop)
-    TileIn<O> cur, nxt;
+    TileIn<O, KS> cur, nxt;
     int64_t tile = g;
     load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);                        // a tile index past the end loads an all-invalid tile
 #ifdef DRIL_STAMPS
@@ -138,7 +146,26 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     for (int64_t it = 0; it < trips; ++it, tile += GP) {
         unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
         const bool valid = cur.valid;
-        const float xk[2] = {cur.xk[0], cur.xk[1]};
+        float xk[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xk[s] = cur.xk[s];
+        if (WIDE_IN && w == 0) {                                                        // the observation image of this tile: row c = 16 x [x_0 .. x_(D-1) | 1 | 0 ..] as two f16 pieces (columns 0-7 and 8-15)
+            unsigned xh[2][4], xl[2][4];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const unsigned u = __float_as_uint(xk[s]);
+                const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);       // {x[2 s], x[2 s + 1]} in every lane
+                const float a0 = 2 * s < D ? kObsScale * __uint_as_float(r[0]) : (2 * s == D ? kObsScale : 0.f), a1 = 2 * s + 1 < D ? kObsScale * __uint_as_float(r[1]) : (2 * s + 1 == D ? kObsScale : 0.f);
+                split2_pair(a0, a1, xh[0][s], xl[0][s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { const float a0 = 8 + 2 * s == D ? kObsScale : 0.f; split2_pair(a0, 0.f, xh[1][s], xl[1][s]); }   // column 8 = the bias column when D = 8
+            if (h == 0) {
+                const int xa = pairB + 4 * L::XI + c * 64;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) { pl_write(lds, xa + 16 * ch, u32x4{xh[ch][0], xh[ch][1], xh[ch][2], xh[ch][3]}); pl_write(lds, xa + 2048 + 16 * ch, u32x4{xl[ch][0], xl[ch][1], xl[ch][2], xl[ch][3]}); }
+            }
+        }
         // ---- h1 tile w; its pieces into the pair's image ----
         f32x16 h1k;                                                                   // kept across the tile where the registers allow it (the critic), rebuilt from the pieces elsewhere
         {
@@ -149,7 +176,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
                 h1w[4 * q + 0] = b[0]; h1w[4 * q + 1] = b[1]; h1w[4 * q + 2] = b[2]; h1w[4 * q + 3] = b[3];
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
+            for (int s = 0; s < KS; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
             tanh16_scaled<false>(h1w, 1.0f);                                              // kActScale h1
             pair_store_pieces2<kP1B>(lds, opaque(ownT), h1w);
             if (kKeepH1) h1k = h1w;
@@ -240,8 +267,8 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[r] = g1[r] * fmaf(-t2, c1, c0); }
         }
         STAMP(6);
-        // ---- dW1 | db1: per-lane accumulation, dW1[unit][d] += dz1[unit][sample] x[sample][d] ----
-        {
+        // ---- dW1 | db1: per-lane accumulation, dW1[unit][d] += dz1[unit][sample] x[sample][d] (D <= 4); D > 4: dz1' [x | 1] on the matrix cores ----
+        if constexpr (!WIDE_IN) {
             float x4[4];                                                               // xk[s] = x[2 s + h]: the lower half's value is x[2 s], the upper half's x[2 s + 1]
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -252,6 +279,21 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
 #pragma unroll
             for (int d = 0; d < D; ++d) fma16(dW1acc[d], x4[d], g1);
             add16(db1acc, g1);
+        } else {
+            // this wave's own 32 columns of the dz1 image (nobody else reads them: the LDS queue of the wave orders the reads behind the stores), transposed fragments of
+            // them as the A operand, of the observation image (complete since B1) as the B operand: (SG dz1)' (16 [x | 1])
+            pair_store_pieces2<kP3B>(lds, opaque(ownT), g1);
+            const int tbw = opaque(tbase) ^ (64 * w), tbw16 = tbw ^ 16;
+            const int kh = lane >> 5, gm = (lane >> 4) & 1, e = lane & 15, xq = e >> 2, xp = e & 3;
+            const int tx = (8 * kh + xq) * 64 + ((2 * gm + (xp >> 1)) << 4) + 8 * (xp & 1);   // wide_tr_base for 64-byte rows without a swizzle (4 KB read eight times per tile)
+            const char* P3 = reinterpret_cast<const char*>(pb + L::P3); const char* XI = reinterpret_cast<const char*>(pb + L::XI);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f16x8 Az[2], Bx[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) { Az[p] = __builtin_bit_cast(f16x8, load_frag_wide_T<64>(P3, tbw, tbw16, p, s)); Bx[p] = __builtin_bit_cast(f16x8, load_frag_wide_T<32>(XI, tx, tx, p, s)); }
+                dW1acc[0] = mfma_split3(Az[0], Az[1], Bx[0], Bx[1], dW1acc[0]);
+            }
         }
         // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the pair's images) ----
         {
@@ -299,10 +341,17 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {                                                    // per-lane sums over samples -> sum over the 32 lanes of each half (the halves hold different units)
         const int unit = 32 * w + rowfn(r, h);
-        const float b2 = half_sum(db2acc[r]) * inv_sg, b1 = half_sum(db1acc[r]) * inv_sg;
-        if (c == 0) { slab[o_b2 + unit] = b2; slab[o_b1 + unit] = b1; }
+        const float b2 = half_sum(db2acc[r]) * inv_sg;
+        if (c == 0) slab[o_b2 + unit] = b2;
+        if constexpr (!WIDE_IN) {
+            const float b1 = half_sum(db1acc[r]) * inv_sg;
+            if (c == 0) slab[o_b1 + unit] = b1;
 #pragma unroll
-        for (int d = 0; d < D; ++d) { const float v = half_sum(dW1acc[d][r]) * inv_sg; if (c == 0) slab[o_w1 + unit + d * H] = v; }
+            for (int d = 0; d < D; ++d) { const float v = half_sum(dW1acc[d][r]) * inv_sg; if (c == 0) slab[o_w1 + unit + d * H] = v; }
+        } else {                                                                      // column c of the MFMA accumulator: observation component c, or the bias
+            const float v = dW1acc[0][r] * (inv_sg * (1.0f / 16.0f));
+            if (c < D) slab[o_w1 + unit + c * H] = v; else if (c == D) slab[o_b1 + unit] = v;
+        }
 #pragma unroll
         for (int o = 0; o < O; ++o) { const float v = half_sum(dW3acc[o][r]) * inv_sa; if (c == 0) slab[o_w3 + o + unit * O] = v; }
     }
@@ -338,7 +387,7 @@ hipError_t launch_ppo_grad_pair(int kind, const GradArgs& a, hipStream_t s) {
 #define CALLP(K) { const size_t lds = grad_pair_lds_bytes<K>(); static bool attr_set = false; \
         if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_pair_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
         ppo_grad_pair_kernel<K><<<(a.G + a.Gc) / 2, 256, lds, s>>>(a); }
-    if (kind == 0) CALLP(0) else if (kind == 3) CALLP(3) else if (kind == 4) CALLP(4) else CALLP(1)
+    if (kind == 0) CALLP(0) else if (kind == 3) CALLP(3) else if (kind == 4) CALLP(4) else if (kind == 6) CALLP(6) else CALLP(1)
 #undef CALLP
     return hipGetLastError();
 }

@@ -208,7 +208,7 @@ def _batch(oracle, cfg, B, seed):
 
 @pytest.mark.parametrize("kind,B,variant", [(0, 64, "default"), (0, 33, "default"), (0, 4096, "ent_vfclip"), (0, 65536, "default"),
                                              (1, 64, "default"), (1, 1000, "ent_vfclip"), (0, 200, "no_norm"), (3, 500, "ent_vfclip"), (4, 129, "default"),
-                                             (6, 64, "default"), (6, 1001, "ent_vfclip"), (6, 131072 + 5, "default")])   # Acrobot (D = 6): three-quad records, the exact-f32 kernel for every size
+                                             (6, 64, "default"), (6, 1001, "ent_vfclip"), (6, 131072 + 5, "default")])   # Acrobot (D = 6): three-quad records; the exact-f32 kernel below 65 536 samples, ppo_grad_pair_kernel (dW1 on the matrix cores) above
 def test_ppo_loss_and_gradient(pkg, oracle_mod, kind, B, variant):
     """(alg::PPO)(...) ppo.jl:365-407 + gradient: loss within 1e-4 rel (north_star), gradient within fp32 noise"""
     kw = dict(n_envs=2, n_steps=2, batch_size=2)

@@ -50,6 +50,8 @@ EXPECTED = {64: "ppo_grad_pair_kernel", 128: "ppo_grad_wide_split_kernel", 256: 
     (0, 64, 262144 + 45, "ent_vfclip"),    # multi-trip loop with unequal actor / critic pair counts and a ragged last tile
     (1, 64, 262144, "default"),
     (3, 64, 131072 + 1, "default"),        # MountainCar: Categorical(3), D = 2
+    (6, 64, 131072 + 77, "ent_vfclip"),    # Acrobot: Categorical(3), D = 6 — four first-layer k-steps, three-quad records, dW1 / db1 through the dz1 image on the matrix cores
+    (6, 64, 65536, "default"),
     (1, 256, 32768, "default"),            # configs[2] shape: 8 tiles per workgroup of the chip-filling grid
     (0, 256, 16384 + 19, "ent_vfclip"),
     (0, 128, 32768, "default"),
