@@ -107,7 +107,7 @@ struct dril_handle {
     bool env_ready = false;
     unsigned long long* dbg = nullptr;
     bool force_allreduce = false, force_stepwise = false;
-    double *epoch_tables = nullptr, *epoch_stats = nullptr; int epoch_blocks = 512, epoch_nb_cap = 0;   // per-epoch advantage moments
+    double *epoch_tables = nullptr, *epoch_stats = nullptr; int epoch_blocks = 2048, epoch_nb_cap = 0;   // per-epoch advantage moments
     float *w2a_actor = nullptr, *w2ta_actor = nullptr, *w2a_critic = nullptr, *w2ta_critic = nullptr; bool wide = false, wimg_dirty = true;   // wide nets (H > 64)
     void *w2pf_actor = nullptr, *w2pf_critic = nullptr;   // wide nets: the forward stream in the k-order of a register B operand (net_forward_wide_split)
     void *w2p_actor = nullptr, *w2tp_actor = nullptr, *w2p_critic = nullptr, *w2tp_critic = nullptr;   // wide nets: pre-split bf16 fragment streams of W2 / W2' (ppo_grad_wide_split_kernel)
@@ -527,6 +527,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     h->no_persistent = std::getenv("DRIL_NO_PERSISTENT_UPDATE") != nullptr; { const char* e = std::getenv("DRIL_NO_EPOCH_INDEX"); h->no_epoch_index = e && std::atoi(e) != 0; }
     if (const char* e = std::getenv("DRIL_SMALL_CHUNK")) { const long c = std::atol(e); if (c > 0) h->small_chunk = c; }   // optimiser steps per launch of ppo_update_small_kernel (tests: launch boundaries)
     h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
+    if (const char* e = std::getenv("DRIL_MOMENT_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8192) h->epoch_blocks = v; }
     // Multi-process RCCL on this platform needs dmabuf IPC: with the legacy IPC mode (the ROCr default) `hipIpcGetMemHandle` fails with "invalid argument" on a
     // host driver that only supports dmabuf, and ncclCommInitRank / the first collective across processes dies with it.  The ROCr runtime reads the variable
     // when it initialises, i.e. at this process's first HIP call — which for a DRiL user is normally the hipSetDevice below.  It is only set if the caller left it
@@ -1028,7 +1029,7 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
     int64_t step = 0;
     // the reference's default PPO() (batch_size = 64) on hidden [64,64]: every optimiser step of the iteration inside ONE launch of two persistent workgroups, one per net (dril_update_small.hip);
     // single-rank only (a data-parallel run all-reduces between the gradient and the step)
-    const bool persistent = !h->wide && !h->generic && h->D <= 4 && world == 1 && !(comm_ready(h) && h->force_allreduce) && h->rec && B >= 2 && B <= 64 && h->P <= 512 * 18 &&
+    const bool persistent = !h->wide && !h->generic && h->D <= 8 && world == 1 && !(comm_ready(h) && h->force_allreduce) && h->rec && B >= 2 && B <= 64 && h->P <= 2 * 256 * 19 &&
                             !h->no_persistent && !h->no_small_path && h->grad_variant < 0 && total_steps > 0;   // (DRIL_GRAD_VARIANT pins one of the per-step kernels)
     if (persistent) {
         if (h->cfg.epochs > h->epoch_keys_cap) {
@@ -1095,7 +1096,8 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
                 h->epoch_nb_cap = (int)nb;
             }
             prof_begin(h, DRIL_K_ADV_MOMENTS);
-            HIPCHK(h, launch_epoch_moments(h->adv, N, B, (int)nb, key, bits, h->epoch_tables, h->epoch_blocks, h->epoch_stats, h->stop_flag, h->stream));
+            const int eb = (int)std::min<int64_t>(h->epoch_blocks, std::max<int64_t>(64, N / 8192));       // eight waves per SIMD at chip-filling sizes: the pass is one dependent chain per sample
+            HIPCHK(h, launch_epoch_moments(h->adv, N, B, (int)nb, key, bits, h->epoch_tables, eb, h->epoch_stats, h->stop_flag, h->stream));
             prof_end(h);
             if (world > 1 || (comm_ready(h) && h->force_allreduce)) {     // ONE all-reduce per epoch for the advantage moments of all its minibatches
                 int rca = rccl_allreduce(h, h->epoch_stats, (size_t)3 * nb, kNcclFloat64); if (rca) return rca;

@@ -960,33 +960,76 @@ __global__ void adv_moments_kernel(MomentsArgs a) {
 // (v1-v4 gathered adv[perm(p)] per optimiser step: 32 x 85 us of random 4-byte reads per epoch).  Each index is mapped back
 // to its position in the epoch order by the inverse bijection, binned by minibatch in LDS (ds_add_f64), one partial
 // table per block; epoch_moments_finalize_kernel folds the blocks in a fixed order.
-__global__ void epoch_moments_kernel(const float* __restrict__ adv, int64_t N, int64_t B, int nb, uint64_t key, int bits,
+// Round 3, end: per sample the pass costs the inverse bijection (eight v_mul_lo_u32), the minibatch of its position and two LDS adds.  Two things were slow (806 us
+// per epoch at configs[1], 134 M samples): the 64-bit `p / B` (an emulated division, more instructions than the bijection) and two waves per SIMD for a loop whose
+// iterations are one dependent chain.  Now: every size the 32-bit bijection covers (bits <= 31) divides by a reciprocal (double, one correction step: exact), the
+// xorshift inverses are two shifts without a loop, and the grid is 2 048 blocks; the bins are replicated R times (copy = lane % R; a copy is nb + 1 slots of 16
+// bytes) — measured to matter little (equal-address adds are not what the loop waits for) and kept for small nb.
+template <bool FAST32>
+__global__ void epoch_moments_kernel(const float* __restrict__ adv, int64_t N, int64_t B, double inv_b, int nb, int R, uint64_t key, int bits,
                                      double* __restrict__ block_tables, const int* stop_flag) {
-    extern __shared__ double bins[];     // [nb][2]
+    extern __shared__ double bins[];     // [R][nb + 1][2]
     if (*stop_flag) return;
-    for (int i = threadIdx.x; i < 2 * nb; i += blockDim.x) bins[i] = 0.0;
+    const int pitch = 2 * (nb + 1);
+    for (int i = threadIdx.x; i < R * pitch; i += blockDim.x) bins[i] = 0.0;
     __syncthreads();
+    double* mine = bins + (threadIdx.x % R) * pitch;
     const int64_t per = (N + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < N ? lo + per : N;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const double x = adv[i];
-        const int64_t p = perm_position(i, N, key, bits);
-        const int k = (int)((uint64_t)p / (uint64_t)B);
-        atomicAdd(&bins[2 * k], x); atomicAdd(&bins[2 * k + 1], x * x);
+    if (FAST32) {                                                    // bits <= 31: positions, indices and B fit 31 bits
+        const uint32_t mask = (1u << bits) - 1u, n32 = (uint32_t)N, b32 = (uint32_t)B;
+        const int s = bits / 2 > 0 ? bits / 2 : 1, s2 = s + 1 < bits ? s + 1 : s;
+        const int ss = 2 * s < 31 ? 2 * s : 31, ss2 = 2 * s2 < 31 ? 2 * s2 : 31;     // x < 2^31: a shift by 31 gives the 0 the loop of unxorshift32 stops at
+        constexpr uint32_t I1 = (uint32_t)mul_inverse(0x9E3779B97F4A7C15ull), I2 = (uint32_t)mul_inverse(0xBF58476D1CE4E5B9ull);
+        uint32_t kr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kr[r] = (uint32_t)(key >> (r * 13)) & mask;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const double x = adv[i];
+            uint32_t p = (uint32_t)i;
+            do {                                                     // mix_bij_inv32 (dril_device.h) with the shift loops written out; cycle walking backwards
+#pragma unroll
+                for (int r = 3; r >= 0; --r) {
+                    p = p ^ (p >> s2) ^ (p >> ss2);
+                    p = (p * I2) & mask;
+                    p = p ^ (p >> s) ^ (p >> ss);
+                    p = ((p - 0xD192ED03u) * I1) & mask;
+                    p ^= kr[r];
+                }
+            } while (p >= n32);
+            uint32_t k = (uint32_t)((double)p * inv_b);              // p / B: off by at most one
+            const uint32_t kb = k * b32;
+            if (kb > p) --k; else if (p - kb >= b32) ++k;
+            atomicAdd(&mine[2 * k], x); atomicAdd(&mine[2 * k + 1], x * x);
+        }
+    } else {
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const double x = adv[i];
+            const int64_t p = perm_position(i, N, key, bits);
+            const int k = (int)((uint64_t)p / (uint64_t)B);
+            atomicAdd(&mine[2 * k], x); atomicAdd(&mine[2 * k + 1], x * x);
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * nb; i += blockDim.x) block_tables[(size_t)blockIdx.x * 2 * nb + i] = bins[i];
+    for (int i = threadIdx.x; i < 2 * nb; i += blockDim.x) {
+        double v = 0.0;
+        for (int r = 0; r < R; ++r) v += bins[r * pitch + i];
+        block_tables[(size_t)blockIdx.x * 2 * nb + i] = v;
+    }
 }
+// one wave per minibatch: lane l folds blocks l, l + 64, ... in order, then the 64 lanes in a fixed tree
 __global__ void epoch_moments_finalize_kernel(const double* __restrict__ block_tables, int nblocks, int nb, int64_t N, int64_t B,
                                               double* __restrict__ table3, const int* stop_flag) {
     if (*stop_flag) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nb) return;
+    const int i = blockIdx.x, lane = threadIdx.x;
     double s = 0, q = 0;
-#pragma unroll 8
-    for (int b = 0; b < nblocks; ++b) { s += block_tables[(size_t)b * 2 * nb + 2 * i]; q += block_tables[(size_t)b * 2 * nb + 2 * i + 1]; }   // unrolled: 16 independent loads in flight
-    const int64_t pos0 = (int64_t)i * B;
-    table3[3 * i] = s; table3[3 * i + 1] = q; table3[3 * i + 2] = (double)(pos0 + B <= N ? B : N - pos0);
+    for (int b = lane; b < nblocks; b += 64) { s += block_tables[(size_t)b * 2 * nb + 2 * i]; q += block_tables[(size_t)b * 2 * nb + 2 * i + 1]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m); q += __shfl_xor(q, m); }
+    if (lane == 0) {
+        const int64_t pos0 = (int64_t)i * B;
+        table3[3 * i] = s; table3[3 * i + 1] = q; table3[3 * i + 2] = (double)(pos0 + B <= N ? B : N - pos0);
+    }
 }
 
 __global__ void moments_finalize_kernel(const double* partials, int nblocks, double* out3, double n_local, const int* stop_flag) {
@@ -1402,8 +1445,12 @@ hipError_t launch_adv_moments(const MomentsArgs& a, int nblocks, hipStream_t s) 
 }
 hipError_t launch_epoch_moments(const float* adv, int64_t N, int64_t B, int nb, uint64_t key, int bits, double* block_tables, int nblocks,
                                 double* table3, const int* stop_flag, hipStream_t s) {
-    epoch_moments_kernel<<<nblocks, 256, (size_t)2 * nb * sizeof(double), s>>>(adv, N, B, nb, key, bits, block_tables, stop_flag);
-    epoch_moments_finalize_kernel<<<(nb + 63) / 64, 64, 0, s>>>(block_tables, nblocks, nb, N, B, table3, stop_flag);
+    int R = 16;
+    while (R > 1 && (size_t)R * 2 * (nb + 1) * sizeof(double) > 32768) R >>= 1;          // nb <= 2048 (dril_api.hip): one copy is at most 32 KB
+    const size_t lds = (size_t)R * 2 * (nb + 1) * sizeof(double);
+    if (bits <= 31) epoch_moments_kernel<true><<<nblocks, 256, lds, s>>>(adv, N, B, 1.0 / (double)B, nb, R, key, bits, block_tables, stop_flag);
+    else epoch_moments_kernel<false><<<nblocks, 256, lds, s>>>(adv, N, B, 0.0, nb, R, key, bits, block_tables, stop_flag);
+    epoch_moments_finalize_kernel<<<nb, 64, 0, s>>>(block_tables, nblocks, nb, N, B, table3, stop_flag);
     return hipGetLastError();
 }
 hipError_t launch_moments_finalize(const double* partials, int nblocks, double* out3, double n_local, const int* stop_flag, hipStream_t s) {

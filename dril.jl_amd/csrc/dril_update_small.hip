@@ -22,7 +22,7 @@ namespace dril {
 
 // one net's weights in LDS (floats), rewritten from the owners' registers every optimiser step; the weight image starts at a multiple of 512 bytes (XOR addressing)
 template <int D, int O> struct SmallNet {
-    static constexpr int H = 64, DP = 4, OP = (O + 3) / 4 * 4;
+    static constexpr int H = 64, DP = FirstLayer<D>::DP, OP = (O + 3) / 4 * 4;   // observations of 5 .. 8 components (Acrobot): four first-layer k-steps, eight rows of W1'
     static constexpr int W1T = 0, B1 = W1T + DP * H, B2 = B1 + H, W3S = B2 + H, W3B = W3S + O * H, B3 = W3B + O * H, LS = (B3 + OP + 3) / 4 * 4;   // W3S = W3 / kActScale (forward), W3B = W3 / kActScale^2 (dh); LS: log_std copy (actor, continuous heads)
     static constexpr int WIMG = (LS + 4 + 127) / 128 * 128, END = WIMG + 2 * 2048;                                                // two f16 pieces x [64 out][64 in]
 };
@@ -52,8 +52,8 @@ __device__ __forceinline__ f16x8 small_frag_W_T(const char* wimg, int tmk, int t
 #define SMALL_STAMP_ARGS
 #endif
 template <int KIND, int O, int HEAD>
-__device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, float* pb, int pairB, TileIn<O>& cur, const float* mom, int normalize_adv, const float* ls, int lane, int w, float inv_sg SMALL_STAMP_PARAMS) {   // ga.invB carries the gradient scale SG (dril_device.h: f16 pieces), inv_sg = 1 / SG
-    constexpr int D = EnvSpec<KIND>::D, H = 64, MT = 2;
+__device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, float* pb, int pairB, TileIn<O, FirstLayer<EnvSpec<KIND>::D>::KS>& cur, const float* mom, int normalize_adv, const float* ls, int lane, int w, float inv_sg SMALL_STAMP_PARAMS) {   // ga.invB carries the gradient scale SG (dril_device.h: f16 pieces), inv_sg = 1 / SG
+    constexpr int D = EnvSpec<KIND>::D, H = 64, MT = 2, KS = FirstLayer<D>::KS;
     constexpr float kInvTanhScale = 1.0f / kTanhScale;
     using L = SmallNet<D, O>; using S = SmallPair<D, O>;
     constexpr int kWimgB = 4 * L::WIMG, kP1B = 4 * S::P1, kP2B = 4 * S::P2;
@@ -70,7 +70,9 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
     const int runit = 32 * w + rowfn(lane & 15, h);                                      // ... of the unit that register (lane & 15) of this half belongs to
     unpack_tile<KIND, O, HEAD, true>(ga, h, cur);
     const bool valid = cur.valid;
-    const float xk[2] = {cur.xk[0], cur.xk[1]};
+    float xk[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xk[s] = cur.xk[s];
     const float inv_sa = inv_sg * (1.0f / kActScale);                                    // products with an activation operand carry SG kActScale, the others SG
     // ---- h1 tile w; its pieces into the pair's image ----
     f32x16 h1k;
@@ -81,7 +83,7 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
             h1k[4 * q + 0] = b[0]; h1k[4 * q + 1] = b[1]; h1k[4 * q + 2] = b[2]; h1k[4 * q + 3] = b[3];
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) h1k = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1k);
+        for (int s = 0; s < KS; ++s) h1k = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1k);
         tanh16_scaled<false>(h1k, 1.0f);                                              // kActScale h1
         pair_store_pieces2<kP1B>(lds, ownT, h1k);
     }
@@ -205,9 +207,9 @@ __device__ __forceinline__ void small_tile(const GradArgs& ga, float* smem, floa
         for (int r = 0; r < 16; ++r) { const float t2 = h1k[r] * h1k[r]; g1[r] = g1[r] * fmaf(-t2, c1, c0); }
     }
     {   // db1 and dW1: per-lane products summed over the samples
-        float x4[4];                                                                  // xk[s] = x[2 s + h]: the lower half's value is x[2 s], the upper half's x[2 s + 1]
+        float x4[2 * KS];                                                             // xk[s] = x[2 s + h]: the lower half's value is x[2 s], the upper half's x[2 s + 1]
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < KS; ++s) {
             const unsigned u = __float_as_uint(xk[s]);
             const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
             x4[2 * s] = __uint_as_float(r[0]); x4[2 * s + 1] = __uint_as_float(r[1]);
@@ -384,17 +386,19 @@ __device__ __forceinline__ void small_net_loop(const SmallUpdateArgs& a, float* 
         return a.perm ? a.perm[(int64_t)ep * a.N + pos] : perm_index(pos, a.N, a.keys[ep], a.perm_bits);
     };
     auto count_of = [&](int s) -> int64_t { const int ep = s / a.nb, k = s - ep * a.nb; const int64_t pos0 = (int64_t)k * a.B; return (pos0 + a.B <= a.N) ? a.B : a.N - pos0; };
-    float4 raw_n = make_float4(0.f, 0.f, 0.f, 0.f); float vold_n = 0.f, adv_n = 0.f; bool valid_n = false;
+    constexpr int RS = RecLayout<D>::RS;
+    float4 raw_n = make_float4(0.f, 0.f, 0.f, 0.f), raw2_n = raw_n; float vold_n = 0.f, adv_n = 0.f; bool valid_n = false;
     auto gather = [&](int s) {
         const int ep = s / a.nb, k = s - ep * a.nb;
         const int64_t pos0 = (int64_t)k * a.B, count = (pos0 + a.B <= a.N) ? a.B : a.N - pos0;
         const int i = 32 * pr + c;
         valid_n = i < count;
         const int64_t idx = sample_index(ep, pos0 + (valid_n ? i : 0));
-        raw_n = a.rec[2 * idx + h];
+        raw_n = a.rec[RS * idx + h];
+        if (RS == 3) raw2_n = a.rec[RS * idx + 2];                                      // three-quad records (D > 4): the scalar quad, every lane
         vold_n = (ROLE == 1 && a.has_clip_vf) ? a.val_old[idx] : 0.f;
         adv_n = 0.f;
-        if (ROLE == 1 && a.normalize_adv && lane < count) adv_n = a.rec[2 * sample_index(ep, pos0 + lane) + 1].y;
+        if (ROLE == 1 && a.normalize_adv && lane < count) adv_n = a.rec[RS * sample_index(ep, pos0 + lane) + RS - 1].y;
     };
     // normalize!(advantages) per minibatch, ppo.jl:350-356 (corrected std + 1e-8): the critic's first wave, from the advantages it gathered for minibatch s
     auto moments_into = [&](int s, float* dst) {
@@ -430,7 +434,7 @@ __device__ __forceinline__ void small_net_loop(const SmallUpdateArgs& a, float* 
         const float sg = __uint_as_float((((__float_as_uint((float)count) >> 23) & 0xffu) + 3u) << 23), inv_sg = 1.0f / sg;   // gradient tiles are split as SG dz2, SG = 4 ... 8 x count, a power of two
         ga.invB = invB * sg;                                                          // what loss_head multiplies dLoss/dout with
         // ---- this step's inputs out of the prefetch registers; the next step's gathers go out now and land under this step's arithmetic ----
-        const float4 raw = raw_n; const float vold = vold_n; const bool valid = valid_n;
+        const float4 raw = raw_n, raw2 = raw2_n; const float vold = vold_n; const bool valid = valid_n;
         if (s + 1 < s_end) gather(s + 1);
         float lsr[kLsMax];
 #pragma unroll
@@ -442,7 +446,7 @@ __device__ __forceinline__ void small_net_loop(const SmallUpdateArgs& a, float* 
         }
         STAMP(0);
         {
-            TileIn<O> cur; cur.raw = raw; cur.valid = valid; cur.s0 = 0.f; cur.s1 = ROLE == 1 ? vold : 0.f; cur.act = 0;
+            TileIn<O, FirstLayer<D>::KS> cur; cur.raw = raw; cur.raw2 = raw2; cur.valid = valid; cur.s0 = 0.f; cur.s1 = ROLE == 1 ? vold : 0.f; cur.act = 0;
             small_tile<KIND, O, HEAD>(ga, smem, pb, pairB, cur, mom, ROLE == 0 ? a.normalize_adv : 0, lsr, lane, w, inv_sg SMALL_STAMP_ARGS);
         }
         STAMP(9);
@@ -570,7 +574,7 @@ hipError_t launch_ppo_update_small(int kind, const SmallUpdateArgs& a, hipStream
 #define CALLU(K) { const size_t lds = update_small_lds_bytes<K>(); static bool attr_set = false; \
         if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_update_small_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
         ppo_update_small_kernel<K><<<a.debug_solo ? 1 : kSmallGrid, 256, lds, s>>>(a); }
-    if (kind == 0) CALLU(0) else if (kind == 3) CALLU(3) else if (kind == 4) CALLU(4) else CALLU(1)
+    if (kind == 0) CALLU(0) else if (kind == 3) CALLU(3) else if (kind == 4) CALLU(4) else if (kind == 6) CALLU(6) else CALLU(1)
 #undef CALLU
     return hipGetLastError();
 }

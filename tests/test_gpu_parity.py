@@ -299,6 +299,46 @@ def test_ppo_update_matches_oracle(pkg, oracle_mod, kind, E, T, B, kw):
         assert e.value.code == capi.ERR_NAN_IN_GRADS
 
 
+@pytest.mark.parametrize("E,T,B", [(24, 37, 100), (100, 77, 1111), (64, 32, 256), (3, 683, 100), (4096, 32, 16384)])
+def test_epoch_moment_table_equals_the_per_step_moments(pkg, oracle_mod, E, T, B):
+    """the advantage moments of all minibatches of an epoch from ONE sequential pass (epoch_moments_kernel: inverse bijection with cycle walking, position / B by a
+    reciprocal, replicated LDS bins) against the per-step route (the same order injected as an index array => adv_moments_kernel gathers per minibatch): buffer sizes
+    that are not powers of two, a partial last minibatch, 2 049 samples (12 bits, 2 047 rejected positions), a chip-filling size.  Same f32 kernels on both routes, the moments are f64 sums: the two
+    updates agree to the last bits of f32"""
+    capi = pkg._capi
+    cfg = _cfg(pkg, 0, n_envs=E, n_steps=T, batch_size=B, epochs=2, episode_len=11, seed=9)
+    a, b, o = pkg.Handle(cfg), pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(a.P, 5, 0.3)
+    o.set_params(flat); o.env_reset(5); o.collect_rollout()
+    for h in (a, b):
+        h.set_params(flat)
+        for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+            h.set_buffer(which, o.buffer(which))
+    N, L = E * T, oracle_mod.lib()
+    if N <= 10000:
+        perm = np.asarray([[L.orc_perm_index(p, N, L.orc_perm_key(cfg.seed, 0, ep)) for p in range(N)] for ep in range(cfg.epochs)], np.int64)
+    else:                                                     # the bijection vectorised (dril_device.h mix_bij32; bits = 17 here, no rejected positions when N is a power of two)
+        assert N & (N - 1) == 0
+        bits = N.bit_length() - 1; mask = np.uint64(N - 1); sh = bits // 2; rows = []
+        for ep in range(cfg.epochs):
+            key = L.orc_perm_key(cfg.seed, 0, ep); x = np.arange(N, dtype=np.uint64)
+            for r in range(4):
+                x ^= np.uint64((key >> (13 * r)) & (N - 1))
+                x = (x * np.uint64(0x7F4A7C15) + np.uint64(0xD192ED03)) & mask; x ^= x >> np.uint64(sh)
+                x = (x * np.uint64(0x1CE4E5B9)) & mask; x ^= x >> np.uint64(sh + 1 if sh + 1 < bits else sh)
+            rows.append(x.astype(np.int64))
+        perm = np.stack(rows)
+        assert [L.orc_perm_index(p, N, L.orc_perm_key(cfg.seed, 0, 1)) for p in (0, 1, N - 1)] == [int(perm[1][p]) for p in (0, 1, N - 1)]
+    assert all(np.array_equal(np.sort(row), np.arange(N)) for row in perm)
+    b.set_permutation(perm)
+    sa, sb = a.ppo_update(), b.ppo_update()
+    assert sa.n_updates == sb.n_updates == cfg.epochs * -(-N // B)
+    for f in ("policy_loss", "value_loss", "entropy_loss", "approx_kl_div", "clip_fraction", "loss", "grad_norm"):
+        assert getattr(sa, f) == pytest.approx(getattr(sb, f), rel=2e-6, abs=1e-8), f
+    np.testing.assert_allclose(a.get_params(), b.get_params(), rtol=2e-6, atol=1e-8)
+    assert not np.array_equal(a.get_params(), flat)
+
+
 def test_device_permutation_matches_oracle_and_train_end_to_end(pkg, oracle_mod):
     """train! (ppo.jl:100-325) for 3 iterations with the device-generated DataLoader order and Philox sampling:
     the oracle draws the same streams, so parameters and learn_stats agree to fp32 noise on a small problem"""
@@ -987,6 +1027,8 @@ def test_forced_pair_kernel_on_small_minibatches(pkg, oracle_mod, monkeypatch, B
     (1, 8, 16, 20, {"ent_coef": 0.01}),                                                # DiagGaussian: the log_std parameter and its staged copy
     (3, 10, 13, 50, {}),                                                               # N = 130: a ragged last minibatch of 30
     (0, 4, 1024, 2, {"epochs": 5}),                                                    # 10 240 optimiser steps of 2 samples
+    (6, 12, 20, 64, {"ent_coef": 0.01}),                                               # Acrobot-v1 (D = 6): four first-layer k-steps, three-quad records, 9 476 parameters
+    (6, 7, 19, 40, {"has_clip_range_vf": 1, "clip_range_vf": 0.2}),                    # ... ragged: 133 samples = 3 x 40 + 13, eight valid lanes in the second pair's tile
 ])
 def test_persistent_small_update_matches_oracle(pkg, oracle_mod, monkeypatch, kind, E, T, B, kw):
     """ppo_update_small_kernel (batch_size <= 64: the reference's default PPO()): all optimiser steps of an iteration in one persistent workgroup, against the oracle
