@@ -233,8 +233,10 @@ __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
 }
 __device__ __forceinline__ void split2_pair(float a, float b, unsigned& hi, unsigned& lo) {
     hi = cvt_pk_f16(a, b);
-    const f16x2_t h = __builtin_bit_cast(f16x2_t, hi);
-    lo = cvt_pk_f16(a - (float)h[0], b - (float)h[1]);                                            // exact remainders (Sterbenz), rounded once
+    float ra, rb;                                                                                 // x - (float)hi.half in ONE instruction (left to itself the compiler picks the mixed form for about half of them and v_cvt_f32_f16 + v_sub for the rest)
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hi), "v"(b));
+    lo = cvt_pk_f16(ra, rb);                                                                      // exact remainders (Sterbenz), rounded once
 }
 __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 // one k16 step of the two-piece product, small terms first.  -DDRIL_DEBUG_DROP_LO (negative control): hi.hi only, an 11-bit product

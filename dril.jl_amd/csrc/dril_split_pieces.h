@@ -24,6 +24,12 @@ template <int IMG> __device__ __forceinline__ void pair_store_pieces2(lds_char* 
         pl_write(lds, a + IMG, u32x2{hi[0], hi[1]}); pl_write(lds, a + IMG + 4096, u32x2{lo[0], lo[1]});
     }
 }
+// (float)hi.half + (float)lo.half of two packed f16 pairs in ONE instruction per element: v_fma_mix_f32 takes f16 sources from either half of a register (the compiler
+// emits two v_cvt_f32_f16 and an add — 48 instead of 16 vector instructions per 16-register tile; it has no pattern from `fpext + fpext` to the mixed form)
+__device__ __forceinline__ void pieces_sum2(unsigned hk, unsigned lk, float& x0, float& x1) {
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(x0) : "v"(hk), "v"(lk));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x1) : "v"(hk), "v"(lk));
+}
 template <int IMG> __device__ __forceinline__ void pair_load_pieces2(const lds_char* lds, int t, f32x16& x) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -32,8 +38,8 @@ template <int IMG> __device__ __forceinline__ void pair_load_pieces2(const lds_c
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const unsigned hk = k ? hi.y : hi.x, lk = k ? lo.y : lo.x;                         // (NOT __builtin_bit_cast(f16x2_t, hi[k]): hipcc 7.2 folds that to element 0 for every k)
-            const f16x2_t h = __builtin_bit_cast(f16x2_t, hk), l = __builtin_bit_cast(f16x2_t, lk);
-            x[4 * g + 2 * k] = (float)h[0] + (float)l[0]; x[4 * g + 2 * k + 1] = (float)h[1] + (float)l[1];     // the value that was split, to 2^-24 relative
+            float x0, x1; pieces_sum2(hk, lk, x0, x1);                                         // the value that was split, to 2^-24 relative
+            x[4 * g + 2 * k] = x0; x[4 * g + 2 * k + 1] = x1;
         }
     }
 }
@@ -67,8 +73,8 @@ __device__ __forceinline__ void load_tile_pieces2(const char* pimg, int w, f32x1
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const unsigned hk = k ? hi.y : hi.x, lk = k ? lo.y : lo.x;                         // (not __builtin_bit_cast(f16x2_t, hi[k]): see pair_load_pieces2)
-            const f16x2_t hh = __builtin_bit_cast(f16x2_t, hk), ll = __builtin_bit_cast(f16x2_t, lk);
-            x[4 * g + 2 * k] = (float)hh[0] + (float)ll[0]; x[4 * g + 2 * k + 1] = (float)hh[1] + (float)ll[1];
+            float x0, x1; pieces_sum2(hk, lk, x0, x1);
+            x[4 * g + 2 * k] = x0; x[4 * g + 2 * k + 1] = x1;
         }
     }
 }
