@@ -623,6 +623,63 @@ __global__ void sac_push_kernel(PushArgs g) {
     for (int a = 0; a < g.A; ++a) g.rb_act[slot * g.A + a] = g.raw[e * g.A + a];               // unprocessed action, :72
     g.rb_rew[slot] = g.rew[e]; g.rb_term[slot] = g.term[e]; g.rb_trunc[slot] = g.trunc[e];
 }
+// One env step of the collection for a DEVICE env in ONE launch: sac_collect_head_kernel -> env_step_kernel -> env_observe_kernel -> sac_push_kernel are all one thread per env
+// on data of that env only (four dependent launches of 4 - 5 us and their boundaries per collected step).  Same device functions, same order of operations, and every
+// intermediate buffer (e_raw, e_envact, e_rew, e_term, e_trunc, e_tobs, obs_nxt) still written: bit-identical to the four-launch sequence (A = 1: every device Box env).
+struct CollectEnvArgs { CollectHeadArgs head; PushArgs push; uint64_t seed0; int episode_len; float* state; int32_t* step_count; uint32_t* episode; uint32_t* gstep;
+                        float* rew; uint8_t* term; uint8_t* trunc; float* tobs; float* nobs; };
+template <int KIND>
+__global__ void sac_collect_env_kernel(CollectEnvArgs c) {
+    constexpr int S = EnvSpec<KIND>::S, D = EnvSpec<KIND>::D;
+    const CollectHeadArgs& g = c.head;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= g.E) return;
+    // ---- the action (sac_collect_head_kernel, A = 1) ----
+    float z;
+    if (g.inj_noise) z = g.inj_noise[e];
+    else {
+        uint32_t o[4]; const uint64_t k = g.seed0 + (uint64_t)e;
+        philox4x32_10((uint32_t)k, (uint32_t)(k >> 32), c.gstep[e], 0u, 1u, 0u, o);
+        z = g.use_random ? u01_f32(o[0]) : randn_f32(o[0], o[1]);
+    }
+    float r, ev;
+    if (g.use_random) { r = g.low + z * (g.high - g.low); ev = r; }
+    else {
+        r = tanhf(g.mu[e] + expf(g.log_std[0]) * z);
+        ev = tanhf(r) * (g.high - g.low) / 2.0f + (g.low + g.high) / 2.0f;
+    }
+    g.raw[e] = r; g.envact[e] = ev;
+    // ---- act! with auto-reset (env_step_kernel) ----
+    float st[S];
+#pragma unroll
+    for (int i = 0; i < S; ++i) st[i] = c.state[(size_t)e * S + i];
+    bool t;
+    const float rw = env_step<KIND>(st, ev, 0, false, &t);
+    const int sc = c.step_count[e] + 1;
+    const bool tr = sc >= c.episode_len;
+    c.rew[e] = rw; c.term[e] = t; c.trunc[e] = tr; c.gstep[e] += 1;
+    float to[D];
+    env_obs<KIND>(st, to);                                                              // terminal_observation (stored where truncated)
+    if (tr) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) c.tobs[(size_t)e * D + i] = to[i];
+    }
+    if (t || tr) { const uint32_t ep = c.episode[e] + 1; c.episode[e] = ep; c.step_count[e] = 0; env_reset<KIND>(c.seed0 + (uint64_t)e, ep, st); }
+    else c.step_count[e] = sc;
+#pragma unroll
+    for (int i = 0; i < S; ++i) c.state[(size_t)e * S + i] = st[i];
+    // ---- observe (env_observe_kernel) ----
+    float no[D];
+    env_obs<KIND>(st, no);
+#pragma unroll
+    for (int i = 0; i < D; ++i) c.nobs[(size_t)e * D + i] = no[i];
+    // ---- push! (sac_push_kernel) ----
+    const PushArgs& q = c.push;
+    const long long slot = (q.tail + e) % q.cap;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { q.rb_obs[slot * D + d] = q.obs[(size_t)e * D + d]; q.rb_next[slot * D + d] = tr ? to[d] : no[d]; }
+    q.rb_act[slot] = r; q.rb_rew[slot] = rw; q.rb_term[slot] = t; q.rb_trunc[slot] = tr;
+}
 // host-batch helpers
 __global__ void sac_squash_eval_kernel(int B, int A, const float* mu, const float* log_std, const float* noise, int deterministic, float low, float high,
                                        float* actions, float* logp, float* envact) {
@@ -886,6 +943,22 @@ int collect_step(dril_sac_handle* h, int use_random, const float* inj_noise) {
     const int E = h->cfg.n_envs, D = h->D, A = h->A;
     if (!use_random) SDO(net_forward(h, h->params, h->actor, 0, D, A, h->obs_cur, D, 0, E, actor_bufs(h), 1));          // predict_actions_raw :55
     CollectHeadArgs ca{E, A, use_random, h->mu, h->params + h->log_std_off, inj_noise, h->gstep, h->env_seed0, h->act_lo, h->act_hi, h->e_raw, h->e_envact};
+    static const bool no_fused_collect = std::getenv("DRIL_SAC_NO_FUSED_COLLECT") != nullptr;
+    if (A == 1 && !h->external && !no_fused_collect) {                                                            // every device Box env: head + act! + observe + push! in one launch
+        const long long tail1 = (h->head + h->size) % h->cap;
+        PushArgs pa1{E, D, A, h->cap, tail1, h->obs_cur, h->e_raw, h->e_rew, h->e_tobs, h->obs_nxt, h->e_term, h->e_trunc,
+                     h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc};
+        CollectEnvArgs ce{ca, pa1, h->env_seed0, h->cfg.episode_len, h->state, h->step_count, h->episode, h->gstep, h->e_rew, h->e_term, h->e_trunc, h->e_tobs, h->obs_nxt};
+        const dim3 grid((E + 255) / 256), block(256);
+        if (h->cfg.env_kind == DRIL_ENV_PENDULUM) hipLaunchKernelGGL(sac_collect_env_kernel<1>, grid, block, 0, h->stream, ce);
+        else if (h->cfg.env_kind == DRIL_ENV_PENDULUM_SCALED) hipLaunchKernelGGL(sac_collect_env_kernel<2>, grid, block, 0, h->stream, ce);
+        else hipLaunchKernelGGL(sac_collect_env_kernel<4>, grid, block, 0, h->stream, ce);
+        SHIP(h, hipGetLastError());
+        const long long over1 = h->size + E - h->cap;
+        if (over1 > 0) { h->head = (h->head + over1) % h->cap; h->size = h->cap; } else h->size += E;
+        std::swap(h->obs_cur, h->obs_nxt);
+        return DRIL_OK;
+    }
     hipLaunchKernelGGL(sac_collect_head_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, ca);
     MonitorArgs mon{nullptr, nullptr, nullptr, nullptr, nullptr};
     SHIP(h, launch_env_step(h->cfg.env_kind, E, h->env_seed0, h->cfg.episode_len, 0, 0, h->e_envact, h->state, h->step_count, h->episode, h->gstep,
