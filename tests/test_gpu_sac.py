@@ -158,6 +158,30 @@ def test_collect_matches_oracle(pkg, scaled):
     close(h.replay(C.RB_REWARDS), o.replay(C.RB_REWARDS), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("scaled", [False, True, "mountaincar"])
+def test_one_launch_collection_equals_the_four_launch_sequence(pkg, monkeypatch, scaled):
+    """sac_collect_env_kernel (head + act! + observe + push! per env in one launch) against sac_collect_head_kernel -> env_step_kernel -> env_observe_kernel ->
+    sac_push_kernel (DRIL_SAC_NO_FUSED_COLLECT=1, latched at create): same device functions in the same order => every replay field, the observation and the env
+    state after truncations, a ring wrap, random and policy actions, injected and Philox noise are bit-identical"""
+    E, L = 70, 4
+    a, _, layer, _ = make_pair(pkg, E=E, max_steps=L, cap=300, scaled=scaled)
+    monkeypatch.setenv("DRIL_SAC_NO_FUSED_COLLECT", "1")
+    b, _, _, _ = make_pair(pkg, E=E, max_steps=L, cap=300, scaled=scaled)
+    monkeypatch.delenv("DRIL_SAC_NO_FUSED_COLLECT")
+    flat = init_params(pkg, layer)
+    rng = np.random.default_rng(5)
+    nz = rng.normal(0, 1, (3, E, 1)).astype(np.float32)
+    for x in (a, b):
+        x.set_params(flat); x.env_reset(3)
+        x.collect_rollout(2, True); x.set_collect_noise(nz); x.collect_rollout(3, False); x.collect_rollout(4, False)      # 9 steps x 70 envs into 300 slots, two truncations
+    C = pkg._capi
+    assert a.replay_size() == b.replay_size() == 300
+    for which in (C.RB_OBSERVATIONS, C.RB_NEXT_OBSERVATIONS, C.RB_ACTIONS, C.RB_REWARDS, C.RB_TERMINATED, C.RB_TRUNCATED):
+        np.testing.assert_array_equal(a.replay(which), b.replay(which))
+    np.testing.assert_array_equal(a.env_observe(), b.env_observe())
+    assert a.replay(C.RB_TRUNCATED).sum() > 0
+
+
 def test_replay_fill_copy_out_and_errors(pkg):
     h, _, layer, _ = make_pair(pkg, cap=64)
     rng = np.random.default_rng(0)
