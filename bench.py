@@ -107,17 +107,14 @@ def run_sac(pkg, *, steps: int, warmup: int, iters: int, E: int = 4096, H: int =
     h.set_params(flat); h.env_reset(42)
     h.collect_rollout(max(1, alg.start_steps // E), True)          # train!'s first, random-action collection (sac.jl:436-440)
 
-    # the loop body of train! without its per-iteration host bookkeeping: collect 1 step, 1 update (both enqueue-only until their sync)
-    def iteration():
-        h.collect_rollout(alg.train_freq, False)
-        h.update(pkg.get_gradient_steps(alg, alg.train_freq, E))
-
-    for _ in range(warmup * iters):
-        iteration()
+    # the loop body of train! as dril_sac_train runs it after its first iteration (dril_sac_iterate): {collect train_freq env steps, the gradient steps} enqueued
+    # back to back, the stream drained every 64 iterations; statistics of every gradient step and fps of every iteration come back with each call
+    for _ in range(warmup):
+        h.iterate(iters)
     h.profile_reset()
     t0 = time.perf_counter()
-    for _ in range(steps * iters):
-        iteration()
+    for _ in range(steps):
+        h.iterate(iters)
     dt = time.perf_counter() - t0
     prof = h.profile()
     n_it = steps * iters

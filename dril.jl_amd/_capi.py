@@ -211,6 +211,7 @@ _SAC_SIG = {
     "debug_set_batches": (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P]),
     "get_last_grads": (C.c_int32, [_P, _P, _P, C.c_size_t]),
     "train": (C.c_int32, [_P, C.c_int64, _P, C.c_int64, _PI64, _PD, C.c_int64, C.POINTER(C.c_int32), _PI64]),
+    "iterate": (C.c_int32, [_P, C.c_int32, _P, C.c_int64, _PD, C.c_int64]),
     "profile_get": (C.c_int32, [_P, _PD, _PI64, _PD, _PI64]),
     "profile_reset": (C.c_int32, [_P]),
 }

@@ -723,7 +723,7 @@ struct dril_sac_handle {
     double* ssq_rows = nullptr;   // [stats_cap][adam_blocks_c + end_blocks] squared-gradient partials per update, summed on the host (grad_norm statistic)
     unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
     SacScalars* sc_next = nullptr;   // ping-pong partner of `sc` (fused heads: the entropy step writes the new state here, then the two are swapped)
-    double* head_partials = nullptr; unsigned int* head_counter = nullptr; bool fused_heads = true; bool fused_collect = true; bool trace_enqueue = false;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
+    double* head_partials = nullptr; unsigned int* head_counter = nullptr; bool fused_heads = true; bool fused_collect = true; bool trace_enqueue = false; std::vector<hipEvent_t> it_events; int iter_chunk = 64;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
     float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
     float target_entropy = 0, act_lo = -2.0f, act_hi = 2.0f; bool external = false;   // bounds of the agent-facing action space: Box(-2,2), Box(-1,1) under ScalingWrapperEnv
     // env
@@ -1005,6 +1005,17 @@ void fill_stats(const dril_sac_handle* h, const float* rows, int n, dril_sac_sta
         s.entropy_coefficient = r[4]; s.grad_norm = r[5]; s.has_entropy_loss = h->cfg.auto_ent_coef ? 1 : 0;
     }
 }
+// the statistics rows of the last n gradient steps (stream drained): device rows + the squared-gradient partials summed here
+int fetch_stats(dril_sac_handle* h, int n, dril_sac_stats* out) {
+    std::vector<float> rows((size_t)n * 8);
+    SHIP(h, hipMemcpy(rows.data(), h->stats_out, rows.size() * 4, hipMemcpyDeviceToHost));
+    const int nb = h->adam_blocks_c + h->end_blocks;
+    std::vector<double> ssq((size_t)n * nb);
+    SHIP(h, hipMemcpy(ssq.data(), h->ssq_rows, ssq.size() * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n; ++k) { double t = 0; for (int b = 0; b < nb; ++b) t += ssq[(size_t)k * nb + b]; rows[(size_t)k * 8 + 5] = (float)sqrt(t); }   // grad_norm, sac.jl:393 (index order: deterministic)
+    fill_stats(h, rows.data(), n, out);
+    return DRIL_OK;
+}
 int run_updates(dril_sac_handle* h, int n_updates, bool injected, dril_sac_stats* out) {
     if (h->size <= 0) return sfail(h, DRIL_ERR_NOT_INITIALISED, "the replay buffer is empty");
     SDO(ensure_stats(h, n_updates));
@@ -1020,14 +1031,37 @@ int run_updates(dril_sac_handle* h, int n_updates, bool injected, dril_sac_stats
                 std::chrono::duration<double, std::micro>(t_enq1 - t_enq0).count(), std::chrono::duration<double, std::micro>(t_done - t_enq0).count());
     }
     if (h->cfg.profile_events) { float ms = 0; if (hipEventElapsedTime(&ms, h->ev_a, h->ev_b) == hipSuccess) { h->update_ms += ms; h->updates += n_updates; } }
-    if (out) {
-        std::vector<float> rows((size_t)n_updates * 8);
-        SHIP(h, hipMemcpy(rows.data(), h->stats_out, rows.size() * 4, hipMemcpyDeviceToHost));
-        const int nb = h->adam_blocks_c + h->end_blocks;
-        std::vector<double> ssq((size_t)n_updates * nb);
-        SHIP(h, hipMemcpy(ssq.data(), h->ssq_rows, ssq.size() * 8, hipMemcpyDeviceToHost));
-        for (int k = 0; k < n_updates; ++k) { double t = 0; for (int b = 0; b < nb; ++b) t += ssq[(size_t)k * nb + b]; rows[(size_t)k * 8 + 5] = (float)sqrt(t); }   // grad_norm, sac.jl:393 (index order: deterministic)
-        fill_stats(h, rows.data(), n_updates, out);
+    if (out) SDO(fetch_stats(h, n_updates, out));
+    return DRIL_OK;
+}
+// train!'s loop body (sac.jl:464-535) for `count` iterations WITHOUT a host synchronisation between them: {train_freq env steps, n_upd gradient steps} enqueued back to
+// back, one drain at the end.  Nothing the host decides depends on device results (the replay ring's head / size are host counters, batch indices and noise are
+// device Philox streams keyed by the update counter), so the launches are the ones the step-by-step sequence issues, in the same order: bit-identical state.
+// fps of an iteration = env steps / HIP-event time of its collection (the reference times the same span on the host clock, off_policy_collection.jl:126-128).
+int run_iterations(dril_sac_handle* h, int count, int tf, int n_upd, dril_sac_stats* stats, int64_t stats_room, double* fps, int64_t fps_room) {
+    if (count <= 0) return DRIL_OK;
+    SDO(ensure_obs(h));
+    if (n_upd > 0) { if (h->size <= 0 && tf <= 0) return sfail(h, DRIL_ERR_NOT_INITIALISED, "the replay buffer is empty"); SDO(ensure_stats(h, count * n_upd)); }
+    const bool timed = h->cfg.profile_events || fps;
+    while (timed && (int)h->it_events.size() < 3 * count) { hipEvent_t e; SHIP(h, hipEventCreate(&e)); h->it_events.push_back(e); }
+    for (int j = 0; j < count; ++j) {
+        if (timed) hipEventRecord(h->it_events[3 * j], h->stream);
+        for (int t = 0; t < tf; ++t) SDO(collect_step(h, 0, nullptr));
+        if (timed) hipEventRecord(h->it_events[3 * j + 1], h->stream);
+        for (int k = 0; k < n_upd; ++k) SDO(sac_one_update(h, -1, h->stats_out + ((size_t)j * n_upd + k) * 8));
+        if (timed) hipEventRecord(h->it_events[3 * j + 2], h->stream);
+    }
+    SDO(ssync(h));
+    if (timed) for (int j = 0; j < count; ++j) {
+        float c = 0, u = 0;
+        if (hipEventElapsedTime(&c, h->it_events[3 * j], h->it_events[3 * j + 1]) != hipSuccess || hipEventElapsedTime(&u, h->it_events[3 * j + 1], h->it_events[3 * j + 2]) != hipSuccess) continue;
+        if (h->cfg.profile_events) { h->collect_ms += c; h->collect_steps += tf; h->update_ms += u; h->updates += n_upd; }
+        if (fps && j < fps_room) fps[j] = (double)tf * h->cfg.n_envs / (c > 0 ? 1e-3 * c : 1e-9);
+    }
+    if (stats && n_upd > 0 && stats_room > 0) {
+        std::vector<dril_sac_stats> tmp((size_t)count * n_upd);
+        SDO(fetch_stats(h, count * n_upd, tmp.data()));
+        for (int64_t k = 0; k < std::min<int64_t>(stats_room, (int64_t)tmp.size()); ++k) stats[k] = tmp[(size_t)k];
     }
     return DRIL_OK;
 }
@@ -1085,6 +1119,7 @@ DRIL_EXPORT int32_t dril_sac_destroy(dril_sac_handle* h) {
                     h->b_nlp, h->a_pi, h->g_pi, h->lp_pi, h->b_term, h->collect_noise, h->inj_idx, h->inj_ne, h->inj_nn, h->inj_np, h->s_in, h->s_act, h->s_noise, h->s_out, h->s_out2};
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->ev_a) hipEventDestroy(h->ev_a); if (h->ev_b) hipEventDestroy(h->ev_b);
+    for (hipEvent_t e : h->it_events) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return DRIL_OK;
@@ -1379,18 +1414,24 @@ DRIL_EXPORT int32_t dril_sac_train(dril_sac_handle* h, int64_t max_steps, dril_s
     const int64_t total = n_steps * E + tf * E * (iterations - 1);                                // :445
     const int64_t n_upd = h->cfg.gradient_steps == -1 ? tf * E : h->cfg.gradient_steps;           // get_gradient_steps :59-65
     int64_t done = 0; int64_t it = 0;
-    for (; it < iterations; ++it) {
+    if (iterations > 0) {                                                                         // the first iteration: the start_steps collection (random actions), then its gradient steps
         double f = 0;
-        SDO(collect(h, (int)n_steps, it == 0 && h->cfg.start_steps > 0, &f));                     // :485-489
-        if (fps && it < fps_capacity) fps[it] = f;
-        n_steps = tf;                                                                             // :511
+        SDO(collect(h, (int)n_steps, h->cfg.start_steps > 0, &f));                                // :485-489
+        if (fps && fps_capacity > 0) fps[0] = f;
         if (n_upd > 0) {
-            const int64_t room = stats ? std::max<int64_t>(0, std::min<int64_t>(n_upd, stats_capacity - done)) : 0;
+            const int64_t room = stats ? std::max<int64_t>(0, std::min<int64_t>(n_upd, stats_capacity)) : 0;
             std::vector<dril_sac_stats> tmp((size_t)n_upd);
             SDO(run_updates(h, (int)n_upd, false, tmp.data()));                                   // :514-531
-            for (int64_t k = 0; k < room; ++k) stats[done + k] = tmp[(size_t)k];
+            for (int64_t k = 0; k < room; ++k) stats[k] = tmp[(size_t)k];
             done += n_upd;
         }
+        it = 1;
+    }
+    while (it < iterations) {                                                                     // every later iteration collects train_freq steps (:511): chunks without a host sync inside
+        const int cnt = (int)std::min<int64_t>(h->iter_chunk, iterations - it);
+        SDO(run_iterations(h, cnt, (int)tf, (int)n_upd, stats ? stats + std::min<int64_t>(done, stats_capacity) : nullptr, stats ? std::max<int64_t>(0, stats_capacity - done) : 0,
+                           fps && it < fps_capacity ? fps + it : nullptr, fps ? std::max<int64_t>(0, fps_capacity - it) : 0));
+        done += (int64_t)cnt * n_upd; it += cnt;
     }
     if (n_updates_done) *n_updates_done = done;
     if (iterations_done) *iterations_done = (int32_t)std::max<int64_t>(0, it);
@@ -1398,6 +1439,21 @@ DRIL_EXPORT int32_t dril_sac_train(dril_sac_handle* h, int64_t max_steps, dril_s
     return DRIL_OK;
 }
 
+DRIL_EXPORT int32_t dril_sac_iterate(dril_sac_handle* h, int32_t iterations, dril_sac_stats* stats, int64_t stats_capacity, double* fps, int64_t fps_capacity) {
+    SNEED(h); S_NOT_EXTERNAL(h, "dril_sac_iterate");
+    if (iterations <= 0) return sfail(h, DRIL_ERR_INVALID_ARG, "iterations must be positive");
+    if (!h->env_ready) return sfail(h, DRIL_ERR_NOT_INITIALISED, "dril_sac_env_reset has not been called");
+    const int64_t E = h->cfg.n_envs, tf = h->cfg.train_freq;
+    const int64_t n_upd = h->cfg.gradient_steps == -1 ? tf * E : h->cfg.gradient_steps;
+    int64_t done = 0;
+    for (int64_t it = 0; it < iterations; ) {
+        const int cnt = (int)std::min<int64_t>(h->iter_chunk, iterations - it);
+        SDO(run_iterations(h, cnt, (int)tf, (int)n_upd, stats ? stats + std::min<int64_t>(done, stats_capacity) : nullptr, stats ? std::max<int64_t>(0, stats_capacity - done) : 0,
+                           fps && it < fps_capacity ? fps + it : nullptr, fps ? std::max<int64_t>(0, fps_capacity - it) : 0));
+        done += (int64_t)cnt * n_upd; it += cnt;
+    }
+    return DRIL_OK;
+}
 DRIL_EXPORT int32_t dril_sac_profile_get(dril_sac_handle* h, double* collect_ms, int64_t* collect_steps, double* update_ms, int64_t* updates) {
     SNEED(h);
     if (collect_ms) *collect_ms = h->collect_ms; if (collect_steps) *collect_steps = h->collect_steps;

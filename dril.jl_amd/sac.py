@@ -337,6 +337,17 @@ class SacHandle:
                                    fps.ctypes.data_as(C.POINTER(C.c_double)), fps_capacity, C.byref(iters), C.byref(total)))
         return list(stats[:min(n_upd.value, stats_capacity)]), fps[:min(iters.value, fps_capacity)], n_upd.value, iters.value, total.value
 
+    def iterate(self, iterations: int, want_stats: bool = True):
+        """`iterations` rounds of train!'s loop body (sac.jl:464-535: collect train_freq env steps, then the gradient steps) without a host sync between them
+        (dril_sac_iterate) -> (stats of every gradient step, fps of every iteration)"""
+        n_upd = self.cfg.train_freq * self.E if self.cfg.gradient_steps == -1 else self.cfg.gradient_steps
+        cap = iterations * max(n_upd, 0) if want_stats else 0
+        stats = (DrilSacStats * max(cap, 1))()
+        fps = np.zeros(iterations if want_stats else 1, np.float64)
+        self._chk(self._f("iterate")(self._h, C.c_int32(iterations), C.cast(stats, C.c_void_p) if want_stats else None, C.c_int64(cap),
+                                     fps.ctypes.data_as(C.POINTER(C.c_double)) if want_stats else None, C.c_int64(iterations if want_stats else 0)))
+        return list(stats[:cap]), fps[:iterations] if want_stats else fps[:0]
+
     def profile(self) -> dict:
         cm, um, cs, us = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
         self._chk(self._f("profile_get")(self._h, C.byref(cm), C.byref(cs), C.byref(um), C.byref(us)))

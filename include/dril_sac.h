@@ -184,6 +184,13 @@ int32_t dril_sac_train(dril_sac_handle* h, int64_t max_steps, dril_sac_stats* st
                        int64_t* n_updates_done, double* fps, int64_t fps_capacity, int32_t* iterations_done,
                        int64_t* total_steps);
 
+/* the loop body of train! (sac.jl:464-535) for `iterations` iterations on a handle whose env has been reset: {collect train_freq env steps with the policy,
+ * get_gradient_steps updates} enqueued back to back, the stream drained once per 64 iterations (dril_sac_train runs its iterations after the first through the same
+ * loop).  Bit-identical to calling dril_sac_collect_rollout(train_freq, 0) + dril_sac_update(n) per iteration.  stats: one entry per gradient step; fps: one entry per
+ * iteration = env steps / HIP-event time of its collection */
+int32_t dril_sac_iterate(dril_sac_handle* h, int32_t iterations, dril_sac_stats* stats, int64_t stats_capacity, double* fps,
+                         int64_t fps_capacity);
+
 /* ---- measurement: accumulated HIP-event milliseconds since the last reset --------------------------------------------- */
 int32_t dril_sac_profile_get(dril_sac_handle* h, double* collect_ms, int64_t* collect_steps, double* update_ms,
                              int64_t* updates);

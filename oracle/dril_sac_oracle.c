@@ -501,6 +501,23 @@ ORC_API void orc_sac_schedule(int64_t max_steps, int32_t n_envs, int32_t start_s
     *first_steps = n_steps; *iterations = it; *total_steps = n_steps * E + (int64_t)train_freq * E * (it - 1);   /* :445 */
     *updates_per_iteration = gradient_steps == -1 ? (int64_t)train_freq * E : gradient_steps; /* get_gradient_steps :59-65 */
 }
+/* the loop body of train! (sac.jl:464-535) for `iterations` iterations: collect train_freq steps with the policy, then the gradient steps (include/dril_sac.h dril_sac_iterate) */
+ORC_API int32_t orc_sac_iterate(orc_sac* c, int32_t iterations, dril_sac_stats* stats, int64_t stats_capacity, double* fps, int64_t fps_capacity) {
+    const int64_t n_upd = c->cfg.gradient_steps == -1 ? (int64_t)c->cfg.train_freq * c->cfg.n_envs : c->cfg.gradient_steps;
+    int64_t done = 0;
+    for (int it = 0; it < iterations; ++it) {
+        double f = 0;
+        int32_t rc = orc_sac_collect_rollout(c, c->cfg.train_freq, 0, &f);
+        if (rc) return rc;
+        if (fps && it < fps_capacity) fps[it] = f;
+        for (int64_t k = 0; k < n_upd; ++k) {
+            dril_sac_stats s; sac_one_update(c, -1, &s);
+            if (stats && done < stats_capacity) stats[done] = s;
+            ++done;
+        }
+    }
+    return DRIL_OK;
+}
 ORC_API int32_t orc_sac_train(orc_sac* c, int64_t max_steps, dril_sac_stats* stats, int64_t stats_capacity, int64_t* n_updates_done,
                               double* fps, int64_t fps_capacity, int32_t* iterations_done, int64_t* total_steps) {
     int64_t n_steps, iterations, total, n_upd;

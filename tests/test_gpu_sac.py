@@ -182,6 +182,33 @@ def test_one_launch_collection_equals_the_four_launch_sequence(pkg, monkeypatch,
     assert a.replay(C.RB_TRUNCATED).sum() > 0
 
 
+def test_iterations_without_host_sync_equal_the_step_by_step_loop(pkg):
+    """dril_sac_iterate (train!'s loop body enqueued back to back, one drain per 64 iterations; dril_sac_train's own loop) against collect_rollout(train_freq) +
+    update(n) per iteration with a drain after each: the same launches in the same order => parameters, targets, entropy coefficient, replay contents and the
+    statistics of every gradient step are bit-identical; 70 iterations = one full chunk and a partial one"""
+    E = 24
+    a, _, layer, _ = make_pair(pkg, E=E, max_steps=9, cap=1000)
+    b, _, _, _ = make_pair(pkg, E=E, max_steps=9, cap=1000)
+    flat = init_params(pkg, layer)
+    for x in (a, b):
+        x.set_params(flat); x.env_reset(4); x.collect_rollout(3, True)
+    n_it = 70
+    sa, fps = a.iterate(n_it)
+    sb = []
+    for _ in range(n_it):
+        b.collect_rollout(b.cfg.train_freq, False); sb += b.update(1)
+    assert len(sa) == len(sb) == n_it and len(fps) == n_it and (fps > 0).all()
+    for x, y in zip(sa, sb):
+        assert (x.actor_loss, x.critic_loss, x.entropy_coefficient, x.mean_q_values, x.grad_norm) == (y.actor_loss, y.critic_loss, y.entropy_coefficient, y.mean_q_values, y.grad_norm)
+    np.testing.assert_array_equal(a.get_params(), b.get_params())
+    np.testing.assert_array_equal(a.get_target_params(), b.get_target_params())
+    assert a.get_log_ent_coef() == b.get_log_ent_coef()
+    C = pkg._capi
+    for which in (C.RB_OBSERVATIONS, C.RB_NEXT_OBSERVATIONS, C.RB_ACTIONS, C.RB_REWARDS, C.RB_TERMINATED, C.RB_TRUNCATED):
+        np.testing.assert_array_equal(a.replay(which), b.replay(which))
+    assert not np.array_equal(a.get_params(), flat)
+
+
 def test_replay_fill_copy_out_and_errors(pkg):
     h, _, layer, _ = make_pair(pkg, cap=64)
     rng = np.random.default_rng(0)
