@@ -231,6 +231,9 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
                                    rocprof_avg_launch_ms=rocprof_ms, launches=gk["launches"], flops_per_launch=flops,
                                    record_bytes_per_launch=(B_global // world) * 64)      # one 32-byte record per sample and net (the algorithmic gather volume of the record path)
             out["kernel_ms_per_step"] = {k: v["total_ms"] / steps for k, v in prof.items() if v["launches"]}
+            rk = prof.get("rollout_kernel", {"total_ms": 0, "launches": 0})
+            if rk["launches"]:                           # what the reference logs as env/fps (rollout_buffer.jl:60-64, ppo.jl:176): env steps per second of the collection alone (HIP events around the rollout)
+                out["rollout_only_env_steps_per_s"] = N_local * world * steps / (rk["total_ms"] * 1e-3)
     h.close()
     return out
 
