@@ -19,7 +19,13 @@ struct GemmArgs {
     int dbg;                                      // DRIL_GEMM_DBG bits (diagnostic, results wrong): 1 no global operand loads after the first chunk, 2 no MFMA, 4 no epilogue, 8 no staging stores
     int allow_split;                              // large contractions may run on the bf16 matrix cores with fp32-equivalent 3-piece operand splitting (generic on-policy path; SAC keeps the f32 MFMA)
 };
-enum { EPI_NONE = 0, EPI_RELU = 1, EPI_TANH = 2, EPI_MASK_RELU = 3, EPI_MASK_TANH = 4 };
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_TANH = 2, EPI_MASK_RELU = 3, EPI_MASK_TANH = 4,
+       // round 3: the other activations whose derivative is a function of the OUTPUT (the reverse pass keeps activations, not pre-activations): NNlib sigmoid,
+       // elu (alpha = 1), leakyrelu (a = 0.01), softplus — generic PPO path only (the reference takes any activation, layer_constructors.jl:8,56)
+       EPI_SIGMOID = 5, EPI_ELU = 6, EPI_LEAKY = 7, EPI_SOFTPLUS = 8, EPI_MASK_SIGMOID = 9, EPI_MASK_ELU = 10, EPI_MASK_LEAKY = 11, EPI_MASK_SOFTPLUS = 12 };
+// activation codes of dril_config.activation -> the forward epilogue and the mask (act'(y)) epilogue
+inline int epi_of_activation(int act) { return act == 1 ? EPI_RELU : act == 2 ? EPI_SIGMOID : act == 3 ? EPI_ELU : act == 4 ? EPI_LEAKY : act == 5 ? EPI_SOFTPLUS : EPI_TANH; }
+inline int mask_epi_of_activation(int act) { return act == 1 ? EPI_MASK_RELU : act == 2 ? EPI_MASK_SIGMOID : act == 3 ? EPI_MASK_ELU : act == 4 ? EPI_MASK_LEAKY : act == 5 ? EPI_MASK_SOFTPLUS : EPI_MASK_TANH; }
 
 GemmArgs gemm_args();
 // one contraction, Z batches (blockIdx.z); picks the split-K / tile-parallel / LDS-tiled shape from the tile count

@@ -45,6 +45,14 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, float
     else if (g.epi == EPI_TANH) v = tanhf(v);
     else if (g.epi == EPI_MASK_RELU) v = y > 0.f ? v : 0.f;
     else if (g.epi == EPI_MASK_TANH) v *= 1.0f - y * y;
+    else if (g.epi == EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+    else if (g.epi == EPI_ELU) v = v > 0.f ? v : expm1f(v);
+    else if (g.epi == EPI_LEAKY) v = v > 0.f ? v : 0.01f * v;
+    else if (g.epi == EPI_SOFTPLUS) v = fmaxf(v, 0.f) + log1pf(expf(-fabsf(v)));
+    else if (g.epi == EPI_MASK_SIGMOID) v *= y * (1.0f - y);
+    else if (g.epi == EPI_MASK_ELU) v *= y > 0.f ? 1.0f : y + 1.0f;                 // alpha e^x = elu(x) + alpha
+    else if (g.epi == EPI_MASK_LEAKY) v *= y > 0.f ? 1.0f : 0.01f;
+    else if (g.epi == EPI_MASK_SOFTPLUS) v *= 1.0f - expf(-y);                       // sigmoid(x) = 1 - e^(-softplus(x))
     return v;
 }
 // one 32 x 32 output tile out of the LDS transposition buffer: lane -> 16 elements (row ml = lane & 31 fixed, 16 columns), stores along C's unit-stride axis.
@@ -57,7 +65,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, float* __restrict_
     const int ml = lane & 31, mm = m_base + ml;
     const bool m_ok = mm < g.M;
     const float b = (bias && m_ok) ? bias[mm] : 0.f;
-    const bool need_aux = aux && (g.epi == EPI_MASK_RELU || g.epi == EPI_MASK_TANH);
+    const bool need_aux = aux && (g.epi == EPI_MASK_RELU || g.epi == EPI_MASK_TANH || g.epi >= EPI_MASK_SIGMOID);
     float y[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -111,7 +119,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)
     const float* __restrict__ aux = g.aux ? g.aux + (size_t)z * g.zAux : nullptr;
     // element e of a 32x32 tile: m_local = e & 31 (fastest, C's unit stride), n_local = e >> 5; it sits in register rr of lane ll
     if (SPLIT) {
-        const bool need_aux = aux && (g.epi == EPI_MASK_RELU || g.epi == EPI_MASK_TANH);
+        const bool need_aux = aux && (g.epi == EPI_MASK_RELU || g.epi == EPI_MASK_TANH || g.epi >= EPI_MASK_SIGMOID);
         const int ml = threadIdx.x & 31, mm = bx * 32 + ml, rr = (ml & 3) + 4 * (ml >> 3), lb = 32 * ((ml >> 2) & 1);
         const float b = (bias && mm < g.M) ? bias[mm] : 0.f;
         float y[2]; bool ok[2]; size_t ci[2];

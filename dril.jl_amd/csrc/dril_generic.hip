@@ -47,8 +47,8 @@ NetLay net_lay(const GenericDims& d, int base, int O) {
 int hidden_sum(const GenericDims& d) { int s = 0; for (int l = 0; l < d.nh; ++l) s += d.H[l]; return s; }
 // hidden activations: one 16-byte-aligned block per layer (hb[l]); inside a block net z follows net z - 1 (n * H[l] floats apart), one row per sample —
 // the layout mlp_forward_both's batched launches write and the reverse pass reads
-int act_epi(const GenericDims& d) { return d.act ? EPI_RELU : EPI_TANH; }
-int mask_epi(const GenericDims& d) { return d.act ? EPI_MASK_RELU : EPI_MASK_TANH; }
+int act_epi(const GenericDims& d) { return epi_of_activation(d.act); }
+int mask_epi(const GenericDims& d) { return mask_epi_of_activation(d.act); }
 
 // out[n][O] = net(X[n][D]) with every hidden activation kept (layer l in hb[l]): Dense(in => h, act) ... Dense(h_nh => out), layer_helpers.jl:27-57
 hipError_t mlp_forward(const GenericDims& d, const float* P, const NetLay& L, const float* X, int n, float* const* hb, float* out, hipStream_t s) {

@@ -202,6 +202,9 @@ def _orthogonal(rng: np.random.Generator, out_dims: int, in_dims: int, gain: flo
     return (gain * w).astype(np.float32)
 
 
+ACTIVATIONS = ("tanh", "relu", "sigmoid", "elu", "leakyrelu", "softplus")   # dril_config.activation codes 0 .. 5 (include/dril_hip.h)
+
+
 @dataclass
 class ActorCriticLayer:
     """ActorCriticLayer(observation_space, action_space; hidden_dims=[64,64], activation=tanh, log_std_init=0)
@@ -211,14 +214,14 @@ class ActorCriticLayer:
     action_space: object
     hidden_dims: Sequence[int] = (64, 64)      # any length 1..4 (get_mlp, layer_helpers.jl:27-57); two equal layers of 64 / 128 / 256 with tanh run the fused kernels
     log_std_init: float = 0.0
-    activation: str = "tanh"                   # "tanh" (the reference's default, layer_constructors.jl:8,56) or "relu"
+    activation: str = "tanh"                   # "tanh" (the reference's default, layer_constructors.jl:8,56), "relu", "sigmoid", "elu", "leakyrelu", "softplus" (NNlib's definitions; anything but tanh runs the generic kernels)
 
     def __post_init__(self):
         self.hidden_dims = tuple(int(h) for h in self.hidden_dims)
         if not 1 <= len(self.hidden_dims) <= 4:
             raise ValueError("hidden_dims: 1..4 hidden layers are supported on the device path")
-        if self.activation not in ("tanh", "relu"):
-            raise ValueError("activation: tanh or relu")
+        if self.activation not in ACTIVATIONS:
+            raise ValueError("activation: one of " + ", ".join(ACTIVATIONS))
 
     @property
     def discrete(self) -> bool:
@@ -336,7 +339,7 @@ def make_config(env, n_envs: int, alg: PPO, layer: Optional[ActorCriticLayer] = 
             c.n_hidden = len(hd)
             for i, w in enumerate(hd):
                 c.hidden[i] = w
-            c.activation = 1 if layer.activation == "relu" else 0
+            c.activation = ACTIVATIONS.index(layer.activation)
         c.log_std_init = layer.log_std_init
     c.episode_len = getattr(env, "max_steps", 0)
     c.fixed_length_episodes = int(fixed_length_episodes)

@@ -226,7 +226,7 @@ function hidden_dims_of(ps)
 end
 first_dense(l) = hasproperty(l, :activation) ? l : first_dense(first(l.layers))
 """
-The C ABI (include/dril_hip.h, dril_config v2) carries `hidden_dims` of length 1..4 and tanh / relu; the reference accepts any depth and activation
+The C ABI (include/dril_hip.h, dril_config v2) carries `hidden_dims` of length 1..4 and tanh / relu / sigmoid / elu / leakyrelu / softplus (activations whose derivative is a function of the output); the reference accepts any depth and activation
 (layer_constructors.jl:6-10,55-56, layer_helpers.jl:27-57).  Anything else is REJECTED here with a clear message — round 1 read layer_1..layer_3
 unconditionally and would have mis-flattened a deeper net silently.  Returns the activation code of dril_config.
 """
@@ -239,7 +239,11 @@ function check_supported_layer(agent)
     act = first_dense(agent.layer.actor_head).activation
     (act === tanh || nameof(act) === :tanh_fast) && return Int32(0)
     (nameof(act) === :relu) && return Int32(1)
-    error("DRiLHIP: activation $(act) is not supported on the device PPO path (tanh, relu). Use DRiL's CPU train! for this layer.")
+    (nameof(act) in (:sigmoid, :sigmoid_fast, :σ)) && return Int32(2)      # the plain NNlib functions only: elu with alpha = 1, leakyrelu with a = 0.01
+    (nameof(act) === :elu) && return Int32(3)
+    (nameof(act) === :leakyrelu) && return Int32(4)
+    (nameof(act) === :softplus) && return Int32(5)
+    error("DRiLHIP: activation $(act) is not supported on the device PPO path (tanh, relu, sigmoid, elu, leakyrelu, softplus). Use DRiL's CPU train! for this layer.")
 end
 function push_params!(env, agent)
     flat = flatten_params(agent.train_state.parameters)
