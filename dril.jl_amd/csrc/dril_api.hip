@@ -505,7 +505,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
         case DRIL_ENV_CARTPOLE: h->discrete = true; h->D = 4; h->A = 2; h->S = 4; break;
         case DRIL_ENV_MOUNTAINCAR: h->discrete = true; h->D = 2; h->A = 3; h->S = 2; break;
         case DRIL_ENV_MOUNTAINCAR_CONTINUOUS: h->discrete = false; h->D = 2; h->A = 1; h->S = 2; break;
-        case DRIL_ENV_ACROBOT: h->discrete = true; h->D = 6; h->A = 3; h->S = 4; h->generic = !(nh == 2 && hd[0] == 64 && hd[1] == 64 && cfg->activation == 0); break;   // six observation dims: fused at hidden [64,64] tanh (four first-layer k-steps, round 3: forward / rollout kernels + the exact-f32 update kernel), generic kernels for every other hidden_dims
+        case DRIL_ENV_ACROBOT: h->discrete = true; h->D = 6; h->A = 3; h->S = 4; h->generic = !fused_shape; break;   // six observation dims: four first-layer k-steps and three-quad records in every fused kernel (round 3)
         case DRIL_ENV_EXTERNAL: h->discrete = cfg->ext_discrete != 0; h->D = cfg->ext_obs_dim; h->A = cfg->ext_action_dim; h->S = 0; h->external = true; h->generic = true; break;
         default: h->discrete = false; h->D = 3; h->A = 1; h->S = 2; break;                    // Pendulum, ScalingWrapperEnv(Pendulum)
     }

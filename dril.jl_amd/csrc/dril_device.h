@@ -263,7 +263,7 @@ template <> struct EnvSpec<1> { static constexpr int D = 3, S = 2, A = 1; static
 template <> struct EnvSpec<2> : EnvSpec<1> {};   // ScalingWrapperEnv(PendulumEnv()): same simulator, affine maps at the boundary
 template <> struct EnvSpec<3> { static constexpr int D = 2, S = 2, A = 3; static constexpr bool discrete = true; };    // MountainCar-v0: (position, velocity), Discrete(3)
 template <> struct EnvSpec<4> { static constexpr int D = 2, S = 2, A = 1; static constexpr bool discrete = false; };   // MountainCarContinuous-v0: Box(-1, 1)
-template <> struct EnvSpec<6> { static constexpr int D = 6, S = 4, A = 3; static constexpr bool discrete = true; };    // Acrobot-v1: (cos t1, sin t1, cos t2, sin t2, w1, w2), Discrete(3); fused at [64,64] through FirstLayer<6>, generic otherwise
+template <> struct EnvSpec<6> { static constexpr int D = 6, S = 4, A = 3; static constexpr bool discrete = true; };    // Acrobot-v1: (cos t1, sin t1, cos t2, sin t2, w1, w2), Discrete(3); fused at [64,64] / [128,128] / [256,256] through FirstLayer<6>, generic otherwise
 // ScalingWrapperEnv (scalingWrapperEnv.jl): scale! :71-74 `(x - low) * sf - 1`, unscale! :76-79 `(x + 1) / sf + low`, sf = 2 / (high - low) :36-44
 __host__ __device__ inline float scale_to_unit(float x, float low, float high) { const float sf = 2.0f / (high - low); return (x - low) * sf - 1.0f; }
 __host__ __device__ inline float unscale_from_unit(float x, float low, float high) { const float sf = 2.0f / (high - low); return (x + 1.0f) / sf + low; }

@@ -134,7 +134,7 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
 
     const int g = (int)(blockIdx.x % a.G);
     const int64_t ntiles = (a.count + kTile - 1) / kTile;
-    TileIn<O> cur, nxt;
+    TileIn<O, FirstLayer<D>::KS> cur, nxt;
     int64_t tile = g;
     if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
 #ifdef DRIL_STAMPS
@@ -144,7 +144,10 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
     for (; tile < ntiles; tile += a.G) {
         unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
         const bool valid = cur.valid;
-        const float xk[2] = {cur.xk[0], cur.xk[1]};
+        constexpr int KS = FirstLayer<D>::KS;                                           // two first-layer k-steps for D <= 4, four for D <= 8 (Acrobot)
+        float xk[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xk[s] = cur.xk[s];
         // ---- S2: h1 tile w ----
         f32x16 h1w;
         {
@@ -154,14 +157,14 @@ __device__ __forceinline__ void grad_body_wide(const GradArgs& a, float* smem) {
                 h1w[4 * q + 0] = b[0]; h1w[4 * q + 1] = b[1]; h1w[4 * q + 2] = b[2]; h1w[4 * q + 3] = b[3];
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
+            for (int s = 0; s < KS; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
             tanh16(h1w);
         }
         store_breg(XA, w, h1w, lane);
         store_image_tile(TA, w, h1w, lane);
         if (w == 0) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
+            for (int s = 0; s < KS; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
         }
         STAMP(0);
         f32x4 afw[4];
@@ -453,7 +456,7 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
 
     const int g = (int)(blockIdx.x % a.G);
     const int64_t ntiles = (a.count + kTile - 1) / kTile;
-    TileIn<O> cur, nxt;
+    TileIn<O, FirstLayer<D>::KS> cur, nxt;
     int64_t tile = g;
     if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
 #ifdef DRIL_STAMPS
@@ -463,7 +466,10 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
     for (; tile < ntiles; tile += a.G) {
         unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
         const bool valid = cur.valid;
-        const float xk[2] = {cur.xk[0], cur.xk[1]};
+        constexpr int KS = FirstLayer<D>::KS;                                           // two first-layer k-steps for D <= 4, four for D <= 8 (Acrobot)
+        float xk[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xk[s] = cur.xk[s];
         // ---- h1 tile w; its pieces into the workgroup image ----
         f32x16 h1w;
         {
@@ -473,14 +479,14 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
                 h1w[4 * q + 0] = b[0]; h1w[4 * q + 1] = b[1]; h1w[4 * q + 2] = b[2]; h1w[4 * q + 3] = b[3];
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
+            for (int s = 0; s < KS; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
             tanh16_scaled<false>(h1w, 1.0f);                                          // kActScale h1
         }
         // `opaque(lane)`: the image addresses are lane constants, and hoisted out of the tile loop as loop invariants they hold ~60 registers for the whole kernel (they cost 2-3 VALU to rebuild)
         store_tile_pieces2<H>(P1, w, h1w, opaque(lane));
         if (w == 0) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
+            for (int s = 0; s < KS; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
         }
         STAMP(0);
         u32x4 afw[2][2];
@@ -679,7 +685,7 @@ hipError_t launch_ppo_grad_wide(int kind, int hidden, const GradArgs& a, hipStre
         ppo_grad_wide_split_kernel<K, HH><<<2 * a.G, HH * 2, lds, s>>>(a);                                    \
     }
 #define CALLWSH(K) { if (hidden == 256) CALLWS(K, 256) else if (hidden == 128) CALLWS(K, 128) else return hipErrorInvalidValue; }
-        if (kind == 0) CALLWSH(0) else if (kind == 3) CALLWSH(3) else if (kind == 4) CALLWSH(4) else CALLWSH(1)
+        if (kind == 0) CALLWSH(0) else if (kind == 3) CALLWSH(3) else if (kind == 4) CALLWSH(4) else if (kind == 6) CALLWSH(6) else CALLWSH(1)
 #undef CALLWSH
 #undef CALLWS
         return hipGetLastError();
@@ -694,7 +700,7 @@ hipError_t launch_ppo_grad_wide(int kind, int hidden, const GradArgs& a, hipStre
     }
 #define CALLWK(K, HH) { if (a.rec) CALLW(K, HH, true) else CALLW(K, HH, false) }
 #define CALLWH(K) { if (hidden == 256) CALLWK(K, 256) else if (hidden == 128) CALLWK(K, 128) else return hipErrorInvalidValue; }
-    if (kind == 0) CALLWH(0) else if (kind == 3) CALLWH(3) else if (kind == 4) CALLWH(4) else CALLWH(1)
+    if (kind == 0) CALLWH(0) else if (kind == 3) CALLWH(3) else if (kind == 4) CALLWH(4) else if (kind == 6) CALLWH(6) else CALLWH(1)
 #undef CALLWH
 #undef CALLWK
 #undef CALLW

@@ -1287,7 +1287,7 @@ template <int KIND, int H, bool WIDE> static size_t fwd_lds_bytes() {
         else if ((kind) == 1 || (kind) == 2) DRIL_DISPATCH_H(1, hidden, CALL)        \
         else if ((kind) == 3) DRIL_DISPATCH_H(3, hidden, CALL)                       \
         else if ((kind) == 4) DRIL_DISPATCH_H(4, hidden, CALL)                       \
-        else if ((kind) == 6 && (hidden) == 64) { CALL(6, 64); }                     \
+        else if ((kind) == 6) DRIL_DISPATCH_H(6, hidden, CALL)                       \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
@@ -1299,7 +1299,7 @@ template <int KIND, int H, bool WIDE> static size_t fwd_lds_bytes() {
         else if ((kind) == 2) DRIL_DISPATCH_H(2, hidden, CALL)                       \
         else if ((kind) == 3) DRIL_DISPATCH_H(3, hidden, CALL)                       \
         else if ((kind) == 4) DRIL_DISPATCH_H(4, hidden, CALL)                       \
-        else if ((kind) == 6 && (hidden) == 64) { CALL(6, 64); }                     \
+        else if ((kind) == 6) DRIL_DISPATCH_H(6, hidden, CALL)                       \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 

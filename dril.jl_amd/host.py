@@ -100,7 +100,7 @@ class MountainCarEnv:
 
 @dataclass
 class AcrobotEnv:
-    """Acrobot-v1 (Gymnasium "book" dynamics; ClassicControlEnvironments.jl in the reference): six observation dims: fused kernels at hidden [64,64], generic kernels otherwise"""
+    """Acrobot-v1 (Gymnasium "book" dynamics; ClassicControlEnvironments.jl in the reference): six observation dims: the fused kernels at hidden [64,64] / [128,128] / [256,256] (four first-layer k-steps), generic kernels otherwise"""
     max_steps: int = 500
     action_start: int = 1
     kind: int = capi.ENV_ACROBOT

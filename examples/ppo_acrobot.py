@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""PPO on Acrobot-v1 as a DEVICE env (six observation dims: fused kernels at hidden [64,64] since round 3 — four first-layer k-steps, ppo_grad_pair_kernel from 65 536 samples per minibatch —, the generic kernels for any other hidden_dims; DRIL_FORCE_GENERIC=1 runs this example on them).
+"""PPO on Acrobot-v1 as a DEVICE env (six observation dims: fused kernels at hidden [64,64], [128,128], [256,256] since round 3 — four first-layer k-steps, ppo_grad_pair_kernel from 65 536 samples per minibatch —, the generic kernels for any other hidden_dims; DRIL_FORCE_GENERIC=1 runs this example on them).
 
 usage: python examples/ppo_acrobot.py [n_envs=1024] [iterations=40]"""
 import sys

@@ -645,7 +645,7 @@ def test_stepwise_path_equals_persistent_kernel(pkg, monkeypatch):
 # ---- hidden_dims = [256, 256] (BASELINE configs[2]) and [128, 128]: wide forward (W2 streamed from L2) and the workgroup-cooperative grad
 # kernel (H / 32 waves per workgroup) ----
 @pytest.mark.parametrize("H", [256, 128])
-@pytest.mark.parametrize("kind,B", [(1, 100), (0, 33), (3, 70), (4, 45)])
+@pytest.mark.parametrize("kind,B", [(1, 100), (0, 33), (3, 70), (4, 45), (6, 77)])      # 6 = Acrobot-v1 (D = 6: four first-layer k-steps in the wide kernels, end of round 3)
 def test_wide_forward_evaluate(pkg, oracle_mod, kind, B, H):
     cfg = _cfg(pkg, kind, n_envs=2, n_steps=2, batch_size=2, hidden1=H, hidden2=H)
     h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
@@ -654,10 +654,10 @@ def test_wide_forward_evaluate(pkg, oracle_mod, kind, B, H):
     flat = _params(h.P, 3, 0.12); h.set_params(flat); o.set_params(flat)
     rng = np.random.default_rng(B)
     obs = rng.uniform(-2, 2, (B, h.D)).astype(np.float32)
-    noise = rng.random(B) if kind == 0 else rng.standard_normal((B, h.A)).astype(np.float32)
+    noise = rng.random(B) if kind in (0, 6) else rng.standard_normal((B, h.A)).astype(np.float32)
     ah, vh, lh = h.policy_forward(obs, noise); ao, vo, lo = o.policy_forward(obs, noise)
     np.testing.assert_allclose(vh, vo, atol=5e-5, rtol=5e-5)
-    if kind == 0:
+    if kind in (0, 6):
         assert (ah == ao).mean() >= 0.99
     else:
         np.testing.assert_allclose(ah, ao, atol=5e-5, rtol=5e-5)
@@ -667,7 +667,7 @@ def test_wide_forward_evaluate(pkg, oracle_mod, kind, B, H):
 
 
 @pytest.mark.parametrize("H", [256, 128])
-@pytest.mark.parametrize("kind,B,variant", [(1, 64, "default"), (1, 1000, "ent_vfclip"), (0, 333, "default"), (3, 200, "default"), (4, 129, "ent_vfclip")])
+@pytest.mark.parametrize("kind,B,variant", [(1, 64, "default"), (1, 1000, "ent_vfclip"), (0, 333, "default"), (3, 200, "default"), (4, 129, "ent_vfclip"), (6, 150, "ent_vfclip"), (6, 16403, "default")])   # Acrobot: three-quad records; 16 403 samples = the wide split kernel by the size rule
 def test_wide_ppo_loss_and_gradient(pkg, oracle_mod, kind, B, variant, H):
     kw = dict(n_envs=2, n_steps=2, batch_size=2, hidden1=H, hidden2=H)
     if variant == "ent_vfclip":

@@ -158,7 +158,7 @@ def test_full_size_minibatch_is_the_weighted_mean_of_its_halves(pkg, kind, H, va
     h.close()
 
 
-@pytest.mark.parametrize("kind,H,E,T", [(0, 64, 2048, 128), (1, 64, 2048, 128), (1, 256, 512, 64), (0, 128, 512, 64)])
+@pytest.mark.parametrize("kind,H,E,T", [(0, 64, 2048, 128), (1, 64, 2048, 128), (1, 256, 512, 64), (0, 128, 512, 64), (6, 256, 512, 64), (6, 128, 512, 64)])
 def test_selected_kernel_update_vs_oracle(pkg, oracle_mod, kind, H, E, T):
     """one dril_ppo_update (2 epochs x 2 minibatches of N/2 samples: 131 072 at hidden 64, i.e. the pair kernel by the size rule) on the oracle's rollout and an
     injected DataLoader order: statistics and parameters after four Adam steps against orc_ppo_update"""
