@@ -414,10 +414,12 @@ _SAC_STAT_KEYS = ("actor_losses", "critic_losses", "entropy_losses", "entropy_co
 def sac_train_(agent: SACAgent, env, alg: SAC, max_steps: int, *, replay_buffer: Optional[ReplayBuffer] = None, callbacks=None):
     """train!(agent, env, alg::SAC, max_steps) sac.jl:406-549 -> (agent, replay_buffer, training_stats, timer); `env` is a
     DeviceParallelEnv over PendulumEnv.  training_stats carries the fields of SACTrainingStats (sac.jl:243-257)."""
-    if callbacks:
-        raise NotImplementedError("callbacks need the step-granular path; not wired for SAC")
     if getattr(env, "kind", None) == capi.ENV_EXTERNAL:
+        if callbacks:
+            raise NotImplementedError("callbacks over host envs: drive _sac_train_host's loop yourself (collect on the host, h.ext_push, h.update)")
         return _sac_train_host(agent, env, alg, max_steps, replay_buffer)
+    if callbacks:
+        return _sac_train_callbacks(agent, env, alg, max_steps, replay_buffer, list(callbacks))
     t0 = time.perf_counter()
     rb = replay_buffer or ReplayBuffer(env.observation_space(), env.action_space(), alg.buffer_capacity)     # sac.jl:411
     cfg = make_sac_config(env.env, env.n_envs, alg, agent.layer, seed=env.seed, device=env._kw.get("device", 0), profile_events=env._kw.get("profile_events", False))
@@ -442,6 +444,83 @@ def sac_train_(agent: SACAgent, env, alg: SAC, max_steps: int, *, replay_buffer:
     agent.q_target_parameters = h.get_target_params()
     agent.log_ent_coef = h.get_log_ent_coef()
     return agent, rb, ts, {"training_loop": time.perf_counter() - t0, "iterations": iters}
+
+
+def _jl_div(a: int, b: int) -> int:
+    """Julia's div: truncation toward zero"""
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b >= 0) else -q
+
+
+def _sac_train_callbacks(agent: SACAgent, env, alg: SAC, max_steps: int, replay_buffer: Optional[ReplayBuffer], cbs: list):
+    """train!(agent, replay_buffer, env, alg::SAC, max_steps; callbacks) (sac.jl:428-559) step by step, so that the hooks run where the reference runs them:
+    on_training_start (:476-483), on_rollout_start (:488-495), on_step before every env step of the collection (off_policy_collection.jl:44-49), on_rollout_end
+    (:508-515), on_training_end (:545-552).  Each gets a dict of the reference's locals; a false return stops the training and — as in the reference — the early
+    returns are (agent, replay_buffer, training_stats) without the timer.  Differences: the transitions of a collection that on_step interrupted are already in
+    the device ring (the reference drops that partial rollout), and one env step is one `dril_sac_collect_rollout(1)` (a drain per step: callbacks want the state)."""
+    hook = lambda name, loc: all(getattr(c, name)(loc) for c in cbs if hasattr(c, name))
+    step_hooks = [c for c in cbs if hasattr(c, "on_step")]
+    t0 = time.perf_counter()
+    rb = replay_buffer or ReplayBuffer(env.observation_space(), env.action_space(), alg.buffer_capacity)
+    cfg = make_sac_config(env.env, env.n_envs, alg, agent.layer, seed=env.seed, device=env._kw.get("device", 0), profile_events=env._kw.get("profile_events", False))
+    h = rb.handle if rb.handle is not None else SacHandle(cfg)
+    rb.handle = h
+    h.set_params(sac_flatten_params(agent.parameters)); h.set_target_params(agent.q_target_parameters); h.set_log_ent_coef(agent.log_ent_coef)
+    h.env_reset(env.seed)
+    E = env.n_envs
+    total_start = alg.start_steps if alg.start_steps > 0 else alg.train_freq * E              # sac.jl:456-458
+    adjusted = max(1, _jl_div(total_start, E)) * E
+    n_steps = _jl_div(adjusted, E)
+    iterations = _jl_div(max_steps - adjusted, alg.train_freq * E) + 1                          # :463
+    total_steps = n_steps * E + alg.train_freq * E * (iterations - 1)
+    ts = {k: [] for k in _SAC_STAT_KEYS}
+    loc = dict(agent=agent, replay_buffer=rb, env=env, alg=alg, max_steps=max_steps, callbacks=cbs, n_envs=E, layer=agent.layer, training_stats=ts,
+               gradient_updates_performed=0, total_start_steps=total_start, adjusted_total_start_steps=adjusted, n_steps=n_steps, training_iteration=0,
+               iterations=iterations, total_steps=total_steps, update_entropy_coef=isinstance(alg.ent_coef, AutoEntropyCoefficient))
+    done_updates = 0
+
+    def sync_agent():
+        agent.parameters = sac_unflatten_params(h.get_params(), agent.parameters)
+        agent.q_target_parameters = h.get_target_params()
+        agent.log_ent_coef = h.get_log_ent_coef()
+
+    try:
+        if not hook("on_training_start", loc):
+            return agent, rb, ts
+        for it in range(1, max(iterations, 0) + 1):
+            loc.update(training_iteration=it, n_steps=n_steps)
+            if not hook("on_rollout_start", loc):
+                return agent, rb, ts
+            use_random = it == 1 and alg.start_steps > 0
+            a = time.perf_counter()
+            for i in range(1, n_steps + 1):
+                loc.update(i=i, use_random_actions=use_random)
+                if step_hooks and not all(c.on_step(loc) for c in step_hooks):
+                    return agent, rb, ts                                                          # "Collecting rollout stopped due to callback failure", :502-505
+                h.collect_rollout(1, use_random)
+            fps = n_steps * E / max(time.perf_counter() - a, 1e-9)
+            loc.update(fps=fps, success=True)
+            if not hook("on_rollout_end", loc):
+                return agent, rb, ts
+            ts["fps"].append(fps)
+            agent.steps_taken += n_steps * E
+            n_steps = alg.train_freq                                                              # :521
+            n_upd = get_gradient_steps(alg, alg.train_freq, E)
+            for s_ in (h.update(n_upd) if n_upd > 0 else []):
+                ts["actor_losses"].append(s_.actor_loss); ts["critic_losses"].append(s_.critic_loss)
+                if s_.has_entropy_loss:
+                    ts["entropy_losses"].append(s_.entropy_loss)
+                ts["entropy_coefficients"].append(s_.entropy_coefficient); ts["q_values"].append(s_.mean_q_values)
+                ts["learning_rates"].append(alg.learning_rate); ts["grad_norms"].append(s_.grad_norm)
+                done_updates += 1
+            agent.gradient_updates += n_upd
+            loc.update(gradient_updates_performed=done_updates, n_updates=n_upd)
+        timer = {"training_loop": time.perf_counter() - t0, "iterations": max(iterations, 0)}
+        if not hook("on_training_end", loc):
+            return agent, rb, ts, timer                                                           # :548-550 (this one returns the timer too)
+        return agent, rb, ts, timer
+    finally:
+        sync_agent()                                                                              # the reference mutates the agent's train_state in place: every exit leaves the trained weights in it
 
 
 def _sac_train_host(agent: SACAgent, env, alg: SAC, max_steps: int, replay_buffer: Optional[ReplayBuffer] = None):

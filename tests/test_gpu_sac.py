@@ -273,6 +273,52 @@ def test_host_mirror_and_config5_shape(pkg):
     assert np.abs(rb.actions).max() <= 2.0
 
 
+def test_sac_callbacks_run_where_the_reference_runs_them(pkg):
+    """train!(...; callbacks) for SAC (sac.jl:476-552, off_policy_collection.jl:44-49): the five hooks fire in the reference's places with its locals, the
+    step-by-step loop they need is bit-identical to the sync-free loop of the callback-less train, and a false return stops the training with the reference's
+    early-return shape (no timer) and the partially trained weights in the agent"""
+    E = 64
+
+    def fresh():
+        env = pkg.DeviceParallelEnv(pkg.PendulumEnv(max_steps=200), E, seed=7)
+        alg = pkg.SAC(start_steps=3 * E, buffer_capacity=10_000, batch_size=64)
+        layer = pkg.SACLayer(env.observation_space(), env.action_space(), hidden_dims=(64, 64))
+        return env, alg, pkg.SACAgent(layer, alg, seed=2)
+
+    class Rec:
+        def __init__(self, stop_at=None):
+            self.n = dict(training_start=0, rollout_start=0, step=0, rollout_end=0, training_end=0); self.stop_at = stop_at; self.seen = {}
+        def on_training_start(self, loc):
+            self.n["training_start"] += 1; self.seen["start"] = set(loc); return True
+        def on_rollout_start(self, loc):
+            self.n["rollout_start"] += 1; return self.stop_at is None or loc["training_iteration"] < self.stop_at
+        def on_step(self, loc):
+            self.n["step"] += 1; self.seen["step"] = set(loc); return True
+        def on_rollout_end(self, loc):
+            self.n["rollout_end"] += 1; assert loc["fps"] > 0; return True
+        def on_training_end(self, loc):
+            self.n["training_end"] += 1; return True
+
+    max_steps = 3 * E + 9 * E                                     # 3 start steps, then 9 more iterations of train_freq = 1
+    env, alg, agent = fresh(); ref_agent, ref_rb, ref_stats, _ = pkg.sac_train_(agent, env, alg, max_steps)
+    env, alg, agent = fresh(); cb = Rec()
+    out = pkg.sac_train_(agent, env, alg, max_steps, callbacks=[cb])
+    assert len(out) == 4
+    agent, rb, stats, timer = out
+    assert cb.n == dict(training_start=1, rollout_start=10, step=3 + 9, rollout_end=10, training_end=1) and timer["iterations"] == 10
+    assert {"agent", "replay_buffer", "env", "alg", "max_steps", "callbacks", "n_envs", "iterations", "total_steps", "n_steps", "training_stats"} <= cb.seen["start"]
+    assert {"i", "use_random_actions", "training_iteration"} <= cb.seen["step"]
+    np.testing.assert_array_equal(pkg.sac_flatten_params(agent.parameters), pkg.sac_flatten_params(ref_agent.parameters))
+    assert stats["critic_losses"] == ref_stats["critic_losses"] and len(stats["fps"]) == 10
+    assert agent.steps_taken == ref_agent.steps_taken == 12 * E and agent.gradient_updates == ref_agent.gradient_updates == 10
+    np.testing.assert_array_equal(rb.rewards, ref_rb.rewards)
+    # a hook that says no at the start of iteration 4
+    env, alg, agent = fresh(); before = pkg.sac_flatten_params(agent.parameters).copy(); cb = Rec(stop_at=4)
+    out = pkg.sac_train_(agent, env, alg, max_steps, callbacks=[cb])
+    assert len(out) == 3 and cb.n["rollout_start"] == 4 and cb.n["rollout_end"] == 3 and cb.n["training_end"] == 0
+    assert len(out[2]["critic_losses"]) == 3 and not np.array_equal(pkg.sac_flatten_params(out[0].parameters), before)
+
+
 def test_critic_learns_fixed_targets(pkg):
     """learning signal: on a fixed replay with terminated transitions only (target = reward), the critic loss falls by > 10x"""
     h, _, layer, _ = make_pair(pkg, hidden=(64, 64), B=128, learning_rate=3e-3, ent_coef=pkg.FixedEntropyCoefficient(0.01))
