@@ -415,9 +415,7 @@ def sac_train_(agent: SACAgent, env, alg: SAC, max_steps: int, *, replay_buffer:
     """train!(agent, env, alg::SAC, max_steps) sac.jl:406-549 -> (agent, replay_buffer, training_stats, timer); `env` is a
     DeviceParallelEnv over PendulumEnv.  training_stats carries the fields of SACTrainingStats (sac.jl:243-257)."""
     if getattr(env, "kind", None) == capi.ENV_EXTERNAL:
-        if callbacks:
-            raise NotImplementedError("callbacks over host envs: drive _sac_train_host's loop yourself (collect on the host, h.ext_push, h.update)")
-        return _sac_train_host(agent, env, alg, max_steps, replay_buffer)
+        return _sac_train_host(agent, env, alg, max_steps, replay_buffer, list(callbacks or []))
     if callbacks:
         return _sac_train_callbacks(agent, env, alg, max_steps, replay_buffer, list(callbacks))
     t0 = time.perf_counter()
@@ -523,9 +521,14 @@ def _sac_train_callbacks(agent: SACAgent, env, alg: SAC, max_steps: int, replay_
         sync_agent()                                                                              # the reference mutates the agent's train_state in place: every exit leaves the trained weights in it
 
 
-def _sac_train_host(agent: SACAgent, env, alg: SAC, max_steps: int, replay_buffer: Optional[ReplayBuffer] = None):
+def _sac_train_host(agent: SACAgent, env, alg: SAC, max_steps: int, replay_buffer: Optional[ReplayBuffer] = None, cbs: Optional[list] = None):
     """train!(agent, replay_buffer, env, alg::SAC, max_steps) (sac.jl:428-559) over the caller's own envs (HostParallelEnv): the envs step on the
-    host, the policy, the replay ring and every gradient step live on the device (DRIL_ENV_EXTERNAL: dril_sac_predict_actions + dril_sac_ext_push)"""
+    host, the policy, the replay ring and every gradient step live on the device (DRIL_ENV_EXTERNAL: dril_sac_predict_actions + dril_sac_ext_push).
+    `cbs`: callbacks with the reference's five hooks in the reference's places (see _sac_train_callbacks); a false return ends the training with the
+    reference's early-return shape (agent, replay_buffer, training_stats), the trained weights in the agent"""
+    cbs = cbs or []
+    hook = lambda name, loc: all(getattr(c, name)(loc) for c in cbs if hasattr(c, name))
+    step_hooks = [c for c in cbs if hasattr(c, "on_step")]
     t0 = time.perf_counter()
     E, asp = env.n_envs, env.action_space()
     rb = replay_buffer or ReplayBuffer(env.observation_space(), asp, alg.buffer_capacity)
@@ -544,10 +547,32 @@ def _sac_train_host(agent: SACAgent, env, alg: SAC, max_steps: int, replay_buffe
     total = n_upd = 0
     t_env = t_dev = 0.0
     obs = np.stack(env.observe())
+    loc = dict(agent=agent, replay_buffer=rb, env=env, alg=alg, max_steps=max_steps, callbacks=cbs, n_envs=E, layer=agent.layer, training_stats=ts,
+               gradient_updates_performed=0, total_start_steps=total_start, adjusted_total_start_steps=adjusted, n_steps=n_steps, training_iteration=0,
+               iterations=iterations, total_steps=n_steps * E + alg.train_freq * E * (iterations - 1))
+
+    def leave(early):
+        agent.steps_taken += total
+        agent.gradient_updates += n_upd
+        agent.parameters = sac_unflatten_params(h.get_params(), agent.parameters)
+        agent.q_target_parameters = h.get_target_params()
+        agent.log_ent_coef = h.get_log_ent_coef()
+        timer = {"training_loop": time.perf_counter() - t0, "iterations": max(iterations, 0), "collect_rollout": t_env, "device": t_dev}
+        return (agent, rb, ts) if early else (agent, rb, ts, timer)
+
+    if not hook("on_training_start", loc):
+        return leave(True)
     for it in range(max(iterations, 0)):
         use_random = it == 0 and alg.start_steps > 0                                                # :487
+        loc.update(training_iteration=it + 1, n_steps=n_steps)
+        if not hook("on_rollout_start", loc):
+            return leave(True)
         a = time.perf_counter()
-        for _ in range(n_steps):                                                                    # collect_trajectories, off_policy_collection.jl:28-96
+        for i_step in range(n_steps):                                                               # collect_trajectories, off_policy_collection.jl:28-96
+            if step_hooks:
+                loc.update(i=i_step + 1, use_random_actions=use_random)
+                if not all(c.on_step(loc) for c in step_hooks):
+                    return leave(True)
             if use_random:
                 stored = env_act = rng.uniform(low, high, (E, h.A)).astype(np.float32)              # rand(rng, act_space): env space, stored as is (:50-53,72)
             else:
@@ -566,8 +591,12 @@ def _sac_train_host(agent: SACAgent, env, alg: SAC, max_steps: int, replay_buffe
             t_dev += time.perf_counter() - b
             obs = nobs
         t_env += time.perf_counter() - a
-        ts["fps"].append(n_steps * E / max(time.perf_counter() - a, 1e-12))
+        fps = n_steps * E / max(time.perf_counter() - a, 1e-12)
         total += n_steps * E
+        loc.update(fps=fps, success=True)
+        if not hook("on_rollout_end", loc):
+            return leave(True)
+        ts["fps"].append(fps)
         n_steps = alg.train_freq                                                                    # :520
         if n_updates > 0:
             b = time.perf_counter()
@@ -579,9 +608,6 @@ def _sac_train_host(agent: SACAgent, env, alg: SAC, max_steps: int, replay_buffe
                 ts["learning_rates"].append(alg.learning_rate); ts["grad_norms"].append(s.grad_norm)
             t_dev += time.perf_counter() - b
             n_upd += n_updates
-    agent.steps_taken += total
-    agent.gradient_updates += n_upd
-    agent.parameters = sac_unflatten_params(h.get_params(), agent.parameters)
-    agent.q_target_parameters = h.get_target_params()
-    agent.log_ent_coef = h.get_log_ent_coef()
-    return agent, rb, ts, {"training_loop": time.perf_counter() - t0, "iterations": max(iterations, 0), "collect_rollout": t_env, "device": t_dev}
+            loc.update(gradient_updates_performed=n_upd)
+    hook("on_training_end", loc)                                                                    # (a failure here still returns the timer, sac.jl:548-550)
+    return leave(False)

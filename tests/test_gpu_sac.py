@@ -476,3 +476,33 @@ def test_sac_trains_on_host_envs(pkg):
     assert len(r) == agent.steps_taken and np.isfinite(stats["critic_losses"]).all()
     assert r[-800:].mean() > r[:400].mean() + 0.5, (r[:400].mean(), r[-800:].mean())
     assert np.abs(rb.actions[:400]).max() <= 1.0 and len(stats["entropy_losses"]) == 4 * iters
+
+
+def test_sac_callbacks_on_host_envs(pkg):
+    """the same five hooks over the caller's Python envs (HostParallelEnv): counts per the schedule of sac.jl:456-466; a false on_step in the middle of a
+    collection ends the training with the reference's early-return shape and the counters / weights of what was done"""
+    E = 4
+    calls = dict(training_start=0, rollout_start=0, step=0, rollout_end=0, training_end=0)
+
+    class Cb:
+        def __init__(self, stop_step=None): self.stop_step = stop_step
+        def on_training_start(self, loc): calls["training_start"] += 1; return True
+        def on_rollout_start(self, loc): calls["rollout_start"] += 1; return True
+        def on_step(self, loc): calls["step"] += 1; return self.stop_step is None or calls["step"] < self.stop_step
+        def on_rollout_end(self, loc): calls["rollout_end"] += 1; return True
+        def on_training_end(self, loc): calls["training_end"] += 1; return True
+
+    def run(cb, max_steps=200):
+        env = pkg.HostParallelEnv([_PyPointEnv(pkg, s) for s in range(E)], seed=0)
+        alg = pkg.SAC(start_steps=40, buffer_capacity=5000, batch_size=32, gradient_steps=1)
+        agent = pkg.SACAgent(pkg.SACLayer(env.observation_space(), env.action_space(), hidden_dims=(32, 32)), alg, seed=0)
+        return pkg.sac_train_(agent, env, alg, max_steps, callbacks=[cb])
+
+    out = run(Cb())
+    iters = (200 - 40) // E + 1
+    assert len(out) == 4 and out[3]["iterations"] == iters
+    assert calls == dict(training_start=1, rollout_start=iters, step=10 + (iters - 1), rollout_end=iters, training_end=1)
+    for k in calls: calls[k] = 0
+    out = run(Cb(stop_step=14))                                              # the 14th env step = the 4th iteration after the 10-step start phase
+    assert len(out) == 3 and calls["step"] == 14 and calls["rollout_end"] == 4 and calls["training_end"] == 0
+    assert out[0].steps_taken == 13 * E and out[0].gradient_updates == 4 == len(out[2]["critic_losses"])
