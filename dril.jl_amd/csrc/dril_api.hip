@@ -127,6 +127,7 @@ struct dril_handle {
     void* comm = nullptr;
     LoopGroup* loop = nullptr;   // debug loopback communicator (dril_debug_comm_loopback)
     int64_t allreduce_calls = 0;
+    float* retry_snap = nullptr; bool no_f32_retry = false; int64_t f32_retries = 0;   // ppo_update: state before the update (for the exact-f32 redo of an update that left f16's range); DRIL_NO_F32_RETRY; how often it happened
     bool no_small_path = false, no_epoch_moments = false;   // DRIL_NO_SMALL_PATH / DRIL_NO_EPOCH_MOMENTS, latched in dril_create
     bool no_persistent = false; unsigned long long* small_xchg = nullptr; uint64_t* epoch_keys = nullptr; int epoch_keys_cap = 0; int64_t small_chunk = 16384;   // ppo_update_small_kernel (batch_size <= 64): DRIL_NO_PERSISTENT_UPDATE; per-epoch DataLoader keys on the device
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
@@ -527,6 +528,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     h->no_persistent = std::getenv("DRIL_NO_PERSISTENT_UPDATE") != nullptr; { const char* e = std::getenv("DRIL_NO_EPOCH_INDEX"); h->no_epoch_index = e && std::atoi(e) != 0; }
     if (const char* e = std::getenv("DRIL_SMALL_CHUNK")) { const long c = std::atol(e); if (c > 0) h->small_chunk = c; }   // optimiser steps per launch of ppo_update_small_kernel (tests: launch boundaries)
     h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
+    h->no_f32_retry = std::getenv("DRIL_NO_F32_RETRY") != nullptr;
     if (const char* e = std::getenv("DRIL_MOMENT_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8192) h->epoch_blocks = v; }
     // Multi-process RCCL on this platform needs dmabuf IPC: with the legacy IPC mode (the ROCr default) `hipIpcGetMemHandle` fails with "invalid argument" on a
     // host driver that only supports dmabuf, and ncclCommInitRank / the first collective across processes dies with it.  The ROCr runtime reads the variable
@@ -605,7 +607,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     }
     generic_ws_free(h->gws);
     if (h->ext_stage_rew) (void)hipHostFree(h->ext_stage_rew); if (h->ext_stage_flags) (void)hipHostFree(h->ext_stage_flags);
-    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->slabs_a, h->slabs_c, h->state,
+    void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->retry_snap, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
                     h->flags, h->last_values, h->noise_dev, h->perm_dev, h->epoch_index, h->epoch_keys, h->small_xchg, h->w2pf_actor, h->w2pf_critic, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
                     h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->e_rew_n, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->gen_tmp, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->w2p_actor, h->w2tp_actor, h->w2p_critic, h->w2tp_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
@@ -1012,7 +1014,7 @@ DRIL_EXPORT int32_t dril_debug_set_permutation(dril_handle* h, const int64_t* pe
 }
 
 namespace {
-int ppo_update(dril_handle* h, dril_ppo_stats* out) {
+int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
     const int world = comm_ready(h) ? h->cfg.world_size : 1;
     if (h->cfg.world_size > 1 && !comm_ready(h)) return fail(h, DRIL_ERR_NOT_INITIALISED, "world_size > 1 but dril_comm_init was not called");
     const int64_t N = h->N, B = h->cfg.batch_size / h->cfg.world_size;
@@ -1167,6 +1169,35 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
     if (nan == 2) return fail(h, DRIL_ERR_HIP, "ppo_update_small_kernel: the partner workgroup did not answer within the spin limit (its two workgroups must be resident together); DRIL_NO_PERSISTENT_UPDATE=1 selects the per-step kernels");
     if (nan) return fail(h, DRIL_ERR_NAN_IN_GRADS, "gradient contains nan or is not finite (ppo.jl:213-214)");
     return DRIL_OK;
+}
+// The f16-piece kernels (the default of the fused path) compute fp32-equivalent products inside f16's RANGE: a staged weight beyond ~ 350 or a gradient tile beyond
+// 65 504 / SG overflows a hi piece, and the step that meets it reports a non-finite gradient without touching the parameters.  Range is not something the reference
+// asks of its user, so such an update is taken back (parameters, Adam moments, beta powers and the counters as they were before it) and redone on the exact-f32
+// kernels; only a gradient that is non-finite there as well is an error (ppo.jl:213-214).  Costs three small device copies per update.
+int ppo_update(dril_handle* h, dril_ppo_stats* out) {
+    const bool may_retry = !h->generic && h->grad_variant < 0 && !h->no_f32_retry;
+    const int64_t adam_steps0 = h->adam_steps; const uint64_t counter0 = h->update_counter;
+    const size_t P = (size_t)h->P;
+    if (may_retry) {
+        if (!h->retry_snap) HIPCHK(h, dmalloc(&h->retry_snap, 3 * P + 4));
+        HIPCHK(h, hipMemcpyAsync(h->retry_snap, h->params, P * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->retry_snap + P, h->adam_m, P * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->retry_snap + 2 * P, h->adam_v, P * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->retry_snap + 3 * P, h->bt, 4 * 4, hipMemcpyDeviceToDevice, h->stream));
+    }
+    int rc = ppo_update_once(h, out);
+    const bool f16_kernel = h->last_variant == 4 || h->last_variant == 5 || h->last_variant == 6;
+    if (rc == DRIL_ERR_NAN_IN_GRADS && may_retry && f16_kernel) {
+        HIPCHK(h, hipMemcpyAsync(h->params, h->retry_snap, P * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->adam_m, h->retry_snap + P, P * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->adam_v, h->retry_snap + 2 * P, P * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->bt, h->retry_snap + 3 * P, 4 * 4, hipMemcpyDeviceToDevice, h->stream));
+        h->adam_steps = adam_steps0; h->update_counter = counter0; h->wimg_dirty = true;
+        const int gv = h->grad_variant; h->grad_variant = 0;                            // the exact-f32 kernels for this update (the persistent small kernel is f16 as well: per-step path)
+        rc = ppo_update_once(h, out);
+        h->grad_variant = gv; h->f32_retries += 1;
+    }
+    return rc;
 }
 }  // namespace
 DRIL_EXPORT int32_t dril_ppo_update(dril_handle* h, dril_ppo_stats* out) { NEED(h); return ppo_update(h, out); }

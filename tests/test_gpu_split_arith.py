@@ -97,29 +97,50 @@ def test_f16_pieces_across_the_operand_range(pkg, oracle_mod, kind, H, scale):
     assert lh == pytest.approx(lo, rel=1e-4) and rel <= 2e-4
 
 
-def test_f16_overflow_is_a_reported_non_finite_gradient(pkg, oracle_mod):
-    """what f32 has and the f16 pieces do not is range: a staged weight beyond ~ 350 overflows its hi piece.  The documented behaviour is the
-    reference's for a non-finite gradient — an error (ppo.jl:213-214), never a silently wrong update; the exact-f32 kernels (DRIL_GRAD_VARIANT=0) take the same weights"""
+def test_an_update_outside_the_f16_range_is_redone_on_the_exact_f32_kernels(pkg, oracle_mod, monkeypatch):
+    """what f32 has and the f16 pieces do not is range: a staged weight beyond ~ 350 overflows its hi piece, and the step that meets it reports a non-finite
+    gradient without touching the parameters.  dril_ppo_update then takes the update back (parameters, Adam moments, beta powers, counters) and redoes it on the
+    exact-f32 kernels (dril_api.hip ppo_update): the result is the one DRIL_GRAD_VARIANT=0 gives from the same state, bit for bit, and equals the oracle's; with
+    DRIL_NO_F32_RETRY=1 the non-finite gradient surfaces as the reference's error (ppo.jl:213-214) — never a silently wrong update"""
     capi = pkg._capi
-    cfg = _cfg(pkg, 0, n_envs=4096, n_steps=64, batch_size=4096 * 64 // 2, epochs=1, episode_len=25)
+    cfg = _cfg(pkg, 0, n_envs=4096, n_steps=64, batch_size=4096 * 64 // 2, epochs=2, episode_len=25)
     o = oracle_mod.Oracle(cfg)
     flat = (np.random.default_rng(5).standard_normal(o.P) * 0.3).astype(np.float32)
     o.set_params(flat); o.env_reset(3); o.collect_rollout()
     big = flat.copy(); big[4 * 64 + 64 + 5] = 1000.0                                  # one W2 entry of the actor
-    for variant, fails in ((None, True), ("0", False)):
+    perm = np.stack([np.random.default_rng(e).permutation(4096 * 64) for e in range(2)]).astype(np.int64)
+
+    def run(variant, no_retry=False):
+        if no_retry:
+            monkeypatch.setenv("DRIL_NO_F32_RETRY", "1")
         with split_budget.grad_variant(variant):
             h = pkg.Handle(cfg)
+        monkeypatch.delenv("DRIL_NO_F32_RETRY", raising=False)
         h.set_params(big)
         for which in BUFS:
             h.set_buffer(getattr(capi, which), o.buffer(getattr(capi, which)))
-        if fails:
-            with pytest.raises(Exception) as ei:
-                h.ppo_update()
-            assert "nan" in str(ei.value).lower() and h.grad_kernel_info().split(":")[0] == "ppo_grad_pair_kernel"
-        else:
-            st = h.ppo_update()
-            assert np.isfinite(st.loss) and np.isfinite(st.grad_norm) and h.grad_kernel_info().split(":")[0] == "ppo_grad_kernel"
-        h.close()
+        h.set_permutation(perm)
+        return h
+
+    h = run(None, no_retry=True)
+    with pytest.raises(Exception) as ei:
+        h.ppo_update()
+    assert "nan" in str(ei.value).lower() and h.grad_kernel_info().split(":")[0] == "ppo_grad_pair_kernel"
+    np.testing.assert_array_equal(h.get_params(), big)                                # the step that met the overflow did not touch the parameters
+    h.close()
+    ha, hb = run(None), run("0")
+    sa, sb = ha.ppo_update(), hb.ppo_update()
+    assert ha.grad_kernel_info().split(":")[0] == hb.grad_kernel_info().split(":")[0] == "ppo_grad_kernel"
+    assert (sa.n_updates, sa.loss, sa.grad_norm) == (sb.n_updates, sb.loss, sb.grad_norm) and sa.n_updates == 4 and np.isfinite(sa.loss)
+    np.testing.assert_array_equal(ha.get_params(), hb.get_params())
+    o.set_params(big); o.set_permutation(perm); so = o.ppo_update()
+    assert sa.loss == pytest.approx(so.loss, rel=1e-4)
+    np.testing.assert_allclose(ha.get_params(), o.get_params(), rtol=2e-4, atol=3e-6)
+    # the next update of the same handle starts from the redone state: optimiser state and counters were restored consistently
+    sa2, sb2 = ha.ppo_update(), hb.ppo_update()
+    assert np.isfinite(sa2.loss) and sa2.loss == sb2.loss
+    np.testing.assert_array_equal(ha.get_params(), hb.get_params())
+    ha.close(); hb.close()
 
 
 @pytest.mark.parametrize("kind,H,variant", [(0, 64, "ent_vfclip"), (1, 64, "default"), (1, 256, "default")])
