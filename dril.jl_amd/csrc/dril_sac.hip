@@ -1428,7 +1428,7 @@ DRIL_EXPORT int32_t dril_sac_train(dril_sac_handle* h, int64_t max_steps, dril_s
         it = 1;
     }
     while (it < iterations) {                                                                     // every later iteration collects train_freq steps (:511): chunks without a host sync inside
-        const int cnt = (int)std::min<int64_t>(h->iter_chunk, iterations - it);
+        const int cnt = (int)std::min<int64_t>(std::min<int64_t>(h->iter_chunk, std::max<int64_t>(1, 4096 / std::max<int64_t>(1, n_upd))), iterations - it);   // at most 4 096 statistics rows per drain (gradient_steps = -1 means train_freq x n_envs updates per iteration)
         SDO(run_iterations(h, cnt, (int)tf, (int)n_upd, stats ? stats + std::min<int64_t>(done, stats_capacity) : nullptr, stats ? std::max<int64_t>(0, stats_capacity - done) : 0,
                            fps && it < fps_capacity ? fps + it : nullptr, fps ? std::max<int64_t>(0, fps_capacity - it) : 0));
         done += (int64_t)cnt * n_upd; it += cnt;
@@ -1447,7 +1447,7 @@ DRIL_EXPORT int32_t dril_sac_iterate(dril_sac_handle* h, int32_t iterations, dri
     const int64_t n_upd = h->cfg.gradient_steps == -1 ? tf * E : h->cfg.gradient_steps;
     int64_t done = 0;
     for (int64_t it = 0; it < iterations; ) {
-        const int cnt = (int)std::min<int64_t>(h->iter_chunk, iterations - it);
+        const int cnt = (int)std::min<int64_t>(std::min<int64_t>(h->iter_chunk, std::max<int64_t>(1, 4096 / std::max<int64_t>(1, n_upd))), iterations - it);   // at most 4 096 statistics rows per drain (gradient_steps = -1 means train_freq x n_envs updates per iteration)
         SDO(run_iterations(h, cnt, (int)tf, (int)n_upd, stats ? stats + std::min<int64_t>(done, stats_capacity) : nullptr, stats ? std::max<int64_t>(0, stats_capacity - done) : 0,
                            fps && it < fps_capacity ? fps + it : nullptr, fps ? std::max<int64_t>(0, fps_capacity - it) : 0));
         done += (int64_t)cnt * n_upd; it += cnt;
