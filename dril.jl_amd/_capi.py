@@ -16,7 +16,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["DRIL_HIP_LIBRARY"]) if os.environ.get("DRIL_HIP_LIBRARY") else PKG_DIR / "csrc" / "libdril_hip.so"
 
 ABI_VERSION = 2
-ENV_CARTPOLE, ENV_PENDULUM, ENV_PENDULUM_SCALED, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONTINUOUS, ENV_EXTERNAL, ENV_ACROBOT = 0, 1, 2, 3, 4, 5, 6
+ENV_CARTPOLE, ENV_PENDULUM, ENV_PENDULUM_SCALED, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONTINUOUS, ENV_EXTERNAL, ENV_ACROBOT, ENV_MOUNTAINCAR_CONTINUOUS_SCALED = 0, 1, 2, 3, 4, 5, 6, 7
 (BUF_OBSERVATIONS, BUF_ACTIONS, BUF_REWARDS, BUF_ADVANTAGES, BUF_RETURNS, BUF_LOGPROBS, BUF_VALUES,
  BUF_FLAGS, BUF_BOOTSTRAP, BUF_LAST_VALUES) = range(10)
 (K_ROLLOUT, K_GAE, K_ADV_MOMENTS, K_PPO_GRAD, K_GRAD_REDUCE, K_ADAM, K_ALLREDUCE, K_COUNT) = range(8)
@@ -95,7 +95,7 @@ def default_config(env_kind: int) -> DrilConfig:
     c.env_kind = env_kind
     c.n_envs, c.n_steps = 4, 2048
     c.hidden1 = c.hidden2 = 64
-    c.episode_len = 500 if env_kind in (ENV_CARTPOLE, ENV_ACROBOT) else 999 if env_kind == ENV_MOUNTAINCAR_CONTINUOUS else 200   # the Gymnasium time limits
+    c.episode_len = 500 if env_kind in (ENV_CARTPOLE, ENV_ACROBOT) else 999 if env_kind in (ENV_MOUNTAINCAR_CONTINUOUS, ENV_MOUNTAINCAR_CONTINUOUS_SCALED) else 200   # the Gymnasium time limits
     c.fixed_length_episodes = 0
     c.action_start = 1
     c.gamma, c.gae_lambda, c.clip_range = 0.99, 0.95, 0.2

@@ -469,10 +469,10 @@ void* buf_ptr(dril_handle* h, int which, size_t* bytes) {
 
 // ================================================================================================
 DRIL_EXPORT int32_t dril_config_default(dril_config* c, int32_t env_kind) {
-    if (!c || env_kind < DRIL_ENV_CARTPOLE || env_kind > DRIL_ENV_ACROBOT) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad cfg/env_kind");
+    if (!c || env_kind < DRIL_ENV_CARTPOLE || env_kind > DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad cfg/env_kind");
     std::memset(c, 0, sizeof(*c));
     c->abi_version = DRIL_ABI_VERSION; c->env_kind = env_kind; c->n_envs = 4; c->n_steps = 2048; c->hidden1 = c->hidden2 = 64;
-    c->episode_len = (env_kind == DRIL_ENV_CARTPOLE || env_kind == DRIL_ENV_ACROBOT) ? 500 : env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS ? 999 : 200; c->action_start = 1;   // the Gymnasium time limits
+    c->episode_len = (env_kind == DRIL_ENV_CARTPOLE || env_kind == DRIL_ENV_ACROBOT) ? 500 : (env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS || env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED) ? 999 : 200; c->action_start = 1;   // the Gymnasium time limits
     c->gamma = 0.99f; c->gae_lambda = 0.95f; c->clip_range = 0.2f; c->ent_coef = 0.0f; c->vf_coef = 0.5f;
     c->max_grad_norm = 0.5f; c->has_max_grad_norm = 1; c->normalize_advantage = 1; c->batch_size = 64; c->epochs = 10;
     c->learning_rate = 3.0e-4f; c->adam_beta1 = 0.9f; c->adam_beta2 = 0.999f; c->adam_eps = 1.0e-5f;
@@ -483,7 +483,7 @@ DRIL_EXPORT int32_t dril_config_default(dril_config* c, int32_t env_kind) {
 DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (!cfg || !out) return fail(nullptr, DRIL_ERR_INVALID_ARG, "null cfg/out");
     if (cfg->abi_version != DRIL_ABI_VERSION) return fail(nullptr, DRIL_ERR_INVALID_ARG, "abi_version mismatch");
-    if (cfg->env_kind < DRIL_ENV_CARTPOLE || cfg->env_kind > DRIL_ENV_ACROBOT) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
+    if (cfg->env_kind < DRIL_ENV_CARTPOLE || cfg->env_kind > DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED) return fail(nullptr, DRIL_ERR_INVALID_ARG, "unknown env_kind");
     const bool ext = cfg->env_kind == DRIL_ENV_EXTERNAL;
     if (ext && (cfg->ext_obs_dim < 1 || cfg->ext_obs_dim > 1024 || cfg->ext_action_dim < 1 || cfg->ext_action_dim > 64)) return fail(nullptr, DRIL_ERR_INVALID_ARG, "DRIL_ENV_EXTERNAL: ext_obs_dim must be 1..1024 and ext_action_dim 1..64");
     // hidden_dims / activation: n_hidden == 0 is the two-layer form (hidden1, hidden2); otherwise hidden[0 .. n_hidden-1]
@@ -505,7 +505,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     switch (cfg->env_kind) {
         case DRIL_ENV_CARTPOLE: h->discrete = true; h->D = 4; h->A = 2; h->S = 4; break;
         case DRIL_ENV_MOUNTAINCAR: h->discrete = true; h->D = 2; h->A = 3; h->S = 2; break;
-        case DRIL_ENV_MOUNTAINCAR_CONTINUOUS: h->discrete = false; h->D = 2; h->A = 1; h->S = 2; break;
+        case DRIL_ENV_MOUNTAINCAR_CONTINUOUS: case DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED: h->discrete = false; h->D = 2; h->A = 1; h->S = 2; break;
         case DRIL_ENV_ACROBOT: h->discrete = true; h->D = 6; h->A = 3; h->S = 4; h->generic = !fused_shape; break;   // six observation dims: four first-layer k-steps and three-quad records in every fused kernel (round 3)
         case DRIL_ENV_EXTERNAL: h->discrete = cfg->ext_discrete != 0; h->D = cfg->ext_obs_dim; h->A = cfg->ext_action_dim; h->S = 0; h->external = true; h->generic = true; break;
         default: h->discrete = false; h->D = 3; h->A = 1; h->S = 2; break;                    // Pendulum, ScalingWrapperEnv(Pendulum)

@@ -263,12 +263,13 @@ template <> struct EnvSpec<1> { static constexpr int D = 3, S = 2, A = 1; static
 template <> struct EnvSpec<2> : EnvSpec<1> {};   // ScalingWrapperEnv(PendulumEnv()): same simulator, affine maps at the boundary
 template <> struct EnvSpec<3> { static constexpr int D = 2, S = 2, A = 3; static constexpr bool discrete = true; };    // MountainCar-v0: (position, velocity), Discrete(3)
 template <> struct EnvSpec<4> { static constexpr int D = 2, S = 2, A = 1; static constexpr bool discrete = false; };   // MountainCarContinuous-v0: Box(-1, 1)
+template <> struct EnvSpec<7> : EnvSpec<4> {};   // ScalingWrapperEnv(MountainCarContinuousEnv()): same simulator, affine maps at the boundary (observations Box((-1.2, -0.07), (0.6, 0.07)) -> Box(-1, 1))
 template <> struct EnvSpec<6> { static constexpr int D = 6, S = 4, A = 3; static constexpr bool discrete = true; };    // Acrobot-v1: (cos t1, sin t1, cos t2, sin t2, w1, w2), Discrete(3); fused at [64,64] / [128,128] / [256,256] through FirstLayer<6>, generic otherwise
 // ScalingWrapperEnv (scalingWrapperEnv.jl): scale! :71-74 `(x - low) * sf - 1`, unscale! :76-79 `(x + 1) / sf + low`, sf = 2 / (high - low) :36-44
 __host__ __device__ inline float scale_to_unit(float x, float low, float high) { const float sf = 2.0f / (high - low); return (x - low) * sf - 1.0f; }
 __host__ __device__ inline float unscale_from_unit(float x, float low, float high) { const float sf = 2.0f / (high - low); return (x + 1.0f) / sf + low; }
 // bound of the agent-facing action space (ClampAdapter / TanhScaleAdapter act on action_space(env)): Box(-2,2), Box(-1,1) under the wrapper
-template <int KIND> __host__ __device__ constexpr float act_bound() { return (KIND == 2 || KIND == 4) ? 1.0f : 2.0f; }
+template <int KIND> __host__ __device__ constexpr float act_bound() { return (KIND == 2 || KIND == 4 || KIND == 7) ? 1.0f : 2.0f; }
 
 // Acrobot-v1 (Gymnasium, "book" dynamics): d(theta1, theta2, dtheta1, dtheta2)/dt under torque a on the second joint
 __host__ __device__ inline void acrobot_dsdt(const float* s, float a, float* ds) {
@@ -317,7 +318,7 @@ template <int KIND> __device__ inline void env_reset(uint64_t env_seed, uint32_t
     } else if (KIND == 6) {                                        // Acrobot: U(-0.1, 0.1)^4
 #pragma unroll
         for (int i = 0; i < 4; ++i) st[i] = u01_f32(r[i]) * 0.2f - 0.1f;
-    } else if (KIND == 3 || KIND == 4) {                           // MountainCar: position ~ U(-0.6, -0.4), velocity 0
+    } else if (KIND == 3 || KIND == 4 || KIND == 7) {              // MountainCar: position ~ U(-0.6, -0.4), velocity 0
         st[0] = u01_f32(r[0]) * 0.2f - 0.6f; st[1] = 0.f;
     } else {
         st[0] = u01_f32(r[0]) * 6.28318530717958647692f - 3.14159265358979323846f;
@@ -329,6 +330,7 @@ template <int KIND> __device__ inline void env_obs(const float* st, float* obs) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) obs[i] = st[i];
     } else if (KIND == 3 || KIND == 4) { obs[0] = st[0]; obs[1] = st[1]; }
+    else if (KIND == 7) { obs[0] = scale_to_unit(st[0], -1.2f, 0.6f); obs[1] = scale_to_unit(st[1], -0.07f, 0.07f); }   // observe(::ScalingWrapperEnv) :93-98
     else if (KIND == 6) { obs[0] = cosf(st[0]); obs[1] = sinf(st[0]); obs[2] = cosf(st[1]); obs[3] = sinf(st[1]); obs[4] = st[2]; obs[5] = st[3]; }
     else {
         obs[0] = cosf(st[0]); obs[1] = sinf(st[0]); obs[2] = st[1];
@@ -355,8 +357,9 @@ template <int KIND> __device__ inline float env_step(float* st, float act_f, int
         const bool term = (x < -2.4f) || (x > 2.4f) || (th < -0.20943951023931953f) || (th > 0.20943951023931953f);
         *terminated = fixed_len ? false : term;
         return 1.0f;
-    } else if (KIND == 3 || KIND == 4) {
+    } else if (KIND == 3 || KIND == 4 || KIND == 7) {
         // MountainCar-v0 (act_i in {0,1,2}) / MountainCarContinuous-v0 (act_f clipped to [-1,1]); Gymnasium equations
+        if (KIND == 7) act_f = unscale_from_unit(act_f, -1.0f, 1.0f);   // act!(::ScalingWrapperEnv, action) :110-113 (the same Box: the affine map is still evaluated)
         const float min_position = -1.2f, max_position = 0.6f, max_speed = 0.07f;
         float position = st[0], velocity = st[1], reward;
         float force = 0.f;

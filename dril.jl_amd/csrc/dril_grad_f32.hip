@@ -303,7 +303,7 @@ template <int KIND, int H> static size_t grad_lds_bytes() {
         if ((kind) == 0 && (hidden) == 64) { CALL(0, 64); }                          \
         else if (((kind) == 1 || (kind) == 2) && (hidden) == 64) { CALL(1, 64); }    \
         else if ((kind) == 3 && (hidden) == 64) { CALL(3, 64); }                     \
-        else if ((kind) == 4 && (hidden) == 64) { CALL(4, 64); }                     \
+        else if (((kind) == 4 || (kind) == 7) && (hidden) == 64) { CALL(4, 64); }    \
         else if ((kind) == 6 && (hidden) == 64) { CALL(6, 64); }                     \
         else return hipErrorInvalidValue;                                            \
     } while (0)

@@ -384,6 +384,7 @@ template <int KIND> static size_t grad_pair_lds_bytes() {
 }
 
 hipError_t launch_ppo_grad_pair(int kind, const GradArgs& a, hipStream_t s) {
+    if (kind == 7) kind = 4;                  // ScalingWrapperEnv(MountainCarContinuous): the update never touches the simulator
 #define CALLP(K) { const size_t lds = grad_pair_lds_bytes<K>(); static bool attr_set = false; \
         if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_pair_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
         ppo_grad_pair_kernel<K><<<(a.G + a.Gc) / 2, 256, lds, s>>>(a); }

@@ -675,6 +675,7 @@ template <int KIND, int H> static size_t grad_wide_split_lds_bytes() {
 }
 
 hipError_t launch_ppo_grad_wide(int kind, int hidden, const GradArgs& a, hipStream_t s) {
+    if (kind == 7) kind = 4;                  // ScalingWrapperEnv(MountainCarContinuous): the update never touches the simulator
     if (a.variant && a.rec) {      // bf16 matrix cores
 #define CALLWS(K, HH)                                                                                         \
     {                                                                                                         \

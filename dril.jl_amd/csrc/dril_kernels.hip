@@ -1274,7 +1274,7 @@ template <int KIND, int H, bool WIDE> static size_t fwd_lds_bytes() {
         if ((kind) == 0 && (hidden) == 64) { CALL(0, 64); }                          \
         else if (((kind) == 1 || (kind) == 2) && (hidden) == 64) { CALL(1, 64); }    \
         else if ((kind) == 3 && (hidden) == 64) { CALL(3, 64); }                     \
-        else if ((kind) == 4 && (hidden) == 64) { CALL(4, 64); }                     \
+        else if (((kind) == 4 || (kind) == 7) && (hidden) == 64) { CALL(4, 64); }    \
         else return hipErrorInvalidValue;                                            \
     } while (0)
 
@@ -1286,7 +1286,7 @@ template <int KIND, int H, bool WIDE> static size_t fwd_lds_bytes() {
         if ((kind) == 0) DRIL_DISPATCH_H(0, hidden, CALL)                            \
         else if ((kind) == 1 || (kind) == 2) DRIL_DISPATCH_H(1, hidden, CALL)        \
         else if ((kind) == 3) DRIL_DISPATCH_H(3, hidden, CALL)                       \
-        else if ((kind) == 4) DRIL_DISPATCH_H(4, hidden, CALL)                       \
+        else if ((kind) == 4 || (kind) == 7) DRIL_DISPATCH_H(4, hidden, CALL)        \
         else if ((kind) == 6) DRIL_DISPATCH_H(6, hidden, CALL)                       \
         else return hipErrorInvalidValue;                                            \
     } while (0)
@@ -1299,6 +1299,7 @@ template <int KIND, int H, bool WIDE> static size_t fwd_lds_bytes() {
         else if ((kind) == 2) DRIL_DISPATCH_H(2, hidden, CALL)                       \
         else if ((kind) == 3) DRIL_DISPATCH_H(3, hidden, CALL)                       \
         else if ((kind) == 4) DRIL_DISPATCH_H(4, hidden, CALL)                       \
+        else if ((kind) == 7) DRIL_DISPATCH_H(7, hidden, CALL)                       \
         else if ((kind) == 6) DRIL_DISPATCH_H(6, hidden, CALL)                       \
         else return hipErrorInvalidValue;                                            \
     } while (0)
@@ -1320,7 +1321,7 @@ hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a,
 hipError_t launch_env_reset(int kind, int E, uint64_t seed0, float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* dr, hipStream_t s) {
     const int blocks = (E + 255) / 256;
     if (kind == 0) env_reset_kernel<0><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
-    else if (kind == 3 || kind == 4) env_reset_kernel<3><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
+    else if (kind == 3 || kind == 4 || kind == 7) env_reset_kernel<3><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
     else if (kind == 6) env_reset_kernel<6><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
     else env_reset_kernel<1><<<blocks, 256, 0, s>>>(E, seed0, state, sc, ep, gs, dr);
     return hipGetLastError();
@@ -1331,6 +1332,7 @@ hipError_t launch_env_observe(int kind, int E, const float* state, float* obs, h
     else if (kind == 1) env_observe_kernel<1><<<blocks, 256, 0, s>>>(E, state, obs);
     else if (kind == 2) env_observe_kernel<2><<<blocks, 256, 0, s>>>(E, state, obs);
     else if (kind == 6) env_observe_kernel<6><<<blocks, 256, 0, s>>>(E, state, obs);
+    else if (kind == 7) env_observe_kernel<7><<<blocks, 256, 0, s>>>(E, state, obs);
     else env_observe_kernel<3><<<blocks, 256, 0, s>>>(E, state, obs);
     return hipGetLastError();
 }
@@ -1343,6 +1345,7 @@ hipError_t launch_env_step(int kind, int E, uint64_t seed0, int episode_len, int
     else if (kind == 2) env_step_kernel<2><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
     else if (kind == 3) env_step_kernel<3><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
     else if (kind == 6) env_step_kernel<6><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
+    else if (kind == 7) env_step_kernel<7><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
     else env_step_kernel<4><<<blocks, 256, 0, s>>>(E, seed0, episode_len, fixed_len, action_start, actions, state, sc, ep, gs, rew, term, trunc, tobs, mon);
     return hipGetLastError();
 }
@@ -1355,7 +1358,7 @@ hipError_t launch_monitor_collect(const uint8_t* flags, const float* ep_ret, con
 
 hipError_t launch_norm_step(int kind, const NormStepArgs& a, int nblocks, hipStream_t s) {
     if (kind == 0) norm_step_kernel<0><<<nblocks, 256, 0, s>>>(a); else if (kind == 1) norm_step_kernel<1><<<nblocks, 256, 0, s>>>(a); else if (kind == 2) norm_step_kernel<2><<<nblocks, 256, 0, s>>>(a);
-    else if (kind == 3) norm_step_kernel<3><<<nblocks, 256, 0, s>>>(a); else if (kind == 6) norm_step_kernel<6><<<nblocks, 256, 0, s>>>(a); else norm_step_kernel<4><<<nblocks, 256, 0, s>>>(a);
+    else if (kind == 3) norm_step_kernel<3><<<nblocks, 256, 0, s>>>(a); else if (kind == 6) norm_step_kernel<6><<<nblocks, 256, 0, s>>>(a); else if (kind == 7) norm_step_kernel<7><<<nblocks, 256, 0, s>>>(a); else norm_step_kernel<4><<<nblocks, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 hipError_t launch_norm_apply(const NormApplyArgs& a, hipStream_t s) {
@@ -1368,6 +1371,7 @@ hipError_t launch_obs_partials(int kind, int E, const float* state, float* raw, 
     else if (kind == 1) obs_partials_kernel<1><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
     else if (kind == 2) obs_partials_kernel<2><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
     else if (kind == 6) obs_partials_kernel<6><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
+    else if (kind == 7) obs_partials_kernel<7><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
     else obs_partials_kernel<3><<<nblocks, 256, 0, s>>>(E, state, raw, partials);
     return hipGetLastError();
 }
@@ -1410,12 +1414,12 @@ template <int KIND, int H> static size_t duo_lds_bytes() {
 }
 hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_t s) {
     static const bool no_duo = std::getenv("DRIL_NO_ROLLOUT_DUO") != nullptr;          // A/B knob
-    if (hidden == 64 && a.E <= 16384 && !no_duo && ((kind >= 0 && kind <= 4) || kind == 6)) {                                      // env counts that leave SIMDs idle: two waves per tile of 32 envs
+    if (hidden == 64 && a.E <= 16384 && !no_duo && ((kind >= 0 && kind <= 4) || kind == 6 || kind == 7)) {                                      // env counts that leave SIMDs idle: two waves per tile of 32 envs
         const int blocks = (a.E + kTile - 1) / kTile;
 #define CALLD(K) { const size_t lds = duo_lds_bytes<K, 64>(); static bool attr_set = false; \
             if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)rollout_duo_kernel<K, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
             rollout_duo_kernel<K, 64><<<blocks, 128, lds, s>>>(a); }
-        if (kind == 0) CALLD(0) else if (kind == 1) CALLD(1) else if (kind == 2) CALLD(2) else if (kind == 3) CALLD(3) else if (kind == 6) CALLD(6) else CALLD(4)
+        if (kind == 0) CALLD(0) else if (kind == 1) CALLD(1) else if (kind == 2) CALLD(2) else if (kind == 3) CALLD(3) else if (kind == 6) CALLD(6) else if (kind == 7) CALLD(7) else CALLD(4)
 #undef CALLD
         return hipGetLastError();
     }
@@ -1479,7 +1483,7 @@ hipError_t launch_pack_records(int kind, int64_t N, const float* obs, const void
     int blocks = (int)((N + 255) / 256); if (blocks > 8192) blocks = 8192;
     if (kind == 0) pack_records_kernel<0><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
     else if (kind == 3) pack_records_kernel<3><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
-    else if (kind == 4) pack_records_kernel<4><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
+    else if (kind == 4 || kind == 7) pack_records_kernel<4><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
     else if (kind == 6) pack_records_kernel<6><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
     else pack_records_kernel<1><<<blocks, 256, 0, s>>>(N, obs, act, adv, logp, ret, rec);
     return hipGetLastError();
@@ -1509,7 +1513,7 @@ static void kind_dims(int kind, int& D, int& A, bool& disc) {
     switch (kind) {
         case 0: D = 4; A = 2; disc = true; break;
         case 3: D = 2; A = 3; disc = true; break;
-        case 4: D = 2; A = 1; disc = false; break;
+        case 4: case 7: D = 2; A = 1; disc = false; break;
         case 6: D = 6; A = 3; disc = true; break;
         default: D = 3; A = 1; disc = false; break;
     }

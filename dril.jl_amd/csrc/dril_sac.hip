@@ -951,6 +951,7 @@ int collect_step(dril_sac_handle* h, int use_random, const float* inj_noise) {
         const dim3 grid((E + 255) / 256), block(256);
         if (h->cfg.env_kind == DRIL_ENV_PENDULUM) hipLaunchKernelGGL(sac_collect_env_kernel<1>, grid, block, 0, h->stream, ce);
         else if (h->cfg.env_kind == DRIL_ENV_PENDULUM_SCALED) hipLaunchKernelGGL(sac_collect_env_kernel<2>, grid, block, 0, h->stream, ce);
+        else if (h->cfg.env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED) hipLaunchKernelGGL(sac_collect_env_kernel<7>, grid, block, 0, h->stream, ce);
         else hipLaunchKernelGGL(sac_collect_env_kernel<4>, grid, block, 0, h->stream, ce);
         SHIP(h, hipGetLastError());
         const long long over1 = h->size + E - h->cap;
@@ -1096,9 +1097,9 @@ int params_from_device(dril_sac_handle* h, float* host, const float* dev) {
 // exported entry points (include/dril_sac.h)
 // =================================================================================================================
 DRIL_EXPORT int32_t dril_sac_config_default(dril_sac_config* c, int32_t env_kind) {
-    if (!c || (env_kind != DRIL_ENV_PENDULUM && env_kind != DRIL_ENV_PENDULUM_SCALED && env_kind != DRIL_ENV_MOUNTAINCAR_CONTINUOUS && env_kind != DRIL_ENV_EXTERNAL)) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "SAC needs a Box action space (sac.jl:74): env_kind must be DRIL_ENV_PENDULUM[_SCALED] or DRIL_ENV_EXTERNAL");
+    if (!c || (env_kind != DRIL_ENV_PENDULUM && env_kind != DRIL_ENV_PENDULUM_SCALED && env_kind != DRIL_ENV_MOUNTAINCAR_CONTINUOUS && env_kind != DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED && env_kind != DRIL_ENV_EXTERNAL)) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "SAC needs a Box action space (sac.jl:74): env_kind must be DRIL_ENV_PENDULUM[_SCALED] or DRIL_ENV_EXTERNAL");
     memset(c, 0, sizeof(*c));
-    c->abi_version = DRIL_SAC_ABI_VERSION; c->env_kind = env_kind; c->n_envs = 1; c->episode_len = env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS ? 999 : 200;
+    c->abi_version = DRIL_SAC_ABI_VERSION; c->env_kind = env_kind; c->n_envs = 1; c->episode_len = (env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS || env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED) ? 999 : 200;
     c->hidden1 = 512; c->hidden2 = 512; c->activation = 1;
     c->buffer_capacity = 1000000; c->start_steps = 100; c->batch_size = 256; c->tau = 0.005f; c->gamma = 0.99f;
     c->train_freq = 1; c->gradient_steps = 1; c->target_update_interval = 1;
@@ -1129,7 +1130,7 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     if (!cfg || !out) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "null config / out pointer");
     if (cfg->abi_version != DRIL_SAC_ABI_VERSION) return sfail(nullptr, DRIL_ERR_INVALID_ARG, "dril_sac_config.abi_version mismatch");
     const bool ext = cfg->env_kind == DRIL_ENV_EXTERNAL;
-    if (!ext && cfg->env_kind != DRIL_ENV_PENDULUM && cfg->env_kind != DRIL_ENV_PENDULUM_SCALED && cfg->env_kind != DRIL_ENV_MOUNTAINCAR_CONTINUOUS) return sfail(nullptr, DRIL_ERR_UNSUPPORTED, "SAC needs a Box action space (sac.jl:74): DRIL_ENV_PENDULUM[_SCALED] or DRIL_ENV_EXTERNAL");
+    if (!ext && cfg->env_kind != DRIL_ENV_PENDULUM && cfg->env_kind != DRIL_ENV_PENDULUM_SCALED && cfg->env_kind != DRIL_ENV_MOUNTAINCAR_CONTINUOUS && cfg->env_kind != DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED) return sfail(nullptr, DRIL_ERR_UNSUPPORTED, "SAC needs a Box action space (sac.jl:74): DRIL_ENV_PENDULUM[_SCALED] or DRIL_ENV_EXTERNAL");
     if (ext && (cfg->ext_obs_dim < 1 || cfg->ext_obs_dim > 1024 || cfg->ext_action_dim < 1 || cfg->ext_action_dim > kMaxA || !(cfg->ext_action_low < cfg->ext_action_high)))
         return sfail(nullptr, DRIL_ERR_INVALID_ARG, "DRIL_ENV_EXTERNAL: ext_obs_dim 1..1024, ext_action_dim 1..16, ext_action_low < ext_action_high");
     if (cfg->n_envs <= 0 || (!ext && cfg->episode_len <= 0) || cfg->batch_size <= 0 || cfg->buffer_capacity < cfg->n_envs || cfg->train_freq <= 0 || cfg->target_update_interval <= 0)
@@ -1143,13 +1144,13 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
 #define CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_sac_destroy(h); return sfail(nullptr, DRIL_ERR_HIP, m); } } while (0)
     CHK(hipSetDevice(cfg->device));
     CHK(hipStreamCreate(&h->stream));
-    const int D = h->D = ext ? cfg->ext_obs_dim : (cfg->env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS ? 2 : 3), A = h->A = ext ? cfg->ext_action_dim : 1, S = h->S = ext ? 0 : 2, H1 = h->H1 = cfg->hidden1, H2 = h->H2 = cfg->hidden2, E = cfg->n_envs, B = cfg->batch_size, W = D + A;
+    const int D = h->D = ext ? cfg->ext_obs_dim : ((cfg->env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS || cfg->env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED) ? 2 : 3), A = h->A = ext ? cfg->ext_action_dim : 1, S = h->S = ext ? 0 : 2, H1 = h->H1 = cfg->hidden1, H2 = h->H2 = cfg->hidden2, E = cfg->n_envs, B = cfg->batch_size, W = D + A;
     h->Pa = D * H1 + H1 + H1 * H2 + H2 + H2 * A + A; h->Pq = W * H1 + H1 + H1 * H2 + H2 + H2 + 1; h->P = h->Pa + 2 * h->Pq + A;
     h->actor = net_off(0, D, H1, H2, A); h->Pqd = round4(h->Pq); h->q0 = net_off(round4(h->actor.end), W, H1, H2, 1);
     h->log_std_off = h->q0.w1 + 4 * h->Pqd; h->Pd = round4(h->log_std_off + A);      // device layout: actor | q1 | q2 | target q1 | target q2 | log_std
     h->nq = B; h->nmax = std::max(E, 2 * B);
     h->target_entropy = cfg->auto_target_entropy ? -(float)A : cfg->target_entropy;
-    h->act_hi = (cfg->env_kind == DRIL_ENV_PENDULUM_SCALED || cfg->env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS) ? 1.0f : 2.0f; h->act_lo = -h->act_hi; h->external = ext;
+    h->act_hi = (cfg->env_kind == DRIL_ENV_PENDULUM_SCALED || cfg->env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS || cfg->env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED) ? 1.0f : 2.0f; h->act_lo = -h->act_hi; h->external = ext;
     if (ext) { h->act_lo = cfg->ext_action_low; h->act_hi = cfg->ext_action_high; }
     CHK(smalloc(&h->params, h->Pd)); CHK(smalloc(&h->adam_m, h->Pd)); CHK(smalloc(&h->adam_v, h->Pd));
     h->target = h->params + h->q0.w1 + 2 * h->Pqd;   // the targets sit right behind the critics so that one launch runs all four Q nets (blockIdx.z stride Pqd)

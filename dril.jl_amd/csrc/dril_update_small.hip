@@ -569,6 +569,7 @@ template <int KIND> static size_t update_small_lds_bytes() {
 }
 
 hipError_t launch_ppo_update_small(int kind, const SmallUpdateArgs& a, hipStream_t s) {
+    if (kind == 7) kind = 4;                  // ScalingWrapperEnv(MountainCarContinuous): the update never touches the simulator
     if (!a.xchg) return hipErrorInvalidValue;
     { hipError_t e = hipMemsetAsync(a.xchg, 0, sizeof(unsigned long long) * kSmallXchgWords, s); if (e != hipSuccess) return e; }   // sequence number 0 = no message yet
 #define CALLU(K) { const size_t lds = update_small_lds_bytes<K>(); static bool attr_set = false; \

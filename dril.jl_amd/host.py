@@ -128,12 +128,12 @@ class MountainCarContinuousEnv:
 @dataclass
 class ScalingWrapperEnv:
     """ScalingWrapperEnv(env) (src/environment_wrappers/scalingWrapperEnv.jl:15-49) around a Box/Box env: the agent-facing spaces become
-    [-1, 1]; on device the two affine maps are fused into the env kernels (env kind DRIL_ENV_PENDULUM_SCALED)."""
-    env: PendulumEnv
+    [-1, 1]; on device the two affine maps are fused into the env kernels (env kinds DRIL_ENV_PENDULUM_SCALED, DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED)."""
+    env: object
 
     def __post_init__(self):
-        if not isinstance(self.env, PendulumEnv):
-            raise NotImplementedError("ScalingWrapperEnv needs Box observation and action spaces (scalingWrapperEnv.jl:22); the device env with both is Pendulum-v1")
+        if not isinstance(self.env, (PendulumEnv, MountainCarContinuousEnv)):
+            raise NotImplementedError("ScalingWrapperEnv needs Box observation and action spaces (scalingWrapperEnv.jl:22); the device envs with both are Pendulum-v1 and MountainCarContinuous-v0")
 
     @property
     def max_steps(self) -> int:
@@ -141,7 +141,7 @@ class ScalingWrapperEnv:
 
     @property
     def kind(self) -> int:
-        return capi.ENV_PENDULUM_SCALED
+        return capi.ENV_PENDULUM_SCALED if isinstance(self.env, PendulumEnv) else capi.ENV_MOUNTAINCAR_CONTINUOUS_SCALED
 
     def unwrap(self):
         return self.env

@@ -69,7 +69,7 @@ struct DrilPPOStats
     n_updates::Int32; early_stopped::Int32; nan_or_inf::Int32; reserved::Int32
 end
 
-const ENV_KINDS = Dict(:CartPole => Int32(0), :Pendulum => Int32(1), :ScaledPendulum => Int32(2), :MountainCar => Int32(3), :MountainCarContinuous => Int32(4), :Acrobot => Int32(6))   # :ScaledPendulum = ScalingWrapperEnv(PendulumEnv()) on every sub-env (scalingWrapperEnv.jl)
+const ENV_KINDS = Dict(:CartPole => Int32(0), :Pendulum => Int32(1), :ScaledPendulum => Int32(2), :MountainCar => Int32(3), :MountainCarContinuous => Int32(4), :Acrobot => Int32(6), :ScaledMountainCarContinuous => Int32(7))   # :ScaledPendulum = ScalingWrapperEnv(PendulumEnv()) on every sub-env (scalingWrapperEnv.jl)
 
 """
     DeviceParallelEnv(kind, n_envs; max_steps, seed, fixed_length_episodes, device) <: AbstractParallelEnv
@@ -95,7 +95,7 @@ mutable struct DeviceParallelEnv <: AbstractParallelEnv
     last_kernel_seconds::Dict{String, Float64}
 end
 
-function DeviceParallelEnv(kind::Symbol, n_envs::Integer; max_steps::Integer = (kind === :CartPole || kind === :Acrobot) ? 500 : kind === :MountainCarContinuous ? 999 : 200,
+function DeviceParallelEnv(kind::Symbol, n_envs::Integer; max_steps::Integer = (kind === :CartPole || kind === :Acrobot) ? 500 : (kind === :MountainCarContinuous || kind === :ScaledMountainCarContinuous) ? 999 : 200,
         seed::Integer = 42, fixed_length_episodes::Bool = false, device::Integer = 0, monitor_window::Integer = 0,
         normalize::Union{Nothing, NamedTuple} = nothing)
     haskey(ENV_KINDS, kind) || error("unknown device env $kind")
@@ -107,13 +107,13 @@ end
 
 number_of_envs(env::DeviceParallelEnv) = env.n_envs
 is_discrete(env) = env.kind === :CartPole || env.kind === :MountainCar || env.kind === :Acrobot
-observation_space(env::DeviceParallelEnv) = env.kind === :Acrobot ? Box(Float32[-1, -1, -1, -1, -4π, -9π], Float32[1, 1, 1, 1, 4π, 9π]) : (env.kind === :MountainCar || env.kind === :MountainCarContinuous) ? Box(Float32[-1.2, -0.07], Float32[0.6, 0.07]) :
+observation_space(env::DeviceParallelEnv) = env.kind === :Acrobot ? Box(Float32[-1, -1, -1, -1, -4π, -9π], Float32[1, 1, 1, 1, 4π, 9π]) : (env.kind === :MountainCar || env.kind === :MountainCarContinuous) ? Box(Float32[-1.2, -0.07], Float32[0.6, 0.07]) : env.kind === :ScaledMountainCarContinuous ? Box(Float32[-1, -1], Float32[1, 1]) :
     env.kind === :CartPole ?
     Box(Float32[-4.8, -Inf, -0.41887903, -Inf], Float32[4.8, Inf, 0.41887903, Inf]) :
     env.kind === :ScaledPendulum ? Box(Float32[-1, -1, -1], Float32[1, 1, 1]) : Box(Float32[-1, -1, -8], Float32[1, 1, 8])
 action_space(env::DeviceParallelEnv) = env.kind === :CartPole ? Discrete(2) : (env.kind === :MountainCar || env.kind === :Acrobot) ? Discrete(3) :
-    (env.kind === :ScaledPendulum || env.kind === :MountainCarContinuous) ? Box(Float32[-1], Float32[1]) : Box(Float32[-2], Float32[2])
-obs_dim(env::DeviceParallelEnv) = env.kind === :CartPole ? 4 : env.kind === :Acrobot ? 6 : (env.kind === :MountainCar || env.kind === :MountainCarContinuous) ? 2 : 3
+    (env.kind === :ScaledPendulum || env.kind === :MountainCarContinuous || env.kind === :ScaledMountainCarContinuous) ? Box(Float32[-1], Float32[1]) : Box(Float32[-2], Float32[2])
+obs_dim(env::DeviceParallelEnv) = env.kind === :CartPole ? 4 : env.kind === :Acrobot ? 6 : (env.kind === :MountainCar || env.kind === :MountainCarContinuous || env.kind === :ScaledMountainCarContinuous) ? 2 : 3
 
 last_error(h) = unsafe_string(ccall((:dril_last_error, LIB[]), Cstring, (Ptr{Cvoid},), h))
 function check(rc::Int32, h = C_NULL)

@@ -57,7 +57,7 @@ function sac_scatter_targets!(tp, flat::Vector{Float32})
 end
 
 function sac_config(env::DeviceParallelEnv, alg::DRiL.SAC, agent)
-    is_discrete(env) && error("SAC needs a Box action space (sac.jl:74): DeviceParallelEnv(:Pendulum | :ScaledPendulum | :MountainCarContinuous, ...)")
+    is_discrete(env) && error("SAC needs a Box action space (sac.jl:74): DeviceParallelEnv(:Pendulum | :ScaledPendulum | :MountainCarContinuous | :ScaledMountainCarContinuous, ...)")
     hd = hidden_dims_of(agent.train_state.parameters)
     act = agent.layer.actor_head.layers[1].layers[1].activation === DRiL.Lux.relu ? Int32(1) : Int32(0)   # SACLayer default relu (sac.jl:77)
     ec = alg.ent_coef

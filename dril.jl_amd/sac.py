@@ -136,7 +136,7 @@ def sac_unflatten_params(flat: np.ndarray, like: dict) -> dict:
 def make_sac_config(env, n_envs: int, alg: SAC, layer: SACLayer, *, seed: int = 42, device: int = 0,
                     profile_events: bool = False) -> DrilSacConfig:
     external = getattr(env, "kind", None) == capi.ENV_EXTERNAL
-    if not external and getattr(env, "kind", None) not in (capi.ENV_PENDULUM, capi.ENV_PENDULUM_SCALED, capi.ENV_MOUNTAINCAR_CONTINUOUS):
+    if not external and getattr(env, "kind", None) not in (capi.ENV_PENDULUM, capi.ENV_PENDULUM_SCALED, capi.ENV_MOUNTAINCAR_CONTINUOUS, capi.ENV_MOUNTAINCAR_CONTINUOUS_SCALED):
         raise NotImplementedError("SAC needs a Box action space (sac.jl:74); the device envs with one are Pendulum-v1 (optionally under ScalingWrapperEnv) and MountainCarContinuous-v0")
     c = DrilSacConfig()
     c.abi_version = capi.SAC_ABI_VERSION

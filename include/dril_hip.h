@@ -65,7 +65,10 @@ enum dril_env_kind {
     /* Acrobot-v1 (Gymnasium "book" dynamics, one RK4 step of 0.2 s per env step): D=6 (cos t1, sin t1, cos t2, sin t2, w1, w2), Discrete(3) torques
      * -1/0/+1, reward -1 per step (0 on reaching the height), limit 500.  A device env like the others; hidden_dims [64,64] run the fused kernels (four
      * first-layer k-steps for its six observation dims, the exact-f32 update kernel), any other hidden_dims the generic kernels */
-    DRIL_ENV_ACROBOT = 6
+    DRIL_ENV_ACROBOT = 6,
+    /* ScalingWrapperEnv(MountainCarContinuousEnv()): observations Box((-1.2, -0.07), (0.6, 0.07)) scaled to Box(-1, 1), actions Box(-1, 1) mapped back by the same
+     * affine formulas (scalingWrapperEnv.jl:71-79); every kernel that does not touch the simulator is shared with DRIL_ENV_MOUNTAINCAR_CONTINUOUS */
+    DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED = 7
 };
 
 /* ids for dril_buffer_copy_out / dril_buffer_copy_in (fields of RolloutBuffer,

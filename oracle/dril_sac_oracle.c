@@ -131,7 +131,7 @@ ORC_API int32_t orc_sac_reset_optimizer(orc_sac* c) {
 }
 ORC_API int32_t orc_sac_create(const dril_sac_config* cfg, orc_sac** out) {
     const int ext = cfg && cfg->env_kind == DRIL_ENV_EXTERNAL;
-    if (!cfg || cfg->abi_version != DRIL_SAC_ABI_VERSION || (!ext && cfg->env_kind != DRIL_ENV_PENDULUM && cfg->env_kind != DRIL_ENV_PENDULUM_SCALED && cfg->env_kind != DRIL_ENV_MOUNTAINCAR_CONTINUOUS)) return DRIL_ERR_INVALID_ARG;
+    if (!cfg || cfg->abi_version != DRIL_SAC_ABI_VERSION || (!ext && cfg->env_kind != DRIL_ENV_PENDULUM && cfg->env_kind != DRIL_ENV_PENDULUM_SCALED && cfg->env_kind != DRIL_ENV_MOUNTAINCAR_CONTINUOUS && cfg->env_kind != DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED)) return DRIL_ERR_INVALID_ARG;
     if (ext && (cfg->ext_obs_dim < 1 || cfg->ext_obs_dim > 1024 || cfg->ext_action_dim < 1 || cfg->ext_action_dim > 16 || !(cfg->ext_action_low < cfg->ext_action_high))) return DRIL_ERR_INVALID_ARG;
     orc_sac* c = (orc_sac*)calloc(1, sizeof(orc_sac)); c->cfg = *cfg; c->es = spec_of(cfg->env_kind);
     c->act_hi = act_bound(cfg->env_kind); c->act_lo = -c->act_hi;

@@ -120,7 +120,7 @@ class Oracle:
         rc = self.L.orc_create(C.byref(cfg), C.byref(self._h))
         assert rc == 0, rc
         self.discrete = cfg.env_kind in (capi.ENV_CARTPOLE, capi.ENV_MOUNTAINCAR, capi.ENV_ACROBOT)
-        self.D, self.A, self.S = {capi.ENV_CARTPOLE: (4, 2, 4), capi.ENV_MOUNTAINCAR: (2, 3, 2), capi.ENV_MOUNTAINCAR_CONTINUOUS: (2, 1, 2), capi.ENV_ACROBOT: (6, 3, 4)}.get(cfg.env_kind, (3, 1, 2))
+        self.D, self.A, self.S = {capi.ENV_CARTPOLE: (4, 2, 4), capi.ENV_MOUNTAINCAR: (2, 3, 2), capi.ENV_MOUNTAINCAR_CONTINUOUS: (2, 1, 2), capi.ENV_MOUNTAINCAR_CONTINUOUS_SCALED: (2, 1, 2), capi.ENV_ACROBOT: (6, 3, 4)}.get(cfg.env_kind, (3, 1, 2))
         if cfg.env_kind == capi.ENV_EXTERNAL:
             self.discrete, self.D, self.A, self.S = bool(cfg.ext_discrete), cfg.ext_obs_dim, cfg.ext_action_dim, 0
         self.P = int(self.L.orc_param_count(self._h))

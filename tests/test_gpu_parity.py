@@ -76,7 +76,7 @@ def test_gae_random_vs_oracle(pkg, lib, oracle_mod):
         np.testing.assert_allclose(out[1], out[3], atol=1e-4, rtol=1e-5)
 
 
-@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 6])              # 2 = ScalingWrapperEnv(Pendulum); 3 / 4 = MountainCar-v0 / MountainCarContinuous-v0; 6 = Acrobot-v1
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 6, 7])           # 2 = ScalingWrapperEnv(Pendulum); 3 / 4 = MountainCar-v0 / MountainCarContinuous-v0; 6 = Acrobot-v1; 7 = ScalingWrapperEnv(MountainCarContinuous)
 def test_env_verbs_match_oracle(pkg, oracle_mod, kind):
     """reset!/observe/act! with auto-reset and terminal_observation (multithreadedParallelEnv.jl:12-74)"""
     cfg = _cfg(pkg, kind, n_envs=300, n_steps=4, episode_len=7, batch_size=4)
@@ -260,6 +260,8 @@ def test_apply_gradients_clip_adam_nan(pkg, oracle_mod):
     (2, 12, 20, 60, {}),                                   # ScalingWrapperEnv(Pendulum): the update shares the Pendulum kernels
     (3, 12, 20, 60, {"ent_coef": 0.01}),                   # MountainCar-v0: Categorical over 3 actions, D = 2
     (4, 12, 20, 48, {}),                                   # MountainCarContinuous-v0
+    (7, 12, 20, 48, {"ent_coef": 0.01}),                   # ScalingWrapperEnv(MountainCarContinuous): the update shares kind 4's kernels
+    (7, 8, 16, 20, {}),                                    # ... on ppo_update_small_kernel (batch_size <= 64)
     (6, 12, 20, 60, {"ent_coef": 0.01}),                   # Acrobot-v1 on the fused kernels (D = 6)
     (6, 64, 32, 512, {}),
     (0, 16, 24, 96, {"has_target_kl": 1, "target_kl": 0.002}),
@@ -546,7 +548,7 @@ def test_rccl_plumbing_single_rank(pkg, oracle_mod, monkeypatch):
     np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=5e-4, atol=5e-6)
 
 
-@pytest.mark.parametrize("kind,flags", [(1, (1, 1)), (0, (1, 1)), (1, (1, 0)), (1, (0, 1)), (2, (1, 1)), (3, (1, 1)), (4, (1, 1))])   # 2: Normalize(Parallel([Scaling(Pendulum)])); 3, 4: MountainCar
+@pytest.mark.parametrize("kind,flags", [(1, (1, 1)), (0, (1, 1)), (1, (1, 0)), (1, (0, 1)), (2, (1, 1)), (3, (1, 1)), (4, (1, 1)), (7, (1, 1))])   # 2: Normalize(Parallel([Scaling(Pendulum)])); 3, 4: MountainCar
 @pytest.mark.parametrize("via_rccl", [False, True])
 def test_normalize_wrapper_rollout_matches_oracle(pkg, oracle_mod, kind, flags, via_rccl, monkeypatch):
     """NormalizeWrapperEnv on device (normalizeWrapperEnv.jl:21-50,123-197): running obs/return statistics (updated on EVERY
@@ -684,7 +686,7 @@ def test_wide_ppo_loss_and_gradient(pkg, oracle_mod, kind, B, variant, H):
     assert lh2 == lh and np.array_equal(gh, gh2)
 
 
-@pytest.mark.parametrize("kind,H", [(1, 256), (1, 128), (4, 128), (2, 128)])
+@pytest.mark.parametrize("kind,H", [(1, 256), (1, 128), (4, 128), (2, 128), (7, 128), (7, 256)])
 def test_wide_rollout_and_update_config3_shape(pkg, oracle_mod, kind, H):
     """configs[2] at test size: Pendulum, DiagGaussian, hidden [256,256], NormalizeWrapperEnv — rollout then PPO update"""
     capi = pkg._capi

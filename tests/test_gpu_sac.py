@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 
 
 def make_pair(pkg, E=8, hidden=(32, 32), B=16, cap=4096, act="relu", seed=7, max_steps=200, scaled=False, **alg_kw):
-    env = pkg.MountainCarContinuousEnv(max_steps=max_steps) if scaled == "mountaincar" else pkg.PendulumEnv(max_steps=max_steps)
-    if scaled is True:
+    env = pkg.MountainCarContinuousEnv(max_steps=max_steps) if scaled in ("mountaincar", "mountaincar_scaled") else pkg.PendulumEnv(max_steps=max_steps)
+    if scaled is True or scaled == "mountaincar_scaled":
         env = pkg.ScalingWrapperEnv(env)
     alg = pkg.SAC(batch_size=B, buffer_capacity=cap, **alg_kw)
     layer = pkg.SACLayer(env.observation_space(), env.action_space(), hidden_dims=hidden, activation=act)
@@ -128,7 +128,7 @@ def test_many_updates_in_one_call_and_reset_optimizer(pkg):
     close(h.get_params(), o.get_params(), rtol=2e-4, atol=5e-6)
 
 
-@pytest.mark.parametrize("scaled", [False, True, "mountaincar"])      # "mountaincar": MountainCarContinuous-v0 as the device env (D = 2, Box(-1, 1))
+@pytest.mark.parametrize("scaled", [False, True, "mountaincar", "mountaincar_scaled"])      # "mountaincar": MountainCarContinuous-v0 as the device env (D = 2, Box(-1, 1)); "_scaled": under ScalingWrapperEnv
 def test_collect_matches_oracle(pkg, scaled):
     """off_policy_collection.jl:28-96 with injected noise: the replay contents agree field by field, through a truncation and a ring wrap;
     scaled = under ScalingWrapperEnv (TanhScaleAdapter then maps onto the wrapper's Box(-1, 1))"""
@@ -158,7 +158,7 @@ def test_collect_matches_oracle(pkg, scaled):
     close(h.replay(C.RB_REWARDS), o.replay(C.RB_REWARDS), rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("scaled", [False, True, "mountaincar"])
+@pytest.mark.parametrize("scaled", [False, True, "mountaincar", "mountaincar_scaled"])
 def test_one_launch_collection_equals_the_four_launch_sequence(pkg, monkeypatch, scaled):
     """sac_collect_env_kernel (head + act! + observe + push! per env in one launch) against sac_collect_head_kernel -> env_step_kernel -> env_observe_kernel ->
     sac_push_kernel (DRIL_SAC_NO_FUSED_COLLECT=1, latched at create): same device functions in the same order => every replay field, the observation and the env
