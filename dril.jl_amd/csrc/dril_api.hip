@@ -488,7 +488,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (ext && (cfg->ext_obs_dim < 1 || cfg->ext_obs_dim > 1024 || cfg->ext_action_dim < 1 || cfg->ext_action_dim > 64)) return fail(nullptr, DRIL_ERR_INVALID_ARG, "DRIL_ENV_EXTERNAL: ext_obs_dim must be 1..1024 and ext_action_dim 1..64");
     // hidden_dims / activation: n_hidden == 0 is the two-layer form (hidden1, hidden2); otherwise hidden[0 .. n_hidden-1]
     if (cfg->n_hidden < 0 || cfg->n_hidden > kMaxHidden) return fail(nullptr, DRIL_ERR_INVALID_ARG, "n_hidden must be 0 (hidden1 / hidden2) or 1..4");
-    if (cfg->activation < 0 || cfg->activation > 5) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "activation must be 0 (tanh), 1 (relu), 2 (sigmoid), 3 (elu), 4 (leakyrelu) or 5 (softplus)");
+    if (cfg->activation < 0 || cfg->activation > 7) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "activation must be 0 (tanh), 1 (relu), 2 (sigmoid), 3 (elu), 4 (leakyrelu), 5 (softplus), 6 (gelu) or 7 (swish)");
     int nh = cfg->n_hidden ? cfg->n_hidden : 2, hd[kMaxHidden] = {cfg->hidden1, cfg->hidden2, 0, 0};
     if (cfg->n_hidden) for (int l = 0; l < nh; ++l) hd[l] = cfg->hidden[l];
     for (int l = 0; l < nh; ++l) if (hd[l] < 1 || hd[l] > 1024) return fail(nullptr, DRIL_ERR_INVALID_ARG, "hidden widths must be 1..1024");

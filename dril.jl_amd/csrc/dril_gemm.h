@@ -8,6 +8,7 @@ namespace dril {
 // C[z](M x N) = epi(alpha * A[z](M x K) . B[z](K x N) + bias[z](M)), every operand addressed by element strides
 struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias; const float* aux;
+    float* zout;                                  // when set: the pre-activation alpha * A.B + bias goes here too (C's strides), for activations whose derivative needs it (gelu, swish)
     int M, N, K;
     int sAm, sAk, sBk, sBn, sCm, sCn;             // element strides
     long long zA, zB, zC, zBias, zAux;            // batch (blockIdx.z) strides
@@ -22,10 +23,14 @@ struct GemmArgs {
 enum { EPI_NONE = 0, EPI_RELU = 1, EPI_TANH = 2, EPI_MASK_RELU = 3, EPI_MASK_TANH = 4,
        // round 3: the other activations whose derivative is a function of the OUTPUT (the reverse pass keeps activations, not pre-activations): NNlib sigmoid,
        // elu (alpha = 1), leakyrelu (a = 0.01), softplus — generic PPO path only (the reference takes any activation, layer_constructors.jl:8,56)
-       EPI_SIGMOID = 5, EPI_ELU = 6, EPI_LEAKY = 7, EPI_SOFTPLUS = 8, EPI_MASK_SIGMOID = 9, EPI_MASK_ELU = 10, EPI_MASK_LEAKY = 11, EPI_MASK_SOFTPLUS = 12 };
+       EPI_SIGMOID = 5, EPI_ELU = 6, EPI_LEAKY = 7, EPI_SOFTPLUS = 8, EPI_MASK_SIGMOID = 9, EPI_MASK_ELU = 10, EPI_MASK_LEAKY = 11, EPI_MASK_SOFTPLUS = 12,
+       // gelu (NNlib: the tanh form) and swish: the derivative is a function of the PRE-activation, which the forward of an update keeps beside the activation (GemmArgs.zout); their mask epilogues read it as `aux`
+       EPI_GELU = 13, EPI_SWISH = 14, EPI_MASK_GELU = 15, EPI_MASK_SWISH = 16 };
+__host__ __device__ inline bool epi_reads_aux(int epi) { return epi == EPI_MASK_RELU || epi == EPI_MASK_TANH || (epi >= EPI_MASK_SIGMOID && epi <= EPI_MASK_SOFTPLUS) || epi == EPI_MASK_GELU || epi == EPI_MASK_SWISH; }
+inline bool activation_needs_preactivation(int act) { return act == 6 || act == 7; }
 // activation codes of dril_config.activation -> the forward epilogue and the mask (act'(y)) epilogue
-inline int epi_of_activation(int act) { return act == 1 ? EPI_RELU : act == 2 ? EPI_SIGMOID : act == 3 ? EPI_ELU : act == 4 ? EPI_LEAKY : act == 5 ? EPI_SOFTPLUS : EPI_TANH; }
-inline int mask_epi_of_activation(int act) { return act == 1 ? EPI_MASK_RELU : act == 2 ? EPI_MASK_SIGMOID : act == 3 ? EPI_MASK_ELU : act == 4 ? EPI_MASK_LEAKY : act == 5 ? EPI_MASK_SOFTPLUS : EPI_MASK_TANH; }
+inline int epi_of_activation(int act) { return act == 1 ? EPI_RELU : act == 2 ? EPI_SIGMOID : act == 3 ? EPI_ELU : act == 4 ? EPI_LEAKY : act == 5 ? EPI_SOFTPLUS : act == 6 ? EPI_GELU : act == 7 ? EPI_SWISH : EPI_TANH; }
+inline int mask_epi_of_activation(int act) { return act == 1 ? EPI_MASK_RELU : act == 2 ? EPI_MASK_SIGMOID : act == 3 ? EPI_MASK_ELU : act == 4 ? EPI_MASK_LEAKY : act == 5 ? EPI_MASK_SOFTPLUS : act == 6 ? EPI_MASK_GELU : act == 7 ? EPI_MASK_SWISH : EPI_MASK_TANH; }
 
 GemmArgs gemm_args();
 // one contraction, Z batches (blockIdx.z); picks the split-K / tile-parallel / LDS-tiled shape from the tile count

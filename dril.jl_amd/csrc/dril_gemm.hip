@@ -53,6 +53,12 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, float
     else if (g.epi == EPI_MASK_ELU) v *= y > 0.f ? 1.0f : y + 1.0f;                 // alpha e^x = elu(x) + alpha
     else if (g.epi == EPI_MASK_LEAKY) v *= y > 0.f ? 1.0f : 0.01f;
     else if (g.epi == EPI_MASK_SOFTPLUS) v *= 1.0f - expf(-y);                       // sigmoid(x) = 1 - e^(-softplus(x))
+    else if (g.epi == EPI_GELU) { const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v); v = 0.5f * v * (1.0f + tanhf(u)); }   // NNlib.gelu (tanh form)
+    else if (g.epi == EPI_SWISH) v = v / (1.0f + expf(-v));
+    else if (g.epi == EPI_MASK_GELU) {                                               // y = the pre-activation x
+        const float u = 0.7978845608028654f * (y + 0.044715f * y * y * y), t = tanhf(u);
+        v *= 0.5f * (1.0f + t) + 0.5f * y * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * y * y);
+    } else if (g.epi == EPI_MASK_SWISH) { const float sg = 1.0f / (1.0f + expf(-y)); v *= sg * (1.0f + y * (1.0f - sg)); }
     return v;
 }
 // one 32 x 32 output tile out of the LDS transposition buffer: lane -> 16 elements (row ml = lane & 31 fixed, 16 columns), stores along C's unit-stride axis.
@@ -65,7 +71,8 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, float* __restrict_
     const int ml = lane & 31, mm = m_base + ml;
     const bool m_ok = mm < g.M;
     const float b = (bias && m_ok) ? bias[mm] : 0.f;
-    const bool need_aux = aux && (g.epi == EPI_MASK_RELU || g.epi == EPI_MASK_TANH || g.epi >= EPI_MASK_SIGMOID);
+    float* __restrict__ Zp = g.zout ? g.zout + (C - g.C) : nullptr;                        // same batch offset as C
+    const bool need_aux = aux && epi_reads_aux(g.epi);
     float y[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -77,7 +84,9 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, float* __restrict_
     for (int i = 0; i < 16; ++i) {
         const int nl = (lane >> 5) + 2 * i, nn = n_base + nl;
         if (!m_ok || nn >= g.N) continue;
-        C[(size_t)mm * g.sCm + (size_t)nn * g.sCn] = gemm_epilogue(g, value(rr, nl + lb), b, y[i]);
+        const size_t ci = (size_t)mm * g.sCm + (size_t)nn * g.sCn; const float raw = value(rr, nl + lb);
+        if (Zp) Zp[ci] = raw * g.alpha + b;
+        C[ci] = gemm_epilogue(g, raw, b, y[i]);
     }
 }
 template <bool SPLIT>
@@ -119,7 +128,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)
     const float* __restrict__ aux = g.aux ? g.aux + (size_t)z * g.zAux : nullptr;
     // element e of a 32x32 tile: m_local = e & 31 (fastest, C's unit stride), n_local = e >> 5; it sits in register rr of lane ll
     if (SPLIT) {
-        const bool need_aux = aux && (g.epi == EPI_MASK_RELU || g.epi == EPI_MASK_TANH || g.epi >= EPI_MASK_SIGMOID);
+        const bool need_aux = aux && epi_reads_aux(g.epi);
         const int ml = threadIdx.x & 31, mm = bx * 32 + ml, rr = (ml & 3) + 4 * (ml >> 3), lb = 32 * ((ml >> 2) & 1);
         const float b = (bias && mm < g.M) ? bias[mm] : 0.f;
         float y[2]; bool ok[2]; size_t ci[2];
@@ -136,6 +145,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)
             float v = red[0][rr][ll];
 #pragma unroll
             for (int w = 1; w < kGemmWaves; ++w) v += red[w][rr][ll];                          // fixed order
+            if (g.zout) (g.zout + (C - g.C))[ci[i]] = v * g.alpha + b;
             C[ci[i]] = gemm_epilogue(g, v, b, y[i]);
         }
     } else store_tile(g, C, bias, aux, bx * 32, tile_n * 32, lane, [&](int rr, int ll) { return red[wave][rr][ll]; });

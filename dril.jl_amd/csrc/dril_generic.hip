@@ -67,14 +67,14 @@ hipError_t mlp_forward(const GenericDims& d, const float* P, const NetLay& L, co
 // both nets of the ActorCriticLayer on the same rows: their hidden layers have the same shapes, so each is ONE launch with blockIdx.z = net
 // (layer l's block of hb holds the actor's activations followed by the critic's, n * H[l] floats apart); the output layers differ in width and share a
 // launch through the pair kernel while the batch is small.  Halves the launch count of a rollout step / small minibatch (latency-bound there).
-hipError_t mlp_forward_both(const GenericDims& d, const float* P, const NetLay& La, const NetLay& Lc, const float* X, int n, float* const* hb, float* out, float* v, hipStream_t s) {
+hipError_t mlp_forward_both(const GenericDims& d, const float* P, const NetLay& La, const NetLay& Lc, const float* X, int n, float* const* hb, float* out, float* v, hipStream_t s, float* const* zb = nullptr) {   // zb: pre-activations beside the activations (gelu / swish: the reverse pass needs them)
     const long long zP = (long long)Lc.w[0] - La.w[0];                              // same layout in both nets up to the output layer
     const float* in = X; long long zin = 0;
     for (int l = 0; l < d.nh; ++l) {
         float* dst = hb[l];
         GemmArgs g = gargs();
         g.A = P + La.w[l]; g.sAm = 1; g.sAk = La.out[l]; g.zA = zP; g.B = in; g.sBk = 1; g.sBn = La.in[l]; g.zB = zin; g.C = dst; g.sCm = 1; g.sCn = La.out[l]; g.zC = (long long)n * La.out[l];
-        g.bias = P + La.b[l]; g.zBias = zP; g.M = La.out[l]; g.N = n; g.K = La.in[l]; g.epi = act_epi(d);
+        g.bias = P + La.b[l]; g.zBias = zP; g.M = La.out[l]; g.N = n; g.K = La.in[l]; g.epi = act_epi(d); g.zout = zb ? zb[l] : nullptr;
         hipError_t e = launch_gemm(g, 2, s); if (e != hipSuccess) return e;
         in = dst; zin = (long long)n * La.out[l];
     }
@@ -277,7 +277,7 @@ constexpr int kMaxStages = 2 * (kMaxHidden + 1) - 1;
 struct BackwardPlan { GemmArgs g[kMaxStages]; int Z[kMaxStages]; int n; };
 // hb: this net's hidden activations, layer l at hb[l] (R rows x H[l]); dz: scratch of the same shapes; dOut: R x O
 BackwardPlan plan_backward(const GenericDims& d, const float* P, const NetLay& L, const float* X, const float* const* hb, float* const* dz, const float* dOut,
-                           int64_t R, int Cr, int G, float* slabs, int slab_stride) {
+                           int64_t R, int Cr, int G, float* slabs, int slab_stride, const float* const* zb = nullptr) {   // zb: pre-activations (the mask's operand for gelu / swish)
     const int base = L.w[0];                                                         // slab offsets are relative to the net's first parameter
     BackwardPlan p; p.n = 0;
     const float* up = dOut;                                                          // gradient w.r.t. the pre-activation of layer l
@@ -290,7 +290,7 @@ BackwardPlan plan_backward(const GenericDims& d, const float* P, const NetLay& L
         p.g[p.n] = w; p.Z[p.n] = G; ++p.n;
         if (l == 0) break;
         GemmArgs g = gargs();                                                        // dz_{l-1} = (W_l' up) .* act'(h_{l-1})
-        g.A = P + L.w[l]; g.sAm = O; g.sAk = 1; g.B = up; g.sBk = 1; g.sBn = O; g.C = dz[l - 1]; g.sCm = 1; g.sCn = I; g.aux = hb[l - 1]; g.M = I; g.N = (int)R; g.K = O; g.epi = mask_epi(d);
+        g.A = P + L.w[l]; g.sAm = O; g.sAk = 1; g.B = up; g.sBk = 1; g.sBn = O; g.C = dz[l - 1]; g.sCm = 1; g.sCn = I; g.aux = zb ? zb[l - 1] : hb[l - 1]; g.M = I; g.N = (int)R; g.K = O; g.epi = mask_epi(d);
         p.g[p.n] = g; p.Z[p.n] = 1; ++p.n;
         up = dz[l - 1];
     }
@@ -323,7 +323,7 @@ int generic_slab_size(const GenericDims& d, bool actor) {
     return (generic_net_size(d, actor ? d.A : 1) + ((actor && !d.discrete) ? d.A : 0) + 8 + 3) / 4 * 4;
 }
 
-static size_t grad_floats_per_row(const GenericDims& d) { return (size_t)d.D + 3 * (size_t)d.A + 4 * (size_t)hidden_sum(d) + 40 + 8 * kMaxHidden; }
+static size_t grad_floats_per_row(const GenericDims& d) { return (size_t)d.D + 3 * (size_t)d.A + (activation_needs_preactivation(d.act) ? 6 : 4) * (size_t)hidden_sum(d) + 40 + 8 * kMaxHidden; }
 static int64_t grad_rows_max(const GenericDims& d) { return std::max<int64_t>((int64_t)(((size_t)1 << 29) / grad_floats_per_row(d)), 64); }   // <= 2 GiB of workspace per pass
 int generic_pick_slabs(const GenericDims& d, int64_t count, int Gmax) {
     if (count < 1 || Gmax < 1) return -1;
@@ -377,8 +377,9 @@ hipError_t generic_ppo_grad(const GenericDims& d, const GradArgs& a, GenericWs& 
     float* X = c.take((size_t)R * d.D); float* act = c.take((size_t)R * d.A); float* adv = c.take(R); float* lpo = c.take(R); float* ret = c.take(R);
     float* vold = c.take(R); float* valid = c.take(R);
     const NetLay La = net_lay(d, a.actor.w1, d.A), Lc = net_lay(d, a.critic.w1, 1);
-    float* hb[kMaxHidden]; float* dzb[kMaxHidden];                                                              // per layer: the actor's rows, then the critic's
-    for (int l = 0; l < d.nh; ++l) { hb[l] = c.take((size_t)2 * R * d.H[l]); dzb[l] = c.take((size_t)2 * R * d.H[l]); }
+    float* hb[kMaxHidden]; float* dzb[kMaxHidden]; float* zbb[kMaxHidden];                                      // per layer: the actor's rows, then the critic's
+    const bool need_z = activation_needs_preactivation(d.act);
+    for (int l = 0; l < d.nh; ++l) { hb[l] = c.take((size_t)2 * R * d.H[l]); dzb[l] = c.take((size_t)2 * R * d.H[l]); zbb[l] = need_z ? c.take((size_t)2 * R * d.H[l]) : nullptr; }
     float* outa = c.take((size_t)R * d.A); float* v = c.take(R);
     float* dout = c.take((size_t)R * d.A); float* dv = c.take(R); float* dlp = c.take(R);
     for (int slab0 = 0; slab0 < G; slab0 += Gp) {
@@ -387,17 +388,18 @@ hipError_t generic_ppo_grad(const GenericDims& d, const GradArgs& a, GenericWs& 
         const int64_t ge = Rn * (d.D + 1);
         generic_gather_kernel<<<(unsigned)((ge + 255) / 256), 256, 0, s>>>(ga);
         e = hipGetLastError(); if (e != hipSuccess) return e;
-        e = mlp_forward_both(d, a.params, La, Lc, X, (int)Rn, hb, outa, v, s); if (e != hipSuccess) return e;
-        const float* ha[kMaxHidden]; const float* hc[kMaxHidden]; float* dza[kMaxHidden]; float* dzc[kMaxHidden];
+        e = mlp_forward_both(d, a.params, La, Lc, X, (int)Rn, hb, outa, v, s, need_z ? zbb : nullptr); if (e != hipSuccess) return e;
+        const float* ha[kMaxHidden]; const float* hc[kMaxHidden]; float* dza[kMaxHidden]; float* dzc[kMaxHidden]; const float* za[kMaxHidden]; const float* zc[kMaxHidden];
         for (int l = 0; l < d.nh; ++l) {                                               // layer l's block: the actor's rows, then the critic's (mlp_forward_both)
             ha[l] = hb[l]; hc[l] = ha[l] + (size_t)Rn * d.H[l];
             dza[l] = dzb[l]; dzc[l] = dza[l] + (size_t)Rn * d.H[l];
+            za[l] = zbb[l]; zc[l] = need_z ? zbb[l] + (size_t)Rn * d.H[l] : nullptr;
         }
         LossHeadArgs lh{a, d.A, d.discrete, Rn, Cr, slab0, outa, v, act, adv, lpo, ret, vold, valid, dout, dv, dlp};
         generic_loss_head_kernel<<<Gn, 256, 0, s>>>(lh);
         e = hipGetLastError(); if (e != hipSuccess) return e;
-        const BackwardPlan pa = plan_backward(d, a.params, La, X, ha, dza, dout, Rn, (int)Cr, Gn, a.slabs_actor + (size_t)slab0 * a.slab_a, a.slab_a);
-        const BackwardPlan pc = plan_backward(d, a.params, Lc, X, hc, dzc, dv, Rn, (int)Cr, Gn, a.slabs_critic + (size_t)slab0 * a.slab_c, a.slab_c);
+        const BackwardPlan pa = plan_backward(d, a.params, La, X, ha, dza, dout, Rn, (int)Cr, Gn, a.slabs_actor + (size_t)slab0 * a.slab_a, a.slab_a, need_z ? za : nullptr);
+        const BackwardPlan pc = plan_backward(d, a.params, Lc, X, hc, dzc, dv, Rn, (int)Cr, Gn, a.slabs_critic + (size_t)slab0 * a.slab_c, a.slab_c, need_z ? zc : nullptr);
         e = run_backward_both(pa, pc, s); if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -202,7 +202,7 @@ def _orthogonal(rng: np.random.Generator, out_dims: int, in_dims: int, gain: flo
     return (gain * w).astype(np.float32)
 
 
-ACTIVATIONS = ("tanh", "relu", "sigmoid", "elu", "leakyrelu", "softplus")   # dril_config.activation codes 0 .. 5 (include/dril_hip.h)
+ACTIVATIONS = ("tanh", "relu", "sigmoid", "elu", "leakyrelu", "softplus", "gelu", "swish")   # dril_config.activation codes 0 .. 7 (include/dril_hip.h)
 
 
 @dataclass
@@ -214,7 +214,7 @@ class ActorCriticLayer:
     action_space: object
     hidden_dims: Sequence[int] = (64, 64)      # any length 1..4 (get_mlp, layer_helpers.jl:27-57); two equal layers of 64 / 128 / 256 with tanh run the fused kernels
     log_std_init: float = 0.0
-    activation: str = "tanh"                   # "tanh" (the reference's default, layer_constructors.jl:8,56), "relu", "sigmoid", "elu", "leakyrelu", "softplus" (NNlib's definitions; anything but tanh runs the generic kernels)
+    activation: str = "tanh"                   # "tanh" (the reference's default, layer_constructors.jl:8,56), "relu", "sigmoid", "elu", "leakyrelu", "softplus", "gelu", "swish" (NNlib's definitions; anything but tanh runs the generic kernels)
 
     def __post_init__(self):
         self.hidden_dims = tuple(int(h) for h in self.hidden_dims)

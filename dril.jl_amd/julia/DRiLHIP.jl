@@ -243,7 +243,9 @@ function check_supported_layer(agent)
     (nameof(act) === :elu) && return Int32(3)
     (nameof(act) === :leakyrelu) && return Int32(4)
     (nameof(act) === :softplus) && return Int32(5)
-    error("DRiLHIP: activation $(act) is not supported on the device PPO path (tanh, relu, sigmoid, elu, leakyrelu, softplus). Use DRiL's CPU train! for this layer.")
+    (nameof(act) in (:gelu, :gelu_tanh)) && return Int32(6)                # NNlib.gelu is the tanh form
+    (nameof(act) in (:swish, :swish_fast)) && return Int32(7)
+    error("DRiLHIP: activation $(act) is not supported on the device PPO path (tanh, relu, sigmoid, elu, leakyrelu, softplus, gelu, swish). Use DRiL's CPU train! for this layer.")
 end
 function push_params!(env, agent)
     flat = flatten_params(agent.train_state.parameters)

@@ -141,7 +141,7 @@ typedef struct dril_config {
     float ext_action_low, ext_action_high;
     /* ActorCriticLayer(...; hidden_dims, activation) in full (src/layers/layer_constructors.jl:6-10,55-56; get_mlp layer_helpers.jl:27-57 builds
      * Dense(in => h_1, act), ..., Dense(h_{n-1} => h_n, act), Dense(h_n => out)): n_hidden = length(hidden_dims) in 1..4 with hidden[0..n_hidden-1]
-     * (1..1024 each), or 0 = the two-layer form hidden1 / hidden2 above.  activation: 0 tanh (the reference's default), 1 relu, 2 sigmoid, 3 elu (alpha 1), 4 leakyrelu (0.01), 5 softplus (NNlib's definitions; the generic kernels).  Every shape other
+     * (1..1024 each), or 0 = the two-layer form hidden1 / hidden2 above.  activation: 0 tanh (the reference's default), 1 relu, 2 sigmoid, 3 elu (alpha 1), 4 leakyrelu (0.01), 5 softplus, 6 gelu (the tanh form), 7 swish (NNlib's definitions; the generic kernels).  Every shape other
      * than two equal tanh layers of 64 / 128 / 256 runs the generic kernels.  Parameter layout per net: {W_1 b_1 ... W_{n+1} b_{n+1}} */
     int32_t n_hidden, hidden[4], activation;
     int32_t reserved[1];

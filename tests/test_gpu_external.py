@@ -335,7 +335,7 @@ def test_device_env_with_other_hidden_dims(pkg, oracle_mod, kind, H1, H2, norm):
 # ---- ActorCriticLayer(...; hidden_dims, activation) in full: any depth 1..4 and relu (dril_config v2) on the generic kernels ------------------------------
 @pytest.mark.parametrize("kind,hidden,act,norm", [(0, (48,), 0, 0), (1, (40, 24, 56), 0, 1), (0, (32, 32, 16, 8), 1, 0), (1, (64, 64), 1, 0), (3, (96, 20, 33), 1, 0), (4, (128, 128, 128), 0, 0),
                                                   (0, (64, 64), 2, 0), (1, (40, 24, 56), 3, 1), (3, (96, 20), 4, 0), (4, (64, 64), 5, 0), (6, (32, 48), 3, 0),
-                                                  (6, (128, 128), 0, 0), (6, (256, 256), 0, 1)])   # sigmoid, elu, leakyrelu, softplus (NNlib); Acrobot with elu
+                                                  (6, (128, 128), 0, 0), (6, (256, 256), 0, 1), (0, (64, 64), 6, 0), (1, (40, 24, 56), 7, 1), (3, (512, 512), 6, 0)])   # sigmoid, elu, leakyrelu, softplus (NNlib); Acrobot with elu
 def test_any_depth_and_relu_on_device(pkg, oracle_mod, kind, hidden, act, norm):
     """hidden_dims of length 1, 3, 4 and relu (the reference accepts any, layer_constructors.jl:6-10,55-56; layer_helpers.jl:27-57) on device envs: forward /
     evaluate / loss + gradient / rollout (truncation bootstraps, NormalizeWrapperEnv) / update against the oracle, whose any-depth MLP is pinned to torch
@@ -414,7 +414,7 @@ def test_relu_three_layer_agent_learns_through_the_mirror(pkg):
     with pytest.raises(ValueError):
         pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(8, 8, 8, 8, 8))
     with pytest.raises(ValueError):
-        pkg.ActorCriticLayer(env.observation_space(), env.action_space(), activation="gelu")      # needs the pre-activation in the reverse pass: not offered
+        pkg.ActorCriticLayer(env.observation_space(), env.action_space(), activation="mish")      # not one of the eight
 
 
 def test_forced_generic_equals_fused(pkg, monkeypatch):

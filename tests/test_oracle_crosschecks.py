@@ -12,7 +12,7 @@ def _hidden_of(cfg):
     """hidden_dims and activation carried by a dril_config (n_hidden == 0: the two-layer tanh form)"""
     hd = [cfg.hidden[i] for i in range(cfg.n_hidden)] if cfg.n_hidden else [cfg.hidden1, cfg.hidden2]
     F = torch.nn.functional                                   # dril_config.activation codes (NNlib's definitions: elu alpha = 1, leakyrelu 0.01)
-    return hd, (torch.tanh, torch.relu, torch.sigmoid, F.elu, lambda z: F.leaky_relu(z, 0.01), F.softplus)[cfg.activation]
+    return hd, (torch.tanh, torch.relu, torch.sigmoid, F.elu, lambda z: F.leaky_relu(z, 0.01), F.softplus, lambda z: F.gelu(z, approximate="tanh"), F.silu)[cfg.activation]
 
 
 def _nets(flat, D, hidden, A, discrete, dtype=torch.float64):
@@ -111,10 +111,11 @@ def test_ppo_loss_and_gradient_vs_torch_autograd(oracle_mod, pkg, kind, B, varia
 
 
 @pytest.mark.parametrize("kind,hidden,act,B", [(0, (48,), 0, 100), (1, (40, 24, 56), 0, 257), (0, (32, 32, 16, 8), 1, 64), (1, (64, 64), 1, 129), (3, (96, 20, 33), 1, 77),
-                                               (0, (40, 24), 2, 90), (1, (33, 65, 17), 3, 101), (3, (64,), 4, 55), (4, (48, 48), 5, 70)])   # sigmoid, elu, leakyrelu, softplus
+                                               (0, (40, 24), 2, 90), (1, (33, 65, 17), 3, 101), (3, (64,), 4, 55), (4, (48, 48), 5, 70),
+                                               (0, (48, 32), 6, 80), (1, (40, 24, 56), 7, 97), (6, (64, 64), 6, 60)])   # sigmoid, elu, leakyrelu, softplus; gelu, swish (pre-activation kept)
 def test_any_depth_and_relu_vs_torch_autograd(oracle_mod, pkg, kind, hidden, act, B):
     """ActorCriticLayer(...; hidden_dims, activation) beyond two tanh layers (layer_constructors.jl:6-10,55-56; get_mlp layer_helpers.jl:27-57): the oracle's
-    any-depth MLP (1 to 4 hidden layers; tanh, relu, sigmoid, elu, leakyrelu, softplus) — loss, statistics and every layer's gradient against torch autograd"""
+    any-depth MLP (1 to 4 hidden layers; tanh, relu, sigmoid, elu, leakyrelu, softplus, gelu, swish) — loss, statistics and every layer's gradient against torch autograd"""
     cfg = pkg._capi.default_config(kind); cfg.n_envs, cfg.n_steps = 2, 2; cfg.ent_coef = 0.01
     cfg.n_hidden = len(hidden); cfg.activation = act
     for i, h in enumerate(hidden):
