@@ -39,26 +39,32 @@ __device__ __forceinline__ void load_operand4(const float* __restrict__ P, int i
 // kGemmDepth chunks instead of one per chunk).  The epilogue goes through LDS so that global stores run along C's unit-stride axis
 // (m): a wave writes 2 x 128 contiguous bytes per instruction instead of 64 scattered words.
 constexpr int kGemmWaves = 8, kGemmDepth = 8, kRedStride = 65;
+// the activations beyond tanh / relu (generic PPO path only) live in ONE out-of-line function: inlined into every epilogue of every instantiation their libm
+// expansions grew this file's code by 45 % and cost the SAC collection forward 8 us per step (end of round 3, same-box A/B: 64.8 -> 72.8 us); SAC never calls it
+__device__ __noinline__ float gemm_epilogue_rare(int epi, float v, float y) {
+    if (epi == EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+    else if (epi == EPI_ELU) v = v > 0.f ? v : expm1f(v);
+    else if (epi == EPI_LEAKY) v = v > 0.f ? v : 0.01f * v;
+    else if (epi == EPI_SOFTPLUS) v = fmaxf(v, 0.f) + log1pf(expf(-fabsf(v)));
+    else if (epi == EPI_MASK_SIGMOID) v *= y * (1.0f - y);
+    else if (epi == EPI_MASK_ELU) v *= y > 0.f ? 1.0f : y + 1.0f;                 // alpha e^x = elu(x) + alpha
+    else if (epi == EPI_MASK_LEAKY) v *= y > 0.f ? 1.0f : 0.01f;
+    else if (epi == EPI_MASK_SOFTPLUS) v *= 1.0f - expf(-y);                       // sigmoid(x) = 1 - e^(-softplus(x))
+    else if (epi == EPI_GELU) { const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v); v = 0.5f * v * (1.0f + tanhf(u)); }   // NNlib.gelu (tanh form)
+    else if (epi == EPI_SWISH) v = v / (1.0f + expf(-v));
+    else if (epi == EPI_MASK_GELU) {                                               // y = the pre-activation x
+        const float u = 0.7978845608028654f * (y + 0.044715f * y * y * y), t = tanhf(u);
+        v *= 0.5f * (1.0f + t) + 0.5f * y * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * y * y);
+    } else if (epi == EPI_MASK_SWISH) { const float sg = 1.0f / (1.0f + expf(-y)); v *= sg * (1.0f + y * (1.0f - sg)); }
+    return v;
+}
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, float b, float y) {
     v = v * g.alpha + b;
     if (g.epi == EPI_RELU) v = v > 0.f ? v : 0.f;
     else if (g.epi == EPI_TANH) v = tanhf(v);
     else if (g.epi == EPI_MASK_RELU) v = y > 0.f ? v : 0.f;
     else if (g.epi == EPI_MASK_TANH) v *= 1.0f - y * y;
-    else if (g.epi == EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-    else if (g.epi == EPI_ELU) v = v > 0.f ? v : expm1f(v);
-    else if (g.epi == EPI_LEAKY) v = v > 0.f ? v : 0.01f * v;
-    else if (g.epi == EPI_SOFTPLUS) v = fmaxf(v, 0.f) + log1pf(expf(-fabsf(v)));
-    else if (g.epi == EPI_MASK_SIGMOID) v *= y * (1.0f - y);
-    else if (g.epi == EPI_MASK_ELU) v *= y > 0.f ? 1.0f : y + 1.0f;                 // alpha e^x = elu(x) + alpha
-    else if (g.epi == EPI_MASK_LEAKY) v *= y > 0.f ? 1.0f : 0.01f;
-    else if (g.epi == EPI_MASK_SOFTPLUS) v *= 1.0f - expf(-y);                       // sigmoid(x) = 1 - e^(-softplus(x))
-    else if (g.epi == EPI_GELU) { const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v); v = 0.5f * v * (1.0f + tanhf(u)); }   // NNlib.gelu (tanh form)
-    else if (g.epi == EPI_SWISH) v = v / (1.0f + expf(-v));
-    else if (g.epi == EPI_MASK_GELU) {                                               // y = the pre-activation x
-        const float u = 0.7978845608028654f * (y + 0.044715f * y * y * y), t = tanhf(u);
-        v *= 0.5f * (1.0f + t) + 0.5f * y * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * y * y);
-    } else if (g.epi == EPI_MASK_SWISH) { const float sg = 1.0f / (1.0f + expf(-y)); v *= sg * (1.0f + y * (1.0f - sg)); }
+    else if (g.epi != EPI_NONE) v = gemm_epilogue_rare(g.epi, v, y);
     return v;
 }
 // one 32 x 32 output tile out of the LDS transposition buffer: lane -> 16 elements (row ml = lane & 31 fixed, 16 columns), stores along C's unit-stride axis.
