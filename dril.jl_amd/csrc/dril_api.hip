@@ -414,12 +414,13 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     prof_begin(h, DRIL_K_GRAD_REDUCE);
     HIPCHK(h, launch_grad_reduce(r, h->stream));
     prof_end(h);
+    const bool norm_in_adam = reduce && apply && h->P <= 65536;                        // data-parallel: adam_kernel sums |g|^2 from the all-reduced gradient itself (one launch less per step)
     if (reduce) {
         int rc = rccl_allreduce(h, h->flat, (size_t)h->P + 8, kNcclFloat32); if (rc) return rc;
-        HIPCHK(h, launch_grad_norm(h->flat, h->P, h->norm_partials, h->stop_flag, h->stream));
+        if (!norm_in_adam) HIPCHK(h, launch_grad_norm(h->flat, h->P, h->norm_partials, h->stop_flag, h->stream));
     }
     if (!apply) return DRIL_OK;
-    AdamArgs ad{};
+    AdamArgs ad{}; ad.norm_from_flat = norm_in_adam ? 1 : 0;
     ad.params = h->params; ad.m = h->adam_m; ad.v = h->adam_v; ad.flat = h->flat; ad.P = h->P;
     ad.norm_partials = h->norm_partials; ad.n_partials = h->n_norm_partials; ad.bt = h->bt; ad.step_parity = (int)(h->adam_steps & 1);
     ad.beta1 = h->cfg.adam_beta1; ad.beta2 = h->cfg.adam_beta2; ad.eps = h->cfg.adam_eps; ad.lr = h->lr;

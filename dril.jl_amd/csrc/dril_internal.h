@@ -103,6 +103,7 @@ struct ReduceArgs {
 struct AdamArgs {
     float* params; float* m; float* v; const float* flat; int P;
     const double* norm_partials; int n_partials;
+    int norm_from_flat;                            // data-parallel steps: |g|^2 summed here from the all-reduced flat gradient (every block, same order) instead of a grad_norm_kernel launch in between
     float* bt; int step_parity;
     float beta1, beta2, eps, lr, max_grad_norm, target_kl, ent_coef, vf_coef;
     int has_max_grad_norm, has_target_kl, use_stats;

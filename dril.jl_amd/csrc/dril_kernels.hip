@@ -1143,7 +1143,8 @@ __global__ void adam_kernel(AdamArgs a) {
     if (*a.stop_flag) return;
     __shared__ double shn[16];
     double ps = 0;
-    for (int i = threadIdx.x; i < a.n_partials; i += blockDim.x) ps += a.norm_partials[i];    // same order in every block
+    if (a.norm_from_flat) { for (int i = threadIdx.x; i < a.P; i += blockDim.x) { const double g = a.flat[i]; ps += g * g; } }   // 9 k values per block: cheaper than a launch
+    else for (int i = threadIdx.x; i < a.n_partials; i += blockDim.x) ps += a.norm_partials[i];    // same order in every block
     const float norm = sqrtf((float)block_sum_f64(ps, shn));
     const float* stf = a.flat + a.P;
     const float n = a.use_stats ? stf[6] : 1.f;
