@@ -165,6 +165,9 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
         uid = [h.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         h.comm_init(uid[0])
+        progress(rank, f"RCCL communicator up: {h.comm_ranks()} ranks")
+        if h.comm_ranks() != world:        # what the communicator itself counts (ncclCommCount), not what the launcher asked for
+            raise SystemExit(f"rank {rank}: the RCCL communicator has {h.comm_ranks()} ranks, --gpus asked for {world}")
     h.env_reset(42)
 
     def iteration():
@@ -172,14 +175,17 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
         h.lib.dril_collect_rollout(h._h, None)      # no fps query: keeps the iteration free of host syncs until the update's end
         return h.ppo_update()
 
-    for _ in range(warmup):
+    for i in range(warmup):
         iteration()
+        if world > 1: progress(rank, f"warm-up iteration {i + 1}/{warmup} done")
     h.synchronize(); h.profile_reset()
+    calls0 = h.comm_allreduce_calls()
     if dist: dist.barrier()
     t0 = time.perf_counter()
     last = None
-    for _ in range(steps):
+    for i in range(steps):
         last = iteration()
+        if world > 1: progress(rank, f"iteration {i + 1}/{steps} done")      # (stderr, after the iteration's own end-of-update sync: no extra device sync in the timed region)
     h.synchronize()
     if dist: dist.barrier()
     dt = time.perf_counter() - t0
@@ -187,6 +193,13 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
         import torch
         t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     prof = h.profile()
+    if world > 1:
+        # a data-parallel result must have BEEN data-parallel: one gradient all-reduce per optimiser step of the timed region at least (+ the per-epoch moment tables);
+        # a KL stop (target_kl, off in PPO() defaults) would legitimately lower it, the bench workloads have none
+        need = epochs * (-(-N_local * world // B_global)) * steps
+        got = h.comm_allreduce_calls() - calls0
+        if got < need:
+            raise SystemExit(f"rank {rank}: {got} all-reduces in the timed region, expected at least {need} (epochs x minibatches x steps): not a data-parallel run")
     out = None
     if rank == 0:
         total_env_steps = N_local * world * steps
@@ -250,7 +263,139 @@ def secondary_runs(pkg) -> list:
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: `python bench.py --gpus N` starts its own ranks.  The parent makes NO GPU call, imports neither the package nor torch and
+# loads no shared library: it starts N fresh children of this script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and HSA_ENABLE_IPC_MODE_LEGACY=0 in their
+# environment, each in its own session), relays their stderr, watches them (exit code, a total time limit, a silence limit per rank — every rank prints a progress line per
+# phase and per iteration), on any failure ends exactly the process groups it started and exits non-zero, and on success prints rank 0's JSON line after checking that
+# the line really is an N-rank result.  Under torch.distributed.run (WORLD_SIZE already set) none of this runs.
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def _end_groups(procs) -> None:
+    import signal
+    for sig, grace in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+        live = [p for p in procs if p.poll() is None]
+        if not live:
+            return
+        for p in live:
+            try:
+                os.killpg(p.pid, sig)          # the child's own session (start_new_session): exactly the group this launcher created
+            except (ProcessLookupError, PermissionError):
+                pass
+        t_end = time.monotonic() + grace
+        while time.monotonic() < t_end and any(p.poll() is None for p in live):
+            time.sleep(0.05)
+
+
+def launch_ranks(n: int, argv: list, total_timeout: float, silent_timeout: float) -> int:
+    import subprocess
+    import threading
+    port = _free_port()
+    procs, out_lines, last_seen, threads = [], [[] for _ in range(n)], [time.monotonic()] * n, []
+
+    def pump(r: int, stream, is_err: bool) -> None:
+        for line in stream:
+            last_seen[r] = time.monotonic()
+            if is_err:
+                sys.stderr.write(f"[rank {r}] {line}"); sys.stderr.flush()
+            else:
+                out_lines[r].append(line)
+
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONUNBUFFERED="1")
+        p = subprocess.Popen([sys.executable, "-u", str(Path(__file__).resolve())] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                             start_new_session=True, cwd=str(ROOT))
+        procs.append(p)
+        for stream, is_err in ((p.stdout, False), (p.stderr, True)):
+            t = threading.Thread(target=pump, args=(r, stream, is_err), daemon=True); t.start(); threads.append(t)
+    t0 = time.monotonic()
+    why = None
+    while why is None:
+        time.sleep(0.1)
+        now = time.monotonic()
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            why = "rank %d exited with code %d" % bad[0]
+        elif all(c == 0 for c in codes):
+            break
+        elif now - t0 > total_timeout:
+            why = f"the ranks did not finish within {total_timeout:.0f} s"
+        else:
+            quiet = [r for r, c in enumerate(codes) if c is None and now - last_seen[r] > silent_timeout]
+            if quiet:
+                why = f"rank {quiet[0]} printed nothing for {silent_timeout:.0f} s"
+    if why is not None:
+        _end_groups(procs)
+        sys.stderr.write(f"bench.py --gpus {n}: {why}; all ranks ended, no result line\n")
+        return 1
+    for t in threads:
+        t.join(timeout=5.0)
+    line = None
+    for cand in reversed(out_lines[0]):
+        try:
+            rec = json.loads(cand)
+        except ValueError:
+            continue
+        if isinstance(rec, dict) and "metric" in rec:
+            line = rec; break
+    if line is None:
+        sys.stderr.write(f"bench.py --gpus {n}: rank 0 exited 0 without a JSON result line\n")
+        return 1
+    if line.get("n_gpus") != n or line.get("rccl_ranks") != n:
+        sys.stderr.write(f"bench.py --gpus {n}: rank 0 reports n_gpus={line.get('n_gpus')} rccl_ranks={line.get('rccl_ranks')}: not an {n}-rank result\n")
+        return 1
+    line["launcher"] = f"bench.py started its own {n} ranks (no WORLD_SIZE in the environment)"
+    print(json.dumps(line), flush=True)
+    return 0
+
+
+def progress(rank: int, msg: str) -> None:
+    """one line on stderr per phase / iteration: the launcher's silence watchdog reads these (stdout carries only the JSON line)"""
+    sys.stderr.write(f"[bench rank {rank} +{time.perf_counter() - _T_START:7.1f}s] {msg}\n"); sys.stderr.flush()
+
+
+_T_START = time.perf_counter()
+
+
+def stub_worker(args) -> int:
+    """DRIL_BENCH_STUB=1 (tests/test_bench_launcher.py): a rank that loads NO library and touches no GPU — it proves the launcher's plumbing (environment of every
+    rank, a real gloo rendezvous on MASTER_ADDR:MASTER_PORT, barrier + max over ranks, a failing rank, a silent rank, a rank-count mismatch)."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
+    sys.stderr.write("STUBENV " + json.dumps({k: os.environ.get(k) for k in keys}) + "\n"); sys.stderr.flush()
+    if os.environ.get("DRIL_BENCH_STUB_FAIL_RANK") == str(rank):
+        progress(rank, "stub: failing on purpose"); return 7
+    if os.environ.get("DRIL_BENCH_STUB_SILENT_RANK") == str(rank):
+        time.sleep(3600); return 0
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ranks = 1 if os.environ.get("DRIL_BENCH_STUB_WRONG_RANKS") else world
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": 0.0, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) * 1e3,
+                          "rccl_ranks": ranks, "stub": True}), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+    return 0
+
+
 def main() -> None:
+    # RCCL across processes needs dmabuf IPC on this platform (legacy IPC: hipIpcGetMemHandle "invalid argument").  ROCr reads the variable when it initialises, so it is
+    # exported FIRST — before the package import, before libdril_hip.so is loaded (fat-binary registration), before any HIP call of this process or of its children
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--algo", choices=["ppo", "sac"], default="ppo", help="sac = BASELINE configs[4] (single GPU)")
     ap.add_argument("--sac-iters", type=int, default=500, help="train! iterations per bench step in --algo sac")
@@ -267,7 +412,21 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of configs[2] / configs[4] / configs[0] appended to the default line")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--launch-timeout", type=float, default=1800.0, help="--gpus N > 1 without WORLD_SIZE: seconds the self-started ranks may take in total")
+    ap.add_argument("--silent-timeout", type=float, default=420.0, help="... and seconds one rank may stay without a progress line (the first import of a fresh box takes 1-2 min)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # a plain `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU (no package import, no library load above this line)
+        if args.algo == "sac":
+            raise SystemExit("--algo sac is a single-learner path: --gpus 1 only")
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout, args.silent_timeout))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
+    if os.environ.get("DRIL_BENCH_STUB"):
+        sys.exit(stub_worker(args))
+    progress(int(os.environ.get("RANK", "0")), "loading libdril_hip.so")
     pkg = g.load_package()           # loads libdril_hip.so first (binds /opt/rocm's HIP runtime); no CPU fallback exists
     pkg._capi.load_library()
     if args.algo == "sac":
@@ -280,15 +439,12 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     if world > 1:
-        # RCCL across processes needs dmabuf IPC on this platform (legacy IPC: hipIpcGetMemHandle "invalid argument"); ROCr reads this at its initialisation, i.e.
-        # before the library's first HIP call — dril_create sets it too when it is the process's first HIP user (README "Multi-GPU")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
         import torch.distributed as dist  # rendezvous / barrier only; never touches torch.cuda
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        progress(rank, f"gloo rendezvous of {world} ranks done")
 
     out = run_ppo(pkg, env_name=args.env, E=args.n_envs, T=args.n_steps, hidden=args.hidden, minibatches=args.minibatches, epochs=args.epochs, normalize=args.normalize,
                   steps=args.steps, warmup=args.warmup, events=not args.no_events, rank=rank, local_rank=local_rank, world=world, dist=dist)

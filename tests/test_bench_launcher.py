@@ -1,0 +1,94 @@
+"""`python bench.py --gpus N` (N > 1) without a launcher starts its own ranks (north_star / SURVEY.md section 8e: the 1/2/4/8-GPU curve).
+
+The worker here is bench.py's stub (DRIL_BENCH_STUB=1): it loads no library and touches no GPU, so these tests run on the CPU box and prove the launcher's plumbing:
+environment of every rank, a real gloo rendezvous on the port the launcher picked, a failing rank, a silent rank, a rank-count mismatch, WORLD_SIZE disagreeing with
+--gpus.  The real worker behind the same launcher is what the driver's SCALE runs execute.
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def run_bench(extra_env, *argv, timeout=180):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    env.update(DRIL_BENCH_STUB="1", **extra_env)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+    return r, time.monotonic() - t0
+
+
+def stub_envs(stderr):
+    return [json.loads(l.split("STUBENV ", 1)[1]) for l in stderr.splitlines() if "STUBENV " in l]
+
+
+def test_launcher_starts_n_ranks_with_their_environment_and_relays_rank0():
+    r, _ = run_bench({}, "--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                      # ONE JSON line, rank 0's
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["ms_per_step"] == 2.0                      # the max over ranks went through a real gloo all-reduce: rank 1's 2 ms, not rank 0's 1 ms
+    assert "launcher" in rec
+    envs = sorted(stub_envs(r.stderr), key=lambda e: int(e["RANK"]))
+    assert [e["RANK"] for e in envs] == ["0", "1"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1"]
+    assert all(e["WORLD_SIZE"] == "2" and e["MASTER_ADDR"] == "127.0.0.1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)
+    assert envs[0]["MASTER_PORT"] == envs[1]["MASTER_PORT"] and int(envs[0]["MASTER_PORT"]) > 0
+
+
+def test_a_failing_rank_ends_all_ranks_and_the_exit_code_is_nonzero():
+    r, dt = run_bench({"DRIL_BENCH_STUB_FAIL_RANK": "1"}, "--gpus", "2")
+    assert r.returncode != 0
+    assert "rank 1 exited with code 7" in r.stderr
+    assert not r.stdout.strip()                           # no result line: a partial job is not a measurement
+    assert dt < 120                                       # rank 0 (waiting in the rendezvous for a rank that will never come) was ended, not waited for
+
+
+def test_a_silent_rank_is_ended_by_the_watchdog():
+    r, dt = run_bench({"DRIL_BENCH_STUB_SILENT_RANK": "0"}, "--gpus", "2", "--silent-timeout", "4")
+    assert r.returncode != 0
+    assert "printed nothing for 4 s" in r.stderr
+    assert not r.stdout.strip()
+    assert dt < 60
+
+
+def test_total_timeout():
+    r, dt = run_bench({"DRIL_BENCH_STUB_SILENT_RANK": "1"}, "--gpus", "2", "--launch-timeout", "3", "--silent-timeout", "1000")
+    assert r.returncode != 0 and "did not finish within 3 s" in r.stderr and dt < 60
+
+
+def test_a_result_with_the_wrong_rank_count_is_refused():
+    r, _ = run_bench({"DRIL_BENCH_STUB_WRONG_RANKS": "1"}, "--gpus", "2")
+    assert r.returncode != 0
+    assert "not an 2-rank result" in r.stderr and not r.stdout.strip()
+
+
+def test_world_size_that_disagrees_with_gpus_is_refused():
+    # under a launcher (WORLD_SIZE set) bench.py does not start ranks of its own; a mismatch is an error in both directions
+    for ws, gpus in (("1", "2"), ("2", "1")):
+        r, _ = run_bench({"WORLD_SIZE": ws, "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", gpus)
+        assert r.returncode != 0 and f"--gpus {gpus} but WORLD_SIZE={ws}" in r.stderr
+
+
+def test_single_gpu_stub_runs_in_process():
+    r, _ = run_bench({}, "--gpus", "1")
+    assert r.returncode == 0, r.stderr
+    rec = json.loads(r.stdout.strip())
+    assert rec["n_gpus"] == 1 and "launcher" not in rec
+    assert stub_envs(r.stderr)[0]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"      # exported at the top of main(), before any library load
+
+
+def test_under_torch_distributed_run_it_behaves_as_before():
+    # the driver's own launch line (WORLD_SIZE set by torchrun): no ranks of our own, rank 0 prints the line
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DRIL_BENCH_STUB"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                        str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(recs) == 1 and recs[0]["n_gpus"] == 2 and "launcher" not in recs[0]
