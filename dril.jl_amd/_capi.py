@@ -19,7 +19,7 @@ ABI_VERSION = 2
 ENV_CARTPOLE, ENV_PENDULUM, ENV_PENDULUM_SCALED, ENV_MOUNTAINCAR, ENV_MOUNTAINCAR_CONTINUOUS, ENV_EXTERNAL, ENV_ACROBOT, ENV_MOUNTAINCAR_CONTINUOUS_SCALED = 0, 1, 2, 3, 4, 5, 6, 7
 (BUF_OBSERVATIONS, BUF_ACTIONS, BUF_REWARDS, BUF_ADVANTAGES, BUF_RETURNS, BUF_LOGPROBS, BUF_VALUES,
  BUF_FLAGS, BUF_BOOTSTRAP, BUF_LAST_VALUES) = range(10)
-(K_ROLLOUT, K_GAE, K_ADV_MOMENTS, K_PPO_GRAD, K_GRAD_REDUCE, K_ADAM, K_ALLREDUCE, K_COUNT) = range(8)
+(K_ROLLOUT, K_GAE, K_ADV_MOMENTS, K_PPO_GRAD, K_GRAD_REDUCE, K_ADAM, K_ALLREDUCE, K_PACK_RECORDS, K_EXPLAINED_VAR, K_COUNT) = range(10)
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_RCCL, ERR_NAN_IN_GRADS, ERR_NOT_INITIALISED, ERR_UNSUPPORTED = range(7)
 
 
@@ -53,8 +53,14 @@ class DrilPPOStats(C.Structure):
         ("entropy_loss", C.c_float), ("policy_loss", C.c_float), ("value_loss", C.c_float),
         ("approx_kl_div", C.c_float), ("clip_fraction", C.c_float), ("loss", C.c_float), ("grad_norm", C.c_float),
         ("explained_variance", C.c_float), ("entropy", C.c_float), ("ratio_first", C.c_float),
-        ("n_updates", C.c_int32), ("early_stopped", C.c_int32), ("nan_or_inf", C.c_int32), ("reserved", C.c_int32),
+        ("n_updates", C.c_int32), ("early_stopped", C.c_int32), ("nan_or_inf", C.c_int32), ("f32_path", C.c_int32),
     ]
+
+
+class DrilF32Fallback(C.Structure):
+    """struct dril_f32_fallback, include/dril_hip.h"""
+    _fields_ = [("retries", C.c_int64), ("direct_updates", C.c_int64), ("persistent_fallbacks", C.c_int64),
+                ("latch_updates_left", C.c_int32), ("forward_exact_f32", C.c_int32), ("max_abs_w2", C.c_float), ("reserved", C.c_int32)]
 
 
 class DrilEvalStats(C.Structure):
@@ -160,6 +166,8 @@ _SIG = {
     "dril_compute_gae": (C.c_int32, [_P]),
     "dril_gae": (C.c_int32, [C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "dril_ppo_update": (C.c_int32, [_P, C.POINTER(DrilPPOStats)]),
+    "dril_f32_retries": (C.c_int64, [_P]),
+    "dril_f32_fallback_info": (C.c_int32, [_P, C.POINTER(DrilF32Fallback)]),
     "dril_debug_set_permutation": (C.c_int32, [_P, _P, C.c_size_t]),
     "dril_ppo_loss_grad": (C.c_int32, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_float), _P, _P]),
     "dril_apply_gradients": (C.c_int32, [_P, _P, C.c_size_t, C.POINTER(C.c_float)]),
@@ -173,6 +181,7 @@ _SIG = {
     "dril_profile_get": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dril_profile_reset": (C.c_int32, [_P]),
     "dril_kernel_name": (C.c_char_p, [C.c_int32]),
+    "dril_kernel_count": (C.c_int32, []),
     "dril_grad_kernel_info": (C.c_char_p, [_P]),
     "dril_version": (C.c_char_p, []),
 }

@@ -128,6 +128,11 @@ struct dril_handle {
     LoopGroup* loop = nullptr;   // debug loopback communicator (dril_debug_comm_loopback)
     int64_t allreduce_calls = 0;
     float* retry_snap = nullptr; bool no_f32_retry = false; int64_t f32_retries = 0;   // ppo_update: state before the update (for the exact-f32 redo of an update that left f16's range); DRIL_NO_F32_RETRY; how often it happened
+    // the redo's bookkeeping (dril_f32_fallback_info): used_f16 = an f16-piece kernel ran in the current update (sticky over its optimiser steps — the LAST step's kernel says nothing
+    // about a ragged tail); streak = consecutive redone updates; after kRetryLatchAfter of them the next kRetryLatchUpdates updates run the exact-f32 kernels directly (no wasted f16
+    // pass, no snapshot), then ONE update probes f16 again; direct = updates run that way (latched, or max |W2| out of f16's range)
+    bool used_f16 = false, spin_timeout = false; int f32_streak = 0, f32_latch_left = 0; int64_t f32_direct_updates = 0, persistent_fallbacks = 0;
+    unsigned* w2max_dev = nullptr; float w2max = 0.f;   // max |W2| over both nets (fused kernels): host copy refreshed by dril_set_params and with every optimiser run's statistics
     bool no_small_path = false, no_epoch_moments = false;   // DRIL_NO_SMALL_PATH / DRIL_NO_EPOCH_MOMENTS, latched in dril_create
     bool no_persistent = false; unsigned long long* small_xchg = nullptr; uint64_t* epoch_keys = nullptr; int epoch_keys_cap = 0; int64_t small_chunk = 16384;   // ppo_update_small_kernel (batch_size <= 64): DRIL_NO_PERSISTENT_UPDATE; per-epoch DataLoader keys on the device
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
@@ -228,11 +233,14 @@ int wide_variant(const dril_handle* h) { return (h->wide && h->rec && (h->grad_v
 // exact-f32 kernel, 16 384 samples 42.2 against 39.0; with the bf16 x 3 arithmetic of rounds 2 - 3 the crossover was at 16 tiles per CU)
 constexpr int kPairTilesPerCu = 8;
 bool pair_variant(const dril_handle* h) { return !h->wide && !h->generic && h->grad_variant != 0 && h->rec && h->D <= 8; }   // (D > 4, Acrobot: dW1 / db1 through a third piece image on the matrix cores — 16 (D + 1) per-lane accumulators would not fit)
+// the forward of the fused rollout / policy kernels: f16 two-piece W2 while every W2 entry is inside f16's range, else (or with DRIL_GRAD_VARIANT=0: "exact f32 everywhere") the f32-MFMA instantiations
+bool fwd_exact(const dril_handle* h) { return h->grad_variant == 0 || !(h->w2max < kFwdSplitMaxW); }
+constexpr int kRetryLatchAfter = 2, kRetryLatchUpdates = 16;
 int ensure_wimg(dril_handle* h) {
     if (!h->wide || !h->wimg_dirty) return DRIL_OK;
     HIPCHK(h, launch_build_wimg(h->params, h->actor, h->cfg.hidden1, h->w2a_actor, h->w2ta_actor, h->stream));
     HIPCHK(h, launch_build_wimg(h->params, h->critic, h->cfg.hidden1, h->w2a_critic, h->w2ta_critic, h->stream));
-    if (wide_variant(h) || DRIL_FWD_SPLIT) {      // the pre-split f16 fragment streams: ppo_grad_wide_split_kernel, and the forward of rollout / policy kernels
+    {                                             // the pre-split f16 fragment streams: ppo_grad_wide_split_kernel, and the forward of rollout / policy kernels
         HIPCHK(h, launch_build_wimg_split(h->params, h->actor, h->cfg.hidden1, h->w2p_actor, h->w2tp_actor, h->w2pf_actor, h->stream));
         HIPCHK(h, launch_build_wimg_split(h->params, h->critic, h->cfg.hidden1, h->w2p_critic, h->w2tp_critic, h->w2pf_critic, h->stream));
     }
@@ -260,7 +268,8 @@ PolicyArgs policy_args(dril_handle* h, const float* obs, int64_t B, const void* 
     a.params = h->params; a.obs = obs; a.B = B; a.noise = noise; a.actions = actions; a.values = values; a.logp = logp; a.entropy = entropy;
     a.mode = mode; a.action_start = h->cfg.action_start; a.log_std_off = h->log_std_off; a.seed = h->cfg.seed; a.call_counter = h->policy_calls;
     a.actor = h->actor; a.critic = h->critic;
-    a.w2a_actor = DRIL_FWD_SPLIT ? (const float*)h->w2pf_actor : h->w2a_actor; a.w2a_critic = DRIL_FWD_SPLIT ? (const float*)h->w2pf_critic : h->w2a_critic;   // wide nets: W2 operand of the forward
+    a.exact_f32 = fwd_exact(h) ? 1 : 0;
+    a.w2a_actor = a.exact_f32 ? h->w2a_actor : (const float*)h->w2pf_actor; a.w2a_critic = a.exact_f32 ? h->w2a_critic : (const float*)h->w2pf_critic;   // wide nets: W2 operand of the forward
     return a;
 }
 
@@ -357,6 +366,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     if (h->generic) { G = generic_pick_slabs(h->gd, count, h->Gmax); if (G < 1) return fail(h, DRIL_ERR_UNSUPPORTED, "minibatch too large for the generic path's workspace"); Gc = G; }
     { int rcw = ensure_wimg(h); if (rcw) return rcw; }
     h->last_variant = h->generic ? 3 : h->wide ? (variant ? 4 : 2) : (variant == 2 ? 5 : variant);
+    if (h->last_variant == 4 || h->last_variant == 5) h->used_f16 = true;
     const double* adv_stats = h->adv_stats;
     // launch-bound regime (the reference's default batch_size = 64): the advantage moments are computed inside the grad kernel and
     // reduce + norm + Adam run as one workgroup: 2 dependent launches per optimiser step instead of 6
@@ -544,7 +554,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const size_t E = cfg->n_envs, N = (size_t)h->N, P = h->P;
     CCHK(dmalloc(&h->params, P)); CCHK(dmalloc(&h->adam_m, P)); CCHK(dmalloc(&h->adam_v, P)); CCHK(dmalloc(&h->bt, 4));
-    CCHK(dmalloc(&h->flat, P + 8)); CCHK(dmalloc(&h->norm_out, 1));
+    CCHK(dmalloc(&h->flat, P + 8)); CCHK(dmalloc(&h->norm_out, 1)); CCHK(dmalloc(&h->w2max_dev, 1));
     h->n_norm_partials = (int)((P + 31) / 32); CCHK(dmalloc(&h->norm_partials, h->n_norm_partials));
     if (h->generic) { h->slab_a = generic_slab_size(h->gd, true); h->slab_c = generic_slab_size(h->gd, false); }
     else { h->slab_a = slab_size_actor(cfg->env_kind, hd[0]); h->slab_c = slab_size_critic(cfg->env_kind, hd[0]); }
@@ -610,7 +620,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     if (h->ext_stage_rew) (void)hipHostFree(h->ext_stage_rew); if (h->ext_stage_flags) (void)hipHostFree(h->ext_stage_flags);
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->retry_snap, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
-                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->epoch_index, h->epoch_keys, h->small_xchg, h->w2pf_actor, h->w2pf_critic, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
+                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->epoch_index, h->epoch_keys, h->small_xchg, h->w2max_dev, h->w2pf_actor, h->w2pf_critic, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
                     h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->e_rew_n, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->gen_tmp, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->w2p_actor, h->w2tp_actor, h->w2p_critic, h->w2tp_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
                     h->mon_ring_len, h->e_ep_len, h->mon_cnt, h->mon_meta, h->e_flags};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -629,7 +639,13 @@ DRIL_EXPORT int64_t dril_param_count(const dril_handle* h) { return h ? h->P : -
 
 DRIL_EXPORT int32_t dril_set_params(dril_handle* h, const float* flat, size_t n) {
     NEED(h); if (!flat || n != (size_t)h->P) return fail(h, DRIL_ERR_INVALID_ARG, "dril_set_params: n != dril_param_count");
-    HIPCHK(h, hipMemcpyAsync(h->params, flat, n * 4, hipMemcpyHostToDevice, h->stream)); h->wimg_dirty = true; return sync(h);
+    HIPCHK(h, hipMemcpyAsync(h->params, flat, n * 4, hipMemcpyHostToDevice, h->stream)); h->wimg_dirty = true;
+    if (!h->generic) {                                                                // max |W2| of the new parameters decides the forward's arithmetic (fwd_exact)
+        const size_t HH = (size_t)h->cfg.hidden1 * h->cfg.hidden1; float m = 0.f;
+        for (const float* w : {flat + h->actor.w2, flat + h->critic.w2}) for (size_t i = 0; i < HH; ++i) { const float x = std::fabs(w[i]); m = (x > m || x != x) ? (x != x ? INFINITY : x) : m; }
+        h->w2max = m;
+    }
+    return sync(h);
 }
 DRIL_EXPORT int32_t dril_get_params(dril_handle* h, float* flat, size_t n) {
     NEED(h); if (!flat || n != (size_t)h->P) return fail(h, DRIL_ERR_INVALID_ARG, "dril_get_params: n != dril_param_count");
@@ -869,7 +885,8 @@ int collect_rollout(dril_handle* h, double* fps, bool do_sync) {
     a.noise = h->noise_set ? h->noise_dev : nullptr;
     a.E = h->cfg.n_envs; a.T = h->cfg.n_steps; a.episode_len = h->cfg.episode_len; a.fixed_len = h->cfg.fixed_length_episodes;
     a.action_start = h->cfg.action_start; a.log_std_off = h->log_std_off; a.env_seed0 = h->env_seed0; a.actor = h->actor; a.critic = h->critic;
-    a.w2a_actor = DRIL_FWD_SPLIT ? (const float*)h->w2pf_actor : h->w2a_actor; a.w2a_critic = DRIL_FWD_SPLIT ? (const float*)h->w2pf_critic : h->w2a_critic;
+    a.exact_f32 = fwd_exact(h) ? 1 : 0;
+    a.w2a_actor = a.exact_f32 ? h->w2a_actor : (const float*)h->w2pf_actor; a.w2a_critic = a.exact_f32 ? h->w2a_critic : (const float*)h->w2pf_critic;
     a.mon_cur_ret = h->mon_cur_ret; a.mon_cur_len = h->mon_cur_len; a.ep_ret = h->ep_ret; a.ep_len = h->ep_len;
     const auto t0 = std::chrono::steady_clock::now();
     if (fps) HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1021,6 +1038,8 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
     const int64_t N = h->N, B = h->cfg.batch_size / h->cfg.world_size;
     const int64_t nb = (N + B - 1) / B;                       // partial last batch kept (MLUtils partial=true)
     const int64_t total_steps = nb * h->cfg.epochs;
+    const uint64_t adam_steps0 = h->adam_steps;
+    h->used_f16 = false; h->spin_timeout = false;
     if (total_steps > h->step_stats_cap) {
         if (h->step_stats) hipFree(h->step_stats);
         h->step_stats = nullptr; HIPCHK(h, dmalloc(&h->step_stats, (size_t)total_steps * 16)); h->step_stats_cap = (int)total_steps;
@@ -1028,7 +1047,7 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
     if (total_steps > 0) HIPCHK(h, hipMemsetAsync(h->step_stats, 0, (size_t)total_steps * 16 * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(h->stop_flag, 0, 4, h->stream)); HIPCHK(h, hipMemsetAsync(h->nan_flag, 0, 4, h->stream));
     const int bits = perm_bits(N);
-    if (h->rec) HIPCHK(h, launch_pack_records(h->cfg.env_kind, N, h->obs, h->act, h->adv, h->logp, h->ret, h->rec, h->stream));
+    if (h->rec) { prof_begin(h, DRIL_K_PACK_RECORDS); HIPCHK(h, launch_pack_records(h->cfg.env_kind, N, h->obs, h->act, h->adv, h->logp, h->ret, h->rec, h->stream)); prof_end(h); }
     int64_t step = 0;
     // the reference's default PPO() (batch_size = 64) on hidden [64,64]: every optimiser step of the iteration inside ONE launch of two persistent workgroups, one per net (dril_update_small.hip);
     // single-rank only (a data-parallel run all-reduces between the gradient and the step)
@@ -1061,7 +1080,7 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
             HIPCHK(h, launch_ppo_update_small(h->cfg.env_kind, u, h->stream));
             prof_end(h);
         }
-        h->adam_steps += total_steps; h->wimg_dirty = true; h->last_variant = 6;
+        h->adam_steps += total_steps; h->wimg_dirty = true; h->last_variant = 6; h->used_f16 = true;
 #ifdef DRIL_STAMPS
         {   // per-phase s_memtime ticks of the last launch, per wave
             hipStreamSynchronize(h->stream);
@@ -1114,12 +1133,19 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
         }
     }
     h->update_counter += 1;
+    prof_begin(h, DRIL_K_EXPLAINED_VAR);
     HIPCHK(h, launch_explained_var(h->val, h->ret, N, h->ev_partials, h->ev_blocks, h->stream));
-    std::vector<float> st((size_t)total_steps * 16); std::vector<double> ev(4 * (size_t)h->ev_blocks); int nan = 0;
+    prof_end(h);
+    std::vector<float> st((size_t)total_steps * 16); std::vector<double> ev(4 * (size_t)h->ev_blocks); int nan = 0; unsigned w2bits = 0;
+    if (!h->generic) {    // max |W2| of the parameters this update leaves behind rides home with its statistics (fwd_exact: the next rollout's arithmetic)
+        HIPCHK(h, launch_w2_absmax(h->params, h->actor, h->critic, h->cfg.hidden1, h->w2max_dev, h->stream));
+        HIPCHK(h, hipMemcpyAsync(&w2bits, h->w2max_dev, 4, hipMemcpyDeviceToHost, h->stream));
+    }
     if (total_steps > 0) HIPCHK(h, hipMemcpyAsync(st.data(), h->step_stats, st.size() * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(ev.data(), h->ev_partials, ev.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&nan, h->nan_flag, 4, hipMemcpyDeviceToHost, h->stream));
     int rc = sync(h); if (rc) return rc;
+    if (!h->generic) { float m; std::memcpy(&m, &w2bits, 4); h->w2max = (m == m) ? m : INFINITY; }
 #ifdef DRIL_STAMPS
     {   // shares of the LAST grad launch, averaged over waves, per head
         std::vector<unsigned long long> d((size_t)2 * h->Gmax * 4 * 12);
@@ -1158,6 +1184,7 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
         s0 = v[0]; s1 = v[1]; s2 = v[2]; s3 = v[3]; nn = v[4];
     }
     const double var_d = (s1 - s0 * s0 / nn) / (nn - 1.0), var_r = (s3 - s2 * s2 / nn) / (nn - 1.0);
+    h->adam_steps = adam_steps0 + (uint64_t)n_upd;     // the steps the device APPLIED (a KL stop or a non-finite gradient skips the rest; the stopping step leaves both slots of the beta powers equal, so the parity is free)
     if (out) {
         std::memset(out, 0, sizeof(*out));
         const double den = n_upd > 0 ? n_upd : 1, gden = n_gn > 0 ? n_gn : 1;
@@ -1167,7 +1194,7 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
         out->explained_variance = (float)(1.0 - var_d / var_r); out->ratio_first = ratio_first;
         out->n_updates = n_upd; out->early_stopped = stopped; out->nan_or_inf = nan;
     }
-    if (nan == 2) return fail(h, DRIL_ERR_HIP, "ppo_update_small_kernel: the partner workgroup did not answer within the spin limit (its two workgroups must be resident together); DRIL_NO_PERSISTENT_UPDATE=1 selects the per-step kernels");
+    if (nan == 2) { h->spin_timeout = true; return fail(h, DRIL_ERR_HIP, "ppo_update_small_kernel: the partner workgroup did not answer within the spin limit (its two workgroups must be resident together); DRIL_NO_PERSISTENT_UPDATE=1 selects the per-step kernels"); }
     if (nan) return fail(h, DRIL_ERR_NAN_IN_GRADS, "gradient contains nan or is not finite (ppo.jl:213-214)");
     return DRIL_OK;
 }
@@ -1177,7 +1204,17 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
 // kernels; only a gradient that is non-finite there as well is an error (ppo.jl:213-214).  Costs three small device copies per update.
 int ppo_update(dril_handle* h, dril_ppo_stats* out) {
     const bool may_retry = !h->generic && h->grad_variant < 0 && !h->no_f32_retry;
-    const int64_t adam_steps0 = h->adam_steps; const uint64_t counter0 = h->update_counter;
+    // (a) known in advance that f16 cannot hold this update: a W2 entry out of range, or the latch (kRetryLatchAfter consecutive redone updates: the workload lives outside
+    //     f16's range, so the next kRetryLatchUpdates run the exact-f32 kernels at once instead of paying an f16 pass + snapshot + redo each) — no wasted pass, no snapshot
+    if (may_retry && (h->f32_latch_left > 0 || !(h->w2max < kFwdSplitMaxW))) {
+        if (h->f32_latch_left > 0) h->f32_latch_left -= 1;
+        const int gv = h->grad_variant; h->grad_variant = 0;
+        const int rc = ppo_update_once(h, out);
+        h->grad_variant = gv; h->f32_direct_updates += 1;
+        if (out) out->f32_path = 2;
+        return rc;
+    }
+    const uint64_t adam_steps0 = h->adam_steps; const uint64_t counter0 = h->update_counter;
     const size_t P = (size_t)h->P;
     if (may_retry) {
         if (!h->retry_snap) HIPCHK(h, dmalloc(&h->retry_snap, 3 * P + 4));
@@ -1186,22 +1223,45 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
         HIPCHK(h, hipMemcpyAsync(h->retry_snap + 2 * P, h->adam_v, P * 4, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->retry_snap + 3 * P, h->bt, 4 * 4, hipMemcpyDeviceToDevice, h->stream));
     }
-    int rc = ppo_update_once(h, out);
-    const bool f16_kernel = h->last_variant == 4 || h->last_variant == 5 || h->last_variant == 6;
-    if (rc == DRIL_ERR_NAN_IN_GRADS && may_retry && f16_kernel) {
+    auto restore = [&]() -> int {
         HIPCHK(h, hipMemcpyAsync(h->params, h->retry_snap, P * 4, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->adam_m, h->retry_snap + P, P * 4, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->adam_v, h->retry_snap + 2 * P, P * 4, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->bt, h->retry_snap + 3 * P, 4 * 4, hipMemcpyDeviceToDevice, h->stream));
         h->adam_steps = adam_steps0; h->update_counter = counter0; h->wimg_dirty = true;
+        return DRIL_OK;
+    };
+    int rc = ppo_update_once(h, out);
+    // (b) the persistent two-workgroup kernel gave up waiting for its partner (the GPU is shared with another stream / process and the two workgroups were not resident
+    //     together): nothing is lost — the state of before the update is in the snapshot and the per-step kernels need no co-residency.  Redone once; the handle stays on them.
+    if (rc == DRIL_ERR_HIP && h->spin_timeout && may_retry) {
+        { const int rr = restore(); if (rr) return rr; }
+        h->no_persistent = true; h->persistent_fallbacks += 1;
+        rc = ppo_update_once(h, out);
+        if (rc == DRIL_OK) h->err.clear();
+    }
+    // (c) an f16-piece kernel ran somewhere in this update (sticky flag, not the last step's kernel) and a step met a non-finite gradient: redo on the exact-f32 kernels
+    if (rc == DRIL_ERR_NAN_IN_GRADS && may_retry && h->used_f16) {
+        { const int rr = restore(); if (rr) return rr; }
         const int gv = h->grad_variant; h->grad_variant = 0;                            // the exact-f32 kernels for this update (the persistent small kernel is f16 as well: per-step path)
         rc = ppo_update_once(h, out);
         h->grad_variant = gv; h->f32_retries += 1;
-    }
+        if (out) out->f32_path = 1;
+        if (rc == DRIL_OK) h->err.clear();                                              // the first pass's message is not this call's outcome
+        if (++h->f32_streak >= kRetryLatchAfter) h->f32_latch_left = kRetryLatchUpdates;
+    } else if (rc == DRIL_OK && h->used_f16) h->f32_streak = 0;                         // an update inside f16's range: the streak (and with it the latch's re-arming) ends
     return rc;
 }
 }  // namespace
 DRIL_EXPORT int32_t dril_ppo_update(dril_handle* h, dril_ppo_stats* out) { NEED(h); return ppo_update(h, out); }
+// how often the f16-piece arithmetic had to be left (include/dril_hip.h): nothing here is an error — every number delivered came from kernels that could hold it
+DRIL_EXPORT int64_t dril_f32_retries(const dril_handle* h) { return h ? h->f32_retries : -1; }
+DRIL_EXPORT int32_t dril_f32_fallback_info(const dril_handle* h, dril_f32_fallback* out) {
+    if (!h || !out) return fail(nullptr, DRIL_ERR_INVALID_ARG, "dril_f32_fallback_info: null argument");
+    out->retries = h->f32_retries; out->direct_updates = h->f32_direct_updates; out->persistent_fallbacks = h->persistent_fallbacks;
+    out->latch_updates_left = h->f32_latch_left; out->forward_exact_f32 = (!h->generic && fwd_exact(h)) ? 1 : 0; out->max_abs_w2 = h->w2max;
+    return DRIL_OK;
+}
 
 DRIL_EXPORT int32_t dril_ppo_loss_grad(dril_handle* h, const float* obs, const void* actions, const float* advantages, const float* returns,
                                        const float* old_logprobs, const float* old_values, int64_t batch, float* loss, float* stats7, float* grads) {
@@ -1249,10 +1309,12 @@ DRIL_EXPORT int32_t dril_apply_gradients(dril_handle* h, const float* grads, siz
     ad.nan_flag = h->nan_flag; ad.stop_flag = h->stop_flag; ad.stop_flag_w = h->stop_flag;
     HIPCHK(h, launch_adam(ad, h->stream));
     h->adam_steps += 1; h->wimg_dirty = true;
-    float norm = 0; int nan = 0;
+    float norm = 0; int nan = 0; unsigned w2bits = 0;
+    if (!h->generic) { HIPCHK(h, launch_w2_absmax(h->params, h->actor, h->critic, h->cfg.hidden1, h->w2max_dev, h->stream)); HIPCHK(h, hipMemcpyAsync(&w2bits, h->w2max_dev, 4, hipMemcpyDeviceToHost, h->stream)); }
     HIPCHK(h, hipMemcpyAsync(&norm, h->norm_out, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&nan, h->nan_flag, 4, hipMemcpyDeviceToHost, h->stream));
     int rc = sync(h); if (rc) return rc;
+    if (!h->generic) { float m; std::memcpy(&m, &w2bits, 4); h->w2max = (m == m) ? m : INFINITY; }
     if (grad_norm) *grad_norm = norm;
     if (nan == 2) return fail(h, DRIL_ERR_HIP, "ppo_update_small_kernel: the partner workgroup did not answer within the spin limit (its two workgroups must be resident together); DRIL_NO_PERSISTENT_UPDATE=1 selects the per-step kernels");
     if (nan) return fail(h, DRIL_ERR_NAN_IN_GRADS, "gradient contains nan or is not finite (ppo.jl:213-214)");
@@ -1383,9 +1445,11 @@ DRIL_EXPORT int32_t dril_profile_reset(dril_handle* h) {
     return DRIL_OK;
 }
 DRIL_EXPORT const char* dril_kernel_name(int32_t kid) {
-    static const char* names[] = {"rollout_kernel", "gae_kernel", "adv_moments_kernel", "ppo_grad_kernel", "grad_reduce_kernel", "adam_kernel", "ncclAllReduce"};
+    static const char* names[] = {"rollout_kernel", "gae_kernel", "adv_moments_kernel", "ppo_grad_kernel", "grad_reduce_kernel", "adam_kernel", "ncclAllReduce", "pack_records_kernel", "explained_var_kernel"};
+    static_assert(sizeof(names) / sizeof(names[0]) == DRIL_K_COUNT, "one name per kernel class");
     return (kid >= 0 && kid < DRIL_K_COUNT) ? names[kid] : "?";
 }
+DRIL_EXPORT int32_t dril_kernel_count(void) { return DRIL_K_COUNT; }
 DRIL_EXPORT const char* dril_grad_kernel_info(const dril_handle* h) {
     if (!h) return "?";
     switch (h->last_variant) {

@@ -49,7 +49,7 @@ __device__ __noinline__ float gemm_epilogue_rare(int epi, float v, float y) {
     else if (epi == EPI_MASK_SIGMOID) v *= y * (1.0f - y);
     else if (epi == EPI_MASK_ELU) v *= y > 0.f ? 1.0f : y + 1.0f;                 // alpha e^x = elu(x) + alpha
     else if (epi == EPI_MASK_LEAKY) v *= y > 0.f ? 1.0f : 0.01f;
-    else if (epi == EPI_MASK_SOFTPLUS) v *= 1.0f - expf(-y);                       // sigmoid(x) = 1 - e^(-softplus(x))
+    else if (epi == EPI_MASK_SOFTPLUS) v *= -expm1f(-y);                          // sigmoid(x) = 1 - e^(-softplus(x)); expm1: no cancellation for x << 0, where y = softplus(x) ~ e^x is tiny
     else if (epi == EPI_GELU) { const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v); v = 0.5f * v * (1.0f + tanhf(u)); }   // NNlib.gelu (tanh form)
     else if (epi == EPI_SWISH) v = v / (1.0f + expf(-v));
     else if (epi == EPI_MASK_GELU) {                                               // y = the pre-activation x

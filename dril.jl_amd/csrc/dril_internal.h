@@ -5,10 +5,10 @@
 
 #include "dril_device.h"
 
-#ifndef DRIL_FWD_SPLIT
-#define DRIL_FWD_SPLIT 1     // 0: the f32-MFMA forward in rollout_kernel / policy_kernel (A/B build); 1: the f16 two-piece forward (the W2 operand of wide nets is then the
-                             // pre-split fragment stream w2p, which the host passes in the w2a fields of PolicyArgs / RolloutArgs)
-#endif
+// The forward of rollout_kernel / rollout_duo_kernel / policy_kernel puts ONE operand on f16 pieces: kTanhScale kWScale W2 (h1 = tanh is bounded, L1 and L3 are f32).
+// A W2 entry at or beyond this magnitude would overflow its hi piece (2.885 x 64 x 354.7 = 65 504), so the host tracks max |W2| of both nets (dril_set_params, and with
+// every update's statistics) and launches the f32-MFMA instantiations of the same kernels instead (exact_f32 below) — the reference puts no range limit on parameters.
+constexpr float kFwdSplitMaxW = 350.0f;
 namespace dril {
 
 struct PolicyArgs {
@@ -21,6 +21,7 @@ struct PolicyArgs {
     const float* w2a_actor; const float* w2a_critic;   // wide nets: pre-tiled W2 images in global memory
     int deterministic;                           // predict_actions(...; deterministic = true): mode(d) instead of rand(d)
     const float* boot_obs; const uint8_t* boot_where; float* boot_out;   // fused V(terminal_observation) of the PREVIOUS env step (trajectory.jl:57-61)
+    int exact_f32;                               // 1: the f32-MFMA forward (w2a_* = the f32 W2 images), 0: the f16 two-piece forward (w2a_* = the pre-split fragment streams)
     NetOff actor, critic;
 };
 
@@ -47,7 +48,7 @@ struct RolloutArgs {
     const void* noise;
     int E, T, episode_len, fixed_len, action_start, log_std_off;
     uint64_t env_seed0;
-    const float* w2a_actor; const float* w2a_critic;
+    const float* w2a_actor; const float* w2a_critic; int exact_f32;   // as in PolicyArgs
     float* mon_cur_ret; int32_t* mon_cur_len; float* ep_ret; int32_t* ep_len;   // MonitorWrapperEnv (null = off)
     NetOff actor, critic;
 };
@@ -158,6 +159,7 @@ hipError_t launch_adam(const AdamArgs& a, hipStream_t s);
 hipError_t launch_finish_small(const ReduceArgs& r, const AdamArgs& a, hipStream_t s);   // grad_reduce + norm + Adam in one workgroup (few slabs)
 hipError_t launch_explained_var(const float* val, const float* ret, int64_t N, double* partials, int nblocks, hipStream_t s);
 hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a, float* w2ta, hipStream_t s);
+hipError_t launch_w2_absmax(const float* params, NetOff actor, NetOff critic, int H, unsigned* out_bits, hipStream_t s);   // max |W2| of both nets, as float bits
 hipError_t launch_build_wimg_split(const float* params, NetOff off, int H, void* w2p, void* w2tp, void* w2pf, hipStream_t s);
 int slab_size_actor(int kind, int hidden);
 int slab_size_critic(int kind, int hidden);

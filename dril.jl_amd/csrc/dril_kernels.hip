@@ -520,19 +520,34 @@ __device__ __forceinline__ void net_forward_wide_split(const float* __restrict__
     for (int o = 0; o < O; ++o) out[o] = part[o] + __shfl_xor(part[o], 32) + lds[L::B3 + o];
 }
 // forward of one net for a 32-sample tile: LDS-resident weights (H = 64) or the wide path (W2 streamed from L2)
-template <int D, int H, int O, bool WIDE>
+// SPLIT: the f16 two-piece forward (the default; W2 inside f16's range, |W2| < kFwdSplitMaxW); !SPLIT: the f32-MFMA forward, exact for any finite weight — the host
+// picks per launch (PolicyArgs / RolloutArgs::exact_f32: a W2 entry out of range, or DRIL_GRAD_VARIANT=0) and hands the matching W2 operand of wide nets in w2a
+template <int D, int H, int O, bool WIDE, bool SPLIT>
 __device__ __forceinline__ void eval_net(const float* __restrict__ lds, const float* __restrict__ w2a, const float (&xk)[FirstLayer<D>::KS], float (&out)[O], int lane) {
-    if constexpr (WIDE && DRIL_FWD_SPLIT) net_forward_wide_split<D, H, O>(lds, reinterpret_cast<const u32x4*>(w2a), xk, out, lane);
+    if constexpr (WIDE && SPLIT) net_forward_wide_split<D, H, O>(lds, reinterpret_cast<const u32x4*>(w2a), xk, out, lane);
     else if constexpr (WIDE) net_forward_wide<D, H, O>(lds, w2a, xk, out, lane);
-    else if constexpr (DRIL_FWD_SPLIT) net_forward_split<D, H, O>(lds, xk, out, lane);
+    else if constexpr (SPLIT) net_forward_split<D, H, O>(lds, xk, out, lane);
     else { f32x16 h1[H / 32], h2[H / 32]; net_forward<D, H, H, O>(lds, xk, h1, h2, out, lane); }
 }
-template <int D, int H, int O, bool WIDE> struct FwdLds { static constexpr int SIZE = WIDE ? NetLdsSmall<D, H, O>::END : DRIL_FWD_SPLIT ? (NetLdsSplit<D, 64, O>::END + 3) / 4 * 4 : NetLds<D, H, H, O>::FWD_END; };
-template <int D, int H, int O, bool WIDE>
+template <int D, int H, int O, bool WIDE, bool SPLIT> struct FwdLds { static constexpr int SIZE = WIDE ? NetLdsSmall<D, H, O>::END : SPLIT ? (NetLdsSplit<D, 64, O>::END + 3) / 4 * 4 : NetLds<D, H, H, O>::FWD_END; };
+template <int D, int H, int O, bool WIDE, bool SPLIT>
 __device__ __forceinline__ void stage_fwd(float* lds, const float* __restrict__ P, NetOff n, int tid, int nthreads) {
     if constexpr (WIDE) stage_net_small<D, H, O>(lds, P, n, tid, nthreads);
-    else if constexpr (DRIL_FWD_SPLIT) stage_net_split<D, H, O>(lds, P, n, tid, nthreads);
+    else if constexpr (SPLIT) stage_net_split<D, H, O>(lds, P, n, tid, nthreads);
     else stage_net<D, H, H, O, false>(lds, P, n, tid, nthreads);
+}
+// max |W2| over both nets as the bits of a non-negative float (atomicMax on the unsigned image orders them; a NaN's bits lie above +inf's, so it reads as "out of range"):
+// what decides between the f16 two-piece forward and the f32-MFMA forward (kFwdSplitMaxW).  Enqueued behind every optimiser run, read back with its statistics.
+__global__ void w2_absmax_kernel(const float* __restrict__ P, int w2_actor, int w2_critic, int HH, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * HH; i += gridDim.x * blockDim.x) {
+        const float w = i < HH ? P[w2_actor + i] : P[w2_critic + i - HH];
+        const unsigned b = __float_as_uint(w) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { const unsigned q = __shfl_xor(m, o); m = q > m ? q : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 // pre-tile W2 and W2' of one net for the wide path (see dril_device.h "wide nets")
 __global__ void build_wimg_kernel(const float* __restrict__ P, NetOff off, int H, float* __restrict__ w2a, float* __restrict__ w2ta) {
@@ -549,15 +564,15 @@ __global__ void build_wimg_kernel(const float* __restrict__ P, NetOff off, int H
 // policy_kernel: host-batch / step-granular forward.  One wave = 32 samples.
 // mode 0: sample + logprob + value; 1: evaluate given actions (+entropy); 2: critic only
 // =============================================================================================
-template <int KIND, int H, bool WIDE>
+template <int KIND, int H, bool WIDE, bool SPLIT>
 __global__ __launch_bounds__(256, WIDE ? 1 : 2) void policy_kernel(PolicyArgs a) {
     constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
     constexpr bool DISC = EnvSpec<KIND>::discrete;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* la = smem; float* lc = smem + FwdLds<D, H, A, WIDE>::SIZE;
+    float* la = smem; float* lc = smem + FwdLds<D, H, A, WIDE, SPLIT>::SIZE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (a.mode != 2) stage_fwd<D, H, A, WIDE>(la, a.params, a.actor, tid, blockDim.x);
-    stage_fwd<D, H, 1, WIDE>(lc, a.params, a.critic, tid, blockDim.x);
+    if (a.mode != 2) stage_fwd<D, H, A, WIDE, SPLIT>(la, a.params, a.actor, tid, blockDim.x);
+    stage_fwd<D, H, 1, WIDE, SPLIT>(lc, a.params, a.critic, tid, blockDim.x);
     __syncthreads();
     const int64_t ntiles = (a.B + kTile - 1) / kTile;
     const int c = lane & 31, h = lane >> 5;
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void policy_kernel(PolicyArgs a)
 #pragma unroll
                 for (int s = 0; s < FirstLayer<D>::KS; ++s) { const int d = 2 * s + h; tk[s] = d < D ? a.boot_obs[bb * D + d] : 0.f; }
                 float bv[1];
-                eval_net<D, H, 1, WIDE>(lc, a.w2a_critic, tk, bv, lane);
+                eval_net<D, H, 1, WIDE, SPLIT>(lc, a.w2a_critic, tk, bv, lane);
                 if (tr && h == 0) a.boot_out[b] = bv[0];
             }
         }
@@ -585,11 +600,11 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void policy_kernel(PolicyArgs a)
             for (int s = 0; s < FirstLayer<D>::KS; ++s) { const int d = 2 * s + h; if (d < D) a.obs_out[b * D + d] = xk[s]; }
         }
         float v[1];
-        eval_net<D, H, 1, WIDE>(lc, a.w2a_critic, xk, v, lane);
+        eval_net<D, H, 1, WIDE, SPLIT>(lc, a.w2a_critic, xk, v, lane);
         if (valid && h == 0 && a.values) a.values[b] = v[0];
         if (a.mode == 2) continue;
         float out[A];
-        eval_net<D, H, A, WIDE>(la, a.w2a_actor, xk, out, lane);
+        eval_net<D, H, A, WIDE, SPLIT>(la, a.w2a_actor, xk, out, lane);
         if (DISC) {
             float p[A]; softmax_n<A>(out, p);
             int act;
@@ -641,15 +656,15 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void policy_kernel(PolicyArgs a)
 // Buffer layout: time-major, index k = t*E + e; every store of a wave is one full 128-byte line
 // (or 512 B for the float4 observation rows).
 // =============================================================================================
-template <int KIND, int H, bool WIDE>
+template <int KIND, int H, bool WIDE, bool SPLIT>
 __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs a) {
     constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A, S = EnvSpec<KIND>::S;
     constexpr bool DISC = EnvSpec<KIND>::discrete;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* la = smem; float* lc = smem + FwdLds<D, H, A, WIDE>::SIZE;
+    float* la = smem; float* lc = smem + FwdLds<D, H, A, WIDE, SPLIT>::SIZE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    stage_fwd<D, H, A, WIDE>(la, a.params, a.actor, tid, blockDim.x);
-    stage_fwd<D, H, 1, WIDE>(lc, a.params, a.critic, tid, blockDim.x);
+    stage_fwd<D, H, A, WIDE, SPLIT>(la, a.params, a.actor, tid, blockDim.x);
+    stage_fwd<D, H, 1, WIDE, SPLIT>(lc, a.params, a.critic, tid, blockDim.x);
     __syncthreads();
     const int c = lane & 31, h = lane >> 5;
     const int e_raw = (blockIdx.x * 4 + wave) * kTile + c;
@@ -684,9 +699,9 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
         float xk[FirstLayer<D>::KS];
         pair_obs<D>(obs, h, xk);
         float v[1], out[A];
-        eval_net<D, H, 1, WIDE>(lc_t, a.w2a_critic, xk, v, lane);
+        eval_net<D, H, 1, WIDE, SPLIT>(lc_t, a.w2a_critic, xk, v, lane);
         __builtin_amdgcn_sched_barrier(0);   // do not interleave the two nets: that doubles the live weight fragments
-        eval_net<D, H, A, WIDE>(la_t, a.w2a_actor, xk, out, lane);
+        eval_net<D, H, A, WIDE, SPLIT>(la_t, a.w2a_actor, xk, out, lane);
         __builtin_amdgcn_sched_barrier(0);
         // ---- sample (layer_forward.jl:10-11 / :36-37) ----
         int act_env = 0; float actf_env = 0.f; float logp;
@@ -730,7 +745,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
             float tk[FirstLayer<D>::KS];
             pair_obs<D>(tobs, h, tk);
             float bv[1];
-            eval_net<D, H, 1, WIDE>(lc_t, a.w2a_critic, tk, bv, lane);
+            eval_net<D, H, 1, WIDE, SPLIT>(lc_t, a.w2a_critic, tk, bv, lane);
             if (writer && trunc) a.boot[k] = bv[0];
         }
         mon_ret += rew; mon_len += 1;
@@ -746,7 +761,7 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
         float xk[FirstLayer<D>::KS];
         pair_obs<D>(obs, h, xk);
         float v[1];
-        eval_net<D, H, 1, WIDE>(lc, a.w2a_critic, xk, v, lane);
+        eval_net<D, H, 1, WIDE, SPLIT>(lc, a.w2a_critic, xk, v, lane);
         if (writer) a.last_values[e] = v[0];
     }
     if (writer) {
@@ -764,19 +779,19 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
 // (value of every observation, V(terminal_observation) of truncated steps, the last values), one step behind through a double-buffered observation slot in LDS and ONE
 // barrier per env step.  Same device functions as rollout_kernel (eval_net, env_step, heads), so every stored number is bit-identical to the one-wave kernel.
 // =============================================================================================
-template <int KIND, int H>
+template <int KIND, int H, bool SPLIT>
 __global__ __launch_bounds__(128, 2) void rollout_duo_kernel(RolloutArgs a) {
     constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A, S = EnvSpec<KIND>::S;
     constexpr bool DISC = EnvSpec<KIND>::discrete;
-    constexpr int LA = FwdLds<D, H, A, false>::SIZE, LC = FwdLds<D, H, 1, false>::SIZE;
+    constexpr int LA = FwdLds<D, H, A, false, SPLIT>::SIZE, LC = FwdLds<D, H, 1, false, SPLIT>::SIZE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* la = smem; float* lc = smem + LA;
     float* slot = smem + LA + LC;                                       // [2 parities][obs D x 32 | terminal obs D x 32 | truncated flag 32]
     constexpr int SLOT = (2 * D + 1) * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    stage_fwd<D, H, A, false>(la, a.params, a.actor, tid, blockDim.x);
-    stage_fwd<D, H, 1, false>(lc, a.params, a.critic, tid, blockDim.x);
+    stage_fwd<D, H, A, false, SPLIT>(la, a.params, a.actor, tid, blockDim.x);
+    stage_fwd<D, H, 1, false, SPLIT>(lc, a.params, a.critic, tid, blockDim.x);
     const int c = lane & 31, h = lane >> 5;
     const int e_raw = blockIdx.x * kTile + c;
     const bool valid = e_raw < a.E;
@@ -812,7 +827,7 @@ __global__ __launch_bounds__(128, 2) void rollout_duo_kernel(RolloutArgs a) {
             float xk[FirstLayer<D>::KS];
             pair_obs<D>(obs, h, xk);
             float out[A];
-            eval_net<D, H, A, false>(la_t, a.w2a_actor, xk, out, lane);
+            eval_net<D, H, A, false, SPLIT>(la_t, a.w2a_actor, xk, out, lane);
             int act_env = 0; float actf_env = 0.f; float logp;
             if (DISC) {
                 float p[A]; softmax_n<A>(out, p);
@@ -887,7 +902,7 @@ __global__ __launch_bounds__(128, 2) void rollout_duo_kernel(RolloutArgs a) {
             for (int i = 0; i < D; ++i) obs[i] = sl[i * 32 + c];
             float xk[FirstLayer<D>::KS], v[1];
             pair_obs<D>(obs, h, xk);
-            eval_net<D, H, 1, false>(lc_t, a.w2a_critic, xk, v, lane);
+            eval_net<D, H, 1, false, SPLIT>(lc_t, a.w2a_critic, xk, v, lane);
             if (t < a.T) { if (writer) a.val[(size_t)t * a.E + e] = v[0]; }
             else if (writer) a.last_values[e] = v[0];                  // V(new_obs) for rollout-limited trajectories, trajectory.jl:65-70
             if (t > 0) {
@@ -898,7 +913,7 @@ __global__ __launch_bounds__(128, 2) void rollout_duo_kernel(RolloutArgs a) {
                     for (int i = 0; i < D; ++i) tobs[i] = sl[(D + i) * 32 + c];
                     float tk[FirstLayer<D>::KS], bv[1];
                     pair_obs<D>(tobs, h, tk);
-                    eval_net<D, H, 1, false>(lc_t, a.w2a_critic, tk, bv, lane);
+                    eval_net<D, H, 1, false, SPLIT>(lc_t, a.w2a_critic, tk, bv, lane);
                     if (writer && trunc) a.boot[(size_t)(t - 1) * a.E + e] = bv[0];
                 }
             }
@@ -1266,8 +1281,8 @@ __global__ void explained_var_kernel(const float* val, const float* ret, int64_t
 // =============================================================================================
 // launchers
 // =============================================================================================
-template <int KIND, int H, bool WIDE> static size_t fwd_lds_bytes() {
-    return sizeof(float) * (FwdLds<EnvSpec<KIND>::D, H, EnvSpec<KIND>::A, WIDE>::SIZE + FwdLds<EnvSpec<KIND>::D, H, 1, WIDE>::SIZE);
+template <int KIND, int H, bool WIDE, bool SPLIT> static size_t fwd_lds_bytes() {
+    return sizeof(float) * (FwdLds<EnvSpec<KIND>::D, H, EnvSpec<KIND>::A, WIDE, SPLIT>::SIZE + FwdLds<EnvSpec<KIND>::D, H, 1, WIDE, SPLIT>::SIZE);
 }
 // kind 2 (ScalingWrapperEnv(Pendulum)) shares every kernel that never touches the simulator with kind 1
 #define DRIL_DISPATCH(kind, hidden, CALL)                                            \
@@ -1312,6 +1327,12 @@ hipError_t launch_fold_partials(const double* partials, int nblocks, double* out
 hipError_t launch_build_wimg_split(const float* params, NetOff off, int H, void* w2p, void* w2tp, void* w2pf, hipStream_t s) {
     const int total = (H / 32) * (H / 32) * 2 * 64;
     build_wimg_split_kernel<<<(total + 255) / 256, 256, 0, s>>>(params, off, H, (u32x4*)w2p, (u32x4*)w2tp, (u32x4*)w2pf);
+    return hipGetLastError();
+}
+hipError_t launch_w2_absmax(const float* params, NetOff actor, NetOff critic, int H, unsigned* out_bits, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out_bits, 0, sizeof(unsigned), s); if (e != hipSuccess) return e;
+    const int total = 2 * H * H;
+    w2_absmax_kernel<<<(total + 4095) / 4096, 256, 0, s>>>(params, actor.w2, critic.w2, H * H, out_bits);
     return hipGetLastError();
 }
 hipError_t launch_build_wimg(const float* params, NetOff off, int H, float* w2a, float* w2ta, hipStream_t s) {
@@ -1396,45 +1417,51 @@ hipError_t launch_policy(int kind, int hidden, const PolicyArgs& a, int max_bloc
     int blocks = (int)((ntiles + 3) / 4);
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-#define CALL(K, HH)                                                                                           \
+#define CALLS(K, HH, SP)                                                                                      \
     {                                                                                                         \
-        const size_t lds = fwd_lds_bytes<K, HH, (HH > 64)>();                                                 \
+        const size_t lds = fwd_lds_bytes<K, HH, (HH > 64), SP>();                                             \
         static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)policy_kernel<K, HH, (HH > 64)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)policy_kernel<K, HH, (HH > 64), SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e; attr_set = true; }                                                 \
-        policy_kernel<K, HH, (HH > 64)><<<blocks, 256, lds, s>>>(a);                                          \
+        policy_kernel<K, HH, (HH > 64), SP><<<blocks, 256, lds, s>>>(a);                                      \
     }
+#define CALL(K, HH) { if (a.exact_f32) CALLS(K, HH, false) else CALLS(K, HH, true) }
     DRIL_DISPATCH_FWD(kind, hidden, CALL);
 #undef CALL
+#undef CALLS
     return hipGetLastError();
 }
 
-template <int KIND, int H> static size_t duo_lds_bytes() {
+template <int KIND, int H, bool SPLIT> static size_t duo_lds_bytes() {
     constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
-    return sizeof(float) * (FwdLds<D, H, A, false>::SIZE + FwdLds<D, H, 1, false>::SIZE + 2 * (2 * D + 1) * 32);
+    return sizeof(float) * (FwdLds<D, H, A, false, SPLIT>::SIZE + FwdLds<D, H, 1, false, SPLIT>::SIZE + 2 * (2 * D + 1) * 32);
 }
 hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_t s) {
     static const bool no_duo = std::getenv("DRIL_NO_ROLLOUT_DUO") != nullptr;          // A/B knob
     if (hidden == 64 && a.E <= 16384 && !no_duo && ((kind >= 0 && kind <= 4) || kind == 6 || kind == 7)) {                                      // env counts that leave SIMDs idle: two waves per tile of 32 envs
         const int blocks = (a.E + kTile - 1) / kTile;
-#define CALLD(K) { const size_t lds = duo_lds_bytes<K, 64>(); static bool attr_set = false; \
-            if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)rollout_duo_kernel<K, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
-            rollout_duo_kernel<K, 64><<<blocks, 128, lds, s>>>(a); }
+#define CALLDS(K, SP) { const size_t lds = duo_lds_bytes<K, 64, SP>(); static bool attr_set = false; \
+            if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)rollout_duo_kernel<K, 64, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
+            rollout_duo_kernel<K, 64, SP><<<blocks, 128, lds, s>>>(a); }
+#define CALLD(K) { if (a.exact_f32) CALLDS(K, false) else CALLDS(K, true) }
         if (kind == 0) CALLD(0) else if (kind == 1) CALLD(1) else if (kind == 2) CALLD(2) else if (kind == 3) CALLD(3) else if (kind == 6) CALLD(6) else if (kind == 7) CALLD(7) else CALLD(4)
 #undef CALLD
+#undef CALLDS
         return hipGetLastError();
     }
     const int blocks = (a.E + 4 * kTile - 1) / (4 * kTile);
-#define CALL(K, HH)                                                                                           \
+#define CALLS(K, HH, SP)                                                                                      \
     {                                                                                                         \
-        const size_t lds = fwd_lds_bytes<K, HH, (HH > 64)>();                                                 \
+        const size_t lds = fwd_lds_bytes<K, HH, (HH > 64), SP>();                                             \
         static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel<K, HH, (HH > 64)>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)rollout_kernel<K, HH, (HH > 64), SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e; attr_set = true; }                                                 \
-        rollout_kernel<K, HH, (HH > 64)><<<blocks, 256, lds, s>>>(a);                                         \
+        rollout_kernel<K, HH, (HH > 64), SP><<<blocks, 256, lds, s>>>(a);                                     \
     }
+#define CALL(K, HH) { if (a.exact_f32) CALLS(K, HH, false) else CALLS(K, HH, true) }
     DRIL_DISPATCH_ENV(kind, hidden, CALL);
 #undef CALL
+#undef CALLS
     return hipGetLastError();
 }
 

@@ -601,6 +601,16 @@ class Handle:
         self._chk(self.lib.dril_ppo_update(self._h, C.byref(st)))
         return st
 
+    def f32_retries(self) -> int:
+        """updates redone on the exact-f32 kernels because an f16-piece kernel left f16's range (dril_f32_retries)"""
+        return int(self.lib.dril_f32_retries(self._h))
+
+    def f32_fallback_info(self) -> dict:
+        """struct dril_f32_fallback as a dict: retries, direct_updates, persistent_fallbacks, latch_updates_left, forward_exact_f32, max_abs_w2"""
+        fb = capi.DrilF32Fallback()
+        self._chk(self.lib.dril_f32_fallback_info(self._h, C.byref(fb)))
+        return {k: getattr(fb, k) for k, _ in fb._fields_ if k != "reserved"}
+
     def set_permutation(self, perm: Optional[np.ndarray]):
         if perm is None:
             self._chk(self.lib.dril_debug_set_permutation(self._h, None, 0))
@@ -712,6 +722,11 @@ class DeviceParallelEnv:
         self._bound_key = None
         self._last_term = np.zeros(n_envs, bool)
         self._last_trunc = np.zeros(n_envs, bool)
+        self.last_f32_paths: list = []      # dril_ppo_stats.f32_path of every iteration of the last train_ (0 = the default kernels throughout)
+
+    def f32_fallback_info(self) -> dict:
+        """how often this env's handle left the f16-piece arithmetic (dril_f32_fallback_info); all zeros for a healthy run on normalised data"""
+        return self.handle.f32_fallback_info() if self.handle else {}
 
     # binding: one handle carries env + agent + alg state; (re)created when the alg/layer shape changes
     def bind(self, alg: PPO, layer: Optional[ActorCriticLayer] = None) -> Handle:
@@ -1004,6 +1019,7 @@ def train_(agent: Agent, env: DeviceParallelEnv, alg: PPO, max_steps: int, callb
     iterations = max_steps // per_iter  # ppo.jl:117
     timer["setup"] = time.perf_counter() - t0
     learn_stats = {k: [] for k in _STAT_KEYS}
+    env.last_f32_paths = []
     loc = dict.fromkeys(TRAINING_START_LOCALS)                                                # the keys test/test_callbacks.jl:25-27 looks for in Base.@locals
     loc.update(agent=agent, env=env, alg=alg, iterations=iterations, total_steps=iterations * per_iter, max_steps=max_steps, n_steps=alg.n_steps,
                n_envs=env.n_envs, roll_buffer=None, total_fps=learn_stats["fps"], callbacks=cbs, learn_stats=learn_stats)
@@ -1047,6 +1063,7 @@ def train_(agent: Agent, env: DeviceParallelEnv, alg: PPO, max_steps: int, callb
             learn_stats["losses"].append(st.loss)
             learn_stats["explained_variances"].append(st.explained_variance)
             learn_stats["grad_norms"].append(st.grad_norm)
+            env.last_f32_paths.append(int(st.f32_path))                                       # per iteration: 0 default kernels, 1 redone on exact f32, 2 run directly on exact f32 (learn_stats keeps the reference's keys)
         timer["training_loop"] = time.perf_counter() - t1
         timer["collect_rollout"] = t_roll
         timer["epoch loop"] = t_upd

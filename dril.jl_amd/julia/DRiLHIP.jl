@@ -66,7 +66,14 @@ end
 struct DrilPPOStats
     entropy_loss::Float32; policy_loss::Float32; value_loss::Float32; approx_kl_div::Float32; clip_fraction::Float32
     loss::Float32; grad_norm::Float32; explained_variance::Float32; entropy::Float32; ratio_first::Float32
-    n_updates::Int32; early_stopped::Int32; nan_or_inf::Int32; reserved::Int32
+    n_updates::Int32; early_stopped::Int32; nan_or_inf::Int32
+    f32_path::Int32      # 0 default kernels; 1 redone on the exact-f32 kernels (an f16-piece kernel left f16's range); 2 run directly on them (latch / W2 out of range)
+end
+
+# struct dril_f32_fallback (include/dril_hip.h): how often the library left its f16-piece arithmetic; a healthy run on normalised data shows retries == direct_updates == 0
+struct DrilF32Fallback
+    retries::Int64; direct_updates::Int64; persistent_fallbacks::Int64
+    latch_updates_left::Int32; forward_exact_f32::Int32; max_abs_w2::Float32; reserved::Int32
 end
 
 const ENV_KINDS = Dict(:CartPole => Int32(0), :Pendulum => Int32(1), :ScaledPendulum => Int32(2), :MountainCar => Int32(3), :MountainCarContinuous => Int32(4), :Acrobot => Int32(6), :ScaledMountainCarContinuous => Int32(7))   # :ScaledPendulum = ScalingWrapperEnv(PendulumEnv()) on every sub-env (scalingWrapperEnv.jl)
@@ -355,12 +362,18 @@ end
 "seconds of HIP-event time per kernel class since the last reset (dril_profile_get; cfg.profile_events = 1)"
 function kernel_seconds(h)
     out = Dict{String, Float64}()
-    for kid in 0:6
+    for kid in 0:(Int(ccall((:dril_kernel_count, LIB[]), Int32, ())) - 1)
         ms = Ref{Float64}(0); n = Ref{Int64}(0)
         ccall((:dril_profile_get, LIB[]), Int32, (Ptr{Cvoid}, Int32, Ref{Float64}, Ref{Int64}), h, kid, ms, n) == 0 || continue
         out[unsafe_string(ccall((:dril_kernel_name, LIB[]), Cstring, (Int32,), kid))] = ms[] * 1.0e-3
     end
     return out
+end
+"counters of the exact-f32 redo / latch / forward fallback of this env's handle (dril_f32_fallback_info); also logged per iteration as train/f32_path"
+function f32_fallback_info(env::DeviceParallelEnv)
+    out = Ref{DrilF32Fallback}()
+    check(ccall((:dril_f32_fallback_info, LIB[]), Int32, (Ptr{Cvoid}, Ref{DrilF32Fallback}), env.handle, out), env.handle)
+    return out[]
 end
 "which gradient kernel the last optimiser step ran and the arithmetic it computes in, e.g. \"ppo_grad_pair_kernel: f32 (f16x2 split, f32 accumulate; ...)\" (dril_grad_kernel_info)"
 grad_kernel_info(env::DeviceParallelEnv) = unsafe_string(ccall((:dril_grad_kernel_info, LIB[]), Cstring, (Ptr{Cvoid},), env.handle))
@@ -450,6 +463,7 @@ function train!(agent::PPOAgent, env::DeviceParallelEnv, alg::PPO{T}, max_steps:
                 "grad_norm" => s.grad_norm, "learning_rate" => learning_rate)
                 DRiL.log_scalar!(agent.logger, "train/" * k, v)                                                    # ppo.jl:286-294
             end
+            s.f32_path != 0 && DRiL.log_scalar!(agent.logger, "train/f32_path", Float32(s.f32_path))               # (not a reference key: this update left the f16-piece kernels; learn_stats keeps the reference's shape)
         end
         env.last_kernel_seconds = kernel_seconds(env.handle)
         add_device_sections!(to, env.last_kernel_seconds, n_updates)

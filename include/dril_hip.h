@@ -64,7 +64,8 @@ enum dril_env_kind {
     DRIL_ENV_EXTERNAL = 5,
     /* Acrobot-v1 (Gymnasium "book" dynamics, one RK4 step of 0.2 s per env step): D=6 (cos t1, sin t1, cos t2, sin t2, w1, w2), Discrete(3) torques
      * -1/0/+1, reward -1 per step (0 on reaching the height), limit 500.  A device env like the others; hidden_dims [64,64] run the fused kernels (four
-     * first-layer k-steps for its six observation dims, the exact-f32 update kernel), any other hidden_dims the generic kernels */
+     * first-layer k-steps for its six observation dims; the update on the pair / persistent f16-piece kernels like the other envs, dW1 through a third piece image),
+     * hidden 128 / 256 the wide fused kernels, any other hidden_dims the generic kernels */
     DRIL_ENV_ACROBOT = 6,
     /* ScalingWrapperEnv(MountainCarContinuousEnv()): observations Box((-1.2, -0.07), (0.6, 0.07)) scaled to Box(-1, 1), actions Box(-1, 1) mapped back by the same
      * affine formulas (scalingWrapperEnv.jl:71-79); every kernel that does not touch the simulator is shared with DRIL_ENV_MOUNTAINCAR_CONTINUOUS */
@@ -96,7 +97,9 @@ enum dril_kernel_id {
     DRIL_K_GRAD_REDUCE = 4,
     DRIL_K_ADAM = 5,
     DRIL_K_ALLREDUCE = 6,
-    DRIL_K_COUNT = 7
+    DRIL_K_PACK_RECORDS = 7,   /* pack_records_kernel: the rollout buffer's SoA fields -> one 32-byte record per sample and net, once per update */
+    DRIL_K_EXPLAINED_VAR = 8,  /* explained_var_kernel: the four sums of ppo.jl:256 over the whole buffer */
+    DRIL_K_COUNT = 9           /* grows with the library: loop to dril_kernel_count() */
 };
 
 /* Plain-C mirror of `PPO` (src/algorithms/ppo.jl:25-40), the layer kwargs
@@ -155,8 +158,21 @@ typedef struct dril_ppo_stats {
     int32_t n_updates;         /* optimiser steps actually applied */
     int32_t early_stopped;     /* 1 if target_kl stopped the loops, ppo.jl:235-238 */
     int32_t nan_or_inf;        /* 1 if a gradient contained NaN/Inf (status is DRIL_ERR_NAN_IN_GRADS too) */
-    int32_t reserved;
+    int32_t f32_path;          /* which kernels produced THIS update (was `reserved`): 0 the default ones; 1 redone on the exact-f32 kernels after an f16-piece kernel
+                                * left f16's range; 2 run directly on the exact-f32 kernels (latched after repeated redos, or a W2 entry out of range) */
 } dril_ppo_stats;
+
+/* The fused kernels' default arithmetic (fp32-equivalent products from two f16 pieces per operand) holds fp32's PRECISION but f16's RANGE.  The reference asks no range of
+ * its user (ppo.jl:213-214 only asserts finiteness), so leaving it is handled inside the library and merely COUNTED here:
+ *   retries              updates taken back and redone on the exact-f32 kernels because an f16-piece step met a non-finite gradient (2x the update's time, each)
+ *   direct_updates       updates run on the exact-f32 kernels at once: after 2 consecutive retries the next 16 updates (then one update probes f16 again), or max|W2| >= 350
+ *   persistent_fallbacks updates of the two-workgroup persistent kernel (batch_size <= 64) redone on the per-step kernels because its workgroups were not co-resident
+ *   latch_updates_left   updates the latch still covers; forward_exact_f32: 1 while rollout / policy forwards run the f32-MFMA kernels (max_abs_w2 >= 350 or DRIL_GRAD_VARIANT=0) */
+typedef struct dril_f32_fallback {
+    int64_t retries, direct_updates, persistent_fallbacks;
+    int32_t latch_updates_left, forward_exact_f32;
+    float max_abs_w2; int32_t reserved;
+} dril_f32_fallback;
 
 /* fill cfg with the reference defaults: PPO() ppo.jl:26-39, hidden_dims [64,64]
  * layer_constructors.jl:55, NormalizeWrapperEnv kwargs normalizeWrapperEnv.jl:71-80 (disabled) */
@@ -276,6 +292,9 @@ int32_t dril_gae(int32_t n_envs, int32_t n_steps, float gamma, float gae_lambda,
  * NaN asserts :213-214, nested_norm/nested_scale! :216-232, target_kl :235-238, Adam :239,
  * explained_variance :256, per-iteration means :257-264) */
 int32_t dril_ppo_update(dril_handle* h, dril_ppo_stats* out);
+/* see dril_f32_fallback above; dril_f32_retries = its `retries` alone (-1 for a null handle).  A healthy run on normalised data shows 0 / 0 */
+int64_t dril_f32_retries(const dril_handle* h);
+int32_t dril_f32_fallback_info(const dril_handle* h, dril_f32_fallback* out);
 /* injected DataLoader order: perm[e*N + p] = 0-based buffer index at position p of epoch e
  * (ppo.jl:188-195); NULL = device-generated pseudo-random bijection per epoch */
 int32_t dril_debug_set_permutation(dril_handle* h, const int64_t* perm, size_t count);
@@ -332,6 +351,7 @@ int32_t dril_debug_comm_loopback(dril_handle** handles, int32_t n);
 int32_t dril_profile_get(dril_handle* h, int32_t kernel_id, double* total_ms, int64_t* launches);
 int32_t dril_profile_reset(dril_handle* h);
 const char* dril_kernel_name(int32_t kernel_id);
+int32_t dril_kernel_count(void);   /* DRIL_K_COUNT of the loaded library */
 /* which gradient kernel the handle's LAST optimiser step ran and the arithmetic it computes in ("<kernel>: <arithmetic>"; "none yet" before the
  * first step): hidden [64,64] runs ppo_grad_pair_kernel (f16 matrix cores, fp32-equivalent two-piece operand split) on large minibatches and the f32-MFMA
  * ppo_grad_kernel on small ones, [128,128] and [256,256] ppo_grad_wide_split_kernel, everything else the generic path (DESIGN.md section 5;

@@ -397,6 +397,37 @@ def test_any_depth_and_relu_on_device(pkg, oracle_mod, kind, hidden, act, norm):
     np.testing.assert_allclose(h.get_params(), o.get_params(), rtol=3e-4, atol=3e-6)
 
 
+@pytest.mark.parametrize("bias", [-10.0, -15.0])
+def test_softplus_far_negative_preactivations_on_device(pkg, oracle_mod, bias):
+    """ADVICE r3 (dril_gemm.hip EPI_MASK_SOFTPLUS): sigmoid(x) from y = softplus(x) as -expm1(-y): the first layer's gradient behind far-negative pre-activations
+    against the oracle (pinned to float64 torch autograd for this very case, tests/test_oracle_crosschecks.py) to 1e-3 of its own size"""
+    c = pkg._capi.default_config(4)
+    for k, v in dict(n_envs=8, n_steps=8, batch_size=32, epochs=1, ent_coef=0.01, n_hidden=2, activation=5).items():
+        setattr(c, k, v)
+    c.hidden[0] = c.hidden[1] = 48
+    h, o = pkg.Handle(c), oracle_mod.Oracle(c)
+    flat = _params(h.P, 3, 0.3)
+    D, H = h.D, 48
+    per_net = [D * H + H + H * H + H + H * O + O for O in (h.A, 1)]
+    l1 = []
+    for base in (0, per_net[0]):
+        flat[base + D * H: base + D * H + H] = bias
+        l1.append(slice(base, base + D * H + H))
+    h.set_params(flat); o.set_params(flat)
+    rng = np.random.default_rng(5)
+    B = 333
+    obs = rng.uniform(-1.5, 1.5, (B, D)).astype(np.float32)
+    act_b = rng.normal(0, 1, (B, h.A)).astype(np.float32)
+    adv, ret, ov = (rng.standard_normal(B).astype(np.float32) for _ in range(3))
+    lp = (o.evaluate_actions(obs, act_b)[1] + rng.normal(0, 0.1, B)).astype(np.float32)
+    lh, _, gh = h.ppo_loss_grad(obs, act_b, adv, ret, lp, ov); lo, _, go = o.ppo_loss_grad(obs, act_b, adv, ret, lp, ov)
+    assert lh == pytest.approx(lo, rel=1e-4)
+    for sl in l1:
+        assert np.linalg.norm(go[sl]) > 0 and np.linalg.norm(gh[sl] - go[sl]) <= 1e-3 * np.linalg.norm(go[sl])
+    assert np.linalg.norm(gh - go) <= 3e-4 * np.linalg.norm(go)
+    h.close()
+
+
 def test_relu_three_layer_agent_learns_through_the_mirror(pkg):
     """the host mirror carries hidden_dims / activation end to end: ActorCriticLayer(...; hidden_dims = [32, 32, 32], activation = relu) trains on CartPole"""
     env = pkg.DeviceParallelEnv(pkg.CartPoleEnv(max_steps=200), 256, seed=1)

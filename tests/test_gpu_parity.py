@@ -1100,18 +1100,42 @@ def test_persistent_small_update_across_launch_boundaries(pkg, oracle_mod, monke
 
 
 def test_persistent_small_update_gives_up_instead_of_hanging(pkg, oracle_mod, monkeypatch):
-    """the persistent update is TWO workgroups (actor | critic) that exchange one message per optimiser step through L2.  If the partner never runs, a workgroup
-    must leave after a bounded wait and the call must return a status code — never hang the device.  DRIL_SMALL_DEBUG_SOLO launches the actor's workgroup alone:
-    the update fails with DRIL_ERR_HIP within seconds, leaves the parameters untouched, and the same handle trains normally afterwards"""
+    """the persistent update is TWO workgroups (actor | critic) that exchange one message per optimiser step through L2.  If the partner never runs (the GPU is shared and the
+    two were not resident together), a workgroup must leave after a bounded wait — never hang the device.  DRIL_SMALL_DEBUG_SOLO launches the actor's workgroup alone:
+      * with the snapshot the library keeps for its redos, nothing is lost: the update is taken back and redone on the per-step kernels (bitwise what
+        DRIL_NO_PERSISTENT_UPDATE=1 gives), counted in persistent_fallbacks, and the handle stays on the per-step kernels (ADVICE r3);
+      * without it (DRIL_NO_F32_RETRY=1) the call returns DRIL_ERR_HIP within seconds and leaves the parameters untouched."""
     import time
     capi = pkg._capi
     cfg = _cfg(pkg, 0, n_envs=8, n_steps=16, batch_size=32, epochs=1, episode_len=11)
     o = oracle_mod.Oracle(cfg)
     flat = _params(o.P, 3, 0.3); o.set_params(flat); o.env_reset(5); o.collect_rollout()
+
+    def make(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = pkg.Handle(cfg); h.set_params(flat)
+        for k in env:
+            monkeypatch.delenv(k)
+        for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
+            h.set_buffer(which, o.buffer(which))
+        return h
+    h, href = make(), make(DRIL_NO_PERSISTENT_UPDATE="1")
     monkeypatch.setenv("DRIL_SMALL_DEBUG_SOLO", "1")
-    h = pkg.Handle(cfg); h.set_params(flat)
-    for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
-        h.set_buffer(which, o.buffer(which))
+    t0 = time.time()
+    st = h.ppo_update()
+    assert time.time() - t0 < 30.0
+    monkeypatch.delenv("DRIL_SMALL_DEBUG_SOLO")
+    sr = href.ppo_update()
+    assert h.f32_fallback_info()["persistent_fallbacks"] == 1 and st.n_updates == sr.n_updates == 4 and st.loss == sr.loss
+    np.testing.assert_array_equal(h.get_params(), href.get_params())
+    assert h.get_optimizer_state()["steps"] == href.get_optimizer_state()["steps"] == 4
+    assert not h.grad_kernel_info().startswith("ppo_update_small_kernel")
+    st = h.ppo_update(); sr = href.ppo_update()                                       # the handle stays on the per-step kernels
+    assert h.f32_fallback_info()["persistent_fallbacks"] == 1 and st.loss == sr.loss and not h.grad_kernel_info().startswith("ppo_update_small_kernel")
+    h.close(); href.close()
+    h = make(DRIL_NO_F32_RETRY="1")                                                    # no snapshot: the failure surfaces
+    monkeypatch.setenv("DRIL_SMALL_DEBUG_SOLO", "1")
     t0 = time.time()
     with pytest.raises(Exception) as ei:
         h.ppo_update()
@@ -1119,7 +1143,7 @@ def test_persistent_small_update_gives_up_instead_of_hanging(pkg, oracle_mod, mo
     assert np.array_equal(h.get_params(), flat)
     monkeypatch.delenv("DRIL_SMALL_DEBUG_SOLO")
     st = h.ppo_update()                                                               # the knob is read per update: both workgroups again
-    assert st.n_updates == 4 and np.isfinite(st.loss) and not np.array_equal(h.get_params(), flat)
+    assert st.n_updates == 4 and np.isfinite(st.loss) and not np.array_equal(h.get_params(), flat) and h.grad_kernel_info().startswith("ppo_update_small_kernel")
     h.close()
 
 

@@ -135,6 +135,32 @@ def test_any_depth_and_relu_vs_torch_autograd(oracle_mod, pkg, kind, hidden, act
     np.testing.assert_allclose(grads, tg, rtol=5e-3, atol=5e-6)
 
 
+@pytest.mark.parametrize("bias", [-10.0, -15.0])
+def test_softplus_far_negative_preactivations_vs_torch_autograd(oracle_mod, pkg, bias):
+    """softplus'(x) = sigmoid(x) recovered from the stored activation y = softplus(x) as 1 - e^(-y) cancels for x << 0 (y ~ e^x: 1 % error at x = -10, all digits
+    gone near -16).  With first-layer biases of -10 / -15 the first layer's gradient is tiny but must still be RELATIVELY right (-expm1(-y)); checked layer by layer
+    against float64 torch autograd — the same case runs on the device in tests/test_gpu_external.py"""
+    cfg = pkg._capi.default_config(4); cfg.n_envs, cfg.n_steps = 2, 2; cfg.ent_coef = 0.01      # MountainCarContinuous: D = 2, Box(1)
+    cfg.n_hidden = 2; cfg.activation = 5; cfg.hidden[0] = cfg.hidden[1] = 48
+    o = oracle_mod.Oracle(cfg)
+    flat = (np.random.default_rng(3).standard_normal(o.P) * 0.3).astype(np.float32)
+    D, H = o.D, 48
+    per_net = [D * H + H + H * H + H + H * O + O for O in (o.A, 1)]
+    l1 = []
+    for base in (0, per_net[0]):
+        flat[base + D * H: base + D * H + H] = bias                                    # b1 of this net
+        l1.append(slice(base, base + D * H + H))
+    o.set_params(flat)
+    batch = make_batch(o, cfg, 90, 11, o.discrete, o.A)
+    loss, stats, grads = o.ppo_loss_grad(*batch)
+    tl, ts, tg = torch_ppo_loss(flat, cfg, *batch, o.discrete, o.A)
+    assert loss == pytest.approx(tl, rel=1e-4)
+    for sl in l1:
+        assert 0 < np.linalg.norm(tg[sl]) < 1e-2 * np.linalg.norm(tg)                   # the far-negative units really are nearly closed ...
+        assert np.linalg.norm(grads[sl] - tg[sl]) <= 1e-3 * np.linalg.norm(tg[sl])      # ... and their gradient is right to 1e-3 of ITS size (1 - e^(-y) gave 1e-2 at -10, O(1) at -15)
+    assert np.linalg.norm(grads - tg) <= 1e-4 * np.linalg.norm(tg)
+
+
 def _ext_cfg(pkg, D, A, discrete, H1, H2):
     c = pkg._capi.default_config(pkg._capi.ENV_EXTERNAL)
     c.ext_obs_dim, c.ext_action_dim, c.ext_discrete, c.hidden1, c.hidden2, c.n_envs, c.n_steps = D, A, int(discrete), H1, H2, 2, 2
