@@ -38,7 +38,35 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16,
 # kernels until the end of round 3), THREE f16 ones with two-piece operands (the fused kernels since) — the kernel's own ceiling in delivered f32 flops
 # is the dense 16-bit peak (the same for f16 and bf16) over that count
 PEAK_BF16_SPLIT6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6
-PMC_FILE = "r03_ppo_grad_pmc.json"  # HBM traffic (PMC) + rocprofv3 average of the dominant kernel on configs[1], with the commit it was taken at
+# HBM traffic (PMC) + rocprofv3 average of the dominant kernel, replayed from the committed profile of exactly that workload (each file names the commit it was taken at)
+PMC_FILES = {("cartpole", 64): "r04_ppo_grad_pmc.json", ("pendulum", 256): "r04_wide_split_pmc.json"}
+PEAK_HBM_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s (~ 6.3 TB/s is what a streaming kernel reaches)
+
+
+def hbm_kernels(prof: dict, *, N: int, D: int, A: int, discrete: bool, P: int, epochs: int, steps: int, normalize: bool) -> list:
+    """the bandwidth-class kernels of the path one by one — ALGORITHMIC bytes per launch class (what the data structure obliges the kernel to move,
+    not what the caches saw) / HIP-event time of that class in the timed region / the 8 TB/s HBM peak.  Units: N = env-steps of one rollout (per GPU), P = parameters."""
+    act = 4 if discrete else 4 * A
+    recq = 2 if D <= 4 else 3
+    rows = [
+        ("rollout_kernel", 4 * D + act + 4 + 4 + 4 + 2, N, "buffer WRITE per env-step: obs 4D + action + reward + logprob + value + flags (the kernel is bound by its two MLP forwards, not by this)"),
+        ("gae_kernel", 18, N, "read r, V, flags (+ V of the next row from cache) 10 B, write A, R 8 B"),
+        ("pack_records_kernel", 32 + 16 * recq, N, f"read obs 4D + action + adv + logp + ret, write {recq} float4 per sample"),
+        ("adv_moments_kernel", 12 * epochs, N, "per epoch: epoch_index_kernel writes 8 B per sample (the DataLoader order), epoch_moments_kernel gathers 4 B per sample"),
+        ("explained_var_kernel", 8, N, "read V, R"),
+        ("adam_kernel", 28, P, "per launch: read g, p, m, v, write p, m, v (a few hundred KB: launch-latency-bound, not bandwidth-bound)"),
+    ]
+    out = []
+    for name, bpu, units, what in rows:
+        k = prof.get(name)
+        if not k or not k["launches"]:
+            continue
+        per_launch = name == "adam_kernel"
+        total_bytes = bpu * units * (k["launches"] if per_launch else steps)
+        gbps = total_bytes / (k["total_ms"] * 1e-3) / 1e9
+        out.append({"kernel": name, "bytes_per_unit": bpu, "unit": "parameter, per launch" if per_launch else "env-step, per rollout", "what": what, "launches": k["launches"],
+                    "ms_per_step": k["total_ms"] / steps, "achieved_GBps": gbps, "peak_GBps": PEAK_HBM_GBPS, "frac": gbps / PEAK_HBM_GBPS})
+    return out
 
 
 def mfma_roofline(ach_tflops: float, arith: str) -> dict:
@@ -149,7 +177,8 @@ def run_sac(pkg, *, steps: int, warmup: int, iters: int, E: int = 4096, H: int =
 
 
 def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int, epochs: int, normalize: bool, steps: int, warmup: int, events: bool = True,
-            batch_size: int | None = None, fixed_length: bool = True, label: str = "", rank: int = 0, local_rank: int = 0, world: int = 1, dist=None) -> dict | None:
+            batch_size: int | None = None, fixed_length: bool = True, label: str = "", rank: int = 0, local_rank: int = 0, world: int = 1, dist=None,
+            grad_variant: str | None = None) -> dict | None:
     """one PPO workload: `warmup` untimed iterations, then exactly `steps` iterations (rollout + GAE + epochs x minibatches update) between a barrier +
     stream synchronisation on both sides, max over ranks; returns the result dict on rank 0."""
     N_local = E * T
@@ -159,7 +188,14 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
     layer = pkg.ActorCriticLayer(env.observation_space(), env.action_space(), hidden_dims=(hidden, hidden))
     cfg = pkg.make_config(env, E, alg, layer, seed=42, fixed_length_episodes=fixed_length, device=local_rank, rank=rank, world_size=world,
                           profile_events=events, normalize={} if normalize else None)
-    h = pkg.Handle(cfg)
+    old_gv = os.environ.get("DRIL_GRAD_VARIANT")
+    if grad_variant is not None:
+        os.environ["DRIL_GRAD_VARIANT"] = grad_variant      # latched by dril_create: "0" = the exact-f32 kernels (v_mfma_f32_32x32x2_f32) for update AND forward
+    try:
+        h = pkg.Handle(cfg)
+    finally:
+        if grad_variant is not None:
+            os.environ.pop("DRIL_GRAD_VARIANT") if old_gv is None else os.environ.__setitem__("DRIL_GRAD_VARIANT", old_gv)
     h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(42))))   # random-init weights of the named architecture
     if world > 1:
         uid = [h.comm_unique_id() if rank == 0 else None]
@@ -217,6 +253,8 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
             "loss_last": last.loss, "n_updates_last": last.n_updates,
             # what the communicator itself reports (ncclCommCount), not the launcher's WORLD_SIZE; 1 = no communicator (single GPU)
             "rccl_ranks": h.comm_ranks(), "allreduce_calls": h.comm_allreduce_calls(),
+            # updates that left the f16-piece arithmetic (dril_f32_fallback_info): retries = redone on the exact-f32 kernels, direct = run on them at once; 0 / 0 for this workload
+            "f32_retries": h.f32_retries(), "f32_fallback": h.f32_fallback_info(),
             "value_per_gpu": value / world,      # N = 1-equivalent figure, to be read against the N = 1 BENCH line
         }
         gk = prof.get("ppo_grad_kernel", {"total_ms": 0, "launches": 0})
@@ -232,11 +270,12 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
             # traffic and the rocprofv3 average are NOT measured in this run (PMC needs its own rocprofv3 passes): they are replayed from the
             # committed profile of exactly this workload, and the line says so (traffic_source: file + the commit the profile was taken at)
             traffic = traffic_source = rocprof_ms = None
-            pmc = ROOT / "profiles" / PMC_FILE
-            if pmc.exists() and env_name == "cartpole" and hidden == 64 and minibatches == 32 and E == 65536 and T == 2048 and not batch_size:
+            pmc_name = PMC_FILES.get((env_name, hidden))
+            pmc = ROOT / "profiles" / pmc_name if pmc_name else None
+            if pmc and pmc.exists() and minibatches == 32 and E == 65536 and T == 2048 and not batch_size and grad_variant is None and world == 1:
                 rec = json.loads(pmc.read_text())
                 traffic, rocprof_ms = rec.get("hbm_bytes_per_launch"), rec.get("rocprof_avg_launch_ms")
-                traffic_source = f"replayed from profiles/{PMC_FILE} (rocprofv3 --pmc passes at commit {rec.get('commit', '?')}); not measured in this run"
+                traffic_source = f"replayed from profiles/{pmc_name} (rocprofv3 --pmc passes at commit {rec.get('commit', '?')}); not measured in this run"
             kname, arith = info.split(": ", 1)
             out["dtype"] = "f32 (f16x2 split, f32 accumulate)" if "f16x2" in arith else "f32 (bf16x3 split, f32 accumulate)" if "bf16x3" in arith else "f32"
             out["roofline"] = dict(mfma_roofline(ach, arith), traffic=traffic, traffic_source=traffic_source, kernel=kname, avg_launch_ms=avg_ms,
@@ -244,6 +283,7 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
                                    rocprof_avg_launch_ms=rocprof_ms, launches=gk["launches"], flops_per_launch=flops,
                                    record_bytes_per_launch=(B_global // world) * 64)      # one 32-byte record per sample and net (the algorithmic gather volume of the record path)
             out["kernel_ms_per_step"] = {k: v["total_ms"] / steps for k, v in prof.items() if v["launches"]}
+            out["hbm_kernels"] = hbm_kernels(prof, N=N_local, D=h.D, A=h.A, discrete=bool(h.discrete), P=h.P, epochs=epochs, steps=steps, normalize=normalize)
             rk = prof.get("rollout_kernel", {"total_ms": 0, "launches": 0})
             if rk["launches"]:                           # what the reference logs as env/fps (rollout_buffer.jl:60-64, ppo.jl:176): env steps per second of the collection alone (HIP events around the rollout)
                 out["rollout_only_env_steps_per_s"] = N_local * world * steps / (rk["total_ms"] * 1e-3)
@@ -253,9 +293,13 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
 
 def secondary_runs(pkg) -> list:
     """short, timed runs of the other single-GPU configs of BASELINE.json beside the headline line (a driver-observed number for each):
-    configs[2] Pendulum [256,256] + NormalizeWrapperEnv at full size (1 warm-up + 2 iterations), configs[4] SAC (1 + 2 steps of 500 iterations),
+    configs[1] on the exact-f32 kernels (1 warm-up + 2 iterations), configs[2] Pendulum [256,256] + NormalizeWrapperEnv at full size (1 warm-up + 2 iterations), configs[4] SAC (1 + 2 steps of 500 iterations),
     configs[0] the reference's README quick-start (4 envs, PPO() defaults, real CartPole episodes).  Each entry has its own config / roofline."""
     out = []
+    # configs[1] again on the exact-f32 kernels (DRIL_GRAD_VARIANT=0: v_mfma_f32_32x32x2_f32 for update and forward) — the literal reading of "all arithmetic is fp32"
+    # (SURVEY.md section 8 preamble); its roofline.frac is against the 157.3 TFLOP/s f32-MFMA peak
+    out.append(run_ppo(pkg, env_name="cartpole", E=65536, T=2048, hidden=64, minibatches=32, epochs=10, normalize=False, steps=2, warmup=1, grad_variant="0",
+                       label="CartPole-v1 configs[1] on the exact-f32 kernels (DRIL_GRAD_VARIANT=0)"))
     out.append(run_ppo(pkg, env_name="pendulum", E=65536, T=2048, hidden=256, minibatches=32, epochs=10, normalize=True, steps=2, warmup=1))
     out.append(run_sac(pkg, steps=2, warmup=1, iters=500, cpu=False))
     out.append(run_ppo(pkg, env_name="cartpole", E=4, T=2048, hidden=64, minibatches=0, epochs=10, normalize=False, steps=5, warmup=2, batch_size=64, fixed_length=False,

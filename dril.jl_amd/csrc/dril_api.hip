@@ -132,6 +132,7 @@ struct dril_handle {
     // about a ragged tail); streak = consecutive redone updates; after kRetryLatchAfter of them the next kRetryLatchUpdates updates run the exact-f32 kernels directly (no wasted f16
     // pass, no snapshot), then ONE update probes f16 again; direct = updates run that way (latched, or max |W2| out of f16's range)
     bool used_f16 = false, spin_timeout = false; int f32_streak = 0, f32_latch_left = 0; int64_t f32_direct_updates = 0, persistent_fallbacks = 0;
+    unsigned long long* gae_carry = nullptr; unsigned gae_tag = 0; int* gae_err = nullptr;   // gae_scan_kernel: the chunk-to-chunk carry words, the launch tag that validates them, its give-up flag
     unsigned* w2max_dev = nullptr; float w2max = 0.f;   // max |W2| over both nets (fused kernels): host copy refreshed by dril_set_params and with every optimiser run's statistics
     bool no_small_path = false, no_epoch_moments = false;   // DRIL_NO_SMALL_PATH / DRIL_NO_EPOCH_MOMENTS, latched in dril_create
     bool no_persistent = false; unsigned long long* small_xchg = nullptr; uint64_t* epoch_keys = nullptr; int epoch_keys_cap = 0; int64_t small_chunk = 16384;   // ppo_update_small_kernel (batch_size <= 64): DRIL_NO_PERSISTENT_UPDATE; per-epoch DataLoader keys on the device
@@ -555,6 +556,8 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     const size_t E = cfg->n_envs, N = (size_t)h->N, P = h->P;
     CCHK(dmalloc(&h->params, P)); CCHK(dmalloc(&h->adam_m, P)); CCHK(dmalloc(&h->adam_v, P)); CCHK(dmalloc(&h->bt, 4));
     CCHK(dmalloc(&h->flat, P + 8)); CCHK(dmalloc(&h->norm_out, 1)); CCHK(dmalloc(&h->w2max_dev, 1));
+    { const size_t words = (size_t)gae_chunks(cfg->n_steps) * cfg->n_envs; CCHK(dmalloc(&h->gae_carry, words)); CCHK(hipMemsetAsync(h->gae_carry, 0, words * 8, h->stream));
+      CCHK(dmalloc(&h->gae_err, 1)); CCHK(hipMemsetAsync(h->gae_err, 0, 4, h->stream)); }
     h->n_norm_partials = (int)((P + 31) / 32); CCHK(dmalloc(&h->norm_partials, h->n_norm_partials));
     if (h->generic) { h->slab_a = generic_slab_size(h->gd, true); h->slab_c = generic_slab_size(h->gd, false); }
     else { h->slab_a = slab_size_actor(cfg->env_kind, hd[0]); h->slab_c = slab_size_critic(cfg->env_kind, hd[0]); }
@@ -620,7 +623,7 @@ DRIL_EXPORT int32_t dril_destroy(dril_handle* h) {
     if (h->ext_stage_rew) (void)hipHostFree(h->ext_stage_rew); if (h->ext_stage_flags) (void)hipHostFree(h->ext_stage_flags);
     void* ptrs[] = {h->params, h->adam_m, h->adam_v, h->bt, h->flat, h->norm_out, h->norm_partials, h->retry_snap, h->slabs_a, h->slabs_c, h->state,
                     h->step_count, h->episode, h->gstep, h->disc_returns, h->obs, h->act, h->rew, h->adv, h->ret, h->logp, h->val, h->boot,
-                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->epoch_index, h->epoch_keys, h->small_xchg, h->w2max_dev, h->w2pf_actor, h->w2pf_critic, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
+                    h->flags, h->last_values, h->noise_dev, h->perm_dev, h->epoch_index, h->epoch_keys, h->small_xchg, h->w2max_dev, h->gae_carry, h->gae_err, h->w2pf_actor, h->w2pf_critic, h->adv_partials, h->adv_stats, h->ev_partials, h->step_stats,
                     h->stop_flag, h->nan_flag, h->e_obs, h->e_rew, h->e_tobs, h->e_term, h->e_trunc, h->e_act, h->e_obs_raw, h->e_rew_n, h->obs_rms, h->ret_rms, h->rms_partials, h->rms_red, h->gen_tmp, h->dbg, h->rec, h->epoch_tables, h->epoch_stats, h->w2a_actor, h->w2ta_actor, h->w2a_critic, h->w2ta_critic, h->w2p_actor, h->w2tp_actor, h->w2p_critic, h->w2tp_critic, h->mon_cur_ret, h->ep_ret, h->mon_ring_ret, h->e_ep_ret, h->mon_cur_len, h->ep_len,
                     h->mon_ring_len, h->e_ep_len, h->mon_cnt, h->mon_meta, h->e_flags};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -818,9 +821,10 @@ DRIL_EXPORT int32_t dril_predict_values(dril_handle* h, const float* obs, int64_
 // ---- rollout ---------------------------------------------------------------------------------------
 namespace {
 int compute_gae(dril_handle* h) {
+    if (++h->gae_tag == 0) h->gae_tag = 1;                                            // 0 = "never written" (the carry words are zero at allocation)
     prof_begin(h, DRIL_K_GAE);
     HIPCHK(h, launch_gae(h->cfg.n_envs, h->cfg.n_steps, h->cfg.gamma, h->cfg.gae_lambda, h->rew, h->val, h->flags, h->boot, h->last_values,
-                         h->adv, h->ret, h->stream));
+                         h->adv, h->ret, h->gae_carry, h->gae_tag, h->gae_err, h->stream));
     prof_end(h);
     return DRIL_OK;
 }
@@ -996,22 +1000,32 @@ DRIL_EXPORT int32_t dril_buffer_copy_in(dril_handle* h, int32_t which, const voi
     if (!p || !host || b != bytes) return fail(h, DRIL_ERR_INVALID_ARG, "dril_buffer_copy_in: bad id or byte count");
     HIPCHK(h, hipMemcpyAsync(p, host, b, hipMemcpyHostToDevice, h->stream)); return sync(h);
 }
-DRIL_EXPORT int32_t dril_compute_gae(dril_handle* h) { NEED(h); int rc = compute_gae(h); return rc ? rc : sync(h); }
+DRIL_EXPORT int32_t dril_compute_gae(dril_handle* h) {
+    NEED(h); int rc = compute_gae(h); if (rc) return rc;
+    int gave_up = 0; HIPCHK(h, hipMemcpyAsync(&gave_up, h->gae_err, 4, hipMemcpyDeviceToHost, h->stream));
+    rc = sync(h); if (rc) return rc;
+    if (gave_up) { (void)hipMemsetAsync(h->gae_err, 0, 4, h->stream); return fail(h, DRIL_ERR_HIP, "gae_scan_kernel: a chunk's predecessor did not publish its carry within the spin limit"); }
+    return DRIL_OK;
+}
 
 DRIL_EXPORT int32_t dril_gae(int32_t E, int32_t T, float gamma, float lam, const float* rewards, const float* values, const uint8_t* flags,
                              const float* bootstrap, const float* last_values, float* advantages, float* returns) {
     if (E < 1 || T < 1 || !rewards || !values || !flags || !bootstrap || !last_values || !advantages || !returns)
         return fail(nullptr, DRIL_ERR_INVALID_ARG, "dril_gae: bad argument");
     const size_t N = (size_t)E * T;
-    float *d_r = nullptr, *d_v = nullptr, *d_b = nullptr, *d_l = nullptr, *d_a = nullptr, *d_ret = nullptr; uint8_t* d_f = nullptr;
-    auto cleanup = [&]() { hipFree(d_r); hipFree(d_v); hipFree(d_b); hipFree(d_l); hipFree(d_a); hipFree(d_ret); hipFree(d_f); };
+    float *d_r = nullptr, *d_v = nullptr, *d_b = nullptr, *d_l = nullptr, *d_a = nullptr, *d_ret = nullptr; uint8_t* d_f = nullptr; unsigned long long* d_c = nullptr; int* d_e = nullptr;
+    auto cleanup = [&]() { hipFree(d_r); hipFree(d_v); hipFree(d_b); hipFree(d_l); hipFree(d_a); hipFree(d_ret); hipFree(d_f); hipFree(d_c); hipFree(d_e); };
 #define GCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(nullptr, DRIL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
     GCHK(dmalloc(&d_r, N)); GCHK(dmalloc(&d_v, N)); GCHK(dmalloc(&d_b, N)); GCHK(dmalloc(&d_l, (size_t)E)); GCHK(dmalloc(&d_a, N)); GCHK(dmalloc(&d_ret, N)); GCHK(dmalloc(&d_f, N));
     GCHK(hipMemcpy(d_r, rewards, N * 4, hipMemcpyHostToDevice)); GCHK(hipMemcpy(d_v, values, N * 4, hipMemcpyHostToDevice));
     GCHK(hipMemcpy(d_b, bootstrap, N * 4, hipMemcpyHostToDevice)); GCHK(hipMemcpy(d_l, last_values, (size_t)E * 4, hipMemcpyHostToDevice));
     GCHK(hipMemcpy(d_f, flags, N, hipMemcpyHostToDevice));
-    GCHK(launch_gae(E, T, gamma, lam, d_r, d_v, d_f, d_b, d_l, d_a, d_ret, nullptr));
+    const size_t words = (size_t)gae_chunks(T) * E; int gave_up = 0;
+    GCHK(dmalloc(&d_c, words)); GCHK(hipMemset(d_c, 0, words * 8)); GCHK(dmalloc(&d_e, 1)); GCHK(hipMemset(d_e, 0, 4));
+    GCHK(launch_gae(E, T, gamma, lam, d_r, d_v, d_f, d_b, d_l, d_a, d_ret, d_c, 1u, d_e, nullptr));
     GCHK(hipDeviceSynchronize());
+    GCHK(hipMemcpy(&gave_up, d_e, 4, hipMemcpyDeviceToHost));
+    if (gave_up) { cleanup(); return fail(nullptr, DRIL_ERR_HIP, "gae_scan_kernel: a chunk's predecessor did not publish its carry within the spin limit"); }
     GCHK(hipMemcpy(advantages, d_a, N * 4, hipMemcpyDeviceToHost)); GCHK(hipMemcpy(returns, d_ret, N * 4, hipMemcpyDeviceToHost));
 #undef GCHK
     cleanup();
@@ -1144,7 +1158,9 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
     if (total_steps > 0) HIPCHK(h, hipMemcpyAsync(st.data(), h->step_stats, st.size() * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(ev.data(), h->ev_partials, ev.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(&nan, h->nan_flag, 4, hipMemcpyDeviceToHost, h->stream));
+    int gae_gave_up = 0; HIPCHK(h, hipMemcpyAsync(&gae_gave_up, h->gae_err, 4, hipMemcpyDeviceToHost, h->stream));
     int rc = sync(h); if (rc) return rc;
+    if (gae_gave_up) { (void)hipMemsetAsync(h->gae_err, 0, 4, h->stream); return fail(h, DRIL_ERR_HIP, "gae_scan_kernel: a chunk's predecessor did not publish its carry within the spin limit (advantages of this rollout are NaN)"); }
     if (!h->generic) { float m; std::memcpy(&m, &w2bits, 4); h->w2max = (m == m) ? m : INFINITY; }
 #ifdef DRIL_STAMPS
     {   // shares of the LAST grad launch, averaged over waves, per head

@@ -141,8 +141,11 @@ hipError_t launch_norm_obs_apply(const NormObsArgs& a, hipStream_t s);
 hipError_t launch_rew_partials(int E, const float* rew_raw, float* disc_returns, float gamma, int update, double* partials, int nblocks, hipStream_t s);
 hipError_t launch_norm_rew_apply(const NormRewArgs& a, hipStream_t s);
 hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_t s);
+// carry: gae_chunks(T) x E 64-bit words {tag | f32}, zero at allocation; tag: a non-zero number no earlier launch on this carry buffer used; err: device int, set to 1 if a
+// workgroup gave up waiting for its predecessor (the advantages it wrote are NaN)
+int gae_chunks(int T);
 hipError_t launch_gae(int E, int T, float gamma, float lam, const float* rew, const float* val, const uint8_t* flags,
-                      const float* boot, const float* last_values, float* adv, float* ret, hipStream_t s);
+                      const float* boot, const float* last_values, float* adv, float* ret, unsigned long long* carry, unsigned tag, int* err, hipStream_t s);
 hipError_t launch_adv_moments(const MomentsArgs& a, int nblocks, hipStream_t s);
 hipError_t launch_epoch_moments(const float* adv, int64_t N, int64_t B, int nb, uint64_t key, int bits, double* block_tables, int nblocks,
                                 double* table3, const int* stop_flag, hipStream_t s);

@@ -923,36 +923,80 @@ __global__ __launch_bounds__(128, 2) void rollout_duo_kernel(RolloutArgs a) {
 }
 
 // =============================================================================================
-// gae_kernel: one thread per env, backward scan over the time-major buffer (coalesced 256 B rows)
+// gae_scan_kernel — compute_advantages! (trajectory.jl:80-102) + returns = advantages + values (rollout_buffer.jl:87) over the time-major buffer.
+//
+// The recurrence A_t = delta_t + gamma lambda A_{t+1} (cut where a trajectory ends) is serial in t, and one thread per env walking all T rows (the round 1 - 3 kernel:
+// 1 024 waves on 256 CUs, a dependent chain of 2 048 small loads each) left HBM at 25 % of its peak.  Here the time axis is cut into chunks of kGaeRows rows:
+// a workgroup owns ONE chunk of 256 envs, issues all of its loads at once (kGaeRows x {r, V, flags}: 18 KB in flight per wave), forms every delta_t — which needs
+// nothing but memory: V_{t+1} is a buffer row — and only then needs ONE number per env from the chunk that follows it in time: A at that chunk's first row.
+// That carry travels through L2 as one 8-byte word per (chunk, env), {launch tag | f32 value}, written and polled with agent-scope atomics — value and validity in
+// one word: no flag, no fence (the message scheme of ppo_update_small_kernel).  With the carry in hand the chunk runs the SAME fma chain the serial kernel ran, so
+// every advantage is bit-identical to the serial scan — the chunking changes the schedule, not the arithmetic.
+// Order / progress: later chunks get lower block indices, so a workgroup only ever waits for one that was dispatched before it; the chain of a 256-env column is
+// C = T / kGaeRows hops long, but columns are independent and a hop (poll, 32 fmas, 64 stores) is short against a chunk's load time, so the machine streams.  The wait
+// is bounded (kGaeSpinLimit polls); on expiry the workgroup writes NaN advantages, raises *err and leaves — a status code for the host, never a hang.
 // =============================================================================================
-__global__ void gae_kernel(int E, int T, float gamma, float lam, const float* __restrict__ rew,
-                           const float* __restrict__ val, const uint8_t* __restrict__ flags,
-                           const float* __restrict__ boot, const float* __restrict__ last_values,
-                           float* __restrict__ adv, float* __restrict__ ret) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    float next_adv = 0.f, next_val = 0.f;
-    const float lv = last_values[e];
-#pragma unroll 8
-    for (int t = T - 1; t >= 0; --t) {
+constexpr int kGaeRows = 32;
+constexpr unsigned kGaeSpinLimit = 1u << 22;
+__global__ __launch_bounds__(256) void gae_scan_kernel(int E, int T, int C, int GB, float gamma, float lam, const float* __restrict__ rew,
+                                                       const float* __restrict__ val, const uint8_t* __restrict__ flags,
+                                                       const float* __restrict__ boot, const float* __restrict__ last_values,
+                                                       float* __restrict__ adv, float* __restrict__ ret, unsigned long long* __restrict__ carry, unsigned tag, int* __restrict__ err) {
+    const int n = blockIdx.x;
+    const int j = C - 1 - n / GB;                               // chunk (time-later chunks first)
+    const int e_raw = (n % GB) * 256 + (int)threadIdx.x;
+    const bool live = e_raw < E;
+    const int e = live ? e_raw : E - 1;                         // dead lanes read in bounds and store nothing
+    const int t0 = j * kGaeRows;
+    const int rows = (T - t0) < kGaeRows ? (T - t0) : kGaeRows;
+    float r[kGaeRows], v[kGaeRows]; unsigned f[kGaeRows];
+#pragma unroll
+    for (int i = 0; i < kGaeRows; ++i) {                        // every load of the chunk in flight before the first use
+        const int t = t0 + i < T ? t0 + i : T - 1;
         const size_t k = (size_t)t * E + e;
-        const float r = rew[k], v = val[k];
-        const uint8_t f = flags[k];
-        const bool term = f & 1, trunc = f & 2;
-        float a;
-        if (term || trunc || t == T - 1) {                    // last step of a trajectory, trajectory.jl:85-95
-            float delta;
-            if (term) delta = r - v;
-            else if (trunc) delta = r + gamma * boot[k] - v;
-            else delta = r + gamma * lv - v;
-            a = delta;
-        } else {                                              // trajectory.jl:96-99
-            const float delta = r + gamma * next_val - v;
-            a = delta + gamma * lam * next_adv;
-        }
-        adv[k] = a; ret[k] = a + v;                           // rollout_buffer.jl:87
-        next_adv = a; next_val = v;
+        r[i] = rew[k]; v[i] = val[k]; f[i] = flags[k];
     }
+    const bool last_chunk = t0 + rows == T;
+    const float v_after = last_chunk ? 0.f : val[(size_t)(t0 + rows) * E + e];        // V of the row that follows the chunk
+    const float lv = last_values[e];
+    const float gl = gamma * lam;
+    unsigned done_mask = 0;
+#pragma unroll
+    for (int i = 0; i < kGaeRows; ++i) {                        // delta_t and the cut flag of every row (independent of each other; trajectory.jl:85-99)
+        const int t = t0 + i;
+        const bool term = f[i] & 1u, trunc = f[i] & 2u;
+        const float vn = (i + 1 < kGaeRows) ? ((i + 1 < rows) ? v[i + 1] : v_after) : v_after;
+        float delta;
+        if (term) delta = r[i] - v[i];
+        else if (trunc) delta = r[i] + gamma * boot[(size_t)(t < T ? t : T - 1) * E + e] - v[i];
+        else if (t == T - 1) delta = r[i] + gamma * lv - v[i];
+        else delta = r[i] + gamma * vn - v[i];
+        r[i] = delta;
+        if (term || trunc || t >= T - 1) done_mask |= 1u << i;
+    }
+    float a = 0.f;
+    bool ok = true;
+    if (!last_chunk) {                                           // A at the first row of chunk j + 1, published by its workgroup
+        const unsigned long long* src = carry + (size_t)(j + 1) * E + e;
+        unsigned long long w = 0; unsigned spins = 0;
+        for (;;) {
+            w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((unsigned)(w >> 32) == tag)) break;       // wave-uniform
+            if (++spins > kGaeSpinLimit) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        a = ok ? __uint_as_float((unsigned)w) : __builtin_nanf("");
+        if (!ok && (threadIdx.x & 63) == 0) atomicExch(err, 1);
+    }
+#pragma unroll
+    for (int i = kGaeRows - 1; i >= 0; --i) {
+        if (i < rows) {
+            a = ((done_mask >> i) & 1u) ? r[i] : r[i] + gl * a;  // the serial kernel's expression (contracted to one fma by the compiler, as there)
+            if (!ok) a = __builtin_nanf("");
+            if (live) { const size_t k = (size_t)(t0 + i) * E + e; adv[k] = a; ret[k] = a + v[i]; }   // rollout_buffer.jl:87
+        }
+    }
+    if (j > 0 && live) __hip_atomic_store(carry + (size_t)j * E + e, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // =============================================================================================
@@ -1465,9 +1509,11 @@ hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_
     return hipGetLastError();
 }
 
+int gae_chunks(int T) { return (T + kGaeRows - 1) / kGaeRows; }
 hipError_t launch_gae(int E, int T, float gamma, float lam, const float* rew, const float* val, const uint8_t* flags,
-                      const float* boot, const float* last_values, float* adv, float* ret, hipStream_t s) {
-    gae_kernel<<<(E + 63) / 64, 64, 0, s>>>(E, T, gamma, lam, rew, val, flags, boot, last_values, adv, ret);
+                      const float* boot, const float* last_values, float* adv, float* ret, unsigned long long* carry, unsigned tag, int* err, hipStream_t s) {
+    const int C = gae_chunks(T), GB = (E + 255) / 256;
+    gae_scan_kernel<<<(unsigned)((size_t)C * GB), 256, 0, s>>>(E, T, C, GB, gamma, lam, rew, val, flags, boot, last_values, adv, ret, carry, tag, err);
     return hipGetLastError();
 }
 

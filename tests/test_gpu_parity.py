@@ -62,18 +62,42 @@ def test_gae_golden_on_device(pkg, lib, case):
 
 
 def test_gae_random_vs_oracle(pkg, lib, oracle_mod):
+    """gae_scan_kernel cuts the time axis into chunks of 32 rows, one workgroup per (chunk, 256 envs), the carry between chunks travelling through L2: shapes that are
+    ragged in both directions (a last chunk of 1 ... 31 rows, a last workgroup with a few live lanes), one chunk only, hundreds of chunks with few envs (the reference's
+    own scale: a chain of T / 32 dependent hops), and — gamma = lambda = 1 with no trajectory end anywhere — carries that run through EVERY chunk undamped.
+    The chain inside a chunk is the serial kernel's, so the agreement with the serial oracle is at rounding level"""
     import ctypes as C
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     rng = np.random.default_rng(0)
-    for E, T in ((1, 1), (3, 7), (257, 33), (1000, 129)):   # ragged: not multiples of the wave / unroll factor
+    for E, T, gamma, lam, cuts in ((1, 1, 0.99, 0.95, True), (3, 7, 0.99, 0.95, True), (257, 33, 0.99, 0.95, True), (1000, 129, 0.99, 0.95, True), (4, 2048, 0.99, 0.95, True),
+                                   (513, 32, 0.99, 0.95, True), (70, 64, 0.99, 0.95, True), (300, 1000, 1.0, 1.0, False), (5, 4096, 1.0, 1.0, False), (4096, 97, 0.9, 0.8, True)):
         r = rng.standard_normal(E * T).astype(np.float32); v = rng.standard_normal(E * T).astype(np.float32)
-        fl = rng.choice([0, 0, 0, 0, 1, 2, 3], E * T).astype(np.uint8)
+        fl = (rng.choice([0, 0, 0, 0, 1, 2, 3], E * T) if cuts else np.zeros(E * T)).astype(np.uint8)
+        if not cuts:
+            r *= np.float32(0.01)                                   # undamped sums over thousands of steps stay O(1)
         b = rng.standard_normal(E * T).astype(np.float32); lv = rng.standard_normal(E).astype(np.float32)
-        out = [np.zeros(E * T, np.float32) for _ in range(4)]
-        assert lib.dril_gae(E, T, 0.99, 0.95, p(r), p(v), p(fl), p(b), p(lv), p(out[0]), p(out[1])) == 0
-        assert oracle_mod.lib().orc_gae(E, T, 0.99, 0.95, p(r), p(v), p(fl), p(b), p(lv), p(out[2]), p(out[3])) == 0
-        np.testing.assert_allclose(out[0], out[2], atol=1e-4, rtol=1e-5)
-        np.testing.assert_allclose(out[1], out[3], atol=1e-4, rtol=1e-5)
+        out = [np.full(E * T, np.nan, np.float32) for _ in range(4)]
+        assert lib.dril_gae(E, T, gamma, lam, p(r), p(v), p(fl), p(b), p(lv), p(out[0]), p(out[1])) == 0
+        assert oracle_mod.lib().orc_gae(E, T, gamma, lam, p(r), p(v), p(fl), p(b), p(lv), p(out[2]), p(out[3])) == 0
+        np.testing.assert_allclose(out[0], out[2], atol=2e-6 * max(1.0, float(np.abs(out[2]).max())), rtol=1e-5, err_msg=f"advantages E {E} T {T}")
+        np.testing.assert_allclose(out[1], out[3], atol=2e-6 * max(1.0, float(np.abs(out[3]).max())), rtol=1e-5, err_msg=f"returns E {E} T {T}")
+
+
+def test_gae_twice_on_one_handle_uses_fresh_carries(pkg, oracle_mod):
+    """the carry words of gae_scan_kernel are validated by a per-launch tag: a second rollout on the same handle (other rewards) must not read the first one's carries"""
+    capi = pkg._capi
+    cfg = _cfg(pkg, 0, n_envs=300, n_steps=200, episode_len=500, batch_size=300, fixed_length_episodes=1)
+    h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
+    flat = _params(h.P, 1, 0.3); h.set_params(flat); o.set_params(flat)
+    h.env_reset(2); o.env_reset(2); h.collect_rollout(); o.collect_rollout()
+    for k in range(3):
+        rw = np.random.default_rng(k).standard_normal(300 * 200).astype(np.float32)
+        h.set_buffer(capi.BUF_REWARDS, rw); o.set_buffer(capi.BUF_REWARDS, rw)
+        h.set_buffer(capi.BUF_VALUES, o.buffer(capi.BUF_VALUES))
+        h.compute_gae(); o.compute_gae()
+        np.testing.assert_allclose(h.buffer(capi.BUF_ADVANTAGES), o.buffer(capi.BUF_ADVANTAGES), atol=1e-4, rtol=1e-5)   # (the two rollouts' last values agree to 1e-5)
+        np.testing.assert_allclose(h.buffer(capi.BUF_RETURNS), o.buffer(capi.BUF_RETURNS), atol=1e-4, rtol=1e-5)
+    h.close()
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 6, 7])           # 2 = ScalingWrapperEnv(Pendulum); 3 / 4 = MountainCar-v0 / MountainCarContinuous-v0; 6 = Acrobot-v1; 7 = ScalingWrapperEnv(MountainCarContinuous)
