@@ -14,6 +14,8 @@ struct GemmArgs {
     long long zA, zB, zC, zBias, zAux;            // batch (blockIdx.z) strides
     int zdivB;                                    // B uses batch index z / zdivB (several nets reading one input)
     int vecA, vecB;                               // operand has unit stride along k, 16-byte aligned rows and K % 4 == 0: float4 loads
+    int use_lds;                                  // the LDS-staged (coalesced-load) split-K body for this contraction (set by gemm_prepare: K >= 64)
+    int ldsA, ldsB;                               // access pattern of the LDS-staged split-K shape (set by gemm_prepare): 0 k-contiguous float4, 1 row-contiguous float4, 2 element by element
     int vecBn;                                    // B has unit stride along n with 16-byte aligned rows: float4 runs along n (LDS-tiled kernel only)
     int ones_n;                                   // B(:, N-1) == 1 (appends the bias column to a weight-gradient contraction)
     int epi; float alpha;

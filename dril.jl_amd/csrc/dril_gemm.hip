@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
+#include <mutex>
+#include <vector>
 
 #include "dril_device.h"
 #include "dril_gemm.h"
@@ -113,7 +115,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)
 #pragma unroll
         for (int u = 0; u < kGemmDepth; ++u) {
             const int k0 = 8 * (q + u) + 4 * h;
-            if (q + u < q1) {
+            if (g.dbg & 16) { for (int t = 0; t < 4; ++t) { a[u][t] = 1.f; b[u][t] = 1.f; } }       // ablation (tools/micro/sac_gemm_shapes.hip): no operand loads
+            else if (q + u < q1) {
                 load_operand4(A, m, g.M, g.sAm, g.sAk, k0, g.K, g.vecA, a[u]);
                 if (ones) { for (int t = 0; t < 4; ++t) b[u][t] = k0 + t < g.K ? 1.f : 0.f; }
                 else load_operand4(B, n, g.N, g.sBn, g.sBk, k0, g.K, g.vecB, b[u]);
@@ -122,10 +125,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)
 #pragma unroll
         for (int u = 0; u < kGemmDepth; ++u)
             if (q + u < q1) {
+                if (g.dbg & 32) { acc[u] += a[u][0] + b[u][1]; continue; }                          // ablation: no MFMA
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc = mfma32(a[u][t], b[u][t], acc);
             }
     }
+    if (g.dbg & 64) { if (acc[0] == 123.456f) g.C[0] = 1.f; return; }                               // ablation: no reduction / epilogue
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
@@ -155,6 +160,130 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, int z, float (&red)
             C[ci[i]] = gemm_epilogue(g, v, b, y[i]);
         }
     } else store_tile(g, C, bias, aux, bx * 32, tile_n * 32, lane, [&](int rr, int ll) { return red[wave][rr][ll]; });
+}
+// ---- the split-K shape with COALESCED operand loads (round 4) -----------------------------------------------------------------------------------------
+// gemm_body<true> lets every lane fetch its own MFMA operand straight from memory: 16 bytes out of 64 different cache lines per wave instruction (a k-contiguous
+// operand: 32 rows 2 KB apart) or 4-byte words k-strided.  Ablated (tools/micro/sac_gemm_shapes.hip, DRIL_GEMM_DBG bits), those loads are HALF of a launch — the four-net
+// 512 x 256 x 512 forward of update!: 17.4 us = 4.1 launch floor + 8.6 operand loads + 4.6 MFMA + 1.7 epilogue, purely additive because all waves of a workgroup
+// (and, the launch being one round, of the chip) sit in the same phase.  Here the workgroup's 512 threads read the tile's operand rows the way memory stores them —
+// consecutive lanes, consecutive 16 bytes: every wave instruction covers whole 128-byte lines — kLdsKc contraction steps at a time into LDS ([row][k], stride
+// kLdsKc + 4 floats: the ds_read_b128 operand fetch of lane (row c, k-half h) is conflict-free), the NEXT pass's lines already in flight (registers) under this
+// pass's MFMAs.  Same v_mfma_f32_32x32x2_f32 products; wave w contracts k in [32 w, 32 w + 32) of every pass, partial tiles summed through LDS in fixed wave
+// order (deterministic).  The epilogue's buffer overlays the operand images.
+constexpr int kLdsMinK = 64;                                                                  // shorter contractions (a first layer over 4 inputs) keep the direct-load body
+constexpr int kLdsKc = 256, kLdsStride = kLdsKc + 4, kLdsTile = 32 * kLdsStride;              // floats
+constexpr size_t kLdsBytes = sizeof(float) * 2 * kLdsTile;                                    // 66 560 B: two workgroups per CU
+static_assert(2 * kLdsTile >= kGemmWaves * 16 * kRedStride, "the epilogue buffer overlays the operand images");
+// one operand tile (32 rows x kLdsKc steps) of pass kc: global -> registers (issue) and registers -> LDS (commit).  Three access patterns, picked per operand
+// (uniform over the launch): k-contiguous rows (a weight read transposed, an activation row per sample), row-contiguous (a column-major weight, the activation operand
+// of a weight gradient: 32 consecutive rows of one k are one 128-byte line), anything else element by element.
+struct LdsOperand { const float* P; int row0, lim, s_row, s_k, ones_row; };                    // ones_row: this row (global index) is the synthetic ones column, -1 none
+// MODE 0 k-contiguous float4, 1 row-contiguous float4 (compile-time: one access pattern's addresses live at a time; an operand that fits neither keeps the direct-load body)
+template <int MODE>
+__device__ __forceinline__ void lds_issue(const LdsOperand& o, int kc, int K, int tid, float4 (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + 512 * j;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 0) {
+            const int r = f >> 6, k = kc + ((f & 63) << 2), row = o.row0 + r;
+            if (row < o.lim && k < K) t = row == o.ones_row ? make_float4(1.f, 1.f, 1.f, 1.f) : *reinterpret_cast<const float4*>(o.P + (size_t)row * o.s_row + k);     // K % 4 == 0 (mode 0)
+        } else {
+            const int k = kc + (f >> 3), row = o.row0 + ((f & 7) << 2);
+            if (k < K) {
+                const float* src = o.P + (size_t)k * o.s_k + row;
+                if (row + 3 < o.lim && (o.ones_row < row || o.ones_row > row + 3)) t = *reinterpret_cast<const float4*>(src);
+                else {
+                    float e[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) e[q] = row + q == o.ones_row ? 1.f : (row + q < o.lim ? src[q] : 0.f);
+                    t = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+        }
+        v[j] = t;
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void lds_commit(int tid, const float4 (&v)[4], float* __restrict__ img) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = tid + 512 * j;
+        if (MODE == 0) *reinterpret_cast<float4*>(img + (f >> 6) * kLdsStride + ((f & 63) << 2)) = v[j];
+        else {
+            const int k = f >> 3, r = (f & 7) << 2;
+            img[(r + 0) * kLdsStride + k] = v[j].x; img[(r + 1) * kLdsStride + k] = v[j].y; img[(r + 2) * kLdsStride + k] = v[j].z; img[(r + 3) * kLdsStride + k] = v[j].w;
+        }
+    }
+}
+template <int AM, int BM>
+__device__ __forceinline__ void gemm_body_lds(const GemmArgs& g, int z, float* __restrict__ smem, int bx, int by) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
+    if (bx * 32 >= g.M || by * 32 >= g.N) return;                                               // pair / multi launches: the grid covers the larger problem (uniform per workgroup)
+    float* __restrict__ As = smem; float* __restrict__ Bs = smem + kLdsTile;
+    const int n_real = g.N - (g.ones_n ? 1 : 0);
+    const LdsOperand oa{g.A + (size_t)z * g.zA, bx * 32, g.M, g.sAm, g.sAk, -1};
+    const LdsOperand ob{g.B + (size_t)(z / g.zdivB) * g.zB, by * 32, g.N, g.sBn, g.sBk, g.ones_n ? n_real : -1};
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 va[4], vb[4];
+    if (!(g.dbg & 16)) { lds_issue<AM>(oa, 0, g.K, tid, va); lds_issue<BM>(ob, 0, g.K, tid, vb); }
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) va[j] = vb[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    for (int kc = 0; kc < g.K; kc += kLdsKc) {
+        lds_commit<AM>(tid, va, As); lds_commit<BM>(tid, vb, Bs);
+        __syncthreads();
+        if (kc + kLdsKc < g.K && !(g.dbg & 16)) { lds_issue<AM>(oa, kc + kLdsKc, g.K, tid, va); lds_issue<BM>(ob, kc + kLdsKc, g.K, tid, vb); }   // next pass in flight under this pass's MFMAs
+        if (kc + 32 * wave < g.K) {                                                              // (a ragged last pass leaves the upper waves without work)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(As + c * kLdsStride + 32 * wave + 8 * q + 4 * h);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(Bs + c * kLdsStride + 32 * wave + 8 * q + 4 * h);
+                if (g.dbg & 32) { acc[q] += a[0] + b[1]; continue; }
+                acc = mfma32(a[0], b[0], acc); acc = mfma32(a[1], b[1], acc); acc = mfma32(a[2], b[2], acc); acc = mfma32(a[3], b[3], acc);
+            }
+        }
+        __syncthreads();
+    }
+    if (g.dbg & 64) { if (acc[0] == 123.456f) g.C[0] = 1.f; return; }
+    float (*red)[16][kRedStride] = reinterpret_cast<float (*)[16][kRedStride]>(smem);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    float* __restrict__ C = g.C + (size_t)z * g.zC;
+    const float* __restrict__ bias = g.bias ? g.bias + (size_t)z * g.zBias : nullptr;
+    const float* __restrict__ aux = g.aux ? g.aux + (size_t)z * g.zAux : nullptr;
+    const bool need_aux = aux && epi_reads_aux(g.epi);
+    const int ml = threadIdx.x & 31, mm = bx * 32 + ml, rr = (ml & 3) + 4 * (ml >> 3), lb = 32 * ((ml >> 2) & 1);
+    const float bv = (bias && mm < g.M) ? bias[mm] : 0.f;
+    float y[2]; bool ok[2]; size_t ci[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                                              // both operand loads before the first store (see store_tile)
+        const int nn = by * 32 + (int)(threadIdx.x >> 5) + 16 * i;
+        ok[i] = mm < g.M && nn < g.N; ci[i] = (size_t)mm * g.sCm + (size_t)nn * g.sCn;
+        y[i] = (need_aux && ok[i]) ? aux[ci[i]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (!ok[i]) continue;
+        const int ll = (int)(threadIdx.x >> 5) + 16 * i + lb;
+        float v = red[0][rr][ll];
+#pragma unroll
+        for (int w = 1; w < kGemmWaves; ++w) v += red[w][rr][ll];                              // fixed order
+        if (g.zout) (g.zout + (C - g.C))[ci[i]] = v * g.alpha + bv;
+        C[ci[i]] = gemm_epilogue(g, v, bv, y[i]);
+    }
+}
+__device__ __forceinline__ void gemm_body_lds_any(const GemmArgs& g, int z, float* smem, int bx, int by) {
+    if (g.ldsA == 0) { if (g.ldsB == 0) gemm_body_lds<0, 0>(g, z, smem, bx, by); else gemm_body_lds<0, 1>(g, z, smem, bx, by); }
+    else { if (g.ldsB == 0) gemm_body_lds<1, 0>(g, z, smem, bx, by); else gemm_body_lds<1, 1>(g, z, smem, bx, by); }
+}
+__global__ __launch_bounds__(64 * kGemmWaves, 4) void sac_gemm_lds_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds_smem[];
+    gemm_body_lds_any(g, blockIdx.z, lds_smem, blockIdx.x, blockIdx.y);
 }
 template <bool SPLIT>
 __global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_kernel(GemmArgs g) {
@@ -400,23 +529,25 @@ __global__ __launch_bounds__(64 * kGemmWaves, 4) void sac_gemm_split_kernel(Gemm
 }
 // two independent contractions in one launch (the weight-gradient and the data-gradient of one layer): blockIdx.z < za runs `a`
 struct GemmPair { GemmArgs a, b; int za; };
-__global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_pair_kernel(GemmPair p) {
-    __shared__ float red[kGemmWaves][16][kRedStride];
-    if ((int)blockIdx.z < p.za) gemm_body<true>(p.a, blockIdx.z, red); else gemm_body<true>(p.b, (int)blockIdx.z - p.za, red);
+// (both bodies: a contraction with K >= kLdsMinK runs the LDS-staged one, a short one the direct-load one; the dynamic LDS block serves either)
+using RedBuf = float[kGemmWaves][16][kRedStride];
+__device__ __forceinline__ void gemm_body_any(const GemmArgs& g, int z, float* smem, int bx, int by) {
+    if (g.use_lds) gemm_body_lds_any(g, z, smem, bx, by); else gemm_body<true>(g, z, *reinterpret_cast<RedBuf*>(smem), bx, by);
+}
+__global__ __launch_bounds__(64 * kGemmWaves, 4) void sac_gemm_pair_kernel(GemmPair p) {
+    extern __shared__ __attribute__((aligned(16))) float lds_smem[];
+    if ((int)blockIdx.z < p.za) gemm_body_any(p.a, blockIdx.z, lds_smem, blockIdx.x, blockIdx.y); else gemm_body_any(p.b, (int)blockIdx.z - p.za, lds_smem, blockIdx.x, blockIdx.y);
 }
 
 // up to four independent contractions in one launch (a net's [dW3|db3], [dW2|db2] and dz1 of the reverse pass): blockIdx.z picks the contraction
 struct GemmMulti { GemmArgs g[4]; int end[4], tm[4], tn[4]; int n; };   // flat grid: blocks [end[i-1], end[i]) run contraction i, tile (bx, by) of batch z
-__global__ __launch_bounds__(64 * kGemmWaves) void sac_gemm_multi_kernel(GemmMulti p) {
-    __shared__ float red[kGemmWaves][16][kRedStride];
+__global__ __launch_bounds__(64 * kGemmWaves, 4) void sac_gemm_multi_kernel(GemmMulti p) {
+    extern __shared__ __attribute__((aligned(16))) float lds_smem[];
     const int b = blockIdx.x;
     const int i = b < p.end[0] ? 0 : b < p.end[1] ? 1 : b < p.end[2] ? 2 : 3;
     const int local = b - (i ? p.end[i - 1] : 0), per = p.tm[i] * p.tn[i];
     const int z = local / per, r = local - z * per, by = r / p.tm[i], bx = r - by * p.tm[i];
-    if (i == 0) gemm_body<true>(p.g[0], z, red, bx, by);
-    else if (i == 1) gemm_body<true>(p.g[1], z, red, bx, by);
-    else if (i == 2) gemm_body<true>(p.g[2], z, red, bx, by);
-    else gemm_body<true>(p.g[3], z, red, bx, by);
+    gemm_body_any(p.g[i], z, lds_smem, bx, by);                                                 // (the argument block is read from the kernel-argument segment at a uniform runtime offset: scalar loads)
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
@@ -425,11 +556,26 @@ bool gemm_prepare(GemmArgs& g) {
     g.vecB = !g.ones_n && g.sBk == 1 && g.sBn % 4 == 0 && g.K % 4 == 0 && aligned16(g.B) && g.zB % 4 == 0;
     g.vecBn = g.sBn == 1 && g.sBk != 1 && g.sBk % 4 == 0 && aligned16(g.B) && g.zB % 4 == 0;        // n-contiguous operand: float4 runs along n (big kernel, BN)
     if (g.zdivB <= 0) g.zdivB = 1;
+    // the LDS-staged split-K shape: access pattern per operand (rows = m for A, n for B)
+    g.ldsA = g.vecA ? 0 : (g.sAm == 1 && g.sAk % 4 == 0 && aligned16(g.A) && g.zA % 4 == 0) ? 1 : 2;
+    g.ldsB = g.vecB ? 0 : (g.sBn == 1 && g.sBk % 4 == 0 && aligned16(g.B) && g.zB % 4 == 0) ? 1 : 2;
+    static const bool no_lds = std::getenv("DRIL_GEMM_NO_LDS") != nullptr;                                 // A/B knob: the direct-load split-K body for every contraction
+    g.use_lds = (g.K >= kLdsMinK && g.ldsA < 2 && g.ldsB < 2 && !no_lds) ? 1 : 0;
+    static const int dbg_bits = std::getenv("DRIL_GEMM_DBG") ? std::atoi(std::getenv("DRIL_GEMM_DBG")) : 0; g.dbg = dbg_bits;   // diagnostic ablations (results wrong on purpose)
     return g.M > 0 && g.N > 0 && g.K > 0;
 }
 
 }  // namespace
 
+// kernels that take the 66 KB dynamic LDS block: raise the limit once per kernel and device context
+static hipError_t lds_attr(const void* fn) {
+    static std::mutex mu; static std::vector<const void*> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if (std::find(done.begin(), done.end(), fn) != done.end()) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e == hipSuccess) done.push_back(fn);
+    return e;
+}
 GemmArgs gemm_args() { GemmArgs g; memset(&g, 0, sizeof(g)); g.alpha = 1.0f; return g; }
 
 hipError_t launch_gemm_pair(GemmArgs a, int Za, GemmArgs b, int Zb, hipStream_t s) {
@@ -437,7 +583,8 @@ hipError_t launch_gemm_pair(GemmArgs a, int Za, GemmArgs b, int Zb, hipStream_t 
     GemmPair p{a, b, Za};
     const int tm = std::max((a.M + 31) / 32, (b.M + 31) / 32), tn = std::max((a.N + 31) / 32, (b.N + 31) / 32);
     if (tn > 65535 || Za + Zb > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sac_gemm_pair_kernel, dim3(tm, tn, Za + Zb), dim3(64 * kGemmWaves), 0, s, p);
+    { hipError_t e = lds_attr((const void*)sac_gemm_pair_kernel); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(sac_gemm_pair_kernel, dim3(tm, tn, Za + Zb), dim3(64 * kGemmWaves), kLdsBytes, s, p);
     return hipGetLastError();
 }
 hipError_t launch_gemm_multi(const GemmArgs* gs, const int* Zs, int n, hipStream_t s) {
@@ -451,18 +598,19 @@ hipError_t launch_gemm_multi(const GemmArgs* gs, const int* Zs, int n, hipStream
         p.end[i] = (int)total;
     }
     if (total > 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sac_gemm_multi_kernel, dim3((unsigned)total), dim3(64 * kGemmWaves), 0, s, p);
+    { hipError_t e = lds_attr((const void*)sac_gemm_multi_kernel); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(sac_gemm_multi_kernel, dim3((unsigned)total), dim3(64 * kGemmWaves), kLdsBytes, s, p);
     return hipGetLastError();
 }
 hipError_t launch_gemm(GemmArgs g, int Z, hipStream_t s) {
     if (!gemm_prepare(g)) return hipErrorInvalidValue;
     const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
     if ((tn + kGemmWaves - 1) / kGemmWaves > 65535 || Z > 65535) return hipErrorInvalidValue;
-    const bool many = (long long)tm * tn * Z >= 2048 && g.K >= kBigKc;
+    static const long long many_tiles = std::getenv("DRIL_GEMM_MANY") ? std::atoll(std::getenv("DRIL_GEMM_MANY")) : 2048;   // A/B knob: tile count from which the LDS-tiled throughput shapes take over from split-K
+    const bool many = (long long)tm * tn * Z >= many_tiles && g.K >= kBigKc;
     const bool a_m = g.sAm == 1, a_k = !a_m && g.sAk == 1;                                             // A m-contiguous / k-contiguous
     const bool b_k = g.sBk == 1 && g.vecB && !g.ones_n, b_n = !b_k && g.sBn == 1 && g.sBk != 1;        // B k-contiguous (float4 rows) / n-contiguous
     const dim3 bgrid(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), bblock(64 * kGemmWaves);
-    static const int dbg_bits = std::getenv("DRIL_GEMM_DBG") ? std::atoi(std::getenv("DRIL_GEMM_DBG")) : 0; g.dbg = dbg_bits;
     static const bool f32_only = std::getenv("DRIL_GEMM_F32") != nullptr;                                // A/B knob: keep the large contractions on v_mfma_f32_32x32x2_f32
     static const bool split_all = std::getenv("DRIL_GEMM_SPLIT") != nullptr;                              // A/B knob: also for callers that did not ask (SAC)
     const bool split = many && !f32_only && (g.allow_split || split_all) && g.K >= 64;
@@ -490,7 +638,11 @@ hipError_t launch_gemm(GemmArgs g, int Z, hipStream_t s) {
     else if (many && a_k && b_k) hipLaunchKernelGGL((sac_gemm_big_kernel<true, false>), bgrid, bblock, 0, s, g);
     else if (many && a_m && b_n) hipLaunchKernelGGL((sac_gemm_big_kernel<false, true>), bgrid, bblock, 0, s, g);
     else if (many && a_k && b_n) hipLaunchKernelGGL((sac_gemm_big_kernel<true, true>), bgrid, bblock, 0, s, g);
-    else if ((long long)tm * tn * Z >= 2048) hipLaunchKernelGGL(sac_gemm_kernel<false>, dim3(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), dim3(64 * kGemmWaves), 0, s, g);
+    else if ((long long)tm * tn * Z >= many_tiles) hipLaunchKernelGGL(sac_gemm_kernel<false>, dim3(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), dim3(64 * kGemmWaves), 0, s, g);
+    else if (g.use_lds) {
+        hipError_t e = lds_attr((const void*)sac_gemm_lds_kernel); if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(sac_gemm_lds_kernel, dim3(tm, tn, Z), dim3(64 * kGemmWaves), kLdsBytes, s, g);
+    }
     else hipLaunchKernelGGL(sac_gemm_kernel<true>, dim3(tm, tn, Z), dim3(64 * kGemmWaves), 0, s, g);
     return hipGetLastError();
 }

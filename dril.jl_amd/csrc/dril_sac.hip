@@ -119,6 +119,29 @@ __device__ __forceinline__ void first_layer_row(const float* __restrict__ W1, co
         h1[u] = relu ? (acc > 0.f ? acc : 0.f) : tanhf(acc);
     }
 }
+// the first layer of the collection forward for a narrow input: h1[e][u] = act(W1[u, :] . x[e, :] + b1[u]), eight envs per block with the weights of a unit in
+// registers across them (a contraction with K = 3 in the generic kernel took 9.6 us for 4096 envs x 512 units; this is a store-bound elementwise pass)
+struct CollectL1Args { int E, D, H1, relu; const float* x; const float* W1; const float* b1; float* h1; };
+__global__ __launch_bounds__(256) void sac_collect_l1_kernel(CollectL1Args f) {
+    __shared__ float xs[8][4];
+    const int e0 = blockIdx.x * 8;
+    if (threadIdx.x < 32) { const int r = threadIdx.x >> 2, d = threadIdx.x & 3, e = e0 + r; xs[r][d] = (d < f.D && e < f.E) ? f.x[(size_t)e * f.D + d] : 0.f; }
+    __syncthreads();
+    for (int u = threadIdx.x; u < f.H1; u += 256) {
+        float wv[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) wv[d] = d < f.D ? f.W1[u + (size_t)d * f.H1] : 0.f;
+        const float b = f.b1[u];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (e0 + r >= f.E) break;
+            float acc = b;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) acc = fmaf(wv[d], xs[r][d], acc);          // (d >= D: zero weights) — the order of first_layer_row
+            f.h1[(size_t)(e0 + r) * f.H1 + u] = f.relu ? (acc > 0.f ? acc : 0.f) : tanhf(acc);
+        }
+    }
+}
 // get_data_loader + the first layer of the actor on (obs | next obs) and of the two critics on (obs, stored action): sac_gather_kernel + the first launch of two
 // net_forward calls.  One block per sample.
 struct GatherL1Args {
@@ -159,6 +182,14 @@ __global__ __launch_bounds__(256) void sac_gather_l1_kernel(GatherL1Args f) {
     for (int z = 0; z < 2; ++z) first_layer_row(f.P + f.qw1 + z * f.zP, f.P + f.qb1 + z * f.zP, xqs, W, f.H1, f.relu, f.qh1 + z * f.zh + (size_t)i * f.H1);
 }
 
+// In-stream time stamps of dril_sac_iterate: the fps of every iteration's collection (off_policy_collection.jl:126-128) and the update / collection split of the
+// profile need the time at the phase boundaries.  A HIP event per boundary costs the stream ~5 us each (three per iteration: 16 us of a 205 us iteration, seen as
+// gaps in the rocprofv3 trace); instead the LAST kernel of a phase stores the constant-rate wall clock (s_memrealtime) when its highest-numbered workgroup is done —
+// one store, no atomics, nothing waits.  Kernels of one stream run back to back, so a phase lasts from the previous phase's stamp to its own.
+__device__ __forceinline__ void phase_stamp(unsigned long long* stamp) {
+    if (stamp && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *stamp = wall_clock64();
+}
+__global__ void sac_stamp_kernel(unsigned long long* stamp) { phase_stamp(stamp); }
 // device scalars shared by the kernels of one gradient step
 struct SacScalars { float log_ent, ent_m, ent_v, alpha; };
 
@@ -532,6 +563,7 @@ struct StepEndArgs {
     // deferred sums of the fused head kernels (nhead = 0: the unfused sequence wrote stats / the log_std gradient itself): per-sample rows [nhead][2] of the critic and
     // actor loss heads, [n_ls][nhead] of the log_std gradient
     int nhead, B; const double *hp_critic, *hp_actor, *hp_ls; float* g_ls;
+    unsigned long long* stamp;   // phase_stamp (null: none)
 };
 // n_actor and n_q are multiples of 4 (the device layout pads every net to 16 bytes; pads hold zero parameters and zero gradients)
 __global__ __launch_bounds__(256) void sac_step_end_kernel(StepEndArgs a) {
@@ -570,6 +602,7 @@ __global__ __launch_bounds__(256) void sac_step_end_kernel(StepEndArgs a) {
     }
     ss = block_sum(ss, sh);
     if (threadIdx.x == 0) a.ssq_a[blockIdx.x] = ss;          // squared-gradient partial of this block: summed on the host with the critic's (sac.jl:393) — no grid-wide fold for a statistic
+    phase_stamp(a.stamp);
     if (blockIdx.x != 0) return;
     if (a.nhead) {                                                                              // statistics of the fused loss heads
         double c0 = 0, c1 = 0, p0 = 0;
@@ -582,12 +615,59 @@ __global__ __launch_bounds__(256) void sac_step_end_kernel(StepEndArgs a) {
 
 // ---- collection (off_policy_collection.jl:28-96) ---------------------------------------------------------------------------
 struct CollectHeadArgs {
-    int E, A, use_random; const float* mu; const float* log_std; const float* inj_noise; const uint32_t* gstep; uint64_t seed0;
+    int E, A, use_random; float* mu; const float* log_std; const float* inj_noise; const uint32_t* gstep; uint64_t seed0;
     float low, high; float* raw; float* envact;
+    const float* h2; const float* w3; const float* b3; int H2;     // h2 != null: the actor's output layer mu = W3 h2 + b3 is evaluated HERE (sac_mu_rows) instead of in a launch of its own
 };
-__global__ void sac_collect_head_kernel(CollectHeadArgs g) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= g.E) return;
+// mu[e][a] = W3[a, :] . h2[e, :] + b3[a] for the kEnvsPerBlock envs of a 256-thread block (4096 envs = 256 blocks: every CU takes part in what is a latency-bound
+// pass): each of the four waves takes kMuRows envs, the wave across the features — per 256-feature slice all rows' loads (one coalesced 1 KB line run each) are in
+// flight together, then one butterfly sum per row (every lane ends with the total; fixed order => deterministic).  Result in mu_s[] (shared), valid after the
+// caller's barrier.  Every thread of the block takes part whatever E is.
+constexpr int kEnvsPerBlock = 16, kMuRows = kEnvsPerBlock / 4;
+__device__ __forceinline__ void sac_mu_block(const CollectHeadArgs& g, int a, int e_block0, float* mu_s) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, e0 = e_block0 + kMuRows * wave;
+    const float* __restrict__ w = g.w3 + a;                          // W3 column-major (A x H2): W3[a + k A]
+    float acc[kMuRows];
+#pragma unroll
+    for (int r = 0; r < kMuRows; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < g.H2; k0 += 256) {                         // H2 % 4 == 0 (host-checked): a lane's four features are inside the row or all outside
+        const int k = k0 + 4 * lane;
+        const bool in = k < g.H2;
+        const int kk = in ? k : 0;                                    // out-of-range lanes re-read the row's start and multiply by zero weights: no branch around the loads
+        float wk[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const float x = w[(size_t)(kk + t) * g.A]; wk[t] = in ? x : 0.f; }
+        float4 v[kMuRows];
+#pragma unroll
+        for (int r = 0; r < kMuRows; ++r) {
+            const int e = e0 + r < g.E ? e0 + r : g.E - 1;           // rows past E re-read the last one (in bounds, unused)
+            v[r] = *reinterpret_cast<const float4*>(g.h2 + (size_t)e * g.H2 + kk);
+        }
+#pragma unroll
+        for (int r = 0; r < kMuRows; ++r) { acc[r] = fmaf(v[r].x, wk[0], acc[r]); acc[r] = fmaf(v[r].y, wk[1], acc[r]); acc[r] = fmaf(v[r].z, wk[2], acc[r]); acc[r] = fmaf(v[r].w, wk[3], acc[r]); }
+    }
+    const float b = g.b3[a];
+#pragma unroll
+    for (int r = 0; r < kMuRows; ++r) {
+        float s2 = acc[r];
+#pragma unroll
+        for (int o = 32; o; o >>= 1) s2 += __shfl_xor(s2, o);
+        if (lane == r) mu_s[kMuRows * wave + r] = s2 + b;
+    }
+}
+// 256 threads per kEnvsPerBlock envs: the output layer by all four waves (g.h2 set), then one thread per env
+__global__ __launch_bounds__(256) void sac_collect_head_kernel(CollectHeadArgs g) {
+    __shared__ float mu_s[kEnvsPerBlock];
+    const int e = blockIdx.x * kEnvsPerBlock + threadIdx.x;
+    if (g.h2 && !g.use_random) {                                     // the output layer first (whole block: no early return before it)
+        for (int a = 0; a < g.A; ++a) {
+            sac_mu_block(g, a, blockIdx.x * kEnvsPerBlock, mu_s);
+            __syncthreads();
+            if (threadIdx.x < kEnvsPerBlock && e < g.E) g.mu[(size_t)e * g.A + a] = mu_s[threadIdx.x];
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x >= kEnvsPerBlock || e >= g.E) return;
     for (int a0 = 0; a0 < g.A; a0 += 2) {
         float z[2];
         if (g.inj_noise) { z[0] = g.inj_noise[e * g.A + a0]; z[1] = a0 + 1 < g.A ? g.inj_noise[e * g.A + a0 + 1] : 0.f; }
@@ -610,9 +690,11 @@ __global__ void sac_collect_head_kernel(CollectHeadArgs g) {
 struct PushArgs {
     int E, D, A; long long cap, tail; const float *obs, *raw, *rew, *tobs, *nobs; const uint8_t *term, *trunc;
     float *rb_obs, *rb_next, *rb_act, *rb_rew; uint8_t *rb_term, *rb_trunc;
+    unsigned long long* stamp;   // phase_stamp (null: none)
 };
 __global__ void sac_push_kernel(PushArgs g) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    phase_stamp(g.stamp);                                    // (within a microsecond of the kernel's end: the stamp feeds a per-iteration fps statistic)
     if (e >= g.E) return;
     const long long slot = (g.tail + e) % g.cap;
     const bool tr = g.trunc[e] != 0;
@@ -629,11 +711,16 @@ __global__ void sac_push_kernel(PushArgs g) {
 struct CollectEnvArgs { CollectHeadArgs head; PushArgs push; uint64_t seed0; int episode_len; float* state; int32_t* step_count; uint32_t* episode; uint32_t* gstep;
                         float* rew; uint8_t* term; uint8_t* trunc; float* tobs; float* nobs; };
 template <int KIND>
-__global__ void sac_collect_env_kernel(CollectEnvArgs c) {
+__global__ __launch_bounds__(256) void sac_collect_env_kernel(CollectEnvArgs c) {
     constexpr int S = EnvSpec<KIND>::S, D = EnvSpec<KIND>::D;
+    __shared__ float mu_s[kEnvsPerBlock];
     const CollectHeadArgs& g = c.head;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= g.E) return;
+    const int e = blockIdx.x * kEnvsPerBlock + threadIdx.x;          // 256 threads per kEnvsPerBlock envs: all four waves on the output layer, then one thread per env
+    if (!g.use_random && g.h2) { sac_mu_block(g, 0, blockIdx.x * kEnvsPerBlock, mu_s); __syncthreads(); }   // the actor's output layer (A = 1), same device function as the head kernel
+    phase_stamp(c.push.stamp);
+    if (threadIdx.x >= kEnvsPerBlock || e >= g.E) return;
+    float mu_e = 0.f;
+    if (!g.use_random) { if (g.h2) { mu_e = mu_s[threadIdx.x]; g.mu[e] = mu_e; } else mu_e = g.mu[e]; }
     // ---- the action (sac_collect_head_kernel, A = 1) ----
     float z;
     if (g.inj_noise) z = g.inj_noise[e];
@@ -645,7 +732,7 @@ __global__ void sac_collect_env_kernel(CollectEnvArgs c) {
     float r, ev;
     if (g.use_random) { r = g.low + z * (g.high - g.low); ev = r; }
     else {
-        r = tanhf(g.mu[e] + expf(g.log_std[0]) * z);
+        r = tanhf(mu_e + expf(g.log_std[0]) * z);
         ev = tanhf(r) * (g.high - g.low) / 2.0f + (g.low + g.high) / 2.0f;
     }
     g.raw[e] = r; g.envact[e] = ev;
@@ -723,7 +810,7 @@ struct dril_sac_handle {
     double* ssq_rows = nullptr;   // [stats_cap][adam_blocks_c + end_blocks] squared-gradient partials per update, summed on the host (grad_norm statistic)
     unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
     SacScalars* sc_next = nullptr;   // ping-pong partner of `sc` (fused heads: the entropy step writes the new state here, then the two are swapped)
-    double* head_partials = nullptr; unsigned int* head_counter = nullptr; bool fused_heads = true; bool fused_collect = true; bool trace_enqueue = false; std::vector<hipEvent_t> it_events; int iter_chunk = 64;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
+    double* head_partials = nullptr; unsigned int* head_counter = nullptr; unsigned long long* it_stamps = nullptr; int it_stamps_cap = 0; double wall_hz = 1e8; bool fused_heads = true; bool fused_collect = true; bool fused_fwd = true; bool trace_enqueue = false; std::vector<hipEvent_t> it_events; int iter_chunk = 64;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
     float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
     float target_entropy = 0, act_lo = -2.0f, act_hi = 2.0f; bool external = false;   // bounds of the agent-facing action space: Box(-2,2), Box(-1,1) under ScalingWrapperEnv
     // env
@@ -782,7 +869,13 @@ int net_forward(dril_sac_handle* h, const float* P, NetOff off, long long zP, in
                 NetBufs b, int Z, int zdivX = 1, bool hidden_only = false, bool first_done = false) {
     const int H1 = h->H1, H2 = h->H2, act = h->cfg.activation ? EPI_RELU : EPI_TANH;
     GemmArgs g = gemm_args();                                                       // h1 = act(W1 x + b1)
-    if (!first_done) {
+    // a narrow input (Pendulum: 3 features) over many rows (the collection forward): an elementwise pass instead of a K = 3 contraction
+    const bool elem_l1 = !first_done && h->fused_fwd && Z == 1 && in <= 4 && ldx == in && n >= 1024;
+    if (elem_l1) {
+        CollectL1Args l1{n, in, H1, h->cfg.activation ? 1 : 0, X, P + off.w1, P + off.b1, b.h1};
+        hipLaunchKernelGGL(sac_collect_l1_kernel, dim3((n + 7) / 8), dim3(256), 0, h->stream, l1);
+    }
+    if (!first_done && !elem_l1) {
     g.A = P + off.w1; g.sAm = 1; g.sAk = H1; g.zA = zP; g.B = X; g.sBk = 1; g.sBn = ldx; g.zB = zX; g.zdivB = zdivX;
     g.C = b.h1; g.sCm = 1; g.sCn = H1; g.zC = b.zh; g.bias = P + off.b1; g.zBias = zP; g.M = H1; g.N = n; g.K = in; g.epi = act;
     SDO(gemm(h, g, Z));
@@ -840,7 +933,7 @@ int adam_range(dril_sac_handle* h, int lo, int n, const float* grads, const floa
 }
 
 // one update!(agent, alg, batch): sac.jl:299-404.  `slot` = index into the injected batches (-1 = Philox), `out` = device stats row
-int sac_one_update(dril_sac_handle* h, int slot, float* out) {
+int sac_one_update(dril_sac_handle* h, int slot, float* out, unsigned long long* stamp = nullptr) {
     double* ssq_row = h->ssq_rows + (size_t)((out - h->stats_out) / 8) * (h->adam_blocks_c + h->end_blocks);   // this update's squared-gradient partials: [critic Adam blocks | end blocks]
     const int B = h->cfg.batch_size, D = h->D, A = h->A, W = D + A;
     const SacRng rng{h->cfg.seed ^ 0x5ac5ac5ac5ac5ac5ull, h->update_counter};
@@ -924,7 +1017,7 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out) {
     StepEndArgs se{h->params, h->adam_m, h->adam_v, h->g_actor, round4(h->actor.end), h->log_std_off, A, h->q0.w1, 2 * h->Pqd,
                    h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->bt_actor[0], h->bt_actor[1], h->bt_critic[0], h->bt_critic[1],
                    h->target, h->cfg.tau, do_polyak, ssq_row + h->adam_blocks_c, h->stats, out,
-                   h->fused_heads ? hb : 0, B, h->head_partials, h->head_partials + 2 * (size_t)hb, h->head_partials + 4 * (size_t)hb, h->g_actor + h->log_std_off};
+                   h->fused_heads ? hb : 0, B, h->head_partials, h->head_partials + 2 * (size_t)hb, h->head_partials + 4 * (size_t)hb, h->g_actor + h->log_std_off, stamp};
     hipLaunchKernelGGL(sac_step_end_kernel, dim3(h->end_blocks), dim3(256), 0, h->stream, se);
     SHIP(h, hipGetLastError());
     h->bt_actor[0] *= h->cfg.adam_beta1; h->bt_actor[1] *= h->cfg.adam_beta2;
@@ -939,16 +1032,20 @@ int ensure_obs(dril_sac_handle* h) {
     return DRIL_OK;
 }
 // one step of collect_trajectories (off_policy_collection.jl:42-93) for all envs
-int collect_step(dril_sac_handle* h, int use_random, const float* inj_noise) {
+int collect_step(dril_sac_handle* h, int use_random, const float* inj_noise, unsigned long long* stamp = nullptr) {
     const int E = h->cfg.n_envs, D = h->D, A = h->A;
-    if (!use_random) SDO(net_forward(h, h->params, h->actor, 0, D, A, h->obs_cur, D, 0, E, actor_bufs(h), 1));          // predict_actions_raw :55
-    CollectHeadArgs ca{E, A, use_random, h->mu, h->params + h->log_std_off, inj_noise, h->gstep, h->env_seed0, h->act_lo, h->act_hi, h->e_raw, h->e_envact};
+    // predict_actions_raw :55 — the hidden layers as contractions (the first one inside the second's staging when the input is narrow); the output layer inside the head /
+    // env kernel that follows (fused_fwd; DRIL_SAC_NO_FUSED_FWD=1: three contractions and mu through memory, the round 1 - 3 form)
+    const bool mu_in_head = h->fused_fwd && !use_random && h->H2 % 4 == 0;
+    if (!use_random) SDO(net_forward(h, h->params, h->actor, 0, D, A, h->obs_cur, D, 0, E, actor_bufs(h), 1, 1, mu_in_head));
+    CollectHeadArgs ca{E, A, use_random, h->mu, h->params + h->log_std_off, inj_noise, h->gstep, h->env_seed0, h->act_lo, h->act_hi, h->e_raw, h->e_envact,
+                       mu_in_head ? h->ah2 : nullptr, h->params + h->actor.w3, h->params + h->actor.b3, h->H2};
     if (A == 1 && !h->external && h->fused_collect) {                                                            // every device Box env: head + act! + observe + push! in one launch
         const long long tail1 = (h->head + h->size) % h->cap;
         PushArgs pa1{E, D, A, h->cap, tail1, h->obs_cur, h->e_raw, h->e_rew, h->e_tobs, h->obs_nxt, h->e_term, h->e_trunc,
-                     h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc};
+                     h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc, stamp};
         CollectEnvArgs ce{ca, pa1, h->env_seed0, h->cfg.episode_len, h->state, h->step_count, h->episode, h->gstep, h->e_rew, h->e_term, h->e_trunc, h->e_tobs, h->obs_nxt};
-        const dim3 grid((E + 255) / 256), block(256);
+        const dim3 grid((E + kEnvsPerBlock - 1) / kEnvsPerBlock), block(256);
         if (h->cfg.env_kind == DRIL_ENV_PENDULUM) hipLaunchKernelGGL(sac_collect_env_kernel<1>, grid, block, 0, h->stream, ce);
         else if (h->cfg.env_kind == DRIL_ENV_PENDULUM_SCALED) hipLaunchKernelGGL(sac_collect_env_kernel<2>, grid, block, 0, h->stream, ce);
         else if (h->cfg.env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED) hipLaunchKernelGGL(sac_collect_env_kernel<7>, grid, block, 0, h->stream, ce);
@@ -959,14 +1056,14 @@ int collect_step(dril_sac_handle* h, int use_random, const float* inj_noise) {
         std::swap(h->obs_cur, h->obs_nxt);
         return DRIL_OK;
     }
-    hipLaunchKernelGGL(sac_collect_head_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, ca);
+    hipLaunchKernelGGL(sac_collect_head_kernel, dim3((E + kEnvsPerBlock - 1) / kEnvsPerBlock), dim3(256), 0, h->stream, ca);
     MonitorArgs mon{nullptr, nullptr, nullptr, nullptr, nullptr};
     SHIP(h, launch_env_step(h->cfg.env_kind, E, h->env_seed0, h->cfg.episode_len, 0, 0, h->e_envact, h->state, h->step_count, h->episode, h->gstep,
                             h->e_rew, h->e_term, h->e_trunc, h->e_tobs, mon, h->stream));                                     // act! :60
     SHIP(h, launch_env_observe(h->cfg.env_kind, E, h->state, h->obs_nxt, h->stream));                                         // observe :61
     const long long tail = (h->head + h->size) % h->cap;
     PushArgs pa{E, D, A, h->cap, tail, h->obs_cur, h->e_raw, h->e_rew, h->e_tobs, h->obs_nxt, h->e_term, h->e_trunc,
-                h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc};
+                h->rb_obs, h->rb_next, h->rb_act, h->rb_rew, h->rb_term, h->rb_trunc, stamp};
     hipLaunchKernelGGL(sac_push_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, pa);
     SHIP(h, hipGetLastError());
     const long long over = h->size + E - h->cap;                                                  // CircularBuffer: overwrite the oldest
@@ -1044,20 +1141,28 @@ int run_iterations(dril_sac_handle* h, int count, int tf, int n_upd, dril_sac_st
     SDO(ensure_obs(h));
     if (n_upd > 0) { if (h->size <= 0 && tf <= 0) return sfail(h, DRIL_ERR_NOT_INITIALISED, "the replay buffer is empty"); SDO(ensure_stats(h, count * n_upd)); }
     const bool timed = h->cfg.profile_events || fps;
-    while (timed && (int)h->it_events.size() < 3 * count) { hipEvent_t e; SHIP(h, hipEventCreate(&e)); h->it_events.push_back(e); }
+    const int n_st = 1 + 2 * count;                                                        // [loop start | per iteration: collection end, update end] (phase_stamp)
+    if (timed) {
+        if (n_st > h->it_stamps_cap) { if (h->it_stamps) hipFree(h->it_stamps); h->it_stamps = nullptr; SHIP(h, smalloc(&h->it_stamps, (size_t)n_st)); h->it_stamps_cap = n_st; }
+        SHIP(h, hipMemsetAsync(h->it_stamps, 0, sizeof(unsigned long long) * n_st, h->stream));
+        hipLaunchKernelGGL(sac_stamp_kernel, dim3(1), dim3(64), 0, h->stream, h->it_stamps);
+    }
     for (int j = 0; j < count; ++j) {
-        if (timed) hipEventRecord(h->it_events[3 * j], h->stream);
-        for (int t = 0; t < tf; ++t) SDO(collect_step(h, 0, nullptr));
-        if (timed) hipEventRecord(h->it_events[3 * j + 1], h->stream);
-        for (int k = 0; k < n_upd; ++k) SDO(sac_one_update(h, -1, h->stats_out + ((size_t)j * n_upd + k) * 8));
-        if (timed) hipEventRecord(h->it_events[3 * j + 2], h->stream);
+        for (int t = 0; t < tf; ++t) SDO(collect_step(h, 0, nullptr, timed && t == tf - 1 ? h->it_stamps + 1 + 2 * j : nullptr));
+        for (int k = 0; k < n_upd; ++k) SDO(sac_one_update(h, -1, h->stats_out + ((size_t)j * n_upd + k) * 8, timed && k == n_upd - 1 ? h->it_stamps + 2 + 2 * j : nullptr));
     }
     SDO(ssync(h));
-    if (timed) for (int j = 0; j < count; ++j) {
-        float c = 0, u = 0;
-        if (hipEventElapsedTime(&c, h->it_events[3 * j], h->it_events[3 * j + 1]) != hipSuccess || hipEventElapsedTime(&u, h->it_events[3 * j + 1], h->it_events[3 * j + 2]) != hipSuccess) continue;
-        if (h->cfg.profile_events) { h->collect_ms += c; h->collect_steps += tf; h->update_ms += u; h->updates += n_upd; }
-        if (fps && j < fps_room) fps[j] = (double)tf * h->cfg.n_envs / (c > 0 ? 1e-3 * c : 1e-9);
+    if (timed) {
+        std::vector<unsigned long long> st((size_t)n_st);
+        SHIP(h, hipMemcpy(st.data(), h->it_stamps, st.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long prev = st[0];
+        for (int j = 0; j < count; ++j) {
+            const unsigned long long ce = st[1 + 2 * j] ? st[1 + 2 * j] : prev, ue = st[2 + 2 * j] ? st[2 + 2 * j] : ce;   // (a phase that did not run left no stamp: zero length)
+            const double c = 1e3 * (double)(ce - prev) / h->wall_hz, u = 1e3 * (double)(ue - ce) / h->wall_hz;             // ms
+            if (h->cfg.profile_events) { h->collect_ms += c; h->collect_steps += tf; h->update_ms += u; h->updates += n_upd; }
+            if (fps && j < fps_room) fps[j] = (double)tf * h->cfg.n_envs / (c > 0 ? 1e-3 * c : 1e-9);
+            prev = ue;
+        }
     }
     if (stats && n_upd > 0 && stats_room > 0) {
         std::vector<dril_sac_stats> tmp((size_t)count * n_upd);
@@ -1121,6 +1226,7 @@ DRIL_EXPORT int32_t dril_sac_destroy(dril_sac_handle* h) {
     for (void* p : ptrs) if (p) hipFree(p);
     if (h->ev_a) hipEventDestroy(h->ev_a); if (h->ev_b) hipEventDestroy(h->ev_b);
     for (hipEvent_t e : h->it_events) hipEventDestroy(e);
+    if (h->it_stamps) hipFree(h->it_stamps);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return DRIL_OK;
@@ -1144,6 +1250,7 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
 #define CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { std::string m = std::string(#expr) + ": " + hipGetErrorString(_e); dril_sac_destroy(h); return sfail(nullptr, DRIL_ERR_HIP, m); } } while (0)
     CHK(hipSetDevice(cfg->device));
     CHK(hipStreamCreate(&h->stream));
+    { int khz = 0; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device) == hipSuccess && khz > 0) h->wall_hz = 1e3 * (double)khz; }   // wall_clock64 ticks per second (phase_stamp)
     const int D = h->D = ext ? cfg->ext_obs_dim : ((cfg->env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS || cfg->env_kind == DRIL_ENV_MOUNTAINCAR_CONTINUOUS_SCALED) ? 2 : 3), A = h->A = ext ? cfg->ext_action_dim : 1, S = h->S = ext ? 0 : 2, H1 = h->H1 = cfg->hidden1, H2 = h->H2 = cfg->hidden2, E = cfg->n_envs, B = cfg->batch_size, W = D + A;
     h->Pa = D * H1 + H1 + H1 * H2 + H2 + H2 * A + A; h->Pq = W * H1 + H1 + H1 * H2 + H2 + H2 + 1; h->P = h->Pa + 2 * h->Pq + A;
     h->actor = net_off(0, D, H1, H2, A); h->Pqd = round4(h->Pq); h->q0 = net_off(round4(h->actor.end), W, H1, H2, 1);
@@ -1158,7 +1265,7 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     h->adam_blocks_c = std::min(kSacAdamBlocks, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(kSacAdamBlocks, ((h->actor.end + 3) / 4 + 2 * h->Pqd / 4 + 255) / 256);   // elementwise optimiser kernels: up to 1 024 blocks (no grid-wide fold is left in them; 256 -> 1 024: update! 0.174 -> 0.168 ms)
     CHK(smalloc(&h->counter, 1));
     CHK(smalloc(&h->head_partials, (size_t)(2 * kMaxA + 8) * ((B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock + 1))); CHK(smalloc(&h->head_counter, kMaxA + 1));   // doubles: [critic 2 | actor 2 | log_std kMaxA | entropy 2] x blocks
-    h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr; h->fused_collect = std::getenv("DRIL_SAC_NO_FUSED_COLLECT") == nullptr; h->trace_enqueue = std::getenv("DRIL_SAC_TRACE_ENQUEUE") != nullptr;   // latched here: no getenv on the update path
+    h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr; h->fused_collect = std::getenv("DRIL_SAC_NO_FUSED_COLLECT") == nullptr; h->fused_fwd = std::getenv("DRIL_SAC_NO_FUSED_FWD") == nullptr; h->trace_enqueue = std::getenv("DRIL_SAC_TRACE_ENQUEUE") != nullptr;   // latched here: no getenv on the update path
     CHK(smalloc(&h->state, (size_t)E * S)); CHK(smalloc(&h->step_count, E)); CHK(smalloc(&h->episode, E)); CHK(smalloc(&h->gstep, E)); CHK(smalloc(&h->disc_returns, E));
     CHK(smalloc(&h->obs_cur, (size_t)E * D)); CHK(smalloc(&h->obs_nxt, (size_t)E * D)); CHK(smalloc(&h->e_rew, E)); CHK(smalloc(&h->e_tobs, (size_t)E * D));
     CHK(smalloc(&h->e_raw, (size_t)E * A)); CHK(smalloc(&h->e_envact, (size_t)E * A)); CHK(smalloc(&h->e_term, E)); CHK(smalloc(&h->e_trunc, E));

@@ -182,6 +182,31 @@ def test_one_launch_collection_equals_the_four_launch_sequence(pkg, monkeypatch,
     assert a.replay(C.RB_TRUNCATED).sum() > 0
 
 
+@pytest.mark.parametrize("E,hidden,act", [(4096, (512, 512), "relu"), (4100, (512, 512), "tanh"), (16400, (96, 160), "relu")])
+def test_fused_collection_forward_matches_the_three_contraction_form_and_the_oracle(pkg, monkeypatch, E, hidden, act):
+    """the collection forward of configs[4]-sized env counts: the first layer (3 input features) is an elementwise pass instead of a K = 3 contraction and
+    the output layer mu = W3 h2 + b3 inside the head / env kernel (two launches and two round trips through memory less per env step); DRIL_SAC_NO_FUSED_FWD=1
+    (latched at create) keeps the three-contraction form.  Same fp32 products in another summation order: replay contents agree to rounding with each other and
+    with the oracle's collection (off_policy_collection.jl:28-96), incl. an env count that is no multiple of the tile sizes and unequal hidden widths"""
+    a, o, layer, _ = make_pair(pkg, E=E, hidden=hidden, act=act, cap=4 * E, max_steps=3)
+    monkeypatch.setenv("DRIL_SAC_NO_FUSED_FWD", "1")
+    b, _, _, _ = make_pair(pkg, E=E, hidden=hidden, act=act, cap=4 * E, max_steps=3)
+    monkeypatch.delenv("DRIL_SAC_NO_FUSED_FWD")
+    flat = init_params(pkg, layer, scale_out=3.0)
+    nz = np.random.default_rng(5).normal(0, 1, (3, E, 1)).astype(np.float32)
+    for x in (a, b, o):
+        x.set_params(flat); x.env_reset(3); x.set_collect_noise(nz); x.collect_rollout(3, False)      # three policy steps, one truncation
+    C = pkg._capi
+    for which in (C.RB_TERMINATED, C.RB_TRUNCATED):
+        np.testing.assert_array_equal(a.replay(which), b.replay(which)); np.testing.assert_array_equal(a.replay(which), o.replay(which))
+    for which in (C.RB_OBSERVATIONS, C.RB_NEXT_OBSERVATIONS, C.RB_ACTIONS, C.RB_REWARDS):
+        close(a.replay(which), b.replay(which), rtol=1e-4, atol=2e-5)
+        close(a.replay(which), o.replay(which), rtol=1e-4, atol=5e-5)
+    assert a.replay(C.RB_TRUNCATED).sum() == E and np.abs(a.replay(C.RB_ACTIONS)).max() < 1.0 and np.std(a.replay(C.RB_ACTIONS)) > 0.1
+    for x in (a, b):
+        x.close()
+
+
 def test_iterations_without_host_sync_equal_the_step_by_step_loop(pkg):
     """dril_sac_iterate (train!'s loop body enqueued back to back, one drain per 64 iterations; dril_sac_train's own loop) against collect_rollout(train_freq) +
     update(n) per iteration with a drain after each: the same launches in the same order => parameters, targets, entropy coefficient, replay contents and the
