@@ -97,7 +97,7 @@ struct dril_handle {
     void* act = nullptr; uint8_t* flags = nullptr;
     void* noise_dev = nullptr; bool noise_set = false;
     int64_t* perm_dev = nullptr; size_t perm_count = 0;
-    int64_t* epoch_index = nullptr; bool no_epoch_index = false;   // the device DataLoader order of the current epoch, written out (large minibatches; DRIL_NO_EPOCH_INDEX)
+    int32_t* epoch_index = nullptr; bool no_epoch_index = false;   // the device DataLoader order of the current epoch, written out (large minibatches; DRIL_NO_EPOCH_INDEX)
     double *adv_partials = nullptr, *adv_stats = nullptr, *ev_partials = nullptr; int adv_blocks = 0, ev_blocks = 0;
     float* step_stats = nullptr; int step_stats_cap = 0;
     int *stop_flag = nullptr, *nan_flag = nullptr;
@@ -342,7 +342,7 @@ int step_dev(dril_handle* h, const void* actions, float* rew_out, uint8_t* flags
 // one optimiser step on [pos0, pos0+count) of the current epoch order; all launches asynchronous
 int ppo_step(dril_handle* h, const float* obs, const void* actions, const float* adv, const float* ret, const float* logp_old,
              const float* val_old, const int64_t* perm, int64_t pos0, int64_t count, int64_t N, uint64_t key, int bits,
-             float* step_stats, bool apply, const float4* rec = nullptr, const double* pre_stats = nullptr) {
+             float* step_stats, bool apply, const float4* rec = nullptr, const double* pre_stats = nullptr, const int32_t* perm32 = nullptr) {
     const int world = comm_ready(h) ? h->cfg.world_size : 1;
     const bool reduce = world > 1 || (comm_ready(h) && h->force_allreduce);   // force: exercise the RCCL path on one rank (tests)
     const int64_t tiles = (count + kTile - 1) / kTile;
@@ -375,7 +375,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     if (h->cfg.normalize_advantage && pre_stats) adv_stats = pre_stats;   // per-epoch table (already all-reduced in data-parallel runs)
     else if (h->cfg.normalize_advantage && small) adv_stats = nullptr;
     else if (h->cfg.normalize_advantage) {
-        MomentsArgs m{}; m.adv = adv; m.perm = perm; m.pos0 = pos0; m.count = count; m.N = N; m.idx_lo = 0; m.n_local = N;
+        MomentsArgs m{}; m.adv = adv; m.perm = perm; m.perm32 = perm32; m.pos0 = pos0; m.count = count; m.N = N; m.idx_lo = 0; m.n_local = N;
         m.perm_key = key; m.perm_bits = bits; m.partials = h->adv_partials; m.stop_flag = h->stop_flag;
         int nb = (int)((count + 255) / 256); if (nb > h->adv_blocks) nb = h->adv_blocks; if (nb < 1) nb = 1;
         prof_begin(h, DRIL_K_ADV_MOMENTS);
@@ -386,7 +386,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     }
     GradArgs g{};
     g.params = h->params; g.obs = obs; g.actions = actions; g.adv = adv; g.ret = ret; g.logp_old = logp_old; g.val_old = val_old;
-    g.perm = perm; g.pos0 = pos0; g.count = count; g.N = N; g.idx_lo = 0; g.n_local = N; g.perm_key = key; g.perm_bits = bits;
+    g.perm = perm; g.perm32 = perm32; g.pos0 = pos0; g.count = count; g.N = N; g.idx_lo = 0; g.n_local = N; g.perm_key = key; g.perm_bits = bits;
     g.w2p_actor = (const u32x4*)h->w2p_actor; g.w2tp_actor = (const u32x4*)h->w2tp_actor; g.w2p_critic = (const u32x4*)h->w2p_critic; g.w2tp_critic = (const u32x4*)h->w2tp_critic;
     g.rec = rec; g.w2a_actor = h->w2a_actor; g.w2ta_actor = h->w2ta_actor; g.w2a_critic = h->w2a_critic; g.w2ta_critic = h->w2ta_critic;
     g.adv_stats = adv_stats; g.inline_moments = (h->cfg.normalize_advantage && adv_stats == nullptr) ? 1 : 0; g.invB = 1.0f / (float)(count * world);
@@ -406,6 +406,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     prof_end(h);
     ReduceArgs r{};
     r.slabs_actor = h->slabs_a; r.slabs_critic = h->slabs_c; r.slab_a = h->slab_a; r.slab_c = h->slab_c; r.G = G; r.Gc = Gc;
+    if (h->last_variant == 5) { r.G = G / 2; r.Gc = Gc / 2; }                       // ppo_grad_pair_kernel: G / Gc count pairs, its workgroups (two pairs each) write one slab
     r.P = h->P; r.Pa = h->Pa; r.Pc = h->Pc; r.flat = h->flat; r.norm_partials = h->norm_partials; r.n_samples_local = (double)count;
     r.stop_flag = h->stop_flag;
     if (small && apply && h->P <= 16384 && G <= 32) {
@@ -1117,7 +1118,7 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
         const bool epoch_moments = h->cfg.normalize_advantage && !perm && nb >= 2 && nb <= 2048 && !h->no_epoch_moments;
         // chip-filling minibatches of the fused kernels: the epoch's order as an index array (the update kernels then read 8 bytes per sample instead of evaluating the
         // keyed bijection per lane, wave, net and tile)
-        const bool index_array = !perm && !h->generic && !h->no_epoch_index && (B + kTile - 1) / kTile >= kPairTilesPerCu * (int64_t)h->num_cus;
+        const bool index_array = !perm && !h->generic && !h->no_epoch_index && N < (1ll << 31) && (B + kTile - 1) / kTile >= kPairTilesPerCu * (int64_t)h->num_cus;
         if (index_array) {
             if (!h->epoch_index) HIPCHK(h, dmalloc(&h->epoch_index, (size_t)N));
             prof_begin(h, DRIL_K_ADV_MOMENTS);
@@ -1141,8 +1142,8 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
         }
         for (int64_t k = 0; k < nb; ++k, ++step) {
             const int64_t pos0 = k * B, count = (pos0 + B <= N) ? B : N - pos0;
-            int rc = ppo_step(h, h->obs, h->act, h->adv, h->ret, h->logp, h->val, index_array ? h->epoch_index : perm, pos0, count, N, key, bits, h->step_stats + step * 16, true, h->rec,
-                              epoch_moments ? h->epoch_stats + 3 * k : nullptr);
+            int rc = ppo_step(h, h->obs, h->act, h->adv, h->ret, h->logp, h->val, perm, pos0, count, N, key, bits, h->step_stats + step * 16, true, h->rec,
+                              epoch_moments ? h->epoch_stats + 3 * k : nullptr, index_array ? h->epoch_index : nullptr);
             if (rc) return rc;
         }
     }

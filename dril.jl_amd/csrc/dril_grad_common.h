@@ -57,7 +57,7 @@ __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64
     const int64_t i = (live ? tile : ntiles - 1) * kTile + c;
     const bool inb = live && i < a.count;
     const int64_t p = a.pos0 + (inb ? i : 0);
-    const int64_t gidx = a.perm ? a.perm[p] : (a.perm_bits ? perm_index(p, a.N, a.perm_key, a.perm_bits) : p);   // bits 0 = identity order
+    const int64_t gidx = a.perm32 ? (int64_t)a.perm32[p] : a.perm ? a.perm[p] : (a.perm_bits ? perm_index(p, a.N, a.perm_key, a.perm_bits) : p);   // bits 0 = identity order
     const int64_t li = gidx - a.idx_lo;
     t.valid = inb && li >= 0 && li < a.n_local;
     const int64_t idx = t.valid ? li : 0;

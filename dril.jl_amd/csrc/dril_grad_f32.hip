@@ -42,7 +42,7 @@ __device__ __forceinline__ void grad_body(const GradArgs& a, float* smem) {
             double ls_ = 0, lq_ = 0;
             for (int64_t i2 = tid; i2 < a.count; i2 += blockDim.x) {
                 const int64_t p2 = a.pos0 + i2;
-                const int64_t gi = a.perm ? a.perm[p2] : (a.perm_bits ? perm_index(p2, a.N, a.perm_key, a.perm_bits) : p2);
+                const int64_t gi = a.perm32 ? (int64_t)a.perm32[p2] : a.perm ? a.perm[p2] : (a.perm_bits ? perm_index(p2, a.N, a.perm_key, a.perm_bits) : p2);
                 const int64_t li2 = gi - a.idx_lo;
                 if (li2 >= 0 && li2 < a.n_local) { const float v = REC ? a.rec[RecLayout<D>::RS * li2 + RecLayout<D>::RS - 1].y : a.adv[li2]; ls_ += v; lq_ += (double)v * v; }
             }

@@ -1,4 +1,5 @@
-// dril_grad_pair.hip — ppo_grad_pair_kernel: the update kernel of hidden [64,64] for large minibatches (THE HEADLINE KERNEL): bf16 matrix cores, fp32-equivalent 3-piece operand split, two waves per tile
+// dril_grad_pair.hip — ppo_grad_pair_kernel: the update kernel of hidden [64,64] for large minibatches (THE HEADLINE KERNEL): f16 matrix cores (v_mfma_f32_32x32x16_f16),
+// fp32-equivalent two-piece operand split (three MFMAs per k16 step; dril_device.h), two waves per tile
 #include <utility>
 
 #include "dril_grad_common.h"
@@ -10,16 +11,16 @@ namespace dril {
 // ppo_grad_pair_kernel — hidden [64,64], large minibatches: TWO waves own one 32-sample tile (wave p the m-tile p of every layer and the 32 x 64 slice p of dW2: the
 // decomposition of ppo_grad_wide_split_kernel at MT = 2), two pairs per workgroup, two workgroups per CU = TWO waves per SIMD at <= 256 registers: the second wave
 // covers the first one's LDS round trips, barriers and dependency stalls.  (It does NOT hide the vector work behind the MFMAs, as round 2 believed: matrix-pipe time and
-// vector-ALU time add on a SIMD, also across waves — profiles/r03_pair_kernel_notes.md.)  Same arithmetic as the one-wave split kernel of round 2 (bf16 matrix cores,
-// fp32-equivalent 3-piece operand splitting).
-//   * W2 lives in LDS once per workgroup as three bf16 pieces in the piece-image layout of the wide split kernel (128-byte rows, 16-byte chunk ch of row r at ch ^ f(r)):
+// vector-ALU time add on a SIMD, also across waves — profiles/r03_pair_kernel_notes.md.)  Arithmetic: every f32 operand of the H x H contractions as two f16 pieces
+// (hi + lo, scaled by powers of two into f16's dense range), products hi.hi + hi.lo + lo.hi accumulated in f32 (2^-24 relative; profiles/r03_split_arith.md section 6).
+//   * W2 lives in LDS once per workgroup as two f16 pieces in the piece-image layout of the wide split kernel (128-byte rows, 16-byte chunk ch of row r at ch ^ f(r)):
 //     row reads (ds_read_b128) give the A operand of L2, ds_read_b64_tr_b16 the A operand of dh1 (W2'); pre-scaled by kTanhScale, dh1 folds 1 / kTanhScale into its mask.
 //   * each pair has two 12 KB piece images (h1, dz2): every wave writes its own 32 columns once; row reads give the B operand of L2 / dh1 (both m-tiles), transposed
 //     reads both operands of dW2.
 //   * no f32 image at all: dW3, db2, dW1 and db1 are per-lane accumulations (the lane is the sample), reduced over the 32 lanes of a half once, in the epilogue.
 //   * four workgroup barriers per tile; both pairs of a workgroup run the same number of tiles (the second pair's last tile may be an all-invalid one).
-// Every wave owns distinct rows of every gradient: one slab per PAIR, written straight from registers.  a.G / a.Gc = pairs of the actor / the critic (even);
-// grid = (a.G + a.Gc) / 2 workgroups, the first a.G / 2 run the actor.
+// Every wave owns distinct rows of every gradient; the two pairs of a workgroup are summed through LDS into ONE slab per workgroup (epilogue).  a.G / a.Gc = pairs of
+// the actor / the critic (even); grid = (a.G + a.Gc) / 2 workgroups, the first a.G / 2 run the actor; slabs: a.G / 2 of the actor, a.Gc / 2 of the critic.
 // =============================================================================================
 // Every image starts at a multiple of 512 bytes of LDS (the dynamic segment itself is declared 1 KB-aligned).  Then bits 4-6 of a swizzled address ARE the chunk field
 // chunk ^ g(row), and stepping the chunk by a constant is an XOR of the whole address with that constant — one VALU per access, the image and piece offsets going into
@@ -328,43 +329,55 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     }
 #endif
 
-    // ---- epilogue: every wave owns distinct gradient rows -> straight to the pair's slab ----
+    // ---- epilogue: every wave owns distinct gradient rows; the TWO pairs of a workgroup are summed into ONE slab (round 4: grad_reduce_kernel then folds half as many
+    // slabs — 512 instead of 1 024 at configs[1], 15.6 -> ~8 us per optimiser step).  The piece images are dead after the last tile: pair 1 parks its values in them as
+    // plain f32 at the slab's own offsets, a barrier, pair 0 adds its own and writes the slab (pair 0 + pair 1: a fixed order, deterministic).  Both pairs ran the same
+    // number of tiles, so every wave reaches both barriers. ----
     const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
     const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
     const int o_ls = o_b3 + O, o_st = SL - 8;
-    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)g * SL;
+    float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)nb * SL;
+    float* park = smem + L::PAIR0;                                                    // 2 x PAIR_SIZE floats >= SL (checked by the launcher)
     const float inv_sa = inv_sg * (1.0f / kActScale);                                  // products with an activation operand carry SG kActScale, the others SG (powers of two: exact)
+    auto emit = [&](auto&& put) {
 #pragma unroll
-    for (int mj = 0; mj < MT; ++mj)
+        for (int mj = 0; mj < MT; ++mj)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H] = dW2[mj][r] * inv_sa;
+            for (int r = 0; r < 16; ++r) put(o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H, dW2[mj][r] * inv_sa);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {                                                    // per-lane sums over samples -> sum over the 32 lanes of each half (the halves hold different units)
-        const int unit = 32 * w + rowfn(r, h);
-        const float b2 = half_sum(db2acc[r]) * inv_sg;
-        if (c == 0) slab[o_b2 + unit] = b2;
-        if constexpr (!WIDE_IN) {
-            const float b1 = half_sum(db1acc[r]) * inv_sg;
-            if (c == 0) slab[o_b1 + unit] = b1;
+        for (int r = 0; r < 16; ++r) {                                                // per-lane sums over samples -> sum over the 32 lanes of each half (the halves hold different units)
+            const int unit = 32 * w + rowfn(r, h);
+            const float b2 = half_sum(db2acc[r]) * inv_sg;
+            if (c == 0) put(o_b2 + unit, b2);
+            if constexpr (!WIDE_IN) {
+                const float b1 = half_sum(db1acc[r]) * inv_sg;
+                if (c == 0) put(o_b1 + unit, b1);
 #pragma unroll
-            for (int d = 0; d < D; ++d) { const float v = half_sum(dW1acc[d][r]) * inv_sg; if (c == 0) slab[o_w1 + unit + d * H] = v; }
-        } else {                                                                      // column c of the MFMA accumulator: observation component c, or the bias
-            const float v = dW1acc[0][r] * (inv_sg * (1.0f / 16.0f));
-            if (c < D) slab[o_w1 + unit + c * H] = v; else if (c == D) slab[o_b1 + unit] = v;
+                for (int d = 0; d < D; ++d) { const float v = half_sum(dW1acc[d][r]) * inv_sg; if (c == 0) put(o_w1 + unit + d * H, v); }
+            } else {                                                                  // column c of the MFMA accumulator: observation component c, or the bias
+                const float v = dW1acc[0][r] * (inv_sg * (1.0f / 16.0f));
+                if (c < D) put(o_w1 + unit + c * H, v); else if (c == D) put(o_b1 + unit, v);
+            }
+#pragma unroll
+            for (int o = 0; o < O; ++o) { const float v = half_sum(dW3acc[o][r]) * inv_sa; if (c == 0) put(o_w3 + o + unit * O, v); }
         }
 #pragma unroll
-        for (int o = 0; o < O; ++o) { const float v = half_sum(dW3acc[o][r]) * inv_sa; if (c == 0) slab[o_w3 + o + unit * O] = v; }
-    }
+        for (int o = 0; o < O; ++o) {
+            const float b3 = half_sum(db3p[o]) * inv_sg;
+            if (w == 0 && lane == 0) put(o_b3 + o, b3);
+            if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]) * inv_sg; if (w == 0 && lane == 0) put(o_ls + o, l); }
+        }
 #pragma unroll
-    for (int o = 0; o < O; ++o) {
-        const float b3 = half_sum(db3p[o]) * inv_sg;
-        if (w == 0 && lane == 0) slab[o_b3 + o] = b3;
-        if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]) * inv_sg; if (w == 0 && lane == 0) slab[o_ls + o] = l; }
+        for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (w == 0 && lane == 0) put(o_st + k, v); }
+    };
+    __syncthreads();                                                                  // the other pair may still be reading its images
+    if (pr == 1) emit([&](int i, float v) { park[i] = v; });
+    __syncthreads();
+    if (pr == 0) {
+        emit([&](int i, float v) { slab[i] = v + park[i]; });
+        if (w == 0 && lane < 3) slab[o_st + 5 + lane] = 0.f;
+        for (int i = (HEAD == HEAD_GAUSSIAN ? o_ls + O : o_ls) + w * 64 + lane; i < o_st; i += 128) slab[i] = 0.f;   // padding
     }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (w == 0 && lane == 0) slab[o_st + k] = v; }
-    if (w == 0 && lane < 3) slab[o_st + 5 + lane] = 0.f;
-    for (int i = (HEAD == HEAD_GAUSSIAN ? o_ls + O : o_ls) + w * 64 + lane; i < o_st; i += 128) slab[i] = 0.f;   // padding
 }
 
 template <int KIND>
@@ -386,6 +399,7 @@ template <int KIND> static size_t grad_pair_lds_bytes() {
 hipError_t launch_ppo_grad_pair(int kind, const GradArgs& a, hipStream_t s) {
     if (kind == 7) kind = 4;                  // ScalingWrapperEnv(MountainCarContinuous): the update never touches the simulator
 #define CALLP(K) { const size_t lds = grad_pair_lds_bytes<K>(); static bool attr_set = false; \
+        if (a.slab_a > 2 * PairLds<EnvSpec<K>::D, EnvSpec<K>::A>::PAIR_SIZE || a.slab_c > 2 * PairLds<EnvSpec<K>::D, 1>::PAIR_SIZE) return hipErrorInvalidValue;   /* the epilogue parks a slab in the pair images */ \
         if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_pair_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
         ppo_grad_pair_kernel<K><<<(a.G + a.Gc) / 2, 256, lds, s>>>(a); }
     if (kind == 0) CALLP(0) else if (kind == 3) CALLP(3) else if (kind == 4) CALLP(4) else if (kind == 6) CALLP(6) else CALLP(1)

@@ -56,12 +56,14 @@ struct RolloutArgs {
 struct MomentsArgs {
     const float* adv; const int64_t* perm; int64_t pos0, count, N, idx_lo, n_local; uint64_t perm_key; int perm_bits;
     double* partials; const int* stop_flag;
+    const int32_t* perm32;    // the epoch's order as 32-bit indices (epoch_index_kernel, N < 2^31): takes precedence over perm
 };
 
 struct GradArgs {
     const float* params; const float* obs; const void* actions; const float* adv; const float* ret;
     const float* logp_old; const float* val_old;
     const int64_t* perm; int64_t pos0, count, N, idx_lo, n_local; uint64_t perm_key; int perm_bits;
+    const int32_t* perm32;    // the epoch's DataLoader order written out as 32-bit indices (epoch_index_kernel; N < 2^31): takes precedence over perm / the keyed bijection
     const float* w2a_actor; const float* w2ta_actor; const float* w2a_critic; const float* w2ta_critic;   // wide nets: pre-tiled W2 / W2' images
     const u32x4* w2p_actor; const u32x4* w2tp_actor; const u32x4* w2p_critic; const u32x4* w2tp_critic;   // wide nets, bf16-split form: pre-split fragment streams
     const float4* rec;   // packed minibatch records [N][2] x float4: {obs0..3} {action bits, adv, logp_old, ret}; null = gather from the SoA buffers
@@ -94,7 +96,7 @@ struct SmallUpdateArgs {
 };
 constexpr int kSmallXchgWords = 4 * 16;
 hipError_t launch_ppo_update_small(int kind, const SmallUpdateArgs& a, hipStream_t s);
-hipError_t launch_epoch_index(int64_t N, uint64_t key, int bits, int64_t* out, hipStream_t s);
+hipError_t launch_epoch_index(int64_t N, uint64_t key, int bits, int32_t* out, hipStream_t s);   // N < 2^31
 
 struct ReduceArgs {
     const float* slabs_actor; const float* slabs_critic; int slab_a, slab_c, G, Gc;   // G actor slabs, Gc critic slabs

@@ -1008,7 +1008,7 @@ __global__ void adv_moments_kernel(MomentsArgs a) {
     double s = 0, q = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.count; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = a.pos0 + i;
-        const int64_t idx = a.perm ? a.perm[p] : (a.perm_bits ? perm_index(p, a.N, a.perm_key, a.perm_bits) : p);
+        const int64_t idx = a.perm32 ? (int64_t)a.perm32[p] : a.perm ? a.perm[p] : (a.perm_bits ? perm_index(p, a.N, a.perm_key, a.perm_bits) : p);
         const int64_t li = idx - a.idx_lo;                    // this rank's shard of the buffer
         if (li >= 0 && li < a.n_local) { const double x = a.adv[li]; s += x; q += x * x; }
     }
@@ -1544,11 +1544,12 @@ hipError_t launch_ppo_grad(int kind, int hidden, const GradArgs& a, hipStream_t 
 }
 
 // the DataLoader order of one epoch written out once: position -> buffer index (perm_index evaluated N times here instead of once per lane, wave, net and tile inside the
-// update kernels, where it costs ~35 VALU of an issue-bound loop; 8 bytes per sample, read back coalesced)
-__global__ void epoch_index_kernel(int64_t N, uint64_t key, int bits, int64_t* __restrict__ out) {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) out[p] = perm_index(p, N, key, bits);
+// update kernels, where it costs ~35 VALU of an issue-bound loop).  The pass is bound by its WRITES (134 M x 8 bytes in 0.195 ms = 5.5 TB/s at configs[1]), so the
+// indices are 32-bit (N < 2^31, host-checked): half the bytes here and in every read-back
+__global__ void epoch_index_kernel(int64_t N, uint64_t key, int bits, int32_t* __restrict__ out) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) out[p] = (int32_t)perm_index(p, N, key, bits);
 }
-hipError_t launch_epoch_index(int64_t N, uint64_t key, int bits, int64_t* out, hipStream_t s) {
+hipError_t launch_epoch_index(int64_t N, uint64_t key, int bits, int32_t* out, hipStream_t s) {
     int blocks = (int)((N + 255) / 256); if (blocks > 8192) blocks = 8192;
     epoch_index_kernel<<<blocks, 256, 0, s>>>(N, key, bits, out);
     return hipGetLastError();
