@@ -330,14 +330,11 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
 #endif
 
     // ---- epilogue: every wave owns distinct gradient rows; the TWO pairs of a workgroup are summed into ONE slab (round 4: grad_reduce_kernel then folds half as many
-    // slabs — 512 instead of 1 024 at configs[1], 15.6 -> ~8 us per optimiser step).  The piece images are dead after the last tile: pair 1 parks its values in them as
-    // plain f32 at the slab's own offsets, a barrier, pair 0 adds its own and writes the slab (pair 0 + pair 1: a fixed order, deterministic).  Both pairs ran the same
-    // number of tiles, so every wave reaches both barriers. ----
+    // slabs — 512 instead of 1 024 at configs[1]).  Both pairs ran the same number of tiles, so every wave reaches both barriers. ----
     const int SL = HEAD == HEAD_VALUE ? a.slab_c : a.slab_a;
     const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
     const int o_ls = o_b3 + O, o_st = SL - 8;
     float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)nb * SL;
-    float* park = smem + L::PAIR0;                                                    // 2 x PAIR_SIZE floats >= SL (checked by the launcher)
     const float inv_sa = inv_sg * (1.0f / kActScale);                                  // products with an activation operand carry SG kActScale, the others SG (powers of two: exact)
     auto emit = [&](auto&& put) {
 #pragma unroll
@@ -370,13 +367,17 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (w == 0 && lane == 0) put(o_st + k, v); }
     };
+    // both pairs park at the same time (pair 0 in the first SL floats of the workgroup's LDS, pair 1 behind it: everything staged there is dead now), then all 256
+    // threads write slab[i] = pair0[i] + pair1[i] with consecutive lanes on consecutive floats — a coalesced store instead of the per-lane scatter of the round 3 epilogue
+    const int SLr = (SL + 3) & ~3;
+    float* park = smem + pr * SLr;
     __syncthreads();                                                                  // the other pair may still be reading its images
-    if (pr == 1) emit([&](int i, float v) { park[i] = v; });
+    emit([&](int i, float v) { park[i] = v; });
     __syncthreads();
-    if (pr == 0) {
-        emit([&](int i, float v) { slab[i] = v + park[i]; });
-        if (w == 0 && lane < 3) slab[o_st + 5 + lane] = 0.f;
-        for (int i = (HEAD == HEAD_GAUSSIAN ? o_ls + O : o_ls) + w * 64 + lane; i < o_st; i += 128) slab[i] = 0.f;   // padding
+    const int pad0 = HEAD == HEAD_GAUSSIAN ? o_ls + O : o_ls;
+    for (int i = tid; i < SL; i += 256) {
+        const bool pad = (i >= pad0 && i < o_st) || i >= o_st + 5;                    // slab padding and the three unused statistics slots
+        slab[i] = pad ? 0.f : smem[i] + smem[SLr + i];
     }
 }
 
@@ -399,7 +400,7 @@ template <int KIND> static size_t grad_pair_lds_bytes() {
 hipError_t launch_ppo_grad_pair(int kind, const GradArgs& a, hipStream_t s) {
     if (kind == 7) kind = 4;                  // ScalingWrapperEnv(MountainCarContinuous): the update never touches the simulator
 #define CALLP(K) { const size_t lds = grad_pair_lds_bytes<K>(); static bool attr_set = false; \
-        if (a.slab_a > 2 * PairLds<EnvSpec<K>::D, EnvSpec<K>::A>::PAIR_SIZE || a.slab_c > 2 * PairLds<EnvSpec<K>::D, 1>::PAIR_SIZE) return hipErrorInvalidValue;   /* the epilogue parks a slab in the pair images */ \
+        if (2 * ((a.slab_a + 3) & ~3) > PairLds<EnvSpec<K>::D, EnvSpec<K>::A>::END || 2 * ((a.slab_c + 3) & ~3) > PairLds<EnvSpec<K>::D, 1>::END) return hipErrorInvalidValue;   /* the epilogue parks both pairs' slabs in the workgroup's LDS */ \
         if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_pair_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
         ppo_grad_pair_kernel<K><<<(a.G + a.Gc) / 2, 256, lds, s>>>(a); }
     if (kind == 0) CALLP(0) else if (kind == 3) CALLP(3) else if (kind == 4) CALLP(4) else if (kind == 6) CALLP(6) else CALLP(1)
