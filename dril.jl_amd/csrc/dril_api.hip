@@ -233,9 +233,9 @@ int wide_variant(const dril_handle* h) { return (h->wide && h->rec && (h->grad_v
 // minibatches of at least this many 32-sample tiles per CU run ppo_grad_pair_kernel (measured on the f16 arithmetic, 256 CUs: 65 536 samples 50.7 us against 64.8 us on the
 // exact-f32 kernel, 16 384 samples 42.2 against 39.0; with the bf16 x 3 arithmetic of rounds 2 - 3 the crossover was at 16 tiles per CU)
 constexpr int kPairTilesPerCu = 8;
-bool pair_variant(const dril_handle* h) { return !h->wide && !h->generic && h->grad_variant != 0 && h->rec && h->D <= 8; }   // (D > 4, Acrobot: dW1 / db1 through a third piece image on the matrix cores — 16 (D + 1) per-lane accumulators would not fit)
+bool pair_variant(const dril_handle* h) { return !h->wide && !h->generic && h->cfg.hidden1 == 64 && h->grad_variant != 0 && h->rec && h->D <= 8; }   // (D > 4, Acrobot: dW1 / db1 through a third piece image on the matrix cores — 16 (D + 1) per-lane accumulators would not fit)
 // the forward of the fused rollout / policy kernels: f16 two-piece W2 while every W2 entry is inside f16's range, else (or with DRIL_GRAD_VARIANT=0: "exact f32 everywhere") the f32-MFMA instantiations
-bool fwd_exact(const dril_handle* h) { return h->grad_variant == 0 || !(h->w2max < kFwdSplitMaxW); }
+bool fwd_exact(const dril_handle* h) { return h->grad_variant == 0 || h->cfg.hidden1 == 32 || !(h->w2max < kFwdSplitMaxW); }   // (hidden 32 has no f16-piece instantiation)
 constexpr int kRetryLatchAfter = 2, kRetryLatchUpdates = 16;
 int ensure_wimg(dril_handle* h) {
     if (!h->wide || !h->wimg_dirty) return DRIL_OK;
@@ -507,7 +507,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     for (int l = 0; l < nh; ++l) if (hd[l] < 1 || hd[l] > 1024) return fail(nullptr, DRIL_ERR_INVALID_ARG, "hidden widths must be 1..1024");
     if (ext && (cfg->norm_obs || cfg->norm_reward || cfg->monitor_window)) return fail(nullptr, DRIL_ERR_UNSUPPORTED, "DRIL_ENV_EXTERNAL: NormalizeWrapperEnv / MonitorWrapperEnv wrap the host env on the host");
     if (cfg->n_envs < 1 || cfg->n_steps < 1 || cfg->epochs < 0 || cfg->batch_size < 1) return fail(nullptr, DRIL_ERR_INVALID_ARG, "n_envs/n_steps/batch_size must be positive");
-    const bool fused_shape = nh == 2 && cfg->activation == 0 && hd[0] == hd[1] && (hd[0] == 64 || hd[0] == 128 || hd[0] == 256);   // everything else: the generic kernels (any depth <= 4, any width <= 1024, tanh / relu)
+    const bool fused_shape = nh == 2 && cfg->activation == 0 && hd[0] == hd[1] && (hd[0] == 32 || hd[0] == 64 || hd[0] == 128 || hd[0] == 256);   // 32: the reference's benchmark-suite shape (f32-MFMA kernels only)   // everything else: the generic kernels (any depth <= 4, any width <= 1024, tanh / relu)
     if (cfg->monitor_window < 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "monitor_window must be >= 0");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, DRIL_ERR_INVALID_ARG, "bad rank/world_size");
     if (cfg->batch_size % cfg->world_size != 0) return fail(nullptr, DRIL_ERR_INVALID_ARG, "batch_size must be divisible by world_size");
@@ -1066,7 +1066,7 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
     int64_t step = 0;
     // the reference's default PPO() (batch_size = 64) on hidden [64,64]: every optimiser step of the iteration inside ONE launch of two persistent workgroups, one per net (dril_update_small.hip);
     // single-rank only (a data-parallel run all-reduces between the gradient and the step)
-    const bool persistent = !h->wide && !h->generic && h->D <= 8 && world == 1 && !(comm_ready(h) && h->force_allreduce) && h->rec && B >= 2 && B <= 64 && h->P <= 2 * 256 * 19 &&
+    const bool persistent = !h->wide && !h->generic && h->cfg.hidden1 == 64 && h->D <= 8 && world == 1 && !(comm_ready(h) && h->force_allreduce) && h->rec && B >= 2 && B <= 64 && h->P <= 2 * 256 * 19 &&
                             !h->no_persistent && !h->no_small_path && h->grad_variant < 0 && total_steps > 0;   // (DRIL_GRAD_VARIANT pins one of the per-step kernels)
     if (persistent) {
         if (h->cfg.epochs > h->epoch_keys_cap) {

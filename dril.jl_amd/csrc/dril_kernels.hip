@@ -1340,7 +1340,7 @@ template <int KIND, int H, bool WIDE, bool SPLIT> static size_t fwd_lds_bytes() 
 
 // every kernel below is built for hidden widths 64 (one wave per net), 128 and 256 (wide path)
 #define DRIL_DISPATCH_H(K, hidden, CALL)                                             \
-    { if ((hidden) == 64) { CALL(K, 64); } else if ((hidden) == 128) { CALL(K, 128); } else if ((hidden) == 256) { CALL(K, 256); } else return hipErrorInvalidValue; }
+    { if ((hidden) == 64) { CALL(K, 64); } else if ((hidden) == 128) { CALL(K, 128); } else if ((hidden) == 256) { CALL(K, 256); } else if ((hidden) == 32) { CALL(K, 32); } else return hipErrorInvalidValue; }
 #define DRIL_DISPATCH_FWD(kind, hidden, CALL)                                        \
     do {                                                                             \
         if ((kind) == 0) DRIL_DISPATCH_H(0, hidden, CALL)                            \
@@ -1469,7 +1469,8 @@ hipError_t launch_policy(int kind, int hidden, const PolicyArgs& a, int max_bloc
             if (e != hipSuccess) return e; attr_set = true; }                                                 \
         policy_kernel<K, HH, (HH > 64), SP><<<blocks, 256, lds, s>>>(a);                                      \
     }
-#define CALL(K, HH) { if (a.exact_f32) CALLS(K, HH, false) else CALLS(K, HH, true) }
+// (hidden 32 — the reference's benchmark-suite shape — exists on the f32-MFMA forward only: the f16-piece images are laid out for 64-wide layers)
+#define CALL(K, HH) { if constexpr (HH == 32) { CALLS(K, HH, false) } else { if (a.exact_f32) CALLS(K, HH, false) else CALLS(K, HH, true) } }
     DRIL_DISPATCH_FWD(kind, hidden, CALL);
 #undef CALL
 #undef CALLS
@@ -1482,12 +1483,12 @@ template <int KIND, int H, bool SPLIT> static size_t duo_lds_bytes() {
 }
 hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_t s) {
     static const bool no_duo = std::getenv("DRIL_NO_ROLLOUT_DUO") != nullptr;          // A/B knob
-    if (hidden == 64 && a.E <= 16384 && !no_duo && ((kind >= 0 && kind <= 4) || kind == 6 || kind == 7)) {                                      // env counts that leave SIMDs idle: two waves per tile of 32 envs
+    if ((hidden == 64 || hidden == 32) && a.E <= 16384 && !no_duo && ((kind >= 0 && kind <= 4) || kind == 6 || kind == 7)) {                                      // env counts that leave SIMDs idle: two waves per tile of 32 envs
         const int blocks = (a.E + kTile - 1) / kTile;
-#define CALLDS(K, SP) { const size_t lds = duo_lds_bytes<K, 64, SP>(); static bool attr_set = false; \
-            if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)rollout_duo_kernel<K, 64, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
-            rollout_duo_kernel<K, 64, SP><<<blocks, 128, lds, s>>>(a); }
-#define CALLD(K) { if (a.exact_f32) CALLDS(K, false) else CALLDS(K, true) }
+#define CALLDS(K, HH, SP) { const size_t lds = duo_lds_bytes<K, HH, SP>(); static bool attr_set = false; \
+            if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)rollout_duo_kernel<K, HH, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
+            rollout_duo_kernel<K, HH, SP><<<blocks, 128, lds, s>>>(a); }
+#define CALLD(K) { if (hidden == 32) CALLDS(K, 32, false) else if (a.exact_f32) CALLDS(K, 64, false) else CALLDS(K, 64, true) }
         if (kind == 0) CALLD(0) else if (kind == 1) CALLD(1) else if (kind == 2) CALLD(2) else if (kind == 3) CALLD(3) else if (kind == 6) CALLD(6) else if (kind == 7) CALLD(7) else CALLD(4)
 #undef CALLD
 #undef CALLDS
@@ -1502,7 +1503,7 @@ hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_
             if (e != hipSuccess) return e; attr_set = true; }                                                 \
         rollout_kernel<K, HH, (HH > 64), SP><<<blocks, 256, lds, s>>>(a);                                     \
     }
-#define CALL(K, HH) { if (a.exact_f32) CALLS(K, HH, false) else CALLS(K, HH, true) }
+#define CALL(K, HH) { if constexpr (HH == 32) { CALLS(K, HH, false) } else { if (a.exact_f32) CALLS(K, HH, false) else CALLS(K, HH, true) } }
     DRIL_DISPATCH_ENV(kind, hidden, CALL);
 #undef CALL
 #undef CALLS
