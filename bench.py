@@ -35,7 +35,7 @@ def flop_fwd(D: int, H: int, A: int) -> int:
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense
 # an fp32-equivalent contraction on the 16-bit matrix cores spends several MFMAs per product: SIX bf16 ones with three-piece operands (the generic contractions; the fused
-# kernels until the end of round 3), THREE f16 ones with two-piece operands (the fused kernels since; DESIGN.md section 5) — the kernel's own ceiling in delivered f32 flops
+# kernels until the end of round 3), THREE f16 ones with two-piece operands (the fused kernels since; DESIGN.md section 6) — the kernel's own ceiling in delivered f32 flops
 # is the dense 16-bit peak (the same for f16 and bf16) over that count
 PEAK_BF16_SPLIT6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6
 # HBM traffic (PMC) + rocprofv3 average of the dominant kernel, replayed from the committed profile of exactly that workload (each file names the commit it was taken at)
@@ -52,7 +52,7 @@ def hbm_kernels(prof: dict, *, N: int, D: int, A: int, discrete: bool, P: int, e
         ("rollout_kernel", 4 * D + act + 4 + 4 + 4 + 2, N, "buffer WRITE per env-step: obs 4D + action + reward + logprob + value + flags (the kernel is bound by its two MLP forwards, not by this)"),
         ("gae_kernel", 18, N, "read r, V, flags (+ V of the next row from cache) 10 B, write A, R 8 B"),
         ("pack_records_kernel", 32 + 16 * recq, N, f"read obs 4D + action + adv + logp + ret, write {recq} float4 per sample"),
-        ("adv_moments_kernel", 12 * epochs, N, "per epoch: epoch_index_kernel writes 8 B per sample (the DataLoader order), epoch_moments_kernel gathers 4 B per sample"),
+        ("adv_moments_kernel", 8 * epochs, N, "per epoch: epoch_index_kernel writes 4 B per sample (the DataLoader order as int32), epoch_moments_kernel reads 4 B per sample"),
         ("explained_var_kernel", 8, N, "read V, R"),
         ("adam_kernel", 28, P, "per launch: read g, p, m, v, write p, m, v (a few hundred KB: launch-latency-bound, not bandwidth-bound)"),
     ]

@@ -134,7 +134,7 @@ struct dril_handle {
     bool used_f16 = false, spin_timeout = false; int f32_streak = 0, f32_latch_left = 0; int64_t f32_direct_updates = 0, persistent_fallbacks = 0;
     unsigned long long* gae_carry = nullptr; unsigned gae_tag = 0; int* gae_err = nullptr;   // gae_scan_kernel: the chunk-to-chunk carry words, the launch tag that validates them, its give-up flag
     unsigned* w2max_dev = nullptr; float w2max = 0.f;   // max |W2| over both nets (fused kernels): host copy refreshed by dril_set_params and with every optimiser run's statistics
-    bool no_small_path = false, no_epoch_moments = false;   // DRIL_NO_SMALL_PATH / DRIL_NO_EPOCH_MOMENTS, latched in dril_create
+    bool no_small_path = false;   // DRIL_NO_SMALL_PATH (with DRIL_DEBUG=1), latched in dril_create
     bool no_persistent = false; unsigned long long* small_xchg = nullptr; uint64_t* epoch_keys = nullptr; int epoch_keys_cap = 0; int64_t small_chunk = 16384;   // ppo_update_small_kernel (batch_size <= 64): DRIL_NO_PERSISTENT_UPDATE; per-epoch DataLoader keys on the device
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
     double prof_ms[DRIL_K_COUNT] = {0}; int64_t prof_n[DRIL_K_COUNT] = {0};
@@ -539,10 +539,9 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (const char* e = std::getenv("DRIL_GRAD_ACTOR_PERMILLE")) { h->grad_actor_pct = std::atoi(e); if (h->grad_actor_pct < 100 || h->grad_actor_pct > 900) h->grad_actor_pct = 0; }
     if (const char* e = std::getenv("DRIL_GRAD_VARIANT")) { h->grad_variant = std::atoi(e); if (h->grad_variant < -1 || h->grad_variant > 2) h->grad_variant = -1; if (h->grad_variant == 2) h->grad_variant = 1; }
     h->no_persistent = std::getenv("DRIL_NO_PERSISTENT_UPDATE") != nullptr; { const char* e = std::getenv("DRIL_NO_EPOCH_INDEX"); h->no_epoch_index = e && std::atoi(e) != 0; }
-    if (const char* e = std::getenv("DRIL_SMALL_CHUNK")) { const long c = std::atol(e); if (c > 0) h->small_chunk = c; }   // optimiser steps per launch of ppo_update_small_kernel (tests: launch boundaries)
-    h->no_small_path = std::getenv("DRIL_NO_SMALL_PATH") != nullptr; h->no_epoch_moments = std::getenv("DRIL_NO_EPOCH_MOMENTS") != nullptr;
+    if (const char* e = debug_env("DRIL_SMALL_CHUNK")) { const long c = std::atol(e); if (c > 0) h->small_chunk = c; }   // optimiser steps per launch of ppo_update_small_kernel (tests: launch boundaries)
+    h->no_small_path = debug_env("DRIL_NO_SMALL_PATH") != nullptr;
     h->no_f32_retry = std::getenv("DRIL_NO_F32_RETRY") != nullptr;
-    if (const char* e = std::getenv("DRIL_MOMENT_BLOCKS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8192) h->epoch_blocks = v; }
     // Multi-process RCCL on this platform needs dmabuf IPC: with the legacy IPC mode (the ROCr default) `hipIpcGetMemHandle` fails with "invalid argument" on a
     // host driver that only supports dmabuf, and ncclCommInitRank / the first collective across processes dies with it.  The ROCr runtime reads the variable
     // when it initialises, i.e. at this process's first HIP call — which for a DRiL user is normally the hipSetDevice below.  It is only set if the caller left it
@@ -564,8 +563,8 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     else { h->slab_a = slab_size_actor(cfg->env_kind, hd[0]); h->slab_c = slab_size_critic(cfg->env_kind, hd[0]); }
     h->wide = !h->generic && hd[0] > 64;
     h->Gmax = (h->wide && hd[0] > 128) ? (h->num_cus / 2 > 0 ? h->num_cus / 2 : 1) : (!h->wide && h->grad_variant != 0) ? 3 * h->num_cus : h->num_cus;   // H = 128: 4 waves and 77 KB LDS per workgroup, two workgroups per CU   // [64,64]: 2 workgroups per CU (actor + critic), 4 waves each; wide: 1 workgroup of H/32 waves per CU
-    if (h->generic) { h->Gmax = std::getenv("DRIL_EXT_GMAX") ? std::atoi(std::getenv("DRIL_EXT_GMAX")) : 64; if (h->Gmax < 1) h->Gmax = 1; }                                                        // generic path: one slab per row chunk of the minibatch
-    if (const char* e = std::getenv("DRIL_GRAD_GMAX")) { const int g = std::atoi(e); if (g > 0 && g < h->Gmax) h->Gmax = g; }   // diagnostic: fewer workgroups per net
+    if (h->generic) h->Gmax = 64;                                                                                                                                                                                             // generic path: one slab per row chunk of the minibatch
+    if (const char* e = debug_env("DRIL_GRAD_GMAX")) { const int g = std::atoi(e); if (g > 0 && g < h->Gmax) h->Gmax = g; }   // diagnostic: fewer workgroups per net
     if (h->wide) { const size_t pb = (size_t)hd[0] * hd[0] * 6;    // three bf16 pieces per element
         CCHK(hipMalloc(&h->w2p_actor, pb)); CCHK(hipMalloc(&h->w2tp_actor, pb)); CCHK(hipMalloc(&h->w2p_critic, pb)); CCHK(hipMalloc(&h->w2tp_critic, pb));
         CCHK(hipMalloc(&h->w2pf_actor, pb)); CCHK(hipMalloc(&h->w2pf_critic, pb)); }
@@ -576,7 +575,7 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     CCHK(dmalloc(&h->obs, N * h->D)); CCHK(hipMalloc(&h->act, N * act_bytes_per(h))); CCHK(dmalloc(&h->rew, N)); CCHK(dmalloc(&h->adv, N));
     CCHK(dmalloc(&h->ret, N)); CCHK(dmalloc(&h->logp, N)); CCHK(dmalloc(&h->val, N)); CCHK(dmalloc(&h->boot, N)); CCHK(dmalloc(&h->flags, N));
     CCHK(dmalloc(&h->last_values, E));
-    if (!h->generic && !std::getenv("DRIL_NO_RECORDS")) CCHK(dmalloc(&h->rec, (size_t)(h->D <= 4 ? 2 : 3) * N));   // packed minibatch records: 2 (D <= 4) or 3 (D <= 8) float4 per sample
+    if (!h->generic) CCHK(dmalloc(&h->rec, (size_t)(h->D <= 4 ? 2 : 3) * N));   // packed minibatch records: 2 (D <= 4) or 3 (D <= 8) float4 per sample
     if (h->generic) CCHK(dmalloc(&h->gen_tmp, E));
     if (ext) { CCHK(hipHostMalloc((void**)&h->ext_stage_rew, N * 4)); CCHK(hipHostMalloc((void**)&h->ext_stage_flags, N)); }
     if (cfg->monitor_window > 0) {
@@ -1115,7 +1114,7 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
     for (int ep = 0; ep < h->cfg.epochs && !persistent; ++ep) {
         const uint64_t key = perm_key(h->cfg.seed + (uint64_t)h->cfg.rank, h->update_counter, ep);
         const int64_t* perm = h->perm_count ? h->perm_dev + (size_t)ep * N : nullptr;
-        const bool epoch_moments = h->cfg.normalize_advantage && !perm && nb >= 2 && nb <= 2048 && !h->no_epoch_moments;
+        const bool epoch_moments = h->cfg.normalize_advantage && !perm && nb >= 2 && nb <= 2048;
         // chip-filling minibatches of the fused kernels: the epoch's order as an index array (the update kernels then read 8 bytes per sample instead of evaluating the
         // keyed bijection per lane, wave, net and tile)
         const bool index_array = !perm && !h->generic && !h->no_epoch_index && N < (1ll << 31) && (B + kTile - 1) / kTile >= kPairTilesPerCu * (int64_t)h->num_cus;

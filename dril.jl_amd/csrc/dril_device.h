@@ -4,7 +4,7 @@
 //   * env physics (Gymnasium CartPole-v1 / Pendulum-v1 — SURVEY.md §8c item 3)
 //   * the wave-level MLP tile: exact-f32 MFMA (v_mfma_f32_32x32x2_f32) with weights staged in LDS
 //
-// MLP tile geometry.  One wave owns a tile of 32 samples.  Activations live in
+// MLP tile geometry (docs/kernels/ppo_kernels.md).  One wave owns a tile of 32 samples.  Activations live in
 // MFMA C/D layout: f32x16 X[H/32]; element (mt, r, lane) is X[row = 32*mt + rowfn(r, lane>>5)][col = lane&31]
 // with rows = hidden units and cols = samples.  A layer Y = W * X takes X straight from the accumulator
 // registers as the B operand (k-step (mi, r): lanes 0-31 contribute hidden row rowfn(r,0), lanes 32-63
@@ -14,7 +14,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 namespace dril {
+
+// Diagnostic / experiment switches (ablation bits, grid caps, the older form of a kernel for an A/B) are honoured only when DRIL_DEBUG=1 is set as well: a stray variable
+// cannot change what a production run executes.  The documented switches (DRIL_GRAD_VARIANT, DRIL_NO_F32_RETRY, DRIL_NO_PERSISTENT_UPDATE, DRIL_FORCE_*, DRIL_NO_EPOCH_INDEX,
+// DRIL_SAC_NO_FUSED_*, DRIL_SMALL_DEBUG_SOLO, DRIL_GRAD_ACTOR_PERMILLE) are read directly; DESIGN.md section 9 lists both groups.
+inline const char* debug_env(const char* name) {
+    static const bool on = [] { const char* e = std::getenv("DRIL_DEBUG"); return e && std::atoi(e) != 0; }();
+    return on ? std::getenv(name) : nullptr;
+}
+
+
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

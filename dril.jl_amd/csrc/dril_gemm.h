@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 namespace dril {
 
 // C[z](M x N) = epi(alpha * A[z](M x K) . B[z](K x N) + bias[z](M)), every operand addressed by element strides

@@ -1,5 +1,5 @@
 // dril_gemm.hip — generic strided fp32 contraction on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate); see dril_gemm.h.
-// Written for the SAC update (~25 small dense contractions per gradient step) and reused by the generic on-policy path.
+// Written for the SAC update (docs/sac.md: ~25 small dense contractions per gradient step) and reused by the generic on-policy path.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -72,7 +72,7 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, float
 // one 32 x 32 output tile out of the LDS transposition buffer: lane -> 16 elements (row ml = lane & 31 fixed, 16 columns), stores along C's unit-stride axis.
 // Two phases on purpose: ALL bias / aux operand loads of the 16 elements are issued before the first store.  Interleaved (load, compute, store per element)
 // the compiler may not move element i+1's loads above element i's store, and every element then waits a full memory round trip: measured, that — not the
-// contraction — set the 190 us of a 512 x 32768 x 512 reverse-pass contraction in every blocking and on both MFMA types
+// contraction — set the 190 us of a 512 x 32768 x 512 reverse-pass contraction in every blocking and on both MFMA types (docs/external_envs.md)
 template <class F>
 __device__ __forceinline__ void store_tile(const GemmArgs& g, float* __restrict__ C, const float* __restrict__ bias, const float* __restrict__ aux,
                                            int m_base, int n_base, int lane, F&& value) {
@@ -559,9 +559,9 @@ bool gemm_prepare(GemmArgs& g) {
     // the LDS-staged split-K shape: access pattern per operand (rows = m for A, n for B)
     g.ldsA = g.vecA ? 0 : (g.sAm == 1 && g.sAk % 4 == 0 && aligned16(g.A) && g.zA % 4 == 0) ? 1 : 2;
     g.ldsB = g.vecB ? 0 : (g.sBn == 1 && g.sBk % 4 == 0 && aligned16(g.B) && g.zB % 4 == 0) ? 1 : 2;
-    static const bool no_lds = std::getenv("DRIL_GEMM_NO_LDS") != nullptr;                                 // A/B knob: the direct-load split-K body for every contraction
+    static const bool no_lds = debug_env("DRIL_GEMM_NO_LDS") != nullptr;                                // A/B knob: the direct-load split-K body for every contraction
     g.use_lds = (g.K >= kLdsMinK && g.ldsA < 2 && g.ldsB < 2 && !no_lds) ? 1 : 0;
-    static const int dbg_bits = std::getenv("DRIL_GEMM_DBG") ? std::atoi(std::getenv("DRIL_GEMM_DBG")) : 0; g.dbg = dbg_bits;   // diagnostic ablations (results wrong on purpose)
+    static const int dbg_bits = debug_env("DRIL_GEMM_DBG") ? std::atoi(debug_env("DRIL_GEMM_DBG")) : 0; g.dbg = dbg_bits;   // diagnostic ablations (results wrong on purpose)
     return g.M > 0 && g.N > 0 && g.K > 0;
 }
 
@@ -606,14 +606,13 @@ hipError_t launch_gemm(GemmArgs g, int Z, hipStream_t s) {
     if (!gemm_prepare(g)) return hipErrorInvalidValue;
     const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
     if ((tn + kGemmWaves - 1) / kGemmWaves > 65535 || Z > 65535) return hipErrorInvalidValue;
-    static const long long many_tiles = std::getenv("DRIL_GEMM_MANY") ? std::atoll(std::getenv("DRIL_GEMM_MANY")) : 2048;   // A/B knob: tile count from which the LDS-tiled throughput shapes take over from split-K
+    constexpr long long many_tiles = 2048;                                                                 // tile count from which the LDS-tiled throughput shapes take over from split-K (measured both ways at 2 048 tiles: 31 vs 43 us)
     const bool many = (long long)tm * tn * Z >= many_tiles && g.K >= kBigKc;
     const bool a_m = g.sAm == 1, a_k = !a_m && g.sAk == 1;                                             // A m-contiguous / k-contiguous
     const bool b_k = g.sBk == 1 && g.vecB && !g.ones_n, b_n = !b_k && g.sBn == 1 && g.sBk != 1;        // B k-contiguous (float4 rows) / n-contiguous
     const dim3 bgrid(tm, (tn + kGemmWaves - 1) / kGemmWaves, Z), bblock(64 * kGemmWaves);
-    static const bool f32_only = std::getenv("DRIL_GEMM_F32") != nullptr;                                // A/B knob: keep the large contractions on v_mfma_f32_32x32x2_f32
-    static const bool split_all = std::getenv("DRIL_GEMM_SPLIT") != nullptr;                              // A/B knob: also for callers that did not ask (SAC)
-    const bool split = many && !f32_only && (g.allow_split || split_all) && g.K >= 64;
+    static const bool split_all = debug_env("DRIL_GEMM_SPLIT") != nullptr;                                // A/B: also for callers that did not ask (SAC)
+    const bool split = many && (g.allow_split || split_all) && g.K >= 64;
     if (split && (a_m || a_k) && (b_k || b_n)) {
         // output rows per workgroup: 64 (two m-tiles per wave) when that still leaves >= 2 workgroups per CU, else 32 (a 4096-row collection forward has 256
         // blocks of 32 x 256: it stays at MB = 1).  Taller blocks were built and measured (MB = 4, and full-height 256 / 512-row blocks that stage every
@@ -623,7 +622,7 @@ hipError_t launch_gemm(GemmArgs g, int Z, hipStream_t s) {
         // inside one workgroup (staging of chunk i + 1 interleaved with the MFMAs of chunk i, loads two chunks ahead; built, parity-green) was slower still (55):
         // the split form reads 0.75 ds_read_b128 per MFMA (9 reads per 12 MFMAs of 32 cycles), ~2000 LDS cycles per chunk against 1536 MFMA cycles per SIMD —
         // the kernel is LDS-read-bound, and the next step is 2 x 2 register tiling per wave (0.5 reads per MFMA), not more overlap.
-        static const int mb_cap = std::getenv("DRIL_GEMM_MB") ? std::atoi(std::getenv("DRIL_GEMM_MB")) : 2;   // A/B knob (1, 2, 4 are built)
+        constexpr int mb_cap = 2;                                                                           // (1, 2, 4 are built; 4 measured slower, comment above)
         int MB = 1;
         const long long tn256 = (g.N + 255) / 256;
         for (int cand = 4; cand > 1; cand >>= 1) if (cand <= mb_cap && g.M >= 32 * cand && (long long)((g.M + 32 * cand - 1) / (32 * cand)) * tn256 * Z >= 512) { MB = cand; break; }

@@ -1482,7 +1482,7 @@ template <int KIND, int H, bool SPLIT> static size_t duo_lds_bytes() {
     return sizeof(float) * (FwdLds<D, H, A, false, SPLIT>::SIZE + FwdLds<D, H, 1, false, SPLIT>::SIZE + 2 * (2 * D + 1) * 32);
 }
 hipError_t launch_rollout(int kind, int hidden, const RolloutArgs& a, hipStream_t s) {
-    static const bool no_duo = std::getenv("DRIL_NO_ROLLOUT_DUO") != nullptr;          // A/B knob
+    static const bool no_duo = debug_env("DRIL_NO_ROLLOUT_DUO") != nullptr;             // A/B (DRIL_DEBUG=1)
     if ((hidden == 64 || hidden == 32) && a.E <= 16384 && !no_duo && ((kind >= 0 && kind <= 4) || kind == 6 || kind == 7)) {                                      // env counts that leave SIMDs idle: two waves per tile of 32 envs
         const int blocks = (a.E + kTile - 1) / kTile;
 #define CALLDS(K, HH, SP) { const size_t lds = duo_lds_bytes<K, HH, SP>(); static bool attr_set = false; \

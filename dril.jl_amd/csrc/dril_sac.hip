@@ -4,7 +4,7 @@
 // src/buffers/off_policy_collection.jl, src/DRiLDistributions/squashedDiagGaussian.jl.  BASELINE.json configs[4]:
 // Pendulum-v1, 4096 device envs, SACLayer [512,512] relu, batch 256.
 //
-// Shape of the work: one gradient step is ~25 small dense contractions (256 samples x 512 x 512) separated by
+// Shape of the work (docs/sac.md): one gradient step is ~25 small dense contractions (256 samples x 512 x 512) separated by
 // per-sample head math, all on one stream with no host round trip; one env step of the collection is the actor forward over
 // 4096 envs + the env kernels of the on-policy path + a ring write.  The contractions are fp32 MFMA (v_mfma_f32_32x32x2_f32:
 // exact fp32 products, fp32 accumulate) in ONE generic strided kernel: a workgroup owns one 32x32 output tile and its four
@@ -1265,7 +1265,7 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     h->adam_blocks_c = std::min(kSacAdamBlocks, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(kSacAdamBlocks, ((h->actor.end + 3) / 4 + 2 * h->Pqd / 4 + 255) / 256);   // elementwise optimiser kernels: up to 1 024 blocks (no grid-wide fold is left in them; 256 -> 1 024: update! 0.174 -> 0.168 ms)
     CHK(smalloc(&h->counter, 1));
     CHK(smalloc(&h->head_partials, (size_t)(2 * kMaxA + 8) * ((B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock + 1))); CHK(smalloc(&h->head_counter, kMaxA + 1));   // doubles: [critic 2 | actor 2 | log_std kMaxA | entropy 2] x blocks
-    h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr; h->fused_collect = std::getenv("DRIL_SAC_NO_FUSED_COLLECT") == nullptr; h->fused_fwd = std::getenv("DRIL_SAC_NO_FUSED_FWD") == nullptr; h->trace_enqueue = std::getenv("DRIL_SAC_TRACE_ENQUEUE") != nullptr;   // latched here: no getenv on the update path
+    h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr; h->fused_collect = std::getenv("DRIL_SAC_NO_FUSED_COLLECT") == nullptr; h->fused_fwd = std::getenv("DRIL_SAC_NO_FUSED_FWD") == nullptr; h->trace_enqueue = false;   // latched here: no getenv on the update path
     CHK(smalloc(&h->state, (size_t)E * S)); CHK(smalloc(&h->step_count, E)); CHK(smalloc(&h->episode, E)); CHK(smalloc(&h->gstep, E)); CHK(smalloc(&h->disc_returns, E));
     CHK(smalloc(&h->obs_cur, (size_t)E * D)); CHK(smalloc(&h->obs_nxt, (size_t)E * D)); CHK(smalloc(&h->e_rew, E)); CHK(smalloc(&h->e_tobs, (size_t)E * D));
     CHK(smalloc(&h->e_raw, (size_t)E * A)); CHK(smalloc(&h->e_envact, (size_t)E * A)); CHK(smalloc(&h->e_term, E)); CHK(smalloc(&h->e_trunc, E));

@@ -7,7 +7,7 @@
 //
 //   workgroup = 4 waves = two PAIRS of waves, pair p owns samples 32p .. 32p+31 of the minibatch; a pair runs the tile code of ppo_grad_pair_kernel (wave w = m-tile w
 //   of every layer; bf16 matrix cores, fp32-equivalent 3-piece operand split, dril_device.h).  One wave per SIMD (round 3, first form: both nets in ONE workgroup of
-//   eight waves, 12 us per step — two waves per SIMD on one CU; two CUs: see DESIGN.md section 5).
+//   eight waves, 12 us per step — two waves per SIMD on one CU; two CUs: see docs/kernels/ppo_update_small_kernel.md).
 //   per step:  gather (prefetched one step ahead)  ->  L1, h1 pieces | B | L2, output partials | B | loss head, dz2 pieces | B | dh1, dW1, dW2 | B |
 //              the pair's gradient slab into its own (now dead) image area | B | all 256 threads: g = slab0 + slab1, partial |g|^2 | B | message out, message in | B |
 //              norm, KL / NaN flags, Adam on the registers, new weight images.

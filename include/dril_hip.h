@@ -354,7 +354,7 @@ const char* dril_kernel_name(int32_t kernel_id);
 int32_t dril_kernel_count(void);   /* DRIL_K_COUNT of the loaded library */
 /* which gradient kernel the handle's LAST optimiser step ran and the arithmetic it computes in ("<kernel>: <arithmetic>"; "none yet" before the
  * first step): hidden [64,64] runs ppo_grad_pair_kernel (f16 matrix cores, fp32-equivalent two-piece operand split) on large minibatches and the f32-MFMA
- * ppo_grad_kernel on small ones, [128,128] and [256,256] ppo_grad_wide_split_kernel, everything else the generic path (DESIGN.md section 5;
+ * ppo_grad_kernel on small ones, [128,128] and [256,256] ppo_grad_wide_split_kernel, everything else the generic path (docs/kernels/ppo_kernels.md;
  * DRIL_GRAD_VARIANT overrides the choice) */
 const char* dril_grad_kernel_info(const dril_handle* h);
 const char* dril_version(void);

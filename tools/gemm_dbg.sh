@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 for d in 0 1 2 4 8 15; do
-  export DRIL_GEMM_DBG=$d GENERIC_SHAPE=${GENERIC_SHAPE:-64,18,1,512,512}
+  export DRIL_DEBUG=1 DRIL_GEMM_DBG=$d GENERIC_SHAPE=${GENERIC_SHAPE:-64,18,1,512,512}
   rm -rf $R/gpurun_out/prof_dbg; rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dbg -- python3 $R/tools/generic_update.py > /dev/null 2>&1
   f=$(find $R/gpurun_out/prof_dbg -name "*kernel_stats.csv" | head -1)
   echo "DBG=$d"; python3 -c "
