@@ -21,8 +21,8 @@ namespace dril {
 // cannot change what a production run executes.  The documented switches (DRIL_GRAD_VARIANT, DRIL_NO_F32_RETRY, DRIL_NO_PERSISTENT_UPDATE, DRIL_FORCE_*, DRIL_NO_EPOCH_INDEX,
 // DRIL_SAC_NO_FUSED_*, DRIL_SMALL_DEBUG_SOLO, DRIL_GRAD_ACTOR_PERMILLE) are read directly; DESIGN.md section 9 lists both groups.
 inline const char* debug_env(const char* name) {
-    static const bool on = [] { const char* e = std::getenv("DRIL_DEBUG"); return e && std::atoi(e) != 0; }();
-    return on ? std::getenv(name) : nullptr;
+    const char* e = std::getenv("DRIL_DEBUG");                  // read at every call (handle creation, first launch of a contraction shape): tests toggle it per handle
+    return (e && std::atoi(e) != 0) ? std::getenv(name) : nullptr;
 }
 
 

@@ -1027,7 +1027,7 @@ def test_forced_pair_kernel_on_small_minibatches(pkg, oracle_mod, monkeypatch, B
     capi = pkg._capi
     monkeypatch.setenv("DRIL_GRAD_VARIANT", "2")
     if gmax:
-        monkeypatch.setenv("DRIL_GRAD_GMAX", gmax)
+        monkeypatch.setenv("DRIL_DEBUG", "1"); monkeypatch.setenv("DRIL_GRAD_GMAX", gmax)        # (a diagnostic switch: honoured only with DRIL_DEBUG=1)
     E, T = 4, 32
     cfg = _cfg(pkg, 0, n_envs=E, n_steps=T, batch_size=B, epochs=2, episode_len=9)
     h, o = pkg.Handle(cfg), oracle_mod.Oracle(cfg)
@@ -1112,7 +1112,7 @@ def test_persistent_small_update_across_launch_boundaries(pkg, oracle_mod, monke
     flat = _params(o.P, 7, 0.3); o.set_params(flat); o.env_reset(5); o.collect_rollout()
     res = []
     for chunk in (None, "5"):
-        if chunk: monkeypatch.setenv("DRIL_SMALL_CHUNK", chunk)
+        if chunk: monkeypatch.setenv("DRIL_DEBUG", "1"); monkeypatch.setenv("DRIL_SMALL_CHUNK", chunk)
         h = pkg.Handle(cfg); h.set_params(flat)
         for which in (capi.BUF_OBSERVATIONS, capi.BUF_ACTIONS, capi.BUF_ADVANTAGES, capi.BUF_RETURNS, capi.BUF_LOGPROBS, capi.BUF_VALUES):
             h.set_buffer(which, o.buffer(which))
