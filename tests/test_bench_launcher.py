@@ -92,3 +92,20 @@ def test_under_torch_distributed_run_it_behaves_as_before():
     assert r.returncode == 0, r.stderr
     recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(recs) == 1 and recs[0]["n_gpus"] == 2 and "launcher" not in recs[0]
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_real_worker_on_a_one_gpu_box_a_missing_device_fails_the_whole_job():
+    """the REAL worker (libdril_hip.so, no stub) behind the launcher on a box with one GPU: rank 1 asks for device 1, dril_create refuses it, the rank exits non-zero;
+    the launcher ends rank 0 (which holds a handle on device 0 and waits in the rendezvous) and exits non-zero WITHOUT a result line — never a 1-GPU number under an
+    `n_gpus: 2` label.  (Two ranks on one device are not possible: RCCL refuses duplicate GPUs; tests/test_gpu_dataparallel.py covers the library's N > 1 code.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DRIL_BENCH_STUB")}
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--n-envs", "1024", "--n-steps", "32", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not r.stdout.strip(), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    assert "rank 1 exited with code" in r.stderr and "all ranks ended, no result line" in r.stderr, r.stderr[-1500:]
+    assert time.monotonic() - t0 < 300
