@@ -376,8 +376,8 @@ __global__ __launch_bounds__(256) void sac_actor_out_ent_kernel(ActorHeadFusedAr
     }
     if (threadIdx.x == 0) ssum = 0.0;
     __syncthreads();
-    if (threadIdx.x < 3) {                                                       // phase 2: the three squashed samples of the row on three threads (libm-heavy scalar math)
-        const int which = threadIdx.x;
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 192) {                          // phase 2: the three squashed samples of the row on lane 0 of three WAVES (libm-heavy scalar math: on three
+        const int which = threadIdx.x >> 6;                                       // lanes of one wave the divergent branches ran one after the other — 3 x ~1.5 us of an 11 us kernel)
         float a_[kMaxA], gg[kMaxA];
         if (which == 0) { if (g.auto_ent) ssum = (double)(squashed_sample_logp(mus[0], ls, g.ne + (size_t)i * g.A, g.A, a_, gg) + g.target_entropy); }
         else if (which == 1) {

@@ -95,6 +95,8 @@ DRiL.on_step(c::StopAtStep, locals::Dict) = DRiL.steps_taken(locals[:agent]) < c
         @test propertynames(stats) == (:entropy_losses, :policy_losses, :value_losses, :approx_kl_divs, :clip_fractions, :losses, :explained_variances, :fps, :grad_norms, :learning_rates)
         @test agent.train_state.parameters.actor_head.layer_1.weight != p0.actor_head.layer_1.weight
         @test occursin("ppo_", DRiLHIP.grad_kernel_info(env))
+        fb = DRiLHIP.f32_fallback_info(env)                                   # struct dril_f32_fallback: a healthy run on CartPole never leaves the f16-piece arithmetic
+        @test fb.retries == 0 && fb.direct_updates == 0 && fb.forward_exact_f32 == 0 && 0 < fb.max_abs_w2 < 350
     end
 
     @testset "optimiser state follows the TrainState (ppo.jl:52-53,239)" begin
