@@ -75,7 +75,8 @@ def test_layer_calls_match_oracle(pkg, hidden, act):
 
 @pytest.mark.parametrize("act,auto_ent,interval,hidden,B", [("relu", True, 1, (32, 32), 16), ("tanh", True, 2, (64, 32), 40),
                                                             ("relu", False, 1, (32, 32), 16), ("relu", True, 1, (512, 512), 256),
-                                                            ("tanh", True, 1, (40, 24), 7), ("relu", True, 1, (24, 40), 9)])      # ragged: hidden dims and batch off every 32-wide tile; H2 > H1 and H2 < H1
+                                                            ("tanh", True, 1, (40, 24), 7), ("relu", True, 1, (24, 40), 9),      # ragged: hidden dims and batch off every 32-wide tile; H2 > H1 and H2 < H1
+                                                            ("relu", True, 1, (96, 160), 100), ("tanh", True, 1, (320, 288), 200)])   # the LDS-staged split-K body (K >= 64): one ragged pass (K = 96 / 100 / 160), a full + a ragged pass (K = 320 / 288), ragged tiles in m and n
 def test_update_matches_oracle(pkg, act, auto_ent, interval, hidden, B):
     """three consecutive update! steps with injected batches: losses, both gradients, parameters, targets, log_ent_coef"""
     ent = pkg.AutoEntropyCoefficient(initial_value=0.7) if auto_ent else pkg.FixedEntropyCoefficient(0.3)
