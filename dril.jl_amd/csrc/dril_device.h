@@ -20,6 +20,9 @@ namespace dril {
 // Diagnostic / experiment switches (ablation bits, grid caps, the older form of a kernel for an A/B) are honoured only when DRIL_DEBUG=1 is set as well: a stray variable
 // cannot change what a production run executes.  The documented switches (DRIL_GRAD_VARIANT, DRIL_NO_F32_RETRY, DRIL_NO_PERSISTENT_UPDATE, DRIL_FORCE_*, DRIL_NO_EPOCH_INDEX,
 // DRIL_SAC_NO_FUSED_*, DRIL_SMALL_DEBUG_SOLO, DRIL_GRAD_ACTOR_PERMILLE) are read directly; DESIGN.md section 9 lists both groups.
+// NNlib.relu(x) = max(zero(x), x), and Julia's max PROPAGATES NaN: a NaN pre-activation must stay NaN (x > 0 ? x : 0 would turn it into 0 and hide a broken parameter
+// from the finiteness checks downstream)
+__host__ __device__ inline float relu_nan(float x) { return (x > 0.f || x != x) ? x : 0.f; }
 inline const char* debug_env(const char* name) {
     const char* e = std::getenv("DRIL_DEBUG");                  // read at every call (handle creation, first launch of a contraction shape): tests toggle it per handle
     return (e && std::atoi(e) != 0) ? std::getenv(name) : nullptr;

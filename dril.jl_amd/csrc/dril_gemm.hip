@@ -62,7 +62,7 @@ __device__ __noinline__ float gemm_epilogue_rare(int epi, float v, float y) {
 }
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, float b, float y) {
     v = v * g.alpha + b;
-    if (g.epi == EPI_RELU) v = v > 0.f ? v : 0.f;
+    if (g.epi == EPI_RELU) v = relu_nan(v);
     else if (g.epi == EPI_TANH) v = tanhf(v);
     else if (g.epi == EPI_MASK_RELU) v = y > 0.f ? v : 0.f;
     else if (g.epi == EPI_MASK_TANH) v *= 1.0f - y * y;

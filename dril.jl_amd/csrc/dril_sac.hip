@@ -116,29 +116,166 @@ __device__ __forceinline__ void first_layer_row(const float* __restrict__ W1, co
     for (int u = threadIdx.x; u < H1; u += blockDim.x) {
         float acc = b1[u];
         for (int k = 0; k < in; ++k) acc = fmaf(W1[u + (size_t)k * H1], x[k], acc);
-        h1[u] = relu ? (acc > 0.f ? acc : 0.f) : tanhf(acc);
+        h1[u] = relu ? relu_nan(acc) : tanhf(acc);
     }
 }
-// the first layer of the collection forward for a narrow input: h1[e][u] = act(W1[u, :] . x[e, :] + b1[u]), eight envs per block with the weights of a unit in
-// registers across them (a contraction with K = 3 in the generic kernel took 9.6 us for 4096 envs x 512 units; this is a store-bound elementwise pass)
-struct CollectL1Args { int E, D, H1, relu; const float* x; const float* W1; const float* b1; float* h1; };
+// =================================================================================================================
+// The collection forward (off_policy_collection.jl:55: predict_actions_raw over all envs) for a narrow observation — BASELINE configs[4]: 4096 envs, [512,512].
+// Its second layer, a 512 x 4096 x 512 contraction, is the largest kernel of a SAC iteration and the one place of the SAC path where the matrix pipe is the bound
+// (31 us on v_mfma_f32_32x32x2_f32: 12 of MFMA + a 14 us staging skeleton, docs/sac.md).  Here it runs on v_mfma_f32_32x32x16_f16 with the fp32-equivalent two-piece
+// operands of the PPO kernels (dril_device.h: x S = hi + lo, three products per k16 step, f32 accumulate: 2^-24 relative), and — unlike a split at staging time, which
+// every workgroup would repeat for the rows it stages — the operands are split ONCE, by their producers:
+//   * sac_collect_l1_kernel (first layer, elementwise) writes h1 as f32 AND as two f16 planes [n][H1] (kColActScale h1);
+//   * the same launch (extra blocks) re-cuts the actor's W2 into two f16 planes [out][in] (kColWScale W2, k-contiguous rows) whenever the actor changed;
+//   * sac_collect_l2_kernel: 64 (n) x 128 (m) output block per workgroup, 4 waves as 2 x 2 (one n-tile x two m-tiles each), 64-deep chunks of both operands'
+//     planes through a double-buffered LDS image (coalesced 16-byte loads, rows of 144 bytes: conflict-free ds_read_b128 fragment reads), ONE barrier per chunk,
+//     6 MFMAs per 6 fragment reads; D = h1 . W2' so that consecutive lanes hold consecutive output units: 128-byte runs in the store of h2 [n][H2].
+// RANGE.  f16 pieces overflow beyond 65 504 / scale: |h1| >= 4 094 (relu activations are unbounded) or |W2| >= 1 023.  The producers check every value they cut and
+// raise a tagged flag (atomicMax with the launch's tag: no clearing pass); the contraction reads the flags first and, if either is up, computes its block with f32
+// MFMAs straight from the f32 operands instead (slow, exact) — decided on the device, no host round trip, never a silently wrong action.
+// =================================================================================================================
+constexpr float kColActScale = 16.0f, kColWScale = 64.0f;
+constexpr float kF16Max = 65504.0f;
+struct CollectL1Args {
+    int E, D, H1, relu; const float* x; const float* W1; const float* b1; float* h1;
+    unsigned* h1p; int* flag; int tag;                         // h1p != null: also the two f16 planes [2][E][H1 / 2] (packed pairs); overflow -> atomicMax(flag, tag)
+    int nb_l1; const float* W2; int H2; unsigned* w2p; int* w2flag; int w2tag;   // blocks >= nb_l1 (present when the actor changed): W2 (H2 x H1, column-major) -> planes [2][H2][H1 / 2]
+};
 __global__ __launch_bounds__(256) void sac_collect_l1_kernel(CollectL1Args f) {
     __shared__ float xs[8][4];
+    if ((int)blockIdx.x >= f.nb_l1) {                                                   // ---- the actor's W2 as two f16 planes, rows of one output unit contiguous in k ----
+        const int words = f.H2 * (f.H1 / 2);                                            // one packed pair (k, k + 1) per word
+        bool bad = false;
+        for (int w = ((int)blockIdx.x - f.nb_l1) * 256 + threadIdx.x; w < words; w += ((int)gridDim.x - f.nb_l1) * 256) {
+            const int o = w % f.H2, kp = w / f.H2;                                      // consecutive threads: consecutive output units (the column-major weight's unit stride)
+            const float a = kColWScale * f.W2[o + (size_t)(2 * kp) * f.H2], b = kColWScale * f.W2[o + (size_t)(2 * kp + 1) * f.H2];
+            bad |= !(fabsf(a) < kF16Max) || !(fabsf(b) < kF16Max);
+            unsigned hi, lo; split2_pair(a, b, hi, lo);
+            f.w2p[(size_t)o * (f.H1 / 2) + kp] = hi; f.w2p[(size_t)words + (size_t)o * (f.H1 / 2) + kp] = lo;
+        }
+        if (bad) atomicMax(f.w2flag, f.w2tag);
+        return;
+    }
     const int e0 = blockIdx.x * 8;
     if (threadIdx.x < 32) { const int r = threadIdx.x >> 2, d = threadIdx.x & 3, e = e0 + r; xs[r][d] = (d < f.D && e < f.E) ? f.x[(size_t)e * f.D + d] : 0.f; }
     __syncthreads();
-    for (int u = threadIdx.x; u < f.H1; u += 256) {
-        float wv[4];
+    bool bad = false;
+    for (int u2 = threadIdx.x; u2 < f.H1 / 2; u2 += 256) {                              // a thread owns units 2 u2, 2 u2 + 1 (one packed word per plane); H1 is even (host-checked)
+        float wv[2][4], bv[2];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) wv[d] = d < f.D ? f.W1[u + (size_t)d * f.H1] : 0.f;
-        const float b = f.b1[u];
+        for (int t = 0; t < 2; ++t) {
+            bv[t] = f.b1[2 * u2 + t];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) wv[t][d] = d < f.D ? f.W1[2 * u2 + t + (size_t)d * f.H1] : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             if (e0 + r >= f.E) break;
-            float acc = b;
+            float v[2];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) acc = fmaf(wv[d], xs[r][d], acc);          // (d >= D: zero weights) — the order of first_layer_row
-            f.h1[(size_t)(e0 + r) * f.H1 + u] = f.relu ? (acc > 0.f ? acc : 0.f) : tanhf(acc);
+            for (int t = 0; t < 2; ++t) {
+                float acc = bv[t];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc = fmaf(wv[t][d], xs[r][d], acc);        // (d >= D: zero weights) — the order of first_layer_row
+                v[t] = f.relu ? relu_nan(acc) : tanhf(acc);
+            }
+            *reinterpret_cast<float2*>(f.h1 + (size_t)(e0 + r) * f.H1 + 2 * u2) = make_float2(v[0], v[1]);
+            if (f.h1p) {
+                const float a = kColActScale * v[0], b = kColActScale * v[1];
+                bad |= !(fabsf(a) < kF16Max) || !(fabsf(b) < kF16Max);
+                unsigned hi, lo; split2_pair(a, b, hi, lo);
+                f.h1p[(size_t)(e0 + r) * (f.H1 / 2) + u2] = hi; f.h1p[(size_t)f.E * (f.H1 / 2) + (size_t)(e0 + r) * (f.H1 / 2) + u2] = lo;
+            }
+        }
+    }
+    if (bad) atomicMax(f.flag, f.tag);
+}
+constexpr int kL2TN = 64, kL2TM = 128, kL2KC = 64, kL2Row = kL2KC + 8;                  // output block (n x m), chunk depth, LDS row in f16 elements (144 bytes)
+constexpr int kL2Plane = (kL2TN + kL2TM) * kL2Row;                                      // f16 elements of one plane (hi or lo) of one buffer: A rows then B rows
+constexpr size_t kL2LdsBytes = sizeof(_Float16) * 2 * 2 * kL2Plane;                     // two buffers x two planes = 110 592 B
+struct CollectL2Args {
+    int E, H1, H2, relu; const unsigned* h1p; const unsigned* w2p; const float* b2; float* h2;
+    const int* flag; int tag; const int* w2flag; int w2tag; const float* h1; const float* W2;   // out-of-range: exact-f32 path from the f32 operands
+};
+// loader of sac_collect_l2_kernel: per chunk and plane 512 sixteen-byte pieces of the activation rows (two per thread) and 1 024 of the weight rows (four per thread);
+// piece p = (row p >> 3, seg p & 7): 8 f16 of that row at k = kc + 8 seg — eight consecutive lanes read one row's 128 bytes
+__device__ __forceinline__ void l2_issue(const CollectL2Args& a, int tid, int n0, int m0, int kc, u32x4 (&la)[4], u32x4 (&lb)[8]) {
+    const int hw = a.H1 / 2;                                                           // words per row in memory
+    const size_t plane_a = (size_t)a.E * hw, plane_b = (size_t)a.H2 * hw;              // words per plane in memory
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                                      // j = 2 plane + u
+        const int p = tid + 256 * (j & 1), row = p >> 3, seg = p & 7; int gr = n0 + row; gr = gr < a.E ? gr : a.E - 1;   // rows past E re-read the last env (in bounds, never stored)
+        la[j] = *reinterpret_cast<const u32x4*>(a.h1p + (size_t)(j >> 1) * plane_a + (size_t)gr * hw + (kc >> 1) + 4 * seg);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                                                      // j = 4 plane + u
+        const int p = tid + 256 * (j & 3), row = p >> 3, seg = p & 7;
+        lb[j] = *reinterpret_cast<const u32x4*>(a.w2p + (size_t)(j >> 2) * plane_b + (size_t)(m0 + row) * hw + (kc >> 1) + 4 * seg);
+    }
+}
+__device__ __forceinline__ void l2_commit(_Float16* l2s, int tid, int buf, const u32x4 (&la)[4], const u32x4 (&lb)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int p = tid + 256 * (j & 1); *reinterpret_cast<u32x4*>(l2s + (size_t)(2 * buf + (j >> 1)) * kL2Plane + (size_t)(p >> 3) * kL2Row + 8 * (p & 7)) = la[j]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int p = tid + 256 * (j & 3); *reinterpret_cast<u32x4*>(l2s + (size_t)(2 * buf + (j >> 2)) * kL2Plane + (size_t)(kL2TN + (p >> 3)) * kL2Row + 8 * (p & 7)) = lb[j]; }
+}
+__global__ __launch_bounds__(256) void sac_collect_l2_kernel(CollectL2Args a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 l2s[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, kh = lane >> 5, wn = wave & 1, wm = wave >> 1;
+    const int n0 = blockIdx.x * kL2TN, m0 = blockIdx.y * kL2TM;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float unscale = 1.0f / (kColActScale * kColWScale);
+    if (*a.flag == a.tag || *a.w2flag == a.w2tag) {                                    // ---- out of f16's range somewhere this step: v_mfma_f32_32x32x2_f32 from the f32 operands ----
+        const int n = n0 + 32 * wn + c; const int nn = n < a.E ? n : a.E - 1;
+        for (int k0 = 0; k0 < a.H1; k0 += 8) {
+            const int k = k0 + 4 * kh;
+            const float4 av = *reinterpret_cast<const float4*>(a.h1 + (size_t)nn * a.H1 + k);          // H1 % 64 == 0 (host-checked)
+            const float af[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int m = m0 + 64 * wm + 32 * t + c;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[t] = mfma32(af[q], a.W2[m + (size_t)(k + q) * a.H2], acc[t]);
+            }
+        }
+        unscale = 1.0f;
+    } else {
+        u32x4 la[4], lb[8];
+        const int NC = a.H1 / kL2KC;
+        l2_issue(a, tid, n0, m0, 0, la, lb); l2_commit(l2s, tid, 0, la, lb);
+        __syncthreads();
+        for (int ci = 0; ci < NC; ++ci) {
+            const int buf = ci & 1;
+            if (ci + 1 < NC) l2_issue(a, tid, n0, m0, (ci + 1) * kL2KC, la, lb);         // next chunk in flight under this chunk's MFMAs (two chunks ahead, in a second
+            const _Float16* Ph = l2s + (size_t)(2 * buf) * kL2Plane; const _Float16* Pl = Ph + kL2Plane;   // register set, was measured: 18.0 vs 18.6 us — not what the kernel waits for)
+#pragma unroll
+            for (int st = 0; st < kL2KC / 16; ++st) {
+                const int ko = 16 * st + 8 * kh;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(Ph + (size_t)(32 * wn + c) * kL2Row + ko), al = *reinterpret_cast<const f16x8*>(Pl + (size_t)(32 * wn + c) * kL2Row + ko);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const size_t brow = (size_t)(kL2TN + 64 * wm + 32 * t + c) * kL2Row + ko;
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(Ph + brow), bl = *reinterpret_cast<const f16x8*>(Pl + brow);
+                    acc[t] = mfma_split3(ah, al, bh, bl, acc[t]);
+                }
+            }
+            if (ci + 1 < NC) l2_commit(l2s, tid, buf ^ 1, la, lb);                       // (every wave left that buffer at the previous barrier)
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = m0 + 64 * wm + 32 * t + c; const float b = a.b2[m];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + 32 * wn + rowfn(r, kh);
+            if (n >= a.E) continue;
+            const float v = fmaf(acc[t][r], unscale, b);
+            a.h2[(size_t)n * a.H2 + m] = a.relu ? relu_nan(v) : tanhf(v);
         }
     }
 }
@@ -810,7 +947,8 @@ struct dril_sac_handle {
     double* ssq_rows = nullptr;   // [stats_cap][adam_blocks_c + end_blocks] squared-gradient partials per update, summed on the host (grad_norm statistic)
     unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
     SacScalars* sc_next = nullptr;   // ping-pong partner of `sc` (fused heads: the entropy step writes the new state here, then the two are swapped)
-    double* head_partials = nullptr; unsigned int* head_counter = nullptr; unsigned long long* it_stamps = nullptr; int it_stamps_cap = 0; double wall_hz = 1e8; bool fused_heads = true; bool fused_collect = true; bool fused_fwd = true; bool trace_enqueue = false; std::vector<hipEvent_t> it_events; int iter_chunk = 64;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
+    double* head_partials = nullptr; unsigned int* head_counter = nullptr; unsigned* col_h1p = nullptr; unsigned* col_w2p = nullptr; int* col_flags = nullptr; int col_tag = 0, col_w2tag = 0; bool col_w2_dirty = true, f16_fwd = true;   // the f16-piece collection forward (sac_collect_l2_kernel)
+    unsigned long long* it_stamps = nullptr; int it_stamps_cap = 0; double wall_hz = 1e8; bool fused_heads = true; bool fused_collect = true; bool fused_fwd = true; bool trace_enqueue = false; std::vector<hipEvent_t> it_events; int iter_chunk = 64;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
     float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
     float target_entropy = 0, act_lo = -2.0f, act_hi = 2.0f; bool external = false;   // bounds of the agent-facing action space: Box(-2,2), Box(-1,1) under ScalingWrapperEnv
     // env
@@ -870,9 +1008,9 @@ int net_forward(dril_sac_handle* h, const float* P, NetOff off, long long zP, in
     const int H1 = h->H1, H2 = h->H2, act = h->cfg.activation ? EPI_RELU : EPI_TANH;
     GemmArgs g = gemm_args();                                                       // h1 = act(W1 x + b1)
     // a narrow input (Pendulum: 3 features) over many rows (the collection forward): an elementwise pass instead of a K = 3 contraction
-    const bool elem_l1 = !first_done && h->fused_fwd && Z == 1 && in <= 4 && ldx == in && n >= 1024;
+    const bool elem_l1 = !first_done && h->fused_fwd && Z == 1 && in <= 4 && ldx == in && n >= 1024 && H1 % 2 == 0;
     if (elem_l1) {
-        CollectL1Args l1{n, in, H1, h->cfg.activation ? 1 : 0, X, P + off.w1, P + off.b1, b.h1};
+        CollectL1Args l1{n, in, H1, h->cfg.activation ? 1 : 0, X, P + off.w1, P + off.b1, b.h1, nullptr, nullptr, 0, (n + 7) / 8, nullptr, 0, nullptr, nullptr, 0};
         hipLaunchKernelGGL(sac_collect_l1_kernel, dim3((n + 7) / 8), dim3(256), 0, h->stream, l1);
     }
     if (!first_done && !elem_l1) {
@@ -1022,7 +1160,7 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out, unsigned long long*
     SHIP(h, hipGetLastError());
     h->bt_actor[0] *= h->cfg.adam_beta1; h->bt_actor[1] *= h->cfg.adam_beta2;
     h->bt_critic[0] *= h->cfg.adam_beta1; h->bt_critic[1] *= h->cfg.adam_beta2;
-    h->grad_updates += 1; h->update_counter += 1;
+    h->grad_updates += 1; h->update_counter += 1; h->col_w2_dirty = true;      // (the actor moved: its W2 planes are re-cut by the next collection step)
     return DRIL_OK;
 }
 
@@ -1037,7 +1175,22 @@ int collect_step(dril_sac_handle* h, int use_random, const float* inj_noise, uns
     // predict_actions_raw :55 — the hidden layers as contractions (the first one inside the second's staging when the input is narrow); the output layer inside the head /
     // env kernel that follows (fused_fwd; DRIL_SAC_NO_FUSED_FWD=1: three contractions and mu through memory, the round 1 - 3 form)
     const bool mu_in_head = h->fused_fwd && !use_random && h->H2 % 4 == 0;
-    if (!use_random) SDO(net_forward(h, h->params, h->actor, 0, D, A, h->obs_cur, D, 0, E, actor_bufs(h), 1, 1, mu_in_head));
+    // the hidden layers: for a narrow observation and tile-sized widths the f16-piece form (sac_collect_l1_kernel cuts h1 and, when the actor changed, W2 into f16 planes;
+    // sac_collect_l2_kernel contracts them; out-of-range values fall back to f32 MFMAs inside the kernel), else the generic contractions
+    const bool f16_path = mu_in_head && h->f16_fwd && D <= 4 && h->H1 % kL2KC == 0 && h->H2 % kL2TM == 0 && E >= 1024 && h->col_h1p;
+    if (f16_path) {
+        const int relu = h->cfg.activation ? 1 : 0, nb_l1 = (E + 7) / 8, nb_w2 = h->col_w2_dirty ? 128 : 0;
+        h->col_tag += 1; if (h->col_w2_dirty) h->col_w2tag += 1;
+        CollectL1Args l1{E, D, h->H1, relu, h->obs_cur, h->params + h->actor.w1, h->params + h->actor.b1, h->ah1, h->col_h1p, h->col_flags, h->col_tag,
+                         nb_l1, h->params + h->actor.w2, h->H2, h->col_w2p, h->col_flags + 1, h->col_w2tag};
+        hipLaunchKernelGGL(sac_collect_l1_kernel, dim3(nb_l1 + nb_w2), dim3(256), 0, h->stream, l1);
+        h->col_w2_dirty = false;
+        CollectL2Args l2{E, h->H1, h->H2, relu, h->col_h1p, h->col_w2p, h->params + h->actor.b2, h->ah2, h->col_flags, h->col_tag, h->col_flags + 1, h->col_w2tag, h->ah1, h->params + h->actor.w2};
+        static bool attr_set = false;
+        if (!attr_set) { SHIP(h, hipFuncSetAttribute((const void*)sac_collect_l2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2LdsBytes)); attr_set = true; }
+        hipLaunchKernelGGL(sac_collect_l2_kernel, dim3((E + kL2TN - 1) / kL2TN, h->H2 / kL2TM), dim3(256), kL2LdsBytes, h->stream, l2);
+        SHIP(h, hipGetLastError());
+    } else if (!use_random) SDO(net_forward(h, h->params, h->actor, 0, D, A, h->obs_cur, D, 0, E, actor_bufs(h), 1, 1, mu_in_head));
     CollectHeadArgs ca{E, A, use_random, h->mu, h->params + h->log_std_off, inj_noise, h->gstep, h->env_seed0, h->act_lo, h->act_hi, h->e_raw, h->e_envact,
                        mu_in_head ? h->ah2 : nullptr, h->params + h->actor.w3, h->params + h->actor.b3, h->H2};
     if (A == 1 && !h->external && h->fused_collect) {                                                            // every device Box env: head + act! + observe + push! in one launch
@@ -1227,6 +1380,7 @@ DRIL_EXPORT int32_t dril_sac_destroy(dril_sac_handle* h) {
     if (h->ev_a) hipEventDestroy(h->ev_a); if (h->ev_b) hipEventDestroy(h->ev_b);
     for (hipEvent_t e : h->it_events) hipEventDestroy(e);
     if (h->it_stamps) hipFree(h->it_stamps);
+    if (h->col_h1p) hipFree(h->col_h1p); if (h->col_w2p) hipFree(h->col_w2p); if (h->col_flags) hipFree(h->col_flags);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return DRIL_OK;
@@ -1265,7 +1419,7 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     h->adam_blocks_c = std::min(kSacAdamBlocks, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(kSacAdamBlocks, ((h->actor.end + 3) / 4 + 2 * h->Pqd / 4 + 255) / 256);   // elementwise optimiser kernels: up to 1 024 blocks (no grid-wide fold is left in them; 256 -> 1 024: update! 0.174 -> 0.168 ms)
     CHK(smalloc(&h->counter, 1));
     CHK(smalloc(&h->head_partials, (size_t)(2 * kMaxA + 8) * ((B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock + 1))); CHK(smalloc(&h->head_counter, kMaxA + 1));   // doubles: [critic 2 | actor 2 | log_std kMaxA | entropy 2] x blocks
-    h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr; h->fused_collect = std::getenv("DRIL_SAC_NO_FUSED_COLLECT") == nullptr; h->fused_fwd = std::getenv("DRIL_SAC_NO_FUSED_FWD") == nullptr; h->trace_enqueue = false;   // latched here: no getenv on the update path
+    h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr; h->fused_collect = std::getenv("DRIL_SAC_NO_FUSED_COLLECT") == nullptr; h->fused_fwd = std::getenv("DRIL_SAC_NO_FUSED_FWD") == nullptr; h->f16_fwd = std::getenv("DRIL_SAC_NO_F16_FWD") == nullptr; h->trace_enqueue = false;   // latched here: no getenv on the update path
     CHK(smalloc(&h->state, (size_t)E * S)); CHK(smalloc(&h->step_count, E)); CHK(smalloc(&h->episode, E)); CHK(smalloc(&h->gstep, E)); CHK(smalloc(&h->disc_returns, E));
     CHK(smalloc(&h->obs_cur, (size_t)E * D)); CHK(smalloc(&h->obs_nxt, (size_t)E * D)); CHK(smalloc(&h->e_rew, E)); CHK(smalloc(&h->e_tobs, (size_t)E * D));
     CHK(smalloc(&h->e_raw, (size_t)E * A)); CHK(smalloc(&h->e_envact, (size_t)E * A)); CHK(smalloc(&h->e_term, E)); CHK(smalloc(&h->e_trunc, E));
@@ -1273,6 +1427,7 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     CHK(smalloc(&h->rb_obs, (size_t)h->cap * D)); CHK(smalloc(&h->rb_next, (size_t)h->cap * D)); CHK(smalloc(&h->rb_act, (size_t)h->cap * A));
     CHK(smalloc(&h->rb_rew, (size_t)h->cap)); CHK(smalloc(&h->rb_term, (size_t)h->cap)); CHK(smalloc(&h->rb_trunc, (size_t)h->cap));
     const size_t nm = h->nmax, nq = h->nq;
+    if (H1 % 2 == 0) { CHK(smalloc(&h->col_h1p, (size_t)2 * nm * (H1 / 2))); CHK(smalloc(&h->col_w2p, (size_t)2 * H2 * (H1 / 2))); CHK(smalloc(&h->col_flags, 2)); }   // f16 planes of h1 [2][nm][H1/2] and of the actor's W2 [2][H2][H1/2]; their range flags
     CHK(smalloc(&h->xa, nm * D)); CHK(smalloc(&h->ah1, nm * H1)); CHK(smalloc(&h->ah2, nm * H2)); CHK(smalloc(&h->mu, nm * A));
     CHK(smalloc(&h->xq, 2 * nq * W)); h->xq_next = h->xq + nq * W; CHK(smalloc(&h->xq_pi, nq * W));       // [xq | xq_next]: one input buffer, batch index z / 2
     CHK(smalloc(&h->qh1, 4 * nq * H1)); CHK(smalloc(&h->qh2, 4 * nq * H2)); h->th1 = h->qh1 + 2 * nq * H1; h->th2 = h->qh2 + 2 * nq * H2;   // z = 0,1 critics (kept for the reverse pass), 2,3 targets
@@ -1297,7 +1452,7 @@ DRIL_EXPORT int64_t dril_sac_q_param_count(const dril_sac_handle* h) { return h 
 
 DRIL_EXPORT int32_t dril_sac_set_params(dril_sac_handle* h, const float* flat, size_t n) {
     SNEED(h); if (!flat || n != (size_t)h->P) return sfail(h, DRIL_ERR_INVALID_ARG, "dril_sac_set_params: n must equal dril_sac_param_count");
-    SDO(params_to_device(h, h->params, flat));
+    SDO(params_to_device(h, h->params, flat)); h->col_w2_dirty = true;
     SHIP(h, hipMemcpy(h->target, h->params + h->q0.w1, 2 * (size_t)h->Pqd * 4, hipMemcpyDeviceToDevice));   // copy_critic_parameters sac.jl:172,191-197
     return DRIL_OK;
 }

@@ -44,7 +44,7 @@ static void dense_a(const float* W, const float* b, int out, int in, const float
     for (int o = 0; o < out; ++o) y[o] = b[o];
     for (int i = 0; i < in; ++i) { const float xi = x[i]; const float* w = W + (size_t)i * out; for (int o = 0; o < out; ++o) y[o] += w[o] * xi; }
     if (act == 0) for (int o = 0; o < out; ++o) y[o] = tanhf(y[o]);
-    else if (act == 1) for (int o = 0; o < out; ++o) y[o] = y[o] > 0.0f ? y[o] : 0.0f;
+    else if (act == 1) for (int o = 0; o < out; ++o) y[o] = (y[o] > 0.0f || y[o] != y[o]) ? y[o] : 0.0f;   /* NNlib.relu = max(0, x): Julia's max propagates NaN */
 }
 static void mlp_fwd_a(const float* P, const sac_net* n, const float* x, float* h1, float* h2, float* out, int act) {
     dense_a(P + n->w1, P + n->b1, n->H1, n->D, x, h1, act);

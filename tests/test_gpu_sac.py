@@ -183,29 +183,79 @@ def test_one_launch_collection_equals_the_four_launch_sequence(pkg, monkeypatch,
     assert a.replay(C.RB_TRUNCATED).sum() > 0
 
 
-@pytest.mark.parametrize("E,hidden,act", [(4096, (512, 512), "relu"), (4100, (512, 512), "tanh"), (16400, (96, 160), "relu")])
+@pytest.mark.parametrize("E,hidden,act", [(4096, (512, 512), "relu"), (4100, (512, 512), "tanh"), (16400, (96, 160), "relu"), (2050, (128, 256), "relu")])
 def test_fused_collection_forward_matches_the_three_contraction_form_and_the_oracle(pkg, monkeypatch, E, hidden, act):
-    """the collection forward of configs[4]-sized env counts: the first layer (3 input features) is an elementwise pass instead of a K = 3 contraction and
-    the output layer mu = W3 h2 + b3 inside the head / env kernel (two launches and two round trips through memory less per env step); DRIL_SAC_NO_FUSED_FWD=1
-    (latched at create) keeps the three-contraction form.  Same fp32 products in another summation order: replay contents agree to rounding with each other and
-    with the oracle's collection (off_policy_collection.jl:28-96), incl. an env count that is no multiple of the tile sizes and unequal hidden widths"""
+    """the collection forward of configs[4]-sized env counts, three forms inside the library and the oracle's collection (off_policy_collection.jl:28-96):
+      a  default: first layer as an elementwise pass that also cuts h1 into two f16 planes, the second layer on the f16 matrix cores from pre-split operands
+         (sac_collect_l2_kernel; widths that are multiples of its tiles: (512, 512), (128, 256)), the output layer inside the env kernel;
+      b  DRIL_SAC_NO_F16_FWD=1: the same launch structure with the second layer as the generic f32-MFMA contraction;
+      c  DRIL_SAC_NO_FUSED_FWD=1: three generic contractions and mu through memory (rounds 1 - 3).
+    Same fp32-equivalent products in other summation orders: replay contents agree to rounding, incl. an env count that is no multiple of the tile sizes"""
     a, o, layer, _ = make_pair(pkg, E=E, hidden=hidden, act=act, cap=4 * E, max_steps=3)
-    monkeypatch.setenv("DRIL_SAC_NO_FUSED_FWD", "1")
+    monkeypatch.setenv("DRIL_SAC_NO_F16_FWD", "1")
     b, _, _, _ = make_pair(pkg, E=E, hidden=hidden, act=act, cap=4 * E, max_steps=3)
+    monkeypatch.delenv("DRIL_SAC_NO_F16_FWD")
+    monkeypatch.setenv("DRIL_SAC_NO_FUSED_FWD", "1")
+    c, _, _, _ = make_pair(pkg, E=E, hidden=hidden, act=act, cap=4 * E, max_steps=3)
     monkeypatch.delenv("DRIL_SAC_NO_FUSED_FWD")
     flat = init_params(pkg, layer, scale_out=3.0)
     nz = np.random.default_rng(5).normal(0, 1, (3, E, 1)).astype(np.float32)
-    for x in (a, b, o):
+    for x in (a, b, c, o):
         x.set_params(flat); x.env_reset(3); x.set_collect_noise(nz); x.collect_rollout(3, False)      # three policy steps, one truncation
     C = pkg._capi
     for which in (C.RB_TERMINATED, C.RB_TRUNCATED):
-        np.testing.assert_array_equal(a.replay(which), b.replay(which)); np.testing.assert_array_equal(a.replay(which), o.replay(which))
+        for x in (b, c, o):
+            np.testing.assert_array_equal(a.replay(which), x.replay(which))
     for which in (C.RB_OBSERVATIONS, C.RB_NEXT_OBSERVATIONS, C.RB_ACTIONS, C.RB_REWARDS):
         close(a.replay(which), b.replay(which), rtol=1e-4, atol=2e-5)
+        close(a.replay(which), c.replay(which), rtol=1e-4, atol=2e-5)
         close(a.replay(which), o.replay(which), rtol=1e-4, atol=5e-5)
+    da = np.abs(a.replay(C.RB_ACTIONS).astype(np.float64) - b.replay(C.RB_ACTIONS)).max()
+    print(f"[collection forward] E {E} hidden {hidden}: max |action(f16 pieces) - action(f32 MFMA)| = {da:.2e}")
+    assert da <= 5e-6                                                 # fp32-equivalent: three steps of closed-loop dynamics apart by rounding only
     assert a.replay(C.RB_TRUNCATED).sum() == E and np.abs(a.replay(C.RB_ACTIONS)).max() < 1.0 and np.std(a.replay(C.RB_ACTIONS)) > 0.1
-    for x in (a, b):
+    for x in (a, b, c):
         x.close()
+
+
+@pytest.mark.parametrize("what", ["h1", "w2", "nan"])
+def test_collection_forward_outside_the_f16_range_falls_back_inside_the_kernel(pkg, monkeypatch, what):
+    """f16 pieces overflow beyond 65 504 / scale: a relu activation >= 4 094 (first-layer bias 5 000: every h1 is) or an actor W2 entry >= 1 023.  The producers flag it
+    on the device, sac_collect_l2_kernel computes its block with f32 MFMAs from the f32 operands instead — no host round trip, and never a silently wrong action:
+    the replay equals the f32 form's.  A NaN weight must surface as NaN in both forms, not be laundered."""
+    E, hidden = 4096, (512, 512)
+    a, _, layer, _ = make_pair(pkg, E=E, hidden=hidden, act="relu", cap=2 * E, max_steps=50)
+    monkeypatch.setenv("DRIL_SAC_NO_F16_FWD", "1")
+    b, _, _, _ = make_pair(pkg, E=E, hidden=hidden, act="relu", cap=2 * E, max_steps=50)
+    monkeypatch.delenv("DRIL_SAC_NO_F16_FWD")
+    ps = layer.initialparameters(np.random.default_rng(0))
+    if what == "h1":
+        ps["actor_head"]["layer_1"]["bias"][:] = 5000.0
+        ps["actor_head"]["layer_2"]["weight"] *= 1e-3                  # keep h2 (and the sampled action) in a sane range
+    elif what == "w2":
+        ps["actor_head"]["layer_2"]["weight"][7, 11] = 2000.0
+        ps["actor_head"]["layer_3"]["weight"] *= 1e-3
+    else:
+        ps["actor_head"]["layer_2"]["weight"][3, 5] = np.nan
+    flat = pkg.sac_flatten_params(ps)
+    nz = np.random.default_rng(5).normal(0, 1, (2, E, 1)).astype(np.float32)
+    for x in (a, b):
+        x.set_params(flat); x.env_reset(3); x.set_collect_noise(nz); x.collect_rollout(2, False)
+    C = pkg._capi
+    ra, rb = a.replay(C.RB_ACTIONS), b.replay(C.RB_ACTIONS)
+    if what == "nan":
+        assert np.isnan(ra).all() and np.isnan(rb).all()
+    else:
+        assert np.isfinite(ra).all()
+        close(ra, rb, rtol=1e-5, atol=2e-6)
+        close(a.replay(C.RB_REWARDS), b.replay(C.RB_REWARDS), rtol=1e-5, atol=1e-5)
+    # back in range: the very next step runs the f16 form again (the flags are tagged per launch, nothing to clear)
+    flat2 = init_params(pkg, layer, scale_out=3.0)
+    for x in (a, b):
+        x.set_params(flat2); x.env_reset(4); x.set_collect_noise(nz); x.collect_rollout(2, False)
+    close(a.replay(C.RB_ACTIONS), b.replay(C.RB_ACTIONS), rtol=1e-4, atol=2e-5)
+    assert np.isfinite(a.replay(C.RB_ACTIONS)).all()
+    a.close(); b.close()
 
 
 def test_iterations_without_host_sync_equal_the_step_by_step_loop(pkg):
