@@ -149,15 +149,16 @@ def run_sac(pkg, *, steps: int, warmup: int, iters: int, E: int = 4096, H: int =
     f_upd, f_col = sac_flops(3, 1, H, B, E)
     out = {"metric": "env-steps/s (SAC collect + update!) at n_envs=4096", "value": E * n_it / dt, "unit": "env-steps/s", "n_gpus": 1,
            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "vs_baseline": None, "dtype": "f32 (collection contraction: f16 two-piece split, f32 accumulate)", "data": "synthetic",
            "config": {"workload": f"Pendulum-v1 configs[4]: SAC, device-resident envs + replay ring, SACLayer hidden_dims=[{H},{H}] relu, batch {B}, "
                                   f"train_freq 1, gradient_steps 1; one step = {iters} iterations of (1 env step x {E} envs, 1 update!)",
                       "n_envs": E, "batch_size": B, "iterations_per_step": iters, "buffer_capacity": alg.buffer_capacity}}
     if prof["updates"]:
         u_ms, c_ms = prof["update_ms"] / prof["updates"], prof["collect_ms"] / max(1, prof["collect_steps"])
         ach = (f_upd + f_col) / ((u_ms + c_ms) * 1e-3) / 1e12
-        out["roofline"] = dict(mfma_roofline(ach, "f32 (v_mfma_f32_32x32x2_f32)"), traffic=None,
-                               kernel="sac_gemm_kernel (all launches of one iteration; HIP events around update! and around the collection step)",
+        # priced against the f32-MFMA peak: update!'s sixteen launches run v_mfma_f32_32x32x2_f32; only the collection's 512 x 4096 x 512 contraction runs on two-piece f16 operands
+        out["roofline"] = dict(mfma_roofline(ach, "f32 (update!: v_mfma_f32_32x32x2_f32; the collection's second layer: two f16 pieces per operand, three v_mfma_f32_32x32x16_f16 per k16 step, f32 accumulate)"), traffic=None,
+                               kernel="all launches of one SAC iteration (sac_gemm_lds_kernel / sac_gemm_multi_kernel / head kernels of update!; sac_collect_l1 / l2 / env kernels of the collection step); in-kernel wall-clock stamps at the phase boundaries",
                                update_ms=u_ms, collect_step_ms=c_ms, flops_per_update=f_upd, flops_per_collect_step=f_col)
     if cpu:
         sys.path.insert(0, str(ROOT / "tests"))
