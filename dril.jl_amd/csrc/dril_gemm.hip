@@ -6,6 +6,7 @@
 #include <type_traits>
 #include <mutex>
 #include <vector>
+#include <utility>
 
 #include "dril_device.h"
 #include "dril_gemm.h"
@@ -569,11 +570,12 @@ bool gemm_prepare(GemmArgs& g) {
 
 // kernels that take the 66 KB dynamic LDS block: raise the limit once per kernel and device context
 static hipError_t lds_attr(const void* fn) {
-    static std::mutex mu; static std::vector<const void*> done;
+    static std::mutex mu; static std::vector<std::pair<const void*, int>> done;            // (kernel, device): a process may hold handles on several devices
+    int dev = 0; (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
-    if (std::find(done.begin(), done.end(), fn) != done.end()) return hipSuccess;
+    if (std::find(done.begin(), done.end(), std::make_pair(fn, dev)) != done.end()) return hipSuccess;
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-    if (e == hipSuccess) done.push_back(fn);
+    if (e == hipSuccess) done.push_back(std::make_pair(fn, dev));
     return e;
 }
 GemmArgs gemm_args() { GemmArgs g; memset(&g, 0, sizeof(g)); g.alpha = 1.0f; return g; }

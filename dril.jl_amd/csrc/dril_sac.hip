@@ -854,7 +854,6 @@ __global__ __launch_bounds__(256) void sac_collect_env_kernel(CollectEnvArgs c) 
     const CollectHeadArgs& g = c.head;
     const int e = blockIdx.x * kEnvsPerBlock + threadIdx.x;          // 256 threads per kEnvsPerBlock envs: all four waves on the output layer, then one thread per env
     if (!g.use_random && g.h2) { sac_mu_block(g, 0, blockIdx.x * kEnvsPerBlock, mu_s); __syncthreads(); }   // the actor's output layer (A = 1), same device function as the head kernel
-    phase_stamp(c.push.stamp);
     if (threadIdx.x >= kEnvsPerBlock || e >= g.E) return;
     float mu_e = 0.f;
     if (!g.use_random) { if (g.h2) { mu_e = mu_s[threadIdx.x]; g.mu[e] = mu_e; } else mu_e = g.mu[e]; }
@@ -903,6 +902,7 @@ __global__ __launch_bounds__(256) void sac_collect_env_kernel(CollectEnvArgs c) 
 #pragma unroll
     for (int d = 0; d < D; ++d) { q.rb_obs[slot * D + d] = q.obs[(size_t)e * D + d]; q.rb_next[slot * D + d] = tr ? to[d] : no[d]; }
     q.rb_act[slot] = r; q.rb_rew[slot] = rw; q.rb_term[slot] = t; q.rb_trunc[slot] = tr;
+    phase_stamp(q.stamp);                                               // thread 0 of the last workgroup owns a live env (grid = ceil(E / kEnvsPerBlock)): the end of its work ~ the end of the phase
 }
 // host-batch helpers
 __global__ void sac_squash_eval_kernel(int B, int A, const float* mu, const float* log_std, const float* noise, int deterministic, float low, float high,
@@ -947,7 +947,7 @@ struct dril_sac_handle {
     double* ssq_rows = nullptr;   // [stats_cap][adam_blocks_c + end_blocks] squared-gradient partials per update, summed on the host (grad_norm statistic)
     unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
     SacScalars* sc_next = nullptr;   // ping-pong partner of `sc` (fused heads: the entropy step writes the new state here, then the two are swapped)
-    double* head_partials = nullptr; unsigned int* head_counter = nullptr; unsigned* col_h1p = nullptr; unsigned* col_w2p = nullptr; int* col_flags = nullptr; int col_tag = 0, col_w2tag = 0; bool col_w2_dirty = true, f16_fwd = true;   // the f16-piece collection forward (sac_collect_l2_kernel)
+    double* head_partials = nullptr; unsigned int* head_counter = nullptr; unsigned* col_h1p = nullptr; unsigned* col_w2p = nullptr; int* col_flags = nullptr; int col_tag = 0, col_w2tag = 0; bool col_w2_dirty = true, f16_fwd = true, l2_attr_set = false;   // the f16-piece collection forward (sac_collect_l2_kernel)
     unsigned long long* it_stamps = nullptr; int it_stamps_cap = 0; double wall_hz = 1e8; bool fused_heads = true; bool fused_collect = true; bool fused_fwd = true; bool trace_enqueue = false; std::vector<hipEvent_t> it_events; int iter_chunk = 64;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
     float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
     float target_entropy = 0, act_lo = -2.0f, act_hi = 2.0f; bool external = false;   // bounds of the agent-facing action space: Box(-2,2), Box(-1,1) under ScalingWrapperEnv
@@ -1186,8 +1186,7 @@ int collect_step(dril_sac_handle* h, int use_random, const float* inj_noise, uns
         hipLaunchKernelGGL(sac_collect_l1_kernel, dim3(nb_l1 + nb_w2), dim3(256), 0, h->stream, l1);
         h->col_w2_dirty = false;
         CollectL2Args l2{E, h->H1, h->H2, relu, h->col_h1p, h->col_w2p, h->params + h->actor.b2, h->ah2, h->col_flags, h->col_tag, h->col_flags + 1, h->col_w2tag, h->ah1, h->params + h->actor.w2};
-        static bool attr_set = false;
-        if (!attr_set) { SHIP(h, hipFuncSetAttribute((const void*)sac_collect_l2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2LdsBytes)); attr_set = true; }
+        if (!h->l2_attr_set) { SHIP(h, hipFuncSetAttribute((const void*)sac_collect_l2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL2LdsBytes)); h->l2_attr_set = true; }   // per handle = per device
         hipLaunchKernelGGL(sac_collect_l2_kernel, dim3((E + kL2TN - 1) / kL2TN, h->H2 / kL2TM), dim3(256), kL2LdsBytes, h->stream, l2);
         SHIP(h, hipGetLastError());
     } else if (!use_random) SDO(net_forward(h, h->params, h->actor, 0, D, A, h->obs_cur, D, 0, E, actor_bufs(h), 1, 1, mu_in_head));
