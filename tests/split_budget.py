@@ -54,8 +54,9 @@ def w2_slices(D, H, A, discrete):
     return out
 
 
-def measure(pkg, oracle_mod, kind, H, B, split_variant, seed=0, ent_coef=0.01):
-    """-> dict of error norms; split_variant: None = the library's own selection, 2 = force the pair kernel (hidden 64)"""
+def measure(pkg, oracle_mod, kind, H, B, split_variant, seed=0, ent_coef=0.01, scale=1.0):
+    """-> dict of error norms; split_variant: None = the library's own selection, 2 = force the pair kernel (hidden 64); scale: advantages, returns and old values
+    are N(0, scale^2) instead of N(0, 1) (the budget must hold away from benign inputs — un-normalised rewards give returns of 1e3, sparse ones 1e-3)"""
     from test_oracle_crosschecks import make_batch, torch_ppo_loss
     capi = pkg._capi
     cfg = capi.default_config(kind)
@@ -64,6 +65,9 @@ def measure(pkg, oracle_mod, kind, H, B, split_variant, seed=0, ent_coef=0.01):
     flat = (np.random.default_rng(40 + seed).standard_normal(o.P) * (0.25 if H == 64 else 0.08)).astype(np.float32)
     o.set_params(flat)
     batch = make_batch(o, cfg, B, seed, o.discrete, o.A)
+    if scale != 1.0:
+        obs_, act_, adv_, ret_, lp_, ov_ = batch
+        batch = (obs_, act_, (adv_ * np.float32(scale)).astype(np.float32), (ret_ * np.float32(scale)).astype(np.float32), lp_, (ov_ * np.float32(scale)).astype(np.float32))
     l64, s64, g64 = torch_ppo_loss(flat, cfg, *batch, o.discrete, o.A)
     res = {}
     for name, v in (("split", split_variant), ("f32", 0)):
@@ -77,7 +81,7 @@ def measure(pkg, oracle_mod, kind, H, B, split_variant, seed=0, ent_coef=0.01):
     gn = float(np.linalg.norm(g64))
     sl = w2_slices(o.D, H, o.A, o.discrete)
     idx = np.r_[sl[0], sl[1]]
-    out = {"kind": kind, "H": H, "B": B, "kernel_split": res["split"][2], "kernel_f32": res["f32"][2], "grad_norm": gn, "loss_f64": l64}
+    out = {"kind": kind, "H": H, "B": B, "scale": scale, "kernel_split": res["split"][2], "kernel_f32": res["f32"][2], "grad_norm": gn, "loss_f64": l64}
     for name in ("split", "f32"):
         l, g, _ = res[name]
         e = g - g64

@@ -219,6 +219,28 @@ def test_split_error_budget_vs_float64(pkg, oracle_mod, kind, H, B, forced):
     assert m["grad_err_split"] <= 5e-7                                    # absolute: fp32-level agreement with float64 (measured 1.0 - 1.5e-7, profiles/r03_split_arith.md section 6)
 
 
+@pytest.mark.parametrize("kind,H,B,scale", [(0, 64, 131072, 1e3), (1, 64, 131072, 1e3), (0, 64, 131072, 1e-3), (1, 64, 131072, 1e-3), (1, 256, 8192, 1e3), (0, 128, 8192, 1e-3)])
+def test_split_error_budget_away_from_benign_inputs(pkg, oracle_mod, kind, H, B, scale):
+    """the same measurement with advantages / returns / old values of N(0, scale^2), scale 1e3 (un-normalised rewards: the value head's gradient tiles are 1e3 x the benign
+    case, still inside f16's range) and 1e-3 (tiny returns: gradient tiles whose `lo` pieces approach f16's subnormals).  Per-minibatch advantage normalisation cancels the
+    scale of the advantages, not that of the returns.  No redo may be involved: dril_ppo_loss_grad runs the selected kernel once.
+    At 1e-3 the full budget of the benign case holds.  At 1e3 the gradient is dominated by the critic's sums of +-1e3 terms that cancel to ~1 / 360 of their absolute sum,
+    and EVERY f32 kernel loses digits there (the exact-f32 kernel is 5 x further from float64 than at scale 1: 6.2e-7).  What is asked of the f16 pieces is asked where
+    they act — the sample contraction dW2 = dz2' h1: its error spread must match the exact-f32 kernel's (measured 4.4e-8 vs 4.1e-8) — while the whole gradient, whose other
+    blocks are f32 sums in another order in the pair kernel (per-lane accumulators over a workgroup's tiles instead of MFMA accumulation), must stay at fp32 level: within
+    4 x the exact-f32 kernel's distance and 5e-6 of the gradient norm (measured 1.0e-6 - 1.6e-6)."""
+    m = split_budget.measure(pkg, oracle_mod, kind, H, B, None, scale=scale)
+    print("[budget, scaled]", json.dumps(m))
+    assert m["kernel_split"] == EXPECTED[H] and np.isfinite(m["grad_err_split"])
+    ok_grad, ok_loss, _ = split_budget.within_budget(m)
+    assert ok_loss, (m["loss_err_split"], m["loss_err_f32"])
+    if scale < 1.0:
+        assert ok_grad and m["grad_err_split"] <= 5e-7, (m["grad_err_split"], m["grad_err_f32"])
+    else:
+        assert m["dW2_std_err_split"] <= 1.25 * m["dW2_std_err_f32"], (m["dW2_std_err_split"], m["dW2_std_err_f32"])
+        assert m["grad_err_split"] <= 4.0 * m["grad_err_f32"] and m["grad_err_split"] <= 5e-6, (m["grad_err_split"], m["grad_err_f32"])
+
+
 def test_negative_control_two_piece_split_breaks_the_budget(pkg):
     """the same measurement on libdril_hip_droplo.so (mfma_split3 without its two `lo` products = hi.hi only, an 11-bit product): the gradient criterion of the
     budget test must FAIL for every case — a test that a short product passes would prove nothing about 2^-24"""
