@@ -212,10 +212,41 @@ def test_fused_collection_forward_matches_the_three_contraction_form_and_the_ora
         close(a.replay(which), o.replay(which), rtol=1e-4, atol=5e-5)
     da = np.abs(a.replay(C.RB_ACTIONS).astype(np.float64) - b.replay(C.RB_ACTIONS)).max()
     print(f"[collection forward] E {E} hidden {hidden}: max |action(f16 pieces) - action(f32 MFMA)| = {da:.2e}")
-    assert da <= 5e-6                                                 # fp32-equivalent: three steps of closed-loop dynamics apart by rounding only
+    assert da <= 5e-7                                                 # fp32-equivalent: three steps of closed-loop dynamics apart by rounding only (measured 0 - 1.2e-7; hi.hi alone: 2.7e-6, the negative control below)
     assert a.replay(C.RB_TRUNCATED).sum() == E and np.abs(a.replay(C.RB_ACTIONS)).max() < 1.0 and np.std(a.replay(C.RB_ACTIONS)) > 0.1
     for x in (a, b, c):
         x.close()
+
+
+def test_negative_control_dropping_the_lo_products_breaks_the_collection_forward(pkg):
+    """the agreement test above has power: the same comparison (f16-piece second layer vs f32-MFMA second layer, three closed-loop steps) on libdril_hip_droplo.so —
+    mfma_split3 without its two `lo` products: an 11-bit product — must miss the 5e-7 bound"""
+    import json, os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    so = root / "dril.jl_amd" / "csrc" / "libdril_hip_droplo.so"
+    assert so.exists(), f"{so} missing: __graft_entry__.build() compiles it"
+    code = (
+        "import sys, json, os, numpy as np\n"
+        f"sys.path.insert(0, {str(root)!r}); sys.path.insert(0, {str(root / 'tests')!r})\n"
+        "import __graft_entry__ as g; pkg = g.load_package()\n"
+        "import test_gpu_sac as T\n"
+        "res = []\n"
+        "for flag in (None, '1'):\n"
+        "    if flag: os.environ['DRIL_SAC_NO_F16_FWD'] = flag\n"
+        "    h, _, layer, _ = T.make_pair(pkg, E=4096, hidden=(512, 512), act='relu', cap=16384, max_steps=3)\n"
+        "    os.environ.pop('DRIL_SAC_NO_F16_FWD', None)\n"
+        "    h.set_params(T.init_params(pkg, layer, scale_out=3.0)); h.env_reset(3)\n"
+        "    h.set_collect_noise(np.random.default_rng(5).normal(0, 1, (3, 4096, 1)).astype(np.float32)); h.collect_rollout(3, False)\n"
+        "    res.append(h.replay(pkg._capi.RB_ACTIONS).astype(np.float64))\n"
+        "print(json.dumps(float(np.abs(res[0] - res[1]).max())))\n")
+    env = dict(os.environ, DRIL_HIP_LIBRARY=str(so))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    print(f"[negative control] max |action(hi.hi only) - action(f32 MFMA)| = {d:.2e}")
+    assert d > 1e-6                                                    # 5e-7 is the bound of the real arithmetic (measured 6e-8 - 1.2e-7); an 11-bit product gives 2.7e-6 — the rounding errors of
+                                                                       # 512-term sums average out, so the control sits 20 - 45 x above the product, not 2^13 x
 
 
 @pytest.mark.parametrize("what", ["h1", "w2", "nan"])
