@@ -177,7 +177,7 @@ def run_sac(pkg, *, steps: int, warmup: int, iters: int, E: int = 4096, H: int =
     return out
 
 
-def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int, epochs: int, normalize: bool, steps: int, warmup: int, events: bool = True,
+def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int, epochs: int, normalize: bool, steps: int, warmup: int, events: int = 8,
             batch_size: int | None = None, fixed_length: bool = True, label: str = "", rank: int = 0, local_rank: int = 0, world: int = 1, dist=None,
             grad_variant: str | None = None) -> dict | None:
     """one PPO workload: `warmup` untimed iterations, then exactly `steps` iterations (rollout + GAE + epochs x minibatches update) between a barrier +
@@ -280,7 +280,8 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
             kname, arith = info.split(": ", 1)
             out["dtype"] = "f32 (f16x2 split, f32 accumulate)" if "f16x2" in arith else "f32 (bf16x3 split, f32 accumulate)" if "bf16x3" in arith else "f32"
             out["roofline"] = dict(mfma_roofline(ach, arith), traffic=traffic, traffic_source=traffic_source, kernel=kname, avg_launch_ms=avg_ms,
-                                   avg_launch_ms_source="HIP events on the library's stream around every launch of the timed region",
+                                   avg_launch_ms_source=f"HIP events on the library's stream around every {'' if events == 1 else str(int(events)) + 'th '}launch of the timed region",
+                                   timed_launches=gk["timed_launches"],
                                    rocprof_avg_launch_ms=rocprof_ms, launches=gk["launches"], flops_per_launch=flops,
                                    record_bytes_per_launch=(B_global // world) * 64)      # one 32-byte record per sample and net (the algorithmic gather volume of the record path)
             out["kernel_ms_per_step"] = {k: v["total_ms"] / steps for k, v in prof.items() if v["launches"]}
@@ -303,7 +304,7 @@ def secondary_runs(pkg) -> list:
                        label="CartPole-v1 configs[1] on the exact-f32 kernels (DRIL_GRAD_VARIANT=0)"))
     out.append(run_ppo(pkg, env_name="pendulum", E=65536, T=2048, hidden=256, minibatches=32, epochs=10, normalize=True, steps=2, warmup=1))
     out.append(run_sac(pkg, steps=2, warmup=1, iters=500, cpu=False))
-    out.append(run_ppo(pkg, env_name="cartpole", E=4, T=2048, hidden=64, minibatches=0, epochs=10, normalize=False, steps=5, warmup=2, batch_size=64, fixed_length=False,
+    out.append(run_ppo(pkg, env_name="cartpole", E=4, T=2048, hidden=64, minibatches=0, epochs=10, normalize=False, steps=5, warmup=2, batch_size=64, fixed_length=False, events=1,
                        label="CartPole-v1 configs[0] (README quick-start: MultiThreadedParallelEnv n_envs=4, PPO() defaults, batch_size 64)"))
     return out
 
@@ -457,6 +458,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of configs[2] / configs[4] / configs[0] appended to the default line")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--event-stride", type=int, default=8, help="bracket every K-th launch of the per-optimiser-step kernels with HIP events (1 = every launch; "
+                    "an event record costs the stream ~3.5 us, 960 launches an iteration: 2 %% of configs[1] at K = 1)")
     ap.add_argument("--launch-timeout", type=float, default=1800.0, help="--gpus N > 1 without WORLD_SIZE: seconds the self-started ranks may take in total")
     ap.add_argument("--silent-timeout", type=float, default=420.0, help="... and seconds one rank may stay without a progress line (the first import of a fresh box takes 1-2 min)")
     args = ap.parse_args()
@@ -492,7 +495,7 @@ def main() -> None:
         progress(rank, f"gloo rendezvous of {world} ranks done")
 
     out = run_ppo(pkg, env_name=args.env, E=args.n_envs, T=args.n_steps, hidden=args.hidden, minibatches=args.minibatches, epochs=args.epochs, normalize=args.normalize,
-                  steps=args.steps, warmup=args.warmup, events=not args.no_events, rank=rank, local_rank=local_rank, world=world, dist=dist)
+                  steps=args.steps, warmup=args.warmup, events=0 if args.no_events else max(1, args.event_stride), rank=rank, local_rank=local_rank, world=world, dist=dist)
     if rank == 0:
         default_workload = (args.env, args.n_envs, args.n_steps, args.hidden, args.minibatches, args.epochs, args.normalize) == ("cartpole", 65536, 2048, 64, 32, 10, False)
         out["metric"] = "env-steps/s (rollout+PPO update) at n_envs=65536" if args.n_envs == 65536 else out["metric"]

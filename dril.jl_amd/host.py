@@ -366,7 +366,7 @@ def make_config(env, n_envs: int, alg: PPO, layer: Optional[ActorCriticLayer] = 
     c.normalize_advantage = int(alg.normalize_advantage)
     c.batch_size, c.epochs, c.learning_rate = alg.batch_size, alg.epochs, alg.learning_rate
     c.seed, c.device, c.rank, c.world_size = seed, device, rank, world_size
-    c.profile_events = int(profile_events)
+    c.profile_events = int(profile_events)      # True / 1: every launch bracketed; k > 1: the per-optimiser-step kernels at every k-th launch
     c.monitor_window = int(monitor_window)
     if normalize is not None:   # NormalizeWrapperEnv kwargs, normalizeWrapperEnv.jl:71-80
         c.norm_training = int(normalize.get("training", True))
@@ -692,11 +692,15 @@ class Handle:
         self._chk(self.lib.dril_synchronize(self._h))
 
     def profile(self) -> dict:
+        """per kernel class since the last reset: `launches` (all of them), `timed_launches` / `timed_ms` (the launches bracketed by HIP events: all of them at
+        profile_events = 1, every k-th of the per-optimiser-step classes at profile_events = k) and `total_ms` = timed average x launches"""
         out = {}
         for k in range(capi.K_COUNT):
-            ms, n = C.c_double(), C.c_int64()
+            ms, n, na = C.c_double(), C.c_int64(), C.c_int64()
             self._chk(self.lib.dril_profile_get(self._h, k, C.byref(ms), C.byref(n)))
-            out[self.lib.dril_kernel_name(k).decode()] = {"total_ms": ms.value, "launches": n.value}
+            self._chk(self.lib.dril_profile_launches(self._h, k, C.byref(na)))
+            out[self.lib.dril_kernel_name(k).decode()] = {"total_ms": ms.value * (na.value / n.value if n.value else 0.0), "launches": na.value if n.value else 0,
+                                                          "timed_ms": ms.value, "timed_launches": n.value}
         return out
 
     def profile_reset(self):

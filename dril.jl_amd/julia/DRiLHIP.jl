@@ -144,7 +144,7 @@ function make_config(env::DeviceParallelEnv, alg::PPO, hidden::Vector{Int}, log_
         0.9f0, 0.999f0, 1.0f-5, log_std_init,                    # Optimisers.Adam(eta, (0.9, 0.999), 1e-5): ppo.jl:64-66
         on * Int32(nget(:norm_obs, true)), on * Int32(nget(:norm_reward, true)), on * Int32(nget(:training, true)),
         Float32(nget(:clip_obs, 10)), Float32(nget(:clip_reward, 10)), Float32(nget(:gamma, 0.99)), Float32(nget(:epsilon, 1.0e-8)),
-        env.seed, env.device, 0, 1, 1, env.monitor_window, 0, 0, 0, 0.0f0, 0.0f0, layer_fields(hidden, act)..., ntuple(_ -> Int32(0), 1))   # profile_events = 1: HIP-event kernel times fill the TimerOutput sections
+        env.seed, env.device, 0, 1, 8, env.monitor_window, 0, 0, 0, 0.0f0, 0.0f0, layer_fields(hidden, act)..., ntuple(_ -> Int32(0), 1))   # profile_events = 8: HIP-event kernel times fill the TimerOutput sections (per-optimiser-step kernels bracketed at every 8th launch: bracketing all of them costs 1 - 2 %)
 end
 
 "(re)create the handle when the algorithm / layer shape changes; Random.seed!(env, seed) + reset!(env) follow"
@@ -359,13 +359,15 @@ function Base.getproperty(b::DeviceRolloutBuffer, f::Symbol)
     return dst
 end
 
-"seconds of HIP-event time per kernel class since the last reset (dril_profile_get; cfg.profile_events = 1)"
+"seconds of HIP-event time per kernel class since the last reset: average bracketed launch (dril_profile_get) x all launches of the class (dril_profile_launches)"
 function kernel_seconds(h)
     out = Dict{String, Float64}()
     for kid in 0:(Int(ccall((:dril_kernel_count, LIB[]), Int32, ())) - 1)
         ms = Ref{Float64}(0); n = Ref{Int64}(0)
         ccall((:dril_profile_get, LIB[]), Int32, (Ptr{Cvoid}, Int32, Ref{Float64}, Ref{Int64}), h, kid, ms, n) == 0 || continue
-        out[unsafe_string(ccall((:dril_kernel_name, LIB[]), Cstring, (Int32,), kid))] = ms[] * 1.0e-3
+        all = Ref{Int64}(0)
+        ccall((:dril_profile_launches, LIB[]), Int32, (Ptr{Cvoid}, Int32, Ref{Int64}), h, kid, all)
+        out[unsafe_string(ccall((:dril_kernel_name, LIB[]), Cstring, (Int32,), kid))] = n[] > 0 ? ms[] * 1.0e-3 * all[] / n[] : 0.0
     end
     return out
 end

@@ -135,7 +135,7 @@ typedef struct dril_config {
     uint64_t seed;             /* env i (0-based, global index) is seeded seed + i, wrapper_utils.jl:39-44 */
     int32_t device;            /* HIP device ordinal */
     int32_t rank, world_size;  /* data-parallel position; global env index = rank*n_envs + local */
-    int32_t profile_events;    /* 1: bracket hot kernels with HIP events (dril_profile_get) */
+    int32_t profile_events;    /* k >= 1: bracket hot kernels with HIP events (dril_profile_get); the per-optimiser-step kernels at every k-th launch */
     int32_t monitor_window;    /* MonitorWrapperEnv(env, stats_window): > 0 tracks episode returns/lengths (monitorWrapperEnv.jl:15-24); 0 = no wrapper */
     /* DRIL_ENV_EXTERNAL only (ignored otherwise): observation_space = Box of ext_obs_dim floats (<= 1024); action_space =
      * Discrete(ext_action_dim, action_start) when ext_discrete, else Box(ext_action_low, ext_action_high) of ext_action_dim floats (<= 64);
@@ -347,8 +347,10 @@ int64_t dril_comm_allreduce_calls(const dril_handle* h);
 int32_t dril_debug_comm_loopback(dril_handle** handles, int32_t n);
 
 /* ---- measurement ---------------------------------------------------------------- */
-/* accumulated HIP-event time and launch count of one kernel class since the last reset */
+/* accumulated HIP-event time and count of the BRACKETED launches of one kernel class since the last reset (total_ms / launches = average launch);
+ * dril_profile_launches: all launches of the class in the same window (= launches unless cfg.profile_events > 1 thinned the per-step classes) */
 int32_t dril_profile_get(dril_handle* h, int32_t kernel_id, double* total_ms, int64_t* launches);
+int32_t dril_profile_launches(dril_handle* h, int32_t kernel_id, int64_t* all_launches);
 int32_t dril_profile_reset(dril_handle* h);
 const char* dril_kernel_name(int32_t kernel_id);
 int32_t dril_kernel_count(void);   /* DRIL_K_COUNT of the loaded library */

@@ -1186,3 +1186,29 @@ def test_epoch_index_array_is_the_same_dataloader_order(pkg, monkeypatch):
         h.env_reset(3); h.collect_rollout(); st = h.ppo_update()
         res.append((h.get_params().copy(), st.loss, st.grad_norm)); h.close()
     assert res[0][1] == res[1][1] and res[0][2] == res[1][2] and np.array_equal(res[0][0], res[1][0])
+
+
+@pytest.mark.parametrize("stride", [1, 4])
+def test_profile_events_stride(pkg, stride):
+    """cfg.profile_events = k: the per-iteration kernels are bracketed at every launch, the per-optimiser-step kernels at every k-th; `launches` counts all of them either way
+    and the parameters do not depend on the bracketing"""
+    res = []
+    for k in (0, stride):
+        cfg = pkg._capi.default_config(0)
+        cfg.n_envs, cfg.n_steps, cfg.batch_size, cfg.epochs, cfg.profile_events = 256, 16, 512, 3, k
+        h = pkg.Handle(cfg)
+        h.set_params((np.random.default_rng(1).standard_normal(h.P) * 0.3).astype(np.float32)); h.env_reset(3)
+        h.collect_rollout(); st = h.ppo_update()
+        assert st.n_updates == 24
+        pr = h.profile()
+        if k:
+            assert pr["rollout_kernel"]["launches"] == pr["rollout_kernel"]["timed_launches"] == 1 and pr["gae_kernel"]["timed_launches"] == 1
+            for name in ("ppo_grad_kernel", "adam_kernel"):
+                assert pr[name]["launches"] == 24 and pr[name]["timed_launches"] == 24 // k and pr[name]["timed_ms"] > 0
+                assert pr[name]["total_ms"] == pytest.approx(pr[name]["timed_ms"] * k)
+            h.profile_reset()
+            assert h.profile()["ppo_grad_kernel"] == {"total_ms": 0.0, "launches": 0, "timed_ms": 0.0, "timed_launches": 0}
+        else:
+            assert all(v["launches"] == 0 for v in pr.values())
+        res.append(h.get_params()); h.close()
+    assert np.array_equal(res[0], res[1])
