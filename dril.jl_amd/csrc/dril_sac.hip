@@ -119,6 +119,32 @@ __device__ __forceinline__ void first_layer_row(const float* __restrict__ W1, co
         h1[u] = relu ? relu_nan(acc) : tanhf(acc);
     }
 }
+// the same with the weights requested EARLY (before the barrier behind which the sample's inputs appear: one round of memory latency less in kernels that are
+// nothing but dependent round trips): in <= 4 features, H1 <= 512 (two units per thread of a 256-thread block); same fma order
+constexpr int kL1PreMaxIn = 4, kL1PreMaxH = 512;
+struct L1Pre { float w[2][kL1PreMaxIn]; float b[2]; };
+__device__ __forceinline__ bool first_layer_pre_ok(int in, int H1) { return in <= kL1PreMaxIn && H1 <= kL1PreMaxH; }
+__device__ __forceinline__ void first_layer_pre(L1Pre& r, const float* __restrict__ W1, const float* __restrict__ b1, int in, int H1) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int u = threadIdx.x + 256 * t; const bool ok = u < H1;
+#pragma unroll
+        for (int k = 0; k < kL1PreMaxIn; ++k) r.w[t][k] = (ok && k < in) ? W1[u + (size_t)k * H1] : 0.f;
+        r.b[t] = ok ? b1[u] : 0.f;
+    }
+}
+__device__ __forceinline__ void first_layer_post(const L1Pre& r, const float* x, int in, int H1, int relu, float* __restrict__ h1) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int u = threadIdx.x + 256 * t;
+        if (u < H1) {
+            float acc = r.b[t];
+#pragma unroll
+            for (int k = 0; k < kL1PreMaxIn; ++k) if (k < in) acc = fmaf(r.w[t][k], x[k], acc);
+            h1[u] = relu ? relu_nan(acc) : tanhf(acc);
+        }
+    }
+}
 // =================================================================================================================
 // The collection forward (off_policy_collection.jl:55: predict_actions_raw over all envs) for a narrow observation — BASELINE configs[4]: 4096 envs, [512,512].
 // Its second layer, a 512 x 4096 x 512 contraction, is the largest kernel of a SAC iteration and the one place of the SAC path where the matrix pipe is the bound
@@ -290,6 +316,9 @@ __global__ __launch_bounds__(256) void sac_gather_l1_kernel(GatherL1Args f) {
     __shared__ float xs[2][kFusedL1MaxIn], xqs[kFusedL1MaxIn];
     const GatherArgs& g = f.g;
     const int i = blockIdx.x, W = g.D + g.A;
+    const bool pre = first_layer_pre_ok(W, f.H1);                                    // weights of the three first layers requested before the sample is known
+    L1Pre pa, pq[2];
+    if (pre) { first_layer_pre(pa, f.aW1, f.ab1, g.D, f.H1); for (int z = 0; z < 2; ++z) first_layer_pre(pq[z], f.P + f.qw1 + z * f.zP, f.P + f.qb1 + z * f.zP, W, f.H1); }
     if (threadIdx.x == 0) {
         long long j;
         if (g.inj_idx) j = g.inj_idx[i];
@@ -313,6 +342,13 @@ __global__ __launch_bounds__(256) void sac_gather_l1_kernel(GatherL1Args f) {
         dst[i * g.A + a] = inj ? inj[i * g.A + a] : sac_noise(g.rng, 5 + which, i, a);
     }
     __syncthreads();
+    if (pre) {
+        first_layer_post(pa, xs[0], g.D, f.H1, f.relu, f.ah1 + (size_t)i * f.H1);
+        first_layer_post(pa, xs[1], g.D, f.H1, f.relu, f.ah1 + (size_t)(g.B + i) * f.H1);
+#pragma unroll
+        for (int z = 0; z < 2; ++z) first_layer_post(pq[z], xqs, W, f.H1, f.relu, f.qh1 + z * f.zh + (size_t)i * f.H1);
+        return;
+    }
     first_layer_row(f.aW1, f.ab1, xs[0], g.D, f.H1, f.relu, f.ah1 + (size_t)i * f.H1);
     first_layer_row(f.aW1, f.ab1, xs[1], g.D, f.H1, f.relu, f.ah1 + (size_t)(g.B + i) * f.H1);
 #pragma unroll
@@ -498,13 +534,29 @@ struct ActorHeadFusedArgs {
     // first layer of the two TARGET critics on (next obs, next action), when the input is narrow (first_l1 != 0): z = 2, 3 of the four-net forward
     int first_l1, H1, relu; const float* P; int qw1, qb1; long long zP, zh; float* qh1;
 };
+// PRE (narrow spaces: D + A <= 4, H1 <= 512 when first_l1): everything the later phases read from memory and that does not depend on this kernel's results is
+// requested at the top — the noise of the three samples and the two observation rows (lane 0 of waves 0 - 2), the first-layer weights of the two target critics
+// (all threads) — and the (next obs, next action) row reaches the first layers through LDS: the kernel was four dependent round trips long, now two.
+template <bool PRE>
 __global__ __launch_bounds__(256) void sac_actor_out_ent_kernel(ActorHeadFusedArgs f) {
     __shared__ double sh[256];
     __shared__ float mus[2][kMaxA];
     __shared__ double ssum;
+    __shared__ float xn[kFusedL1MaxIn];
     const EntNextArgs& g = f.e;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = blockIdx.x;
     float ls[kMaxA]; for (int a = 0; a < g.A; ++a) ls[a] = g.log_std[a];
+    L1Pre pq[2];
+    float nz[kL1PreMaxIn], xrow[kL1PreMaxIn];
+    if constexpr (PRE) {
+        if (f.first_l1) for (int z = 0; z < 2; ++z) first_layer_pre(pq[z], f.P + f.qw1 + (z + 2) * f.zP, f.P + f.qb1 + (z + 2) * f.zP, g.D + g.A, f.H1);
+        if (lane == 0 && wave < 3) {
+            const float* src = wave == 0 ? g.ne : wave == 1 ? g.nn : g.np;
+            const float* xr = g.xa + (size_t)((wave == 1 ? g.B : 0) + i) * g.D;
+#pragma unroll
+            for (int a = 0; a < kL1PreMaxIn; ++a) { nz[a] = a < g.A ? src[(size_t)i * g.A + a] : 0.f; xrow[a] = a < g.D ? xr[a] : 0.f; }
+        }
+    }
     // phase 1: mu = W3 h2 + b3 for row i (obs) and row B + i (next obs): (row, a) pairs over the four waves
     for (int p = wave; p < 2 * g.A; p += 4) {
         const int row = p / g.A, a = p - row * g.A;
@@ -516,24 +568,31 @@ __global__ __launch_bounds__(256) void sac_actor_out_ent_kernel(ActorHeadFusedAr
     if ((threadIdx.x & 63) == 0 && threadIdx.x < 192) {                          // phase 2: the three squashed samples of the row on lane 0 of three WAVES (libm-heavy scalar math: on three
         const int which = threadIdx.x >> 6;                                       // lanes of one wave the divergent branches ran one after the other — 3 x ~1.5 us of an 11 us kernel)
         float a_[kMaxA], gg[kMaxA];
-        if (which == 0) { if (g.auto_ent) ssum = (double)(squashed_sample_logp(mus[0], ls, g.ne + (size_t)i * g.A, g.A, a_, gg) + g.target_entropy); }
+        const float* noise = which == 0 ? g.ne + (size_t)i * g.A : which == 1 ? g.nn + (size_t)i * g.A : g.np + (size_t)i * g.A;
+        const float* xr = g.xa + (size_t)((which == 1 ? g.B : 0) + i) * g.D;
+        float lp;
+        if constexpr (PRE) lp = squashed_sample_logp(mus[which == 1 ? 1 : 0], ls, nz, g.A, a_, gg);
+        else lp = (which || g.auto_ent) ? squashed_sample_logp(mus[which == 1 ? 1 : 0], ls, noise, g.A, a_, gg) : 0.f;
+        auto xv = [&](int d) { if constexpr (PRE) { float v = xrow[0]; for (int t = 1; t < kL1PreMaxIn; ++t) v = d == t ? xrow[t] : v; return v; } else return xr[d]; };
+        if (which == 0) { if (g.auto_ent) ssum = (double)(lp + g.target_entropy); }
         else if (which == 1) {
-            g.nlp[i] = squashed_sample_logp(mus[1], ls, g.nn + (size_t)i * g.A, g.A, a_, gg);
-            for (int d = 0; d < g.D; ++d) g.xq_next[(size_t)i * (g.D + g.A) + d] = g.xa[(size_t)(g.B + i) * g.D + d];
-            for (int a = 0; a < g.A; ++a) g.xq_next[(size_t)i * (g.D + g.A) + g.D + a] = a_[a];
+            g.nlp[i] = lp;
+            const bool to_lds = f.first_l1 != 0;                                 // (first_l1 implies D + A <= kFusedL1MaxIn)
+            for (int d = 0; d < g.D; ++d) { const float v = xv(d); g.xq_next[(size_t)i * (g.D + g.A) + d] = v; if (to_lds) xn[d] = v; }
+            for (int a = 0; a < g.A; ++a) { g.xq_next[(size_t)i * (g.D + g.A) + g.D + a] = a_[a]; if (to_lds) xn[g.D + a] = a_[a]; }
         } else {
-            g.lp_pi[i] = squashed_sample_logp(mus[0], ls, g.np + (size_t)i * g.A, g.A, a_, gg);
-            for (int d = 0; d < g.D; ++d) g.xq_pi[(size_t)i * (g.D + g.A) + d] = g.xa[(size_t)i * g.D + d];
+            g.lp_pi[i] = lp;
+            for (int d = 0; d < g.D; ++d) g.xq_pi[(size_t)i * (g.D + g.A) + d] = xv(d);
             for (int a = 0; a < g.A; ++a) { g.xq_pi[(size_t)i * (g.D + g.A) + g.D + a] = a_[a]; g.a_pi[i * g.A + a] = a_[a]; g.g_pi[i * g.A + a] = gg[a]; }
         }
     }
     __syncthreads();
-    if (f.first_l1) {                                                             // thread 1 wrote this sample's (next obs, next action) row above
-        __shared__ float xn[kFusedL1MaxIn];
-        if (threadIdx.x < g.D + g.A) xn[threadIdx.x] = g.xq_next[(size_t)i * (g.D + g.A) + threadIdx.x];
-        __syncthreads();
+    if (f.first_l1) {                                                             // lane 0 of wave 1 left this sample's (next obs, next action) row in xn
 #pragma unroll
-        for (int z = 2; z < 4; ++z) first_layer_row(f.P + f.qw1 + z * f.zP, f.P + f.qb1 + z * f.zP, xn, g.D + g.A, f.H1, f.relu, f.qh1 + z * f.zh + (size_t)i * f.H1);
+        for (int z = 2; z < 4; ++z) {
+            if constexpr (PRE) first_layer_post(pq[z - 2], xn, g.D + g.A, f.H1, f.relu, f.qh1 + z * f.zh + (size_t)i * f.H1);
+            else first_layer_row(f.P + f.qw1 + z * f.zP, f.P + f.qb1 + z * f.zP, xn, g.D + g.A, f.H1, f.relu, f.qh1 + z * f.zh + (size_t)i * f.H1);
+        }
     }
     // the entropy-coefficient step itself (mean over the batch, scalar Adam) runs at the head of the next kernel that needs alpha (sac_q_out_head_kernel, mode 0):
     // every one of its blocks sums these B per-sample terms in the same order — cheaper than a grid-wide fold here (an atomic ticket, a fence and a second phase: ~7 us)
@@ -666,20 +725,118 @@ __device__ __forceinline__ float4 adam_vec(float* p, float* m, float* v, int i, 
     *reinterpret_cast<float4*>(p + i) = pp; *reinterpret_cast<float4*>(m + i) = mm; *reinterpret_cast<float4*>(v + i) = vv;
     return pp;
 }
+// ---- the first layer's parameter gradients INSIDE the optimiser kernels ------------------------------------------------------
+// [dW1 | db1] = dz1 . [x' | 1] of a narrow input (Pendulum: 3 / 4 features) is a (H1 x 5) x B contraction: 0.7 MFLOP in a launch of its own (7 us: the floor
+// of a dependent launch), followed by the optimiser kernel that consumes it — and, on the critic side, by another small launch that re-evaluates the first layer
+// with the stepped parameters for the actor loss.  Here extra blocks at the END of the optimiser kernel's grid own the first layer: a block takes kOptL1Units hidden
+// units of one net; thread = (unit, one of 16 sample groups): per-thread sums over its samples (all loads in flight), the 16 groups folded through LDS in
+// index order (deterministic), 5 x 16 threads then write the gradient (dril_sac_get_last_grads), take the Adam step and — x2 given — all threads evaluate the
+// layer on x2 with the stepped parameters in the order of first_layer_row.  The elementwise loop of the kernel skips these parameters.
+constexpr int kOptL1MaxIn = 4, kOptL1Units = 16, kOptL1Groups = 16, kOptL1MaxB = 1024;      // (2 B in floats of dynamic LDS: 32 KB at the cap)
+struct FirstLayerOpt {
+    int nblocks;                      // 0: off.  Z * ceil(H1 / kOptL1Units) blocks behind the elementwise ones
+    int Z, in, H1, B, relu;
+    int w1, b1; long long zP;         // W1 (H1 x in, column-major) / b1 of net z at index w1 / b1 + z zP of the kernel's parameter, moment and gradient arrays
+    const float* dz1; long long zdz;  // [Z][B][H1]
+    const float* x; int ldx;          // [B][ldx] rows (the same input for every z)
+    const float* x2; float* h1; long long zh;   // x2 != null: h1[z][b][:] = act(W1 x2[b] + b1) with the stepped parameters; x2 [B][in]
+};
+__device__ __forceinline__ double first_layer_opt_block(const FirstLayerOpt& f, int blk, float* p, float* m, float* v, float* g,
+                                                        float lr, float b1c, float b2c, float eps, float bt1, float bt2) {
+    // ONE round of memory latency: the block's dz1 values (16 per thread at B = 256), both input matrices (into LDS) and the parameters / moments it will step are
+    // all requested before anything waits
+    extern __shared__ __attribute__((aligned(16))) float fl_x[];      // [B][4] x, then [B][4] x2 (launch: first_layer_opt_lds bytes)
+    __shared__ float part[kOptL1Groups][kOptL1MaxIn + 1][kOptL1Units];
+    __shared__ float wnew[kOptL1MaxIn + 1][kOptL1Units];
+    const int nbu = (f.H1 + kOptL1Units - 1) / kOptL1Units, z = blk / nbu, u = threadIdx.x & (kOptL1Units - 1), grp = threadIdx.x / kOptL1Units;
+    const int unit = (blk - z * nbu) * kOptL1Units + u;
+    const bool live = unit < f.H1;
+    const float* __restrict__ dz = f.dz1 + (size_t)z * f.zdz + (live ? unit : 0);
+    float4* xs = reinterpret_cast<float4*>(fl_x); float4* x2s = xs + f.B;      // rows padded to four features (zeros): one ds_read_b128 per sample, no branches on `in`
+    const int kk = threadIdx.x / kOptL1Units;                         // the parameter row this thread steps (threads < 5 x 16): k < in a column of W1, k == 4 the bias
+    const bool steps = threadIdx.x < (kOptL1MaxIn + 1) * kOptL1Units && live && (kk < f.in || kk == kOptL1MaxIn);
+    const int idx = (int)(z * f.zP) + (kk == kOptL1MaxIn ? f.b1 + unit : f.w1 + unit + kk * f.H1);
+    float p0 = 0.f, m0 = 0.f, v0 = 0.f;
+    if (steps) { p0 = p[idx]; m0 = m[idx]; v0 = v[idx]; }
+    float acc[kOptL1MaxIn + 1];
+#pragma unroll
+    for (int k = 0; k <= kOptL1MaxIn; ++k) acc[k] = 0.f;
+    for (int b0 = 0; b0 < f.B; b0 += kOptL1Groups * 16) {
+        float d[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int b = b0 + grp + kOptL1Groups * j; d[j] = dz[(size_t)(b < f.B ? b : f.B - 1) * f.H1]; }
+        if (b0 == 0) {
+            for (int i = threadIdx.x; i < f.B * kOptL1MaxIn; i += blockDim.x) {
+                const int b = i / kOptL1MaxIn, k = i % kOptL1MaxIn;
+                fl_x[i] = k < f.in ? f.x[(size_t)b * f.ldx + k] : 0.f;
+                if (f.x2) fl_x[(size_t)f.B * kOptL1MaxIn + i] = k < f.in ? f.x2[(size_t)b * f.in + k] : 0.f;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int b = b0 + grp + kOptL1Groups * j;
+            const float dd = b < f.B ? d[j] : 0.f;                    // (rows past B re-read the last one and count as zero)
+            const float4 xv = xs[b < f.B ? b : f.B - 1];
+            acc[0] = fmaf(dd, xv.x, acc[0]); acc[1] = fmaf(dd, xv.y, acc[1]); acc[2] = fmaf(dd, xv.z, acc[2]); acc[3] = fmaf(dd, xv.w, acc[3]);
+            acc[kOptL1MaxIn] += dd;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k <= kOptL1MaxIn; ++k) part[grp][k][u] = acc[k];
+    __syncthreads();
+    double ss = 0;
+    if (threadIdx.x < (kOptL1MaxIn + 1) * kOptL1Units) {
+        float gs = 0.f, np_ = 0.f;
+#pragma unroll
+        for (int q = 0; q < kOptL1Groups; ++q) gs += part[q][kk][u];
+        if (steps) {                                                   // adam_one on the values requested at the top
+            if (g) g[idx] = gs;
+            const float mm = b1c * m0 + (1.0f - b1c) * gs, vv = b2c * v0 + (1.0f - b2c) * gs * gs;
+            m[idx] = mm; v[idx] = vv;
+            np_ = p0 - mm / (1.0f - bt1) / (sqrtf(vv / (1.0f - bt2)) + eps) * lr;
+            p[idx] = np_;
+            ss = (double)gs * gs;
+        }
+        wnew[kk][u] = np_;                                             // (rows k >= in: zero weights against the zero padding of x2)
+    }
+    if (!f.x2) return ss;
+    __syncthreads();
+    const float w0 = wnew[0][u], w1 = wnew[1][u], w2 = wnew[2][u], w3 = wnew[3][u], bb = wnew[kOptL1MaxIn][u];
+    float* __restrict__ out = f.h1 + (size_t)z * f.zh + unit;
+#pragma unroll 4
+    for (int b = grp; b < f.B; b += kOptL1Groups) {
+        const float4 xv = x2s[b];
+        float a = fmaf(w0, xv.x, bb); a = fmaf(w1, xv.y, a); a = fmaf(w2, xv.z, a); a = fmaf(w3, xv.w, a);      // the order of first_layer_row (+ exact zero terms)
+        if (live) out[(size_t)b * f.H1] = f.relu ? relu_nan(a) : tanhf(a);
+    }
+    return ss;
+}
+inline size_t first_layer_opt_lds(const FirstLayerOpt& f) { return f.nblocks ? (size_t)2 * f.B * kOptL1MaxIn * sizeof(float) : 0; }
+// is element i one of the first-layer parameters those blocks own (net_off: b1 follows W1, so a net's run is (in + 1) H1 long — a multiple of 4 when H1 % 4 == 0)
+__device__ __forceinline__ bool first_layer_opt_owns(const FirstLayerOpt& f, int i) {
+    if (!f.nblocks) return false;
+    for (int z = 0; z < f.Z; ++z) { const int o = i - (f.w1 + (int)(z * f.zP)); if (o >= 0 && o < (f.in + 1) * f.H1) return true; }
+    return false;
+}
 constexpr int kSacAdamBlocks = DRIL_SAC_ADAM_BLOCKS;   // grid cap of the two elementwise optimiser kernels (measured: see the Makefile-free default below)
-struct AdamRangeArgs { float* p; float* m; float* v; const float* g; int n; float lr, b1, b2, eps, bt1, bt2; double* sumsq_partials; };
+struct AdamRangeArgs { float* p; float* m; float* v; float* g; int n; float lr, b1, b2, eps, bt1, bt2; double* sumsq_partials; FirstLayerOpt fl; };
 __global__ __launch_bounds__(256) void sac_adam_kernel(AdamRangeArgs a) {
     __shared__ double sh[256];
     double ss = 0;
+    const int nfl = a.fl.nblocks, nb = gridDim.x - nfl, eb = (int)blockIdx.x - nfl;   // the first nfl blocks own the first layers (the longest dependent chain of the launch: dispatched first), the rest are elementwise
     const bool vec = (a.n & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(a.m) | reinterpret_cast<uintptr_t>(a.v) | reinterpret_cast<uintptr_t>(a.g)) & 15) == 0;
-    if (vec) {                                                                      // the padded device layout: 16-byte rows
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n / 4; i += gridDim.x * 256) {
+    if (eb < 0) ss = first_layer_opt_block(a.fl, blockIdx.x, a.p, a.m, a.v, a.g, a.lr, a.b1, a.b2, a.eps, a.bt1, a.bt2);
+    else if (vec) {                                                                 // the padded device layout: 16-byte rows
+        for (int i = eb * 256 + threadIdx.x; i < a.n / 4; i += nb * 256) {
+            if (first_layer_opt_owns(a.fl, 4 * i)) continue;
             const float4 g = a.g ? *reinterpret_cast<const float4*>(a.g + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
             adam_vec(a.p, a.m, a.v, 4 * i, g, a.lr, a.b1, a.b2, a.eps, a.bt1, a.bt2);
             ss += (double)g.x * g.x + (double)g.y * g.y + (double)g.z * g.z + (double)g.w * g.w;
         }
     } else {
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
+        for (int i = eb * 256 + threadIdx.x; i < a.n; i += nb * 256) {
+            if (first_layer_opt_owns(a.fl, i)) continue;
             const float gi = a.g ? a.g[i] : 0.f;
             const float m = a.b1 * a.m[i] + (1.0f - a.b1) * gi, v = a.b2 * a.v[i] + (1.0f - a.b2) * gi * gi;
             a.m[i] = m; a.v[i] = v;
@@ -701,14 +858,18 @@ struct StepEndArgs {
     // actor loss heads, [n_ls][nhead] of the log_std gradient
     int nhead, B; const double *hp_critic, *hp_actor, *hp_ls; float* g_ls;
     unsigned long long* stamp;   // phase_stamp (null: none)
+    FirstLayerOpt fl;            // the actor's first layer: gradient + step in blocks of their own (nblocks = 0: its gradient is in g_actor like the rest)
+    float* g_actor_w;            // (writable alias of g_actor for those blocks)
 };
 // n_actor and n_q are multiples of 4 (the device layout pads every net to 16 bytes; pads hold zero parameters and zero gradients)
 __global__ __launch_bounds__(256) void sac_step_end_kernel(StepEndArgs a) {
     __shared__ double sh[256];
-    const int va = a.n_actor / 4, vq = a.n_q / 4;
+    const int va = a.n_actor / 4, vq = a.n_q / 4, nb = gridDim.x - a.fl.nblocks;
     double ss = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < va + vq; i += gridDim.x * 256) {
+    if ((int)blockIdx.x >= nb) ss = first_layer_opt_block(a.fl, blockIdx.x - nb, a.p, a.m, a.v, a.g_actor_w, a.lr, a.b1, a.b2, a.eps, a.bt1_a, a.bt2_a);
+    else for (int i = blockIdx.x * 256 + threadIdx.x; i < va + vq; i += nb * 256) {
         if (i < va) {
+            if (first_layer_opt_owns(a.fl, 4 * i)) continue;
             const float4 g = *reinterpret_cast<const float4*>(a.g_actor + 4 * i);
             adam_vec(a.p, a.m, a.v, 4 * i, g, a.lr, a.b1, a.b2, a.eps, a.bt1_a, a.bt2_a);
             ss += (double)g.x * g.x + (double)g.y * g.y + (double)g.z * g.z + (double)g.w * g.w;
@@ -948,7 +1109,7 @@ struct dril_sac_handle {
     unsigned int* counter = nullptr; int adam_blocks_c = 0, end_blocks = 0;
     SacScalars* sc_next = nullptr;   // ping-pong partner of `sc` (fused heads: the entropy step writes the new state here, then the two are swapped)
     double* head_partials = nullptr; unsigned int* head_counter = nullptr; unsigned* col_h1p = nullptr; unsigned* col_w2p = nullptr; int* col_flags = nullptr; int col_tag = 0, col_w2tag = 0; bool col_w2_dirty = true, f16_fwd = true, l2_attr_set = false;   // the f16-piece collection forward (sac_collect_l2_kernel)
-    unsigned long long* it_stamps = nullptr; int it_stamps_cap = 0; double wall_hz = 1e8; bool fused_heads = true; bool fused_collect = true; bool fused_fwd = true; bool trace_enqueue = false; std::vector<hipEvent_t> it_events; int iter_chunk = 64;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
+    unsigned long long* it_stamps = nullptr; int it_stamps_cap = 0; double wall_hz = 1e8; bool fused_heads = true; bool fused_dw1 = false; int fl_c = 0, fl_a = 0; bool fused_collect = true; bool fused_fwd = true; bool trace_enqueue = false; std::vector<hipEvent_t> it_events; int iter_chunk = 64;   // fused output-layer + head kernels (DRIL_SAC_NO_FUSED_HEADS=1: the round-1 launch sequence, A/B)
     float bt_actor[2], bt_critic[2], bt_ent[2]; int64_t grad_updates = 0; uint64_t update_counter = 0, aux_counter = 0;
     float target_entropy = 0, act_lo = -2.0f, act_hi = 2.0f; bool external = false;   // bounds of the agent-facing action space: Box(-2,2), Box(-1,1) under ScalingWrapperEnv
     // env
@@ -1031,7 +1192,7 @@ int net_forward(dril_sac_handle* h, const float* P, NetOff off, long long zP, in
 // reverse pass given dOut [Z][n][O]: parameter gradients into G (same layout as P; null = skip) and/or dX [Z][n][in] (null = skip)
 // have_dz2: the fused head kernel already wrote dz2 = (W3' dOut) .* act'(h2); then [dW3|db3], [dW2|db2] and dz1 share ONE launch (three independent contractions)
 int net_backward(dril_sac_handle* h, const float* P, NetOff off, long long zP, int in, int O, const float* X, int ldx, long long zX, int n,
-                 NetBufs b, const float* dOut, float* G, float* dX, int Z, bool have_dz2 = false) {
+                 NetBufs b, const float* dOut, float* G, float* dX, int Z, bool have_dz2 = false, bool skip_w1 = false) {
     const int H1 = h->H1, H2 = h->H2, mask = h->cfg.activation ? EPI_MASK_RELU : EPI_MASK_TANH;
     const long long zd = (long long)h->nq * H1;   // dz buffers are [2][nq][H] (H1 == H2 layouts are separate buffers)
     const bool big = (long long)((H2 + 31) / 32) * ((n + 31) / 32) * Z >= 2048;          // large batches: one launch per contraction (the pair kernel is the split-K shape)
@@ -1054,6 +1215,7 @@ int net_backward(dril_sac_handle* h, const float* P, NetOff off, long long zP, i
     w.C = G ? G + off.w1 : nullptr; w.sCm = 1; w.sCn = H1; w.zC = zP; w.M = H1; w.N = in + 1; w.K = n;
     g = gemm_args(); g.A = P + off.w1; g.sAm = H1; g.sAk = 1; g.zA = zP; g.B = h->dz1; g.sBk = 1; g.sBn = H1; g.zB = zd;               // dx = W1' dz1
     g.C = dX; g.sCm = 1; g.sCn = in; g.zC = (long long)h->nq * in; g.M = in; g.N = n; g.K = H1;
+    if (skip_w1) { if (dX) SDO(gemm(h, g, Z)); return DRIL_OK; }                     // [dW1 | db1] is computed by the optimiser kernel that follows (first_layer_opt_block)
     if (G && dX && !big) SDO(gemm_pair(h, w, Z, g, Z)); else { if (G) SDO(gemm(h, w, Z)); if (dX) SDO(gemm(h, g, Z)); }
     return DRIL_OK;
 }
@@ -1062,10 +1224,10 @@ NetBufs q_bufs(dril_sac_handle* h, float* h1, float* h2, float* out) { return Ne
 
 int ssync(dril_sac_handle* h) { SHIP(h, hipStreamSynchronize(h->stream)); return DRIL_OK; }
 
-int adam_range(dril_sac_handle* h, int lo, int n, const float* grads, const float* bt, double* ssq, int blocks) {
+int adam_range(dril_sac_handle* h, int lo, int n, float* grads, const float* bt, double* ssq, int blocks, FirstLayerOpt fl = FirstLayerOpt{}) {
     AdamRangeArgs a{h->params + lo, h->adam_m + lo, h->adam_v + lo, grads ? grads + lo : nullptr, n, h->cfg.learning_rate, h->cfg.adam_beta1,
-                    h->cfg.adam_beta2, h->cfg.adam_eps, bt[0], bt[1], ssq};
-    hipLaunchKernelGGL(sac_adam_kernel, dim3(blocks), dim3(256), 0, h->stream, a);
+                    h->cfg.adam_beta2, h->cfg.adam_eps, bt[0], bt[1], ssq, fl};
+    hipLaunchKernelGGL(sac_adam_kernel, dim3(blocks), dim3(256), first_layer_opt_lds(fl), h->stream, a);
     SHIP(h, hipGetLastError());
     return DRIL_OK;
 }
@@ -1097,7 +1259,8 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out, unsigned long long*
         double* hp_critic = h->head_partials; double* hp_actor = hp_critic + 2 * (size_t)hb; double* hp_ls = hp_actor + 2 * (size_t)hb; double* hp_ent = hp_ls + (size_t)kMaxA * hb;   // one region per head kernel
         ActorHeadFusedArgs af{en, h->ah2, h->H2, h->params + h->actor.w3, h->params + h->actor.b3, h->mu, hp_ent, h->head_counter,
                               l1 ? 1 : 0, h->H1, relu, h->params, h->q0.w1, h->q0.b1, h->Pqd, (long long)h->nq * h->H1, h->qh1};
-        hipLaunchKernelGGL(sac_actor_out_ent_kernel, dim3(hb), dim3(256), 0, h->stream, af);
+        if (W <= kL1PreMaxIn && (!l1 || h->H1 <= kL1PreMaxH)) hipLaunchKernelGGL(sac_actor_out_ent_kernel<true>, dim3(hb), dim3(256), 0, h->stream, af);
+        else hipLaunchKernelGGL(sac_actor_out_ent_kernel<false>, dim3(hb), dim3(256), 0, h->stream, af);
         if (h->cfg.auto_ent_coef) { h->bt_ent[0] *= h->cfg.adam_beta1; h->bt_ent[1] *= h->cfg.adam_beta2; }
         // critic: all four Q nets' hidden layers in one pass (z = 0,1 the critics on (obs, action), z = 2,3 the targets on (next obs, next action)), then output
         // layers + Bellman target + loss head + dz2 of the critics in one launch; [dW3|db3], [dW2|db2], dz1 in one launch; [dW1|db1]; Adam (:362)
@@ -1106,12 +1269,15 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out, unsigned long long*
                           0, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc, h->cfg.gamma, h->dq, h->stats, hp_critic, h->head_counter,
                           hp_ent, h->sc_next, h->cfg.auto_ent_coef, h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, ent_bt1, ent_bt2};
         hipLaunchKernelGGL(sac_q_out_head_kernel, dim3(hb), dim3(256), 0, h->stream, qc);
-        SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), h->dq, h->g_critic, nullptr, 2, true));
-        SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, ssq_row, h->adam_blocks_c));
+        const bool fl = h->fused_dw1;
+        SDO(net_backward(h, h->params, h->q0, h->Pqd, W, 1, h->xq, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_cur), h->dq, h->g_critic, nullptr, 2, true, fl));
+        FirstLayerOpt flc{};
+        if (fl) flc = FirstLayerOpt{h->fl_c, 2, W, h->H1, B, relu, 0, h->q0.b1 - h->q0.w1, h->Pqd, h->dz1, (long long)h->nq * h->H1, h->xq, W, h->xq_pi, h->qh1, (long long)h->nq * h->H1};
+        SDO(adam_range(h, h->q0.w1, 2 * h->Pqd, h->g_critic, h->bt_critic, ssq_row, h->adam_blocks_c, flc));
         h->bt_critic[0] *= h->cfg.adam_beta1; h->bt_critic[1] *= h->cfg.adam_beta2;
         // actor (:93-105) with the UPDATED critics: hidden layers, then output layers + loss head + dz2 in one launch; dz1; then the action columns of W1' dz1, the
         // reverse of the squashed sample and the actor's dz2 in one launch; the actor's [dW3|db3], [dW2|db2], dz1 in one launch; [dW1|db1]
-        SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), 2, 1, true));
+        SDO(net_forward(h, h->params, h->q0, h->Pqd, W, 1, h->xq_pi, W, 0, B, q_bufs(h, h->qh1, h->qh2, h->q_pi), 2, 1, true, fl));   // (fl: the critics' Adam launch already evaluated the first layer)
         QHeadFusedArgs qp{B, h->H2, h->nq, relu, 2, h->Pqd, (long long)h->nq * h->H2, h->params, h->q0.w3, h->q0.b3, h->qh2, h->q_pi, h->dz2,
                           1, h->b_rew, h->b_nlp, h->lp_pi, h->b_term, h->sc_next, h->cfg.gamma, h->dq, h->stats, hp_actor, h->head_counter,
                           nullptr, nullptr, 0, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1126,7 +1292,7 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out, unsigned long long*
         }
         SquashFusedArgs sf{sb, h->H1, h->H2, relu, h->nq, h->params, h->q0.w1, h->Pqd, h->dz1, h->params + h->actor.w3, h->ah2, h->dz2, hp_ls, h->head_counter};
         hipLaunchKernelGGL(sac_dx_squash_kernel, dim3(hb), dim3(256), 0, h->stream, sf);
-        SDO(net_backward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, B, actor_bufs(h), h->dmu, h->g_actor, nullptr, 1, true));
+        SDO(net_backward(h, h->params, h->actor, 0, D, A, h->xa, D, 0, B, actor_bufs(h), h->dmu, h->g_actor, nullptr, 1, true, fl));
         std::swap(h->sc, h->sc_next);                                                 // h->sc is the current state again for whoever reads it next
     } else {
         // actor means of (obs | next obs) in one pass: the entropy constant (:318-325) and the actor loss (:101) share the obs half,
@@ -1155,8 +1321,11 @@ int sac_one_update(dril_sac_handle* h, int slot, float* out, unsigned long long*
     StepEndArgs se{h->params, h->adam_m, h->adam_v, h->g_actor, round4(h->actor.end), h->log_std_off, A, h->q0.w1, 2 * h->Pqd,
                    h->cfg.learning_rate, h->cfg.adam_beta1, h->cfg.adam_beta2, h->cfg.adam_eps, h->bt_actor[0], h->bt_actor[1], h->bt_critic[0], h->bt_critic[1],
                    h->target, h->cfg.tau, do_polyak, ssq_row + h->adam_blocks_c, h->stats, out,
-                   h->fused_heads ? hb : 0, B, h->head_partials, h->head_partials + 2 * (size_t)hb, h->head_partials + 4 * (size_t)hb, h->g_actor + h->log_std_off, stamp};
-    hipLaunchKernelGGL(sac_step_end_kernel, dim3(h->end_blocks), dim3(256), 0, h->stream, se);
+                   h->fused_heads ? hb : 0, B, h->head_partials, h->head_partials + 2 * (size_t)hb, h->head_partials + 4 * (size_t)hb, h->g_actor + h->log_std_off, stamp,
+                   FirstLayerOpt{}, h->g_actor};
+    if (h->fused_heads && h->fused_dw1)      // the actor's [dW1 | db1] = dz1 . [obs' | 1] and its step: blocks of this launch
+        se.fl = FirstLayerOpt{h->fl_a, 1, D, h->H1, B, relu_, h->actor.w1, h->actor.b1, 0, h->dz1, 0, h->xa, D, nullptr, nullptr, 0};
+    hipLaunchKernelGGL(sac_step_end_kernel, dim3(h->end_blocks), dim3(256), first_layer_opt_lds(se.fl), h->stream, se);
     SHIP(h, hipGetLastError());
     h->bt_actor[0] *= h->cfg.adam_beta1; h->bt_actor[1] *= h->cfg.adam_beta2;
     h->bt_critic[0] *= h->cfg.adam_beta1; h->bt_critic[1] *= h->cfg.adam_beta2;
@@ -1416,6 +1585,9 @@ DRIL_EXPORT int32_t dril_sac_create(const dril_sac_config* cfg, dril_sac_handle*
     h->target = h->params + h->q0.w1 + 2 * h->Pqd;   // the targets sit right behind the critics so that one launch runs all four Q nets (blockIdx.z stride Pqd)
     CHK(smalloc(&h->g_critic, h->Pd)); CHK(smalloc(&h->g_actor, h->Pd)); CHK(smalloc(&h->sc, 1)); CHK(smalloc(&h->sc_next, 1)); CHK(smalloc(&h->stats, 8));
     h->adam_blocks_c = std::min(kSacAdamBlocks, (2 * h->Pqd + 255) / 256); h->end_blocks = std::min(kSacAdamBlocks, ((h->actor.end + 3) / 4 + 2 * h->Pqd / 4 + 255) / 256);   // elementwise optimiser kernels: up to 1 024 blocks (no grid-wide fold is left in them; 256 -> 1 024: update! 0.174 -> 0.168 ms)
+    // narrow first layers: their gradient, step and (critics) re-evaluation inside the optimiser kernels (first_layer_opt_block; DRIL_SAC_NO_FUSED_DW1=1: launches of their own)
+    h->fused_dw1 = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr && std::getenv("DRIL_SAC_NO_FUSED_DW1") == nullptr && W <= kOptL1MaxIn && H1 % 4 == 0 && B <= kOptL1MaxB;
+    if (h->fused_dw1) { h->fl_a = (H1 + kOptL1Units - 1) / kOptL1Units; h->fl_c = 2 * h->fl_a; h->adam_blocks_c += h->fl_c; h->end_blocks += h->fl_a; }
     CHK(smalloc(&h->counter, 1));
     CHK(smalloc(&h->head_partials, (size_t)(2 * kMaxA + 8) * ((B + kHeadSamplesPerBlock - 1) / kHeadSamplesPerBlock + 1))); CHK(smalloc(&h->head_counter, kMaxA + 1));   // doubles: [critic 2 | actor 2 | log_std kMaxA | entropy 2] x blocks
     h->fused_heads = std::getenv("DRIL_SAC_NO_FUSED_HEADS") == nullptr; h->fused_collect = std::getenv("DRIL_SAC_NO_FUSED_COLLECT") == nullptr; h->fused_fwd = std::getenv("DRIL_SAC_NO_FUSED_FWD") == nullptr; h->f16_fwd = std::getenv("DRIL_SAC_NO_F16_FWD") == nullptr; h->trace_enqueue = false;   // latched here: no getenv on the update path

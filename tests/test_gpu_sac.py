@@ -110,6 +110,32 @@ def test_update_matches_oracle(pkg, act, auto_ent, interval, hidden, B):
         assert h.get_log_ent_coef() == pytest.approx(o.get_log_ent_coef(), rel=1e-5, abs=1e-6)
 
 
+@pytest.mark.parametrize("act,hidden,B", [("relu", (512, 512), 256), ("tanh", (40, 24), 7), ("relu", (100, 64), 50)])
+def test_first_layer_gradient_inside_the_optimiser_kernels_equals_the_contraction_form(pkg, monkeypatch, act, hidden, B):
+    """[dW1 | db1] of the narrow first layers, their Adam step and the critics' re-evaluated first layer come from blocks of sac_adam_kernel / sac_step_end_kernel
+    (first_layer_opt_block) by default and from launches of their own under DRIL_SAC_NO_FUSED_DW1=1 (the sequence of rounds 1 - 3): the same sums in a different
+    order — gradients, statistics, parameters and targets after four steps agree to summation-order rounding"""
+    res = []
+    rng = np.random.default_rng(5)
+    rb = random_replay(rng, 400)
+    idx = rng.integers(0, 400, (4, B)); nz = [rng.normal(0, 1, (4, B, 1)).astype(np.float32) for _ in range(3)]
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("DRIL_SAC_NO_FUSED_DW1", "1")
+        h, _, layer, _ = make_pair(pkg, hidden=hidden, B=B, act=act, learning_rate=3e-3, tau=0.05)
+        monkeypatch.delenv("DRIL_SAC_NO_FUSED_DW1", raising=False)
+        h.set_params(init_params(pkg, layer)); h.replay_fill(*rb); h.set_batches(4, idx, *nz)
+        st = h.update(4)
+        res.append((st, h.last_grads(), h.get_params(), h.get_target_params()))
+    (s1, (gc1, ga1), p1, t1), (s2, (gc2, ga2), p2, t2) = res
+    for a, b in zip(s1, s2):
+        for f in ("critic_loss", "actor_loss", "mean_q_values", "grad_norm", "entropy_loss"):
+            assert getattr(a, f) == pytest.approx(getattr(b, f), rel=2e-5, abs=1e-6), f
+    close(gc1, gc2, rtol=2e-5, atol=2e-6 * max(1.0, np.abs(gc2).max())); close(ga1, ga2, rtol=2e-5, atol=2e-6 * max(1.0, np.abs(ga2).max()))
+    assert np.abs(gc2).max() > 0 and np.abs(ga2).max() > 0
+    close(p1, p2, rtol=5e-5, atol=2e-6); close(t1, t2, rtol=2e-5, atol=1e-6)
+
+
 def test_many_updates_in_one_call_and_reset_optimizer(pkg):
     h, o, layer, _ = make_pair(pkg, B=32, learning_rate=1e-3)
     flat = init_params(pkg, layer)

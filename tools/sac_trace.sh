@@ -15,7 +15,7 @@ t0 = int(rows[a]["Start_Timestamp"])
 with open("$OUT/iteration.txt", "w") as o:
     for r in rows[a:b]:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-        n = r["Kernel_Name"].split("(")[0].replace("dril::(anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+        n = r["Kernel_Name"].replace("dril::(anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ", "").replace("dril::", "").split("(")[0].split("<")[0]
         line = f"{(s - t0) / 1e3:8.1f} us  +{(e - s) / 1e3:6.1f} us  grid {r['Grid_Size_X']:>7}x{r['Grid_Size_Y']:>4}x{r['Grid_Size_Z']:>2} wg {r['Workgroup_Size_X']:>4}  lds {r.get('LDS_Block_Size', '?'):>6}  {n}"
         print(line); o.write(line + "\n")
     tot = (int(rows[b]["Start_Timestamp"]) - t0) / 1e3
