@@ -264,8 +264,13 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             f32x16 h1r;
             if (kKeepH1) h1r = h1k; else pair_load_pieces2<kP1B>(lds, opaque(ownT), h1r);  // kActScale h1 of tile w back from its own pieces (to 2^-24)
             constexpr float c0 = kInvTanhScale / kWScale, c1 = c0 / (kActScale * kActScale);   // g1 = (kTanhScale kWScale W2' . SG dz2) (1 - h1^2) / (kTanhScale kWScale) = SG dz1
+            if constexpr (WIDE_IN) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[r] = g1[r] * fmaf(-t2, c1, c0); }
+                for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[r] = g1[r] * fmaf(-t2, c1, c0); }
+            } else {                                                                      // SG dz1 / c1: the constant waits for the epilogue (dW1 | db1 are its only readers) — one multiply per element less
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g1[r] = g1[r] * fmaf(-h1r[r], h1r[r], kActScale * kActScale);
+            }
         }
         STAMP(6);
         // ---- dW1 | db1: per-lane accumulation, dW1[unit][d] += dz1[unit][sample] x[sample][d] (D <= 4); D > 4: dz1' [x | 1] on the matrix cores ----
@@ -335,6 +340,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     const int o_w1 = 0, o_b1 = H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + H * H, o_w3 = o_b2 + H, o_b3 = o_w3 + O * H;
     const int o_ls = o_b3 + O, o_st = SL - 8;
     float* slab = (HEAD == HEAD_VALUE ? a.slabs_critic : a.slabs_actor) + (size_t)nb * SL;
+    const float inv_s1 = inv_sg * ((kInvTanhScale / kWScale) / (kActScale * kActScale));   // the per-lane dW1 | db1 sums carry SG / c1 (the dz1 mask above)
     const float inv_sa = inv_sg * (1.0f / kActScale);                                  // products with an activation operand carry SG kActScale, the others SG (powers of two: exact)
     auto emit = [&](auto&& put) {
 #pragma unroll
@@ -347,10 +353,10 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             const float b2 = half_sum(db2acc[r]) * inv_sg;
             if (c == 0) put(o_b2 + unit, b2);
             if constexpr (!WIDE_IN) {
-                const float b1 = half_sum(db1acc[r]) * inv_sg;
+                const float b1 = half_sum(db1acc[r]) * inv_s1;
                 if (c == 0) put(o_b1 + unit, b1);
 #pragma unroll
-                for (int d = 0; d < D; ++d) { const float v = half_sum(dW1acc[d][r]) * inv_sg; if (c == 0) put(o_w1 + unit + d * H, v); }
+                for (int d = 0; d < D; ++d) { const float v = half_sum(dW1acc[d][r]) * inv_s1; if (c == 0) put(o_w1 + unit + d * H, v); }
             } else {                                                                  // column c of the MFMA accumulator: observation component c, or the bias
                 const float v = dW1acc[0][r] * (inv_sg * (1.0f / 16.0f));
                 if (c < D) put(o_w1 + unit + c * H, v); else if (c == D) put(o_b1 + unit, v);
