@@ -378,7 +378,11 @@ template <int D, int H, int O> struct NetLdsSplit {
     static constexpr int W2P = SMALL_END;                    // two f16 pieces x [64][64] = 2 x 8192 bytes
     static constexpr int END = W2P + 2 * H * H / 2;          // in floats
 };
-__device__ __forceinline__ int w2img_gw(int r) { return (((r >> 1) & 1) << 3) | (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 4) & 1); }
+// 16-byte slot swizzle of the forward's W2 piece image (128-byte rows; lane c reads slot 2 j + h of row c with one ds_read_b128: the row-read pattern of the update kernels'
+// images, dril_split_pieces.h wimg_g<64>).  A slot holds the EIGHT k values half-wave h contracts in k16 step j — k = 16 j + 4 h + {0..3} and 16 j + 8 + 4 h + {0..3}, the k order
+// of a register B operand — so the A fragment is one 16-byte read per piece.  (Until round 4 the row was in plain k order: two 8-byte reads per piece, regrouped into the
+// operand's four consecutive registers by 4 - 6 v_mov per MFMA group: 160 of the ~1 200 vector instructions of a rollout step.)
+__device__ __forceinline__ int w2img_gw(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 __device__ __forceinline__ int timg_gs(int r) { return (((r >> 1) & 1) << 3) | (((r >> 2) & 1) << 2) | (((r >> 3) & 1) << 1) | (r & 1); }
 
 template <int D, int H, int O>
@@ -393,7 +397,8 @@ __device__ inline void stage_net_split(float* lds, const float* __restrict__ P, 
         const int o = i % H, kp = i / H;
         unsigned hi, lo;
         split2_pair((kTanhScale * kWScale) * P[n.w2 + o + H * (2 * kp)], (kTanhScale * kWScale) * P[n.w2 + o + H * (2 * kp + 1)], hi, lo);
-        const int byte = o * 128 + ((((kp >> 1) ^ w2img_gw(o)) & 15) << 3) + ((kp & 1) << 2);
+        const int j = kp >> 3, x = (kp >> 1) & 3;                  // k16 step; quarter of the step (k = 16 j + 4 x + 2 (kp & 1) + {0, 1})
+        const int byte = o * 128 + (((2 * j + (x & 1)) ^ w2img_gw(o)) << 4) + ((x >> 1) << 3) + ((kp & 1) << 2);
         *reinterpret_cast<unsigned*>(img + byte) = hi; *reinterpret_cast<unsigned*>(img + 8192 + byte) = lo;
     }
 }
@@ -409,7 +414,7 @@ __device__ __forceinline__ void net_forward_split(const float* __restrict__ lds,
     constexpr int MT = H / 32;
     const int c = lane & 31, h = lane >> 5;
     const char* Wimg = reinterpret_cast<const char*>(lds + L::W2P);
-    const int wf_base = c * 128 + (((h ^ w2img_gw(c)) & 15) << 3);
+    const int wf_base = c * 128 + ((h ^ w2img_gw(c)) << 4);
     f32x16 h1[MT], acc[MT];
     dense_first<H, MT, FirstLayer<D>::KS>(lds + L::W1T, lds + L::B1, xk, h1, lane);
 #pragma unroll
@@ -437,7 +442,7 @@ __device__ __forceinline__ void net_forward_split(const float* __restrict__ lds,
                 f16x8 A[2];
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
-                    A[p] = __builtin_bit_cast(f16x8, frag8(*reinterpret_cast<const u32x2*>(Wimg + 8192 * p + a0), *reinterpret_cast<const u32x2*>(Wimg + 8192 * p + (a0 ^ 16))));
+                    A[p] = *reinterpret_cast<const f16x8*>(Wimg + 8192 * p + a0);
                 acc[mo] = mfma_split3(A[0], A[1], chunk_frag(pc, 0), chunk_frag(pc, 1), acc[mo]);
             }
         }
