@@ -109,3 +109,26 @@ def test_real_worker_on_a_one_gpu_box_a_missing_device_fails_the_whole_job():
     assert r.returncode != 0 and not r.stdout.strip(), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
     assert "rank 1 exited with code" in r.stderr and "all ranks ended, no result line" in r.stderr, r.stderr[-1500:]
     assert time.monotonic() - t0 < 300
+
+
+def test_roofline_helpers_price_what_they_say():
+    """bench.py's pure functions (no GPU): the §8(d) table of the bandwidth-class kernels — algorithmic bytes / HIP-event time / 8 TB/s — from a profile() dict in which only
+    every 8th launch of the per-step kernels was bracketed (total_ms = timed average x all launches), and the ceiling each arithmetic is priced against"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    N, P, steps, epochs = 1 << 20, 9155, 2, 10
+    prof = {"rollout_kernel": {"total_ms": 2.0, "launches": 2, "timed_ms": 2.0, "timed_launches": 2},
+            "gae_kernel": {"total_ms": 0.02, "launches": 2, "timed_ms": 0.02, "timed_launches": 2},
+            "adam_kernel": {"total_ms": 3.2, "launches": 640, "timed_ms": 0.4, "timed_launches": 80},
+            "adv_moments_kernel": {"total_ms": 0.0, "launches": 0, "timed_ms": 0.0, "timed_launches": 0}}
+    rows = {r["kernel"]: r for r in b.hbm_kernels(prof, N=N, D=4, A=2, discrete=True, P=P, epochs=epochs, steps=steps, normalize=False)}
+    assert set(rows) == {"rollout_kernel", "gae_kernel", "adam_kernel"}                      # classes without launches are left out
+    g = rows["gae_kernel"]
+    assert g["bytes_per_unit"] == 18 and g["achieved_GBps"] == 18 * N * steps / 0.02e-3 / 1e9 and g["frac"] == g["achieved_GBps"] / 8000.0
+    a = rows["adam_kernel"]
+    assert a["launches"] == 640 and a["achieved_GBps"] == 28 * P * 640 / 3.2e-3 / 1e9      # per launch: all launches x the timed average
+    assert rows["rollout_kernel"]["bytes_per_unit"] == 4 * 4 + 4 + 14
+    r16 = b.mfma_roofline(228.0, "f16x2 split, f32 accumulate"); r32 = b.mfma_roofline(113.0, "f32")
+    assert abs(r16["peak"] - 2516.6 / 3) < 0.5 and abs(r32["peak"] - 157.3) < 0.1
+    assert r16["frac"] == 228.0 / r16["peak"] and r16["frac_vs_f32_peak"] == 228.0 / r16["f32_mfma_peak"] > 1 > r16["frac"]
