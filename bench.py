@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of one full PPO iteration (rollout + GAE + epochs x minibatches update) on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with
-torch.distributed.run (one rank per GPU).  A "step" = one PPO iteration of BASELINE.json configs[1]:
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 either under a launcher that sets
+WORLD_SIZE (torch.distributed.run: one rank per GPU) or plain, in which case this script starts its own N ranks
+(launch_ranks below).  A "step" = one PPO iteration of BASELINE.json configs[1]:
 CartPole-v1, n_envs = 65 536 per GPU, hidden [64,64], PPO defaults, n_steps = 2048, synthetic fixed-length
 episodes (termination disabled, truncation every 500 steps), batch_size = N/32 (BASELINE.json leaves it open;
-SURVEY.md §8d) — all state resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+SURVEY.md §8d) — all state resident in HBM before the timed region.  Prints ONE JSON line on rank 0, kept under 8 KB
+(the driver keeps the last 8 KB of stdout): the other configs' runs appear in it as compact `secondary` entries and
+in full on stderr (`--full`: in full in the line).
 
 N > 1: envs are sharded (weak scaling, 65 536 per GPU), the only data-path collective is the RCCL all-reduce of
 [gradients | loss sums] per optimiser step (+ the 3-double advantage-moment reduce), issued inside the library
@@ -177,7 +180,7 @@ def run_sac(pkg, *, steps: int, warmup: int, iters: int, E: int = 4096, H: int =
     return out
 
 
-def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int, epochs: int, normalize: bool, steps: int, warmup: int, events: int = 8,
+def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int, epochs: int, normalize: bool, steps: int, warmup: int, events: int = 7,
             batch_size: int | None = None, fixed_length: bool = True, label: str = "", rank: int = 0, local_rank: int = 0, world: int = 1, dist=None,
             grad_variant: str | None = None) -> dict | None:
     """one PPO workload: `warmup` untimed iterations, then exactly `steps` iterations (rollout + GAE + epochs x minibatches update) between a barrier +
@@ -198,11 +201,15 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
         if grad_variant is not None:
             os.environ.pop("DRIL_GRAD_VARIANT") if old_gv is None else os.environ.__setitem__("DRIL_GRAD_VARIANT", old_gv)
     h.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(42))))   # random-init weights of the named architecture
-    if world > 1:
+    force_ar = os.environ.get("DRIL_FORCE_ALLREDUCE", "0") not in ("", "0")      # one rank through RCCL (tests): the same all-reduce call sites, a 1-rank communicator
+    if world > 1 or force_ar:
+        # banner BEFORE the communicator: if ncclCommInitRank hangs or fails, the record already says which device every rank had bound
+        rank_banner(rank, world, local_rank, h.device_info())
         uid = [h.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
         h.comm_init(uid[0])
-        progress(rank, f"RCCL communicator up: {h.comm_ranks()} ranks")
+        progress(rank, f"RCCL communicator up: ncclCommCount = {h.comm_ranks()} ranks")
         if h.comm_ranks() != world:        # what the communicator itself counts (ncclCommCount), not what the launcher asked for
             raise SystemExit(f"rank {rank}: the RCCL communicator has {h.comm_ranks()} ranks, --gpus asked for {world}")
     h.env_reset(42)
@@ -280,12 +287,21 @@ def run_ppo(pkg, *, env_name: str, E: int, T: int, hidden: int, minibatches: int
             kname, arith = info.split(": ", 1)
             out["dtype"] = "f32 (f16x2 split, f32 accumulate)" if "f16x2" in arith else "f32 (bf16x3 split, f32 accumulate)" if "bf16x3" in arith else "f32"
             out["roofline"] = dict(mfma_roofline(ach, arith), traffic=traffic, traffic_source=traffic_source, kernel=kname, avg_launch_ms=avg_ms,
-                                   avg_launch_ms_source=f"HIP events on the library's stream around every {'' if events == 1 else str(int(events)) + 'th '}launch of the timed region",
+                                   avg_launch_ms_source=f"HIP events on the library's stream around every {'' if events == 1 else str(int(events)) + 'th '}launch of the timed region"
+                                                        + ("" if events == 1 else f" (launch i of the class is bracketed when i % {int(events)} == 0, counted from the profile reset)"),
                                    timed_launches=gk["timed_launches"],
                                    rocprof_avg_launch_ms=rocprof_ms, launches=gk["launches"], flops_per_launch=flops,
                                    record_bytes_per_launch=(B_global // world) * 64)      # one 32-byte record per sample and net (the algorithmic gather volume of the record path)
             out["kernel_ms_per_step"] = {k: v["total_ms"] / steps for k, v in prof.items() if v["launches"]}
             out["hbm_kernels"] = hbm_kernels(prof, N=N_local, D=h.D, A=h.A, discrete=bool(h.discrete), P=h.P, epochs=epochs, steps=steps, normalize=normalize)
+            ar = prof.get("ncclAllReduce", {"total_ms": 0, "launches": 0})
+            if ar["launches"]:
+                # HIP events around the library's ncclAllReduce launches (the same thinning as the other per-step classes): time the stream spent in all-reduces per
+                # optimiser step — the gradient all-reduce of [P + 8] floats plus, amortised, the per-epoch moment table and the explained-variance sums
+                opt_steps = epochs * (-(-N_local * world // B_global)) * steps
+                out["allreduce_us_per_step"] = 1e3 * ar["total_ms"] / opt_steps
+                out["allreduce"] = {"launches": ar["launches"], "timed_launches": ar["timed_launches"], "avg_us_per_launch": 1e3 * ar["total_ms"] / ar["launches"],
+                                    "gradient_bytes": 4 * (h.P + 8), "ranks": h.comm_ranks()}
             rk = prof.get("rollout_kernel", {"total_ms": 0, "launches": 0})
             if rk["launches"]:                           # what the reference logs as env/fps (rollout_buffer.jl:60-64, ppo.jl:176): env steps per second of the collection alone (HIP events around the rollout)
                 out["rollout_only_env_steps_per_s"] = N_local * world * steps / (rk["total_ms"] * 1e-3)
@@ -304,9 +320,47 @@ def secondary_runs(pkg) -> list:
                        label="CartPole-v1 configs[1] on the exact-f32 kernels (DRIL_GRAD_VARIANT=0)"))
     out.append(run_ppo(pkg, env_name="pendulum", E=65536, T=2048, hidden=256, minibatches=32, epochs=10, normalize=True, steps=2, warmup=1))
     out.append(run_sac(pkg, steps=2, warmup=1, iters=500, cpu=False))
-    out.append(run_ppo(pkg, env_name="cartpole", E=4, T=2048, hidden=64, minibatches=0, epochs=10, normalize=False, steps=5, warmup=2, batch_size=64, fixed_length=False, events=1,
-                       label="CartPole-v1 configs[0] (README quick-start: MultiThreadedParallelEnv n_envs=4, PPO() defaults, batch_size 64)"))
+    c0 = run_ppo(pkg, env_name="cartpole", E=4, T=2048, hidden=64, minibatches=0, epochs=10, normalize=False, steps=5, warmup=2, batch_size=64, fixed_length=False, events=1,
+                 label="CartPole-v1 configs[0] (README quick-start: MultiThreadedParallelEnv n_envs=4, PPO() defaults, batch_size 64)")
+    c0["cpu_baseline"] = cpu_baseline_configs0(pkg, 42)      # the one shape where a CPU is close: the reference's own README case, the same iteration on the host cores
+    out.append(c0)
     return out
+
+
+def cpu_baseline_configs0(pkg, seed: int) -> dict:
+    """configs[0] on the CPU oracle: one full iteration of the README quick-start (4 envs x 2048 steps, real CartPole episodes, batch 64, 10 epochs = 1 280 optimiser
+    steps), timed whole — no extrapolation.  kind "port" (C restatement; the Julia reference cannot run here)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib
+    capi = pkg._capi
+    cfg = capi.default_config(capi.ENV_CARTPOLE)
+    cfg.n_envs, cfg.n_steps, cfg.episode_len, cfg.fixed_length_episodes, cfg.batch_size, cfg.epochs, cfg.seed = 4, 2048, 500, 0, 64, 10, seed
+    o = oracle_lib.Oracle(cfg)
+    layer = pkg.ActorCriticLayer(pkg.CartPoleEnv().observation_space(), pkg.CartPoleEnv().action_space())
+    o.set_params(pkg.flatten_params(layer.initialparameters(np.random.default_rng(seed))))
+    o.env_reset(seed)
+    o.collect_rollout(); o.ppo_update()          # warm-up iteration (page faults, OpenMP team start)
+    n = 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        o.collect_rollout(); o.ppo_update()
+    dt = time.perf_counter() - t0
+    return {"value": 4 * 2048 * n / dt, "unit": "env-steps/s", "cores": int(oracle_lib.lib().orc_num_threads()), "kind": "port",
+            "sample": f"C/OpenMP oracle: {n} full iterations of configs[0] (4 envs x 2048 steps + 10 epochs x 128 minibatches of 64) in {dt:.3f}s after one warm-up iteration"}
+
+
+def compact_entry(e: dict) -> dict:
+    """a secondary run as it appears inside the headline line: workload, value, its roofline numbers, its CPU figure — the full entry goes to stderr"""
+    r = e.get("roofline") or {}
+    c = {"workload": e["config"]["workload"].split(":")[0], "value": e["value"], "unit": e["unit"], "ms_per_step": e["ms_per_step"], "steps": e["steps"], "dtype": e.get("dtype")}
+    if r:
+        c["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "update_ms", "collect_step_ms") if k in r}
+        c["roofline"]["kernel"] = str(c["roofline"].get("kernel", ""))[:60]
+    if "cpu_baseline" in e:
+        c["cpu_baseline"] = {k: e["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind")}
+    for k in ("f32_retries", "allreduce_us_per_step"):
+        if k in e: c[k] = e[k]
+    return c
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -356,6 +410,7 @@ def launch_ranks(n: int, argv: list, total_timeout: float, silent_timeout: float
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONUNBUFFERED="1")
+        env.setdefault("NCCL_DEBUG", "WARN")      # a failing ncclCommInitRank / first collective must say why on stderr (which rank, device, transport); the caller's own setting wins
         p = subprocess.Popen([sys.executable, "-u", str(Path(__file__).resolve())] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                              start_new_session=True, cwd=str(ROOT))
         procs.append(p)
@@ -411,12 +466,21 @@ def progress(rank: int, msg: str) -> None:
 _T_START = time.perf_counter()
 
 
+def rank_banner(rank: int, world: int, local_rank: int, device_info: str) -> None:
+    """what every rank of a data-parallel job says BEFORE it enters ncclCommInitRank: which device it bound (ordinal, PCI bus id, visibility masks) and the two environment
+    settings a failing first contact is usually about — so that a hang or failure inside RCCL leaves a record that names the rank -> device map"""
+    progress(rank, f"BANNER rank {rank}/{world} local_rank {local_rank} -> {device_info}; NCCL_DEBUG={os.environ.get('NCCL_DEBUG', '(unset)')} "
+                   f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '(unset)')}")
+
+
 def stub_worker(args) -> int:
     """DRIL_BENCH_STUB=1 (tests/test_bench_launcher.py): a rank that loads NO library and touches no GPU — it proves the launcher's plumbing (environment of every
     rank, a real gloo rendezvous on MASTER_ADDR:MASTER_PORT, barrier + max over ranks, a failing rank, a silent rank, a rank-count mismatch)."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
+    keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG")
     sys.stderr.write("STUBENV " + json.dumps({k: os.environ.get(k) for k in keys}) + "\n"); sys.stderr.flush()
+    if world > 1:
+        rank_banner(rank, world, int(os.environ.get("LOCAL_RANK", "0")), "(stub worker: no library loaded, no device bound)")
     if os.environ.get("DRIL_BENCH_STUB_FAIL_RANK") == str(rank):
         progress(rank, "stub: failing on purpose"); return 7
     if os.environ.get("DRIL_BENCH_STUB_SILENT_RANK") == str(rank):
@@ -458,8 +522,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of configs[2] / configs[4] / configs[0] appended to the default line")
     ap.add_argument("--no-events", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--event-stride", type=int, default=8, help="bracket every K-th launch of the per-optimiser-step kernels with HIP events (1 = every launch; "
-                    "an event record costs the stream ~3.5 us, 960 launches an iteration: 2 %% of configs[1] at K = 1)")
+    ap.add_argument("--full", action="store_true", help="the secondary runs and the per-kernel bandwidth table in full inside the JSON line (default: compact there, full on stderr)")
+    ap.add_argument("--event-stride", type=int, default=7, help="bracket every K-th launch of the per-optimiser-step kernels with HIP events (1 = every launch; "
+                    "an event record costs the stream ~3.5 us, 960 launches an iteration: 2 %% of configs[1] at K = 1).  7 is coprime to the 32 minibatches of an epoch: the "
+                    "sampled launches visit every position of the epoch in turn (a stride of 8 always sampled positions 0, 8, 16, 24 — position 0 follows the epoch's index / moments kernels)")
     ap.add_argument("--launch-timeout", type=float, default=1800.0, help="--gpus N > 1 without WORLD_SIZE: seconds the self-started ranks may take in total")
     ap.add_argument("--silent-timeout", type=float, default=420.0, help="... and seconds one rank may stay without a progress line (the first import of a fresh box takes 1-2 min)")
     args = ap.parse_args()
@@ -502,7 +568,14 @@ def main() -> None:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, 42)
         if world == 1 and default_workload and not args.no_secondary:
-            out["secondary"] = secondary_runs(pkg)
+            full = secondary_runs(pkg)
+            for e in full:
+                sys.stderr.write("[bench secondary, full entry] " + json.dumps(e) + "\n")
+            sys.stderr.flush()
+            out["secondary"] = full if args.full else [compact_entry(e) for e in full]
+        if not args.full:
+            for row in out.get("hbm_kernels", []):
+                row.pop("what", None); row.pop("peak_GBps", None)      # the definitions are in docs/measurement.md; the line stays under the driver's 8 KB tail
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

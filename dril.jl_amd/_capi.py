@@ -177,6 +177,7 @@ _SIG = {
     "dril_comm_init": (C.c_int32, [_P, _P]),
     "dril_comm_ranks": (C.c_int32, [_P]),
     "dril_comm_allreduce_calls": (C.c_int64, [_P]),
+    "dril_device_info": (C.c_char_p, [_P]),
     "dril_debug_comm_loopback": (C.c_int32, [C.POINTER(_P), C.c_int32]),
     "dril_profile_get": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dril_profile_launches": (C.c_int32, [_P, C.c_int32, C.POINTER(C.c_int64)]),

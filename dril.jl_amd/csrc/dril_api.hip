@@ -34,6 +34,7 @@ struct RcclApi {
     int (*CommDestroy)(void*) = nullptr;
     int (*CommCount)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    const char* (*GetLastError)(void*) = nullptr;       // ncclGetLastError(comm): the human-readable cause behind a status code (which rank / device / transport)
 };
 struct NcclId { char bytes[128]; };
 typedef int (*nccl_init_rank_fn)(void**, int, NcclId, int);
@@ -49,10 +50,17 @@ bool load_rccl(std::string& err) {
     g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
     g_rccl.CommCount = (int (*)(void*, int*))dlsym(g_rccl.lib, "ncclCommCount");
+    g_rccl.GetLastError = (const char* (*)(void*))dlsym(g_rccl.lib, "ncclGetLastError");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce) { err = "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclAllReduce"; return false; }
     return true;
 }
 constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0;
+// "<call>: <ncclGetErrorString(rc)> [<ncclGetLastError(comm)>]": a failing first contact with a multi-GPU node must name its cause in dril_last_error
+std::string rccl_error(const char* call, int rc, void* comm) {
+    std::string m = std::string(call) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error") + " (status " + std::to_string(rc) + ")";
+    if (g_rccl.GetLastError) { const char* le = g_rccl.GetLastError(comm); if (le && *le) m += std::string(" [ncclGetLastError: ") + le + "]"; }
+    return m;
+}
 
 // ---- debug loopback communicator -----------------------------------------------------------------
 // RCCL refuses two ranks on one device, so the data-parallel code of this file (every `reduce` branch below) could only be
@@ -89,6 +97,7 @@ struct dril_handle {
     int64_t N = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
+    std::string device_info;   // "device <ordinal> of <visible>: <name> <arch>, PCI <bus id>, HIP_VISIBLE_DEVICES=.. ROCR_VISIBLE_DEVICES=.." (dril_device_info; part of every RCCL failure message)
     float *params = nullptr, *adam_m = nullptr, *adam_v = nullptr, *bt = nullptr, *flat = nullptr, *norm_out = nullptr;
     double* norm_partials = nullptr; int n_norm_partials = 0;
     float *slabs_a = nullptr, *slabs_c = nullptr; int slab_a = 0, slab_c = 0, Gmax = 0;
@@ -227,7 +236,7 @@ int rccl_allreduce(dril_handle* h, void* buf, size_t count, int dtype) {
     if (h->loop) { const int lrc = loop_allreduce(h, buf, count, dtype); prof_end(h); return lrc; }
     rc = g_rccl.AllReduce(buf, buf, count, dtype, kNcclSum, h->comm, h->stream);
     prof_end(h);
-    if (rc != 0) return fail(h, DRIL_ERR_RCCL, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+    if (rc != 0) return fail(h, DRIL_ERR_RCCL, rccl_error("ncclAllReduce", rc, h->comm) + "; " + h->device_info);
     return DRIL_OK;
 }
 
@@ -360,6 +369,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     // the f32 kernel, whose weight staging is cheaper (no operand split per workgroup) and which the launch-bound small path is tuned for
     int variant = 0;
     if (h->wide) variant = (wide_variant(h) && rec) ? 1 : 0;
+    if (h->wide && variant == 1) { const int64_t passes = (tiles + kWideSplitNT - 1) / kWideSplitNT; G = (int)(passes < h->Gmax ? passes : h->Gmax); if (G < 1) G = 1; }   // ppo_grad_wide_split_kernel takes kWideSplitNT sample tiles per pass
     if (!h->wide && !h->generic) {
         variant = h->grad_variant == 0 ? 0 : h->grad_variant > 0 ? 2 : (tiles >= kPairTilesPerCu * (int64_t)h->num_cus ? 2 : 0);   // large minibatches: the pair kernel
         if (variant == 2 && !(pair_variant(h) && rec && h->Gmax >= 2)) variant = 0;   // the pair kernel reads packed records and needs two slabs per workgroup (DRIL_GRAD_GMAX=1: not the pair kernel)
@@ -561,6 +571,12 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     hipDeviceProp_t prop; CCHK(hipGetDeviceProperties(&prop, cfg->device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { std::string m = std::string("libdril_hip targets gfx950 (MI355X) only; device is ") + prop.gcnArchName; dril_destroy(h); return fail(nullptr, DRIL_ERR_UNSUPPORTED, m); }
     h->num_cus = prop.multiProcessorCount;
+    {
+        char bus[64] = "?"; int ndev = -1; (void)hipDeviceGetPCIBusId(bus, (int)sizeof(bus), cfg->device); (void)hipGetDeviceCount(&ndev);
+        const char* hv = std::getenv("HIP_VISIBLE_DEVICES"); const char* rv = std::getenv("ROCR_VISIBLE_DEVICES");
+        h->device_info = "device " + std::to_string(cfg->device) + " of " + std::to_string(ndev) + " visible: " + prop.name + " " + prop.gcnArchName + ", " + std::to_string(prop.multiProcessorCount) + " CUs, PCI " + bus +
+                         ", HIP_VISIBLE_DEVICES=" + (hv ? hv : "(unset)") + " ROCR_VISIBLE_DEVICES=" + (rv ? rv : "(unset)");
+    }
     CCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const size_t E = cfg->n_envs, N = (size_t)h->N, P = h->P;
     CCHK(dmalloc(&h->params, P)); CCHK(dmalloc(&h->adam_m, P)); CCHK(dmalloc(&h->adam_v, P)); CCHK(dmalloc(&h->bt, 4));
@@ -1415,7 +1431,7 @@ DRIL_EXPORT int32_t dril_comm_unique_id(uint8_t id[128]) {
     if (!load_rccl(err)) return fail(nullptr, DRIL_ERR_RCCL, err);
     NcclId nid; std::memset(&nid, 0, sizeof(nid));
     const int rc = g_rccl.GetUniqueId(&nid);
-    if (rc != 0) return fail(nullptr, DRIL_ERR_RCCL, "ncclGetUniqueId failed");
+    if (rc != 0) return fail(nullptr, DRIL_ERR_RCCL, rccl_error("ncclGetUniqueId", rc, nullptr));
     std::memcpy(id, nid.bytes, 128);
     return DRIL_OK;
 }
@@ -1426,7 +1442,7 @@ DRIL_EXPORT int32_t dril_comm_init(dril_handle* h, const uint8_t id[128]) {
     NcclId nid; std::memcpy(nid.bytes, id, 128);
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int rc = ((nccl_init_rank_fn)(void*)g_rccl.CommInitRank)(&h->comm, h->cfg.world_size, nid, h->cfg.rank);
-    if (rc != 0) { h->comm = nullptr; return fail(h, DRIL_ERR_RCCL, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error")); }
+    if (rc != 0) { const std::string m = rccl_error("ncclCommInitRank", rc, nullptr) + "; rank " + std::to_string(h->cfg.rank) + " of " + std::to_string(h->cfg.world_size) + " on " + h->device_info; h->comm = nullptr; return fail(h, DRIL_ERR_RCCL, m); }
     return DRIL_OK;
 }
 
@@ -1456,6 +1472,7 @@ DRIL_EXPORT int32_t dril_comm_ranks(dril_handle* h) {
     return 1;
 }
 DRIL_EXPORT int64_t dril_comm_allreduce_calls(const dril_handle* h) { return h ? h->allreduce_calls : -1; }
+DRIL_EXPORT const char* dril_device_info(const dril_handle* h) { return h ? h->device_info.c_str() : ""; }
 
 // ---- measurement ----------------------------------------------------------------------------------------
 DRIL_EXPORT int32_t dril_profile_get(dril_handle* h, int32_t kid, double* total_ms, int64_t* launches) {

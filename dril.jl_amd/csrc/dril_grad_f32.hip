@@ -314,9 +314,7 @@ hipError_t launch_ppo_grad_f32(int kind, int hidden, const GradArgs& a, hipStrea
 #define CALLR(K, HH, R)                                                                                       \
     {                                                                                                         \
         const size_t lds = grad_lds_bytes<K, HH>();                                                           \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_kernel<K, HH, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e; attr_set = true; }                                                 \
+        { hipError_t e = set_max_dynamic_lds((const void*)ppo_grad_kernel<K, HH, R>, lds); if (e != hipSuccess) return e; } \
         ppo_grad_kernel<K, HH, R><<<2 * a.G, 256, lds, s>>>(a);                                               \
     }
 #define CALL(K, HH) { if (a.rec) CALLR(K, HH, true) else CALLR(K, HH, false) }

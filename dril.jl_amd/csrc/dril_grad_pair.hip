@@ -405,9 +405,9 @@ template <int KIND> static size_t grad_pair_lds_bytes() {
 
 hipError_t launch_ppo_grad_pair(int kind, const GradArgs& a, hipStream_t s) {
     if (kind == 7) kind = 4;                  // ScalingWrapperEnv(MountainCarContinuous): the update never touches the simulator
-#define CALLP(K) { const size_t lds = grad_pair_lds_bytes<K>(); static bool attr_set = false; \
+#define CALLP(K) { const size_t lds = grad_pair_lds_bytes<K>(); \
         if (2 * ((a.slab_a + 3) & ~3) > PairLds<EnvSpec<K>::D, EnvSpec<K>::A>::END || 2 * ((a.slab_c + 3) & ~3) > PairLds<EnvSpec<K>::D, 1>::END) return hipErrorInvalidValue;   /* the epilogue parks both pairs' slabs in the workgroup's LDS */ \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_pair_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
+        { hipError_t e = set_max_dynamic_lds((const void*)ppo_grad_pair_kernel<K>, lds); if (e != hipSuccess) return e; } \
         ppo_grad_pair_kernel<K><<<(a.G + a.Gc) / 2, 256, lds, s>>>(a); }
     if (kind == 0) CALLP(0) else if (kind == 3) CALLP(3) else if (kind == 4) CALLP(4) else if (kind == 6) CALLP(6) else CALLP(1)
 #undef CALLP

@@ -326,33 +326,38 @@ __global__ __launch_bounds__(H * 2, 2) void ppo_grad_wide_kernel(GradArgs a) {
 }
 
 // =============================================================================================
-// ppo_grad_wide_split_kernel — ppo_grad_wide_kernel with its three H x H contractions on the bf16 matrix cores (fp32-equivalent 3-piece operand
-// splitting, dril_device.h).  Same decomposition (a workgroup of H/32 waves owns a 32-sample tile, wave w the m-tile w of every layer and the
-// 32 x H slice of dW2), same four workgroup barriers per tile; what changes is the operand plumbing:
-//   * W2 / W2' stream from L2 as PRE-SPLIT bf16 fragments (build_wimg_split_kernel, once per optimiser step): [(mo*MT + mi)*2 + s][piece][lane][8 bf16],
-//     one 16-byte load per lane, piece and k16 step; 1.5 x the bytes of the f32 stream for a third of the matrix-pipe time.
-//   * activations: every wave splits its own 16 registers once and writes the packed pieces into ONE workgroup image per activation set,
-//     [piece][32 samples][H units] bf16, 16-byte chunk ch of row n stored at ch ^ g(n), g(n) = ((n & 3) << 2) | ((n >> 2) & 3).  The same image gives the
-//     B operand of a product that sums over units (ds_read_b128 along the row: 8 consecutive units of one sample) and both operands of the product
-//     that sums over samples (ds_read_b64_tr_b16: 4 samples x 16 units per 16-lane group); row reads, transposed reads and the 8-byte stores are all
-//     bank-conflict-free under that swizzle (the 4 rows of a transposed read land in the 4 different 64-byte windows, 16 consecutive rows in 16 different chunks).
-//     Two images (h1, dz2) of 192 H bytes replace the four f32 images XA, XB, TA and half of TB.
+// ppo_grad_wide_split_kernel — ppo_grad_wide_kernel with its three H x H contractions on the f16 matrix cores (fp32-equivalent two-piece operand
+// splitting, dril_device.h).  A workgroup of H/32 waves owns a tile of kWideSplitNT x 32 samples; wave w owns the m-tile w of every layer and the
+// 32 x H slice of dW2 (H/2 VGPRs).  Round 5 form:
+//   * W2 / W2' stream from L2 as PRE-SPLIT f16 fragments (build_wimg_split_kernel, once per optimiser step): [(mo*MT + mi)*2 + s][piece][lane][8 f16],
+//     one 16-byte load per lane, piece and k16 step.  At one 32-sample tile per pass that stream was the bound of the two streaming stages (2 x 256 KB
+//     per tile and CU at H = 256 = 42 B/clk/CU, 22 TB/s chip-wide against the L2's 34.5: profiles/r05_wide_split.md); every fragment now feeds the MFMAs
+//     of NT = 2 sample tiles, so the stream per sample is halved and the workgroup crosses its four barriers once per 64 samples.
+//   * activations: every wave splits its own 16 registers once and writes the packed pieces into ONE workgroup image per activation set and sample tile,
+//     [piece][32 samples][H units] f16, 16-byte chunk ch of row n stored at ch ^ g(n), g(n) = ((n & 3) << 2) | ((n >> 2) & 3).  The same image gives the
+//     operand of a product that sums over units (ds_read_b128 along the row: 8 consecutive units of one sample) and both operands of the product
+//     that sums over samples (ds_read_b64_tr_b16: 4 samples x 16 units per 16-lane group).
+//   * no f32 transpose images any more (36 KB at H = 256 — the room the second sample tile needed): the three small products that sum over SAMPLES get their operands another way.
+//       dh1 is computed TRANSPOSED — the same two register operands in the other order give D' — so its accumulator holds (lane = unit, register = sample): dz1 needs h1 in that
+//         layout (four transposed reads per piece from the h1 image), and dW1 | db1 become per-lane sums over the lane's 16 samples against x read as LDS broadcasts
+//         (D + 1 accumulators instead of two 16x16x4 MFMA tiles and a 4.6 KB image per wave);
+//       dW3: the products h2 dz are summed over the two sample tiles in registers and reduced across the lanes of a half-wave by the register-halving DPP
+//         reduce-scatter (half_reduce16_lane: ~52 VALU per output, once per 64 samples);
+//       db2: from the transposed f16 fragments of dz2 that the dW2 product loads anyway (v_dot2c_f32_f16 against ones).
 //   * no AGPRs: at two waves per SIMD the allocator gives a function that uses ANY AGPR only 128 VGPRs; the 128 dW2 accumulators are VGPR-form MFMA results like the rest.
+// LDS at H = 256: two piece images of 64 KB + ~12 KB of small parameters = 143 - 156 KB of the CU's 160 (one workgroup per CU, two waves per SIMD); H = 128: 72 KB, two workgroups per CU.
 // =============================================================================================
-template <int D, int H, int O> struct WideSplitScratch {
+template <int D, int H, int O, int NT> struct WideSplitScratch {
     static constexpr int MT = H / 32;
     static constexpr int SMALL = NetLdsSmall<D, H, O>::END;
-    static constexpr int P1 = (SMALL + 3) / 4 * 4;          // h1 pieces: 2 x 32 x H f16 = 32 H floats
-    static constexpr int P2 = P1 + 32 * H;                  // dz2 pieces
-    static constexpr int TB = P2 + 32 * H;                  // per-wave rows [H][kTS] f32: h2', then dz2' (bias gradient), then dz1'
-    static constexpr int XI = TB + H * kTS;                 // [D+2][kTS]
-    static constexpr int ZI = XI + (D + 2) * kTS;           // [MT waves][O][kTS]
-    static constexpr int PO = ZI + MT * O * kTS;            // [MT waves][O][32] output-layer partial sums
-    static constexpr int W3B = PO + MT * O * 32;            // W3 / kActScale^2 (dh); the staged W3S is W3 / kActScale (output layer on kActScale h2)
+    static constexpr int P1 = (SMALL + 3) / 4 * 4;          // h1 pieces: NT x 2 x 32 x H f16 = NT 32 H floats
+    static constexpr int P2 = P1 + NT * 32 * H;             // dz2 pieces
+    static constexpr int XI = P2 + NT * 32 * H;             // [NT][D+2][kTS]: the tile's observations, component-major (row D + 1 takes the padding components' writes)
+    static constexpr int PO = XI + NT * (D + 2) * kTS;      // [NT][MT waves][O][32] output-layer partial sums
+    static constexpr int W3B = PO + NT * MT * O * 32;       // W3 / kActScale^2 (dh); the staged W3S is W3 / kActScale (output layer on kActScale h2)
     static constexpr int SIZE = W3B + O * H;
+    static_assert(SIZE * 4 <= 160 * 1024, "ppo_grad_wide_split_kernel: LDS");
 };
-// chunk swizzle of the piece images.  Rows of >= 256 bytes (H >= 128) alias in every bank: 16 consecutive rows must land in 16 different 16-byte chunks and the 4 rows of a
-// transposed read in the 4 different 64-byte windows.  128-byte rows (H = 64): rows n and n + 1 already sit in different halves of the 256-byte bank window, so 3 bits suffice
 __device__ __forceinline__ void wide_split_preload(const u32x4* __restrict__ wimg, int MTv, int mo, int lane, u32x4 (&af)[2][2]) {
     const u32x4* base = wimg + ((size_t)mo * MTv * 4) * 64 + lane;
 #pragma unroll
@@ -360,17 +365,19 @@ __device__ __forceinline__ void wide_split_preload(const u32x4* __restrict__ wim
 #pragma unroll
         for (int p = 0; p < 2; ++p) af[s][p] = base[(size_t)(s * 2 + p) * 64];
 }
-// output m-tile mo of Y = W X: W as pre-split fragments from L2 (af arrives preloaded with m-tile 0's, each refilled in place right after its MFMAs), X from the piece image
-template <int H, bool BIAS>
-__device__ __forceinline__ f32x16 dense_tile_split(const u32x4* __restrict__ wimg, const float* __restrict__ bias, const char* pimg, int mo, int lane, u32x4 (&af)[2][2]) {
-    constexpr int MT = H / 32, RB = 2 * H, PS = 32 * RB;
+// output m-tile mo of Y = W X for NT sample tiles at once: W as pre-split fragments from L2 (af arrives preloaded with m-tile 0's, each refilled in place right after its MFMAs),
+// X from the piece images (one per sample tile, NTS bytes apart).  TRANSPOSED: the two operands in the other order — the accumulator then holds Y' (lane = unit 32 mo + (lane & 31),
+// register r = sample rowfn(r, lane >> 5))
+template <int H, int NT, bool BIAS, bool TRANSPOSED>
+__device__ __forceinline__ void dense_tile_split(const u32x4* __restrict__ wimg, const float* __restrict__ bias, const char* pimg, int mo, int lane, u32x4 (&af)[2][2], f32x16 (&acc)[NT]) {
+    constexpr int MT = H / 32, RB = 2 * H, PS = 32 * RB, NTS = 2 * PS;
     const int c = lane & 31, h = lane >> 5, rowb = c * RB, gsw = wimg_g<H>(c);
-    f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         f32x4 b = {0.f, 0.f, 0.f, 0.f};
         if (BIAS) b = *reinterpret_cast<const f32x4*>(bias + 32 * mo + 8 * q + 4 * h);
-        acc[4 * q + 0] = b[0]; acc[4 * q + 1] = b[1]; acc[4 * q + 2] = b[2]; acc[4 * q + 3] = b[3];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { acc[t][4 * q + 0] = b[0]; acc[t][4 * q + 1] = b[1]; acc[t][4 * q + 2] = b[2]; acc[t][4 * q + 3] = b[3]; }
     }
     const u32x4* base = wimg + ((size_t)mo * MT * 4) * 64 + lane;
 #pragma unroll 1
@@ -379,23 +386,34 @@ __device__ __forceinline__ f32x16 dense_tile_split(const u32x4* __restrict__ wim
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int a = rowb + (((4 * mi + 2 * s + h) ^ gsw) << 4);
-            f16x8 B[2];
+            f16x8 X[NT][2];
 #pragma unroll
-            for (int p = 0; p < 2; ++p) B[p] = *reinterpret_cast<const f16x8*>(pimg + p * PS + a);
-            acc = mfma_split3(__builtin_bit_cast(f16x8, af[s][0]), __builtin_bit_cast(f16x8, af[s][1]), B[0], B[1], acc);
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) X[t][p] = *reinterpret_cast<const f16x8*>(pimg + t * NTS + p * PS + a);
+            const f16x8 W0 = __builtin_bit_cast(f16x8, af[s][0]), W1 = __builtin_bit_cast(f16x8, af[s][1]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = TRANSPOSED ? mfma_split3(X[t][0], X[t][1], W0, W1, acc[t]) : mfma_split3(W0, W1, X[t][0], X[t][1], acc[t]);
 #pragma unroll
             for (int p = 0; p < 2; ++p) af[s][p] = nextp[(size_t)(s * 2 + p) * 64];
         }
     }
+}
+// sum of the eight f16 values of a fragment register set, in f32 (v_dot2c_f32_f16 against {1, 1}: the products are exact, the sum is an f32 sum)
+__device__ __forceinline__ float frag_sum8(f16x8 v, float acc) {
+    const f16x2_t one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_fdot2(f16x2_t{v[2 * k], v[2 * k + 1]}, one, acc, false);
     return acc;
 }
 
 template <int KIND, int H, int O, int HEAD>
 __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* smem) {
-    constexpr int D = EnvSpec<KIND>::D, MT = H / 32;
+    constexpr int D = EnvSpec<KIND>::D, MT = H / 32, NT = kWideSplitNT;
+    constexpr int RB = 2 * H, PS = 32 * RB, NTS = 2 * PS;            // bytes of an image row, of one piece of a sample tile, of a sample tile's image
     constexpr bool REC = true;
     using L = NetLdsSmall<D, H, O>;
-    using SC = WideSplitScratch<D, H, O>;
+    using SC = WideSplitScratch<D, H, O, NT>;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // this wave's m-tile
     const int c = lane & 31, h = lane >> 5;
@@ -404,7 +422,7 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
     const u32x4* w2tp = HEAD == HEAD_VALUE ? a.w2tp_critic : a.w2tp_actor;
     float* wl = smem;
     char* P1 = reinterpret_cast<char*>(smem + SC::P1); char* P2 = reinterpret_cast<char*>(smem + SC::P2);
-    float* TB = smem + SC::TB; float* XI = smem + SC::XI; float* ZI = smem + SC::ZI + w * O * kTS; float* PO = smem + SC::PO;
+    float* XI = smem + SC::XI; float* PO = smem + SC::PO;
     // staged small parameters in the scales of the f16-piece arithmetic (dril_device.h): b2 starts the SCALED accumulator of L2, W3S = W3 / kActScale for the output layer
     // (its operand is kActScale h2), W3B = W3 / kActScale^2 for dh
     {
@@ -414,7 +432,7 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
         for (int i = tid; i < O * H; i += blockDim.x) { const int o = i % O, k = i / O; const float w3 = P[off.w3 + i]; wl[L::W3S + o * H + k] = w3 * (1.0f / kActScale); smem[SC::W3B + o * H + k] = w3 * (1.0f / (kActScale * kActScale)); }
         for (int i = tid; i < L::OP; i += blockDim.x) wl[L::B3 + i] = i < O ? P[off.b3 + i] : 0.0f;
     }
-    for (int i = tid; i < (D + 2) * kTS; i += blockDim.x) XI[i] = (i / kTS == D) ? 1.0f : 0.0f;
+    for (int i = tid; i < NT * (D + 2) * kTS; i += blockDim.x) XI[i] = 0.0f;
     __syncthreads();
 
     float adv_mean = 0.f, adv_den = 1.f;
@@ -435,7 +453,7 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
         for (int o = 0; o < O; ++o) lsr[o] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.params[a.log_std_off + o])));
     }
     const float* ls = lsr;
-    const int tbase = wide_tr_base<H>(lane);
+    const int tbase = wide_tr_base<H>(lane), tmbase = wide_trm_base<H>(lane);
     // gradient tiles are split as dz2 SG with SG = 2^(exponent of 1 / invB + 3): 4 ... 8 / invB, a power of two; every scale is undone exactly in the epilogue
     const float sg = __uint_as_float((((__float_as_uint(1.0f / a.invB) >> 23) & 0xffu) + 3u) << 23);
     const float inv_sg = 1.0f / sg, inv_sa = inv_sg * (1.0f / kActScale);
@@ -443,181 +461,197 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
     const float* W3B = smem + SC::W3B;
 
     f32x16 dW2[MT];                                                  // rows 32w.., all H columns
-    f32x4 dW1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    float dW3a[O], db2p = 0.f, db3p[O], dlsp[O], st[5];
+    float dW1a[D], db1a = 0.f, dW3a[O], db2a = 0.f, db3p[O], dlsp[O], st[5];   // per-lane partial sums: dW1a / db1a / db2a for unit 32w + (lane & 31) over the samples of this half-wave, dW3a for unit 32w + rowfn(lane & 15, h)
 #pragma unroll
     for (int j = 0; j < MT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dW2[j][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) dW1a[d] = 0.f;
 #pragma unroll
     for (int o = 0; o < O; ++o) { dW3a[o] = 0.f; db3p[o] = 0.f; dlsp[o] = 0.f; }
 #pragma unroll
     for (int i = 0; i < 5; ++i) st[i] = 0.f;
 
     const int g = (int)(blockIdx.x % a.G);
-    const int64_t ntiles = (a.count + kTile - 1) / kTile;
-    TileIn<O, FirstLayer<D>::KS> cur, nxt;
-    int64_t tile = g;
-    if (tile < ntiles) load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);
+    const int64_t ntiles = (a.count + kTile - 1) / kTile;            // sample tiles of 32; the workgroup takes NT consecutive ones per pass (a missing last one is all-invalid)
+    constexpr int KS = FirstLayer<D>::KS;                            // two first-layer k-steps for D <= 4, four for D <= 8 (Acrobot)
+    TileIn<O, KS> cur[NT], nxt[NT];
+    int64_t tile = (int64_t)g * NT;
+    if (tile < ntiles) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) load_tile<KIND, O, HEAD, REC>(a, tile + t, ntiles, c, h, cur[t]);
+    }
 #ifdef DRIL_STAMPS
     unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
 #endif
-    for (; tile < ntiles; tile += a.G) {
-        unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
-        const bool valid = cur.valid;
-        constexpr int KS = FirstLayer<D>::KS;                                           // two first-layer k-steps for D <= 4, four for D <= 8 (Acrobot)
-        float xk[KS];
+    for (; tile < ntiles; tile += (int64_t)a.G * NT) {
+        // ---- h1 tile w of every sample tile; its pieces into the workgroup images ----
 #pragma unroll
-        for (int s = 0; s < KS; ++s) xk[s] = cur.xk[s];
-        // ---- h1 tile w; its pieces into the workgroup image ----
-        f32x16 h1w;
-        {
+        for (int t = 0; t < NT; ++t) {
+            unpack_tile<KIND, O, HEAD, REC>(a, h, cur[t]);
+            f32x16 h1w;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(wl + L::B1 + 32 * w + 8 * q + 4 * h);
                 h1w[4 * q + 0] = b[0]; h1w[4 * q + 1] = b[1]; h1w[4 * q + 2] = b[2]; h1w[4 * q + 3] = b[3];
             }
 #pragma unroll
-            for (int s = 0; s < KS; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
+            for (int s = 0; s < KS; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], cur[t].xk[s], h1w);
             tanh16_scaled<false>(h1w, 1.0f);                                          // kActScale h1
-        }
-        // `opaque(lane)`: the image addresses are lane constants, and hoisted out of the tile loop as loop invariants they hold ~60 registers for the whole kernel (they cost 2-3 VALU to rebuild)
-        store_tile_pieces2<H>(P1, w, h1w, opaque(lane));
-        if (w == 0) {
+            // `opaque(lane)`: the image addresses are lane constants, and hoisted out of the tile loop as loop invariants they hold ~60 registers for the whole kernel (they cost 2-3 VALU to rebuild)
+            store_tile_pieces2<H>(P1 + t * NTS, w, h1w, opaque(lane));
+            if (w == t) {                                                             // wave t keeps sample tile t's observations for the dW1 sums
 #pragma unroll
-            for (int s = 0; s < KS; ++s) { const int d = 2 * s + h; XI[(d < D ? d : D + 1) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the zero row
+                for (int s = 0; s < KS; ++s) { const int d = 2 * s + h; XI[(t * (D + 2) + (d < D ? d : D + 1)) * kTS + c] = d < D ? cur[t].xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the spare row
+            }
         }
         STAMP(0);
         u32x4 afw[2][2];
         wide_split_preload(w2p, MT, w, lane, afw);                                    // first W2 fragments in flight across the barrier
         __syncthreads();                                                              // B1: P1, XI complete
         STAMP(1);
-        load_tile<KIND, O, HEAD, REC>(a, tile + a.G, ntiles, c, h, nxt);              // after the barrier (see ppo_grad_wide_kernel)
+        // the next pass's records are requested only now: issued before unpack_tile(cur) they sat behind cur's loads in the in-order vmcnt queue (see ppo_grad_wide_kernel)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) load_tile<KIND, O, HEAD, REC>(a, tile + (int64_t)a.G * NT + t, ntiles, c, h, nxt[t]);
         // ---- h2 tile w ----
-        f32x16 h2w = dense_tile_split<H, true>(w2p, wl + L::B2, P1, w, opaque(lane), afw);
-        tanh16_scaled<true>(h2w, 1.0f / (kWScale * kActScale));                        // kActScale h2
+        f32x16 h2w[NT];
+        dense_tile_split<H, NT, true, false>(w2p, wl + L::B2, P1, w, opaque(lane), afw, h2w);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tanh16_scaled<true>(h2w[t], 1.0f / (kWScale * kActScale));   // kActScale h2
         STAMP(2);
         // ---- output layer: partial over this wave's rows, summed across waves through LDS ----
-        float out[O], dz[O];
 #pragma unroll
-        for (int o = 0; o < O; ++o) {
-            float p = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
-                p = fmaf(wv[0], h2w[4 * q + 0], p); p = fmaf(wv[1], h2w[4 * q + 1], p);
-                p = fmaf(wv[2], h2w[4 * q + 2], p); p = fmaf(wv[3], h2w[4 * q + 3], p);
-            }
-            p += __shfl_xor(p, 32);
-            if (h == 0) PO[(w * O + o) * 32 + c] = p;
-        }
-        store_image_tile(TB, w, h2w, lane);                                            // h2' (own rows; only this wave reads them)
-        __syncthreads();                                                              // B2: PO complete
-        STAMP(3);
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            float v = wl[L::B3 + o];
-#pragma unroll
-            for (int ww = 0; ww < MT; ++ww) v += PO[(ww * O + o) * 32 + c];            // fixed order: every wave gets the same bits
-            out[o] = v;
-        }
-        loss_head<O, HEAD>(as, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);     // dz = SG dLoss/dout
-        // ---- dW3 (own rows) ----
-#pragma unroll
-        for (int o = 0; o < O; ++o) { if (h == 0) { if (w == 0) db3p[o] += dz[o]; ZI[o * kTS + c] = dz[o]; } }
-        {
-            const f32x16 Bh2 = load_operand(TB, w, lane);
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int o = 0; o < O; ++o) {
-                float acc = 0.f;
+                float p = 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 z = *reinterpret_cast<const f32x4*>(ZI + o * kTS + 16 * h + 4 * q);
-                    acc = fmaf(Bh2[4 * q + 0], z[0], acc); acc = fmaf(Bh2[4 * q + 1], z[1], acc);
-                    acc = fmaf(Bh2[4 * q + 2], z[2], acc); acc = fmaf(Bh2[4 * q + 3], z[3], acc);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + L::W3S + o * H + 32 * w + 8 * q + 4 * h);
+                    p = fmaf(wv[0], h2w[t][4 * q + 0], p); p = fmaf(wv[1], h2w[t][4 * q + 1], p);
+                    p = fmaf(wv[2], h2w[t][4 * q + 2], p); p = fmaf(wv[3], h2w[t][4 * q + 3], p);
                 }
-                dW3a[o] += acc;
+                p += __shfl_xor(p, 32);
+                if (h == 0) PO[((t * MT + w) * O + o) * 32 + c] = p;
             }
-        }
-        // ---- dz2 tile w (in h2w's registers); its pieces into the workgroup image; the f32 transposed copy (own rows) gives db2 ----
+        __syncthreads();                                                              // B2: PO complete
+        STAMP(3);
+        float dz[NT][O];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float dh[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) {
+            float out[O];
 #pragma unroll
             for (int o = 0; o < O; ++o) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(W3B + o * H + 32 * w + 8 * q + 4 * h);
+                float v = wl[L::B3 + o];
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(wv[cc], dz[o], dh[cc]);
+                for (int ww = 0; ww < MT; ++ww) v += PO[((t * MT + ww) * O + o) * 32 + c];  // fixed order: every wave gets the same bits
+                out[o] = v;
             }
+            loss_head<O, HEAD>(as, cur[t], out, cur[t].valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz[t], st, dlsp);     // dz = SG dLoss/dout
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[4 * q + cc]; h2w[4 * q + cc] = dh[cc] * fmaf(-hv, hv, kActScale * kActScale); }   // = SG dz2
+            for (int o = 0; o < O; ++o) db3p[o] += (h == 0 && w == 0) ? dz[t][o] : 0.f;
         }
-        store_tile_pieces2<H>(P2, w, h2w, opaque(lane));
-        store_image_tile(TB, w, h2w, lane);                                            // dz2' (after the Bh2 read: same wave, LDS in order)
+        // ---- dW3 (own rows): sum over the sample tiles in registers, then over the lanes (= samples) of each half-wave; lane l ends with unit 32w + rowfn(l & 15, h) ----
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            f32x16 v;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = h2w[0][r] * dz[0][o];
+#pragma unroll
+            for (int t = 1; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaf(h2w[t][r], dz[t][o], v[r]);
+            dW3a[o] += half_reduce16_lane(v, lane);
+        }
+        // ---- dz2 tile w (in h2w's registers); its pieces into the workgroup images ----
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float dh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < O; ++o) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(W3B + o * H + 32 * w + 8 * q + 4 * h);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) dh[cc] = fmaf(wv[cc], dz[t][o], dh[cc]);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[t][4 * q + cc]; h2w[t][4 * q + cc] = dh[cc] * fmaf(-hv, hv, kActScale * kActScale); }   // = SG dz2
+            }
+            store_tile_pieces2<H>(P2 + t * NTS, w, h2w[t], opaque(lane));
+        }
         wide_split_preload(w2tp, MT, w, lane, afw);                                   // first W2' fragments in flight across the barrier
         STAMP(4);
         __syncthreads();                                                              // B3: P2 complete
         STAMP(5);
-        // ---- dh1 tile w = W2' dz2 ; dz1 ----
-        f32x16 g1 = dense_tile_split<H, false>(w2tp, nullptr, P2, w, opaque(lane), afw);
-        {
-            f32x16 h1r;
-            load_tile_pieces2<H>(P1, w, h1r, opaque(lane));                                    // kActScale h1 of tile w back from its own pieces (to 2^-24): 16 registers less across both MFMA chains
-            constexpr float c0 = 1.0f / kWScale, c1 = c0 / (kActScale * kActScale);             // g1 = (kWScale W2' . SG dz2) (1 - h1^2) / kWScale = SG dz1
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[r] = g1[r] * fmaf(-t2, c1, c0); }
-        }
+        // ---- dh1' tile w = (W2' dz2)', transposed: lane = unit 32w + (lane & 31), register r = sample rowfn(r, h); dz1' ----
+        f32x16 g1[NT];
+        dense_tile_split<H, NT, false, true>(w2tp, nullptr, P2, w, opaque(lane), afw, g1);
         STAMP(6);
-        // ---- db2 from the f32 transposed copy; then dW1 | db1 (own rows) BEFORE dW2, so that dz1 is dead while the 128 accumulators are being updated ----
+        // ---- dz1', then dW1 | db1 as per-lane sums over the lane's samples (before dW2, so that dz1 is dead while the 128 accumulators are being updated) ----
         {
-            const f32x16 Az32 = load_operand(TB, w, lane);
-            db2p += sum16(Az32);
-        }
-        store_image_tile(TB, w, g1, lane);
-        {
-            const int j = lane & 15;
-            float bx[8];
-            load_row8(XI, j <= D ? j : D + 1, lane, bx);
+            constexpr float c0 = 1.0f / kWScale, c1 = c0 / (kActScale * kActScale);             // g1 = (SG dz2 . kWScale W2) (1 - h1^2) / kWScale = SG dz1
+            const int tmw = opaque(tmbase) ^ (64 * w);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float az[8];
-                load_row8(TB, 32 * w + 16 * t + j, lane, az);
+            for (int t = 0; t < NT; ++t) {
+                f32x16 h1r;
+                load_tile_pieces2_T<H>(P1 + t * NTS, tmw, h1r);                                // kActScale h1 of the lane's unit at its 16 samples, back from the pieces (to 2^-24)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) dW1[t] = mfma16(az[k], bx[k], dW1[t]);
+                for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[t][r] = g1[t][r] * fmaf(-t2, c1, c0); }
+                db1a += sum16(g1[t]);
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(XI + (t * (D + 2) + d) * kTS + 8 * q + 4 * h);     // two addresses per wave: broadcast reads
+                        dW1a[d] = fmaf(g1[t][4 * q + 0], x[0], dW1a[d]); dW1a[d] = fmaf(g1[t][4 * q + 1], x[1], dW1a[d]);
+                        dW1a[d] = fmaf(g1[t][4 * q + 2], x[2], dW1a[d]); dW1a[d] = fmaf(g1[t][4 * q + 3], x[3], dW1a[d]);
+                    }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         STAMP(7);
-        // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the piece images) ----
+        // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the piece images; k = the NT x 32 samples); db2 from the dz2 fragments ----
         {
             const int tb = opaque(tbase), tbw = tb ^ (64 * w), tbw16 = tbw ^ 16;
-            f16x8 Az[2][2];
+            f16x8 Az[2 * NT][2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) Az[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<H>(P2, tbw, tbw16, p, s));
-#pragma unroll
-            for (int mj = 0; mj < MT; ++mj) {
-                f16x8 Bh[2][2];
-                const int tbj = tb ^ (64 * mj), tbj16 = tbj ^ 16;
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) Bh[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<H>(P1, tbj, tbj16, p, s));
+                    for (int p = 0; p < 2; ++p) {
+                        Az[2 * t + s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<H>(P2 + t * NTS, tbw, tbw16, p, s));
+                        db2a = frag_sum8(Az[2 * t + s][p], db2a);
+                    }
 #pragma unroll
-                for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split3(Az[s][0], Az[s][1], Bh[s][0], Bh[s][1], dW2[mj]);   // (SG dz2)(kActScale h1)'
+            for (int mj = 0; mj < MT; ++mj) {
+                const int tbj = tb ^ (64 * mj), tbj16 = tbj ^ 16;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f16x8 Bh[2][2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) Bh[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<H>(P1 + t * NTS, tbj, tbj16, p, s));
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split3(Az[2 * t + s][0], Az[2 * t + s][1], Bh[s][0], Bh[s][1], dW2[mj]);   // (SG dz2)(kActScale h1)'
+                }
                 __builtin_amdgcn_sched_barrier(0);                                    // keep the next m-tile's fragment requests behind these MFMAs (hoisted, they spill)
             }
         }
-        __syncthreads();                                                              // B4: P1 / P2 / PO / XI free for the next tile
+        __syncthreads();                                                              // B4: P1 / P2 / PO / XI free for the next pass
         STAMP(8);
-        cur = nxt;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
     }
 #ifdef DRIL_STAMPS
     if (lane == 0 && a.dbg) {
         unsigned long long* o_ = a.dbg + ((size_t)(blockIdx.x % (2 * a.G)) * 4 + (w & 3)) * 12;
-        if (w < 4) { for (int k = 0; k < 10; ++k) o_[k] = stamp_acc[k]; o_[10] = (unsigned long long)((ntiles - g + a.G - 1) / a.G); o_[11] = HEAD; }
+        const int64_t stride = (int64_t)a.G * NT, first = (int64_t)g * NT;
+        if (w < 4) { for (int k = 0; k < 10; ++k) o_[k] = stamp_acc[k]; o_[10] = (unsigned long long)(first < ntiles ? (ntiles - first + stride - 1) / stride : 0); o_[11] = HEAD; }
     }
 #endif
 
@@ -631,18 +665,12 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
 #pragma unroll
         for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H] = dW2[mj][r] * inv_sa;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 32 * w + 16 * t + 4 * (lane >> 4) + r, col = lane & 15;
-            if (col < D) slab[o_w1 + row + col * H] = dW1[t][r] * inv_sg;
-            else if (col == D) slab[o_b1 + row] = dW1[t][r] * inv_sg;
-        }
-    { const float b2 = (db2p + __shfl_xor(db2p, 32)) * inv_sg; if (h == 0) slab[o_b2 + 32 * w + c] = b2; }
+    for (int d = 0; d < D; ++d) { const float v = (dW1a[d] + __shfl_xor(dW1a[d], 32)) * inv_sg; if (h == 0) slab[o_w1 + 32 * w + c + d * H] = v; }
+    { const float b1 = (db1a + __shfl_xor(db1a, 32)) * inv_sg; if (h == 0) slab[o_b1 + 32 * w + c] = b1; }
+    { const float b2 = (db2a + __shfl_xor(db2a, 32)) * inv_sg; if (h == 0) slab[o_b2 + 32 * w + c] = b2; }
 #pragma unroll
     for (int o = 0; o < O; ++o) {
-        const float v = (dW3a[o] + __shfl_xor(dW3a[o], 32)) * inv_sa;
-        if (h == 0) slab[o_w3 + o + (32 * w + c) * O] = v;
+        if ((lane & 16) == 0) slab[o_w3 + o + (32 * w + rowfn(lane & 15, h)) * O] = dW3a[o] * inv_sa;
         const float b3 = half_sum(db3p[o]) * inv_sg;
         if (w == 0 && lane == 0) slab[o_b3 + o] = b3;
         if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]) * inv_sg; if (w == 0 && lane == 0) slab[o_ls + o] = l; }
@@ -670,7 +698,7 @@ template <int KIND, int H> static size_t grad_wide_lds_bytes() {
 }
 template <int KIND, int H> static size_t grad_wide_split_lds_bytes() {
     constexpr int D = EnvSpec<KIND>::D, A = EnvSpec<KIND>::A;
-    constexpr int wa = WideSplitScratch<D, H, A>::SIZE, wc = WideSplitScratch<D, H, 1>::SIZE;
+    constexpr int wa = WideSplitScratch<D, H, A, kWideSplitNT>::SIZE, wc = WideSplitScratch<D, H, 1, kWideSplitNT>::SIZE;
     return sizeof(float) * (wa > wc ? wa : wc);
 }
 
@@ -680,9 +708,7 @@ hipError_t launch_ppo_grad_wide(int kind, int hidden, const GradArgs& a, hipStre
 #define CALLWS(K, HH)                                                                                         \
     {                                                                                                         \
         const size_t lds = grad_wide_split_lds_bytes<K, HH>();                                                \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wide_split_kernel<K, HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e; attr_set = true; }                                                 \
+        { hipError_t e = set_max_dynamic_lds((const void*)ppo_grad_wide_split_kernel<K, HH>, lds); if (e != hipSuccess) return e; } \
         ppo_grad_wide_split_kernel<K, HH><<<2 * a.G, HH * 2, lds, s>>>(a);                                    \
     }
 #define CALLWSH(K) { if (hidden == 256) CALLWS(K, 256) else if (hidden == 128) CALLWS(K, 128) else return hipErrorInvalidValue; }
@@ -694,9 +720,7 @@ hipError_t launch_ppo_grad_wide(int kind, int hidden, const GradArgs& a, hipStre
 #define CALLW(K, HH, R)                                                                                       \
     {                                                                                                         \
         const size_t lds = grad_wide_lds_bytes<K, HH>();                                                      \
-        static bool attr_set = false;                                                                         \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_grad_wide_kernel<K, HH, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return e; attr_set = true; }                                                 \
+        { hipError_t e = set_max_dynamic_lds((const void*)ppo_grad_wide_kernel<K, HH, R>, lds); if (e != hipSuccess) return e; } \
         ppo_grad_wide_kernel<K, HH, R><<<2 * a.G, HH * 2, lds, s>>>(a);                                       \
     }
 #define CALLWK(K, HH) { if (a.rec) CALLW(K, HH, true) else CALLW(K, HH, false) }

@@ -114,6 +114,12 @@ struct AdamArgs {
     float* step_stats; float* norm_out; int* nan_flag; const int* stop_flag; int* stop_flag_w;
 };
 
+// raise a kernel's dynamic-LDS limit once per (kernel, device): a process may hold handles on several devices, and the attribute is per device context
+// (dril_kernels.hip; the launchers of every kernel that takes more than 64 KB call it before each launch — a vector scan under a mutex after the first call)
+hipError_t set_max_dynamic_lds(const void* fn, size_t bytes);
+// n-tiles of 32 samples that one workgroup of ppo_grad_wide_split_kernel takes through its stages together (dril_grad_wide.hip); ppo_step sizes the grid by it
+constexpr int kWideSplitNT = 2;
+
 hipError_t launch_env_reset(int kind, int E, uint64_t seed0, float* state, int32_t* sc, uint32_t* ep, uint32_t* gs, float* dr, hipStream_t s);
 hipError_t launch_env_observe(int kind, int E, const float* state, float* obs, hipStream_t s);
 struct MonitorArgs { float* cur_ret; int32_t* cur_len; float* ep_ret; int32_t* ep_len; uint8_t* flags_out; };

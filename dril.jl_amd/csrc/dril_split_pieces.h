@@ -78,6 +78,31 @@ __device__ __forceinline__ void load_tile_pieces2(const char* pimg, int w, f32x1
         }
     }
 }
+// the tile back in the TRANSPOSED accumulator layout (lane = unit 32m + (lane & 31), register r = sample rowfn(r, lane >> 5): what a product with its two operands exchanged
+// leaves): register group Q (r = 4Q .. 4Q + 3) = samples 8Q + 4h + {0..3} of the lane's unit = ONE ds_read_b64_tr_b16 per piece, whose 16-lane group addresses rows
+// (samples) 8Q + 4h + q, q = e >> 2, and columns (units) 16 gm + 4 (e & 3) .. + 3.  g(8Q + 4h + q) = (q << 2) | ((2Q + h) & 3) = g(4h + q) ^ (2Q & 3): Q enters the address
+// as `+ 8 Q RB` (an immediate) and, for odd Q, `^ 32` — two base registers (tm, tm ^ 32) for the four groups.  tm = wide_trm_base ^ (64 m).  H >= 128 (the four-bit swizzle)
+template <int H>
+__device__ __forceinline__ int wide_trm_base(int lane) {
+    static_assert(H >= 128, "wide_trm_base: the four-bit chunk swizzle of rows >= 256 bytes");
+    constexpr int RB = 2 * H;
+    const int h = lane >> 5, gm = (lane >> 4) & 1, e = lane & 15, q = e >> 2, p = e & 3, n = 4 * h + q;
+    return n * RB + ((((2 * gm + (p >> 1)) ^ wimg_g<H>(n)) & 15) << 4) + 8 * (p & 1);
+}
+template <int H>
+__device__ __forceinline__ void load_tile_pieces2_T(const char* pimg, int tm, f32x16& x) {
+    constexpr int RB = 2 * H, PS = 32 * RB;
+    static_assert((8 * RB) % 64 == 0 && PS % 64 == 0, "offsets must leave bits 0-5 alone");
+    const int tm32 = tm ^ 32;
+#pragma unroll
+    for (int Q = 0; Q < 4; ++Q) {
+        const int a = ((Q & 1) ? tm32 : tm) + 8 * Q * RB;
+        const u32x2 hi = __builtin_bit_cast(u32x2, lds_read_tr16(pimg, a)), lo = __builtin_bit_cast(u32x2, lds_read_tr16(pimg, a + PS));
+        float x0, x1, x2, x3;
+        pieces_sum2(hi.x, lo.x, x0, x1); pieces_sum2(hi.y, lo.y, x2, x3);                        // the value that was split, to 2^-24 relative
+        x[4 * Q] = x0; x[4 * Q + 1] = x1; x[4 * Q + 2] = x2; x[4 * Q + 3] = x3;
+    }
+}
 // operand of a product that sums over SAMPLES: lane (unit 32m + (lane & 31), half kh) gets samples 16s + 8kh + j of its unit; tbase from wide_tr_base
 template <int H>
 __device__ __forceinline__ int wide_tr_base(int lane) {

@@ -572,8 +572,8 @@ hipError_t launch_ppo_update_small(int kind, const SmallUpdateArgs& a, hipStream
     if (kind == 7) kind = 4;                  // ScalingWrapperEnv(MountainCarContinuous): the update never touches the simulator
     if (!a.xchg) return hipErrorInvalidValue;
     { hipError_t e = hipMemsetAsync(a.xchg, 0, sizeof(unsigned long long) * kSmallXchgWords, s); if (e != hipSuccess) return e; }   // sequence number 0 = no message yet
-#define CALLU(K) { const size_t lds = update_small_lds_bytes<K>(); static bool attr_set = false; \
-        if (!attr_set) { hipError_t e = hipFuncSetAttribute((const void*)ppo_update_small_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; attr_set = true; } \
+#define CALLU(K) { const size_t lds = update_small_lds_bytes<K>(); \
+        { hipError_t e = set_max_dynamic_lds((const void*)ppo_update_small_kernel<K>, lds); if (e != hipSuccess) return e; } \
         ppo_update_small_kernel<K><<<a.debug_solo ? 1 : kSmallGrid, 256, lds, s>>>(a); }
     if (kind == 0) CALLU(0) else if (kind == 3) CALLU(3) else if (kind == 4) CALLU(4) else if (kind == 6) CALLU(6) else CALLU(1)
 #undef CALLU

@@ -675,6 +675,10 @@ class Handle:
     def comm_allreduce_calls(self) -> int:
         return int(self.lib.dril_comm_allreduce_calls(self._h))
 
+    def device_info(self) -> str:
+        """"device <ordinal> of <n> visible: <name> <arch>, <CUs> CUs, PCI <bus id>, HIP_VISIBLE_DEVICES=.. ROCR_VISIBLE_DEVICES=.." (dril_device_info)"""
+        return (self.lib.dril_device_info(self._h) or b"").decode()
+
     @staticmethod
     def comm_loopback(handles: Sequence["Handle"]):
         """DEBUG / TEST: join handles (ranks 0..n-1 of one process, one device) into a loopback communicator; afterwards every handle

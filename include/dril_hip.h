@@ -339,6 +339,10 @@ int32_t dril_comm_ranks(dril_handle* h);
 /* all-reduces this handle has issued since dril_create (every call site counts: advantage moments, [grads || 8 sums], the per-epoch
  * moment table, NormalizeWrapperEnv's batch moments, the explained-variance sums) */
 int64_t dril_comm_allreduce_calls(const dril_handle* h);
+/* which device the handle lives on, for the banner every rank of a multi-GPU job prints before dril_comm_init and for RCCL failure messages:
+ * "device <ordinal> of <visible count> visible: <name> <arch>, <CUs> CUs, PCI <bus id>, HIP_VISIBLE_DEVICES=... ROCR_VISIBLE_DEVICES=..." (new; no reference counterpart).
+ * A failing ncclCommInitRank / ncclAllReduce puts ncclGetErrorString, ncclGetLastError and this line into dril_last_error. */
+const char* dril_device_info(const dril_handle* h);
 /* DEBUG / TEST: join n handles of THIS process, all on ONE device, with cfg.world_size == n and ranks 0..n-1, into a loopback
  * communicator (RCCL refuses two ranks per device).  Every all-reduce call site, count and dtype of the data-parallel path is unchanged;
  * the transport is an in-process rendezvous plus one kernel that sums the ranks' device buffers in rank order and writes the sum back to

@@ -39,6 +39,17 @@ def test_launcher_starts_n_ranks_with_their_environment_and_relays_rank0():
     assert [e["RANK"] for e in envs] == ["0", "1"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1"]
     assert all(e["WORLD_SIZE"] == "2" and e["MASTER_ADDR"] == "127.0.0.1" and e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)
     assert envs[0]["MASTER_PORT"] == envs[1]["MASTER_PORT"] and int(envs[0]["MASTER_PORT"]) > 0
+    # first multi-GPU contact must be self-diagnosing: RCCL's own warnings on, and every rank names the device it bound BEFORE the communicator
+    assert all(e["NCCL_DEBUG"] == "WARN" for e in envs)
+    banners = [l for l in r.stderr.splitlines() if "BANNER rank " in l]
+    assert len(banners) == 2 and all("NCCL_DEBUG=WARN" in b and "HSA_ENABLE_IPC_MODE_LEGACY=0" in b for b in banners), r.stderr
+    assert any("rank 0/2 local_rank 0 ->" in b for b in banners) and any("rank 1/2 local_rank 1 ->" in b for b in banners)
+
+
+def test_the_callers_own_nccl_debug_setting_wins():
+    r, _ = run_bench({"NCCL_DEBUG": "INFO"}, "--gpus", "2")
+    assert r.returncode == 0, r.stderr
+    assert all(e["NCCL_DEBUG"] == "INFO" for e in stub_envs(r.stderr))
 
 
 def test_a_failing_rank_ends_all_ranks_and_the_exit_code_is_nonzero():
@@ -103,12 +114,51 @@ def test_real_worker_on_a_one_gpu_box_a_missing_device_fails_the_whole_job():
     the launcher ends rank 0 (which holds a handle on device 0 and waits in the rendezvous) and exits non-zero WITHOUT a result line — never a 1-GPU number under an
     `n_gpus: 2` label.  (Two ranks on one device are not possible: RCCL refuses duplicate GPUs; tests/test_gpu_dataparallel.py covers the library's N > 1 code.)"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DRIL_BENCH_STUB")}
+    env["HIP_VISIBLE_DEVICES"] = "0"          # ONE visible device whatever the box has (ADVICE r4): on a multi-GPU node rank 1 would otherwise find device 1 and the job would succeed
     t0 = time.monotonic()
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--n-envs", "1024", "--n-steps", "32", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and not r.stdout.strip(), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
     assert "rank 1 exited with code" in r.stderr and "all ranks ended, no result line" in r.stderr, r.stderr[-1500:]
     assert time.monotonic() - t0 < 300
+
+
+def _visible_gpus() -> int:
+    """device count seen by a FRESH child (this process must not initialise HIP for a count; torch.cuda.device_count() does not, on this image)"""
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+    return int(r.stdout.strip() or 0) if r.returncode == 0 else 0
+
+
+@pytest.mark.gpu
+def test_real_worker_on_two_devices_gives_a_two_rank_result():
+    """the sibling of the test above for a node with >= 2 GPUs (never the builder's one-GPU box: skipped there): the real worker behind the launcher must give ONE line
+    that RCCL itself counts as two ranks, with the per-rank banners before it and the all-reduce time in it"""
+    if _visible_gpus() < 2:
+        pytest.skip("needs >= 2 visible GPUs (the driver's multi-GPU node); the one-GPU box runs the missing-device test instead")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DRIL_BENCH_STUB")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--n-envs", "1024", "--n-steps", "32", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["allreduce_us_per_step"] > 0
+    assert sum("BANNER rank " in l for l in r.stderr.splitlines()) == 2
+
+
+@pytest.mark.gpu
+def test_one_rank_through_rccl_reports_the_allreduce_time():
+    """DRIL_FORCE_ALLREDUCE=1 on the one-GPU box: the worker builds a 1-rank RCCL communicator, every optimiser step goes through ncclAllReduce, and the line carries
+    the measured time per step (what the 8-GPU record will be read for), the banner precedes the communicator"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DRIL_BENCH_STUB")}
+    env["DRIL_FORCE_ALLREDUCE"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--n-envs", "1024", "--n-steps", "64", "--no-cpu-baseline", "--no-secondary"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["rccl_ranks"] == 1 and rec["allreduce_calls"] >= 2 * 10 * 32
+    assert rec["allreduce_us_per_step"] > 0 and rec["allreduce"]["launches"] >= 2 * 10 * 32 and rec["allreduce"]["gradient_bytes"] == 4 * (9155 + 8)
+    err = r.stderr.splitlines()
+    b = [i for i, l in enumerate(err) if "BANNER rank 0/1" in l]; c = [i for i, l in enumerate(err) if "RCCL communicator up" in l]
+    assert b and c and b[0] < c[0] and "PCI " in err[b[0]] and "device 0 of" in err[b[0]]
 
 
 def test_roofline_helpers_price_what_they_say():
