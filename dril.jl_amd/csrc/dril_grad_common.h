@@ -50,16 +50,31 @@ __device__ __forceinline__ double block_sum_f64(double v, double* sh) {
 template <int D> struct RecLayout { static constexpr int RS = D <= 4 ? 2 : 3; };
 template <int O, int KS = 2> struct TileIn { float xk[KS]; float s0, s1; int act; float xa[O]; bool valid; float4 raw; float4 raw2; };   // raw2: the scalar quad of a 3-quad record (KS = 4) only
 
-template <int KIND, int O, int HEAD, bool REC>
-__device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64_t ntiles, int c, int h, TileIn<O, FirstLayer<EnvSpec<KIND>::D>::KS>& t) {
-    constexpr int D = EnvSpec<KIND>::D, KS = FirstLayer<D>::KS, RS = RecLayout<D>::RS;
+// the two halves of load_tile, so that a kernel can request the INDEX of a tile one pass before its records (ppo_grad_wide_split_kernel: perm32[p] -> wait -> rec[idx] is a
+// dependent pair of memory round trips; issued back to back after a barrier they were ~2 k cycles of every pass): tile_index issues the load of the epoch order's entry
+// (or evaluates the keyed bijection), load_tile_at the record / field loads for a known index
+struct TileIdx { int64_t gidx; bool inb; };
+__device__ __forceinline__ TileIdx tile_index(const GradArgs& a, int64_t tile, int64_t ntiles, int c) {
     const bool live = tile < ntiles;
     const int64_t i = (live ? tile : ntiles - 1) * kTile + c;
-    const bool inb = live && i < a.count;
-    const int64_t p = a.pos0 + (inb ? i : 0);
-    const int64_t gidx = a.perm32 ? (int64_t)a.perm32[p] : a.perm ? a.perm[p] : (a.perm_bits ? perm_index(p, a.N, a.perm_key, a.perm_bits) : p);   // bits 0 = identity order
-    const int64_t li = gidx - a.idx_lo;
-    t.valid = inb && li >= 0 && li < a.n_local;
+    TileIdx r; r.inb = live && i < a.count;
+    const int64_t p = a.pos0 + (r.inb ? i : 0);
+    if (a.perm32) r.gidx = (int64_t)a.perm32[p];
+    else if (a.perm) r.gidx = a.perm[p];
+    else {
+        // (the keyed bijection's masks and shift counts are loop invariants of the caller's tile loop: hidden from the optimiser here, they are rebuilt per call on this
+        // cold path instead of living in ~50 scalar registers — and their spills — across the whole loop of a kernel that is at its register limit)
+        uint64_t key = a.perm_key; int bits = a.perm_bits; int64_t n = a.N;
+        asm volatile("" : "+s"(key), "+s"(bits), "+s"(n));
+        r.gidx = bits ? perm_index(p, n, key, bits) : p;                      // bits 0 = identity order
+    }
+    return r;
+}
+template <int KIND, int O, int HEAD, bool REC>
+__device__ __forceinline__ void load_tile_at(const GradArgs& a, const TileIdx& ti, int h, TileIn<O, FirstLayer<EnvSpec<KIND>::D>::KS>& t) {
+    constexpr int D = EnvSpec<KIND>::D, KS = FirstLayer<D>::KS, RS = RecLayout<D>::RS;
+    const int64_t li = ti.gidx - a.idx_lo;
+    t.valid = ti.inb && li >= 0 && li < a.n_local;
     const int64_t idx = t.valid ? li : 0;
     t.act = 0; t.s0 = 0.f; t.s1 = 0.f;
     if (REC) {
@@ -81,6 +96,10 @@ __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64
             for (int o = 0; o < O; ++o) t.xa[o] = ((const float*)a.actions)[idx * O + o];
         }
     }
+}
+template <int KIND, int O, int HEAD, bool REC>
+__device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64_t ntiles, int c, int h, TileIn<O, FirstLayer<EnvSpec<KIND>::D>::KS>& t) {
+    load_tile_at<KIND, O, HEAD, REC>(a, tile_index(a, tile, ntiles, c), h, t);
 }
 
 // exchange the two record halves between the half-waves: v_permlane32_swap(a, b) swaps a[32..63] with b[0..31], so with

@@ -355,9 +355,35 @@ template <int D, int H, int O, int NT> struct WideSplitScratch {
     static constexpr int XI = P2 + NT * 32 * H;             // [NT][D+2][kTS]: the tile's observations, component-major (row D + 1 takes the padding components' writes)
     static constexpr int PO = XI + NT * (D + 2) * kTS;      // [NT][MT waves][O][32] output-layer partial sums
     static constexpr int W3B = PO + NT * MT * O * 32;       // W3 / kActScale^2 (dh); the staged W3S is W3 / kActScale (output layer on kActScale h2)
-    static constexpr int SIZE = W3B + O * H;
+    static constexpr int RQ = RecLayout<D>::RS == 3 ? 4 : 2; // record quads kept per sample tile (three-quad records: the second DMA's upper half-wave lands in a fourth)
+    static constexpr int REC = W3B + O * H;                 // [NT][RQ][32] float4: the pass's minibatch records, quad-major (wide_request_records)
+    static constexpr int VO = REC + NT * RQ * 32 * 4;       // [NT][64] old values (critic with a value clip)
+    static constexpr int VAL = VO + NT * 64;                // [NT][64] validity words
+    static constexpr int SIZE = VAL + NT * 64;
+    static_assert(REC % 4 == 0, "records: 16-byte aligned");
     static_assert(SIZE * 4 <= 160 * 1024, "ppo_grad_wide_split_kernel: LDS");
 };
+// LDS-DMA (global_load_lds_dwordx4 / _dword): lane l's 16 / 4 bytes land at the wave-uniform LDS base + l x size; no destination registers, counted by vmcnt
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+// the minibatch records of ONE sample tile straight into the workgroup's LDS, by one wave: lane (c, h) fetches quad h of sample c's record -> rec_t[h][c] (a three-quad
+// record's scalar quad with a second instruction -> rec_t[2][c]), the old value -> vo_t[c], and writes the validity word.  Until round 5 every one of the H/32 waves
+// gathered the same records into its own registers (8 - 12 of them, live across the whole pass) in front of a streaming chain, whose first fragment wait then sat out the gather
+template <int KIND, int HEAD>
+__device__ __forceinline__ void wide_request_records(const GradArgs& a, const TileIdx& ti, int lane, float* rec_t, float* vo_t, int* val_t) {
+    constexpr int RS = RecLayout<EnvSpec<KIND>::D>::RS;
+    const int64_t li = ti.gidx - a.idx_lo;
+    const bool valid = ti.inb && li >= 0 && li < a.n_local;
+    const int64_t idx = valid ? li : 0;
+    glds16(a.rec + RS * idx + (lane >> 5), rec_t);
+    if (RS == 3) glds16(a.rec + RS * idx + 2, rec_t + 64 * 4);
+    if (HEAD == HEAD_VALUE && a.has_clip_vf) glds4(a.val_old + idx, vo_t);
+    val_t[lane] = valid ? 1 : 0;
+}
 __device__ __forceinline__ void wide_split_preload(const u32x4* __restrict__ wimg, int MTv, int mo, int lane, u32x4 (&af)[2][2]) {
     const u32x4* base = wimg + ((size_t)mo * MTv * 4) * 64 + lane;
 #pragma unroll
@@ -423,6 +449,8 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
     float* wl = smem;
     char* P1 = reinterpret_cast<char*>(smem + SC::P1); char* P2 = reinterpret_cast<char*>(smem + SC::P2);
     float* XI = smem + SC::XI; float* PO = smem + SC::PO;
+    float* RECS = smem + SC::REC; float* VO = smem + SC::VO; int* VAL = reinterpret_cast<int*>(smem + SC::VAL);
+    constexpr int RS = RecLayout<D>::RS, RECT = SC::RQ * 32 * 4;    // record quads per sample; floats of one sample tile's record block
     // staged small parameters in the scales of the f16-piece arithmetic (dril_device.h): b2 starts the SCALED accumulator of L2, W3S = W3 / kActScale for the output layer
     // (its operand is kActScale h2), W3B = W3 / kActScale^2 for dh
     {
@@ -476,21 +504,28 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
     const int g = (int)(blockIdx.x % a.G);
     const int64_t ntiles = (a.count + kTile - 1) / kTile;            // sample tiles of 32; the workgroup takes NT consecutive ones per pass (a missing last one is all-invalid)
     constexpr int KS = FirstLayer<D>::KS;                            // two first-layer k-steps for D <= 4, four for D <= 8 (Acrobot)
-    TileIn<O, KS> cur[NT], nxt[NT];
     int64_t tile = (int64_t)g * NT;
-    if (tile < ntiles) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) load_tile<KIND, O, HEAD, REC>(a, tile + t, ntiles, c, h, cur[t]);
+    const int64_t stride = (int64_t)a.G * NT;
+    // wave t (< NT) is the loader of sample tile t: it holds the epoch-order entries of the NEXT pass's samples and requests their records in front of the dW2 stage — the
+    // one stage without vector-memory instructions, under which the gather (and the entry load for the pass after) completes unseen
+    TileIdx nidx; nidx.gidx = 0; nidx.inb = false;
+    if (w < NT && tile < ntiles) {
+        wide_request_records<KIND, HEAD>(a, tile_index(a, tile + w, ntiles, c), lane, RECS + w * RECT, VO + w * 64, VAL + w * 64);
+        nidx = tile_index(a, tile + stride + w, ntiles, c);
     }
+    __syncthreads();                                                 // (drains the LDS-DMA: the first pass's records are in place)
 #ifdef DRIL_STAMPS
     unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
 #endif
-    for (; tile < ntiles; tile += (int64_t)a.G * NT) {
+    for (; tile < ntiles; tile += stride) {
         // ---- h1 tile w of every sample tile; its pieces into the workgroup images ----
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            unpack_tile<KIND, O, HEAD, REC>(a, h, cur[t]);
+            const int ln_ = opaque(lane), c = ln_ & 31, h = ln_ >> 5;      // stage-local lane coordinates: every LDS address below is a lane constant, and derived from values the optimiser can see through they are all hoisted out of the pass loop and held in registers (or spilled) for the whole kernel
+            float xk[KS];                                                             // xk[s] = component 2s + h of sample c (zero beyond D: the records are zero-padded)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) xk[s] = RECS[t * RECT + ((((2 * s) >> 2) * 32 + c) << 2) + ((2 * s) & 3) + h];
             f32x16 h1w;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -498,13 +533,13 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
                 h1w[4 * q + 0] = b[0]; h1w[4 * q + 1] = b[1]; h1w[4 * q + 2] = b[2]; h1w[4 * q + 3] = b[3];
             }
 #pragma unroll
-            for (int s = 0; s < KS; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], cur[t].xk[s], h1w);
+            for (int s = 0; s < KS; ++s) h1w = mfma32(wl[L::W1T + (2 * s + h) * H + 32 * w + c], xk[s], h1w);
             tanh16_scaled<false>(h1w, 1.0f);                                          // kActScale h1
             // `opaque(lane)`: the image addresses are lane constants, and hoisted out of the tile loop as loop invariants they hold ~60 registers for the whole kernel (they cost 2-3 VALU to rebuild)
-            store_tile_pieces2<H>(P1 + t * NTS, w, h1w, opaque(lane));
+            store_tile_pieces2<H>(P1 + t * NTS, w, h1w, ln_);
             if (w == t) {                                                             // wave t keeps sample tile t's observations for the dW1 sums
 #pragma unroll
-                for (int s = 0; s < KS; ++s) { const int d = 2 * s + h; XI[(t * (D + 2) + (d < D ? d : D + 1)) * kTS + c] = d < D ? cur[t].xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the spare row
+                for (int s = 0; s < KS; ++s) { const int d = 2 * s + h; XI[(t * (D + 2) + (d < D ? d : D + 1)) * kTS + c] = d < D ? xk[s] : 0.f; }   // branch-free: out-of-range components rewrite the spare row
             }
         }
         STAMP(0);
@@ -512,9 +547,6 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
         wide_split_preload(w2p, MT, w, lane, afw);                                    // first W2 fragments in flight across the barrier
         __syncthreads();                                                              // B1: P1, XI complete
         STAMP(1);
-        // the next pass's records are requested only now: issued before unpack_tile(cur) they sat behind cur's loads in the in-order vmcnt queue (see ppo_grad_wide_kernel)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) load_tile<KIND, O, HEAD, REC>(a, tile + (int64_t)a.G * NT + t, ntiles, c, h, nxt[t]);
         // ---- h2 tile w ----
         f32x16 h2w[NT];
         dense_tile_split<H, NT, true, false>(w2p, wl + L::B2, P1, w, opaque(lane), afw, h2w);
@@ -526,6 +558,7 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int o = 0; o < O; ++o) {
+                const int ln_ = opaque(lane), c = ln_ & 31, h = ln_ >> 5;
                 float p = 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -541,6 +574,7 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
         float dz[NT][O];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            const int ln_ = opaque(lane), c = ln_ & 31, h = ln_ >> 5;
             float out[O];
 #pragma unroll
             for (int o = 0; o < O; ++o) {
@@ -549,7 +583,16 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
                 for (int ww = 0; ww < MT; ++ww) v += PO[((t * MT + ww) * O + o) * 32 + c];  // fixed order: every wave gets the same bits
                 out[o] = v;
             }
-            loss_head<O, HEAD>(as, cur[t], out, cur[t].valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz[t], st, dlsp);     // dz = SG dLoss/dout
+            // this lane's sample: the record's scalar quad {action bits, adv, logp_old, ret}, the old value, the validity word
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(RECS + t * RECT + (((RS - 1) * 32 + c) << 2));
+            TileIn<O, KS> cur; cur.act = 0; cur.s0 = 0.f; cur.s1 = 0.f;
+            const bool valid = VAL[t * 64 + c] != 0;
+            if (HEAD == HEAD_VALUE) { cur.s0 = sc[3]; cur.s1 = a.has_clip_vf ? VO[t * 64 + c] : 0.f; }
+            else {
+                cur.s0 = sc[1]; cur.s1 = sc[2];
+                if (HEAD == HEAD_CATEGORICAL) cur.act = __float_as_int(sc[0]) - a.action_start; else cur.xa[0] = sc[0];
+            }
+            loss_head<O, HEAD>(as, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz[t], st, dlsp);     // dz = SG dLoss/dout
 #pragma unroll
             for (int o = 0; o < O; ++o) db3p[o] += (h == 0 && w == 0) ? dz[t][o] : 0.f;
         }
@@ -563,11 +606,12 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
             for (int t = 1; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = fmaf(h2w[t][r], dz[t][o], v[r]);
-            dW3a[o] += half_reduce16_lane(v, lane);
+            dW3a[o] += half_reduce16_lane(v, opaque(lane));
         }
         // ---- dz2 tile w (in h2w's registers); its pieces into the workgroup images ----
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            const int ln_ = opaque(lane), h = ln_ >> 5;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float dh[4] = {0.f, 0.f, 0.f, 0.f};
@@ -580,7 +624,7 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) { const float hv = h2w[t][4 * q + cc]; h2w[t][4 * q + cc] = dh[cc] * fmaf(-hv, hv, kActScale * kActScale); }   // = SG dz2
             }
-            store_tile_pieces2<H>(P2 + t * NTS, w, h2w[t], opaque(lane));
+            store_tile_pieces2<H>(P2 + t * NTS, w, h2w[t], ln_);
         }
         wide_split_preload(w2tp, MT, w, lane, afw);                                   // first W2' fragments in flight across the barrier
         STAMP(4);
@@ -590,12 +634,21 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
         f32x16 g1[NT];
         dense_tile_split<H, NT, false, true>(w2tp, nullptr, P2, w, opaque(lane), afw, g1);
         STAMP(6);
+        // loader waves: next pass's records (LDS-DMA), the pass after next's epoch-order entries — requested in front of the two stages that issue no vector-memory
+        // instruction (dz1 / dW1, then the dW2 product: ~11 k cycles): vmcnt retires in order, so a gather in front of a streaming chain holds that chain's first fragment wait
+        // for the whole gather latency.  (NOT between the sched_barrier below and the dW2 stage: a branch there costs the register allocator ~200 spilled registers.)
+        if (w < NT) {
+            const int ln_ = opaque(lane);
+            wide_request_records<KIND, HEAD>(a, nidx, ln_, RECS + w * RECT, VO + w * 64, VAL + w * 64);
+            nidx = tile_index(a, tile + 2 * stride + w, ntiles, ln_ & 31);
+        }
         // ---- dz1', then dW1 | db1 as per-lane sums over the lane's samples (before dW2, so that dz1 is dead while the 128 accumulators are being updated) ----
         {
             constexpr float c0 = 1.0f / kWScale, c1 = c0 / (kActScale * kActScale);             // g1 = (SG dz2 . kWScale W2) (1 - h1^2) / kWScale = SG dz1
             const int tmw = opaque(tmbase) ^ (64 * w);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
+                const int h = opaque(lane) >> 5;
                 f32x16 h1r;
                 load_tile_pieces2_T<H>(P1 + t * NTS, tmw, h1r);                                // kActScale h1 of the lane's unit at its 16 samples, back from the pieces (to 2^-24)
 #pragma unroll
@@ -642,15 +695,13 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
                 __builtin_amdgcn_sched_barrier(0);                                    // keep the next m-tile's fragment requests behind these MFMAs (hoisted, they spill)
             }
         }
-        __syncthreads();                                                              // B4: P1 / P2 / PO / XI free for the next pass
+        __syncthreads();                                                              // B4: P1 / P2 / PO / XI free for the next pass; the next pass's records have landed (the barrier's fence drains the DMA)
         STAMP(8);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
     }
 #ifdef DRIL_STAMPS
     if (lane == 0 && a.dbg) {
         unsigned long long* o_ = a.dbg + ((size_t)(blockIdx.x % (2 * a.G)) * 4 + (w & 3)) * 12;
-        const int64_t stride = (int64_t)a.G * NT, first = (int64_t)g * NT;
+        const int64_t first = (int64_t)g * NT;
         if (w < 4) { for (int k = 0; k < 10; ++k) o_[k] = stamp_acc[k]; o_[10] = (unsigned long long)(first < ntiles ? (ntiles - first + stride - 1) / stride : 0); o_[11] = HEAD; }
     }
 #endif

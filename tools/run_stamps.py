@@ -9,7 +9,9 @@ pkg = g.load_package()
 capi = pkg._capi
 import subprocess
 _so = ROOT / "dril.jl_amd" / "csrc" / "libdril_hip_stamps.so"
-subprocess.run(["make", "-C", str(ROOT / "dril.jl_amd" / "csrc"), "-j8", "stamps"], check=True, stdout=sys.stderr)   # diagnostic build (-DDRIL_STAMPS); never used for timing claims
+import os
+if not os.environ.get("STAMPS_NO_MAKE"):      # (a library prebuilt in the container travels with the gpurun snapshot: STAMPS_NO_MAKE=1 skips the rebuild on the box)
+    subprocess.run(["make", "-C", str(ROOT / "dril.jl_amd" / "csrc"), "-j8", "stamps"], check=True, stdout=sys.stderr)   # diagnostic build (-DDRIL_STAMPS); never used for timing claims
 lib = capi.load_library(_so)
 wide = len(sys.argv) > 1 and sys.argv[1] == "wide"       # config 3 shape: Pendulum, [256,256]
 small = len(sys.argv) > 1 and sys.argv[1] == "small"     # configs[0] shape: 4 envs, PPO() defaults (the persistent small-minibatch kernel)
