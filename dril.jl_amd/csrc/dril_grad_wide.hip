@@ -406,23 +406,52 @@ __device__ __forceinline__ void dense_tile_split(const u32x4* __restrict__ wimg,
         for (int t = 0; t < NT; ++t) { acc[t][4 * q + 0] = b[0]; acc[t][4 * q + 1] = b[1]; acc[t][4 * q + 2] = b[2]; acc[t][4 * q + 3] = b[3]; }
     }
     const u32x4* base = wimg + ((size_t)mo * MT * 4) * 64 + lane;
+    // the activation fragments of a k16 step are requested one step AHEAD of the MFMAs that use them (two named register sets, X0 for the even steps and X1 for the odd ones:
+    // no copies): read-then-wait-then-MFMA left every step's six MFMAs behind an LDS round trip, with both waves of a SIMD in the same place
+    f16x8 X0[NT][2], X1[NT][2];
+    {
+        const int a = rowb + (((0 + h) ^ gsw) << 4);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) X0[t][p] = *reinterpret_cast<const f16x8*>(pimg + t * NTS + p * PS + a);
+    }
 #pragma unroll 1
     for (int mi = 0; mi < MT; ++mi) {
-        const u32x4* nextp = base + (size_t)((mi + 1 < MT ? mi + 1 : mi) * 4) * 64;   // the last iteration re-reads its own fragments (in bounds, unused)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int a = rowb + (((4 * mi + 2 * s + h) ^ gsw) << 4);
-            f16x8 X[NT][2];
+        const int mn = mi + 1 < MT ? mi + 1 : mi;                                      // the last iteration re-reads its own fragments (in bounds, unused)
+        const u32x4* nextp = base + (size_t)(mn * 4) * 64;
+        {
+            const int a = rowb + (((4 * mi + 2 + h) ^ gsw) << 4);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) X[t][p] = *reinterpret_cast<const f16x8*>(pimg + t * NTS + p * PS + a);
-            const f16x8 W0 = __builtin_bit_cast(f16x8, af[s][0]), W1 = __builtin_bit_cast(f16x8, af[s][1]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = TRANSPOSED ? mfma_split3(X[t][0], X[t][1], W0, W1, acc[t]) : mfma_split3(W0, W1, X[t][0], X[t][1], acc[t]);
-#pragma unroll
-            for (int p = 0; p < 2; ++p) af[s][p] = nextp[(size_t)(s * 2 + p) * 64];
+                for (int p = 0; p < 2; ++p) X1[t][p] = *reinterpret_cast<const f16x8*>(pimg + t * NTS + p * PS + a);
         }
+        __builtin_amdgcn_sched_barrier(0);                                             // (the scheduler otherwise sinks the reads back to just in front of their MFMAs to save the registers)
+        {
+            const f16x8 W0 = __builtin_bit_cast(f16x8, af[0][0]), W1 = __builtin_bit_cast(f16x8, af[0][1]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = TRANSPOSED ? mfma_split3(X0[t][0], X0[t][1], W0, W1, acc[t]) : mfma_split3(W0, W1, X0[t][0], X0[t][1], acc[t]);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) af[0][p] = nextp[(size_t)p * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int a = rowb + (((4 * mn + h) ^ gsw) << 4);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) X0[t][p] = *reinterpret_cast<const f16x8*>(pimg + t * NTS + p * PS + a);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const f16x8 W0 = __builtin_bit_cast(f16x8, af[1][0]), W1 = __builtin_bit_cast(f16x8, af[1][1]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = TRANSPOSED ? mfma_split3(X1[t][0], X1[t][1], W0, W1, acc[t]) : mfma_split3(W0, W1, X1[t][0], X1[t][1], acc[t]);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) af[1][p] = nextp[(size_t)(2 + p) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 // sum of the eight f16 values of a fragment register set, in f32 (v_dot2c_f32_f16 against {1, 1}: the products are exact, the sum is an f32 sum)
@@ -643,26 +672,32 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
             nidx = tile_index(a, tile + 2 * stride + w, ntiles, ln_ & 31);
         }
         // ---- dz1', then dW1 | db1 as per-lane sums over the lane's samples (before dW2, so that dz1 is dead while the 128 accumulators are being updated) ----
+        // Eight groups (sample tile t, register group q = samples 8q + 4h + {0..3} of the lane's unit): two transposed reads (the h1 pieces) and D broadcast reads (x) each.
+        // The loads of group g + 1 are requested before group g is computed (two named buffers) — left to itself the allocator, short of registers here, gave every read
+        // the same four registers and a full LDS wait (round-5 stamps: 4.3 k cycles for ~300 vector instructions)
         {
             constexpr float c0 = 1.0f / kWScale, c1 = c0 / (kActScale * kActScale);             // g1 = (SG dz2 . kWScale W2) (1 - h1^2) / kWScale = SG dz1
-            const int tmw = opaque(tmbase) ^ (64 * w);
+            const int ln_ = opaque(lane), h = ln_ >> 5;
+            const int tmw = opaque(tmbase) ^ (64 * w), tmw32 = tmw ^ 32;
+            const float* xrow = XI + 4 * h;
+            u32x2 hp[2][2]; f32x4 xq[2][D];
+#define S3_LOAD(B, T, Q) { const int a_ = (((Q) & 1) ? tmw32 : tmw) + 8 * (Q) * RB; \
+                           hp[B][0] = __builtin_bit_cast(u32x2, lds_read_tr16(P1 + (T) * NTS, a_)); hp[B][1] = __builtin_bit_cast(u32x2, lds_read_tr16(P1 + (T) * NTS, a_ + PS)); \
+                           _Pragma("unroll") for (int d = 0; d < D; ++d) xq[B][d] = *reinterpret_cast<const f32x4*>(xrow + ((T) * (D + 2) + d) * kTS + 8 * (Q)); }
+#define S3_COMP(B, T, Q) { float hv[4]; pieces_sum2(hp[B][0].x, hp[B][1].x, hv[0], hv[1]); pieces_sum2(hp[B][0].y, hp[B][1].y, hv[2], hv[3]); \
+                           _Pragma("unroll") for (int i = 0; i < 4; ++i) { const float t2 = hv[i] * hv[i]; const float gz = g1[T][4 * (Q) + i] * fmaf(-t2, c1, c0); db1a += gz; \
+                               _Pragma("unroll") for (int d = 0; d < D; ++d) dW1a[d] = fmaf(gz, xq[B][d][i], dW1a[d]); } }
+            S3_LOAD(0, 0, 0)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int h = opaque(lane) >> 5;
-                f32x16 h1r;
-                load_tile_pieces2_T<H>(P1 + t * NTS, tmw, h1r);                                // kActScale h1 of the lane's unit at its 16 samples, back from the pieces (to 2^-24)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { const float t2 = h1r[r] * h1r[r]; g1[t][r] = g1[t][r] * fmaf(-t2, c1, c0); }
-                db1a += sum16(g1[t]);
-#pragma unroll
-                for (int d = 0; d < D; ++d)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 x = *reinterpret_cast<const f32x4*>(XI + (t * (D + 2) + d) * kTS + 8 * q + 4 * h);     // two addresses per wave: broadcast reads
-                        dW1a[d] = fmaf(g1[t][4 * q + 0], x[0], dW1a[d]); dW1a[d] = fmaf(g1[t][4 * q + 1], x[1], dW1a[d]);
-                        dW1a[d] = fmaf(g1[t][4 * q + 2], x[2], dW1a[d]); dW1a[d] = fmaf(g1[t][4 * q + 3], x[3], dW1a[d]);
-                    }
+            for (int gq = 0; gq < 4 * NT; ++gq) {
+                const int t = gq >> 2, q = gq & 3, tn = (gq + 1) >> 2, qn = (gq + 1) & 3;
+                if (gq & 1) { if (gq + 1 < 4 * NT) S3_LOAD(0, tn, qn) } else { S3_LOAD(1, tn < NT ? tn : NT - 1, qn) }
+                __builtin_amdgcn_sched_barrier(0);
+                if (gq & 1) S3_COMP(1, t, q) else S3_COMP(0, t, q)
+                __builtin_amdgcn_sched_barrier(0);
             }
+#undef S3_LOAD
+#undef S3_COMP
         }
         __builtin_amdgcn_sched_barrier(0);
         STAMP(7);
@@ -679,20 +714,33 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
                         Az[2 * t + s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<H>(P2 + t * NTS, tbw, tbw16, p, s));
                         db2a = frag_sum8(Az[2 * t + s][p], db2a);
                     }
+            // the h1 fragments of a step (m-tile mj, sample tile t) are requested one step ahead of its MFMAs, in two named register sets (BhA: t = 0, BhB: t = 1)
+            static_assert(NT == 2, "the dW2 stage alternates two fragment sets");
+            f16x8 BhA[2][2], BhB[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) BhA[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<H>(P1, tb, tb ^ 16, p, s));      // m-tile 0
 #pragma unroll
             for (int mj = 0; mj < MT; ++mj) {
                 const int tbj = tb ^ (64 * mj), tbj16 = tbj ^ 16;
+                const int mn = mj + 1 < MT ? mj + 1 : mj, tbn = tb ^ (64 * mn), tbn16 = tbn ^ 16;       // (the last step requests its own fragments again: in bounds, unused)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    f16x8 Bh[2][2];
+                for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int s = 0; s < 2; ++s)
+                    for (int p = 0; p < 2; ++p) BhB[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<H>(P1 + NTS, tbj, tbj16, p, s));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int p = 0; p < 2; ++p) Bh[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<H>(P1 + t * NTS, tbj, tbj16, p, s));
+                for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split3(Az[s][0], Az[s][1], BhA[s][0], BhA[s][1], dW2[mj]);            // (SG dz2)(kActScale h1)', sample tile 0
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split3(Az[2 * t + s][0], Az[2 * t + s][1], Bh[s][0], Bh[s][1], dW2[mj]);   // (SG dz2)(kActScale h1)'
-                }
-                __builtin_amdgcn_sched_barrier(0);                                    // keep the next m-tile's fragment requests behind these MFMAs (hoisted, they spill)
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) BhA[s][p] = __builtin_bit_cast(f16x8, load_frag_wide_T<H>(P1, tbn, tbn16, p, s));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) dW2[mj] = mfma_split3(Az[2 + s][0], Az[2 + s][1], BhB[s][0], BhB[s][1], dW2[mj]);    // sample tile 1
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();                                                              // B4: P1 / P2 / PO / XI free for the next pass; the next pass's records have landed (the barrier's fence drains the DMA)
