@@ -1191,16 +1191,18 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
     {   // shares of the LAST grad launch, averaged over waves, per head
         std::vector<unsigned long long> d((size_t)2 * h->Gmax * 4 * 12);
         hipMemcpy(d.data(), h->dbg, d.size() * 8, hipMemcpyDeviceToHost);
-        const char* names_f32[] = {"gather/loop", "L1+tanh", "L2+tanh", "out+head", "dW3 block", "dz2", "h1img+dh1+dz1", "dW2 block", "dW1 block"};
-        const char* names_split[] = {"S1 unpack+L1", "S2 tanh+split+L2+tanh", "S3 L3+head+dW3", "S4 dz2+split+dh1+mask", "S5 dW2", "S6 dz1 img+dW1", "-", "-", "-"};
-        const char** names = std::getenv("DRIL_GRAD_VARIANT") && std::atoi(std::getenv("DRIL_GRAD_VARIANT")) == 0 ? names_f32 : names_split;
+        const char* names_f32[] = {"gather/loop", "L1+tanh", "L2+tanh", "out+head", "dW3 block", "dz2", "h1img+dh1+dz1", "dW2 block", "dW1 block", "-"};
+        const char* names_split[] = {"S1 unpack+L1", "S2 tanh+split+L2+tanh", "S3 L3+head+dW3", "S4 dz2+split+dh1+mask", "S5 dW2", "S6 dz1 img+dW1", "-", "-", "-", "-"};
+        // ppo_grad_wide_split_kernel (round 5; per pass of kWideSplitNT x 32 samples)
+        const char* names_wide[] = {"L1+tanh+h1 pieces", "wait B1", "L2 chain+tanh", "out partials+wait B2", "head+dW3+dz2+pieces", "wait B3", "dh1 chain", "loader+dz1+dW1", "dW2 chain", "wait B4 (+DMA)"};
+        const char** names = std::getenv("DRIL_GRAD_VARIANT") && std::atoi(std::getenv("DRIL_GRAD_VARIANT")) == 0 ? names_f32 : h->wide ? names_wide : names_split;
         for (int head = 0; head < 3; ++head) {
             double acc[10] = {0}; double tiles = 0; int nw = 0;
             for (size_t w = 0; w < d.size() / 12; ++w) if (d[w * 12 + 10] > 0 && (int)d[w * 12 + 11] == head) { for (int k = 0; k < 10; ++k) acc[k] += (double)d[w * 12 + k]; tiles += (double)d[w * 12 + 10]; ++nw; }
             if (!nw) continue;
-            double tot = 0; for (int k = 0; k < 9; ++k) tot += acc[k];
+            double tot = 0; for (int k = 0; k < 10; ++k) tot += acc[k];
             fprintf(stderr, "[stamps] head %d: %d waves, %.0f tiles/wave, %.0f ticks/tile (s_memtime ticks)\n", head, nw, tiles / nw, tot / tiles);
-            for (int k = 0; k < 9; ++k) fprintf(stderr, "   %-16s %8.0f ticks/tile  %5.1f %%\n", names[k], acc[k] / tiles, 100.0 * acc[k] / tot);
+            for (int k = 0; k < 10; ++k) fprintf(stderr, "   %-22s %8.0f ticks/tile  %5.1f %%\n", names[k], acc[k] / tiles, 100.0 * acc[k] / tot);
         }
     }
 #endif

@@ -743,14 +743,20 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();                                                              // B4: P1 / P2 / PO / XI free for the next pass; the next pass's records have landed (the barrier's fence drains the DMA)
         STAMP(8);
+        __syncthreads();                                                              // B4: P1 / P2 / PO / XI free for the next pass; the next pass's records have landed (the barrier's fence drains the DMA)
+        STAMP(9);
     }
 #ifdef DRIL_STAMPS
     if (lane == 0 && a.dbg) {
         unsigned long long* o_ = a.dbg + ((size_t)(blockIdx.x % (2 * a.G)) * 4 + (w & 3)) * 12;
         const int64_t first = (int64_t)g * NT;
-        if (w < 4) { for (int k = 0; k < 10; ++k) o_[k] = stamp_acc[k]; o_[10] = (unsigned long long)(first < ntiles ? (ntiles - first + stride - 1) / stride : 0); o_[11] = HEAD; }
+#ifdef DRIL_STAMPS_HI                                                                  // (the upper half of the workgroup's waves instead: the younger wave of every SIMD)
+        if (w >= MT / 2)
+#else
+        if (w < 4)
+#endif
+        { for (int k = 0; k < 10; ++k) o_[k] = stamp_acc[k]; o_[10] = (unsigned long long)(first < ntiles ? (ntiles - first + stride - 1) / stride : 0); o_[11] = HEAD; }
     }
 #endif
 

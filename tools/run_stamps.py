@@ -8,7 +8,8 @@ import __graft_entry__ as g
 pkg = g.load_package()
 capi = pkg._capi
 import subprocess
-_so = ROOT / "dril.jl_amd" / "csrc" / "libdril_hip_stamps.so"
+import os
+_so = ROOT / "dril.jl_amd" / "csrc" / os.environ.get("STAMPS_LIB", "libdril_hip_stamps.so")   # STAMPS_LIB=libdril_stamps_hi.so (tools/build_variant.sh, -DDRIL_STAMPS_HI): the younger wave of every SIMD
 import os
 if not os.environ.get("STAMPS_NO_MAKE"):      # (a library prebuilt in the container travels with the gpurun snapshot: STAMPS_NO_MAKE=1 skips the rebuild on the box)
     subprocess.run(["make", "-C", str(ROOT / "dril.jl_amd" / "csrc"), "-j8", "stamps"], check=True, stdout=sys.stderr)   # diagnostic build (-DDRIL_STAMPS); never used for timing claims
