@@ -379,6 +379,8 @@ function f32_fallback_info(env::DeviceParallelEnv)
 end
 "which gradient kernel the last optimiser step ran and the arithmetic it computes in, e.g. \"ppo_grad_pair_kernel: f32 (f16x2 split, f32 accumulate; ...)\" (dril_grad_kernel_info)"
 grad_kernel_info(env::DeviceParallelEnv) = unsafe_string(ccall((:dril_grad_kernel_info, LIB[]), Cstring, (Ptr{Cvoid},), env.handle))
+"which device the handle lives on: ordinal, name, PCI bus id, visibility masks (dril_device_info) — the line every rank of a multi-GPU job should print before `comm_init`"
+device_info(env::DeviceParallelEnv) = unsafe_string(ccall((:dril_device_info, LIB[]), Cstring, (Ptr{Cvoid},), env.handle))
 """
 "batch loop" / "compute_gradients" / "apply_gradients" (ppo.jl:206-207,239) have no host-side extent here — the whole epoch x minibatch loop is ONE
 library call — so their times come from the device: HIP events around the kernels that stand in for them.  TimerOutputs has no public API for adding a

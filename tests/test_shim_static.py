@@ -43,6 +43,33 @@ def test_checker_catches_a_missing_locals_key(tmp_path):
     assert r.returncode == 1 and "TRAINING_START_LOCALS" in r.stdout, r.stdout
 
 
+def test_checker_catches_a_wrong_ccall_width_and_arity(tmp_path):
+    """a ccall whose argument is 8 bytes where the header says int32_t does not fail at run time, it corrupts: the prototype check must see it"""
+    import shutil
+    for f in SHIM.parent.glob("DRiLHIP_*.jl"): shutil.copy(f, tmp_path / f.name)
+    text = SHIM.read_text()
+    good = "ccall((:dril_env_observe, LIB[]), Int32, (Ptr{Cvoid}, Ptr{Float32}, Int32)"
+    assert good in text
+    for bad_sig, what in ((good.replace("Ptr{Float32}, Int32)", "Ptr{Float32}, Int64)"), "argument 3 Int64"),            # width
+                          (good.replace("(Ptr{Cvoid}, Ptr{Float32}, Int32)", "(Ptr{Cvoid}, Ptr{Float32})"), "2 argument types"),   # arity
+                          (good.replace("Ptr{Float32}, Int32)", "Float32, Int32)"), "argument 2 Float32"),              # pointer-ness
+                          (good.replace("Ptr{Float32}, Int32)", "Ptr{Float64}, Int32)"), "argument 2 Ptr{Float64}")):  # element type
+        bad = tmp_path / "DRiLHIP.jl"
+        bad.write_text(text.replace(good, bad_sig))
+        r = _run("--shim", str(bad))
+        assert r.returncode == 1 and "ccall dril_env_observe" in r.stdout and what in r.stdout, r.stdout[-1500:]
+
+
+def test_checker_catches_an_unbalanced_block(tmp_path):
+    import shutil
+    for f in SHIM.parent.glob("DRiLHIP_*.jl"): shutil.copy(f, tmp_path / f.name)
+    extras = tmp_path / "DRiLHIP_extras.jl"
+    extras.write_text(extras.read_text() + "\nfunction forgot_its_end(x)\n    x[end] + 1   # `end` inside an index is not a block end\n")
+    (tmp_path / "DRiLHIP.jl").write_text(SHIM.read_text())
+    r = _run("--shim", str(tmp_path / "DRiLHIP.jl"))
+    assert r.returncode == 1 and "DRiLHIP_extras.jl" in r.stdout and "block openers" in r.stdout, r.stdout[-1500:]
+
+
 def test_locals_lists_match_the_python_mirror(pkg):
     import re
     text = SHIM.read_text()

@@ -9,6 +9,8 @@
      test reads (test/test_callbacks.jl:25-27,36-39).
   3. C ABI.  Every `ccall((:symbol, LIB[]), ...)` names a function declared in include/*.h; the Julia mirror structs list the header structs'
      fields in the same order.
+  4. ccall PROTOTYPES.  Arity, pointer-ness and scalar width / kind of every argument type and of the result type of every ccall against the C prototype.
+  5. BLOCK BALANCE.  Per .jl file: block openers == `end`s.
 
 Exit status 0 = all checks pass.  `--markdown` prints the dispatch table of INTEGRATION.md §2.  Without /root/reference (the GPU box) check 1 and the
 test-file half of check 2 are skipped and said so.
@@ -271,11 +273,134 @@ def check_abi() -> list[str]:
     return errors
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# 4. ccall PROTOTYPES: for every `ccall((:sym, LIB[]), Ret, (T...), args...)` arity, pointer-ness and scalar width / kind of every argument and of the result
+#    against the C prototype of include/*.h (done by hand once — a ccall with a wrong width does not fail, it corrupts).
+# 5. BLOCK BALANCE per file: openers (function / struct / if / for / while / let / begin / do / try / module / macro / quote) == `end`s, outside strings, comments,
+#    brackets (a[end], generators) and symbols — what a parser would refuse first.
+# ---------------------------------------------------------------------------------------------------------------------------------
+C_SCALARS = {"int32_t": ("i", 4), "uint32_t": ("i", 4), "int": ("i", 4), "unsigned": ("i", 4), "int64_t": ("i", 8), "uint64_t": ("i", 8), "size_t": ("i", 8),
+             "long long": ("i", 8), "unsigned long long": ("i", 8), "float": ("f", 4), "double": ("f", 8), "uint8_t": ("i", 1), "int8_t": ("i", 1), "char": ("i", 1), "void": ("v", 0)}
+JL_SCALARS = {"Int32": ("i", 4), "UInt32": ("i", 4), "Cint": ("i", 4), "Cuint": ("i", 4), "Int64": ("i", 8), "UInt64": ("i", 8), "Csize_t": ("i", 8), "Clonglong": ("i", 8),
+              "Float32": ("f", 4), "Cfloat": ("f", 4), "Float64": ("f", 8), "Cdouble": ("f", 8), "UInt8": ("i", 1), "Int8": ("i", 1), "Cvoid": ("v", 0), "Nothing": ("v", 0)}
+
+
+def c_class(t: str):
+    """C parameter / return type -> ("ptr", element class or None) | (kind, bytes)"""
+    t = re.sub(r"\b(const|struct|restrict|volatile)\b", " ", t)
+    ptr = "*" in t or "[" in t
+    base = re.sub(r"\[.*?\]", "", t).replace("*", " ")
+    words = base.split()
+    # drop the parameter name (last word) when the remaining words still form a type
+    for cut in (len(words), len(words) - 1):
+        name = " ".join(words[:cut])
+        if name in C_SCALARS:
+            return ("ptr", C_SCALARS[name]) if ptr else C_SCALARS[name]
+    return ("ptr", None) if ptr else ("?", " ".join(words))     # a struct / opaque handle pointer, or something this table does not know
+
+
+def jl_class(t: str):
+    t = t.strip()
+    if t == "Cstring":
+        return ("ptr", ("i", 1))
+    m = re.match(r"^(Ptr|Ref)\{(.*)\}$", t)
+    if m:
+        return ("ptr", JL_SCALARS.get(m.group(2).strip()))      # Ptr{Cvoid} / Ptr{SomeStruct} -> element None or ("v", 0): compatible with any pointer
+    return JL_SCALARS.get(t, ("?", t))
+
+
+def c_prototypes() -> dict:
+    text = "\n".join(p.read_text() for p in sorted((ROOT / "include").glob("*.h")))
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S); text = re.sub(r"//[^\n]*", " ", text)
+    protos = {}
+    for m in re.finditer(r"([\w \*]+?)\b(dril_\w+)\s*\(([^;{}]*?)\)\s*;", text, re.S):
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "typedef" in ret or "(" in ret:
+            continue
+        plist = [] if params in ("", "void") else [p.strip() for p in split_top(params)]
+        protos[name] = (ret, plist)
+    return protos
+
+
+def compatible(j, c) -> bool:
+    if j[0] == "?" or c[0] == "?":
+        return False
+    if (j[0] == "ptr") != (c[0] == "ptr"):
+        return False
+    if j[0] == "ptr":
+        je, ce = j[1], c[1]
+        return je is None or ce is None or je[0] == "v" or ce[0] == "v" or je == ce      # element types compared only when both sides name a scalar
+    return j == c
+
+
+def check_ccalls() -> list[str]:
+    errors, n = [], 0
+    protos = c_prototypes()
+    shim = read_shim(SHIM)
+    for m in re.finditer(r"ccall\(\(:(\w+),\s*LIB\[\]\),\s*([\w{}]+),\s*\(", shim):
+        sym, ret = m.group(1), m.group(2)
+        # the argument-type tuple: balanced parentheses from the '(' that ends the match
+        i, depth = m.end(), 1
+        while depth and i < len(shim):
+            depth += shim[i] in "({["; depth -= shim[i] in ")}]"; i += 1
+        types = [t for t in split_top(shim[m.end():i - 1]) if t]
+        line = shim.count("\n", 0, m.start()) + 1
+        if sym not in protos:
+            errors.append(f"ccall {sym} (line {line} of the joined shim): no prototype parsed from include/*.h"); continue
+        cret, cparams = protos[sym]
+        n += 1
+        if len(types) != len(cparams):
+            errors.append(f"ccall {sym} (line {line}): {len(types)} argument types {types}, the header declares {len(cparams)}: {cparams}"); continue
+        if not compatible(jl_class(ret), c_class(cret + " _")):
+            errors.append(f"ccall {sym} (line {line}): result {ret} vs C `{cret}`")
+        for k, (jt, ct) in enumerate(zip(types, cparams)):
+            if not compatible(jl_class(jt), c_class(ct)):
+                errors.append(f"ccall {sym} (line {line}): argument {k + 1} {jt} vs C `{ct}`")
+    print(f"ccall prototypes: {n} call sites checked against {len(protos)} prototypes of include/*.h")
+    if n < 40:
+        errors.append(f"only {n} ccall sites parsed — parser out of date?")
+    return errors
+
+
+def block_balance(text: str) -> tuple[int, int]:
+    """(openers, ends) at bracket depth 0 outside strings / comments / symbols"""
+    text = re.sub(r'"""(?:.|\n)*?"""', '""', text)
+    text = re.sub(r'"(?:\\.|[^"\\\n])*"', '""', text)
+    text = re.sub(r"#=(?:.|\n)*?=#", " ", text); text = re.sub(r"#[^\n]*", " ", text)
+    text = re.sub(r"'(?:\\.|[^'\\])'", "' '", text)
+    opens = ends = depth = 0
+    for m in re.finditer(r"[\[\]()]|:?\b[A-Za-z_]\w*\b", text):
+        tok = m.group(0)
+        if tok in "[(":
+            depth += 1
+        elif tok in "])":
+            depth -= 1
+        elif depth == 0 and not tok.startswith(":"):
+            prev = text[max(0, m.start() - 1):m.start()]
+            if prev == ".":                                     # a field named like a keyword (x.end)
+                continue
+            if tok in ("function", "struct", "if", "for", "while", "let", "begin", "do", "try", "module", "macro", "quote"):
+                opens += 1
+            elif tok == "end":
+                ends += 1
+    return opens, ends
+
+
+def check_blocks() -> list[str]:
+    errors = []
+    for p in sorted(SHIM.parent.glob("*.jl")):
+        o, e = block_balance(p.read_text())
+        if o != e:
+            errors.append(f"{p.name}: {o} block openers but {e} `end`s")
+    print("block balance: " + ", ".join(f"{p.name} {block_balance(p.read_text())[0]}" for p in sorted(SHIM.parent.glob('*.jl'))))
+    return errors
+
+
 def main() -> int:
     global SHIM
     if "--shim" in sys.argv:                                    # check another copy (tests mutate one to prove that the round-1 bug would be caught)
         SHIM = Path(sys.argv[sys.argv.index("--shim") + 1])
-    errors = check_dispatch("--markdown" in sys.argv) + check_locals() + check_abi()
+    errors = check_dispatch("--markdown" in sys.argv) + check_locals() + check_abi() + check_ccalls() + check_blocks()
     for e in errors:
         print("ERROR:", e)
     print("check_shim:", "FAILED" if errors else "ok")

@@ -7,7 +7,7 @@ import os, re, subprocess, sys, tempfile
 src = sys.argv[1]; filt = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else ""
 extra = [a for a in sys.argv[2:] if a.startswith("-")]
 csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dril.jl_amd", "csrc")
-flags = "-O3 -fno-slp-vectorize -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form".split()
+flags = "-O3 -fno-slp-vectorize -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950".split() + ([] if "NO_VGPR_FORM" in os.environ else ["-mllvm", "-amdgpu-mfma-vgpr-form"])
 with tempfile.TemporaryDirectory() as td:
     obj = os.path.join(td, "o.o")
     r = subprocess.run(["/opt/rocm/bin/hipcc", *flags, *extra, "-Rpass-analysis=kernel-resource-usage", "-save-temps=obj", "-c", os.path.join(csrc, src), "-o", obj], capture_output=True, text=True, cwd=csrc)
