@@ -1185,7 +1185,9 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
     HIPCHK(h, hipMemcpyAsync(&nan, h->nan_flag, 4, hipMemcpyDeviceToHost, h->stream));
     int gae_gave_up = 0; HIPCHK(h, hipMemcpyAsync(&gae_gave_up, h->gae_err, 4, hipMemcpyDeviceToHost, h->stream));
     int rc = sync(h); if (rc) return rc;
-    if (gae_gave_up) { (void)hipMemsetAsync(h->gae_err, 0, 4, h->stream); return fail(h, DRIL_ERR_HIP, "gae_scan_kernel: a chunk's predecessor did not publish its carry within the spin limit (advantages of this rollout are NaN)"); }
+    // (a rank-local early return here would leave the other ranks of a data-parallel job alone in the collectives that follow — they saw this rank's NaN advantages in the
+    // all-reduced gradient and start the exact-f32 redo: the flag is folded into the explained-variance all-reduce below, and every rank returns the same code at the same point)
+    if (gae_gave_up && world == 1) { (void)hipMemsetAsync(h->gae_err, 0, 4, h->stream); return fail(h, DRIL_ERR_HIP, "gae_scan_kernel: a chunk's predecessor did not publish its carry within the spin limit (advantages of this rollout are NaN)"); }
     if (!h->generic) { float m; std::memcpy(&m, &w2bits, 4); h->w2max = (m == m) ? m : INFINITY; }
 #ifdef DRIL_STAMPS
     {   // shares of the LAST grad launch, averaged over waves, per head
@@ -1219,12 +1221,17 @@ int ppo_update_once(dril_handle* h, dril_ppo_stats* out) {
     for (int i = 0; i < h->ev_blocks; ++i) { s0 += ev[4 * i]; s1 += ev[4 * i + 1]; s2 += ev[4 * i + 2]; s3 += ev[4 * i + 3]; }
     double nn = (double)N;
     if (world > 1) {   // explained variance over all shards: tiny host-free all-reduce of the four sums
-        double v[5] = {s0, s1, s2, s3, nn}; double* d = h->adv_stats;   // reuse the 4-double scratch + norm scratch is too small: use ev_partials
+        double v[6] = {s0, s1, s2, s3, nn, gae_gave_up ? 1.0 : 0.0}; double* d = h->adv_stats;   // reuse the 4-double scratch + norm scratch is too small: use ev_partials
         HIPCHK(h, hipMemcpyAsync(h->ev_partials, v, sizeof(v), hipMemcpyHostToDevice, h->stream)); (void)d;
-        rc = rccl_allreduce(h, h->ev_partials, 5, kNcclFloat64); if (rc) return rc;
+        rc = rccl_allreduce(h, h->ev_partials, 6, kNcclFloat64); if (rc) return rc;
         HIPCHK(h, hipMemcpyAsync(v, h->ev_partials, sizeof(v), hipMemcpyDeviceToHost, h->stream));
         rc = sync(h); if (rc) return rc;
         s0 = v[0]; s1 = v[1]; s2 = v[2]; s3 = v[3]; nn = v[4];
+        if (v[5] > 0.0) {                                                  // some rank's GAE scan gave up: every rank reports it, at this same point
+            if (gae_gave_up) (void)hipMemsetAsync(h->gae_err, 0, 4, h->stream);
+            return fail(h, DRIL_ERR_HIP, gae_gave_up ? "gae_scan_kernel: a chunk's predecessor did not publish its carry within the spin limit (advantages of this rollout are NaN)"
+                                                     : "gae_scan_kernel gave up on another rank of the data-parallel job (its advantages are NaN): the update is invalid on every rank");
+        }
     }
     const double var_d = (s1 - s0 * s0 / nn) / (nn - 1.0), var_r = (s3 - s2 * s2 / nn) / (nn - 1.0);
     h->adam_steps = adam_steps0 + (uint64_t)n_upd;     // the steps the device APPLIED (a KL stop or a non-finite gradient skips the rest; the stopping step leaves both slots of the beta powers equal, so the parity is free)
@@ -1291,7 +1298,7 @@ int ppo_update(dril_handle* h, dril_ppo_stats* out) {
         h->grad_variant = gv; h->f32_retries += 1;
         if (out) out->f32_path = 1;
         if (rc == DRIL_OK) h->err.clear();                                              // the first pass's message is not this call's outcome
-        if (++h->f32_streak >= kRetryLatchAfter) h->f32_latch_left = kRetryLatchUpdates;
+        if (rc == DRIL_OK && ++h->f32_streak >= kRetryLatchAfter) h->f32_latch_left = kRetryLatchUpdates;   // (a gradient that is non-finite on exact f32 too is not a range problem: it arms nothing)
     } else if (rc == DRIL_OK && h->used_f16) h->f32_streak = 0;                         // an update inside f16's range: the streak (and with it the latch's re-arming) ends
     return rc;
 }

@@ -547,7 +547,8 @@ def test_host_mirror_train(pkg):
 def test_rccl_plumbing_single_rank(pkg, oracle_mod, monkeypatch):
     """dril_comm_unique_id / dril_comm_init / the in-stream ncclAllReduce of [grads | sums] and of the advantage moments,
     exercised with a 1-rank communicator (DRIL_FORCE_ALLREDUCE=1): results must equal the oracle's single-process update.
-    The N>1 arithmetic is covered on CPU by tests/test_distributed_gloo.py; the driver runs the real 2/4/8-GPU bench."""
+    The N>1 arithmetic is covered on CPU by tests/test_distributed_gloo.py and on one device by the loopback ranks of tests/test_gpu_dataparallel.py;
+    RCCL across more than one device has not run yet (the driver's multi-GPU bench is the first contact: bench.py's launcher makes it self-diagnosing)."""
     monkeypatch.setenv("DRIL_FORCE_ALLREDUCE", "1")
     monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     capi = pkg._capi
