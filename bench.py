@@ -42,7 +42,7 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16,
 # is the dense 16-bit peak (the same for f16 and bf16) over that count
 PEAK_BF16_SPLIT6_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6
 # HBM traffic (PMC) + rocprofv3 average of the dominant kernel, replayed from the committed profile of exactly that workload (each file names the commit it was taken at)
-PMC_FILES = {("cartpole", 64): "r04_ppo_grad_pmc.json", ("pendulum", 256): "r04_wide_split_pmc.json"}
+PMC_FILES = {("cartpole", 64): "r05_ppo_grad_pmc.json", ("pendulum", 256): "r05_wide_split_pmc.json"}
 PEAK_HBM_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s (~ 6.3 TB/s is what a streaming kernel reaches)
 
 
