@@ -1513,7 +1513,7 @@ DRIL_EXPORT const char* dril_grad_kernel_info(const dril_handle* h) {
         case 2: return "ppo_grad_wide_kernel: f32 (v_mfma_f32_32x32x2_f32)";
         case 6: return "ppo_update_small_kernel: f32 (f16x2 split, f32 accumulate; v_mfma_f32_32x32x16_f16 x 3 per k16 step on two-piece f16 operands = 2^-24 relative, input layer on v_mfma_f32_32x32x2_f32; two persistent workgroups (actor | critic), all optimiser steps of the iteration in one launch)";
         case 5: return "ppo_grad_pair_kernel: f32 (f16x2 split, f32 accumulate; v_mfma_f32_32x32x16_f16 x 3 per k16 step on two-piece f16 operands = 2^-24 relative, input layer on v_mfma_f32_32x32x2_f32)";
-        case 4: return "ppo_grad_wide_split_kernel: f32 (f16x2 split, f32 accumulate; v_mfma_f32_32x32x16_f16 x 3 per k16 step on two-piece f16 operands = 2^-24 relative, input layer and dW1 on f32 MFMAs)";
+        case 4: return "ppo_grad_wide_split_kernel: f32 (f16x2 split, f32 accumulate; v_mfma_f32_32x32x16_f16 x 3 per k16 step on two-piece f16 operands = 2^-24 relative, input layer on f32 MFMAs, dW1 / dW3 in f32 on the vector ALU)";
         case 3: return "generic path: f32 contractions (sac_gemm_*; large ones bf16x3 split, f32 accumulate)";
         default: return "none yet";
     }

@@ -1,4 +1,5 @@
-// dril_grad_wide.hip — the update kernels of hidden [128,128] and [256,256]: ppo_grad_wide_kernel (exact f32 MFMA) and ppo_grad_wide_split_kernel (bf16 matrix cores, fp32-equivalent 3-piece operand split; the default)
+// dril_grad_wide.hip — the update kernels of hidden [128,128] and [256,256]: ppo_grad_wide_kernel (exact f32 MFMA; here) and ppo_grad_wide_split_kernel (f16 matrix cores,
+// fp32-equivalent two-piece operand split; the default; dril_grad_wide_split.h), and their launcher
 #include <utility>
 
 #include "dril_grad_common.h"
@@ -341,7 +342,7 @@ template <int KIND, int H> static size_t grad_wide_split_lds_bytes() {
 
 hipError_t launch_ppo_grad_wide(int kind, int hidden, const GradArgs& a, hipStream_t s) {
     if (kind == 7) kind = 4;                  // ScalingWrapperEnv(MountainCarContinuous): the update never touches the simulator
-    if (a.variant && a.rec) {      // bf16 matrix cores
+    if (a.variant && a.rec) {      // f16 matrix cores (two-piece split)
 #define CALLWS(K, HH)                                                                                         \
     {                                                                                                         \
         const size_t lds = grad_wide_split_lds_bytes<K, HH>();                                                \

@@ -182,3 +182,20 @@ def test_roofline_helpers_price_what_they_say():
     r16 = b.mfma_roofline(228.0, "f16x2 split, f32 accumulate"); r32 = b.mfma_roofline(113.0, "f32")
     assert abs(r16["peak"] - 2516.6 / 3) < 0.5 and abs(r32["peak"] - 157.3) < 0.1
     assert r16["frac"] == 228.0 / r16["peak"] and r16["frac_vs_f32_peak"] == 228.0 / r16["f32_mfma_peak"] > 1 > r16["frac"]
+
+
+def test_the_json_line_fits_the_drivers_tail():
+    """the driver keeps the last 8 KB of stdout: a line built from full-size secondary entries must come out under that when compacted (round 4's was 17 KB and its
+    tail showed none of the headline's fields)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", ROOT / "bench.py")
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    full = [json.loads(l) for l in (ROOT / "profiles" / "r05_bench_default_secondary_full.jsonl").read_text().splitlines() if l.strip()]
+    assert len(full) == 4 and max(len(json.dumps(e)) for e in full) > 3000                  # the real, verbose entries of a run
+    compact = [b.compact_entry(e) for e in full]
+    head = json.loads((ROOT / "profiles" / "r05_bench_default.json").read_text()); head["secondary"] = compact
+    assert len(json.dumps(head)) < 8000
+    c2 = [c for c in compact if "configs[2]" in c["workload"]][0]
+    assert c2["roofline"]["kernel"] == "ppo_grad_wide_split_kernel" and 0 < c2["roofline"]["frac"] < 1 and c2["value"] > 0
+    c0 = [c for c in compact if "configs[0]" in c["workload"]][0]
+    assert c0["cpu_baseline"]["kind"] == "port" and c0["cpu_baseline"]["value"] > 0
