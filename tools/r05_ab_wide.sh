@@ -3,6 +3,8 @@
 #   ab_r3/  = the tree at 2e39a12 (round-3 HEAD) with its own library and bench.py
 #   ab_r4/  = libdril_hip.so built at 33d0f8c (round-4 HEAD), under this tree's bench.py (DRIL_HIP_LIBRARY)
 #   HEAD    = this tree
+# (how the two trees were made: `mkdir ab_r3 && git archive 2e39a12 | tar -x -C ab_r3 && make -C ab_r3/dril.jl_amd/csrc libdril_hip.so`; `mkdir ab_r4 && git archive 33d0f8c dril.jl_amd/csrc include |
+#  tar -x -C ab_r4 && make -C ab_r4/dril.jl_amd/csrc libdril_hip.so`; both git-ignored, travelling to the box with the gpurun snapshot; removed after the round's A/Bs — absent trees are skipped)
 # alternating, ROUNDS times.  Answers VERDICT r4 item 1(a) (did ppo_grad_wide_split_kernel regress between rounds 3 and 4?) and measures the round-5 kernel beside both.
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out/${TAG:-r05_ab}; mkdir -p $OUT; ROUNDS=${ROUNDS:-3}
 cd $R
