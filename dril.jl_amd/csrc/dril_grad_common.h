@@ -53,13 +53,16 @@ template <int O, int KS = 2> struct TileIn { float xk[KS]; float s0, s1; int act
 // the two halves of load_tile, so that a kernel can request the INDEX of a tile one pass before its records (ppo_grad_wide_split_kernel: perm32[p] -> wait -> rec[idx] is a
 // dependent pair of memory round trips; issued back to back after a barrier they were ~2 k cycles of every pass): tile_index issues the load of the epoch order's entry
 // (or evaluates the keyed bijection), load_tile_at the record / field loads for a known index
-struct TileIdx { int64_t gidx; bool inb; };
+// (g32: the epoch order's 32-bit entry exactly as loaded — widening it at the load would put the `s_waitcnt vmcnt(0)` of its first use right behind the request: a kernel
+// that requests an entry one pass ahead, behind an LDS-DMA, then waits for both on the spot; tile_gidx() widens it where the index is consumed)
+struct TileIdx { int64_t gidx; int32_t g32; bool is32; bool inb; };
+__device__ __forceinline__ int64_t tile_gidx(const TileIdx& t) { return t.is32 ? (int64_t)t.g32 : t.gidx; }
 __device__ __forceinline__ TileIdx tile_index(const GradArgs& a, int64_t tile, int64_t ntiles, int c) {
     const bool live = tile < ntiles;
     const int64_t i = (live ? tile : ntiles - 1) * kTile + c;
-    TileIdx r; r.inb = live && i < a.count;
+    TileIdx r; r.inb = live && i < a.count; r.gidx = 0; r.g32 = 0; r.is32 = a.perm32 != nullptr;
     const int64_t p = a.pos0 + (r.inb ? i : 0);
-    if (a.perm32) r.gidx = (int64_t)a.perm32[p];
+    if (a.perm32) r.g32 = a.perm32[p];
     else if (a.perm) r.gidx = a.perm[p];
     else {
         // (the keyed bijection's masks and shift counts are loop invariants of the caller's tile loop: hidden from the optimiser here, they are rebuilt per call on this
@@ -73,7 +76,7 @@ __device__ __forceinline__ TileIdx tile_index(const GradArgs& a, int64_t tile, i
 template <int KIND, int O, int HEAD, bool REC>
 __device__ __forceinline__ void load_tile_at(const GradArgs& a, const TileIdx& ti, int h, TileIn<O, FirstLayer<EnvSpec<KIND>::D>::KS>& t) {
     constexpr int D = EnvSpec<KIND>::D, KS = FirstLayer<D>::KS, RS = RecLayout<D>::RS;
-    const int64_t li = ti.gidx - a.idx_lo;
+    const int64_t li = tile_gidx(ti) - a.idx_lo;
     t.valid = ti.inb && li >= 0 && li < a.n_local;
     const int64_t idx = t.valid ? li : 0;
     t.act = 0; t.s0 = 0.f; t.s1 = 0.f;
@@ -102,6 +105,27 @@ __device__ __forceinline__ void load_tile(const GradArgs& a, int64_t tile, int64
     load_tile_at<KIND, O, HEAD, REC>(a, tile_index(a, tile, ntiles, c), h, t);
 }
 
+// LDS-DMA (global_load_lds_dwordx4 / _dword): lane l's 16 / 4 bytes land at the wave-uniform LDS base + l x size; no destination registers, counted by vmcnt
+__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+// the minibatch records of ONE sample tile straight into the workgroup's LDS, by one wave: lane (c, h) fetches quad h of sample c's record -> rec_t[h][c] (a three-quad
+// record's scalar quad with a second instruction -> rec_t[2][c]), the old value -> vo_t[c], and writes the validity word (ppo_grad_wide_split_kernel; ppo_grad_pair_kernel with -DDRIL_PAIR_LDS_REC).  Until round 5 every one of the H/32 waves
+// gathered the same records into its own registers (8 - 12 of them, live across the whole pass) in front of a streaming chain, whose first fragment wait then sat out the gather
+template <int KIND, int HEAD>
+__device__ __forceinline__ void request_records_lds(const GradArgs& a, const TileIdx& ti, int lane, float* rec_t, float* vo_t, int* val_t) {
+    constexpr int RS = RecLayout<EnvSpec<KIND>::D>::RS;
+    const int64_t li = tile_gidx(ti) - a.idx_lo;
+    const bool valid = ti.inb && li >= 0 && li < a.n_local;
+    const int64_t idx = valid ? li : 0;
+    glds16(a.rec + RS * idx + (lane >> 5), rec_t);
+    if (RS == 3) glds16(a.rec + RS * idx + 2, rec_t + 64 * 4);
+    if (HEAD == HEAD_VALUE && a.has_clip_vf) glds4(a.val_old + idx, vo_t);
+    val_t[lane] = valid ? 1 : 0;
+}
 // exchange the two record halves between the half-waves: v_permlane32_swap(a, b) swaps a[32..63] with b[0..31], so with
 // a = b = v the results are {lo-half value in every lane, hi-half value in every lane}
 template <int KIND, int O, int HEAD, bool REC>

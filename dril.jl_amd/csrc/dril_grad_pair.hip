@@ -18,6 +18,9 @@ namespace dril {
 //   * each pair has two 12 KB piece images (h1, dz2): every wave writes its own 32 columns once; row reads give the B operand of L2 / dh1 (both m-tiles), transposed
 //     reads both operands of dW2.
 //   * no f32 image at all: dW3, db2, dW1 and db1 are per-lane accumulations (the lane is the sample), reduced over the 32 lanes of a half once, in the epilogue.
+//   * the minibatch records reach the pair by LDS-DMA (round 5: request_records_lds, dril_grad_common.h): wave 0 of the pair requests the NEXT tile's records after barrier B1
+//     into the other of two buffers — one gather per pair instead of one per wave into registers (the traffic counters had the records read twice), no index arithmetic and no
+//     half-wave exchange in the second wave; barriers B1 - B3 order LDS only (the DMA stays in flight), B4 drains it.  0.996 - 1.002 -> 0.982 ms per launch (same box).
 //   * four workgroup barriers per tile; both pairs of a workgroup run the same number of tiles (the second pair's last tile may be an all-invalid one).
 // Every wave owns distinct rows of every gradient; the two pairs of a workgroup are summed through LDS into ONE slab per workgroup (epilogue).  a.G / a.Gc = pairs of
 // the actor / the critic (even); grid = (a.G + a.Gc) / 2 workgroups, the first a.G / 2 run the actor; slabs: a.G / 2 of the actor, a.Gc / 2 of the critic.
@@ -32,7 +35,10 @@ template <int D, int O> struct PairLds {
     static constexpr int WIMG = SMALL_END;                    // two f16 pieces x [64 out][64 in] = 2 x 8192 bytes
     static constexpr int PAIR0 = WIMG + 2 * 2048;
     // per pair: two 8 KB piece images (h1, dz2), [2 waves][O][32] partial sums; D > 4: a third piece image (dz1, 8 KB) and the observation image (two f16 pieces x [32 samples][32 columns])
-    static constexpr int P1 = 0, P2 = P1 + 2 * 1024, P3 = P2 + 2 * 1024, XI = P3 + (WIDE_IN ? 2 * 1024 : 0), PO = XI + (WIDE_IN ? 2 * 512 : 0), PAIR_SIZE = (PO + 2 * O * 32 + 127) / 128 * 128;
+    static constexpr int P1 = 0, P2 = P1 + 2 * 1024, P3 = P2 + 2 * 1024, XI = P3 + (WIDE_IN ? 2 * 1024 : 0), PO = XI + (WIDE_IN ? 2 * 512 : 0);
+    // the pair's minibatch records by LDS-DMA (request_records_lds, dril_grad_common.h): two buffers (the next tile's records land while this tile's are read), quad-major
+    static constexpr int RQ = RecLayout<D>::RS == 3 ? 4 : 2, RECB = RQ * 32 * 4;            // floats of one buffer
+    static constexpr int REC = (PO + 2 * O * 32 + 3) / 4 * 4, VO = REC + 2 * RECB, VAL = VO + 2 * 64, PAIR_SIZE = (VAL + 2 * 64 + 127) / 128 * 128;
     static constexpr int END = PAIR0 + 2 * PAIR_SIZE;
     static_assert((4 * WIMG) % 512 == 0 && (4 * PAIR0) % 512 == 0 && (4 * PAIR_SIZE) % 512 == 0 && (4 * P2) % 512 == 0, "image bases must be multiples of 512 bytes");
 };
@@ -137,19 +143,25 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     const int64_t ntiles = (a.count + kTile - 1) / kTile;
     const int64_t g0 = 2 * nb;
     const int64_t trips = g0 < ntiles ? (ntiles - g0 + GP - 1) / GP : 0;           // the same for both pairs of the workgroup (barriers inside the loop)
-    TileIn<O, KS> cur, nxt;
     int64_t tile = g;
-    load_tile<KIND, O, HEAD, REC>(a, tile, ntiles, c, h, cur);                        // a tile index past the end loads an all-invalid tile
+    // wave 0 of each pair is its loader: the tile's records go straight into the pair's LDS block (one gather per pair instead of one per wave into registers)
+    float* RECp = pb + L::REC; float* VOp = pb + L::VO; int* VALp = reinterpret_cast<int*>(pb + L::VAL);
+    TileIdx nidx; nidx.gidx = 0; nidx.g32 = 0; nidx.is32 = false; nidx.inb = false;
+    if (w == 0) {
+        request_records_lds<KIND, HEAD>(a, tile_index(a, tile, ntiles, c), lane, RECp, VOp, VALp);          // a tile index past the end gives an all-invalid tile
+        nidx = tile_index(a, tile + GP, ntiles, c);
+    }
+    __syncthreads();                                                                  // (drains the LDS-DMA)
 #ifdef DRIL_STAMPS
     unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
 #endif
     for (int64_t it = 0; it < trips; ++it, tile += GP) {
-        unpack_tile<KIND, O, HEAD, REC>(a, h, cur);
-        const bool valid = cur.valid;
-        float xk[KS];
+        const int buf = (int)(it & 1);
+        const float* recb = RECp + buf * L::RECB;
+        float xk[KS];                                                                 // xk[s] = component 2s + h of sample c (zero beyond D: the records are zero-padded)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) xk[s] = cur.xk[s];
+        for (int s = 0; s < KS; ++s) xk[s] = recb[((((2 * s) >> 2) * 32 + c) << 2) + ((2 * s) & 3) + h];
         if (WIDE_IN && w == 0) {                                                        // the observation image of this tile: row c = 16 x [x_0 .. x_(D-1) | 1 | 0 ..] as two f16 pieces (columns 0-7 and 8-15)
             unsigned xh[2][4], xl[2][4];
 #pragma unroll
@@ -183,9 +195,12 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             if (kKeepH1) h1k = h1w;
         }
         STAMP(0);
-        __syncthreads();                                                              // B1: the pair's h1 image complete
+        lds_barrier();                                                                // B1: the pair's h1 image complete (LDS only: the next tile's DMA stays in flight across B1 - B3)
         STAMP(1);
-        load_tile<KIND, O, HEAD, REC>(a, tile + GP, ntiles, c, h, nxt);
+        if (w == 0) {                                                                 // next tile's records into the other buffer (last read a tile ago), the tile after next's epoch-order entry
+            request_records_lds<KIND, HEAD>(a, nidx, lane, RECp + (buf ^ 1) * L::RECB, VOp + (buf ^ 1) * 64, VALp + (buf ^ 1) * 64);
+            nidx = tile_index(a, tile + 2 * GP, ntiles, c);
+        }
         // ---- h2 tile w = tanh(W2[rows of w] h1 + b2): A from the weight image, B from the pair's h1 image (both row reads with the same chunk index) ----
         f32x16 h2w;
         {
@@ -219,8 +234,16 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             }
             PO[(w * O + o) * 32 + c] = both_halves_sum(p);                                // both half-waves write the same bits to the same word
         }
-        __syncthreads();                                                              // B2: both partial sums
+        lds_barrier();                                                                // B2: both partial sums
         STAMP(3);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(recb + (((RecLayout<D>::RS - 1) * 32 + c) << 2));   // {action bits, adv, logp_old, ret} of this lane's sample
+        TileIn<O, KS> cur; cur.act = 0; cur.s0 = 0.f; cur.s1 = 0.f;
+        const bool valid = VALp[buf * 64 + c] != 0;
+        if (HEAD == HEAD_VALUE) { cur.s0 = sc[3]; cur.s1 = a.has_clip_vf ? VOp[buf * 64 + c] : 0.f; }
+        else {
+            cur.s0 = sc[1]; cur.s1 = sc[2];
+            if (HEAD == HEAD_CATEGORICAL) cur.act = __float_as_int(sc[0]) - a.action_start; else cur.xa[0] = sc[0];
+        }
 #pragma unroll
         for (int o = 0; o < O; ++o) out[o] = (wl[L::B3 + o] + PO[o * 32 + c]) + PO[(O + o) * 32 + c];   // fixed order: both waves get the same bits
         loss_head<O, HEAD>(as, cur, out, valid, h == 0 && w == 0, ls, adv_mean, adv_inv, dz, st, dlsp);     // dz = SG dLoss/dout
@@ -245,7 +268,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
         add16(db2acc, h2w);
         pair_store_pieces2<kP2B>(lds, opaque(ownT), h2w);
         STAMP(4);
-        __syncthreads();                                                              // B3: the pair's dz2 image complete
+        lds_barrier();                                                                // B3: the pair's dz2 image complete
         STAMP(5);
         // ---- dz1 tile w = (W2'[rows of w] dz2) .* (1 - h1^2): A = transposed reads of the weight image, B = row reads of the dz2 image ----
         f32x16 g1;
@@ -276,12 +299,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
         // ---- dW1 | db1: per-lane accumulation, dW1[unit][d] += dz1[unit][sample] x[sample][d] (D <= 4); D > 4: dz1' [x | 1] on the matrix cores ----
         if constexpr (!WIDE_IN) {
             float x4[4];                                                               // xk[s] = x[2 s + h]: the lower half's value is x[2 s], the upper half's x[2 s + 1]
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const unsigned u = __float_as_uint(xk[s]);
-                const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-                x4[2 * s] = __uint_as_float(r[0]); x4[2 * s + 1] = __uint_as_float(r[1]);
-            }
+            { const f32x4 xq = *reinterpret_cast<const f32x4*>(recb + (c << 2)); x4[0] = xq[0]; x4[1] = xq[1]; x4[2] = xq[2]; x4[3] = xq[3]; }   // the observation quad of this lane's sample
 #pragma unroll
             for (int d = 0; d < D; ++d) fma16(dW1acc[d], x4[d], g1);
             add16(db1acc, g1);
@@ -322,9 +340,8 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             }
         }
         STAMP(7);
-        __syncthreads();                                                              // B4: the pair's images and partial sums free for the next tile
+        __syncthreads();                                                              // B4: the pair's images and partial sums free for the next tile (and, with the records in LDS, the next tile's DMA drained)
         STAMP(8);
-        cur = nxt;
     }
 #ifdef DRIL_STAMPS
     if (lane == 0 && a.dbg) {

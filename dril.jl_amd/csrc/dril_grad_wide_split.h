@@ -45,27 +45,6 @@ template <int D, int H, int O, int NT> struct WideSplitScratch {
     static_assert(REC % 4 == 0, "records: 16-byte aligned");
     static_assert(SIZE * 4 <= 160 * 1024, "ppo_grad_wide_split_kernel: LDS");
 };
-// LDS-DMA (global_load_lds_dwordx4 / _dword): lane l's 16 / 4 bytes land at the wave-uniform LDS base + l x size; no destination registers, counted by vmcnt
-__device__ __forceinline__ void glds16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-__device__ __forceinline__ void glds4(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
-}
-// the minibatch records of ONE sample tile straight into the workgroup's LDS, by one wave: lane (c, h) fetches quad h of sample c's record -> rec_t[h][c] (a three-quad
-// record's scalar quad with a second instruction -> rec_t[2][c]), the old value -> vo_t[c], and writes the validity word.  Until round 5 every one of the H/32 waves
-// gathered the same records into its own registers (8 - 12 of them, live across the whole pass) in front of a streaming chain, whose first fragment wait then sat out the gather
-template <int KIND, int HEAD>
-__device__ __forceinline__ void wide_request_records(const GradArgs& a, const TileIdx& ti, int lane, float* rec_t, float* vo_t, int* val_t) {
-    constexpr int RS = RecLayout<EnvSpec<KIND>::D>::RS;
-    const int64_t li = ti.gidx - a.idx_lo;
-    const bool valid = ti.inb && li >= 0 && li < a.n_local;
-    const int64_t idx = valid ? li : 0;
-    glds16(a.rec + RS * idx + (lane >> 5), rec_t);
-    if (RS == 3) glds16(a.rec + RS * idx + 2, rec_t + 64 * 4);
-    if (HEAD == HEAD_VALUE && a.has_clip_vf) glds4(a.val_old + idx, vo_t);
-    val_t[lane] = valid ? 1 : 0;
-}
 __device__ __forceinline__ void wide_split_preload(const u32x4* __restrict__ wimg, int MTv, int mo, int lane, u32x4 (&af)[2][2]) {
     const u32x4* base = wimg + ((size_t)mo * MTv * 4) * 64 + lane;
 #pragma unroll
@@ -231,9 +210,9 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
     const int64_t stride = (int64_t)a.G * NT;
     // wave t (< NT) is the loader of sample tile t: it holds the epoch-order entries of the NEXT pass's samples and requests their records in front of the dW2 stage — the
     // one stage without vector-memory instructions, under which the gather (and the entry load for the pass after) completes unseen
-    TileIdx nidx; nidx.gidx = 0; nidx.inb = false;
+    TileIdx nidx; nidx.gidx = 0; nidx.g32 = 0; nidx.is32 = false; nidx.inb = false;
     if (w < NT && tile < ntiles) {
-        wide_request_records<KIND, HEAD>(a, tile_index(a, tile + w, ntiles, c), lane, RECS + w * RECT, VO + w * 64, VAL + w * 64);
+        request_records_lds<KIND, HEAD>(a, tile_index(a, tile + w, ntiles, c), lane, RECS + w * RECT, VO + w * 64, VAL + w * 64);
         nidx = tile_index(a, tile + stride + w, ntiles, c);
     }
     __syncthreads();                                                 // (drains the LDS-DMA: the first pass's records are in place)
@@ -375,7 +354,7 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
         // for the whole gather latency.  (NOT between the sched_barrier below and the dW2 stage: a branch there costs the register allocator ~200 spilled registers.)
         if (w < NT) {
             const int ln_ = opaque(lane);
-            wide_request_records<KIND, HEAD>(a, nidx, ln_, RECS + w * RECT, VO + w * 64, VAL + w * 64);
+            request_records_lds<KIND, HEAD>(a, nidx, ln_, RECS + w * RECT, VO + w * 64, VAL + w * 64);
             nidx = tile_index(a, tile + 2 * stride + w, ntiles, ln_ & 31);
         }
         // ---- dz1', then dW1 | db1 as per-lane sums over the lane's samples (before dW2, so that dz1 is dead while the 128 accumulators are being updated) ----
