@@ -70,6 +70,16 @@ def test_checker_catches_an_unbalanced_block(tmp_path):
     assert r.returncode == 1 and "DRiLHIP_extras.jl" in r.stdout and "block openers" in r.stdout, r.stdout[-1500:]
 
 
+def test_checker_catches_an_unclosed_bracket(tmp_path):
+    import shutil
+    for f in SHIM.parent.glob("DRiLHIP_*.jl"): shutil.copy(f, tmp_path / f.name)
+    extras = tmp_path / "DRiLHIP_extras.jl"
+    extras.write_text(extras.read_text() + "\nconst FORGOT = (1, 2, [3, 4)\n")
+    (tmp_path / "DRiLHIP.jl").write_text(SHIM.read_text())
+    r = _run("--shim", str(tmp_path / "DRiLHIP.jl"))
+    assert r.returncode == 1 and "DRiLHIP_extras.jl" in r.stdout and "unexpected `)`" in r.stdout, r.stdout[-1500:]
+
+
 def test_locals_lists_match_the_python_mirror(pkg):
     import re
     text = SHIM.read_text()

@@ -386,8 +386,34 @@ def block_balance(text: str) -> tuple[int, int]:
     return opens, ends
 
 
+def bracket_balance(text: str) -> list[str]:
+    """unbalanced (), [], {} outside strings / comments / character literals, with the line of the first offence"""
+    text = re.sub(r'"""(?:.|\n)*?"""', lambda m: '""' + "\n" * m.group(0).count("\n"), text)
+    text = re.sub(r'"(?:\\.|[^"\\\n])*"', '""', text)
+    text = re.sub(r"#=(?:.|\n)*?=#", lambda m: "\n" * m.group(0).count("\n"), text); text = re.sub(r"#[^\n]*", " ", text)
+    text = re.sub(r"'(?:\\.|[^'\\\n])'", "' '", text)
+    pairs, stack, out = {")": "(", "]": "[", "}": "{"}, [], []
+    for i, ch in enumerate(text):
+        if ch in "([{":
+            stack.append((ch, text.count("\n", 0, i) + 1))
+        elif ch in ")]}":
+            if not stack or stack[-1][0] != pairs[ch]:
+                out.append(f"line {text.count(chr(10), 0, i) + 1}: unexpected `{ch}`"); break
+            stack.pop()
+    if not out and stack:
+        out.append(f"line {stack[-1][1]}: `{stack[-1][0]}` never closed")
+    if text.count('"') % 2:
+        out.append("an unterminated string literal")
+    return out
+
+
 def check_blocks() -> list[str]:
     errors = []
+    for p in sorted(SHIM.parent.glob("*.jl")) + [ROOT / "tests" / "golden" / "gen_reference_golden.jl"]:
+        if not p.exists():
+            continue
+        for msg in bracket_balance(p.read_text()):
+            errors.append(f"{p.name}: {msg}")
     for p in sorted(SHIM.parent.glob("*.jl")):
         o, e = block_balance(p.read_text())
         if o != e:
