@@ -143,7 +143,6 @@ struct dril_handle {
     bool used_f16 = false, spin_timeout = false; int f32_streak = 0, f32_latch_left = 0; int64_t f32_direct_updates = 0, persistent_fallbacks = 0;
     unsigned long long* gae_carry = nullptr; unsigned gae_tag = 0; int* gae_err = nullptr;   // gae_scan_kernel: the chunk-to-chunk carry words, the launch tag that validates them, its give-up flag
     unsigned* w2max_dev = nullptr; float w2max = 0.f;   // max |W2| over both nets (fused kernels): host copy refreshed by dril_set_params and with every optimiser run's statistics
-    bool wide_teams = false;      // DRIL_WIDE_TEAMS: hidden [256,256] on ppo_grad_wide_teams_kernel instead of ppo_grad_wide_split_kernel
     bool no_small_path = false;   // DRIL_NO_SMALL_PATH (with DRIL_DEBUG=1), latched in dril_create
     bool no_persistent = false; unsigned long long* small_xchg = nullptr; uint64_t* epoch_keys = nullptr; int epoch_keys_cap = 0; int64_t small_chunk = 16384;   // ppo_update_small_kernel (batch_size <= 64): DRIL_NO_PERSISTENT_UPDATE; per-epoch DataLoader keys on the device
     std::vector<ProfEvent> prof_pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
@@ -387,7 +386,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     if (h->generic) { G = generic_pick_slabs(h->gd, count, h->Gmax); if (G < 1) return fail(h, DRIL_ERR_UNSUPPORTED, "minibatch too large for the generic path's workspace"); Gc = G; }
     { int rcw = ensure_wimg(h); if (rcw) return rcw; }
     h->last_variant = h->generic ? 3 : h->wide ? (variant ? 4 : 2) : (variant == 2 ? 5 : variant);
-    if (h->last_variant == 4 || h->last_variant == 5) h->used_f16 = true;   // (7, ppo_grad_wide_teams_kernel, is set where the launch arguments are: it is 4's arithmetic)
+    if (h->last_variant == 4 || h->last_variant == 5) h->used_f16 = true;
     const double* adv_stats = h->adv_stats;
     // launch-bound regime (the reference's default batch_size = 64): the advantage moments are computed inside the grad kernel and
     // reduce + norm + Adam run as one workgroup: 2 dependent launches per optimiser step instead of 6
@@ -413,8 +412,7 @@ int ppo_step(dril_handle* h, const float* obs, const void* actions, const float*
     g.clip_range = h->cfg.clip_range; g.ent_coef = h->cfg.ent_coef; g.vf_coef = h->cfg.vf_coef; g.clip_range_vf = h->cfg.clip_range_vf;
     g.has_clip_vf = h->cfg.has_clip_range_vf; g.normalize_adv = h->cfg.normalize_advantage; g.action_start = h->cfg.action_start;
     g.log_std_off = h->log_std_off; g.slabs_actor = h->slabs_a; g.slabs_critic = h->slabs_c; g.slab_a = h->slab_a; g.slab_c = h->slab_c;
-    g.G = G; g.Gc = Gc; g.dbg = h->dbg; g.variant = (h->wide && variant == 1 && h->wide_teams && h->cfg.hidden1 == 256) ? 3 : variant;
-    if (g.variant == 3) h->last_variant = 7; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
+    g.G = G; g.Gc = Gc; g.dbg = h->dbg; g.variant = variant; g.stop_flag = h->stop_flag; g.actor = h->actor; g.critic = h->critic;
     // host-side preconditions of the gradient kernels: a violated one would be a device fault (null advantage moments in a kernel without in-kernel
     // moments — the SIGABRT of profiles/r02_split_kernel.md "the abort of 09:41" —, a slab index past the Gmax slabs that were allocated); only a status code
     // may cross the ABI
@@ -563,7 +561,6 @@ DRIL_EXPORT int32_t dril_create(const dril_config* cfg, dril_handle** out) {
     if (const char* e = debug_env("DRIL_SMALL_CHUNK")) { const long c = std::atol(e); if (c > 0) h->small_chunk = c; }   // optimiser steps per launch of ppo_update_small_kernel (tests: launch boundaries)
     h->no_small_path = debug_env("DRIL_NO_SMALL_PATH") != nullptr;
     h->no_f32_retry = std::getenv("DRIL_NO_F32_RETRY") != nullptr;
-    if (const char* e = std::getenv("DRIL_WIDE_TEAMS")) h->wide_teams = std::atoi(e) != 0;
     // Multi-process RCCL on this platform needs dmabuf IPC: with the legacy IPC mode (the ROCr default) `hipIpcGetMemHandle` fails with "invalid argument" on a
     // host driver that only supports dmabuf, and ncclCommInitRank / the first collective across processes dies with it.  The ROCr runtime reads the variable
     // when it initialises, i.e. at this process's first HIP call — which for a DRiL user is normally the hipSetDevice below.  It is only set if the caller left it
@@ -1517,7 +1514,6 @@ DRIL_EXPORT const char* dril_grad_kernel_info(const dril_handle* h) {
         case 6: return "ppo_update_small_kernel: f32 (f16x2 split, f32 accumulate; v_mfma_f32_32x32x16_f16 x 3 per k16 step on two-piece f16 operands = 2^-24 relative, input layer on v_mfma_f32_32x32x2_f32; two persistent workgroups (actor | critic), all optimiser steps of the iteration in one launch)";
         case 5: return "ppo_grad_pair_kernel: f32 (f16x2 split, f32 accumulate; v_mfma_f32_32x32x16_f16 x 3 per k16 step on two-piece f16 operands = 2^-24 relative, input layer on v_mfma_f32_32x32x2_f32)";
         case 4: return "ppo_grad_wide_split_kernel: f32 (f16x2 split, f32 accumulate; v_mfma_f32_32x32x16_f16 x 3 per k16 step on two-piece f16 operands = 2^-24 relative, input layer on f32 MFMAs, dW1 / dW3 in f32 on the vector ALU)";
-        case 7: return "ppo_grad_wide_teams_kernel: f32 (f16x2 split, f32 accumulate; the arithmetic of ppo_grad_wide_split_kernel, the workgroup's waves as two teams half a pass apart)";
         case 3: return "generic path: f32 contractions (sac_gemm_*; large ones bf16x3 split, f32 accumulate)";
         default: return "none yet";
     }

@@ -5,7 +5,6 @@
 #include "dril_grad_common.h"
 #include "dril_split_pieces.h"
 #include "dril_grad_wide_split.h"   // ppo_grad_wide_split_kernel (the f16-piece form)
-#include "dril_grad_wide_teams.h"   // ppo_grad_wide_teams_kernel (two teams of waves half a pass apart)
 
 namespace dril {
 
@@ -343,17 +342,6 @@ template <int KIND, int H> static size_t grad_wide_split_lds_bytes() {
 
 hipError_t launch_ppo_grad_wide(int kind, int hidden, const GradArgs& a, hipStream_t s) {
     if (kind == 7) kind = 4;                  // ScalingWrapperEnv(MountainCarContinuous): the update never touches the simulator
-    if (a.variant == 3 && a.rec && hidden == 256) {      // f16 matrix cores, the workgroup's waves as two teams half a pass apart (dril_grad_wide_teams.h)
-#define CALLWT(K)                                                                                             \
-    {                                                                                                         \
-        const size_t lds = grad_wide_split_lds_bytes<K, 256>();                                               \
-        { hipError_t e = set_max_dynamic_lds((const void*)ppo_grad_wide_teams_kernel<K, 256>, lds); if (e != hipSuccess) return e; } \
-        ppo_grad_wide_teams_kernel<K, 256><<<2 * a.G, 512, lds, s>>>(a);                                      \
-    }
-        if (kind == 0) CALLWT(0) else if (kind == 3) CALLWT(3) else if (kind == 4) CALLWT(4) else if (kind == 6) CALLWT(6) else CALLWT(1)
-#undef CALLWT
-        return hipGetLastError();
-    }
     if (a.variant && a.rec) {      // f16 matrix cores (two-piece split)
 #define CALLWS(K, HH)                                                                                         \
     {                                                                                                         \
