@@ -54,6 +54,12 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     constexpr bool REC = true, kKeepH1 = HEAD == HEAD_VALUE;
     constexpr float kInvTanhScale = 1.0f / kTanhScale;
     using L = PairLds<D, O>;
+#ifdef DRIL_STAMPS_EDGES
+    unsigned long long e_[6];
+#endif
+#ifdef DRIL_STAMPS_EDGES
+    { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); e_[0] = t_; }
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wave & 1, pr = wave >> 1;                                           // this wave's m-tile; this wave's pair
@@ -79,6 +85,9 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     }
     if (L::WIDE_IN) { for (int i = tid; i < 2 * L::PAIR_SIZE; i += blockDim.x) { const int q = i % L::PAIR_SIZE; if (q >= L::XI && q < L::PO) smem[L::PAIR0 + i] = 0.f; } }
     __syncthreads();
+#ifdef DRIL_STAMPS_EDGES
+    { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); e_[1] = t_; }
+#endif
 
     float adv_mean = 0.f, adv_den = 1.f;
     if (HEAD != HEAD_VALUE && a.normalize_adv) {
@@ -152,6 +161,9 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
         nidx = tile_index(a, tile + GP, ntiles, c);
     }
     __syncthreads();                                                                  // (drains the LDS-DMA)
+#ifdef DRIL_STAMPS_EDGES
+    { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); e_[2] = t_; }
+#endif
 #ifdef DRIL_STAMPS
     unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory");
@@ -343,7 +355,10 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
         __syncthreads();                                                              // B4: the pair's images and partial sums free for the next tile (and, with the records in LDS, the next tile's DMA drained)
         STAMP(8);
     }
-#ifdef DRIL_STAMPS
+#ifdef DRIL_STAMPS_EDGES
+    { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); e_[3] = t_; }
+#endif
+#if defined(DRIL_STAMPS) && !defined(DRIL_STAMPS_EDGES)
     if (lane == 0 && a.dbg) {
         unsigned long long* o_ = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
         for (int k = 0; k < 10; ++k) o_[k] = stamp_acc[k];
@@ -364,31 +379,43 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
         for (int mj = 0; mj < MT; ++mj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) put(o_w2 + 32 * w + rowfn(r, h) + (32 * mj + c) * H, dW2[mj][r] * inv_sa);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {                                                // per-lane sums over samples -> sum over the 32 lanes of each half (the halves hold different units)
-            const int unit = 32 * w + rowfn(r, h);
-            const float b2 = half_sum(db2acc[r]) * inv_sg;
-            if (c == 0) put(o_b2 + unit, b2);
+        // per-lane sums over samples -> sums over the 32 lanes of each half (the halves hold different units).  One register-halving DPP reduce-scatter per accumulator
+        // (half_reduce16_lane, ~52 vector instructions: lane l ends with the half's sum of register l & 15) — until round 5 this was 16 x 5 `__shfl_xor` steps per accumulator,
+        // ~690 ds_bpermute per wave with a wait behind each: 45 - 59 k cycles per launch (DRIL_STAMPS_EDGES), 2.5 % of the kernel
+        {
+            const int rl = lane & 15, unit = 32 * w + rowfn(rl, h);
+            const bool wr = (lane & 16) == 0;                                             // lanes l and l ^ 16 hold the same sums
+            { const float b2 = half_reduce16_lane(db2acc, lane) * inv_sg; if (wr) put(o_b2 + unit, b2); }
             if constexpr (!WIDE_IN) {
-                const float b1 = half_sum(db1acc[r]) * inv_s1;
-                if (c == 0) put(o_b1 + unit, b1);
+                { const float b1 = half_reduce16_lane(db1acc, lane) * inv_s1; if (wr) put(o_b1 + unit, b1); }
 #pragma unroll
-                for (int d = 0; d < D; ++d) { const float v = half_sum(dW1acc[d][r]) * inv_s1; if (c == 0) put(o_w1 + unit + d * H, v); }
+                for (int d = 0; d < D; ++d) { const float v = half_reduce16_lane(dW1acc[d], lane) * inv_s1; if (wr) put(o_w1 + unit + d * H, v); }
             } else {                                                                  // column c of the MFMA accumulator: observation component c, or the bias
-                const float v = dW1acc[0][r] * (inv_sg * (1.0f / 16.0f));
-                if (c < D) put(o_w1 + unit + c * H, v); else if (c == D) put(o_b1 + unit, v);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int u_ = 32 * w + rowfn(r, h);
+                    const float v = dW1acc[0][r] * (inv_sg * (1.0f / 16.0f));
+                    if (c < D) put(o_w1 + u_ + c * H, v); else if (c == D) put(o_b1 + u_, v);
+                }
             }
 #pragma unroll
-            for (int o = 0; o < O; ++o) { const float v = half_sum(dW3acc[o][r]) * inv_sa; if (c == 0) put(o_w3 + o + unit * O, v); }
-        }
+            for (int o = 0; o < O; ++o) { const float v = half_reduce16_lane(dW3acc[o], lane) * inv_sa; if (wr) put(o_w3 + o + unit * O, v); }
+            // db3 | dlog_std | the five loss sums: accumulated by the lower half of wave 0 only — one more reduce-scatter, lane l < 16 of that half ends with the sum of value l
+            static_assert(2 * O + 5 <= 16, "scalar sums: one f32x16");
+            f32x16 sc16;
 #pragma unroll
-        for (int o = 0; o < O; ++o) {
-            const float b3 = half_sum(db3p[o]) * inv_sg;
-            if (w == 0 && lane == 0) put(o_b3 + o, b3);
-            if (HEAD == HEAD_GAUSSIAN) { const float l = half_sum(dlsp[o]) * inv_sg; if (w == 0 && lane == 0) put(o_ls + o, l); }
-        }
+            for (int r = 0; r < 16; ++r) sc16[r] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) { const float v = half_sum(st[k]); if (w == 0 && lane == 0) put(o_st + k, v); }
+            for (int o = 0; o < O; ++o) { sc16[o] = db3p[o]; sc16[O + o] = dlsp[o]; }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) sc16[2 * O + k] = st[k];
+            const float tot = half_reduce16_lane(sc16, lane);
+            if (w == 0 && lane < 16) {
+                if (lane < O) put(o_b3 + lane, tot * inv_sg);
+                else if (lane < 2 * O) { if (HEAD == HEAD_GAUSSIAN) put(o_ls + lane - O, tot * inv_sg); }
+                else if (lane < 2 * O + 5) put(o_st + lane - 2 * O, tot);
+            }
+        }
     };
     // both pairs park at the same time (pair 0 in the first SL floats of the workgroup's LDS, pair 1 behind it: everything staged there is dead now), then all 256
     // threads write slab[i] = pair0[i] + pair1[i] with consecutive lanes on consecutive floats — a coalesced store instead of the per-lane scatter of the round 3 epilogue
@@ -397,11 +424,25 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     __syncthreads();                                                                  // the other pair may still be reading its images
     emit([&](int i, float v) { park[i] = v; });
     __syncthreads();
+#ifdef DRIL_STAMPS_EDGES
+    { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); e_[4] = t_; }
+#endif
     const int pad0 = HEAD == HEAD_GAUSSIAN ? o_ls + O : o_ls;
     for (int i = tid; i < SL; i += 256) {
         const bool pad = (i >= pad0 && i < o_st) || i >= o_st + 5;                    // slab padding and the three unused statistics slots
         slab[i] = pad ? 0.f : smem[i] + smem[SLr + i];
     }
+#ifdef DRIL_STAMPS_EDGES
+    { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); e_[5] = t_; }
+#endif
+#ifdef DRIL_STAMPS_EDGES
+    if (lane == 0 && a.dbg) {           // rows: staging | first records | tile loop | sums + park | slab write   (the reader divides by o_[10] = 1)
+        unsigned long long* o_ = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
+        for (int k = 0; k < 5; ++k) o_[k] = e_[k + 1] - e_[k];
+        for (int k = 5; k < 10; ++k) o_[k] = 0;
+        o_[10] = 1; o_[11] = HEAD;
+    }
+#endif
 }
 
 template <int KIND>
