@@ -26,6 +26,8 @@ namespace dril {
 //       dW3: the products h2 dz are summed over the two sample tiles in registers and reduced across the lanes of a half-wave by the register-halving DPP
 //         reduce-scatter (half_reduce16_lane: ~52 VALU per output, once per 64 samples);
 //       db2: from the transposed f16 fragments of dz2 that the dW2 product loads anyway (v_dot2c_f32_f16 against ones).
+//   * the dW2 product runs in the v_mfma_f32_16x16x32_f16 shape (end of round 5): same pipe cycles and LDS reads as 32x32x16, but the chip sustains a higher clock on it
+//     (tools/micro/mfma_shape_f16.hip: 1.93 against 1.67 GHz in a bare loop) — this kernel is the clock-limited one (1.90 GHz): - 1 % per launch.
 //   * no AGPRs: at two waves per SIMD the allocator gives a function that uses ANY AGPR only 128 VGPRs; the 128 dW2 accumulators are VGPR-form MFMA results like the rest.
 // LDS at H = 256: two piece images of 64 KB + ~12 KB of small parameters = 143 - 156 KB of the CU's 160 (one workgroup per CU, two waves per SIMD); H = 128: 72 KB, two workgroups per CU.
 // =============================================================================================
@@ -127,6 +129,31 @@ __device__ __forceinline__ float frag_sum8(f16x8 v, float acc) {
     return acc;
 }
 
+#ifndef DRIL_WIDE_DW2_16
+#define DRIL_WIDE_DW2_16 1
+#endif
+// ---- the dW2 product in the v_mfma_f32_16x16x32_f16 shape (-DDRIL_WIDE_DW2_16=0: the 32x32x16 form it replaced; profiles/r05_mfma_shape_f16_microbench.md, r05_wide_split.md §9) ----
+// one k32 step of the two-piece product on a 16 x 16 tile, small terms first (mfma_split3's order)
+__device__ __forceinline__ f32x4 mfma16_split3(f16x8 Ah, f16x8 Al, f16x8 Bh, f16x8 Bl, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, acc, 0, 0, 0); acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, acc, 0, 0, 0);
+}
+// operand of a 16x16x32 product that sums over the 32 SAMPLES of a tile: lane (unit 16 f + (lane & 15) of m-tile m, k-block kb = lane >> 4) gets samples 8 kb + j of its unit.
+// The 16-lane group kb addresses rows (samples) 8 kb + q (+ 4 for the second read), q = e >> 2, and columns (units) 4 (e & 3) .. + 3 of the 16; address = base ^ (64 m) ^ (32 f),
+// second read (base ^ 16) + 4 RB — g(n + 4) = g(n) ^ 1 for these rows.  A half-wave covers rows {0-3, 8-11} or {16-19, 24-27}: 16 distinct chunks x 16 bytes = all 64 banks once
+template <int H>
+__device__ __forceinline__ int wide_tr16_base(int lane) {
+    static_assert(H >= 128, "wide_tr16_base: the four-bit chunk swizzle");
+    constexpr int RB = 2 * H;
+    const int kb = lane >> 4, e = lane & 15, q = e >> 2, p = e & 3, n = 8 * kb + q;
+    return n * RB + ((((p >> 1) ^ wimg_g<H>(n)) & 15) << 4) + 8 * (p & 1);
+}
+template <int H>
+__device__ __forceinline__ f16x8 load_frag16_T(const char* pimg, int t, int piece) {     // t = base ^ (64 m) ^ (32 f)
+    constexpr int RB = 2 * H, PS = 32 * RB;
+    return __builtin_bit_cast(f16x8, frag8(lds_read_tr16(pimg, t + piece * PS), lds_read_tr16(pimg, (t ^ 16) + piece * PS + 4 * RB)));
+}
+
 template <int KIND, int H, int O, int HEAD, int MW>
 __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* smem) {
     constexpr int D = EnvSpec<KIND>::D, MT = H / 32, NT = kWideSplitNT, NW = MT / MW;   // NW waves, each owning MW consecutive m-tiles of every layer
@@ -185,6 +212,7 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
     const float* W3B = smem + SC::W3B;
 
     f32x16 dW2[MW][MT];                                              // rows of the own m-tiles, all H columns
+    float db2a16[2] = {0.f, 0.f};                                    // (DRIL_WIDE_DW2_16: db2 partials for units 16 fa + (lane & 15) of the own m-tile, over the lane's k-block)
     float dW1a[MW][D], db1a[MW], dW3a[MW][O], db2a[MW], db3p[O], dlsp[O], st[5];   // per-lane partial sums: dW1a / db1a / db2a for unit 32 (mw0 + m) + (lane & 31) over the samples of this half-wave, dW3a for unit 32 (mw0 + m) + rowfn(lane & 15, h)
 #pragma unroll
     for (int m = 0; m < MW; ++m) {
@@ -387,6 +415,61 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
         }
         __builtin_amdgcn_sched_barrier(0);
         STAMP(7);
+#if DRIL_WIDE_DW2_16
+        // ---- dW2 in the 16x16x32 shape: per (m-tile mj, sample tile t) four 16 x 16 tiles (fa, fb), one k32 step each; dW2[m][mj] holds them as registers 4 (2 fa + fb) .. + 3;
+        // db2 from the dz2 fragments (per lane: unit 16 fa + (lane & 15), the 8 samples of its k-block) ----
+        {
+            static_assert(MW == 1 && NT == 2, "16x16x32 dW2: one m-tile per wave, two sample tiles");
+            const int t16 = opaque(wide_tr16_base<H>(lane)), tw = t16 ^ (64 * mw0);
+            f16x8 Az[NT][2][2];                                                        // [tile][fa][piece]
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        Az[t][fa][p] = load_frag16_T<H>(P2 + t * NTS, tw ^ (32 * fa), p);
+                        db2a16[fa] = frag_sum8(Az[t][fa][p], db2a16[fa]);
+                    }
+            f16x8 BhA[2][2], BhB[2][2];                                                // [fb][piece]: sample tile 0 | 1 of the m-tile in flight
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) BhA[fb][p] = load_frag16_T<H>(P1, t16 ^ (32 * fb), p);
+#pragma unroll
+            for (int mj = 0; mj < MT; ++mj) {
+                const int tj = t16 ^ (64 * mj), mn = mj + 1 < MT ? mj + 1 : mj, tn = t16 ^ (64 * mn);
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) BhB[fb][p] = load_frag16_T<H>(P1 + NTS, tj ^ (32 * fb), p);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb) {
+                        f32x4 acc = {dW2[0][mj][4 * (2 * fa + fb)], dW2[0][mj][4 * (2 * fa + fb) + 1], dW2[0][mj][4 * (2 * fa + fb) + 2], dW2[0][mj][4 * (2 * fa + fb) + 3]};
+                        acc = mfma16_split3(Az[0][fa][0], Az[0][fa][1], BhA[fb][0], BhA[fb][1], acc);
+                        dW2[0][mj][4 * (2 * fa + fb)] = acc[0]; dW2[0][mj][4 * (2 * fa + fb) + 1] = acc[1]; dW2[0][mj][4 * (2 * fa + fb) + 2] = acc[2]; dW2[0][mj][4 * (2 * fa + fb) + 3] = acc[3];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) BhA[fb][p] = load_frag16_T<H>(P1, tn ^ (32 * fb), p);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb) {
+                        f32x4 acc = {dW2[0][mj][4 * (2 * fa + fb)], dW2[0][mj][4 * (2 * fa + fb) + 1], dW2[0][mj][4 * (2 * fa + fb) + 2], dW2[0][mj][4 * (2 * fa + fb) + 3]};
+                        acc = mfma16_split3(Az[1][fa][0], Az[1][fa][1], BhB[fb][0], BhB[fb][1], acc);
+                        dW2[0][mj][4 * (2 * fa + fb)] = acc[0]; dW2[0][mj][4 * (2 * fa + fb) + 1] = acc[1]; dW2[0][mj][4 * (2 * fa + fb) + 2] = acc[2]; dW2[0][mj][4 * (2 * fa + fb) + 3] = acc[3];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
         // ---- dW2[rows of w][:] += dz2 h1' (both operands as transposed fragments of the piece images; k = the NT x 32 samples); db2 from the dz2 fragments ----
         {
             const int tb = opaque(tbase);
@@ -438,6 +521,7 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#endif
         STAMP(8);
         __syncthreads();                                                              // B4: P1 / P2 / PO / XI free for the next pass; the next pass's records have landed (the barrier's fence drains the DMA)
         STAMP(9);
@@ -463,14 +547,34 @@ __device__ __forceinline__ void grad_body_wide_split(const GradArgs& a, float* s
 #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int mt = mw0 + m;
+#if DRIL_WIDE_DW2_16
+#pragma unroll
+        for (int mj = 0; mj < MT; ++mj)
+#pragma unroll
+            for (int fa = 0; fa < 2; ++fa)
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)       // tile (fa, fb): lane = column 16 fb + (lane & 15), registers = rows 16 fa + 4 (lane >> 4) + r
+                        slab[o_w2 + 32 * mt + 16 * fa + 4 * (lane >> 4) + r + (32 * mj + 16 * fb + (lane & 15)) * H] = dW2[m][mj][4 * (2 * fa + fb) + r] * inv_sa;
+#else
 #pragma unroll
         for (int mj = 0; mj < MT; ++mj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) slab[o_w2 + 32 * mt + rowfn(r, h) + (32 * mj + c) * H] = dW2[m][mj][r] * inv_sa;
+#endif
 #pragma unroll
         for (int d = 0; d < D; ++d) { const float v = (dW1a[m][d] + __shfl_xor(dW1a[m][d], 32)) * inv_sg; if (h == 0) slab[o_w1 + 32 * mt + c + d * H] = v; }
         { const float b1 = (db1a[m] + __shfl_xor(db1a[m], 32)) * inv_sg; if (h == 0) slab[o_b1 + 32 * mt + c] = b1; }
+#if DRIL_WIDE_DW2_16
+#pragma unroll
+        for (int fa = 0; fa < 2; ++fa) {                                               // the four k-blocks of a unit sit in lanes l, l ^ 16, l ^ 32, l ^ 48
+            float v = db2a16[fa]; v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            if (lane < 16) slab[o_b2 + 32 * mt + 16 * fa + lane] = v * inv_sg;
+        }
+#else
         { const float b2 = (db2a[m] + __shfl_xor(db2a[m], 32)) * inv_sg; if (h == 0) slab[o_b2 + 32 * mt + c] = b2; }
+#endif
 #pragma unroll
         for (int o = 0; o < O; ++o) if ((lane & 16) == 0) slab[o_w3 + o + (32 * mt + rowfn(lane & 15, h)) * O] = dW3a[m][o] * inv_sa;
     }
