@@ -69,13 +69,15 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     char* Wimg = reinterpret_cast<char*>(smem + L::WIMG);
     float* pb = smem + L::PAIR0 + pr * L::PAIR_SIZE;
     char* P1 = reinterpret_cast<char*>(pb + L::P1); char* P2 = reinterpret_cast<char*>(pb + L::P2); float* PO = pb + L::PO;
+    constexpr int kNT = 256;                                                          // the workgroup: two pairs (compile-time strides: the staging loops unroll and their global loads leave together — at a run-time blockDim.x every iteration was its own round trip)
     {   // stage the small parts (as stage_net_split) and the W2 piece image
         const float* __restrict__ P = a.params;
-        for (int i = tid; i < L::DP * H; i += blockDim.x) { const int o = i % H, k = i / H; wl[L::W1T + k * H + o] = k < D ? kTanhScale * P[off.w1 + o + k * H] : 0.0f; }
-        for (int i = tid; i < H; i += blockDim.x) { wl[L::B1 + i] = kTanhScale * P[off.b1 + i]; wl[L::B2 + i] = (kTanhScale * kWScale * kActScale) * P[off.b2 + i]; }   // b2 starts the SCALED accumulator of L2
-        for (int i = tid; i < O * H; i += blockDim.x) { const int o = i % O, k = i / O; const float w3 = P[off.w3 + i]; wl[L::W3S + o * H + k] = w3 * (1.0f / kActScale); wl[L::W3B + o * H + k] = w3 * (1.0f / (kActScale * kActScale)); }
-        for (int i = tid; i < L::OP; i += blockDim.x) wl[L::B3 + i] = i < O ? P[off.b3 + i] : 0.0f;
-        for (int i = tid; i < H * H / 2; i += blockDim.x) {       // pair (k, k+1) of row o: W2 is column-major (out x in), consecutive threads read consecutive o
+        for (int i = tid; i < L::DP * H; i += kNT) { const int o = i % H, k = i / H; wl[L::W1T + k * H + o] = k < D ? kTanhScale * P[off.w1 + o + k * H] : 0.0f; }
+        for (int i = tid; i < H; i += kNT) { wl[L::B1 + i] = kTanhScale * P[off.b1 + i]; wl[L::B2 + i] = (kTanhScale * kWScale * kActScale) * P[off.b2 + i]; }   // b2 starts the SCALED accumulator of L2
+        for (int i = tid; i < O * H; i += kNT) { const int o = i % O, k = i / O; const float w3 = P[off.w3 + i]; wl[L::W3S + o * H + k] = w3 * (1.0f / kActScale); wl[L::W3B + o * H + k] = w3 * (1.0f / (kActScale * kActScale)); }
+        for (int i = tid; i < L::OP; i += kNT) wl[L::B3 + i] = i < O ? P[off.b3 + i] : 0.0f;
+#pragma unroll
+        for (int i = tid; i < H * H / 2; i += kNT) {       // pair (k, k+1) of row o: W2 is column-major (out x in), consecutive threads read consecutive o
             const int o = i % H, kp = i / H;
             unsigned hi, lo;
             split2_pair((kTanhScale * kWScale) * P[off.w2 + o + H * (2 * kp)], (kTanhScale * kWScale) * P[off.w2 + o + H * (2 * kp + 1)], hi, lo);
@@ -83,7 +85,7 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
             *reinterpret_cast<unsigned*>(Wimg + byte) = hi; *reinterpret_cast<unsigned*>(Wimg + 8192 + byte) = lo;
         }
     }
-    if (L::WIDE_IN) { for (int i = tid; i < 2 * L::PAIR_SIZE; i += blockDim.x) { const int q = i % L::PAIR_SIZE; if (q >= L::XI && q < L::PO) smem[L::PAIR0 + i] = 0.f; } }
+    if (L::WIDE_IN) { for (int i = tid; i < 2 * L::PAIR_SIZE; i += kNT) { const int q = i % L::PAIR_SIZE; if (q >= L::XI && q < L::PO) smem[L::PAIR0 + i] = 0.f; } }
     __syncthreads();
 #ifdef DRIL_STAMPS_EDGES
     { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); e_[1] = t_; }

@@ -579,8 +579,8 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void policy_kernel(PolicyArgs a)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* la = smem; float* lc = smem + FwdLds<D, H, A, WIDE, SPLIT>::SIZE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (a.mode != 2) stage_fwd<D, H, A, WIDE, SPLIT>(la, a.params, a.actor, tid, blockDim.x);
-    stage_fwd<D, H, 1, WIDE, SPLIT>(lc, a.params, a.critic, tid, blockDim.x);
+    if (a.mode != 2) stage_fwd<D, H, A, WIDE, SPLIT>(la, a.params, a.actor, tid, 256);
+    stage_fwd<D, H, 1, WIDE, SPLIT>(lc, a.params, a.critic, tid, 256);
     __syncthreads();
     const int64_t ntiles = (a.B + kTile - 1) / kTile;
     const int c = lane & 31, h = lane >> 5;
@@ -671,8 +671,8 @@ __global__ __launch_bounds__(256, WIDE ? 1 : 2) void rollout_kernel(RolloutArgs 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* la = smem; float* lc = smem + FwdLds<D, H, A, WIDE, SPLIT>::SIZE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    stage_fwd<D, H, A, WIDE, SPLIT>(la, a.params, a.actor, tid, blockDim.x);
-    stage_fwd<D, H, 1, WIDE, SPLIT>(lc, a.params, a.critic, tid, blockDim.x);
+    stage_fwd<D, H, A, WIDE, SPLIT>(la, a.params, a.actor, tid, 256);
+    stage_fwd<D, H, 1, WIDE, SPLIT>(lc, a.params, a.critic, tid, 256);
     __syncthreads();
     const int c = lane & 31, h = lane >> 5;
     const int e_raw = (blockIdx.x * 4 + wave) * kTile + c;
@@ -798,8 +798,8 @@ __global__ __launch_bounds__(128, 2) void rollout_duo_kernel(RolloutArgs a) {
     constexpr int SLOT = (2 * D + 1) * 32;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    stage_fwd<D, H, A, false, SPLIT>(la, a.params, a.actor, tid, blockDim.x);
-    stage_fwd<D, H, 1, false, SPLIT>(lc, a.params, a.critic, tid, blockDim.x);
+    stage_fwd<D, H, A, false, SPLIT>(la, a.params, a.actor, tid, 128);
+    stage_fwd<D, H, 1, false, SPLIT>(lc, a.params, a.critic, tid, 128);
     const int c = lane & 31, h = lane >> 5;
     const int e_raw = blockIdx.x * kTile + c;
     const bool valid = e_raw < a.E;
