@@ -430,7 +430,8 @@ __device__ __forceinline__ void grad_body_pair(const GradArgs& a, float* smem) {
     { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); e_[4] = t_; }
 #endif
     const int pad0 = HEAD == HEAD_GAUSSIAN ? o_ls + O : o_ls;
-    for (int i = tid; i < SL; i += 256) {
+#pragma unroll 6
+    for (int i = tid; i < SL; i += 256) {                                             // (unrolled: the LDS reads of six iterations leave together)
         const bool pad = (i >= pad0 && i < o_st) || i >= o_st + 5;                    // slab padding and the three unused statistics slots
         slab[i] = pad ? 0.f : smem[i] + smem[SLr + i];
     }
