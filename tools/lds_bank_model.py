@@ -46,8 +46,22 @@ def wide(H):
         for m in (0,5):
             for Q in range(4):
                 report("dz1 S3_LOAD tr read m %d Q %d"%(m,Q), HALF, lambda l: (trm_base(l)^(64*m)^(32 if Q&1 else 0))+8*Q*RB, 8, 64)
+def wide_dw2_16(H):
+    # the dW2 product's 16x16x32 operand (wide_tr16_base / load_frag16_T, dril_grad_wide_split.h)
+    RB=2*H
+    print("== wide split kernel, dW2 product in the 16x16x32 shape, H =",H)
+    def tr16_base(l):
+        kb=l>>4; e=l&15; q=e>>2; p=e&3; n=8*kb+q
+        return n*RB+((((p>>1)^wimg_g(H,n))&15)<<4)+8*(p&1)
+    for m in (0,3):
+        for f_ in (0,1):
+            t=lambda l: tr16_base(l)^(64*m)^(32*f_)
+            report("load_frag16_T tr read (rows 8 kb + 0..3) m %d f %d"%(m,f_), HALF, lambda l: t(l), 8, 64)
+            report("load_frag16_T tr read (rows 8 kb + 4..7) m %d f %d"%(m,f_), HALF, lambda l: (t(l)^16)+4*RB, 8, 64)
 wide(256)
 wide(128)
+wide_dw2_16(256)
+wide_dw2_16(128)
 def pair():
     H=64; print("== pair kernel, H = 64 (rows of 128 bytes)")
     def rowc(l): c=l&31; h=l>>5; return c*128+((h^wimg_g(64,c))<<4)
